@@ -1,0 +1,635 @@
+"""CPU oracle for the neuronika dense-tensor hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file is a NumPy restatement of the reference's ndarray node kernels
+(`/root/reference/neuronika-variable/src/node/*/mod.rs`).  It exists to CHECK the HIP
+backend; nothing in the product path (`neuronika_amd/`, `include/`) may import it.  Only
+`tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg use it.
+
+Parity status: PINNED.  The reference is Rust and cannot be compiled here (no rustc/cargo),
+so the restatement is pinned against the known-answer vectors of the reference's own unit
+tests, transcribed by `tests/golden/extract_reference_fixtures.py` into
+`tests/golden/*.json` and replayed by `tests/test_oracle_golden.py`.
+
+Third-party arithmetic restated (not under /root/reference): `ndarray ^0.15.4`
+`linalg::general_mat_mul` -> `matrixmultiply ^0.3` sgemm (C = alpha*A*B + beta*C);
+`ndarray::ArrayBase::{sum,mean,fold}`; Rust std f32 `exp`/`ln`; `rand 0.8` Bernoulli.
+Summation order of those libraries is not reproducible bit for bit, so contractions and
+reductions are compared with a stated tolerance; data movement, masks and index-like
+behaviour are compared bit-exactly.
+
+Conventions restated from the reference:
+  * every forward OVERWRITES its output buffer (GEMM beta = 0),
+  * every backward ACCUMULATES (`+=`) into the operand gradient (GEMM beta = 1),
+  * all arrays are C-contiguous; dtype is whatever the caller passes (f32 twin / f64 yardstick).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+# --------------------------------------------------------------------------------------
+# a-1 / a-2  MatMul, MatMulT      node/matrix_matrix_mul/mod.rs, node/matrix_matrix_mul_t/mod.rs
+# --------------------------------------------------------------------------------------
+
+
+def mm_forward(left, right, out):
+    """`MatrixMatrixMul::forward` (matrix_matrix_mul/mod.rs:31-41): out = left . right, beta=0."""
+    np.matmul(left, right, out=out)
+
+
+def mm_backward_left(left_grad, grad, right):
+    """`MatrixMatrixMulBackwardLeft::backward` (:63-73): dA += G . B^T."""
+    left_grad += grad @ right.T
+
+
+def mm_backward_right(right_grad, grad, left):
+    """`MatrixMatrixMulBackwardRight::backward` (:95-105): dB += A^T . G."""
+    right_grad += left.T @ grad
+
+
+def mm_t_forward(left, right, out):
+    """`MatrixMatrixMulT::forward` (matrix_matrix_mul_t/mod.rs:31-41): out = left . right^T."""
+    np.matmul(left, right.T, out=out)
+
+
+def mm_t_backward_left(left_grad, grad, right):
+    """`MatrixMatrixMulTBackwardLeft::backward` (:63-73): dA += G . B."""
+    left_grad += grad @ right
+
+
+def mm_t_backward_right(right_grad, grad, left):
+    """`MatrixMatrixMulTBackwardRight::backward` (:95-105): dB += G^T . A."""
+    right_grad += grad.T @ left
+
+
+# --------------------------------------------------------------------------------------
+# a-3  Convolution (1/2/3-d, stride, dilation, groups)        node/convolution/mod.rs
+# --------------------------------------------------------------------------------------
+
+
+def conv_out_shape(input_shape, kernel_shape, stride, dilation):
+    """`conv_out_shape` (utils.rs:207-237): no internal padding."""
+    spatial = [
+        (i - d * (k - 1) - 1) // s + 1
+        for i, k, s, d in zip(input_shape[2:], kernel_shape[2:], stride, dilation)
+    ]
+    return (input_shape[0], kernel_shape[0], *spatial)
+
+
+def check_conv_args(input_shape, kernel_shape, stride, dilation):
+    """`check_conv_args` (utils.rs:427-474); panics become AssertionError."""
+    nd = len(input_shape) - 2
+    assert nd == len(stride), f"Invalid stride {list(stride)} for {nd}d conv."
+    assert nd == len(dilation), f"Invalid dilation {list(dilation)} for {nd}d conv."
+    assert len(kernel_shape) == len(input_shape), (
+        f"Invalid kernel shape {list(kernel_shape)} for {nd}d conv"
+    )
+    for i, k, d in zip(input_shape[2:], kernel_shape[2:], dilation):
+        assert i >= (k - 1) * d + 1, "The kernel size can't be greater than actual input size."
+
+
+def check_groups_args(input_shape, kernel_shape, groups):
+    """`check_groups_args` (utils.rs:481-497)."""
+    assert input_shape[1] % groups == 0, (
+        f"In channels {input_shape[1]} is not divisible by groups {groups}"
+    )
+    assert kernel_shape[0] % groups == 0, (
+        f"Out channels {kernel_shape[0]} is not divisible by groups {groups}"
+    )
+
+
+def im2col(x, kernel_shape, stride, dilation):
+    """Rolling-window view -> dense columns, `as_windows` + `columns_shape`
+    (utils.rs:249-353, 403-420): result (N, L, Cin*prod(k)) with the window axis ordered
+    (ci, k0, k1, ...), L = prod(out spatial) in row-major order."""
+    nd = x.ndim - 2
+    ks = tuple(kernel_shape[2:])
+    out_sp = conv_out_shape(x.shape, kernel_shape, stride, dilation)[2:]
+    n, c = x.shape[:2]
+    cols = np.empty((n, *out_sp, c, *ks), dtype=x.dtype)
+    for kidx in np.ndindex(*ks):
+        sl = tuple(
+            slice(kidx[a] * dilation[a], kidx[a] * dilation[a] + stride[a] * (out_sp[a] - 1) + 1, stride[a])
+            for a in range(nd)
+        )
+        patch = x[(slice(None), slice(None), *sl)]  # (N, C, *out_sp)
+        cols[(slice(None), *([slice(None)] * nd), slice(None), *kidx)] = np.moveaxis(patch, 1, -1)
+    return cols.reshape(n, int(np.prod(out_sp)), c * int(np.prod(ks)))
+
+
+def _col2im_add(dest, cols, kernel_shape, stride, dilation):
+    """`assign_from_cols` (convolution/mod.rs:63-83): dest windows += cols."""
+    nd = dest.ndim - 2
+    ks = tuple(kernel_shape[2:])
+    out_sp = conv_out_shape(dest.shape, kernel_shape, stride, dilation)[2:]
+    n, c = dest.shape[:2]
+    cols = cols.reshape(n, *out_sp, c, *ks)
+    for kidx in np.ndindex(*ks):
+        sl = tuple(
+            slice(kidx[a] * dilation[a], kidx[a] * dilation[a] + stride[a] * (out_sp[a] - 1) + 1, stride[a])
+            for a in range(nd)
+        )
+        src = cols[(slice(None), *([slice(None)] * nd), slice(None), *kidx)]  # (N,*out_sp,C)
+        dest[(slice(None), slice(None), *sl)] += np.moveaxis(src, -1, 1)
+
+
+def _convolution(x, w, out, stride, dilation):
+    """`convolution` (convolution/mod.rs:85-123): out[n] = Wflat . cols[n]^T, beta = 0."""
+    wf = w.reshape(w.shape[0], -1)
+    cols = im2col(x, w.shape, stride, dilation)
+    res = np.einsum("ok,nlk->nol", wf, cols, optimize=True)
+    out[...] = res.reshape(out.shape)
+
+
+def _convolution_backward_input(x_grad, grad, w, stride, dilation):
+    """`convolution_backward_input` (:146-189): buf[n] = Wflat^T . G[n]; col2im `+=`."""
+    wf = w.reshape(w.shape[0], -1)
+    g = grad.reshape(grad.shape[0], grad.shape[1], -1)  # (N, Cout, L)
+    buf = np.einsum("ok,nol->nlk", wf, g, optimize=True)  # windows order (N, L, K)
+    _col2im_add(x_grad, buf, w.shape, stride, dilation)
+
+
+def _convolution_backward_kernel(w_grad, grad, x, stride, dilation):
+    """`convolution_backward_kernel` (:191-226): dW[c,:] += G[:,c,:] . cols."""
+    cols = im2col(x, w_grad.shape, stride, dilation)  # (N, L, K)
+    g = grad.reshape(grad.shape[0], grad.shape[1], -1)  # (N, Cout, L)
+    dw = np.einsum("nol,nlk->ok", g, cols, optimize=True)
+    w_grad += dw.reshape(w_grad.shape)
+
+
+def _groups(a, axis, groups):
+    step = a.shape[axis] // groups
+    for g in range(groups):
+        idx = [slice(None)] * a.ndim
+        idx[axis] = slice(g * step, (g + 1) * step)
+        yield tuple(idx)
+
+
+def convolution_forward(x, w, out, stride, dilation, groups=1):
+    """`Convolution::forward` (:331-355) -> `grouped_convolution` (:125-144): input split on
+    axis 1, kernel on axis 0, output on axis 1."""
+    for xs, ws, os in zip(_groups(x, 1, groups), _groups(w, 0, groups), _groups(out, 1, groups)):
+        o = np.zeros(out[os].shape, dtype=out.dtype)
+        _convolution(np.ascontiguousarray(x[xs]), np.ascontiguousarray(w[ws]), o, stride, dilation)
+        out[os] = o
+
+
+def convolution_backward_input(x_grad, grad, w, stride, dilation, groups=1):
+    """`grouped_convolution_backward_input` (:256-274)."""
+    for xs, gs, ws in zip(_groups(x_grad, 1, groups), _groups(grad, 1, groups), _groups(w, 0, groups)):
+        xg = np.ascontiguousarray(x_grad[xs])
+        _convolution_backward_input(xg, np.ascontiguousarray(grad[gs]), np.ascontiguousarray(w[ws]), stride, dilation)
+        x_grad[xs] = xg
+
+
+def convolution_backward_kernel(w_grad, grad, x, stride, dilation, groups=1):
+    """`grouped_convolution_backward_kernel` (:276-294)."""
+    for ws, gs, xs in zip(_groups(w_grad, 0, groups), _groups(grad, 1, groups), _groups(x, 1, groups)):
+        wg = np.ascontiguousarray(w_grad[ws])
+        _convolution_backward_kernel(wg, np.ascontiguousarray(grad[gs]), np.ascontiguousarray(x[xs]), stride, dilation)
+        w_grad[ws] = wg
+
+
+# --------------------------------------------------------------------------------------
+# a-4 / a-5  broadcast binaries + un-broadcast accumulate
+# --------------------------------------------------------------------------------------
+
+
+def cobroadcast(left_shape, right_shape):
+    """`cobroadcast` (utils.rs:97-125): NumPy right-aligned broadcasting, ndim = max."""
+    bigger, smaller = (left_shape, right_shape) if len(left_shape) >= len(right_shape) else (right_shape, left_shape)
+    out = list(bigger)
+    off = len(bigger) - len(smaller)
+    for i, r in enumerate(smaller):
+        l = out[off + i]
+        if l != r:
+            if l == 1:
+                out[off + i] = r
+            else:
+                assert r == 1, "The two tensors have incompatible shape."
+    return tuple(out)
+
+
+def accumulate(target, source):
+    """INTENDED semantics of `utils::accumulate` (utils.rs:152-192): target += source summed
+    over every axis `target` lacks or has with extent 1.  The reference's lane-axis choice is
+    defective for non-square shapes; it is NOT replicated.  The
+    reference's own fixtures (addition/test.rs:110-124, multiplication/test.rs:121-139) pass
+    against this."""
+    if source.shape == target.shape:
+        target += source
+        return
+    k = source.ndim - target.ndim
+    red = source.sum(axis=tuple(range(k))) if k > 0 else source
+    keep = tuple(i for i, (t, s) in enumerate(zip(target.shape, red.shape)) if t == 1 and s != 1)
+    if keep:
+        red = red.sum(axis=keep, keepdims=True)
+    target += red.reshape(target.shape)
+
+
+_BIN = {
+    "add": lambda l, r: l + r,
+    "sub": lambda l, r: l - r,
+    "mul": lambda l, r: l * r,
+    "div": lambda l, r: l / r,
+}
+
+
+def binary_forward(op, left, right, out):
+    """`Addition|Subtraction|Multiplication|Division::forward` (node/<op>/mod.rs:39-50)."""
+    out[...] = _BIN[op](left, right)
+
+
+def binary_backward_left(op, left_grad, grad, left, right):
+    """`<Op>BackwardLeft::backward`: addition/mod.rs:86-91, subtraction/mod.rs:87-92,
+    multiplication/mod.rs:91-103 (buf = g*r), division/mod.rs:90-99 (buf = g/r)."""
+    if op in ("add", "sub"):
+        local = grad
+    elif op == "mul":
+        local = grad * right
+    else:
+        local = grad / right
+    accumulate(left_grad, np.broadcast_to(local, grad.shape) if np.ndim(local) else local)
+
+
+def binary_backward_right(op, right_grad, grad, left, right):
+    """`<Op>BackwardRight::backward`: addition/mod.rs:129-134, subtraction/mod.rs:130-136
+    (-g), multiplication/mod.rs:138-149 (g*l), division/mod.rs:139-149 (-g*l/r^2)."""
+    if op == "add":
+        local = grad
+    elif op == "sub":
+        local = -grad
+    elif op == "mul":
+        local = grad * left
+    else:
+        local = -grad * left / (right * right)
+    accumulate(right_grad, local)
+
+
+# --------------------------------------------------------------------------------------
+# a-6  Sum / Mean          node/sum/mod.rs, node/mean/mod.rs
+# --------------------------------------------------------------------------------------
+
+
+def sum_forward(x, out):
+    """`Sum::forward` (sum/mod.rs:28-35): full reduction to Ix0."""
+    out[...] = x.sum(dtype=x.dtype)
+
+
+def sum_backward(x_grad, grad):
+    """`SumBackward::backward` (:60-67): dx += g."""
+    x_grad += grad
+
+
+def mean_forward(x, out):
+    """`Mean::forward` (mean/mod.rs:28-35): sum/len."""
+    out[...] = x.sum(dtype=x.dtype) / x.dtype.type(x.size)
+
+
+def mean_backward(x_grad, grad):
+    """`MeanBackward::backward` (:60-72): dx += g/len."""
+    x_grad += grad / x_grad.dtype.type(x_grad.size)
+
+
+# --------------------------------------------------------------------------------------
+# a-7  Softmax / LogSoftmax      node/softmax/mod.rs, node/logsoftmax/mod.rs
+# --------------------------------------------------------------------------------------
+
+
+def softmax_forward(x, out, axis):
+    """`Softmax::forward` (softmax/mod.rs:37-53): m = max, e = exp(x-m), y = e/sum(e)."""
+    m = np.maximum(x.max(axis=axis, keepdims=True), np.finfo(np.float32).min).astype(x.dtype)
+    e = np.exp(x - m)
+    out[...] = e / e.sum(axis=axis, keepdims=True, dtype=x.dtype)
+
+
+def softmax_backward(x_grad, grad, data, axis):
+    """`SoftmaxBackward::backward` (:84-104): dx += y*(g - sum(g*y))."""
+    s = (grad * data).sum(axis=axis, keepdims=True, dtype=data.dtype)
+    x_grad += data * (grad - s)
+
+
+def log_softmax_forward(x, out, axis):
+    """`LogSoftmax::forward` (logsoftmax/mod.rs:37-53): y = x - ln(sum exp(x-m)) - m."""
+    m = np.maximum(x.max(axis=axis, keepdims=True), np.finfo(np.float32).min).astype(x.dtype)
+    lse = np.log(np.exp(x - m).sum(axis=axis, keepdims=True, dtype=x.dtype))
+    out[...] = x - lse - m
+
+
+def log_softmax_backward(x_grad, grad, data, axis):
+    """`LogSoftmaxBackward::backward` (:84-102): dx += g - exp(y)*sum(g)."""
+    x_grad += grad - np.exp(data) * grad.sum(axis=axis, keepdims=True, dtype=data.dtype)
+
+
+# --------------------------------------------------------------------------------------
+# a-8  Dropout            node/dropout/mod.rs
+# --------------------------------------------------------------------------------------
+
+_PHILOX_M0 = np.uint64(0xD2511F53)
+_PHILOX_M1 = np.uint64(0xCD9E8D57)
+_PHILOX_W0 = np.uint32(0x9E3779B9)
+_PHILOX_W1 = np.uint32(0xBB67AE85)
+
+
+def philox4x32_10(counter, key):
+    """Philox4x32-10 (Salmon et al., SC'11), vectorised.  `counter` is (n,4) uint32, `key`
+    (2,) uint32.  This is the device RNG of the HIP backend (the reference uses
+    `rand::thread_rng`, which is non-reproducible by design, dropout/mod.rs:68-70), restated
+    here so the keep/drop pattern can be checked bit-exactly."""
+    c = counter.astype(np.uint32).copy()
+    k0, k1 = np.uint32(key[0]), np.uint32(key[1])
+    mask = np.uint64(0xFFFFFFFF)
+    with np.errstate(over="ignore"):
+        for _ in range(10):
+            p0 = _PHILOX_M0 * c[:, 0].astype(np.uint64)
+            p1 = _PHILOX_M1 * c[:, 2].astype(np.uint64)
+            hi0, lo0 = (p0 >> np.uint64(32)).astype(np.uint32), (p0 & mask).astype(np.uint32)
+            hi1, lo1 = (p1 >> np.uint64(32)).astype(np.uint32), (p1 & mask).astype(np.uint32)
+            c = np.stack([hi1 ^ c[:, 1] ^ k0, lo1, hi0 ^ c[:, 3] ^ k1, lo0], axis=1)
+            k0 = np.uint32(k0 + _PHILOX_W0)
+            k1 = np.uint32(k1 + _PHILOX_W1)
+    return c
+
+
+def dropout_noise(n, p, seed, offset):
+    """Bernoulli(1-p) 0/1 noise for `n` elements as the HIP backend draws it: element `i`
+    uses word `i % 4` of Philox4x32-10(counter = (i/4 + offset, 0, 0, 0) as 64-bit lo/hi,
+    key = seed lo/hi); keep iff u = word * 2^-32 < 1-p, compared in f32 as
+    `(float)(word >> 8) * 2^-24 < (float)(1-p)`."""
+    nblk = (n + 3) // 4
+    idx = np.arange(nblk, dtype=np.uint64) + np.uint64(offset)
+    ctr = np.zeros((nblk, 4), dtype=np.uint32)
+    ctr[:, 0] = (idx & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    ctr[:, 1] = (idx >> np.uint64(32)).astype(np.uint32)
+    key = np.array([seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF], dtype=np.uint32)
+    words = philox4x32_10(ctr, key).reshape(-1)[:n]
+    u = (words >> np.uint32(8)).astype(np.float32) * np.float32(2.0 ** -24)
+    return (u < np.float32(1.0 - p)).astype(np.float32)
+
+
+def dropout_forward(x, out, noise, p, train=True):
+    """`Dropout::forward` (dropout/mod.rs:53-79) with the 0/1 `noise` supplied by the caller
+    (the reference resamples it with thread_rng on every forward).  eval or p == 0: copy;
+    p == 1: zeros (noise untouched); else y = (x*noise)/(1-p)."""
+    assert 0.0 <= p <= 1.0, f"Wrong probability received: {p}."
+    if (not train) or p == 0.0:
+        out[...] = x
+        return
+    if 1.0 - p == 0.0:
+        out[...] = 0
+        return
+    out[...] = (x * noise) / x.dtype.type(np.float32(1.0 - p))
+
+
+def dropout_backward(x_grad, grad, noise, p, train=True):
+    """`DropoutBackward::backward` (:113-128): eval or p == 0: dx += g; else dx += g*noise —
+    NOT divided by (1-p): reference behaviour, replicated on purpose."""
+    if (not train) or p == 0.0:
+        x_grad += grad
+        return
+    x_grad += grad * noise
+
+
+# --------------------------------------------------------------------------------------
+# a-9  ReLU               node/relu/mod.rs
+# --------------------------------------------------------------------------------------
+
+
+def relu_forward(x, out):
+    """`ReLU::forward` (relu/mod.rs:29-38): max(x, 0)."""
+    np.maximum(x, 0, out=out)
+
+
+def relu_backward(x_grad, grad, x):
+    """`ReLUBackward::backward` (:67-79): dx += (x > 0) * g, strict, on the INPUT."""
+    x_grad += (x > 0).astype(grad.dtype) * grad
+
+
+# --------------------------------------------------------------------------------------
+# a-10  glue: SquaredError, Pad(Constant/Zero), Chunk, MultiConcatenate, Transpose
+# --------------------------------------------------------------------------------------
+
+
+def squared_error_forward(x, target, out, reduction="mean"):
+    """`SquaredError::forward` (squared_error/mod.rs:42-59)."""
+    total = ((x - target) ** 2).sum(dtype=x.dtype)
+    out[...] = total / x.dtype.type(x.size) if reduction == "mean" else total
+
+
+def squared_error_backward(x_grad, grad, x, target, reduction="mean"):
+    """`SquaredErrorBackward::backward` (:94-123): dx += 2(x-t)*g[/n]."""
+    local = (2 * (x - target)) * grad
+    if reduction == "mean":
+        local = local / x.dtype.type(x.size)
+    x_grad += local
+
+
+def pad_constant_forward(x, out, padding, value=0.0):
+    """`Pad::forward` with `Constant(value)` / `Zero` (pad/mod.rs:97-129,
+    pad/constant/mod.rs:14-39, pad/zero/mod.rs:12-22): symmetric padding[i] on both sides of
+    spatial axis i (axes 2..), fill then assign the centre."""
+    out[...] = value
+    centre = (slice(None), slice(None)) + tuple(slice(p, out.shape[2 + i] - p) for i, p in enumerate(padding))
+    out[centre] = x
+
+
+def pad_backward(x_grad, grad, padding):
+    """`PadBackward::backward` (pad/mod.rs:157-181): dx += centre slice of g."""
+    centre = (slice(None), slice(None)) + tuple(slice(p, grad.shape[2 + i] - p) for i, p in enumerate(padding))
+    x_grad += grad[centre]
+
+
+def _chunk_slices(operand_shape, chunk_shape, chunk_no):
+    """`exact_chunks(shape)` iteration order: row-major over the chunk grid, remainder skipped."""
+    grid = [o // c for o, c in zip(operand_shape, chunk_shape)]
+    idx = np.unravel_index(chunk_no, grid)
+    return tuple(slice(i * c, (i + 1) * c) for i, c in zip(idx, chunk_shape))
+
+
+def chunk_forward(x, out, chunk_no):
+    """`Chunk::forward` (chunk/mod.rs:48-64)."""
+    out[...] = x[_chunk_slices(x.shape, out.shape, chunk_no)]
+
+
+def chunk_backward(x_grad, grad, chunk_no):
+    """`ChunkBackward::backward` (:99-113): tile `+=`."""
+    x_grad[_chunk_slices(x_grad.shape, grad.shape, chunk_no)] += grad
+
+
+def multi_concatenate_forward(operands, out, axis):
+    """`MultiConcatenate::forward` (multi_concatenate/mod.rs:37-50)."""
+    off = 0
+    for o in operands:
+        idx = [slice(None)] * out.ndim
+        idx[axis] = slice(off, off + o.shape[axis])
+        out[tuple(idx)] = o
+        off += o.shape[axis]
+
+
+def multi_concatenate_backward(operand_grads, grad, axis):
+    """`MultiConcatenateBackward::backward` (:81-97): slice `+=`."""
+    off = 0
+    for og in operand_grads:
+        idx = [slice(None)] * grad.ndim
+        idx[axis] = slice(off, off + og.shape[axis])
+        og += grad[tuple(idx)]
+        off += og.shape[axis]
+
+
+def transpose_forward(x, out):
+    """`Transpose::forward` (transpose/mod.rs:28-37): reversed axes, materialised."""
+    out[...] = x.T
+
+
+def transpose_backward(x_grad, grad):
+    """`TransposeBackward::backward` (:62-69): dx += g^T."""
+    x_grad += grad.T
+
+
+# --------------------------------------------------------------------------------------
+# f-1  optimizer step (first "next" row): SGD + penalties     neuronika-optim/src/sgd/mod.rs
+# --------------------------------------------------------------------------------------
+
+
+def penalty_grad(kind, w, l1=0.0, l2=0.0):
+    """`Penalty::penalize` (neuronika-optim/src/penalty.rs:63-79): L1 -> l*sign(w),
+    L2 -> 2*l*w, ElasticNet -> both."""
+    if kind == "none":
+        return np.zeros_like(w)
+    if kind == "l1":
+        return l1 * np.sign(w)
+    if kind == "l2":
+        return 2 * l2 * w
+    return l1 * np.sign(w) + 2 * l2 * w
+
+
+def sgd_step(w, grad, lr, velocity=None, momentum=0.0, dampening=0.0, nesterov=False,
+             first_step=False, penalty="none", l1=0.0, l2=0.0):
+    """`SGDParam::optimize` plain / momentum / Nesterov (sgd/mod.rs:186-236).  In place:
+    grad += penalty(w); plain: w -= lr*grad.  momentum: buf = grad on the first step else
+    buf = momentum*buf + (1-dampening)*grad; nesterov: w -= lr*(grad + momentum*buf) else
+    w -= lr*buf."""
+    grad += penalty_grad(penalty, w, l1, l2).astype(w.dtype)
+    if velocity is None:
+        w -= w.dtype.type(lr) * grad
+        return
+    if first_step:
+        velocity[...] = grad
+    else:
+        velocity[...] = velocity * w.dtype.type(momentum) + grad * w.dtype.type(1.0 - dampening)
+    if nesterov:
+        w -= w.dtype.type(lr) * (grad + velocity * w.dtype.type(momentum))
+    else:
+        w -= w.dtype.type(lr) * velocity
+
+
+# --------------------------------------------------------------------------------------
+# a-11  tape-level compositions used by the BASELINE configs
+# --------------------------------------------------------------------------------------
+
+
+def linear_forward(x, w, b):
+    """`nn::Linear::forward` (neuronika-nn/src/lib.rs:441-447): x.mm_t(W) + b."""
+    z = np.zeros((x.shape[0], w.shape[0]), dtype=x.dtype)
+    mm_t_forward(x, w, z)
+    out = np.zeros_like(z)
+    binary_forward("add", z, b, out)
+    return out
+
+
+def mlp_step(x, target, params, seed=1.0):
+    """One `loss.forward(); loss.backward(seed)` of the C1/C4 MLP on a fresh graph:
+    Linear -> ReLU -> ... -> Linear -> MSE(mean).  `params` = [(W1,b1),(W2,b2),...].
+    Returns (loss, [(dW1,db1),...]) — input `x` is a non-differentiable `Var`, so no dX for
+    layer 1 (var.rs:1081-1094).  Tape: [MMT,Add,ReLU]* MMT,Add,SquaredError."""
+    dt = x.dtype
+    acts, pre = [x], []
+    h = x
+    for i, (w, b) in enumerate(params):
+        z = linear_forward(h, w, b)
+        pre.append(z)
+        if i + 1 < len(params):
+            a = np.zeros_like(z)
+            relu_forward(z, a)
+            h = a
+            acts.append(a)
+        else:
+            h = z
+    loss = np.zeros((), dtype=dt)
+    squared_error_forward(h, target, loss, "mean")
+
+    g_root = np.full((), seed, dtype=dt)
+    g = np.zeros_like(h)
+    squared_error_backward(g, g_root, h, target, "mean")
+    grads = [None] * len(params)
+    for i in reversed(range(len(params))):
+        w, b = params[i]
+        # Addition backward: left (N,out) same shape, right bias un-broadcast.
+        g_mm = np.zeros_like(g)
+        accumulate(g_mm, g)
+        db = np.zeros_like(b)
+        accumulate(db, g)
+        dw = np.zeros_like(w)
+        mm_t_backward_right(dw, g_mm, acts[i])
+        grads[i] = (dw, db)
+        if i > 0:
+            da = np.zeros_like(acts[i])
+            mm_t_backward_left(da, g_mm, w)
+            g = np.zeros_like(pre[i - 1])
+            relu_backward(g, da, pre[i - 1])
+    return loss, grads
+
+
+def mha_forward_backward(x, wq, bq, wk, bk, wv, bv, wo, bo, heads, batch, p, noise, g_out):
+    """The composed MHA of SURVEY.md section 8a (module absent from the reference; oracle =
+    composition of a-2, a-4, a-7, a-8, a-1, a-10):
+      Q,K,V = x.mm_t(W)+b; per (b,h): P = dropout(softmax((Q_bh.mm_t(K_bh))*dh^-1/2, axis=1));
+      O_bh = P.mm(V_bh); out = cat(O).mm_t(Wo)+bo.
+    x is a differentiable leaf here.  `noise` has shape (batch*heads, S, S).  Returns out and
+    a dict of gradients."""
+    dt = x.dtype
+    bs, d = x.shape
+    s = bs // batch
+    dh = d // heads
+    scale = dt.type(1.0 / np.sqrt(dh))
+    q, k, v = linear_forward(x, wq, bq), linear_forward(x, wk, bk), linear_forward(x, wv, bv)
+
+    def split(t):  # (B*S, d) -> (B*H, S, dh)   chunks((S,dh)) row-major order (var.rs:401-417)
+        return np.ascontiguousarray(t.reshape(batch, s, heads, dh).transpose(0, 2, 1, 3)).reshape(batch * heads, s, dh)
+
+    def merge(t):  # cat(axis 1) per batch then cat(axis 0)
+        return np.ascontiguousarray(t.reshape(batch, heads, s, dh).transpose(0, 2, 1, 3)).reshape(bs, d)
+
+    qh, kh, vh = split(q), split(k), split(v)
+    sc = np.matmul(qh, kh.transpose(0, 2, 1))
+    scs = sc * scale
+    pr = np.zeros_like(scs)
+    softmax_forward(scs, pr, axis=2)
+    pd = np.zeros_like(pr)
+    dropout_forward(pr, pd, noise, p, True)
+    oh = np.matmul(pd, vh)
+    o = merge(oh)
+    out = linear_forward(o, wo, bo)
+
+    # backward
+    g = g_out
+    dbo = np.zeros_like(bo); accumulate(dbo, g)
+    dwo = np.zeros_like(wo); mm_t_backward_right(dwo, g, o)
+    do = np.zeros_like(o); mm_t_backward_left(do, g, wo)
+    doh = split(do)
+    dpd = np.matmul(doh, vh.transpose(0, 2, 1))
+    dvh = np.matmul(pd.transpose(0, 2, 1), doh)
+    dpr = np.zeros_like(pr); dropout_backward(dpr, dpd, noise, p, True)
+    dscs = np.zeros_like(scs); softmax_backward(dscs, dpr, pr, axis=2)
+    dsc = dscs * scale
+    dqh = np.matmul(dsc, kh)
+    dkh = np.matmul(dsc.transpose(0, 2, 1), qh)
+    dq, dk, dv = merge(dqh), merge(dkh), merge(dvh)
+    grads = {}
+    dx = np.zeros_like(x)
+    for name, w, b, dz in (("q", wq, bq, dq), ("k", wk, bk, dk), ("v", wv, bv, dv)):
+        db = np.zeros_like(b); accumulate(db, dz)
+        dw = np.zeros_like(w); mm_t_backward_right(dw, dz, x)
+        mm_t_backward_left(dx, dz, w)
+        grads["w" + name], grads["b" + name] = dw, db
+    grads.update(wo=dwo, bo=dbo, x=dx)
+    return out, grads
