@@ -1,0 +1,267 @@
+/*
+ * neuronika_hip.h — C ABI of the MI355X (gfx950) dense-tensor backend for neuronika's
+ * Var/VarDiff op graph.
+ *
+ * This is the drop-in boundary.  The reference has no FFI of its own:
+ * the seam is the pair of crate-private traits
+ *     trait Forward  { fn forward(&self);  }   neuronika-variable/src/autograd.rs:7-12
+ *     trait Backward { fn backward(&self); }   neuronika-variable/src/autograd.rs:20-25
+ * implemented by node structs that own handles to their operand/output buffers.  Each entry
+ * point below replaces the BODY of one such `forward()` / `backward()` (cited per function);
+ * the reference's own accelerator template (`neuronika-variable/src/cuda/`) shows the shape a
+ * backend takes: a `Device` handle (cuda/device.rs:11-58), a device array replacing
+ * `ndarray::Array` (cuda/cuarray.rs:10-19) and nodes that call the library in `forward()`
+ * (cuda/cunode/binary_op/mod.rs:55-82).  INTEGRATION.md shows the Rust binding.
+ *
+ * Conventions (identical to the reference's ndarray path):
+ *   - every tensor is dense f32, C-contiguous (row-major), described by (pointer, shape[]);
+ *   - every *_fwd OVERWRITES its output (GEMM beta = 0); every *_bwd ACCUMULATES (`+=`)
+ *     into the operand gradient (GEMM beta = 1);
+ *   - the host owns every device buffer; the library never keeps a data pointer past a call;
+ *   - calls are asynchronous on the device's compute stream, in call (= tape) order; the host
+ *     synchronises only in nk_download / nk_device_sync / nk_event_* queries;
+ *   - one host thread per nk_device (the reference graph is Rc<RefCell<..>>, i.e. !Send);
+ *     different devices may be driven from different threads / processes concurrently;
+ *   - every function returns NK_OK (0) or an error code; nk_last_error() gives the message
+ *     of the calling thread's last failure.  The reference convention is panic
+ *     (`.unwrap()`, cuda/device.rs:36-45; `assert!`, utils.rs:438-496): a host binding turns
+ *     a non-zero status into a panic.  Shape validation that the reference does on the host
+ *     (`check_conv_args`, `cobroadcast`) is repeated here and reported as NK_ERR_INVALID.
+ *
+ * No torch / C++ types cross this boundary: plain pointers, sizes and scalars only.
+ */
+#ifndef NEURONIKA_HIP_H
+#define NEURONIKA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct nk_device nk_device; /* cuda/device.rs:11-16  `Device`            */
+typedef struct nk_event nk_event;   /* hipEvent on a device stream (timing/ordering) */
+typedef struct nk_comm nk_comm;     /* one rank of a RCCL communicator (net-new)  */
+
+enum nk_status {
+    NK_OK = 0,
+    NK_ERR_INVALID = 1,     /* bad argument / shape (reference: assert!/panic!)      */
+    NK_ERR_HIP = 2,         /* HIP runtime failure                                   */
+    NK_ERR_RCCL = 3,        /* RCCL failure                                          */
+    NK_ERR_OOM = 4,         /* device allocation failed                              */
+    NK_ERR_UNSUPPORTED = 5  /* valid in the reference, not implemented by this build */
+};
+
+enum nk_binary_op { NK_ADD = 0, NK_SUB = 1, NK_MUL = 2, NK_DIV = 3 };
+enum nk_reduction { NK_REDUCTION_SUM = 0, NK_REDUCTION_MEAN = 1 }; /* lib.rs:29-36 */
+
+#define NK_MAX_DIMS 8
+
+/* ------------------------------------------------------------------ lifecycle ---------- */
+/* `Device::new(idx)` cuda/device.rs:34-58.  Creates the compute stream and the side
+ * (communication) stream of GPU `idx`. */
+int nk_device_count(int* out);
+int nk_device_create(int idx, nk_device** out);
+int nk_device_destroy(nk_device* dev);
+int nk_device_sync(nk_device* dev);
+int nk_device_index(const nk_device* dev);
+void* nk_stream_compute(nk_device* dev); /* hipStream_t */
+void* nk_stream_comm(nk_device* dev);    /* hipStream_t */
+const char* nk_last_error(void);
+const char* nk_version(void);
+
+/* ------------------------------------------------------------------ memory ------------- */
+/* `CuArray::zeroed` cuda/cuarray.rs:35-42; outputs and gradients are allocated zeroed at
+ * graph-build time (var.rs:224,1041; gradient.rs:47-54). */
+int nk_alloc_zeroed(nk_device* dev, size_t n_f32, float** out);
+int nk_free(nk_device* dev, float* ptr);
+/* `CuArray::from_slice / from_ndarray` cuda/cuarray.rs:62-72,114-117 (H2D) */
+int nk_upload(nk_device* dev, float* dst, const float* host_src, size_t n);
+/* `CuArray::as_ndarray` cuda/cuarray.rs:101-106 (D2H, synchronises the compute stream) */
+int nk_download(nk_device* dev, float* host_dst, const float* src, size_t n);
+/* root-gradient seeding `grad_mut().fill(seed)` vardiff.rs:133; `zero_grad` vardiff.rs:100-102;
+ * `Gradient::with_grad` re-zero gradient.rs:71-78 */
+int nk_fill(nk_device* dev, float* ptr, size_t n, float value);
+int nk_copy(nk_device* dev, float* dst, const float* src, size_t n);
+
+/* ------------------------------------------------------------------ events ------------- */
+int nk_event_create(nk_device* dev, nk_event** out);
+int nk_event_destroy(nk_event* ev);
+int nk_event_record(nk_event* ev, int on_comm_stream); /* 0: compute stream, 1: comm stream */
+int nk_event_sync(nk_event* ev);
+int nk_event_elapsed_ms(nk_event* start, nk_event* stop, float* ms);
+int nk_stream_wait_event(nk_device* dev, int on_comm_stream, nk_event* ev);
+
+/* ------------------------------------------------------------------ GEMM (MFMA) -------- */
+/* Row-major C(MxN) = alpha * op(A)(MxK) * op(B)(KxN) + beta * C; op(X) = X or X^T
+ * (trans != 0: the stored matrix is the transpose, i.e. A is stored KxM with leading
+ * dimension lda).  Replaces `ndarray::linalg::general_mat_mul` at its six call sites:
+ * node/matrix_matrix_mul/mod.rs:33,65,97 and node/matrix_matrix_mul_t/mod.rs:33,65,97. */
+int nk_sgemm(nk_device* dev, int transA, int transB, int M, int N, int K, float alpha,
+             const float* A, int lda, const float* B, int ldb, float beta, float* C, int ldc);
+/* Batched over a two-level batch index b = bo * batch_inner + bi; operand offset =
+ * bo * stride_outer + bi * stride_inner (elements).  Used by the composed multi-head
+ * attention: bo = sample, bi = head, so Q_bh is a strided view of the (B*S) x d projection. */
+int nk_sgemm_batched(nk_device* dev, int transA, int transB, int M, int N, int K, float alpha,
+                     const float* A, int lda, long long sAo, long long sAi,
+                     const float* B, int ldb, long long sBo, long long sBi, float beta,
+                     float* C, int ldc, long long sCo, long long sCi,
+                     int batch_outer, int batch_inner);
+
+/* Node-level wrappers, one per reference forward()/backward() body. */
+/* MatrixMatrixMul::forward  node/matrix_matrix_mul/mod.rs:31-41   C(n,o) = A(n,m).B(m,o) */
+int nk_mm_fwd(nk_device* dev, const float* A, const float* B, float* C, int n, int m, int o);
+/* MatrixMatrixMulBackwardLeft::backward  :63-73    dA(n,m) += G(n,o).B(m,o)^T */
+int nk_mm_bwd_left(nk_device* dev, float* dA, const float* G, const float* B, int n, int m, int o);
+/* MatrixMatrixMulBackwardRight::backward :95-105   dB(m,o) += A(n,m)^T.G(n,o) */
+int nk_mm_bwd_right(nk_device* dev, float* dB, const float* A, const float* G, int n, int m, int o);
+/* MatrixMatrixMulT::forward  node/matrix_matrix_mul_t/mod.rs:31-41  C(n,o) = A(n,m).B(o,m)^T */
+int nk_mm_t_fwd(nk_device* dev, const float* A, const float* B, float* C, int n, int m, int o);
+/* MatrixMatrixMulTBackwardLeft::backward  :63-73   dA(n,m) += G(n,o).B(o,m) */
+int nk_mm_t_bwd_left(nk_device* dev, float* dA, const float* G, const float* B, int n, int m, int o);
+/* MatrixMatrixMulTBackwardRight::backward :95-105  dB(o,m) += G(n,o)^T.A(n,m) */
+int nk_mm_t_bwd_right(nk_device* dev, float* dB, const float* G, const float* A, int n, int m, int o);
+
+/* ------------------------------------------------------------------ convolution -------- */
+/* N-d (nd = 1,2,3) cross-correlation without internal padding, NC[D]HW layout.
+ *   x: [N, Cin, in...]   w: [Cout, Cin/groups, k...]   y: [N, Cout, out...]
+ *   out_i = (in_i - dilation_i*(k_i-1) - 1)/stride_i + 1          utils.rs:207-237
+ * x_shape has 2+nd entries, w_shape 2+nd entries.
+ * Convolution::forward            node/convolution/mod.rs:331-355 (-> :85-144)  y  = conv(x,w)
+ * ConvolutionBackwardInput        :427-449 (-> :146-189, 256-274)               dx += ...
+ * ConvolutionBackwardKernel       :488-510 (-> :191-226, 276-294)               dw += ...   */
+int nk_conv_fwd(nk_device* dev, int nd, const float* x, const int* x_shape, const float* w,
+                const int* w_shape, float* y, const int* stride, const int* dilation, int groups);
+int nk_conv_bwd_input(nk_device* dev, int nd, float* dx, const int* x_shape, const float* g,
+                      const float* w, const int* w_shape, const int* stride, const int* dilation,
+                      int groups);
+int nk_conv_bwd_kernel(nk_device* dev, int nd, float* dw, const int* w_shape, const float* g,
+                       const float* x, const int* x_shape, const int* stride, const int* dilation,
+                       int groups);
+/* Pad<Constant|Zero>::forward  node/pad/mod.rs:97-129 + pad/constant/mod.rs:14-39;
+ * symmetric `padding[i]` on both sides of spatial axis i.  x_shape = [N, C, in...]. */
+int nk_pad_const_fwd(nk_device* dev, int nd, const float* x, const int* x_shape, float* y,
+                     const int* padding, float value);
+/* PadBackward::backward  node/pad/mod.rs:157-181   dx += centre(g) */
+int nk_pad_bwd(nk_device* dev, int nd, float* dx, const int* x_shape, const float* g,
+               const int* padding);
+
+/* ------------------------------------------------------------------ broadcast binaries - */
+/* Addition|Subtraction|Multiplication|Division::forward node/<op>/mod.rs:39-50.
+ * out_shape must equal cobroadcast(l_shape, r_shape) (utils.rs:97-125). */
+int nk_binary_fwd(nk_device* dev, int op, float* out, const int* out_shape, int out_nd,
+                  const float* l, const int* l_shape, int l_nd,
+                  const float* r, const int* r_shape, int r_nd);
+/* <Op>BackwardLeft::backward : d_left += unbroadcast(local),
+ *   add/sub: local = g; mul: g*r; div: g/r            (addition/mod.rs:86-91, subtraction
+ *   :87-92, multiplication :91-103, division :90-99).  `l` may be NULL for add/sub/mul/div
+ *   (unused); `r` is needed for mul/div. */
+int nk_binary_bwd_left(nk_device* dev, int op, float* d_left, const int* l_shape, int l_nd,
+                       const float* g, const int* g_shape, int g_nd,
+                       const float* r, const int* r_shape, int r_nd);
+/* <Op>BackwardRight::backward : d_right += unbroadcast(local),
+ *   add: g; sub: -g; mul: g*l; div: -g*l/r^2          (addition/mod.rs:129-134, subtraction
+ *   :130-136, multiplication :138-149, division :139-149). */
+int nk_binary_bwd_right(nk_device* dev, int op, float* d_right, const int* r_shape, int r_nd,
+                        const float* g, const int* g_shape, int g_nd,
+                        const float* l, const int* l_shape, int l_nd, const float* r);
+/* `utils::accumulate` (utils.rs:152-192) with the INTENDED semantics: dst += src summed
+ * over every axis dst lacks or has with extent 1 (the reference's lane-axis choice is
+ * defective for non-square shapes; not replicated). */
+int nk_unbroadcast_add(nk_device* dev, float* dst, const int* dst_shape, int dst_nd,
+                       const float* src, const int* src_shape, int src_nd);
+/* ReLU::forward node/relu/mod.rs:29-38; ReLUBackward::backward :67-79 (dx += (x>0)*g) */
+int nk_relu_fwd(nk_device* dev, const float* x, float* y, size_t n);
+int nk_relu_bwd(nk_device* dev, float* dx, const float* g, const float* x, size_t n);
+
+/* ------------------------------------------------------------------ reductions --------- */
+/* Sum::forward node/sum/mod.rs:28-35 ; SumBackward :60-67 (dx += g, g a device scalar) */
+int nk_sum_fwd(nk_device* dev, const float* x, size_t n, float* out);
+int nk_sum_bwd(nk_device* dev, float* dx, size_t n, const float* g);
+/* Mean::forward node/mean/mod.rs:28-35 ; MeanBackward :60-72 (dx += g/len) */
+int nk_mean_fwd(nk_device* dev, const float* x, size_t n, float* out);
+int nk_mean_bwd(nk_device* dev, float* dx, size_t n, const float* g);
+/* SquaredError::forward node/squared_error/mod.rs:42-59 ; backward :94-123 */
+int nk_mse_fwd(nk_device* dev, const float* x, const float* target, size_t n, int reduction,
+               float* out);
+int nk_mse_bwd(nk_device* dev, float* dx, const float* g, const float* x, const float* target,
+               size_t n, int reduction);
+
+/* ------------------------------------------------------------------ softmax ------------ */
+/* Softmax::forward node/softmax/mod.rs:37-53 ; SoftmaxBackward :84-104
+ * LogSoftmax::forward node/logsoftmax/mod.rs:37-53 ; LogSoftmaxBackward :84-102
+ * `axis` is any axis of `shape`. */
+int nk_softmax_fwd(nk_device* dev, const float* x, float* y, const int* shape, int nd, int axis);
+int nk_softmax_bwd(nk_device* dev, float* dx, const float* g, const float* y, const int* shape,
+                   int nd, int axis);
+int nk_log_softmax_fwd(nk_device* dev, const float* x, float* y, const int* shape, int nd, int axis);
+int nk_log_softmax_bwd(nk_device* dev, float* dx, const float* g, const float* y,
+                       const int* shape, int nd, int axis);
+
+/* ------------------------------------------------------------------ dropout ------------ */
+/* Dropout::forward node/dropout/mod.rs:53-79.  train && 0<p<1: noise ~ Bernoulli(1-p) in
+ * {0,1} is (re)drawn from Philox4x32-10(seed, offset) and written to `noise` (f32, like the
+ * reference's shared noise array); y = x*noise/(1-p).  !train or p==0: y = x.  p==1: y = 0
+ * and `noise` is left untouched.  p outside [0,1] -> NK_ERR_INVALID (reference panics,
+ * dropout/mod.rs:38-40). */
+int nk_dropout_fwd(nk_device* dev, const float* x, float* y, float* noise, size_t n, double p,
+                   int train, uint64_t seed, uint64_t offset);
+/* DropoutBackward::backward :113-128.  !train or p==0: dx += g; else dx += g*noise
+ * (NOT divided by 1-p: reference behaviour, kept). */
+int nk_dropout_bwd(nk_device* dev, float* dx, const float* g, const float* noise, size_t n,
+                   double p, int train);
+
+/* ------------------------------------------------------------------ layout glue -------- */
+/* Chunk::forward node/chunk/mod.rs:48-64 ; ChunkBackward :99-113.  `chunk_no` indexes
+ * ndarray's exact_chunks(chunk_shape) iteration order (row-major over the chunk grid). */
+int nk_chunk_fwd(nk_device* dev, const float* x, const int* x_shape, float* y,
+                 const int* chunk_shape, int nd, int chunk_no);
+int nk_chunk_bwd(nk_device* dev, float* dx, const int* x_shape, const float* g,
+                 const int* chunk_shape, int nd, int chunk_no);
+/* MultiConcatenate::forward node/multi_concatenate/mod.rs:37-50 ; backward :81-97.
+ * One call per operand: copies/accumulates the slice [offset, offset+op_len) of `axis`. */
+int nk_concat_fwd_part(nk_device* dev, const float* operand, float* out, const int* out_shape,
+                       int nd, int axis, int offset, int op_len);
+int nk_concat_bwd_part(nk_device* dev, float* d_operand, const float* g, const int* g_shape,
+                       int nd, int axis, int offset, int op_len);
+/* Transpose::forward node/transpose/mod.rs:28-37 (reversed axes) ; backward :62-69 */
+int nk_transpose_fwd(nk_device* dev, const float* x, float* y, const int* x_shape, int nd);
+int nk_transpose_bwd(nk_device* dev, float* dx, const float* g, const int* x_shape, int nd);
+/* Head split / merge for the composed attention = Chunk((S,dh)) for every (b,h) tile followed
+ * by the per-tile consumers, collapsed into one strided copy:  x[(B*S), H*dh] <-> y[B*H, S, dh].
+ * fwd overwrites, bwd accumulates — the same data movement as B*H Chunk nodes
+ * (var.rs:401-417) resp. cat(axis 1) per sample then cat(axis 0) (var.rs:564-584). */
+int nk_split_heads_fwd(nk_device* dev, const float* x, float* y, int B, int S, int H, int dh);
+int nk_split_heads_bwd(nk_device* dev, float* dx, const float* g, int B, int S, int H, int dh);
+int nk_merge_heads_fwd(nk_device* dev, const float* x, float* y, int B, int S, int H, int dh);
+int nk_merge_heads_bwd(nk_device* dev, float* dx, const float* g, int B, int S, int H, int dh);
+
+/* ------------------------------------------------------------------ optimizer (next row)  */
+/* SGDParam::optimize  neuronika-optim/src/sgd/mod.rs:186-236 with Penalty
+ * (penalty.rs:63-79): grad += l1*sign(w) + 2*l2*w; then the plain / momentum / Nesterov
+ * update.  velocity == NULL selects plain SGD.  first_step != 0: velocity = grad. */
+int nk_sgd_step(nk_device* dev, float* w, float* grad, float* velocity, size_t n, float lr,
+                float momentum, float dampening, int nesterov, int first_step, float l1, float l2);
+
+/* ------------------------------------------------------------------ data parallel ------ */
+/* Net-new (the reference has no communication backend).  One nk_comm per process/GPU; the
+ * 128-byte unique id is created on rank 0 and distributed by the host (any side channel). */
+#define NK_COMM_ID_BYTES 128
+int nk_comm_unique_id(char id[NK_COMM_ID_BYTES]);
+int nk_comm_init_rank(nk_device* dev, int nranks, int rank, const char id[NK_COMM_ID_BYTES],
+                      nk_comm** out);
+int nk_comm_destroy(nk_comm* comm);
+/* In-place sum all-reduce of buf[0..n) on the device's SIDE stream.  The side stream first
+ * waits for `after` (an event recorded on the compute stream once the bucket's gradients are
+ * final; NULL: waits for everything enqueued on the compute stream so far). */
+int nk_allreduce_sum_async(nk_comm* comm, float* buf, size_t n, nk_event* after);
+/* Make the compute stream wait for all all-reduces issued so far (no host sync). */
+int nk_comm_join(nk_comm* comm);
+int nk_comm_rank(const nk_comm* comm);
+int nk_comm_size(const nk_comm* comm);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NEURONIKA_HIP_H */

@@ -1,0 +1,474 @@
+"""ctypes binding of the C ABI in include/neuronika_hip.h (libneuronika_hip.so).
+
+This is the Python twin of the Rust binding a maintainer would add: a
+`Device` handle (reference template: neuronika-variable/src/cuda/device.rs:11-58), a
+`HipArray` owning one device buffer (cuda/cuarray.rs:10-19) and one function per C entry
+point.  There is NO CPU fallback: if the HIP library is missing or a call fails, this module
+raises — a GPU test can never silently pass on another code path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libneuronika_hip.so")
+
+
+class NeuronikaHipError(RuntimeError):
+    """A C-ABI call returned non-zero.  The reference convention is panic (`.unwrap()`,
+    cuda/device.rs:36-45; `assert!`, utils.rs:438-496); here it is an exception."""
+
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"[nk status {code}] {msg}")
+        self.code = code
+
+
+def _load() -> C.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -m neuronika_amd.build` "
+            "(the HIP backend has no CPU fallback)")
+    return C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+
+
+lib = _load()
+
+c_f32p = C.POINTER(C.c_float)
+c_intp = C.POINTER(C.c_int)
+VP = C.c_void_p
+
+# name -> argtypes (restype is int unless listed in _RESTYPES)
+_SIGS = {
+    "nk_device_count": [c_intp],
+    "nk_device_create": [C.c_int, C.POINTER(VP)],
+    "nk_device_destroy": [VP],
+    "nk_device_sync": [VP],
+    "nk_device_index": [VP],
+    "nk_stream_compute": [VP],
+    "nk_stream_comm": [VP],
+    "nk_last_error": [],
+    "nk_version": [],
+    "nk_alloc_zeroed": [VP, C.c_size_t, C.POINTER(VP)],
+    "nk_free": [VP, VP],
+    "nk_upload": [VP, VP, VP, C.c_size_t],
+    "nk_download": [VP, VP, VP, C.c_size_t],
+    "nk_fill": [VP, VP, C.c_size_t, C.c_float],
+    "nk_copy": [VP, VP, VP, C.c_size_t],
+    "nk_event_create": [VP, C.POINTER(VP)],
+    "nk_event_destroy": [VP],
+    "nk_event_record": [VP, C.c_int],
+    "nk_event_sync": [VP],
+    "nk_event_elapsed_ms": [VP, VP, C.POINTER(C.c_float)],
+    "nk_stream_wait_event": [VP, C.c_int, VP],
+    "nk_sgemm": [VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, VP, C.c_int, VP, C.c_int, C.c_float, VP, C.c_int],
+    "nk_sgemm_batched": [VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                         VP, C.c_int, C.c_longlong, C.c_longlong, VP, C.c_int, C.c_longlong, C.c_longlong,
+                         C.c_float, VP, C.c_int, C.c_longlong, C.c_longlong, C.c_int, C.c_int],
+    "nk_mm_fwd": [VP, VP, VP, VP, C.c_int, C.c_int, C.c_int],
+    "nk_mm_bwd_left": [VP, VP, VP, VP, C.c_int, C.c_int, C.c_int],
+    "nk_mm_bwd_right": [VP, VP, VP, VP, C.c_int, C.c_int, C.c_int],
+    "nk_mm_t_fwd": [VP, VP, VP, VP, C.c_int, C.c_int, C.c_int],
+    "nk_mm_t_bwd_left": [VP, VP, VP, VP, C.c_int, C.c_int, C.c_int],
+    "nk_mm_t_bwd_right": [VP, VP, VP, VP, C.c_int, C.c_int, C.c_int],
+    "nk_conv_fwd": [VP, C.c_int, VP, c_intp, VP, c_intp, VP, c_intp, c_intp, C.c_int],
+    "nk_conv_bwd_input": [VP, C.c_int, VP, c_intp, VP, VP, c_intp, c_intp, c_intp, C.c_int],
+    "nk_conv_bwd_kernel": [VP, C.c_int, VP, c_intp, VP, VP, c_intp, c_intp, c_intp, C.c_int],
+    "nk_pad_const_fwd": [VP, C.c_int, VP, c_intp, VP, c_intp, C.c_float],
+    "nk_pad_bwd": [VP, C.c_int, VP, c_intp, VP, c_intp],
+    "nk_binary_fwd": [VP, C.c_int, VP, c_intp, C.c_int, VP, c_intp, C.c_int, VP, c_intp, C.c_int],
+    "nk_binary_bwd_left": [VP, C.c_int, VP, c_intp, C.c_int, VP, c_intp, C.c_int, VP, c_intp, C.c_int],
+    "nk_binary_bwd_right": [VP, C.c_int, VP, c_intp, C.c_int, VP, c_intp, C.c_int, VP, c_intp, C.c_int, VP],
+    "nk_unbroadcast_add": [VP, VP, c_intp, C.c_int, VP, c_intp, C.c_int],
+    "nk_relu_fwd": [VP, VP, VP, C.c_size_t],
+    "nk_relu_bwd": [VP, VP, VP, VP, C.c_size_t],
+    "nk_sum_fwd": [VP, VP, C.c_size_t, VP],
+    "nk_sum_bwd": [VP, VP, C.c_size_t, VP],
+    "nk_mean_fwd": [VP, VP, C.c_size_t, VP],
+    "nk_mean_bwd": [VP, VP, C.c_size_t, VP],
+    "nk_mse_fwd": [VP, VP, VP, C.c_size_t, C.c_int, VP],
+    "nk_mse_bwd": [VP, VP, VP, VP, VP, C.c_size_t, C.c_int],
+    "nk_softmax_fwd": [VP, VP, VP, c_intp, C.c_int, C.c_int],
+    "nk_softmax_bwd": [VP, VP, VP, VP, c_intp, C.c_int, C.c_int],
+    "nk_log_softmax_fwd": [VP, VP, VP, c_intp, C.c_int, C.c_int],
+    "nk_log_softmax_bwd": [VP, VP, VP, VP, c_intp, C.c_int, C.c_int],
+    "nk_dropout_fwd": [VP, VP, VP, VP, C.c_size_t, C.c_double, C.c_int, C.c_uint64, C.c_uint64],
+    "nk_dropout_bwd": [VP, VP, VP, VP, C.c_size_t, C.c_double, C.c_int],
+    "nk_chunk_fwd": [VP, VP, c_intp, VP, c_intp, C.c_int, C.c_int],
+    "nk_chunk_bwd": [VP, VP, c_intp, VP, c_intp, C.c_int, C.c_int],
+    "nk_concat_fwd_part": [VP, VP, VP, c_intp, C.c_int, C.c_int, C.c_int, C.c_int],
+    "nk_concat_bwd_part": [VP, VP, VP, c_intp, C.c_int, C.c_int, C.c_int, C.c_int],
+    "nk_transpose_fwd": [VP, VP, VP, c_intp, C.c_int],
+    "nk_transpose_bwd": [VP, VP, VP, c_intp, C.c_int],
+    "nk_split_heads_fwd": [VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int],
+    "nk_split_heads_bwd": [VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int],
+    "nk_merge_heads_fwd": [VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int],
+    "nk_merge_heads_bwd": [VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int],
+    "nk_sgd_step": [VP, VP, VP, VP, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_float, C.c_float],
+    "nk_comm_unique_id": [C.c_char_p],
+    "nk_comm_init_rank": [VP, C.c_int, C.c_int, C.c_char_p, C.POINTER(VP)],
+    "nk_comm_destroy": [VP],
+    "nk_allreduce_sum_async": [VP, VP, C.c_size_t, VP],
+    "nk_comm_join": [VP],
+    "nk_comm_rank": [VP],
+    "nk_comm_size": [VP],
+}
+_RESTYPES = {"nk_last_error": C.c_char_p, "nk_version": C.c_char_p, "nk_stream_compute": VP, "nk_stream_comm": VP}
+EXPORTED = tuple(_SIGS)
+
+for _name, _args in _SIGS.items():
+    _fn = getattr(lib, _name)  # AttributeError here = header/library mismatch: fail loudly
+    _fn.argtypes = _args
+    _fn.restype = _RESTYPES.get(_name, C.c_int)
+
+ADD, SUB, MUL, DIV = 0, 1, 2, 3
+OPS = {"add": ADD, "sub": SUB, "mul": MUL, "div": DIV}
+REDUCTION = {"sum": 0, "mean": 1}
+COMM_ID_BYTES = 128
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise NeuronikaHipError(rc, lib.nk_last_error().decode())
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    check(lib.nk_device_count(C.byref(n)))
+    return n.value
+
+
+def ints(v: Sequence[int]):
+    return (C.c_int * max(1, len(v)))(*[int(i) for i in v])
+
+
+class Event:
+    def __init__(self, dev: "Device"):
+        self.dev = dev
+        h = VP()
+        check(lib.nk_event_create(dev.h, C.byref(h)))
+        self.h = h
+
+    def record(self, comm_stream: bool = False):
+        check(lib.nk_event_record(self.h, 1 if comm_stream else 0))
+        return self
+
+    def sync(self):
+        check(lib.nk_event_sync(self.h))
+
+    def elapsed_ms(self, stop: "Event") -> float:
+        ms = C.c_float(0)
+        check(lib.nk_event_elapsed_ms(self.h, stop.h, C.byref(ms)))
+        return ms.value
+
+    def __del__(self):
+        try:
+            lib.nk_event_destroy(self.h)
+        except Exception:
+            pass
+
+
+class Device:
+    """`Device::new(idx)` (cuda/device.rs:34-58): one GPU, its compute + communication streams."""
+
+    def __init__(self, idx: int = 0):
+        h = VP()
+        check(lib.nk_device_create(idx, C.byref(h)))
+        self.h = h
+        self.idx = idx
+
+    def sync(self):
+        check(lib.nk_device_sync(self.h))
+
+    def event(self) -> Event:
+        return Event(self)
+
+    # ---- arrays
+    def zeros(self, shape) -> "HipArray":
+        return HipArray(self, shape)
+
+    def array(self, a) -> "HipArray":
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        out = HipArray(self, a.shape)
+        out.upload(a)
+        return out
+
+    def full(self, shape, value: float) -> "HipArray":
+        out = HipArray(self, shape)
+        out.fill(value)
+        return out
+
+    def close(self):
+        if self.h:
+            lib.nk_device_destroy(self.h)
+            self.h = None
+
+
+class HipArray:
+    """Device twin of `ndarray::Array<f32, D>` — `CuArray<f32, D>` in the reference's template
+    (cuda/cuarray.rs:10-19): owns one zero-initialised device buffer + its shape; frees on drop."""
+
+    def __init__(self, dev: Device, shape):
+        if isinstance(shape, (int, np.integer)):
+            shape = (int(shape),)
+        self.dev = dev
+        self.shape = tuple(int(s) for s in shape)
+        self.size = int(np.prod(self.shape, dtype=np.int64)) if len(self.shape) else 1
+        p = VP()
+        check(lib.nk_alloc_zeroed(dev.h, self.size, C.byref(p)))
+        self.p = p
+
+    @property
+    def ndim(self):
+        return len(self.shape)
+
+    def upload(self, a: np.ndarray):
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        assert a.size == self.size, (a.shape, self.shape)
+        check(lib.nk_upload(self.dev.h, self.p, a.ctypes.data_as(VP), self.size))
+        return self
+
+    def numpy(self) -> np.ndarray:
+        out = np.empty(self.shape, dtype=np.float32)
+        check(lib.nk_download(self.dev.h, out.ctypes.data_as(VP), self.p, self.size))
+        return out
+
+    def item(self) -> float:
+        return float(self.numpy().reshape(-1)[0])
+
+    def fill(self, v: float):
+        check(lib.nk_fill(self.dev.h, self.p, self.size, float(v)))
+        return self
+
+    def shape_c(self):
+        return ints(self.shape)
+
+    def __del__(self):
+        try:
+            if self.p and self.dev.h:
+                lib.nk_free(self.dev.h, self.p)
+        except Exception:
+            pass
+
+
+# ------------------------------------------------------------------------------------------------
+# thin per-entry-point wrappers (argument order = C ABI order)
+# ------------------------------------------------------------------------------------------------
+
+def sgemm(dev, ta, tb, M, N, K, alpha, A, lda, B, ldb, beta, Cm, ldc):
+    check(lib.nk_sgemm(dev.h, int(ta), int(tb), M, N, K, alpha, A.p, lda, B.p, ldb, beta, Cm.p, ldc))
+
+
+def sgemm_batched(dev, ta, tb, M, N, K, alpha, A, lda, sAo, sAi, B, ldb, sBo, sBi, beta, Cm, ldc, sCo, sCi, bo, bi):
+    check(lib.nk_sgemm_batched(dev.h, int(ta), int(tb), M, N, K, alpha, A.p, lda, sAo, sAi, B.p, ldb, sBo, sBi,
+                               beta, Cm.p, ldc, sCo, sCi, bo, bi))
+
+
+def mm_fwd(dev, A, B, out):
+    n, m = A.shape; o = B.shape[1]
+    check(lib.nk_mm_fwd(dev.h, A.p, B.p, out.p, n, m, o))
+
+
+def mm_bwd_left(dev, dA, G, B):
+    n, o = G.shape; m = B.shape[0]
+    check(lib.nk_mm_bwd_left(dev.h, dA.p, G.p, B.p, n, m, o))
+
+
+def mm_bwd_right(dev, dB, A, G):
+    n, m = A.shape; o = G.shape[1]
+    check(lib.nk_mm_bwd_right(dev.h, dB.p, A.p, G.p, n, m, o))
+
+
+def mm_t_fwd(dev, A, B, out):
+    n, m = A.shape; o = B.shape[0]
+    check(lib.nk_mm_t_fwd(dev.h, A.p, B.p, out.p, n, m, o))
+
+
+def mm_t_bwd_left(dev, dA, G, B):
+    n, o = G.shape; m = B.shape[1]
+    check(lib.nk_mm_t_bwd_left(dev.h, dA.p, G.p, B.p, n, m, o))
+
+
+def mm_t_bwd_right(dev, dB, G, A):
+    n, o = G.shape; m = A.shape[1]
+    check(lib.nk_mm_t_bwd_right(dev.h, dB.p, G.p, A.p, n, m, o))
+
+
+def conv_fwd(dev, x, w, y, stride, dilation, groups=1):
+    nd = x.ndim - 2
+    check(lib.nk_conv_fwd(dev.h, nd, x.p, x.shape_c(), w.p, w.shape_c(), y.p, ints(stride), ints(dilation), groups))
+
+
+def conv_bwd_input(dev, dx, g, w, stride, dilation, groups=1):
+    nd = dx.ndim - 2
+    check(lib.nk_conv_bwd_input(dev.h, nd, dx.p, dx.shape_c(), g.p, w.p, w.shape_c(), ints(stride), ints(dilation), groups))
+
+
+def conv_bwd_kernel(dev, dw, g, x, stride, dilation, groups=1):
+    nd = x.ndim - 2
+    check(lib.nk_conv_bwd_kernel(dev.h, nd, dw.p, dw.shape_c(), g.p, x.p, x.shape_c(), ints(stride), ints(dilation), groups))
+
+
+def pad_const_fwd(dev, x, y, padding, value=0.0):
+    check(lib.nk_pad_const_fwd(dev.h, x.ndim - 2, x.p, x.shape_c(), y.p, ints(padding), float(value)))
+
+
+def pad_bwd(dev, dx, g, padding):
+    check(lib.nk_pad_bwd(dev.h, dx.ndim - 2, dx.p, dx.shape_c(), g.p, ints(padding)))
+
+
+def binary_fwd(dev, op, out, l, r):
+    check(lib.nk_binary_fwd(dev.h, OPS[op], out.p, out.shape_c(), out.ndim, l.p, l.shape_c(), l.ndim, r.p, r.shape_c(), r.ndim))
+
+
+def binary_bwd_left(dev, op, d_left, g, r=None):
+    rp, rs, rn = (r.p, r.shape_c(), r.ndim) if r is not None else (None, ints([]), 0)
+    check(lib.nk_binary_bwd_left(dev.h, OPS[op], d_left.p, d_left.shape_c(), d_left.ndim, g.p, g.shape_c(), g.ndim, rp, rs, rn))
+
+
+def binary_bwd_right(dev, op, d_right, g, l=None, r=None):
+    lp, ls, ln = (l.p, l.shape_c(), l.ndim) if l is not None else (None, ints([]), 0)
+    check(lib.nk_binary_bwd_right(dev.h, OPS[op], d_right.p, d_right.shape_c(), d_right.ndim, g.p, g.shape_c(), g.ndim,
+                                  lp, ls, ln, r.p if r is not None else None))
+
+
+def unbroadcast_add(dev, dst, src):
+    check(lib.nk_unbroadcast_add(dev.h, dst.p, dst.shape_c(), dst.ndim, src.p, src.shape_c(), src.ndim))
+
+
+def relu_fwd(dev, x, y):
+    check(lib.nk_relu_fwd(dev.h, x.p, y.p, x.size))
+
+
+def relu_bwd(dev, dx, g, x):
+    check(lib.nk_relu_bwd(dev.h, dx.p, g.p, x.p, x.size))
+
+
+def sum_fwd(dev, x, out):
+    check(lib.nk_sum_fwd(dev.h, x.p, x.size, out.p))
+
+
+def sum_bwd(dev, dx, g):
+    check(lib.nk_sum_bwd(dev.h, dx.p, dx.size, g.p))
+
+
+def mean_fwd(dev, x, out):
+    check(lib.nk_mean_fwd(dev.h, x.p, x.size, out.p))
+
+
+def mean_bwd(dev, dx, g):
+    check(lib.nk_mean_bwd(dev.h, dx.p, dx.size, g.p))
+
+
+def mse_fwd(dev, x, t, out, reduction="mean"):
+    check(lib.nk_mse_fwd(dev.h, x.p, t.p, x.size, REDUCTION[reduction], out.p))
+
+
+def mse_bwd(dev, dx, g, x, t, reduction="mean"):
+    check(lib.nk_mse_bwd(dev.h, dx.p, g.p, x.p, t.p, x.size, REDUCTION[reduction]))
+
+
+def softmax_fwd(dev, x, y, axis):
+    check(lib.nk_softmax_fwd(dev.h, x.p, y.p, x.shape_c(), x.ndim, axis))
+
+
+def softmax_bwd(dev, dx, g, y, axis):
+    check(lib.nk_softmax_bwd(dev.h, dx.p, g.p, y.p, y.shape_c(), y.ndim, axis))
+
+
+def log_softmax_fwd(dev, x, y, axis):
+    check(lib.nk_log_softmax_fwd(dev.h, x.p, y.p, x.shape_c(), x.ndim, axis))
+
+
+def log_softmax_bwd(dev, dx, g, y, axis):
+    check(lib.nk_log_softmax_bwd(dev.h, dx.p, g.p, y.p, y.shape_c(), y.ndim, axis))
+
+
+def dropout_fwd(dev, x, y, noise, p, train=True, seed=0, offset=0):
+    check(lib.nk_dropout_fwd(dev.h, x.p, y.p, noise.p if noise is not None else None, x.size, float(p), int(train), seed, offset))
+
+
+def dropout_bwd(dev, dx, g, noise, p, train=True):
+    check(lib.nk_dropout_bwd(dev.h, dx.p, g.p, noise.p if noise is not None else None, dx.size, float(p), int(train)))
+
+
+def chunk_fwd(dev, x, y, chunk_no):
+    check(lib.nk_chunk_fwd(dev.h, x.p, x.shape_c(), y.p, y.shape_c(), x.ndim, chunk_no))
+
+
+def chunk_bwd(dev, dx, g, chunk_no):
+    check(lib.nk_chunk_bwd(dev.h, dx.p, dx.shape_c(), g.p, g.shape_c(), dx.ndim, chunk_no))
+
+
+def concat_fwd(dev, operands, out, axis):
+    off = 0
+    for o in operands:
+        check(lib.nk_concat_fwd_part(dev.h, o.p, out.p, out.shape_c(), out.ndim, axis, off, o.shape[axis]))
+        off += o.shape[axis]
+
+
+def concat_bwd(dev, d_operands, g, axis):
+    off = 0
+    for d in d_operands:
+        check(lib.nk_concat_bwd_part(dev.h, d.p, g.p, g.shape_c(), g.ndim, axis, off, d.shape[axis]))
+        off += d.shape[axis]
+
+
+def transpose_fwd(dev, x, y):
+    check(lib.nk_transpose_fwd(dev.h, x.p, y.p, x.shape_c(), x.ndim))
+
+
+def transpose_bwd(dev, dx, g):
+    check(lib.nk_transpose_bwd(dev.h, dx.p, g.p, dx.shape_c(), dx.ndim))
+
+
+def split_heads_fwd(dev, x, y, B, S, H, dh):
+    check(lib.nk_split_heads_fwd(dev.h, x.p, y.p, B, S, H, dh))
+
+
+def split_heads_bwd(dev, dx, g, B, S, H, dh):
+    check(lib.nk_split_heads_bwd(dev.h, dx.p, g.p, B, S, H, dh))
+
+
+def merge_heads_fwd(dev, x, y, B, S, H, dh):
+    check(lib.nk_merge_heads_fwd(dev.h, x.p, y.p, B, S, H, dh))
+
+
+def merge_heads_bwd(dev, dx, g, B, S, H, dh):
+    check(lib.nk_merge_heads_bwd(dev.h, dx.p, g.p, B, S, H, dh))
+
+
+def sgd_step(dev, w, grad, velocity=None, lr=0.01, momentum=0.0, dampening=0.0, nesterov=False, first_step=False,
+             l1=0.0, l2=0.0):
+    check(lib.nk_sgd_step(dev.h, w.p, grad.p, velocity.p if velocity is not None else None, w.size, lr, momentum,
+                          dampening, int(nesterov), int(first_step), l1, l2))
+
+
+class Comm:
+    """One rank of the RCCL communicator (net-new; no reference counterpart)."""
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = C.create_string_buffer(COMM_ID_BYTES)
+        check(lib.nk_comm_unique_id(buf))
+        return buf.raw
+
+    def __init__(self, dev: Device, nranks: int, rank: int, uid: bytes):
+        assert len(uid) == COMM_ID_BYTES
+        h = VP()
+        check(lib.nk_comm_init_rank(dev.h, nranks, rank, uid, C.byref(h)))
+        self.h, self.dev, self.rank, self.size = h, dev, rank, nranks
+
+    def allreduce_sum_async(self, buf: HipArray, after: Event | None = None, n: int | None = None):
+        check(lib.nk_allreduce_sum_async(self.h, buf.p, buf.size if n is None else n, after.h if after else None))
+
+    def join(self):
+        check(lib.nk_comm_join(self.h))
+
+    def close(self):
+        if self.h:
+            lib.nk_comm_destroy(self.h)
+            self.h = None

@@ -1,0 +1,89 @@
+// Data-parallel gradient exchange: RCCL sum all-reduce on the device's SIDE stream, ordered
+// after a compute-stream event, joined back without a host sync.  Net-new: the reference has no
+// communication backend; the insertion point is between `VarDiff::backward`
+// (neuronika-variable/src/vardiff.rs:125-141) and `Optimizer::step`
+// (neuronika-optim/src/optimizer.rs:81-86); the message is the leaf gradient buffers of the
+// parameters registered with the optimizer (optimizer.rs:70-77).
+#include <rccl/rccl.h>
+
+#include "nk_common.h"
+
+struct nk_comm {
+    nk_device* dev;
+    ncclComm_t comm;
+    int rank, size;
+};
+
+static int fail_rccl(ncclResult_t r, const char* what) {
+    nk_set_error("RCCL error %d (%s) in `%s`", (int)r, ncclGetErrorString(r), what);
+    return NK_ERR_RCCL;
+}
+#define NK_RCCL(call)                                        \
+    do {                                                     \
+        ncclResult_t _r = (call);                            \
+        if (_r != ncclSuccess) return fail_rccl(_r, #call);  \
+    } while (0)
+
+static_assert(sizeof(ncclUniqueId) == NK_COMM_ID_BYTES, "unique id size");
+
+extern "C" {
+
+int nk_comm_unique_id(char id[NK_COMM_ID_BYTES]) {
+    NK_CHECK(id != nullptr, "null id");
+    ncclUniqueId u;
+    NK_RCCL(ncclGetUniqueId(&u));
+    memcpy(id, &u, NK_COMM_ID_BYTES);
+    return NK_OK;
+}
+
+int nk_comm_init_rank(nk_device* dev, int nranks, int rank, const char id[NK_COMM_ID_BYTES], nk_comm** out) {
+    NK_USE(dev);
+    NK_CHECK(out && id, "null argument");
+    NK_CHECK(nranks >= 1 && rank >= 0 && rank < nranks, "bad rank %d / %d", rank, nranks);
+    ncclUniqueId u;
+    memcpy(&u, id, NK_COMM_ID_BYTES);
+    nk_comm* c = new nk_comm{dev, nullptr, rank, nranks};
+    ncclResult_t r = ncclCommInitRank(&c->comm, nranks, u, rank);
+    if (r != ncclSuccess) { delete c; return fail_rccl(r, "ncclCommInitRank"); }
+    *out = c;
+    return NK_OK;
+}
+
+int nk_comm_destroy(nk_comm* comm) {
+    if (!comm) return NK_OK;
+    (void)hipSetDevice(comm->dev->idx);
+    (void)hipStreamSynchronize(comm->dev->comm);
+    (void)ncclCommDestroy(comm->comm);
+    delete comm;
+    return NK_OK;
+}
+
+int nk_allreduce_sum_async(nk_comm* comm, float* buf, size_t n, nk_event* after) {
+    NK_CHECK(comm != nullptr, "null communicator");
+    nk_device* dev = comm->dev;
+    NK_USE(dev);
+    if (n == 0) return NK_OK;
+    NK_CHECK(buf != nullptr, "null buffer");
+    if (after) {
+        NK_HIP(hipStreamWaitEvent(dev->comm, after->ev, 0));
+    } else {
+        NK_HIP(hipEventRecord(dev->fork, dev->compute));
+        NK_HIP(hipStreamWaitEvent(dev->comm, dev->fork, 0));
+    }
+    NK_RCCL(ncclAllReduce(buf, buf, n, ncclFloat32, ncclSum, comm->comm, dev->comm));
+    return NK_OK;
+}
+
+int nk_comm_join(nk_comm* comm) {
+    NK_CHECK(comm != nullptr, "null communicator");
+    nk_device* dev = comm->dev;
+    NK_USE(dev);
+    NK_HIP(hipEventRecord(dev->join, dev->comm));
+    NK_HIP(hipStreamWaitEvent(dev->compute, dev->join, 0));
+    return NK_OK;
+}
+
+int nk_comm_rank(const nk_comm* comm) { return comm ? comm->rank : -1; }
+int nk_comm_size(const nk_comm* comm) { return comm ? comm->size : 0; }
+
+}  // extern "C"

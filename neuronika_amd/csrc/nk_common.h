@@ -1,0 +1,107 @@
+// Internal definitions shared by the HIP translation units of libneuronika_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "neuronika_hip.h"
+
+struct nk_device {
+    int idx = 0;
+    hipStream_t compute = nullptr;  // tape-ordered kernels
+    hipStream_t comm = nullptr;     // RCCL all-reduce (side stream)
+    hipEvent_t fork = nullptr;      // compute -> comm ordering helper
+    hipEvent_t join = nullptr;      // comm -> compute ordering helper
+    void* workspace = nullptr;      // stream-ordered scratch (split-K slabs, reduction partials)
+    size_t workspace_bytes = 0;
+    int num_cus = 256;
+};
+
+struct nk_event {
+    nk_device* dev;
+    hipEvent_t ev;
+};
+
+void nk_set_error(const char* fmt, ...);
+int nk_fail_hip(hipError_t e, const char* what, const char* file, int line);
+// Stream-ordered scratch of at least `bytes` (grown by realloc when too small; the old block
+// is released after a device sync, so kernels already enqueued keep a valid pointer).
+int nk_workspace(nk_device* dev, size_t bytes, void** out);
+
+#define NK_HIP(call)                                                         \
+    do {                                                                     \
+        hipError_t _e = (call);                                              \
+        if (_e != hipSuccess) return nk_fail_hip(_e, #call, __FILE__, __LINE__); \
+    } while (0)
+
+#define NK_CHECK(cond, ...)              \
+    do {                                 \
+        if (!(cond)) {                   \
+            nk_set_error(__VA_ARGS__);   \
+            return NK_ERR_INVALID;       \
+        }                                \
+    } while (0)
+
+#define NK_USE(dev)                                        \
+    do {                                                   \
+        NK_CHECK((dev) != nullptr, "null device handle");  \
+        NK_HIP(hipSetDevice((dev)->idx));                  \
+    } while (0)
+
+#define NK_LAUNCH_CHECK() NK_HIP(hipGetLastError())
+
+static inline size_t nk_numel(const int* shape, int nd) {
+    size_t n = 1;
+    for (int i = 0; i < nd; ++i) n *= (size_t)shape[i];
+    return n;
+}
+
+// Grid for HBM-bound grid-stride kernels: enough blocks to fill 256 CUs x 8, capped
+// (cdna_hip_programming.md Guideline 11).
+static inline int nk_stream_grid(size_t work_items, int block) {
+    size_t b = (work_items + block - 1) / block;
+    if (b < 1) b = 1;
+    if (b > 2048) b = 2048;
+    return (int)b;
+}
+
+constexpr int NK_WAVE = 64;
+
+__device__ __forceinline__ float nk_wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ float nk_wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+// Block-wide sum for blocks of NT threads (NT multiple of 64, <= 1024); result in all threads.
+template <int NT>
+__device__ __forceinline__ float nk_block_sum(float v, float* smem /* NT/64 floats */) {
+    v = nk_wave_sum(v);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) smem[wid] = v;
+    __syncthreads();
+    float r = 0.f;
+#pragma unroll
+    for (int i = 0; i < NT / 64; ++i) r += smem[i];
+    return r;
+}
+template <int NT>
+__device__ __forceinline__ float nk_block_max(float v, float* smem) {
+    v = nk_wave_max(v);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) smem[wid] = v;
+    __syncthreads();
+    float r = smem[0];
+#pragma unroll
+    for (int i = 1; i < NT / 64; ++i) r = fmaxf(r, smem[i]);
+    return r;
+}

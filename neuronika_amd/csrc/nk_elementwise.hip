@@ -1,0 +1,573 @@
+// HBM-bound elementwise kernels of the hot path (bound: 8 TB/s HBM3E; every kernel moves
+// 16 B per lane per access, grid-stride, no LDS):
+//   broadcast binaries fwd  — node/{addition,subtraction,multiplication,division}/mod.rs:39-50
+//   their backward          — local gradient fused with the un-broadcast reduction
+//                             (`utils::accumulate`, utils.rs:152-192, intended semantics)
+//   ReLU fwd/bwd            — node/relu/mod.rs:29-38, 67-79
+//   fill / SGD step         — vardiff.rs:100-102,133 ; neuronika-optim/src/sgd/mod.rs:186-236
+#include "nk_common.h"
+
+namespace {
+
+// Broadcast descriptor: the output index space, right-aligned and collapsed, with the element
+// stride of each operand along every collapsed dim (0 where the operand is broadcast).
+struct Bcast {
+    int nd;
+    int shape[NK_MAX_DIMS];
+    long long ls[NK_MAX_DIMS];
+    long long rs[NK_MAX_DIMS];
+};
+
+// strides of `shape` (nd dims, right-aligned into out_nd dims) in the out index space
+void bstrides(const int* shape, int nd, const int* out_shape, int out_nd, long long* st) {
+    (void)out_shape;
+    long long acc = 1;
+    for (int i = out_nd - 1; i >= 0; --i) {
+        const int j = i - (out_nd - nd);
+        if (j < 0) { st[i] = 0; continue; }
+        st[i] = shape[j] == 1 ? 0 : acc;  // extent-1 (broadcast) axes never advance
+        acc *= shape[j];
+    }
+}
+
+int check_bcast(const int* out_shape, int out_nd, const int* s, int nd, const char* who) {
+    NK_CHECK(nd <= out_nd && out_nd <= NK_MAX_DIMS, "%s: rank %d > output rank %d (max %d)", who, nd, out_nd, NK_MAX_DIMS);
+    for (int j = 0; j < nd; ++j) {
+        const int o = out_shape[j + out_nd - nd];
+        NK_CHECK(s[j] == o || s[j] == 1, "The two tensors have incompatible shape. (%s axis %d: %d vs %d)", who, j, s[j], o);
+    }
+    return NK_OK;
+}
+
+// Collapse adjacent dims that are mergeable for every stride vector in `sts` (nvec vectors).
+int collapse(const int* shape, int nd, long long** sts, int nvec, int* oshape) {
+    int m = 0;
+    for (int i = 0; i < nd; ++i) {
+        if (shape[i] == 1) continue;  // drop unit dims
+        bool merged = false;
+        if (m > 0) {
+            bool ok = true;
+            for (int v = 0; v < nvec; ++v) {
+                const long long prev = sts[v][m - 1], cur = sts[v][i];
+                if (!((prev == 0 && cur == 0) || (cur != 0 && prev == cur * shape[i]))) ok = false;
+            }
+            if (ok) {
+                oshape[m - 1] *= shape[i];
+                for (int v = 0; v < nvec; ++v) sts[v][m - 1] = sts[v][i];
+                merged = true;
+            }
+        }
+        if (!merged) {
+            oshape[m] = shape[i];
+            for (int v = 0; v < nvec; ++v) sts[v][m] = sts[v][i];
+            ++m;
+        }
+    }
+    if (m == 0) {
+        oshape[0] = 1;
+        for (int v = 0; v < nvec; ++v) sts[v][0] = 0;
+        m = 1;
+    }
+    return m;
+}
+
+template <int OP>
+__device__ __forceinline__ float bin(float l, float r) {
+    return OP == NK_ADD ? l + r : OP == NK_SUB ? l - r : OP == NK_MUL ? l * r : l / r;
+}
+
+__device__ __forceinline__ float4 ld4(const float* p, long long off, long long inner_stride) {
+    if (inner_stride == 1) return *reinterpret_cast<const float4*>(p + off);
+    const float v = p[off];
+    return make_float4(v, v, v, v);
+}
+
+// out[i] = l (op) r over the collapsed index space; 4 consecutive inner elements per thread
+// when VEC (inner extent % 4 == 0, operands' inner strides in {0,1}, 16-B aligned).
+template <int OP, bool VEC>
+__global__ void binary_fwd_kernel(float* __restrict__ out, const float* __restrict__ l,
+                                  const float* __restrict__ r, Bcast b, long long total) {
+    constexpr int W = VEC ? 4 : 1;
+    const long long groups = total / W;
+    for (long long g = blockIdx.x * (long long)blockDim.x + threadIdx.x; g < groups;
+         g += (long long)gridDim.x * blockDim.x) {
+        long long rem = g * W, lo = 0, ro = 0;
+#pragma unroll 1
+        for (int d = b.nd - 1; d >= 0; --d) {
+            const long long c = rem % b.shape[d];
+            rem /= b.shape[d];
+            lo += c * b.ls[d];
+            ro += c * b.rs[d];
+        }
+        if (VEC) {
+            const float4 a = ld4(l, lo, b.ls[b.nd - 1]), c = ld4(r, ro, b.rs[b.nd - 1]);
+            float4 o;
+            o.x = bin<OP>(a.x, c.x); o.y = bin<OP>(a.y, c.y); o.z = bin<OP>(a.z, c.z); o.w = bin<OP>(a.w, c.w);
+            *reinterpret_cast<float4*>(out + g * 4) = o;
+        } else {
+            out[g] = bin<OP>(l[lo], r[ro]);
+        }
+    }
+}
+
+// ---- backward: local gradient -------------------------------------------------------------
+// MODE 0: g        (add left/right, sub left)
+// MODE 1: -g       (sub right)
+// MODE 2: g * o    (mul left: o = r ; mul right: o = l)
+// MODE 3: g / o    (div left: o = r)
+// MODE 4: -g*l/r^2 (div right: o = l, q = r)
+template <int MODE>
+__device__ __forceinline__ float local_grad(float g, float o, float q) {
+    return MODE == 0 ? g : MODE == 1 ? -g : MODE == 2 ? g * o : MODE == 3 ? g / o : -g * o / (q * q);
+}
+
+// No reduction needed (operand shape == gradient shape): d += local, 16 B per lane.
+// o / q follow their own (collapsed) broadcast strides.
+struct Bcast3 {
+    int nd;
+    int shape[NK_MAX_DIMS];
+    long long os[NK_MAX_DIMS];
+    long long qs[NK_MAX_DIMS];
+};
+
+template <int MODE, bool VEC>
+__global__ void binary_bwd_same_kernel(float* __restrict__ d, const float* __restrict__ g,
+                                       const float* __restrict__ o, const float* __restrict__ q,
+                                       Bcast3 b, long long total) {
+    constexpr int W = VEC ? 4 : 1;
+    const long long groups = total / W;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < groups;
+         i += (long long)gridDim.x * blockDim.x) {
+        long long oo = 0, qo = 0;
+        if (MODE >= 2) {
+            long long rem = i * W;
+#pragma unroll 1
+            for (int k = b.nd - 1; k >= 0; --k) {
+                const long long c = rem % b.shape[k];
+                rem /= b.shape[k];
+                oo += c * b.os[k];
+                qo += c * b.qs[k];
+            }
+        }
+        if (VEC) {
+            const float4 gv = *reinterpret_cast<const float4*>(g + i * 4);
+            float4 dv = *reinterpret_cast<float4*>(d + i * 4);
+            float4 ov = make_float4(0, 0, 0, 0), qv = make_float4(1, 1, 1, 1);
+            if (MODE >= 2) ov = ld4(o, oo, b.os[b.nd - 1]);
+            if (MODE == 4) qv = ld4(q, qo, b.qs[b.nd - 1]);
+            dv.x += local_grad<MODE>(gv.x, ov.x, qv.x);
+            dv.y += local_grad<MODE>(gv.y, ov.y, qv.y);
+            dv.z += local_grad<MODE>(gv.z, ov.z, qv.z);
+            dv.w += local_grad<MODE>(gv.w, ov.w, qv.w);
+            *reinterpret_cast<float4*>(d + i * 4) = dv;
+        } else {
+            d[i] += local_grad<MODE>(g[i], MODE >= 2 ? o[oo] : 0.f, MODE == 4 ? q[qo] : 1.f);
+        }
+    }
+}
+
+// Reduction over an index space viewed as [R0][K][R1]: part[chunk][k] = sum over the chunk's
+// r0 rows and all r1 of local(r0,k,r1).  g is contiguous; o/q have strides (s0,sk,s1).
+struct Rkr {
+    int R0, K, R1;
+    long long os0, osk, os1, qs0, qsk, qs1;
+    int rows_per_chunk;
+    int vec;  // float4 path allowed (R1 % 4 == 0, 16-B aligned bases, unit/zero inner strides)
+};
+
+// R1 == 1: column reduction.  Threads along k (coalesced 256-B rows per wave); blockIdx.y
+// splits R0.  Deterministic: fixed chunking, fixed order.
+template <int MODE>
+__global__ void reduce_cols_kernel(float* __restrict__ part, const float* __restrict__ g,
+                                   const float* __restrict__ o, const float* __restrict__ q, Rkr p) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= p.K) return;
+    const int r_beg = blockIdx.y * p.rows_per_chunk;
+    const int r_end = min(p.R0, r_beg + p.rows_per_chunk);
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+    int r = r_beg;
+    for (; r + 3 < r_end; r += 4) {
+#define NK_TERM(RR) local_grad<MODE>(g[(long long)(RR) * p.K + k], MODE >= 2 ? o[(RR) * p.os0 + k * p.osk] : 0.f, \
+                                     MODE == 4 ? q[(RR) * p.qs0 + k * p.qsk] : 1.f)
+        acc0 += NK_TERM(r);
+        acc1 += NK_TERM(r + 1);
+        acc2 += NK_TERM(r + 2);
+        acc3 += NK_TERM(r + 3);
+    }
+    for (; r < r_end; ++r) acc0 += NK_TERM(r);
+#undef NK_TERM
+    part[(long long)blockIdx.y * p.K + k] = (acc0 + acc1) + (acc2 + acc3);
+}
+
+// R1 > 1: one block per (k, chunk); threads stride over (r0 in chunk) x r1 with r1 contiguous.
+template <int MODE>
+__global__ void reduce_rkr_kernel(float* __restrict__ part, const float* __restrict__ g,
+                                  const float* __restrict__ o, const float* __restrict__ q, Rkr p) {
+    __shared__ float red[4];
+    const int k = blockIdx.x;
+    const int r_beg = blockIdx.y * p.rows_per_chunk;
+    const int r_end = min(p.R0, r_beg + p.rows_per_chunk);
+    float acc = 0.f;
+    const bool vec = p.vec != 0;
+    for (int r = r_beg; r < r_end; ++r) {
+        const float* gp = g + ((long long)r * p.K + k) * p.R1;
+        const long long ob = r * p.os0 + k * p.osk, qb = r * p.qs0 + k * p.qsk;
+        if (vec) {
+            for (int c = threadIdx.x * 4; c < p.R1; c += blockDim.x * 4) {
+                const float4 gv = *reinterpret_cast<const float4*>(gp + c);
+                float4 ov = make_float4(0, 0, 0, 0), qv = make_float4(1, 1, 1, 1);
+                if (MODE >= 2) ov = ld4(o, ob + c * p.os1, p.os1);
+                if (MODE == 4) qv = ld4(q, qb + c * p.qs1, p.qs1);
+                acc += (local_grad<MODE>(gv.x, ov.x, qv.x) + local_grad<MODE>(gv.y, ov.y, qv.y)) +
+                       (local_grad<MODE>(gv.z, ov.z, qv.z) + local_grad<MODE>(gv.w, ov.w, qv.w));
+            }
+        } else {
+            for (int c = threadIdx.x; c < p.R1; c += blockDim.x)
+                acc += local_grad<MODE>(gp[c], MODE >= 2 ? o[ob + c * p.os1] : 0.f,
+                                        MODE == 4 ? q[qb + c * p.qs1] : 1.f);
+        }
+    }
+    acc = nk_block_sum<256>(acc, red);
+    if (threadIdx.x == 0) part[(long long)blockIdx.y * p.K + k] = acc;
+}
+
+__global__ void reduce_finish_kernel(float* __restrict__ d, const float* __restrict__ part, int K, int chunks) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    float s = 0.f;
+    for (int c = 0; c < chunks; ++c) s += part[(long long)c * K + k];
+    d[k] += s;
+}
+
+// Fallback for reduction patterns with more than three collapsed groups: one thread per kept
+// element, sequential over the reduced index space.  Correct for any broadcast; slow.
+struct Gen {
+    int nd;
+    int shape[NK_MAX_DIMS];
+    long long ds[NK_MAX_DIMS];  // target strides (0 on reduced dims)
+    long long os[NK_MAX_DIMS];
+    long long qs[NK_MAX_DIMS];
+    long long gs[NK_MAX_DIMS];
+};
+template <int MODE>
+__global__ void reduce_generic_kernel(float* __restrict__ d, const float* __restrict__ g,
+                                      const float* __restrict__ o, const float* __restrict__ q, Gen p,
+                                      long long kept, long long reduced) {
+    for (long long ki = blockIdx.x * (long long)blockDim.x + threadIdx.x; ki < kept;
+         ki += (long long)gridDim.x * blockDim.x) {
+        // decode kept coordinate
+        long long rem = ki, dofs = 0, gofs = 0, oofs = 0, qofs = 0;
+        for (int a = p.nd - 1; a >= 0; --a) {
+            if (p.ds[a] == 0) continue;
+            const long long c = rem % p.shape[a];
+            rem /= p.shape[a];
+            dofs += c * p.ds[a]; gofs += c * p.gs[a]; oofs += c * p.os[a]; qofs += c * p.qs[a];
+        }
+        float acc = 0.f;
+        for (long long ri = 0; ri < reduced; ++ri) {
+            long long rr = ri, go = gofs, oo = oofs, qo = qofs;
+            for (int a = p.nd - 1; a >= 0; --a) {
+                if (p.ds[a] != 0) continue;
+                const long long c = rr % p.shape[a];
+                rr /= p.shape[a];
+                go += c * p.gs[a]; oo += c * p.os[a]; qo += c * p.qs[a];
+            }
+            acc += local_grad<MODE>(g[go], MODE >= 2 ? o[oo] : 0.f, MODE == 4 ? q[qo] : 1.f);
+        }
+        d[dofs] += acc;
+    }
+}
+
+bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// d_target(t_shape) += unbroadcast( local<MODE>(g, o, q) ) over g_shape.
+template <int MODE>
+int bwd_dispatch(nk_device* dev, float* d, const int* t_shape, int t_nd, const float* g, const int* g_shape,
+                 int g_nd, const float* o, const int* o_shape, int o_nd, const float* q, const int* q_shape,
+                 int q_nd) {
+    NK_USE(dev);
+    NK_CHECK(d && g, "null gradient pointer");
+    int rc = check_bcast(g_shape, g_nd, t_shape, t_nd, "target");
+    if (rc) return rc;
+    if (MODE >= 2) { NK_CHECK(o, "operand data required"); rc = check_bcast(g_shape, g_nd, o_shape, o_nd, "operand"); if (rc) return rc; }
+    if (MODE == 4) { NK_CHECK(q, "operand data required"); rc = check_bcast(g_shape, g_nd, q_shape, q_nd, "operand"); if (rc) return rc; }
+    const long long total = (long long)nk_numel(g_shape, g_nd);
+    if (total == 0) return NK_OK;
+
+    long long ts[NK_MAX_DIMS], os[NK_MAX_DIMS] = {0}, qs[NK_MAX_DIMS] = {0}, gs[NK_MAX_DIMS];
+    bstrides(t_shape, t_nd, g_shape, g_nd, ts);
+    bstrides(g_shape, g_nd, g_shape, g_nd, gs);
+    if (MODE >= 2) bstrides(o_shape, o_nd, g_shape, g_nd, os);
+    if (MODE == 4) bstrides(q_shape, q_nd, g_shape, g_nd, qs);
+    int cshape[NK_MAX_DIMS];
+    long long* vecs[4] = {ts, os, qs, gs};
+    const int nd = collapse(g_shape, g_nd, vecs, 4, cshape);
+
+    bool any_reduced = false;
+    for (int i = 0; i < nd; ++i) if (ts[i] == 0 && cshape[i] != 1) any_reduced = true;
+
+    if (!any_reduced) {
+        Bcast3 b{};
+        b.nd = nd;
+        for (int i = 0; i < nd; ++i) { b.shape[i] = cshape[i]; b.os[i] = os[i]; b.qs[i] = qs[i]; }
+        const bool vec = (cshape[nd - 1] % 4 == 0) && al16(d) && al16(g) &&
+                         (MODE < 2 || (os[nd - 1] <= 1 && al16(o))) && (MODE != 4 || (qs[nd - 1] <= 1 && al16(q)));
+        const int grid = nk_stream_grid((size_t)(total / (vec ? 4 : 1)), 256);
+        if (vec) hipLaunchKernelGGL((binary_bwd_same_kernel<MODE, true>), dim3(grid), dim3(256), 0, dev->compute, d, g, o, q, b, total);
+        else hipLaunchKernelGGL((binary_bwd_same_kernel<MODE, false>), dim3(grid), dim3(256), 0, dev->compute, d, g, o, q, b, total);
+        NK_LAUNCH_CHECK();
+        return NK_OK;
+    }
+
+    // classify into [R0][K][R1]
+    int pat[NK_MAX_DIMS];
+    for (int i = 0; i < nd; ++i) pat[i] = ts[i] == 0 ? 0 : 1;  // 0 = reduced, 1 = kept
+    int groups = 1;
+    for (int i = 1; i < nd; ++i) if (pat[i] != pat[i - 1]) ++groups;
+    // count of kept groups
+    int kept_groups = 0;
+    for (int i = 0; i < nd; ++i) if (pat[i] == 1 && (i == 0 || pat[i - 1] == 0)) ++kept_groups;
+    const bool rkr = (nd <= 3) && kept_groups <= 1 && groups <= 3;
+    if (rkr) {
+        Rkr p{};
+        p.R0 = 1; p.K = 1; p.R1 = 1;
+        int ki = -1;
+        for (int i = 0; i < nd; ++i) if (pat[i] == 1) ki = i;
+        if (ki < 0) {  // everything reduced (scalar target): view the flat range as [R0][1][R1]
+            if (nd != 1) goto generic;  // o/q strides prevented merging into one flat range
+            long long r1 = 8192;
+            while (r1 > 1 && total % r1 != 0) r1 >>= 1;
+            if (total / r1 > 0x7fffffffLL) goto generic;
+            p.R1 = (int)r1; p.R0 = (int)(total / r1);
+            p.os1 = os[0]; p.qs1 = qs[0]; p.os0 = os[0] * r1; p.qs0 = qs[0] * r1;
+        } else {
+            if (ki > 1 || nd - 1 - ki > 1) goto generic;
+            p.K = cshape[ki]; p.osk = os[ki]; p.qsk = qs[ki];
+            if (ki == 1) { p.R0 = cshape[0]; p.os0 = os[0]; p.qs0 = qs[0]; }
+            if (ki + 1 < nd) { p.R1 = cshape[ki + 1]; p.os1 = os[ki + 1]; p.qs1 = qs[ki + 1]; }
+        }
+        // chunking of R0 so that the grid fills the chip; partials in the workspace
+        int chunks;
+        if (p.R1 == 1) {
+            const int colblocks = (p.K + 255) / 256;
+            chunks = (2048 + colblocks - 1) / colblocks;
+            if (chunks > (p.R0 + 15) / 16) chunks = (p.R0 + 15) / 16;
+        } else {
+            chunks = (1024 + p.K - 1) / p.K;
+            if (chunks > p.R0) chunks = p.R0;
+        }
+        if (chunks < 1) chunks = 1;
+        p.rows_per_chunk = (p.R0 + chunks - 1) / chunks;
+        chunks = (p.R0 + p.rows_per_chunk - 1) / p.rows_per_chunk;
+        p.vec = (p.R1 % 4 == 0) && al16(g) && (MODE < 2 || (p.os1 <= 1 && al16(o))) &&
+                (MODE != 4 || (p.qs1 <= 1 && al16(q)));
+        void* ws = nullptr;
+        rc = nk_workspace(dev, (size_t)chunks * p.K * sizeof(float), &ws);
+        if (rc) return rc;
+        float* part = (float*)ws;
+        if (p.R1 == 1)
+            hipLaunchKernelGGL((reduce_cols_kernel<MODE>), dim3((p.K + 255) / 256, chunks), dim3(256), 0, dev->compute, part, g, o, q, p);
+        else
+            hipLaunchKernelGGL((reduce_rkr_kernel<MODE>), dim3(p.K, chunks), dim3(256), 0, dev->compute, part, g, o, q, p);
+        NK_LAUNCH_CHECK();
+        hipLaunchKernelGGL(reduce_finish_kernel, dim3((p.K + 255) / 256), dim3(256), 0, dev->compute, d, part, p.K, chunks);
+        NK_LAUNCH_CHECK();
+        return NK_OK;
+    }
+generic: {
+        Gen p{};
+        p.nd = nd;
+        long long kept = 1, reduced = 1;
+        for (int i = 0; i < nd; ++i) {
+            p.shape[i] = cshape[i]; p.ds[i] = ts[i]; p.os[i] = os[i]; p.qs[i] = qs[i]; p.gs[i] = gs[i];
+            if (ts[i] == 0) reduced *= cshape[i]; else kept *= cshape[i];
+        }
+        hipLaunchKernelGGL((reduce_generic_kernel<MODE>), dim3(nk_stream_grid((size_t)kept, 64)), dim3(64), 0,
+                           dev->compute, d, g, o, q, p, kept, reduced);
+        NK_LAUNCH_CHECK();
+        return NK_OK;
+    }
+}
+
+__global__ void fill_kernel(float* __restrict__ p, size_t n, float v) {
+    const size_t n4 = n / 4;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x)
+        reinterpret_cast<float4*>(p)[i] = make_float4(v, v, v, v);
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) p[n4 * 4 + threadIdx.x] = v;
+}
+
+template <bool VEC>
+__global__ void relu_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n) {
+    if (VEC) {
+        const size_t n4 = n / 4;
+        for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+            float4 v = reinterpret_cast<const float4*>(x)[i];
+            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+            reinterpret_cast<float4*>(y)[i] = v;
+        }
+        if (blockIdx.x == 0 && threadIdx.x < (n & 3)) y[n4 * 4 + threadIdx.x] = fmaxf(x[n4 * 4 + threadIdx.x], 0.f);
+    } else {
+        for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+            y[i] = fmaxf(x[i], 0.f);
+    }
+}
+
+template <bool VEC>
+__global__ void relu_bwd_kernel(float* __restrict__ dx, const float* __restrict__ g, const float* __restrict__ x, size_t n) {
+    if (VEC) {
+        const size_t n4 = n / 4;
+        for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+            const float4 xv = reinterpret_cast<const float4*>(x)[i], gv = reinterpret_cast<const float4*>(g)[i];
+            float4 d = reinterpret_cast<float4*>(dx)[i];
+            d.x += xv.x > 0.f ? gv.x : 0.f * gv.x; d.y += xv.y > 0.f ? gv.y : 0.f * gv.y;
+            d.z += xv.z > 0.f ? gv.z : 0.f * gv.z; d.w += xv.w > 0.f ? gv.w : 0.f * gv.w;
+            reinterpret_cast<float4*>(dx)[i] = d;
+        }
+        if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+            const size_t i = n4 * 4 + threadIdx.x;
+            dx[i] += x[i] > 0.f ? g[i] : 0.f * g[i];
+        }
+    } else {
+        for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+            dx[i] += x[i] > 0.f ? g[i] : 0.f * g[i];
+    }
+}
+
+// SGDParam::optimize (sgd/mod.rs:186-236) + Penalty (penalty.rs:63-79), one pass over w/grad[/velocity]
+__global__ void sgd_kernel(float* __restrict__ w, float* __restrict__ grad, float* __restrict__ vel, size_t n,
+                           float lr, float momentum, float dampening, int nesterov, int first, float l1, float l2) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float wi = w[i], gi = grad[i];
+        if (l1 != 0.f) gi += l1 * (wi > 0.f ? 1.f : (wi < 0.f ? -1.f : 0.f));
+        if (l2 != 0.f) gi += 2.f * l2 * wi;
+        if (l1 != 0.f || l2 != 0.f) grad[i] = gi;
+        if (vel == nullptr) {
+            wi -= lr * gi;
+        } else {
+            const float v = first ? gi : vel[i] * momentum + gi * (1.f - dampening);
+            vel[i] = v;
+            wi -= nesterov ? lr * (gi + v * momentum) : lr * v;
+        }
+        w[i] = wi;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int nk_fill(nk_device* dev, float* ptr, size_t n, float value) {
+    NK_USE(dev);
+    if (n == 0) return NK_OK;
+    NK_CHECK(ptr != nullptr, "null pointer in nk_fill");
+    if (value == 0.f) {
+        NK_HIP(hipMemsetAsync(ptr, 0, n * sizeof(float), dev->compute));
+        return NK_OK;
+    }
+    NK_CHECK(al16(ptr), "nk_fill: pointer must be 16-byte aligned");
+    hipLaunchKernelGGL(fill_kernel, dim3(nk_stream_grid(n / 4 + 1, 256)), dim3(256), 0, dev->compute, ptr, n, value);
+    NK_LAUNCH_CHECK();
+    return NK_OK;
+}
+
+int nk_binary_fwd(nk_device* dev, int op, float* out, const int* out_shape, int out_nd, const float* l,
+                  const int* l_shape, int l_nd, const float* r, const int* r_shape, int r_nd) {
+    NK_USE(dev);
+    NK_CHECK(op >= NK_ADD && op <= NK_DIV, "unknown binary op %d", op);
+    NK_CHECK(out && l && r, "null operand in nk_binary_fwd");
+    int rc = check_bcast(out_shape, out_nd, l_shape, l_nd, "left");
+    if (rc) return rc;
+    rc = check_bcast(out_shape, out_nd, r_shape, r_nd, "right");
+    if (rc) return rc;
+    for (int i = 0; i < out_nd; ++i) {  // out must be exactly cobroadcast(l, r)
+        const int jl = i - (out_nd - l_nd), jr = i - (out_nd - r_nd);
+        const int dl = jl >= 0 ? l_shape[jl] : 1, dr = jr >= 0 ? r_shape[jr] : 1;
+        NK_CHECK(out_shape[i] == (dl > dr ? dl : dr), "output axis %d has extent %d, broadcast gives %d", i, out_shape[i], dl > dr ? dl : dr);
+    }
+    const long long total = (long long)nk_numel(out_shape, out_nd);
+    if (total == 0) return NK_OK;
+    Bcast b{};
+    long long ls[NK_MAX_DIMS], rs[NK_MAX_DIMS];
+    bstrides(l_shape, l_nd, out_shape, out_nd, ls);
+    bstrides(r_shape, r_nd, out_shape, out_nd, rs);
+    long long* vecs[2] = {ls, rs};
+    b.nd = collapse(out_shape, out_nd, vecs, 2, b.shape);
+    for (int i = 0; i < b.nd; ++i) { b.ls[i] = ls[i]; b.rs[i] = rs[i]; }
+    const bool vec = (b.shape[b.nd - 1] % 4 == 0) && al16(out) && al16(l) && al16(r) && b.ls[b.nd - 1] <= 1 &&
+                     b.rs[b.nd - 1] <= 1;
+    const int grid = nk_stream_grid((size_t)(total / (vec ? 4 : 1)), 256);
+#define NK_BIN_CASE(OP)                                                                                            \
+    case OP:                                                                                                       \
+        if (vec) hipLaunchKernelGGL((binary_fwd_kernel<OP, true>), dim3(grid), dim3(256), 0, dev->compute, out, l, r, b, total); \
+        else hipLaunchKernelGGL((binary_fwd_kernel<OP, false>), dim3(grid), dim3(256), 0, dev->compute, out, l, r, b, total);    \
+        break;
+    switch (op) { NK_BIN_CASE(NK_ADD) NK_BIN_CASE(NK_SUB) NK_BIN_CASE(NK_MUL) NK_BIN_CASE(NK_DIV) }
+#undef NK_BIN_CASE
+    NK_LAUNCH_CHECK();
+    return NK_OK;
+}
+
+int nk_binary_bwd_left(nk_device* dev, int op, float* d_left, const int* l_shape, int l_nd, const float* g,
+                       const int* g_shape, int g_nd, const float* r, const int* r_shape, int r_nd) {
+    switch (op) {
+        case NK_ADD:
+        case NK_SUB: return bwd_dispatch<0>(dev, d_left, l_shape, l_nd, g, g_shape, g_nd, nullptr, nullptr, 0, nullptr, nullptr, 0);
+        case NK_MUL: return bwd_dispatch<2>(dev, d_left, l_shape, l_nd, g, g_shape, g_nd, r, r_shape, r_nd, nullptr, nullptr, 0);
+        case NK_DIV: return bwd_dispatch<3>(dev, d_left, l_shape, l_nd, g, g_shape, g_nd, r, r_shape, r_nd, nullptr, nullptr, 0);
+    }
+    nk_set_error("unknown binary op %d", op);
+    return NK_ERR_INVALID;
+}
+
+int nk_binary_bwd_right(nk_device* dev, int op, float* d_right, const int* r_shape, int r_nd, const float* g,
+                        const int* g_shape, int g_nd, const float* l, const int* l_shape, int l_nd,
+                        const float* r) {
+    switch (op) {
+        case NK_ADD: return bwd_dispatch<0>(dev, d_right, r_shape, r_nd, g, g_shape, g_nd, nullptr, nullptr, 0, nullptr, nullptr, 0);
+        case NK_SUB: return bwd_dispatch<1>(dev, d_right, r_shape, r_nd, g, g_shape, g_nd, nullptr, nullptr, 0, nullptr, nullptr, 0);
+        case NK_MUL: return bwd_dispatch<2>(dev, d_right, r_shape, r_nd, g, g_shape, g_nd, l, l_shape, l_nd, nullptr, nullptr, 0);
+        case NK_DIV: return bwd_dispatch<4>(dev, d_right, r_shape, r_nd, g, g_shape, g_nd, l, l_shape, l_nd, r, r_shape, r_nd);
+    }
+    nk_set_error("unknown binary op %d", op);
+    return NK_ERR_INVALID;
+}
+
+int nk_unbroadcast_add(nk_device* dev, float* dst, const int* dst_shape, int dst_nd, const float* src,
+                       const int* src_shape, int src_nd) {
+    return bwd_dispatch<0>(dev, dst, dst_shape, dst_nd, src, src_shape, src_nd, nullptr, nullptr, 0, nullptr, nullptr, 0);
+}
+
+int nk_relu_fwd(nk_device* dev, const float* x, float* y, size_t n) {
+    NK_USE(dev);
+    if (n == 0) return NK_OK;
+    NK_CHECK(x && y, "null pointer in nk_relu_fwd");
+    const bool vec = al16(x) && al16(y);
+    if (vec) hipLaunchKernelGGL((relu_fwd_kernel<true>), dim3(nk_stream_grid(n / 4 + 1, 256)), dim3(256), 0, dev->compute, x, y, n);
+    else hipLaunchKernelGGL((relu_fwd_kernel<false>), dim3(nk_stream_grid(n, 256)), dim3(256), 0, dev->compute, x, y, n);
+    NK_LAUNCH_CHECK();
+    return NK_OK;
+}
+
+int nk_relu_bwd(nk_device* dev, float* dx, const float* g, const float* x, size_t n) {
+    NK_USE(dev);
+    if (n == 0) return NK_OK;
+    NK_CHECK(dx && g && x, "null pointer in nk_relu_bwd");
+    const bool vec = al16(x) && al16(g) && al16(dx);
+    if (vec) hipLaunchKernelGGL((relu_bwd_kernel<true>), dim3(nk_stream_grid(n / 4 + 1, 256)), dim3(256), 0, dev->compute, dx, g, x, n);
+    else hipLaunchKernelGGL((relu_bwd_kernel<false>), dim3(nk_stream_grid(n, 256)), dim3(256), 0, dev->compute, dx, g, x, n);
+    NK_LAUNCH_CHECK();
+    return NK_OK;
+}
+
+int nk_sgd_step(nk_device* dev, float* w, float* grad, float* velocity, size_t n, float lr, float momentum,
+                float dampening, int nesterov, int first_step, float l1, float l2) {
+    NK_USE(dev);
+    if (n == 0) return NK_OK;
+    NK_CHECK(w && grad, "null pointer in nk_sgd_step");
+    hipLaunchKernelGGL(sgd_kernel, dim3(nk_stream_grid(n, 256)), dim3(256), 0, dev->compute, w, grad, velocity, n, lr,
+                       momentum, dampening, nesterov, first_step, l1, l2);
+    NK_LAUNCH_CHECK();
+    return NK_OK;
+}
+
+}  // extern "C"

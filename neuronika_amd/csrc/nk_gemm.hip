@@ -1,0 +1,243 @@
+// f32 GEMM on the gfx950 matrix cores: replaces `ndarray::linalg::general_mat_mul` at the six
+// call sites of the reference's MatMul nodes
+//   node/matrix_matrix_mul/mod.rs:33 (NN, beta 0), :65 (NT, beta 1), :97 (TN, beta 1)
+//   node/matrix_matrix_mul_t/mod.rs:33 (NT, beta 0), :65 (NN, beta 1), :97 (TN, beta 1)
+// Bound: f32 MFMA (157.3 TFLOP/s).  Structure: 128x128x32 block tile, double-buffered LDS,
+// register-staged global loads issued before the MFMAs of the current tile and written to
+// LDS after them (one barrier per k-tile), XCD-aware tile order, split-K with a deterministic
+// second pass when M*N alone cannot fill the chip.
+#include "nk_mma.h"
+
+using namespace nkmma;
+
+struct GemmArgs {
+    const float* A;
+    const float* B;
+    float* C;
+    int M, N, K;
+    long long lda, ldb, ldc;
+    float alpha, beta;
+    // two-level batch
+    int batch_inner;
+    long long sAo, sAi, sBo, sBi, sCo, sCi;
+    // split-K
+    int splits;          // >= 1
+    int k_per_split;     // multiple of BK
+    float* slabs;        // [splits][batch][M][N] partials when splits > 1
+    int tiles_m, tiles_n;
+};
+
+template <bool TA, bool TB, bool ALIGNED>
+__global__ __launch_bounds__(NT, 2) void sgemm_kernel(GemmArgs p) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE_FLOATS];  // 73,728 B -> 2 blocks/CU
+    constexpr bool AKC = !TA;  // A (M x K): k-contiguous unless stored transposed
+    constexpr bool BKC = TB;   // B (K x N) stored as N x K when transposed -> k-contiguous
+
+    const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    const int wr = wid >> 1, wc = wid & 1;
+    int tm, tn;
+    tile_coords(blockIdx.x, gridDim.x, p.tiles_m, p.tiles_n, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int batch = blockIdx.z, split = blockIdx.y;
+    const int bo = batch / p.batch_inner, bi = batch % p.batch_inner;
+    const float* A = p.A + bo * p.sAo + bi * p.sAi;
+    const float* B = p.B + bo * p.sBo + bi * p.sBi;
+
+    const int kbeg = split * p.k_per_split;
+    const int kend = min(p.K, kbeg + p.k_per_split);
+    const int nt = (kend - kbeg + BK - 1) / BK;
+
+    f32x16 acc[2][2];
+    acc_zero(acc);
+
+    Stage ra, rb;
+    TileLoader<AKC> la;
+    TileLoader<BKC> lb;
+    la.init(A, p.lda, m0, kbeg, p.M, kend, t);
+    lb.init(B, p.ldb, n0, kbeg, p.N, kend, t);
+    if (nt > 0) {
+        ra = la.template load<ALIGNED>(t);
+        rb = lb.template load<ALIGNED>(t);
+        stage_store<AKC>(smem, ra, t);
+        stage_store<BKC>(smem + TILE_FLOATS, rb, t);
+    }
+    __syncthreads();
+    for (int it = 0; it + 1 < nt; ++it) {
+        float* cur = smem + (it & 1) * STAGE_FLOATS;
+        float* nxt = smem + ((it + 1) & 1) * STAGE_FLOATS;
+        // issue the next tile's HBM/L2 loads before the MFMAs (their latency hides under them),
+        // write them to the other LDS buffer after the MFMAs: one barrier per k-tile
+        ra = la.template load<ALIGNED>(t);
+        rb = lb.template load<ALIGNED>(t);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_tile<AKC, BKC>(cur, cur + TILE_FLOATS, acc, wr, wc, lane);
+        stage_store<AKC>(nxt, ra, t);
+        stage_store<BKC>(nxt + TILE_FLOATS, rb, t);
+        __syncthreads();
+    }
+    if (nt > 0) {
+        float* cur = smem + ((nt - 1) & 1) * STAGE_FLOATS;
+        mma_tile<AKC, BKC>(cur, cur + TILE_FLOATS, acc, wr, wc, lane);
+    }
+
+    if (p.splits > 1) {
+        float* S = p.slabs + ((long long)split * gridDim.z + batch) * (long long)p.M * p.N;
+        const int M = p.M, N = p.N;
+        acc_foreach(acc, wr, wc, lane, [&](int r, int c, float v) {
+            const int row = m0 + r, col = n0 + c;
+            if (ALIGNED || (row < M && col < N)) S[(long long)row * N + col] = v;
+        });
+        return;
+    }
+    float* C = p.C + bo * p.sCo + bi * p.sCi;
+    const float alpha = p.alpha, beta = p.beta;
+    const int M = p.M, N = p.N;
+    const long long ldc = p.ldc;
+    if (beta == 0.f) {
+        acc_foreach(acc, wr, wc, lane, [&](int r, int c, float v) {
+            const int row = m0 + r, col = n0 + c;
+            if (ALIGNED || (row < M && col < N)) C[row * ldc + col] = alpha * v;
+        });
+    } else {
+        acc_foreach(acc, wr, wc, lane, [&](int r, int c, float v) {
+            const int row = m0 + r, col = n0 + c;
+            if (ALIGNED || (row < M && col < N)) {
+                float* q = &C[row * ldc + col];
+                *q = fmaf(beta, *q, alpha * v);
+            }
+        });
+    }
+}
+
+// Second pass of split-K: C = alpha * sum_s slab[s] + beta * C, fixed summation order.
+__global__ void splitk_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ C, int M, int N,
+                                     long long ldc, int splits, int nbatch, int batch_inner,
+                                     long long sCo, long long sCi, float alpha, float beta) {
+    const long long per = (long long)M * N;
+    const long long total = per * nbatch;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int b = (int)(i / per);
+        const long long e = i % per;
+        const int row = (int)(e / N), col = (int)(e % N);
+        float s = 0.f;
+        for (int k = 0; k < splits; ++k) s += slabs[((long long)k * nbatch + b) * per + e];
+        float* q = C + (b / batch_inner) * sCo + (b % batch_inner) * sCi + row * ldc + col;
+        *q = beta == 0.f ? alpha * s : fmaf(beta, *q, alpha * s);
+    }
+}
+
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+template <bool TA, bool TB>
+static int launch(nk_device* dev, const GemmArgs& p, int nbatch, bool aligned) {
+    dim3 grid(p.tiles_m * p.tiles_n, p.splits, nbatch), block(NT);
+    if (aligned)
+        hipLaunchKernelGGL((sgemm_kernel<TA, TB, true>), grid, block, 0, dev->compute, p);
+    else
+        hipLaunchKernelGGL((sgemm_kernel<TA, TB, false>), grid, block, 0, dev->compute, p);
+    NK_LAUNCH_CHECK();
+    return NK_OK;
+}
+
+static int gemm_impl(nk_device* dev, int transA, int transB, int M, int N, int K, float alpha,
+                     const float* A, int lda, long long sAo, long long sAi, const float* B, int ldb,
+                     long long sBo, long long sBi, float beta, float* C, int ldc, long long sCo,
+                     long long sCi, int batch_outer, int batch_inner) {
+    NK_USE(dev);
+    NK_CHECK(M >= 0 && N >= 0 && K >= 0 && batch_outer >= 0 && batch_inner >= 0, "negative GEMM extent");
+    const int nbatch = batch_outer * batch_inner;
+    if (M == 0 || N == 0 || nbatch == 0) return NK_OK;
+    NK_CHECK(A && B && C, "null GEMM operand");
+    NK_CHECK(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N,
+             "leading dimension too small (lda=%d ldb=%d ldc=%d)", lda, ldb, ldc);
+    NK_CHECK(nbatch <= 65535, "batch count %d exceeds grid.z", nbatch);
+
+    GemmArgs p{};
+    p.A = A; p.B = B; p.C = C;
+    p.M = M; p.N = N; p.K = K;
+    p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.alpha = alpha; p.beta = beta;
+    p.batch_inner = batch_inner;
+    p.sAo = sAo; p.sAi = sAi; p.sBo = sBo; p.sBi = sBi; p.sCo = sCo; p.sCi = sCi;
+    p.tiles_m = (M + BM - 1) / BM;
+    p.tiles_n = (N + BN - 1) / BN;
+
+    // split-K when the output tiles alone leave most of the 256 CUs idle and K is long
+    const long long tiles = (long long)p.tiles_m * p.tiles_n * nbatch;
+    int splits = 1;
+    const int ktiles = (K + BK - 1) / BK;
+    if (tiles * 2 <= dev->num_cus && ktiles >= 16) {
+        long long want = (2LL * dev->num_cus + tiles - 1) / tiles;
+        long long maxs = ktiles / 8;  // keep >= 8 k-tiles per split
+        splits = (int)(want < maxs ? want : maxs);
+        if (splits < 1) splits = 1;
+    }
+    int kts = (ktiles + splits - 1) / splits;
+    splits = (ktiles + kts - 1) / kts;
+    if (splits < 1) splits = 1;
+    p.splits = splits;
+    p.k_per_split = kts * BK;
+    if (K == 0) { p.splits = 1; p.k_per_split = BK; }
+    if (p.splits > 1) {
+        void* ws = nullptr;
+        int rc = nk_workspace(dev, (size_t)p.splits * nbatch * M * N * sizeof(float), &ws);
+        if (rc) return rc;
+        p.slabs = (float*)ws;
+    }
+
+    const bool aligned = (M % BM == 0) && (N % BN == 0) && (K % BK == 0) && (lda % 4 == 0) &&
+                         (ldb % 4 == 0) && aligned16(A) && aligned16(B) && (sAo % 4 == 0) &&
+                         (sAi % 4 == 0) && (sBo % 4 == 0) && (sBi % 4 == 0);
+    int rc;
+    if (!transA && !transB) rc = launch<false, false>(dev, p, nbatch, aligned);
+    else if (!transA && transB) rc = launch<false, true>(dev, p, nbatch, aligned);
+    else if (transA && !transB) rc = launch<true, false>(dev, p, nbatch, aligned);
+    else rc = launch<true, true>(dev, p, nbatch, aligned);
+    if (rc) return rc;
+    if (p.splits > 1) {
+        const long long total = (long long)M * N * nbatch;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(nk_stream_grid((size_t)total, 256)), dim3(256), 0,
+                           dev->compute, p.slabs, C, M, N, (long long)ldc, p.splits, nbatch, batch_inner,
+                           sCo, sCi, alpha, beta);
+        NK_LAUNCH_CHECK();
+    }
+    return NK_OK;
+}
+
+extern "C" {
+
+int nk_sgemm(nk_device* dev, int transA, int transB, int M, int N, int K, float alpha, const float* A,
+             int lda, const float* B, int ldb, float beta, float* C, int ldc) {
+    return gemm_impl(dev, transA, transB, M, N, K, alpha, A, lda, 0, 0, B, ldb, 0, 0, beta, C, ldc, 0, 0, 1, 1);
+}
+
+int nk_sgemm_batched(nk_device* dev, int transA, int transB, int M, int N, int K, float alpha,
+                     const float* A, int lda, long long sAo, long long sAi, const float* B, int ldb,
+                     long long sBo, long long sBi, float beta, float* C, int ldc, long long sCo,
+                     long long sCi, int batch_outer, int batch_inner) {
+    return gemm_impl(dev, transA, transB, M, N, K, alpha, A, lda, sAo, sAi, B, ldb, sBo, sBi, beta, C, ldc,
+                     sCo, sCi, batch_outer, batch_inner);
+}
+
+// ---- node-level wrappers: one per reference forward()/backward() body ------------------------
+int nk_mm_fwd(nk_device* dev, const float* A, const float* B, float* C, int n, int m, int o) {
+    return nk_sgemm(dev, 0, 0, n, o, m, 1.f, A, m, B, o, 0.f, C, o);
+}
+int nk_mm_bwd_left(nk_device* dev, float* dA, const float* G, const float* B, int n, int m, int o) {
+    return nk_sgemm(dev, 0, 1, n, m, o, 1.f, G, o, B, o, 1.f, dA, m);  // dA += G . B^T
+}
+int nk_mm_bwd_right(nk_device* dev, float* dB, const float* A, const float* G, int n, int m, int o) {
+    return nk_sgemm(dev, 1, 0, m, o, n, 1.f, A, m, G, o, 1.f, dB, o);  // dB += A^T . G
+}
+int nk_mm_t_fwd(nk_device* dev, const float* A, const float* B, float* C, int n, int m, int o) {
+    return nk_sgemm(dev, 0, 1, n, o, m, 1.f, A, m, B, m, 0.f, C, o);  // C = A . B^T, B is (o,m)
+}
+int nk_mm_t_bwd_left(nk_device* dev, float* dA, const float* G, const float* B, int n, int m, int o) {
+    return nk_sgemm(dev, 0, 0, n, m, o, 1.f, G, o, B, m, 1.f, dA, m);  // dA += G . B
+}
+int nk_mm_t_bwd_right(nk_device* dev, float* dB, const float* G, const float* A, int n, int m, int o) {
+    return nk_sgemm(dev, 1, 0, o, m, n, 1.f, G, o, A, m, 1.f, dB, m);  // dB += G^T . A
+}
+
+}  // extern "C"

@@ -1,0 +1,443 @@
+// Dropout (device RNG) and the data-movement glue of the hot path — all HBM-bound copies:
+//   Dropout            node/dropout/mod.rs:53-79,113-128
+//   Pad<Constant|Zero> node/pad/mod.rs:97-129,157-181 ; pad/constant/mod.rs:14-39
+//   Chunk              node/chunk/mod.rs:48-64,99-113
+//   MultiConcatenate   node/multi_concatenate/mod.rs:37-50,81-97
+//   Transpose          node/transpose/mod.rs:28-37,62-69
+//   head split/merge   = the Chunk / MultiConcatenate pattern of the composed attention
+#include "nk_common.h"
+
+namespace {
+
+bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// ------------------------------------------------------------------ Philox4x32-10 ------------
+__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = 0xD2511F53ull * c.x, p1 = 0xCD9E8D57ull * c.z;
+        const unsigned hi0 = (unsigned)(p0 >> 32), lo0 = (unsigned)p0;
+        const unsigned hi1 = (unsigned)(p1 >> 32), lo1 = (unsigned)p1;
+        c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
+        k.x += 0x9E3779B9u;
+        k.y += 0xBB67AE85u;
+    }
+    return c;
+}
+
+__device__ __forceinline__ float keep_bit(unsigned word, float keep_prob) {
+    return ((float)(word >> 8) * 5.9604644775390625e-08f /* 2^-24 */ < keep_prob) ? 1.f : 0.f;
+}
+
+// element i uses word i%4 of Philox(counter = i/4 + offset, key = seed); y = (x*noise)/scale
+__global__ void dropout_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ noise,
+                                   size_t n, float keep_prob, float scale, unsigned long long seed,
+                                   unsigned long long offset) {
+    const size_t n4 = (n + 3) / 4;
+    const uint2 key = make_uint2((unsigned)seed, (unsigned)(seed >> 32));
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const unsigned long long ctr = i + offset;
+        const uint4 r = philox4x32_10(make_uint4((unsigned)ctr, (unsigned)(ctr >> 32), 0u, 0u), key);
+        const float4 nz = make_float4(keep_bit(r.x, keep_prob), keep_bit(r.y, keep_prob), keep_bit(r.z, keep_prob),
+                                      keep_bit(r.w, keep_prob));
+        if (i * 4 + 3 < n) {
+            const float4 xv = reinterpret_cast<const float4*>(x)[i];
+            float4 o;
+            o.x = (xv.x * nz.x) / scale; o.y = (xv.y * nz.y) / scale; o.z = (xv.z * nz.z) / scale; o.w = (xv.w * nz.w) / scale;
+            reinterpret_cast<float4*>(y)[i] = o;
+            reinterpret_cast<float4*>(noise)[i] = nz;
+        } else {
+            const float nn[4] = {nz.x, nz.y, nz.z, nz.w};
+            for (int c = 0; c < 4; ++c) {
+                const size_t e = i * 4 + c;
+                if (e < n) { y[e] = (x[e] * nn[c]) / scale; noise[e] = nn[c]; }
+            }
+        }
+    }
+}
+
+// MODE 0: dx += g ; MODE 1: dx += g * noise
+template <int MODE>
+__global__ void dropout_bwd_kernel(float* __restrict__ dx, const float* __restrict__ g, const float* __restrict__ noise, size_t n) {
+    const size_t n4 = n / 4;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 d = reinterpret_cast<float4*>(dx)[i];
+        const float4 gv = reinterpret_cast<const float4*>(g)[i];
+        if (MODE == 0) { d.x += gv.x; d.y += gv.y; d.z += gv.z; d.w += gv.w; }
+        else {
+            const float4 nz = reinterpret_cast<const float4*>(noise)[i];
+            d.x += gv.x * nz.x; d.y += gv.y * nz.y; d.z += gv.z * nz.z; d.w += gv.w * nz.w;
+        }
+        reinterpret_cast<float4*>(dx)[i] = d;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const size_t i = n4 * 4 + threadIdx.x;
+        dx[i] += MODE == 0 ? g[i] : g[i] * noise[i];
+    }
+}
+
+// ------------------------------------------------------------------ sub-block copies ----------
+// `small` (contiguous, shape s[]) <-> the sub-block of `big` (shape b[]) starting at origin o[].
+// DIR 0: small (=|+=) big[sub]      DIR 1: big[sub] (=|+=) small
+struct Sub {
+    int nd;
+    int s[NK_MAX_DIMS];
+    long long bstride[NK_MAX_DIMS];
+    long long origin_off;
+};
+
+template <int DIR, bool ACC, bool VEC>
+__global__ void subblock_kernel(float* __restrict__ small, float* __restrict__ big, Sub p, long long total) {
+    constexpr int W = VEC ? 4 : 1;
+    const long long groups = total / W;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < groups;
+         i += (long long)gridDim.x * blockDim.x) {
+        long long rem = i * W, bo = p.origin_off;
+#pragma unroll 1
+        for (int d = p.nd - 1; d >= 0; --d) {
+            const long long c = rem % p.s[d];
+            rem /= p.s[d];
+            bo += c * p.bstride[d];
+        }
+        if (VEC) {
+            float4* sp = reinterpret_cast<float4*>(small + i * 4);
+            float4* bp = reinterpret_cast<float4*>(big + bo);
+            if (DIR == 0) {
+                float4 v = *bp;
+                if (ACC) { const float4 d = *sp; v.x += d.x; v.y += d.y; v.z += d.z; v.w += d.w; }
+                *sp = v;
+            } else {
+                float4 v = *sp;
+                if (ACC) { const float4 d = *bp; v.x += d.x; v.y += d.y; v.z += d.z; v.w += d.w; }
+                *bp = v;
+            }
+        } else {
+            if (DIR == 0) small[i] = ACC ? small[i] + big[bo] : big[bo];
+            else big[bo] = ACC ? big[bo] + small[i] : small[i];
+        }
+    }
+}
+
+// small_shape/big_shape/origin: nd entries each.
+template <int DIR, bool ACC>
+int subblock(nk_device* dev, float* small, const int* small_shape, float* big, const int* big_shape,
+             const int* origin, int nd) {
+    NK_USE(dev);
+    NK_CHECK(nd >= 1 && nd <= NK_MAX_DIMS, "bad rank %d", nd);
+    NK_CHECK(small && big, "null pointer");
+    long long bst[NK_MAX_DIMS];
+    long long acc = 1;
+    for (int i = nd - 1; i >= 0; --i) { bst[i] = acc; acc *= big_shape[i]; }
+    long long total = 1, off = 0;
+    for (int i = 0; i < nd; ++i) {
+        NK_CHECK(origin[i] >= 0 && origin[i] + small_shape[i] <= big_shape[i], "sub-block exceeds axis %d", i);
+        total *= small_shape[i];
+        off += origin[i] * bst[i];
+    }
+    if (total == 0) return NK_OK;
+    // collapse dims where the sub-block spans the whole big axis
+    Sub p{};
+    int m = 0;
+    for (int i = 0; i < nd; ++i) {
+        if (m > 0 && small_shape[i] == big_shape[i]) {  // axis fully covered: merge into previous
+            p.s[m - 1] *= small_shape[i];
+            p.bstride[m - 1] = bst[i];
+        } else {
+            p.s[m] = small_shape[i];
+            p.bstride[m] = bst[i];
+            ++m;
+        }
+    }
+    p.nd = m;
+    p.origin_off = off;
+    const bool vec = (p.s[m - 1] % 4 == 0) && (off % 4 == 0) && al16(small) && al16(big);
+    bool strides_ok = true;
+    for (int i = 0; i + 1 < m; ++i) if (p.bstride[i] % 4 != 0) strides_ok = false;
+    const bool v = vec && strides_ok;
+    const int grid = nk_stream_grid((size_t)(total / (v ? 4 : 1)), 256);
+    if (v) hipLaunchKernelGGL((subblock_kernel<DIR, ACC, true>), dim3(grid), dim3(256), 0, dev->compute, small, big, p, total);
+    else hipLaunchKernelGGL((subblock_kernel<DIR, ACC, false>), dim3(grid), dim3(256), 0, dev->compute, small, big, p, total);
+    NK_LAUNCH_CHECK();
+    return NK_OK;
+}
+
+// ------------------------------------------------------------------ pad ------------------------
+struct PadDesc {
+    int nd;                  // spatial dims
+    int in[3], out[3], pad[3];
+};
+__global__ void pad_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, PadDesc p, long long planes,
+                               long long out_plane, long long in_plane, float value) {
+    const long long total = planes * out_plane;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long plane = i / out_plane;
+        long long rem = i % out_plane, src = 0, mul = 1;
+        bool inside = true;
+        for (int d = p.nd - 1; d >= 0; --d) {
+            const int c = (int)(rem % p.out[d]) - p.pad[d];
+            rem /= p.out[d];
+            if (c < 0 || c >= p.in[d]) inside = false;
+            src += c * mul;
+            mul *= p.in[d];
+        }
+        y[i] = inside ? x[plane * in_plane + src] : value;
+    }
+}
+
+// ------------------------------------------------------------------ transpose -------------------
+// 2-D: 32x32 tiles through LDS (+1 padding: conflict-free column reads), both sides coalesced.
+template <bool ACC>
+__global__ void transpose2d_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int C) {
+    __shared__ float tile[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+        const int r = r0 + j, c = c0 + threadIdx.x;
+        if (r < R && c < C) tile[j][threadIdx.x] = in[(long long)r * C + c];
+    }
+    __syncthreads();
+    for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+        const int c = c0 + j, r = r0 + threadIdx.x;  // out is C x R
+        if (r < R && c < C) {
+            float* q = &out[(long long)c * R + r];
+            *q = ACC ? *q + tile[threadIdx.x][j] : tile[threadIdx.x][j];
+        }
+    }
+}
+
+// N-d reversed axes: out[i_{n-1},...,i_0] (=|+=) in[i_0,...,i_{n-1}].  Thread per out element.
+struct Rev {
+    int nd;
+    int oshape[NK_MAX_DIMS];      // out shape = reversed in shape
+    long long istride[NK_MAX_DIMS];  // stride in `in` of out axis d
+};
+template <bool ACC>
+__global__ void transpose_nd_kernel(const float* __restrict__ in, float* __restrict__ out, Rev p, long long total) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        long long rem = i, src = 0;
+        for (int d = p.nd - 1; d >= 0; --d) {
+            src += (rem % p.oshape[d]) * p.istride[d];
+            rem /= p.oshape[d];
+        }
+        out[i] = ACC ? out[i] + in[src] : in[src];
+    }
+}
+
+template <bool ACC>
+int transpose(nk_device* dev, const float* in, float* out, const int* in_shape, int nd) {
+    NK_USE(dev);
+    NK_CHECK(nd >= 1 && nd <= NK_MAX_DIMS, "bad rank %d", nd);
+    const long long total = (long long)nk_numel(in_shape, nd);
+    if (total == 0) return NK_OK;
+    NK_CHECK(in && out, "null pointer");
+    if (nd == 2) {
+        const int R = in_shape[0], C = in_shape[1];
+        hipLaunchKernelGGL((transpose2d_kernel<ACC>), dim3((C + 31) / 32, (R + 31) / 32), dim3(32, 8), 0, dev->compute, in, out, R, C);
+    } else {
+        Rev p{};
+        p.nd = nd;
+        long long st[NK_MAX_DIMS], acc = 1;
+        for (int i = nd - 1; i >= 0; --i) { st[i] = acc; acc *= in_shape[i]; }
+        for (int d = 0; d < nd; ++d) { p.oshape[d] = in_shape[nd - 1 - d]; p.istride[d] = st[nd - 1 - d]; }
+        hipLaunchKernelGGL((transpose_nd_kernel<ACC>), dim3(nk_stream_grid((size_t)total, 256)), dim3(256), 0, dev->compute, in, out, p, total);
+    }
+    NK_LAUNCH_CHECK();
+    return NK_OK;
+}
+
+// ------------------------------------------------------------------ head split / merge ----------
+// flat[(b*S + s)*(H*dh) + h*dh + e]  <->  heads[((b*H + h)*S + s)*dh + e]
+// TO_HEADS: heads (=|+=) flat ; else flat (=|+=) heads.  dh % 4 == 0 -> float4.
+template <bool TO_HEADS, bool ACC, bool VEC>
+__global__ void heads_kernel(float* __restrict__ flat, float* __restrict__ heads, int B, int S, int H, int dh) {
+    constexpr int W = VEC ? 4 : 1;
+    const long long total = (long long)B * S * H * dh / W;
+    const int dq = dh / W;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        // i indexes the flat layout (coalesced on the flat side, dh-contiguous on the heads side)
+        const int e = (int)(i % dq);
+        long long rem = i / dq;
+        const int h = (int)(rem % H); rem /= H;
+        const int s = (int)(rem % S);
+        const int b = (int)(rem / S);
+        const long long fo = i * W;
+        const long long ho = (((long long)(b * H + h) * S + s) * dh) + e * W;
+        if (VEC) {
+            float4* fp = reinterpret_cast<float4*>(flat + fo);
+            float4* hp = reinterpret_cast<float4*>(heads + ho);
+            float4 v = TO_HEADS ? *fp : *hp;
+            float4* dst = TO_HEADS ? hp : fp;
+            if (ACC) { const float4 d = *dst; v.x += d.x; v.y += d.y; v.z += d.z; v.w += d.w; }
+            *dst = v;
+        } else {
+            const float v = TO_HEADS ? flat[fo] : heads[ho];
+            float* dst = TO_HEADS ? &heads[ho] : &flat[fo];
+            *dst = ACC ? *dst + v : v;
+        }
+    }
+}
+
+template <bool TO_HEADS, bool ACC>
+int heads(nk_device* dev, float* flat, float* hd, int B, int S, int H, int dh) {
+    NK_USE(dev);
+    NK_CHECK(B >= 0 && S >= 0 && H >= 0 && dh >= 0, "negative extent");
+    const long long total = (long long)B * S * H * dh;
+    if (total == 0) return NK_OK;
+    NK_CHECK(flat && hd, "null pointer");
+    const bool vec = (dh % 4 == 0) && al16(flat) && al16(hd);
+    const int grid = nk_stream_grid((size_t)(total / (vec ? 4 : 1)), 256);
+    if (vec) hipLaunchKernelGGL((heads_kernel<TO_HEADS, ACC, true>), dim3(grid), dim3(256), 0, dev->compute, flat, hd, B, S, H, dh);
+    else hipLaunchKernelGGL((heads_kernel<TO_HEADS, ACC, false>), dim3(grid), dim3(256), 0, dev->compute, flat, hd, B, S, H, dh);
+    NK_LAUNCH_CHECK();
+    return NK_OK;
+}
+
+int chunk_origin(const int* x_shape, const int* chunk_shape, int nd, int chunk_no, int* origin) {
+    NK_CHECK(nd >= 1 && nd <= NK_MAX_DIMS, "bad rank %d", nd);
+    long long grid_total = 1;
+    int grid[NK_MAX_DIMS];
+    for (int i = 0; i < nd; ++i) {
+        NK_CHECK(chunk_shape[i] >= 1 && chunk_shape[i] <= x_shape[i], "chunk axis %d: %d does not fit %d", i, chunk_shape[i], x_shape[i]);
+        grid[i] = x_shape[i] / chunk_shape[i];  // exact_chunks: remainder skipped
+        grid_total *= grid[i];
+    }
+    NK_CHECK(chunk_no >= 0 && chunk_no < grid_total, "chunk_no %d out of range (%lld chunks)", chunk_no, grid_total);
+    int rem = chunk_no;
+    for (int i = nd - 1; i >= 0; --i) { origin[i] = (rem % grid[i]) * chunk_shape[i]; rem /= grid[i]; }
+    return NK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int nk_dropout_fwd(nk_device* dev, const float* x, float* y, float* noise, size_t n, double p, int train,
+                   uint64_t seed, uint64_t offset) {
+    NK_USE(dev);
+    NK_CHECK(p >= 0.0 && p <= 1.0, "Wrong probability received: %g.", p);
+    if (n == 0) return NK_OK;
+    NK_CHECK(x && y, "null pointer in nk_dropout_fwd");
+    if (!train || p == 0.0) {
+        NK_HIP(hipMemcpyAsync(y, x, n * sizeof(float), hipMemcpyDeviceToDevice, dev->compute));
+        return NK_OK;
+    }
+    if (1.0 - p == 0.0) {
+        NK_HIP(hipMemsetAsync(y, 0, n * sizeof(float), dev->compute));
+        return NK_OK;
+    }
+    NK_CHECK(noise != nullptr, "noise buffer required in training mode");
+    NK_CHECK(al16(x) && al16(y) && al16(noise), "dropout buffers must be 16-byte aligned");
+    const float keep = (float)(1.0 - p);      // Bernoulli::new(1. - p), dropout/mod.rs:46
+    const float scale = 1.f - (float)p;       // `(1. - self.p as f32)`, dropout/mod.rs:76
+    hipLaunchKernelGGL(dropout_fwd_kernel, dim3(nk_stream_grid((n + 3) / 4, 256)), dim3(256), 0, dev->compute, x, y, noise,
+                       n, keep, scale, (unsigned long long)seed, (unsigned long long)offset);
+    NK_LAUNCH_CHECK();
+    return NK_OK;
+}
+
+int nk_dropout_bwd(nk_device* dev, float* dx, const float* g, const float* noise, size_t n, double p, int train) {
+    NK_USE(dev);
+    NK_CHECK(p >= 0.0 && p <= 1.0, "Wrong probability received: %g.", p);
+    if (n == 0) return NK_OK;
+    NK_CHECK(dx && g, "null pointer in nk_dropout_bwd");
+    NK_CHECK(al16(dx) && al16(g), "dropout buffers must be 16-byte aligned");
+    const int grid = nk_stream_grid(n / 4 + 1, 256);
+    if (!train || p == 0.0) {
+        hipLaunchKernelGGL((dropout_bwd_kernel<0>), dim3(grid), dim3(256), 0, dev->compute, dx, g, noise, n);
+    } else {
+        NK_CHECK(noise != nullptr && al16(noise), "noise buffer required in training mode");
+        hipLaunchKernelGGL((dropout_bwd_kernel<1>), dim3(grid), dim3(256), 0, dev->compute, dx, g, noise, n);
+    }
+    NK_LAUNCH_CHECK();
+    return NK_OK;
+}
+
+int nk_pad_const_fwd(nk_device* dev, int nd, const float* x, const int* x_shape, float* y, const int* padding, float value) {
+    NK_USE(dev);
+    NK_CHECK(nd >= 1 && nd <= 3, "pad supports 1-3 spatial dims, got %d", nd);
+    PadDesc p{};
+    p.nd = nd;
+    long long in_plane = 1, out_plane = 1;
+    for (int i = 0; i < nd; ++i) {
+        NK_CHECK(padding[i] >= 0, "negative padding");
+        p.in[i] = x_shape[2 + i]; p.pad[i] = padding[i]; p.out[i] = x_shape[2 + i] + 2 * padding[i];
+        in_plane *= p.in[i]; out_plane *= p.out[i];
+    }
+    const long long planes = (long long)x_shape[0] * x_shape[1];
+    if (planes * out_plane == 0) return NK_OK;
+    NK_CHECK(x && y, "null pointer in nk_pad_const_fwd");
+    hipLaunchKernelGGL(pad_fwd_kernel, dim3(nk_stream_grid((size_t)(planes * out_plane), 256)), dim3(256), 0, dev->compute, x,
+                       y, p, planes, out_plane, in_plane, value);
+    NK_LAUNCH_CHECK();
+    return NK_OK;
+}
+
+int nk_pad_bwd(nk_device* dev, int nd, float* dx, const int* x_shape, const float* g, const int* padding) {
+    NK_CHECK(nd >= 1 && nd <= 3, "pad supports 1-3 spatial dims, got %d", nd);
+    int gshape[5], origin[5] = {0, 0, 0, 0, 0};
+    gshape[0] = x_shape[0]; gshape[1] = x_shape[1];
+    for (int i = 0; i < nd; ++i) { gshape[2 + i] = x_shape[2 + i] + 2 * padding[i]; origin[2 + i] = padding[i]; }
+    return subblock<0, true>(dev, dx, x_shape, const_cast<float*>(g), gshape, origin, nd + 2);  // dx += g[centre]
+}
+
+int nk_chunk_fwd(nk_device* dev, const float* x, const int* x_shape, float* y, const int* chunk_shape, int nd, int chunk_no) {
+    int origin[NK_MAX_DIMS];
+    int rc = chunk_origin(x_shape, chunk_shape, nd, chunk_no, origin);
+    if (rc) return rc;
+    return subblock<0, false>(dev, y, chunk_shape, const_cast<float*>(x), x_shape, origin, nd);
+}
+
+int nk_chunk_bwd(nk_device* dev, float* dx, const int* x_shape, const float* g, const int* chunk_shape, int nd, int chunk_no) {
+    int origin[NK_MAX_DIMS];
+    int rc = chunk_origin(x_shape, chunk_shape, nd, chunk_no, origin);
+    if (rc) return rc;
+    return subblock<1, true>(dev, const_cast<float*>(g), chunk_shape, dx, x_shape, origin, nd);
+}
+
+int nk_concat_fwd_part(nk_device* dev, const float* operand, float* out, const int* out_shape, int nd, int axis,
+                       int offset, int op_len) {
+    NK_CHECK(nd >= 1 && nd <= NK_MAX_DIMS && axis >= 0 && axis < nd, "bad rank/axis");
+    int s[NK_MAX_DIMS], origin[NK_MAX_DIMS] = {0};
+    for (int i = 0; i < nd; ++i) s[i] = out_shape[i];
+    s[axis] = op_len;
+    origin[axis] = offset;
+    return subblock<1, false>(dev, const_cast<float*>(operand), s, out, out_shape, origin, nd);
+}
+
+int nk_concat_bwd_part(nk_device* dev, float* d_operand, const float* g, const int* g_shape, int nd, int axis,
+                       int offset, int op_len) {
+    NK_CHECK(nd >= 1 && nd <= NK_MAX_DIMS && axis >= 0 && axis < nd, "bad rank/axis");
+    int s[NK_MAX_DIMS], origin[NK_MAX_DIMS] = {0};
+    for (int i = 0; i < nd; ++i) s[i] = g_shape[i];
+    s[axis] = op_len;
+    origin[axis] = offset;
+    return subblock<0, true>(dev, d_operand, s, const_cast<float*>(g), g_shape, origin, nd);
+}
+
+int nk_transpose_fwd(nk_device* dev, const float* x, float* y, const int* x_shape, int nd) {
+    return transpose<false>(dev, x, y, x_shape, nd);
+}
+int nk_transpose_bwd(nk_device* dev, float* dx, const float* g, const int* x_shape, int nd) {
+    // g has the reversed shape; dx += g^T
+    int gs[NK_MAX_DIMS];
+    NK_CHECK(nd >= 1 && nd <= NK_MAX_DIMS, "bad rank %d", nd);
+    for (int i = 0; i < nd; ++i) gs[i] = x_shape[nd - 1 - i];
+    return transpose<true>(dev, g, dx, gs, nd);
+}
+
+int nk_split_heads_fwd(nk_device* dev, const float* x, float* y, int B, int S, int H, int dh) {
+    return heads<true, false>(dev, const_cast<float*>(x), y, B, S, H, dh);
+}
+int nk_split_heads_bwd(nk_device* dev, float* dx, const float* g, int B, int S, int H, int dh) {
+    return heads<false, true>(dev, dx, const_cast<float*>(g), B, S, H, dh);
+}
+int nk_merge_heads_fwd(nk_device* dev, const float* x, float* y, int B, int S, int H, int dh) {
+    return heads<false, false>(dev, y, const_cast<float*>(x), B, S, H, dh);
+}
+int nk_merge_heads_bwd(nk_device* dev, float* dx, const float* g, int B, int S, int H, int dh) {
+    return heads<true, true>(dev, const_cast<float*>(g), dx, B, S, H, dh);
+}
+
+}  // extern "C"

@@ -1,0 +1,366 @@
+// Reductions and (log-)softmax: HBM-bound, wave64 shuffles, rows cached in registers so every
+// element is read once and written once (bound: 8 TB/s HBM3E).
+//   Sum / Mean          node/sum/mod.rs:28-35,60-67 ; node/mean/mod.rs:28-35,60-72
+//   SquaredError        node/squared_error/mod.rs:42-59,94-123
+//   Softmax / LogSoftmax node/softmax/mod.rs:37-53,84-104 ; node/logsoftmax/mod.rs:37-53,84-102
+#include "nk_common.h"
+
+namespace {
+
+bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+constexpr int RB = 256;       // reduction block
+constexpr int MAX_PART = 1024;  // partial sums per full reduction
+
+// MODE 0: sum x ; MODE 1: sum (x-t)^2
+template <int MODE>
+__global__ void reduce_partial_kernel(const float* __restrict__ x, const float* __restrict__ t, size_t n,
+                                      float* __restrict__ part) {
+    __shared__ float red[RB / 64];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    const size_t n4 = n / 4;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 v = reinterpret_cast<const float4*>(x)[i];
+        if (MODE == 1) {
+            const float4 w = reinterpret_cast<const float4*>(t)[i];
+            v.x -= w.x; v.y -= w.y; v.z -= w.z; v.w -= w.w;
+            v.x *= v.x; v.y *= v.y; v.z *= v.z; v.w *= v.w;
+        }
+        a0 += v.x; a1 += v.y; a2 += v.z; a3 += v.w;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const size_t i = n4 * 4 + threadIdx.x;
+        float v = x[i];
+        if (MODE == 1) { v -= t[i]; v *= v; }
+        a0 += v;
+    }
+    const float s = nk_block_sum<RB>((a0 + a1) + (a2 + a3), red);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
+__global__ void reduce_final_kernel(const float* __restrict__ part, int nparts, float scale_den, float* __restrict__ out) {
+    __shared__ float red[RB / 64];
+    float a = 0.f;
+    for (int i = threadIdx.x; i < nparts; i += blockDim.x) a += part[i];
+    const float s = nk_block_sum<RB>(a, red);
+    if (threadIdx.x == 0) out[0] = scale_den > 0.f ? s / scale_den : s;
+}
+
+// MODE 0: dx += g            (SumBackward)
+// MODE 1: dx += g / den      (MeanBackward: `grad_el / den`)
+// MODE 2: dx += (2*(x-t))*g / den   (SquaredErrorBackward, Mean)
+// MODE 3: dx += (2*(x-t))*g         (SquaredErrorBackward, Sum)
+template <int MODE>
+__global__ void scalar_bwd_kernel(float* __restrict__ dx, const float* __restrict__ gs, const float* __restrict__ x,
+                                  const float* __restrict__ t, size_t n, float den) {
+    const float g = gs[0];
+    const size_t n4 = n / 4;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 d = reinterpret_cast<float4*>(dx)[i];
+        if (MODE == 0) { d.x += g; d.y += g; d.z += g; d.w += g; }
+        if (MODE == 1) { const float v = g / den; d.x += v; d.y += v; d.z += v; d.w += v; }
+        if (MODE >= 2) {
+            const float4 xv = reinterpret_cast<const float4*>(x)[i], tv = reinterpret_cast<const float4*>(t)[i];
+            if (MODE == 2) {
+                d.x += (2.f * (xv.x - tv.x)) * g / den; d.y += (2.f * (xv.y - tv.y)) * g / den;
+                d.z += (2.f * (xv.z - tv.z)) * g / den; d.w += (2.f * (xv.w - tv.w)) * g / den;
+            } else {
+                d.x += (2.f * (xv.x - tv.x)) * g; d.y += (2.f * (xv.y - tv.y)) * g;
+                d.z += (2.f * (xv.z - tv.z)) * g; d.w += (2.f * (xv.w - tv.w)) * g;
+            }
+        }
+        reinterpret_cast<float4*>(dx)[i] = d;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const size_t i = n4 * 4 + threadIdx.x;
+        if (MODE == 0) dx[i] += g;
+        if (MODE == 1) dx[i] += g / den;
+        if (MODE == 2) dx[i] += (2.f * (x[i] - t[i])) * g / den;
+        if (MODE == 3) dx[i] += (2.f * (x[i] - t[i])) * g;
+    }
+}
+
+template <int MODE>
+int full_reduce(nk_device* dev, const float* x, const float* t, size_t n, float den, float* out) {
+    NK_USE(dev);
+    NK_CHECK(out != nullptr, "null output scalar");
+    NK_CHECK(n == 0 || x != nullptr, "null input");
+    NK_CHECK(al16(x) && (MODE == 0 || al16(t)), "reduction inputs must be 16-byte aligned");
+    void* ws = nullptr;
+    int rc = nk_workspace(dev, MAX_PART * sizeof(float), &ws);
+    if (rc) return rc;
+    int parts = nk_stream_grid(n / 4 + 1, RB);
+    if (parts > MAX_PART) parts = MAX_PART;
+    hipLaunchKernelGGL((reduce_partial_kernel<MODE>), dim3(parts), dim3(RB), 0, dev->compute, x, t, n, (float*)ws);
+    NK_LAUNCH_CHECK();
+    hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(RB), 0, dev->compute, (const float*)ws, parts, den, out);
+    NK_LAUNCH_CHECK();
+    return NK_OK;
+}
+
+template <int MODE>
+int scalar_bwd(nk_device* dev, float* dx, const float* g, const float* x, const float* t, size_t n, float den) {
+    NK_USE(dev);
+    if (n == 0) return NK_OK;
+    NK_CHECK(dx && g, "null pointer");
+    NK_CHECK(al16(dx) && (MODE < 2 || (al16(x) && al16(t))), "gradient buffers must be 16-byte aligned");
+    hipLaunchKernelGGL((scalar_bwd_kernel<MODE>), dim3(nk_stream_grid(n / 4 + 1, 256)), dim3(256), 0, dev->compute, dx, g, x, t, n, den);
+    NK_LAUNCH_CHECK();
+    return NK_OK;
+}
+
+// --------------------------------------------------------------------------- softmax ----------
+// Row kernels (axis is the innermost, contiguous one): ONE WAVE PER ROW, the row lives in
+// registers (V float4 per lane, L <= 256*V), max / sum by wave64 xor-shuffles.
+// LOG: log-softmax.   The max fold starts from f32::MIN (finite), softmax/mod.rs:45.
+constexpr float F32_MIN = -3.40282347e+38f;
+
+template <int V, bool LOG>
+__global__ void softmax_fwd_row_kernel(const float* __restrict__ x, float* __restrict__ y, long long rows, int L) {
+    const int lane = threadIdx.x & 63;
+    const long long row = blockIdx.x * (long long)(blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * L;
+    float* yr = y + row * L;
+    float4 v[V];
+    float m = F32_MIN;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < L) {
+            v[i] = *reinterpret_cast<const float4*>(xr + c);
+            m = fmaxf(m, fmaxf(fmaxf(v[i].x, v[i].y), fmaxf(v[i].z, v[i].w)));
+        }
+    }
+    m = nk_wave_max(m);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < L) {
+            float4 e;
+            e.x = expf(v[i].x - m); e.y = expf(v[i].y - m); e.z = expf(v[i].z - m); e.w = expf(v[i].w - m);
+            s += (e.x + e.y) + (e.z + e.w);
+            if (!LOG) v[i] = e;
+        }
+    }
+    s = nk_wave_sum(s);
+    const float lse = LOG ? logf(s) : 0.f;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < L) {
+            float4 o;
+            if (LOG) { o.x = v[i].x - lse - m; o.y = v[i].y - lse - m; o.z = v[i].z - lse - m; o.w = v[i].w - lse - m; }
+            else { o.x = v[i].x / s; o.y = v[i].y / s; o.z = v[i].z / s; o.w = v[i].w / s; }
+            *reinterpret_cast<float4*>(yr + c) = o;
+        }
+    }
+}
+
+// softmax: dx += y*(g - sum(g*y)) ; log-softmax: dx += g - exp(y)*sum(g)
+template <int V, bool LOG>
+__global__ void softmax_bwd_row_kernel(float* __restrict__ dx, const float* __restrict__ g, const float* __restrict__ y,
+                                       long long rows, int L) {
+    const int lane = threadIdx.x & 63;
+    const long long row = blockIdx.x * (long long)(blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* gr = g + row * L;
+    const float* yr = y + row * L;
+    float* dr = dx + row * L;
+    float4 gv[V], yv[V];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < L) {
+            gv[i] = *reinterpret_cast<const float4*>(gr + c);
+            yv[i] = *reinterpret_cast<const float4*>(yr + c);
+            if (LOG) s += (gv[i].x + gv[i].y) + (gv[i].z + gv[i].w);
+            else s += (gv[i].x * yv[i].x + gv[i].y * yv[i].y) + (gv[i].z * yv[i].z + gv[i].w * yv[i].w);
+        }
+    }
+    s = nk_wave_sum(s);
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < L) {
+            float4 d = *reinterpret_cast<float4*>(dr + c);
+            if (LOG) {
+                d.x += gv[i].x - expf(yv[i].x) * s; d.y += gv[i].y - expf(yv[i].y) * s;
+                d.z += gv[i].z - expf(yv[i].z) * s; d.w += gv[i].w - expf(yv[i].w) * s;
+            } else {
+                d.x += yv[i].x * (gv[i].x - s); d.y += yv[i].y * (gv[i].y - s);
+                d.z += yv[i].z * (gv[i].z - s); d.w += yv[i].w * (gv[i].w - s);
+            }
+            *reinterpret_cast<float4*>(dr + c) = d;
+        }
+    }
+}
+
+// General kernels: lanes of length L with element stride `inner` (any axis, any L).
+// inner == 1: one 256-thread block per lane, threads stride along the lane.
+// inner  > 1: one thread per (outer, inner) lane, threads along `inner` (coalesced).
+template <bool LOG>
+__global__ void softmax_fwd_block_kernel(const float* __restrict__ x, float* __restrict__ y, int L) {
+    __shared__ float red[4];
+    const float* xr = x + (long long)blockIdx.x * L;
+    float* yr = y + (long long)blockIdx.x * L;
+    float m = F32_MIN;
+    for (int c = threadIdx.x; c < L; c += blockDim.x) m = fmaxf(m, xr[c]);
+    m = nk_block_max<256>(m, red);
+    float s = 0.f;
+    for (int c = threadIdx.x; c < L; c += blockDim.x) s += expf(xr[c] - m);
+    s = nk_block_sum<256>(s, red);
+    const float lse = LOG ? logf(s) : 0.f;
+    for (int c = threadIdx.x; c < L; c += blockDim.x) yr[c] = LOG ? xr[c] - lse - m : expf(xr[c] - m) / s;
+}
+
+template <bool LOG>
+__global__ void softmax_bwd_block_kernel(float* __restrict__ dx, const float* __restrict__ g, const float* __restrict__ y, int L) {
+    __shared__ float red[4];
+    const long long o = (long long)blockIdx.x * L;
+    float s = 0.f;
+    for (int c = threadIdx.x; c < L; c += blockDim.x) s += LOG ? g[o + c] : g[o + c] * y[o + c];
+    s = nk_block_sum<256>(s, red);
+    for (int c = threadIdx.x; c < L; c += blockDim.x)
+        dx[o + c] += LOG ? g[o + c] - expf(y[o + c]) * s : y[o + c] * (g[o + c] - s);
+}
+
+template <bool LOG>
+__global__ void softmax_fwd_strided_kernel(const float* __restrict__ x, float* __restrict__ y, long long lanes, int L,
+                                           long long inner) {
+    for (long long id = blockIdx.x * (long long)blockDim.x + threadIdx.x; id < lanes;
+         id += (long long)gridDim.x * blockDim.x) {
+        const long long base = (id / inner) * L * inner + id % inner;
+        float m = F32_MIN;
+        for (int c = 0; c < L; ++c) m = fmaxf(m, x[base + c * inner]);
+        float s = 0.f;
+        for (int c = 0; c < L; ++c) s += expf(x[base + c * inner] - m);
+        const float lse = LOG ? logf(s) : 0.f;
+        for (int c = 0; c < L; ++c) {
+            const float v = x[base + c * inner];
+            y[base + c * inner] = LOG ? v - lse - m : expf(v - m) / s;
+        }
+    }
+}
+
+template <bool LOG>
+__global__ void softmax_bwd_strided_kernel(float* __restrict__ dx, const float* __restrict__ g, const float* __restrict__ y,
+                                           long long lanes, int L, long long inner) {
+    for (long long id = blockIdx.x * (long long)blockDim.x + threadIdx.x; id < lanes;
+         id += (long long)gridDim.x * blockDim.x) {
+        const long long base = (id / inner) * L * inner + id % inner;
+        float s = 0.f;
+        for (int c = 0; c < L; ++c) s += LOG ? g[base + c * inner] : g[base + c * inner] * y[base + c * inner];
+        for (int c = 0; c < L; ++c) {
+            const long long o = base + c * inner;
+            dx[o] += LOG ? g[o] - expf(y[o]) * s : y[o] * (g[o] - s);
+        }
+    }
+}
+
+int lane_geometry(const int* shape, int nd, int axis, long long* outer, int* L, long long* inner) {
+    NK_CHECK(nd >= 1 && nd <= NK_MAX_DIMS, "bad rank %d", nd);
+    NK_CHECK(axis >= 0 && axis < nd, "axis %d out of range for rank %d", axis, nd);
+    *outer = 1; *inner = 1;
+    for (int i = 0; i < axis; ++i) *outer *= shape[i];
+    for (int i = axis + 1; i < nd; ++i) *inner *= shape[i];
+    *L = shape[axis];
+    return NK_OK;
+}
+
+template <bool LOG>
+int softmax_fwd(nk_device* dev, const float* x, float* y, const int* shape, int nd, int axis) {
+    NK_USE(dev);
+    long long outer, inner; int L;
+    int rc = lane_geometry(shape, nd, axis, &outer, &L, &inner);
+    if (rc) return rc;
+    if (outer * inner * L == 0) return NK_OK;
+    NK_CHECK(x && y, "null pointer");
+    if (inner == 1) {
+        const bool vec = (L % 4 == 0) && al16(x) && al16(y) && L <= 2048;
+        if (vec) {
+            const int wpb = 4;
+            const dim3 grid((unsigned)((outer + wpb - 1) / wpb)), block(64 * wpb);
+            if (L <= 256) hipLaunchKernelGGL((softmax_fwd_row_kernel<1, LOG>), grid, block, 0, dev->compute, x, y, outer, L);
+            else if (L <= 512) hipLaunchKernelGGL((softmax_fwd_row_kernel<2, LOG>), grid, block, 0, dev->compute, x, y, outer, L);
+            else if (L <= 1024) hipLaunchKernelGGL((softmax_fwd_row_kernel<4, LOG>), grid, block, 0, dev->compute, x, y, outer, L);
+            else hipLaunchKernelGGL((softmax_fwd_row_kernel<8, LOG>), grid, block, 0, dev->compute, x, y, outer, L);
+        } else {
+            hipLaunchKernelGGL((softmax_fwd_block_kernel<LOG>), dim3((unsigned)outer), dim3(256), 0, dev->compute, x, y, L);
+        }
+    } else {
+        const long long lanes = outer * inner;
+        hipLaunchKernelGGL((softmax_fwd_strided_kernel<LOG>), dim3(nk_stream_grid((size_t)lanes, 256)), dim3(256), 0,
+                           dev->compute, x, y, lanes, L, inner);
+    }
+    NK_LAUNCH_CHECK();
+    return NK_OK;
+}
+
+template <bool LOG>
+int softmax_bwd(nk_device* dev, float* dx, const float* g, const float* y, const int* shape, int nd, int axis) {
+    NK_USE(dev);
+    long long outer, inner; int L;
+    int rc = lane_geometry(shape, nd, axis, &outer, &L, &inner);
+    if (rc) return rc;
+    if (outer * inner * L == 0) return NK_OK;
+    NK_CHECK(dx && g && y, "null pointer");
+    if (inner == 1) {
+        const bool vec = (L % 4 == 0) && al16(dx) && al16(g) && al16(y) && L <= 2048;
+        if (vec) {
+            const int wpb = 4;
+            const dim3 grid((unsigned)((outer + wpb - 1) / wpb)), block(64 * wpb);
+            if (L <= 256) hipLaunchKernelGGL((softmax_bwd_row_kernel<1, LOG>), grid, block, 0, dev->compute, dx, g, y, outer, L);
+            else if (L <= 512) hipLaunchKernelGGL((softmax_bwd_row_kernel<2, LOG>), grid, block, 0, dev->compute, dx, g, y, outer, L);
+            else if (L <= 1024) hipLaunchKernelGGL((softmax_bwd_row_kernel<4, LOG>), grid, block, 0, dev->compute, dx, g, y, outer, L);
+            else hipLaunchKernelGGL((softmax_bwd_row_kernel<8, LOG>), grid, block, 0, dev->compute, dx, g, y, outer, L);
+        } else {
+            hipLaunchKernelGGL((softmax_bwd_block_kernel<LOG>), dim3((unsigned)outer), dim3(256), 0, dev->compute, dx, g, y, L);
+        }
+    } else {
+        const long long lanes = outer * inner;
+        hipLaunchKernelGGL((softmax_bwd_strided_kernel<LOG>), dim3(nk_stream_grid((size_t)lanes, 256)), dim3(256), 0,
+                           dev->compute, dx, g, y, lanes, L, inner);
+    }
+    NK_LAUNCH_CHECK();
+    return NK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int nk_sum_fwd(nk_device* dev, const float* x, size_t n, float* out) { return full_reduce<0>(dev, x, nullptr, n, 0.f, out); }
+int nk_mean_fwd(nk_device* dev, const float* x, size_t n, float* out) { return full_reduce<0>(dev, x, nullptr, n, (float)n, out); }
+int nk_sum_bwd(nk_device* dev, float* dx, size_t n, const float* g) { return scalar_bwd<0>(dev, dx, g, nullptr, nullptr, n, 1.f); }
+int nk_mean_bwd(nk_device* dev, float* dx, size_t n, const float* g) { return scalar_bwd<1>(dev, dx, g, nullptr, nullptr, n, (float)n); }
+
+int nk_mse_fwd(nk_device* dev, const float* x, const float* target, size_t n, int reduction, float* out) {
+    NK_CHECK(reduction == NK_REDUCTION_SUM || reduction == NK_REDUCTION_MEAN, "unknown reduction %d", reduction);
+    NK_CHECK(n == 0 || target != nullptr, "null target");
+    return full_reduce<1>(dev, x, target, n, reduction == NK_REDUCTION_MEAN ? (float)n : 0.f, out);
+}
+
+int nk_mse_bwd(nk_device* dev, float* dx, const float* g, const float* x, const float* target, size_t n, int reduction) {
+    NK_CHECK(reduction == NK_REDUCTION_SUM || reduction == NK_REDUCTION_MEAN, "unknown reduction %d", reduction);
+    NK_CHECK(n == 0 || (x && target), "null input/target");
+    return reduction == NK_REDUCTION_MEAN ? scalar_bwd<2>(dev, dx, g, x, target, n, (float)n)
+                                          : scalar_bwd<3>(dev, dx, g, x, target, n, 1.f);
+}
+
+int nk_softmax_fwd(nk_device* dev, const float* x, float* y, const int* shape, int nd, int axis) {
+    return softmax_fwd<false>(dev, x, y, shape, nd, axis);
+}
+int nk_softmax_bwd(nk_device* dev, float* dx, const float* g, const float* y, const int* shape, int nd, int axis) {
+    return softmax_bwd<false>(dev, dx, g, y, shape, nd, axis);
+}
+int nk_log_softmax_fwd(nk_device* dev, const float* x, float* y, const int* shape, int nd, int axis) {
+    return softmax_fwd<true>(dev, x, y, shape, nd, axis);
+}
+int nk_log_softmax_bwd(nk_device* dev, float* dx, const float* g, const float* y, const int* shape, int nd, int axis) {
+    return softmax_bwd<true>(dev, dx, g, y, shape, nd, axis);
+}
+
+}  // extern "C"

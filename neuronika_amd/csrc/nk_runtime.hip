@@ -1,0 +1,184 @@
+// Device / memory / event entry points of the C ABI (include/neuronika_hip.h).
+// Mirrors the role of the reference's accelerator template: `Device::new`
+// (neuronika-variable/src/cuda/device.rs:34-58) and `CuArray::{zeroed,from_slice,as_ndarray}`
+// (cuda/cuarray.rs:35-117) — re-designed for HIP: two explicit streams per device (compute +
+// communication), stream-ordered zero-fill, no library handles.
+#include "nk_common.h"
+
+static thread_local char g_err[512] = "";
+
+void nk_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int nk_fail_hip(hipError_t e, const char* what, const char* file, int line) {
+    nk_set_error("HIP error %d (%s) in `%s` at %s:%d", (int)e, hipGetErrorString(e), what, file, line);
+    return e == hipErrorOutOfMemory ? NK_ERR_OOM : NK_ERR_HIP;
+}
+
+int nk_workspace(nk_device* dev, size_t bytes, void** out) {
+    if (bytes > dev->workspace_bytes) {
+        size_t want = bytes < (size_t(64) << 20) ? (size_t(64) << 20) : bytes;
+        if (dev->workspace) {
+            NK_HIP(hipDeviceSynchronize());
+            NK_HIP(hipFree(dev->workspace));
+            dev->workspace = nullptr;
+            dev->workspace_bytes = 0;
+        }
+        NK_HIP(hipMalloc(&dev->workspace, want));
+        dev->workspace_bytes = want;
+    }
+    *out = dev->workspace;
+    return NK_OK;
+}
+
+extern "C" {
+
+const char* nk_last_error(void) { return g_err; }
+const char* nk_version(void) { return "neuronika_hip 0.1 (gfx950)"; }
+
+int nk_device_count(int* out) {
+    NK_CHECK(out != nullptr, "null out");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { (void)hipGetLastError(); n = 0; }
+    *out = n;
+    return NK_OK;
+}
+
+int nk_device_create(int idx, nk_device** out) {
+    NK_CHECK(out != nullptr, "null out");
+    int n = 0;
+    NK_HIP(hipGetDeviceCount(&n));
+    NK_CHECK(idx >= 0 && idx < n, "device index %d out of range (%d devices)", idx, n);
+    NK_HIP(hipSetDevice(idx));
+    nk_device* d = new nk_device();
+    d->idx = idx;
+    NK_HIP(hipStreamCreateWithFlags(&d->compute, hipStreamNonBlocking));
+    NK_HIP(hipStreamCreateWithFlags(&d->comm, hipStreamNonBlocking));
+    NK_HIP(hipEventCreateWithFlags(&d->fork, hipEventDisableTiming));
+    NK_HIP(hipEventCreateWithFlags(&d->join, hipEventDisableTiming));
+    hipDeviceProp_t prop;
+    NK_HIP(hipGetDeviceProperties(&prop, idx));
+    d->num_cus = prop.multiProcessorCount;
+    *out = d;
+    return NK_OK;
+}
+
+int nk_device_destroy(nk_device* dev) {
+    if (!dev) return NK_OK;
+    NK_HIP(hipSetDevice(dev->idx));
+    NK_HIP(hipDeviceSynchronize());
+    if (dev->workspace) (void)hipFree(dev->workspace);
+    (void)hipEventDestroy(dev->fork);
+    (void)hipEventDestroy(dev->join);
+    (void)hipStreamDestroy(dev->compute);
+    (void)hipStreamDestroy(dev->comm);
+    delete dev;
+    return NK_OK;
+}
+
+int nk_device_sync(nk_device* dev) {
+    NK_USE(dev);
+    NK_HIP(hipStreamSynchronize(dev->compute));
+    NK_HIP(hipStreamSynchronize(dev->comm));
+    return NK_OK;
+}
+
+int nk_device_index(const nk_device* dev) { return dev ? dev->idx : -1; }
+void* nk_stream_compute(nk_device* dev) { return dev ? (void*)dev->compute : nullptr; }
+void* nk_stream_comm(nk_device* dev) { return dev ? (void*)dev->comm : nullptr; }
+
+int nk_alloc_zeroed(nk_device* dev, size_t n, float** out) {
+    NK_USE(dev);
+    NK_CHECK(out != nullptr, "null out");
+    void* p = nullptr;
+    size_t bytes = (n ? n : 1) * sizeof(float);
+    NK_HIP(hipMalloc(&p, bytes));
+    NK_HIP(hipMemsetAsync(p, 0, bytes, dev->compute));
+    *out = (float*)p;
+    return NK_OK;
+}
+
+int nk_free(nk_device* dev, float* ptr) {
+    NK_USE(dev);
+    if (ptr) NK_HIP(hipFree(ptr));
+    return NK_OK;
+}
+
+int nk_upload(nk_device* dev, float* dst, const float* host_src, size_t n) {
+    NK_USE(dev);
+    if (n == 0) return NK_OK;
+    NK_CHECK(dst && host_src, "null pointer in nk_upload");
+    NK_HIP(hipMemcpyAsync(dst, host_src, n * sizeof(float), hipMemcpyHostToDevice, dev->compute));
+    // pageable host memory: the copy has been staged when the call returns, but keep the
+    // contract simple for the host (the reference's from_slice is synchronous too).
+    NK_HIP(hipStreamSynchronize(dev->compute));
+    return NK_OK;
+}
+
+int nk_download(nk_device* dev, float* host_dst, const float* src, size_t n) {
+    NK_USE(dev);
+    if (n == 0) return NK_OK;
+    NK_CHECK(host_dst && src, "null pointer in nk_download");
+    NK_HIP(hipMemcpyAsync(host_dst, src, n * sizeof(float), hipMemcpyDeviceToHost, dev->compute));
+    NK_HIP(hipStreamSynchronize(dev->compute));
+    return NK_OK;
+}
+
+int nk_copy(nk_device* dev, float* dst, const float* src, size_t n) {
+    NK_USE(dev);
+    if (n == 0) return NK_OK;
+    NK_HIP(hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, dev->compute));
+    return NK_OK;
+}
+
+int nk_event_create(nk_device* dev, nk_event** out) {
+    NK_USE(dev);
+    NK_CHECK(out != nullptr, "null out");
+    nk_event* e = new nk_event{dev, nullptr};
+    NK_HIP(hipEventCreate(&e->ev));
+    *out = e;
+    return NK_OK;
+}
+
+int nk_event_destroy(nk_event* ev) {
+    if (!ev) return NK_OK;
+    (void)hipSetDevice(ev->dev->idx);
+    (void)hipEventDestroy(ev->ev);
+    delete ev;
+    return NK_OK;
+}
+
+int nk_event_record(nk_event* ev, int on_comm_stream) {
+    NK_CHECK(ev != nullptr, "null event");
+    NK_USE(ev->dev);
+    NK_HIP(hipEventRecord(ev->ev, on_comm_stream ? ev->dev->comm : ev->dev->compute));
+    return NK_OK;
+}
+
+int nk_event_sync(nk_event* ev) {
+    NK_CHECK(ev != nullptr, "null event");
+    NK_USE(ev->dev);
+    NK_HIP(hipEventSynchronize(ev->ev));
+    return NK_OK;
+}
+
+int nk_event_elapsed_ms(nk_event* start, nk_event* stop, float* ms) {
+    NK_CHECK(start && stop && ms, "null argument");
+    NK_USE(start->dev);
+    NK_HIP(hipEventElapsedTime(ms, start->ev, stop->ev));
+    return NK_OK;
+}
+
+int nk_stream_wait_event(nk_device* dev, int on_comm_stream, nk_event* ev) {
+    NK_USE(dev);
+    NK_CHECK(ev != nullptr, "null event");
+    NK_HIP(hipStreamWaitEvent(on_comm_stream ? dev->comm : dev->compute, ev->ev, 0));
+    return NK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,45 @@
+"""CPU checks of the drop-in boundary: the C-ABI library builds, loads, and exports every
+symbol include/neuronika_hip.h declares (no compute calls: there is no GPU here)."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    src = open(os.path.join(ROOT, "include", "neuronika_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(nk_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from neuronika_amd import capi
+    syms = header_symbols()
+    assert len(syms) > 60
+    missing = [s for s in syms if not hasattr(capi.lib, s)]
+    assert not missing, f"declared in the header but not exported: {missing}"
+    # and the ctypes table binds exactly the header's functions
+    assert sorted(capi.EXPORTED) == syms
+
+
+def test_no_gpu_means_loud_failure():
+    from neuronika_amd import capi
+    if capi.device_count() > 0:
+        pytest.skip("GPU present")
+    with pytest.raises(capi.NeuronikaHipError):
+        capi.Device(0)
+
+
+def test_product_path_does_not_import_oracle():
+    """The oracle is test infrastructure: nothing under neuronika_amd/ or include/ may use it."""
+    bad = []
+    for base in ("neuronika_amd", "include"):
+        for dp, _, fs in os.walk(os.path.join(ROOT, base)):
+            for f in fs:
+                if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp")):
+                    txt = open(os.path.join(dp, f), errors="ignore").read()
+                    if re.search(r"^\s*(from|import)\s+oracle|neuronika_oracle", txt, re.M):
+                        bad.append(os.path.join(dp, f))
+    assert not bad, bad

@@ -1,0 +1,519 @@
+"""GPU parity tests: every C-ABI entry point of the hot path against the CPU oracle, on the
+reference's own golden vectors and on seeded random inputs.  All calls go through the C ABI
+(neuronika_amd.capi -> libneuronika_hip.so); there is no fallback path.
+
+Tolerance policy:
+  * reference fixtures: the reference's own |d| <= 4.88e-4 (utils.rs:500); exact equality for
+    the integer-valued convolution fixtures and for data movement / masks;
+  * random contractions of length K: err_gpu <= max(2*err_cpu32, 1e-6*K*max|a|*max|b|), both
+    measured against the f64 oracle;
+  * elementwise / softmax: rtol 1e-5, atol 1e-6.
+"""
+import numpy as np
+import pytest
+
+from oracle import neuronika_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+F16_EPSILON = 4.88e-4
+
+
+def capi():
+    from neuronika_amd import capi as c
+    return c
+
+
+def f32(v, shape=None):
+    a = np.asarray(v, dtype=np.float32)
+    return a.reshape(shape) if shape is not None else a
+
+
+def rnd(seed, shape, lo=0.0, hi=1.0):
+    return (np.random.default_rng(seed).random(shape, dtype=np.float32) * (hi - lo) + lo).astype(np.float32)
+
+
+def close(a, b, rtol=1e-5, atol=1e-6):
+    np.testing.assert_allclose(np.asarray(a), np.asarray(b), rtol=rtol, atol=atol)
+
+
+def contraction_ok(gpu, cpu32, ref64, K, amax, bmax):
+    err_gpu = np.abs(gpu.astype(np.float64) - ref64).max()
+    err_cpu = np.abs(cpu32.astype(np.float64) - ref64).max()
+    bound = max(2 * err_cpu, 1e-6 * K * amax * bmax)
+    assert err_gpu <= bound, (err_gpu, err_cpu, bound)
+
+
+# ------------------------------------------------------------------------------ golden: conv
+CONV = ["conv1d", "conv2d", "conv3d", "conv1d_strided", "conv2d_strided", "conv3d_strided",
+        "conv1d_dilated", "conv2d_dilated", "conv3d_dilated",
+        "grouped_conv1d", "grouped_conv2d", "grouped_conv3d"]
+
+
+@pytest.mark.parametrize("name", CONV)
+def test_conv_golden_exact(dev, golden, name):
+    c = capi()
+    case = next(k for k in golden["convolution"] if k["name"] == name)
+    x = np.arange(case["input"]["arange"], dtype=np.float32).reshape(case["input"]["shape"])
+    w = np.ones(case["kernel"]["ones"], dtype=np.float32)
+    s, d, g = case["stride"], case["dilation"], case["groups"]
+    oshape = O.conv_out_shape(x.shape, w.shape, s, d)
+    X, W, Y = dev.array(x), dev.array(w), dev.full(oshape, 123.0)   # forward must OVERWRITE
+    c.conv_fwd(dev, X, W, Y, s, d, g)
+    assert np.array_equal(Y.numpy(), f32(case["output"], oshape)), case["cite"]
+    G = dev.full(oshape, 1.0)
+    DX, DW = dev.zeros(x.shape), dev.zeros(w.shape)
+    c.conv_bwd_input(dev, DX, G, W, s, d, g)
+    c.conv_bwd_kernel(dev, DW, G, X, s, d, g)
+    assert np.array_equal(DX.numpy(), f32(case["input_grad"], x.shape)), case["cite"]
+    assert np.array_equal(DW.numpy(), f32(case["kernel_grad"], w.shape)), case["cite"]
+    c.conv_bwd_input(dev, DX, G, W, s, d, g)      # backward ACCUMULATES
+    c.conv_bwd_kernel(dev, DW, G, X, s, d, g)
+    assert np.array_equal(DX.numpy(), 2 * f32(case["input_grad"], x.shape))
+    assert np.array_equal(DW.numpy(), 2 * f32(case["kernel_grad"], w.shape))
+
+
+CONV_RANDOM = [
+    # x shape, w shape, stride, dilation, groups
+    ((2, 8, 10, 10), (16, 8, 3, 3), (1, 1), (1, 1), 1),
+    ((3, 6, 11, 9), (8, 3, 3, 2), (2, 1), (1, 2), 2),
+    ((2, 4, 20), (6, 4, 5), (3,), (2,), 1),
+    ((1, 4, 6, 7, 8), (4, 2, 2, 3, 2), (1, 2, 1), (2, 1, 2), 2),
+    ((4, 130, 9, 9), (140, 130, 3, 3), (1, 1), (1, 1), 1),       # > one 128 tile in M and K
+    ((2, 64, 16, 16), (128, 64, 3, 3), (1, 1), (1, 1), 1),        # aligned fast paths (C3-shaped)
+]
+
+
+@pytest.mark.parametrize("xs,ws,s,d,g", CONV_RANDOM)
+def test_conv_random_vs_oracle(dev, xs, ws, s, d, g):
+    c = capi()
+    x, w = rnd(0, xs), rnd(1, ws, -1, 1)
+    oshape = O.conv_out_shape(xs, ws, s, d)
+    go = rnd(2, oshape)
+    K = int(np.prod(ws[1:]))
+    X, W, Y, G = dev.array(x), dev.array(w), dev.zeros(oshape), dev.array(go)
+    c.conv_fwd(dev, X, W, Y, s, d, g)
+    y32 = np.zeros(oshape, np.float32); O.convolution_forward(x, w, y32, s, d, g)
+    y64 = np.zeros(oshape, np.float64); O.convolution_forward(x.astype(np.float64), w.astype(np.float64), y64, s, d, g)
+    contraction_ok(Y.numpy(), y32, y64, K, 1.0, 1.0)
+    dx0, dw0 = rnd(3, xs), rnd(4, ws)    # non-zero initial gradients: `+=`
+    DX, DW = dev.array(dx0), dev.array(dw0)
+    c.conv_bwd_input(dev, DX, G, W, s, d, g)
+    c.conv_bwd_kernel(dev, DW, G, X, s, d, g)
+    dx32, dw32 = dx0.copy(), dw0.copy()
+    O.convolution_backward_input(dx32, go, w, s, d, g); O.convolution_backward_kernel(dw32, go, x, s, d, g)
+    dx64, dw64 = dx0.astype(np.float64), dw0.astype(np.float64)
+    O.convolution_backward_input(dx64, go.astype(np.float64), w.astype(np.float64), s, d, g)
+    O.convolution_backward_kernel(dw64, go.astype(np.float64), x.astype(np.float64), s, d, g)
+    contraction_ok(DX.numpy(), dx32, dx64, ws[0] // g * int(np.prod(ws[2:])), 1.0, 1.0)
+    contraction_ok(DW.numpy(), dw32, dw64, xs[0] * int(np.prod(oshape[2:])), 1.0, 1.0)
+
+
+def test_conv_arg_errors(dev):
+    c = capi()
+    X, W, Y = dev.zeros((1, 2, 4, 4)), dev.zeros((1, 2, 5, 5)), dev.zeros((1, 1, 1, 1))
+    with pytest.raises(c.NeuronikaHipError, match="kernel size can't be greater"):
+        c.conv_fwd(dev, X, W, Y, (1, 1), (1, 1), 1)
+    X, W = dev.zeros((3, 3, 10, 10)), dev.zeros((3, 3, 3, 3))
+    with pytest.raises(c.NeuronikaHipError, match="not divisible by groups"):
+        c.conv_fwd(dev, X, W, dev.zeros((3, 3, 8, 8)), (1, 1), (1, 1), 5)
+
+
+# ------------------------------------------------------------------------------ golden: matmul
+def test_mm_golden(dev, golden):
+    c = capi()
+    g = golden["nodes"]["mm_backward"]
+    right = np.linspace(10.0, 18.0, 9, dtype=np.float32).reshape(3, 3)
+    left = np.linspace(1.0, 9.0, 9, dtype=np.float32).reshape(3, 3)
+    G = dev.full((3, 3), 1.0)
+    DA, DB = dev.zeros((3, 3)), dev.zeros((3, 3))
+    R, L = dev.array(right), dev.array(left)
+    c.mm_bwd_left(dev, DA, G, R); close(DA.numpy(), f32(g["left_bwd"]["left_grad_once"], (3, 3)), 0, F16_EPSILON)
+    c.mm_bwd_left(dev, DA, G, R); close(DA.numpy(), f32(g["left_bwd"]["left_grad_twice"], (3, 3)), 0, F16_EPSILON)
+    c.mm_bwd_right(dev, DB, L, G); close(DB.numpy(), f32(g["right_bwd"]["right_grad_once"], (3, 3)), 0, F16_EPSILON)
+    c.mm_bwd_right(dev, DB, L, G); close(DB.numpy(), f32(g["right_bwd"]["right_grad_twice"], (3, 3)), 0, F16_EPSILON)
+    out = dev.full((3, 3), 7.0)
+    c.mm_fwd(dev, L, R, out); close(out.numpy(), left @ right, 0, F16_EPSILON)   # overwrite, beta = 0
+
+
+def test_mm_t_golden(dev, golden):
+    c = capi()
+    g = golden["nodes"]["mm_t_forward"]
+    A, B = dev.array(f32(g["left"], g["left_shape"])), dev.array(f32(g["right"], g["right_shape"]))
+    out = dev.full(g["out_shape"], -3.0)
+    c.mm_t_fwd(dev, A, B, out)
+    close(out.numpy(), f32(g["out"], g["out_shape"]), 0, F16_EPSILON)
+    lit = golden["nodes"]["mm_t_backward"]["literals"]
+    A, B, G = dev.array(f32(lit[2], (3, 3))), dev.array(f32(lit[3], (2, 3))), dev.array(f32(lit[4], (3, 2)))
+    DA, DB = dev.zeros((3, 3)), dev.zeros((2, 3))
+    c.mm_t_bwd_left(dev, DA, G, B); c.mm_t_bwd_right(dev, DB, G, A)
+    close(DA.numpy(), f32(lit[6], (3, 3)), 0, F16_EPSILON); close(DB.numpy(), f32(lit[7], (2, 3)), 0, F16_EPSILON)
+    c.mm_t_bwd_left(dev, DA, G, B); c.mm_t_bwd_right(dev, DB, G, A)
+    close(DA.numpy(), f32(lit[8], (3, 3)), 0, F16_EPSILON); close(DB.numpy(), f32(lit[9], (2, 3)), 0, F16_EPSILON)
+
+
+GEMM_SHAPES = [(3, 5, 7), (257, 131, 77), (128, 128, 32), (256, 384, 160), (64, 200, 1000), (128, 128, 4096),
+               (1, 1, 1), (130, 4, 33)]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_sgemm_random(dev, M, N, K, ta, tb):
+    """Asymmetric random operands (a transposed C-write or operand would not pass)."""
+    c = capi()
+    a = rnd(10, (K, M) if ta else (M, K), -1, 1)
+    b = rnd(11, (N, K) if tb else (K, N), -1, 1)
+    c0 = rnd(12, (M, N))
+    opa, opb = (a.T if ta else a), (b.T if tb else b)
+    A, B, Cd = dev.array(a), dev.array(b), dev.array(c0)
+    c.sgemm(dev, ta, tb, M, N, K, 1.0, A, a.shape[1], B, b.shape[1], 0.0, Cd, N)
+    ref64 = opa.astype(np.float64) @ opb.astype(np.float64)
+    contraction_ok(Cd.numpy(), opa @ opb, ref64, K, 1.0, 1.0)
+    c.sgemm(dev, ta, tb, M, N, K, 0.5, A, a.shape[1], B, b.shape[1], 1.0, Cd, N)   # accumulate
+    contraction_ok(Cd.numpy(), (opa @ opb) * 1.5, ref64 * 1.5, K, 1.5, 1.0)
+
+
+def test_sgemm_batched_strided(dev):
+    """Two-level batch with the attention strides: Q_bh is a strided view of (B*S, H*dh)."""
+    c = capi()
+    B_, S, H, dh = 2, 96, 3, 32
+    d = H * dh
+    q, k = rnd(20, (B_ * S, d), -1, 1), rnd(21, (B_ * S, d), -1, 1)
+    Q, Kd, Sc = dev.array(q), dev.array(k), dev.zeros((B_ * H, S, S))
+    c.sgemm_batched(dev, 0, 1, S, S, dh, 1.0, Q, d, S * d, dh, Kd, d, S * d, dh, 0.0, Sc, S, H * S * S, S * S, B_, H)
+    qh = q.reshape(B_, S, H, dh).transpose(0, 2, 1, 3).reshape(B_ * H, S, dh).astype(np.float64)
+    kh = k.reshape(B_, S, H, dh).transpose(0, 2, 1, 3).reshape(B_ * H, S, dh).astype(np.float64)
+    ref = qh @ kh.transpose(0, 2, 1)
+    contraction_ok(Sc.numpy(), ref.astype(np.float32), ref, dh, 1.0, 1.0)
+
+
+def test_sgemm_large_rowsum_identity(dev):
+    """Size-independent check at the BASELINE size (4096^2): (A.B).1 == A.(B.1)."""
+    c = capi()
+    n = 4096
+    a, b = rnd(0, (n, n)), rnd(1, (n, n))
+    A, B, Cd = dev.array(a), dev.array(b), dev.zeros((n, n))
+    for ta, tb in ((0, 0), (0, 1), (1, 0)):
+        c.sgemm(dev, ta, tb, n, n, n, 1.0, A, n, B, n, 0.0, Cd, n)
+        opa = (a.T if ta else a).astype(np.float64)
+        opb = (b.T if tb else b).astype(np.float64)
+        got = Cd.numpy().astype(np.float64)
+        want_rows = opa @ opb.sum(axis=1)
+        np.testing.assert_allclose(got.sum(axis=1), want_rows, rtol=2e-6)
+        want_cols = opa.sum(axis=0) @ opb
+        np.testing.assert_allclose(got.sum(axis=0), want_cols, rtol=2e-6)
+        # spot-check 64 entries exactly against f64 dot products
+        rng = np.random.default_rng(5)
+        for i, j in zip(rng.integers(0, n, 64), rng.integers(0, n, 64)):
+            assert abs(got[i, j] - opa[i] @ opb[:, j]) <= 1e-6 * n
+
+
+# ------------------------------------------------------------------------------ binaries
+BCAST = [((64, 96), (96,)), ((96,), (64, 96)), ((2, 2, 3), (1, 3)), ((1, 3), (2, 2, 3)), ((4, 8, 5, 6), (8, 1, 1)),
+         ((7, 5), ()), ((33, 1), (1, 17)), ((2, 3, 1, 5, 2), (3, 4, 1, 2)), ((512, 1024), (512, 1024)), ((5, 7), (5, 7))]
+
+
+@pytest.mark.parametrize("ls,rs", BCAST)
+@pytest.mark.parametrize("op", ["add", "sub", "mul", "div"])
+def test_binary_fwd_bwd(dev, op, ls, rs):
+    c = capi()
+    l, r = rnd(1, ls, 0.5, 1.5), rnd(2, rs, 0.5, 1.5)
+    oshape = O.cobroadcast(ls, rs)
+    L, R, OUT = dev.array(l), dev.array(r), dev.full(oshape, 9.0)
+    c.binary_fwd(dev, op, OUT, L, R)
+    want = np.zeros(oshape, np.float32); O.binary_forward(op, l, r, want)
+    close(OUT.numpy(), want)
+    g = rnd(3, oshape)
+    G = dev.array(g)
+    dl0, dr0 = rnd(4, ls), rnd(5, rs)
+    DL, DR = dev.array(dl0), dev.array(dr0)
+    c.binary_bwd_left(dev, op, DL, G, R)
+    c.binary_bwd_right(dev, op, DR, G, L, R)
+    dl, dr = dl0.astype(np.float64), dr0.astype(np.float64)
+    O.binary_backward_left(op, dl, g.astype(np.float64), l.astype(np.float64), r.astype(np.float64))
+    O.binary_backward_right(op, dr, g.astype(np.float64), l.astype(np.float64), r.astype(np.float64))
+    red_l = max(1, int(np.prod(oshape)) // max(1, l.size))
+    red_r = max(1, int(np.prod(oshape)) // max(1, r.size))
+    close(DL.numpy(), dl, rtol=1e-5, atol=2e-6 * red_l)
+    close(DR.numpy(), dr, rtol=1e-5, atol=2e-5 * red_r)
+
+
+def test_binary_reduction_golden(dev, golden):
+    """addition/test.rs:110-124, multiplication/test.rs:121-139, division/test.rs:121-207."""
+    c = capi()
+    n = golden["nodes"]
+
+    def pair(cs):
+        v = [k["value"] for k in cs["constructors"] if k["shape"] == [3]]
+        return v[-2], v[-1]
+
+    G = dev.full((3, 3), 1.0)
+    D = dev.zeros((3,))
+    once, twice = pair(n["addition_backward_left_reduction"])
+    c.binary_bwd_left(dev, "add", D, G); close(D.numpy(), np.full(3, once), 0, F16_EPSILON)
+    c.binary_bwd_left(dev, "add", D, G); close(D.numpy(), np.full(3, twice), 0, F16_EPSILON)
+    cs = n["multiplication_backward_left_reduction"]
+    once, twice = pair(cs)
+    R = dev.full((3, 3), cs["constructors"][0]["value"]); D = dev.zeros((3,))
+    c.binary_bwd_left(dev, "mul", D, G, R); close(D.numpy(), np.full(3, once), 0, F16_EPSILON)
+    c.binary_bwd_left(dev, "mul", D, G, R); close(D.numpy(), np.full(3, twice), 0, F16_EPSILON)
+    cs = n["division_backward_right_reduction"]
+    once, twice = pair(cs)
+    L = dev.full((3, 3), cs["constructors"][1]["value"]); R = dev.full((3,), cs["constructors"][2]["value"])
+    D = dev.zeros((3,))
+    c.binary_bwd_right(dev, "div", D, G, L, R); close(D.numpy(), np.full(3, once), 0, F16_EPSILON)
+    c.binary_bwd_right(dev, "div", D, G, L, R); close(D.numpy(), np.full(3, twice), 0, F16_EPSILON)
+
+
+def test_binary_incompatible_shapes(dev):
+    c = capi()
+    with pytest.raises(c.NeuronikaHipError, match="incompatible shape"):
+        c.binary_fwd(dev, "add", dev.zeros((2, 3)), dev.zeros((2, 3)), dev.zeros((2, 4)))
+
+
+def test_bias_column_reduction_full_size(dev):
+    """C4 bias gradient: (4096,4096) -> (4096); checked against f64 column sums."""
+    c = capi()
+    g = rnd(7, (4096, 4096), -1, 1)
+    G, D = dev.array(g), dev.zeros((4096,))
+    c.unbroadcast_add(dev, D, G)
+    close(D.numpy(), g.astype(np.float64).sum(0), rtol=1e-5, atol=1e-3)
+
+
+# ------------------------------------------------------------------------------ relu / sum / mean / mse
+def test_relu(dev, golden):
+    c = capi()
+    lit = golden["nodes"]["relu_forward"]["literals"]
+    X, Y = dev.array(f32(lit[0], (3, 3))), dev.full((3, 3), 5.0)
+    c.relu_fwd(dev, X, Y); assert np.array_equal(Y.numpy(), f32(lit[1], (3, 3)))
+    lit = golden["nodes"]["relu_backward"]["literals"]
+    DX, X, G = dev.array(f32(lit[0])), dev.array(f32(lit[1])), dev.array(f32(lit[2]))
+    c.relu_bwd(dev, DX, G, X); assert np.array_equal(DX.numpy(), f32(lit[4]))
+    c.relu_bwd(dev, DX, G, X); assert np.array_equal(DX.numpy(), f32(lit[5]))
+    x = rnd(1, (1000, 37), -1, 1); x[::7] = 0.0          # strict `>`: gradient at 0 is 0
+    g, d0 = rnd(2, x.shape, -1, 1), rnd(3, x.shape)
+    X, G, D, Y = dev.array(x), dev.array(g), dev.array(d0), dev.zeros(x.shape)
+    c.relu_fwd(dev, X, Y); c.relu_bwd(dev, D, G, X)
+    y = np.zeros_like(x); O.relu_forward(x, y); d = d0.copy(); O.relu_backward(d, g, x)
+    assert np.array_equal(Y.numpy(), y) and np.array_equal(D.numpy(), d)     # bit-exact mask
+
+
+def test_sum_mean_mse(dev, golden):
+    c = capi()
+    n = golden["nodes"]
+    out = dev.zeros(())
+    X = dev.array(f32(n["sum_forward"]["literals"][0], (3, 3)))
+    c.sum_fwd(dev, X, out); close(out.item(), n["sum_forward"]["scalars"][0], 0, F16_EPSILON)
+    c.mean_fwd(dev, X, out); close(out.item(), n["mean_forward"]["scalars"][0], 0, F16_EPSILON)
+    for op, fn in (("sum", c.sum_bwd), ("mean", c.mean_bwd)):
+        lit = n[f"{op}_backward"]["literals"]
+        D, G = dev.array(f32(lit[0], (10, 10))), dev.full((), n[f"{op}_backward"]["scalars"][0])
+        fn(dev, D, G); close(D.numpy(), f32(lit[1], (10, 10)), 0, F16_EPSILON)
+        fn(dev, D, G); close(D.numpy(), f32(lit[2], (10, 10)), 0, F16_EPSILON)
+    for red in ("mean", "sum"):
+        cs = n[f"squared_error_{red}"]; lit = cs["literals"]
+        T, X = dev.array(f32(lit[0], (3, 3))), dev.array(f32(lit[1], (3, 3)))
+        c.mse_fwd(dev, X, T, out, red); close(out.item(), cs["scalars"][0], 0, F16_EPSILON)
+        D, G = dev.array(f32(lit[2], (3, 3))), dev.full((), cs["scalars"][1])
+        c.mse_bwd(dev, D, G, X, T, red); close(D.numpy(), f32(lit[3], (3, 3)), 0, F16_EPSILON)
+        c.mse_bwd(dev, D, G, X, T, red); close(D.numpy(), f32(lit[4], (3, 3)), 0, F16_EPSILON)
+    # large random: tolerance against f64
+    x, t = rnd(1, (4096, 1025)), rnd(2, (4096, 1025))
+    X, T = dev.array(x), dev.array(t)
+    c.sum_fwd(dev, X, out); close(out.item(), x.astype(np.float64).sum(), rtol=1e-6)
+    c.mean_fwd(dev, X, out); close(out.item(), x.astype(np.float64).mean(), rtol=1e-6)
+    c.mse_fwd(dev, X, T, out, "mean"); close(out.item(), ((x.astype(np.float64) - t) ** 2).mean(), rtol=1e-6)
+    D, G = dev.zeros(x.shape), dev.full((), 0.5)
+    c.mse_bwd(dev, D, G, X, T, "mean")
+    d = np.zeros_like(x); O.squared_error_backward(d, np.float32(0.5), x, t, "mean")
+    close(D.numpy(), d, rtol=1e-6, atol=1e-12)
+
+
+# ------------------------------------------------------------------------------ softmax
+@pytest.mark.parametrize("op", ["softmax", "logsoftmax"])
+def test_softmax_golden(dev, golden, op):
+    c = capi()
+    fwd = c.softmax_fwd if op == "softmax" else c.log_softmax_fwd
+    bwd = c.softmax_bwd if op == "softmax" else c.log_softmax_bwd
+    for which in ("rows", "columns"):
+        cs = golden["nodes"][f"{op}_forward_{which}"]
+        X, Y = dev.array(f32(cs["input"], cs["shape"])), dev.full(cs["shape"], 3.0)
+        fwd(dev, X, Y, cs["axis"]); close(Y.numpy(), f32(cs["out"], cs["shape"]), 0, F16_EPSILON)
+        b = golden["nodes"][f"{op}_backward_{which}"]; lit = b["literals"]
+        X, G, Y, D = dev.array(f32(lit[1], (3, 3))), dev.array(f32(lit[2], (3, 3))), dev.zeros((3, 3)), dev.array(f32(lit[0], (3, 3)))
+        fwd(dev, X, Y, b["axis"])
+        bwd(dev, D, G, Y, b["axis"]); close(D.numpy(), f32(lit[4], (3, 3)), 0, F16_EPSILON)
+        bwd(dev, D, G, Y, b["axis"]); close(D.numpy(), f32(lit[5], (3, 3)), 0, F16_EPSILON)
+
+
+@pytest.mark.parametrize("shape,axis", [((64, 1024), 1), ((33, 1000), 1), ((7, 3000), 1), ((5, 10), 1), ((300, 40), 0),
+                                        ((6, 50, 12), 1), ((4, 8, 256), 2), ((3, 2052), 1)])
+@pytest.mark.parametrize("op", ["softmax", "logsoftmax"])
+def test_softmax_random(dev, op, shape, axis):
+    c = capi()
+    fwd = c.softmax_fwd if op == "softmax" else c.log_softmax_fwd
+    bwd = c.softmax_bwd if op == "softmax" else c.log_softmax_bwd
+    ofwd = O.softmax_forward if op == "softmax" else O.log_softmax_forward
+    obwd = O.softmax_backward if op == "softmax" else O.log_softmax_backward
+    x, g, d0 = rnd(1, shape, -4, 4), rnd(2, shape, -1, 1), rnd(3, shape)
+    X, G, D, Y = dev.array(x), dev.array(g), dev.array(d0), dev.zeros(shape)
+    fwd(dev, X, Y, axis)
+    y = np.zeros(shape, np.float64); ofwd(x.astype(np.float64), y, axis)
+    close(Y.numpy(), y, rtol=1e-5, atol=1e-6)
+    if op == "softmax":   # index-like behaviour: arg-max of each lane is preserved exactly
+        assert np.array_equal(Y.numpy().argmax(axis), x.argmax(axis))
+    bwd(dev, D, G, Y, axis)
+    d = d0.astype(np.float64); obwd(d, g.astype(np.float64), Y.numpy().astype(np.float64), axis)
+    close(D.numpy(), d, rtol=1e-5, atol=2e-6)
+
+
+# ------------------------------------------------------------------------------ dropout
+def test_dropout(dev):
+    c = capi()
+    n = 100_003
+    x = rnd(1, (n,), 0.1, 1.0)
+    X, Y, NZ = dev.array(x), dev.full((n,), 5.0), dev.zeros((n,))
+    c.dropout_fwd(dev, X, Y, NZ, 1.0, True)                  # dropout/test.rs:57-68
+    assert np.array_equal(Y.numpy(), np.zeros(n, np.float32)) and np.array_equal(NZ.numpy(), np.zeros(n, np.float32))
+    c.dropout_fwd(dev, X, Y, NZ, 0.0, True)                  # :71-85
+    assert np.array_equal(Y.numpy(), x)
+    c.dropout_fwd(dev, X, Y, NZ, 0.5, False)                 # eval mode: copy
+    assert np.array_equal(Y.numpy(), x)
+    for p, seed, off in ((0.5, 7, 0), (0.1, 123456789012345, 1 << 33)):
+        c.dropout_fwd(dev, X, Y, NZ, p, True, seed, off)
+        noise = O.dropout_noise(n, p, seed, off)
+        assert np.array_equal(NZ.numpy(), noise)             # bit-exact keep/drop pattern
+        y = np.zeros_like(x); O.dropout_forward(x, y, noise, p, True)
+        assert np.array_equal(Y.numpy(), y)
+        assert np.all(Y.numpy() <= x / np.float32(1 - p) * (1 + 1e-6))   # :88-104 (<= 2x at p=.5)
+        g, d0 = rnd(2, (n,)), rnd(3, (n,))
+        G, D = dev.array(g), dev.array(d0)
+        c.dropout_bwd(dev, D, G, NZ, p, True)
+        d = d0.copy(); O.dropout_backward(d, g, noise, p, True)  # NOT divided by 1-p
+        assert np.array_equal(D.numpy(), d)
+    D = dev.zeros((n,)); G = dev.full((n,), 1.0)
+    c.dropout_bwd(dev, D, G, NZ, 0.0, True); assert np.array_equal(D.numpy(), np.ones(n, np.float32))  # :133-158
+    with pytest.raises(c.NeuronikaHipError, match="Wrong probability"):
+        c.dropout_fwd(dev, X, Y, NZ, 1.5, True)
+
+
+# ------------------------------------------------------------------------------ layout glue
+def test_pad_chunk_concat_transpose(dev, golden):
+    c = capi()
+    for mode in ("zero", "constant"):
+        cs = golden["nodes"][f"pad_{mode}_test"]
+        want = f32(cs["literals"][0], (7, 9))
+        base = np.arange(25, dtype=np.float32).reshape(1, 1, 5, 5)
+        X, Y = dev.array(base), dev.full((1, 1, 7, 9), -1.0)
+        c.pad_const_fwd(dev, X, Y, (1, 2), float(want[0, 0]))
+        assert np.array_equal(Y.numpy()[0, 0], want), cs["cite"]
+        D = dev.array(base)
+        c.pad_bwd(dev, D, Y, (1, 2))
+        assert np.array_equal(D.numpy(), 2 * base)
+    x = rnd(1, (3, 4, 9, 12)); y = np.zeros((3, 4, 11, 18), np.float32)
+    X, Y = dev.array(x), dev.zeros(y.shape)
+    c.pad_const_fwd(dev, X, Y, (1, 3), 0.25); O.pad_constant_forward(x, y, (1, 3), 0.25)
+    assert np.array_equal(Y.numpy(), y)
+    x3 = rnd(2, (2, 2, 3, 4, 5)); y3 = np.zeros((2, 2, 5, 4, 9), np.float32)
+    X3, Y3 = dev.array(x3), dev.zeros(y3.shape)
+    c.pad_const_fwd(dev, X3, Y3, (1, 0, 2), 0.0); O.pad_constant_forward(x3, y3, (1, 0, 2), 0.0)
+    assert np.array_equal(Y3.numpy(), y3)
+
+    lit = golden["nodes"]["chunk_forward_base_case"]["literals"]
+    xin = np.linspace(-4.0, 4.0, 9, dtype=np.float32).reshape(3, 3)
+    X = dev.array(xin)
+    for i in range(3):
+        Y = dev.zeros((1, 3)); c.chunk_fwd(dev, X, Y, i)
+        assert np.array_equal(Y.numpy(), f32(lit[i], (1, 3)))
+    lit = golden["nodes"]["chunk_backward_base_case"]["literals"]
+    G = dev.full((1, 3), 1.0)
+    for i in range(3):
+        D = dev.zeros((3, 3))
+        c.chunk_bwd(dev, D, G, i); assert np.array_equal(D.numpy(), f32(lit[2 * i], (3, 3)))
+        c.chunk_bwd(dev, D, G, i); assert np.array_equal(D.numpy(), f32(lit[2 * i + 1], (3, 3)))
+    x = rnd(3, (10, 64, 20))
+    X = dev.array(x)
+    for no in (0, 3, 7):
+        Y = dev.zeros((5, 16, 8)); c.chunk_fwd(dev, X, Y, no)
+        y = np.zeros((5, 16, 8), np.float32); O.chunk_forward(x, y, no)
+        assert np.array_equal(Y.numpy(), y)
+        D = dev.array(x); c.chunk_bwd(dev, D, Y, no)
+        d = x.copy(); O.chunk_backward(d, y, no)
+        assert np.array_equal(D.numpy(), d)
+
+    parts = [rnd(4, (3, 5, 8)), rnd(5, (3, 2, 8)), rnd(6, (3, 9, 8))]
+    out = np.zeros((3, 16, 8), np.float32); O.multi_concatenate_forward(parts, out, 1)
+    P, OUT = [dev.array(p) for p in parts], dev.zeros(out.shape)
+    c.concat_fwd(dev, P, OUT, 1); assert np.array_equal(OUT.numpy(), out)
+    d0 = [rnd(7 + i, p.shape) for i, p in enumerate(parts)]
+    DP = [dev.array(d) for d in d0]
+    c.concat_bwd(dev, DP, OUT, 1)
+    dd = [d.copy() for d in d0]; O.multi_concatenate_backward(dd, out, 1)
+    for a, b in zip(DP, dd):
+        assert np.array_equal(a.numpy(), b)
+
+    lit = golden["nodes"]["transpose_forward"]["literals"]
+    X, Y = dev.array(f32(lit[0], (3, 3))), dev.zeros((3, 3))
+    c.transpose_fwd(dev, X, Y); assert np.array_equal(Y.numpy(), f32(lit[1], (3, 3)))
+    for shape in ((70, 45), (3, 5, 7), (128, 256)):
+        x = rnd(9, shape); X, Y = dev.array(x), dev.zeros(shape[::-1])
+        c.transpose_fwd(dev, X, Y); assert np.array_equal(Y.numpy(), x.T)
+        d0 = rnd(10, shape); D = dev.array(d0)
+        c.transpose_bwd(dev, D, Y); assert np.array_equal(D.numpy(), d0 + x)
+
+    B_, S, H, dh = 2, 5, 3, 8
+    x = rnd(11, (B_ * S, H * dh))
+    X, Yh = dev.array(x), dev.zeros((B_ * H, S, dh))
+    c.split_heads_fwd(dev, X, Yh, B_, S, H, dh)
+    want = x.reshape(B_, S, H, dh).transpose(0, 2, 1, 3).reshape(B_ * H, S, dh)
+    assert np.array_equal(Yh.numpy(), want)
+    # ... which is exactly chunks((S, dh)) in ndarray order (var.rs:401-417)
+    for no in range(B_ * H):
+        t = np.zeros((S, dh), np.float32); O.chunk_forward(x, t, no)
+        assert np.array_equal(t, want[no])
+    D = dev.array(x); c.split_heads_bwd(dev, D, Yh, B_, S, H, dh); assert np.array_equal(D.numpy(), 2 * x)
+    Z = dev.zeros(x.shape); c.merge_heads_fwd(dev, Yh, Z, B_, S, H, dh); assert np.array_equal(Z.numpy(), x)
+    Dh = dev.array(want); c.merge_heads_bwd(dev, Dh, Z, B_, S, H, dh); assert np.array_equal(Dh.numpy(), 2 * want)
+
+
+# ------------------------------------------------------------------------------ optimizer (next row)
+def test_sgd_step(dev):
+    c = capi()
+    w, g = rnd(1, (1000,), -1, 1), rnd(2, (1000,), -1, 1)
+    W, G = dev.array(w), dev.array(g)
+    c.sgd_step(dev, W, G, None, lr=0.1, l2=0.01)
+    ww, gg = w.copy(), g.copy(); O.sgd_step(ww, gg, 0.1, penalty="l2", l2=0.01)
+    close(W.numpy(), ww, 1e-6, 1e-7); close(G.numpy(), gg, 1e-6, 1e-7)
+    V = dev.zeros((1000,)); vv = np.zeros(1000, np.float32)
+    for first in (True, False):
+        c.sgd_step(dev, W, G, V, lr=0.1, momentum=0.9, dampening=0.1, nesterov=True, first_step=first)
+        O.sgd_step(ww, gg, 0.1, vv, 0.9, 0.1, True, first)
+        close(W.numpy(), ww, 1e-6, 1e-7); close(V.numpy(), vv, 1e-6, 1e-7)
+
+
+# ------------------------------------------------------------------------------ composed MLP step
+def test_mlp_step_through_c_abi(dev):
+    """C1-shaped plumbing: the tape order of `Linear -> ReLU -> Linear -> MSE` issued as raw C-ABI
+    calls (the C++ tape mirror is covered in test_gpu_tape.py)."""
+    c = capi()
+    rng = np.random.default_rng(0)
+    n, din, dh, dout = 64, 3, 5, 1
+    x, t = rng.random((n, din), dtype=np.float32), rng.random((n, dout), dtype=np.float32)
+    w1, b1 = (rng.random((dh, din), dtype=np.float32) - .5), (rng.random(dh, dtype=np.float32) - .5)
+    w2, b2 = (rng.random((dout, dh), dtype=np.float32) - .5), (rng.random(dout, dtype=np.float32) - .5)
+    loss, grads = O.mlp_step(x, t, [(w1, b1), (w2, b2)])
+    X, T, W1, B1, W2, B2 = map(dev.array, (x, t, w1, b1, w2, b2))
+    Z1, H1, A1, Z2, H2, LOSS = dev.zeros((n, dh)), dev.zeros((n, dh)), dev.zeros((n, dh)), dev.zeros((n, dout)), dev.zeros((n, dout)), dev.zeros(())
+    c.mm_t_fwd(dev, X, W1, Z1); c.binary_fwd(dev, "add", H1, Z1, B1); c.relu_fwd(dev, H1, A1)
+    c.mm_t_fwd(dev, A1, W2, Z2); c.binary_fwd(dev, "add", H2, Z2, B2); c.mse_fwd(dev, H2, T, LOSS, "mean")
+    close(LOSS.item(), loss, 1e-5, 1e-6)
+    GL = dev.full((), 1.0)
+    dH2, dZ2, dB2, dW2, dA1, dH1, dZ1, dB1, dW1 = (dev.zeros(s) for s in ((n, dout), (n, dout), (dout,), (dout, dh), (n, dh), (n, dh), (n, dh), (dh,), (dh, din)))
+    c.mse_bwd(dev, dH2, GL, H2, T, "mean")
+    c.binary_bwd_left(dev, "add", dZ2, dH2); c.binary_bwd_right(dev, "add", dB2, dH2)
+    c.mm_t_bwd_left(dev, dA1, dZ2, W2); c.mm_t_bwd_right(dev, dW2, dZ2, A1)
+    c.relu_bwd(dev, dH1, dA1, H1)
+    c.binary_bwd_left(dev, "add", dZ1, dH1); c.binary_bwd_right(dev, "add", dB1, dH1)
+    c.mm_t_bwd_right(dev, dW1, dZ1, X)
+    close(dW1.numpy(), grads[0][0], 1e-4, 1e-6); close(dB1.numpy(), grads[0][1], 1e-4, 1e-6)
+    close(dW2.numpy(), grads[1][0], 1e-4, 1e-6); close(dB2.numpy(), grads[1][1], 1e-4, 1e-6)
