@@ -30,7 +30,8 @@ def f32(v, shape=None):
 
 
 def rnd(seed, shape, lo=0.0, hi=1.0):
-    return (np.random.default_rng(seed).random(shape, dtype=np.float32) * (hi - lo) + lo).astype(np.float32)
+    a = np.asarray(np.random.default_rng(seed).random(shape, dtype=np.float32), dtype=np.float32)
+    return np.asarray(a * np.float32(hi - lo) + np.float32(lo), dtype=np.float32).reshape(shape)
 
 
 def close(a, b, rtol=1e-5, atol=1e-6):
@@ -229,7 +230,7 @@ def test_binary_fwd_bwd(dev, op, ls, rs):
     DL, DR = dev.array(dl0), dev.array(dr0)
     c.binary_bwd_left(dev, op, DL, G, R)
     c.binary_bwd_right(dev, op, DR, G, L, R)
-    dl, dr = dl0.astype(np.float64), dr0.astype(np.float64)
+    dl, dr = np.array(dl0, dtype=np.float64), np.array(dr0, dtype=np.float64)   # 0-d stays an ndarray
     O.binary_backward_left(op, dl, g.astype(np.float64), l.astype(np.float64), r.astype(np.float64))
     O.binary_backward_right(op, dr, g.astype(np.float64), l.astype(np.float64), r.astype(np.float64))
     red_l = max(1, int(np.prod(oshape)) // max(1, l.size))
