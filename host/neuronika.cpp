@@ -1,0 +1,967 @@
+// Implementation of the host-side tape mirror (see neuronika.hpp).  Every node's forward() /
+// backward() body is ONE call into the C ABI (include/neuronika_hip.h), issued asynchronously
+// on the device's compute stream in tape order.
+#include "neuronika.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <random>
+
+namespace neuronika {
+
+void panic(const std::string& msg) { throw Panic(msg); }
+void check(int status) {
+    if (status != NK_OK) panic(nk_last_error());
+}
+size_t numel(const Shape& s) {
+    size_t n = 1;
+    for (int d : s) n *= (size_t)d;
+    return n;
+}
+
+// =================================================================================================
+// Device / HipArray / Gradient
+// =================================================================================================
+std::shared_ptr<Device> Device::create(int idx) {
+    std::shared_ptr<Device> d(new Device());
+    check(nk_device_create(idx, &d->h_));
+    d->idx_ = idx;
+    return d;
+}
+Device::~Device() {
+    if (!h_) return;
+    nk_device_sync(h_);
+    for (auto& kv : pool_)
+        for (float* p : kv.second) nk_free(h_, p);
+    nk_device_destroy(h_);
+}
+void Device::sync() const { check(nk_device_sync(h_)); }
+float* Device::alloc_zeroed(size_t n) {
+    auto it = pool_.find(n);
+    float* p = nullptr;
+    if (it != pool_.end() && !it->second.empty()) {
+        p = it->second.back();
+        it->second.pop_back();
+        check(nk_fill(h_, p, n, 0.f));
+    } else {
+        check(nk_alloc_zeroed(h_, n, &p));
+    }
+    in_use_ += n * sizeof(float);
+    return p;
+}
+void Device::release(float* p, size_t n) {
+    if (!p) return;
+    pool_[n].push_back(p);
+    in_use_ -= n * sizeof(float);
+}
+
+HipArray::HipArray(DevicePtr dev, Shape shape)
+    : dev_(std::move(dev)), shape_(std::move(shape)), len_(numel(shape_)), ptr_(dev_->alloc_zeroed(len_)) {}
+HipArray::~HipArray() { dev_->release(ptr_, len_); }
+std::shared_ptr<HipArray> HipArray::from_host(DevicePtr dev, const Shape& shape, const float* host) {
+    auto a = std::make_shared<HipArray>(std::move(dev), shape);
+    a->upload(host);
+    return a;
+}
+void HipArray::upload(const float* host) { check(nk_upload(dev_->raw(), ptr_, host, len_)); }
+void HipArray::download(float* host) const { check(nk_download(dev_->raw(), host, ptr_, len_)); }
+std::vector<float> HipArray::to_vec() const {
+    std::vector<float> v(len_);
+    download(v.data());
+    return v;
+}
+void HipArray::fill(float v) { check(nk_fill(dev_->raw(), ptr_, len_, v)); }
+
+Gradient::Gradient(DevicePtr dev, Shape shape)
+    : dev_(std::move(dev)), shape_(std::move(shape)), array_(std::make_shared<HipArray>(dev_, shape_)) {}
+HipArray& Gradient::borrow() const {
+    if (!array_)
+        panic("Trying to get a de-allocated gradient. Switch on the gradients first by using `.with_grad()`");
+    return *array_;
+}
+void Gradient::no_grad() { array_.reset(); }
+void Gradient::with_grad() {
+    if (!array_) array_ = std::make_shared<HipArray>(dev_, shape_);
+}
+
+// =================================================================================================
+// History
+// =================================================================================================
+template <class T>
+void History<T>::merge(const History& other) {
+    for (const Item& it : other.path_) {
+        bool present = false;
+        for (const Item& mine : path_)
+            if (mine.ptr == it.ptr) { present = true; break; }
+        if (!present) path_.push_back(it);
+    }
+    std::stable_sort(path_.begin(), path_.end(), [](const Item& a, const Item& b) { return a.order < b.order; });
+}
+template <class T>
+void History<T>::insert(const void* ptr, T op) {
+    path_.push_back(Item{ptr, path_.size(), std::move(op)});
+    buffer_->clear();
+}
+template <class T>
+std::vector<T> History<T>::to_vec() const {
+    std::vector<T> v;
+    v.reserve(path_.size());
+    for (const Item& it : path_) v.push_back(it.op);
+    return v;
+}
+template class History<ForwardEntry>;
+template class History<BackwardEntry>;
+
+// =================================================================================================
+// helpers
+// =================================================================================================
+namespace {
+
+nk_device* D(const Shared<HipArray>& a) { return a->device()->raw(); }
+Shared<HipArray> zeros_like(const Shared<HipArray>& a, Shape s) { return std::make_shared<HipArray>(a->device(), std::move(s)); }
+
+Shape cobroadcast(const Shape& l, const Shape& r) {  // utils.rs:97-125
+    const Shape& big = l.size() >= r.size() ? l : r;
+    const Shape& small = l.size() >= r.size() ? r : l;
+    Shape out = big;
+    const size_t off = big.size() - small.size();
+    for (size_t i = 0; i < small.size(); ++i) {
+        int& o = out[off + i];
+        if (o != small[i]) {
+            if (o == 1) o = small[i];
+            else if (small[i] != 1) panic("The two tensors have incompatible shape.");
+        }
+    }
+    return out;
+}
+
+// ---- forward nodes -------------------------------------------------------------------------------
+struct BinaryFwd : Forward {  // node/{addition,subtraction,multiplication,division}/mod.rs
+    int op;
+    Shared<HipArray> l, r, out;
+    BinaryFwd(int op, Shared<HipArray> l, Shared<HipArray> r, Shared<HipArray> out)
+        : op(op), l(std::move(l)), r(std::move(r)), out(std::move(out)) {}
+    void forward() const override {
+        check(nk_binary_fwd(D(out), op, out->ptr(), out->shape().data(), (int)out->shape().size(), l->ptr(),
+                            l->shape().data(), (int)l->shape().size(), r->ptr(), r->shape().data(),
+                            (int)r->shape().size()));
+    }
+};
+struct BinaryBwd : Backward {  // <Op>Backward{Left,Right}; either side may be absent
+    int op;
+    Shared<Gradient> lg, rg, g;
+    Shared<HipArray> l, r;
+    void backward() const override {
+        const HipArray& G = g->borrow();
+        if (lg) {
+            HipArray& d = lg->borrow();
+            check(nk_binary_bwd_left(D(l), op, d.ptr(), d.shape().data(), (int)d.shape().size(), G.ptr(),
+                                     G.shape().data(), (int)G.shape().size(), r->ptr(), r->shape().data(),
+                                     (int)r->shape().size()));
+        }
+        if (rg) {
+            HipArray& d = rg->borrow();
+            check(nk_binary_bwd_right(D(l), op, d.ptr(), d.shape().data(), (int)d.shape().size(), G.ptr(),
+                                      G.shape().data(), (int)G.shape().size(), l->ptr(), l->shape().data(),
+                                      (int)l->shape().size(), r->ptr()));
+        }
+    }
+    void targets(std::vector<const Gradient*>& out) const override {
+        if (lg) out.push_back(lg.get());
+        if (rg) out.push_back(rg.get());
+    }
+};
+
+enum class Unary { Relu, Softmax, LogSoftmax, Transpose, Sum, Mean };
+struct UnaryFwd : Forward {
+    Unary kind;
+    int axis;
+    Shared<HipArray> x, y;
+    UnaryFwd(Unary k, int axis, Shared<HipArray> x, Shared<HipArray> y) : kind(k), axis(axis), x(std::move(x)), y(std::move(y)) {}
+    void forward() const override {
+        const int nd = (int)x->shape().size();
+        switch (kind) {
+            case Unary::Relu: check(nk_relu_fwd(D(x), x->ptr(), y->ptr(), x->len())); break;
+            case Unary::Softmax: check(nk_softmax_fwd(D(x), x->ptr(), y->ptr(), x->shape().data(), nd, axis)); break;
+            case Unary::LogSoftmax: check(nk_log_softmax_fwd(D(x), x->ptr(), y->ptr(), x->shape().data(), nd, axis)); break;
+            case Unary::Transpose: check(nk_transpose_fwd(D(x), x->ptr(), y->ptr(), x->shape().data(), nd)); break;
+            case Unary::Sum: check(nk_sum_fwd(D(x), x->ptr(), x->len(), y->ptr())); break;
+            case Unary::Mean: check(nk_mean_fwd(D(x), x->ptr(), x->len(), y->ptr())); break;
+        }
+    }
+};
+struct UnaryBwd : Backward {
+    Unary kind;
+    int axis;
+    Shared<Gradient> dx, g;
+    Shared<HipArray> x, y;  // ReLU needs the input, (log)softmax the output
+    void backward() const override {
+        HipArray& d = dx->borrow();
+        const HipArray& G = g->borrow();
+        const int nd = (int)d.shape().size();
+        switch (kind) {
+            case Unary::Relu: check(nk_relu_bwd(D(x), d.ptr(), G.ptr(), x->ptr(), d.len())); break;
+            case Unary::Softmax: check(nk_softmax_bwd(D(y), d.ptr(), G.ptr(), y->ptr(), d.shape().data(), nd, axis)); break;
+            case Unary::LogSoftmax: check(nk_log_softmax_bwd(D(y), d.ptr(), G.ptr(), y->ptr(), d.shape().data(), nd, axis)); break;
+            case Unary::Transpose: check(nk_transpose_bwd(d.device()->raw(), d.ptr(), G.ptr(), d.shape().data(), nd)); break;
+            case Unary::Sum: check(nk_sum_bwd(d.device()->raw(), d.ptr(), d.len(), G.ptr())); break;
+            case Unary::Mean: check(nk_mean_bwd(d.device()->raw(), d.ptr(), d.len(), G.ptr())); break;
+        }
+    }
+    void targets(std::vector<const Gradient*>& out) const override { out.push_back(dx.get()); }
+};
+
+// MatMul family.  kind: 0 = mm, 1 = mm_t, 2 = batched mm over [B,*,*] tiles, 3 = batched mm_t
+struct MatMulFwd : Forward {
+    int kind;
+    Shared<HipArray> a, b, c;
+    MatMulFwd(int kind, Shared<HipArray> a, Shared<HipArray> b, Shared<HipArray> c)
+        : kind(kind), a(std::move(a)), b(std::move(b)), c(std::move(c)) {}
+    void forward() const override {
+        const Shape& as = a->shape();
+        const Shape& bs = b->shape();
+        if (kind == 0) check(nk_mm_fwd(D(a), a->ptr(), b->ptr(), c->ptr(), as[0], as[1], bs[1]));
+        else if (kind == 1) check(nk_mm_t_fwd(D(a), a->ptr(), b->ptr(), c->ptr(), as[0], as[1], bs[0]));
+        else if (kind == 2)  // C[b] (n,o) = A[b] (n,m) . B[b] (m,o)
+            check(nk_sgemm_batched(D(a), 0, 0, as[1], bs[2], as[2], 1.f, a->ptr(), as[2], (long long)as[1] * as[2], 0,
+                                   b->ptr(), bs[2], (long long)bs[1] * bs[2], 0, 0.f, c->ptr(), bs[2],
+                                   (long long)as[1] * bs[2], 0, as[0], 1));
+        else  // C[b] (n,o) = A[b] (n,m) . B[b] (o,m)^T
+            check(nk_sgemm_batched(D(a), 0, 1, as[1], bs[1], as[2], 1.f, a->ptr(), as[2], (long long)as[1] * as[2], 0,
+                                   b->ptr(), bs[2], (long long)bs[1] * bs[2], 0, 0.f, c->ptr(), bs[1],
+                                   (long long)as[1] * bs[1], 0, as[0], 1));
+    }
+};
+struct MatMulBwd : Backward {
+    int kind;
+    Shared<HipArray> a, b;
+    Shared<Gradient> da, db, g;  // da / db may be null
+    void backward() const override {
+        const HipArray& G = g->borrow();
+        const Shape& as = a->shape();
+        const Shape& bs = b->shape();
+        nk_device* dev = D(a);
+        if (kind == 0) {
+            if (da) check(nk_mm_bwd_left(dev, da->borrow().ptr(), G.ptr(), b->ptr(), as[0], as[1], bs[1]));
+            if (db) check(nk_mm_bwd_right(dev, db->borrow().ptr(), a->ptr(), G.ptr(), as[0], as[1], bs[1]));
+        } else if (kind == 1) {
+            if (da) check(nk_mm_t_bwd_left(dev, da->borrow().ptr(), G.ptr(), b->ptr(), as[0], as[1], bs[0]));
+            if (db) check(nk_mm_t_bwd_right(dev, db->borrow().ptr(), G.ptr(), a->ptr(), as[0], as[1], bs[0]));
+        } else if (kind == 2) {
+            const int B = as[0], n = as[1], m = as[2], o = bs[2];
+            if (da)  // dA[b] += G[b] . B[b]^T
+                check(nk_sgemm_batched(dev, 0, 1, n, m, o, 1.f, G.ptr(), o, (long long)n * o, 0, b->ptr(), o,
+                                       (long long)m * o, 0, 1.f, da->borrow().ptr(), m, (long long)n * m, 0, B, 1));
+            if (db)  // dB[b] += A[b]^T . G[b]
+                check(nk_sgemm_batched(dev, 1, 0, m, o, n, 1.f, a->ptr(), m, (long long)n * m, 0, G.ptr(), o,
+                                       (long long)n * o, 0, 1.f, db->borrow().ptr(), o, (long long)m * o, 0, B, 1));
+        } else {
+            const int B = as[0], n = as[1], m = as[2], o = bs[1];
+            if (da)  // dA[b] += G[b] . B[b]
+                check(nk_sgemm_batched(dev, 0, 0, n, m, o, 1.f, G.ptr(), o, (long long)n * o, 0, b->ptr(), m,
+                                       (long long)o * m, 0, 1.f, da->borrow().ptr(), m, (long long)n * m, 0, B, 1));
+            if (db)  // dB[b] += G[b]^T . A[b]
+                check(nk_sgemm_batched(dev, 1, 0, o, m, n, 1.f, G.ptr(), o, (long long)n * o, 0, a->ptr(), m,
+                                       (long long)n * m, 0, 1.f, db->borrow().ptr(), m, (long long)o * m, 0, B, 1));
+        }
+    }
+    void targets(std::vector<const Gradient*>& out) const override {
+        if (da) out.push_back(da.get());
+        if (db) out.push_back(db.get());
+    }
+};
+
+struct ConvFwd : Forward {  // node/convolution/mod.rs:296-355
+    Shared<HipArray> x, w, y;
+    std::vector<int> stride, dilation;
+    int groups;
+    void forward() const override {
+        check(nk_conv_fwd(D(x), (int)x->shape().size() - 2, x->ptr(), x->shape().data(), w->ptr(), w->shape().data(),
+                          y->ptr(), stride.data(), dilation.data(), groups));
+    }
+};
+struct ConvBwd : Backward {  // ConvolutionBackward{Input,Kernel}  :357-510
+    Shared<HipArray> x, w;
+    Shared<Gradient> dx, dw, g;  // dx may be null (input is a non-differentiable Var)
+    std::vector<int> stride, dilation;
+    int groups;
+    void backward() const override {
+        const HipArray& G = g->borrow();
+        const int nd = (int)x->shape().size() - 2;
+        if (dx)
+            check(nk_conv_bwd_input(D(x), nd, dx->borrow().ptr(), x->shape().data(), G.ptr(), w->ptr(),
+                                    w->shape().data(), stride.data(), dilation.data(), groups));
+        if (dw)
+            check(nk_conv_bwd_kernel(D(x), nd, dw->borrow().ptr(), w->shape().data(), G.ptr(), x->ptr(),
+                                     x->shape().data(), stride.data(), dilation.data(), groups));
+    }
+    void targets(std::vector<const Gradient*>& out) const override {
+        if (dx) out.push_back(dx.get());
+        if (dw) out.push_back(dw.get());
+    }
+};
+
+struct PadFwd : Forward {
+    Shared<HipArray> x, y;
+    std::vector<int> padding;
+    float value;
+    void forward() const override {
+        check(nk_pad_const_fwd(D(x), (int)x->shape().size() - 2, x->ptr(), x->shape().data(), y->ptr(), padding.data(), value));
+    }
+};
+struct PadBwd : Backward {
+    Shared<Gradient> dx, g;
+    std::vector<int> padding;
+    void backward() const override {
+        HipArray& d = dx->borrow();
+        check(nk_pad_bwd(d.device()->raw(), (int)d.shape().size() - 2, d.ptr(), d.shape().data(), g->borrow().ptr(), padding.data()));
+    }
+    void targets(std::vector<const Gradient*>& out) const override { out.push_back(dx.get()); }
+};
+
+struct DropoutFwd : Forward {  // node/dropout/mod.rs:17-79
+    Shared<HipArray> x, y, noise;
+    double p;
+    Shared<bool> status;
+    uint64_t seed;
+    Shared<uint64_t> calls;  // Philox offset advances on every forward (noise is resampled)
+    void forward() const override {
+        const uint64_t offset = (*calls) * ((x->len() + 3) / 4);
+        ++(*calls);
+        check(nk_dropout_fwd(D(x), x->ptr(), y->ptr(), noise->ptr(), x->len(), p, *status ? 1 : 0, seed, offset));
+    }
+};
+struct DropoutBwd : Backward {
+    Shared<Gradient> dx, g;
+    Shared<HipArray> noise;
+    double p;
+    Shared<bool> status;
+    void backward() const override {
+        HipArray& d = dx->borrow();
+        check(nk_dropout_bwd(d.device()->raw(), d.ptr(), g->borrow().ptr(), noise->ptr(), d.len(), p, *status ? 1 : 0));
+    }
+    void targets(std::vector<const Gradient*>& out) const override { out.push_back(dx.get()); }
+};
+
+struct ChunkFwd : Forward {
+    Shared<HipArray> x, y;
+    int chunk_no;
+    void forward() const override {
+        check(nk_chunk_fwd(D(x), x->ptr(), x->shape().data(), y->ptr(), y->shape().data(), (int)x->shape().size(), chunk_no));
+    }
+};
+struct ChunkBwd : Backward {
+    Shared<Gradient> dx, g;
+    int chunk_no;
+    void backward() const override {
+        HipArray& d = dx->borrow();
+        const HipArray& G = g->borrow();
+        check(nk_chunk_bwd(d.device()->raw(), d.ptr(), d.shape().data(), G.ptr(), G.shape().data(), (int)d.shape().size(), chunk_no));
+    }
+    void targets(std::vector<const Gradient*>& out) const override { out.push_back(dx.get()); }
+};
+
+struct CatFwd : Forward {  // node/multi_concatenate/mod.rs
+    std::vector<Shared<HipArray>> operands;
+    Shared<HipArray> out;
+    int axis;
+    void forward() const override {
+        int off = 0;
+        for (const auto& o : operands) {
+            check(nk_concat_fwd_part(D(out), o->ptr(), out->ptr(), out->shape().data(), (int)out->shape().size(), axis, off, o->shape()[axis]));
+            off += o->shape()[axis];
+        }
+    }
+};
+struct CatBwd : Backward {
+    std::vector<Shared<Gradient>> operands;
+    Shared<Gradient> g;
+    int axis;
+    void backward() const override {
+        const HipArray& G = g->borrow();
+        int off = 0;
+        for (const auto& o : operands) {
+            HipArray& d = o->borrow();
+            check(nk_concat_bwd_part(d.device()->raw(), d.ptr(), G.ptr(), G.shape().data(), (int)G.shape().size(), axis, off, d.shape()[axis]));
+            off += d.shape()[axis];
+        }
+    }
+    void targets(std::vector<const Gradient*>& out) const override {
+        for (const auto& o : operands) out.push_back(o.get());
+    }
+};
+
+struct HeadsFwd : Forward {
+    bool split;
+    Shared<HipArray> x, y;
+    int B, S, H, dh;
+    void forward() const override {
+        check(split ? nk_split_heads_fwd(D(x), x->ptr(), y->ptr(), B, S, H, dh) : nk_merge_heads_fwd(D(x), x->ptr(), y->ptr(), B, S, H, dh));
+    }
+};
+struct HeadsBwd : Backward {
+    bool split;
+    Shared<Gradient> dx, g;
+    int B, S, H, dh;
+    void backward() const override {
+        HipArray& d = dx->borrow();
+        check(split ? nk_split_heads_bwd(d.device()->raw(), d.ptr(), g->borrow().ptr(), B, S, H, dh)
+                    : nk_merge_heads_bwd(d.device()->raw(), d.ptr(), g->borrow().ptr(), B, S, H, dh));
+    }
+    void targets(std::vector<const Gradient*>& out) const override { out.push_back(dx.get()); }
+};
+
+struct MseFwd : Forward {  // node/squared_error/mod.rs:42-59
+    Shared<HipArray> x, t, out;
+    Reduction red;
+    void forward() const override { check(nk_mse_fwd(D(x), x->ptr(), t->ptr(), x->len(), (int)red, out->ptr())); }
+};
+struct MseBwd : Backward {
+    Shared<HipArray> x, t;
+    Shared<Gradient> dx, g;
+    Reduction red;
+    void backward() const override {
+        check(nk_mse_bwd(D(x), dx->borrow().ptr(), g->borrow().ptr(), x->ptr(), t->ptr(), x->len(), (int)red));
+    }
+    void targets(std::vector<const Gradient*>& out) const override { out.push_back(dx.get()); }
+};
+
+template <class Op>
+BackwardEntry entry(Shared<Op> op, Shared<Gradient> grad) {
+    return BackwardEntry{std::move(op), std::move(grad)};
+}
+
+Shape mm_shape(const Shape& a, const Shape& b, int kind) {  // utils.rs:46-55 `DotDim`
+    if (kind <= 1) {
+        if (a.size() != 2 || b.size() != 2) panic("mm: matrices expected");
+        const int inner_b = kind == 0 ? b[0] : b[1];
+        if (a[1] != inner_b) panic("Shapes are incompatible for matrix multiplication.");
+        return Shape{a[0], kind == 0 ? b[1] : b[0]};
+    }
+    if (a.size() != 3 || b.size() != 3 || a[0] != b[0]) panic("bmm: [B,n,m] x [B,*,*] expected");
+    const int inner_b = kind == 2 ? b[1] : b[2];
+    if (a[2] != inner_b) panic("Shapes are incompatible for matrix multiplication.");
+    return Shape{a[0], a[1], kind == 2 ? b[2] : b[1]};
+}
+
+Var matmul_var(int kind, const Var& a, const Var& b) {
+    History<ForwardEntry> h = a.history;
+    h.merge(b.history);
+    auto out = zeros_like(a.data, mm_shape(a.shape(), b.shape(), kind));
+    return Var::node(out, std::make_shared<MatMulFwd>(kind, a.data, b.data, out), std::move(h));
+}
+VarDiff matmul_diff(int kind, const Var& a, const Shared<Gradient>& da, const History<BackwardEntry>* ha, const Var& b,
+                    const Shared<Gradient>& db, const History<BackwardEntry>* hb) {
+    Var var = matmul_var(kind, a, b);
+    History<BackwardEntry> h;
+    if (ha) h = *ha;
+    if (hb) h.merge(*hb);
+    auto grad = std::make_shared<Gradient>(var.device(), var.shape());
+    auto op = std::make_shared<MatMulBwd>();
+    op->kind = kind; op->a = a.data; op->b = b.data; op->da = da; op->db = db; op->g = grad;
+    return VarDiff::node(std::move(var), grad, entry(op, grad), std::move(h));
+}
+
+Var binary_var(int op, const Var& l, const Var& r) {
+    History<ForwardEntry> h = l.history;
+    h.merge(r.history);
+    auto out = zeros_like(l.data, cobroadcast(l.shape(), r.shape()));
+    return Var::node(out, std::make_shared<BinaryFwd>(op, l.data, r.data, out), std::move(h));
+}
+VarDiff binary_diff(int op, const Var& l, const Shared<Gradient>& lg, const History<BackwardEntry>* lh, const Var& r,
+                    const Shared<Gradient>& rg, const History<BackwardEntry>* rh) {
+    Var var = binary_var(op, l, r);
+    History<BackwardEntry> h;
+    if (lh) h = *lh;
+    if (rh) h.merge(*rh);
+    auto grad = std::make_shared<Gradient>(var.device(), var.shape());
+    auto bw = std::make_shared<BinaryBwd>();
+    bw->op = op; bw->lg = lg; bw->rg = rg; bw->g = grad; bw->l = l.data; bw->r = r.data;
+    return VarDiff::node(std::move(var), grad, entry(bw, grad), std::move(h));
+}
+
+Var unary_var(Unary k, int axis, const Var& x, Shape out_shape) {
+    auto y = zeros_like(x.data, std::move(out_shape));
+    return Var::node(y, std::make_shared<UnaryFwd>(k, axis, x.data, y), x.history);
+}
+VarDiff unary_diff(Unary k, int axis, const VarDiff& x, Shape out_shape) {
+    Var var = unary_var(k, axis, x.var, std::move(out_shape));
+    auto grad = std::make_shared<Gradient>(var.device(), var.shape());
+    auto bw = std::make_shared<UnaryBwd>();
+    bw->kind = k; bw->axis = axis; bw->dx = x.grad; bw->g = grad; bw->x = x.var.data; bw->y = var.data;
+    return VarDiff::node(std::move(var), grad, entry(bw, grad), x.history);
+}
+
+void check_axis(const Shape& s, int axis) {
+    if (axis < 0 || axis >= (int)s.size()) panic("axis out of bounds");
+}
+
+Shape conv_out_shape(const Shape& in, const Shape& k, const std::vector<int>& stride, const std::vector<int>& dil, int groups) {
+    // check_conv_args / check_groups_args / conv_out_shape  utils.rs:207-237, 427-497
+    const int nd = (int)in.size() - 2;
+    if ((int)stride.size() != nd) panic("Invalid stride for " + std::to_string(nd) + "d conv.");
+    if ((int)dil.size() != nd) panic("Invalid dilation for " + std::to_string(nd) + "d conv.");
+    if (k.size() != in.size()) panic("Invalid kernel shape for " + std::to_string(nd) + "d conv");
+    if (in[1] % groups != 0) panic("In channels " + std::to_string(in[1]) + " is not divisible by groups " + std::to_string(groups));
+    if (k[0] % groups != 0) panic("Out channels " + std::to_string(k[0]) + " is not divisible by groups " + std::to_string(groups));
+    Shape out{in[0], k[0]};
+    for (int d = 0; d < nd; ++d) {
+        if (in[2 + d] < (k[2 + d] - 1) * dil[d] + 1) panic("The kernel size can't be greater than actual input size.");
+        out.push_back((in[2 + d] - dil[d] * (k[2 + d] - 1) - 1) / stride[d] + 1);
+    }
+    return out;
+}
+
+}  // namespace
+
+// =================================================================================================
+// Var
+// =================================================================================================
+Var Var::leaf(Shared<HipArray> array) {
+    Var v;
+    v.data = std::move(array);
+    return v;
+}
+Var Var::node(Shared<HipArray> data, Shared<Forward> op, History<ForwardEntry> h) {
+    const void* ptr = op.get();
+    h.insert(ptr, ForwardEntry{std::move(op), std::make_shared<bool>(false)});
+    Var v;
+    v.data = std::move(data);
+    v.history = std::move(h);
+    return v;
+}
+VarDiff Var::requires_grad() const { return VarDiff::leaf(*this, std::make_shared<Gradient>(device(), shape())); }
+void Var::forward() const {
+    auto& buffer = history.buffer_mut();
+    if (buffer.empty()) buffer = history.to_vec();
+    else
+        for (auto& e : buffer) *e.computed = false;
+    for (auto& e : buffer)
+        if (!*e.computed) {
+            e.op->forward();
+            *e.computed = true;
+        }
+}
+float Var::item() const {
+    if (data->len() != 1) panic("item(): not a scalar");
+    float v;
+    data->download(&v);
+    return v;
+}
+Var Var::sum() const { return unary_var(Unary::Sum, 0, *this, {}); }
+Var Var::mean() const { return unary_var(Unary::Mean, 0, *this, {}); }
+Var Var::relu() const { return unary_var(Unary::Relu, 0, *this, shape()); }
+Var Var::softmax(int axis) const { check_axis(shape(), axis); return unary_var(Unary::Softmax, axis, *this, shape()); }
+Var Var::log_softmax(int axis) const { check_axis(shape(), axis); return unary_var(Unary::LogSoftmax, axis, *this, shape()); }
+Var Var::t() const { return unary_var(Unary::Transpose, 0, *this, Shape(shape().rbegin(), shape().rend())); }
+Var Var::dropout(double p, Shared<bool> status) const {
+    if (!(p >= 0.0 && p <= 1.0)) panic("Wrong probability received: " + std::to_string(p) + ".");
+    auto op = std::make_shared<DropoutFwd>();
+    op->x = data; op->y = zeros_like(data, shape()); op->noise = zeros_like(data, shape());
+    op->p = p; op->status = std::move(status);
+    static uint64_t next_seed = 0x9E3779B97F4A7C15ull;
+    op->seed = next_seed; next_seed += 0x632BE59BD9B4E019ull;
+    op->calls = std::make_shared<uint64_t>(0);
+    auto y = op->y;
+    return Var::node(y, op, history);
+}
+std::vector<Var> Var::chunks(const Shape& chunk_size) const {
+    if (chunk_size.size() != shape().size()) panic("chunks: rank mismatch");
+    size_t n = 1;
+    for (size_t i = 0; i < chunk_size.size(); ++i) {
+        if (chunk_size[i] <= 0) panic("chunks: chunk size must be positive");
+        n *= (size_t)(shape()[i] / chunk_size[i]);
+    }
+    std::vector<Var> out;
+    for (size_t i = 0; i < n; ++i) {
+        auto op = std::make_shared<ChunkFwd>();
+        op->x = data; op->y = zeros_like(data, chunk_size); op->chunk_no = (int)i;
+        auto y = op->y;
+        out.push_back(Var::node(y, op, history));
+    }
+    return out;
+}
+Var Var::cat(const std::vector<Var>& variables, int axis) const {
+    check_axis(shape(), axis);
+    History<ForwardEntry> h = history;
+    auto op = std::make_shared<CatFwd>();
+    op->operands.push_back(data);
+    Shape s = shape();
+    for (const Var& v : variables) {
+        h.merge(v.history);
+        op->operands.push_back(v.data);
+        for (size_t i = 0; i < s.size(); ++i)
+            if ((int)i != axis && v.shape()[i] != s[i]) panic("cat: incompatible shapes");
+        s[axis] += v.shape()[axis];
+    }
+    op->axis = axis;
+    op->out = zeros_like(data, s);
+    auto y = op->out;
+    return Var::node(y, op, std::move(h));
+}
+Var Var::mse(const Var& target, Reduction reduction) const {
+    if (target.shape() != shape()) panic("mse: input and target shapes differ");
+    History<ForwardEntry> h = history;
+    h.merge(target.history);
+    auto op = std::make_shared<MseFwd>();
+    op->x = data; op->t = target.data; op->out = zeros_like(data, {}); op->red = reduction;
+    auto y = op->out;
+    return Var::node(y, op, std::move(h));
+}
+Var Var::pad(const std::vector<int>& padding, float value) const {
+    if (padding.size() + 2 != shape().size()) panic("pad: one padding per spatial dimension expected");
+    Shape s = shape();
+    for (size_t i = 0; i < padding.size(); ++i) s[2 + i] += 2 * padding[i];
+    auto op = std::make_shared<PadFwd>();
+    op->x = data; op->y = zeros_like(data, s); op->padding = padding; op->value = value;
+    auto y = op->y;
+    return Var::node(y, op, history);
+}
+Var Var::mm(const Var& rhs) const { return matmul_var(0, *this, rhs); }
+VarDiff Var::mm(const VarDiff& rhs) const { return matmul_diff(0, *this, nullptr, nullptr, rhs.var, rhs.grad, &rhs.history); }
+Var Var::mm_t(const Var& rhs) const { return matmul_var(1, *this, rhs); }
+VarDiff Var::mm_t(const VarDiff& rhs) const { return matmul_diff(1, *this, nullptr, nullptr, rhs.var, rhs.grad, &rhs.history); }
+Var Var::bmm(const Var& rhs) const { return matmul_var(2, *this, rhs); }
+Var Var::bmm_t(const Var& rhs) const { return matmul_var(3, *this, rhs); }
+Var Var::convolution(const Var& input, const std::vector<int>& stride, const std::vector<int>& dilation, int groups) const {
+    Shape kfull = shape();  // kernel (Cout, Cin/groups, k...) checked against the input
+    Shape kcheck = kfull;
+    kcheck[1] *= groups;
+    (void)kcheck;
+    Shape out = conv_out_shape(input.shape(), kfull, stride, dilation, groups);
+    History<ForwardEntry> h = history;
+    h.merge(input.history);
+    auto op = std::make_shared<ConvFwd>();
+    op->x = input.data; op->w = data; op->y = zeros_like(data, out); op->stride = stride; op->dilation = dilation; op->groups = groups;
+    auto y = op->y;
+    return Var::node(y, op, std::move(h));
+}
+static Var heads_var(bool split, const Var& x, int B, int S, int H, int dh) {
+    auto op = std::make_shared<HeadsFwd>();
+    op->split = split; op->x = x.data; op->B = B; op->S = S; op->H = H; op->dh = dh;
+    const Shape want = split ? Shape{B * S, H * dh} : Shape{B * H, S, dh};
+    if (x.shape() != want) panic("split/merge heads: unexpected input shape");
+    op->y = zeros_like(x.data, split ? Shape{B * H, S, dh} : Shape{B * S, H * dh});
+    auto y = op->y;
+    return Var::node(y, op, x.history);
+}
+Var Var::split_heads(int B, int S, int H, int dh) const { return heads_var(true, *this, B, S, H, dh); }
+Var Var::merge_heads(int B, int S, int H, int dh) const { return heads_var(false, *this, B, S, H, dh); }
+
+// =================================================================================================
+// VarDiff
+// =================================================================================================
+VarDiff VarDiff::leaf(Var var, Shared<Gradient> grad) {
+    VarDiff v;
+    v.var = std::move(var);
+    v.grad = std::move(grad);
+    return v;
+}
+VarDiff VarDiff::node(Var var, Shared<Gradient> grad, BackwardEntry op, History<BackwardEntry> h) {
+    const void* ptr = op.op.get();
+    h.insert(ptr, std::move(op));
+    VarDiff v;
+    v.var = std::move(var);
+    v.grad = std::move(grad);
+    v.history = std::move(h);
+    return v;
+}
+void VarDiff::zero_grad() const { grad->borrow().fill(0.f); }
+void VarDiff::forward() const {
+    var.forward();
+    auto& buffer = history.buffer_mut();
+    if (buffer.empty()) buffer = history.to_vec();
+}
+void VarDiff::backward(float seed, BackwardHook* hook) const {
+    if (var.history.len() != var.history.buffer_len()) panic("Perhaps you forgot to call .forward()?");
+    grad->borrow().fill(seed);
+    auto& buffer = history.buffer_mut();
+    if (!hook) {
+        for (auto it = buffer.rbegin(); it != buffer.rend(); ++it) it->op->backward();
+        return;
+    }
+    // a gradient is final once the last node (in reverse order) that accumulates into it ran
+    std::unordered_map<const Gradient*, size_t> last;
+    std::vector<const Gradient*> ts;
+    for (size_t i = 0; i < buffer.size(); ++i) {  // reverse execution order: index 0 runs last
+        ts.clear();
+        buffer[i].op->targets(ts);
+        for (const Gradient* g : ts)
+            if (!last.count(g)) last[g] = i;  // smallest index = last to run
+    }
+    for (size_t k = buffer.size(); k-- > 0;) {
+        buffer[k].op->backward();
+        ts.clear();
+        buffer[k].op->targets(ts);
+        for (const Gradient* g : ts)
+            if (last[g] == k) hook->grad_ready(g);
+    }
+}
+void VarDiff::no_grad() const {
+    auto& buffer = history.buffer_mut();
+    if (buffer.empty()) buffer = history.to_vec();
+    for (auto& e : buffer) e.grad->no_grad();
+}
+void VarDiff::with_grad() const {
+    auto& buffer = history.buffer_mut();
+    if (buffer.empty()) buffer = history.to_vec();
+    for (auto& e : buffer) e.grad->with_grad();
+}
+
+VarDiff VarDiff::sum() const { return unary_diff(Unary::Sum, 0, *this, {}); }
+VarDiff VarDiff::mean() const { return unary_diff(Unary::Mean, 0, *this, {}); }
+VarDiff VarDiff::relu() const { return unary_diff(Unary::Relu, 0, *this, shape()); }
+VarDiff VarDiff::softmax(int axis) const { check_axis(shape(), axis); return unary_diff(Unary::Softmax, axis, *this, shape()); }
+VarDiff VarDiff::log_softmax(int axis) const { check_axis(shape(), axis); return unary_diff(Unary::LogSoftmax, axis, *this, shape()); }
+VarDiff VarDiff::t() const { return unary_diff(Unary::Transpose, 0, *this, Shape(shape().rbegin(), shape().rend())); }
+VarDiff VarDiff::dropout(double p, Shared<bool> status) const {
+    Var v = var.dropout(p, status);
+    // the forward node owns the noise buffer; share it with the backward node (var.rs:375-393)
+    auto fwd = std::dynamic_pointer_cast<DropoutFwd>(v.history.to_vec().back().op);
+    auto g = std::make_shared<Gradient>(device(), shape());
+    auto bw = std::make_shared<DropoutBwd>();
+    bw->dx = grad; bw->g = g; bw->noise = fwd->noise; bw->p = p; bw->status = status;
+    return VarDiff::node(std::move(v), g, entry(bw, g), history);
+}
+std::vector<VarDiff> VarDiff::chunks(const Shape& chunk_size) const {
+    std::vector<Var> vs = var.chunks(chunk_size);
+    std::vector<VarDiff> out;
+    for (size_t i = 0; i < vs.size(); ++i) {
+        auto g = std::make_shared<Gradient>(device(), chunk_size);
+        auto bw = std::make_shared<ChunkBwd>();
+        bw->dx = grad; bw->g = g; bw->chunk_no = (int)i;
+        out.push_back(VarDiff::node(std::move(vs[i]), g, entry(bw, g), history));
+    }
+    return out;
+}
+VarDiff VarDiff::cat(const std::vector<VarDiff>& vars, int axis) const {
+    std::vector<Var> vs;
+    History<BackwardEntry> h = history;
+    auto bw = std::make_shared<CatBwd>();
+    bw->operands.push_back(grad);
+    for (const VarDiff& v : vars) {
+        vs.push_back(v.var);
+        h.merge(v.history);
+        bw->operands.push_back(v.grad);
+    }
+    Var out = var.cat(vs, axis);
+    auto g = std::make_shared<Gradient>(device(), out.shape());
+    bw->g = g; bw->axis = axis;
+    return VarDiff::node(std::move(out), g, entry(bw, g), std::move(h));
+}
+VarDiff VarDiff::mse(const Var& target, Reduction reduction) const {
+    Var out = var.mse(target, reduction);
+    auto g = std::make_shared<Gradient>(device(), Shape{});
+    auto bw = std::make_shared<MseBwd>();
+    bw->x = var.data; bw->t = target.data; bw->dx = grad; bw->g = g; bw->red = reduction;
+    return VarDiff::node(std::move(out), g, entry(bw, g), history);
+}
+VarDiff VarDiff::pad(const std::vector<int>& padding, float value) const {
+    Var out = var.pad(padding, value);
+    auto g = std::make_shared<Gradient>(device(), out.shape());
+    auto bw = std::make_shared<PadBwd>();
+    bw->dx = grad; bw->g = g; bw->padding = padding;
+    return VarDiff::node(std::move(out), g, entry(bw, g), history);
+}
+VarDiff VarDiff::mm(const Var& rhs) const { return matmul_diff(0, var, grad, &history, rhs, nullptr, nullptr); }
+VarDiff VarDiff::mm(const VarDiff& rhs) const { return matmul_diff(0, var, grad, &history, rhs.var, rhs.grad, &rhs.history); }
+VarDiff VarDiff::mm_t(const Var& rhs) const { return matmul_diff(1, var, grad, &history, rhs, nullptr, nullptr); }
+VarDiff VarDiff::mm_t(const VarDiff& rhs) const { return matmul_diff(1, var, grad, &history, rhs.var, rhs.grad, &rhs.history); }
+VarDiff VarDiff::bmm(const VarDiff& rhs) const { return matmul_diff(2, var, grad, &history, rhs.var, rhs.grad, &rhs.history); }
+VarDiff VarDiff::bmm_t(const VarDiff& rhs) const { return matmul_diff(3, var, grad, &history, rhs.var, rhs.grad, &rhs.history); }
+
+static VarDiff conv_diff(const VarDiff& kernel, const Var& input, const Shared<Gradient>& dx,
+                         const History<BackwardEntry>* hx, const std::vector<int>& stride,
+                         const std::vector<int>& dilation, int groups) {
+    Var out = kernel.var.convolution(input, stride, dilation, groups);
+    History<BackwardEntry> h = kernel.history;
+    if (hx) h.merge(*hx);
+    auto g = std::make_shared<Gradient>(out.device(), out.shape());
+    auto bw = std::make_shared<ConvBwd>();
+    bw->x = input.data; bw->w = kernel.var.data; bw->dx = dx; bw->dw = kernel.grad; bw->g = g;
+    bw->stride = stride; bw->dilation = dilation; bw->groups = groups;
+    return VarDiff::node(std::move(out), g, entry(bw, g), std::move(h));
+}
+VarDiff VarDiff::convolution(const Var& input, const std::vector<int>& stride, const std::vector<int>& dilation, int groups) const {
+    return conv_diff(*this, input, nullptr, nullptr, stride, dilation, groups);
+}
+VarDiff VarDiff::convolution(const VarDiff& input, const std::vector<int>& stride, const std::vector<int>& dilation, int groups) const {
+    return conv_diff(*this, input.var, input.grad, &input.history, stride, dilation, groups);
+}
+static VarDiff heads_diff(bool split, const VarDiff& x, int B, int S, int H, int dh) {
+    Var out = split ? x.var.split_heads(B, S, H, dh) : x.var.merge_heads(B, S, H, dh);
+    auto g = std::make_shared<Gradient>(out.device(), out.shape());
+    auto bw = std::make_shared<HeadsBwd>();
+    bw->split = split; bw->dx = x.grad; bw->g = g; bw->B = B; bw->S = S; bw->H = H; bw->dh = dh;
+    return VarDiff::node(std::move(out), g, entry(bw, g), x.history);
+}
+VarDiff VarDiff::split_heads(int B, int S, int H, int dh) const { return heads_diff(true, *this, B, S, H, dh); }
+VarDiff VarDiff::merge_heads(int B, int S, int H, int dh) const { return heads_diff(false, *this, B, S, H, dh); }
+
+// ---- arithmetic operators -------------------------------------------------------------------------
+static Var scalar_leaf(const DevicePtr& dev, float v) {  // the f32 is wrapped in an Ix0 leaf (var.rs:746-838)
+    auto a = std::make_shared<HipArray>(dev, Shape{});
+    a->fill(v);
+    return Var::leaf(a);
+}
+#define NK_DEFINE_BINARY(OP, CODE)                                                                          \
+    Var operator OP(const Var& l, const Var& r) { return binary_var(CODE, l, r); }                          \
+    VarDiff operator OP(const Var& l, const VarDiff& r) { return binary_diff(CODE, l, nullptr, nullptr, r.var, r.grad, &r.history); } \
+    VarDiff operator OP(const VarDiff& l, const Var& r) { return binary_diff(CODE, l.var, l.grad, &l.history, r, nullptr, nullptr); } \
+    VarDiff operator OP(const VarDiff& l, const VarDiff& r) { return binary_diff(CODE, l.var, l.grad, &l.history, r.var, r.grad, &r.history); } \
+    Var operator OP(const Var& l, float r) { return binary_var(CODE, l, scalar_leaf(l.device(), r)); }      \
+    VarDiff operator OP(const VarDiff& l, float r) { return binary_diff(CODE, l.var, l.grad, &l.history, scalar_leaf(l.device(), r), nullptr, nullptr); }
+NK_DEFINE_BINARY(+, NK_ADD)
+NK_DEFINE_BINARY(-, NK_SUB)
+NK_DEFINE_BINARY(*, NK_MUL)
+NK_DEFINE_BINARY(/, NK_DIV)
+#undef NK_DEFINE_BINARY
+
+// ---- leaf constructors ----------------------------------------------------------------------------
+Var from_host(DevicePtr dev, const Shape& shape, const float* host) { return Var::leaf(HipArray::from_host(std::move(dev), shape, host)); }
+Var zeros(DevicePtr dev, const Shape& shape) { return Var::leaf(std::make_shared<HipArray>(std::move(dev), shape)); }
+Var full(DevicePtr dev, const Shape& shape, float value) {
+    auto a = std::make_shared<HipArray>(std::move(dev), shape);
+    a->fill(value);
+    return Var::leaf(a);
+}
+Var ones(DevicePtr dev, const Shape& shape) { return full(std::move(dev), shape, 1.f); }
+static std::vector<float> uniform(size_t n, float lo, float hi, uint64_t seed) {
+    std::mt19937_64 rng(seed);
+    std::vector<float> v(n);
+    for (float& x : v) x = lo + (hi - lo) * (float)((rng() >> 40) * (1.0 / 16777216.0));
+    return v;
+}
+Var rand(DevicePtr dev, const Shape& shape, uint64_t seed) {
+    const auto v = uniform(numel(shape), 0.f, 1.f, seed);
+    return from_host(std::move(dev), shape, v.data());
+}
+
+// =================================================================================================
+// nn
+// =================================================================================================
+namespace nn {
+
+static VarDiff uniform_param(const DevicePtr& dev, const Shape& s, float k, uint64_t seed) {
+    const auto v = uniform(numel(s), -k, k, seed);
+    return from_host(dev, s, v.data()).requires_grad();
+}
+Linear::Linear(DevicePtr dev, int in_features, int out_features, uint64_t seed)
+    : weight(uniform_param(dev, {out_features, in_features}, 1.f / std::sqrt((float)in_features), seed)),
+      bias(uniform_param(dev, {out_features}, 1.f / std::sqrt((float)in_features), seed + 1)) {}
+VarDiff Linear::forward(const Var& input) const { return input.mm_t(weight) + bias; }
+VarDiff Linear::forward(const VarDiff& input) const { return input.mm_t(weight) + bias; }
+
+Conv2d::Conv2d(DevicePtr dev, int in_channels, int out_channels, std::vector<int> kernel, std::vector<int> padding_,
+               std::vector<int> stride_, std::vector<int> dilation_, int groups_, uint64_t seed)
+    : weight(uniform_param(dev, {out_channels, in_channels / groups_, kernel[0], kernel[1]},
+                           1.f / std::sqrt((float)(in_channels / groups_ * kernel[0] * kernel[1])), seed)),
+      bias(uniform_param(dev, {out_channels, 1, 1}, 1.f / std::sqrt((float)(in_channels / groups_ * kernel[0] * kernel[1])), seed + 1)),
+      padding(std::move(padding_)), stride(std::move(stride_)), dilation(std::move(dilation_)), groups(groups_) {}
+VarDiff Conv2d::forward(const Var& input) const {
+    return weight.convolution(input.pad(padding, pad_value), stride, dilation, groups) + bias;
+}
+VarDiff Conv2d::forward(const VarDiff& input) const {
+    return weight.convolution(input.pad(padding, pad_value), stride, dilation, groups) + bias;
+}
+
+MultiheadAttention::MultiheadAttention(DevicePtr dev, int d_model_, int heads_, double p, uint64_t seed)
+    : q(dev, d_model_, d_model_, seed), k(dev, d_model_, d_model_, seed + 2), v(dev, d_model_, d_model_, seed + 4),
+      o(dev, d_model_, d_model_, seed + 6), d_model(d_model_), heads(heads_), drop(p) {
+    if (d_model % heads != 0) panic("d_model must be divisible by heads");
+}
+VarDiff MultiheadAttention::forward(const VarDiff& x, int batch) const {
+    const int rows = x.shape()[0], S = rows / batch, dh = d_model / heads;
+    if (rows % batch != 0 || x.shape()[1] != d_model) panic("MultiheadAttention: bad input shape");
+    const VarDiff Q = q.forward(x).split_heads(batch, S, heads, dh);
+    const VarDiff K = k.forward(x).split_heads(batch, S, heads, dh);
+    const VarDiff V = v.forward(x).split_heads(batch, S, heads, dh);
+    const VarDiff scores = Q.bmm_t(K) * (1.f / std::sqrt((float)dh));
+    const VarDiff P = drop.forward(scores.softmax(2));
+    const VarDiff O = P.bmm(V).merge_heads(batch, S, heads, dh);
+    return o.forward(O);
+}
+
+}  // namespace nn
+
+// =================================================================================================
+// optim
+// =================================================================================================
+namespace optim {
+
+SGD::SGD(float lr, Penalty penalty, float momentum, float dampening, bool nesterov)
+    : lr_(lr), momentum_(momentum), dampening_(dampening), nesterov_(nesterov), penalty_(penalty) {}
+void SGD::register_param(const VarDiff& p) {
+    params_.push_back(p);
+    velocity_.push_back(momentum_ != 0.f ? std::make_shared<HipArray>(p.device(), p.shape()) : nullptr);
+}
+void SGD::step() {
+    for (size_t i = 0; i < params_.size(); ++i) {
+        const VarDiff& p = params_[i];
+        HipArray& g = p.grad->borrow();
+        check(nk_sgd_step(p.device()->raw(), p.var.data->ptr(), g.ptr(), velocity_[i] ? velocity_[i]->ptr() : nullptr,
+                          g.len(), lr_, momentum_, dampening_, nesterov_ ? 1 : 0, first_ ? 1 : 0, penalty_.l1, penalty_.l2));
+    }
+    first_ = false;
+}
+void SGD::zero_grad() const {
+    for (const VarDiff& p : params_) p.zero_grad();
+}
+
+}  // namespace optim
+
+// =================================================================================================
+// dp
+// =================================================================================================
+namespace dp {
+
+std::string Communicator::unique_id() {
+    std::string id(NK_COMM_ID_BYTES, '\0');
+    check(nk_comm_unique_id(&id[0]));
+    return id;
+}
+Communicator::Communicator(DevicePtr dev, int nranks, int rank, const std::string& id)
+    : dev_(std::move(dev)), rank_(rank), size_(nranks) {
+    if (id.size() != NK_COMM_ID_BYTES) panic("communicator id must be 128 bytes");
+    check(nk_comm_init_rank(dev_->raw(), nranks, rank, id.data(), &h_));
+}
+Communicator::~Communicator() { nk_comm_destroy(h_); }
+
+GradientSync::GradientSync(std::shared_ptr<Communicator> comm, const std::vector<VarDiff>& params) : comm_(std::move(comm)) {
+    for (const VarDiff& p : params) {
+        params_[p.grad.get()] = p.grad;
+        bytes_ += numel(p.shape()) * sizeof(float);
+        nk_event* ev = nullptr;
+        check(nk_event_create(comm_->device()->raw(), &ev));
+        events_.push_back(ev);
+    }
+}
+GradientSync::~GradientSync() {
+    for (nk_event* e : events_) nk_event_destroy(e);
+}
+void GradientSync::grad_ready(const Gradient* g) {
+    auto it = params_.find(g);
+    if (it == params_.end()) return;
+    if (comm_->size() == 1) return;  // nothing to exchange
+    nk_event* ev = events_[next_event_++ % events_.size()];
+    check(nk_event_record(ev, 0));  // everything up to the node that finalised g
+    HipArray& a = it->second->borrow();
+    check(nk_allreduce_sum_async(comm_->raw(), a.ptr(), a.len(), ev));
+}
+void GradientSync::join() {
+    next_event_ = 0;
+    if (comm_->size() > 1) check(nk_comm_join(comm_->raw()));
+}
+
+void all_reduce_gradients(const Communicator& comm, const std::vector<VarDiff>& params) {
+    if (comm.size() == 1) return;
+    for (const VarDiff& p : params) {
+        HipArray& a = p.grad->borrow();
+        check(nk_allreduce_sum_async(comm.raw(), a.ptr(), a.len(), nullptr));
+    }
+    check(nk_comm_join(comm.raw()));
+}
+
+}  // namespace dp
+
+}  // namespace neuronika

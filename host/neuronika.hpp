@@ -1,0 +1,435 @@
+// Host-side mirror of neuronika's Var / VarDiff tape for the HIP backend (C++17).
+//
+// The reference's host code is Rust; no Rust toolchain exists in this environment, so the
+// host side above the C ABI (include/neuronika_hip.h) is written in C++ with the reference's
+// own names, argument meaning and error behaviour:
+//
+//   reference (neuronika-variable/src)              here
+//   ------------------------------------------------------------------------------------------
+//   autograd.rs:7-25    trait Forward / Backward     struct Forward / Backward
+//   gradient.rs:8-79    NoGrad, Gradient             struct NoGrad, class Gradient
+//   history.rs:9-125    HistoryId, History<T>        class History<T>
+//   var.rs:34-128       Var<D>                       class Var   (rank is a run-time Shape)
+//   vardiff.rs:35-168   VarDiff<D>                   class VarDiff
+//   cuda/device.rs, cuda/cuarray.rs                  class Device, class HipArray
+//   lib.rs:29-36        enum Reduction               enum class Reduction
+//   neuronika-nn/src/lib.rs:406-448  Linear          nn::Linear   (+ Conv2d, Dropout, MHA)
+//   neuronika-optim/src/optimizer.rs, sgd/mod.rs     optim::SGD
+//   (net-new)                                         dp::Communicator / dp::GradientSync
+//
+// Semantics kept from the reference: graph construction allocates ZEROED output / gradient
+// buffers and computes nothing; `.forward()` runs the forward tape in insertion order and
+// overwrites every node output; `.backward(seed)` fills the root gradient with `seed` and runs
+// the backward tape in reverse, every node accumulating (`+=`) into its operands' gradients;
+// intermediate gradients are NOT re-zeroed between calls (vardiff.rs:125-141) — use
+// `no_grad()` + `with_grad()` (gradient.rs:64-79) to drop and re-create them.
+// Errors: the reference panics; here `neuronika::Panic` (a std::runtime_error) is thrown.
+// Threading: like `Rc<RefCell<..>>` graphs, one host thread per graph/device.
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "neuronika_hip.h"
+
+namespace neuronika {
+
+using Shape = std::vector<int>;
+
+struct Panic : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+[[noreturn]] void panic(const std::string& msg);
+void check(int status);  // non-zero C-ABI status -> Panic(nk_last_error())
+
+size_t numel(const Shape& s);
+
+// ---------------------------------------------------------------------------------------------
+// Device + device array (reference template: cuda/device.rs:11-58, cuda/cuarray.rs:10-117)
+// ---------------------------------------------------------------------------------------------
+class Device : public std::enable_shared_from_this<Device> {
+   public:
+    static std::shared_ptr<Device> create(int idx);
+    ~Device();
+    nk_device* raw() const { return h_; }
+    int index() const { return idx_; }
+    void sync() const;
+    // Stream-ordered caching allocator: blocks released by graph buffers are re-used for later
+    // allocations of the same size (all work runs in order on the compute stream).
+    float* alloc_zeroed(size_t n);
+    void release(float* p, size_t n);
+    size_t bytes_in_use() const { return in_use_; }
+
+   private:
+    Device() = default;
+    nk_device* h_ = nullptr;
+    int idx_ = 0;
+    std::unordered_map<size_t, std::vector<float*>> pool_;
+    size_t in_use_ = 0;
+};
+using DevicePtr = std::shared_ptr<Device>;
+
+class HipArray {
+   public:
+    HipArray(DevicePtr dev, Shape shape);  // `CuArray::zeroed`
+    ~HipArray();
+    HipArray(const HipArray&) = delete;
+    HipArray& operator=(const HipArray&) = delete;
+
+    static std::shared_ptr<HipArray> from_host(DevicePtr dev, const Shape& shape, const float* host);
+    void upload(const float* host);              // `CuArray::from_ndarray`
+    void download(float* host) const;            // `CuArray::as_ndarray`
+    std::vector<float> to_vec() const;
+    void fill(float v);
+    size_t len() const { return len_; }
+    const Shape& shape() const { return shape_; }
+    float* ptr() const { return ptr_; }
+    const DevicePtr& device() const { return dev_; }
+
+   private:
+    DevicePtr dev_;
+    Shape shape_;
+    size_t len_;
+    float* ptr_;
+};
+template <class T>
+using Shared = std::shared_ptr<T>;  // utils.rs:9  `Shared<T> = Rc<RefCell<T>>`
+
+// ---------------------------------------------------------------------------------------------
+// autograd.rs / gradient.rs
+// ---------------------------------------------------------------------------------------------
+struct Forward {
+    virtual ~Forward() = default;
+    virtual void forward() const = 0;
+};
+class Gradient;
+struct Backward {
+    virtual ~Backward() = default;
+    virtual void backward() const = 0;
+    // gradients this node accumulates into (used to tell when a leaf gradient is final)
+    virtual void targets(std::vector<const Gradient*>& out) const = 0;
+};
+// Called by VarDiff::backward right after the LAST tape node writing into a gradient has been
+// issued: the hook of the data-parallel exchange (dp::GradientSync).
+struct BackwardHook {
+    virtual ~BackwardHook() = default;
+    virtual void grad_ready(const Gradient* g) = 0;
+};
+struct NoGrad {
+    virtual ~NoGrad() = default;
+    virtual void no_grad() = 0;
+    virtual void with_grad() = 0;
+};
+
+class Gradient : public NoGrad {
+   public:
+    Gradient(DevicePtr dev, Shape shape);  // `ndarray_zeros`
+    HipArray& borrow() const;              // panics when de-allocated
+    Shared<HipArray> array() const { return array_; }
+    const Shape& shape() const { return shape_; }
+    void no_grad() override;
+    void with_grad() override;
+
+   private:
+    DevicePtr dev_;
+    Shape shape_;
+    Shared<HipArray> array_;
+};
+
+// ---------------------------------------------------------------------------------------------
+// history.rs — the tape.  Entries are identified by node address and ordered by the size of
+// the history at insertion; merging keeps one entry per address.
+// ---------------------------------------------------------------------------------------------
+template <class T>
+class History {
+   public:
+    void merge(const History& other);
+    void insert(const void* ptr, T op);
+    size_t len() const { return path_.size(); }
+    size_t buffer_len() const { return buffer_->size(); }
+    std::vector<T> to_vec() const;
+    std::vector<T>& buffer_mut() const { return *buffer_; }
+
+   private:
+    struct Item {
+        const void* ptr;
+        size_t order;
+        T op;
+    };
+    std::vector<Item> path_;  // sorted by order (stable)
+    // the reference clones the RefCell<Vec> with the History; a fresh buffer per copy is
+    // equivalent because insert() truncates it and forward() repopulates an empty one.
+    std::shared_ptr<std::vector<T>> buffer_ = std::make_shared<std::vector<T>>();
+
+   public:
+    History() = default;
+    History(const History& o) : path_(o.path_), buffer_(std::make_shared<std::vector<T>>(*o.buffer_)) {}
+    History& operator=(const History& o) {
+        path_ = o.path_;
+        buffer_ = std::make_shared<std::vector<T>>(*o.buffer_);
+        return *this;
+    }
+};
+
+struct ForwardEntry {
+    Shared<Forward> op;
+    Shared<bool> computed;
+};
+struct BackwardEntry {
+    Shared<Backward> op;
+    Shared<NoGrad> grad;
+};
+
+enum class Reduction { Sum = 0, Mean = 1 };  // lib.rs:29-36
+
+class VarDiff;
+
+// ---------------------------------------------------------------------------------------------
+// var.rs — non-differentiable variable
+// ---------------------------------------------------------------------------------------------
+class Var {
+   public:
+    Shared<HipArray> data;
+    History<ForwardEntry> history;
+
+    static Var leaf(Shared<HipArray> array);                                          // var.rs:46
+    static Var node(Shared<HipArray> data, Shared<Forward> op, History<ForwardEntry> h);  // var.rs:53
+    const Shape& shape() const { return data->shape(); }
+    DevicePtr device() const { return data->device(); }
+
+    VarDiff requires_grad() const;  // var.rs:103
+    void forward() const;           // var.rs:110-128
+    float item() const;             // var.rs:133
+    std::vector<float> to_vec() const { return data->to_vec(); }
+
+    Var sum() const;                                  // var.rs:201
+    Var mean() const;                                 // var.rs:209
+    Var relu() const;                                 // var.rs:243
+    Var softmax(int axis) const;                      // var.rs:318
+    Var log_softmax(int axis) const;                  // var.rs:338
+    Var t() const;                                    // var.rs:347
+    Var dropout(double p, Shared<bool> status) const; // var.rs:375
+    std::vector<Var> chunks(const Shape& chunk_size) const;             // var.rs:401
+    Var cat(const std::vector<Var>& variables, int axis) const;         // var.rs:564
+    Var mse(const Var& target, Reduction reduction) const;              // var.rs:454
+    Var pad(const std::vector<int>& padding, float value = 0.f) const;  // var.rs:726 (Zero/Constant)
+    Var mm(const Var& rhs) const;                                        // var.rs:1034
+    VarDiff mm(const VarDiff& rhs) const;
+    Var mm_t(const Var& rhs) const;                                      // var.rs:1065
+    VarDiff mm_t(const VarDiff& rhs) const;                              // var.rs:1081
+    // `kernel.convolution(input, stride, dilation, groups)`  var.rs:1296-1371
+    Var convolution(const Var& input, const std::vector<int>& stride, const std::vector<int>& dilation,
+                    int groups) const;
+    // composed-attention glue (Chunk((S,dh)) tiles / cat): SURVEY.md 8a note
+    Var split_heads(int B, int S, int H, int dh) const;
+    Var merge_heads(int B, int S, int H, int dh) const;
+    // batched (b,h) matrix products over [B*H, S, *] tiles = B*H `mm` / `mm_t` nodes
+    Var bmm(const Var& rhs) const;
+    Var bmm_t(const Var& rhs) const;
+};
+
+// ---------------------------------------------------------------------------------------------
+// vardiff.rs — differentiable variable
+// ---------------------------------------------------------------------------------------------
+class VarDiff {
+   public:
+    Var var;
+    Shared<Gradient> grad;
+    History<BackwardEntry> history;
+
+    static VarDiff leaf(Var var, Shared<Gradient> grad);                                        // vardiff.rs:48
+    static VarDiff node(Var var, Shared<Gradient> grad, BackwardEntry op, History<BackwardEntry> h);  // :56
+    const Shape& shape() const { return var.shape(); }
+    DevicePtr device() const { return var.device(); }
+    Shared<HipArray> data() const { return var.data; }
+
+    void zero_grad() const;         // vardiff.rs:100
+    void forward() const;           // vardiff.rs:106-116
+    void backward(float seed, BackwardHook* hook = nullptr) const;  // vardiff.rs:125-141
+    void no_grad() const;           // vardiff.rs:145
+    void with_grad() const;         // vardiff.rs:157
+    float item() const { return var.item(); }
+    std::vector<float> to_vec() const { return var.to_vec(); }
+    std::vector<float> grad_to_vec() const { return grad->borrow().to_vec(); }
+
+    VarDiff sum() const;
+    VarDiff mean() const;
+    VarDiff relu() const;
+    VarDiff softmax(int axis) const;
+    VarDiff log_softmax(int axis) const;
+    VarDiff t() const;
+    VarDiff dropout(double p, Shared<bool> status) const;
+    std::vector<VarDiff> chunks(const Shape& chunk_size) const;
+    VarDiff cat(const std::vector<VarDiff>& vars, int axis) const;
+    VarDiff mse(const Var& target, Reduction reduction) const;
+    VarDiff pad(const std::vector<int>& padding, float value = 0.f) const;
+    VarDiff mm(const Var& rhs) const;
+    VarDiff mm(const VarDiff& rhs) const;
+    VarDiff mm_t(const Var& rhs) const;
+    VarDiff mm_t(const VarDiff& rhs) const;
+    VarDiff convolution(const Var& input, const std::vector<int>& stride, const std::vector<int>& dilation,
+                        int groups) const;
+    VarDiff convolution(const VarDiff& input, const std::vector<int>& stride, const std::vector<int>& dilation,
+                        int groups) const;
+    VarDiff split_heads(int B, int S, int H, int dh) const;
+    VarDiff merge_heads(int B, int S, int H, int dh) const;
+    VarDiff bmm(const VarDiff& rhs) const;
+    VarDiff bmm_t(const VarDiff& rhs) const;
+};
+
+// `Add/Sub/Mul/Div` with NumPy broadcasting, all four differentiability combinations
+// (var.rs:859-1026, vardiff.rs:866-1069) and the f32 scalar forms (var.rs:746-838).
+#define NK_DECLARE_BINARY(OP)                         \
+    Var operator OP(const Var& l, const Var& r);      \
+    VarDiff operator OP(const Var& l, const VarDiff& r);   \
+    VarDiff operator OP(const VarDiff& l, const Var& r);   \
+    VarDiff operator OP(const VarDiff& l, const VarDiff& r); \
+    Var operator OP(const Var& l, float r);           \
+    VarDiff operator OP(const VarDiff& l, float r);
+NK_DECLARE_BINARY(+)
+NK_DECLARE_BINARY(-)
+NK_DECLARE_BINARY(*)
+NK_DECLARE_BINARY(/)
+#undef NK_DECLARE_BINARY
+
+// leaf constructors (lib.rs:51-143)
+Var from_host(DevicePtr dev, const Shape& shape, const float* host);  // `from_ndarray`
+Var zeros(DevicePtr dev, const Shape& shape);
+Var ones(DevicePtr dev, const Shape& shape);
+Var full(DevicePtr dev, const Shape& shape, float value);
+Var rand(DevicePtr dev, const Shape& shape, uint64_t seed);  // U[0,1) (host RNG, uploaded)
+
+// ---------------------------------------------------------------------------------------------
+// neuronika-nn
+// ---------------------------------------------------------------------------------------------
+namespace nn {
+
+// `Linear` neuronika-nn/src/lib.rs:406-448: weight (out,in), bias (out), U(-k,k), k = 1/sqrt(in)
+struct Linear {
+    VarDiff weight, bias;
+    Linear(DevicePtr dev, int in_features, int out_features, uint64_t seed);
+    Linear(VarDiff weight, VarDiff bias) : weight(std::move(weight)), bias(std::move(bias)) {}
+    VarDiff forward(const Var& input) const;      // input.mm_t(W) + b
+    VarDiff forward(const VarDiff& input) const;
+};
+
+// `Conv2d` struct/new neuronika-nn/src/lib.rs:724-788; its forward is `todo!()` in the reference
+// snapshot (:809-814) and is defined here as pad -> convolution -> + bias.
+struct Conv2d {
+    VarDiff weight, bias;  // (Cout, Cin/groups, kh, kw), (Cout, 1, 1)
+    std::vector<int> padding, stride, dilation;
+    float pad_value = 0.f;  // Zero / Constant(v)
+    int groups = 1;
+    Conv2d(DevicePtr dev, int in_channels, int out_channels, std::vector<int> kernel, std::vector<int> padding,
+           std::vector<int> stride, std::vector<int> dilation, int groups, uint64_t seed);
+    VarDiff forward(const Var& input) const;
+    VarDiff forward(const VarDiff& input) const;
+};
+
+// `ModelStatus`-style train/eval switch shared with the Dropout nodes (node/dropout/mod.rs:27).
+struct Dropout {
+    double p;
+    Shared<bool> status;
+    explicit Dropout(double p) : p(p), status(std::make_shared<bool>(true)) {}
+    void train() const { *status = true; }
+    void eval() const { *status = false; }
+    VarDiff forward(const VarDiff& x) const { return x.dropout(p, status); }
+};
+
+// Multi-head attention composed from reference ops (the module does not exist in the reference;
+// SURVEY.md 8a note): Q,K,V = x.mm_t(W)+b; per (b,h): P = dropout(softmax(Q.mm_t(K)*dh^-1/2, 1));
+// O = P.mm(V); out = cat(O).mm_t(Wo)+bo.
+struct MultiheadAttention {
+    Linear q, k, v, o;
+    int d_model, heads;
+    Dropout drop;
+    MultiheadAttention(DevicePtr dev, int d_model, int heads, double p, uint64_t seed);
+    VarDiff forward(const VarDiff& x, int batch) const;  // x: (batch*seq, d_model)
+};
+
+}  // namespace nn
+
+// ---------------------------------------------------------------------------------------------
+// neuronika-optim: Optimizer / StochasticGD (optimizer.rs:33-95, sgd/mod.rs:186-236)
+// ---------------------------------------------------------------------------------------------
+namespace optim {
+
+struct Penalty {  // penalty.rs:2-79
+    float l1 = 0.f, l2 = 0.f;
+};
+
+class SGD {
+   public:
+    SGD(float lr, Penalty penalty = {}, float momentum = 0.f, float dampening = 0.f, bool nesterov = false);
+    void register_param(const VarDiff& p);  // `register`
+    void step();
+    void zero_grad() const;
+    float get_lr() const { return lr_; }
+    void set_lr(float lr) { lr_ = lr; }
+    const std::vector<VarDiff>& params() const { return params_; }
+
+   private:
+    float lr_, momentum_, dampening_;
+    bool nesterov_;
+    Penalty penalty_;
+    std::vector<VarDiff> params_;
+    std::vector<Shared<HipArray>> velocity_;
+    bool first_ = true;
+};
+
+}  // namespace optim
+
+// ---------------------------------------------------------------------------------------------
+// data-parallel gradient exchange (net-new): RCCL sum all-reduce of the registered parameters'
+// gradient buffers on the side stream, bucketed in reverse registration order so a bucket can
+// start as soon as backward has produced it.
+// ---------------------------------------------------------------------------------------------
+namespace dp {
+
+class Communicator {
+   public:
+    static std::string unique_id();  // 128 raw bytes, create on rank 0
+    Communicator(DevicePtr dev, int nranks, int rank, const std::string& id);
+    ~Communicator();
+    int rank() const { return rank_; }
+    int size() const { return size_; }
+    nk_comm* raw() const { return h_; }
+    DevicePtr device() const { return dev_; }
+
+   private:
+    DevicePtr dev_;
+    nk_comm* h_ = nullptr;
+    int rank_, size_;
+};
+
+// Overlapped exchange: pass to `loss.backward(1/world, &sync)`; each registered parameter's
+// gradient is all-reduced (sum) on the side stream as soon as the last backward node writing it
+// has been issued (reverse layer order), while the remaining backward GEMMs keep the compute
+// stream busy.  `join()` makes the compute stream wait for the exchange (no host sync).
+class GradientSync : public BackwardHook {
+   public:
+    GradientSync(std::shared_ptr<Communicator> comm, const std::vector<VarDiff>& params);
+    ~GradientSync() override;
+    void grad_ready(const Gradient* g) override;
+    void join();
+    size_t bytes_per_step() const { return bytes_; }
+
+   private:
+    std::shared_ptr<Communicator> comm_;
+    std::unordered_map<const Gradient*, Shared<Gradient>> params_;
+    std::vector<nk_event*> events_;
+    size_t next_event_ = 0;
+    size_t bytes_ = 0;
+};
+
+// Non-overlapped form: all-reduce every gradient after backward has been issued.
+void all_reduce_gradients(const Communicator& comm, const std::vector<VarDiff>& params);
+
+}  // namespace dp
+
+}  // namespace neuronika

@@ -1,0 +1,188 @@
+// pybind11 glue exposing the C++ tape mirror (host/neuronika.hpp) to the Python test / bench
+// harness as `neuronika_amd._tape`.  Harness plumbing only: the drop-in boundary is the C ABI.
+#include <pybind11/numpy.h>
+#include <pybind11/pybind11.h>
+#include <pybind11/stl.h>
+
+#include "neuronika.hpp"
+
+namespace py = pybind11;
+using namespace neuronika;
+
+using Arr = py::array_t<float, py::array::c_style | py::array::forcecast>;
+
+struct Status {
+    std::shared_ptr<bool> flag;
+};
+
+static Shape shape_of(const Arr& a) {
+    Shape s;
+    for (py::ssize_t i = 0; i < a.ndim(); ++i) s.push_back((int)a.shape(i));
+    return s;
+}
+static py::array_t<float> to_numpy(const HipArray& h) {
+    std::vector<py::ssize_t> s(h.shape().begin(), h.shape().end());
+    py::array_t<float> out(s);
+    h.download(out.mutable_data());
+    return out;
+}
+
+PYBIND11_MODULE(_tape, m) {
+    m.doc() = "C++ mirror of neuronika's Var/VarDiff tape on the HIP backend";
+    py::register_exception<Panic>(m, "Panic", PyExc_RuntimeError);
+
+    py::class_<Device, std::shared_ptr<Device>>(m, "Device")
+        .def(py::init(&Device::create), py::arg("idx") = 0)
+        .def("sync", &Device::sync)
+        .def("bytes_in_use", &Device::bytes_in_use)
+        .def_property_readonly("index", &Device::index)
+        .def("raw", [](const Device& d) { return (uintptr_t)d.raw(); });
+
+    py::enum_<Reduction>(m, "Reduction").value("Sum", Reduction::Sum).value("Mean", Reduction::Mean);
+
+    py::class_<Status>(m, "Status")  // `Rc<Cell<bool>>` train/eval switch of the Dropout nodes
+        .def(py::init([](bool v) { return Status{std::make_shared<bool>(v)}; }), py::arg("train") = true)
+        .def("set", [](Status& s, bool v) { *s.flag = v; })
+        .def("get", [](const Status& s) { return *s.flag; });
+
+    py::class_<Var>(m, "Var")
+        .def_property_readonly("shape", [](const Var& v) { return v.shape(); })
+        .def("requires_grad", &Var::requires_grad)
+        .def("forward", &Var::forward)
+        .def("item", &Var::item)
+        .def("data", [](const Var& v) { return to_numpy(*v.data); })
+        .def("set_data", [](const Var& v, const Arr& a) {
+            if ((size_t)a.size() != v.data->len()) panic("set_data: size mismatch");
+            v.data->upload(a.data());
+        })
+        .def("history_len", [](const Var& v) { return v.history.len(); })
+        .def("sum", &Var::sum).def("mean", &Var::mean).def("relu", &Var::relu)
+        .def("softmax", &Var::softmax).def("log_softmax", &Var::log_softmax).def("t", &Var::t)
+        .def("dropout", [](const Var& v, double p, const Status& s) { return v.dropout(p, s.flag); }).def("chunks", &Var::chunks).def("cat", &Var::cat)
+        .def("mse", &Var::mse).def("pad", &Var::pad, py::arg("padding"), py::arg("value") = 0.f)
+        .def("mm", py::overload_cast<const Var&>(&Var::mm, py::const_))
+        .def("mm", py::overload_cast<const VarDiff&>(&Var::mm, py::const_))
+        .def("mm_t", py::overload_cast<const Var&>(&Var::mm_t, py::const_))
+        .def("mm_t", py::overload_cast<const VarDiff&>(&Var::mm_t, py::const_))
+        .def("convolution", &Var::convolution)
+        .def("__add__", [](const Var& a, const Var& b) { return a + b; })
+        .def("__add__", [](const Var& a, const VarDiff& b) { return a + b; })
+        .def("__add__", [](const Var& a, float b) { return a + b; })
+        .def("__sub__", [](const Var& a, const Var& b) { return a - b; })
+        .def("__sub__", [](const Var& a, const VarDiff& b) { return a - b; })
+        .def("__sub__", [](const Var& a, float b) { return a - b; })
+        .def("__mul__", [](const Var& a, const Var& b) { return a * b; })
+        .def("__mul__", [](const Var& a, const VarDiff& b) { return a * b; })
+        .def("__mul__", [](const Var& a, float b) { return a * b; })
+        .def("__truediv__", [](const Var& a, const Var& b) { return a / b; })
+        .def("__truediv__", [](const Var& a, const VarDiff& b) { return a / b; })
+        .def("__truediv__", [](const Var& a, float b) { return a / b; });
+
+    py::class_<VarDiff>(m, "VarDiff")
+        .def_property_readonly("shape", [](const VarDiff& v) { return v.shape(); })
+        .def("forward", &VarDiff::forward)
+        .def("backward", [](const VarDiff& v, float seed) { v.backward(seed); }, py::arg("seed") = 1.f)
+        .def("backward_sync", [](const VarDiff& v, float seed, dp::GradientSync& s) { v.backward(seed, &s); })
+        .def("zero_grad", &VarDiff::zero_grad)
+        .def("no_grad", &VarDiff::no_grad)
+        .def("with_grad", &VarDiff::with_grad)
+        .def("item", &VarDiff::item)
+        .def("data", [](const VarDiff& v) { return to_numpy(*v.var.data); })
+        .def("set_data", [](const VarDiff& v, const Arr& a) {
+            if ((size_t)a.size() != v.var.data->len()) panic("set_data: size mismatch");
+            v.var.data->upload(a.data());
+        })
+        .def("grad", [](const VarDiff& v) { return to_numpy(v.grad->borrow()); })
+        .def("set_grad", [](const VarDiff& v, const Arr& a) {
+            if ((size_t)a.size() != v.grad->borrow().len()) panic("set_grad: size mismatch");
+            v.grad->borrow().upload(a.data());
+        })
+        .def("history_len", [](const VarDiff& v) { return v.history.len(); })
+        .def("forward_history_len", [](const VarDiff& v) { return v.var.history.len(); })
+        .def("sum", &VarDiff::sum).def("mean", &VarDiff::mean).def("relu", &VarDiff::relu)
+        .def("softmax", &VarDiff::softmax).def("log_softmax", &VarDiff::log_softmax).def("t", &VarDiff::t)
+        .def("dropout", [](const VarDiff& v, double p, const Status& s) { return v.dropout(p, s.flag); }).def("chunks", &VarDiff::chunks).def("cat", &VarDiff::cat)
+        .def("mse", &VarDiff::mse).def("pad", &VarDiff::pad, py::arg("padding"), py::arg("value") = 0.f)
+        .def("mm", py::overload_cast<const Var&>(&VarDiff::mm, py::const_))
+        .def("mm", py::overload_cast<const VarDiff&>(&VarDiff::mm, py::const_))
+        .def("mm_t", py::overload_cast<const Var&>(&VarDiff::mm_t, py::const_))
+        .def("mm_t", py::overload_cast<const VarDiff&>(&VarDiff::mm_t, py::const_))
+        .def("convolution", py::overload_cast<const Var&, const std::vector<int>&, const std::vector<int>&, int>(&VarDiff::convolution, py::const_))
+        .def("convolution", py::overload_cast<const VarDiff&, const std::vector<int>&, const std::vector<int>&, int>(&VarDiff::convolution, py::const_))
+        .def("__add__", [](const VarDiff& a, const Var& b) { return a + b; })
+        .def("__add__", [](const VarDiff& a, const VarDiff& b) { return a + b; })
+        .def("__add__", [](const VarDiff& a, float b) { return a + b; })
+        .def("__sub__", [](const VarDiff& a, const Var& b) { return a - b; })
+        .def("__sub__", [](const VarDiff& a, const VarDiff& b) { return a - b; })
+        .def("__sub__", [](const VarDiff& a, float b) { return a - b; })
+        .def("__mul__", [](const VarDiff& a, const Var& b) { return a * b; })
+        .def("__mul__", [](const VarDiff& a, const VarDiff& b) { return a * b; })
+        .def("__mul__", [](const VarDiff& a, float b) { return a * b; })
+        .def("__truediv__", [](const VarDiff& a, const Var& b) { return a / b; })
+        .def("__truediv__", [](const VarDiff& a, const VarDiff& b) { return a / b; })
+        .def("__truediv__", [](const VarDiff& a, float b) { return a / b; });
+
+    m.def("from_ndarray", [](DevicePtr dev, const Arr& a) { return from_host(std::move(dev), shape_of(a), a.data()); });
+    m.def("zeros", &zeros);
+    m.def("ones", &ones);
+    m.def("full", &full);
+    m.def("rand", &neuronika::rand);
+
+    py::module_ nn = m.def_submodule("nn");
+    py::class_<nn::Linear>(nn, "Linear")
+        .def(py::init<DevicePtr, int, int, uint64_t>(), py::arg("dev"), py::arg("in_features"), py::arg("out_features"), py::arg("seed") = 0)
+        .def(py::init<VarDiff, VarDiff>())
+        .def_readonly("weight", &nn::Linear::weight)
+        .def_readonly("bias", &nn::Linear::bias)
+        .def("forward", py::overload_cast<const Var&>(&nn::Linear::forward, py::const_))
+        .def("forward", py::overload_cast<const VarDiff&>(&nn::Linear::forward, py::const_));
+    py::class_<nn::Conv2d>(nn, "Conv2d")
+        .def(py::init<DevicePtr, int, int, std::vector<int>, std::vector<int>, std::vector<int>, std::vector<int>, int, uint64_t>(),
+             py::arg("dev"), py::arg("in_channels"), py::arg("out_channels"), py::arg("kernel"), py::arg("padding"),
+             py::arg("stride"), py::arg("dilation"), py::arg("groups") = 1, py::arg("seed") = 0)
+        .def_readonly("weight", &nn::Conv2d::weight)
+        .def_readonly("bias", &nn::Conv2d::bias)
+        .def("forward", py::overload_cast<const Var&>(&nn::Conv2d::forward, py::const_))
+        .def("forward", py::overload_cast<const VarDiff&>(&nn::Conv2d::forward, py::const_));
+    py::class_<nn::Dropout>(nn, "Dropout")
+        .def(py::init<double>())
+        .def("train", &nn::Dropout::train)
+        .def("eval", &nn::Dropout::eval)
+        .def("forward", &nn::Dropout::forward);
+    py::class_<nn::MultiheadAttention>(nn, "MultiheadAttention")
+        .def(py::init<DevicePtr, int, int, double, uint64_t>(), py::arg("dev"), py::arg("d_model"), py::arg("heads"),
+             py::arg("p") = 0.0, py::arg("seed") = 0)
+        .def_readonly("q", &nn::MultiheadAttention::q)
+        .def_readonly("k", &nn::MultiheadAttention::k)
+        .def_readonly("v", &nn::MultiheadAttention::v)
+        .def_readonly("o", &nn::MultiheadAttention::o)
+        .def_readonly("drop", &nn::MultiheadAttention::drop)
+        .def("forward", &nn::MultiheadAttention::forward);
+
+    py::module_ optim = m.def_submodule("optim");
+    py::class_<optim::SGD>(optim, "SGD")
+        .def(py::init([](float lr, float l1, float l2, float momentum, float dampening, bool nesterov) {
+                 return optim::SGD(lr, optim::Penalty{l1, l2}, momentum, dampening, nesterov);
+             }),
+             py::arg("lr"), py::arg("l1") = 0.f, py::arg("l2") = 0.f, py::arg("momentum") = 0.f, py::arg("dampening") = 0.f,
+             py::arg("nesterov") = false)
+        .def("register", &optim::SGD::register_param)
+        .def("step", &optim::SGD::step)
+        .def("zero_grad", &optim::SGD::zero_grad)
+        .def("get_lr", &optim::SGD::get_lr)
+        .def("set_lr", &optim::SGD::set_lr);
+
+    py::module_ dpm = m.def_submodule("dp");
+    py::class_<dp::Communicator, std::shared_ptr<dp::Communicator>>(dpm, "Communicator")
+        .def_static("unique_id", []() { return py::bytes(dp::Communicator::unique_id()); })
+        .def(py::init([](DevicePtr dev, int nranks, int rank, py::bytes id) {
+            return std::make_shared<dp::Communicator>(std::move(dev), nranks, rank, std::string(id));
+        }))
+        .def_property_readonly("rank", &dp::Communicator::rank)
+        .def_property_readonly("size", &dp::Communicator::size);
+    py::class_<dp::GradientSync>(dpm, "GradientSync")
+        .def(py::init<std::shared_ptr<dp::Communicator>, const std::vector<VarDiff>&>())
+        .def("join", &dp::GradientSync::join)
+        .def("bytes_per_step", &dp::GradientSync::bytes_per_step);
+    dpm.def("all_reduce_gradients", &dp::all_reduce_gradients);
+}

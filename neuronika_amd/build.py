@@ -66,5 +66,41 @@ def build(force: bool = False, verbose: bool = True) -> str:
     return LIB
 
 
+def build_tape(force: bool = False, verbose: bool = True) -> str:
+    """Build the C++ host tape mirror (host/*.cpp) + its pybind11 glue as neuronika_amd/_tape*.so,
+    linked against libneuronika_hip.so (rpath = $ORIGIN/lib)."""
+    import sysconfig
+
+    import pybind11
+
+    host = os.path.join(ROOT, "host")
+    srcs = [os.path.join(host, "neuronika.cpp"), os.path.join(host, "pymodule.cpp")]
+    deps = srcs + [os.path.join(host, "neuronika.hpp"), os.path.join(ROOT, "include", "neuronika_hip.h")]
+    ext = sysconfig.get_config_var("EXT_SUFFIX") or ".so"
+    out = os.path.join(HERE, "_tape" + ext)
+    if not force and os.path.exists(out) and os.path.getmtime(out) > max(os.path.getmtime(d) for d in deps):
+        if verbose:
+            print(f"[neuronika_amd.build] {out} (up to date)")
+        return out
+    cxx = os.environ.get("CXX", "g++")
+    cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-Wall",
+           "-I" + os.path.join(ROOT, "include"), "-I" + host, "-I" + pybind11.get_include(),
+           "-I" + sysconfig.get_paths()["include"], *srcs, "-o", out,
+           "-L" + LIBDIR, "-lneuronika_hip", "-Wl,-rpath,$ORIGIN/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"host tape build failed:\n{r.stdout}\n{r.stderr}")
+    if r.stderr.strip():
+        sys.stderr.write(r.stderr)
+    if verbose:
+        print(f"[neuronika_amd.build] {out} (rebuilt)")
+    return out
+
+
+def build_all(force: bool = False, verbose: bool = True):
+    build(force, verbose)
+    build_tape(force, verbose)
+
+
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build_all(force="--force" in sys.argv)

@@ -302,6 +302,20 @@ def other_cases():
     return c
 
 
+def quickstart_weights():
+    """The 3->5->5->1 MLP weights embedded as JSON in examples/quickstart.rs:53-169 (config C1)."""
+    src = open(os.path.join(REF, "examples", "quickstart.rs")).read()
+    m = re.search(r'r#"(.*?)"#', src, re.S)
+    line = src.count("\n", 0, m.start()) + 1
+    model = json.loads(m.group(1))
+    out = {"cite": f"examples/quickstart.rs:{line}"}
+    for name in ("lin1", "lin2", "lin3"):
+        for p in ("weight", "bias"):
+            t = model[name][p]
+            out[f"{name}.{p}"] = {"dim": t["dim"], "data": t["data"]}
+    return out
+
+
 def main():
     if not os.path.isdir(NODE):
         sys.exit(f"reference not found at {REF}; fixtures can only be regenerated in the authoring container")
@@ -312,6 +326,7 @@ def main():
         "convolution": conv,
         "im2col": im2col,
         "nodes": other_cases(),
+        "quickstart_mlp": quickstart_weights(),
     }
     with open(OUT, "w") as f:
         json.dump(fixtures, f, indent=1)

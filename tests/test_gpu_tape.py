@@ -1,0 +1,199 @@
+"""GPU tests of the C++ tape mirror (host/neuronika.hpp via neuronika_amd._tape): graph-level
+behaviour of Var / VarDiff as in the reference's neuronika-variable/src/test.rs, and the
+BASELINE configurations composed from it, against the CPU oracle."""
+import numpy as np
+import pytest
+
+from oracle import neuronika_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def nk():
+    import neuronika_amd
+    return neuronika_amd.tape
+
+
+@pytest.fixture(scope="module")
+def tdev(nk):
+    return nk.Device(0)
+
+
+def rnd(seed, shape, lo=0.0, hi=1.0):
+    a = np.random.default_rng(seed).random(shape, dtype=np.float32)
+    return np.asarray(a * np.float32(hi - lo) + np.float32(lo), dtype=np.float32).reshape(shape)
+
+
+def close(a, b, rtol=1e-5, atol=1e-6):
+    np.testing.assert_allclose(np.asarray(a), np.asarray(b), rtol=rtol, atol=atol)
+
+
+def test_differentiate_loop(nk, tdev):
+    """neuronika-variable/src/test.rs:127-141: x*4 five times -> 1024, grad 1024."""
+    x = nk.ones(tdev, []).requires_grad()
+    y = x
+    for _ in range(5):
+        x = x * 4.0
+    x.forward()
+    x.backward(1.0)
+    assert x.data()[()] == 1024.0
+    assert y.grad()[()] == 1024.0
+
+
+def test_scalar_ops(nk, tdev):
+    """test.rs:19-125 style: scalar arithmetic on full((2,2), 3)."""
+    x = nk.full(tdev, [2, 2], 3.0)
+    for op, want in ((lambda v: v + 9.0, 12.0), (lambda v: v - 1.0, 2.0), (lambda v: v * 3.0, 9.0), (lambda v: v / 3.0, 1.0)):
+        y = op(x)
+        y.forward()
+        assert np.array_equal(y.data(), np.full((2, 2), want, np.float32))
+
+
+def test_tape_lengths_and_laziness(nk, tdev):
+    """test.rs:538-806: each op adds exactly one tape entry; nothing is computed before forward()."""
+    a, b = nk.rand(tdev, [3, 3], 1).requires_grad(), nk.rand(tdev, [3, 3], 2).requires_grad()
+    for build in (lambda: a.mm(b), lambda: a.mm_t(b), lambda: a + b, lambda: a.relu(), lambda: a.softmax(1),
+                  lambda: a.log_softmax(0), lambda: a.sum(), lambda: a.mean(), lambda: a.t(),
+                  lambda: a.dropout(0.5, nk.Status(True))):
+        y = build()
+        assert y.history_len() == 1 and y.forward_history_len() == 1
+        assert not y.data().any()                 # zero-filled until forward()
+    y = (a.mm(b) + a).relu()
+    assert y.history_len() == 3
+    with pytest.raises(RuntimeError, match="forgot to call .forward"):
+        y.backward(1.0)
+    shared = a.mm(b)
+    z = shared + shared                            # one node reached twice is recorded once
+    assert z.history_len() == 2
+
+
+def test_backward_accumulates_and_no_grad(nk, tdev):
+    """matrix_matrix_mul/test.rs:85-91 at graph level + gradient.rs:64-79."""
+    a = nk.from_ndarray(tdev, np.linspace(1, 9, 9, dtype=np.float32).reshape(3, 3)).requires_grad()
+    b = nk.from_ndarray(tdev, np.linspace(10, 18, 9, dtype=np.float32).reshape(3, 3)).requires_grad()
+    y = a.mm(b)
+    y.forward(); y.backward(1.0)
+    want = np.array([[33, 42, 51]] * 3, np.float32)
+    close(a.grad(), want)
+    y.backward(1.0)
+    close(a.grad(), 2 * want)                      # leaves accumulate
+    a.zero_grad(); close(a.grad(), 0 * want)
+    h = a.mm(b).relu()                              # fresh intermediate node
+    h.forward(); h.backward(1.0); h.backward(1.0)   # intermediate grads are NOT re-zeroed
+    close(a.grad(), 3 * want)                       # 1 + 2 (the mm node's grad is 1 then 2)
+    h.no_grad()
+    with pytest.raises(RuntimeError, match="de-allocated gradient"):
+        h.grad()
+    h.with_grad()
+    a.zero_grad()
+    h.backward(1.0)
+    close(a.grad(), want)
+
+
+def test_quickstart_mlp_C1(nk, tdev, golden):
+    """Config C1: the 3->5->5->1 MLP of examples/quickstart.rs with its embedded weights,
+    batch 64, MSE mean, backward(1.0) — checked against the oracle's mlp_step."""
+    q = golden["quickstart_mlp"]
+    params = []
+    for name in ("lin1", "lin2", "lin3"):
+        w = np.asarray(q[f"{name}.weight"]["data"], np.float32).reshape(q[f"{name}.weight"]["dim"])
+        b = np.asarray(q[f"{name}.bias"]["data"], np.float32).reshape(q[f"{name}.bias"]["dim"])
+        params.append((w, b))
+    x, t = rnd(0, (64, 3)), rnd(1, (64, 1))
+    loss_ref, grads_ref = O.mlp_step(x, t, params)
+    lins = [nk.nn.Linear(nk.from_ndarray(tdev, w).requires_grad(), nk.from_ndarray(tdev, b).requires_grad()) for w, b in params]
+    X, T = nk.from_ndarray(tdev, x), nk.from_ndarray(tdev, t)
+    out = lins[2].forward(lins[1].forward(lins[0].forward(X).relu()).relu())
+    loss = out.mse(T, nk.Reduction.Mean)
+    assert loss.history_len() == 9 and loss.forward_history_len() == 9   # [MMT,Add,ReLU]x2, MMT, Add, MSE
+    loss.forward(); loss.backward(1.0)
+    close(loss.item(), loss_ref, 1e-5, 1e-6)
+    for lin, (dw, db) in zip(lins, grads_ref):
+        close(lin.weight.grad(), dw, 1e-4, 1e-6)
+        close(lin.bias.grad(), db, 1e-4, 1e-6)
+    # one SGD step (neuronika-optim/src/sgd/mod.rs:186-236), then zero_grad
+    opt = nk.optim.SGD(0.01)
+    for lin in lins:
+        opt.register(lin.weight); opt.register(lin.bias)
+    opt.step()
+    close(lins[0].weight.data(), params[0][0] - np.float32(0.01) * grads_ref[0][0], 1e-5, 1e-7)
+    opt.zero_grad()
+    assert not lins[0].weight.grad().any()
+
+
+def test_mlp_C4_shape_small_and_linearity(nk, tdev):
+    """C4-shaped MLP (three Linear(n,n) + ReLU, MSE mean) at n=256: parity with the oracle, and
+    the seed scales every leaf gradient linearly (backward(1/p) = mean over p shards)."""
+    n = 256
+    x, t = rnd(100, (n, n)), rnd(200, (n, n))
+    k = 1 / np.sqrt(n)
+    params = [(rnd(s, (n, n), -k, k), rnd(s + 10, (n,), -k, k)) for s in (1, 2, 3)]
+    loss_ref, grads_ref = O.mlp_step(x.astype(np.float64), t.astype(np.float64),
+                                     [(w.astype(np.float64), b.astype(np.float64)) for w, b in params], seed=0.25)
+    lins = [nk.nn.Linear(nk.from_ndarray(tdev, w).requires_grad(), nk.from_ndarray(tdev, b).requires_grad()) for w, b in params]
+    X, T = nk.from_ndarray(tdev, x), nk.from_ndarray(tdev, t)
+    loss = lins[2].forward(lins[1].forward(lins[0].forward(X).relu()).relu()).mse(T, nk.Reduction.Mean)
+    loss.forward(); loss.backward(0.25)
+    close(loss.item(), loss_ref, 1e-5)
+    for lin, (dw, db) in zip(lins, grads_ref):
+        close(lin.weight.grad(), dw, 1e-3, 1e-7)
+        close(lin.bias.grad(), db, 1e-3, 1e-7)
+
+
+def test_conv2d_module(nk, tdev):
+    """nn::Conv2d forward = pad -> convolution -> + bias (defined here; `todo!()` in the reference)."""
+    conv = nk.nn.Conv2d(tdev, 4, 6, [3, 3], [1, 1], [1, 1], [1, 1], 2, 5)
+    x = rnd(0, (2, 4, 9, 8))
+    X = nk.from_ndarray(tdev, x).requires_grad()
+    y = conv.forward(X)
+    y.forward()
+    w, b = conv.weight.data(), conv.bias.data()
+    xp = np.zeros((2, 4, 11, 10), np.float32); O.pad_constant_forward(x, xp, (1, 1), 0.0)
+    yr = np.zeros((2, 6, 9, 8), np.float32); O.convolution_forward(xp, w, yr, (1, 1), (1, 1), 2)
+    close(y.data(), yr + b, 1e-5, 1e-5)
+    s = y.sum(); s.forward(); s.backward(1.0)
+    g = np.ones_like(yr)
+    dw = np.zeros_like(w); O.convolution_backward_kernel(dw, g, xp, (1, 1), (1, 1), 2)
+    dxp = np.zeros_like(xp); O.convolution_backward_input(dxp, g, w, (1, 1), (1, 1), 2)
+    close(conv.weight.grad(), dw, 1e-4, 1e-4)
+    close(conv.bias.grad().reshape(-1), g.sum((0, 2, 3)), 1e-5, 1e-4)
+    close(X.grad(), dxp[:, :, 1:-1, 1:-1], 1e-4, 1e-5)
+
+
+def test_chunks_cat_dropout_graph(nk, tdev):
+    x = rnd(3, (6, 8))
+    X = nk.from_ndarray(tdev, x).requires_grad()
+    parts = X.chunks([3, 4])
+    assert len(parts) == 4
+    y = parts[0].cat([parts[1]], 1).cat([parts[2].cat([parts[3]], 1)], 0)   # reassembles x
+    st = nk.Status(True)
+    z = y.dropout(0.0, st)
+    s = (z * 2.0).sum()
+    s.forward(); s.backward(1.0)
+    close(y.data(), x)
+    close(s.item(), 2 * x.astype(np.float64).sum(), 1e-5)
+    close(X.grad(), np.full_like(x, 2.0))
+    with pytest.raises(RuntimeError, match="Wrong probability"):
+        X.dropout(1.5, st)
+
+
+def test_mha_C5_small(nk, tdev):
+    """C5-shaped composed attention at a small size against the oracle composition, with the
+    dropout mask read back from the device (same-mask parity) — p = 0 here, p > 0 in bench."""
+    B, S, d, H = 2, 64, 128, 4
+    mha = nk.nn.MultiheadAttention(tdev, d, H, 0.0, 11)
+    x = rnd(0, (B * S, d))
+    X = nk.from_ndarray(tdev, x).requires_grad()
+    out = mha.forward(X, B)
+    g = rnd(5, (B * S, d))
+    loss = (out * nk.from_ndarray(tdev, g)).sum()
+    loss.forward(); loss.backward(1.0)
+    W = {n: (getattr(mha, n).weight.data().astype(np.float64), getattr(mha, n).bias.data().astype(np.float64)) for n in "qkvo"}
+    noise = np.ones((B * H, S, S))
+    ref, grads = O.mha_forward_backward(x.astype(np.float64), *W["q"], *W["k"], *W["v"], *W["o"], H, B, 0.0, noise, g.astype(np.float64))
+    close(out.data(), ref, 1e-4, 1e-5)
+    close(X.grad(), grads["x"], 1e-3, 1e-5)
+    for n in "qkvo":
+        close(getattr(mha, n).weight.grad(), grads["w" + n], 1e-3, 1e-4)
+        close(getattr(mha, n).bias.grad(), grads["b" + n], 1e-3, 1e-4)
