@@ -93,6 +93,16 @@ int nk_event_sync(nk_event* ev);
 int nk_event_elapsed_ms(nk_event* start, nk_event* stop, float* ms);
 int nk_stream_wait_event(nk_device* dev, int on_comm_stream, nk_event* ev);
 
+/* ------------------------------------------------------------------ kernel timing ------ */
+/* Bench instrumentation: between nk_profile_begin and nk_profile_end every launch of the
+ * MFMA kernels is bracketed by a HIP event pair on the compute stream.  nk_profile_end
+ * synchronises and returns, for one kernel class, the number of launches, the sum of their
+ * durations and the algorithmic flop they performed (2*M*N*K per GEMM; 2*N*Cout*L*K per conv
+ * pass). */
+enum nk_kernel_class { NK_KERNEL_SGEMM = 0, NK_KERNEL_CONV = 1 };
+int nk_profile_begin(nk_device* dev);
+int nk_profile_end(nk_device* dev, int kernel_class, int* launches, double* total_ms, double* total_flop);
+
 /* ------------------------------------------------------------------ GEMM (MFMA) -------- */
 /* Row-major C(MxN) = alpha * op(A)(MxK) * op(B)(KxN) + beta * C; op(X) = X or X^T
  * (trans != 0: the stored matrix is the transpose, i.e. A is stored KxM with leading

@@ -64,6 +64,8 @@ _SIGS = {
     "nk_event_sync": [VP],
     "nk_event_elapsed_ms": [VP, VP, C.POINTER(C.c_float)],
     "nk_stream_wait_event": [VP, C.c_int, VP],
+    "nk_profile_begin": [VP],
+    "nk_profile_end": [VP, C.c_int, c_intp, C.POINTER(C.c_double), C.POINTER(C.c_double)],
     "nk_sgemm": [VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, VP, C.c_int, VP, C.c_int, C.c_float, VP, C.c_int],
     "nk_sgemm_batched": [VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                          VP, C.c_int, C.c_longlong, C.c_longlong, VP, C.c_int, C.c_longlong, C.c_longlong,
@@ -174,11 +176,16 @@ class Event:
 class Device:
     """`Device::new(idx)` (cuda/device.rs:34-58): one GPU, its compute + communication streams."""
 
-    def __init__(self, idx: int = 0):
+    def __init__(self, idx: int = 0, handle: int | None = None):
+        """`handle`: wrap an existing nk_device* (e.g. `tape.Device.raw()`) without owning it."""
+        if handle is not None:
+            self.h, self.idx, self._own = VP(handle), lib.nk_device_index(VP(handle)), False
+            return
         h = VP()
         check(lib.nk_device_create(idx, C.byref(h)))
         self.h = h
         self.idx = idx
+        self._own = True
 
     def sync(self):
         check(lib.nk_device_sync(self.h))
@@ -202,9 +209,18 @@ class Device:
         return out
 
     def close(self):
-        if self.h:
+        if self.h and self._own:
             lib.nk_device_destroy(self.h)
-            self.h = None
+        self.h = None
+
+    def profile_begin(self):
+        check(lib.nk_profile_begin(self.h))
+
+    def profile_end(self, kernel_class: int = 0):
+        """-> (launches, total_ms, total_flop) of one kernel class since profile_begin."""
+        n, ms, fl = C.c_int(0), C.c_double(0), C.c_double(0)
+        check(lib.nk_profile_end(self.h, kernel_class, C.byref(n), C.byref(ms), C.byref(fl)))
+        return n.value, ms.value, fl.value
 
 
 class HipArray:
@@ -252,6 +268,9 @@ class HipArray:
                 lib.nk_free(self.dev.h, self.p)
         except Exception:
             pass
+
+
+KERNEL_SGEMM, KERNEL_CONV = 0, 1
 
 
 # ------------------------------------------------------------------------------------------------

@@ -6,8 +6,15 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <vector>
 
 #include "neuronika_hip.h"
+
+struct nk_prof_rec {
+    hipEvent_t start, stop;
+    int klass;
+    double flop;
+};
 
 struct nk_device {
     int idx = 0;
@@ -18,7 +25,15 @@ struct nk_device {
     void* workspace = nullptr;      // stream-ordered scratch (split-K slabs, reduction partials)
     size_t workspace_bytes = 0;
     int num_cus = 256;
+    // bench instrumentation (nk_profile_begin/end)
+    bool prof_on = false;
+    std::vector<nk_prof_rec> prof;      // records of the current window
+    std::vector<nk_prof_rec> prof_free;  // recycled event pairs
 };
+
+// Event bracket around one kernel launch when profiling is on (no-ops otherwise).
+int nk_prof_start(nk_device* dev, int klass, double flop);
+int nk_prof_stop(nk_device* dev);
 
 struct nk_event {
     nk_device* dev;

@@ -446,10 +446,12 @@ int nk_conv_fwd(nk_device* dev, int nd, const float* x, const int* x_shape, cons
     p.tiles_n = (int)((cols + BN - 1) / BN);
     const bool aligned_a = (g.Mg % BM == 0) && (K % BK == 0) && al16(w);
     dim3 grid(p.tiles_m * p.tiles_n, 1, groups);
+    rc = nk_prof_start(dev, NK_KERNEL_CONV, 2.0 * g.N * (double)g.Cout * g.L * g.Cg * g.KK);
+    if (rc) return rc;
     if (aligned_a) hipLaunchKernelGGL((conv_fwd_kernel<true>), grid, dim3(NT), 0, dev->compute, p);
     else hipLaunchKernelGGL((conv_fwd_kernel<false>), grid, dim3(NT), 0, dev->compute, p);
     NK_LAUNCH_CHECK();
-    return NK_OK;
+    return nk_prof_stop(dev);
 }
 
 int nk_conv_bwd_input(nk_device* dev, int nd, float* dx, const int* x_shape, const float* gy, const float* w,
@@ -480,12 +482,14 @@ int nk_conv_bwd_input(nk_device* dev, int nd, float* dx, const int* x_shape, con
     const bool aligned_a = (g.Cg % BM == 0) && (K % BK == 0);
     const bool unit = g.stride[0] == 1 && g.stride[1] == 1 && g.stride[2] == 1;
     dim3 grid(p.tiles_m * p.tiles_n, 1, groups);
+    rc = nk_prof_start(dev, NK_KERNEL_CONV, 2.0 * g.N * (double)g.Cout * g.L * g.Cg * g.KK);
+    if (rc) return rc;
     if (aligned_a && unit) hipLaunchKernelGGL((conv_bwd_input_kernel<true, true>), grid, dim3(NT), 0, dev->compute, p);
     else if (aligned_a) hipLaunchKernelGGL((conv_bwd_input_kernel<true, false>), grid, dim3(NT), 0, dev->compute, p);
     else if (unit) hipLaunchKernelGGL((conv_bwd_input_kernel<false, true>), grid, dim3(NT), 0, dev->compute, p);
     else hipLaunchKernelGGL((conv_bwd_input_kernel<false, false>), grid, dim3(NT), 0, dev->compute, p);
     NK_LAUNCH_CHECK();
-    return NK_OK;
+    return nk_prof_stop(dev);
 }
 
 int nk_conv_bwd_kernel(nk_device* dev, int nd, float* dw, const int* w_shape, const float* gy, const float* x,
@@ -523,13 +527,15 @@ int nk_conv_bwd_kernel(nk_device* dev, int nd, float* dw, const int* w_shape, co
     NK_LAUNCH_CHECK();
     dim3 grid(p.tiles_m * p.tiles_n, (unsigned)splits, groups);
     const bool vec_g = (g.L % 4 == 0) && al16(gy);
+    rc = nk_prof_start(dev, NK_KERNEL_CONV, 2.0 * g.N * (double)g.Cout * g.L * g.Cg * g.KK);
+    if (rc) return rc;
     if (vec_g) hipLaunchKernelGGL((conv_bwd_kernel_kernel<true>), grid, dim3(NT), 0, dev->compute, p);
     else hipLaunchKernelGGL((conv_bwd_kernel_kernel<false>), grid, dim3(NT), 0, dev->compute, p);
     NK_LAUNCH_CHECK();
     hipLaunchKernelGGL(conv_dw_reduce_kernel, dim3(nk_stream_grid((size_t)dw_elems, 256)), dim3(256), 0, dev->compute, dw,
                        p.slabs, dw_elems, (int)splits);
     NK_LAUNCH_CHECK();
-    return NK_OK;
+    return nk_prof_stop(dev);
 }
 
 }  // extern "C"

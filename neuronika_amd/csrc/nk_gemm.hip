@@ -189,7 +189,8 @@ static int gemm_impl(nk_device* dev, int transA, int transB, int M, int N, int K
     const bool aligned = (M % BM == 0) && (N % BN == 0) && (K % BK == 0) && (lda % 4 == 0) &&
                          (ldb % 4 == 0) && aligned16(A) && aligned16(B) && (sAo % 4 == 0) &&
                          (sAi % 4 == 0) && (sBo % 4 == 0) && (sBi % 4 == 0);
-    int rc;
+    int rc = nk_prof_start(dev, NK_KERNEL_SGEMM, 2.0 * M * N * (double)K * nbatch);
+    if (rc) return rc;
     if (!transA && !transB) rc = launch<false, false>(dev, p, nbatch, aligned);
     else if (!transA && transB) rc = launch<false, true>(dev, p, nbatch, aligned);
     else if (transA && !transB) rc = launch<true, false>(dev, p, nbatch, aligned);
@@ -202,7 +203,7 @@ static int gemm_impl(nk_device* dev, int transA, int transB, int M, int N, int K
                            sCo, sCi, alpha, beta);
         NK_LAUNCH_CHECK();
     }
-    return NK_OK;
+    return nk_prof_stop(dev);
 }
 
 extern "C" {

@@ -35,7 +35,54 @@ int nk_workspace(nk_device* dev, size_t bytes, void** out) {
     return NK_OK;
 }
 
+int nk_prof_start(nk_device* dev, int klass, double flop) {
+    if (!dev->prof_on) return NK_OK;
+    nk_prof_rec r;
+    if (!dev->prof_free.empty()) {
+        r = dev->prof_free.back();
+        dev->prof_free.pop_back();
+    } else {
+        NK_HIP(hipEventCreate(&r.start));
+        NK_HIP(hipEventCreate(&r.stop));
+    }
+    r.klass = klass;
+    r.flop = flop;
+    NK_HIP(hipEventRecord(r.start, dev->compute));
+    dev->prof.push_back(r);
+    return NK_OK;
+}
+int nk_prof_stop(nk_device* dev) {
+    if (!dev->prof_on || dev->prof.empty()) return NK_OK;
+    NK_HIP(hipEventRecord(dev->prof.back().stop, dev->compute));
+    return NK_OK;
+}
+
 extern "C" {
+
+int nk_profile_begin(nk_device* dev) {
+    NK_USE(dev);
+    for (auto& r : dev->prof) dev->prof_free.push_back(r);
+    dev->prof.clear();
+    dev->prof_on = true;
+    return NK_OK;
+}
+
+int nk_profile_end(nk_device* dev, int kernel_class, int* launches, double* total_ms, double* total_flop) {
+    NK_USE(dev);
+    NK_CHECK(launches && total_ms && total_flop, "null output");
+    dev->prof_on = false;
+    NK_HIP(hipStreamSynchronize(dev->compute));
+    int n = 0;
+    double ms = 0.0, flop = 0.0;
+    for (auto& r : dev->prof) {
+        if (r.klass != kernel_class) continue;
+        float t = 0.f;
+        NK_HIP(hipEventElapsedTime(&t, r.start, r.stop));
+        ms += t; flop += r.flop; ++n;
+    }
+    *launches = n; *total_ms = ms; *total_flop = flop;
+    return NK_OK;
+}
 
 const char* nk_last_error(void) { return g_err; }
 const char* nk_version(void) { return "neuronika_hip 0.1 (gfx950)"; }
@@ -73,6 +120,8 @@ int nk_device_destroy(nk_device* dev) {
     NK_HIP(hipSetDevice(dev->idx));
     NK_HIP(hipDeviceSynchronize());
     if (dev->workspace) (void)hipFree(dev->workspace);
+    for (auto* v : {&dev->prof, &dev->prof_free})
+        for (auto& r : *v) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
     (void)hipEventDestroy(dev->fork);
     (void)hipEventDestroy(dev->join);
     (void)hipStreamDestroy(dev->compute);
