@@ -54,55 +54,35 @@ def parse():
 
 
 class Dist:
-    """Control plane only (rendezvous, barrier, max-reduction of timings, broadcasting the RCCL
-    id): torch.distributed over gloo.  The data path uses RCCL directly inside the HIP library."""
+    """Control plane only (rendezvous, barrier, max over ranks, broadcasting the RCCL id): plain
+    TCP over MASTER_ADDR:MASTER_PORT (neuronika_amd/rendezvous.py).  torch is deliberately NOT
+    imported in this process: its wheel bundles a second HIP/HSA runtime (see rendezvous.py).
+    The data path (gradient all-reduce) is RCCL inside the HIP library."""
 
     def __init__(self, want):
-        self.rank = int(os.environ.get("RANK", "0"))
-        self.world = int(os.environ.get("WORLD_SIZE", "1"))
-        self.local = int(os.environ.get("LOCAL_RANK", "0"))
-        self.td = None
-        if self.world > 1:
-            import torch.distributed as td
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29512")
-            td.init_process_group("gloo", rank=self.rank, world_size=self.world)
-            self.td = td
+        from neuronika_amd.rendezvous import Rendezvous
+        self.rv = Rendezvous()
+        self.rank, self.world, self.local = self.rv.rank, self.rv.world, self.rv.local
         if want != self.world and self.rank == 0:
             print(f"[bench] --gpus {want} but WORLD_SIZE={self.world}: running on {self.world} process(es)", file=sys.stderr)
 
     def barrier(self):
-        if self.td:
-            self.td.barrier()
+        self.rv.barrier()
 
     def bcast_bytes(self, b):
-        if not self.td:
-            return b
-        obj = [b]
-        self.td.broadcast_object_list(obj, src=0)
-        return obj[0]
+        return self.rv.broadcast(b)
 
     def max(self, v: float) -> float:
-        if not self.td:
-            return v
-        import torch
-        t = torch.tensor([v], dtype=torch.float64)
-        self.td.all_reduce(t, op=self.td.ReduceOp.MAX)
-        return float(t.item())
+        return self.rv.max(v)
 
     def close(self):
-        if self.td:
-            self.td.destroy_process_group()
+        self.rv.close()
 
 
 def device_sync(tdev):
+    """Drain both streams of this rank's device (our equivalent of torch.cuda.synchronize(): the
+    work runs on the library's own HIP streams, which torch does not see)."""
     tdev.sync()
-    try:  # the contract asks for torch.cuda.synchronize() as well; our streams are our own
-        import torch
-        if torch.cuda.is_available():
-            torch.cuda.synchronize()
-    except Exception:
-        pass
 
 
 def timed_steps(dist, tdev, cdev, step, steps, warmup):

@@ -35,8 +35,9 @@ struct nk_device {
 int nk_prof_start(nk_device* dev, int klass, double flop);
 int nk_prof_stop(nk_device* dev);
 
-struct nk_event {
-    nk_device* dev;
+struct nk_event {  // self-contained: stays valid (for destroy) after its device handle is gone
+    int idx;
+    hipStream_t compute, comm;
     hipEvent_t ev;
 };
 

@@ -188,7 +188,7 @@ int nk_copy(nk_device* dev, float* dst, const float* src, size_t n) {
 int nk_event_create(nk_device* dev, nk_event** out) {
     NK_USE(dev);
     NK_CHECK(out != nullptr, "null out");
-    nk_event* e = new nk_event{dev, nullptr};
+    nk_event* e = new nk_event{dev->idx, dev->compute, dev->comm, nullptr};
     NK_HIP(hipEventCreate(&e->ev));
     *out = e;
     return NK_OK;
@@ -196,7 +196,7 @@ int nk_event_create(nk_device* dev, nk_event** out) {
 
 int nk_event_destroy(nk_event* ev) {
     if (!ev) return NK_OK;
-    (void)hipSetDevice(ev->dev->idx);
+    (void)hipSetDevice(ev->idx);
     (void)hipEventDestroy(ev->ev);
     delete ev;
     return NK_OK;
@@ -204,21 +204,21 @@ int nk_event_destroy(nk_event* ev) {
 
 int nk_event_record(nk_event* ev, int on_comm_stream) {
     NK_CHECK(ev != nullptr, "null event");
-    NK_USE(ev->dev);
-    NK_HIP(hipEventRecord(ev->ev, on_comm_stream ? ev->dev->comm : ev->dev->compute));
+    NK_HIP(hipSetDevice(ev->idx));
+    NK_HIP(hipEventRecord(ev->ev, on_comm_stream ? ev->comm : ev->compute));
     return NK_OK;
 }
 
 int nk_event_sync(nk_event* ev) {
     NK_CHECK(ev != nullptr, "null event");
-    NK_USE(ev->dev);
+    NK_HIP(hipSetDevice(ev->idx));
     NK_HIP(hipEventSynchronize(ev->ev));
     return NK_OK;
 }
 
 int nk_event_elapsed_ms(nk_event* start, nk_event* stop, float* ms) {
     NK_CHECK(start && stop && ms, "null argument");
-    NK_USE(start->dev);
+    NK_HIP(hipSetDevice(start->idx));
     NK_HIP(hipEventElapsedTime(ms, start->ev, stop->ev));
     return NK_OK;
 }
