@@ -199,6 +199,42 @@ __global__ void reduce_cols_kernel(float* __restrict__ part, const float* __rest
     part[(long long)blockIdx.y * p.K + k] = (acc0 + acc1) + (acc2 + acc3);
 }
 
+// Column reduction, wide form (K % 4 == 0, no operand data needed: add / sub gradients, i.e. the
+// bias gradient of `x.mm_t(W) + b`): a block is 64 column-quads x 4 row-lanes, every lane moves
+// 16 B per row (one wave = 1 KiB contiguous), the 4 row-lanes are folded through LDS.
+template <int MODE>
+__global__ void reduce_cols4_kernel(float* __restrict__ part, const float* __restrict__ g, Rkr p) {
+    __shared__ float4 red[4][64];
+    const int cq = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int k = (blockIdx.x * 64 + cq) * 4;
+    const int r_beg = blockIdx.y * p.rows_per_chunk;
+    const int r_end = min(p.R0, r_beg + p.rows_per_chunk);
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (k < p.K) {
+        int r = r_beg + rl;
+        for (; r + 4 < r_end; r += 8) {
+            const float4 u = *reinterpret_cast<const float4*>(g + (long long)r * p.K + k);
+            const float4 v = *reinterpret_cast<const float4*>(g + (long long)(r + 4) * p.K + k);
+            a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+            b.x += v.x; b.y += v.y; b.z += v.z; b.w += v.w;
+        }
+        for (; r < r_end; r += 4) {
+            const float4 u = *reinterpret_cast<const float4*>(g + (long long)r * p.K + k);
+            a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+        }
+    }
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    red[rl][cq] = a;
+    __syncthreads();
+    if (rl == 0 && k < p.K) {
+        float4 s = red[0][cq];
+#pragma unroll
+        for (int i = 1; i < 4; ++i) { s.x += red[i][cq].x; s.y += red[i][cq].y; s.z += red[i][cq].z; s.w += red[i][cq].w; }
+        if (MODE == 1) { s.x = -s.x; s.y = -s.y; s.z = -s.z; s.w = -s.w; }
+        *reinterpret_cast<float4*>(part + (long long)blockIdx.y * p.K + k) = s;
+    }
+}
+
 // R1 > 1: one block per (k, chunk); threads stride over (r0 in chunk) x r1 with r1 contiguous.
 template <int MODE>
 __global__ void reduce_rkr_kernel(float* __restrict__ part, const float* __restrict__ g,
@@ -348,10 +384,11 @@ int bwd_dispatch(nk_device* dev, float* d, const int* t_shape, int t_nd, const f
         }
         // chunking of R0 so that the grid fills the chip; partials in the workspace
         int chunks;
+        const bool cols4 = p.R1 == 1 && MODE <= 1 && p.K % 4 == 0 && al16(g);
         if (p.R1 == 1) {
             const int colblocks = (p.K + 255) / 256;
-            chunks = (2048 + colblocks - 1) / colblocks;
-            if (chunks > (p.R0 + 15) / 16) chunks = (p.R0 + 15) / 16;
+            chunks = (1024 + colblocks - 1) / colblocks;
+            if (chunks > (p.R0 + 31) / 32) chunks = (p.R0 + 31) / 32;
         } else {
             chunks = (1024 + p.K - 1) / p.K;
             if (chunks > p.R0) chunks = p.R0;
@@ -365,7 +402,9 @@ int bwd_dispatch(nk_device* dev, float* d, const int* t_shape, int t_nd, const f
         rc = nk_workspace(dev, (size_t)chunks * p.K * sizeof(float), &ws);
         if (rc) return rc;
         float* part = (float*)ws;
-        if (p.R1 == 1)
+        if (cols4)
+            hipLaunchKernelGGL((reduce_cols4_kernel<MODE>), dim3((p.K + 255) / 256, chunks), dim3(256), 0, dev->compute, part, g, p);
+        else if (p.R1 == 1)
             hipLaunchKernelGGL((reduce_cols_kernel<MODE>), dim3((p.K + 255) / 256, chunks), dim3(256), 0, dev->compute, part, g, o, q, p);
         else
             hipLaunchKernelGGL((reduce_rkr_kernel<MODE>), dim3(p.K, chunks), dim3(256), 0, dev->compute, part, g, o, q, p);

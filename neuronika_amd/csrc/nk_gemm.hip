@@ -6,6 +6,8 @@
 // register-staged global loads issued before the MFMAs of the current tile and written to
 // LDS after them (one barrier per k-tile), XCD-aware tile order, split-K with a deterministic
 // second pass when M*N alone cannot fill the chip.
+#include <cstdlib>
+
 #include "nk_mma.h"
 
 using namespace nkmma;
@@ -27,7 +29,8 @@ struct GemmArgs {
     int tiles_m, tiles_n;
 };
 
-template <bool TA, bool TB, bool ALIGNED>
+// VAR: tuning experiments (selected by env NK_GEMM_VARIANT; 0 = default)
+template <bool TA, bool TB, bool ALIGNED, int VAR = 0>
 __global__ __launch_bounds__(NT, 2) void sgemm_kernel(GemmArgs p) {
     __shared__ __attribute__((aligned(16))) float smem[2 * STAGE_FLOATS];  // 73,728 B -> 2 blocks/CU
     constexpr bool AKC = !TA;  // A (M x K): k-contiguous unless stored transposed
@@ -49,6 +52,9 @@ __global__ __launch_bounds__(NT, 2) void sgemm_kernel(GemmArgs p) {
 
     f32x16 acc[2][2];
     acc_zero(acc);
+    if (VAR == 3 && (blockIdx.x & 256)) {  // de-phase the two blocks that share a CU
+        for (int i = 0; i < 32; ++i) __builtin_amdgcn_s_sleep(127);
+    }
 
     Stage ra, rb;
     TileLoader<AKC> la;
@@ -69,8 +75,9 @@ __global__ __launch_bounds__(NT, 2) void sgemm_kernel(GemmArgs p) {
         // write them to the other LDS buffer after the MFMAs: one barrier per k-tile
         ra = la.template load<ALIGNED>(t);
         rb = lb.template load<ALIGNED>(t);
-        __builtin_amdgcn_sched_barrier(0);
-        mma_tile<AKC, BKC>(cur, cur + TILE_FLOATS, acc, wr, wc, lane);
+        if (VAR != 2) __builtin_amdgcn_sched_barrier(0);
+        mma_tile<AKC, BKC, VAR == 1>(cur, cur + TILE_FLOATS, acc, wr, wc, lane);
+        if (VAR == 4) __builtin_amdgcn_sched_barrier(0);  // all 64 MFMAs issued before the vmcnt wait
         stage_store<AKC>(nxt, ra, t);
         stage_store<BKC>(nxt + TILE_FLOATS, rb, t);
         __syncthreads();
@@ -132,7 +139,16 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 template <bool TA, bool TB>
 static int launch(nk_device* dev, const GemmArgs& p, int nbatch, bool aligned) {
     dim3 grid(p.tiles_m * p.tiles_n, p.splits, nbatch), block(NT);
-    if (aligned)
+    static const int variant = getenv("NK_GEMM_VARIANT") ? atoi(getenv("NK_GEMM_VARIANT")) : 0;
+    if (aligned && variant == 1)
+        hipLaunchKernelGGL((sgemm_kernel<TA, TB, true, 1>), grid, block, 0, dev->compute, p);
+    else if (aligned && variant == 2)
+        hipLaunchKernelGGL((sgemm_kernel<TA, TB, true, 2>), grid, block, 0, dev->compute, p);
+    else if (aligned && variant == 3)
+        hipLaunchKernelGGL((sgemm_kernel<TA, TB, true, 3>), grid, block, 0, dev->compute, p);
+    else if (aligned && variant == 4)
+        hipLaunchKernelGGL((sgemm_kernel<TA, TB, true, 4>), grid, block, 0, dev->compute, p);
+    else if (aligned)
         hipLaunchKernelGGL((sgemm_kernel<TA, TB, true>), grid, block, 0, dev->compute, p);
     else
         hipLaunchKernelGGL((sgemm_kernel<TA, TB, false>), grid, block, 0, dev->compute, p);

@@ -131,7 +131,7 @@ __device__ __forceinline__ void frag_read(float (&f)[4], const float* Xs, int ro
 
 // Fragments of k-group g+1 are read from LDS BEFORE the 16 MFMAs of group g are issued (the
 // sched_barrier pins that order), so the ds_read latency hides under 16 x 64 MFMA cycles.
-template <bool AKC, bool BKC>
+template <bool AKC, bool BKC, bool PRIO = false>
 __device__ __forceinline__ void mma_tile(const float* As, const float* Bs, f32x16 (&acc)[2][2],
                                          int wr, int wc, int lane) {
     float a[2][2][4], b[2][2][4];  // [buffer][tile][step]
@@ -149,6 +149,7 @@ __device__ __forceinline__ void mma_tile(const float* As, const float* Bs, f32x1
             for (int j = 0; j < 2; ++j) frag_read<BKC>(b[nb][j], Bs, wc * 64 + j * 32, (g + 1) * 8, lane);
             __builtin_amdgcn_sched_barrier(0);
         }
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -156,6 +157,7 @@ __device__ __forceinline__ void mma_tile(const float* As, const float* Bs, f32x1
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cb][i][s], b[cb][j][s], acc[i][j], 0, 0, 0);
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
     }
 }
 
