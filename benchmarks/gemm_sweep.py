@@ -12,7 +12,8 @@ def run(M, N, K, ta=0, tb=0, beta=0.0, iters=10):
     ms = timeit(dev, lambda: c.sgemm(dev, ta, tb, M, N, K, 1.0, A, A.shape[1], B, B.shape[1], beta, C, N), iters)
     print(json.dumps(dict(M=M, N=N, K=K, ta=ta, tb=tb, beta=beta, ms=round(ms, 4), tflops=round(2.0 * M * N * K / ms / 1e9, 1))), flush=True)
 
-for K in (512, 1024, 2048, 4096, 8192, 16384):
+for _ in range(30): run(4096, 4096, 4096, iters=10) if _ == 29 else None
+for K in ():
     run(4096, 4096, K)
 for beta in (0.0, 1.0):
     run(4096, 4096, 4096, beta=beta)

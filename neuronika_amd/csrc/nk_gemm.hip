@@ -73,13 +73,17 @@ __global__ __launch_bounds__(NT, 2) void sgemm_kernel(GemmArgs p) {
         float* nxt = smem + ((it + 1) & 1) * STAGE_FLOATS;
         // issue the next tile's HBM/L2 loads before the MFMAs (their latency hides under them),
         // write them to the other LDS buffer after the MFMAs: one barrier per k-tile
-        ra = la.template load<ALIGNED>(t);
-        rb = lb.template load<ALIGNED>(t);
+        if (VAR != 5 && VAR != 6) {
+            ra = la.template load<ALIGNED>(t);
+            rb = lb.template load<ALIGNED>(t);
+        }
         if (VAR != 2) __builtin_amdgcn_sched_barrier(0);
         mma_tile<AKC, BKC, VAR == 1>(cur, cur + TILE_FLOATS, acc, wr, wc, lane);
         if (VAR == 4) __builtin_amdgcn_sched_barrier(0);  // all 64 MFMAs issued before the vmcnt wait
-        stage_store<AKC>(nxt, ra, t);
-        stage_store<BKC>(nxt + TILE_FLOATS, rb, t);
+        if (VAR != 6) {
+            stage_store<AKC>(nxt, ra, t);
+            stage_store<BKC>(nxt + TILE_FLOATS, rb, t);
+        }
         __syncthreads();
     }
     if (nt > 0) {
@@ -116,6 +120,76 @@ __global__ __launch_bounds__(NT, 2) void sgemm_kernel(GemmArgs p) {
     }
 }
 
+// LDS-DMA variant of the same GEMM for fully aligned problems: tiles go HBM/L2 -> LDS directly
+// (`global_load_lds_dwordx4`), two LDS stages of 32 KiB, one `__syncthreads()` (which drains the
+// outstanding DMA) per k-tile.  Removes the staging registers and the ds_write pass that cost
+// ~8 % of the MFMA pipe in the register-staged kernel (ablation in DESIGN.md).
+template <bool TA, bool TB>
+__global__ __launch_bounds__(NT, 2) void sgemm_glds_kernel(GemmArgs p) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * GSTAGE_FLOATS];  // 65,536 B
+    constexpr bool AKC = !TA;
+    constexpr bool BKC = TB;
+    const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    const int wr = wid >> 1, wc = wid & 1;
+    int tm, tn;
+    tile_coords(blockIdx.x, gridDim.x, p.tiles_m, p.tiles_n, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int batch = blockIdx.z, split = blockIdx.y;
+    const int bo = batch / p.batch_inner, bi = batch % p.batch_inner;
+    const float* A = p.A + bo * p.sAo + bi * p.sAi;
+    const float* B = p.B + bo * p.sBo + bi * p.sBi;
+    const int kbeg = split * p.k_per_split;
+    const int kend = min(p.K, kbeg + p.k_per_split);
+    const int nt = (kend - kbeg) / BK;
+
+    f32x16 acc[2][2];
+    acc_zero(acc);
+    GldsLoader<AKC> la;
+    GldsLoader<BKC> lb;
+    la.init(A, p.lda, m0, kbeg, t);
+    lb.init(B, p.ldb, n0, kbeg, t);
+    const unsigned sbase = lds_addr(smem);
+    if (nt > 0) {
+        la.issue(sbase, t);
+        lb.issue(sbase + GTILE_FLOATS * 4u, t);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    for (int it = 0; it < nt; ++it) {
+        const int cb = it & 1;
+        float* cur = smem + cb * GSTAGE_FLOATS;
+        if (it + 1 < nt) {  // DMA of tile it+1 flies under the 64 MFMAs of tile it
+            const unsigned nxt = sbase + (cb ^ 1) * (GSTAGE_FLOATS * 4u);
+            la.issue(nxt, t);
+            lb.issue(nxt + GTILE_FLOATS * 4u, t);
+        }
+        mma_tile_g<AKC, BKC>(cur, cur + GTILE_FLOATS, acc, wr, wc, lane);
+        // my DMA pieces have landed and my fragment reads are done -> everyone may swap buffers
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+
+    if (p.splits > 1) {
+        float* S = p.slabs + ((long long)split * gridDim.z + batch) * (long long)p.M * p.N;
+        const int N = p.N;
+        acc_foreach(acc, wr, wc, lane, [&](int r, int c, float v) { S[(long long)(m0 + r) * N + n0 + c] = v; });
+        return;
+    }
+    float* C = p.C + bo * p.sCo + bi * p.sCi;
+    const float alpha = p.alpha, beta = p.beta;
+    const long long ldc = p.ldc;
+    if (beta == 0.f) {
+        acc_foreach(acc, wr, wc, lane, [&](int r, int c, float v) { C[(m0 + r) * ldc + n0 + c] = alpha * v; });
+    } else {
+        acc_foreach(acc, wr, wc, lane, [&](int r, int c, float v) {
+            float* q = &C[(m0 + r) * ldc + n0 + c];
+            *q = fmaf(beta, *q, alpha * v);
+        });
+    }
+}
+
 // Second pass of split-K: C = alpha * sum_s slab[s] + beta * C, fixed summation order.
 __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ C, int M, int N,
                                      long long ldc, int splits, int nbatch, int batch_inner,
@@ -140,7 +214,9 @@ template <bool TA, bool TB>
 static int launch(nk_device* dev, const GemmArgs& p, int nbatch, bool aligned) {
     dim3 grid(p.tiles_m * p.tiles_n, p.splits, nbatch), block(NT);
     static const int variant = getenv("NK_GEMM_VARIANT") ? atoi(getenv("NK_GEMM_VARIANT")) : 0;
-    if (aligned && variant == 1)
+    if (aligned && variant == 7)  // LDS-DMA staging (same speed as the default; kept selectable)
+        hipLaunchKernelGGL((sgemm_glds_kernel<TA, TB>), grid, block, 0, dev->compute, p);
+    else if (aligned && variant == 1)
         hipLaunchKernelGGL((sgemm_kernel<TA, TB, true, 1>), grid, block, 0, dev->compute, p);
     else if (aligned && variant == 2)
         hipLaunchKernelGGL((sgemm_kernel<TA, TB, true, 2>), grid, block, 0, dev->compute, p);
@@ -148,6 +224,10 @@ static int launch(nk_device* dev, const GemmArgs& p, int nbatch, bool aligned) {
         hipLaunchKernelGGL((sgemm_kernel<TA, TB, true, 3>), grid, block, 0, dev->compute, p);
     else if (aligned && variant == 4)
         hipLaunchKernelGGL((sgemm_kernel<TA, TB, true, 4>), grid, block, 0, dev->compute, p);
+    else if (aligned && variant == 5)  // ablation: no global loads (results are garbage)
+        hipLaunchKernelGGL((sgemm_kernel<TA, TB, true, 5>), grid, block, 0, dev->compute, p);
+    else if (aligned && variant == 6)  // ablation: no global loads, no LDS stores
+        hipLaunchKernelGGL((sgemm_kernel<TA, TB, true, 6>), grid, block, 0, dev->compute, p);
     else if (aligned)
         hipLaunchKernelGGL((sgemm_kernel<TA, TB, true>), grid, block, 0, dev->compute, p);
     else

@@ -129,6 +129,102 @@ __device__ __forceinline__ void frag_read(float (&f)[4], const float* Xs, int ro
     }
 }
 
+// ---- direct global->LDS staging (LDS-DMA) --------------------------------------------------------
+// `global_load_lds_dwordx4` writes wave-uniform-base + lane*16 B, so the LDS image must be
+// lane-linear: KC tiles become UNPADDED [row][32] with the 16-B k-quad XOR-swizzled by (row & 7)
+// on the SOURCE address (and the same XOR on the read: cdna_hip_programming.md rule 21); RC tiles
+// [k][128] are lane-linear as they are.  No staging VGPRs, no ds_write instructions.
+constexpr int LDKS = BK;                     // swizzled KC row stride (floats)
+constexpr int GTILE_FLOATS = 128 * BK;       // one operand tile, 16 KiB
+constexpr int GSTAGE_FLOATS = 2 * GTILE_FLOATS;
+
+template <bool KC>
+struct GldsLoader {
+    const float* base;   // wave-uniform tile origin, advanced per k-tile
+    long long kstep;
+    unsigned o0, o1, o2, o3;  // per-thread element offsets of the four 16-B pieces
+    __device__ __forceinline__ void init(const float* X, long long ld, int row0, int k0, int t) {
+        base = KC ? X + (long long)row0 * ld + k0 : X + (long long)k0 * ld + row0;
+        kstep = KC ? BK : (long long)BK * ld;
+        o0 = off(t, ld); o1 = off(t + NT, ld); o2 = off(t + 2 * NT, ld); o3 = off(t + 3 * NT, ld);
+    }
+    static __device__ __forceinline__ unsigned off(int idx, long long ld) {
+        if (KC) {
+            const int row = idx >> 3, kq = (idx & 7) ^ (row & 7);
+            return (unsigned)(row * ld + kq * 4);
+        }
+        return (unsigned)((idx >> 5) * ld + (idx & 31) * 4);
+    }
+    // One asynchronous 16-B-per-lane copy HBM/L2 -> LDS.  Inline asm on purpose: hipcc would
+    // otherwise wait vmcnt(0) before the next LDS read (it cannot tell which LDS bytes a DMA
+    // writes) and serialise the prefetch; here the wait is placed by hand, once per k-tile, in
+    // front of the barrier (cdna_hip_programming.md 5.7: M0 is set and restored inside the asm).
+    static __device__ __forceinline__ void glds16(const float* gsrc, unsigned lds_byte_addr) {
+        unsigned keep;
+        asm volatile(
+            "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(gsrc), "s"(lds_byte_addr)
+            : "memory");
+    }
+    // issue the four copies of the current k-tile into the tile at LDS byte address `tile_addr`
+    // (wave-uniform) and advance to the next k-tile
+    __device__ __forceinline__ void issue(unsigned tile_addr, int t) {
+        const unsigned wbase = __builtin_amdgcn_readfirstlane(tile_addr + (unsigned)(t & ~63) * 16u);
+        glds16(base + o0, wbase);
+        glds16(base + o1, wbase + NT * 16u);
+        glds16(base + o2, wbase + 2u * NT * 16u);
+        glds16(base + o3, wbase + 3u * NT * 16u);
+        base += kstep;
+    }
+};
+
+// LDS byte address of a __shared__ object (for M0)
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) void*)p;
+}
+
+template <bool KC>
+__device__ __forceinline__ void frag_read_g(float (&f)[4], const float* Xs, int rowbase, int k8, int lane) {
+    const int r = lane & 31, h = lane >> 5;
+    if (KC) {
+        const int row = rowbase + r, q = (k8 >> 2) + h;
+        const float4 v = *reinterpret_cast<const float4*>(&Xs[row * LDKS + ((q ^ (row & 7)) << 2)]);
+        f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) f[i] = Xs[(k8 + 4 * h + i) * LDR + rowbase + r];
+    }
+}
+
+template <bool AKC, bool BKC>
+__device__ __forceinline__ void mma_tile_g(const float* As, const float* Bs, f32x16 (&acc)[2][2],
+                                           int wr, int wc, int lane) {
+    float a[2][2][4], b[2][2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) frag_read_g<AKC>(a[0][i], As, wr * 64 + i * 32, 0, lane);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) frag_read_g<BKC>(b[0][j], Bs, wc * 64 + j * 32, 0, lane);
+#pragma unroll
+    for (int g = 0; g < BK / 8; ++g) {
+        const int cb = g & 1, nb = cb ^ 1;
+        if (g + 1 < BK / 8) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) frag_read_g<AKC>(a[nb][i], As, wr * 64 + i * 32, (g + 1) * 8, lane);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) frag_read_g<BKC>(b[nb][j], Bs, wc * 64 + j * 32, (g + 1) * 8, lane);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cb][i][s], b[cb][j][s], acc[i][j], 0, 0, 0);
+    }
+}
+
 // Fragments of k-group g+1 are read from LDS BEFORE the 16 MFMAs of group g are issued (the
 // sched_barrier pins that order), so the ds_read latency hides under 16 x 64 MFMA cycles.
 template <bool AKC, bool BKC, bool PRIO = false>

@@ -197,3 +197,40 @@ def test_mha_C5_small(nk, tdev):
     for n in "qkvo":
         close(getattr(mha, n).weight.grad(), grads["w" + n], 1e-3, 1e-4)
         close(getattr(mha, n).bias.grad(), grads["b" + n], 1e-3, 1e-4)
+
+
+def test_rccl_single_rank_and_gradient_sync(nk, tdev):
+    """Exercise the RCCL entry points on the GPU box (1 GPU => world of one): unique id,
+    communicator, side-stream all-reduce ordered after a compute-stream event, join; and the
+    overlapped GradientSync hook (grad_ready fires once per registered parameter, in reverse
+    layer order, gradients unchanged by a sum over one rank)."""
+    from neuronika_amd import capi
+    cdev = capi.Device(handle=tdev.raw())
+    uid = capi.Comm.unique_id()
+    assert len(uid) == 128
+    comm = capi.Comm(cdev, 1, 0, uid)
+    x = np.arange(1 << 20, dtype=np.float32)
+    X = cdev.array(x)
+    capi.relu_fwd(cdev, X, X)                       # work on the compute stream first
+    ev = cdev.event().record()
+    comm.allreduce_sum_async(X, ev)
+    comm.allreduce_sum_async(X, None)
+    comm.join()
+    assert np.array_equal(X.numpy(), x)
+    comm.close()
+
+    tcomm = nk.dp.Communicator(tdev, 1, 0, nk.dp.Communicator.unique_id())
+    lins = [nk.nn.Linear(tdev, 32, 32, s) for s in (1, 2)]
+    params = [p for l in lins for p in (l.weight, l.bias)]
+    sync = nk.dp.GradientSync(tcomm, params)
+    assert sync.bytes_per_step() == 2 * (32 * 32 + 32) * 4
+    X = nk.rand(tdev, [16, 32], 3)
+    loss = lins[1].forward(lins[0].forward(X).relu()).mse(nk.rand(tdev, [16, 32], 4), nk.Reduction.Mean)
+    loss.forward(); loss.backward(1.0)
+    want = [p.grad().copy() for p in params]
+    for p in params:
+        p.zero_grad()
+    loss.no_grad(); loss.with_grad()
+    loss.backward_sync(1.0, sync); sync.join()
+    for p, w in zip(params, want):
+        close(p.grad(), w, 1e-6, 1e-7)
