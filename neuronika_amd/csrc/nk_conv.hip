@@ -85,9 +85,11 @@ struct FwdArgs {
     int tiles_m, tiles_n;
 };
 
-template <bool ALIGNED_A>
+template <bool ALIGNED_A, int TI>
 __global__ __launch_bounds__(NT, 2) void conv_fwd_kernel(FwdArgs p) {
-    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE_FLOATS];
+    constexpr int TJ = 2, BM = 64 * TI, BN = 64 * TJ;
+    constexpr int TA_FLOATS = tile_floats<BM>(), STAGE = TA_FLOATS + tile_floats<BN>();
+    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
     const ConvGeom& g = p.g;
     const int t = threadIdx.x, lane = t & 63, wid = t >> 6, wr = wid >> 1, wc = wid & 1;
     int tm, tn;
@@ -116,50 +118,58 @@ __global__ __launch_bounds__(NT, 2) void conv_fwd_kernel(FwdArgs p) {
         NK_COL(0, b0, v0) NK_COL(1, b1, v1) NK_COL(2, b2, v2) NK_COL(3, b3, v3)
 #undef NK_COL
     }
+    // the four columns are neighbours in one output row (unit stride): one 16-B load per k
+    const bool quad = v3 && b1 == b0 + 1 && b2 == b0 + 2 && b3 == b0 + 3;
     auto gather = [&](int k0) {
-        Stage r;
+        Stage<4> r;
 #define NK_ROW(j, V)                                                                  \
     {                                                                                 \
         const int k = k0 + krow + 8 * j;                                              \
         const bool kv = k < K;                                                        \
         const int off = kv ? p.koff[k] : 0;                                           \
-        V = make_float4(kv && v0 ? X[b0 + off] : 0.f, kv && v1 ? X[b1 + off] : 0.f,   \
-                        kv && v2 ? X[b2 + off] : 0.f, kv && v3 ? X[b3 + off] : 0.f);  \
+        if (quad) {                                                                   \
+            const f32x4u q = kv ? *reinterpret_cast<const f32x4u*>(X + b0 + off) : f32x4u{0.f, 0.f, 0.f, 0.f}; \
+            V = make_float4(q.x, q.y, q.z, q.w);                                      \
+        } else {                                                                      \
+            V = make_float4(kv && v0 ? X[b0 + off] : 0.f, kv && v1 ? X[b1 + off] : 0.f, \
+                            kv && v2 ? X[b2 + off] : 0.f, kv && v3 ? X[b3 + off] : 0.f); \
+        }                                                                             \
     }
         NK_ROW(0, r.v0) NK_ROW(1, r.v1) NK_ROW(2, r.v2) NK_ROW(3, r.v3)
 #undef NK_ROW
         return r;
     };
 
-    f32x16 acc[2][2];
-    acc_zero(acc);
-    TileLoader<true> la;
+    f32x16 acc[TI][TJ];
+    acc_zero<TI, TJ>(acc);
+    TileLoader<true, BM> la;
     la.init(W, K, m0, 0, g.Mg, K, t);
-    Stage ra, rb;
+    Stage<BM / 32> ra;
+    Stage<4> rb;
     ra = la.template load<ALIGNED_A>(t);
     rb = gather(0);
-    stage_store<true>(smem, ra, t);
-    stage_store<false>(smem + TILE_FLOATS, rb, t);
+    stage_store<true, BM>(smem, ra, t);
+    stage_store<false, BN>(smem + TA_FLOATS, rb, t);
     __syncthreads();
     for (int it = 0; it + 1 < nt; ++it) {
-        float* cur = smem + (it & 1) * STAGE_FLOATS;
-        float* nxt = smem + ((it + 1) & 1) * STAGE_FLOATS;
+        float* cur = smem + (it & 1) * STAGE;
+        float* nxt = smem + ((it + 1) & 1) * STAGE;
         ra = la.template load<ALIGNED_A>(t);
         rb = gather((it + 1) * BK);
         __builtin_amdgcn_sched_barrier(0);
-        mma_tile<true, false>(cur, cur + TILE_FLOATS, acc, wr, wc, lane);
-        stage_store<true>(nxt, ra, t);
-        stage_store<false>(nxt + TILE_FLOATS, rb, t);
+        mma_tile<true, false, TI, TJ>(cur, cur + TA_FLOATS, acc, wr, wc, lane);
+        stage_store<true, BM>(nxt, ra, t);
+        stage_store<false, BN>(nxt + TA_FLOATS, rb, t);
         __syncthreads();
     }
     {
-        float* cur = smem + ((nt - 1) & 1) * STAGE_FLOATS;
-        mma_tile<true, false>(cur, cur + TILE_FLOATS, acc, wr, wc, lane);
+        float* cur = smem + ((nt - 1) & 1) * STAGE;
+        mma_tile<true, false, TI, TJ>(cur, cur + TA_FLOATS, acc, wr, wc, lane);
     }
     // Y[n][grp*Mg + co][l]
     float* Y = p.y;
     const int Mg = g.Mg, L = g.L, Cout = g.Cout;
-    acc_foreach(acc, wr, wc, lane, [&](int r, int c, float v) {
+    acc_foreach<TI, TJ>(acc, wr, wc, lane, [&](int r, int c, float v) {
         const int co = m0 + r;
         const long long cc = (long long)n0 + c;
         if (co < Mg && cc < cols) {
@@ -181,9 +191,11 @@ struct BwdInArgs {
     int tiles_m, tiles_n;
 };
 
-template <bool ALIGNED_A, bool UNIT_STRIDE>
+template <bool ALIGNED_A, bool UNIT_STRIDE, int TI>
 __global__ __launch_bounds__(NT, 2) void conv_bwd_input_kernel(BwdInArgs p) {
-    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE_FLOATS];
+    constexpr int TJ = 2, BM = 64 * TI, BN = 64 * TJ;
+    constexpr int TA_FLOATS = tile_floats<BM>(), STAGE = TA_FLOATS + tile_floats<BN>();
+    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
     const ConvGeom& g = p.g;
     const int t = threadIdx.x, lane = t & 63, wid = t >> 6, wr = wid >> 1, wc = wid & 1;
     int tm, tn;
@@ -218,6 +230,8 @@ __global__ __launch_bounds__(NT, 2) void conv_bwd_input_kernel(BwdInArgs p) {
         NK_COL(2, gb2, pa2, pb2, pc2, v2) NK_COL(3, gb3, pa3, pb3, pc3, v3)
 #undef NK_COL
     }
+    // the four columns are neighbours in one input row of one sample
+    const bool rowquad = UNIT_STRIDE && v3 && gb3 == gb0 && pa3 == pa0 && pb3 == pb0 && pc3 == pc0 + 3;
     auto one = [&](const int4 kt, bool kv, long long gb, int pa, int pb, int pc, bool v) -> float {
         int a = pa - kt.y, b = pb - kt.z, c = pc - kt.w;
         bool ok = kv && v && a >= 0 && b >= 0 && c >= 0;
@@ -229,49 +243,56 @@ __global__ __launch_bounds__(NT, 2) void conv_bwd_input_kernel(BwdInArgs p) {
         return ok ? G[gb + kt.x + (a * g.out[1] + b) * g.out[2] + c] : 0.f;
     };
     auto gather = [&](int k0) {
-        Stage r;
+        Stage<4> r;
 #define NK_ROW(j, V)                                                                    \
     {                                                                                   \
         const int k = k0 + krow + 8 * j;                                                \
         const bool kv = k < K;                                                          \
         const int4 kt = kv ? p.ktab[k] : make_int4(0, 0, 0, 0);                         \
-        V = make_float4(one(kt, kv, gb0, pa0, pb0, pc0, v0), one(kt, kv, gb1, pa1, pb1, pc1, v1), \
-                        one(kt, kv, gb2, pa2, pb2, pc2, v2), one(kt, kv, gb3, pa3, pb3, pc3, v3)); \
+        const int a = pa0 - kt.y, b = pb0 - kt.z, c = pc0 - kt.w;                       \
+        if (rowquad && kv && a >= 0 && a < g.out[0] && b >= 0 && b < g.out[1] && c >= 0 && c + 3 < g.out[2]) { \
+            const f32x4u q = *reinterpret_cast<const f32x4u*>(G + gb0 + kt.x + (a * g.out[1] + b) * g.out[2] + c); \
+            V = make_float4(q.x, q.y, q.z, q.w);                                        \
+        } else {                                                                        \
+            V = make_float4(one(kt, kv, gb0, pa0, pb0, pc0, v0), one(kt, kv, gb1, pa1, pb1, pc1, v1), \
+                            one(kt, kv, gb2, pa2, pb2, pc2, v2), one(kt, kv, gb3, pa3, pb3, pc3, v3)); \
+        }                                                                               \
     }
         NK_ROW(0, r.v0) NK_ROW(1, r.v1) NK_ROW(2, r.v2) NK_ROW(3, r.v3)
 #undef NK_ROW
         return r;
     };
 
-    f32x16 acc[2][2];
-    acc_zero(acc);
-    TileLoader<true> la;
+    f32x16 acc[TI][TJ];
+    acc_zero<TI, TJ>(acc);
+    TileLoader<true, BM> la;
     la.init(Wt, K, m0, 0, g.Cg, K, t);
-    Stage ra, rb;
+    Stage<BM / 32> ra;
+    Stage<4> rb;
     ra = la.template load<ALIGNED_A>(t);
     rb = gather(0);
-    stage_store<true>(smem, ra, t);
-    stage_store<false>(smem + TILE_FLOATS, rb, t);
+    stage_store<true, BM>(smem, ra, t);
+    stage_store<false, BN>(smem + TA_FLOATS, rb, t);
     __syncthreads();
     for (int it = 0; it + 1 < nt; ++it) {
-        float* cur = smem + (it & 1) * STAGE_FLOATS;
-        float* nxt = smem + ((it + 1) & 1) * STAGE_FLOATS;
+        float* cur = smem + (it & 1) * STAGE;
+        float* nxt = smem + ((it + 1) & 1) * STAGE;
         ra = la.template load<ALIGNED_A>(t);
         rb = gather((it + 1) * BK);
         __builtin_amdgcn_sched_barrier(0);
-        mma_tile<true, false>(cur, cur + TILE_FLOATS, acc, wr, wc, lane);
-        stage_store<true>(nxt, ra, t);
-        stage_store<false>(nxt + TILE_FLOATS, rb, t);
+        mma_tile<true, false, TI, TJ>(cur, cur + TA_FLOATS, acc, wr, wc, lane);
+        stage_store<true, BM>(nxt, ra, t);
+        stage_store<false, BN>(nxt + TA_FLOATS, rb, t);
         __syncthreads();
     }
     {
-        float* cur = smem + ((nt - 1) & 1) * STAGE_FLOATS;
-        mma_tile<true, false>(cur, cur + TILE_FLOATS, acc, wr, wc, lane);
+        float* cur = smem + ((nt - 1) & 1) * STAGE;
+        mma_tile<true, false, TI, TJ>(cur, cur + TA_FLOATS, acc, wr, wc, lane);
     }
     // dX[n][grp*Cg + ci][pos] += acc
     float* DX = p.dx;
     const int Cg = g.Cg, Cin = g.Cin, inplane = g.inplane;
-    acc_foreach(acc, wr, wc, lane, [&](int r, int c, float v) {
+    acc_foreach<TI, TJ>(acc, wr, wc, lane, [&](int r, int c, float v) {
         const int ci = m0 + r;
         const long long cc = (long long)n0 + c;
         if (ci < Cg && cc < cols) {
@@ -295,14 +316,22 @@ struct BwdKArgs {
     long long r_per_split;  // multiple of BK
 };
 
-template <bool VEC_G>
+template <bool VEC_G, int TI, int TJ>
 __global__ __launch_bounds__(NT, 2) void conv_bwd_kernel_kernel(BwdKArgs p) {
-    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE_FLOATS];
+    constexpr int BM = 64 * TI, BN = 64 * TJ;
+    constexpr int TA_FLOATS = tile_floats<BM>(), STAGE = TA_FLOATS + tile_floats<BN>();
+    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
     const ConvGeom& g = p.g;
     const int t = threadIdx.x, lane = t & 63, wid = t >> 6, wr = wid >> 1, wc = wid & 1;
-    int tm, tn;
-    tile_coords(blockIdx.x, gridDim.x, p.tiles_m, p.tiles_n, tm, tn);
-    const int grp = blockIdx.z, split = blockIdx.y;
+    // 1-D grid over (split, tile): the tiles of one split read the same G / X slices, so they are
+    // made neighbours in the per-XCD chunk order (shared through that XCD's L2)
+    const int ntile = p.tiles_m * p.tiles_n;
+    int split, tile;
+    tile_coords(blockIdx.x, gridDim.x, 1, (int)gridDim.x, tile, split);  // split := XCD-chunked linear id
+    tile = split % ntile;
+    split /= ntile;
+    const int tm = tile / p.tiles_n, tn = tile % p.tiles_n;
+    const int grp = blockIdx.z;
     const int m0 = tm * BM, n0 = tn * BN;
     const int Kc = g.Cg * g.KK;  // columns of dW
     const long long R = (long long)g.N * g.L;
@@ -315,15 +344,17 @@ __global__ __launch_bounds__(NT, 2) void conv_bwd_kernel_kernel(BwdKArgs p) {
     // KC staging for both operands: idx = t + 256*j -> row = (t>>3) + 32*j, 4 consecutive r
     const int rq = t & 7, row = t >> 3;
     // B: columns n0 + row + 32*j -> koff (fixed over the k loop)
-    int ko0, ko1, ko2, ko3;
-    bool cv0, cv1, cv2, cv3;
+    int ko0, ko1, ko2 = 0, ko3 = 0;
+    bool cv0, cv1, cv2 = false, cv3 = false;
 #define NK_KO(j, KO, CV) { const int c = n0 + row + 32 * j; CV = c < Kc; KO = CV ? p.koff[c] : 0; }
-    NK_KO(0, ko0, cv0) NK_KO(1, ko1, cv1) NK_KO(2, ko2, cv2) NK_KO(3, ko3, cv3)
+    NK_KO(0, ko0, cv0) NK_KO(1, ko1, cv1)
+    if constexpr (TJ == 2) { NK_KO(2, ko2, cv2) NK_KO(3, ko3, cv3) }
 #undef NK_KO
     // A: rows (co) m0 + row + 32*j
     const bool av0 = m0 + row < g.Mg, av1 = m0 + row + 32 < g.Mg, av2 = m0 + row + 64 < g.Mg, av3 = m0 + row + 96 < g.Mg;
 
-    Stage ra, rb;
+    Stage<BM / 32> ra;
+    Stage<BN / 32> rb;
     auto load_both = [&](long long r0) {
         // decompose the 4 consecutive reduction indices r0 + 4*rq + {0..3} -> (n, l)
         long long xo[4], go[4];
@@ -336,6 +367,8 @@ __global__ __launch_bounds__(NT, 2) void conv_bwd_kernel_kernel(BwdKArgs p) {
             xo[c] = (long long)n * g.Cin * g.inplane + window_origin(g, l);
             go[c] = (long long)n * g.Cout * g.L + l;
         }
+        // the four reduction indices are neighbours in one output row (unit stride)
+        const bool quad = rv[3] && xo[1] == xo[0] + 1 && xo[2] == xo[0] + 2 && xo[3] == xo[0] + 3;
 #define NK_A(j, V, AV)                                                                       \
     {                                                                                        \
         const long long rowoff = (long long)(m0 + row + 32 * j) * g.L;                       \
@@ -343,40 +376,47 @@ __global__ __launch_bounds__(NT, 2) void conv_bwd_kernel_kernel(BwdKArgs p) {
         else V = make_float4(AV && rv[0] ? G[go[0] + rowoff] : 0.f, AV && rv[1] ? G[go[1] + rowoff] : 0.f, \
                              AV && rv[2] ? G[go[2] + rowoff] : 0.f, AV && rv[3] ? G[go[3] + rowoff] : 0.f); \
     }
-        NK_A(0, ra.v0, av0) NK_A(1, ra.v1, av1) NK_A(2, ra.v2, av2) NK_A(3, ra.v3, av3)
+        NK_A(0, ra.v0, av0) NK_A(1, ra.v1, av1)
+        if constexpr (TI == 2) { NK_A(2, ra.v2, av2) NK_A(3, ra.v3, av3) }
 #undef NK_A
 #define NK_B(V, KO, CV)                                                                      \
-    V = make_float4(CV && rv[0] ? X[xo[0] + KO] : 0.f, CV && rv[1] ? X[xo[1] + KO] : 0.f,    \
-                    CV && rv[2] ? X[xo[2] + KO] : 0.f, CV && rv[3] ? X[xo[3] + KO] : 0.f);
-        NK_B(rb.v0, ko0, cv0) NK_B(rb.v1, ko1, cv1) NK_B(rb.v2, ko2, cv2) NK_B(rb.v3, ko3, cv3)
+    if (quad && CV) {                                                                        \
+        const f32x4u q = *reinterpret_cast<const f32x4u*>(X + xo[0] + KO);                   \
+        V = make_float4(q.x, q.y, q.z, q.w);                                                 \
+    } else {                                                                                 \
+        V = make_float4(CV && rv[0] ? X[xo[0] + KO] : 0.f, CV && rv[1] ? X[xo[1] + KO] : 0.f, \
+                        CV && rv[2] ? X[xo[2] + KO] : 0.f, CV && rv[3] ? X[xo[3] + KO] : 0.f); \
+    }
+        NK_B(rb.v0, ko0, cv0) NK_B(rb.v1, ko1, cv1)
+        if constexpr (TJ == 2) { NK_B(rb.v2, ko2, cv2) NK_B(rb.v3, ko3, cv3) }
 #undef NK_B
     };
 
-    f32x16 acc[2][2];
-    acc_zero(acc);
+    f32x16 acc[TI][TJ];
+    acc_zero<TI, TJ>(acc);
     if (nt > 0) {
         load_both(rbeg);
-        stage_store<true>(smem, ra, t);
-        stage_store<true>(smem + TILE_FLOATS, rb, t);
+        stage_store<true, BM>(smem, ra, t);
+        stage_store<true, BN>(smem + TA_FLOATS, rb, t);
     }
     __syncthreads();
     for (int it = 0; it + 1 < nt; ++it) {
-        float* cur = smem + (it & 1) * STAGE_FLOATS;
-        float* nxt = smem + ((it + 1) & 1) * STAGE_FLOATS;
+        float* cur = smem + (it & 1) * STAGE;
+        float* nxt = smem + ((it + 1) & 1) * STAGE;
         load_both(rbeg + (long long)(it + 1) * BK);
         __builtin_amdgcn_sched_barrier(0);
-        mma_tile<true, true>(cur, cur + TILE_FLOATS, acc, wr, wc, lane);
-        stage_store<true>(nxt, ra, t);
-        stage_store<true>(nxt + TILE_FLOATS, rb, t);
+        mma_tile<true, true, TI, TJ>(cur, cur + TA_FLOATS, acc, wr, wc, lane);
+        stage_store<true, BM>(nxt, ra, t);
+        stage_store<true, BN>(nxt + TA_FLOATS, rb, t);
         __syncthreads();
     }
     if (nt > 0) {
-        float* cur = smem + ((nt - 1) & 1) * STAGE_FLOATS;
-        mma_tile<true, true>(cur, cur + TILE_FLOATS, acc, wr, wc, lane);
+        float* cur = smem + ((nt - 1) & 1) * STAGE;
+        mma_tile<true, true, TI, TJ>(cur, cur + TA_FLOATS, acc, wr, wc, lane);
     }
     float* S = p.slabs + ((long long)split * g.groups + grp) * (long long)g.Mg * Kc;
     const int Mg = g.Mg;
-    acc_foreach(acc, wr, wc, lane, [&](int r, int c, float v) {
+    acc_foreach<TI, TJ>(acc, wr, wc, lane, [&](int r, int c, float v) {
         const int co = m0 + r, col = n0 + c;
         if (co < Mg && col < Kc) S[(long long)co * Kc + col] = v;
     });
@@ -389,6 +429,255 @@ __global__ void conv_dw_reduce_kernel(float* __restrict__ dw, const float* __res
         for (int k = 0; k < splits; ++k) s += slabs[(long long)k * n + i];
         dw[i] += s;
     }
+}
+
+// =================================================================================================
+// Fast paths (tap-major reduction order).  When the channel count per group is a multiple of
+// 32, a k-tile of 32 covers 32 channels of ONE kernel tap, so the tap decode / border test is
+// done once per k-tile (wave-uniform, scalar) instead of once per k row, the per-row address is
+// `base + row * plane`, and — for unit stride along the innermost axis — the four columns a
+// thread stages are one unaligned 16-B load.  The weights are re-ordered once per call by a
+// tiny pre-kernel (they are KBs to MBs; the activations are hundreds of MBs).
+// =================================================================================================
+// tapoff[tap] = input offset of kernel tap `tap` relative to the window origin
+__global__ void conv_tapoff_kernel(int* __restrict__ tapoff, int4* __restrict__ tapd, ConvGeom g) {
+    for (int tap = blockIdx.x * blockDim.x + threadIdx.x; tap < g.KK; tap += gridDim.x * blockDim.x) {
+        int rem = tap;
+        const int k2 = rem % g.k[2]; rem /= g.k[2];
+        const int k1 = rem % g.k[1];
+        const int k0 = rem / g.k[1];
+        tapoff[tap] = (k0 * g.dil[0] * g.in[1] + k1 * g.dil[1]) * g.in[2] + k2 * g.dil[2];
+        tapd[tap] = make_int4(k0 * g.dil[0], k1 * g.dil[1], k2 * g.dil[2], 0);
+    }
+}
+// Wp[grp][co][tap][ci] = W[grp*Mg + co][ci][tap]   (forward A operand, k = tap*Cg + ci)
+__global__ void conv_wp_kernel(float* __restrict__ wp, const float* __restrict__ w, ConvGeom g) {
+    const long long total = (long long)g.Cout * g.Cg * g.KK;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % g.Cg);
+        long long rem = i / g.Cg;
+        const int tap = (int)(rem % g.KK);
+        const long long co = rem / g.KK;  // absolute output channel
+        wp[i] = w[(co * g.Cg + ci) * g.KK + tap];
+    }
+}
+// Wq[grp][ci][tap][co] = W[grp*Mg + co][ci][tap]   (backward-input A operand, k = tap*Mg + co)
+__global__ void conv_wq_kernel(float* __restrict__ wq, const float* __restrict__ w, ConvGeom g) {
+    const long long total = (long long)g.Cout * g.Cg * g.KK;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int co = (int)(i % g.Mg);
+        long long rem = i / g.Mg;
+        const int tap = (int)(rem % g.KK); rem /= g.KK;
+        const int ci = (int)(rem % g.Cg);
+        const int grp = (int)(rem / g.Cg);
+        wq[i] = w[((long long)(grp * g.Mg + co) * g.Cg + ci) * g.KK + tap];
+    }
+}
+
+struct FastFwdArgs {
+    ConvGeom g;
+    const float* x;
+    const float* wp;
+    float* y;
+    const int* tapoff;
+    int tiles_m, tiles_n;
+};
+
+// requires Cg % 32 == 0, stride[2] == 1, out[2] % 4 == 0, per-tensor element counts < 2^31
+template <bool ALIGNED_A, int TI>
+__global__ __launch_bounds__(NT, 2) void conv_fwd_fast_kernel(FastFwdArgs p) {
+    constexpr int TJ = 2, BM = 64 * TI, BN = 64 * TJ;
+    constexpr int TA_FLOATS = tile_floats<BM>(), STAGE = TA_FLOATS + tile_floats<BN>();
+    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+    const ConvGeom& g = p.g;
+    const int t = threadIdx.x, lane = t & 63, wid = t >> 6, wr = wid >> 1, wc = wid & 1;
+    int tm, tn;
+    tile_coords(blockIdx.x, gridDim.x, p.tiles_m, p.tiles_n, tm, tn);
+    const int grp = blockIdx.z;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int K = g.Cg * g.KK, nt = K / BK, tpt = g.Cg / BK;  // k-tiles per tap
+    const long long cols = (long long)g.N * g.L;
+    const float* W = p.wp + (long long)grp * g.Mg * K;
+    const float* X = p.x + (long long)grp * g.Cg * g.inplane;
+
+    // this thread stages the column quad n0 + 4*cq .. +3 (one output row) for channel rows
+    // (t>>5) + 8*j of every k-tile
+    const int cq = t & 31, krow = t >> 5;
+    const long long c0 = (long long)n0 + cq * 4;
+    const bool valid = c0 < cols;
+    int xb = 0;
+    if (valid) {
+        const int n = (int)(c0 / g.L), l = (int)(c0 % g.L);
+        xb = n * g.Cin * g.inplane + window_origin(g, l) + krow * g.inplane;
+    }
+    const int jstep = 8 * g.inplane;
+    auto gather = [&](int kt) {
+        const int tap = kt / tpt, ci0 = (kt - tap * tpt) * BK;
+        const float* src = X + (p.tapoff[tap] + ci0 * g.inplane);
+        Stage<4> r;
+        const f32x4u z = {0.f, 0.f, 0.f, 0.f};
+        const f32x4u q0 = valid ? *reinterpret_cast<const f32x4u*>(src + xb) : z;
+        const f32x4u q1 = valid ? *reinterpret_cast<const f32x4u*>(src + xb + jstep) : z;
+        const f32x4u q2 = valid ? *reinterpret_cast<const f32x4u*>(src + xb + 2 * jstep) : z;
+        const f32x4u q3 = valid ? *reinterpret_cast<const f32x4u*>(src + xb + 3 * jstep) : z;
+        r.v0 = make_float4(q0.x, q0.y, q0.z, q0.w);
+        r.v1 = make_float4(q1.x, q1.y, q1.z, q1.w);
+        r.v2 = make_float4(q2.x, q2.y, q2.z, q2.w);
+        r.v3 = make_float4(q3.x, q3.y, q3.z, q3.w);
+        return r;
+    };
+
+    f32x16 acc[TI][TJ];
+    acc_zero<TI, TJ>(acc);
+    TileLoader<true, BM> la;
+    la.init(W, K, m0, 0, g.Mg, K, t);
+    Stage<BM / 32> ra;
+    Stage<4> rb;
+    ra = la.template load<ALIGNED_A>(t);
+    rb = gather(0);
+    stage_store<true, BM>(smem, ra, t);
+    stage_store<false, BN>(smem + TA_FLOATS, rb, t);
+    __syncthreads();
+    for (int it = 0; it + 1 < nt; ++it) {
+        float* cur = smem + (it & 1) * STAGE;
+        float* nxt = smem + ((it + 1) & 1) * STAGE;
+        ra = la.template load<ALIGNED_A>(t);
+        rb = gather(it + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_tile<true, false, TI, TJ>(cur, cur + TA_FLOATS, acc, wr, wc, lane);
+        stage_store<true, BM>(nxt, ra, t);
+        stage_store<false, BN>(nxt + TA_FLOATS, rb, t);
+        __syncthreads();
+    }
+    {
+        float* cur = smem + ((nt - 1) & 1) * STAGE;
+        mma_tile<true, false, TI, TJ>(cur, cur + TA_FLOATS, acc, wr, wc, lane);
+    }
+    float* Y = p.y;
+    const int Mg = g.Mg, L = g.L, Cout = g.Cout;
+    acc_foreach<TI, TJ>(acc, wr, wc, lane, [&](int r, int c, float v) {
+        const int co = m0 + r;
+        const long long cc = (long long)n0 + c;
+        if (co < Mg && cc < cols) {
+            const int n = (int)(cc / L), l = (int)(cc % L);
+            Y[((long long)n * Cout + grp * Mg + co) * L + l] = v;
+        }
+    });
+}
+
+struct FastBwdInArgs {
+    ConvGeom g;
+    float* dx;
+    const float* gy;
+    const float* wq;  // [groups][Cg][KK*Mg]
+    const int4* tapd;
+    int tiles_m, tiles_n;
+};
+
+// requires unit stride on every axis, Mg % 32 == 0, per-tensor element counts < 2^31
+template <bool ALIGNED_A, int TI>
+__global__ __launch_bounds__(NT, 2) void conv_bwd_input_fast_kernel(FastBwdInArgs p) {
+    constexpr int TJ = 2, BM = 64 * TI, BN = 64 * TJ;
+    constexpr int TA_FLOATS = tile_floats<BM>(), STAGE = TA_FLOATS + tile_floats<BN>();
+    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+    const ConvGeom& g = p.g;
+    const int t = threadIdx.x, lane = t & 63, wid = t >> 6, wr = wid >> 1, wc = wid & 1;
+    int tm, tn;
+    tile_coords(blockIdx.x, gridDim.x, p.tiles_m, p.tiles_n, tm, tn);
+    const int grp = blockIdx.z;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int K = g.Mg * g.KK, nt = K / BK, tpt = g.Mg / BK;
+    const long long cols = (long long)g.N * g.inplane;
+    const float* Wq = p.wq + (long long)grp * g.Cg * K;
+    const float* G = p.gy + (long long)grp * g.Mg * g.L;
+
+    const int cq = t & 31, krow = t >> 5;
+    int gb[4], pa[4], pb[4], pc[4];
+    bool cv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const long long cc = (long long)n0 + cq * 4 + i;
+        cv[i] = cc < cols;
+        const int n = cv[i] ? (int)(cc / g.inplane) : 0;
+        int q = cv[i] ? (int)(cc % g.inplane) : 0;
+        pc[i] = q % g.in[2]; q /= g.in[2];
+        pb[i] = q % g.in[1];
+        pa[i] = q / g.in[1];
+        gb[i] = n * g.Cout * g.L + krow * g.L;
+    }
+    const bool rowquad = cv[3] && gb[3] == gb[0] && pa[3] == pa[0] && pb[3] == pb[0] && pc[3] == pc[0] + 3;
+    const int jstep = 8 * g.L;
+    auto gather = [&](int kt) {
+        const int tap = kt / tpt, co0 = (kt - tap * tpt) * BK;
+        const int4 d = p.tapd[tap];
+        const float* src = G + co0 * g.L;
+        // output position each column reads for this tap (-1: outside -> contributes 0)
+        int pos[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int a = pa[i] - d.x, b = pb[i] - d.y, c = pc[i] - d.z;
+            const bool ok = cv[i] && a >= 0 && a < g.out[0] && b >= 0 && b < g.out[1] && c >= 0 && c < g.out[2];
+            pos[i] = ok ? gb[i] + (a * g.out[1] + b) * g.out[2] + c : -1;
+        }
+        Stage<4> r;
+        if (rowquad && pos[0] >= 0 && pos[3] >= 0) {  // whole quad inside: one 16-B load per row
+            const f32x4u q0 = *reinterpret_cast<const f32x4u*>(src + pos[0]);
+            const f32x4u q1 = *reinterpret_cast<const f32x4u*>(src + pos[0] + jstep);
+            const f32x4u q2 = *reinterpret_cast<const f32x4u*>(src + pos[0] + 2 * jstep);
+            const f32x4u q3 = *reinterpret_cast<const f32x4u*>(src + pos[0] + 3 * jstep);
+            r.v0 = make_float4(q0.x, q0.y, q0.z, q0.w);
+            r.v1 = make_float4(q1.x, q1.y, q1.z, q1.w);
+            r.v2 = make_float4(q2.x, q2.y, q2.z, q2.w);
+            r.v3 = make_float4(q3.x, q3.y, q3.z, q3.w);
+        } else {
+#define NK_ROWS(j, V)                                                                              \
+    V = make_float4(pos[0] >= 0 ? src[pos[0] + j * jstep] : 0.f, pos[1] >= 0 ? src[pos[1] + j * jstep] : 0.f, \
+                    pos[2] >= 0 ? src[pos[2] + j * jstep] : 0.f, pos[3] >= 0 ? src[pos[3] + j * jstep] : 0.f);
+            NK_ROWS(0, r.v0) NK_ROWS(1, r.v1) NK_ROWS(2, r.v2) NK_ROWS(3, r.v3)
+#undef NK_ROWS
+        }
+        return r;
+    };
+
+    f32x16 acc[TI][TJ];
+    acc_zero<TI, TJ>(acc);
+    TileLoader<true, BM> la;
+    la.init(Wq, K, m0, 0, g.Cg, K, t);
+    Stage<BM / 32> ra;
+    Stage<4> rb;
+    ra = la.template load<ALIGNED_A>(t);
+    rb = gather(0);
+    stage_store<true, BM>(smem, ra, t);
+    stage_store<false, BN>(smem + TA_FLOATS, rb, t);
+    __syncthreads();
+    for (int it = 0; it + 1 < nt; ++it) {
+        float* cur = smem + (it & 1) * STAGE;
+        float* nxt = smem + ((it + 1) & 1) * STAGE;
+        ra = la.template load<ALIGNED_A>(t);
+        rb = gather(it + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_tile<true, false, TI, TJ>(cur, cur + TA_FLOATS, acc, wr, wc, lane);
+        stage_store<true, BM>(nxt, ra, t);
+        stage_store<false, BN>(nxt + TA_FLOATS, rb, t);
+        __syncthreads();
+    }
+    {
+        float* cur = smem + ((nt - 1) & 1) * STAGE;
+        mma_tile<true, false, TI, TJ>(cur, cur + TA_FLOATS, acc, wr, wc, lane);
+    }
+    float* DX = p.dx;
+    const int Cg = g.Cg, Cin = g.Cin, inplane = g.inplane;
+    acc_foreach<TI, TJ>(acc, wr, wc, lane, [&](int r, int c, float v) {
+        const int ci = m0 + r;
+        const long long cc = (long long)n0 + c;
+        if (ci < Cg && cc < cols) {
+            const int n = (int)(cc / inplane), q = (int)(cc % inplane);
+            float* d = &DX[((long long)n * Cin + grp * Cg + ci) * inplane + q];
+            *d += v;
+        }
+    });
 }
 
 // ---- host side ------------------------------------------------------------------------------------
@@ -434,6 +723,36 @@ int nk_conv_fwd(nk_device* dev, int nd, const float* x, const int* x_shape, cons
     if ((long long)g.N * g.Cout * g.L == 0) return NK_OK;
     NK_CHECK(x && w && y, "null pointer in nk_conv_fwd");
     const int K = g.Cg * g.KK;
+    const long long x_elems = (long long)g.N * g.Cin * g.inplane, y_elems = (long long)g.N * g.Cout * g.L;
+    if (g.Cg % BK == 0 && g.stride[2] == 1 && g.out[2] % 4 == 0 && x_elems < 0x7fffffffLL && y_elems < 0x7fffffffLL) {
+        const size_t wp_bytes = round256((size_t)g.Cout * K * sizeof(float));
+        const size_t to_bytes = round256((size_t)g.KK * sizeof(int));
+        void* wsf = nullptr;
+        rc = nk_workspace(dev, wp_bytes + to_bytes + round256((size_t)g.KK * sizeof(int4)), &wsf);
+        if (rc) return rc;
+        float* wp = (float*)wsf;
+        int* tapoff = (int*)((char*)wsf + wp_bytes);
+        int4* tapd = (int4*)((char*)wsf + wp_bytes + to_bytes);
+        hipLaunchKernelGGL(conv_wp_kernel, dim3(nk_stream_grid((size_t)g.Cout * K, 256)), dim3(256), 0, dev->compute, wp, w, g);
+        NK_LAUNCH_CHECK();
+        hipLaunchKernelGGL(conv_tapoff_kernel, dim3(1), dim3(64), 0, dev->compute, tapoff, tapd, g);
+        NK_LAUNCH_CHECK();
+        FastFwdArgs fp{};
+        fp.g = g; fp.x = x; fp.wp = wp; fp.y = y; fp.tapoff = tapoff;
+        const int fti = g.Mg <= 64 || (g.Mg % 128 != 0 && g.Mg % 64 == 0) ? 1 : 2;
+        fp.tiles_m = (g.Mg + 64 * fti - 1) / (64 * fti);
+        fp.tiles_n = (int)(((long long)g.N * g.L + 127) / 128);
+        const bool al = g.Mg % (64 * fti) == 0;
+        dim3 fgrid(fp.tiles_m * fp.tiles_n, 1, groups);
+        rc = nk_prof_start(dev, NK_KERNEL_CONV, 2.0 * g.N * (double)g.Cout * g.L * g.Cg * g.KK);
+        if (rc) return rc;
+        if (al && fti == 2) hipLaunchKernelGGL((conv_fwd_fast_kernel<true, 2>), fgrid, dim3(NT), 0, dev->compute, fp);
+        else if (al) hipLaunchKernelGGL((conv_fwd_fast_kernel<true, 1>), fgrid, dim3(NT), 0, dev->compute, fp);
+        else if (fti == 2) hipLaunchKernelGGL((conv_fwd_fast_kernel<false, 2>), fgrid, dim3(NT), 0, dev->compute, fp);
+        else hipLaunchKernelGGL((conv_fwd_fast_kernel<false, 1>), fgrid, dim3(NT), 0, dev->compute, fp);
+        NK_LAUNCH_CHECK();
+        return nk_prof_stop(dev);
+    }
     void* ws = nullptr;
     rc = nk_workspace(dev, round256((size_t)K * sizeof(int)), &ws);
     if (rc) return rc;
@@ -441,6 +760,8 @@ int nk_conv_fwd(nk_device* dev, int nd, const float* x, const int* x_shape, cons
     NK_LAUNCH_CHECK();
     FwdArgs p{};
     p.g = g; p.x = x; p.w = w; p.y = y; p.koff = (const int*)ws;
+    const int ti = g.Mg <= 64 || (g.Mg % 128 != 0 && g.Mg % 64 == 0) ? 1 : 2;
+    const int BM = 64 * ti, BN = 128;
     p.tiles_m = (g.Mg + BM - 1) / BM;
     const long long cols = (long long)g.N * g.L;
     p.tiles_n = (int)((cols + BN - 1) / BN);
@@ -448,8 +769,10 @@ int nk_conv_fwd(nk_device* dev, int nd, const float* x, const int* x_shape, cons
     dim3 grid(p.tiles_m * p.tiles_n, 1, groups);
     rc = nk_prof_start(dev, NK_KERNEL_CONV, 2.0 * g.N * (double)g.Cout * g.L * g.Cg * g.KK);
     if (rc) return rc;
-    if (aligned_a) hipLaunchKernelGGL((conv_fwd_kernel<true>), grid, dim3(NT), 0, dev->compute, p);
-    else hipLaunchKernelGGL((conv_fwd_kernel<false>), grid, dim3(NT), 0, dev->compute, p);
+    if (aligned_a && ti == 2) hipLaunchKernelGGL((conv_fwd_kernel<true, 2>), grid, dim3(NT), 0, dev->compute, p);
+    else if (aligned_a) hipLaunchKernelGGL((conv_fwd_kernel<true, 1>), grid, dim3(NT), 0, dev->compute, p);
+    else if (ti == 2) hipLaunchKernelGGL((conv_fwd_kernel<false, 2>), grid, dim3(NT), 0, dev->compute, p);
+    else hipLaunchKernelGGL((conv_fwd_kernel<false, 1>), grid, dim3(NT), 0, dev->compute, p);
     NK_LAUNCH_CHECK();
     return nk_prof_stop(dev);
 }
@@ -463,6 +786,39 @@ int nk_conv_bwd_input(nk_device* dev, int nd, float* dx, const int* x_shape, con
     if ((long long)g.N * g.Cin * g.inplane == 0 || (long long)g.Cout * g.L == 0) return NK_OK;
     NK_CHECK(dx && gy && w, "null pointer in nk_conv_bwd_input");
     const int K = g.Mg * g.KK;
+    {
+        const long long x_elems = (long long)g.N * g.Cin * g.inplane, y_elems = (long long)g.N * g.Cout * g.L;
+        const bool unit_all = g.stride[0] == 1 && g.stride[1] == 1 && g.stride[2] == 1;
+        if (unit_all && g.Mg % BK == 0 && x_elems < 0x7fffffffLL && y_elems < 0x7fffffffLL) {
+            const size_t wq_bytes = round256((size_t)g.Cout * g.Cg * g.KK * sizeof(float));
+            const size_t to_bytes = round256((size_t)g.KK * sizeof(int));
+            void* wsf = nullptr;
+            rc = nk_workspace(dev, wq_bytes + to_bytes + round256((size_t)g.KK * sizeof(int4)), &wsf);
+            if (rc) return rc;
+            float* wq = (float*)wsf;
+            int* tapoff = (int*)((char*)wsf + wq_bytes);
+            int4* tapd = (int4*)((char*)wsf + wq_bytes + to_bytes);
+            hipLaunchKernelGGL(conv_wq_kernel, dim3(nk_stream_grid((size_t)g.Cout * g.Cg * g.KK, 256)), dim3(256), 0, dev->compute, wq, w, g);
+            NK_LAUNCH_CHECK();
+            hipLaunchKernelGGL(conv_tapoff_kernel, dim3(1), dim3(64), 0, dev->compute, tapoff, tapd, g);
+            NK_LAUNCH_CHECK();
+            FastBwdInArgs fp{};
+            fp.g = g; fp.dx = dx; fp.gy = gy; fp.wq = wq; fp.tapd = tapd;
+            const int fti = g.Cg <= 64 || (g.Cg % 128 != 0 && g.Cg % 64 == 0) ? 1 : 2;
+            fp.tiles_m = (g.Cg + 64 * fti - 1) / (64 * fti);
+            fp.tiles_n = (int)(((long long)g.N * g.inplane + 127) / 128);
+            const bool al = g.Cg % (64 * fti) == 0;
+            dim3 fgrid(fp.tiles_m * fp.tiles_n, 1, groups);
+            rc = nk_prof_start(dev, NK_KERNEL_CONV, 2.0 * g.N * (double)g.Cout * g.L * g.Cg * g.KK);
+            if (rc) return rc;
+            if (al && fti == 2) hipLaunchKernelGGL((conv_bwd_input_fast_kernel<true, 2>), fgrid, dim3(NT), 0, dev->compute, fp);
+            else if (al) hipLaunchKernelGGL((conv_bwd_input_fast_kernel<true, 1>), fgrid, dim3(NT), 0, dev->compute, fp);
+            else if (fti == 2) hipLaunchKernelGGL((conv_bwd_input_fast_kernel<false, 2>), fgrid, dim3(NT), 0, dev->compute, fp);
+            else hipLaunchKernelGGL((conv_bwd_input_fast_kernel<false, 1>), fgrid, dim3(NT), 0, dev->compute, fp);
+            NK_LAUNCH_CHECK();
+            return nk_prof_stop(dev);
+        }
+    }
     const size_t wt_bytes = round256((size_t)g.Cout * g.Cg * g.KK * sizeof(float));
     const size_t kt_bytes = round256((size_t)K * sizeof(int4));
     void* ws = nullptr;
@@ -476,6 +832,8 @@ int nk_conv_bwd_input(nk_device* dev, int nd, float* dx, const int* x_shape, con
     NK_LAUNCH_CHECK();
     BwdInArgs p{};
     p.g = g; p.dx = dx; p.gy = gy; p.wt = wt; p.ktab = ktab;
+    const int ti = g.Cg <= 64 || (g.Cg % 128 != 0 && g.Cg % 64 == 0) ? 1 : 2;
+    const int BM = 64 * ti, BN = 128;
     p.tiles_m = (g.Cg + BM - 1) / BM;
     const long long cols = (long long)g.N * g.inplane;
     p.tiles_n = (int)((cols + BN - 1) / BN);
@@ -484,10 +842,19 @@ int nk_conv_bwd_input(nk_device* dev, int nd, float* dx, const int* x_shape, con
     dim3 grid(p.tiles_m * p.tiles_n, 1, groups);
     rc = nk_prof_start(dev, NK_KERNEL_CONV, 2.0 * g.N * (double)g.Cout * g.L * g.Cg * g.KK);
     if (rc) return rc;
-    if (aligned_a && unit) hipLaunchKernelGGL((conv_bwd_input_kernel<true, true>), grid, dim3(NT), 0, dev->compute, p);
-    else if (aligned_a) hipLaunchKernelGGL((conv_bwd_input_kernel<true, false>), grid, dim3(NT), 0, dev->compute, p);
-    else if (unit) hipLaunchKernelGGL((conv_bwd_input_kernel<false, true>), grid, dim3(NT), 0, dev->compute, p);
-    else hipLaunchKernelGGL((conv_bwd_input_kernel<false, false>), grid, dim3(NT), 0, dev->compute, p);
+#define NK_LAUNCH_BWI(AL, UN, TI_) hipLaunchKernelGGL((conv_bwd_input_kernel<AL, UN, TI_>), grid, dim3(NT), 0, dev->compute, p)
+    if (ti == 2) {
+        if (aligned_a && unit) NK_LAUNCH_BWI(true, true, 2);
+        else if (aligned_a) NK_LAUNCH_BWI(true, false, 2);
+        else if (unit) NK_LAUNCH_BWI(false, true, 2);
+        else NK_LAUNCH_BWI(false, false, 2);
+    } else {
+        if (aligned_a && unit) NK_LAUNCH_BWI(true, true, 1);
+        else if (aligned_a) NK_LAUNCH_BWI(true, false, 1);
+        else if (unit) NK_LAUNCH_BWI(false, true, 1);
+        else NK_LAUNCH_BWI(false, false, 1);
+    }
+#undef NK_LAUNCH_BWI
     NK_LAUNCH_CHECK();
     return nk_prof_stop(dev);
 }
@@ -504,6 +871,9 @@ int nk_conv_bwd_kernel(nk_device* dev, int nd, float* dw, const int* w_shape, co
     NK_CHECK(dw && gy && x, "null pointer in nk_conv_bwd_kernel");
     BwdKArgs p{};
     p.g = g; p.gy = gy; p.x = x;
+    const int ti = g.Mg <= 64 || (g.Mg % 128 != 0 && g.Mg % 64 == 0) ? 1 : 2;
+    const int tj = Kc <= 64 ? 1 : 2;
+    const int BM = 64 * ti, BN = 64 * tj;
     p.tiles_m = (g.Mg + BM - 1) / BM;
     p.tiles_n = (Kc + BN - 1) / BN;
     const long long tiles = (long long)p.tiles_m * p.tiles_n * groups;
@@ -525,12 +895,23 @@ int nk_conv_bwd_kernel(nk_device* dev, int nd, float* dw, const int* w_shape, co
     p.slabs = (float*)((char*)ws + ko_bytes);
     hipLaunchKernelGGL(conv_koff_kernel, dim3((Kc + 255) / 256), dim3(256), 0, dev->compute, koff, g);
     NK_LAUNCH_CHECK();
-    dim3 grid(p.tiles_m * p.tiles_n, (unsigned)splits, groups);
+    dim3 grid((unsigned)(p.tiles_m * p.tiles_n * splits), 1, groups);
     const bool vec_g = (g.L % 4 == 0) && al16(gy);
     rc = nk_prof_start(dev, NK_KERNEL_CONV, 2.0 * g.N * (double)g.Cout * g.L * g.Cg * g.KK);
     if (rc) return rc;
-    if (vec_g) hipLaunchKernelGGL((conv_bwd_kernel_kernel<true>), grid, dim3(NT), 0, dev->compute, p);
-    else hipLaunchKernelGGL((conv_bwd_kernel_kernel<false>), grid, dim3(NT), 0, dev->compute, p);
+#define NK_LAUNCH_BWK(VG, TI_, TJ_) hipLaunchKernelGGL((conv_bwd_kernel_kernel<VG, TI_, TJ_>), grid, dim3(NT), 0, dev->compute, p)
+    if (vec_g) {
+        if (ti == 2 && tj == 2) NK_LAUNCH_BWK(true, 2, 2);
+        else if (ti == 2) NK_LAUNCH_BWK(true, 2, 1);
+        else if (tj == 2) NK_LAUNCH_BWK(true, 1, 2);
+        else NK_LAUNCH_BWK(true, 1, 1);
+    } else {
+        if (ti == 2 && tj == 2) NK_LAUNCH_BWK(false, 2, 2);
+        else if (ti == 2) NK_LAUNCH_BWK(false, 2, 1);
+        else if (tj == 2) NK_LAUNCH_BWK(false, 1, 2);
+        else NK_LAUNCH_BWK(false, 1, 1);
+    }
+#undef NK_LAUNCH_BWK
     NK_LAUNCH_CHECK();
     hipLaunchKernelGGL(conv_dw_reduce_kernel, dim3(nk_stream_grid((size_t)dw_elems, 256)), dim3(256), 0, dev->compute, dw,
                        p.slabs, dw_elems, (int)splits);

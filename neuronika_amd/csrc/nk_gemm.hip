@@ -2,12 +2,11 @@
 // call sites of the reference's MatMul nodes
 //   node/matrix_matrix_mul/mod.rs:33 (NN, beta 0), :65 (NT, beta 1), :97 (TN, beta 1)
 //   node/matrix_matrix_mul_t/mod.rs:33 (NT, beta 0), :65 (NN, beta 1), :97 (TN, beta 1)
-// Bound: f32 MFMA (157.3 TFLOP/s).  Structure: 128x128x32 block tile, double-buffered LDS,
-// register-staged global loads issued before the MFMAs of the current tile and written to
-// LDS after them (one barrier per k-tile), XCD-aware tile order, split-K with a deterministic
-// second pass when M*N alone cannot fill the chip.
-#include <cstdlib>
-
+// Bound: f32 MFMA (157.3 TFLOP/s).  Structure: (64*TI)x(64*TJ)x32 block tile (128x128 by default,
+// 64-wide variants for narrow or small problems), double-buffered LDS, register-staged global
+// loads issued before the MFMAs of the current tile and written to LDS behind them (one barrier
+// per k-tile), XCD-aware tile order, split-K with a deterministic second pass when M*N alone
+// cannot fill the chip.
 #include "nk_mma.h"
 
 using namespace nkmma;
@@ -23,16 +22,17 @@ struct GemmArgs {
     int batch_inner;
     long long sAo, sAi, sBo, sBi, sCo, sCi;
     // split-K
-    int splits;          // >= 1
-    int k_per_split;     // multiple of BK
-    float* slabs;        // [splits][batch][M][N] partials when splits > 1
+    int splits;       // >= 1
+    int k_per_split;  // multiple of BK
+    float* slabs;     // [splits][batch][M][N] partials when splits > 1
     int tiles_m, tiles_n;
 };
 
-// VAR: tuning experiments (selected by env NK_GEMM_VARIANT; 0 = default)
-template <bool TA, bool TB, bool ALIGNED, int VAR = 0>
-__global__ __launch_bounds__(NT, 2) void sgemm_kernel(GemmArgs p) {
-    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE_FLOATS];  // 73,728 B -> 2 blocks/CU
+template <bool TA, bool TB, bool ALIGNED, int TI, int TJ>
+__global__ __launch_bounds__(NT, (min_waves<TI, TJ>())) void sgemm_kernel(GemmArgs p) {
+    constexpr int BM = 64 * TI, BN = 64 * TJ;
+    constexpr int TA_FLOATS = tile_floats<BM>(), STAGE = TA_FLOATS + tile_floats<BN>();
+    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];  // 73,728 B at 128x128
     constexpr bool AKC = !TA;  // A (M x K): k-contiguous unless stored transposed
     constexpr bool BKC = TB;   // B (K x N) stored as N x K when transposed -> k-contiguous
 
@@ -50,51 +50,44 @@ __global__ __launch_bounds__(NT, 2) void sgemm_kernel(GemmArgs p) {
     const int kend = min(p.K, kbeg + p.k_per_split);
     const int nt = (kend - kbeg + BK - 1) / BK;
 
-    f32x16 acc[2][2];
-    acc_zero(acc);
-    if (VAR == 3 && (blockIdx.x & 256)) {  // de-phase the two blocks that share a CU
-        for (int i = 0; i < 32; ++i) __builtin_amdgcn_s_sleep(127);
-    }
+    f32x16 acc[TI][TJ];
+    acc_zero<TI, TJ>(acc);
 
-    Stage ra, rb;
-    TileLoader<AKC> la;
-    TileLoader<BKC> lb;
+    Stage<BM / 32> ra;
+    Stage<BN / 32> rb;
+    TileLoader<AKC, BM> la;
+    TileLoader<BKC, BN> lb;
     la.init(A, p.lda, m0, kbeg, p.M, kend, t);
     lb.init(B, p.ldb, n0, kbeg, p.N, kend, t);
     if (nt > 0) {
         ra = la.template load<ALIGNED>(t);
         rb = lb.template load<ALIGNED>(t);
-        stage_store<AKC>(smem, ra, t);
-        stage_store<BKC>(smem + TILE_FLOATS, rb, t);
+        stage_store<AKC, BM>(smem, ra, t);
+        stage_store<BKC, BN>(smem + TA_FLOATS, rb, t);
     }
     __syncthreads();
     for (int it = 0; it + 1 < nt; ++it) {
-        float* cur = smem + (it & 1) * STAGE_FLOATS;
-        float* nxt = smem + ((it + 1) & 1) * STAGE_FLOATS;
+        float* cur = smem + (it & 1) * STAGE;
+        float* nxt = smem + ((it + 1) & 1) * STAGE;
         // issue the next tile's HBM/L2 loads before the MFMAs (their latency hides under them),
-        // write them to the other LDS buffer after the MFMAs: one barrier per k-tile
-        if (VAR != 5 && VAR != 6) {
-            ra = la.template load<ALIGNED>(t);
-            rb = lb.template load<ALIGNED>(t);
-        }
-        if (VAR != 2) __builtin_amdgcn_sched_barrier(0);
-        mma_tile<AKC, BKC, VAR == 1>(cur, cur + TILE_FLOATS, acc, wr, wc, lane);
-        if (VAR == 4) __builtin_amdgcn_sched_barrier(0);  // all 64 MFMAs issued before the vmcnt wait
-        if (VAR != 6) {
-            stage_store<AKC>(nxt, ra, t);
-            stage_store<BKC>(nxt + TILE_FLOATS, rb, t);
-        }
+        // write them to the other LDS buffer behind the MFMAs: one barrier per k-tile
+        ra = la.template load<ALIGNED>(t);
+        rb = lb.template load<ALIGNED>(t);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_tile<AKC, BKC, TI, TJ>(cur, cur + TA_FLOATS, acc, wr, wc, lane);
+        stage_store<AKC, BM>(nxt, ra, t);
+        stage_store<BKC, BN>(nxt + TA_FLOATS, rb, t);
         __syncthreads();
     }
     if (nt > 0) {
-        float* cur = smem + ((nt - 1) & 1) * STAGE_FLOATS;
-        mma_tile<AKC, BKC>(cur, cur + TILE_FLOATS, acc, wr, wc, lane);
+        float* cur = smem + ((nt - 1) & 1) * STAGE;
+        mma_tile<AKC, BKC, TI, TJ>(cur, cur + TA_FLOATS, acc, wr, wc, lane);
     }
 
     if (p.splits > 1) {
         float* S = p.slabs + ((long long)split * gridDim.z + batch) * (long long)p.M * p.N;
         const int M = p.M, N = p.N;
-        acc_foreach(acc, wr, wc, lane, [&](int r, int c, float v) {
+        acc_foreach<TI, TJ>(acc, wr, wc, lane, [&](int r, int c, float v) {
             const int row = m0 + r, col = n0 + c;
             if (ALIGNED || (row < M && col < N)) S[(long long)row * N + col] = v;
         });
@@ -105,87 +98,17 @@ __global__ __launch_bounds__(NT, 2) void sgemm_kernel(GemmArgs p) {
     const int M = p.M, N = p.N;
     const long long ldc = p.ldc;
     if (beta == 0.f) {
-        acc_foreach(acc, wr, wc, lane, [&](int r, int c, float v) {
+        acc_foreach<TI, TJ>(acc, wr, wc, lane, [&](int r, int c, float v) {
             const int row = m0 + r, col = n0 + c;
             if (ALIGNED || (row < M && col < N)) C[row * ldc + col] = alpha * v;
         });
     } else {
-        acc_foreach(acc, wr, wc, lane, [&](int r, int c, float v) {
+        acc_foreach<TI, TJ>(acc, wr, wc, lane, [&](int r, int c, float v) {
             const int row = m0 + r, col = n0 + c;
             if (ALIGNED || (row < M && col < N)) {
                 float* q = &C[row * ldc + col];
                 *q = fmaf(beta, *q, alpha * v);
             }
-        });
-    }
-}
-
-// LDS-DMA variant of the same GEMM for fully aligned problems: tiles go HBM/L2 -> LDS directly
-// (`global_load_lds_dwordx4`), two LDS stages of 32 KiB, one `__syncthreads()` (which drains the
-// outstanding DMA) per k-tile.  Removes the staging registers and the ds_write pass that cost
-// ~8 % of the MFMA pipe in the register-staged kernel (ablation in DESIGN.md).
-template <bool TA, bool TB>
-__global__ __launch_bounds__(NT, 2) void sgemm_glds_kernel(GemmArgs p) {
-    __shared__ __attribute__((aligned(16))) float smem[2 * GSTAGE_FLOATS];  // 65,536 B
-    constexpr bool AKC = !TA;
-    constexpr bool BKC = TB;
-    const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
-    const int wr = wid >> 1, wc = wid & 1;
-    int tm, tn;
-    tile_coords(blockIdx.x, gridDim.x, p.tiles_m, p.tiles_n, tm, tn);
-    const int m0 = tm * BM, n0 = tn * BN;
-    const int batch = blockIdx.z, split = blockIdx.y;
-    const int bo = batch / p.batch_inner, bi = batch % p.batch_inner;
-    const float* A = p.A + bo * p.sAo + bi * p.sAi;
-    const float* B = p.B + bo * p.sBo + bi * p.sBi;
-    const int kbeg = split * p.k_per_split;
-    const int kend = min(p.K, kbeg + p.k_per_split);
-    const int nt = (kend - kbeg) / BK;
-
-    f32x16 acc[2][2];
-    acc_zero(acc);
-    GldsLoader<AKC> la;
-    GldsLoader<BKC> lb;
-    la.init(A, p.lda, m0, kbeg, t);
-    lb.init(B, p.ldb, n0, kbeg, t);
-    const unsigned sbase = lds_addr(smem);
-    if (nt > 0) {
-        la.issue(sbase, t);
-        lb.issue(sbase + GTILE_FLOATS * 4u, t);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    for (int it = 0; it < nt; ++it) {
-        const int cb = it & 1;
-        float* cur = smem + cb * GSTAGE_FLOATS;
-        if (it + 1 < nt) {  // DMA of tile it+1 flies under the 64 MFMAs of tile it
-            const unsigned nxt = sbase + (cb ^ 1) * (GSTAGE_FLOATS * 4u);
-            la.issue(nxt, t);
-            lb.issue(nxt + GTILE_FLOATS * 4u, t);
-        }
-        mma_tile_g<AKC, BKC>(cur, cur + GTILE_FLOATS, acc, wr, wc, lane);
-        // my DMA pieces have landed and my fragment reads are done -> everyone may swap buffers
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-    }
-
-    if (p.splits > 1) {
-        float* S = p.slabs + ((long long)split * gridDim.z + batch) * (long long)p.M * p.N;
-        const int N = p.N;
-        acc_foreach(acc, wr, wc, lane, [&](int r, int c, float v) { S[(long long)(m0 + r) * N + n0 + c] = v; });
-        return;
-    }
-    float* C = p.C + bo * p.sCo + bi * p.sCi;
-    const float alpha = p.alpha, beta = p.beta;
-    const long long ldc = p.ldc;
-    if (beta == 0.f) {
-        acc_foreach(acc, wr, wc, lane, [&](int r, int c, float v) { C[(m0 + r) * ldc + n0 + c] = alpha * v; });
-    } else {
-        acc_foreach(acc, wr, wc, lane, [&](int r, int c, float v) {
-            float* q = &C[(m0 + r) * ldc + n0 + c];
-            *q = fmaf(beta, *q, alpha * v);
         });
     }
 }
@@ -210,30 +133,23 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, float* __r
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-template <bool TA, bool TB>
-static int launch(nk_device* dev, const GemmArgs& p, int nbatch, bool aligned) {
+template <bool TA, bool TB, int TI, int TJ>
+static int launch_tile(nk_device* dev, const GemmArgs& p, int nbatch, bool aligned) {
     dim3 grid(p.tiles_m * p.tiles_n, p.splits, nbatch), block(NT);
-    static const int variant = getenv("NK_GEMM_VARIANT") ? atoi(getenv("NK_GEMM_VARIANT")) : 0;
-    if (aligned && variant == 7)  // LDS-DMA staging (same speed as the default; kept selectable)
-        hipLaunchKernelGGL((sgemm_glds_kernel<TA, TB>), grid, block, 0, dev->compute, p);
-    else if (aligned && variant == 1)
-        hipLaunchKernelGGL((sgemm_kernel<TA, TB, true, 1>), grid, block, 0, dev->compute, p);
-    else if (aligned && variant == 2)
-        hipLaunchKernelGGL((sgemm_kernel<TA, TB, true, 2>), grid, block, 0, dev->compute, p);
-    else if (aligned && variant == 3)
-        hipLaunchKernelGGL((sgemm_kernel<TA, TB, true, 3>), grid, block, 0, dev->compute, p);
-    else if (aligned && variant == 4)
-        hipLaunchKernelGGL((sgemm_kernel<TA, TB, true, 4>), grid, block, 0, dev->compute, p);
-    else if (aligned && variant == 5)  // ablation: no global loads (results are garbage)
-        hipLaunchKernelGGL((sgemm_kernel<TA, TB, true, 5>), grid, block, 0, dev->compute, p);
-    else if (aligned && variant == 6)  // ablation: no global loads, no LDS stores
-        hipLaunchKernelGGL((sgemm_kernel<TA, TB, true, 6>), grid, block, 0, dev->compute, p);
-    else if (aligned)
-        hipLaunchKernelGGL((sgemm_kernel<TA, TB, true>), grid, block, 0, dev->compute, p);
+    if (aligned)
+        hipLaunchKernelGGL((sgemm_kernel<TA, TB, true, TI, TJ>), grid, block, 0, dev->compute, p);
     else
-        hipLaunchKernelGGL((sgemm_kernel<TA, TB, false>), grid, block, 0, dev->compute, p);
+        hipLaunchKernelGGL((sgemm_kernel<TA, TB, false, TI, TJ>), grid, block, 0, dev->compute, p);
     NK_LAUNCH_CHECK();
     return NK_OK;
+}
+
+template <bool TA, bool TB>
+static int launch(nk_device* dev, const GemmArgs& p, int nbatch, bool aligned, int ti, int tj) {
+    if (ti == 2 && tj == 2) return launch_tile<TA, TB, 2, 2>(dev, p, nbatch, aligned);
+    if (ti == 2 && tj == 1) return launch_tile<TA, TB, 2, 1>(dev, p, nbatch, aligned);
+    if (ti == 1 && tj == 2) return launch_tile<TA, TB, 1, 2>(dev, p, nbatch, aligned);
+    return launch_tile<TA, TB, 1, 1>(dev, p, nbatch, aligned);
 }
 
 static int gemm_impl(nk_device* dev, int transA, int transB, int M, int N, int K, float alpha,
@@ -256,10 +172,21 @@ static int gemm_impl(nk_device* dev, int transA, int transB, int M, int N, int K
     p.alpha = alpha; p.beta = beta;
     p.batch_inner = batch_inner;
     p.sAo = sAo; p.sAi = sAi; p.sBo = sBo; p.sBi = sBi; p.sCo = sCo; p.sCi = sCi;
+
+    // tile shape: 128 wide unless the extent is <= 64, only 64-divisible, or (for small problems)
+    // 128x128 tiles would leave most of the 256 CUs without a block
+    auto blocks = [&](int ti, int tj) {
+        return (long long)((M + 64 * ti - 1) / (64 * ti)) * ((N + 64 * tj - 1) / (64 * tj)) * nbatch;
+    };
+    int ti = (M <= 64 || (M % 128 != 0 && M % 64 == 0)) ? 1 : 2;
+    int tj = (N <= 64 || (N % 128 != 0 && N % 64 == 0)) ? 1 : 2;
+    if (blocks(ti, tj) < dev->num_cus && tj == 2) tj = 1;
+    if (blocks(ti, tj) < dev->num_cus && ti == 2) ti = 1;
+    const int BM = 64 * ti, BN = 64 * tj;
     p.tiles_m = (M + BM - 1) / BM;
     p.tiles_n = (N + BN - 1) / BN;
 
-    // split-K when the output tiles alone leave most of the 256 CUs idle and K is long
+    // split-K when the output tiles alone leave most of the CUs idle and K is long
     const long long tiles = (long long)p.tiles_m * p.tiles_n * nbatch;
     int splits = 1;
     const int ktiles = (K + BK - 1) / BK;
@@ -270,11 +197,11 @@ static int gemm_impl(nk_device* dev, int transA, int transB, int M, int N, int K
         if (splits < 1) splits = 1;
     }
     int kts = (ktiles + splits - 1) / splits;
+    if (kts < 1) kts = 1;
     splits = (ktiles + kts - 1) / kts;
     if (splits < 1) splits = 1;
     p.splits = splits;
     p.k_per_split = kts * BK;
-    if (K == 0) { p.splits = 1; p.k_per_split = BK; }
     if (p.splits > 1) {
         void* ws = nullptr;
         int rc = nk_workspace(dev, (size_t)p.splits * nbatch * M * N * sizeof(float), &ws);
@@ -287,10 +214,10 @@ static int gemm_impl(nk_device* dev, int transA, int transB, int M, int N, int K
                          (sAi % 4 == 0) && (sBo % 4 == 0) && (sBi % 4 == 0);
     int rc = nk_prof_start(dev, NK_KERNEL_SGEMM, 2.0 * M * N * (double)K * nbatch);
     if (rc) return rc;
-    if (!transA && !transB) rc = launch<false, false>(dev, p, nbatch, aligned);
-    else if (!transA && transB) rc = launch<false, true>(dev, p, nbatch, aligned);
-    else if (transA && !transB) rc = launch<true, false>(dev, p, nbatch, aligned);
-    else rc = launch<true, true>(dev, p, nbatch, aligned);
+    if (!transA && !transB) rc = launch<false, false>(dev, p, nbatch, aligned, ti, tj);
+    else if (!transA && transB) rc = launch<false, true>(dev, p, nbatch, aligned, ti, tj);
+    else if (transA && !transB) rc = launch<true, false>(dev, p, nbatch, aligned, ti, tj);
+    else rc = launch<true, true>(dev, p, nbatch, aligned, ti, tj);
     if (rc) return rc;
     if (p.splits > 1) {
         const long long total = (long long)M * N * nbatch;

@@ -81,7 +81,14 @@ CONV_RANDOM = [
     ((2, 4, 20), (6, 4, 5), (3,), (2,), 1),
     ((1, 4, 6, 7, 8), (4, 2, 2, 3, 2), (1, 2, 1), (2, 1, 2), 2),
     ((4, 130, 9, 9), (140, 130, 3, 3), (1, 1), (1, 1), 1),       # > one 128 tile in M and K
-    ((2, 64, 16, 16), (128, 64, 3, 3), (1, 1), (1, 1), 1),        # aligned fast paths (C3-shaped)
+    ((2, 64, 16, 16), (128, 64, 3, 3), (1, 1), (1, 1), 1),        # fast bwd-input (tap-major), generic fwd
+    ((2, 64, 18, 18), (128, 64, 3, 3), (1, 1), (1, 1), 1),        # C3-shaped: fast fwd + fast bwd-input
+    ((3, 64, 10, 14), (64, 32, 3, 3), (1, 1), (1, 1), 2),         # grouped fast paths (Cg = Mg = 32)
+    ((2, 32, 12, 16), (96, 32, 3, 3), (1, 1), (2, 2), 1),         # dilated fast paths
+    ((2, 32, 11, 14), (64, 32, 3, 3), (2, 1), (1, 1), 1),         # fast fwd (unit stride on W only), generic bwd-input
+    ((2, 32, 40), (32, 32, 5), (1,), (1,), 1),                    # 1-d fast
+    ((1, 32, 4, 6, 10), (32, 32, 2, 3, 3), (1, 1, 1), (1, 1, 1), 1),  # 3-d fast
+    ((5, 32, 9, 9), (32, 32, 2, 2), (1, 1), (1, 1), 1),           # columns not a multiple of 128 / quads at the tail
 ]
 
 
