@@ -316,7 +316,10 @@ struct BwdKArgs {
     long long r_per_split;  // multiple of BK
 };
 
-template <bool VEC_G, int TI, int TJ>
+// QUADR: out[2] % 4 == 0, unit stride on the innermost axis, L % 4 == 0 -> the four consecutive
+// reduction indices a thread stages are one output-row quad: one (incremental, division-free)
+// decode per k-tile and one 16-B load per staged row.
+template <bool VEC_G, int TI, int TJ, bool QUADR>
 __global__ __launch_bounds__(NT, 2) void conv_bwd_kernel_kernel(BwdKArgs p) {
     constexpr int BM = 64 * TI, BN = 64 * TJ;
     constexpr int TA_FLOATS = tile_floats<BM>(), STAGE = TA_FLOATS + tile_floats<BN>();
@@ -355,20 +358,43 @@ __global__ __launch_bounds__(NT, 2) void conv_bwd_kernel_kernel(BwdKArgs p) {
 
     Stage<BM / 32> ra;
     Stage<BN / 32> rb;
+    // QUADR state: (sample, output coordinates) of this thread's first index in the current tile
+    int qn = 0, q0 = 0, q1 = 0, q2 = 0;
+    if (QUADR) {
+        const long long r = rbeg + rq * 4;
+        qn = (int)(r / g.L);
+        int l = (int)(r % g.L);
+        q2 = l % g.out[2]; l /= g.out[2];
+        q1 = l % g.out[1];
+        q0 = l / g.out[1];
+    }
     auto load_both = [&](long long r0) {
         // decompose the 4 consecutive reduction indices r0 + 4*rq + {0..3} -> (n, l)
         long long xo[4], go[4];
         bool rv[4];
+        if (QUADR) {
+            const bool v = r0 + rq * 4 < rend;
+            const long long x0 = (long long)qn * g.Cin * g.inplane +
+                                 ((q0 * g.stride[0] * g.in[1] + q1 * g.stride[1]) * g.in[2] + q2);
+            const long long g0 = (long long)qn * g.Cout * g.L + ((q0 * g.out[1] + q1) * g.out[2] + q2);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const long long r = r0 + rq * 4 + c;
-            rv[c] = r < rend;
-            const int n = rv[c] ? (int)(r / g.L) : 0, l = rv[c] ? (int)(r % g.L) : 0;
-            xo[c] = (long long)n * g.Cin * g.inplane + window_origin(g, l);
-            go[c] = (long long)n * g.Cout * g.L + l;
+            for (int c = 0; c < 4; ++c) { rv[c] = v; xo[c] = v ? x0 + c : 0; go[c] = v ? g0 + c : 0; }
+            q2 += BK;  // next k-tile: 32 positions further along the flattened (n, out) index
+            while (q2 >= g.out[2]) { q2 -= g.out[2]; ++q1; }
+            while (q1 >= g.out[1]) { q1 -= g.out[1]; ++q0; }
+            while (q0 >= g.out[0]) { q0 -= g.out[0]; ++qn; }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const long long r = r0 + rq * 4 + c;
+                rv[c] = r < rend;
+                const int n = rv[c] ? (int)(r / g.L) : 0, l = rv[c] ? (int)(r % g.L) : 0;
+                xo[c] = (long long)n * g.Cin * g.inplane + window_origin(g, l);
+                go[c] = (long long)n * g.Cout * g.L + l;
+            }
         }
         // the four reduction indices are neighbours in one output row (unit stride)
-        const bool quad = rv[3] && xo[1] == xo[0] + 1 && xo[2] == xo[0] + 2 && xo[3] == xo[0] + 3;
+        const bool quad = QUADR ? rv[0] : (rv[3] && xo[1] == xo[0] + 1 && xo[2] == xo[0] + 2 && xo[3] == xo[0] + 3);
 #define NK_A(j, V, AV)                                                                       \
     {                                                                                        \
         const long long rowoff = (long long)(m0 + row + 32 * j) * g.L;                       \
@@ -878,7 +904,13 @@ int nk_conv_bwd_kernel(nk_device* dev, int nd, float* dw, const int* w_shape, co
     p.tiles_n = (Kc + BN - 1) / BN;
     const long long tiles = (long long)p.tiles_m * p.tiles_n * groups;
     const long long rtiles = (R + BK - 1) / BK;
-    long long splits = (3LL * dev->num_cus + tiles - 1) / tiles;   // ~3 blocks per CU
+    // whole "waves" of blocks: the kernel keeps 2 blocks per CU resident, so the grid is sized to
+    // (a multiple of) 2 * CUs blocks — a ragged second wave would idle most of the chip
+    const long long slots = 2LL * dev->num_cus;
+    long long waves = (tiles * ((rtiles + 127) / 128) + slots - 1) / slots;  // <= ~128 k-tiles per block ...
+    if (waves < 1) waves = 1;
+    long long splits = slots * waves / tiles;             // ... in full waves
+    if (splits < 1) splits = 1;
     if (splits > rtiles) splits = rtiles;
     if (splits > 1024) splits = 1024;
     if (splits < 1) splits = 1;
@@ -899,17 +931,23 @@ int nk_conv_bwd_kernel(nk_device* dev, int nd, float* dw, const int* w_shape, co
     const bool vec_g = (g.L % 4 == 0) && al16(gy);
     rc = nk_prof_start(dev, NK_KERNEL_CONV, 2.0 * g.N * (double)g.Cout * g.L * g.Cg * g.KK);
     if (rc) return rc;
-#define NK_LAUNCH_BWK(VG, TI_, TJ_) hipLaunchKernelGGL((conv_bwd_kernel_kernel<VG, TI_, TJ_>), grid, dim3(NT), 0, dev->compute, p)
-    if (vec_g) {
-        if (ti == 2 && tj == 2) NK_LAUNCH_BWK(true, 2, 2);
-        else if (ti == 2) NK_LAUNCH_BWK(true, 2, 1);
-        else if (tj == 2) NK_LAUNCH_BWK(true, 1, 2);
-        else NK_LAUNCH_BWK(true, 1, 1);
+    const bool quadr = vec_g && g.out[2] % 4 == 0 && g.stride[2] == 1;
+#define NK_LAUNCH_BWK(VG, TI_, TJ_, Q) hipLaunchKernelGGL((conv_bwd_kernel_kernel<VG, TI_, TJ_, Q>), grid, dim3(NT), 0, dev->compute, p)
+    if (quadr) {
+        if (ti == 2 && tj == 2) NK_LAUNCH_BWK(true, 2, 2, true);
+        else if (ti == 2) NK_LAUNCH_BWK(true, 2, 1, true);
+        else if (tj == 2) NK_LAUNCH_BWK(true, 1, 2, true);
+        else NK_LAUNCH_BWK(true, 1, 1, true);
+    } else if (vec_g) {
+        if (ti == 2 && tj == 2) NK_LAUNCH_BWK(true, 2, 2, false);
+        else if (ti == 2) NK_LAUNCH_BWK(true, 2, 1, false);
+        else if (tj == 2) NK_LAUNCH_BWK(true, 1, 2, false);
+        else NK_LAUNCH_BWK(true, 1, 1, false);
     } else {
-        if (ti == 2 && tj == 2) NK_LAUNCH_BWK(false, 2, 2);
-        else if (ti == 2) NK_LAUNCH_BWK(false, 2, 1);
-        else if (tj == 2) NK_LAUNCH_BWK(false, 1, 2);
-        else NK_LAUNCH_BWK(false, 1, 1);
+        if (ti == 2 && tj == 2) NK_LAUNCH_BWK(false, 2, 2, false);
+        else if (ti == 2) NK_LAUNCH_BWK(false, 2, 1, false);
+        else if (tj == 2) NK_LAUNCH_BWK(false, 1, 2, false);
+        else NK_LAUNCH_BWK(false, 1, 1, false);
     }
 #undef NK_LAUNCH_BWK
     NK_LAUNCH_CHECK();
