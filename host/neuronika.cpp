@@ -343,6 +343,41 @@ struct DropoutBwd : Backward {
     void targets(std::vector<const Gradient*>& out) const override { out.push_back(dx.get()); }
 };
 
+// Fused attention probabilities: Multiplication(scalar) + Softmax(last axis) + Dropout
+struct AttnProbsFwd : Forward {
+    Shared<HipArray> x, probs, out;
+    float scale;
+    double p;
+    Shared<bool> status;
+    uint64_t seed;
+    Shared<uint64_t> calls, last_offset;  // the backward node regenerates the mask of the LAST forward
+    void forward() const override {
+        const int L = x->shape().back();
+        const long long rows = (long long)(x->len() / (size_t)L);
+        const uint64_t offset = (*calls) * ((x->len() + 3) / 4);
+        ++(*calls);
+        *last_offset = offset;
+        check(nk_scale_softmax_dropout_fwd(D(x), x->ptr(), probs->ptr(), out->ptr(), nullptr, rows, L, scale, p,
+                                           *status ? 1 : 0, seed, offset));
+    }
+};
+struct AttnProbsBwd : Backward {
+    Shared<Gradient> dx, g;
+    Shared<HipArray> probs;
+    float scale;
+    double p;
+    Shared<bool> status;
+    uint64_t seed;
+    Shared<uint64_t> last_offset;
+    void backward() const override {
+        HipArray& d = dx->borrow();
+        const int L = d.shape().back();
+        check(nk_scale_softmax_dropout_bwd(d.device()->raw(), d.ptr(), g->borrow().ptr(), probs->ptr(), nullptr,
+                                           (long long)(d.len() / (size_t)L), L, scale, p, *status ? 1 : 0, seed, *last_offset));
+    }
+    void targets(std::vector<const Gradient*>& out) const override { out.push_back(dx.get()); }
+};
+
 struct ChunkFwd : Forward {
     Shared<HipArray> x, y;
     int chunk_no;
@@ -623,6 +658,19 @@ Var Var::mm_t(const Var& rhs) const { return matmul_var(1, *this, rhs); }
 VarDiff Var::mm_t(const VarDiff& rhs) const { return matmul_diff(1, *this, nullptr, nullptr, rhs.var, rhs.grad, &rhs.history); }
 Var Var::bmm(const Var& rhs) const { return matmul_var(2, *this, rhs); }
 Var Var::bmm_t(const Var& rhs) const { return matmul_var(3, *this, rhs); }
+Var Var::attention_probs(float scale, double p, Shared<bool> status) const {
+    if (!(p >= 0.0 && p <= 1.0)) panic("Wrong probability received: " + std::to_string(p) + ".");
+    if (shape().empty()) panic("attention_probs: at least one axis expected");
+    auto op = std::make_shared<AttnProbsFwd>();
+    op->x = data; op->probs = zeros_like(data, shape()); op->out = zeros_like(data, shape());
+    op->scale = scale; op->p = p; op->status = std::move(status);
+    static uint64_t next_seed = 0xD1B54A32D192ED03ull;
+    op->seed = next_seed; next_seed += 0x9E3779B97F4A7C15ull;
+    op->calls = std::make_shared<uint64_t>(0);
+    op->last_offset = std::make_shared<uint64_t>(0);
+    auto y = op->out;
+    return Var::node(y, op, history);
+}
 Var Var::convolution(const Var& input, const std::vector<int>& stride, const std::vector<int>& dilation, int groups) const {
     Shape kfull = shape();  // kernel (Cout, Cin/groups, k...) checked against the input
     Shape kcheck = kfull;
@@ -770,6 +818,15 @@ VarDiff VarDiff::mm_t(const VarDiff& rhs) const { return matmul_diff(1, var, gra
 VarDiff VarDiff::bmm(const VarDiff& rhs) const { return matmul_diff(2, var, grad, &history, rhs.var, rhs.grad, &rhs.history); }
 VarDiff VarDiff::bmm_t(const VarDiff& rhs) const { return matmul_diff(3, var, grad, &history, rhs.var, rhs.grad, &rhs.history); }
 
+VarDiff VarDiff::attention_probs(float scale, double p, Shared<bool> status) const {
+    Var v = var.attention_probs(scale, p, status);
+    auto fwd = std::dynamic_pointer_cast<AttnProbsFwd>(v.history.to_vec().back().op);
+    auto g = std::make_shared<Gradient>(device(), shape());
+    auto bw = std::make_shared<AttnProbsBwd>();
+    bw->dx = grad; bw->g = g; bw->probs = fwd->probs; bw->scale = scale; bw->p = p; bw->status = status;
+    bw->seed = fwd->seed; bw->last_offset = fwd->last_offset;
+    return VarDiff::node(std::move(v), g, entry(bw, g), history);
+}
 static VarDiff conv_diff(const VarDiff& kernel, const Var& input, const Shared<Gradient>& dx,
                          const History<BackwardEntry>* hx, const std::vector<int>& stride,
                          const std::vector<int>& dilation, int groups) {
@@ -876,8 +933,10 @@ VarDiff MultiheadAttention::forward(const VarDiff& x, int batch) const {
     const VarDiff Q = q.forward(x).split_heads(batch, S, heads, dh);
     const VarDiff K = k.forward(x).split_heads(batch, S, heads, dh);
     const VarDiff V = v.forward(x).split_heads(batch, S, heads, dh);
-    const VarDiff scores = Q.bmm_t(K) * (1.f / std::sqrt((float)dh));
-    const VarDiff P = drop.forward(scores.softmax(2));
+    const float scale = 1.f / std::sqrt((float)dh);
+    const VarDiff P = (fused && S % 4 == 0 && S <= 2048)
+                          ? Q.bmm_t(K).attention_probs(scale, drop.p, drop.status)
+                          : drop.forward((Q.bmm_t(K) * scale).softmax(2));
     const VarDiff O = P.bmm(V).merge_heads(batch, S, heads, dh);
     return o.forward(O);
 }

@@ -231,6 +231,9 @@ class Var {
     // batched (b,h) matrix products over [B*H, S, *] tiles = B*H `mm` / `mm_t` nodes
     Var bmm(const Var& rhs) const;
     Var bmm_t(const Var& rhs) const;
+    // dropout(softmax(self * scale, last axis), p): the Multiplication + Softmax + Dropout nodes of
+    // the attention probabilities as ONE node (same values, one pass over the score tensor)
+    Var attention_probs(float scale, double p, Shared<bool> status) const;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -280,6 +283,7 @@ class VarDiff {
     VarDiff merge_heads(int B, int S, int H, int dh) const;
     VarDiff bmm(const VarDiff& rhs) const;
     VarDiff bmm_t(const VarDiff& rhs) const;
+    VarDiff attention_probs(float scale, double p, Shared<bool> status) const;
 };
 
 // `Add/Sub/Mul/Div` with NumPy broadcasting, all four differentiability combinations
@@ -348,6 +352,7 @@ struct MultiheadAttention {
     Linear q, k, v, o;
     int d_model, heads;
     Dropout drop;
+    bool fused = true;  // scale + softmax + dropout as one node (false: three reference nodes)
     MultiheadAttention(DevicePtr dev, int d_model, int heads, double p, uint64_t seed);
     VarDiff forward(const VarDiff& x, int batch) const;  // x: (batch*seq, d_model)
 };

@@ -157,6 +157,7 @@ PYBIND11_MODULE(_tape, m) {
         .def_readonly("v", &nn::MultiheadAttention::v)
         .def_readonly("o", &nn::MultiheadAttention::o)
         .def_readonly("drop", &nn::MultiheadAttention::drop)
+        .def_readwrite("fused", &nn::MultiheadAttention::fused)
         .def("forward", &nn::MultiheadAttention::forward);
 
     py::module_ optim = m.def_submodule("optim");

@@ -209,6 +209,22 @@ int nk_log_softmax_fwd(nk_device* dev, const float* x, float* y, const int* shap
 int nk_log_softmax_bwd(nk_device* dev, float* dx, const float* g, const float* y,
                        const int* shape, int nd, int axis);
 
+/* Fused attention probabilities (the Multiplication-by-scalar, Softmax(last axis) and Dropout
+ * nodes of the composed multi-head attention in ONE pass over the rows x L score tensor; the
+ * module does not exist in the reference — SURVEY.md 8a — its oracle is the composition of
+ * node/multiplication, node/softmax and node/dropout, and this produces the same values):
+ *   probs = softmax(scores * scale) ; out = dropout(probs)   (mask = Philox(seed, offset), the
+ *   same stream nk_dropout_fwd draws; `noise` may be NULL: the mask is then regenerated in the
+ *   backward pass instead of being stored).
+ * backward: g_p = g_out * mask (no 1/(1-p): reference quirk) ; d_scaled = probs*(g_p - sum(g_p*probs)) ;
+ *   d_scores += d_scaled * scale. */
+int nk_scale_softmax_dropout_fwd(nk_device* dev, const float* scores, float* probs, float* out, float* noise,
+                                 long long rows, int L, float scale, double p, int train, uint64_t seed,
+                                 uint64_t offset);
+int nk_scale_softmax_dropout_bwd(nk_device* dev, float* d_scores, const float* g_out, const float* probs,
+                                 const float* noise, long long rows, int L, float scale, double p, int train,
+                                 uint64_t seed, uint64_t offset);
+
 /* ------------------------------------------------------------------ dropout ------------ */
 /* Dropout::forward node/dropout/mod.rs:53-79.  train && 0<p<1: noise ~ Bernoulli(1-p) in
  * {0,1} is (re)drawn from Philox4x32-10(seed, offset) and written to `noise` (f32, like the

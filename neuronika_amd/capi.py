@@ -97,6 +97,8 @@ _SIGS = {
     "nk_softmax_bwd": [VP, VP, VP, VP, c_intp, C.c_int, C.c_int],
     "nk_log_softmax_fwd": [VP, VP, VP, c_intp, C.c_int, C.c_int],
     "nk_log_softmax_bwd": [VP, VP, VP, VP, c_intp, C.c_int, C.c_int],
+    "nk_scale_softmax_dropout_fwd": [VP, VP, VP, VP, VP, C.c_longlong, C.c_int, C.c_float, C.c_double, C.c_int, C.c_uint64, C.c_uint64],
+    "nk_scale_softmax_dropout_bwd": [VP, VP, VP, VP, VP, C.c_longlong, C.c_int, C.c_float, C.c_double, C.c_int, C.c_uint64, C.c_uint64],
     "nk_dropout_fwd": [VP, VP, VP, VP, C.c_size_t, C.c_double, C.c_int, C.c_uint64, C.c_uint64],
     "nk_dropout_bwd": [VP, VP, VP, VP, C.c_size_t, C.c_double, C.c_int],
     "nk_chunk_fwd": [VP, VP, c_intp, VP, c_intp, C.c_int, C.c_int],
@@ -412,6 +414,18 @@ def dropout_fwd(dev, x, y, noise, p, train=True, seed=0, offset=0):
 
 def dropout_bwd(dev, dx, g, noise, p, train=True):
     check(lib.nk_dropout_bwd(dev.h, dx.p, g.p, noise.p if noise is not None else None, dx.size, float(p), int(train)))
+
+
+def scale_softmax_dropout_fwd(dev, scores, probs, out, noise, scale, p, train=True, seed=0, offset=0):
+    L = scores.shape[-1]
+    check(lib.nk_scale_softmax_dropout_fwd(dev.h, scores.p, probs.p, out.p, noise.p if noise is not None else None,
+                                           scores.size // L, L, scale, float(p), int(train), seed, offset))
+
+
+def scale_softmax_dropout_bwd(dev, d_scores, g_out, probs, noise, scale, p, train=True, seed=0, offset=0):
+    L = probs.shape[-1]
+    check(lib.nk_scale_softmax_dropout_bwd(dev.h, d_scores.p, g_out.p, probs.p, noise.p if noise is not None else None,
+                                           probs.size // L, L, scale, float(p), int(train), seed, offset))
 
 
 def chunk_fwd(dev, x, y, chunk_no):

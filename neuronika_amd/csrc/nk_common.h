@@ -121,3 +121,22 @@ __device__ __forceinline__ float nk_block_max(float v, float* smem) {
     for (int i = 1; i < NT / 64; ++i) r = fmaxf(r, smem[i]);
     return r;
 }
+
+// ---- Philox4x32-10 (Salmon et al., SC'11): the device RNG of Dropout ------------------------------
+__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = 0xD2511F53ull * c.x, p1 = 0xCD9E8D57ull * c.z;
+        const unsigned hi0 = (unsigned)(p0 >> 32), lo0 = (unsigned)p0;
+        const unsigned hi1 = (unsigned)(p1 >> 32), lo1 = (unsigned)p1;
+        c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
+        k.x += 0x9E3779B9u;
+        k.y += 0xBB67AE85u;
+    }
+    return c;
+}
+
+__device__ __forceinline__ float keep_bit(unsigned word, float keep_prob) {
+    return ((float)(word >> 8) * 5.9604644775390625e-08f /* 2^-24 */ < keep_prob) ? 1.f : 0.f;
+}
+

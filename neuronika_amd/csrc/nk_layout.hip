@@ -11,24 +11,6 @@ namespace {
 
 bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-// ------------------------------------------------------------------ Philox4x32-10 ------------
-__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const unsigned long long p0 = 0xD2511F53ull * c.x, p1 = 0xCD9E8D57ull * c.z;
-        const unsigned hi0 = (unsigned)(p0 >> 32), lo0 = (unsigned)p0;
-        const unsigned hi1 = (unsigned)(p1 >> 32), lo1 = (unsigned)p1;
-        c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
-        k.x += 0x9E3779B9u;
-        k.y += 0xBB67AE85u;
-    }
-    return c;
-}
-
-__device__ __forceinline__ float keep_bit(unsigned word, float keep_prob) {
-    return ((float)(word >> 8) * 5.9604644775390625e-08f /* 2^-24 */ < keep_prob) ? 1.f : 0.f;
-}
-
 // element i uses word i%4 of Philox(counter = i/4 + offset, key = seed); y = (x*noise)/scale
 __global__ void dropout_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ noise,
                                    size_t n, float keep_prob, float scale, unsigned long long seed,

@@ -260,6 +260,113 @@ __global__ void softmax_bwd_strided_kernel(float* __restrict__ dx, const float* 
     }
 }
 
+// ---------------------------------------------------------------- fused attention probabilities --
+// One wave per row, the row in registers (V float4 per lane): scale, max, exp, sum, normalise,
+// Philox mask, dropout — scores are read once, probs / out written once.  MASK: 0 = no dropout
+// (eval / p == 0: out = probs), 1 = Bernoulli mask, 2 = p == 1 (out = 0).
+template <int V, int MASK, bool STORE_NOISE>
+__global__ void attn_probs_fwd_kernel(const float* __restrict__ s, float* __restrict__ probs, float* __restrict__ out,
+                                      float* __restrict__ noise, long long rows, int L, float scale, float keep,
+                                      float dscale, unsigned long long seed, unsigned long long offset) {
+    const int lane = threadIdx.x & 63;
+    const long long row = blockIdx.x * (long long)(blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const long long rb = row * L;
+    float4 v[V];
+    float m = F32_MIN;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < L) {
+            float4 x = *reinterpret_cast<const float4*>(s + rb + c);
+            x.x *= scale; x.y *= scale; x.z *= scale; x.w *= scale;   // Multiplication node
+            v[i] = x;
+            m = fmaxf(m, fmaxf(fmaxf(x.x, x.y), fmaxf(x.z, x.w)));
+        }
+    }
+    m = nk_wave_max(m);
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < L) {
+            float4 e;
+            e.x = expf(v[i].x - m); e.y = expf(v[i].y - m); e.z = expf(v[i].z - m); e.w = expf(v[i].w - m);
+            sum += (e.x + e.y) + (e.z + e.w);
+            v[i] = e;
+        }
+    }
+    sum = nk_wave_sum(sum);
+    const uint2 key = make_uint2((unsigned)seed, (unsigned)(seed >> 32));
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < L) {
+            float4 y;
+            y.x = v[i].x / sum; y.y = v[i].y / sum; y.z = v[i].z / sum; y.w = v[i].w / sum;   // Softmax node
+            *reinterpret_cast<float4*>(probs + rb + c) = y;
+            float4 o = y;
+            if (MASK == 1) {                                                                   // Dropout node
+                const unsigned long long ctr = (unsigned long long)(rb + c) / 4 + offset;
+                const uint4 r = philox4x32_10(make_uint4((unsigned)ctr, (unsigned)(ctr >> 32), 0u, 0u), key);
+                const float4 nz = make_float4(keep_bit(r.x, keep), keep_bit(r.y, keep), keep_bit(r.z, keep), keep_bit(r.w, keep));
+                o.x = (y.x * nz.x) / dscale; o.y = (y.y * nz.y) / dscale; o.z = (y.z * nz.z) / dscale; o.w = (y.w * nz.w) / dscale;
+                if (STORE_NOISE) *reinterpret_cast<float4*>(noise + rb + c) = nz;
+            } else if (MASK == 2) {
+                o = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            *reinterpret_cast<float4*>(out + rb + c) = o;
+        }
+    }
+}
+
+// MASK 0: g_p = g ; 1: g_p = g * mask (stored or regenerated)
+template <int V, int MASK, bool LOAD_NOISE>
+__global__ void attn_probs_bwd_kernel(float* __restrict__ ds, const float* __restrict__ g, const float* __restrict__ probs,
+                                      const float* __restrict__ noise, long long rows, int L, float scale, float keep,
+                                      unsigned long long seed, unsigned long long offset) {
+    const int lane = threadIdx.x & 63;
+    const long long row = blockIdx.x * (long long)(blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const long long rb = row * L;
+    const uint2 key = make_uint2((unsigned)seed, (unsigned)(seed >> 32));
+    float4 gp[V], y[V];
+    float dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < L) {
+            float4 gv = *reinterpret_cast<const float4*>(g + rb + c);
+            y[i] = *reinterpret_cast<const float4*>(probs + rb + c);
+            if (MASK == 1) {                                                                   // DropoutBackward
+                float4 nz;
+                if (LOAD_NOISE) nz = *reinterpret_cast<const float4*>(noise + rb + c);
+                else {
+                    const unsigned long long ctr = (unsigned long long)(rb + c) / 4 + offset;
+                    const uint4 r = philox4x32_10(make_uint4((unsigned)ctr, (unsigned)(ctr >> 32), 0u, 0u), key);
+                    nz = make_float4(keep_bit(r.x, keep), keep_bit(r.y, keep), keep_bit(r.z, keep), keep_bit(r.w, keep));
+                }
+                gv.x *= nz.x; gv.y *= nz.y; gv.z *= nz.z; gv.w *= nz.w;
+            }
+            gp[i] = gv;
+            dot += (gv.x * y[i].x + gv.y * y[i].y) + (gv.z * y[i].z + gv.w * y[i].w);
+        }
+    }
+    dot = nk_wave_sum(dot);
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < L) {
+            float4 d = *reinterpret_cast<float4*>(ds + rb + c);
+            d.x += (y[i].x * (gp[i].x - dot)) * scale;   // SoftmaxBackward then MultiplicationBackwardLeft
+            d.y += (y[i].y * (gp[i].y - dot)) * scale;
+            d.z += (y[i].z * (gp[i].z - dot)) * scale;
+            d.w += (y[i].w * (gp[i].w - dot)) * scale;
+            *reinterpret_cast<float4*>(ds + rb + c) = d;
+        }
+    }
+}
+
 int lane_geometry(const int* shape, int nd, int axis, long long* outer, int* L, long long* inner) {
     NK_CHECK(nd >= 1 && nd <= NK_MAX_DIMS, "bad rank %d", nd);
     NK_CHECK(axis >= 0 && axis < nd, "axis %d out of range for rank %d", axis, nd);
@@ -361,6 +468,58 @@ int nk_log_softmax_fwd(nk_device* dev, const float* x, float* y, const int* shap
 }
 int nk_log_softmax_bwd(nk_device* dev, float* dx, const float* g, const float* y, const int* shape, int nd, int axis) {
     return softmax_bwd<true>(dev, dx, g, y, shape, nd, axis);
+}
+
+int nk_scale_softmax_dropout_fwd(nk_device* dev, const float* scores, float* probs, float* out, float* noise,
+                                 long long rows, int L, float scale, double p, int train, uint64_t seed,
+                                 uint64_t offset) {
+    NK_USE(dev);
+    NK_CHECK(p >= 0.0 && p <= 1.0, "Wrong probability received: %g.", p);
+    NK_CHECK(rows >= 0 && L >= 0, "negative extent");
+    if (rows == 0 || L == 0) return NK_OK;
+    NK_CHECK(scores && probs && out, "null pointer in nk_scale_softmax_dropout_fwd");
+    NK_CHECK(L % 4 == 0 && L <= 2048 && al16(scores) && al16(probs) && al16(out) && (!noise || al16(noise)),
+             "fused attention probabilities need L %% 4 == 0, L <= 2048 and 16-byte aligned buffers (L=%d)", L);
+    const int mask = (!train || p == 0.0) ? 0 : (1.0 - p == 0.0 ? 2 : 1);
+    const float keep = (float)(1.0 - p), dscale = 1.f - (float)p;
+    const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+#define NK_AP(V)                                                                                                   \
+    do {                                                                                                           \
+        if (mask == 0) hipLaunchKernelGGL((attn_probs_fwd_kernel<V, 0, false>), grid, block, 0, dev->compute, scores, probs, out, noise, rows, L, scale, keep, dscale, (unsigned long long)seed, (unsigned long long)offset); \
+        else if (mask == 2) hipLaunchKernelGGL((attn_probs_fwd_kernel<V, 2, false>), grid, block, 0, dev->compute, scores, probs, out, noise, rows, L, scale, keep, dscale, (unsigned long long)seed, (unsigned long long)offset); \
+        else if (noise) hipLaunchKernelGGL((attn_probs_fwd_kernel<V, 1, true>), grid, block, 0, dev->compute, scores, probs, out, noise, rows, L, scale, keep, dscale, (unsigned long long)seed, (unsigned long long)offset); \
+        else hipLaunchKernelGGL((attn_probs_fwd_kernel<V, 1, false>), grid, block, 0, dev->compute, scores, probs, out, noise, rows, L, scale, keep, dscale, (unsigned long long)seed, (unsigned long long)offset); \
+    } while (0)
+    if (L <= 256) NK_AP(1); else if (L <= 512) NK_AP(2); else if (L <= 1024) NK_AP(4); else NK_AP(8);
+#undef NK_AP
+    NK_LAUNCH_CHECK();
+    return NK_OK;
+}
+
+int nk_scale_softmax_dropout_bwd(nk_device* dev, float* d_scores, const float* g_out, const float* probs,
+                                 const float* noise, long long rows, int L, float scale, double p, int train,
+                                 uint64_t seed, uint64_t offset) {
+    NK_USE(dev);
+    NK_CHECK(p >= 0.0 && p <= 1.0, "Wrong probability received: %g.", p);
+    NK_CHECK(rows >= 0 && L >= 0, "negative extent");
+    if (rows == 0 || L == 0) return NK_OK;
+    NK_CHECK(d_scores && g_out && probs, "null pointer in nk_scale_softmax_dropout_bwd");
+    NK_CHECK(L % 4 == 0 && L <= 2048 && al16(d_scores) && al16(g_out) && al16(probs) && (!noise || al16(noise)),
+             "fused attention probabilities need L %% 4 == 0, L <= 2048 and 16-byte aligned buffers (L=%d)", L);
+    // p == 1: the reference's backward multiplies by the (untouched, zero) noise buffer -> no gradient
+    const bool masked = train && p != 0.0;
+    const float keep = (1.0 - p == 0.0) ? -1.f : (float)(1.0 - p);  // keep < 0: every draw is "dropped"
+    const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+#define NK_AP(V)                                                                                                   \
+    do {                                                                                                           \
+        if (!masked) hipLaunchKernelGGL((attn_probs_bwd_kernel<V, 0, false>), grid, block, 0, dev->compute, d_scores, g_out, probs, noise, rows, L, scale, keep, (unsigned long long)seed, (unsigned long long)offset); \
+        else if (noise && keep >= 0.f) hipLaunchKernelGGL((attn_probs_bwd_kernel<V, 1, true>), grid, block, 0, dev->compute, d_scores, g_out, probs, noise, rows, L, scale, keep, (unsigned long long)seed, (unsigned long long)offset); \
+        else hipLaunchKernelGGL((attn_probs_bwd_kernel<V, 1, false>), grid, block, 0, dev->compute, d_scores, g_out, probs, noise, rows, L, scale, keep, (unsigned long long)seed, (unsigned long long)offset); \
+    } while (0)
+    if (L <= 256) NK_AP(1); else if (L <= 512) NK_AP(2); else if (L <= 1024) NK_AP(4); else NK_AP(8);
+#undef NK_AP
+    NK_LAUNCH_CHECK();
+    return NK_OK;
 }
 
 }  // extern "C"

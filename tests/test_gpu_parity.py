@@ -405,6 +405,44 @@ def test_dropout(dev):
         c.dropout_fwd(dev, X, Y, NZ, 1.5, True)
 
 
+def test_fused_attention_probs_equals_three_nodes(dev):
+    """nk_scale_softmax_dropout_* == Multiplication(scalar) -> Softmax(last) -> Dropout, bit for bit
+    on the forward outputs and the mask, and to rounding on the backward (same op order)."""
+    c = capi()
+    rows, L = 96, 1024
+    scale, p, seed, off = 0.125, 0.1, 77, 5
+    s = rnd(1, (rows, L), -8, 8)
+    S, SC = dev.array(s), dev.array(np.full((), scale, np.float32))
+    SCALED, P1, O1, NZ = dev.zeros((rows, L)), dev.zeros((rows, L)), dev.zeros((rows, L)), dev.zeros((rows, L))
+    c.binary_fwd(dev, "mul", SCALED, S, SC); c.softmax_fwd(dev, SCALED, P1, 1); c.dropout_fwd(dev, P1, O1, NZ, p, True, seed, off)
+    P2, O2 = dev.zeros((rows, L)), dev.zeros((rows, L))
+    c.scale_softmax_dropout_fwd(dev, S, P2, O2, None, scale, p, True, seed, off)
+    assert np.array_equal(P1.numpy(), P2.numpy()) and np.array_equal(O1.numpy(), O2.numpy())
+    NZ2, O3 = dev.zeros((rows, L)), dev.zeros((rows, L))
+    c.scale_softmax_dropout_fwd(dev, S, P2, O3, NZ2, scale, p, True, seed, off)       # stored-mask form
+    assert np.array_equal(NZ.numpy(), NZ2.numpy()) and np.array_equal(O3.numpy(), O1.numpy())
+    assert np.array_equal(NZ.numpy().reshape(-1), O.dropout_noise(rows * L, p, seed, off))
+    g, d0 = rnd(2, (rows, L), -1, 1), rnd(3, (rows, L))
+    G = dev.array(g)
+    dP, dSC, dS1 = dev.zeros((rows, L)), dev.zeros((rows, L)), dev.array(d0)
+    c.dropout_bwd(dev, dP, G, NZ, p, True); c.softmax_bwd(dev, dSC, dP, P1, 1); c.binary_bwd_left(dev, "mul", dS1, dSC, SC)
+    dS2, dS3 = dev.array(d0), dev.array(d0)
+    c.scale_softmax_dropout_bwd(dev, dS2, G, P2, None, scale, p, True, seed, off)       # regenerated mask
+    c.scale_softmax_dropout_bwd(dev, dS3, G, P2, NZ2, scale, p, True, seed, off)        # stored mask
+    assert np.array_equal(dS2.numpy(), dS3.numpy())
+    close(dS2.numpy(), dS1.numpy(), rtol=1e-6, atol=1e-7)
+    # eval mode / p = 0 / p = 1 (dropout/test.rs:57-85 semantics carried through)
+    for pp, train in ((0.3, False), (0.0, True)):
+        c.scale_softmax_dropout_fwd(dev, S, P2, O2, None, scale, pp, train, seed, off)
+        assert np.array_equal(O2.numpy(), P1.numpy())
+    c.scale_softmax_dropout_fwd(dev, S, P2, O2, None, scale, 1.0, True, seed, off)
+    assert not O2.numpy().any() and np.array_equal(P2.numpy(), P1.numpy())
+    dS4 = dev.array(d0); c.scale_softmax_dropout_bwd(dev, dS4, G, P2, None, scale, 1.0, True, seed, off)
+    assert np.array_equal(dS4.numpy(), d0)
+    with pytest.raises(c.NeuronikaHipError, match="L % 4 == 0"):
+        c.scale_softmax_dropout_fwd(dev, dev.zeros((4, 6)), dev.zeros((4, 6)), dev.zeros((4, 6)), None, 1.0, 0.0)
+
+
 # ------------------------------------------------------------------------------ layout glue
 def test_pad_chunk_concat_transpose(dev, golden):
     c = capi()

@@ -199,6 +199,35 @@ def test_mha_C5_small(nk, tdev):
         close(getattr(mha, n).bias.grad(), grads["b" + n], 1e-3, 1e-4)
 
 
+def test_mha_fused_equals_unfused_with_dropout(nk, tdev):
+    """The one-node attention probabilities give the same result as the three reference nodes."""
+    B, S, d, H = 2, 64, 128, 4
+    x = rnd(0, (B * S, d)); g = rnd(5, (B * S, d))
+    outs = []
+    for fused in (True, False):
+        mha = nk.nn.MultiheadAttention(tdev, d, H, 0.0, 11)
+        mha.fused = fused
+        X = nk.from_ndarray(tdev, x).requires_grad()
+        loss = (mha.forward(X, B) * nk.from_ndarray(tdev, g)).sum()
+        n_nodes = loss.history_len()
+        loss.forward(); loss.backward(1.0)
+        outs.append((loss.item(), X.grad().copy(), mha.q.weight.grad().copy(), n_nodes))
+    assert outs[0][3] == outs[1][3] - 2                       # three nodes became one
+    close(outs[0][0], outs[1][0], 1e-6)
+    close(outs[0][1], outs[1][1], 1e-5, 1e-7)
+    close(outs[0][2], outs[1][2], 1e-5, 1e-6)
+    # with dropout: outputs are scaled copies of the no-dropout probabilities where kept
+    mha = nk.nn.MultiheadAttention(tdev, d, H, 0.25, 11)
+    X = nk.from_ndarray(tdev, x).requires_grad()
+    out = mha.forward(X, B)
+    out.forward()
+    assert np.isfinite(out.data()).all()
+    mha.drop.eval(); out.forward(); ev = out.data().copy()
+    mha0 = nk.nn.MultiheadAttention(tdev, d, H, 0.0, 11)
+    o0 = mha0.forward(nk.from_ndarray(tdev, x).requires_grad(), B); o0.forward()
+    close(ev, o0.data(), 1e-6, 1e-7)                         # eval mode == no dropout
+
+
 def test_rccl_single_rank_and_gradient_sync(nk, tdev):
     """Exercise the RCCL entry points on the GPU box (1 GPU => world of one): unique id,
     communicator, side-stream all-reduce ordered after a compute-stream event, join; and the
