@@ -948,23 +948,51 @@ VarDiff MultiheadAttention::forward(const VarDiff& x, int batch) const {
 // =================================================================================================
 namespace optim {
 
-SGD::SGD(float lr, Penalty penalty, float momentum, float dampening, bool nesterov)
-    : lr_(lr), momentum_(momentum), dampening_(dampening), nesterov_(nesterov), penalty_(penalty) {}
-void SGD::register_param(const VarDiff& p) {
+void Optimizer::register_param(const VarDiff& p) {
     params_.push_back(p);
-    velocity_.push_back(momentum_ != 0.f ? std::make_shared<HipArray>(p.device(), p.shape()) : nullptr);
+    std::vector<Shared<HipArray>> st;
+    for (int i = 0; i < nstate_; ++i) st.push_back(std::make_shared<HipArray>(p.device(), p.shape()));
+    state_.push_back(std::move(st));
+    steps_.push_back(0);
 }
-void SGD::step() {
-    for (size_t i = 0; i < params_.size(); ++i) {
-        const VarDiff& p = params_[i];
-        HipArray& g = p.grad->borrow();
-        check(nk_sgd_step(p.device()->raw(), p.var.data->ptr(), g.ptr(), velocity_[i] ? velocity_[i]->ptr() : nullptr,
-                          g.len(), lr_, momentum_, dampening_, nesterov_ ? 1 : 0, first_ ? 1 : 0, penalty_.l1, penalty_.l2));
-    }
-    first_ = false;
+void Optimizer::step() {
+    for (size_t i = 0; i < params_.size(); ++i) optimize(params_[i], state_[i], ++steps_[i]);
 }
-void SGD::zero_grad() const {
+void Optimizer::zero_grad() const {
     for (const VarDiff& p : params_) p.zero_grad();
+}
+
+SGD::SGD(float lr, Penalty penalty, float momentum, float dampening, bool nesterov)
+    : Optimizer(lr, penalty, momentum > 1.1920929e-7f ? 1 : 0), momentum_(momentum), dampening_(dampening), nesterov_(nesterov) {}
+void SGD::optimize(const VarDiff& p, std::vector<Shared<HipArray>>& st, int) {
+    HipArray& g = p.grad->borrow();
+    check(nk_sgd_step(p.device()->raw(), p.var.data->ptr(), g.ptr(), st.empty() ? nullptr : st[0]->ptr(), g.len(), lr_,
+                      momentum_, dampening_, nesterov_ ? 1 : 0, penalty_.l1, penalty_.l2));
+}
+
+Adam::Adam(float lr, float beta1, float beta2, float eps, Penalty penalty, bool amsgrad)
+    : Optimizer(lr, penalty, amsgrad ? 3 : 2), beta1_(beta1), beta2_(beta2), eps_(eps), amsgrad_(amsgrad) {}
+void Adam::optimize(const VarDiff& p, std::vector<Shared<HipArray>>& st, int step) {
+    HipArray& g = p.grad->borrow();
+    check(nk_adam_step(p.device()->raw(), p.var.data->ptr(), g.ptr(), st[0]->ptr(), st[1]->ptr(),
+                       amsgrad_ ? st[2]->ptr() : nullptr, g.len(), lr_, beta1_, beta2_, eps_, step, penalty_.l1, penalty_.l2));
+}
+
+Adagrad::Adagrad(float lr, float lr_decay, float eps, Penalty penalty)
+    : Optimizer(lr, penalty, 1), lr_decay_(lr_decay), eps_(eps) {}
+void Adagrad::optimize(const VarDiff& p, std::vector<Shared<HipArray>>& st, int step) {
+    HipArray& g = p.grad->borrow();
+    check(nk_adagrad_step(p.device()->raw(), p.var.data->ptr(), g.ptr(), st[0]->ptr(), g.len(), lr_, lr_decay_, eps_, step,
+                          penalty_.l1, penalty_.l2));
+}
+
+RMSProp::RMSProp(float lr, float alpha, float eps, float momentum, bool centered, Penalty penalty)
+    : Optimizer(lr, penalty, 3), alpha_(alpha), eps_(eps), momentum_(momentum), centered_(centered) {}
+void RMSProp::optimize(const VarDiff& p, std::vector<Shared<HipArray>>& st, int) {
+    HipArray& g = p.grad->borrow();
+    const bool mom = momentum_ > 1.1920929e-7f;
+    check(nk_rmsprop_step(p.device()->raw(), p.var.data->ptr(), g.ptr(), st[0]->ptr(), centered_ ? st[1]->ptr() : nullptr,
+                          mom ? st[2]->ptr() : nullptr, g.len(), lr_, alpha_, eps_, momentum_, penalty_.l1, penalty_.l2));
 }
 
 }  // namespace optim

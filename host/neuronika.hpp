@@ -368,9 +368,11 @@ struct Penalty {  // penalty.rs:2-79
     float l1 = 0.f, l2 = 0.f;
 };
 
-class SGD {
+// `Optimizer<T>` (optimizer.rs:33-95): register / step / zero_grad / get_lr / set_lr.  State
+// buffers (momentum, moments) live on the device, zero-initialised like the reference's.
+class Optimizer {
    public:
-    SGD(float lr, Penalty penalty = {}, float momentum = 0.f, float dampening = 0.f, bool nesterov = false);
+    virtual ~Optimizer() = default;
     void register_param(const VarDiff& p);  // `register`
     void step();
     void zero_grad() const;
@@ -378,13 +380,56 @@ class SGD {
     void set_lr(float lr) { lr_ = lr; }
     const std::vector<VarDiff>& params() const { return params_; }
 
-   private:
-    float lr_, momentum_, dampening_;
-    bool nesterov_;
+   protected:
+    Optimizer(float lr, Penalty penalty, int nstate) : lr_(lr), penalty_(penalty), nstate_(nstate) {}
+    virtual void optimize(const VarDiff& p, std::vector<Shared<HipArray>>& state, int step) = 0;
+    float lr_;
     Penalty penalty_;
+
+   private:
+    int nstate_;
     std::vector<VarDiff> params_;
-    std::vector<Shared<HipArray>> velocity_;
-    bool first_ = true;
+    std::vector<std::vector<Shared<HipArray>>> state_;
+    std::vector<int> steps_;
+};
+
+class SGD : public Optimizer {  // sgd/mod.rs
+   public:
+    SGD(float lr, Penalty penalty = {}, float momentum = 0.f, float dampening = 0.f, bool nesterov = false);
+
+   private:
+    void optimize(const VarDiff& p, std::vector<Shared<HipArray>>& state, int step) override;
+    float momentum_, dampening_;
+    bool nesterov_;
+};
+
+class Adam : public Optimizer {  // adam/mod.rs ; amsgrad/mod.rs when amsgrad = true
+   public:
+    Adam(float lr, float beta1 = 0.9f, float beta2 = 0.999f, float eps = 1e-8f, Penalty penalty = {}, bool amsgrad = false);
+
+   private:
+    void optimize(const VarDiff& p, std::vector<Shared<HipArray>>& state, int step) override;
+    float beta1_, beta2_, eps_;
+    bool amsgrad_;
+};
+
+class Adagrad : public Optimizer {  // adagrad/mod.rs
+   public:
+    Adagrad(float lr, float lr_decay = 0.f, float eps = 1e-10f, Penalty penalty = {});
+
+   private:
+    void optimize(const VarDiff& p, std::vector<Shared<HipArray>>& state, int step) override;
+    float lr_decay_, eps_;
+};
+
+class RMSProp : public Optimizer {  // rmsprop/mod.rs
+   public:
+    RMSProp(float lr, float alpha = 0.99f, float eps = 1e-8f, float momentum = 0.f, bool centered = false, Penalty penalty = {});
+
+   private:
+    void optimize(const VarDiff& p, std::vector<Shared<HipArray>>& state, int step) override;
+    float alpha_, eps_, momentum_;
+    bool centered_;
 };
 
 }  // namespace optim

@@ -161,17 +161,35 @@ PYBIND11_MODULE(_tape, m) {
         .def("forward", &nn::MultiheadAttention::forward);
 
     py::module_ optim = m.def_submodule("optim");
-    py::class_<optim::SGD>(optim, "SGD")
+    py::class_<optim::Optimizer>(optim, "Optimizer")
+        .def("register", &optim::Optimizer::register_param)
+        .def("step", &optim::Optimizer::step)
+        .def("zero_grad", &optim::Optimizer::zero_grad)
+        .def("get_lr", &optim::Optimizer::get_lr)
+        .def("set_lr", &optim::Optimizer::set_lr);
+    py::class_<optim::SGD, optim::Optimizer>(optim, "SGD")
         .def(py::init([](float lr, float l1, float l2, float momentum, float dampening, bool nesterov) {
-                 return optim::SGD(lr, optim::Penalty{l1, l2}, momentum, dampening, nesterov);
+                 return new optim::SGD(lr, optim::Penalty{l1, l2}, momentum, dampening, nesterov);
              }),
              py::arg("lr"), py::arg("l1") = 0.f, py::arg("l2") = 0.f, py::arg("momentum") = 0.f, py::arg("dampening") = 0.f,
-             py::arg("nesterov") = false)
-        .def("register", &optim::SGD::register_param)
-        .def("step", &optim::SGD::step)
-        .def("zero_grad", &optim::SGD::zero_grad)
-        .def("get_lr", &optim::SGD::get_lr)
-        .def("set_lr", &optim::SGD::set_lr);
+             py::arg("nesterov") = false);
+    py::class_<optim::Adam, optim::Optimizer>(optim, "Adam")
+        .def(py::init([](float lr, float beta1, float beta2, float eps, float l1, float l2, bool amsgrad) {
+                 return new optim::Adam(lr, beta1, beta2, eps, optim::Penalty{l1, l2}, amsgrad);
+             }),
+             py::arg("lr"), py::arg("beta1") = 0.9f, py::arg("beta2") = 0.999f, py::arg("eps") = 1e-8f, py::arg("l1") = 0.f,
+             py::arg("l2") = 0.f, py::arg("amsgrad") = false);
+    py::class_<optim::Adagrad, optim::Optimizer>(optim, "Adagrad")
+        .def(py::init([](float lr, float lr_decay, float eps, float l1, float l2) {
+                 return new optim::Adagrad(lr, lr_decay, eps, optim::Penalty{l1, l2});
+             }),
+             py::arg("lr"), py::arg("lr_decay") = 0.f, py::arg("eps") = 1e-10f, py::arg("l1") = 0.f, py::arg("l2") = 0.f);
+    py::class_<optim::RMSProp, optim::Optimizer>(optim, "RMSProp")
+        .def(py::init([](float lr, float alpha, float eps, float momentum, bool centered, float l1, float l2) {
+                 return new optim::RMSProp(lr, alpha, eps, momentum, centered, optim::Penalty{l1, l2});
+             }),
+             py::arg("lr"), py::arg("alpha") = 0.99f, py::arg("eps") = 1e-8f, py::arg("momentum") = 0.f,
+             py::arg("centered") = false, py::arg("l1") = 0.f, py::arg("l2") = 0.f);
 
     py::module_ dpm = m.def_submodule("dp");
     py::class_<dp::Communicator, std::shared_ptr<dp::Communicator>>(dpm, "Communicator")

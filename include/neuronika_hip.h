@@ -264,11 +264,29 @@ int nk_merge_heads_fwd(nk_device* dev, const float* x, float* y, int B, int S, i
 int nk_merge_heads_bwd(nk_device* dev, float* dx, const float* g, int B, int S, int H, int dh);
 
 /* ------------------------------------------------------------------ optimizer (next row)  */
-/* SGDParam::optimize  neuronika-optim/src/sgd/mod.rs:186-236 with Penalty
- * (penalty.rs:63-79): grad += l1*sign(w) + 2*l2*w; then the plain / momentum / Nesterov
- * update.  velocity == NULL selects plain SGD.  first_step != 0: velocity = grad. */
+/* Every optimizer first adds the penalty to the gradient IN PLACE, as the reference does
+ * (`grad += penalize(w)`; Penalty penalty.rs:63-79: L1 -> l1*signum(w) with Rust's signum
+ * (+-0 -> +-1), L2 -> 2*l2*w, ElasticNet -> both; l1 = l2 = 0: no penalty), then updates w.
+ * Optimizer state buffers are owned by the host and start zeroed.
+ *
+ * SGDParam::optimize  neuronika-optim/src/sgd/mod.rs:186-236: velocity == NULL (momentum <=
+ * f32::EPSILON): w -= grad*lr.  Otherwise buffer = buffer*momentum + grad*(1-dampening);
+ * nesterov: w -= (grad + buffer*momentum)*lr, else w -= buffer*lr. */
 int nk_sgd_step(nk_device* dev, float* w, float* grad, float* velocity, size_t n, float lr,
-                float momentum, float dampening, int nesterov, int first_step, float l1, float l2);
+                float momentum, float dampening, int nesterov, float l1, float l2);
+/* AdamParam::optimize adam/mod.rs:131-169 ; AMSGradParam::optimize amsgrad/mod.rs:163-205 when
+ * max_exp_avg_sq != NULL.  `step` is the 1-based step count (bias corrections 1 - beta^step). */
+int nk_adam_step(nk_device* dev, float* w, float* grad, float* exp_avg, float* exp_avg_sq,
+                 float* max_exp_avg_sq, size_t n, float lr, float beta1, float beta2, float eps, int step,
+                 float l1, float l2);
+/* AdagradParam::optimize adagrad/mod.rs:113-140: clr = lr / (1 + (step-1)*lr_decay). */
+int nk_adagrad_step(nk_device* dev, float* w, float* grad, float* grad_sq, size_t n, float lr,
+                    float lr_decay, float eps, int step, float l1, float l2);
+/* RMSPropParam::optimize rmsprop/mod.rs:193-296: grad_avg != NULL selects the centered variant,
+ * buffer != NULL the momentum variant (all four combinations). */
+int nk_rmsprop_step(nk_device* dev, float* w, float* grad, float* square_avg, float* grad_avg,
+                    float* buffer, size_t n, float lr, float alpha, float eps, float momentum, float l1,
+                    float l2);
 
 /* ------------------------------------------------------------------ data parallel ------ */
 /* Net-new (the reference has no communication backend).  One nk_comm per process/GPU; the

@@ -111,7 +111,10 @@ _SIGS = {
     "nk_split_heads_bwd": [VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int],
     "nk_merge_heads_fwd": [VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int],
     "nk_merge_heads_bwd": [VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int],
-    "nk_sgd_step": [VP, VP, VP, VP, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_float, C.c_float],
+    "nk_sgd_step": [VP, VP, VP, VP, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_int, C.c_float, C.c_float],
+    "nk_adam_step": [VP, VP, VP, VP, VP, VP, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_float, C.c_float],
+    "nk_adagrad_step": [VP, VP, VP, VP, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_int, C.c_float, C.c_float],
+    "nk_rmsprop_step": [VP, VP, VP, VP, VP, VP, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float],
     "nk_comm_unique_id": [C.c_char_p],
     "nk_comm_init_rank": [VP, C.c_int, C.c_int, C.c_char_p, C.POINTER(VP)],
     "nk_comm_destroy": [VP],
@@ -474,10 +477,28 @@ def merge_heads_bwd(dev, dx, g, B, S, H, dh):
     check(lib.nk_merge_heads_bwd(dev.h, dx.p, g.p, B, S, H, dh))
 
 
-def sgd_step(dev, w, grad, velocity=None, lr=0.01, momentum=0.0, dampening=0.0, nesterov=False, first_step=False,
-             l1=0.0, l2=0.0):
-    check(lib.nk_sgd_step(dev.h, w.p, grad.p, velocity.p if velocity is not None else None, w.size, lr, momentum,
-                          dampening, int(nesterov), int(first_step), l1, l2))
+def _p(a):
+    return a.p if a is not None else None
+
+
+def sgd_step(dev, w, grad, velocity=None, lr=0.01, momentum=0.0, dampening=0.0, nesterov=False, l1=0.0, l2=0.0):
+    check(lib.nk_sgd_step(dev.h, w.p, grad.p, _p(velocity), w.size, lr, momentum, dampening, int(nesterov), l1, l2))
+
+
+def adam_step(dev, w, grad, exp_avg, exp_avg_sq, max_exp_avg_sq=None, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8,
+              step=1, l1=0.0, l2=0.0):
+    check(lib.nk_adam_step(dev.h, w.p, grad.p, exp_avg.p, exp_avg_sq.p, _p(max_exp_avg_sq), w.size, lr, beta1, beta2,
+                           eps, step, l1, l2))
+
+
+def adagrad_step(dev, w, grad, grad_sq, lr=1e-2, lr_decay=0.0, eps=1e-10, step=1, l1=0.0, l2=0.0):
+    check(lib.nk_adagrad_step(dev.h, w.p, grad.p, grad_sq.p, w.size, lr, lr_decay, eps, step, l1, l2))
+
+
+def rmsprop_step(dev, w, grad, square_avg, grad_avg=None, buffer=None, lr=1e-2, alpha=0.99, eps=1e-8, momentum=0.0,
+                 l1=0.0, l2=0.0):
+    check(lib.nk_rmsprop_step(dev.h, w.p, grad.p, square_avg.p, _p(grad_avg), _p(buffer), w.size, lr, alpha, eps,
+                              momentum, l1, l2))
 
 
 class Comm:

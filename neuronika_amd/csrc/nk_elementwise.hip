@@ -472,23 +472,98 @@ __global__ void relu_bwd_kernel(float* __restrict__ dx, const float* __restrict_
     }
 }
 
-// SGDParam::optimize (sgd/mod.rs:186-236) + Penalty (penalty.rs:63-79), one pass over w/grad[/velocity]
+// ---- optimizers (neuronika-optim): one pass over the parameter, its gradient and the state ------
+// grad += penalize(w)  (penalty.rs:63-79; Rust signum: +-0 -> +-1)
+__device__ __forceinline__ float penalized(float w, float g, float l1, float l2) {
+    if (l1 != 0.f) g += l1 * copysignf(1.f, w);
+    if (l2 != 0.f) g += 2.f * l2 * w;
+    return g;
+}
+
 __global__ void sgd_kernel(float* __restrict__ w, float* __restrict__ grad, float* __restrict__ vel, size_t n,
-                           float lr, float momentum, float dampening, int nesterov, int first, float l1, float l2) {
+                           float lr, float momentum, float dampening, int nesterov, float l1, float l2) {
+    const bool pen = l1 != 0.f || l2 != 0.f;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        float wi = w[i], gi = grad[i];
-        if (l1 != 0.f) gi += l1 * (wi > 0.f ? 1.f : (wi < 0.f ? -1.f : 0.f));
-        if (l2 != 0.f) gi += 2.f * l2 * wi;
-        if (l1 != 0.f || l2 != 0.f) grad[i] = gi;
+        float wi = w[i];
+        const float gi = penalized(wi, grad[i], l1, l2);
+        if (pen) grad[i] = gi;
         if (vel == nullptr) {
-            wi -= lr * gi;
+            wi -= gi * lr;
         } else {
-            const float v = first ? gi : vel[i] * momentum + gi * (1.f - dampening);
+            const float v = vel[i] * momentum + gi * (1.f - dampening);
             vel[i] = v;
-            wi -= nesterov ? lr * (gi + v * momentum) : lr * v;
+            wi -= nesterov ? (gi + v * momentum) * lr : v * lr;
         }
         w[i] = wi;
     }
+}
+
+__global__ void adam_kernel(float* __restrict__ w, float* __restrict__ grad, float* __restrict__ m, float* __restrict__ v,
+                            float* __restrict__ vmax, size_t n, float lr, float beta1, float beta2, float eps,
+                            float bc1, float bc2, float l1, float l2) {
+    const bool pen = l1 != 0.f || l2 != 0.f;
+    const float sbc2 = sqrtf(bc2), step_size = lr / bc1;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float wi = w[i];
+        const float gi = penalized(wi, grad[i], l1, l2);
+        if (pen) grad[i] = gi;
+        const float mi = m[i] * beta1 + gi * (1.f - beta1);
+        const float vi = v[i] * beta2 + gi * gi * (1.f - beta2);
+        m[i] = mi; v[i] = vi;
+        float den = vi;
+        if (vmax != nullptr) { den = fmaxf(vmax[i], vi); vmax[i] = den; }
+        wi -= mi / ((sqrtf(den) / sbc2) + eps) * step_size;
+        w[i] = wi;
+    }
+}
+
+__global__ void adagrad_kernel(float* __restrict__ w, float* __restrict__ grad, float* __restrict__ gsq, size_t n,
+                               float clr, float eps, float l1, float l2) {
+    const bool pen = l1 != 0.f || l2 != 0.f;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float wi = w[i];
+        const float gi = penalized(wi, grad[i], l1, l2);
+        if (pen) grad[i] = gi;
+        const float s = gsq[i] + gi * gi;
+        gsq[i] = s;
+        w[i] = wi - gi / (sqrtf(s) + eps) * clr;
+    }
+}
+
+__global__ void rmsprop_kernel(float* __restrict__ w, float* __restrict__ grad, float* __restrict__ sq,
+                               float* __restrict__ gavg, float* __restrict__ buf, size_t n, float lr, float alpha,
+                               float eps, float momentum, float l1, float l2) {
+    const bool pen = l1 != 0.f || l2 != 0.f;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float wi = w[i];
+        const float gi = penalized(wi, grad[i], l1, l2);
+        if (pen) grad[i] = gi;
+        const float s = sq[i] * alpha + gi * gi * (1.f - alpha);
+        sq[i] = s;
+        float den;
+        if (gavg != nullptr) {  // centered
+            const float a = gavg[i] * alpha + gi * (1.f - alpha);
+            gavg[i] = a;
+            den = sqrtf(s + (-a * a)) + eps;
+        } else {
+            den = sqrtf(s) + eps;
+        }
+        if (buf != nullptr) {
+            const float b = buf[i] * momentum + gi / den;
+            buf[i] = b;
+            wi -= b * lr;
+        } else {
+            wi -= gi / den * lr;
+        }
+        w[i] = wi;
+    }
+}
+
+static float powi_f32(float b, int e) {  // Rust `f32::powi`: repeated squaring in f32
+    float r = 1.f;
+    int k = e < 0 ? -e : e;
+    while (k) { if (k & 1) r *= b; b *= b; k >>= 1; }
+    return e < 0 ? 1.f / r : r;
 }
 
 }  // namespace
@@ -599,12 +674,49 @@ int nk_relu_bwd(nk_device* dev, float* dx, const float* g, const float* x, size_
 }
 
 int nk_sgd_step(nk_device* dev, float* w, float* grad, float* velocity, size_t n, float lr, float momentum,
-                float dampening, int nesterov, int first_step, float l1, float l2) {
+                float dampening, int nesterov, float l1, float l2) {
     NK_USE(dev);
     if (n == 0) return NK_OK;
     NK_CHECK(w && grad, "null pointer in nk_sgd_step");
     hipLaunchKernelGGL(sgd_kernel, dim3(nk_stream_grid(n, 256)), dim3(256), 0, dev->compute, w, grad, velocity, n, lr,
-                       momentum, dampening, nesterov, first_step, l1, l2);
+                       momentum, dampening, nesterov, l1, l2);
+    NK_LAUNCH_CHECK();
+    return NK_OK;
+}
+
+int nk_adam_step(nk_device* dev, float* w, float* grad, float* exp_avg, float* exp_avg_sq, float* max_exp_avg_sq,
+                 size_t n, float lr, float beta1, float beta2, float eps, int step, float l1, float l2) {
+    NK_USE(dev);
+    if (n == 0) return NK_OK;
+    NK_CHECK(w && grad && exp_avg && exp_avg_sq, "null pointer in nk_adam_step");
+    NK_CHECK(step >= 1, "step must be >= 1");
+    const float bc1 = 1.f - powi_f32(beta1, step), bc2 = 1.f - powi_f32(beta2, step);
+    hipLaunchKernelGGL(adam_kernel, dim3(nk_stream_grid(n, 256)), dim3(256), 0, dev->compute, w, grad, exp_avg, exp_avg_sq,
+                       max_exp_avg_sq, n, lr, beta1, beta2, eps, bc1, bc2, l1, l2);
+    NK_LAUNCH_CHECK();
+    return NK_OK;
+}
+
+int nk_adagrad_step(nk_device* dev, float* w, float* grad, float* grad_sq, size_t n, float lr, float lr_decay,
+                    float eps, int step, float l1, float l2) {
+    NK_USE(dev);
+    if (n == 0) return NK_OK;
+    NK_CHECK(w && grad && grad_sq, "null pointer in nk_adagrad_step");
+    NK_CHECK(step >= 1, "step must be >= 1");
+    const float clr = lr / (1.f + (float)(step - 1) * lr_decay);
+    hipLaunchKernelGGL(adagrad_kernel, dim3(nk_stream_grid(n, 256)), dim3(256), 0, dev->compute, w, grad, grad_sq, n, clr,
+                       eps, l1, l2);
+    NK_LAUNCH_CHECK();
+    return NK_OK;
+}
+
+int nk_rmsprop_step(nk_device* dev, float* w, float* grad, float* square_avg, float* grad_avg, float* buffer, size_t n,
+                    float lr, float alpha, float eps, float momentum, float l1, float l2) {
+    NK_USE(dev);
+    if (n == 0) return NK_OK;
+    NK_CHECK(w && grad && square_avg, "null pointer in nk_rmsprop_step");
+    hipLaunchKernelGGL(rmsprop_kernel, dim3(nk_stream_grid(n, 256)), dim3(256), 0, dev->compute, w, grad, square_avg,
+                       grad_avg, buffer, n, lr, alpha, eps, momentum, l1, l2);
     NK_LAUNCH_CHECK();
     return NK_OK;
 }

@@ -486,40 +486,90 @@ def transpose_backward(x_grad, grad):
 
 
 # --------------------------------------------------------------------------------------
-# f-1  optimizer step (first "next" row): SGD + penalties     neuronika-optim/src/sgd/mod.rs
+# f-1  optimizer steps (first "next" row): SGD / Adam / AMSGrad / Adagrad / RMSProp + penalties
 # --------------------------------------------------------------------------------------
 
 
-def penalty_grad(kind, w, l1=0.0, l2=0.0):
-    """`Penalty::penalize` (neuronika-optim/src/penalty.rs:63-79): L1 -> l*sign(w),
-    L2 -> 2*l*w, ElasticNet -> both."""
-    if kind == "none":
-        return np.zeros_like(w)
-    if kind == "l1":
-        return l1 * np.sign(w)
-    if kind == "l2":
-        return 2 * l2 * w
-    return l1 * np.sign(w) + 2 * l2 * w
+def penalty_grad(w, l1=0.0, l2=0.0):
+    """`Penalty::penalize` (neuronika-optim/src/penalty.rs:63-79): L1 -> l1*signum(w) with Rust's
+    `f32::signum` (+0 -> 1, -0 -> -1), L2 -> 2*l2*w, ElasticNet -> both."""
+    dt = w.dtype.type
+    g = np.zeros_like(w)
+    if l1 != 0.0:
+        g = g + dt(l1) * np.copysign(dt(1), w)
+    if l2 != 0.0:
+        g = g + dt(2) * dt(l2) * w
+    return g
 
 
-def sgd_step(w, grad, lr, velocity=None, momentum=0.0, dampening=0.0, nesterov=False,
-             first_step=False, penalty="none", l1=0.0, l2=0.0):
-    """`SGDParam::optimize` plain / momentum / Nesterov (sgd/mod.rs:186-236).  In place:
-    grad += penalty(w); plain: w -= lr*grad.  momentum: buf = grad on the first step else
-    buf = momentum*buf + (1-dampening)*grad; nesterov: w -= lr*(grad + momentum*buf) else
-    w -= lr*buf."""
-    grad += penalty_grad(penalty, w, l1, l2).astype(w.dtype)
+def sgd_step(w, grad, lr, velocity=None, momentum=0.0, dampening=0.0, nesterov=False, l1=0.0, l2=0.0):
+    """`SGDParam::optimize` (sgd/mod.rs:186-236).  In place: grad += penalty(w); plain
+    (`velocity is None`, i.e. momentum <= f32::EPSILON): w -= grad*lr.  Otherwise
+    buffer = buffer*momentum + grad*(1-dampening) (the buffer starts at ZERO; there is no
+    "first step: buffer = grad" special case in the reference); nesterov:
+    w -= (grad + buffer*momentum)*lr, else w -= buffer*lr."""
+    dt = w.dtype.type
+    grad += penalty_grad(w, l1, l2)
     if velocity is None:
-        w -= w.dtype.type(lr) * grad
+        w -= grad * dt(lr)
         return
-    if first_step:
-        velocity[...] = grad
-    else:
-        velocity[...] = velocity * w.dtype.type(momentum) + grad * w.dtype.type(1.0 - dampening)
+    velocity[...] = velocity * dt(momentum) + grad * dt(1.0 - dampening)
     if nesterov:
-        w -= w.dtype.type(lr) * (grad + velocity * w.dtype.type(momentum))
+        w -= (grad + velocity * dt(momentum)) * dt(lr)
     else:
-        w -= w.dtype.type(lr) * velocity
+        w -= velocity * dt(lr)
+
+
+def _powi(b, e, dt):
+    r, b, k = dt(1), dt(b), abs(int(e))
+    while k:
+        if k & 1:
+            r = dt(r * b)
+        b = dt(b * b)
+        k >>= 1
+    return r
+
+
+def adam_step(w, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, max_exp_avg_sq=None, l1=0.0, l2=0.0):
+    """`AdamParam::optimize` (adam/mod.rs:131-169) / `AMSGradParam::optimize`
+    (amsgrad/mod.rs:163-205, when `max_exp_avg_sq` is given).  `step` is 1-based."""
+    dt = w.dtype.type
+    bc1, bc2 = dt(1) - _powi(beta1, step, dt), dt(1) - _powi(beta2, step, dt)
+    grad += penalty_grad(w, l1, l2)
+    exp_avg[...] = exp_avg * dt(beta1) + grad * dt(1.0 - beta1)
+    exp_avg_sq[...] = exp_avg_sq * dt(beta2) + grad * grad * dt(1.0 - beta2)
+    den = exp_avg_sq
+    if max_exp_avg_sq is not None:
+        max_exp_avg_sq[...] = np.maximum(max_exp_avg_sq, exp_avg_sq)
+        den = max_exp_avg_sq
+    w -= exp_avg / ((np.sqrt(den) / np.sqrt(bc2)) + dt(eps)) * (dt(lr) / bc1)
+
+
+def adagrad_step(w, grad, grad_sq, lr, lr_decay, eps, step, l1=0.0, l2=0.0):
+    """`AdagradParam::optimize` (adagrad/mod.rs:113-140)."""
+    dt = w.dtype.type
+    clr = dt(lr) / (dt(1) + dt(step - 1) * dt(lr_decay))
+    grad += penalty_grad(w, l1, l2)
+    grad_sq += grad * grad
+    w -= grad / (np.sqrt(grad_sq) + dt(eps)) * clr
+
+
+def rmsprop_step(w, grad, square_avg, lr, alpha, eps, grad_avg=None, buffer=None, momentum=0.0, l1=0.0, l2=0.0):
+    """`RMSPropParam::optimize` (rmsprop/mod.rs:193-296): `grad_avg` given = centered,
+    `buffer` given = momentum (> f32::EPSILON)."""
+    dt = w.dtype.type
+    grad += penalty_grad(w, l1, l2)
+    square_avg[...] = square_avg * dt(alpha) + grad * grad * dt(1.0 - alpha)
+    if grad_avg is not None:
+        grad_avg[...] = grad_avg * dt(alpha) + grad * dt(1.0 - alpha)
+        den = np.sqrt(square_avg + (-grad_avg * grad_avg)) + dt(eps)
+    else:
+        den = np.sqrt(square_avg) + dt(eps)
+    if buffer is not None:
+        buffer[...] = buffer * dt(momentum) + grad / den
+        w -= buffer * dt(lr)
+    else:
+        w -= grad / den * dt(lr)
 
 
 # --------------------------------------------------------------------------------------

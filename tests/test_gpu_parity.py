@@ -523,18 +523,43 @@ def test_pad_chunk_concat_transpose(dev, golden):
 
 
 # ------------------------------------------------------------------------------ optimizer (next row)
-def test_sgd_step(dev):
+def test_optimizer_steps(dev):
+    """neuronika-optim update rules on the device vs the oracle restatement, several steps each
+    (state carried on the device), with and without penalties."""
     c = capi()
-    w, g = rnd(1, (1000,), -1, 1), rnd(2, (1000,), -1, 1)
-    W, G = dev.array(w), dev.array(g)
-    c.sgd_step(dev, W, G, None, lr=0.1, l2=0.01)
-    ww, gg = w.copy(), g.copy(); O.sgd_step(ww, gg, 0.1, penalty="l2", l2=0.01)
-    close(W.numpy(), ww, 1e-6, 1e-7); close(G.numpy(), gg, 1e-6, 1e-7)
-    V = dev.zeros((1000,)); vv = np.zeros(1000, np.float32)
-    for first in (True, False):
-        c.sgd_step(dev, W, G, V, lr=0.1, momentum=0.9, dampening=0.1, nesterov=True, first_step=first)
-        O.sgd_step(ww, gg, 0.1, vv, 0.9, 0.1, True, first)
-        close(W.numpy(), ww, 1e-6, 1e-7); close(V.numpy(), vv, 1e-6, 1e-7)
+    n = 4097
+    w0, g0 = rnd(1, (n,), -1, 1), rnd(2, (n,), -1, 1)
+    w0[:3] = (0.0, -0.0, 0.5)                                   # Rust signum(+-0) = +-1 under L1
+
+    def run(dev_step, ora_step, nstate, steps=3, tol=2e-6):
+        W, ww = dev.array(w0), w0.copy()
+        ST, st = [dev.zeros((n,)) for _ in range(nstate)], [np.zeros(n, np.float32) for _ in range(nstate)]
+        for k in range(1, steps + 1):
+            gk = (g0 * np.float32(1.0 / k)).astype(np.float32)
+            G, gg = dev.array(gk), gk.copy()
+            dev_step(W, G, ST, k); ora_step(ww, gg, st, k)
+            close(W.numpy(), ww, tol, tol); close(G.numpy(), gg, 1e-6, 1e-7)
+            for a, b in zip(ST, st):
+                close(a.numpy(), b, tol, tol)
+
+    run(lambda W, G, S, k: c.sgd_step(dev, W, G, None, lr=0.1, l1=0.02, l2=0.01),
+        lambda w, g, s, k: O.sgd_step(w, g, 0.1, l1=0.02, l2=0.01), 0)
+    run(lambda W, G, S, k: c.sgd_step(dev, W, G, S[0], lr=0.1, momentum=0.9, dampening=0.1, nesterov=True),
+        lambda w, g, s, k: O.sgd_step(w, g, 0.1, s[0], 0.9, 0.1, True), 1)
+    run(lambda W, G, S, k: c.sgd_step(dev, W, G, S[0], lr=0.1, momentum=0.5),
+        lambda w, g, s, k: O.sgd_step(w, g, 0.1, s[0], 0.5), 1)
+    run(lambda W, G, S, k: c.adam_step(dev, W, G, S[0], S[1], None, 1e-2, 0.9, 0.999, 1e-8, k, l2=0.01),
+        lambda w, g, s, k: O.adam_step(w, g, s[0], s[1], 1e-2, 0.9, 0.999, 1e-8, k, l2=0.01), 2, tol=1e-5)
+    run(lambda W, G, S, k: c.adam_step(dev, W, G, S[0], S[1], S[2], 1e-2, 0.9, 0.999, 1e-8, k),
+        lambda w, g, s, k: O.adam_step(w, g, s[0], s[1], 1e-2, 0.9, 0.999, 1e-8, k, max_exp_avg_sq=s[2]), 3, tol=1e-5)
+    run(lambda W, G, S, k: c.adagrad_step(dev, W, G, S[0], 1e-2, 0.1, 1e-10, k, l1=0.01),
+        lambda w, g, s, k: O.adagrad_step(w, g, s[0], 1e-2, 0.1, 1e-10, k, l1=0.01), 1, tol=1e-5)
+    for centered in (False, True):
+        for mom in (0.0, 0.9):
+            run(lambda W, G, S, k: c.rmsprop_step(dev, W, G, S[0], S[1] if centered else None, S[2] if mom else None,
+                                                  1e-2, 0.99, 1e-8, mom),
+                lambda w, g, s, k: O.rmsprop_step(w, g, s[0], 1e-2, 0.99, 1e-8, s[1] if centered else None,
+                                                  s[2] if mom else None, mom), 3, tol=2e-5)
 
 
 # ------------------------------------------------------------------------------ composed MLP step

@@ -199,6 +199,25 @@ def test_mha_C5_small(nk, tdev):
         close(getattr(mha, n).bias.grad(), grads["b" + n], 1e-3, 1e-4)
 
 
+@pytest.mark.parametrize("make", ["sgd", "sgd_momentum", "adam", "amsgrad", "adagrad", "rmsprop"])
+def test_optimizers_reduce_loss(nk, tdev, make):
+    """neuronika-optim/src/*/test.rs: "loss after 10 steps < initial loss" on a random problem."""
+    opt = {"sgd": lambda: nk.optim.SGD(0.05), "sgd_momentum": lambda: nk.optim.SGD(0.02, momentum=0.9, nesterov=True),
+           "adam": lambda: nk.optim.Adam(0.05), "amsgrad": lambda: nk.optim.Adam(0.05, amsgrad=True),
+           "adagrad": lambda: nk.optim.Adagrad(0.2), "rmsprop": lambda: nk.optim.RMSProp(0.02, momentum=0.5, centered=True)}[make]()
+    lin = nk.nn.Linear(tdev, 3, 3, 7)
+    opt.register(lin.weight); opt.register(lin.bias)
+    X, T = nk.rand(tdev, [16, 3], 1), nk.rand(tdev, [16, 3], 2)
+    loss = lin.forward(X).mse(T, nk.Reduction.Mean)
+    loss.forward()
+    first = loss.item()
+    for _ in range(10):
+        loss.forward(); loss.no_grad(); loss.with_grad(); loss.backward(1.0)
+        opt.step(); opt.zero_grad()
+    loss.forward()
+    assert loss.item() < first
+
+
 def test_mha_fused_equals_unfused_with_dropout(nk, tdev):
     """The one-node attention probabilities give the same result as the three reference nodes."""
     B, S, d, H = 2, 64, 128, 4
