@@ -378,6 +378,37 @@ struct AttnProbsBwd : Backward {
     void targets(std::vector<const Gradient*>& out) const override { out.push_back(dx.get()); }
 };
 
+// Pointwise unary nodes: node/{negation,exp,logn,sqrt,sigmoid,tanh,softplus,leaky_relu,power}
+struct PointwiseFwd : Forward {
+    int op, iparam;
+    Shared<HipArray> x, y;
+    void forward() const override { check(nk_unary_fwd(D(x), op, x->ptr(), y->ptr(), x->len(), iparam)); }
+};
+struct PointwiseBwd : Backward {
+    int op, iparam;
+    Shared<Gradient> dx, g;
+    Shared<HipArray> ref;  // the buffer the reference node keeps: operand data or node data
+    void backward() const override {
+        HipArray& d = dx->borrow();
+        check(nk_unary_bwd(d.device()->raw(), op, d.ptr(), g->borrow().ptr(), ref ? ref->ptr() : nullptr, d.len(), iparam));
+    }
+    void targets(std::vector<const Gradient*>& out) const override { out.push_back(dx.get()); }
+};
+// Unsqueeze: node/unsqueeze/mod.rs:35-40 (copy into the reshaped buffer), :70-78 (dx += g)
+struct UnsqueezeFwd : Forward {
+    Shared<HipArray> x, y;
+    void forward() const override { check(nk_copy(D(x), y->ptr(), x->ptr(), x->len())); }
+};
+struct UnsqueezeBwd : Backward {
+    Shared<Gradient> dx, g;
+    void backward() const override {
+        HipArray& d = dx->borrow();
+        const int n = (int)d.len();
+        check(nk_unbroadcast_add(d.device()->raw(), d.ptr(), &n, 1, g->borrow().ptr(), &n, 1));
+    }
+    void targets(std::vector<const Gradient*>& out) const override { out.push_back(dx.get()); }
+};
+
 struct ChunkFwd : Forward {
     Shared<HipArray> x, y;
     int chunk_no;
@@ -586,6 +617,39 @@ float Var::item() const {
 Var Var::sum() const { return unary_var(Unary::Sum, 0, *this, {}); }
 Var Var::mean() const { return unary_var(Unary::Mean, 0, *this, {}); }
 Var Var::relu() const { return unary_var(Unary::Relu, 0, *this, shape()); }
+static Var pointwise_var(int op, int iparam, const Var& x) {
+    auto n = std::make_shared<PointwiseFwd>();
+    n->op = op; n->iparam = iparam; n->x = x.data; n->y = zeros_like(x.data, x.shape());
+    auto y = n->y;
+    return Var::node(y, n, x.history);
+}
+static VarDiff pointwise_diff(int op, int iparam, const VarDiff& x) {
+    Var v = pointwise_var(op, iparam, x.var);
+    auto g = std::make_shared<Gradient>(v.device(), v.shape());
+    auto bw = std::make_shared<PointwiseBwd>();
+    bw->op = op; bw->iparam = iparam; bw->dx = x.grad; bw->g = g;
+    const bool keeps_output = op == NK_EXP || op == NK_SQRT || op == NK_SIGMOID || op == NK_TANH;
+    if (op != NK_NEG) bw->ref = keeps_output ? v.data : x.var.data;
+    return VarDiff::node(std::move(v), g, entry(bw, g), x.history);
+}
+Var Var::neg() const { return pointwise_var(NK_NEG, 0, *this); }
+Var Var::pow(int e) const { return pointwise_var(NK_POW, e, *this); }
+Var Var::sqrt() const { return pointwise_var(NK_SQRT, 0, *this); }
+Var Var::leaky_relu() const { return pointwise_var(NK_LEAKY_RELU, 0, *this); }
+Var Var::softplus() const { return pointwise_var(NK_SOFTPLUS, 0, *this); }
+Var Var::sigmoid() const { return pointwise_var(NK_SIGMOID, 0, *this); }
+Var Var::tanh() const { return pointwise_var(NK_TANH, 0, *this); }
+Var Var::ln() const { return pointwise_var(NK_LN, 0, *this); }
+Var Var::exp() const { return pointwise_var(NK_EXP, 0, *this); }
+Var Var::unsqueeze(int axis) const {
+    if (axis < 0 || axis > (int)shape().size()) panic("unsqueeze: axis out of bounds");
+    Shape s = shape();
+    s.insert(s.begin() + axis, 1);
+    auto n = std::make_shared<UnsqueezeFwd>();
+    n->x = data; n->y = zeros_like(data, s);
+    auto y = n->y;
+    return Var::node(y, n, history);
+}
 Var Var::softmax(int axis) const { check_axis(shape(), axis); return unary_var(Unary::Softmax, axis, *this, shape()); }
 Var Var::log_softmax(int axis) const { check_axis(shape(), axis); return unary_var(Unary::LogSoftmax, axis, *this, shape()); }
 Var Var::t() const { return unary_var(Unary::Transpose, 0, *this, Shape(shape().rbegin(), shape().rend())); }
@@ -759,6 +823,22 @@ void VarDiff::with_grad() const {
 VarDiff VarDiff::sum() const { return unary_diff(Unary::Sum, 0, *this, {}); }
 VarDiff VarDiff::mean() const { return unary_diff(Unary::Mean, 0, *this, {}); }
 VarDiff VarDiff::relu() const { return unary_diff(Unary::Relu, 0, *this, shape()); }
+VarDiff VarDiff::neg() const { return pointwise_diff(NK_NEG, 0, *this); }
+VarDiff VarDiff::pow(int e) const { return pointwise_diff(NK_POW, e, *this); }
+VarDiff VarDiff::sqrt() const { return pointwise_diff(NK_SQRT, 0, *this); }
+VarDiff VarDiff::leaky_relu() const { return pointwise_diff(NK_LEAKY_RELU, 0, *this); }
+VarDiff VarDiff::softplus() const { return pointwise_diff(NK_SOFTPLUS, 0, *this); }
+VarDiff VarDiff::sigmoid() const { return pointwise_diff(NK_SIGMOID, 0, *this); }
+VarDiff VarDiff::tanh() const { return pointwise_diff(NK_TANH, 0, *this); }
+VarDiff VarDiff::ln() const { return pointwise_diff(NK_LN, 0, *this); }
+VarDiff VarDiff::exp() const { return pointwise_diff(NK_EXP, 0, *this); }
+VarDiff VarDiff::unsqueeze(int axis) const {
+    Var v = var.unsqueeze(axis);
+    auto g = std::make_shared<Gradient>(v.device(), v.shape());
+    auto bw = std::make_shared<UnsqueezeBwd>();
+    bw->dx = grad; bw->g = g;
+    return VarDiff::node(std::move(v), g, entry(bw, g), history);
+}
 VarDiff VarDiff::softmax(int axis) const { check_axis(shape(), axis); return unary_diff(Unary::Softmax, axis, *this, shape()); }
 VarDiff VarDiff::log_softmax(int axis) const { check_axis(shape(), axis); return unary_diff(Unary::LogSoftmax, axis, *this, shape()); }
 VarDiff VarDiff::t() const { return unary_diff(Unary::Transpose, 0, *this, Shape(shape().rbegin(), shape().rend())); }

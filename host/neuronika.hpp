@@ -210,6 +210,17 @@ class Var {
     Var sum() const;                                  // var.rs:201
     Var mean() const;                                 // var.rs:209
     Var relu() const;                                 // var.rs:243
+    // pointwise nodes (var.rs:222-302) + negation (`-x`) and unsqueeze (var.rs:425)
+    Var neg() const;
+    Var pow(int exp) const;
+    Var sqrt() const;
+    Var leaky_relu() const;
+    Var softplus() const;
+    Var sigmoid() const;
+    Var tanh() const;
+    Var ln() const;
+    Var exp() const;
+    Var unsqueeze(int axis) const;
     Var softmax(int axis) const;                      // var.rs:318
     Var log_softmax(int axis) const;                  // var.rs:338
     Var t() const;                                    // var.rs:347
@@ -263,6 +274,16 @@ class VarDiff {
     VarDiff sum() const;
     VarDiff mean() const;
     VarDiff relu() const;
+    VarDiff neg() const;
+    VarDiff pow(int exp) const;
+    VarDiff sqrt() const;
+    VarDiff leaky_relu() const;
+    VarDiff softplus() const;
+    VarDiff sigmoid() const;
+    VarDiff tanh() const;
+    VarDiff ln() const;
+    VarDiff exp() const;
+    VarDiff unsqueeze(int axis) const;
     VarDiff softmax(int axis) const;
     VarDiff log_softmax(int axis) const;
     VarDiff t() const;

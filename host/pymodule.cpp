@@ -57,6 +57,9 @@ PYBIND11_MODULE(_tape, m) {
         })
         .def("history_len", [](const Var& v) { return v.history.len(); })
         .def("sum", &Var::sum).def("mean", &Var::mean).def("relu", &Var::relu)
+        .def("__neg__", &Var::neg).def("pow", &Var::pow).def("sqrt", &Var::sqrt).def("leaky_relu", &Var::leaky_relu)
+        .def("softplus", &Var::softplus).def("sigmoid", &Var::sigmoid).def("tanh", &Var::tanh).def("ln", &Var::ln)
+        .def("exp", &Var::exp).def("unsqueeze", &Var::unsqueeze)
         .def("softmax", &Var::softmax).def("log_softmax", &Var::log_softmax).def("t", &Var::t)
         .def("dropout", [](const Var& v, double p, const Status& s) { return v.dropout(p, s.flag); }).def("chunks", &Var::chunks).def("cat", &Var::cat)
         .def("mse", &Var::mse).def("pad", &Var::pad, py::arg("padding"), py::arg("value") = 0.f)
@@ -100,6 +103,9 @@ PYBIND11_MODULE(_tape, m) {
         .def("history_len", [](const VarDiff& v) { return v.history.len(); })
         .def("forward_history_len", [](const VarDiff& v) { return v.var.history.len(); })
         .def("sum", &VarDiff::sum).def("mean", &VarDiff::mean).def("relu", &VarDiff::relu)
+        .def("__neg__", &VarDiff::neg).def("pow", &VarDiff::pow).def("sqrt", &VarDiff::sqrt).def("leaky_relu", &VarDiff::leaky_relu)
+        .def("softplus", &VarDiff::softplus).def("sigmoid", &VarDiff::sigmoid).def("tanh", &VarDiff::tanh).def("ln", &VarDiff::ln)
+        .def("exp", &VarDiff::exp).def("unsqueeze", &VarDiff::unsqueeze)
         .def("softmax", &VarDiff::softmax).def("log_softmax", &VarDiff::log_softmax).def("t", &VarDiff::t)
         .def("dropout", [](const VarDiff& v, double p, const Status& s) { return v.dropout(p, s.flag); }).def("chunks", &VarDiff::chunks).def("cat", &VarDiff::cat)
         .def("mse", &VarDiff::mse).def("pad", &VarDiff::pad, py::arg("padding"), py::arg("value") = 0.f)

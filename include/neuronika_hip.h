@@ -185,6 +185,24 @@ int nk_unbroadcast_add(nk_device* dev, float* dst, const int* dst_shape, int dst
 int nk_relu_fwd(nk_device* dev, const float* x, float* y, size_t n);
 int nk_relu_bwd(nk_device* dev, float* dx, const float* g, const float* x, size_t n);
 
+/* Pointwise unary nodes ("next" row f-2): forward y = f(x) overwrites; backward dx += f'(.)*g with
+ * `ref` = the buffer the reference node keeps (its INPUT for ln, softplus, leaky_relu, pow; its
+ * OUTPUT for exp, sqrt, sigmoid, tanh; unused for neg).  node/<op>/mod.rs:35 and :73-86.
+ *   NEG   y = -x                       dx -= g                       negation
+ *   EXP   y = exp(x)                   dx += g*y                     exp
+ *   LN    y = ln(x)                    dx += g/x                     logn
+ *   SQRT  y = sqrt(x)                  dx += g/(y*2)                 sqrt
+ *   SIGMOID y = 1/(1+exp(-x))          dx += g*y*(1-y)               sigmoid
+ *   TANH  y = tanh(x)                  dx += g*(1-y^2)               tanh
+ *   SOFTPLUS y = ln(1+exp(x))          dx += g/(1+exp(-x))           softplus
+ *   LEAKY_RELU y = x>0 ? x : 0.01x     dx += (x>0)*g + (x<=0)*0.01   leaky_relu (sic: the reference
+ *                                       adds 0.01, not 0.01*g — leaky_relu/mod.rs:77-80; replicated)
+ *   POW   y = x^e (integer e = iparam) dx += g * x^(e-1) * e         power */
+enum nk_unary_op { NK_NEG = 0, NK_EXP = 1, NK_LN = 2, NK_SQRT = 3, NK_SIGMOID = 4, NK_TANH = 5,
+                   NK_SOFTPLUS = 6, NK_LEAKY_RELU = 7, NK_POW = 8 };
+int nk_unary_fwd(nk_device* dev, int op, const float* x, float* y, size_t n, int iparam);
+int nk_unary_bwd(nk_device* dev, int op, float* dx, const float* g, const float* ref, size_t n, int iparam);
+
 /* ------------------------------------------------------------------ reductions --------- */
 /* Sum::forward node/sum/mod.rs:28-35 ; SumBackward :60-67 (dx += g, g a device scalar) */
 int nk_sum_fwd(nk_device* dev, const float* x, size_t n, float* out);

@@ -85,6 +85,8 @@ _SIGS = {
     "nk_binary_bwd_left": [VP, C.c_int, VP, c_intp, C.c_int, VP, c_intp, C.c_int, VP, c_intp, C.c_int],
     "nk_binary_bwd_right": [VP, C.c_int, VP, c_intp, C.c_int, VP, c_intp, C.c_int, VP, c_intp, C.c_int, VP],
     "nk_unbroadcast_add": [VP, VP, c_intp, C.c_int, VP, c_intp, C.c_int],
+    "nk_unary_fwd": [VP, C.c_int, VP, VP, C.c_size_t, C.c_int],
+    "nk_unary_bwd": [VP, C.c_int, VP, VP, VP, C.c_size_t, C.c_int],
     "nk_relu_fwd": [VP, VP, VP, C.c_size_t],
     "nk_relu_bwd": [VP, VP, VP, VP, C.c_size_t],
     "nk_sum_fwd": [VP, VP, C.c_size_t, VP],
@@ -361,6 +363,17 @@ def binary_bwd_right(dev, op, d_right, g, l=None, r=None):
 
 def unbroadcast_add(dev, dst, src):
     check(lib.nk_unbroadcast_add(dev.h, dst.p, dst.shape_c(), dst.ndim, src.p, src.shape_c(), src.ndim))
+
+
+UNARY = {"neg": 0, "exp": 1, "ln": 2, "sqrt": 3, "sigmoid": 4, "tanh": 5, "softplus": 6, "leaky_relu": 7, "pow": 8}
+
+
+def unary_fwd(dev, op, x, y, iparam=0):
+    check(lib.nk_unary_fwd(dev.h, UNARY[op], x.p, y.p, x.size, iparam))
+
+
+def unary_bwd(dev, op, dx, g, ref=None, iparam=0):
+    check(lib.nk_unary_bwd(dev.h, UNARY[op], dx.p, g.p, ref.p if ref is not None else None, dx.size, iparam))
 
 
 def relu_fwd(dev, x, y):

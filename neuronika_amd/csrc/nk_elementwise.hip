@@ -472,6 +472,71 @@ __global__ void relu_bwd_kernel(float* __restrict__ dx, const float* __restrict_
     }
 }
 
+// ---- pointwise unary nodes (node/{negation,exp,logn,sqrt,sigmoid,tanh,softplus,leaky_relu,power}) --
+__device__ __forceinline__ float powi_dev(float b, int e) {  // Rust `f32::powi`
+    float r = 1.f;
+    int k = e < 0 ? -e : e;
+    while (k) { if (k & 1) r *= b; b *= b; k >>= 1; }
+    return e < 0 ? 1.f / r : r;
+}
+template <int OP>
+__device__ __forceinline__ float unary_f(float x, int e) {
+    switch (OP) {
+        case NK_NEG: return -x;
+        case NK_EXP: return expf(x);
+        case NK_LN: return logf(x);
+        case NK_SQRT: return sqrtf(x);
+        case NK_SIGMOID: return 1.f / (1.f + expf(-x));
+        case NK_TANH: return tanhf(x);
+        case NK_SOFTPLUS: return logf(1.f + expf(x));
+        case NK_LEAKY_RELU: return (x > 0.f ? 1.f : 0.f) * x + (x <= 0.f ? 1.f : 0.f) * (0.01f * x);
+        default: return powi_dev(x, e);
+    }
+}
+// local gradient term added to dx; r = the buffer the reference node keeps (input or output)
+template <int OP>
+__device__ __forceinline__ float unary_df(float g, float r, int e) {
+    switch (OP) {
+        case NK_NEG: return -g;
+        case NK_EXP: return g * r;
+        case NK_LN: return g / r;
+        case NK_SQRT: return g / (r * 2.f);
+        case NK_SIGMOID: return g * r * (1.f - r);
+        case NK_TANH: return g * (1.f - r * r);
+        case NK_SOFTPLUS: return g / (1.f + expf(-r));
+        case NK_LEAKY_RELU: return (r > 0.f ? 1.f : 0.f) * g + (r <= 0.f ? 1.f : 0.f) * 0.01f;
+        default: return g * powi_dev(r, e - 1) * (float)e;
+    }
+}
+template <int OP>
+__global__ void unary_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n, int e) {
+    const size_t n4 = n / 4;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 v = reinterpret_cast<const float4*>(x)[i];
+        v.x = unary_f<OP>(v.x, e); v.y = unary_f<OP>(v.y, e); v.z = unary_f<OP>(v.z, e); v.w = unary_f<OP>(v.w, e);
+        reinterpret_cast<float4*>(y)[i] = v;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) y[n4 * 4 + threadIdx.x] = unary_f<OP>(x[n4 * 4 + threadIdx.x], e);
+}
+template <int OP>
+__global__ void unary_bwd_kernel(float* __restrict__ dx, const float* __restrict__ g, const float* __restrict__ r,
+                                 size_t n, int e) {
+    const size_t n4 = n / 4;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 d = reinterpret_cast<float4*>(dx)[i];
+        const float4 gv = reinterpret_cast<const float4*>(g)[i];
+        float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (OP != NK_NEG) rv = reinterpret_cast<const float4*>(r)[i];
+        d.x += unary_df<OP>(gv.x, rv.x, e); d.y += unary_df<OP>(gv.y, rv.y, e);
+        d.z += unary_df<OP>(gv.z, rv.z, e); d.w += unary_df<OP>(gv.w, rv.w, e);
+        reinterpret_cast<float4*>(dx)[i] = d;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const size_t i = n4 * 4 + threadIdx.x;
+        dx[i] += unary_df<OP>(g[i], OP != NK_NEG ? r[i] : 0.f, e);
+    }
+}
+
 // ---- optimizers (neuronika-optim): one pass over the parameter, its gradient and the state ------
 // grad += penalize(w)  (penalty.rs:63-79; Rust signum: +-0 -> +-1)
 __device__ __forceinline__ float penalized(float w, float g, float l1, float l2) {
@@ -649,6 +714,33 @@ int nk_binary_bwd_right(nk_device* dev, int op, float* d_right, const int* r_sha
 int nk_unbroadcast_add(nk_device* dev, float* dst, const int* dst_shape, int dst_nd, const float* src,
                        const int* src_shape, int src_nd) {
     return bwd_dispatch<0>(dev, dst, dst_shape, dst_nd, src, src_shape, src_nd, nullptr, nullptr, 0, nullptr, nullptr, 0);
+}
+
+int nk_unary_fwd(nk_device* dev, int op, const float* x, float* y, size_t n, int iparam) {
+    NK_USE(dev);
+    NK_CHECK(op >= NK_NEG && op <= NK_POW, "unknown unary op %d", op);
+    if (n == 0) return NK_OK;
+    NK_CHECK(x && y && al16(x) && al16(y), "nk_unary_fwd: null or unaligned pointer");
+    const dim3 grid(nk_stream_grid(n / 4 + 1, 256)), block(256);
+#define NK_U(OP) case OP: hipLaunchKernelGGL((unary_fwd_kernel<OP>), grid, block, 0, dev->compute, x, y, n, iparam); break;
+    switch (op) { NK_U(NK_NEG) NK_U(NK_EXP) NK_U(NK_LN) NK_U(NK_SQRT) NK_U(NK_SIGMOID) NK_U(NK_TANH) NK_U(NK_SOFTPLUS) NK_U(NK_LEAKY_RELU) NK_U(NK_POW) }
+#undef NK_U
+    NK_LAUNCH_CHECK();
+    return NK_OK;
+}
+
+int nk_unary_bwd(nk_device* dev, int op, float* dx, const float* g, const float* ref, size_t n, int iparam) {
+    NK_USE(dev);
+    NK_CHECK(op >= NK_NEG && op <= NK_POW, "unknown unary op %d", op);
+    if (n == 0) return NK_OK;
+    NK_CHECK(dx && g && al16(dx) && al16(g), "nk_unary_bwd: null or unaligned pointer");
+    NK_CHECK(op == NK_NEG || (ref && al16(ref)), "nk_unary_bwd: the node's kept buffer is required");
+    const dim3 grid(nk_stream_grid(n / 4 + 1, 256)), block(256);
+#define NK_U(OP) case OP: hipLaunchKernelGGL((unary_bwd_kernel<OP>), grid, block, 0, dev->compute, dx, g, ref, n, iparam); break;
+    switch (op) { NK_U(NK_NEG) NK_U(NK_EXP) NK_U(NK_LN) NK_U(NK_SQRT) NK_U(NK_SIGMOID) NK_U(NK_TANH) NK_U(NK_SOFTPLUS) NK_U(NK_LEAKY_RELU) NK_U(NK_POW) }
+#undef NK_U
+    NK_LAUNCH_CHECK();
+    return NK_OK;
 }
 
 int nk_relu_fwd(nk_device* dev, const float* x, float* y, size_t n) {

@@ -405,6 +405,52 @@ def relu_backward(x_grad, grad, x):
 
 
 # --------------------------------------------------------------------------------------
+# f-2  pointwise unary nodes   node/{negation,exp,logn,sqrt,sigmoid,tanh,softplus,leaky_relu,power}
+# --------------------------------------------------------------------------------------
+
+
+def _powi_arr(x, e):
+    r, b, k = np.ones_like(x), x.copy(), abs(int(e))
+    while k:
+        if k & 1:
+            r = r * b
+        b = b * b
+        k >>= 1
+    return (1 / r) if e < 0 else r
+
+
+UNARY_KEEPS_OUTPUT = {"exp", "sqrt", "sigmoid", "tanh"}   # the others keep the operand (input)
+
+
+def unary_forward(op, x, out, exp=0):
+    """node/<op>/mod.rs:35 (power: :44, leaky_relu: :36-38)."""
+    dt = x.dtype.type
+    out[...] = {
+        "neg": lambda: -x, "exp": lambda: np.exp(x), "ln": lambda: np.log(x), "sqrt": lambda: np.sqrt(x),
+        "sigmoid": lambda: dt(1) / (dt(1) + np.exp(-x)), "tanh": lambda: np.tanh(x),
+        "softplus": lambda: np.log(dt(1) + np.exp(x)),
+        "leaky_relu": lambda: (x > 0).astype(x.dtype) * x + (x <= 0).astype(x.dtype) * (dt(0.01) * x),
+        "pow": lambda: _powi_arr(x, exp),
+    }[op]()
+
+
+def unary_backward(op, x_grad, grad, ref, exp=0):
+    """node/<op>/mod.rs:73-86; `ref` = the buffer the node keeps (see UNARY_KEEPS_OUTPUT).
+    leaky_relu replicates the reference (adds 0.01, not 0.01*g, where x <= 0: leaky_relu/mod.rs:77-80)."""
+    dt = grad.dtype.type
+    if op == "neg":
+        x_grad -= grad
+        return
+    x_grad += {
+        "exp": lambda: grad * ref, "ln": lambda: grad / ref, "sqrt": lambda: grad / (ref * dt(2)),
+        "sigmoid": lambda: grad * ref * (dt(1) - ref), "tanh": lambda: grad * (dt(1) - ref * ref),
+        "softplus": lambda: grad / (dt(1) + np.exp(-ref)),
+        "leaky_relu": lambda: (ref > 0).astype(grad.dtype) * grad + (ref <= 0).astype(grad.dtype) * dt(0.01),
+        "pow": lambda: grad * _powi_arr(ref, exp - 1) * dt(exp),
+    }[op]()
+
+
+# --------------------------------------------------------------------------------------
 # a-10  glue: SquaredError, Pad(Constant/Zero), Chunk, MultiConcatenate, Transpose
 # --------------------------------------------------------------------------------------
 

@@ -249,6 +249,19 @@ def other_cases():
                                           "literals": [v for _, v in ls], "scalars": scalars(body),
                                           "tol": 4.88e-4}
 
+    # ---- pointwise unary nodes ("next" row): forward = (input, expected), backward = (.., input,
+    # grad, grad, once, twice, ..) in the old-API files; exp/logn are enabled new-API tests
+    for rel_dir in ("negation", "sqrt", "sigmoid", "tanh", "softplus", "leaky_relu", "power"):
+        rel = f"{rel_dir}/test.rs"
+        for fn, mod in (("forward", "forward"), ("backward", "backward"), ("backward_negative_exp", "backward")):
+            try:
+                body, l0 = _fn_body(_read(rel), fn, mod)
+            except KeyError:
+                continue
+            ls = _literals(body, l0)
+            ints_ = [int(v) for v in re.findall(r"(?:Power|PowerBackward)::new\([^;]*?,\s*(-?\d+)\s*\)", body)]
+            c[f"{rel_dir}_{fn}"] = {"cite": cite(rel, l0), "literals": [v for _, v in ls], "exp": ints_[:1], "tol": 4.88e-4}
+
     # ---- broadcast binaries (enabled tests)
     for op in ("addition", "subtraction", "multiplication", "division"):
         rel = f"{op}/test.rs"

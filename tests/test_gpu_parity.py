@@ -522,6 +522,38 @@ def test_pad_chunk_concat_transpose(dev, golden):
     Dh = dev.array(want); c.merge_heads_bwd(dev, Dh, Z, B_, S, H, dh); assert np.array_equal(Dh.numpy(), 2 * want)
 
 
+# ------------------------------------------------------------------------------ pointwise unary (next row f-2)
+UNARY_FIX = {"neg": "negation", "sqrt": "sqrt", "sigmoid": "sigmoid", "tanh": "tanh", "softplus": "softplus",
+             "leaky_relu": "leaky_relu", "pow": "power"}
+
+
+@pytest.mark.parametrize("op", ["neg", "exp", "ln", "sqrt", "sigmoid", "tanh", "softplus", "leaky_relu", "pow"])
+def test_unary_fwd_bwd(dev, golden, op):
+    c = capi()
+    if op in UNARY_FIX:                                   # the reference's own vectors
+        fw = golden["nodes"][f"{UNARY_FIX[op]}_forward"]
+        e = fw["exp"][0] if fw["exp"] else 0
+        X, Y = dev.array(f32(fw["literals"][0], (3, 3))), dev.full((3, 3), 9.0)
+        c.unary_fwd(dev, op, X, Y, e)
+        close(Y.numpy(), f32(fw["literals"][1], (3, 3)), 0, F16_EPSILON)
+    for e in ((3, -3, 2) if op == "pow" else (0,)):       # random, vs the f64 oracle
+        lo, hi = (0.2, 3.0) if op in ("ln", "sqrt", "pow") else (-3.0, 3.0)
+        x, g, d0 = rnd(1, (257, 129), lo, hi), rnd(2, (257, 129), -1, 1), rnd(3, (257, 129))
+        X, G, D, Y = dev.array(x), dev.array(g), dev.array(d0), dev.zeros(x.shape)
+        c.unary_fwd(dev, op, X, Y, e)
+        y64 = np.zeros(x.shape, np.float64); O.unary_forward(op, x.astype(np.float64), y64, e)
+        close(Y.numpy(), y64, rtol=2e-6, atol=1e-7)
+        keeps_out = op in O.UNARY_KEEPS_OUTPUT
+        c.unary_bwd(dev, op, D, G, None if op == "neg" else (Y if keeps_out else X), e)
+        d64 = d0.astype(np.float64)
+        O.unary_backward(op, d64, g.astype(np.float64), (Y.numpy() if keeps_out else x).astype(np.float64), e)
+        close(D.numpy(), d64, rtol=3e-6, atol=1e-6)
+    if op == "leaky_relu":                                # the reference quirk: += 0.01, not 0.01*g
+        X, G, D = dev.array(f32([-1.0, 2.0, -3.0, 0.0])), dev.array(f32([5.0, 5.0, 5.0, 5.0])), dev.zeros((4,))
+        c.unary_bwd(dev, op, D, G, X)
+        assert np.array_equal(D.numpy(), f32([0.01, 5.0, 0.01, 0.01]))
+
+
 # ------------------------------------------------------------------------------ optimizer (next row)
 def test_optimizer_steps(dev):
     """neuronika-optim update rules on the device vs the oracle restatement, several steps each

@@ -199,6 +199,21 @@ def test_mha_C5_small(nk, tdev):
         close(getattr(mha, n).bias.grad(), grads["b" + n], 1e-3, 1e-4)
 
 
+def test_pointwise_nodes_graph(nk, tdev):
+    """Row f-2 through the tape: a chain of the pointwise nodes + unsqueeze against f64 autograd-free math."""
+    x = rnd(1, (6, 5), 0.5, 2.0)
+    X = nk.from_ndarray(tdev, x).requires_grad()
+    y = ((-(X.ln())).exp().sqrt() + X.sigmoid() * X.tanh() + X.softplus() + X.pow(3).leaky_relu()).unsqueeze(1)
+    assert y.shape == [6, 1, 5]
+    s = y.sum(); s.forward(); s.backward(1.0)
+    x64 = x.astype(np.float64)
+    sig = 1 / (1 + np.exp(-x64))
+    f = np.sqrt(np.exp(-np.log(x64))) + sig * np.tanh(x64) + np.log1p(np.exp(x64)) + x64 ** 3
+    close(s.item(), f.sum(), 1e-5)
+    df = -0.5 * x64 ** -1.5 + sig * (1 - sig) * np.tanh(x64) + sig * (1 - np.tanh(x64) ** 2) + sig + 3 * x64 ** 2
+    close(X.grad(), df, 2e-5, 1e-6)
+
+
 @pytest.mark.parametrize("make", ["sgd", "sgd_momentum", "adam", "amsgrad", "adagrad", "rmsprop"])
 def test_optimizers_reduce_loss(nk, tdev, make):
     """neuronika-optim/src/*/test.rs: "loss after 10 steps < initial loss" on a random problem."""

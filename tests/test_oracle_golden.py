@@ -182,6 +182,49 @@ def test_transpose_golden(golden):
     assert np.array_equal(y, f32(lit[1], (3, 3)))
 
 
+# ------------------------------------------------------------------ pointwise unary nodes (row f-2)
+UNARY_FIX = {"neg": "negation", "sqrt": "sqrt", "sigmoid": "sigmoid", "tanh": "tanh", "softplus": "softplus",
+             "leaky_relu": "leaky_relu", "pow": "power"}
+
+
+@pytest.mark.parametrize("op", list(UNARY_FIX))
+def test_unary_golden(golden, op):
+    n = golden["nodes"]
+    fw = n[f"{UNARY_FIX[op]}_forward"]
+    e = fw["exp"][0] if fw["exp"] else 0
+    x = f32(fw["literals"][0], (3, 3)); y = np.zeros_like(x)
+    O.unary_forward(op, x, y, e)
+    close(y, f32(fw["literals"][1], (3, 3)))
+    cases = [n[f"{UNARY_FIX[op]}_backward"]] + ([n["power_backward_negative_exp"]] if op == "pow" else [])
+    for bw in cases:
+        lit = bw["literals"]
+        e = bw["exp"][0] if bw["exp"] else 0
+        if op == "neg":
+            dx, g = f32(lit[0]).copy(), f32(lit[1])
+            O.unary_backward(op, dx, g, None); close(dx, f32(lit[3]))
+            O.unary_backward(op, dx, g, None); close(dx, f32(lit[4]))
+            continue
+        dx, xin, g = f32(lit[0]).copy(), f32(lit[1]), f32(lit[2])
+        ref = xin
+        if op in ("sigmoid", "tanh"):       # their tests run the forward node; sqrt's hands over sqrt(x) itself
+            ref = np.zeros_like(xin); O.unary_forward(op, xin, ref, e)
+        O.unary_backward(op, dx, g, ref, e); close(dx, f32(lit[4]))
+        O.unary_backward(op, dx, g, ref, e); close(dx, f32(lit[5]))
+
+
+def test_exp_ln_golden():
+    """exp/test.rs:22-36,60-74 and logn/test.rs (enabled, new API): linspace(-4,4,9) inputs,
+    expectations computed by ndarray itself (`mapv(f32::exp)`), backward = data / data*2."""
+    x = np.linspace(-4.0, 4.0, 9, dtype=np.float32).reshape(3, 3)
+    y = np.zeros_like(x); O.unary_forward("exp", x, y); close(y, np.exp(x))
+    dx = np.zeros_like(x); g = np.ones_like(x)
+    O.unary_backward("exp", dx, g, y); close(dx, y)
+    O.unary_backward("exp", dx, g, y); close(dx, 2 * y)
+    xp = np.linspace(1.0, 9.0, 9, dtype=np.float32).reshape(3, 3)
+    O.unary_forward("ln", xp, y); close(y, np.log(xp))
+    dx[...] = 0; O.unary_backward("ln", dx, g, xp); close(dx, 1 / xp)
+
+
 # ------------------------------------------------------------------ broadcast binaries
 OPS = {"addition": "add", "subtraction": "sub", "multiplication": "mul", "division": "div"}
 NP = {"add": np.add, "sub": np.subtract, "mul": np.multiply, "div": np.divide}
