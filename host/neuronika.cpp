@@ -221,6 +221,9 @@ struct MatMulFwd : Forward {
         const Shape& as = a->shape();
         const Shape& bs = b->shape();
         if (kind == 0) check(nk_mm_fwd(D(a), a->ptr(), b->ptr(), c->ptr(), as[0], as[1], bs[1]));
+        else if (kind == 4) check(nk_mv_fwd(D(a), a->ptr(), b->ptr(), c->ptr(), as[0], as[1]));
+        else if (kind == 5) check(nk_vm_fwd(D(a), a->ptr(), b->ptr(), c->ptr(), bs[0], bs[1]));
+        else if (kind == 6) check(nk_vv_fwd(D(a), a->ptr(), b->ptr(), a->len(), c->ptr()));
         else if (kind == 1) check(nk_mm_t_fwd(D(a), a->ptr(), b->ptr(), c->ptr(), as[0], as[1], bs[0]));
         else if (kind == 2)  // C[b] (n,o) = A[b] (n,m) . B[b] (m,o)
             check(nk_sgemm_batched(D(a), 0, 0, as[1], bs[2], as[2], 1.f, a->ptr(), as[2], (long long)as[1] * as[2], 0,
@@ -241,7 +244,16 @@ struct MatMulBwd : Backward {
         const Shape& as = a->shape();
         const Shape& bs = b->shape();
         nk_device* dev = D(a);
-        if (kind == 0) {
+        if (kind == 4) {  // matrix_vector_mul/mod.rs:63-69, :92-102
+            if (da) check(nk_mv_bwd_left(dev, da->borrow().ptr(), G.ptr(), b->ptr(), as[0], as[1]));
+            if (db) check(nk_mv_bwd_right(dev, db->borrow().ptr(), a->ptr(), G.ptr(), as[0], as[1]));
+        } else if (kind == 5) {  // vector_matrix_mul/mod.rs:63-73, :95-101
+            if (da) check(nk_vm_bwd_left(dev, da->borrow().ptr(), b->ptr(), G.ptr(), bs[0], bs[1]));
+            if (db) check(nk_vm_bwd_right(dev, db->borrow().ptr(), a->ptr(), G.ptr(), bs[0], bs[1]));
+        } else if (kind == 6) {  // vector_vector_mul/mod.rs:57-63
+            if (da) check(nk_vv_bwd(dev, da->borrow().ptr(), b->ptr(), G.ptr(), a->len()));
+            if (db) check(nk_vv_bwd(dev, db->borrow().ptr(), a->ptr(), G.ptr(), a->len()));
+        } else if (kind == 0) {
             if (da) check(nk_mm_bwd_left(dev, da->borrow().ptr(), G.ptr(), b->ptr(), as[0], as[1], bs[1]));
             if (db) check(nk_mm_bwd_right(dev, db->borrow().ptr(), a->ptr(), G.ptr(), as[0], as[1], bs[1]));
         } else if (kind == 1) {
@@ -304,9 +316,19 @@ struct ConvBwd : Backward {  // ConvolutionBackward{Input,Kernel}  :357-510
 struct PadFwd : Forward {
     Shared<HipArray> x, y;
     std::vector<int> padding;
-    float value;
+    PaddingMode mode;
     void forward() const override {
-        check(nk_pad_const_fwd(D(x), (int)x->shape().size() - 2, x->ptr(), x->shape().data(), y->ptr(), padding.data(), value));
+        const int nd = (int)x->shape().size() - 2;
+        switch (mode.kind) {
+            case PaddingMode::Reflective:
+                check(nk_pad_reflective_fwd(D(x), nd, x->ptr(), x->shape().data(), y->ptr(), padding.data()));
+                break;
+            case PaddingMode::Replicative:
+                check(nk_pad_replicative_fwd(D(x), nd, x->ptr(), x->shape().data(), y->ptr(), padding.data()));
+                break;
+            default:
+                check(nk_pad_const_fwd(D(x), nd, x->ptr(), x->shape().data(), y->ptr(), padding.data(), mode.value));
+        }
     }
 };
 struct PadBwd : Backward {
@@ -431,11 +453,13 @@ struct CatFwd : Forward {  // node/multi_concatenate/mod.rs
     std::vector<Shared<HipArray>> operands;
     Shared<HipArray> out;
     int axis;
+    bool stack = false;  // node/multi_stack/mod.rs:37-47: every operand fills one index of a NEW axis
     void forward() const override {
         int off = 0;
         for (const auto& o : operands) {
-            check(nk_concat_fwd_part(D(out), o->ptr(), out->ptr(), out->shape().data(), (int)out->shape().size(), axis, off, o->shape()[axis]));
-            off += o->shape()[axis];
+            const int len = stack ? 1 : o->shape()[axis];
+            check(nk_concat_fwd_part(D(out), o->ptr(), out->ptr(), out->shape().data(), (int)out->shape().size(), axis, off, len));
+            off += len;
         }
     }
 };
@@ -443,13 +467,15 @@ struct CatBwd : Backward {
     std::vector<Shared<Gradient>> operands;
     Shared<Gradient> g;
     int axis;
+    bool stack = false;  // node/multi_stack/mod.rs:76-86
     void backward() const override {
         const HipArray& G = g->borrow();
         int off = 0;
         for (const auto& o : operands) {
             HipArray& d = o->borrow();
-            check(nk_concat_bwd_part(d.device()->raw(), d.ptr(), G.ptr(), G.shape().data(), (int)G.shape().size(), axis, off, d.shape()[axis]));
-            off += d.shape()[axis];
+            const int len = stack ? 1 : d.shape()[axis];
+            check(nk_concat_bwd_part(d.device()->raw(), d.ptr(), G.ptr(), G.shape().data(), (int)G.shape().size(), axis, off, len));
+            off += len;
         }
     }
     void targets(std::vector<const Gradient*>& out) const override {
@@ -492,12 +518,52 @@ struct MseBwd : Backward {
     void targets(std::vector<const Gradient*>& out) const override { out.push_back(dx.get()); }
 };
 
+// Scalar criteria: node/{absolute_error,bce,bce_with_logits,kldiv,nll}/mod.rs.  kind -1 = NLL.
+struct LossFwd : Forward {
+    int kind;
+    Shared<HipArray> x, t, out;
+    Reduction red;
+    void forward() const override {
+        const Shape& s = x->shape();
+        if (kind < 0) check(nk_nll_fwd(D(x), x->ptr(), t->ptr(), s.data(), (int)s.size(), (int)red, out->ptr()));
+        else check(nk_loss_fwd(D(x), kind, x->ptr(), t->ptr(), s.data(), (int)s.size(), (int)red, out->ptr()));
+    }
+};
+struct LossBwd : Backward {
+    int kind;
+    Shared<HipArray> x, t;
+    Shared<Gradient> dx, g;
+    Reduction red;
+    void backward() const override {
+        HipArray& d = dx->borrow();
+        const Shape& s = d.shape();
+        if (kind < 0) check(nk_nll_bwd(D(x), d.ptr(), g->borrow().ptr(), t->ptr(), s.data(), (int)s.size(), (int)red));
+        else check(nk_loss_bwd(D(x), kind, d.ptr(), g->borrow().ptr(), x->ptr(), t->ptr(), s.data(), (int)s.size(), (int)red));
+    }
+    void targets(std::vector<const Gradient*>& out) const override { out.push_back(dx.get()); }
+};
+
 template <class Op>
 BackwardEntry entry(Shared<Op> op, Shared<Gradient> grad) {
     return BackwardEntry{std::move(op), std::move(grad)};
 }
 
 Shape mm_shape(const Shape& a, const Shape& b, int kind) {  // utils.rs:46-55 `DotDim`
+    if (kind == 4) {
+        if (a.size() != 2 || b.size() != 1) panic("mv: matrix and vector expected");
+        if (a[1] != b[0]) panic("Shapes are incompatible for matrix-vector multiplication.");
+        return Shape{a[0]};
+    }
+    if (kind == 5) {
+        if (a.size() != 1 || b.size() != 2) panic("vm: vector and matrix expected");
+        if (a[0] != b[0]) panic("Shapes are incompatible for vector-matrix multiplication.");
+        return Shape{b[1]};
+    }
+    if (kind == 6) {
+        if (a.size() != 1 || b.size() != 1) panic("vv: vectors expected");
+        if (a[0] != b[0]) panic("Shapes are incompatible for vector-vector multiplication.");
+        return Shape{};
+    }
     if (kind <= 1) {
         if (a.size() != 2 || b.size() != 2) panic("mm: matrices expected");
         const int inner_b = kind == 0 ? b[0] : b[1];
@@ -698,6 +764,68 @@ Var Var::cat(const std::vector<Var>& variables, int axis) const {
     auto y = op->out;
     return Var::node(y, op, std::move(h));
 }
+Var Var::stack(const std::vector<Var>& variables, int axis) const {
+    if (axis < 0 || axis > (int)shape().size()) panic("stack: axis out of bounds");
+    History<ForwardEntry> h = history;
+    auto op = std::make_shared<CatFwd>();
+    op->operands.push_back(data);
+    for (const Var& v : variables) {
+        if (v.shape() != shape()) panic("stack: all the variables must have the same shape");
+        h.merge(v.history);
+        op->operands.push_back(v.data);
+    }
+    Shape s = shape();
+    s.insert(s.begin() + axis, (int)variables.size() + 1);
+    op->axis = axis; op->stack = true;
+    op->out = zeros_like(data, s);
+    auto y = op->out;
+    return Var::node(y, op, std::move(h));
+}
+static Var loss_var(int kind, const Var& x, const Var& target, Reduction reduction) {
+    if (kind < 0) {  // nll: target has the input's shape without the class axis (var.rs:661)
+        Shape want = x.shape();
+        if (want.size() < 2) panic("nll: input of shape (minibatch, C, ...) expected");
+        want.erase(want.begin() + 1);
+        if (target.shape() != want) panic("nll: target must have shape (minibatch, d1, ..., dk)");
+    } else if (target.shape() != x.shape()) {
+        panic("loss: input and target shapes differ");
+    }
+    History<ForwardEntry> h = x.history;
+    h.merge(target.history);
+    auto op = std::make_shared<LossFwd>();
+    op->kind = kind; op->x = x.data; op->t = target.data; op->out = zeros_like(x.data, {}); op->red = reduction;
+    auto y = op->out;
+    return Var::node(y, op, std::move(h));
+}
+static VarDiff loss_diff(int kind, const VarDiff& x, const Var& target, Reduction reduction) {
+    Var out = loss_var(kind, x.var, target, reduction);
+    auto g = std::make_shared<Gradient>(x.device(), Shape{});
+    auto bw = std::make_shared<LossBwd>();
+    bw->kind = kind; bw->x = x.var.data; bw->t = target.data; bw->dx = x.grad; bw->g = g; bw->red = reduction;
+    return VarDiff::node(std::move(out), g, entry(bw, g), x.history);
+}
+Var Var::mae(const Var& t, Reduction r) const { return loss_var(NK_LOSS_MAE, *this, t, r); }
+Var Var::bce(const Var& t, Reduction r) const { return loss_var(NK_LOSS_BCE, *this, t, r); }
+Var Var::bce_with_logits(const Var& t, Reduction r) const { return loss_var(NK_LOSS_BCE_WITH_LOGITS, *this, t, r); }
+Var Var::kldiv(const Var& t, Reduction r) const { return loss_var(NK_LOSS_KLDIV, *this, t, r); }
+Var Var::nll(const Var& t, Reduction r) const { return loss_var(-1, *this, t, r); }
+VarDiff VarDiff::mae(const Var& t, Reduction r) const { return loss_diff(NK_LOSS_MAE, *this, t, r); }
+VarDiff VarDiff::bce(const Var& t, Reduction r) const { return loss_diff(NK_LOSS_BCE, *this, t, r); }
+VarDiff VarDiff::bce_with_logits(const Var& t, Reduction r) const { return loss_diff(NK_LOSS_BCE_WITH_LOGITS, *this, t, r); }
+VarDiff VarDiff::kldiv(const Var& t, Reduction r) const { return loss_diff(NK_LOSS_KLDIV, *this, t, r); }
+VarDiff VarDiff::nll(const Var& t, Reduction r) const { return loss_diff(-1, *this, t, r); }
+Var Var::mv(const Var& rhs) const { return matmul_var(4, *this, rhs); }
+VarDiff Var::mv(const VarDiff& rhs) const { return matmul_diff(4, *this, nullptr, nullptr, rhs.var, rhs.grad, &rhs.history); }
+Var Var::vm(const Var& rhs) const { return matmul_var(5, *this, rhs); }
+VarDiff Var::vm(const VarDiff& rhs) const { return matmul_diff(5, *this, nullptr, nullptr, rhs.var, rhs.grad, &rhs.history); }
+Var Var::vv(const Var& rhs) const { return matmul_var(6, *this, rhs); }
+VarDiff Var::vv(const VarDiff& rhs) const { return matmul_diff(6, *this, nullptr, nullptr, rhs.var, rhs.grad, &rhs.history); }
+VarDiff VarDiff::mv(const Var& rhs) const { return matmul_diff(4, var, grad, &history, rhs, nullptr, nullptr); }
+VarDiff VarDiff::mv(const VarDiff& rhs) const { return matmul_diff(4, var, grad, &history, rhs.var, rhs.grad, &rhs.history); }
+VarDiff VarDiff::vm(const Var& rhs) const { return matmul_diff(5, var, grad, &history, rhs, nullptr, nullptr); }
+VarDiff VarDiff::vm(const VarDiff& rhs) const { return matmul_diff(5, var, grad, &history, rhs.var, rhs.grad, &rhs.history); }
+VarDiff VarDiff::vv(const Var& rhs) const { return matmul_diff(6, var, grad, &history, rhs, nullptr, nullptr); }
+VarDiff VarDiff::vv(const VarDiff& rhs) const { return matmul_diff(6, var, grad, &history, rhs.var, rhs.grad, &rhs.history); }
 Var Var::mse(const Var& target, Reduction reduction) const {
     if (target.shape() != shape()) panic("mse: input and target shapes differ");
     History<ForwardEntry> h = history;
@@ -707,12 +835,13 @@ Var Var::mse(const Var& target, Reduction reduction) const {
     auto y = op->out;
     return Var::node(y, op, std::move(h));
 }
-Var Var::pad(const std::vector<int>& padding, float value) const {
+Var Var::pad(const std::vector<int>& padding, float value) const { return pad(padding, PaddingMode::constant(value)); }
+Var Var::pad(const std::vector<int>& padding, PaddingMode mode) const {
     if (padding.size() + 2 != shape().size()) panic("pad: one padding per spatial dimension expected");
     Shape s = shape();
     for (size_t i = 0; i < padding.size(); ++i) s[2 + i] += 2 * padding[i];
     auto op = std::make_shared<PadFwd>();
-    op->x = data; op->y = zeros_like(data, s); op->padding = padding; op->value = value;
+    op->x = data; op->y = zeros_like(data, s); op->padding = padding; op->mode = mode;
     auto y = op->y;
     return Var::node(y, op, history);
 }
@@ -877,6 +1006,21 @@ VarDiff VarDiff::cat(const std::vector<VarDiff>& vars, int axis) const {
     bw->g = g; bw->axis = axis;
     return VarDiff::node(std::move(out), g, entry(bw, g), std::move(h));
 }
+VarDiff VarDiff::stack(const std::vector<VarDiff>& vars, int axis) const {
+    std::vector<Var> vs;
+    History<BackwardEntry> h = history;
+    auto bw = std::make_shared<CatBwd>();
+    bw->operands.push_back(grad);
+    for (const VarDiff& v : vars) {
+        vs.push_back(v.var);
+        h.merge(v.history);
+        bw->operands.push_back(v.grad);
+    }
+    Var out = var.stack(vs, axis);
+    auto g = std::make_shared<Gradient>(device(), out.shape());
+    bw->g = g; bw->axis = axis; bw->stack = true;
+    return VarDiff::node(std::move(out), g, entry(bw, g), std::move(h));
+}
 VarDiff VarDiff::mse(const Var& target, Reduction reduction) const {
     Var out = var.mse(target, reduction);
     auto g = std::make_shared<Gradient>(device(), Shape{});
@@ -884,8 +1028,9 @@ VarDiff VarDiff::mse(const Var& target, Reduction reduction) const {
     bw->x = var.data; bw->t = target.data; bw->dx = grad; bw->g = g; bw->red = reduction;
     return VarDiff::node(std::move(out), g, entry(bw, g), history);
 }
-VarDiff VarDiff::pad(const std::vector<int>& padding, float value) const {
-    Var out = var.pad(padding, value);
+VarDiff VarDiff::pad(const std::vector<int>& padding, float value) const { return pad(padding, PaddingMode::constant(value)); }
+VarDiff VarDiff::pad(const std::vector<int>& padding, PaddingMode mode) const {
+    Var out = var.pad(padding, mode);
     auto g = std::make_shared<Gradient>(device(), out.shape());
     auto bw = std::make_shared<PadBwd>();
     bw->dx = grad; bw->g = g; bw->padding = padding;
@@ -989,17 +1134,76 @@ Linear::Linear(DevicePtr dev, int in_features, int out_features, uint64_t seed)
 VarDiff Linear::forward(const Var& input) const { return input.mm_t(weight) + bias; }
 VarDiff Linear::forward(const VarDiff& input) const { return input.mm_t(weight) + bias; }
 
-Conv2d::Conv2d(DevicePtr dev, int in_channels, int out_channels, std::vector<int> kernel, std::vector<int> padding_,
-               std::vector<int> stride_, std::vector<int> dilation_, int groups_, uint64_t seed)
-    : weight(uniform_param(dev, {out_channels, in_channels / groups_, kernel[0], kernel[1]},
-                           1.f / std::sqrt((float)(in_channels / groups_ * kernel[0] * kernel[1])), seed)),
-      bias(uniform_param(dev, {out_channels, 1, 1}, 1.f / std::sqrt((float)(in_channels / groups_ * kernel[0] * kernel[1])), seed + 1)),
-      padding(std::move(padding_)), stride(std::move(stride_)), dilation(std::move(dilation_)), groups(groups_) {}
-VarDiff Conv2d::forward(const Var& input) const {
-    return weight.convolution(input.pad(padding, pad_value), stride, dilation, groups) + bias;
+LSTMCell::LSTMCell(DevicePtr dev, int input_size, int hidden_size, uint64_t seed)
+    : weight_ih(uniform_param(dev, {4 * hidden_size, input_size}, 1.f / std::sqrt((float)hidden_size), seed)),
+      weight_hh(uniform_param(dev, {4 * hidden_size, hidden_size}, 1.f / std::sqrt((float)hidden_size), seed + 1)),
+      bias_ih(uniform_param(dev, {4 * hidden_size}, 1.f / std::sqrt((float)hidden_size), seed + 2)),
+      bias_hh(uniform_param(dev, {4 * hidden_size}, 1.f / std::sqrt((float)hidden_size), seed + 3)) {}
+template <class I>
+static std::pair<VarDiff, VarDiff> lstm_step(const LSTMCell& c, const std::pair<VarDiff, VarDiff>& state, const I& input) {
+    const VarDiff& cell_state = state.first;
+    const VarDiff& hidden = state.second;
+    VarDiff gates = hidden.mm_t(c.weight_hh) + c.bias_hh + input.mm_t(c.weight_ih) + c.bias_ih;
+    const Shape gs = gates.shape();
+    auto ch = gates.chunks({gs[0], gs[1] / 4});
+    VarDiff input_gate = ch[0].sigmoid(), forget_gate = ch[1].tanh(), cell_state_gate = ch[2].sigmoid(),
+            output_gate = ch[3].sigmoid();
+    VarDiff new_cell_state = forget_gate * cell_state + (input_gate * cell_state_gate);
+    VarDiff new_hidden = output_gate * new_cell_state.tanh();
+    return {new_cell_state, new_hidden};
 }
-VarDiff Conv2d::forward(const VarDiff& input) const {
-    return weight.convolution(input.pad(padding, pad_value), stride, dilation, groups) + bias;
+std::pair<VarDiff, VarDiff> LSTMCell::forward(const std::pair<VarDiff, VarDiff>& st, const Var& in) const { return lstm_step(*this, st, in); }
+std::pair<VarDiff, VarDiff> LSTMCell::forward(const std::pair<VarDiff, VarDiff>& st, const VarDiff& in) const { return lstm_step(*this, st, in); }
+
+GRUCell::GRUCell(DevicePtr dev, int input_size, int hidden_size, uint64_t seed)
+    : weight_ih(uniform_param(dev, {3 * hidden_size, input_size}, 1.f / std::sqrt((float)hidden_size), seed)),
+      weight_hh(uniform_param(dev, {3 * hidden_size, hidden_size}, 1.f / std::sqrt((float)hidden_size), seed + 1)),
+      bias_ih(uniform_param(dev, {3 * hidden_size}, 1.f / std::sqrt((float)hidden_size), seed + 2)),
+      bias_hh(uniform_param(dev, {3 * hidden_size}, 1.f / std::sqrt((float)hidden_size), seed + 3)) {}
+template <class I>
+static VarDiff gru_step(const GRUCell& c, const VarDiff& hidden, const I& input) {
+    VarDiff igates = input.mm_t(c.weight_ih) + c.bias_ih;
+    VarDiff hgates = hidden.mm_t(c.weight_hh) + c.bias_hh;
+    const Shape gs = hgates.shape();
+    auto ci = igates.chunks({gs[0], gs[1] / 3}), chh = hgates.chunks({gs[0], gs[1] / 3});
+    VarDiff reset_gate = (chh[0] + ci[0]).sigmoid();
+    VarDiff input_gate = (chh[1] + ci[1]).sigmoid();
+    VarDiff new_gate = (ci[2] + (chh[2] * reset_gate)).tanh();
+    return (hidden - new_gate) * input_gate + new_gate;
+}
+VarDiff GRUCell::forward(const VarDiff& h, const Var& in) const { return gru_step(*this, h, in); }
+VarDiff GRUCell::forward(const VarDiff& h, const VarDiff& in) const { return gru_step(*this, h, in); }
+
+static Shape conv_weight_shape(int out_channels, int in_per_group, const std::vector<int>& kernel) {
+    Shape w{out_channels, in_per_group};
+    w.insert(w.end(), kernel.begin(), kernel.end());
+    return w;
+}
+static Shape conv_bias_shape(int out_channels, int nd) {
+    Shape b{out_channels};
+    b.insert(b.end(), nd, 1);
+    return b;
+}
+static float conv_init_bound(int in_per_group, const std::vector<int>& kernel) {
+    int fan = in_per_group;
+    for (int k : kernel) fan *= k;
+    return std::sqrt(1.f / (float)fan);
+}
+ConvNd::ConvNd(int nd, DevicePtr dev, int in_channels, int out_channels, std::vector<int> kernel, std::vector<int> padding_,
+               PaddingMode mode, std::vector<int> stride_, std::vector<int> dilation_, int groups_, uint64_t seed)
+    : weight(uniform_param(dev, conv_weight_shape(out_channels, in_channels / groups_, kernel),
+                           conv_init_bound(in_channels / groups_, kernel), seed)),
+      bias(uniform_param(dev, conv_bias_shape(out_channels, nd), conv_init_bound(in_channels / groups_, kernel), seed + 1)),
+      padding(std::move(padding_)), stride(std::move(stride_)), dilation(std::move(dilation_)), padding_mode(mode),
+      groups(groups_) {
+    if ((int)kernel.size() != nd || (int)padding.size() != nd || (int)stride.size() != nd || (int)dilation.size() != nd)
+        panic("Conv" + std::to_string(nd) + "d: kernel/padding/stride/dilation need " + std::to_string(nd) + " entries");
+}
+VarDiff ConvNd::forward(const Var& input) const {
+    return weight.convolution(input.pad(padding, padding_mode), stride, dilation, groups) + bias;
+}
+VarDiff ConvNd::forward(const VarDiff& input) const {
+    return weight.convolution(input.pad(padding, padding_mode), stride, dilation, groups) + bias;
 }
 
 MultiheadAttention::MultiheadAttention(DevicePtr dev, int d_model_, int heads_, double p, uint64_t seed)

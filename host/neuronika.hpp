@@ -192,6 +192,16 @@ class VarDiff;
 // ---------------------------------------------------------------------------------------------
 // var.rs — non-differentiable variable
 // ---------------------------------------------------------------------------------------------
+// `PaddingMode` implementors (node/pad/{zero,constant,reflective,replicative}/mod.rs)
+struct PaddingMode {
+    enum Kind { Zero, Constant, Reflective, Replicative } kind = Zero;
+    float value = 0.f;
+    static PaddingMode zero() { return {Zero, 0.f}; }
+    static PaddingMode constant(float v) { return {Constant, v}; }
+    static PaddingMode reflective() { return {Reflective, 0.f}; }
+    static PaddingMode replicative() { return {Replicative, 0.f}; }
+};
+
 class Var {
    public:
     Shared<HipArray> data;
@@ -227,8 +237,21 @@ class Var {
     Var dropout(double p, Shared<bool> status) const; // var.rs:375
     std::vector<Var> chunks(const Shape& chunk_size) const;             // var.rs:401
     Var cat(const std::vector<Var>& variables, int axis) const;         // var.rs:564
+    Var stack(const std::vector<Var>& variables, int axis) const;       // var.rs:614 (MultiStack)
     Var mse(const Var& target, Reduction reduction) const;              // var.rs:454
+    Var mae(const Var& target, Reduction reduction) const;              // var.rs:433
+    Var bce(const Var& target, Reduction reduction) const;              // var.rs:484
+    Var bce_with_logits(const Var& target, Reduction reduction) const;  // var.rs:513
+    Var kldiv(const Var& target, Reduction reduction) const;            // var.rs:542
+    Var nll(const Var& target, Reduction reduction) const;              // var.rs:671
+    Var mv(const Var& rhs) const;                                        // var.rs:1098 (matrix . vector)
+    VarDiff mv(const VarDiff& rhs) const;
+    Var vm(const Var& rhs) const;                                        // var.rs:1129 (vector . matrix)
+    VarDiff vm(const VarDiff& rhs) const;
+    Var vv(const Var& rhs) const;                                        // var.rs:1160 (dot product)
+    VarDiff vv(const VarDiff& rhs) const;
     Var pad(const std::vector<int>& padding, float value = 0.f) const;  // var.rs:726 (Zero/Constant)
+    Var pad(const std::vector<int>& padding, PaddingMode mode) const;   // any `PaddingMode` (pad/mod.rs:17-27)
     Var mm(const Var& rhs) const;                                        // var.rs:1034
     VarDiff mm(const VarDiff& rhs) const;
     Var mm_t(const Var& rhs) const;                                      // var.rs:1065
@@ -290,8 +313,21 @@ class VarDiff {
     VarDiff dropout(double p, Shared<bool> status) const;
     std::vector<VarDiff> chunks(const Shape& chunk_size) const;
     VarDiff cat(const std::vector<VarDiff>& vars, int axis) const;
+    VarDiff stack(const std::vector<VarDiff>& vars, int axis) const;
     VarDiff mse(const Var& target, Reduction reduction) const;
+    VarDiff mae(const Var& target, Reduction reduction) const;              // vardiff.rs:474
+    VarDiff bce(const Var& target, Reduction reduction) const;              // vardiff.rs:525
+    VarDiff bce_with_logits(const Var& target, Reduction reduction) const;  // vardiff.rs:554
+    VarDiff kldiv(const Var& target, Reduction reduction) const;            // vardiff.rs:583
+    VarDiff nll(const Var& target, Reduction reduction) const;              // vardiff.rs:725
+    VarDiff mv(const Var& rhs) const;
+    VarDiff mv(const VarDiff& rhs) const;
+    VarDiff vm(const Var& rhs) const;
+    VarDiff vm(const VarDiff& rhs) const;
+    VarDiff vv(const Var& rhs) const;
+    VarDiff vv(const VarDiff& rhs) const;
     VarDiff pad(const std::vector<int>& padding, float value = 0.f) const;
+    VarDiff pad(const std::vector<int>& padding, PaddingMode mode) const;
     VarDiff mm(const Var& rhs) const;
     VarDiff mm(const VarDiff& rhs) const;
     VarDiff mm_t(const Var& rhs) const;
@@ -343,17 +379,55 @@ struct Linear {
     VarDiff forward(const VarDiff& input) const;
 };
 
-// `Conv2d` struct/new neuronika-nn/src/lib.rs:724-788; its forward is `todo!()` in the reference
-// snapshot (:809-814) and is defined here as pad -> convolution -> + bias.
-struct Conv2d {
-    VarDiff weight, bias;  // (Cout, Cin/groups, kh, kw), (Cout, 1, 1)
+// `LSTMCell` neuronika-nn/src/lib.rs:453-541.  Weights (4H,in)/(4H,H), biases (4H), U(-k,k), k = 1/sqrt(H).
+// `forward` keeps the reference's exact composition: state = (cell_state, hidden); gate chunks 0..3 get
+// sigmoid, tanh, sigmoid, sigmoid (:528-533); returns (new_cell_state, new_hidden) (:534-537).
+struct LSTMCell {
+    VarDiff weight_ih, weight_hh, bias_ih, bias_hh;
+    LSTMCell(DevicePtr dev, int input_size, int hidden_size, uint64_t seed);
+    std::pair<VarDiff, VarDiff> forward(const std::pair<VarDiff, VarDiff>& state, const Var& input) const;
+    std::pair<VarDiff, VarDiff> forward(const std::pair<VarDiff, VarDiff>& state, const VarDiff& input) const;
+};
+
+// `GRUCell` neuronika-nn/src/lib.rs:543-625.  Weights (3H,in)/(3H,H), biases (3H); forward :602-624.
+struct GRUCell {
+    VarDiff weight_ih, weight_hh, bias_ih, bias_hh;
+    GRUCell(DevicePtr dev, int input_size, int hidden_size, uint64_t seed);
+    VarDiff forward(const VarDiff& hidden, const Var& input) const;
+    VarDiff forward(const VarDiff& hidden, const VarDiff& input) const;
+};
+
+// `Conv1d` / `Conv2d` / `Conv3d` struct/new neuronika-nn/src/lib.rs:630-722, 724-814, 816-916: weight
+// (Cout, Cin/groups, k...), bias (Cout, 1...), U(-k,k) with k = sqrt(1/(Cin*prod(kernel))).  Their forward
+// is `todo!()` in the reference snapshot (:716-721, :809-814, :908-914) and is defined here as
+// pad(padding, padding_mode) -> convolution(stride, dilation, groups) -> + bias.
+struct ConvNd {
+    VarDiff weight, bias;
     std::vector<int> padding, stride, dilation;
-    float pad_value = 0.f;  // Zero / Constant(v)
+    PaddingMode padding_mode;
     int groups = 1;
-    Conv2d(DevicePtr dev, int in_channels, int out_channels, std::vector<int> kernel, std::vector<int> padding,
-           std::vector<int> stride, std::vector<int> dilation, int groups, uint64_t seed);
+    ConvNd(int nd, DevicePtr dev, int in_channels, int out_channels, std::vector<int> kernel, std::vector<int> padding,
+           PaddingMode mode, std::vector<int> stride, std::vector<int> dilation, int groups, uint64_t seed);
     VarDiff forward(const Var& input) const;
     VarDiff forward(const VarDiff& input) const;
+};
+struct Conv1d : ConvNd {
+    Conv1d(DevicePtr dev, int in_channels, int out_channels, int kernel, int padding, PaddingMode mode, int stride,
+           int dilation, int groups = 1, uint64_t seed = 0)
+        : ConvNd(1, std::move(dev), in_channels, out_channels, {kernel}, {padding}, mode, {stride}, {dilation}, groups, seed) {}
+};
+struct Conv2d : ConvNd {
+    Conv2d(DevicePtr dev, int in_channels, int out_channels, std::vector<int> kernel, std::vector<int> padding,
+           std::vector<int> stride, std::vector<int> dilation, int groups = 1, uint64_t seed = 0,
+           PaddingMode mode = PaddingMode::zero())
+        : ConvNd(2, std::move(dev), in_channels, out_channels, std::move(kernel), std::move(padding), mode, std::move(stride),
+                 std::move(dilation), groups, seed) {}
+};
+struct Conv3d : ConvNd {
+    Conv3d(DevicePtr dev, int in_channels, int out_channels, std::vector<int> kernel, std::vector<int> padding,
+           PaddingMode mode, std::vector<int> stride, std::vector<int> dilation, int groups = 1, uint64_t seed = 0)
+        : ConvNd(3, std::move(dev), in_channels, out_channels, std::move(kernel), std::move(padding), mode, std::move(stride),
+                 std::move(dilation), groups, seed) {}
 };
 
 // `ModelStatus`-style train/eval switch shared with the Dropout nodes (node/dropout/mod.rs:27).

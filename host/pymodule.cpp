@@ -62,7 +62,12 @@ PYBIND11_MODULE(_tape, m) {
         .def("exp", &Var::exp).def("unsqueeze", &Var::unsqueeze)
         .def("softmax", &Var::softmax).def("log_softmax", &Var::log_softmax).def("t", &Var::t)
         .def("dropout", [](const Var& v, double p, const Status& s) { return v.dropout(p, s.flag); }).def("chunks", &Var::chunks).def("cat", &Var::cat)
-        .def("mse", &Var::mse).def("pad", &Var::pad, py::arg("padding"), py::arg("value") = 0.f)
+        .def("mse", &Var::mse).def("mae", &Var::mae).def("bce", &Var::bce).def("bce_with_logits", &Var::bce_with_logits)
+        .def("kldiv", &Var::kldiv).def("nll", &Var::nll).def("stack", &Var::stack)
+        .def("mv", py::overload_cast<const Var&>(&Var::mv, py::const_)).def("mv", py::overload_cast<const VarDiff&>(&Var::mv, py::const_))
+        .def("vm", py::overload_cast<const Var&>(&Var::vm, py::const_)).def("vm", py::overload_cast<const VarDiff&>(&Var::vm, py::const_))
+        .def("vv", py::overload_cast<const Var&>(&Var::vv, py::const_)).def("vv", py::overload_cast<const VarDiff&>(&Var::vv, py::const_)).def("pad", py::overload_cast<const std::vector<int>&, float>(&Var::pad, py::const_), py::arg("padding"), py::arg("value") = 0.f)
+        .def("pad", py::overload_cast<const std::vector<int>&, PaddingMode>(&Var::pad, py::const_))
         .def("mm", py::overload_cast<const Var&>(&Var::mm, py::const_))
         .def("mm", py::overload_cast<const VarDiff&>(&Var::mm, py::const_))
         .def("mm_t", py::overload_cast<const Var&>(&Var::mm_t, py::const_))
@@ -108,7 +113,12 @@ PYBIND11_MODULE(_tape, m) {
         .def("exp", &VarDiff::exp).def("unsqueeze", &VarDiff::unsqueeze)
         .def("softmax", &VarDiff::softmax).def("log_softmax", &VarDiff::log_softmax).def("t", &VarDiff::t)
         .def("dropout", [](const VarDiff& v, double p, const Status& s) { return v.dropout(p, s.flag); }).def("chunks", &VarDiff::chunks).def("cat", &VarDiff::cat)
-        .def("mse", &VarDiff::mse).def("pad", &VarDiff::pad, py::arg("padding"), py::arg("value") = 0.f)
+        .def("mse", &VarDiff::mse).def("mae", &VarDiff::mae).def("bce", &VarDiff::bce).def("bce_with_logits", &VarDiff::bce_with_logits)
+        .def("kldiv", &VarDiff::kldiv).def("nll", &VarDiff::nll).def("stack", &VarDiff::stack)
+        .def("mv", py::overload_cast<const Var&>(&VarDiff::mv, py::const_)).def("mv", py::overload_cast<const VarDiff&>(&VarDiff::mv, py::const_))
+        .def("vm", py::overload_cast<const Var&>(&VarDiff::vm, py::const_)).def("vm", py::overload_cast<const VarDiff&>(&VarDiff::vm, py::const_))
+        .def("vv", py::overload_cast<const Var&>(&VarDiff::vv, py::const_)).def("vv", py::overload_cast<const VarDiff&>(&VarDiff::vv, py::const_)).def("pad", py::overload_cast<const std::vector<int>&, float>(&VarDiff::pad, py::const_), py::arg("padding"), py::arg("value") = 0.f)
+        .def("pad", py::overload_cast<const std::vector<int>&, PaddingMode>(&VarDiff::pad, py::const_))
         .def("mm", py::overload_cast<const Var&>(&VarDiff::mm, py::const_))
         .def("mm", py::overload_cast<const VarDiff&>(&VarDiff::mm, py::const_))
         .def("mm_t", py::overload_cast<const Var&>(&VarDiff::mm_t, py::const_))
@@ -142,14 +152,40 @@ PYBIND11_MODULE(_tape, m) {
         .def_readonly("bias", &nn::Linear::bias)
         .def("forward", py::overload_cast<const Var&>(&nn::Linear::forward, py::const_))
         .def("forward", py::overload_cast<const VarDiff&>(&nn::Linear::forward, py::const_));
-    py::class_<nn::Conv2d>(nn, "Conv2d")
-        .def(py::init<DevicePtr, int, int, std::vector<int>, std::vector<int>, std::vector<int>, std::vector<int>, int, uint64_t>(),
+    using State = std::pair<VarDiff, VarDiff>;
+    py::class_<nn::LSTMCell>(nn, "LSTMCell")
+        .def(py::init<DevicePtr, int, int, uint64_t>(), py::arg("dev"), py::arg("input_size"), py::arg("hidden_size"), py::arg("seed") = 0)
+        .def_readonly("weight_ih", &nn::LSTMCell::weight_ih).def_readonly("weight_hh", &nn::LSTMCell::weight_hh)
+        .def_readonly("bias_ih", &nn::LSTMCell::bias_ih).def_readonly("bias_hh", &nn::LSTMCell::bias_hh)
+        .def("forward", py::overload_cast<const State&, const Var&>(&nn::LSTMCell::forward, py::const_))
+        .def("forward", py::overload_cast<const State&, const VarDiff&>(&nn::LSTMCell::forward, py::const_));
+    py::class_<nn::GRUCell>(nn, "GRUCell")
+        .def(py::init<DevicePtr, int, int, uint64_t>(), py::arg("dev"), py::arg("input_size"), py::arg("hidden_size"), py::arg("seed") = 0)
+        .def_readonly("weight_ih", &nn::GRUCell::weight_ih).def_readonly("weight_hh", &nn::GRUCell::weight_hh)
+        .def_readonly("bias_ih", &nn::GRUCell::bias_ih).def_readonly("bias_hh", &nn::GRUCell::bias_hh)
+        .def("forward", py::overload_cast<const VarDiff&, const Var&>(&nn::GRUCell::forward, py::const_))
+        .def("forward", py::overload_cast<const VarDiff&, const VarDiff&>(&nn::GRUCell::forward, py::const_));
+    py::class_<PaddingMode>(m, "PaddingMode")
+        .def_static("zero", &PaddingMode::zero).def_static("constant", &PaddingMode::constant)
+        .def_static("reflective", &PaddingMode::reflective).def_static("replicative", &PaddingMode::replicative);
+    py::class_<nn::ConvNd>(nn, "ConvNd")
+        .def_readonly("weight", &nn::ConvNd::weight)
+        .def_readonly("bias", &nn::ConvNd::bias)
+        .def("forward", py::overload_cast<const Var&>(&nn::ConvNd::forward, py::const_))
+        .def("forward", py::overload_cast<const VarDiff&>(&nn::ConvNd::forward, py::const_));
+    py::class_<nn::Conv1d, nn::ConvNd>(nn, "Conv1d")
+        .def(py::init<DevicePtr, int, int, int, int, PaddingMode, int, int, int, uint64_t>(), py::arg("dev"), py::arg("in_channels"),
+             py::arg("out_channels"), py::arg("kernel"), py::arg("padding"), py::arg("padding_mode"), py::arg("stride"),
+             py::arg("dilation"), py::arg("groups") = 1, py::arg("seed") = 0);
+    py::class_<nn::Conv2d, nn::ConvNd>(nn, "Conv2d")
+        .def(py::init<DevicePtr, int, int, std::vector<int>, std::vector<int>, std::vector<int>, std::vector<int>, int, uint64_t, PaddingMode>(),
              py::arg("dev"), py::arg("in_channels"), py::arg("out_channels"), py::arg("kernel"), py::arg("padding"),
-             py::arg("stride"), py::arg("dilation"), py::arg("groups") = 1, py::arg("seed") = 0)
-        .def_readonly("weight", &nn::Conv2d::weight)
-        .def_readonly("bias", &nn::Conv2d::bias)
-        .def("forward", py::overload_cast<const Var&>(&nn::Conv2d::forward, py::const_))
-        .def("forward", py::overload_cast<const VarDiff&>(&nn::Conv2d::forward, py::const_));
+             py::arg("stride"), py::arg("dilation"), py::arg("groups") = 1, py::arg("seed") = 0,
+             py::arg("padding_mode") = PaddingMode::zero());
+    py::class_<nn::Conv3d, nn::ConvNd>(nn, "Conv3d")
+        .def(py::init<DevicePtr, int, int, std::vector<int>, std::vector<int>, PaddingMode, std::vector<int>, std::vector<int>, int, uint64_t>(),
+             py::arg("dev"), py::arg("in_channels"), py::arg("out_channels"), py::arg("kernel"), py::arg("padding"),
+             py::arg("padding_mode"), py::arg("stride"), py::arg("dilation"), py::arg("groups") = 1, py::arg("seed") = 0);
     py::class_<nn::Dropout>(nn, "Dropout")
         .def(py::init<double>())
         .def("train", &nn::Dropout::train)

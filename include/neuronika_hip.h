@@ -153,7 +153,15 @@ int nk_conv_bwd_kernel(nk_device* dev, int nd, float* dw, const int* w_shape, co
  * symmetric `padding[i]` on both sides of spatial axis i.  x_shape = [N, C, in...]. */
 int nk_pad_const_fwd(nk_device* dev, int nd, const float* x, const int* x_shape, float* y,
                      const int* padding, float value);
-/* PadBackward::backward  node/pad/mod.rs:157-181   dx += centre(g) */
+/* Pad<Reflective>::forward  pad/reflective/mod.rs:9-136 (border i<pad reads index pad-i, i>=len+pad reads
+ * 2(len-1)-(i-pad); requires padding[i] < in[i]);  Pad<Replicative>::forward  pad/replicative/mod.rs:9-134
+ * (borders repeat the edge element).  Same shapes as nk_pad_const_fwd. */
+int nk_pad_reflective_fwd(nk_device* dev, int nd, const float* x, const int* x_shape, float* y,
+                          const int* padding);
+int nk_pad_replicative_fwd(nk_device* dev, int nd, const float* x, const int* x_shape, float* y,
+                           const int* padding);
+/* PadBackward::backward  node/pad/mod.rs:157-181   dx += centre(g)  (every padding mode: the reference
+ * does not fold the border gradients back for Reflective/Replicative, neither do we) */
 int nk_pad_bwd(nk_device* dev, int nd, float* dx, const int* x_shape, const float* g,
                const int* padding);
 
@@ -215,6 +223,44 @@ int nk_mse_fwd(nk_device* dev, const float* x, const float* target, size_t n, in
                float* out);
 int nk_mse_bwd(nk_device* dev, float* dx, const float* g, const float* x, const float* target,
                size_t n, int reduction);
+
+/* ------------------------------------------------------------------ loss criteria ------- */
+/* Element-pair criteria reducing to a scalar; x and target share `shape`.
+ *   NK_LOSS_MAE             AbsoluteError        node/absolute_error/mod.rs:42-58, :93-123
+ *   NK_LOSS_BCE             BinaryCrossEntropy   node/bce/mod.rs:42-62, :97-127   (ln clamped at -100, bwd denominator >= EPSILON)
+ *   NK_LOSS_BCE_WITH_LOGITS BCEWithLogits        node/bce_with_logits/mod.rs:42-66, :101-131
+ *   NK_LOSS_KLDIV           KLDiv                node/kldiv/mod.rs:42-59, :92-113  (x = log-probabilities; terms with
+ *                           target <= 0 contribute 0 - the masked form the reference's vectors require; Mean divides
+ *                           by shape[0], every other criterion by the element count)
+ * fwd writes out[0]; bwd: dx += d(loss)/dx * g[0]  (g = device scalar). */
+enum nk_loss { NK_LOSS_MAE = 0, NK_LOSS_BCE = 1, NK_LOSS_BCE_WITH_LOGITS = 2, NK_LOSS_KLDIV = 3 };
+int nk_loss_fwd(nk_device* dev, int loss, const float* x, const float* target, const int* shape, int nd,
+                int reduction, float* out);
+int nk_loss_bwd(nk_device* dev, int loss, float* dx, const float* g, const float* x, const float* target,
+                const int* shape, int nd, int reduction);
+/* NegativeLogLikelihood node/nll/mod.rs:43-69, :104-137 on the documented layout (var.rs:645-661):
+ * x (minibatch, C, d1..dk) log-probabilities, target (minibatch, d1..dk) class indices stored as f32 and read
+ * with Rust's saturating `as usize` (NaN / negative -> 0, fraction dropped; index >= C selects nothing).
+ * fwd: out = -sum x[n, target[n,r], r]  (Mean: / shape[0], :64);  bwd: dx[n, target, r] -= g (Mean: / target.len(), :114) */
+int nk_nll_fwd(nk_device* dev, const float* x, const float* target, const int* shape, int nd,
+               int reduction, float* out);
+int nk_nll_bwd(nk_device* dev, float* dx, const float* g, const float* target, const int* shape, int nd,
+               int reduction);
+
+/* ------------------------------------------------------------------ GEMV / dot ---------- */
+/* MatrixVectorMul node/matrix_vector_mul/mod.rs:31-41  y(n) = A(n,m).x(m);  BackwardLeft :63-69  dA += g (x) x;
+ * BackwardRight :92-102  dx += A^T.g */
+int nk_mv_fwd(nk_device* dev, const float* A, const float* x, float* y, int n, int m);
+int nk_mv_bwd_left(nk_device* dev, float* dA, const float* g, const float* x, int n, int m);
+int nk_mv_bwd_right(nk_device* dev, float* dx, const float* A, const float* g, int n, int m);
+/* VectorMatrixMul node/vector_matrix_mul/mod.rs:31-41  y(o) = v(m).B(m,o);  BackwardLeft :63-73  dv += B.g;
+ * BackwardRight :95-101  dB += v (x) g */
+int nk_vm_fwd(nk_device* dev, const float* v, const float* B, float* y, int m, int o);
+int nk_vm_bwd_left(nk_device* dev, float* dv, const float* B, const float* g, int m, int o);
+int nk_vm_bwd_right(nk_device* dev, float* dB, const float* v, const float* g, int m, int o);
+/* VectorVectorMul node/vector_vector_mul/mod.rs:31-34  out = l.r;  backward :57-63  d_operand += other * g[0] */
+int nk_vv_fwd(nk_device* dev, const float* l, const float* r, size_t n, float* out);
+int nk_vv_bwd(nk_device* dev, float* d_operand, const float* other, const float* g, size_t n);
 
 /* ------------------------------------------------------------------ softmax ------------ */
 /* Softmax::forward node/softmax/mod.rs:37-53 ; SoftmaxBackward :84-104

@@ -80,6 +80,8 @@ _SIGS = {
     "nk_conv_bwd_input": [VP, C.c_int, VP, c_intp, VP, VP, c_intp, c_intp, c_intp, C.c_int],
     "nk_conv_bwd_kernel": [VP, C.c_int, VP, c_intp, VP, VP, c_intp, c_intp, c_intp, C.c_int],
     "nk_pad_const_fwd": [VP, C.c_int, VP, c_intp, VP, c_intp, C.c_float],
+    "nk_pad_reflective_fwd": [VP, C.c_int, VP, c_intp, VP, c_intp],
+    "nk_pad_replicative_fwd": [VP, C.c_int, VP, c_intp, VP, c_intp],
     "nk_pad_bwd": [VP, C.c_int, VP, c_intp, VP, c_intp],
     "nk_binary_fwd": [VP, C.c_int, VP, c_intp, C.c_int, VP, c_intp, C.c_int, VP, c_intp, C.c_int],
     "nk_binary_bwd_left": [VP, C.c_int, VP, c_intp, C.c_int, VP, c_intp, C.c_int, VP, c_intp, C.c_int],
@@ -95,6 +97,18 @@ _SIGS = {
     "nk_mean_bwd": [VP, VP, C.c_size_t, VP],
     "nk_mse_fwd": [VP, VP, VP, C.c_size_t, C.c_int, VP],
     "nk_mse_bwd": [VP, VP, VP, VP, VP, C.c_size_t, C.c_int],
+    "nk_loss_fwd": [VP, C.c_int, VP, VP, c_intp, C.c_int, C.c_int, VP],
+    "nk_loss_bwd": [VP, C.c_int, VP, VP, VP, VP, c_intp, C.c_int, C.c_int],
+    "nk_nll_fwd": [VP, VP, VP, c_intp, C.c_int, C.c_int, VP],
+    "nk_nll_bwd": [VP, VP, VP, VP, c_intp, C.c_int, C.c_int],
+    "nk_mv_fwd": [VP, VP, VP, VP, C.c_int, C.c_int],
+    "nk_mv_bwd_left": [VP, VP, VP, VP, C.c_int, C.c_int],
+    "nk_mv_bwd_right": [VP, VP, VP, VP, C.c_int, C.c_int],
+    "nk_vm_fwd": [VP, VP, VP, VP, C.c_int, C.c_int],
+    "nk_vm_bwd_left": [VP, VP, VP, VP, C.c_int, C.c_int],
+    "nk_vm_bwd_right": [VP, VP, VP, VP, C.c_int, C.c_int],
+    "nk_vv_fwd": [VP, VP, VP, C.c_size_t, VP],
+    "nk_vv_bwd": [VP, VP, VP, VP, C.c_size_t],
     "nk_softmax_fwd": [VP, VP, VP, c_intp, C.c_int, C.c_int],
     "nk_softmax_bwd": [VP, VP, VP, VP, c_intp, C.c_int, C.c_int],
     "nk_log_softmax_fwd": [VP, VP, VP, c_intp, C.c_int, C.c_int],
@@ -342,6 +356,11 @@ def pad_const_fwd(dev, x, y, padding, value=0.0):
     check(lib.nk_pad_const_fwd(dev.h, x.ndim - 2, x.p, x.shape_c(), y.p, ints(padding), float(value)))
 
 
+def pad_mode_fwd(dev, x, y, padding, mode):
+    fn = {"reflective": lib.nk_pad_reflective_fwd, "replicative": lib.nk_pad_replicative_fwd}[mode]
+    check(fn(dev.h, x.ndim - 2, x.p, x.shape_c(), y.p, ints(padding)))
+
+
 def pad_bwd(dev, dx, g, padding):
     check(lib.nk_pad_bwd(dev.h, dx.ndim - 2, dx.p, dx.shape_c(), g.p, ints(padding)))
 
@@ -406,6 +425,58 @@ def mse_fwd(dev, x, t, out, reduction="mean"):
 
 def mse_bwd(dev, dx, g, x, t, reduction="mean"):
     check(lib.nk_mse_bwd(dev.h, dx.p, g.p, x.p, t.p, x.size, REDUCTION[reduction]))
+
+
+LOSS = {"mae": 0, "bce": 1, "bce_with_logits": 2, "kldiv": 3}
+
+
+def loss_fwd(dev, loss, x, t, out, reduction="mean"):
+    check(lib.nk_loss_fwd(dev.h, LOSS[loss], x.p, t.p, x.shape_c(), x.ndim, REDUCTION[reduction], out.p))
+
+
+def loss_bwd(dev, loss, dx, g, x, t, reduction="mean"):
+    check(lib.nk_loss_bwd(dev.h, LOSS[loss], dx.p, g.p, x.p if x is not None else None, t.p, dx.shape_c(), dx.ndim,
+                          REDUCTION[reduction]))
+
+
+def nll_fwd(dev, x, t, out, reduction="mean"):
+    check(lib.nk_nll_fwd(dev.h, x.p, t.p, x.shape_c(), x.ndim, REDUCTION[reduction], out.p))
+
+
+def nll_bwd(dev, dx, g, t, reduction="mean"):
+    check(lib.nk_nll_bwd(dev.h, dx.p, g.p, t.p, dx.shape_c(), dx.ndim, REDUCTION[reduction]))
+
+
+def mv_fwd(dev, A, x, y):
+    check(lib.nk_mv_fwd(dev.h, A.p, x.p, y.p, A.shape[0], A.shape[1]))
+
+
+def mv_bwd_left(dev, dA, g, x):
+    check(lib.nk_mv_bwd_left(dev.h, dA.p, g.p, x.p, dA.shape[0], dA.shape[1]))
+
+
+def mv_bwd_right(dev, dx, A, g):
+    check(lib.nk_mv_bwd_right(dev.h, dx.p, A.p, g.p, A.shape[0], A.shape[1]))
+
+
+def vm_fwd(dev, v, B, y):
+    check(lib.nk_vm_fwd(dev.h, v.p, B.p, y.p, B.shape[0], B.shape[1]))
+
+
+def vm_bwd_left(dev, dv, B, g):
+    check(lib.nk_vm_bwd_left(dev.h, dv.p, B.p, g.p, B.shape[0], B.shape[1]))
+
+
+def vm_bwd_right(dev, dB, v, g):
+    check(lib.nk_vm_bwd_right(dev.h, dB.p, v.p, g.p, dB.shape[0], dB.shape[1]))
+
+
+def vv_fwd(dev, l, r, out):
+    check(lib.nk_vv_fwd(dev.h, l.p, r.p, l.size, out.p))
+
+
+def vv_bwd(dev, d_operand, other, g):
+    check(lib.nk_vv_bwd(dev.h, d_operand.p, other.p, g.p, d_operand.size))
 
 
 def softmax_fwd(dev, x, y, axis):

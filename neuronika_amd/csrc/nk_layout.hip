@@ -148,6 +148,9 @@ struct PadDesc {
     int nd;                  // spatial dims
     int in[3], out[3], pad[3];
 };
+// MODE 0: Constant/Zero (pad/constant/mod.rs:14-39), 1: Reflective (pad/reflective/mod.rs:9-136: left
+// border reads index pad-i, right border 2(len-1)-(i-pad)), 2: Replicative (pad/replicative/mod.rs: clamp).
+template <int MODE>
 __global__ void pad_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, PadDesc p, long long planes,
                                long long out_plane, long long in_plane, float value) {
     const long long total = planes * out_plane;
@@ -157,9 +160,15 @@ __global__ void pad_fwd_kernel(const float* __restrict__ x, float* __restrict__ 
         long long rem = i % out_plane, src = 0, mul = 1;
         bool inside = true;
         for (int d = p.nd - 1; d >= 0; --d) {
-            const int c = (int)(rem % p.out[d]) - p.pad[d];
+            int c = (int)(rem % p.out[d]) - p.pad[d];
+            if (MODE == 0) {
+                if (c < 0 || c >= p.in[d]) inside = false;
+            } else if (MODE == 1) {
+                c = c < 0 ? -c : (c >= p.in[d] ? 2 * (p.in[d] - 1) - c : c);
+            } else {
+                c = c < 0 ? 0 : (c >= p.in[d] ? p.in[d] - 1 : c);
+            }
             rem /= p.out[d];
-            if (c < 0 || c >= p.in[d]) inside = false;
             src += c * mul;
             mul *= p.in[d];
         }
@@ -293,6 +302,30 @@ int chunk_origin(const int* x_shape, const int* chunk_shape, int nd, int chunk_n
 
 }  // namespace
 
+template <int MODE>
+static int pad_fwd(nk_device* dev, int nd, const float* x, const int* x_shape, float* y, const int* padding, float value) {
+    NK_USE(dev);
+    NK_CHECK(nd >= 1 && nd <= 3, "pad supports 1-3 spatial dims, got %d", nd);
+    PadDesc p{};
+    p.nd = nd;
+    long long in_plane = 1, out_plane = 1;
+    for (int i = 0; i < nd; ++i) {
+        NK_CHECK(padding[i] >= 0, "negative padding");
+        // the reference indexes out of bounds (panics) past one reflection / on an empty axis
+        NK_CHECK(MODE != 1 || padding[i] == 0 || padding[i] < x_shape[2 + i], "reflective padding %d needs input extent > padding (got %d)", padding[i], x_shape[2 + i]);
+        NK_CHECK(MODE != 2 || padding[i] == 0 || x_shape[2 + i] > 0, "replicative padding of an empty axis");
+        p.in[i] = x_shape[2 + i]; p.pad[i] = padding[i]; p.out[i] = x_shape[2 + i] + 2 * padding[i];
+        in_plane *= p.in[i]; out_plane *= p.out[i];
+    }
+    const long long planes = (long long)x_shape[0] * x_shape[1];
+    if (planes * out_plane == 0) return NK_OK;
+    NK_CHECK(x && y, "null pointer in pad forward");
+    hipLaunchKernelGGL(pad_fwd_kernel<MODE>, dim3(nk_stream_grid((size_t)(planes * out_plane), 256)), dim3(256), 0, dev->compute, x,
+                       y, p, planes, out_plane, in_plane, value);
+    NK_LAUNCH_CHECK();
+    return NK_OK;
+}
+
 extern "C" {
 
 int nk_dropout_fwd(nk_device* dev, const float* x, float* y, float* noise, size_t n, double p, int train,
@@ -337,23 +370,13 @@ int nk_dropout_bwd(nk_device* dev, float* dx, const float* g, const float* noise
 }
 
 int nk_pad_const_fwd(nk_device* dev, int nd, const float* x, const int* x_shape, float* y, const int* padding, float value) {
-    NK_USE(dev);
-    NK_CHECK(nd >= 1 && nd <= 3, "pad supports 1-3 spatial dims, got %d", nd);
-    PadDesc p{};
-    p.nd = nd;
-    long long in_plane = 1, out_plane = 1;
-    for (int i = 0; i < nd; ++i) {
-        NK_CHECK(padding[i] >= 0, "negative padding");
-        p.in[i] = x_shape[2 + i]; p.pad[i] = padding[i]; p.out[i] = x_shape[2 + i] + 2 * padding[i];
-        in_plane *= p.in[i]; out_plane *= p.out[i];
-    }
-    const long long planes = (long long)x_shape[0] * x_shape[1];
-    if (planes * out_plane == 0) return NK_OK;
-    NK_CHECK(x && y, "null pointer in nk_pad_const_fwd");
-    hipLaunchKernelGGL(pad_fwd_kernel, dim3(nk_stream_grid((size_t)(planes * out_plane), 256)), dim3(256), 0, dev->compute, x,
-                       y, p, planes, out_plane, in_plane, value);
-    NK_LAUNCH_CHECK();
-    return NK_OK;
+    return pad_fwd<0>(dev, nd, x, x_shape, y, padding, value);
+}
+int nk_pad_reflective_fwd(nk_device* dev, int nd, const float* x, const int* x_shape, float* y, const int* padding) {
+    return pad_fwd<1>(dev, nd, x, x_shape, y, padding, 0.f);
+}
+int nk_pad_replicative_fwd(nk_device* dev, int nd, const float* x, const int* x_shape, float* y, const int* padding) {
+    return pad_fwd<2>(dev, nd, x, x_shape, y, padding, 0.f);
 }
 
 int nk_pad_bwd(nk_device* dev, int nd, float* dx, const int* x_shape, const float* g, const int* padding) {

@@ -478,6 +478,26 @@ def pad_constant_forward(x, out, padding, value=0.0):
     out[centre] = x
 
 
+def pad_mode_forward(x, out, padding, mode):
+    """`Pad<Reflective|Replicative>::forward` (pad/mod.rs:97-129 per (N*C) sample; index maps of
+    pad/reflective/mod.rs:9-136 and pad/replicative/mod.rs:9-134), restated as one gather per axis:
+    reflective: i<pad -> pad-i, i>=len+pad -> 2(len-1)-(i-pad); replicative: clamp to [0, len-1]."""
+    src = x
+    for ax, pad in enumerate(padding):
+        n = x.shape[2 + ax]
+        c = np.arange(n + 2 * pad) - pad
+        if mode == "reflective":
+            if pad and pad >= n:
+                raise IndexError("reflective padding needs input extent > padding")  # reference: slice index panic
+            idx = np.where(c < 0, -c, np.where(c >= n, 2 * (n - 1) - c, c))
+        elif mode == "replicative":
+            idx = np.clip(c, 0, n - 1)
+        else:
+            raise ValueError(mode)
+        src = np.take(src, idx, axis=2 + ax)
+    out[...] = src
+
+
 def pad_backward(x_grad, grad, padding):
     """`PadBackward::backward` (pad/mod.rs:157-181): dx += centre slice of g."""
     centre = (slice(None), slice(None)) + tuple(slice(p, grad.shape[2 + i] - p) for i, p in enumerate(padding))
@@ -673,6 +693,178 @@ def mlp_step(x, target, params, seed=1.0):
             g = np.zeros_like(pre[i - 1])
             relu_backward(g, da, pre[i - 1])
     return loss, grads
+
+
+# --------------------------------------------------------------------------------------------
+# loss criteria (row f-4).  `out` is a 0-d array; gradients accumulate.
+# --------------------------------------------------------------------------------------------
+def _rust_as_usize(t):
+    """`target as usize` (nll/mod.rs:57): saturating cast - NaN/negatives -> 0, fraction dropped."""
+    t = np.asarray(t, dtype=np.float64)
+    return np.where(np.isnan(t) | (t <= 0), 0, np.trunc(np.minimum(t, 2.0 ** 62))).astype(np.int64)
+
+
+def mae_forward(x, t, reduction="mean"):
+    """`AbsoluteError::forward` absolute_error/mod.rs:42-58."""
+    s = np.abs(x - t).sum(dtype=x.dtype)
+    return s / x.dtype.type(x.size) if reduction == "mean" else s
+
+
+def mae_backward(x_grad, g, x, t, reduction="mean"):
+    """`AbsoluteErrorBackward::backward` :93-123: (diff != 0) * (signum(diff) * g / n)."""
+    diff = x - t
+    v = np.copysign(1, diff).astype(x.dtype) * x.dtype.type(g)
+    if reduction == "mean":
+        v = v / x.dtype.type(x.size)
+    x_grad += (diff != 0).astype(x.dtype) * v
+
+
+def bce_forward(x, t, reduction="mean"):
+    """`BinaryCrossEntropy::forward` bce/mod.rs:42-62: -t*clamp(ln x,-100) + (t-1)*clamp(ln(1-x),-100)."""
+    with np.errstate(divide="ignore", invalid="ignore"):
+        lx = np.maximum(np.log(x), -100, where=~np.isnan(x), out=np.log(x))
+        l1x = np.maximum(np.log(1 - x), -100, where=~np.isnan(x), out=np.log(1 - x))
+    s = (-t * lx + (t - 1) * l1x).sum(dtype=x.dtype)
+    return s / x.dtype.type(x.size) if reduction == "mean" else s
+
+
+def bce_backward(x_grad, g, x, t, reduction="mean"):
+    """`BinaryCrossEntropyBackward::backward` :97-127: (x-t)/max((1-x)x, f32::EPSILON) * g / n."""
+    v = (x - t) / np.maximum((1 - x) * x, x.dtype.type(np.finfo(np.float32).eps)) * x.dtype.type(g)
+    x_grad += v / x.dtype.type(x.size) if reduction == "mean" else v
+
+
+def bce_with_logits_forward(x, t, reduction="mean"):
+    """`BCEWithLogits::forward` bce_with_logits/mod.rs:42-66."""
+    m = np.maximum(-x, 0)
+    s = ((1 - t) * x + m + np.log(np.exp(-m) + np.exp(-x - m))).sum(dtype=x.dtype)
+    return s / x.dtype.type(x.size) if reduction == "mean" else s
+
+
+def bce_with_logits_backward(x_grad, g, x, t, reduction="mean"):
+    """`BCEWithLogitsBackward::backward` :101-131: (sigmoid(x) - t) * g / n."""
+    v = (1 / (1 + np.exp(-x)) - t) * x.dtype.type(g)
+    x_grad += v / x.dtype.type(x.size) if reduction == "mean" else v
+
+
+def kldiv_forward(x, t, reduction="mean"):
+    """`KLDiv::forward` kldiv/mod.rs:42-59 with the mask applied BEFORE the product (the reference's
+    `t*(ln t - x)*(t>0)` is NaN at t = 0, yet kldiv/test.rs:10-21 expects 0.1530 with a 0.0 target);
+    Mean divides by len_of(Axis(0))."""
+    with np.errstate(divide="ignore", invalid="ignore"):
+        term = np.where(t > 0, t * (np.log(np.where(t > 0, t, 1)) - x), 0).astype(x.dtype)
+    s = term.sum(dtype=x.dtype)
+    return s / x.dtype.type(x.shape[0]) if reduction == "mean" else s
+
+
+def kldiv_backward(x_grad, g, t, reduction="mean"):
+    """`KLDivBackward::backward` :92-113: -t * g / len_of(Axis(0))."""
+    v = -t * x_grad.dtype.type(g)
+    x_grad += v / x_grad.dtype.type(t.shape[0]) if reduction == "mean" else v
+
+
+def nll_forward(x, t, reduction="mean"):
+    """`NegativeLogLikelihood::forward` nll/mod.rs:43-69 on the documented layout (var.rs:645-661):
+    x (N, C, d...) log-probabilities, t (N, d...) class indices.  The node as written zips each
+    outer slice of x with the whole target (only shape-consistent when N == C); its vectors
+    (nll/test.rs:11-27: target [2,0,4], x (3,5), mean 1.52222) pin the documented meaning built here.
+    Mean divides by len_of(Axis(0)) (:64)."""
+    cls = _rust_as_usize(t)
+    ok = cls < x.shape[1]
+    picked = np.take_along_axis(x, np.expand_dims(np.where(ok, cls, 0), 1), axis=1)[:, 0]
+    s = -np.where(ok, picked, 0).sum(dtype=x.dtype)
+    return s / x.dtype.type(x.shape[0]) if reduction == "mean" else s
+
+
+def nll_backward(x_grad, g, t, reduction="mean"):
+    """`NegativeLogLikelihoodBackward::backward` :104-137: grad -= g * [class match] (/ target.len() for Mean, :114)."""
+    cls = _rust_as_usize(t)
+    ok = cls < x_grad.shape[1]
+    v = x_grad.dtype.type(g) / x_grad.dtype.type(t.size) if reduction == "mean" else x_grad.dtype.type(g)
+    upd = np.zeros_like(x_grad)
+    np.put_along_axis(upd, np.expand_dims(np.where(ok, cls, 0), 1), np.expand_dims(np.where(ok, v, 0).astype(x_grad.dtype), 1), axis=1)
+    x_grad -= upd
+
+
+# --------------------------------------------------------------------------------------------
+# matrix-vector / vector-matrix / vector-vector products (row f-4)
+# --------------------------------------------------------------------------------------------
+def mv_forward(a, x, out):
+    """`MatrixVectorMul::forward` matrix_vector_mul/mod.rs:31-41."""
+    out[...] = a @ x
+
+
+def mv_backward(a_grad, x_grad, g, a, x):
+    """BackwardLeft :63-69 (dA += g (x) x), BackwardRight :92-102 (dx += A^T g); either may be None."""
+    if a_grad is not None:
+        a_grad += np.outer(g, x)
+    if x_grad is not None:
+        x_grad += a.T @ g
+
+
+def vm_forward(v, b, out):
+    """`VectorMatrixMul::forward` vector_matrix_mul/mod.rs:31-41."""
+    out[...] = v @ b
+
+
+def vm_backward(v_grad, b_grad, g, v, b):
+    """BackwardLeft :63-73 (dv += B g), BackwardRight :95-101 (dB += v (x) g)."""
+    if v_grad is not None:
+        v_grad += b @ g
+    if b_grad is not None:
+        b_grad += np.outer(v, g)
+
+
+def vv_forward(l, r):
+    """`VectorVectorMul::forward` vector_vector_mul/mod.rs:31-34."""
+    return l.dot(r)
+
+
+def vv_backward(op_grad, other, g):
+    """`VectorVectorMulBackwardUnary::backward` :57-63: d_op += other * g."""
+    op_grad += other * op_grad.dtype.type(g)
+
+
+def _sigmoid(x):
+    return 1.0 / (1.0 + np.exp(-x))
+
+
+def lstm_cell_forward(cell_state, hidden, x, w_ih, w_hh, b_ih, b_hh):
+    """`LSTMCell::forward` neuronika-nn/src/lib.rs:512-541, composition kept as written there:
+    gates = h.mm_t(W_hh) + b_hh + x.mm_t(W_ih) + b_ih; chunk k of 4 along axis 1 ->
+    sigmoid, tanh, sigmoid, sigmoid (:528-533); c' = g1*c + g0*g2; h' = g3*tanh(c').  Returns (c', h')."""
+    gates = hidden @ w_hh.T + b_hh + x @ w_ih.T + b_ih
+    hsz = gates.shape[1] // 4
+    g = [gates[:, k * hsz:(k + 1) * hsz] for k in range(4)]
+    input_gate, forget_gate, cell_gate, output_gate = _sigmoid(g[0]), np.tanh(g[1]), _sigmoid(g[2]), _sigmoid(g[3])
+    new_cell = forget_gate * cell_state + input_gate * cell_gate
+    return new_cell, output_gate * np.tanh(new_cell)
+
+
+def gru_cell_forward(hidden, x, w_ih, w_hh, b_ih, b_hh):
+    """`GRUCell::forward` neuronika-nn/src/lib.rs:602-624: r = sigmoid(hg0+ig0); z = sigmoid(hg1+ig1);
+    n = tanh(ig2 + hg2*r); out = (h - n)*z + n."""
+    ig, hg = x @ w_ih.T + b_ih, hidden @ w_hh.T + b_hh
+    hsz = hg.shape[1] // 3
+    ci = [ig[:, k * hsz:(k + 1) * hsz] for k in range(3)]
+    ch = [hg[:, k * hsz:(k + 1) * hsz] for k in range(3)]
+    r, z = _sigmoid(ch[0] + ci[0]), _sigmoid(ch[1] + ci[1])
+    n = np.tanh(ci[2] + ch[2] * r)
+    return (hidden - n) * z + n
+
+
+def numeric_grad(f, x, eps=1e-6):
+    """Central finite differences of a scalar function of an f64 array (test helper for composed modules)."""
+    g = np.zeros_like(x)
+    it = np.nditer(x, flags=["multi_index"])
+    for _ in it:
+        i = it.multi_index
+        old = x[i]
+        x[i] = old + eps; fp = f()
+        x[i] = old - eps; fm = f()
+        x[i] = old
+        g[i] = (fp - fm) / (2 * eps)
+    return g
 
 
 def mha_forward_backward(x, wq, bq, wk, bk, wv, bv, wo, bo, heads, batch, p, noise, g_out):

@@ -300,6 +300,51 @@ def other_cases():
                                      "constructors": from_elems(body),
                                      "padding": _tuple(re.search(r"&\[([0-9, ]+)\]|\(([0-9, ]+)\)\s*\.into_dimension", body).group(0)) if re.search(r"&\[([0-9, ]+)\]|\(([0-9, ]+)\)\s*\.into_dimension", body) else None}
 
+    # ---- pad modes (enabled): pad/reflective/test.rs, pad/replicative/test.rs — base = range(0, n) reshaped,
+    # padded shape from `zeros(..)`, padding from `[..].into_dimension()`, expectation = the array! literal
+    for mode in ("reflective", "replicative"):
+        rel = f"pad/{mode}/test.rs"
+        src = _read(rel)
+        for fn in ("test_1d", "test_2d", "test_3d"):
+            body, l0 = _fn_body(src, fn)
+            ls = _literals(body, l0)
+            n = int(float(re.search(r"range\(0\.?0?,\s*(\d+)\.?0?,", body).group(1)))
+            base_shape = re.search(r"into_shape\(\(([0-9, ]+)\)\)", body)
+            padded_shape = re.search(r"zeros\(\(?([0-9, ]+)\)?\)", body)
+            c[f"pad_{mode}_{fn}"] = {"cite": cite(rel, l0), "arange": n,
+                                     "base_shape": _tuple(base_shape.group(1)) if base_shape else [n],
+                                     "padded_shape": _tuple(padded_shape.group(1)),
+                                     "padding": _tuple(re.search(r"\[([0-9, ]+)\]\s*\.into_dimension", body).group(1)),
+                                     "expected": ls[-1][1]}
+
+    # ---- losses: bce + absolute_error (enabled, forward/backward mods); nll, kldiv, bce_with_logits
+    # (test modules commented out — stale API, numbers valid): literals / arr0 scalars / linspace recipes in
+    # source order
+    def _loss_case(rel, fn, mod):
+        body, l0 = _fn_body(_read(rel), fn, mod)
+        lin = [[float(a), float(b), int(n)] + _tuple(sh) for a, b, n, sh in re.findall(
+            r"linspace\((-?\d+\.?\d*),\s*(-?\d+\.?\d*),\s*(\d+)\)\.into_shape\(\(([0-9, ]+)\)\)", body)]
+        return {"cite": cite(rel, l0), "literals": [v for _, v in _literals(body, l0)], "scalars": scalars(body),
+                "linspace_start_stop_n_shape": lin,
+                "from_elem": [[float(v)] + _tuple(sh) for sh, v in re.findall(r"from_elem\(\(([0-9, ]+)\),\s*(-?\d+\.?\d*)\)", body)],
+                "tol": 4.88e-4}
+    for loss in ("bce", "absolute_error"):
+        for mod in ("forward", "backward"):
+            for fn in ("base_case_mean", "base_case_sum"):
+                c[f"{loss}_{mod}_{fn}"] = _loss_case(f"{loss}/test.rs", fn, mod)
+    for loss in ("nll", "kldiv", "bce_with_logits"):
+        for fn in ("mean", "sum"):
+            c[f"{loss}_{fn}"] = _loss_case(f"{loss}/test.rs", fn, None)
+
+    # ---- matrix-vector / vector-matrix / vector-vector (test modules commented out — stale API, numbers
+    # valid): all numeric literals + arr0 scalars of `forward` / `backward`, in source order
+    for node in ("matrix_vector_mul", "vector_matrix_mul", "vector_vector_mul"):
+        rel = f"{node}/test.rs"
+        for mod in ("forward", "backward"):
+            body, l0 = _fn_body(_read(rel), mod, mod)
+            c[f"{node}_{mod}"] = {"cite": cite(rel, l0), "literals": [v for _, v in _literals(body, l0)],
+                                  "scalars": scalars(body), "tol": 4.88e-4}
+
     # ---- chunk (enabled)
     rel = "chunk/test.rs"
     src = _read(rel)

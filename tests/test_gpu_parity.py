@@ -444,6 +444,36 @@ def test_fused_attention_probs_equals_three_nodes(dev):
 
 
 # ------------------------------------------------------------------------------ layout glue
+@pytest.mark.parametrize("mode", ["reflective", "replicative"])
+def test_pad_modes(dev, golden, mode):
+    """Pad<Reflective|Replicative>: the reference's exact 1/2/3-d vectors, random batched cases vs the oracle,
+    the mode-independent backward (pad/mod.rs:157-181) and the out-of-range reflective case."""
+    c = capi()
+    for fn in ("test_1d", "test_2d", "test_3d"):
+        cs = golden["nodes"][f"pad_{mode}_{fn}"]
+        base = np.arange(cs["arange"], dtype=np.float32).reshape([1, 1] + cs["base_shape"])
+        X, Y = dev.array(base), dev.full([1, 1] + cs["padded_shape"], -7.0)
+        c.pad_mode_fwd(dev, X, Y, cs["padding"], mode)
+        assert np.array_equal(Y.numpy()[0, 0], f32(cs["expected"], cs["padded_shape"])), cs["cite"]
+    for seed, shape, pad in [(1, (3, 5, 17), (4,)), (2, (2, 3, 9, 12), (3, 0)), (3, (2, 2, 4, 5, 6), (1, 2, 3)),
+                             (4, (4, 64, 28, 28), (1, 1))]:
+        x = rnd(seed, shape)
+        oshape = list(shape[:2]) + [n + 2 * p for n, p in zip(shape[2:], pad)]
+        y = np.zeros(oshape, np.float32); O.pad_mode_forward(x, y, pad, mode)
+        X, Y = dev.array(x), dev.zeros(oshape)
+        c.pad_mode_fwd(dev, X, Y, pad, mode)
+        assert np.array_equal(Y.numpy(), y)
+        g = rnd(seed + 10, oshape); d0 = rnd(seed + 20, shape)
+        D, G = dev.array(d0), dev.array(g)
+        c.pad_bwd(dev, D, G, pad)
+        d = d0.copy(); O.pad_backward(d, g, pad)
+        assert np.array_equal(D.numpy(), d)
+    if mode == "reflective":
+        X, Y = dev.array(rnd(5, (1, 1, 3))), dev.zeros((1, 1, 9))
+        with pytest.raises(RuntimeError, match="reflective padding"):
+            c.pad_mode_fwd(dev, X, Y, (3,), mode)
+
+
 def test_pad_chunk_concat_transpose(dev, golden):
     c = capi()
     for mode in ("zero", "constant"):
@@ -552,6 +582,145 @@ def test_unary_fwd_bwd(dev, golden, op):
         X, G, D = dev.array(f32([-1.0, 2.0, -3.0, 0.0])), dev.array(f32([5.0, 5.0, 5.0, 5.0])), dev.zeros((4,))
         c.unary_bwd(dev, op, D, G, X)
         assert np.array_equal(D.numpy(), f32([0.01, 5.0, 0.01, 0.01]))
+
+
+# ------------------------------------------------------------------------------ loss criteria (next row f-4)
+def _lin(spec):
+    a, b, n, *shape = spec
+    return np.linspace(a, b, int(n), dtype=np.float32).reshape(shape)
+
+
+LOSS_ORACLE = {"mae": (O.mae_forward, O.mae_backward), "bce": (O.bce_forward, O.bce_backward),
+               "bce_with_logits": (O.bce_with_logits_forward, O.bce_with_logits_backward)}
+
+
+@pytest.mark.parametrize("red", ["mean", "sum"])
+def test_loss_golden(dev, golden, red):
+    c = capi(); n = golden["nodes"]
+    for name, key in (("bce", "bce"), ("mae", "absolute_error")):
+        cs = n[f"{key}_forward_base_case_{red}"]
+        x, t = (_lin(sp) for sp in cs["linspace_start_stop_n_shape"])
+        X, T, out = dev.array(x), dev.array(t), dev.zeros(())
+        c.loss_fwd(dev, name, X, T, out, red)
+        np.testing.assert_allclose(out.numpy(), cs["scalars"][-1], rtol=2e-6, atol=cs["tol"])
+        cs = n[f"{key}_backward_base_case_{red}"]
+        D, G = dev.zeros((3, 3)), dev.array(f32([cs["scalars"][0]]).reshape(()))
+        c.loss_bwd(dev, name, D, G, X, T, red)
+        want = f32(cs["literals"][0], (3, 3)) if cs["literals"] else np.full((3, 3), cs["from_elem"][0][0], np.float32)
+        np.testing.assert_allclose(D.numpy(), want, rtol=2e-6, atol=cs["tol"])
+    cs = n[f"nll_{red}"]; lit = cs["literals"]
+    lx = np.zeros((3, 5), np.float32); O.log_softmax_forward(f32(lit[1], (3, 5)), lx, 1)
+    X, T, out, G = dev.array(lx), dev.array(f32(lit[0])), dev.zeros(()), dev.array(np.ones((), np.float32))
+    c.nll_fwd(dev, X, T, out, red); close(out.numpy(), cs["scalars"][0], 0, F16_EPSILON)
+    D = dev.zeros((3, 5))
+    c.nll_bwd(dev, D, G, T, red); close(D.numpy(), f32(lit[3], (3, 5)), 0, F16_EPSILON)
+    c.nll_bwd(dev, D, G, T, red); close(D.numpy(), 2 * f32(lit[4], (3, 5)), 0, F16_EPSILON)
+    cs = n[f"kldiv_{red}"]; lit = cs["literals"]
+    X, T = dev.array(np.log(f32(lit[1], (2, 3)))), dev.array(f32(lit[0], (2, 3)))
+    c.loss_fwd(dev, "kldiv", X, T, out, red); close(out.numpy(), cs["scalars"][0], 0, F16_EPSILON)
+    D = dev.zeros((2, 3))
+    c.loss_bwd(dev, "kldiv", D, G, None, T, red); close(D.numpy(), f32(lit[3], (2, 3)), 0, F16_EPSILON)
+    cs = n[f"bce_with_logits_{red}"]; lit = cs["literals"]
+    X, T = dev.array(f32(lit[1], (3, 3))), dev.array(f32(lit[0], (3, 3)))
+    c.loss_fwd(dev, "bce_with_logits", X, T, out, red); close(out.numpy(), cs["scalars"][0], 0, 1e-3)
+    D = dev.zeros((3, 3))
+    c.loss_bwd(dev, "bce_with_logits", D, G, X, T, red); close(D.numpy(), f32(lit[3], (3, 3)), 0, F16_EPSILON)
+
+
+@pytest.mark.parametrize("red", ["mean", "sum"])
+@pytest.mark.parametrize("shape", [(7,), (33, 129), (4, 3, 50, 51), (1 << 20,)])
+def test_loss_random(dev, red, shape):
+    """f32 HIP vs the f64 oracle; forward tolerance covers the parallel (vs sequential) summation order."""
+    c = capi()
+    gval = np.float32(0.75)
+    G = dev.array(np.array(gval, np.float32))
+    for name in ("mae", "bce", "bce_with_logits", "kldiv"):
+        if name in ("bce", "kldiv"):
+            x, t = rnd(1, shape, 0.02, 0.98), rnd(2, shape, 0.0, 1.0)
+            if name == "kldiv":
+                t = np.where(t < 0.1, 0.0, t).astype(np.float32); x = np.log(x)
+        else:
+            x, t = rnd(1, shape, -4, 4), rnd(2, shape, 0.0, 1.0)
+            if name == "mae":
+                t.reshape(-1)[::5] = x.reshape(-1)[::5]          # exact ties: gradient 0 there
+        d0 = rnd(3, shape, -1, 1)
+        X, T, D, out = dev.array(x), dev.array(t), dev.array(d0), dev.zeros(())
+        c.loss_fwd(dev, name, X, T, out, red)
+        x64, t64, d64 = x.astype(np.float64), t.astype(np.float64), d0.astype(np.float64)
+        if name == "kldiv":
+            want = O.kldiv_forward(x64, t64, red); O.kldiv_backward(d64, float(gval), t64, red)
+        else:
+            fwd, bwd = LOSS_ORACLE[name]
+            want = fwd(x64, t64, red); bwd(d64, float(gval), x64, t64, red)
+        close(out.numpy(), want, rtol=2e-5, atol=1e-6)
+        c.loss_bwd(dev, name, D, G, None if name == "kldiv" else X, T, red)
+        close(D.numpy(), d64, rtol=3e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("red", ["mean", "sum"])
+@pytest.mark.parametrize("shape", [(64, 10), (5, 7, 6, 4), (4096, 1000)])
+def test_nll_random(dev, red, shape):
+    c = capi()
+    x = np.log(rnd(1, shape, 0.01, 1.0))
+    tshape = (shape[0],) + tuple(shape[2:])
+    t = np.random.default_rng(5).integers(-1, shape[1] + 2, tshape).astype(np.float32)  # incl. out-of-range / negative
+    t.reshape(-1)[::7] += 0.75                                                          # fraction is dropped
+    d0 = rnd(3, shape, -1, 1)
+    X, T, D, out, G = dev.array(x), dev.array(t), dev.array(d0), dev.zeros(()), dev.array(np.array(0.5, np.float32))
+    c.nll_fwd(dev, X, T, out, red)
+    close(out.numpy(), O.nll_forward(x.astype(np.float64), t, red), rtol=2e-5, atol=1e-6)
+    c.nll_bwd(dev, D, G, T, red)
+    d = d0.copy(); O.nll_backward(d, 0.5, t, red)
+    assert np.array_equal(D.numpy(), d)
+
+
+# ------------------------------------------------------------------------------ GEMV / dot (next row f-4)
+def test_gemv_dot_golden(dev, golden):
+    c = capi(); n = golden["nodes"]
+    lit = n["matrix_vector_mul_forward"]["literals"]
+    A, x, y = dev.array(f32(lit[0], (3, 3))), dev.array(f32(lit[1])), dev.full((3,), 9.0)
+    c.mv_fwd(dev, A, x, y); assert np.array_equal(y.numpy(), f32(lit[2]))
+    lit = n["matrix_vector_mul_backward"]["literals"]
+    dA, dx, A, x, g = (dev.array(f32(lit[0], (3, 3))), dev.array(f32(lit[1])), dev.array(f32(lit[2], (3, 3))),
+                       dev.array(f32(lit[3])), dev.array(f32(lit[4])))
+    for k in (6, 8):
+        c.mv_bwd_left(dev, dA, g, x); c.mv_bwd_right(dev, dx, A, g)
+        assert np.array_equal(dA.numpy(), f32(lit[k], (3, 3))) and np.array_equal(dx.numpy(), f32(lit[k + 1]))
+    lit = n["vector_matrix_mul_forward"]["literals"]
+    v, B, y = dev.array(f32(lit[0])), dev.array(f32(lit[1], (3, 3))), dev.full((3,), 9.0)
+    c.vm_fwd(dev, v, B, y); assert np.array_equal(y.numpy(), f32(lit[2]))
+    lit = n["vector_matrix_mul_backward"]["literals"]
+    dv, dB, v, B, g = (dev.array(f32(lit[0])), dev.array(f32(lit[1], (3, 3))), dev.array(f32(lit[2])),
+                       dev.array(f32(lit[3], (3, 3))), dev.array(f32(lit[4])))
+    for k in (6, 8):
+        c.vm_bwd_left(dev, dv, B, g); c.vm_bwd_right(dev, dB, v, g)
+        assert np.array_equal(dv.numpy(), f32(lit[k])) and np.array_equal(dB.numpy(), f32(lit[k + 1], (3, 3)))
+    cs = n["vector_vector_mul_forward"]
+    l, r, out = dev.array(f32(cs["literals"][0])), dev.array(f32(cs["literals"][1])), dev.zeros(())
+    c.vv_fwd(dev, l, r, out); assert out.numpy() == cs["scalars"][0]
+    cs = n["vector_vector_mul_backward"]; lit = cs["literals"]
+    dl, dr, l, r, g = dev.array(f32(lit[0])), dev.array(f32(lit[1])), dev.array(f32(lit[2])), dev.array(f32(lit[3])), dev.array(np.ones((), np.float32))
+    for k in (4, 6):
+        c.vv_bwd(dev, dl, r, g); c.vv_bwd(dev, dr, l, g)
+        assert np.array_equal(dl.numpy(), f32(lit[k])) and np.array_equal(dr.numpy(), f32(lit[k + 1]))
+
+
+@pytest.mark.parametrize("n,m", [(1, 1), (5, 3), (64, 1000), (1000, 64), (4099, 257), (3, 70001), (2048, 2048), (8192, 512)])
+def test_gemv_random(dev, n, m):
+    c = capi()
+    a, x, g = rnd(1, (n, m), -1, 1), rnd(2, (m,), -1, 1), rnd(3, (n,), -1, 1)
+    a64, x64, g64 = a.astype(np.float64), x.astype(np.float64), g.astype(np.float64)
+    tol = dict(rtol=1e-5, atol=2e-6 * np.sqrt(max(n, m)))
+    A, X, G = dev.array(a), dev.array(x), dev.array(g)
+    Y = dev.full((n,), 5.0); c.mv_fwd(dev, A, X, Y); close(Y.numpy(), a64 @ x64, **tol)
+    d0 = rnd(4, (n, m)); D = dev.array(d0); c.mv_bwd_left(dev, D, G, X); close(D.numpy(), d0 + np.outer(g64, x64), **tol)
+    e0 = rnd(5, (m,)); E = dev.array(e0); c.mv_bwd_right(dev, E, A, G); close(E.numpy(), e0 + a64.T @ g64, **tol)
+    # vector . matrix with B = a (n, m): v (n), result (m)
+    Z = dev.full((m,), 5.0); c.vm_fwd(dev, G, A, Z); close(Z.numpy(), g64 @ a64, **tol)
+    f0 = rnd(6, (n,)); F = dev.array(f0); c.vm_bwd_left(dev, F, A, X); close(F.numpy(), f0 + a64 @ x64, **tol)
+    D = dev.array(d0); c.vm_bwd_right(dev, D, G, X); close(D.numpy(), d0 + np.outer(g64, x64), **tol)
+    out = dev.zeros(()); c.vv_fwd(dev, X, dev.array(e0), out); close(out.numpy(), x64 @ e0.astype(np.float64), **tol)
+    s = dev.array(np.array(-1.5, np.float32)); E = dev.array(e0); c.vv_bwd(dev, E, X, s); close(E.numpy(), e0 - 1.5 * x64, **tol)
 
 
 # ------------------------------------------------------------------------------ optimizer (next row)

@@ -161,6 +161,49 @@ def test_conv2d_module(nk, tdev):
     close(X.grad(), dxp[:, :, 1:-1, 1:-1], 1e-4, 1e-5)
 
 
+@pytest.mark.parametrize("nd,mode", [(1, "reflective"), (1, "zero"), (3, "replicative"), (3, "constant"), (2, "reflective")])
+def test_conv_nd_modules(nk, tdev, nd, mode):
+    """nn::Conv1d / Conv2d / Conv3d (neuronika-nn/src/lib.rs:630-916) with every PaddingMode: forward and the three
+    gradients vs the oracle composition pad -> convolution -> + bias (backward of pad = centre slice, all modes)."""
+    pm = {"zero": nk.PaddingMode.zero(), "constant": nk.PaddingMode.constant(0.5),
+          "reflective": nk.PaddingMode.reflective(), "replicative": nk.PaddingMode.replicative()}[mode]
+    spatial = {1: (19,), 2: (9, 8), 3: (5, 6, 7)}[nd]
+    kernel, pad, stride, dil = {1: ((3,), (2,), (2,), (1,)), 2: ((3, 2), (1, 2), (1, 2), (2, 1)),
+                                3: ((2, 3, 2), (1, 1, 2), (1, 2, 1), (1, 1, 2))}[nd]
+    cin, cout, groups = 4, 6, 2
+    if nd == 1:
+        conv = nk.nn.Conv1d(tdev, cin, cout, kernel[0], pad[0], pm, stride[0], dil[0], groups, 3)
+    elif nd == 2:
+        conv = nk.nn.Conv2d(tdev, cin, cout, list(kernel), list(pad), list(stride), list(dil), groups, 3, pm)
+    else:
+        conv = nk.nn.Conv3d(tdev, cin, cout, list(kernel), list(pad), pm, list(stride), list(dil), groups, 3)
+    w, b = conv.weight.data(), conv.bias.data()
+    assert list(w.shape) == [cout, cin // groups] + list(kernel) and list(b.shape) == [cout] + [1] * nd
+    bound = np.sqrt(1.0 / (cin // groups * np.prod(kernel)))
+    assert np.abs(w).max() <= bound and np.abs(b).max() <= bound
+    x = rnd(0, (2, cin) + spatial, -1, 1)
+    X = nk.from_ndarray(tdev, x).requires_grad()
+    y = conv.forward(X)
+    y.forward()
+    xp = np.zeros((2, cin) + tuple(n + 2 * p for n, p in zip(spatial, pad)), np.float32)
+    if mode in ("zero", "constant"):
+        O.pad_constant_forward(x, xp, pad, 0.5 if mode == "constant" else 0.0)
+    else:
+        O.pad_mode_forward(x, xp, pad, mode)
+    out_sp = tuple((n - d * (k - 1) - 1) // s + 1 for n, k, s, d in zip(xp.shape[2:], kernel, stride, dil))
+    yr = np.zeros((2, cout) + out_sp, np.float32); O.convolution_forward(xp, w, yr, stride, dil, groups)
+    assert list(y.shape) == list(yr.shape)
+    close(y.data(), yr + b, 1e-5, 1e-5)
+    gw = rnd(7, yr.shape, -1, 1)
+    s = (y * nk.from_ndarray(tdev, gw)).sum(); s.forward(); s.backward(1.0)
+    dw = np.zeros_like(w); O.convolution_backward_kernel(dw, gw, xp, stride, dil, groups)
+    dxp = np.zeros_like(xp); O.convolution_backward_input(dxp, gw, w, stride, dil, groups)
+    dx = np.zeros_like(x); O.pad_backward(dx, dxp, pad)
+    close(conv.weight.grad(), dw, 1e-4, 1e-4)
+    close(conv.bias.grad().reshape(-1), gw.sum(tuple(i for i in range(gw.ndim) if i != 1)), 1e-5, 1e-4)
+    close(X.grad(), dx, 1e-4, 1e-5)
+
+
 def test_chunks_cat_dropout_graph(nk, tdev):
     x = rnd(3, (6, 8))
     X = nk.from_ndarray(tdev, x).requires_grad()
@@ -212,6 +255,102 @@ def test_pointwise_nodes_graph(nk, tdev):
     close(s.item(), f.sum(), 1e-5)
     df = -0.5 * x64 ** -1.5 + sig * (1 - sig) * np.tanh(x64) + sig * (1 - np.tanh(x64) ** 2) + sig + 3 * x64 ** 2
     close(X.grad(), df, 2e-5, 1e-6)
+
+
+def test_losses_gemv_stack_graph(nk, tdev):
+    """Row f-4 through the tape: classifier head x.mm_t(W) -> log_softmax -> nll; bce / bce_with_logits / kldiv /
+    mae heads; mv / vm / vv; stack — values and gradients against the oracle nodes."""
+    R = nk.Reduction
+    x, w = rnd(1, (8, 6), -1, 1), rnd(2, (5, 6), -1, 1)
+    t = np.array([0, 4, 2, 2, 1, 3, 0, 4], np.float32)
+    W = nk.from_ndarray(tdev, w).requires_grad()
+    logits = nk.from_ndarray(tdev, x).mm_t(W)
+    loss = logits.log_softmax(1).nll(nk.from_ndarray(tdev, t), R.Mean)
+    loss.forward(); loss.backward(1.0)
+    z = x @ w.T; lz = np.zeros_like(z); O.log_softmax_forward(z, lz, 1)
+    close(loss.item(), O.nll_forward(lz, t, "mean"), 1e-5)
+    dlz = np.zeros_like(z); O.nll_backward(dlz, 1.0, t, "mean")
+    dz = np.zeros_like(z); O.log_softmax_backward(dz, dlz, lz, 1)
+    close(W.grad(), dz.T @ x, 1e-4, 1e-6)
+
+    p, q = rnd(3, (4, 7), 0.05, 0.95), rnd(4, (4, 7), 0.0, 1.0)
+    Q = nk.from_ndarray(tdev, q)
+    for name, fwd, bwd, inp in (("bce", O.bce_forward, O.bce_backward, p), ("mae", O.mae_forward, O.mae_backward, p),
+                                ("bce_with_logits", O.bce_with_logits_forward, O.bce_with_logits_backward, 4 * p - 2)):
+        for red, rname in ((R.Mean, "mean"), (R.Sum, "sum")):
+            P = nk.from_ndarray(tdev, inp).requires_grad()
+            l = getattr(P, name)(Q, red); l.forward(); l.backward(1.0)
+            close(l.item(), fwd(inp, q, rname), 2e-5)
+            d = np.zeros_like(inp); bwd(d, 1.0, inp, q, rname); close(P.grad(), d, 1e-5, 1e-6)
+    P = nk.from_ndarray(tdev, np.log(p)).requires_grad()
+    l = P.kldiv(Q, R.Mean); l.forward(); l.backward(1.0)
+    close(l.item(), O.kldiv_forward(np.log(p), q, "mean"), 2e-5)
+    d = np.zeros_like(p); O.kldiv_backward(d, 1.0, q, "mean"); close(P.grad(), d, 1e-5, 1e-6)
+
+    a, v, u = rnd(5, (6, 9), -1, 1), rnd(6, (9,), -1, 1), rnd(7, (6,), -1, 1)
+    A, V, U = (nk.from_ndarray(tdev, z).requires_grad() for z in (a, v, u))
+    s = A.mv(V).vv(U) + U.vm(A).vv(V)            # u.(A v) twice
+    s.forward(); s.backward(1.0)
+    close(s.item(), 2 * (u @ a @ v), 1e-5)
+    close(A.grad(), 2 * np.outer(u, v), 1e-5, 1e-6); close(V.grad(), 2 * (a.T @ u), 1e-5, 1e-6); close(U.grad(), 2 * (a @ v), 1e-5, 1e-6)
+
+    b, c = rnd(8, (3, 4)), rnd(9, (3, 4))
+    B, C = nk.from_ndarray(tdev, b).requires_grad(), nk.from_ndarray(tdev, c).requires_grad()
+    for axis in (0, 1, 2):
+        st = B.stack([C, B], axis)
+        ref = np.stack([b, c, b], axis)
+        assert list(st.shape) == list(ref.shape)
+        wgt = rnd(10 + axis, ref.shape)
+        B.zero_grad(); C.zero_grad()
+        l = (st * nk.from_ndarray(tdev, wgt)).sum(); l.forward(); l.backward(1.0)
+        close(st.data(), ref)
+        close(C.grad(), np.take(wgt, 1, axis), 1e-6); close(B.grad(), np.take(wgt, 0, axis) + np.take(wgt, 2, axis), 1e-6)
+    with pytest.raises(RuntimeError, match="nll"):
+        nk.from_ndarray(tdev, x).nll(nk.from_ndarray(tdev, x), R.Mean)
+
+
+def test_lstm_gru_cells(nk, tdev):
+    """nn::LSTMCell / nn::GRUCell (neuronika-nn/src/lib.rs:512-541, 602-624) vs the oracle composition in
+    f64; gradients vs central differences of the f64 oracle."""
+    B, I, H = 5, 7, 6
+    x, h0, c0 = rnd(1, (B, I), -1, 1), rnd(2, (B, H), -1, 1), rnd(3, (B, H), -1, 1)
+    wt = rnd(4, (B, H), -1, 1)                               # loss = sum(out * wt)
+    X = nk.from_ndarray(tdev, x)
+    Wt = nk.from_ndarray(tdev, wt)
+    names = ("weight_ih", "weight_hh", "bias_ih", "bias_hh")
+
+    lstm = nk.nn.LSTMCell(tdev, I, H, seed=11)
+    Hh, Cc = nk.from_ndarray(tdev, h0).requires_grad(), nk.from_ndarray(tdev, c0).requires_grad()
+    new_c, new_h = lstm.forward((Cc, Hh), X)
+    loss = (new_h * Wt).sum() + (new_c * Wt).sum()
+    loss.forward(); loss.backward(1.0)
+    p = {n: getattr(lstm, n).data().astype(np.float64) for n in names}
+    st = {"c": c0.astype(np.float64), "h": h0.astype(np.float64)}
+    x64, w64 = x.astype(np.float64), wt.astype(np.float64)
+
+    def f_lstm():
+        c, h = O.lstm_cell_forward(st["c"], st["h"], x64, p["weight_ih"], p["weight_hh"], p["bias_ih"], p["bias_hh"])
+        return float((h * w64).sum() + (c * w64).sum())
+    c_ref, h_ref = O.lstm_cell_forward(st["c"], st["h"], x64, *(p[n] for n in names))
+    close(new_c.data(), c_ref, 2e-5, 1e-6); close(new_h.data(), h_ref, 2e-5, 1e-6)
+    for n in names:
+        close(getattr(lstm, n).grad(), O.numeric_grad(f_lstm, p[n]), 2e-4, 2e-5)
+    close(Hh.grad(), O.numeric_grad(f_lstm, st["h"]), 2e-4, 2e-5)
+    close(Cc.grad(), O.numeric_grad(f_lstm, st["c"]), 2e-4, 2e-5)
+
+    gru = nk.nn.GRUCell(tdev, I, H, seed=21)
+    Hg = nk.from_ndarray(tdev, h0).requires_grad()
+    out = gru.forward(Hg, X)
+    loss = (out * Wt).sum(); loss.forward(); loss.backward(1.0)
+    q = {n: getattr(gru, n).data().astype(np.float64) for n in names}
+    hg = h0.astype(np.float64)
+
+    def f_gru():
+        return float((O.gru_cell_forward(hg, x64, *(q[n] for n in names)) * w64).sum())
+    close(out.data(), O.gru_cell_forward(hg, x64, *(q[n] for n in names)), 2e-5, 1e-6)
+    for n in names:
+        close(getattr(gru, n).grad(), O.numeric_grad(f_gru, q[n]), 2e-4, 2e-5)
+    close(Hg.grad(), O.numeric_grad(f_gru, hg), 2e-4, 2e-5)
 
 
 @pytest.mark.parametrize("make", ["sgd", "sgd_momentum", "adam", "amsgrad", "adagrad", "rmsprop"])

@@ -225,6 +225,89 @@ def test_exp_ln_golden():
     dx[...] = 0; O.unary_backward("ln", dx, g, xp); close(dx, 1 / xp)
 
 
+# ------------------------------------------------------------------ loss criteria (row f-4)
+def _lin(spec):
+    a, b, n, *shape = spec
+    return np.linspace(a, b, int(n), dtype=np.float32).reshape(shape)
+
+
+@pytest.mark.parametrize("red", ["mean", "sum"])
+def test_bce_mae_golden(golden, red):
+    """bce/test.rs and absolute_error/test.rs (enabled): forward scalars and backward gradients."""
+    n = golden["nodes"]
+    for name, fwd, bwd in (("bce", O.bce_forward, O.bce_backward), ("absolute_error", O.mae_forward, O.mae_backward)):
+        c = n[f"{name}_forward_base_case_{red}"]
+        x, t = (_lin(sp) for sp in c["linspace_start_stop_n_shape"])
+        close(fwd(x, t, red), c["scalars"][-1], c["tol"] * max(1.0, abs(c["scalars"][-1]) * 1e-3))
+        c = n[f"{name}_backward_base_case_{red}"]
+        x, t = (_lin(sp) for sp in c["linspace_start_stop_n_shape"])
+        dx = np.zeros_like(x)
+        bwd(dx, c["scalars"][0], x, t, red)
+        want = f32(c["literals"][0], (3, 3)) if c["literals"] else np.full((3, 3), c["from_elem"][0][0], np.float32)
+        np.testing.assert_allclose(dx, want, rtol=2e-6, atol=c["tol"])
+
+
+@pytest.mark.parametrize("red", ["mean", "sum"])
+def test_nll_kldiv_bcelogits_golden(golden, red):
+    """nll / kldiv / bce_with_logits test.rs (modules commented out; numbers valid): pin the documented
+    NLL layout and the masked KLDiv."""
+    n = golden["nodes"]
+    c = n[f"nll_{red}"]; lit = c["literals"]
+    t, x = f32(lit[0]), f32(lit[1], (3, 5))
+    lx = np.zeros_like(x); O.log_softmax_forward(x, lx, 1)
+    close(O.nll_forward(lx, t, red), c["scalars"][0])
+    dx = f32(lit[2], (3, 5)).copy()
+    O.nll_backward(dx, c["scalars"][1], t, red); close(dx, f32(lit[3], (3, 5)))
+    O.nll_backward(dx, c["scalars"][1], t, red); close(dx, 2 * f32(lit[4], (3, 5)))
+
+    c = n[f"kldiv_{red}"]; lit = c["literals"]
+    t, x = f32(lit[0], (2, 3)), np.log(f32(lit[1], (2, 3)))
+    close(O.kldiv_forward(x, t, red), c["scalars"][0])
+    dx = f32(lit[2], (2, 3)).copy()
+    O.kldiv_backward(dx, c["scalars"][1], t, red); close(dx, f32(lit[3], (2, 3)))
+    O.kldiv_backward(dx, c["scalars"][1], t, red); close(dx, 2 * f32(lit[4], (2, 3)))
+
+    c = n[f"bce_with_logits_{red}"]; lit = c["literals"]
+    t, x = f32(lit[0], (3, 3)), f32(lit[1], (3, 3))
+    close(O.bce_with_logits_forward(x, t, red), c["scalars"][0], 1e-3)
+    dx = f32(lit[2], (3, 3)).copy()
+    O.bce_with_logits_backward(dx, c["scalars"][1], x, t, red); close(dx, f32(lit[3], (3, 3)))
+    O.bce_with_logits_backward(dx, c["scalars"][1], x, t, red); close(dx, 2 * f32(lit[4], (3, 3)))
+
+
+def test_nll_target_cast():
+    """`target as usize` (nll/mod.rs:57): NaN / negative -> class 0, fraction dropped, >= C selects nothing."""
+    x = np.log(np.array([[0.2, 0.8], [0.5, 0.5], [0.9, 0.1], [0.3, 0.7]], np.float32))
+    t = np.array([-3.0, 1.9, np.nan, 7.0], np.float32)
+    close(O.nll_forward(x, t, "sum"), -(x[0, 0] + x[1, 1] + x[2, 0]))
+
+
+# ------------------------------------------------------------------ GEMV / dot (row f-4)
+def test_gemv_dot_golden(golden):
+    n = golden["nodes"]
+    lit = n["matrix_vector_mul_forward"]["literals"]
+    y = np.zeros(3, np.float32); O.mv_forward(f32(lit[0], (3, 3)), f32(lit[1]), y); close(y, f32(lit[2]))
+    O.mv_forward(f32(lit[0], (3, 3)), f32(lit[3]), y); close(y, f32(lit[6]))
+    lit = n["matrix_vector_mul_backward"]["literals"]
+    dA, dx, A, x, g = f32(lit[0], (3, 3)).copy(), f32(lit[1]).copy(), f32(lit[2], (3, 3)), f32(lit[3]), f32(lit[4])
+    O.mv_backward(dA, dx, g, A, x); close(dA, f32(lit[6], (3, 3))); close(dx, f32(lit[7]))
+    O.mv_backward(dA, dx, g, A, x); close(dA, f32(lit[8], (3, 3))); close(dx, f32(lit[9]))
+    lit = n["vector_matrix_mul_forward"]["literals"]
+    O.vm_forward(f32(lit[0]), f32(lit[1], (3, 3)), y); close(y, f32(lit[2]))
+    lit = n["vector_matrix_mul_backward"]["literals"]
+    dv, dB, v, B, g = f32(lit[0]).copy(), f32(lit[1], (3, 3)).copy(), f32(lit[2]), f32(lit[3], (3, 3)), f32(lit[4])
+    O.vm_backward(dv, dB, g, v, B); close(dv, f32(lit[6])); close(dB, f32(lit[7], (3, 3)))
+    O.vm_backward(dv, dB, g, v, B); close(dv, f32(lit[8])); close(dB, f32(lit[9], (3, 3)))
+    c = n["vector_vector_mul_forward"]
+    close(O.vv_forward(f32(c["literals"][0]), f32(c["literals"][1])), c["scalars"][0])
+    c = n["vector_vector_mul_backward"]; lit = c["literals"]
+    dl, dr, l, r = f32(lit[0]).copy(), f32(lit[1]).copy(), f32(lit[2]), f32(lit[3])
+    O.vv_backward(dl, r, c["scalars"][0]); O.vv_backward(dr, l, c["scalars"][0])
+    close(dl, f32(lit[4])); close(dr, f32(lit[5]))
+    O.vv_backward(dl, r, c["scalars"][0]); O.vv_backward(dr, l, c["scalars"][0])
+    close(dl, f32(lit[6])); close(dr, f32(lit[7]))
+
+
 # ------------------------------------------------------------------ broadcast binaries
 OPS = {"addition": "add", "subtraction": "sub", "multiplication": "mul", "division": "div"}
 NP = {"add": np.add, "sub": np.subtract, "mul": np.multiply, "div": np.divide}
@@ -317,6 +400,19 @@ def test_pad_golden(golden, mode):
     dx = np.zeros_like(base)
     O.pad_backward(dx, out, (1, 2))
     assert np.array_equal(dx, base)
+
+
+@pytest.mark.parametrize("mode", ["reflective", "replicative"])
+@pytest.mark.parametrize("fn", ["test_1d", "test_2d", "test_3d"])
+def test_pad_mode_golden(golden, mode, fn):
+    """pad/{reflective,replicative}/test.rs: exact (`assert_eq!`) expectations for 1-, 2- and 3-d samples."""
+    c = golden["nodes"][f"pad_{mode}_{fn}"]
+    base = np.arange(c["arange"], dtype=np.float32).reshape([1, 1] + c["base_shape"])
+    out = np.zeros([1, 1] + c["padded_shape"], np.float32)
+    O.pad_mode_forward(base, out, c["padding"], mode)
+    assert np.array_equal(out[0, 0], f32(c["expected"], c["padded_shape"])), c["cite"]
+    with pytest.raises(IndexError):
+        O.pad_mode_forward(base, np.zeros([1, 1] + [n + 2 * n for n in c["base_shape"]], np.float32), c["base_shape"], "reflective")
 
 
 def test_chunk_golden(golden):
