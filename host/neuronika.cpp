@@ -543,6 +543,33 @@ struct LossBwd : Backward {
     void targets(std::vector<const Gradient*>& out) const override { out.push_back(dx.get()); }
 };
 
+// `Linear::forward` as one node: mm_t + broadcast Addition (neuronika-nn/src/lib.rs:443-446)
+struct LinearFwd : Forward {
+    Shared<HipArray> x, w, b, y;
+    void forward() const override {
+        check(nk_linear_fwd(D(x), x->ptr(), w->ptr(), b->ptr(), y->ptr(), x->shape()[0], x->shape()[1], w->shape()[0]));
+    }
+};
+struct LinearBwd : Backward {
+    Shared<HipArray> x, w;
+    Shared<Gradient> dx, dw, db, g;  // dx null for a non-differentiable input
+    void backward() const override {
+        const HipArray& G = g->borrow();
+        nk_device* dev = D(x);
+        const int n = x->shape()[0], m = x->shape()[1], o = w->shape()[0];
+        // same order as MatrixMatrixMulTBackward (left, right) followed by AdditionBackwardRight
+        if (dx) check(nk_mm_t_bwd_left(dev, dx->borrow().ptr(), G.ptr(), w->ptr(), n, m, o));
+        check(nk_mm_t_bwd_right(dev, dw->borrow().ptr(), G.ptr(), x->ptr(), n, m, o));
+        const int gs[2] = {n, o};
+        check(nk_unbroadcast_add(dev, db->borrow().ptr(), &o, 1, G.ptr(), gs, 2));
+    }
+    void targets(std::vector<const Gradient*>& out) const override {
+        if (dx) out.push_back(dx.get());
+        out.push_back(dw.get());
+        out.push_back(db.get());
+    }
+};
+
 template <class Op>
 BackwardEntry entry(Shared<Op> op, Shared<Gradient> grad) {
     return BackwardEntry{std::move(op), std::move(grad)};
@@ -1131,8 +1158,33 @@ static VarDiff uniform_param(const DevicePtr& dev, const Shape& s, float k, uint
 Linear::Linear(DevicePtr dev, int in_features, int out_features, uint64_t seed)
     : weight(uniform_param(dev, {out_features, in_features}, 1.f / std::sqrt((float)in_features), seed)),
       bias(uniform_param(dev, {out_features}, 1.f / std::sqrt((float)in_features), seed + 1)) {}
-VarDiff Linear::forward(const Var& input) const { return input.mm_t(weight) + bias; }
-VarDiff Linear::forward(const VarDiff& input) const { return input.mm_t(weight) + bias; }
+static VarDiff linear_node(const Linear& l, const Var& x, const Shared<Gradient>& dx, const History<BackwardEntry>* hx) {
+    const Shape& xs = x.shape();
+    const Shape& ws = l.weight.shape();
+    if (xs.size() != 2 || ws.size() != 2 || xs[1] != ws[1]) panic("Shapes are incompatible for matrix multiplication.");
+    if (l.bias.shape() != Shape{ws[0]}) panic("Linear: bias must have shape (out_features)");
+    History<ForwardEntry> h = x.history;
+    h.merge(l.weight.var.history);
+    h.merge(l.bias.var.history);
+    auto fw = std::make_shared<LinearFwd>();
+    fw->x = x.data; fw->w = l.weight.var.data; fw->b = l.bias.var.data; fw->y = zeros_like(x.data, Shape{xs[0], ws[0]});
+    auto y = fw->y;
+    Var var = Var::node(y, fw, std::move(h));
+    History<BackwardEntry> hb;
+    if (hx) hb = *hx;
+    hb.merge(l.weight.history);
+    hb.merge(l.bias.history);
+    auto g = std::make_shared<Gradient>(var.device(), var.shape());
+    auto bw = std::make_shared<LinearBwd>();
+    bw->x = x.data; bw->w = l.weight.var.data; bw->dx = dx; bw->dw = l.weight.grad; bw->db = l.bias.grad; bw->g = g;
+    return VarDiff::node(std::move(var), g, entry(bw, g), std::move(hb));
+}
+VarDiff Linear::forward(const Var& input) const {
+    return fused ? linear_node(*this, input, nullptr, nullptr) : input.mm_t(weight) + bias;
+}
+VarDiff Linear::forward(const VarDiff& input) const {
+    return fused ? linear_node(*this, input.var, input.grad, &input.history) : input.mm_t(weight) + bias;
+}
 
 LSTMCell::LSTMCell(DevicePtr dev, int input_size, int hidden_size, uint64_t seed)
     : weight_ih(uniform_param(dev, {4 * hidden_size, input_size}, 1.f / std::sqrt((float)hidden_size), seed)),

@@ -373,6 +373,7 @@ namespace nn {
 // `Linear` neuronika-nn/src/lib.rs:406-448: weight (out,in), bias (out), U(-k,k), k = 1/sqrt(in)
 struct Linear {
     VarDiff weight, bias;
+    bool fused = true;  // bias added in the GEMM epilogue (one node); false: the reference's two nodes mm_t, +
     Linear(DevicePtr dev, int in_features, int out_features, uint64_t seed);
     Linear(VarDiff weight, VarDiff bias) : weight(std::move(weight)), bias(std::move(bias)) {}
     VarDiff forward(const Var& input) const;      // input.mm_t(W) + b

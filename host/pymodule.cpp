@@ -150,6 +150,7 @@ PYBIND11_MODULE(_tape, m) {
         .def(py::init<VarDiff, VarDiff>())
         .def_readonly("weight", &nn::Linear::weight)
         .def_readonly("bias", &nn::Linear::bias)
+        .def_readwrite("fused", &nn::Linear::fused)
         .def("forward", py::overload_cast<const Var&>(&nn::Linear::forward, py::const_))
         .def("forward", py::overload_cast<const VarDiff&>(&nn::Linear::forward, py::const_));
     using State = std::pair<VarDiff, VarDiff>;

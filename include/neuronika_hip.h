@@ -133,6 +133,12 @@ int nk_mm_t_bwd_left(nk_device* dev, float* dA, const float* G, const float* B, 
 /* MatrixMatrixMulTBackwardRight::backward :95-105  dB(o,m) += G(n,o)^T.A(n,m) */
 int nk_mm_t_bwd_right(nk_device* dev, float* dB, const float* G, const float* A, int n, int m, int o);
 
+/* `Linear::forward` neuronika-nn/src/lib.rs:425-447  Y(n,o) = X(n,m).W(o,m)^T + b(o): the MatrixMatrixMulT node
+ * (matrix_matrix_mul_t/mod.rs:31-41) and the broadcast Addition node (addition/mod.rs:39-50) as ONE kernel - the
+ * bias is added to the f32 accumulator in the GEMM epilogue, bit-identical to the two-node result.  Its backward is
+ * nk_mm_t_bwd_left (dX += G.W), nk_mm_t_bwd_right (dW += G^T.X) and nk_unbroadcast_add (db += column sums of G). */
+int nk_linear_fwd(nk_device* dev, const float* X, const float* W, const float* bias, float* Y, int n, int m, int o);
+
 /* ------------------------------------------------------------------ convolution -------- */
 /* N-d (nd = 1,2,3) cross-correlation without internal padding, NC[D]HW layout.
  *   x: [N, Cin, in...]   w: [Cout, Cin/groups, k...]   y: [N, Cout, out...]

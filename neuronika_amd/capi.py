@@ -76,6 +76,7 @@ _SIGS = {
     "nk_mm_t_fwd": [VP, VP, VP, VP, C.c_int, C.c_int, C.c_int],
     "nk_mm_t_bwd_left": [VP, VP, VP, VP, C.c_int, C.c_int, C.c_int],
     "nk_mm_t_bwd_right": [VP, VP, VP, VP, C.c_int, C.c_int, C.c_int],
+    "nk_linear_fwd": [VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int],
     "nk_conv_fwd": [VP, C.c_int, VP, c_intp, VP, c_intp, VP, c_intp, c_intp, C.c_int],
     "nk_conv_bwd_input": [VP, C.c_int, VP, c_intp, VP, VP, c_intp, c_intp, c_intp, C.c_int],
     "nk_conv_bwd_kernel": [VP, C.c_int, VP, c_intp, VP, VP, c_intp, c_intp, c_intp, C.c_int],
@@ -350,6 +351,10 @@ def conv_bwd_input(dev, dx, g, w, stride, dilation, groups=1):
 def conv_bwd_kernel(dev, dw, g, x, stride, dilation, groups=1):
     nd = x.ndim - 2
     check(lib.nk_conv_bwd_kernel(dev.h, nd, dw.p, dw.shape_c(), g.p, x.p, x.shape_c(), ints(stride), ints(dilation), groups))
+
+
+def linear_fwd(dev, X, W, bias, Y):
+    check(lib.nk_linear_fwd(dev.h, X.p, W.p, bias.p, Y.p, X.shape[0], X.shape[1], W.shape[0]))
 
 
 def pad_const_fwd(dev, x, y, padding, value=0.0):

@@ -18,6 +18,7 @@ struct GemmArgs {
     int M, N, K;
     long long lda, ldb, ldc;
     float alpha, beta;
+    const float* bias;  // optional column bias (length N) added in the epilogue: C = alpha*A.B + bias + beta*C
     // two-level batch
     int batch_inner;
     long long sAo, sAi, sBo, sBi, sCo, sCi;
@@ -97,7 +98,17 @@ __global__ __launch_bounds__(NT, (min_waves<TI, TJ>())) void sgemm_kernel(GemmAr
     const float alpha = p.alpha, beta = p.beta;
     const int M = p.M, N = p.N;
     const long long ldc = p.ldc;
-    if (beta == 0.f) {
+    if (p.bias != nullptr) {  // Linear: fl(acc + bias[col]) == the separate Addition node applied to the GEMM result
+        const float* bias = p.bias;
+        acc_foreach<TI, TJ>(acc, wr, wc, lane, [&](int r, int c, float v) {
+            const int row = m0 + r, col = n0 + c;
+            if (ALIGNED || (row < M && col < N)) {
+                float* q = &C[row * ldc + col];
+                const float o = alpha * v + bias[col];
+                *q = beta == 0.f ? o : fmaf(beta, *q, o);
+            }
+        });
+    } else if (beta == 0.f) {
         acc_foreach<TI, TJ>(acc, wr, wc, lane, [&](int r, int c, float v) {
             const int row = m0 + r, col = n0 + c;
             if (ALIGNED || (row < M && col < N)) C[row * ldc + col] = alpha * v;
@@ -116,7 +127,8 @@ __global__ __launch_bounds__(NT, (min_waves<TI, TJ>())) void sgemm_kernel(GemmAr
 // Second pass of split-K: C = alpha * sum_s slab[s] + beta * C, fixed summation order.
 __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ C, int M, int N,
                                      long long ldc, int splits, int nbatch, int batch_inner,
-                                     long long sCo, long long sCi, float alpha, float beta) {
+                                     long long sCo, long long sCi, float alpha, float beta,
+                                     const float* __restrict__ bias) {
     const long long per = (long long)M * N;
     const long long total = per * nbatch;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
@@ -127,7 +139,8 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, float* __r
         float s = 0.f;
         for (int k = 0; k < splits; ++k) s += slabs[((long long)k * nbatch + b) * per + e];
         float* q = C + (b / batch_inner) * sCo + (b % batch_inner) * sCi + row * ldc + col;
-        *q = beta == 0.f ? alpha * s : fmaf(beta, *q, alpha * s);
+        const float o = bias ? alpha * s + bias[col] : alpha * s;
+        *q = beta == 0.f ? o : fmaf(beta, *q, o);
     }
 }
 
@@ -155,7 +168,7 @@ static int launch(nk_device* dev, const GemmArgs& p, int nbatch, bool aligned, i
 static int gemm_impl(nk_device* dev, int transA, int transB, int M, int N, int K, float alpha,
                      const float* A, int lda, long long sAo, long long sAi, const float* B, int ldb,
                      long long sBo, long long sBi, float beta, float* C, int ldc, long long sCo,
-                     long long sCi, int batch_outer, int batch_inner) {
+                     long long sCi, int batch_outer, int batch_inner, const float* bias = nullptr) {
     NK_USE(dev);
     NK_CHECK(M >= 0 && N >= 0 && K >= 0 && batch_outer >= 0 && batch_inner >= 0, "negative GEMM extent");
     const int nbatch = batch_outer * batch_inner;
@@ -170,6 +183,7 @@ static int gemm_impl(nk_device* dev, int transA, int transB, int M, int N, int K
     p.M = M; p.N = N; p.K = K;
     p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.alpha = alpha; p.beta = beta;
+    p.bias = bias;
     p.batch_inner = batch_inner;
     p.sAo = sAo; p.sAi = sAi; p.sBo = sBo; p.sBi = sBi; p.sCo = sCo; p.sCi = sCi;
 
@@ -223,7 +237,7 @@ static int gemm_impl(nk_device* dev, int transA, int transB, int M, int N, int K
         const long long total = (long long)M * N * nbatch;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(nk_stream_grid((size_t)total, 256)), dim3(256), 0,
                            dev->compute, p.slabs, C, M, N, (long long)ldc, p.splits, nbatch, batch_inner,
-                           sCo, sCi, alpha, beta);
+                           sCo, sCi, alpha, beta, bias);
         NK_LAUNCH_CHECK();
     }
     return nk_prof_stop(dev);
@@ -256,6 +270,10 @@ int nk_mm_bwd_right(nk_device* dev, float* dB, const float* A, const float* G, i
 }
 int nk_mm_t_fwd(nk_device* dev, const float* A, const float* B, float* C, int n, int m, int o) {
     return nk_sgemm(dev, 0, 1, n, o, m, 1.f, A, m, B, m, 0.f, C, o);  // C = A . B^T, B is (o,m)
+}
+int nk_linear_fwd(nk_device* dev, const float* X, const float* W, const float* bias, float* Y, int n, int m, int o) {
+    NK_CHECK(bias != nullptr, "null bias");
+    return gemm_impl(dev, 0, 1, n, o, m, 1.f, X, m, 0, 0, W, m, 0, 0, 0.f, Y, o, 0, 0, 1, 1, bias);  // Y = X . W^T + b
 }
 int nk_mm_t_bwd_left(nk_device* dev, float* dA, const float* G, const float* B, int n, int m, int o) {
     return nk_sgemm(dev, 0, 0, n, m, o, 1.f, G, o, B, m, 1.f, dA, m);  // dA += G . B

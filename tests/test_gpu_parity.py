@@ -584,6 +584,23 @@ def test_unary_fwd_bwd(dev, golden, op):
         assert np.array_equal(D.numpy(), f32([0.01, 5.0, 0.01, 0.01]))
 
 
+# ------------------------------------------------------------------------------ fused Linear forward
+@pytest.mark.parametrize("n,m,o", [(64, 3, 5), (4, 8, 1), (128, 128, 128), (300, 77, 200), (8, 4096, 64), (512, 256, 384)])
+def test_linear_fwd_equals_mm_t_plus_bias(dev, n, m, o):
+    """nk_linear_fwd (bias in the GEMM epilogue) is BIT-identical to nk_mm_t_fwd followed by the broadcast
+    Addition node, on aligned, ragged and split-K shapes."""
+    c = capi()
+    x, w, b = rnd(1, (n, m), -1, 1), rnd(2, (o, m), -1, 1), rnd(3, (o,), -1, 1)
+    X, W, Bv = dev.array(x), dev.array(w), dev.array(b)
+    Y0, Y1, Y2 = dev.zeros((n, o)), dev.zeros((n, o)), dev.full((n, o), 3.0)
+    c.mm_t_fwd(dev, X, W, Y0)
+    c.binary_fwd(dev, "add", Y1, Y0, Bv)
+    c.linear_fwd(dev, X, W, Bv, Y2)
+    assert np.array_equal(Y1.numpy(), Y2.numpy())
+    ref = x.astype(np.float64) @ w.astype(np.float64).T + b
+    close(Y2.numpy(), ref, rtol=1e-5, atol=2e-6 * m)
+
+
 # ------------------------------------------------------------------------------ loss criteria (next row f-4)
 def _lin(spec):
     a, b, n, *shape = spec

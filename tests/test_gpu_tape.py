@@ -106,7 +106,13 @@ def test_quickstart_mlp_C1(nk, tdev, golden):
     X, T = nk.from_ndarray(tdev, x), nk.from_ndarray(tdev, t)
     out = lins[2].forward(lins[1].forward(lins[0].forward(X).relu()).relu())
     loss = out.mse(T, nk.Reduction.Mean)
-    assert loss.history_len() == 9 and loss.forward_history_len() == 9   # [MMT,Add,ReLU]x2, MMT, Add, MSE
+    assert loss.history_len() == 6 and loss.forward_history_len() == 6   # [Linear,ReLU]x2, Linear, MSE
+    unfused = []
+    for w, b in params:
+        unfused.append(nk.nn.Linear(nk.from_ndarray(tdev, w).requires_grad(), nk.from_ndarray(tdev, b).requires_grad()))
+        unfused[-1].fused = False
+    ref_graph = unfused[2].forward(unfused[1].forward(unfused[0].forward(X).relu()).relu()).mse(T, nk.Reduction.Mean)
+    assert ref_graph.history_len() == 9 and ref_graph.forward_history_len() == 9   # the reference's [MMT,Add,ReLU]x2, MMT, Add, MSE
     loss.forward(); loss.backward(1.0)
     close(loss.item(), loss_ref, 1e-5, 1e-6)
     for lin, (dw, db) in zip(lins, grads_ref):
@@ -255,6 +261,22 @@ def test_pointwise_nodes_graph(nk, tdev):
     close(s.item(), f.sum(), 1e-5)
     df = -0.5 * x64 ** -1.5 + sig * (1 - sig) * np.tanh(x64) + sig * (1 - np.tanh(x64) ** 2) + sig + 3 * x64 ** 2
     close(X.grad(), df, 2e-5, 1e-6)
+
+
+def test_linear_fused_equals_two_nodes(nk, tdev):
+    """nn::Linear as one node (bias in the GEMM epilogue, backward = the three reference accumulations) gives
+    bit-identical values and gradients to the reference's mm_t + Addition nodes, for Var and VarDiff inputs."""
+    x = rnd(1, (96, 40), -1, 1)
+    res = {}
+    for fused in (True, False):
+        l1, l2 = nk.nn.Linear(tdev, 40, 64, 7), nk.nn.Linear(tdev, 64, 24, 9)
+        l1.fused = l2.fused = fused
+        y = l2.forward(l1.forward(nk.from_ndarray(tdev, x)).relu())
+        s = (y * y).sum(); s.forward(); s.backward(1.0)
+        assert y.history_len() == (3 if fused else 5)                 # backward nodes: 2 Linear + ReLU | 2x(mm_t, +) + ReLU
+        res[fused] = [y.data()] + [p.grad() for p in (l1.weight, l1.bias, l2.weight, l2.bias)]
+    for a, b in zip(res[True], res[False]):
+        assert np.array_equal(a, b)
 
 
 def test_losses_gemv_stack_graph(nk, tdev):
