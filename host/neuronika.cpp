@@ -4,6 +4,8 @@
 #include "neuronika.hpp"
 
 #include <algorithm>
+#include <charconv>
+#include <cstring>
 #include <cmath>
 #include <random>
 
@@ -1278,6 +1280,160 @@ VarDiff MultiheadAttention::forward(const VarDiff& x, int batch) const {
 }
 
 }  // namespace nn
+
+// =================================================================================================
+// serde (neuronika-variable/src/serde.rs:10-58): ndarray's {"v":1,"dim":[..],"data":[..]} wire format
+// =================================================================================================
+namespace serde {
+
+namespace {
+struct Parser {
+    const std::string& s;
+    size_t i = 0;
+    explicit Parser(const std::string& s) : s(s) {}
+    [[noreturn]] void fail(const char* what) const { panic(std::string("json: ") + what + " at offset " + std::to_string(i)); }
+    void ws() { while (i < s.size() && (s[i] == ' ' || s[i] == '\n' || s[i] == '\t' || s[i] == '\r')) ++i; }
+    bool eat(char c) { ws(); if (i < s.size() && s[i] == c) { ++i; return true; } return false; }
+    void expect(char c) { if (!eat(c)) fail("unexpected character"); }
+    std::string string() {
+        expect('"');
+        std::string out;
+        while (i < s.size() && s[i] != '"') {
+            if (s[i] == '\\') {
+                if (++i >= s.size()) fail("bad escape");
+                switch (s[i]) {
+                    case 'n': out += '\n'; break;
+                    case 't': out += '\t'; break;
+                    case 'r': out += '\r'; break;
+                    case 'b': out += '\b'; break;
+                    case 'f': out += '\f'; break;
+                    case 'u': fail("\\u escapes are not needed for this schema");
+                    default: out += s[i];
+                }
+                ++i;
+            } else {
+                out += s[i++];
+            }
+        }
+        if (i >= s.size()) fail("unterminated string");
+        ++i;
+        return out;
+    }
+    Json value() {
+        ws();
+        if (i >= s.size()) fail("unexpected end");
+        Json j;
+        const char c = s[i];
+        if (c == '{') {
+            ++i; j.kind = Json::Object;
+            if (eat('}')) return j;
+            do {
+                ws();
+                std::string k = string();
+                expect(':');
+                j.members.emplace_back(std::move(k), value());
+            } while (eat(','));
+            expect('}');
+        } else if (c == '[') {
+            ++i; j.kind = Json::Array;
+            if (eat(']')) return j;
+            do { j.items.push_back(value()); } while (eat(','));
+            expect(']');
+        } else if (c == '"') {
+            j.kind = Json::String; j.text = string();
+        } else if (s.compare(i, 4, "true") == 0) { j.kind = Json::Bool; j.b = true; i += 4;
+        } else if (s.compare(i, 5, "false") == 0) { j.kind = Json::Bool; i += 5;
+        } else if (s.compare(i, 4, "null") == 0) { i += 4;
+        } else {
+            const size_t b = i;
+            while (i < s.size() && (std::isdigit((unsigned char)s[i]) || s[i] == '-' || s[i] == '+' || s[i] == '.' || s[i] == 'e' || s[i] == 'E')) ++i;
+            if (b == i) fail("unexpected token");
+            j.kind = Json::Number; j.text = s.substr(b, i - b);
+        }
+        return j;
+    }
+};
+
+void write_f32(std::string& out, float v) {
+    if (!std::isfinite(v)) { out += "null"; return; }  // serde_json writes non-finite floats as null
+    char buf[32];
+    auto r = std::to_chars(buf, buf + sizeof buf, v);  // shortest representation that round-trips
+    std::string t(buf, r.ptr);
+    if (t.find_first_of(".en") == std::string::npos) t += ".0";  // serde_json keeps floats recognisable ("1.0")
+    out += t;
+}
+float read_f32(const Json& j) {
+    if (j.kind == Json::Null) return std::numeric_limits<float>::quiet_NaN();
+    if (j.kind != Json::Number) panic("json: number expected in \"data\"");
+    float v = 0.f;
+    auto r = std::from_chars(j.text.data(), j.text.data() + j.text.size(), v);  // correctly rounded, like Rust's parser
+    if (r.ec == std::errc::result_out_of_range) return j.text[0] == '-' ? -INFINITY : INFINITY;
+    if (r.ec != std::errc() || r.ptr != j.text.data() + j.text.size()) panic("json: bad number '" + j.text + "'");
+    return v;
+}
+std::string array_json(const Shape& shape, const std::vector<float>& data) {
+    std::string out = "{\"v\":1,\"dim\":[";
+    for (size_t i = 0; i < shape.size(); ++i) { if (i) out += ','; out += std::to_string(shape[i]); }
+    out += "],\"data\":[";
+    for (size_t i = 0; i < data.size(); ++i) { if (i) out += ','; write_f32(out, data[i]); }
+    out += "]}";
+    return out;
+}
+}  // namespace
+
+const Json& Json::at(const std::string& key) const {
+    for (const auto& m : members) if (m.first == key) return m.second;
+    panic("json: missing field `" + key + "`");
+}
+bool Json::has(const std::string& key) const {
+    for (const auto& m : members) if (m.first == key) return true;
+    return false;
+}
+Json parse(const std::string& text) {
+    Parser p(text);
+    Json j = p.value();
+    p.ws();
+    if (p.i != text.size()) p.fail("trailing characters");
+    return j;
+}
+
+std::string to_json(const Var& v) { return array_json(v.shape(), v.to_vec()); }
+std::string to_json(const VarDiff& v) { return array_json(v.shape(), v.to_vec()); }
+
+Var var_from_json(DevicePtr dev, const Json& j) {
+    if (j.kind != Json::Object) panic("json: ndarray object expected");
+    const Json& ver = j.at("v");
+    if (ver.kind != Json::Number || ver.text != "1") panic("json: unknown array version");  // ndarray's ARRAY_FORMAT_VERSION
+    const Json& dim = j.at("dim");
+    Shape shape;
+    if (dim.kind == Json::Array) {
+        for (const Json& d : dim.items) {
+            if (d.kind != Json::Number) panic("json: bad dim");
+            shape.push_back(std::stoi(d.text));
+        }
+    } else if (dim.kind == Json::Number) {  // Ix1 may also be written as a bare integer by serde tuples of one
+        shape.push_back(std::stoi(dim.text));
+    } else {
+        panic("json: bad dim");
+    }
+    const Json& data = j.at("data");
+    if (data.kind != Json::Array) panic("json: bad data");
+    if (data.items.size() != numel(shape)) panic("json: data length does not match dim");  // ndarray: "data and dimension must match in size"
+    std::vector<float> host(data.items.size());
+    for (size_t i = 0; i < host.size(); ++i) host[i] = read_f32(data.items[i]);
+    return from_host(std::move(dev), shape, host.data());
+}
+Var var_from_json(DevicePtr dev, const std::string& text) { return var_from_json(std::move(dev), parse(text)); }
+VarDiff vardiff_from_json(DevicePtr dev, const Json& j) { return var_from_json(std::move(dev), j).requires_grad(); }
+VarDiff vardiff_from_json(DevicePtr dev, const std::string& text) { return vardiff_from_json(std::move(dev), parse(text)); }
+
+std::string to_json(const nn::Linear& l) { return "{\"weight\":" + to_json(l.weight) + ",\"bias\":" + to_json(l.bias) + "}"; }
+nn::Linear linear_from_json(DevicePtr dev, const Json& j) {
+    return nn::Linear(vardiff_from_json(dev, j.at("weight")), vardiff_from_json(dev, j.at("bias")));
+}
+nn::Linear linear_from_json(DevicePtr dev, const std::string& text) { return linear_from_json(std::move(dev), parse(text)); }
+
+}  // namespace serde
 
 // =================================================================================================
 // optim

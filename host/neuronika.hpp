@@ -456,6 +456,38 @@ struct MultiheadAttention {
 }  // namespace nn
 
 // ---------------------------------------------------------------------------------------------
+// neuronika-variable/src/serde.rs:10-58 — (de)serialisation of leaves in ndarray's serde wire format
+//   {"v":1,"dim":[d0,d1,...],"data":[row-major f32 values]}
+// `Var`/`VarDiff` serialise their data (D2H copy); deserialising creates a leaf (`VarDiff`: a leaf with
+// `requires_grad()`).  Modules serialise as objects of their parameters, like `#[derive(Serialize)]` on
+// the reference structs (neuronika-nn/src/lib.rs:397-404: {"weight":..., "bias":...}).
+// ---------------------------------------------------------------------------------------------
+namespace serde {
+
+struct Json {  // minimal JSON document model (object keys keep their order)
+    enum Kind { Null, Bool, Number, String, Array, Object } kind = Null;
+    bool b = false;
+    std::string text;  // number literal or string value
+    std::vector<Json> items;
+    std::vector<std::pair<std::string, Json>> members;
+    const Json& at(const std::string& key) const;
+    bool has(const std::string& key) const;
+};
+Json parse(const std::string& text);
+
+std::string to_json(const Var& v);
+std::string to_json(const VarDiff& v);
+Var var_from_json(DevicePtr dev, const Json& j);
+Var var_from_json(DevicePtr dev, const std::string& text);
+VarDiff vardiff_from_json(DevicePtr dev, const Json& j);
+VarDiff vardiff_from_json(DevicePtr dev, const std::string& text);
+std::string to_json(const nn::Linear& l);
+nn::Linear linear_from_json(DevicePtr dev, const Json& j);
+nn::Linear linear_from_json(DevicePtr dev, const std::string& text);
+
+}  // namespace serde
+
+// ---------------------------------------------------------------------------------------------
 // neuronika-optim: Optimizer / StochasticGD (optimizer.rs:33-95, sgd/mod.rs:186-236)
 // ---------------------------------------------------------------------------------------------
 namespace optim {

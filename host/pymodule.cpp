@@ -5,6 +5,7 @@
 #include <pybind11/stl.h>
 
 #include "neuronika.hpp"
+#include "data.hpp"
 
 namespace py = pybind11;
 using namespace neuronika;
@@ -143,6 +144,87 @@ PYBIND11_MODULE(_tape, m) {
     m.def("ones", &ones);
     m.def("full", &full);
     m.def("rand", &neuronika::rand);
+
+    {   // neuronika-data mirror + device input pipeline
+        namespace nd = neuronika::data;
+        py::module_ dm = m.def_submodule("data");
+        auto to_np = [](const nd::HostArray& a) {
+            std::vector<py::ssize_t> shape(a.shape().begin(), a.shape().end());
+            Arr out(shape);
+            if (a.len()) std::memcpy(out.mutable_data(), a.ptr(), a.len() * sizeof(float));
+            return out;
+        };
+        auto from_np = [](const Arr& a) { return nd::HostArray(shape_of(a), a.data()); };
+        dm.def("batch_ranges", [](size_t len, size_t size, bool drop_last) {
+            std::vector<std::pair<size_t, size_t>> out;
+            for (const auto& r : nd::batch_ranges(len, size, drop_last)) out.emplace_back(r.start, r.rows);
+            return out;
+        });
+        dm.def("kfold_ids", [](size_t len, size_t k) {
+            std::vector<std::pair<std::vector<size_t>, std::vector<size_t>>> out;
+            for (const auto& f : nd::kfold_ids(len, k)) out.emplace_back(f.train_ids, f.test_ids);
+            return out;
+        });
+        dm.def("shuffle_permutation", &nd::shuffle_permutation);
+        py::class_<nd::Dataset>(dm, "Dataset")
+            .def(py::init([from_np](const Arr& a) { return new nd::Dataset(from_np(a)); }))
+            .def("records", [to_np](const nd::Dataset& d) { return to_np(d.records()); })
+            .def("pinned", [](const nd::Dataset& d) { return d.records().pinned(); })
+            .def("__len__", &nd::Dataset::len).def("is_empty", &nd::Dataset::is_empty)
+            .def("kfold", &nd::Dataset::kfold)
+            .def("batch", [to_np](const nd::Dataset& d, size_t n, bool drop_last) {
+                std::vector<Arr> out;
+                for (const auto& b : d.batch(n, drop_last)) out.push_back(to_np(b));
+                return out;
+            }, py::arg("size"), py::arg("drop_last") = false)
+            .def("split", &nd::Dataset::split)
+            .def("shuffle_with_seed", [](nd::Dataset& d, uint64_t seed) { d.shuffle_with_seed(seed); });
+        py::class_<nd::LabeledDataset>(dm, "LabeledDataset")
+            .def(py::init([from_np](const Arr& r, const Arr& l) { return new nd::LabeledDataset(from_np(r), from_np(l)); }))
+            .def("records", [to_np](const nd::LabeledDataset& d) { return to_np(d.records()); })
+            .def("labels", [to_np](const nd::LabeledDataset& d) { return to_np(d.labels()); })
+            .def("__len__", &nd::LabeledDataset::len).def("is_empty", &nd::LabeledDataset::is_empty)
+            .def("kfold", &nd::LabeledDataset::kfold)
+            .def("batch", [to_np](const nd::LabeledDataset& d, size_t n, bool drop_last) {
+                std::vector<std::pair<Arr, Arr>> out;
+                for (const auto& b : d.batch(n, drop_last)) out.emplace_back(to_np(b.first), to_np(b.second));
+                return out;
+            }, py::arg("size"), py::arg("drop_last") = false)
+            .def("split", &nd::LabeledDataset::split)
+            .def("shuffle_with_seed", [](nd::LabeledDataset& d, uint64_t seed) { d.shuffle_with_seed(seed); });
+        py::class_<nd::DataLoader>(dm, "DataLoader")
+            .def(py::init<>())
+            .def("without_headers", [](nd::DataLoader& l) { l.without_headers(); return l; })
+            .def("with_delimiter", [](nd::DataLoader& l, char d) { l.with_delimiter(d); return l; })
+            .def("with_labels", &nd::DataLoader::with_labels)
+            .def("from_csv", &nd::DataLoader::from_csv)
+            .def("from_string", &nd::DataLoader::from_string);
+        py::class_<nd::LabeledDataLoader>(dm, "LabeledDataLoader")
+            .def("without_headers", [](nd::LabeledDataLoader& l) { l.without_headers(); return l; })
+            .def("with_delimiter", [](nd::LabeledDataLoader& l, char d) { l.with_delimiter(d); return l; })
+            .def("from_csv", &nd::LabeledDataLoader::from_csv)
+            .def("from_string", &nd::LabeledDataLoader::from_string);
+        py::class_<nd::DeviceLoader>(dm, "DeviceLoader")
+            .def(py::init<DevicePtr, const nd::LabeledDataset&, size_t, bool>(), py::arg("dev"), py::arg("dataset"),
+                 py::arg("batch_size"), py::arg("drop_last") = true)
+            .def(py::init<DevicePtr, const nd::Dataset&, size_t, bool>(), py::arg("dev"), py::arg("dataset"),
+                 py::arg("batch_size"), py::arg("drop_last") = true)
+            .def("batches", &nd::DeviceLoader::batches)
+            .def("next_into", [](nd::DeviceLoader& l, const Var& x) { return l.next_into(x, nullptr); })
+            .def("next_into", [](nd::DeviceLoader& l, const Var& x, const Var& y) { return l.next_into(x, &y); })
+            .def("next", [](nd::DeviceLoader& l) {
+                auto b = l.next();
+                return py::make_tuple(b.rows, b.rows ? py::cast(b.x) : py::none(), (b.rows && b.y.data) ? py::cast(b.y) : py::none());
+            });
+    }
+
+    py::module_ sd = m.def_submodule("serde");
+    sd.def("to_json", py::overload_cast<const Var&>(&serde::to_json));
+    sd.def("to_json", py::overload_cast<const VarDiff&>(&serde::to_json));
+    sd.def("to_json", py::overload_cast<const nn::Linear&>(&serde::to_json));
+    sd.def("var_from_json", py::overload_cast<DevicePtr, const std::string&>(&serde::var_from_json));
+    sd.def("vardiff_from_json", py::overload_cast<DevicePtr, const std::string&>(&serde::vardiff_from_json));
+    sd.def("linear_from_json", py::overload_cast<DevicePtr, const std::string&>(&serde::linear_from_json));
 
     py::module_ nn = m.def_submodule("nn");
     py::class_<nn::Linear>(nn, "Linear")

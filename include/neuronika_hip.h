@@ -85,10 +85,18 @@ int nk_download(nk_device* dev, float* host_dst, const float* src, size_t n);
 int nk_fill(nk_device* dev, float* ptr, size_t n, float value);
 int nk_copy(nk_device* dev, float* dst, const float* src, size_t n);
 
+/* H2D input pipeline = the device half of `for batch in dataset.batch(n)` (neuronika-data/src/lib.rs:81,570):
+ * page-locked host staging + a third (copy) stream, so that the upload of batch k+1 overlaps the compute of
+ * batch k.  nk_upload_async returns immediately; order it against the compute stream with events recorded /
+ * waited on stream 2. */
+int nk_host_alloc(size_t bytes, void** out);
+int nk_host_free(void* ptr);
+int nk_upload_async(nk_device* dev, float* dst, const float* pinned_src, size_t n);
+
 /* ------------------------------------------------------------------ events ------------- */
 int nk_event_create(nk_device* dev, nk_event** out);
 int nk_event_destroy(nk_event* ev);
-int nk_event_record(nk_event* ev, int on_comm_stream); /* 0: compute stream, 1: comm stream */
+int nk_event_record(nk_event* ev, int on_comm_stream); /* 0: compute stream, 1: comm stream, 2: copy stream */
 int nk_event_sync(nk_event* ev);
 int nk_event_elapsed_ms(nk_event* start, nk_event* stop, float* ms);
 int nk_stream_wait_event(nk_device* dev, int on_comm_stream, nk_event* ev);

@@ -74,8 +74,9 @@ def build_tape(force: bool = False, verbose: bool = True) -> str:
     import pybind11
 
     host = os.path.join(ROOT, "host")
-    srcs = [os.path.join(host, "neuronika.cpp"), os.path.join(host, "pymodule.cpp")]
-    deps = srcs + [os.path.join(host, "neuronika.hpp"), os.path.join(ROOT, "include", "neuronika_hip.h")]
+    srcs = [os.path.join(host, "neuronika.cpp"), os.path.join(host, "data.cpp"), os.path.join(host, "pymodule.cpp")]
+    deps = srcs + [os.path.join(host, "neuronika.hpp"), os.path.join(host, "data.hpp"),
+                   os.path.join(ROOT, "include", "neuronika_hip.h")]
     ext = sysconfig.get_config_var("EXT_SUFFIX") or ".so"
     out = os.path.join(HERE, "_tape" + ext)
     if not force and os.path.exists(out) and os.path.getmtime(out) > max(os.path.getmtime(d) for d in deps):

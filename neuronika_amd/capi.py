@@ -55,6 +55,9 @@ _SIGS = {
     "nk_alloc_zeroed": [VP, C.c_size_t, C.POINTER(VP)],
     "nk_free": [VP, VP],
     "nk_upload": [VP, VP, VP, C.c_size_t],
+    "nk_host_alloc": [C.c_size_t, C.POINTER(C.c_void_p)],
+    "nk_host_free": [VP],
+    "nk_upload_async": [VP, VP, VP, C.c_size_t],
     "nk_download": [VP, VP, VP, C.c_size_t],
     "nk_fill": [VP, VP, C.c_size_t, C.c_float],
     "nk_copy": [VP, VP, VP, C.c_size_t],

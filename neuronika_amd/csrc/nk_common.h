@@ -20,6 +20,7 @@ struct nk_device {
     int idx = 0;
     hipStream_t compute = nullptr;  // tape-ordered kernels
     hipStream_t comm = nullptr;     // RCCL all-reduce (side stream)
+    hipStream_t copy = nullptr;     // H2D input pipeline (pinned staging, overlaps compute)
     hipEvent_t fork = nullptr;      // compute -> comm ordering helper
     hipEvent_t join = nullptr;      // comm -> compute ordering helper
     void* workspace = nullptr;      // stream-ordered scratch (split-K slabs, reduction partials)
@@ -37,7 +38,7 @@ int nk_prof_stop(nk_device* dev);
 
 struct nk_event {  // self-contained: stays valid (for destroy) after its device handle is gone
     int idx;
-    hipStream_t compute, comm;
+    hipStream_t compute, comm, copy;
     hipEvent_t ev;
 };
 

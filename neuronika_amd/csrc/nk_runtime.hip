@@ -106,6 +106,7 @@ int nk_device_create(int idx, nk_device** out) {
     d->idx = idx;
     NK_HIP(hipStreamCreateWithFlags(&d->compute, hipStreamNonBlocking));
     NK_HIP(hipStreamCreateWithFlags(&d->comm, hipStreamNonBlocking));
+    NK_HIP(hipStreamCreateWithFlags(&d->copy, hipStreamNonBlocking));
     NK_HIP(hipEventCreateWithFlags(&d->fork, hipEventDisableTiming));
     NK_HIP(hipEventCreateWithFlags(&d->join, hipEventDisableTiming));
     hipDeviceProp_t prop;
@@ -126,6 +127,7 @@ int nk_device_destroy(nk_device* dev) {
     (void)hipEventDestroy(dev->join);
     (void)hipStreamDestroy(dev->compute);
     (void)hipStreamDestroy(dev->comm);
+    (void)hipStreamDestroy(dev->copy);
     delete dev;
     return NK_OK;
 }
@@ -134,6 +136,7 @@ int nk_device_sync(nk_device* dev) {
     NK_USE(dev);
     NK_HIP(hipStreamSynchronize(dev->compute));
     NK_HIP(hipStreamSynchronize(dev->comm));
+    NK_HIP(hipStreamSynchronize(dev->copy));
     return NK_OK;
 }
 
@@ -169,6 +172,27 @@ int nk_upload(nk_device* dev, float* dst, const float* host_src, size_t n) {
     return NK_OK;
 }
 
+int nk_host_alloc(size_t bytes, void** out) {
+    NK_CHECK(out != nullptr, "null out pointer");
+    *out = nullptr;
+    if (bytes == 0) return NK_OK;
+    NK_HIP(hipHostMalloc(out, bytes, hipHostMallocDefault));
+    return NK_OK;
+}
+
+int nk_host_free(void* p) {
+    if (p) NK_HIP(hipHostFree(p));
+    return NK_OK;
+}
+
+int nk_upload_async(nk_device* dev, float* dst, const float* pinned_src, size_t n) {
+    NK_USE(dev);
+    if (n == 0) return NK_OK;
+    NK_CHECK(dst && pinned_src, "null pointer in nk_upload_async");
+    NK_HIP(hipMemcpyAsync(dst, pinned_src, n * sizeof(float), hipMemcpyHostToDevice, dev->copy));
+    return NK_OK;
+}
+
 int nk_download(nk_device* dev, float* host_dst, const float* src, size_t n) {
     NK_USE(dev);
     if (n == 0) return NK_OK;
@@ -188,7 +212,7 @@ int nk_copy(nk_device* dev, float* dst, const float* src, size_t n) {
 int nk_event_create(nk_device* dev, nk_event** out) {
     NK_USE(dev);
     NK_CHECK(out != nullptr, "null out");
-    nk_event* e = new nk_event{dev->idx, dev->compute, dev->comm, nullptr};
+    nk_event* e = new nk_event{dev->idx, dev->compute, dev->comm, dev->copy, nullptr};
     NK_HIP(hipEventCreate(&e->ev));
     *out = e;
     return NK_OK;
@@ -205,7 +229,8 @@ int nk_event_destroy(nk_event* ev) {
 int nk_event_record(nk_event* ev, int on_comm_stream) {
     NK_CHECK(ev != nullptr, "null event");
     NK_HIP(hipSetDevice(ev->idx));
-    NK_HIP(hipEventRecord(ev->ev, on_comm_stream ? ev->comm : ev->compute));
+    NK_CHECK(on_comm_stream >= 0 && on_comm_stream <= 2, "unknown stream %d", on_comm_stream);
+    NK_HIP(hipEventRecord(ev->ev, on_comm_stream == 2 ? ev->copy : (on_comm_stream ? ev->comm : ev->compute)));
     return NK_OK;
 }
 
@@ -226,7 +251,8 @@ int nk_event_elapsed_ms(nk_event* start, nk_event* stop, float* ms) {
 int nk_stream_wait_event(nk_device* dev, int on_comm_stream, nk_event* ev) {
     NK_USE(dev);
     NK_CHECK(ev != nullptr, "null event");
-    NK_HIP(hipStreamWaitEvent(on_comm_stream ? dev->comm : dev->compute, ev->ev, 0));
+    NK_CHECK(on_comm_stream >= 0 && on_comm_stream <= 2, "unknown stream %d", on_comm_stream);
+    NK_HIP(hipStreamWaitEvent(on_comm_stream == 2 ? dev->copy : (on_comm_stream ? dev->comm : dev->compute), ev->ev, 0));
     return NK_OK;
 }
 

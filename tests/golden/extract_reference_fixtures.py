@@ -360,6 +360,29 @@ def other_cases():
     return c
 
 
+def data_cases():
+    """neuronika-data/src/test.rs: the CSV text of both modules and, per test, the `vec![..]` literals of its
+    assertions in source order (records / labels of kfold folds, batches, splits)."""
+    path = os.path.join(REF, "neuronika-data", "src", "test.rs")
+    src = open(path).read()
+    out = {}
+    for mod in ("dataset", "labeled_dataset"):
+        m = re.search(r"^mod\s+%s\s*\{" % mod, src, re.M)
+        body_start = m.end()
+        st = re.search(r'static DATASET: &str = "\\\n(.*?)";', src[body_start:], re.S)
+        csv = "".join(line.strip().rstrip("\\") for line in st.group(1).splitlines()).replace("\\n", "\n")
+        case = {"cite": f"neuronika-data/src/test.rs:{src.count(chr(10), 0, body_start) + 1}", "csv": csv, "tests": {}}
+        lab = re.search(r"with_labels\(&\[([0-9, ]+)\]\)", src[body_start:])
+        if mod == "labeled_dataset":
+            case["label_columns"] = _tuple(lab.group(1))
+        for fn in ("from_reader", "kfold", "batch", "split", "drop_last"):
+            body, l0 = _fn_body(src, fn, mod)
+            case["tests"][fn] = {"line": l0, "literals": [v for _, v in _literals(body, l0)],
+                                 "shapes": [_tuple(t) for t in re.findall(r"from_shape_vec\(\s*\(([0-9, ]+)\)", body)]}
+        out[mod] = case
+    return out
+
+
 def quickstart_weights():
     """The 3->5->5->1 MLP weights embedded as JSON in examples/quickstart.rs:53-169 (config C1)."""
     src = open(os.path.join(REF, "examples", "quickstart.rs")).read()
@@ -385,6 +408,7 @@ def main():
         "im2col": im2col,
         "nodes": other_cases(),
         "quickstart_mlp": quickstart_weights(),
+        "data": data_cases(),
     }
     with open(OUT, "w") as f:
         json.dump(fixtures, f, indent=1)

@@ -263,6 +263,74 @@ def test_pointwise_nodes_graph(nk, tdev):
     close(X.grad(), df, 2e-5, 1e-6)
 
 
+def test_device_loader_pipeline(nk, tdev):
+    """data::DeviceLoader: page-locked records, double-buffered uploads on the copy stream, batches arrive in
+    order and intact over several epochs (odd and even batch counts, ragged tail); the refilled leaves drive a
+    graph that was built once."""
+    rng = np.random.default_rng(0)
+    rec, lab = rng.random((70, 6, 5), dtype=np.float32), rng.random((70, 3), dtype=np.float32)
+    ds = nk.data.LabeledDataset(rec, lab)
+    for bs, drop in ((16, True), (16, False), (10, True), (70, True), (64, False)):
+        ranges = nk.data.batch_ranges(70, bs, drop)
+        ld = nk.data.DeviceLoader(tdev, ds, bs, drop)
+        assert ld.batches() == len(ranges)
+        X, Y = nk.zeros(tdev, [ranges[0][1], 6, 5]), nk.zeros(tdev, [ranges[0][1], 3])
+        for epoch in range(3):
+            for start, rows in ranges:
+                assert ld.next_into(X, Y) == rows
+                assert np.array_equal(X.data()[:rows], rec[start:start + rows])
+                assert np.array_equal(Y.data()[:rows], lab[start:start + rows])
+            assert ld.next_into(X, Y) == 0                                   # end of the epoch
+    ld = nk.data.DeviceLoader(tdev, nk.data.Dataset(rec), 32, False)
+    seen = []
+    while True:
+        rows, x, y = ld.next()
+        if rows == 0:
+            break
+        assert y is None and x.shape == [rows, 6, 5]
+        seen.append(x.data())
+    assert np.array_equal(np.concatenate(seen), rec)
+    # a graph built once, fed by the loader: per-batch loss equals the host computation
+    w = rng.random((3, 30), dtype=np.float32)
+    W = nk.from_ndarray(tdev, w).requires_grad()
+    ld = nk.data.DeviceLoader(tdev, ds, 35, True)
+    X, Y = nk.zeros(tdev, [35, 30]), nk.zeros(tdev, [35, 3])
+    loss = X.mm_t(W).mse(Y, nk.Reduction.Mean)
+    for start in (0, 35):
+        assert ld.next_into(X, Y) == 35
+        loss.forward()
+        ref = ((rec[start:start + 35].reshape(35, 30).astype(np.float64) @ w.T.astype(np.float64) - lab[start:start + 35]) ** 2).mean()
+        close(loss.item(), ref, 1e-5)
+
+
+def test_serde_wire_format(nk, tdev, golden):
+    """serde.rs:10-58: leaves travel as ndarray's {"v":1,"dim":[..],"data":[..]}; the quickstart model JSON
+    (examples/quickstart.rs:53-169) loads into nn::Linear, and to_json -> from_json is the identity on the bits."""
+    import json
+    q = golden["quickstart_mlp"]
+    for name in ("lin1", "lin2", "lin3"):
+        text = json.dumps({p: {"v": 1, "dim": q[f"{name}.{p}"]["dim"], "data": q[f"{name}.{p}"]["data"]} for p in ("weight", "bias")},
+                          indent=3)
+        lin = nk.serde.linear_from_json(tdev, text)
+        for p in ("weight", "bias"):
+            want = np.asarray(q[f"{name}.{p}"]["data"], np.float32).reshape(q[f"{name}.{p}"]["dim"])
+            assert np.array_equal(getattr(lin, p).data(), want)
+            assert getattr(lin, p).grad().shape == want.shape          # VarDiff leaves: requires_grad()
+        back = json.loads(nk.serde.to_json(lin))
+        assert list(back) == ["weight", "bias"] and back["weight"]["v"] == 1 and back["weight"]["dim"] == q[f"{name}.weight"]["dim"]
+        assert np.array_equal(np.asarray(back["weight"]["data"], np.float32).reshape(back["weight"]["dim"]), lin.weight.data())
+    x = np.array([[1.0, -0.0, 3.4028235e38], [1e-45, 0.1, -2.5]], np.float32)       # integral, signed zero, max, denormal
+    text = nk.serde.to_json(nk.from_ndarray(tdev, x))
+    assert text.startswith('{"v":1,"dim":[2,3],"data":[1.0,-0.0,')
+    y = nk.serde.var_from_json(tdev, text)
+    assert np.array_equal(y.data().view(np.uint32), x.view(np.uint32))
+    s0 = nk.serde.var_from_json(tdev, '{"v":1,"dim":[],"data":[2.5]}')
+    assert s0.shape == [] and s0.item() == 2.5
+    for bad in ('{"v":2,"dim":[1],"data":[0.0]}', '{"v":1,"dim":[2],"data":[0.0]}', '{"v":1,"dim":[1]}', '[1,2'):
+        with pytest.raises(RuntimeError, match="json"):
+            nk.serde.var_from_json(tdev, bad)
+
+
 def test_linear_fused_equals_two_nodes(nk, tdev):
     """nn::Linear as one node (bias in the GEMM epilogue, backward = the three reference accumulations) gives
     bit-identical values and gradients to the reference's mm_t + Addition nodes, for Var and VarDiff inputs."""
