@@ -51,6 +51,18 @@ float* Device::alloc_zeroed(size_t n) {
     in_use_ += n * sizeof(float);
     return p;
 }
+float* Device::alloc_uninit(size_t n) {
+    auto it = pool_.find(n);
+    float* p = nullptr;
+    if (it != pool_.end() && !it->second.empty()) {
+        p = it->second.back();
+        it->second.pop_back();
+    } else {
+        check(nk_alloc_zeroed(h_, n, &p));
+    }
+    in_use_ += n * sizeof(float);
+    return p;
+}
 void Device::release(float* p, size_t n) {
     if (!p) return;
     pool_[n].push_back(p);
@@ -59,6 +71,8 @@ void Device::release(float* p, size_t n) {
 
 HipArray::HipArray(DevicePtr dev, Shape shape)
     : dev_(std::move(dev)), shape_(std::move(shape)), len_(numel(shape_)), ptr_(dev_->alloc_zeroed(len_)) {}
+HipArray::HipArray(DevicePtr dev, Shape shape, Uninit)
+    : dev_(std::move(dev)), shape_(std::move(shape)), len_(numel(shape_)), ptr_(dev_->alloc_uninit(len_)) {}
 HipArray::~HipArray() { dev_->release(ptr_, len_); }
 std::shared_ptr<HipArray> HipArray::from_host(DevicePtr dev, const Shape& shape, const float* host) {
     auto a = std::make_shared<HipArray>(std::move(dev), shape);
@@ -75,15 +89,34 @@ std::vector<float> HipArray::to_vec() const {
 void HipArray::fill(float v) { check(nk_fill(dev_->raw(), ptr_, len_, v)); }
 
 Gradient::Gradient(DevicePtr dev, Shape shape)
-    : dev_(std::move(dev)), shape_(std::move(shape)), array_(std::make_shared<HipArray>(dev_, shape_)) {}
+    : dev_(std::move(dev)), shape_(std::move(shape)), array_(std::make_shared<HipArray>(dev_, shape_, HipArray::Uninit{})) {}
 HipArray& Gradient::borrow() const {
     if (!array_)
         panic("Trying to get a de-allocated gradient. Switch on the gradients first by using `.with_grad()`");
+    if (pending_zero_) {
+        array_->fill(0.f);
+        pending_zero_ = false;
+    }
     return *array_;
+}
+HipArray& Gradient::borrow_first_write(bool& assign) const {
+    if (!array_)
+        panic("Trying to get a de-allocated gradient. Switch on the gradients first by using `.with_grad()`");
+    assign = pending_zero_;
+    pending_zero_ = false;
+    return *array_;
+}
+void Gradient::zero() {
+    if (!array_)
+        panic("Trying to get a de-allocated gradient. Switch on the gradients first by using `.with_grad()`");
+    pending_zero_ = true;
 }
 void Gradient::no_grad() { array_.reset(); }
 void Gradient::with_grad() {
-    if (!array_) array_ = std::make_shared<HipArray>(dev_, shape_);
+    if (!array_) {
+        array_ = std::make_shared<HipArray>(dev_, shape_, HipArray::Uninit{});
+        pending_zero_ = true;
+    }
 }
 
 // =================================================================================================
@@ -174,6 +207,14 @@ struct BinaryBwd : Backward {  // <Op>Backward{Left,Right}; either side may be a
     }
 };
 
+// First-write access to a gradient: `beta` = 0 when its zero fill is still pending (the node assigns), 1 otherwise.
+static float* first_write(const Shared<Gradient>& gr, float& beta) {
+    bool assign = false;
+    HipArray& d = gr->borrow_first_write(assign);
+    beta = assign ? 0.f : 1.f;
+    return d.ptr();
+}
+
 enum class Unary { Relu, Softmax, LogSoftmax, Transpose, Sum, Mean };
 struct UnaryFwd : Forward {
     Unary kind;
@@ -198,11 +239,17 @@ struct UnaryBwd : Backward {
     Shared<Gradient> dx, g;
     Shared<HipArray> x, y;  // ReLU needs the input, (log)softmax the output
     void backward() const override {
-        HipArray& d = dx->borrow();
         const HipArray& G = g->borrow();
+        if (kind == Unary::Relu) {
+            bool assign = false;
+            HipArray& d = dx->borrow_first_write(assign);
+            check((assign ? nk_relu_bwd_assign : nk_relu_bwd)(D(x), d.ptr(), G.ptr(), x->ptr(), d.len()));
+            return;
+        }
+        HipArray& d = dx->borrow();
         const int nd = (int)d.shape().size();
         switch (kind) {
-            case Unary::Relu: check(nk_relu_bwd(D(x), d.ptr(), G.ptr(), x->ptr(), d.len())); break;
+            case Unary::Relu: break;
             case Unary::Softmax: check(nk_softmax_bwd(D(y), d.ptr(), G.ptr(), y->ptr(), d.shape().data(), nd, axis)); break;
             case Unary::LogSoftmax: check(nk_log_softmax_bwd(D(y), d.ptr(), G.ptr(), y->ptr(), d.shape().data(), nd, axis)); break;
             case Unary::Transpose: check(nk_transpose_bwd(d.device()->raw(), d.ptr(), G.ptr(), d.shape().data(), nd)); break;
@@ -255,28 +302,42 @@ struct MatMulBwd : Backward {
         } else if (kind == 6) {  // vector_vector_mul/mod.rs:57-63
             if (da) check(nk_vv_bwd(dev, da->borrow().ptr(), b->ptr(), G.ptr(), a->len()));
             if (db) check(nk_vv_bwd(dev, db->borrow().ptr(), a->ptr(), G.ptr(), a->len()));
-        } else if (kind == 0) {
-            if (da) check(nk_mm_bwd_left(dev, da->borrow().ptr(), G.ptr(), b->ptr(), as[0], as[1], bs[1]));
-            if (db) check(nk_mm_bwd_right(dev, db->borrow().ptr(), a->ptr(), G.ptr(), as[0], as[1], bs[1]));
-        } else if (kind == 1) {
-            if (da) check(nk_mm_t_bwd_left(dev, da->borrow().ptr(), G.ptr(), b->ptr(), as[0], as[1], bs[0]));
-            if (db) check(nk_mm_t_bwd_right(dev, db->borrow().ptr(), G.ptr(), a->ptr(), as[0], as[1], bs[0]));
+        } else if (kind == 0) {  // = nk_mm_bwd_left / nk_mm_bwd_right with beta 0 on a first write
+            const int n = as[0], m = as[1], o = bs[1];
+            float beta;
+            if (da) { float* d = first_write(da, beta); check(nk_sgemm(dev, 0, 1, n, m, o, 1.f, G.ptr(), o, b->ptr(), o, beta, d, m)); }
+            if (db) { float* d = first_write(db, beta); check(nk_sgemm(dev, 1, 0, m, o, n, 1.f, a->ptr(), m, G.ptr(), o, beta, d, o)); }
+        } else if (kind == 1) {  // = nk_mm_t_bwd_left / nk_mm_t_bwd_right
+            const int n = as[0], m = as[1], o = bs[0];
+            float beta;
+            if (da) { float* d = first_write(da, beta); check(nk_sgemm(dev, 0, 0, n, m, o, 1.f, G.ptr(), o, b->ptr(), m, beta, d, m)); }
+            if (db) { float* d = first_write(db, beta); check(nk_sgemm(dev, 1, 0, o, m, n, 1.f, G.ptr(), o, a->ptr(), m, beta, d, m)); }
         } else if (kind == 2) {
             const int B = as[0], n = as[1], m = as[2], o = bs[2];
-            if (da)  // dA[b] += G[b] . B[b]^T
+            float beta;
+            if (da) {  // dA[b] += G[b] . B[b]^T
+                float* d = first_write(da, beta);
                 check(nk_sgemm_batched(dev, 0, 1, n, m, o, 1.f, G.ptr(), o, (long long)n * o, 0, b->ptr(), o,
-                                       (long long)m * o, 0, 1.f, da->borrow().ptr(), m, (long long)n * m, 0, B, 1));
-            if (db)  // dB[b] += A[b]^T . G[b]
+                                       (long long)m * o, 0, beta, d, m, (long long)n * m, 0, B, 1));
+            }
+            if (db) {  // dB[b] += A[b]^T . G[b]
+                float* d = first_write(db, beta);
                 check(nk_sgemm_batched(dev, 1, 0, m, o, n, 1.f, a->ptr(), m, (long long)n * m, 0, G.ptr(), o,
-                                       (long long)n * o, 0, 1.f, db->borrow().ptr(), o, (long long)m * o, 0, B, 1));
+                                       (long long)n * o, 0, beta, d, o, (long long)m * o, 0, B, 1));
+            }
         } else {
             const int B = as[0], n = as[1], m = as[2], o = bs[1];
-            if (da)  // dA[b] += G[b] . B[b]
+            float beta;
+            if (da) {  // dA[b] += G[b] . B[b]
+                float* d = first_write(da, beta);
                 check(nk_sgemm_batched(dev, 0, 0, n, m, o, 1.f, G.ptr(), o, (long long)n * o, 0, b->ptr(), m,
-                                       (long long)o * m, 0, 1.f, da->borrow().ptr(), m, (long long)n * m, 0, B, 1));
-            if (db)  // dB[b] += G[b]^T . A[b]
+                                       (long long)o * m, 0, beta, d, m, (long long)n * m, 0, B, 1));
+            }
+            if (db) {  // dB[b] += G[b]^T . A[b]
+                float* d = first_write(db, beta);
                 check(nk_sgemm_batched(dev, 1, 0, o, m, n, 1.f, G.ptr(), o, (long long)n * o, 0, a->ptr(), m,
-                                       (long long)n * m, 0, 1.f, db->borrow().ptr(), m, (long long)o * m, 0, B, 1));
+                                       (long long)n * m, 0, beta, d, m, (long long)o * m, 0, B, 1));
+            }
         }
     }
     void targets(std::vector<const Gradient*>& out) const override {
@@ -337,8 +398,10 @@ struct PadBwd : Backward {
     Shared<Gradient> dx, g;
     std::vector<int> padding;
     void backward() const override {
-        HipArray& d = dx->borrow();
-        check(nk_pad_bwd(d.device()->raw(), (int)d.shape().size() - 2, d.ptr(), d.shape().data(), g->borrow().ptr(), padding.data()));
+        bool assign = false;
+        HipArray& d = dx->borrow_first_write(assign);
+        check((assign ? nk_pad_bwd_assign : nk_pad_bwd)(d.device()->raw(), (int)d.shape().size() - 2, d.ptr(), d.shape().data(),
+                                                        g->borrow().ptr(), padding.data()));
     }
     void targets(std::vector<const Gradient*>& out) const override { out.push_back(dx.get()); }
 };
@@ -394,9 +457,10 @@ struct AttnProbsBwd : Backward {
     uint64_t seed;
     Shared<uint64_t> last_offset;
     void backward() const override {
-        HipArray& d = dx->borrow();
+        bool assign = false;
+        HipArray& d = dx->borrow_first_write(assign);
         const int L = d.shape().back();
-        check(nk_scale_softmax_dropout_bwd(d.device()->raw(), d.ptr(), g->borrow().ptr(), probs->ptr(), nullptr,
+        check((assign ? nk_scale_softmax_dropout_bwd_assign : nk_scale_softmax_dropout_bwd)(d.device()->raw(), d.ptr(), g->borrow().ptr(), probs->ptr(), nullptr,
                                            (long long)(d.len() / (size_t)L), L, scale, p, *status ? 1 : 0, seed, *last_offset));
     }
     void targets(std::vector<const Gradient*>& out) const override { out.push_back(dx.get()); }
@@ -498,9 +562,11 @@ struct HeadsBwd : Backward {
     Shared<Gradient> dx, g;
     int B, S, H, dh;
     void backward() const override {
-        HipArray& d = dx->borrow();
-        check(split ? nk_split_heads_bwd(d.device()->raw(), d.ptr(), g->borrow().ptr(), B, S, H, dh)
-                    : nk_merge_heads_bwd(d.device()->raw(), d.ptr(), g->borrow().ptr(), B, S, H, dh));
+        bool assign = false;
+        HipArray& d = dx->borrow_first_write(assign);
+        auto fn = split ? (assign ? nk_split_heads_bwd_assign : nk_split_heads_bwd)
+                        : (assign ? nk_merge_heads_bwd_assign : nk_merge_heads_bwd);
+        check(fn(d.device()->raw(), d.ptr(), g->borrow().ptr(), B, S, H, dh));
     }
     void targets(std::vector<const Gradient*>& out) const override { out.push_back(dx.get()); }
 };
@@ -515,7 +581,9 @@ struct MseBwd : Backward {
     Shared<Gradient> dx, g;
     Reduction red;
     void backward() const override {
-        check(nk_mse_bwd(D(x), dx->borrow().ptr(), g->borrow().ptr(), x->ptr(), t->ptr(), x->len(), (int)red));
+        bool assign = false;
+        HipArray& d = dx->borrow_first_write(assign);
+        check((assign ? nk_mse_bwd_assign : nk_mse_bwd)(D(x), d.ptr(), g->borrow().ptr(), x->ptr(), t->ptr(), x->len(), (int)red));
     }
     void targets(std::vector<const Gradient*>& out) const override { out.push_back(dx.get()); }
 };
@@ -560,8 +628,9 @@ struct LinearBwd : Backward {
         nk_device* dev = D(x);
         const int n = x->shape()[0], m = x->shape()[1], o = w->shape()[0];
         // same order as MatrixMatrixMulTBackward (left, right) followed by AdditionBackwardRight
-        if (dx) check(nk_mm_t_bwd_left(dev, dx->borrow().ptr(), G.ptr(), w->ptr(), n, m, o));
-        check(nk_mm_t_bwd_right(dev, dw->borrow().ptr(), G.ptr(), x->ptr(), n, m, o));
+        float beta;  // nk_mm_t_bwd_left / nk_mm_t_bwd_right, with beta 0 when the gradient's zero fill is still pending
+        if (dx) { float* d = first_write(dx, beta); check(nk_sgemm(dev, 0, 0, n, m, o, 1.f, G.ptr(), o, w->ptr(), m, beta, d, m)); }
+        { float* d = first_write(dw, beta); check(nk_sgemm(dev, 1, 0, o, m, n, 1.f, G.ptr(), o, x->ptr(), m, beta, d, m)); }
         const int gs[2] = {n, o};
         check(nk_unbroadcast_add(dev, db->borrow().ptr(), &o, 1, G.ptr(), gs, 2));
     }
@@ -936,7 +1005,7 @@ VarDiff VarDiff::node(Var var, Shared<Gradient> grad, BackwardEntry op, History<
     v.history = std::move(h);
     return v;
 }
-void VarDiff::zero_grad() const { grad->borrow().fill(0.f); }
+void VarDiff::zero_grad() const { grad->zero(); }
 void VarDiff::forward() const {
     var.forward();
     auto& buffer = history.buffer_mut();
@@ -944,7 +1013,10 @@ void VarDiff::forward() const {
 }
 void VarDiff::backward(float seed, BackwardHook* hook) const {
     if (var.history.len() != var.history.buffer_len()) panic("Perhaps you forgot to call .forward()?");
-    grad->borrow().fill(seed);
+    {
+        bool assign = false;
+        grad->borrow_first_write(assign).fill(seed);  // `grad_mut().fill(seed)` vardiff.rs:133
+    }
     auto& buffer = history.buffer_mut();
     if (!hook) {
         for (auto it = buffer.rbegin(); it != buffer.rend(); ++it) it->op->backward();

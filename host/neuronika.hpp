@@ -62,6 +62,7 @@ class Device : public std::enable_shared_from_this<Device> {
     // Stream-ordered caching allocator: blocks released by graph buffers are re-used for later
     // allocations of the same size (all work runs in order on the compute stream).
     float* alloc_zeroed(size_t n);
+    float* alloc_uninit(size_t n);  // contents undefined (a gradient whose zero fill is still pending)
     void release(float* p, size_t n);
     size_t bytes_in_use() const { return in_use_; }
 
@@ -77,6 +78,8 @@ using DevicePtr = std::shared_ptr<Device>;
 class HipArray {
    public:
     HipArray(DevicePtr dev, Shape shape);  // `CuArray::zeroed`
+    struct Uninit {};
+    HipArray(DevicePtr dev, Shape shape, Uninit);  // undefined contents
     ~HipArray();
     HipArray(const HipArray&) = delete;
     HipArray& operator=(const HipArray&) = delete;
@@ -128,8 +131,15 @@ struct NoGrad {
 
 class Gradient : public NoGrad {
    public:
-    Gradient(DevicePtr dev, Shape shape);  // `ndarray_zeros`
+    // `ndarray_zeros` (gradient.rs:47-54).  The zero fill is LAZY: the buffer is allocated without a memset and
+    // `zero_pending()` stays true until somebody looks at it.  `borrow()` (read / `+=` access) materialises the
+    // zeros first; `borrow_first_write(assign)` hands a pending fill to a node that can ASSIGN instead of `+=`
+    // (`0 + v`, same values, no memset and no read of the destination).
+    Gradient(DevicePtr dev, Shape shape);
     HipArray& borrow() const;              // panics when de-allocated
+    HipArray& borrow_first_write(bool& assign) const;
+    void zero();                           // `zero_grad` (vardiff.rs:100-102), lazily
+    bool zero_pending() const { return pending_zero_; }
     Shared<HipArray> array() const { return array_; }
     const Shape& shape() const { return shape_; }
     void no_grad() override;
@@ -139,6 +149,7 @@ class Gradient : public NoGrad {
     DevicePtr dev_;
     Shape shape_;
     Shared<HipArray> array_;
+    mutable bool pending_zero_ = true;
 };
 
 // ---------------------------------------------------------------------------------------------

@@ -238,6 +238,23 @@ int nk_mse_fwd(nk_device* dev, const float* x, const float* target, size_t n, in
 int nk_mse_bwd(nk_device* dev, float* dx, const float* g, const float* x, const float* target,
                size_t n, int reduction);
 
+/* ------------------------------------------------------------------ first-write variants */
+/* The reference allocates every gradient zeroed (gradient.rs:47-54) and every backward node `+=`s into it.
+ * For the FIRST node writing into a gradient of the current pass, `0 + v` needs neither the memset nor the
+ * read of the destination: the `_assign` variants compute exactly what their `+=` twin computes on an all-zero
+ * destination, writing without reading (the GEMM-shaped nodes get the same through nk_sgemm's beta = 0).
+ * The tape (host `Gradient`) keeps the zero fill pending and hands it to the first writer. */
+int nk_relu_bwd_assign(nk_device* dev, float* dx, const float* g, const float* x, size_t n);
+int nk_mse_bwd_assign(nk_device* dev, float* dx, const float* g, const float* x, const float* target,
+                      size_t n, int reduction);
+int nk_pad_bwd_assign(nk_device* dev, int nd, float* dx, const int* x_shape, const float* g,
+                      const int* padding);
+int nk_split_heads_bwd_assign(nk_device* dev, float* dx, const float* g, int B, int S, int H, int dh);
+int nk_merge_heads_bwd_assign(nk_device* dev, float* dx, const float* g, int B, int S, int H, int dh);
+int nk_scale_softmax_dropout_bwd_assign(nk_device* dev, float* d_scores, const float* g_out,
+                                        const float* probs, const float* noise, long long rows, int L,
+                                        float scale, double p, int train, uint64_t seed, uint64_t offset);
+
 /* ------------------------------------------------------------------ loss criteria ------- */
 /* Element-pair criteria reducing to a scalar; x and target share `shape`.
  *   NK_LOSS_MAE             AbsoluteError        node/absolute_error/mod.rs:42-58, :93-123

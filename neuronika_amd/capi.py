@@ -101,6 +101,12 @@ _SIGS = {
     "nk_mean_bwd": [VP, VP, C.c_size_t, VP],
     "nk_mse_fwd": [VP, VP, VP, C.c_size_t, C.c_int, VP],
     "nk_mse_bwd": [VP, VP, VP, VP, VP, C.c_size_t, C.c_int],
+    "nk_relu_bwd_assign": [VP, VP, VP, VP, C.c_size_t],
+    "nk_mse_bwd_assign": [VP, VP, VP, VP, VP, C.c_size_t, C.c_int],
+    "nk_pad_bwd_assign": [VP, C.c_int, VP, c_intp, VP, c_intp],
+    "nk_split_heads_bwd_assign": [VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int],
+    "nk_merge_heads_bwd_assign": [VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int],
+    "nk_scale_softmax_dropout_bwd_assign": [VP, VP, VP, VP, VP, C.c_longlong, C.c_int, C.c_float, C.c_double, C.c_int, C.c_uint64, C.c_uint64],
     "nk_loss_fwd": [VP, C.c_int, VP, VP, c_intp, C.c_int, C.c_int, VP],
     "nk_loss_bwd": [VP, C.c_int, VP, VP, VP, VP, c_intp, C.c_int, C.c_int],
     "nk_nll_fwd": [VP, VP, VP, c_intp, C.c_int, C.c_int, VP],
@@ -369,8 +375,8 @@ def pad_mode_fwd(dev, x, y, padding, mode):
     check(fn(dev.h, x.ndim - 2, x.p, x.shape_c(), y.p, ints(padding)))
 
 
-def pad_bwd(dev, dx, g, padding):
-    check(lib.nk_pad_bwd(dev.h, dx.ndim - 2, dx.p, dx.shape_c(), g.p, ints(padding)))
+def pad_bwd(dev, dx, g, padding, assign=False):
+    check((lib.nk_pad_bwd_assign if assign else lib.nk_pad_bwd)(dev.h, dx.ndim - 2, dx.p, dx.shape_c(), g.p, ints(padding)))
 
 
 def binary_fwd(dev, op, out, l, r):
@@ -407,8 +413,8 @@ def relu_fwd(dev, x, y):
     check(lib.nk_relu_fwd(dev.h, x.p, y.p, x.size))
 
 
-def relu_bwd(dev, dx, g, x):
-    check(lib.nk_relu_bwd(dev.h, dx.p, g.p, x.p, x.size))
+def relu_bwd(dev, dx, g, x, assign=False):
+    check((lib.nk_relu_bwd_assign if assign else lib.nk_relu_bwd)(dev.h, dx.p, g.p, x.p, x.size))
 
 
 def sum_fwd(dev, x, out):
@@ -431,8 +437,8 @@ def mse_fwd(dev, x, t, out, reduction="mean"):
     check(lib.nk_mse_fwd(dev.h, x.p, t.p, x.size, REDUCTION[reduction], out.p))
 
 
-def mse_bwd(dev, dx, g, x, t, reduction="mean"):
-    check(lib.nk_mse_bwd(dev.h, dx.p, g.p, x.p, t.p, x.size, REDUCTION[reduction]))
+def mse_bwd(dev, dx, g, x, t, reduction="mean", assign=False):
+    check((lib.nk_mse_bwd_assign if assign else lib.nk_mse_bwd)(dev.h, dx.p, g.p, x.p, t.p, x.size, REDUCTION[reduction]))
 
 
 LOSS = {"mae": 0, "bce": 1, "bce_with_logits": 2, "kldiv": 3}
@@ -517,9 +523,9 @@ def scale_softmax_dropout_fwd(dev, scores, probs, out, noise, scale, p, train=Tr
                                            scores.size // L, L, scale, float(p), int(train), seed, offset))
 
 
-def scale_softmax_dropout_bwd(dev, d_scores, g_out, probs, noise, scale, p, train=True, seed=0, offset=0):
+def scale_softmax_dropout_bwd(dev, d_scores, g_out, probs, noise, scale, p, train=True, seed=0, offset=0, assign=False):
     L = probs.shape[-1]
-    check(lib.nk_scale_softmax_dropout_bwd(dev.h, d_scores.p, g_out.p, probs.p, noise.p if noise is not None else None,
+    check((lib.nk_scale_softmax_dropout_bwd_assign if assign else lib.nk_scale_softmax_dropout_bwd)(dev.h, d_scores.p, g_out.p, probs.p, noise.p if noise is not None else None,
                                            probs.size // L, L, scale, float(p), int(train), seed, offset))
 
 
@@ -557,16 +563,16 @@ def split_heads_fwd(dev, x, y, B, S, H, dh):
     check(lib.nk_split_heads_fwd(dev.h, x.p, y.p, B, S, H, dh))
 
 
-def split_heads_bwd(dev, dx, g, B, S, H, dh):
-    check(lib.nk_split_heads_bwd(dev.h, dx.p, g.p, B, S, H, dh))
+def split_heads_bwd(dev, dx, g, B, S, H, dh, assign=False):
+    check((lib.nk_split_heads_bwd_assign if assign else lib.nk_split_heads_bwd)(dev.h, dx.p, g.p, B, S, H, dh))
 
 
 def merge_heads_fwd(dev, x, y, B, S, H, dh):
     check(lib.nk_merge_heads_fwd(dev.h, x.p, y.p, B, S, H, dh))
 
 
-def merge_heads_bwd(dev, dx, g, B, S, H, dh):
-    check(lib.nk_merge_heads_bwd(dev.h, dx.p, g.p, B, S, H, dh))
+def merge_heads_bwd(dev, dx, g, B, S, H, dh, assign=False):
+    check((lib.nk_merge_heads_bwd_assign if assign else lib.nk_merge_heads_bwd)(dev.h, dx.p, g.p, B, S, H, dh))
 
 
 def _p(a):

@@ -452,23 +452,24 @@ __global__ void relu_fwd_kernel(const float* __restrict__ x, float* __restrict__
 }
 
 template <bool VEC>
-__global__ void relu_bwd_kernel(float* __restrict__ dx, const float* __restrict__ g, const float* __restrict__ x, size_t n) {
+__global__ void relu_bwd_kernel(float* __restrict__ dx, const float* __restrict__ g, const float* __restrict__ x, size_t n,
+                                int assign) {  // assign: dx is a freshly zeroed gradient -> write without reading it
     if (VEC) {
         const size_t n4 = n / 4;
         for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
             const float4 xv = reinterpret_cast<const float4*>(x)[i], gv = reinterpret_cast<const float4*>(g)[i];
-            float4 d = reinterpret_cast<float4*>(dx)[i];
+            float4 d = assign ? make_float4(0.f, 0.f, 0.f, 0.f) : reinterpret_cast<float4*>(dx)[i];
             d.x += xv.x > 0.f ? gv.x : 0.f * gv.x; d.y += xv.y > 0.f ? gv.y : 0.f * gv.y;
             d.z += xv.z > 0.f ? gv.z : 0.f * gv.z; d.w += xv.w > 0.f ? gv.w : 0.f * gv.w;
             reinterpret_cast<float4*>(dx)[i] = d;
         }
         if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
             const size_t i = n4 * 4 + threadIdx.x;
-            dx[i] += x[i] > 0.f ? g[i] : 0.f * g[i];
+            dx[i] = (assign ? 0.f : dx[i]) + (x[i] > 0.f ? g[i] : 0.f * g[i]);
         }
     } else {
         for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-            dx[i] += x[i] > 0.f ? g[i] : 0.f * g[i];
+            dx[i] = (assign ? 0.f : dx[i]) + (x[i] > 0.f ? g[i] : 0.f * g[i]);
     }
 }
 
@@ -754,16 +755,18 @@ int nk_relu_fwd(nk_device* dev, const float* x, float* y, size_t n) {
     return NK_OK;
 }
 
-int nk_relu_bwd(nk_device* dev, float* dx, const float* g, const float* x, size_t n) {
+static int relu_bwd(nk_device* dev, float* dx, const float* g, const float* x, size_t n, int assign) {
     NK_USE(dev);
     if (n == 0) return NK_OK;
     NK_CHECK(dx && g && x, "null pointer in nk_relu_bwd");
     const bool vec = al16(x) && al16(g) && al16(dx);
-    if (vec) hipLaunchKernelGGL((relu_bwd_kernel<true>), dim3(nk_stream_grid(n / 4 + 1, 256)), dim3(256), 0, dev->compute, dx, g, x, n);
-    else hipLaunchKernelGGL((relu_bwd_kernel<false>), dim3(nk_stream_grid(n, 256)), dim3(256), 0, dev->compute, dx, g, x, n);
+    if (vec) hipLaunchKernelGGL((relu_bwd_kernel<true>), dim3(nk_stream_grid(n / 4 + 1, 256)), dim3(256), 0, dev->compute, dx, g, x, n, assign);
+    else hipLaunchKernelGGL((relu_bwd_kernel<false>), dim3(nk_stream_grid(n, 256)), dim3(256), 0, dev->compute, dx, g, x, n, assign);
     NK_LAUNCH_CHECK();
     return NK_OK;
 }
+int nk_relu_bwd(nk_device* dev, float* dx, const float* g, const float* x, size_t n) { return relu_bwd(dev, dx, g, x, n, 0); }
+int nk_relu_bwd_assign(nk_device* dev, float* dx, const float* g, const float* x, size_t n) { return relu_bwd(dev, dx, g, x, n, 1); }
 
 int nk_sgd_step(nk_device* dev, float* w, float* grad, float* velocity, size_t n, float lr, float momentum,
                 float dampening, int nesterov, float l1, float l2) {

@@ -386,6 +386,13 @@ int nk_pad_bwd(nk_device* dev, int nd, float* dx, const int* x_shape, const floa
     for (int i = 0; i < nd; ++i) { gshape[2 + i] = x_shape[2 + i] + 2 * padding[i]; origin[2 + i] = padding[i]; }
     return subblock<0, true>(dev, dx, x_shape, const_cast<float*>(g), gshape, origin, nd + 2);  // dx += g[centre]
 }
+int nk_pad_bwd_assign(nk_device* dev, int nd, float* dx, const int* x_shape, const float* g, const int* padding) {
+    NK_CHECK(nd >= 1 && nd <= 3, "pad supports 1-3 spatial dims, got %d", nd);
+    int gshape[5], origin[5] = {0, 0, 0, 0, 0};
+    gshape[0] = x_shape[0]; gshape[1] = x_shape[1];
+    for (int i = 0; i < nd; ++i) { gshape[2 + i] = x_shape[2 + i] + 2 * padding[i]; origin[2 + i] = padding[i]; }
+    return subblock<0, false>(dev, dx, x_shape, const_cast<float*>(g), gshape, origin, nd + 2);  // dx = g[centre]
+}
 
 int nk_chunk_fwd(nk_device* dev, const float* x, const int* x_shape, float* y, const int* chunk_shape, int nd, int chunk_no) {
     int origin[NK_MAX_DIMS];
@@ -438,11 +445,17 @@ int nk_split_heads_fwd(nk_device* dev, const float* x, float* y, int B, int S, i
 int nk_split_heads_bwd(nk_device* dev, float* dx, const float* g, int B, int S, int H, int dh) {
     return heads<false, true>(dev, dx, const_cast<float*>(g), B, S, H, dh);
 }
+int nk_split_heads_bwd_assign(nk_device* dev, float* dx, const float* g, int B, int S, int H, int dh) {
+    return heads<false, false>(dev, dx, const_cast<float*>(g), B, S, H, dh);
+}
 int nk_merge_heads_fwd(nk_device* dev, const float* x, float* y, int B, int S, int H, int dh) {
     return heads<false, false>(dev, y, const_cast<float*>(x), B, S, H, dh);
 }
 int nk_merge_heads_bwd(nk_device* dev, float* dx, const float* g, int B, int S, int H, int dh) {
     return heads<true, true>(dev, const_cast<float*>(g), dx, B, S, H, dh);
+}
+int nk_merge_heads_bwd_assign(nk_device* dev, float* dx, const float* g, int B, int S, int H, int dh) {
+    return heads<true, false>(dev, const_cast<float*>(g), dx, B, S, H, dh);
 }
 
 }  // extern "C"

@@ -52,11 +52,11 @@ __global__ void reduce_final_kernel(const float* __restrict__ part, int nparts, 
 // MODE 3: dx += (2*(x-t))*g         (SquaredErrorBackward, Sum)
 template <int MODE>
 __global__ void scalar_bwd_kernel(float* __restrict__ dx, const float* __restrict__ gs, const float* __restrict__ x,
-                                  const float* __restrict__ t, size_t n, float den) {
+                                  const float* __restrict__ t, size_t n, float den, int assign) {
     const float g = gs[0];
     const size_t n4 = n / 4;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-        float4 d = reinterpret_cast<float4*>(dx)[i];
+        float4 d = assign ? make_float4(0.f, 0.f, 0.f, 0.f) : reinterpret_cast<float4*>(dx)[i];
         if (MODE == 0) { d.x += g; d.y += g; d.z += g; d.w += g; }
         if (MODE == 1) { const float v = g / den; d.x += v; d.y += v; d.z += v; d.w += v; }
         if (MODE >= 2) {
@@ -73,10 +73,11 @@ __global__ void scalar_bwd_kernel(float* __restrict__ dx, const float* __restric
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
         const size_t i = n4 * 4 + threadIdx.x;
-        if (MODE == 0) dx[i] += g;
-        if (MODE == 1) dx[i] += g / den;
-        if (MODE == 2) dx[i] += (2.f * (x[i] - t[i])) * g / den;
-        if (MODE == 3) dx[i] += (2.f * (x[i] - t[i])) * g;
+        const float d0 = assign ? 0.f : dx[i];
+        if (MODE == 0) dx[i] = d0 + g;
+        if (MODE == 1) dx[i] = d0 + g / den;
+        if (MODE == 2) dx[i] = d0 + (2.f * (x[i] - t[i])) * g / den;
+        if (MODE == 3) dx[i] = d0 + (2.f * (x[i] - t[i])) * g;
     }
 }
 
@@ -99,12 +100,12 @@ int full_reduce(nk_device* dev, const float* x, const float* t, size_t n, float 
 }
 
 template <int MODE>
-int scalar_bwd(nk_device* dev, float* dx, const float* g, const float* x, const float* t, size_t n, float den) {
+int scalar_bwd(nk_device* dev, float* dx, const float* g, const float* x, const float* t, size_t n, float den, int assign = 0) {
     NK_USE(dev);
     if (n == 0) return NK_OK;
     NK_CHECK(dx && g, "null pointer");
     NK_CHECK(al16(dx) && (MODE < 2 || (al16(x) && al16(t))), "gradient buffers must be 16-byte aligned");
-    hipLaunchKernelGGL((scalar_bwd_kernel<MODE>), dim3(nk_stream_grid(n / 4 + 1, 256)), dim3(256), 0, dev->compute, dx, g, x, t, n, den);
+    hipLaunchKernelGGL((scalar_bwd_kernel<MODE>), dim3(nk_stream_grid(n / 4 + 1, 256)), dim3(256), 0, dev->compute, dx, g, x, t, n, den, assign);
     NK_LAUNCH_CHECK();
     return NK_OK;
 }
@@ -324,7 +325,7 @@ __global__ void attn_probs_fwd_kernel(const float* __restrict__ s, float* __rest
 template <int V, int MASK, bool LOAD_NOISE>
 __global__ void attn_probs_bwd_kernel(float* __restrict__ ds, const float* __restrict__ g, const float* __restrict__ probs,
                                       const float* __restrict__ noise, long long rows, int L, float scale, float keep,
-                                      unsigned long long seed, unsigned long long offset) {
+                                      unsigned long long seed, unsigned long long offset, int assign) {
     const int lane = threadIdx.x & 63;
     const long long row = blockIdx.x * (long long)(blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -357,7 +358,7 @@ __global__ void attn_probs_bwd_kernel(float* __restrict__ ds, const float* __res
     for (int i = 0; i < V; ++i) {
         const int c = (i * 64 + lane) * 4;
         if (c < L) {
-            float4 d = *reinterpret_cast<float4*>(ds + rb + c);
+            float4 d = assign ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<float4*>(ds + rb + c);
             d.x += (y[i].x * (gp[i].x - dot)) * scale;   // SoftmaxBackward then MultiplicationBackwardLeft
             d.y += (y[i].y * (gp[i].y - dot)) * scale;
             d.z += (y[i].z * (gp[i].z - dot)) * scale;
@@ -450,11 +451,17 @@ int nk_mse_fwd(nk_device* dev, const float* x, const float* target, size_t n, in
     return full_reduce<1>(dev, x, target, n, reduction == NK_REDUCTION_MEAN ? (float)n : 0.f, out);
 }
 
-int nk_mse_bwd(nk_device* dev, float* dx, const float* g, const float* x, const float* target, size_t n, int reduction) {
+static int mse_bwd(nk_device* dev, float* dx, const float* g, const float* x, const float* target, size_t n, int reduction, int assign) {
     NK_CHECK(reduction == NK_REDUCTION_SUM || reduction == NK_REDUCTION_MEAN, "unknown reduction %d", reduction);
     NK_CHECK(n == 0 || (x && target), "null input/target");
-    return reduction == NK_REDUCTION_MEAN ? scalar_bwd<2>(dev, dx, g, x, target, n, (float)n)
-                                          : scalar_bwd<3>(dev, dx, g, x, target, n, 1.f);
+    return reduction == NK_REDUCTION_MEAN ? scalar_bwd<2>(dev, dx, g, x, target, n, (float)n, assign)
+                                          : scalar_bwd<3>(dev, dx, g, x, target, n, 1.f, assign);
+}
+int nk_mse_bwd(nk_device* dev, float* dx, const float* g, const float* x, const float* target, size_t n, int reduction) {
+    return mse_bwd(dev, dx, g, x, target, n, reduction, 0);
+}
+int nk_mse_bwd_assign(nk_device* dev, float* dx, const float* g, const float* x, const float* target, size_t n, int reduction) {
+    return mse_bwd(dev, dx, g, x, target, n, reduction, 1);
 }
 
 int nk_softmax_fwd(nk_device* dev, const float* x, float* y, const int* shape, int nd, int axis) {
@@ -496,9 +503,10 @@ int nk_scale_softmax_dropout_fwd(nk_device* dev, const float* scores, float* pro
     return NK_OK;
 }
 
-int nk_scale_softmax_dropout_bwd(nk_device* dev, float* d_scores, const float* g_out, const float* probs,
-                                 const float* noise, long long rows, int L, float scale, double p, int train,
-                                 uint64_t seed, uint64_t offset) {
+}  // extern "C"
+
+static int attn_probs_bwd(nk_device* dev, float* d_scores, const float* g_out, const float* probs, const float* noise,
+                          long long rows, int L, float scale, double p, int train, uint64_t seed, uint64_t offset, int assign) {
     NK_USE(dev);
     NK_CHECK(p >= 0.0 && p <= 1.0, "Wrong probability received: %g.", p);
     NK_CHECK(rows >= 0 && L >= 0, "negative extent");
@@ -512,9 +520,9 @@ int nk_scale_softmax_dropout_bwd(nk_device* dev, float* d_scores, const float* g
     const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
 #define NK_AP(V)                                                                                                   \
     do {                                                                                                           \
-        if (!masked) hipLaunchKernelGGL((attn_probs_bwd_kernel<V, 0, false>), grid, block, 0, dev->compute, d_scores, g_out, probs, noise, rows, L, scale, keep, (unsigned long long)seed, (unsigned long long)offset); \
-        else if (noise && keep >= 0.f) hipLaunchKernelGGL((attn_probs_bwd_kernel<V, 1, true>), grid, block, 0, dev->compute, d_scores, g_out, probs, noise, rows, L, scale, keep, (unsigned long long)seed, (unsigned long long)offset); \
-        else hipLaunchKernelGGL((attn_probs_bwd_kernel<V, 1, false>), grid, block, 0, dev->compute, d_scores, g_out, probs, noise, rows, L, scale, keep, (unsigned long long)seed, (unsigned long long)offset); \
+        if (!masked) hipLaunchKernelGGL((attn_probs_bwd_kernel<V, 0, false>), grid, block, 0, dev->compute, d_scores, g_out, probs, noise, rows, L, scale, keep, (unsigned long long)seed, (unsigned long long)offset, assign); \
+        else if (noise && keep >= 0.f) hipLaunchKernelGGL((attn_probs_bwd_kernel<V, 1, true>), grid, block, 0, dev->compute, d_scores, g_out, probs, noise, rows, L, scale, keep, (unsigned long long)seed, (unsigned long long)offset, assign); \
+        else hipLaunchKernelGGL((attn_probs_bwd_kernel<V, 1, false>), grid, block, 0, dev->compute, d_scores, g_out, probs, noise, rows, L, scale, keep, (unsigned long long)seed, (unsigned long long)offset, assign); \
     } while (0)
     if (L <= 256) NK_AP(1); else if (L <= 512) NK_AP(2); else if (L <= 1024) NK_AP(4); else NK_AP(8);
 #undef NK_AP
@@ -522,4 +530,15 @@ int nk_scale_softmax_dropout_bwd(nk_device* dev, float* d_scores, const float* g
     return NK_OK;
 }
 
+extern "C" {
+int nk_scale_softmax_dropout_bwd(nk_device* dev, float* d_scores, const float* g_out, const float* probs,
+                                 const float* noise, long long rows, int L, float scale, double p, int train,
+                                 uint64_t seed, uint64_t offset) {
+    return attn_probs_bwd(dev, d_scores, g_out, probs, noise, rows, L, scale, p, train, seed, offset, 0);
+}
+int nk_scale_softmax_dropout_bwd_assign(nk_device* dev, float* d_scores, const float* g_out, const float* probs,
+                                        const float* noise, long long rows, int L, float scale, double p, int train,
+                                        uint64_t seed, uint64_t offset) {
+    return attn_probs_bwd(dev, d_scores, g_out, probs, noise, rows, L, scale, p, train, seed, offset, 1);
+}
 }  // extern "C"

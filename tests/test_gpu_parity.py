@@ -584,6 +584,43 @@ def test_unary_fwd_bwd(dev, golden, op):
         assert np.array_equal(D.numpy(), f32([0.01, 5.0, 0.01, 0.01]))
 
 
+# ------------------------------------------------------------------------------ first-write (_assign) variants
+def test_assign_variants_equal_accumulate_into_zeros(dev):
+    """Every `_assign` entry point writes, without reading the destination, exactly what its `+=` twin leaves in an
+    all-zero destination (the destination is pre-filled with NaN to prove it is not read)."""
+    c = capi()
+    nan = lambda shape: dev.full(shape, float("nan"))
+    x, g, t = rnd(1, (67, 129), -1, 1), rnd(2, (67, 129), -1, 1), rnd(3, (67, 129), -1, 1)
+    X, G, T = dev.array(x), dev.array(g), dev.array(t)
+    A, Z = nan(x.shape), dev.zeros(x.shape)
+    c.relu_bwd(dev, A, G, X, assign=True); c.relu_bwd(dev, Z, G, X)
+    assert np.array_equal(A.numpy(), Z.numpy())
+    gs = dev.array(np.array(0.7, np.float32))
+    for red in ("mean", "sum"):
+        A, Z = nan(x.shape), dev.zeros(x.shape)
+        c.mse_bwd(dev, A, gs, X, T, red, assign=True); c.mse_bwd(dev, Z, gs, X, T, red)
+        assert np.array_equal(A.numpy(), Z.numpy())
+    gp = rnd(4, (3, 4, 9, 14))
+    A, Z = nan((3, 4, 7, 8)), dev.zeros((3, 4, 7, 8))
+    c.pad_bwd(dev, A, dev.array(gp), (1, 3), assign=True); c.pad_bwd(dev, Z, dev.array(gp), (1, 3))
+    assert np.array_equal(A.numpy(), Z.numpy())
+    B, S, H, dh = 2, 10, 3, 8
+    gh, gf = rnd(5, (B * H, S, dh)), rnd(6, (B * S, H * dh))
+    A, Z = nan((B * S, H * dh)), dev.zeros((B * S, H * dh))
+    c.split_heads_bwd(dev, A, dev.array(gh), B, S, H, dh, assign=True); c.split_heads_bwd(dev, Z, dev.array(gh), B, S, H, dh)
+    assert np.array_equal(A.numpy(), Z.numpy())
+    A, Z = nan((B * H, S, dh)), dev.zeros((B * H, S, dh))
+    c.merge_heads_bwd(dev, A, dev.array(gf), B, S, H, dh, assign=True); c.merge_heads_bwd(dev, Z, dev.array(gf), B, S, H, dh)
+    assert np.array_equal(A.numpy(), Z.numpy())
+    sc = rnd(7, (6, 40, 64), -2, 2)
+    Sx, P, O_, Gs = dev.array(sc), dev.zeros(sc.shape), dev.zeros(sc.shape), dev.array(rnd(8, sc.shape, -1, 1))
+    c.scale_softmax_dropout_fwd(dev, Sx, P, O_, None, 0.125, 0.2, True, 11, 5)
+    A, Z = nan(sc.shape), dev.zeros(sc.shape)
+    c.scale_softmax_dropout_bwd(dev, A, Gs, P, None, 0.125, 0.2, True, 11, 5, assign=True)
+    c.scale_softmax_dropout_bwd(dev, Z, Gs, P, None, 0.125, 0.2, True, 11, 5)
+    assert np.array_equal(A.numpy(), Z.numpy())
+
+
 # ------------------------------------------------------------------------------ fused Linear forward
 @pytest.mark.parametrize("n,m,o", [(64, 3, 5), (4, 8, 1), (128, 128, 128), (300, 77, 200), (8, 4096, 64), (512, 256, 384)])
 def test_linear_fwd_equals_mm_t_plus_bias(dev, n, m, o):

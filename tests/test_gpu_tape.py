@@ -263,6 +263,35 @@ def test_pointwise_nodes_graph(nk, tdev):
     close(X.grad(), df, 2e-5, 1e-6)
 
 
+def test_lazy_zero_gradients(nk, tdev):
+    """Gradients are born with a PENDING zero fill (gradient.rs:47-54 semantics, no memset): an untouched gradient
+    reads as zeros, the first writer assigns, later writers accumulate, zero_grad() makes the fill pending again,
+    and a gradient fed by two branches still sums both."""
+    x = rnd(1, (5, 4), -1, 1)
+    X = nk.from_ndarray(tdev, x).requires_grad()
+    U = nk.from_ndarray(tdev, x).requires_grad()                 # never used in a graph
+    assert np.array_equal(U.grad(), np.zeros_like(x))
+    y = (X.relu() + X.relu() * 2.0).sum()                        # two ReLU nodes write into X.grad
+    y.forward(); y.backward(1.0)
+    m = (x > 0).astype(np.float32)
+    close(X.grad(), 3 * m)
+    y.backward(1.0)                                              # no zero_grad: leaves keep accumulating
+    g2 = X.grad()
+    assert g2[m > 0].min() >= 6.0                                # (intermediates accumulate too: reference behaviour)
+    X.zero_grad()
+    y.no_grad(); y.with_grad()
+    y.backward(1.0)
+    close(X.grad(), 3 * m)
+    w = rnd(2, (4, 4), -1, 1)
+    W = nk.from_ndarray(tdev, w).requires_grad()
+    z = X.mm(W).mm(W).sum()                                      # W.grad written by two GEMM nodes: beta 0 then beta 1
+    X.zero_grad(); z.forward(); z.backward(1.0)
+    ones = np.ones((5, 4))
+    x64, w64 = x.astype(np.float64), w.astype(np.float64)
+    close(W.grad(), (x64 @ w64).T @ ones + x64.T @ (ones @ w64.T), 1e-5, 1e-5)
+    close(X.grad(), ones @ w64.T @ w64.T, 1e-5, 1e-5)
+
+
 def test_device_loader_pipeline(nk, tdev):
     """data::DeviceLoader: page-locked records, double-buffered uploads on the copy stream, batches arrive in
     order and intact over several epochs (odd and even batch counts, ragged tail); the refilled leaves drive a
