@@ -346,33 +346,49 @@ struct MatMulBwd : Backward {
     }
 };
 
-struct ConvFwd : Forward {  // node/convolution/mod.rs:296-355
-    Shared<HipArray> x, w, y;
+struct ConvFwd : Forward {  // node/convolution/mod.rs:296-355 (+ the module's broadcast bias Addition when b is set)
+    Shared<HipArray> x, w, b, y;
     std::vector<int> stride, dilation;
     int groups;
     void forward() const override {
-        check(nk_conv_fwd(D(x), (int)x->shape().size() - 2, x->ptr(), x->shape().data(), w->ptr(), w->shape().data(),
-                          y->ptr(), stride.data(), dilation.data(), groups));
+        const int nd = (int)x->shape().size() - 2;
+        if (b)
+            check(nk_conv_bias_fwd(D(x), nd, x->ptr(), x->shape().data(), w->ptr(), w->shape().data(), b->ptr(), y->ptr(),
+                                   stride.data(), dilation.data(), groups));
+        else
+            check(nk_conv_fwd(D(x), nd, x->ptr(), x->shape().data(), w->ptr(), w->shape().data(), y->ptr(), stride.data(),
+                              dilation.data(), groups));
     }
 };
 struct ConvBwd : Backward {  // ConvolutionBackward{Input,Kernel}  :357-510
     Shared<HipArray> x, w;
-    Shared<Gradient> dx, dw, g;  // dx may be null (input is a non-differentiable Var)
+    Shared<Gradient> dx, dw, db, g;  // dx may be null (input is a non-differentiable Var); db only for the fused module node
     std::vector<int> stride, dilation;
     int groups;
     void backward() const override {
         const HipArray& G = g->borrow();
         const int nd = (int)x->shape().size() - 2;
-        if (dx)
-            check(nk_conv_bwd_input(D(x), nd, dx->borrow().ptr(), x->shape().data(), G.ptr(), w->ptr(),
-                                    w->shape().data(), stride.data(), dilation.data(), groups));
-        if (dw)
-            check(nk_conv_bwd_kernel(D(x), nd, dw->borrow().ptr(), w->shape().data(), G.ptr(), x->ptr(),
-                                     x->shape().data(), stride.data(), dilation.data(), groups));
+        bool assign = false;
+        if (dx) {
+            HipArray& d = dx->borrow_first_write(assign);
+            check((assign ? nk_conv_bwd_input_assign : nk_conv_bwd_input)(D(x), nd, d.ptr(), x->shape().data(), G.ptr(), w->ptr(),
+                                                                          w->shape().data(), stride.data(), dilation.data(), groups));
+        }
+        if (dw) {
+            HipArray& d = dw->borrow_first_write(assign);
+            check((assign ? nk_conv_bwd_kernel_assign : nk_conv_bwd_kernel)(D(x), nd, d.ptr(), w->shape().data(), G.ptr(), x->ptr(),
+                                                                            x->shape().data(), stride.data(), dilation.data(), groups));
+        }
+        if (db) {  // AdditionBackwardRight of the bias: sum of G over every axis the (Cout,1,..) bias lacks
+            HipArray& d = db->borrow();
+            check(nk_unbroadcast_add(D(x), d.ptr(), d.shape().data(), (int)d.shape().size(), G.ptr(), G.shape().data(),
+                                     (int)G.shape().size()));
+        }
     }
     void targets(std::vector<const Gradient*>& out) const override {
         if (dx) out.push_back(dx.get());
         if (dw) out.push_back(dw.get());
+        if (db) out.push_back(db.get());
     }
 };
 
@@ -1155,13 +1171,23 @@ VarDiff VarDiff::attention_probs(float scale, double p, Shared<bool> status) con
 }
 static VarDiff conv_diff(const VarDiff& kernel, const Var& input, const Shared<Gradient>& dx,
                          const History<BackwardEntry>* hx, const std::vector<int>& stride,
-                         const std::vector<int>& dilation, int groups) {
+                         const std::vector<int>& dilation, int groups, const VarDiff* bias = nullptr) {
     Var out = kernel.var.convolution(input, stride, dilation, groups);
     History<BackwardEntry> h = kernel.history;
     if (hx) h.merge(*hx);
+    if (bias) {  // one node for `convolution(..) + bias`: the bias joins the forward node and both histories
+        Shape want{out.shape()[1]};
+        want.insert(want.end(), out.shape().size() - 2, 1);
+        if (bias->shape() != want) panic("conv bias must have shape (out_channels, 1, ...)");
+        auto fw = std::dynamic_pointer_cast<ConvFwd>(out.history.to_vec().back().op);
+        fw->b = bias->var.data;
+        out.history.merge(bias->var.history);
+        h.merge(bias->history);
+    }
     auto g = std::make_shared<Gradient>(out.device(), out.shape());
     auto bw = std::make_shared<ConvBwd>();
     bw->x = input.data; bw->w = kernel.var.data; bw->dx = dx; bw->dw = kernel.grad; bw->g = g;
+    if (bias) bw->db = bias->grad;
     bw->stride = stride; bw->dilation = dilation; bw->groups = groups;
     return VarDiff::node(std::move(out), g, entry(bw, g), std::move(h));
 }
@@ -1326,10 +1352,14 @@ ConvNd::ConvNd(int nd, DevicePtr dev, int in_channels, int out_channels, std::ve
         panic("Conv" + std::to_string(nd) + "d: kernel/padding/stride/dilation need " + std::to_string(nd) + " entries");
 }
 VarDiff ConvNd::forward(const Var& input) const {
-    return weight.convolution(input.pad(padding, padding_mode), stride, dilation, groups) + bias;
+    const Var padded = input.pad(padding, padding_mode);
+    if (!fused) return weight.convolution(padded, stride, dilation, groups) + bias;
+    return conv_diff(weight, padded, nullptr, nullptr, stride, dilation, groups, &bias);
 }
 VarDiff ConvNd::forward(const VarDiff& input) const {
-    return weight.convolution(input.pad(padding, padding_mode), stride, dilation, groups) + bias;
+    const VarDiff padded = input.pad(padding, padding_mode);
+    if (!fused) return weight.convolution(padded, stride, dilation, groups) + bias;
+    return conv_diff(weight, padded.var, padded.grad, &padded.history, stride, dilation, groups, &bias);
 }
 
 MultiheadAttention::MultiheadAttention(DevicePtr dev, int d_model_, int heads_, double p, uint64_t seed)

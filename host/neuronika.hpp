@@ -418,6 +418,7 @@ struct ConvNd {
     std::vector<int> padding, stride, dilation;
     PaddingMode padding_mode;
     int groups = 1;
+    bool fused = true;  // bias added in the convolution epilogue (one node); false: convolution node + Addition node
     ConvNd(int nd, DevicePtr dev, int in_channels, int out_channels, std::vector<int> kernel, std::vector<int> padding,
            PaddingMode mode, std::vector<int> stride, std::vector<int> dilation, int groups, uint64_t seed);
     VarDiff forward(const Var& input) const;

@@ -254,6 +254,7 @@ PYBIND11_MODULE(_tape, m) {
     py::class_<nn::ConvNd>(nn, "ConvNd")
         .def_readonly("weight", &nn::ConvNd::weight)
         .def_readonly("bias", &nn::ConvNd::bias)
+        .def_readwrite("fused", &nn::ConvNd::fused)
         .def("forward", py::overload_cast<const Var&>(&nn::ConvNd::forward, py::const_))
         .def("forward", py::overload_cast<const VarDiff&>(&nn::ConvNd::forward, py::const_));
     py::class_<nn::Conv1d, nn::ConvNd>(nn, "Conv1d")

@@ -163,6 +163,12 @@ int nk_conv_bwd_input(nk_device* dev, int nd, float* dx, const int* x_shape, con
 int nk_conv_bwd_kernel(nk_device* dev, int nd, float* dw, const int* w_shape, const float* g,
                        const float* x, const int* x_shape, const int* stride, const int* dilation,
                        int groups);
+/* `Conv{1,2,3}d` module forward = convolution node + broadcast Addition of the (Cout,1,..) bias (neuronika-nn/src/
+ * lib.rs:630-916; addition/mod.rs:39-50) as ONE kernel: bias[co] is added to the f32 accumulator in the epilogue,
+ * bit-identical to the two-node result.  Backward = nk_conv_bwd_input, nk_conv_bwd_kernel, nk_unbroadcast_add. */
+int nk_conv_bias_fwd(nk_device* dev, int nd, const float* x, const int* x_shape, const float* w,
+                     const int* w_shape, const float* bias, float* y, const int* stride,
+                     const int* dilation, int groups);
 /* Pad<Constant|Zero>::forward  node/pad/mod.rs:97-129 + pad/constant/mod.rs:14-39;
  * symmetric `padding[i]` on both sides of spatial axis i.  x_shape = [N, C, in...]. */
 int nk_pad_const_fwd(nk_device* dev, int nd, const float* x, const int* x_shape, float* y,
@@ -244,6 +250,12 @@ int nk_mse_bwd(nk_device* dev, float* dx, const float* g, const float* x, const 
  * read of the destination: the `_assign` variants compute exactly what their `+=` twin computes on an all-zero
  * destination, writing without reading (the GEMM-shaped nodes get the same through nk_sgemm's beta = 0).
  * The tape (host `Gradient`) keeps the zero fill pending and hands it to the first writer. */
+int nk_conv_bwd_input_assign(nk_device* dev, int nd, float* dx, const int* x_shape, const float* g,
+                             const float* w, const int* w_shape, const int* stride,
+                             const int* dilation, int groups);
+int nk_conv_bwd_kernel_assign(nk_device* dev, int nd, float* dw, const int* w_shape, const float* g,
+                              const float* x, const int* x_shape, const int* stride,
+                              const int* dilation, int groups);
 int nk_relu_bwd_assign(nk_device* dev, float* dx, const float* g, const float* x, size_t n);
 int nk_mse_bwd_assign(nk_device* dev, float* dx, const float* g, const float* x, const float* target,
                       size_t n, int reduction);

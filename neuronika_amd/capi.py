@@ -81,6 +81,9 @@ _SIGS = {
     "nk_mm_t_bwd_right": [VP, VP, VP, VP, C.c_int, C.c_int, C.c_int],
     "nk_linear_fwd": [VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int],
     "nk_conv_fwd": [VP, C.c_int, VP, c_intp, VP, c_intp, VP, c_intp, c_intp, C.c_int],
+    "nk_conv_bias_fwd": [VP, C.c_int, VP, c_intp, VP, c_intp, VP, VP, c_intp, c_intp, C.c_int],
+    "nk_conv_bwd_input_assign": [VP, C.c_int, VP, c_intp, VP, VP, c_intp, c_intp, c_intp, C.c_int],
+    "nk_conv_bwd_kernel_assign": [VP, C.c_int, VP, c_intp, VP, VP, c_intp, c_intp, c_intp, C.c_int],
     "nk_conv_bwd_input": [VP, C.c_int, VP, c_intp, VP, VP, c_intp, c_intp, c_intp, C.c_int],
     "nk_conv_bwd_kernel": [VP, C.c_int, VP, c_intp, VP, VP, c_intp, c_intp, c_intp, C.c_int],
     "nk_pad_const_fwd": [VP, C.c_int, VP, c_intp, VP, c_intp, C.c_float],
@@ -347,19 +350,22 @@ def mm_t_bwd_right(dev, dB, G, A):
     check(lib.nk_mm_t_bwd_right(dev.h, dB.p, G.p, A.p, n, m, o))
 
 
-def conv_fwd(dev, x, w, y, stride, dilation, groups=1):
+def conv_fwd(dev, x, w, y, stride, dilation, groups=1, bias=None):
     nd = x.ndim - 2
-    check(lib.nk_conv_fwd(dev.h, nd, x.p, x.shape_c(), w.p, w.shape_c(), y.p, ints(stride), ints(dilation), groups))
+    if bias is not None:
+        check(lib.nk_conv_bias_fwd(dev.h, nd, x.p, x.shape_c(), w.p, w.shape_c(), bias.p, y.p, ints(stride), ints(dilation), groups))
+    else:
+        check(lib.nk_conv_fwd(dev.h, nd, x.p, x.shape_c(), w.p, w.shape_c(), y.p, ints(stride), ints(dilation), groups))
 
 
-def conv_bwd_input(dev, dx, g, w, stride, dilation, groups=1):
+def conv_bwd_input(dev, dx, g, w, stride, dilation, groups=1, assign=False):
     nd = dx.ndim - 2
-    check(lib.nk_conv_bwd_input(dev.h, nd, dx.p, dx.shape_c(), g.p, w.p, w.shape_c(), ints(stride), ints(dilation), groups))
+    check((lib.nk_conv_bwd_input_assign if assign else lib.nk_conv_bwd_input)(dev.h, nd, dx.p, dx.shape_c(), g.p, w.p, w.shape_c(), ints(stride), ints(dilation), groups))
 
 
-def conv_bwd_kernel(dev, dw, g, x, stride, dilation, groups=1):
+def conv_bwd_kernel(dev, dw, g, x, stride, dilation, groups=1, assign=False):
     nd = x.ndim - 2
-    check(lib.nk_conv_bwd_kernel(dev.h, nd, dw.p, dw.shape_c(), g.p, x.p, x.shape_c(), ints(stride), ints(dilation), groups))
+    check((lib.nk_conv_bwd_kernel_assign if assign else lib.nk_conv_bwd_kernel)(dev.h, nd, dw.p, dw.shape_c(), g.p, x.p, x.shape_c(), ints(stride), ints(dilation), groups))
 
 
 def linear_fwd(dev, X, W, bias, Y):

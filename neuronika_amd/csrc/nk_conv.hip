@@ -22,6 +22,8 @@ struct ConvGeom {
     int N, Cin, Cout, groups, Cg, Mg;  // Cg = Cin/groups, Mg = Cout/groups
     int in[3], out[3], k[3], stride[3], dil[3];  // padded in front with 1s to 3 spatial dims
     int inplane, L, KK;                           // prod(in), prod(out), prod(k)
+    const float* bias;                            // forward: optional per-output-channel bias added in the epilogue
+    int assign;                                   // backward: write instead of `+=` (destination's zero fill pending)
 };
 
 // ---- tables (tiny pre-kernels into the device workspace) ---------------------------------------
@@ -88,7 +90,7 @@ struct FwdArgs {
 template <bool ALIGNED_A, int TI>
 __global__ __launch_bounds__(NT, 2) void conv_fwd_kernel(FwdArgs p) {
     constexpr int TJ = 2, BM = 64 * TI, BN = 64 * TJ;
-    constexpr int TA_FLOATS = tile_floats<BM>(), STAGE = TA_FLOATS + tile_floats<BN>();
+    constexpr int TA_FLOATS = tile_floats<true, BM>(), STAGE = TA_FLOATS + tile_floats<false, BN>();
     __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
     const ConvGeom& g = p.g;
     const int t = threadIdx.x, lane = t & 63, wid = t >> 6, wr = wid >> 1, wc = wid & 1;
@@ -168,13 +170,14 @@ __global__ __launch_bounds__(NT, 2) void conv_fwd_kernel(FwdArgs p) {
     }
     // Y[n][grp*Mg + co][l]
     float* Y = p.y;
+    const float* bias = g.bias;
     const int Mg = g.Mg, L = g.L, Cout = g.Cout;
     acc_foreach<TI, TJ>(acc, wr, wc, lane, [&](int r, int c, float v) {
         const int co = m0 + r;
         const long long cc = (long long)n0 + c;
         if (co < Mg && cc < cols) {
             const int n = (int)(cc / L), l = (int)(cc % L);
-            Y[((long long)n * Cout + grp * Mg + co) * L + l] = v;
+            Y[((long long)n * Cout + grp * Mg + co) * L + l] = bias ? v + bias[grp * Mg + co] : v;
         }
     });
 }
@@ -194,7 +197,7 @@ struct BwdInArgs {
 template <bool ALIGNED_A, bool UNIT_STRIDE, int TI>
 __global__ __launch_bounds__(NT, 2) void conv_bwd_input_kernel(BwdInArgs p) {
     constexpr int TJ = 2, BM = 64 * TI, BN = 64 * TJ;
-    constexpr int TA_FLOATS = tile_floats<BM>(), STAGE = TA_FLOATS + tile_floats<BN>();
+    constexpr int TA_FLOATS = tile_floats<true, BM>(), STAGE = TA_FLOATS + tile_floats<false, BN>();
     __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
     const ConvGeom& g = p.g;
     const int t = threadIdx.x, lane = t & 63, wid = t >> 6, wr = wid >> 1, wc = wid & 1;
@@ -291,6 +294,7 @@ __global__ __launch_bounds__(NT, 2) void conv_bwd_input_kernel(BwdInArgs p) {
     }
     // dX[n][grp*Cg + ci][pos] += acc
     float* DX = p.dx;
+    const int assign = g.assign;
     const int Cg = g.Cg, Cin = g.Cin, inplane = g.inplane;
     acc_foreach<TI, TJ>(acc, wr, wc, lane, [&](int r, int c, float v) {
         const int ci = m0 + r;
@@ -298,7 +302,7 @@ __global__ __launch_bounds__(NT, 2) void conv_bwd_input_kernel(BwdInArgs p) {
         if (ci < Cg && cc < cols) {
             const int n = (int)(cc / inplane), q = (int)(cc % inplane);
             float* d = &DX[((long long)n * Cin + grp * Cg + ci) * inplane + q];
-            *d += v;
+            *d = assign ? v : *d + v;
         }
     });
 }
@@ -322,7 +326,7 @@ struct BwdKArgs {
 template <bool VEC_G, int TI, int TJ, bool QUADR>
 __global__ __launch_bounds__(NT, 2) void conv_bwd_kernel_kernel(BwdKArgs p) {
     constexpr int BM = 64 * TI, BN = 64 * TJ;
-    constexpr int TA_FLOATS = tile_floats<BM>(), STAGE = TA_FLOATS + tile_floats<BN>();
+    constexpr int TA_FLOATS = tile_floats<true, BM>(), STAGE = TA_FLOATS + tile_floats<true, BN>();
     __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
     const ConvGeom& g = p.g;
     const int t = threadIdx.x, lane = t & 63, wid = t >> 6, wr = wid >> 1, wc = wid & 1;
@@ -449,11 +453,11 @@ __global__ __launch_bounds__(NT, 2) void conv_bwd_kernel_kernel(BwdKArgs p) {
 }
 
 // dW[i] += sum_s slabs[s][i]  (fixed order -> deterministic)
-__global__ void conv_dw_reduce_kernel(float* __restrict__ dw, const float* __restrict__ slabs, long long n, int splits) {
+__global__ void conv_dw_reduce_kernel(float* __restrict__ dw, const float* __restrict__ slabs, long long n, int splits, int assign) {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         float s = 0.f;
         for (int k = 0; k < splits; ++k) s += slabs[(long long)k * n + i];
-        dw[i] += s;
+        dw[i] = assign ? s : dw[i] + s;
     }
 }
 
@@ -515,7 +519,7 @@ struct FastFwdArgs {
 template <bool ALIGNED_A, int TI>
 __global__ __launch_bounds__(NT, 2) void conv_fwd_fast_kernel(FastFwdArgs p) {
     constexpr int TJ = 2, BM = 64 * TI, BN = 64 * TJ;
-    constexpr int TA_FLOATS = tile_floats<BM>(), STAGE = TA_FLOATS + tile_floats<BN>();
+    constexpr int TA_FLOATS = tile_floats<true, BM>(), STAGE = TA_FLOATS + tile_floats<false, BN>();
     __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
     const ConvGeom& g = p.g;
     const int t = threadIdx.x, lane = t & 63, wid = t >> 6, wr = wid >> 1, wc = wid & 1;
@@ -582,13 +586,14 @@ __global__ __launch_bounds__(NT, 2) void conv_fwd_fast_kernel(FastFwdArgs p) {
         mma_tile<true, false, TI, TJ>(cur, cur + TA_FLOATS, acc, wr, wc, lane);
     }
     float* Y = p.y;
+    const float* bias = g.bias;
     const int Mg = g.Mg, L = g.L, Cout = g.Cout;
     acc_foreach<TI, TJ>(acc, wr, wc, lane, [&](int r, int c, float v) {
         const int co = m0 + r;
         const long long cc = (long long)n0 + c;
         if (co < Mg && cc < cols) {
             const int n = (int)(cc / L), l = (int)(cc % L);
-            Y[((long long)n * Cout + grp * Mg + co) * L + l] = v;
+            Y[((long long)n * Cout + grp * Mg + co) * L + l] = bias ? v + bias[grp * Mg + co] : v;
         }
     });
 }
@@ -606,7 +611,7 @@ struct FastBwdInArgs {
 template <bool ALIGNED_A, int TI>
 __global__ __launch_bounds__(NT, 2) void conv_bwd_input_fast_kernel(FastBwdInArgs p) {
     constexpr int TJ = 2, BM = 64 * TI, BN = 64 * TJ;
-    constexpr int TA_FLOATS = tile_floats<BM>(), STAGE = TA_FLOATS + tile_floats<BN>();
+    constexpr int TA_FLOATS = tile_floats<true, BM>(), STAGE = TA_FLOATS + tile_floats<false, BN>();
     __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
     const ConvGeom& g = p.g;
     const int t = threadIdx.x, lane = t & 63, wid = t >> 6, wr = wid >> 1, wc = wid & 1;
@@ -694,6 +699,7 @@ __global__ __launch_bounds__(NT, 2) void conv_bwd_input_fast_kernel(FastBwdInArg
         mma_tile<true, false, TI, TJ>(cur, cur + TA_FLOATS, acc, wr, wc, lane);
     }
     float* DX = p.dx;
+    const int assign = g.assign;
     const int Cg = g.Cg, Cin = g.Cin, inplane = g.inplane;
     acc_foreach<TI, TJ>(acc, wr, wc, lane, [&](int r, int c, float v) {
         const int ci = m0 + r;
@@ -701,7 +707,7 @@ __global__ __launch_bounds__(NT, 2) void conv_bwd_input_fast_kernel(FastBwdInArg
         if (ci < Cg && cc < cols) {
             const int n = (int)(cc / inplane), q = (int)(cc % inplane);
             float* d = &DX[((long long)n * Cin + grp * Cg + ci) * inplane + q];
-            *d += v;
+            *d = assign ? v : *d + v;
         }
     });
 }
@@ -736,16 +742,13 @@ int make_geom(int nd, const int* x_shape, const int* w_shape, const int* stride,
 bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 size_t round256(size_t b) { return (b + 255) & ~size_t(255); }
 
-}  // namespace
-
-extern "C" {
-
-int nk_conv_fwd(nk_device* dev, int nd, const float* x, const int* x_shape, const float* w, const int* w_shape,
-                float* y, const int* stride, const int* dilation, int groups) {
+int conv_fwd(nk_device* dev, int nd, const float* x, const int* x_shape, const float* w, const int* w_shape,
+             const float* bias, float* y, const int* stride, const int* dilation, int groups) {
     NK_USE(dev);
     ConvGeom g;
     int rc = make_geom(nd, x_shape, w_shape, stride, dilation, groups, &g);
     if (rc) return rc;
+    g.bias = bias;
     if ((long long)g.N * g.Cout * g.L == 0) return NK_OK;
     NK_CHECK(x && w && y, "null pointer in nk_conv_fwd");
     const int K = g.Cg * g.KK;
@@ -803,12 +806,13 @@ int nk_conv_fwd(nk_device* dev, int nd, const float* x, const int* x_shape, cons
     return nk_prof_stop(dev);
 }
 
-int nk_conv_bwd_input(nk_device* dev, int nd, float* dx, const int* x_shape, const float* gy, const float* w,
-                      const int* w_shape, const int* stride, const int* dilation, int groups) {
+int conv_bwd_input(nk_device* dev, int nd, float* dx, const int* x_shape, const float* gy, const float* w,
+                   const int* w_shape, const int* stride, const int* dilation, int groups, int assign) {
     NK_USE(dev);
     ConvGeom g;
     int rc = make_geom(nd, x_shape, w_shape, stride, dilation, groups, &g);
     if (rc) return rc;
+    g.assign = assign;
     if ((long long)g.N * g.Cin * g.inplane == 0 || (long long)g.Cout * g.L == 0) return NK_OK;
     NK_CHECK(dx && gy && w, "null pointer in nk_conv_bwd_input");
     const int K = g.Mg * g.KK;
@@ -885,8 +889,8 @@ int nk_conv_bwd_input(nk_device* dev, int nd, float* dx, const int* x_shape, con
     return nk_prof_stop(dev);
 }
 
-int nk_conv_bwd_kernel(nk_device* dev, int nd, float* dw, const int* w_shape, const float* gy, const float* x,
-                       const int* x_shape, const int* stride, const int* dilation, int groups) {
+int conv_bwd_kernel(nk_device* dev, int nd, float* dw, const int* w_shape, const float* gy, const float* x,
+                    const int* x_shape, const int* stride, const int* dilation, int groups, int assign) {
     NK_USE(dev);
     ConvGeom g;
     int rc = make_geom(nd, x_shape, w_shape, stride, dilation, groups, &g);
@@ -952,9 +956,39 @@ int nk_conv_bwd_kernel(nk_device* dev, int nd, float* dw, const int* w_shape, co
 #undef NK_LAUNCH_BWK
     NK_LAUNCH_CHECK();
     hipLaunchKernelGGL(conv_dw_reduce_kernel, dim3(nk_stream_grid((size_t)dw_elems, 256)), dim3(256), 0, dev->compute, dw,
-                       p.slabs, dw_elems, (int)splits);
+                       p.slabs, dw_elems, (int)splits, assign);
     NK_LAUNCH_CHECK();
     return nk_prof_stop(dev);
+}
+
+}  // namespace
+
+extern "C" {
+
+int nk_conv_fwd(nk_device* dev, int nd, const float* x, const int* x_shape, const float* w, const int* w_shape,
+                float* y, const int* stride, const int* dilation, int groups) {
+    return conv_fwd(dev, nd, x, x_shape, w, w_shape, nullptr, y, stride, dilation, groups);
+}
+int nk_conv_bias_fwd(nk_device* dev, int nd, const float* x, const int* x_shape, const float* w, const int* w_shape,
+                     const float* bias, float* y, const int* stride, const int* dilation, int groups) {
+    NK_CHECK(bias != nullptr, "null bias");
+    return conv_fwd(dev, nd, x, x_shape, w, w_shape, bias, y, stride, dilation, groups);
+}
+int nk_conv_bwd_input(nk_device* dev, int nd, float* dx, const int* x_shape, const float* gy, const float* w,
+                      const int* w_shape, const int* stride, const int* dilation, int groups) {
+    return conv_bwd_input(dev, nd, dx, x_shape, gy, w, w_shape, stride, dilation, groups, 0);
+}
+int nk_conv_bwd_input_assign(nk_device* dev, int nd, float* dx, const int* x_shape, const float* gy, const float* w,
+                             const int* w_shape, const int* stride, const int* dilation, int groups) {
+    return conv_bwd_input(dev, nd, dx, x_shape, gy, w, w_shape, stride, dilation, groups, 1);
+}
+int nk_conv_bwd_kernel(nk_device* dev, int nd, float* dw, const int* w_shape, const float* gy, const float* x,
+                       const int* x_shape, const int* stride, const int* dilation, int groups) {
+    return conv_bwd_kernel(dev, nd, dw, w_shape, gy, x, x_shape, stride, dilation, groups, 0);
+}
+int nk_conv_bwd_kernel_assign(nk_device* dev, int nd, float* dw, const int* w_shape, const float* gy, const float* x,
+                              const int* x_shape, const int* stride, const int* dilation, int groups) {
+    return conv_bwd_kernel(dev, nd, dw, w_shape, gy, x, x_shape, stride, dilation, groups, 1);
 }
 
 }  // extern "C"

@@ -32,10 +32,10 @@ struct GemmArgs {
 template <bool TA, bool TB, bool ALIGNED, int TI, int TJ>
 __global__ __launch_bounds__(NT, (min_waves<TI, TJ>())) void sgemm_kernel(GemmArgs p) {
     constexpr int BM = 64 * TI, BN = 64 * TJ;
-    constexpr int TA_FLOATS = tile_floats<BM>(), STAGE = TA_FLOATS + tile_floats<BN>();
-    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];  // 73,728 B at 128x128
     constexpr bool AKC = !TA;  // A (M x K): k-contiguous unless stored transposed
     constexpr bool BKC = TB;   // B (K x N) stored as N x K when transposed -> k-contiguous
+    constexpr int TA_FLOATS = tile_floats<AKC, BM>(), STAGE = TA_FLOATS + tile_floats<BKC, BN>();
+    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];  // <= 73,728 B at 128x128
 
     const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
     const int wr = wid >> 1, wc = wid & 1;

@@ -35,12 +35,11 @@ constexpr int BK = 32;
 constexpr int NT = 256;
 constexpr int LDK = BK + 4;  // KC row stride (floats)
 
-// floats of one operand tile with R rows (max of the KC and RC images)
-template <int R>
-constexpr int tile_floats() { return R * LDK; }
-// LDS floats of the double-buffered pair of operand tiles
-template <int TI, int TJ>
-constexpr int smem_floats() { return 2 * (tile_floats<64 * TI>() + tile_floats<64 * TJ>()); }
+// floats of one operand tile with R rows: the KC image is padded (stride 36), the RC image is dense.
+// Sizing per layout (not the max of both) is what lets the 64x128 tiles with at least one RC operand keep
+// THREE blocks per CU: 2*(64*36 + 128*32)*4 B = 51,200 B  vs  55,296 B (> 160 KB / 3) for two padded images.
+template <bool KC, int R>
+constexpr int tile_floats() { return KC ? R * LDK : R * BK; }
 // blocks per CU the register/LDS budget is sized for -> min waves per SIMD for launch bounds
 template <int TI, int TJ>
 constexpr int min_waves() { return TI * TJ == 4 ? 2 : (TI * TJ == 2 ? 3 : 4); }

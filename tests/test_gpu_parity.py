@@ -612,6 +612,23 @@ def test_assign_variants_equal_accumulate_into_zeros(dev):
     A, Z = nan((B * H, S, dh)), dev.zeros((B * H, S, dh))
     c.merge_heads_bwd(dev, A, dev.array(gf), B, S, H, dh, assign=True); c.merge_heads_bwd(dev, Z, dev.array(gf), B, S, H, dh)
     assert np.array_equal(A.numpy(), Z.numpy())
+    for xs, ws, st, dl, gr in [((3, 4, 9, 8), (6, 2, 3, 3), (1, 1), (1, 1), 2), ((2, 32, 12, 12), (32, 32, 3, 3), (1, 1), (1, 1), 1),
+                               ((2, 3, 11), (4, 3, 3), (2,), (1,), 1)]:
+        xx, ww = rnd(9, xs, -1, 1), rnd(10, ws, -1, 1)
+        osp = tuple((n - d * (k - 1) - 1) // s + 1 for n, k, s, d in zip(xs[2:], ws[2:], st, dl))
+        gy = rnd(11, (xs[0], ws[0]) + osp, -1, 1)
+        Xc, Wc, Gc = dev.array(xx), dev.array(ww), dev.array(gy)
+        A, Z = nan(xs), dev.zeros(xs)
+        c.conv_bwd_input(dev, A, Gc, Wc, st, dl, gr, assign=True); c.conv_bwd_input(dev, Z, Gc, Wc, st, dl, gr)
+        assert np.array_equal(A.numpy(), Z.numpy())
+        A, Z = nan(ws), dev.zeros(ws)
+        c.conv_bwd_kernel(dev, A, Gc, Xc, st, dl, gr, assign=True); c.conv_bwd_kernel(dev, Z, Gc, Xc, st, dl, gr)
+        assert np.array_equal(A.numpy(), Z.numpy())
+        bias = rnd(12, (ws[0],) + (1,) * len(osp), -1, 1)
+        Y0, Y1, Y2 = dev.zeros(gy.shape), dev.zeros(gy.shape), nan(gy.shape)
+        c.conv_fwd(dev, Xc, Wc, Y0, st, dl, gr); c.binary_fwd(dev, "add", Y1, Y0, dev.array(bias))
+        c.conv_fwd(dev, Xc, Wc, Y2, st, dl, gr, bias=dev.array(bias))
+        assert np.array_equal(Y1.numpy(), Y2.numpy())                 # conv + bias in the epilogue == two nodes
     sc = rnd(7, (6, 40, 64), -2, 2)
     Sx, P, O_, Gs = dev.array(sc), dev.zeros(sc.shape), dev.zeros(sc.shape), dev.array(rnd(8, sc.shape, -1, 1))
     c.scale_softmax_dropout_fwd(dev, Sx, P, O_, None, 0.125, 0.2, True, 11, 5)

@@ -210,6 +210,22 @@ def test_conv_nd_modules(nk, tdev, nd, mode):
     close(X.grad(), dx, 1e-4, 1e-5)
 
 
+def test_conv_module_fused_equals_two_nodes(nk, tdev):
+    """ConvNd as one node (bias in the conv epilogue, db from the node's own G) == convolution node + Addition node."""
+    x = rnd(1, (3, 4, 10, 9), -1, 1)
+    res = {}
+    for fused in (True, False):
+        conv = nk.nn.Conv2d(tdev, 4, 6, [3, 3], [1, 1], [1, 1], [1, 1], 2, 5)
+        conv.fused = fused
+        X = nk.from_ndarray(tdev, x).requires_grad()
+        y = conv.forward(X)
+        s = (y * y).sum(); s.forward(); s.backward(1.0)
+        res[fused] = [y.data(), X.grad(), conv.weight.grad(), conv.bias.grad(), s.history_len()]
+    assert res[True][4] == res[False][4] - 1
+    for a, b in zip(res[True][:4], res[False][:4]):
+        assert np.array_equal(a, b)
+
+
 def test_chunks_cat_dropout_graph(nk, tdev):
     x = rnd(3, (6, 8))
     X = nk.from_ndarray(tdev, x).requires_grad()
