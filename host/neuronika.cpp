@@ -240,10 +240,12 @@ struct UnaryBwd : Backward {
     Shared<HipArray> x, y;  // ReLU needs the input, (log)softmax the output
     void backward() const override {
         const HipArray& G = g->borrow();
-        if (kind == Unary::Relu) {
+        if (kind == Unary::Relu || kind == Unary::Sum || kind == Unary::Mean) {
             bool assign = false;
             HipArray& d = dx->borrow_first_write(assign);
-            check((assign ? nk_relu_bwd_assign : nk_relu_bwd)(D(x), d.ptr(), G.ptr(), x->ptr(), d.len()));
+            if (kind == Unary::Relu) check((assign ? nk_relu_bwd_assign : nk_relu_bwd)(D(x), d.ptr(), G.ptr(), x->ptr(), d.len()));
+            else if (kind == Unary::Sum) check((assign ? nk_sum_bwd_assign : nk_sum_bwd)(d.device()->raw(), d.ptr(), d.len(), G.ptr()));
+            else check((assign ? nk_mean_bwd_assign : nk_mean_bwd)(d.device()->raw(), d.ptr(), d.len(), G.ptr()));
             return;
         }
         HipArray& d = dx->borrow();
@@ -253,8 +255,7 @@ struct UnaryBwd : Backward {
             case Unary::Softmax: check(nk_softmax_bwd(D(y), d.ptr(), G.ptr(), y->ptr(), d.shape().data(), nd, axis)); break;
             case Unary::LogSoftmax: check(nk_log_softmax_bwd(D(y), d.ptr(), G.ptr(), y->ptr(), d.shape().data(), nd, axis)); break;
             case Unary::Transpose: check(nk_transpose_bwd(d.device()->raw(), d.ptr(), G.ptr(), d.shape().data(), nd)); break;
-            case Unary::Sum: check(nk_sum_bwd(d.device()->raw(), d.ptr(), d.len(), G.ptr())); break;
-            case Unary::Mean: check(nk_mean_bwd(d.device()->raw(), d.ptr(), d.len(), G.ptr())); break;
+            case Unary::Sum: case Unary::Mean: break;
         }
     }
     void targets(std::vector<const Gradient*>& out) const override { out.push_back(dx.get()); }

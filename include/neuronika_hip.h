@@ -256,6 +256,8 @@ int nk_conv_bwd_input_assign(nk_device* dev, int nd, float* dx, const int* x_sha
 int nk_conv_bwd_kernel_assign(nk_device* dev, int nd, float* dw, const int* w_shape, const float* g,
                               const float* x, const int* x_shape, const int* stride,
                               const int* dilation, int groups);
+int nk_sum_bwd_assign(nk_device* dev, float* dx, size_t n, const float* g);
+int nk_mean_bwd_assign(nk_device* dev, float* dx, size_t n, const float* g);
 int nk_relu_bwd_assign(nk_device* dev, float* dx, const float* g, const float* x, size_t n);
 int nk_mse_bwd_assign(nk_device* dev, float* dx, const float* g, const float* x, const float* target,
                       size_t n, int reduction);

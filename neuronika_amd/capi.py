@@ -15,7 +15,7 @@ from typing import Sequence
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libneuronika_hip.so")
+LIB_PATH = os.environ.get("NEURONIKA_HIP_LIB") or os.path.join(_HERE, "lib", "libneuronika_hip.so")  # override: A/B builds (benchmarks/ab_build.py)
 
 
 class NeuronikaHipError(RuntimeError):
@@ -104,6 +104,8 @@ _SIGS = {
     "nk_mean_bwd": [VP, VP, C.c_size_t, VP],
     "nk_mse_fwd": [VP, VP, VP, C.c_size_t, C.c_int, VP],
     "nk_mse_bwd": [VP, VP, VP, VP, VP, C.c_size_t, C.c_int],
+    "nk_sum_bwd_assign": [VP, VP, C.c_size_t, VP],
+    "nk_mean_bwd_assign": [VP, VP, C.c_size_t, VP],
     "nk_relu_bwd_assign": [VP, VP, VP, VP, C.c_size_t],
     "nk_mse_bwd_assign": [VP, VP, VP, VP, VP, C.c_size_t, C.c_int],
     "nk_pad_bwd_assign": [VP, C.c_int, VP, c_intp, VP, c_intp],
@@ -427,16 +429,16 @@ def sum_fwd(dev, x, out):
     check(lib.nk_sum_fwd(dev.h, x.p, x.size, out.p))
 
 
-def sum_bwd(dev, dx, g):
-    check(lib.nk_sum_bwd(dev.h, dx.p, dx.size, g.p))
+def sum_bwd(dev, dx, g, assign=False):
+    check((lib.nk_sum_bwd_assign if assign else lib.nk_sum_bwd)(dev.h, dx.p, dx.size, g.p))
 
 
 def mean_fwd(dev, x, out):
     check(lib.nk_mean_fwd(dev.h, x.p, x.size, out.p))
 
 
-def mean_bwd(dev, dx, g):
-    check(lib.nk_mean_bwd(dev.h, dx.p, dx.size, g.p))
+def mean_bwd(dev, dx, g, assign=False):
+    check((lib.nk_mean_bwd_assign if assign else lib.nk_mean_bwd)(dev.h, dx.p, dx.size, g.p))
 
 
 def mse_fwd(dev, x, t, out, reduction="mean"):

@@ -348,8 +348,8 @@ __global__ __launch_bounds__(NT, 2) void conv_bwd_kernel_kernel(BwdKArgs p) {
     const float* G = p.gy + (long long)grp * g.Mg * g.L;
     const float* X = p.x + (long long)grp * g.Cg * g.inplane;
 
-    // KC staging for both operands: idx = t + 256*j -> row = (t>>3) + 32*j, 4 consecutive r
-    const int rq = t & 7, row = t >> 3;
+    // KC staging for both operands: idx = t + 256*j -> row = kc_row(t) + 32*j, 4 consecutive r
+    const int rq = kc_q(t), row = kc_row(t);
     // B: columns n0 + row + 32*j -> koff (fixed over the k loop)
     int ko0, ko1, ko2 = 0, ko3 = 0;
     bool cv0, cv1, cv2 = false, cv3 = false;

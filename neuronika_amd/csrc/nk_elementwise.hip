@@ -267,12 +267,27 @@ __global__ void reduce_rkr_kernel(float* __restrict__ part, const float* __restr
     if (threadIdx.x == 0) part[(long long)blockIdx.y * p.K + k] = acc;
 }
 
+// d[k] += sum_c part[c][k].  A block is 64 columns x 4 chunk-lanes (lane j sums chunks j, j+4, ... with four
+// independent accumulators), folded through LDS in a fixed order: K/64 blocks and chunks/4 loads deep instead of
+// K/256 blocks and `chunks` dependent loads deep (that serial form cost 20-60 us for a few hundred KB).
 __global__ void reduce_finish_kernel(float* __restrict__ d, const float* __restrict__ part, int K, int chunks) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= K) return;
-    float s = 0.f;
-    for (int c = 0; c < chunks; ++c) s += part[(long long)c * K + k];
-    d[k] += s;
+    __shared__ float red[4][64];
+    const int col = threadIdx.x & 63, lane = threadIdx.x >> 6;
+    const int k = blockIdx.x * 64 + col;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (k < K) {
+        int c = lane;
+        for (; c + 12 < chunks; c += 16) {
+            s0 += part[(long long)c * K + k];
+            s1 += part[(long long)(c + 4) * K + k];
+            s2 += part[(long long)(c + 8) * K + k];
+            s3 += part[(long long)(c + 12) * K + k];
+        }
+        for (; c < chunks; c += 4) s0 += part[(long long)c * K + k];
+    }
+    red[lane][col] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (lane == 0 && k < K) d[k] += (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
 }
 
 // Fallback for reduction patterns with more than three collapsed groups: one thread per kept
@@ -409,7 +424,7 @@ int bwd_dispatch(nk_device* dev, float* d, const int* t_shape, int t_nd, const f
         else
             hipLaunchKernelGGL((reduce_rkr_kernel<MODE>), dim3(p.K, chunks), dim3(256), 0, dev->compute, part, g, o, q, p);
         NK_LAUNCH_CHECK();
-        hipLaunchKernelGGL(reduce_finish_kernel, dim3((p.K + 255) / 256), dim3(256), 0, dev->compute, d, part, p.K, chunks);
+        hipLaunchKernelGGL(reduce_finish_kernel, dim3((p.K + 63) / 64), dim3(256), 0, dev->compute, d, part, p.K, chunks);
         NK_LAUNCH_CHECK();
         return NK_OK;
     }

@@ -45,7 +45,9 @@ template <int TI, int TJ>
 constexpr int min_waves() { return TI * TJ == 4 ? 2 : (TI * TJ == 2 ? 3 : 4); }
 
 // ---- register staging of one operand tile: R/32 float4 per thread ------------------------------
-// KC: idx = t + 256*j -> row = idx>>3, kq = idx&7          (8 lanes cover one row's 128 B)
+// KC: idx = t + 256*j -> kq = idx&7 (8 lanes cover one row's 128 B), row = kc_row(idx): lanes 8-15 of every
+//     16-lane group take the row 8 below lanes 0-7, so the group's ds_write_b128 lands in 16 distinct 16-B
+//     slots of the stride-36 image (rows r and r+1 would collide in one slot: 9*1 + 7 = 16 = 0 mod 16).
 // RC: idx = t + 256*j -> k = idx/(R/4), rq = idx%(R/4)     (R/4 lanes cover one k-row)
 // (named members, returned by value: keeps the staging registers out of scratch.)
 template <int NV>
@@ -59,9 +61,16 @@ struct Stage<2> {
     float4 v0, v1;
 };
 
+#ifdef NK_AB_KC_LINEAR  // A/B switch for benchmarks/ab_build.py only
+__device__ __forceinline__ int kc_row(int idx) { return idx >> 3; }
+#else
+__device__ __forceinline__ int kc_row(int idx) { return ((idx >> 7) << 4) + (((idx >> 3) & 1) << 3) + ((idx >> 4) & 7); }
+#endif
+__device__ __forceinline__ int kc_q(int idx) { return idx & 7; }
+
 template <bool KC, int R>
 __device__ __forceinline__ int lds_slot(int idx) {
-    return KC ? (idx >> 3) * LDK + (idx & 7) * 4 : (idx / (R / 4)) * R + (idx % (R / 4)) * 4;
+    return KC ? kc_row(idx) * LDK + kc_q(idx) * 4 : (idx / (R / 4)) * R + (idx % (R / 4)) * 4;
 }
 
 template <bool KC, int R>
@@ -95,13 +104,13 @@ struct TileLoader {
         o0 = off(t, ld_); o1 = off(t + NT, ld_); o2 = off(t + 2 * NT, ld_); o3 = off(t + 3 * NT, ld_);
     }
     static __device__ __forceinline__ unsigned off(int idx, long long ld_) {
-        return KC ? (unsigned)((idx >> 3) * ld_ + (idx & 7) * 4)
+        return KC ? (unsigned)(kc_row(idx) * ld_ + kc_q(idx) * 4)
                   : (unsigned)((idx / (R / 4)) * ld_ + (idx % (R / 4)) * 4);
     }
     __device__ __forceinline__ float4 guarded(int idx) const {
         float v[4];
         if (KC) {
-            const int row = row0 + (idx >> 3), k = k0 + (idx & 7) * 4;
+            const int row = row0 + kc_row(idx), k = k0 + kc_q(idx) * 4;
 #pragma unroll
             for (int c = 0; c < 4; ++c) v[c] = (row < rows && k + c < kend) ? X[row * ld + k + c] : 0.f;
         } else {

@@ -445,6 +445,9 @@ int nk_mean_fwd(nk_device* dev, const float* x, size_t n, float* out) { return f
 int nk_sum_bwd(nk_device* dev, float* dx, size_t n, const float* g) { return scalar_bwd<0>(dev, dx, g, nullptr, nullptr, n, 1.f); }
 int nk_mean_bwd(nk_device* dev, float* dx, size_t n, const float* g) { return scalar_bwd<1>(dev, dx, g, nullptr, nullptr, n, (float)n); }
 
+int nk_sum_bwd_assign(nk_device* dev, float* dx, size_t n, const float* g) { return scalar_bwd<0>(dev, dx, g, nullptr, nullptr, n, 1.f, 1); }
+int nk_mean_bwd_assign(nk_device* dev, float* dx, size_t n, const float* g) { return scalar_bwd<1>(dev, dx, g, nullptr, nullptr, n, (float)n, 1); }
+
 int nk_mse_fwd(nk_device* dev, const float* x, const float* target, size_t n, int reduction, float* out) {
     NK_CHECK(reduction == NK_REDUCTION_SUM || reduction == NK_REDUCTION_MEAN, "unknown reduction %d", reduction);
     NK_CHECK(n == 0 || target != nullptr, "null target");

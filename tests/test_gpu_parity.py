@@ -596,6 +596,10 @@ def test_assign_variants_equal_accumulate_into_zeros(dev):
     c.relu_bwd(dev, A, G, X, assign=True); c.relu_bwd(dev, Z, G, X)
     assert np.array_equal(A.numpy(), Z.numpy())
     gs = dev.array(np.array(0.7, np.float32))
+    for fn in (c.sum_bwd, c.mean_bwd):
+        A, Z = nan(x.shape), dev.zeros(x.shape)
+        fn(dev, A, gs, assign=True); fn(dev, Z, gs)
+        assert np.array_equal(A.numpy(), Z.numpy())
     for red in ("mean", "sum"):
         A, Z = nan(x.shape), dev.zeros(x.shape)
         c.mse_bwd(dev, A, gs, X, T, red, assign=True); c.mse_bwd(dev, Z, gs, X, T, red)
