@@ -144,6 +144,27 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, float* __r
     }
 }
 
+// Same, for a C that is one dense block (ldc == N, batches back to back): no index arithmetic, 16-byte accesses.
+__global__ void splitk_reduce_flat_kernel(const float* __restrict__ slabs, float* __restrict__ C, long long total4, int splits,
+                                          float alpha, float beta, const float* __restrict__ bias, int N) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < splits; ++k) {
+            const float4 v = reinterpret_cast<const float4*>(slabs)[(long long)k * total4 + i];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        float4 o = make_float4(alpha * s.x, alpha * s.y, alpha * s.z, alpha * s.w);
+        if (bias) {
+            const int col = (int)((i * 4) % N);  // N % 4 == 0: the four lanes stay in one row
+            const float4 b = *reinterpret_cast<const float4*>(bias + col);
+            o.x += b.x; o.y += b.y; o.z += b.z; o.w += b.w;
+        }
+        float4* q = reinterpret_cast<float4*>(C) + i;
+        if (beta != 0.f) { const float4 c = *q; o.x = fmaf(beta, c.x, o.x); o.y = fmaf(beta, c.y, o.y); o.z = fmaf(beta, c.z, o.z); o.w = fmaf(beta, c.w, o.w); }
+        *q = o;
+    }
+}
+
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 template <bool TA, bool TB, int TI, int TJ>
@@ -187,29 +208,66 @@ static int gemm_impl(nk_device* dev, int transA, int transB, int M, int N, int K
     p.batch_inner = batch_inner;
     p.sAo = sAo; p.sAi = sAi; p.sBo = sBo; p.sBi = sBi; p.sCo = sCo; p.sCi = sCi;
 
-    // tile shape: 128 wide unless the extent is <= 64, only 64-divisible, or (for small problems)
-    // 128x128 tiles would leave most of the 256 CUs without a block
+    // Tile shape and split-K, from a measured sweep of every (tile, split) candidate over mid-size, long-K and narrow
+    // shapes (benchmarks/ab_force.py; table in DESIGN.md):
+    //  * an extent <= 64, or one that is 64- but not 128-divisible, caps that tile dimension at 64 (no padded half tile);
+    //  * if the largest allowed tile already gives >= 512 blocks (one full set of resident slots), use it unsplit;
+    //  * else keep the large tile when splitting K can raise the grid to >= 384 blocks with >= 16 k-tiles per split
+    //    (128-wide tiles do the most MFMA work per LDS byte, but a block needs a long enough k-chain to amortise its
+    //    prologue/epilogue and the second pass);
+    //  * else 64x64 tiles, split (>= 8 k-tiles per split) only while the grid has fewer than 256 blocks.
     auto blocks = [&](int ti, int tj) {
         return (long long)((M + 64 * ti - 1) / (64 * ti)) * ((N + 64 * tj - 1) / (64 * tj)) * nbatch;
     };
+    const int ktiles = (K + BK - 1) / BK;
     int ti = (M <= 64 || (M % 128 != 0 && M % 64 == 0)) ? 1 : 2;
     int tj = (N <= 64 || (N % 128 != 0 && N % 64 == 0)) ? 1 : 2;
-    if (blocks(ti, tj) < dev->num_cus && tj == 2) tj = 1;
-    if (blocks(ti, tj) < dev->num_cus && ti == 2) ti = 1;
-    const int BM = 64 * ti, BN = 64 * tj;
-    p.tiles_m = (M + BM - 1) / BM;
-    p.tiles_n = (N + BN - 1) / BN;
-
-    // split-K when the output tiles alone leave most of the CUs idle and K is long
-    const long long tiles = (long long)p.tiles_m * p.tiles_n * nbatch;
     int splits = 1;
-    const int ktiles = (K + BK - 1) / BK;
-    if (tiles * 2 <= dev->num_cus && ktiles >= 16) {
-        long long want = (2LL * dev->num_cus + tiles - 1) / tiles;
-        long long maxs = ktiles / 8;  // keep >= 8 k-tiles per split
-        splits = (int)(want < maxs ? want : maxs);
-        if (splits < 1) splits = 1;
+    if (blocks(ti, tj) >= 512) {
+        // plenty of blocks: weigh the last, partly filled wave of resident slots (2 blocks/CU for 128x128, 3 for the
+        // 64-wide shapes) against the lower MFMA density of smaller tiles; many small blocks also tail off smoothly
+        auto wave_eff = [&](long long nb, long long slots) { return (double)nb / (double)(((nb + slots - 1) / slots) * slots); };
+        const int ti0 = ti, tj0 = tj;
+        double best = (ti0 * tj0 == 4 ? 1.0 : ti0 * tj0 == 2 ? 0.9 : 0.8) * wave_eff(blocks(ti0, tj0), ti0 * tj0 == 4 ? 512 : 768);
+        if (ti0 * tj0 == 4) {
+            const double c21 = 0.9 * wave_eff(blocks(2, 1), 768), c12 = 0.9 * wave_eff(blocks(1, 2), 768);
+            if (c12 > best + 0.05) { best = c12; ti = 1; tj = 2; }
+            if (c21 > best + 0.05) { best = c21; ti = 2; tj = 1; }
+        }
+        if (ti0 * tj0 >= 2) {
+            const long long nb1 = blocks(1, 1);
+            double q = wave_eff(nb1, 768);
+            if (nb1 >= 1536 && q < 0.9) q = 0.9;
+            if (0.8 * q > best + 0.05) { ti = 1; tj = 1; }
+        }
+    } else if (blocks(ti, tj) < 512) {
+        const long long nb = blocks(ti, tj);
+        long long s = (512 + nb - 1) / nb;
+        if (s > ktiles / 16) s = ktiles / 16;
+        if (ti * tj > 1 && s >= 1 && nb * s >= 384) {
+            splits = (int)s;
+        } else {
+            ti = tj = 1;
+            const long long nb1 = blocks(1, 1);
+            if (nb1 < 256) {
+                s = 512 / nb1;
+                if (s > ktiles / 8) s = ktiles / 8;
+                splits = s < 1 ? 1 : (int)s;
+            }
+        }
     }
+    p.tiles_m = (M + 64 * ti - 1) / (64 * ti);
+    p.tiles_n = (N + 64 * tj - 1) / (64 * tj);
+#ifdef NK_AB_GEMM_FORCE  // benchmarks/ab_build.py only: NK_GEMM_FORCE="ti,tj,splits" overrides the heuristic
+    if (const char* f = getenv("NK_GEMM_FORCE")) {
+        int a = 0, b = 0, c = 0;
+        if (sscanf(f, "%d,%d,%d", &a, &b, &c) == 3) {
+            ti = a; tj = b; splits = c < 1 ? 1 : c;
+            p.tiles_m = (M + 64 * ti - 1) / (64 * ti);
+            p.tiles_n = (N + 64 * tj - 1) / (64 * tj);
+        }
+    }
+#endif
     int kts = (ktiles + splits - 1) / splits;
     if (kts < 1) kts = 1;
     splits = (ktiles + kts - 1) / kts;
@@ -223,6 +281,7 @@ static int gemm_impl(nk_device* dev, int transA, int transB, int M, int N, int K
         p.slabs = (float*)ws;
     }
 
+    const int BM = 64 * ti, BN = 64 * tj;
     const bool aligned = (M % BM == 0) && (N % BN == 0) && (K % BK == 0) && (lda % 4 == 0) &&
                          (ldb % 4 == 0) && aligned16(A) && aligned16(B) && (sAo % 4 == 0) &&
                          (sAi % 4 == 0) && (sBo % 4 == 0) && (sBi % 4 == 0);
@@ -235,6 +294,12 @@ static int gemm_impl(nk_device* dev, int transA, int transB, int M, int N, int K
     if (rc) return rc;
     if (p.splits > 1) {
         const long long total = (long long)M * N * nbatch;
+        const bool dense = ldc == N && N % 4 == 0 && aligned16(C) && (!bias || aligned16(bias)) &&
+                           (nbatch == 1 || (sCi == (long long)M * N && (batch_outer == 1 || sCo == (long long)batch_inner * M * N)));
+        if (dense)
+            hipLaunchKernelGGL(splitk_reduce_flat_kernel, dim3(nk_stream_grid((size_t)(total / 4), 256)), dim3(256), 0, dev->compute,
+                               p.slabs, C, total / 4, p.splits, alpha, beta, bias, N);
+        else
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(nk_stream_grid((size_t)total, 256)), dim3(256), 0,
                            dev->compute, p.slabs, C, M, N, (long long)ldc, p.splits, nbatch, batch_inner,
                            sCo, sCi, alpha, beta, bias);
