@@ -1590,6 +1590,29 @@ void RMSProp::optimize(const VarDiff& p, std::vector<Shared<HipArray>>& st, int)
                           mom ? st[2]->ptr() : nullptr, g.len(), lr_, alpha_, eps_, momentum_, penalty_.l1, penalty_.l2));
 }
 
+namespace lr_scheduler {
+void LRScheduler::step() {
+    last_lr_ = current_lr_;  // prepare_step, lr_scheduler/mod.rs:51-59
+    epoch_ += 1;
+    float lr = current_lr_;
+    if (update(lr)) {
+        current_lr_ = lr;
+        opt_.set_lr(current_lr_);
+    }
+}
+bool StepLR::update(float& lr) {
+    if (step_size_ == 0) panic("attempt to calculate the remainder with a divisor of zero");  // `rem_euclid(0)`
+    if (epoch_ % step_size_ != 0) return false;
+    lr = last_lr_ * gamma_;
+    return true;
+}
+bool MultiStepLR::update(float& lr) {
+    if (std::find(milestones_.begin(), milestones_.end(), epoch_) == milestones_.end()) return false;
+    lr = last_lr_ * gamma_;
+    return true;
+}
+}  // namespace lr_scheduler
+
 }  // namespace optim
 
 // =================================================================================================

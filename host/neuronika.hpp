@@ -29,6 +29,7 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <functional>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -571,6 +572,74 @@ class RMSProp : public Optimizer {  // rmsprop/mod.rs
     float alpha_, eps_, momentum_;
     bool centered_;
 };
+
+// neuronika-optim/src/lr_scheduler/{mod,step_lr,multi_step_lr,exponential_lr,lambda_lr,multiplicative_lr}.rs:
+// `step()` = prepare_step (last_lr <- current_lr, epoch += 1; mod.rs:51-59) then the policy, then `optimizer.set_lr`.
+namespace lr_scheduler {
+
+class LRScheduler {
+   public:
+    virtual ~LRScheduler() = default;
+    void step();
+    float get_last_lr() const { return last_lr_; }
+    float get_current_lr() const { return current_lr_; }
+    size_t get_current_epoch() const { return epoch_; }
+    void set_current_epoch(size_t e) { epoch_ = e; }
+
+   protected:
+    explicit LRScheduler(Optimizer& opt) : opt_(opt), initial_lr_(opt.get_lr()), last_lr_(opt.get_lr()), current_lr_(opt.get_lr()) {}
+    virtual bool update(float& lr) = 0;  // new lr for epoch_ (already incremented); false = unchanged
+    Optimizer& opt_;
+    float initial_lr_, last_lr_, current_lr_;
+    size_t epoch_ = 0;
+};
+class StepLR : public LRScheduler {  // every `step_size` epochs: lr *= gamma  (step_lr/mod.rs:59-65)
+   public:
+    StepLR(Optimizer& opt, size_t step_size, float gamma) : LRScheduler(opt), step_size_(step_size), gamma_(gamma) {}
+    void set_gamma(float g) { gamma_ = g; }
+
+   private:
+    bool update(float& lr) override;
+    size_t step_size_;
+    float gamma_;
+};
+class MultiStepLR : public LRScheduler {  // at each milestone: lr *= gamma  (multi_step_lr/mod.rs:56-67)
+   public:
+    MultiStepLR(Optimizer& opt, std::vector<size_t> milestones, float gamma) : LRScheduler(opt), milestones_(std::move(milestones)), gamma_(gamma) {}
+    void set_milestones(std::vector<size_t> m) { milestones_ = std::move(m); }
+
+   private:
+    bool update(float& lr) override;
+    std::vector<size_t> milestones_;
+    float gamma_;
+};
+class ExponentialLR : public LRScheduler {  // every epoch: lr *= gamma  (exponential_lr/mod.rs:54-58)
+   public:
+    ExponentialLR(Optimizer& opt, float gamma) : LRScheduler(opt), gamma_(gamma) {}
+    void set_gamma(float g) { gamma_ = g; }
+
+   private:
+    bool update(float& lr) override { lr = last_lr_ * gamma_; return true; }
+    float gamma_;
+};
+class LambdaLR : public LRScheduler {  // lr = initial_lr * f(epoch)  (lambda_lr/mod.rs:56-61)
+   public:
+    LambdaLR(Optimizer& opt, std::function<float(size_t)> f) : LRScheduler(opt), f_(std::move(f)) {}
+
+   private:
+    bool update(float& lr) override { lr = initial_lr_ * f_(epoch_); return true; }
+    std::function<float(size_t)> f_;
+};
+class MultiplicativeLR : public LRScheduler {  // lr = last_lr * f(epoch)  (multiplicative_lr/mod.rs:54-59)
+   public:
+    MultiplicativeLR(Optimizer& opt, std::function<float(size_t)> f) : LRScheduler(opt), f_(std::move(f)) {}
+
+   private:
+    bool update(float& lr) override { lr = last_lr_ * f_(epoch_); return true; }
+    std::function<float(size_t)> f_;
+};
+
+}  // namespace lr_scheduler
 
 }  // namespace optim
 

@@ -2,6 +2,7 @@
 // harness as `neuronika_amd._tape`.  Harness plumbing only: the drop-in boundary is the C ABI.
 #include <pybind11/numpy.h>
 #include <pybind11/pybind11.h>
+#include <pybind11/functional.h>
 #include <pybind11/stl.h>
 
 #include "neuronika.hpp"
@@ -287,6 +288,27 @@ PYBIND11_MODULE(_tape, m) {
         .def("forward", &nn::MultiheadAttention::forward);
 
     py::module_ optim = m.def_submodule("optim");
+    {
+        namespace ls = optim::lr_scheduler;
+        py::module_ lm = optim.def_submodule("lr_scheduler");
+        py::class_<ls::LRScheduler>(lm, "LRScheduler")
+            .def("step", &ls::LRScheduler::step)
+            .def("get_last_lr", &ls::LRScheduler::get_last_lr)
+            .def("get_current_lr", &ls::LRScheduler::get_current_lr)
+            .def("get_current_epoch", &ls::LRScheduler::get_current_epoch)
+            .def("set_current_epoch", &ls::LRScheduler::set_current_epoch);
+        py::class_<ls::StepLR, ls::LRScheduler>(lm, "StepLR")
+            .def(py::init<optim::Optimizer&, size_t, float>(), py::keep_alive<1, 2>()).def("set_gamma", &ls::StepLR::set_gamma);
+        py::class_<ls::MultiStepLR, ls::LRScheduler>(lm, "MultiStepLR")
+            .def(py::init<optim::Optimizer&, std::vector<size_t>, float>(), py::keep_alive<1, 2>())
+            .def("set_milestones", &ls::MultiStepLR::set_milestones);
+        py::class_<ls::ExponentialLR, ls::LRScheduler>(lm, "ExponentialLR")
+            .def(py::init<optim::Optimizer&, float>(), py::keep_alive<1, 2>()).def("set_gamma", &ls::ExponentialLR::set_gamma);
+        py::class_<ls::LambdaLR, ls::LRScheduler>(lm, "LambdaLR")
+            .def(py::init<optim::Optimizer&, std::function<float(size_t)>>(), py::keep_alive<1, 2>());
+        py::class_<ls::MultiplicativeLR, ls::LRScheduler>(lm, "MultiplicativeLR")
+            .def(py::init<optim::Optimizer&, std::function<float(size_t)>>(), py::keep_alive<1, 2>());
+    }
     py::class_<optim::Optimizer>(optim, "Optimizer")
         .def("register", &optim::Optimizer::register_param)
         .def("step", &optim::Optimizer::step)
