@@ -461,13 +461,13 @@ struct AttnProbsFwd : Forward {
         const uint64_t offset = (*calls) * ((x->len() + 3) / 4);
         ++(*calls);
         *last_offset = offset;
-        check(nk_scale_softmax_dropout_fwd(D(x), x->ptr(), probs->ptr(), out->ptr(), nullptr, rows, L, scale, p,
+        check(nk_scale_softmax_dropout_fwd(D(x), x->ptr(), probs ? probs->ptr() : nullptr, out->ptr(), nullptr, rows, L, scale, p,
                                            *status ? 1 : 0, seed, offset));
     }
 };
 struct AttnProbsBwd : Backward {
     Shared<Gradient> dx, g;
-    Shared<HipArray> probs;
+    Shared<HipArray> probs, scores;  // probs null: recomputed from the scores (the forward did not store them)
     float scale;
     double p;
     Shared<bool> status;
@@ -477,8 +477,13 @@ struct AttnProbsBwd : Backward {
         bool assign = false;
         HipArray& d = dx->borrow_first_write(assign);
         const int L = d.shape().back();
-        check((assign ? nk_scale_softmax_dropout_bwd_assign : nk_scale_softmax_dropout_bwd)(d.device()->raw(), d.ptr(), g->borrow().ptr(), probs->ptr(), nullptr,
-                                           (long long)(d.len() / (size_t)L), L, scale, p, *status ? 1 : 0, seed, *last_offset));
+        const long long rows = (long long)(d.len() / (size_t)L);
+        if (!probs)
+            check(nk_scale_softmax_dropout_bwd_from_scores(d.device()->raw(), d.ptr(), g->borrow().ptr(), scores->ptr(), nullptr, rows, L,
+                                                           scale, p, *status ? 1 : 0, seed, *last_offset, assign ? 1 : 0));
+        else
+            check((assign ? nk_scale_softmax_dropout_bwd_assign : nk_scale_softmax_dropout_bwd)(d.device()->raw(), d.ptr(), g->borrow().ptr(), probs->ptr(), nullptr,
+                                               rows, L, scale, p, *status ? 1 : 0, seed, *last_offset));
     }
     void targets(std::vector<const Gradient*>& out) const override { out.push_back(dx.get()); }
 };
@@ -966,11 +971,12 @@ Var Var::mm_t(const Var& rhs) const { return matmul_var(1, *this, rhs); }
 VarDiff Var::mm_t(const VarDiff& rhs) const { return matmul_diff(1, *this, nullptr, nullptr, rhs.var, rhs.grad, &rhs.history); }
 Var Var::bmm(const Var& rhs) const { return matmul_var(2, *this, rhs); }
 Var Var::bmm_t(const Var& rhs) const { return matmul_var(3, *this, rhs); }
-Var Var::attention_probs(float scale, double p, Shared<bool> status) const {
+Var Var::attention_probs(float scale, double p, Shared<bool> status, bool store_probs) const {
     if (!(p >= 0.0 && p <= 1.0)) panic("Wrong probability received: " + std::to_string(p) + ".");
     if (shape().empty()) panic("attention_probs: at least one axis expected");
     auto op = std::make_shared<AttnProbsFwd>();
-    op->x = data; op->probs = zeros_like(data, shape()); op->out = zeros_like(data, shape());
+    op->x = data; op->out = zeros_like(data, shape());
+    if (store_probs) op->probs = zeros_like(data, shape());
     op->scale = scale; op->p = p; op->status = std::move(status);
     static uint64_t next_seed = 0xD1B54A32D192ED03ull;
     op->seed = next_seed; next_seed += 0x9E3779B97F4A7C15ull;
@@ -1161,12 +1167,12 @@ VarDiff VarDiff::mm_t(const VarDiff& rhs) const { return matmul_diff(1, var, gra
 VarDiff VarDiff::bmm(const VarDiff& rhs) const { return matmul_diff(2, var, grad, &history, rhs.var, rhs.grad, &rhs.history); }
 VarDiff VarDiff::bmm_t(const VarDiff& rhs) const { return matmul_diff(3, var, grad, &history, rhs.var, rhs.grad, &rhs.history); }
 
-VarDiff VarDiff::attention_probs(float scale, double p, Shared<bool> status) const {
-    Var v = var.attention_probs(scale, p, status);
+VarDiff VarDiff::attention_probs(float scale, double p, Shared<bool> status, bool store_probs) const {
+    Var v = var.attention_probs(scale, p, status, store_probs);
     auto fwd = std::dynamic_pointer_cast<AttnProbsFwd>(v.history.to_vec().back().op);
     auto g = std::make_shared<Gradient>(device(), shape());
     auto bw = std::make_shared<AttnProbsBwd>();
-    bw->dx = grad; bw->g = g; bw->probs = fwd->probs; bw->scale = scale; bw->p = p; bw->status = status;
+    bw->dx = grad; bw->g = g; bw->probs = fwd->probs; bw->scores = fwd->x; bw->scale = scale; bw->p = p; bw->status = status;
     bw->seed = fwd->seed; bw->last_offset = fwd->last_offset;
     return VarDiff::node(std::move(v), g, entry(bw, g), history);
 }
@@ -1256,6 +1262,77 @@ static VarDiff uniform_param(const DevicePtr& dev, const Shape& s, float k, uint
     const auto v = uniform(numel(s), -k, k, seed);
     return from_host(dev, s, v.data()).requires_grad();
 }
+namespace init {
+float calculate_gain(const std::string& nl) {
+    if (nl == "linear" || nl == "sigmoid") return 1.f;
+    if (nl == "tanh") return 5.f / 3.f;
+    if (nl == "relu") return std::sqrt(2.f);
+    if (nl == "leaky_relu") return std::sqrt(2.f / (1.f + 0.01f * 0.01f));
+    panic("error: unsupported nonlinearity: " + nl);
+}
+std::pair<float, float> calculate_fan_in_fan_out(const VarDiff& param) {
+    const Shape& s = param.shape();
+    if (s.size() < 2) panic("index out of bounds: fan in / fan out need at least 2 dimensions");  // `shape[1]`
+    size_t fan_in = (size_t)s[1], fan_out = (size_t)s[0];
+    if (s.size() > 2) {
+        size_t numel = 0;  // init.rs:55: `.skip(2).sum()` - the reference SUMS the trailing extents
+        for (size_t i = 2; i < s.size(); ++i) numel += (size_t)s[i];
+        fan_in *= numel; fan_out *= numel;
+    }
+    return {(float)fan_in, (float)fan_out};
+}
+void constant(const VarDiff& p, float v) { p.var.data->fill(v); }
+void zeros(const VarDiff& p) { p.var.data->fill(0.f); }
+void ones(const VarDiff& p) { p.var.data->fill(1.f); }
+void eye(const VarDiff& p) {
+    const Shape& s = p.shape();
+    if (s.size() != 2) panic("eye: a 2-dimensional parameter is expected");
+    std::vector<float> h(numel(s), 0.f);
+    for (int i = 0; i < std::min(s[0], s[1]); ++i) h[(size_t)i * s[1] + i] = 1.f;
+    p.var.data->upload(h.data());
+}
+void dirac(const VarDiff& p, int groups) {
+    const Shape& s = p.shape();
+    if (s.size() < 3 || s.size() > 5) panic("error: only 3, 4 and 5 dimensional parameters are supported.");
+    if (groups < 1 || s[0] % groups != 0) panic("error: output channels must be divisible by groups.");
+    std::vector<float> h = p.to_vec();  // only the selected elements are set (init.rs:152-169), the rest is kept
+    const int opg = s[0] / groups, min_dim = std::min(opg, s[1]);
+    std::vector<size_t> stride(s.size(), 1);
+    for (int i = (int)s.size() - 2; i >= 0; --i) stride[i] = stride[i + 1] * (size_t)s[i + 1];
+    for (int g = 0; g < groups; ++g)
+        for (int d = 0; d < min_dim; ++d) {
+            size_t off = (size_t)(g * opg + d) * stride[0] + (size_t)d * stride[1];
+            for (size_t i = 2; i < s.size(); ++i) off += (size_t)(s[i] / 2) * stride[i];
+            h[off] = 1.f;
+        }
+    p.var.data->upload(h.data());
+}
+void uniform(const VarDiff& p, float low, float high, uint64_t seed) {
+    std::mt19937_64 rng(seed);
+    std::uniform_real_distribution<float> d(low, high);
+    std::vector<float> h(numel(p.shape()));
+    for (float& v : h) v = d(rng);
+    p.var.data->upload(h.data());
+}
+void normal(const VarDiff& p, float mean, float std, uint64_t seed) {
+    if (!(std >= 0.f) || !std::isfinite(std)) panic("called `Result::unwrap()` on an `Err` value: BadVariance");  // Normal::new(..).unwrap()
+    std::mt19937_64 rng(seed);
+    std::normal_distribution<float> d(mean, std);
+    std::vector<float> h(numel(p.shape()));
+    for (float& v : h) v = std == 0.f ? mean : d(rng);
+    p.var.data->upload(h.data());
+}
+void xavier_uniform(const VarDiff& p, float gain, uint64_t seed) {
+    const auto f = calculate_fan_in_fan_out(p);
+    const float sd = gain * std::sqrt(2.f / (f.first + f.second)), a = std::sqrt(3.f) * sd;
+    uniform(p, -a, a, seed);
+}
+void xavier_normal(const VarDiff& p, float gain, uint64_t seed) {
+    const auto f = calculate_fan_in_fan_out(p);
+    normal(p, 0.f, gain * std::sqrt(2.f / (f.first + f.second)), seed);
+}
+}  // namespace init
+
 Linear::Linear(DevicePtr dev, int in_features, int out_features, uint64_t seed)
     : weight(uniform_param(dev, {out_features, in_features}, 1.f / std::sqrt((float)in_features), seed)),
       bias(uniform_param(dev, {out_features}, 1.f / std::sqrt((float)in_features), seed + 1)) {}

@@ -279,7 +279,8 @@ class Var {
     Var bmm_t(const Var& rhs) const;
     // dropout(softmax(self * scale, last axis), p): the Multiplication + Softmax + Dropout nodes of
     // the attention probabilities as ONE node (same values, one pass over the score tensor)
-    Var attention_probs(float scale, double p, Shared<bool> status) const;
+    // (store_probs = false: the backward pass recomputes the probabilities from the scores, bit-identically)
+    Var attention_probs(float scale, double p, Shared<bool> status, bool store_probs = false) const;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -352,7 +353,7 @@ class VarDiff {
     VarDiff merge_heads(int B, int S, int H, int dh) const;
     VarDiff bmm(const VarDiff& rhs) const;
     VarDiff bmm_t(const VarDiff& rhs) const;
-    VarDiff attention_probs(float scale, double p, Shared<bool> status) const;
+    VarDiff attention_probs(float scale, double p, Shared<bool> status, bool store_probs = false) const;
 };
 
 // `Add/Sub/Mul/Div` with NumPy broadcasting, all four differentiability combinations
@@ -381,6 +382,22 @@ Var rand(DevicePtr dev, const Shape& shape, uint64_t seed);  // U[0,1) (host RNG
 // neuronika-nn
 // ---------------------------------------------------------------------------------------------
 namespace nn {
+
+// neuronika-nn/src/init.rs: parameter initialisers.  Values are produced on the host and uploaded (one-off work at
+// model construction).  The random ones take an explicit seed (the reference draws from `thread_rng`).
+namespace init {
+float calculate_gain(const std::string& non_linearity);                 // init.rs:25-33
+std::pair<float, float> calculate_fan_in_fan_out(const VarDiff& param);  // init.rs:45-64 (trailing extents are SUMMED there)
+void constant(const VarDiff& param, float value);                        // :74
+void zeros(const VarDiff& param);                                        // :83
+void ones(const VarDiff& param);                                         // :92
+void eye(const VarDiff& param);                                          // :104
+void dirac(const VarDiff& param, int groups);                            // :131-170
+void uniform(const VarDiff& param, float low, float high, uint64_t seed);            // :177
+void normal(const VarDiff& param, float mean, float std, uint64_t seed);             // :195
+void xavier_uniform(const VarDiff& param, float gain, uint64_t seed);                // :213
+void xavier_normal(const VarDiff& param, float gain, uint64_t seed);                 // :236
+}  // namespace init
 
 // `Linear` neuronika-nn/src/lib.rs:406-448: weight (out,in), bias (out), U(-k,k), k = 1/sqrt(in)
 struct Linear {

@@ -236,6 +236,17 @@ PYBIND11_MODULE(_tape, m) {
         .def_readwrite("fused", &nn::Linear::fused)
         .def("forward", py::overload_cast<const Var&>(&nn::Linear::forward, py::const_))
         .def("forward", py::overload_cast<const VarDiff&>(&nn::Linear::forward, py::const_));
+    {
+        py::module_ im = nn.def_submodule("init");
+        im.def("calculate_gain", &nn::init::calculate_gain);
+        im.def("calculate_fan_in_fan_out", &nn::init::calculate_fan_in_fan_out);
+        im.def("constant", &nn::init::constant); im.def("zeros", &nn::init::zeros); im.def("ones", &nn::init::ones);
+        im.def("eye", &nn::init::eye); im.def("dirac", &nn::init::dirac);
+        im.def("uniform", &nn::init::uniform, py::arg("param"), py::arg("low"), py::arg("high"), py::arg("seed") = 0);
+        im.def("normal", &nn::init::normal, py::arg("param"), py::arg("mean"), py::arg("std"), py::arg("seed") = 0);
+        im.def("xavier_uniform", &nn::init::xavier_uniform, py::arg("param"), py::arg("gain"), py::arg("seed") = 0);
+        im.def("xavier_normal", &nn::init::xavier_normal, py::arg("param"), py::arg("gain"), py::arg("seed") = 0);
+    }
     using State = std::pair<VarDiff, VarDiff>;
     py::class_<nn::LSTMCell>(nn, "LSTMCell")
         .def(py::init<DevicePtr, int, int, uint64_t>(), py::arg("dev"), py::arg("input_size"), py::arg("hidden_size"), py::arg("seed") = 0)

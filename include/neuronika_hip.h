@@ -333,6 +333,13 @@ int nk_scale_softmax_dropout_fwd(nk_device* dev, const float* scores, float* pro
 int nk_scale_softmax_dropout_bwd(nk_device* dev, float* d_scores, const float* g_out, const float* probs,
                                  const float* noise, long long rows, int L, float scale, double p, int train,
                                  uint64_t seed, uint64_t offset);
+/* Same backward with the probabilities RECOMPUTED from the scores (the forward kernel's exact operation sequence, so
+ * bit-identical values): pass `probs = NULL` to nk_scale_softmax_dropout_fwd and the 4-byte/element store plus the
+ * buffer disappear.  `assign` != 0: first-write form (see the _assign variants). */
+int nk_scale_softmax_dropout_bwd_from_scores(nk_device* dev, float* d_scores, const float* g_out,
+                                             const float* scores, const float* noise, long long rows,
+                                             int L, float scale, double p, int train, uint64_t seed,
+                                             uint64_t offset, int assign);
 
 /* ------------------------------------------------------------------ dropout ------------ */
 /* Dropout::forward node/dropout/mod.rs:53-79.  train && 0<p<1: noise ~ Bernoulli(1-p) in

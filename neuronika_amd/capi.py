@@ -111,6 +111,7 @@ _SIGS = {
     "nk_pad_bwd_assign": [VP, C.c_int, VP, c_intp, VP, c_intp],
     "nk_split_heads_bwd_assign": [VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int],
     "nk_merge_heads_bwd_assign": [VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int],
+    "nk_scale_softmax_dropout_bwd_from_scores": [VP, VP, VP, VP, VP, C.c_longlong, C.c_int, C.c_float, C.c_double, C.c_int, C.c_uint64, C.c_uint64, C.c_int],
     "nk_scale_softmax_dropout_bwd_assign": [VP, VP, VP, VP, VP, C.c_longlong, C.c_int, C.c_float, C.c_double, C.c_int, C.c_uint64, C.c_uint64],
     "nk_loss_fwd": [VP, C.c_int, VP, VP, c_intp, C.c_int, C.c_int, VP],
     "nk_loss_bwd": [VP, C.c_int, VP, VP, VP, VP, c_intp, C.c_int, C.c_int],
@@ -527,7 +528,7 @@ def dropout_bwd(dev, dx, g, noise, p, train=True):
 
 def scale_softmax_dropout_fwd(dev, scores, probs, out, noise, scale, p, train=True, seed=0, offset=0):
     L = scores.shape[-1]
-    check(lib.nk_scale_softmax_dropout_fwd(dev.h, scores.p, probs.p, out.p, noise.p if noise is not None else None,
+    check(lib.nk_scale_softmax_dropout_fwd(dev.h, scores.p, probs.p if probs is not None else None, out.p, noise.p if noise is not None else None,
                                            scores.size // L, L, scale, float(p), int(train), seed, offset))
 
 
@@ -535,6 +536,12 @@ def scale_softmax_dropout_bwd(dev, d_scores, g_out, probs, noise, scale, p, trai
     L = probs.shape[-1]
     check((lib.nk_scale_softmax_dropout_bwd_assign if assign else lib.nk_scale_softmax_dropout_bwd)(dev.h, d_scores.p, g_out.p, probs.p, noise.p if noise is not None else None,
                                            probs.size // L, L, scale, float(p), int(train), seed, offset))
+
+
+def scale_softmax_dropout_bwd_from_scores(dev, d_scores, g_out, scores, noise, scale, p, train=True, seed=0, offset=0, assign=False):
+    L = scores.shape[-1]
+    check(lib.nk_scale_softmax_dropout_bwd_from_scores(dev.h, d_scores.p, g_out.p, scores.p, noise.p if noise is not None else None,
+                                                       scores.size // L, L, scale, float(p), int(train), seed, offset, int(assign)))
 
 
 def chunk_fwd(dev, x, y, chunk_no):

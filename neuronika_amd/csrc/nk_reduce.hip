@@ -305,7 +305,7 @@ __global__ void attn_probs_fwd_kernel(const float* __restrict__ s, float* __rest
         if (c < L) {
             float4 y;
             y.x = v[i].x / sum; y.y = v[i].y / sum; y.z = v[i].z / sum; y.w = v[i].w / sum;   // Softmax node
-            *reinterpret_cast<float4*>(probs + rb + c) = y;
+            if (probs) *reinterpret_cast<float4*>(probs + rb + c) = y;  // not stored when the backward pass recomputes it
             float4 o = y;
             if (MASK == 1) {                                                                   // Dropout node
                 const unsigned long long ctr = (unsigned long long)(rb + c) / 4 + offset;
@@ -322,7 +322,9 @@ __global__ void attn_probs_fwd_kernel(const float* __restrict__ s, float* __rest
 }
 
 // MASK 0: g_p = g ; 1: g_p = g * mask (stored or regenerated)
-template <int V, int MASK, bool LOAD_NOISE>
+// RECOMP: `probs` holds the SCORES; the probabilities are recomputed with the forward kernel's exact sequence
+// (scale, wave max, expf, wave sum, divide) instead of being read back - the forward then never writes them.
+template <int V, int MASK, bool LOAD_NOISE, bool RECOMP>
 __global__ void attn_probs_bwd_kernel(float* __restrict__ ds, const float* __restrict__ g, const float* __restrict__ probs,
                                       const float* __restrict__ noise, long long rows, int L, float scale, float keep,
                                       unsigned long long seed, unsigned long long offset, int assign) {
@@ -332,13 +334,44 @@ __global__ void attn_probs_bwd_kernel(float* __restrict__ ds, const float* __res
     const long long rb = row * L;
     const uint2 key = make_uint2((unsigned)seed, (unsigned)(seed >> 32));
     float4 gp[V], y[V];
+    if (RECOMP) {
+        float m = F32_MIN;
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            if (c < L) {
+                float4 x = *reinterpret_cast<const float4*>(probs + rb + c);
+                x.x *= scale; x.y *= scale; x.z *= scale; x.w *= scale;
+                y[i] = x;
+                m = fmaxf(m, fmaxf(fmaxf(x.x, x.y), fmaxf(x.z, x.w)));
+            }
+        }
+        m = nk_wave_max(m);
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            if (c < L) {
+                float4 e;
+                e.x = expf(y[i].x - m); e.y = expf(y[i].y - m); e.z = expf(y[i].z - m); e.w = expf(y[i].w - m);
+                sum += (e.x + e.y) + (e.z + e.w);
+                y[i] = e;
+            }
+        }
+        sum = nk_wave_sum(sum);
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            if (c < L) { y[i].x /= sum; y[i].y /= sum; y[i].z /= sum; y[i].w /= sum; }
+        }
+    }
     float dot = 0.f;
 #pragma unroll
     for (int i = 0; i < V; ++i) {
         const int c = (i * 64 + lane) * 4;
         if (c < L) {
             float4 gv = *reinterpret_cast<const float4*>(g + rb + c);
-            y[i] = *reinterpret_cast<const float4*>(probs + rb + c);
+            if (!RECOMP) y[i] = *reinterpret_cast<const float4*>(probs + rb + c);
             if (MASK == 1) {                                                                   // DropoutBackward
                 float4 nz;
                 if (LOAD_NOISE) nz = *reinterpret_cast<const float4*>(noise + rb + c);
@@ -487,8 +520,8 @@ int nk_scale_softmax_dropout_fwd(nk_device* dev, const float* scores, float* pro
     NK_CHECK(p >= 0.0 && p <= 1.0, "Wrong probability received: %g.", p);
     NK_CHECK(rows >= 0 && L >= 0, "negative extent");
     if (rows == 0 || L == 0) return NK_OK;
-    NK_CHECK(scores && probs && out, "null pointer in nk_scale_softmax_dropout_fwd");
-    NK_CHECK(L % 4 == 0 && L <= 2048 && al16(scores) && al16(probs) && al16(out) && (!noise || al16(noise)),
+    NK_CHECK(scores && out, "null pointer in nk_scale_softmax_dropout_fwd");  // probs may be NULL: not stored
+    NK_CHECK(L % 4 == 0 && L <= 2048 && al16(scores) && (!probs || al16(probs)) && al16(out) && (!noise || al16(noise)),
              "fused attention probabilities need L %% 4 == 0, L <= 2048 and 16-byte aligned buffers (L=%d)", L);
     const int mask = (!train || p == 0.0) ? 0 : (1.0 - p == 0.0 ? 2 : 1);
     const float keep = (float)(1.0 - p), dscale = 1.f - (float)p;
@@ -509,7 +542,8 @@ int nk_scale_softmax_dropout_fwd(nk_device* dev, const float* scores, float* pro
 }  // extern "C"
 
 static int attn_probs_bwd(nk_device* dev, float* d_scores, const float* g_out, const float* probs, const float* noise,
-                          long long rows, int L, float scale, double p, int train, uint64_t seed, uint64_t offset, int assign) {
+                          long long rows, int L, float scale, double p, int train, uint64_t seed, uint64_t offset, int assign,
+                          bool recompute = false) {
     NK_USE(dev);
     NK_CHECK(p >= 0.0 && p <= 1.0, "Wrong probability received: %g.", p);
     NK_CHECK(rows >= 0 && L >= 0, "negative extent");
@@ -523,9 +557,13 @@ static int attn_probs_bwd(nk_device* dev, float* d_scores, const float* g_out, c
     const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
 #define NK_AP(V)                                                                                                   \
     do {                                                                                                           \
-        if (!masked) hipLaunchKernelGGL((attn_probs_bwd_kernel<V, 0, false>), grid, block, 0, dev->compute, d_scores, g_out, probs, noise, rows, L, scale, keep, (unsigned long long)seed, (unsigned long long)offset, assign); \
-        else if (noise && keep >= 0.f) hipLaunchKernelGGL((attn_probs_bwd_kernel<V, 1, true>), grid, block, 0, dev->compute, d_scores, g_out, probs, noise, rows, L, scale, keep, (unsigned long long)seed, (unsigned long long)offset, assign); \
-        else hipLaunchKernelGGL((attn_probs_bwd_kernel<V, 1, false>), grid, block, 0, dev->compute, d_scores, g_out, probs, noise, rows, L, scale, keep, (unsigned long long)seed, (unsigned long long)offset, assign); \
+        if (recompute) {                                                                                           \
+            if (!masked) hipLaunchKernelGGL((attn_probs_bwd_kernel<V, 0, false, true>), grid, block, 0, dev->compute, d_scores, g_out, probs, noise, rows, L, scale, keep, (unsigned long long)seed, (unsigned long long)offset, assign); \
+            else if (noise && keep >= 0.f) hipLaunchKernelGGL((attn_probs_bwd_kernel<V, 1, true, true>), grid, block, 0, dev->compute, d_scores, g_out, probs, noise, rows, L, scale, keep, (unsigned long long)seed, (unsigned long long)offset, assign); \
+            else hipLaunchKernelGGL((attn_probs_bwd_kernel<V, 1, false, true>), grid, block, 0, dev->compute, d_scores, g_out, probs, noise, rows, L, scale, keep, (unsigned long long)seed, (unsigned long long)offset, assign); \
+        } else if (!masked) hipLaunchKernelGGL((attn_probs_bwd_kernel<V, 0, false, false>), grid, block, 0, dev->compute, d_scores, g_out, probs, noise, rows, L, scale, keep, (unsigned long long)seed, (unsigned long long)offset, assign); \
+        else if (noise && keep >= 0.f) hipLaunchKernelGGL((attn_probs_bwd_kernel<V, 1, true, false>), grid, block, 0, dev->compute, d_scores, g_out, probs, noise, rows, L, scale, keep, (unsigned long long)seed, (unsigned long long)offset, assign); \
+        else hipLaunchKernelGGL((attn_probs_bwd_kernel<V, 1, false, false>), grid, block, 0, dev->compute, d_scores, g_out, probs, noise, rows, L, scale, keep, (unsigned long long)seed, (unsigned long long)offset, assign); \
     } while (0)
     if (L <= 256) NK_AP(1); else if (L <= 512) NK_AP(2); else if (L <= 1024) NK_AP(4); else NK_AP(8);
 #undef NK_AP
@@ -543,5 +581,10 @@ int nk_scale_softmax_dropout_bwd_assign(nk_device* dev, float* d_scores, const f
                                         const float* noise, long long rows, int L, float scale, double p, int train,
                                         uint64_t seed, uint64_t offset) {
     return attn_probs_bwd(dev, d_scores, g_out, probs, noise, rows, L, scale, p, train, seed, offset, 1);
+}
+int nk_scale_softmax_dropout_bwd_from_scores(nk_device* dev, float* d_scores, const float* g_out, const float* scores,
+                                             const float* noise, long long rows, int L, float scale, double p, int train,
+                                             uint64_t seed, uint64_t offset, int assign) {
+    return attn_probs_bwd(dev, d_scores, g_out, scores, noise, rows, L, scale, p, train, seed, offset, assign ? 1 : 0, true);
 }
 }  // extern "C"

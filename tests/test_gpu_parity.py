@@ -640,6 +640,14 @@ def test_assign_variants_equal_accumulate_into_zeros(dev):
     c.scale_softmax_dropout_bwd(dev, A, Gs, P, None, 0.125, 0.2, True, 11, 5, assign=True)
     c.scale_softmax_dropout_bwd(dev, Z, Gs, P, None, 0.125, 0.2, True, 11, 5)
     assert np.array_equal(A.numpy(), Z.numpy())
+    # probabilities recomputed from the scores in the backward pass (forward called with probs = NULL): same bits
+    O2 = dev.zeros(sc.shape)
+    c.scale_softmax_dropout_fwd(dev, Sx, None, O2, None, 0.125, 0.2, True, 11, 5)
+    assert np.array_equal(O2.numpy(), O_.numpy())
+    for assign in (True, False):
+        R = nan(sc.shape) if assign else dev.zeros(sc.shape)
+        c.scale_softmax_dropout_bwd_from_scores(dev, R, Gs, Sx, None, 0.125, 0.2, True, 11, 5, assign=assign)
+        assert np.array_equal(R.numpy(), Z.numpy())
 
 
 # ------------------------------------------------------------------------------ fused Linear forward

@@ -279,6 +279,45 @@ def test_pointwise_nodes_graph(nk, tdev):
     close(X.grad(), df, 2e-5, 1e-6)
 
 
+def test_nn_init(nk, tdev):
+    """neuronika-nn/src/init.rs: gains, fans (trailing extents summed, as there), constant/eye/dirac patterns and
+    the range / moments of the random initialisers."""
+    I = nk.nn.init
+    assert I.calculate_gain("linear") == 1.0 and I.calculate_gain("sigmoid") == 1.0
+    close(I.calculate_gain("tanh"), 5 / 3, 1e-7); close(I.calculate_gain("relu"), np.sqrt(2), 1e-7)
+    close(I.calculate_gain("leaky_relu"), np.sqrt(2 / (1 + 0.01 ** 2)), 1e-7)
+    with pytest.raises(RuntimeError, match="unsupported nonlinearity"):
+        I.calculate_gain("gelu")
+    P = nk.zeros(tdev, [6, 4, 3, 5]).requires_grad()
+    assert I.calculate_fan_in_fan_out(P) == (4.0 * 8, 6.0 * 8)              # (3 + 5), not 3 * 5: init.rs:55
+    assert I.calculate_fan_in_fan_out(nk.zeros(tdev, [7, 2]).requires_grad()) == (2.0, 7.0)
+    I.constant(P, 2.5); assert np.array_equal(P.data(), np.full((6, 4, 3, 5), 2.5, np.float32))
+    I.ones(P); assert P.data().min() == 1.0
+    I.zeros(P); assert P.data().max() == 0.0
+    I.dirac(P, 2)                                                            # 3 outputs per group, min(3, 4) diagonals
+    want = np.zeros((6, 4, 3, 5), np.float32)
+    for g in range(2):
+        for d in range(3):
+            want[g * 3 + d, d, 1, 2] = 1.0
+    assert np.array_equal(P.data(), want)
+    with pytest.raises(RuntimeError, match="divisible by groups"):
+        I.dirac(P, 4)
+    E = nk.zeros(tdev, [3, 5]).requires_grad()
+    I.eye(E); assert np.array_equal(E.data(), np.eye(3, 5, dtype=np.float32))
+    W = nk.zeros(tdev, [256, 128]).requires_grad()
+    I.uniform(W, -0.5, 0.25, 3); w = W.data()
+    assert w.min() >= -0.5 and w.max() < 0.25 and abs(w.mean() + 0.125) < 0.01
+    I.normal(W, 1.0, 2.0, 3); w = W.data()
+    assert abs(w.mean() - 1.0) < 0.05 and abs(w.std() - 2.0) < 0.05
+    I.xavier_uniform(W, 2.0, 5); w = W.data()
+    a = np.sqrt(3.0) * 2.0 * np.sqrt(2.0 / (128 + 256))
+    assert np.abs(w).max() <= a and np.abs(w).max() > 0.95 * a
+    I.xavier_normal(W, 1.0, 5); w = W.data()
+    assert abs(w.std() - np.sqrt(2.0 / 384)) < 0.003
+    I.uniform(W, 0.0, 1.0, 9); w1 = W.data().copy(); I.uniform(W, 0.0, 1.0, 9)
+    assert np.array_equal(w1, W.data())                                      # reproducible for a seed
+
+
 def test_lazy_zero_gradients(nk, tdev):
     """Gradients are born with a PENDING zero fill (gradient.rs:47-54 semantics, no memset): an untouched gradient
     reads as zeros, the first writer assigns, later writers accumulate, zero_grad() makes the fill pending again,
