@@ -492,17 +492,21 @@ __global__ void conv_wp_kernel(float* __restrict__ wp, const float* __restrict__
         wp[i] = w[(co * g.Cg + ci) * g.KK + tap];
     }
 }
-// Wq[grp][ci][tap][co] = W[grp*Mg + co][ci][tap]   (backward-input A operand, k = tap*Mg + co)
+// Wq[grp][ci][chunk][tap][c32] = W[grp*Mg + chunk*32 + c32][ci][tap]   (backward-input A operand).  k runs over
+// 32-channel chunks of co with the taps INSIDE a chunk: the 32 x (tile + halo) slab of the gradient that one chunk
+// needs is then re-read by all taps back to back (L2 hits) instead of once per tap across all of co (PMC: 1.7 GB
+// fetched per launch at C3 with the tap-major order, 9x the gradient).
 __global__ void conv_wq_kernel(float* __restrict__ wq, const float* __restrict__ w, ConvGeom g) {
     const long long total = (long long)g.Cout * g.Cg * g.KK;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {
-        const int co = (int)(i % g.Mg);
-        long long rem = i / g.Mg;
+        const int c32 = (int)(i % BK);
+        long long rem = i / BK;
         const int tap = (int)(rem % g.KK); rem /= g.KK;
+        const int chunk = (int)(rem % (g.Mg / BK)); rem /= (g.Mg / BK);
         const int ci = (int)(rem % g.Cg);
         const int grp = (int)(rem / g.Cg);
-        wq[i] = w[((long long)(grp * g.Mg + co) * g.Cg + ci) * g.KK + tap];
+        wq[i] = w[((long long)(grp * g.Mg + chunk * BK + c32) * g.Cg + ci) * g.KK + tap];
     }
 }
 
@@ -619,7 +623,7 @@ __global__ __launch_bounds__(NT, 2) void conv_bwd_input_fast_kernel(FastBwdInArg
     tile_coords(blockIdx.x, gridDim.x, p.tiles_m, p.tiles_n, tm, tn);
     const int grp = blockIdx.z;
     const int m0 = tm * BM, n0 = tn * BN;
-    const int K = g.Mg * g.KK, nt = K / BK, tpt = g.Mg / BK;
+    const int K = g.Mg * g.KK, nt = K / BK;
     const long long cols = (long long)g.N * g.inplane;
     const float* Wq = p.wq + (long long)grp * g.Cg * K;
     const float* G = p.gy + (long long)grp * g.Mg * g.L;
@@ -641,7 +645,7 @@ __global__ __launch_bounds__(NT, 2) void conv_bwd_input_fast_kernel(FastBwdInArg
     const bool rowquad = cv[3] && gb[3] == gb[0] && pa[3] == pa[0] && pb[3] == pb[0] && pc[3] == pc[0] + 3;
     const int jstep = 8 * g.L;
     auto gather = [&](int kt) {
-        const int tap = kt / tpt, co0 = (kt - tap * tpt) * BK;
+        const int chunk = kt / g.KK, tap = kt - chunk * g.KK, co0 = chunk * BK;  // taps inside a 32-channel chunk
         const int4 d = p.tapd[tap];
         const float* src = G + co0 * g.L;
         // output position each column reads for this tap (-1: outside -> contributes 0)
