@@ -652,7 +652,22 @@ struct LinearBwd : Backward {
         // same order as MatrixMatrixMulTBackward (left, right) followed by AdditionBackwardRight
         float beta;  // nk_mm_t_bwd_left / nk_mm_t_bwd_right, with beta 0 when the gradient's zero fill is still pending
         if (dx) { float* d = first_write(dx, beta); check(nk_sgemm(dev, 0, 0, n, m, o, 1.f, G.ptr(), o, w->ptr(), m, beta, d, m)); }
-        { float* d = first_write(dw, beta); check(nk_sgemm(dev, 1, 0, o, m, n, 1.f, G.ptr(), o, x->ptr(), m, beta, d, m)); }
+        {
+            float* d = first_write(dw, beta);
+            BackwardHook* hook = active_backward_hook();
+            // data-parallel exchange at row-block granularity: each half of dW (still >= 512 tiles of 128x128, a full
+            // wave of resident blocks) goes to the all-reduce as soon as it is issued, so only half a gradient's
+            // exchange is left exposed behind the last GEMM of the backward pass
+            const int h = o / 2;
+            if (hook && hook->wants_parts(dw.get()) && o % 256 == 0 && (long long)(h / 128) * ((m + 127) / 128) >= 512) {
+                for (int r0 = 0; r0 < o; r0 += h) {
+                    check(nk_sgemm(dev, 1, 0, h, m, n, 1.f, G.ptr() + r0, o, x->ptr(), m, beta, d + (size_t)r0 * m, m));
+                    hook->grad_part_ready(dw.get(), (size_t)r0 * m, (size_t)h * m);
+                }
+            } else {
+                check(nk_sgemm(dev, 1, 0, o, m, n, 1.f, G.ptr(), o, x->ptr(), m, beta, d, m));
+            }
+        }
         const int gs[2] = {n, o};
         check(nk_unbroadcast_add(dev, db->borrow().ptr(), &o, 1, G.ptr(), gs, 2));
     }
@@ -1034,6 +1049,15 @@ void VarDiff::forward() const {
     auto& buffer = history.buffer_mut();
     if (buffer.empty()) buffer = history.to_vec();
 }
+static thread_local BackwardHook* g_active_hook = nullptr;
+BackwardHook* active_backward_hook() { return g_active_hook; }
+namespace {
+struct ActiveHookScope {
+    explicit ActiveHookScope(BackwardHook* h) { g_active_hook = h; }
+    ~ActiveHookScope() { g_active_hook = nullptr; }
+};
+}  // namespace
+
 void VarDiff::backward(float seed, BackwardHook* hook) const {
     if (var.history.len() != var.history.buffer_len()) panic("Perhaps you forgot to call .forward()?");
     {
@@ -1045,6 +1069,7 @@ void VarDiff::backward(float seed, BackwardHook* hook) const {
         for (auto it = buffer.rbegin(); it != buffer.rend(); ++it) it->op->backward();
         return;
     }
+    ActiveHookScope scope(hook);
     // a gradient is final once the last node (in reverse order) that accumulates into it ran
     std::unordered_map<const Gradient*, size_t> last;
     std::vector<const Gradient*> ts;
@@ -1713,26 +1738,51 @@ GradientSync::GradientSync(std::shared_ptr<Communicator> comm, const std::vector
     for (const VarDiff& p : params) {
         params_[p.grad.get()] = p.grad;
         bytes_ += numel(p.shape()) * sizeof(float);
-        nk_event* ev = nullptr;
-        check(nk_event_create(comm_->device()->raw(), &ev));
-        events_.push_back(ev);
+        for (int k = 0; k < 2; ++k) {  // up to two pieces per gradient in flight
+            nk_event* ev = nullptr;
+            check(nk_event_create(comm_->device()->raw(), &ev));
+            events_.push_back(ev);
+        }
     }
 }
 GradientSync::~GradientSync() {
     for (nk_event* e : events_) nk_event_destroy(e);
 }
+bool GradientSync::wants_parts(const Gradient* g) const {
+    auto it = params_.find(g);
+    return it != params_.end() && active() && numel(it->second->shape()) >= (size_t)(4u << 20);  // >= 16 MB
+}
+void GradientSync::grad_part_ready(const Gradient* g, size_t offset, size_t count) {
+    auto it = params_.find(g);
+    if (it == params_.end() || !active()) return;
+    HipArray& a = it->second->borrow();
+    if (offset + count > a.len()) panic("grad_part_ready: piece exceeds the gradient");
+    nk_event* ev = events_[next_event_++ % events_.size()];
+    check(nk_event_record(ev, 0));  // everything up to the launch that finished this piece
+    check(nk_allreduce_sum_async(comm_->raw(), a.ptr() + offset, count, ev));
+    parts_done_[g] += count;
+    ++issued_;
+}
 void GradientSync::grad_ready(const Gradient* g) {
     auto it = params_.find(g);
     if (it == params_.end()) return;
-    if (comm_->size() == 1) return;  // nothing to exchange
+    if (!active()) return;  // nothing to exchange
+    HipArray& a = it->second->borrow();
+    auto pd = parts_done_.find(g);
+    if (pd != parts_done_.end() && pd->second != 0) {
+        const size_t done = pd->second;
+        pd->second = 0;
+        if (done == a.len()) return;  // already exchanged piece by piece
+        panic("GradientSync: a gradient was only partly exchanged piecewise");
+    }
     nk_event* ev = events_[next_event_++ % events_.size()];
     check(nk_event_record(ev, 0));  // everything up to the node that finalised g
-    HipArray& a = it->second->borrow();
     check(nk_allreduce_sum_async(comm_->raw(), a.ptr(), a.len(), ev));
+    ++issued_;
 }
 void GradientSync::join() {
     next_event_ = 0;
-    if (comm_->size() > 1) check(nk_comm_join(comm_->raw()));
+    if (active()) check(nk_comm_join(comm_->raw()));
 }
 
 void all_reduce_gradients(const Communicator& comm, const std::vector<VarDiff>& params) {

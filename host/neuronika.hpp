@@ -123,7 +123,14 @@ struct Backward {
 struct BackwardHook {
     virtual ~BackwardHook() = default;
     virtual void grad_ready(const Gradient* g) = 0;
+    // Optional finer grain: a node that produces a large gradient in several launches (Linear's weight gradient, as
+    // row blocks) asks `wants_parts` and reports each finished contiguous piece, so its exchange starts before the
+    // whole gradient is done.  `grad_ready` still follows once the node has been issued.
+    virtual bool wants_parts(const Gradient*) const { return false; }
+    virtual void grad_part_ready(const Gradient*, size_t /*offset*/, size_t /*count*/) {}
 };
+// the hook of the backward pass currently being issued on this thread (null outside `backward(seed, hook)`)
+BackwardHook* active_backward_hook();
 struct NoGrad {
     virtual ~NoGrad() = default;
     virtual void no_grad() = 0;
@@ -692,15 +699,24 @@ class GradientSync : public BackwardHook {
     GradientSync(std::shared_ptr<Communicator> comm, const std::vector<VarDiff>& params);
     ~GradientSync() override;
     void grad_ready(const Gradient* g) override;
+    bool wants_parts(const Gradient* g) const override;
+    void grad_part_ready(const Gradient* g, size_t offset, size_t count) override;
     void join();
     size_t bytes_per_step() const { return bytes_; }
+    // run the exchange even with a single rank (RCCL then copies in place): lets one GPU exercise every code path
+    void set_force_exchange(bool on) { force_ = on; }
+    size_t exchanges_issued() const { return issued_; }
 
    private:
     std::shared_ptr<Communicator> comm_;
     std::unordered_map<const Gradient*, Shared<Gradient>> params_;
+    std::unordered_map<const Gradient*, size_t> parts_done_;  // elements already exchanged piecewise this pass
     std::vector<nk_event*> events_;
     size_t next_event_ = 0;
     size_t bytes_ = 0;
+    size_t issued_ = 0;
+    bool force_ = false;
+    bool active() const { return comm_->size() > 1 || force_; }
 };
 
 // Non-overlapped form: all-reduce every gradient after backward has been issued.

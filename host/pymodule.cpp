@@ -361,6 +361,8 @@ PYBIND11_MODULE(_tape, m) {
     py::class_<dp::GradientSync>(dpm, "GradientSync")
         .def(py::init<std::shared_ptr<dp::Communicator>, const std::vector<VarDiff>&>())
         .def("join", &dp::GradientSync::join)
-        .def("bytes_per_step", &dp::GradientSync::bytes_per_step);
+        .def("bytes_per_step", &dp::GradientSync::bytes_per_step)
+        .def("set_force_exchange", &dp::GradientSync::set_force_exchange)
+        .def("exchanges_issued", &dp::GradientSync::exchanges_issued);
     dpm.def("all_reduce_gradients", &dp::all_reduce_gradients);
 }

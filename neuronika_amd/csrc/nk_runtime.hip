@@ -105,7 +105,12 @@ int nk_device_create(int idx, nk_device** out) {
     nk_device* d = new nk_device();
     d->idx = idx;
     NK_HIP(hipStreamCreateWithFlags(&d->compute, hipStreamNonBlocking));
-    NK_HIP(hipStreamCreateWithFlags(&d->comm, hipStreamNonBlocking));
+    {   // the all-reduce stream gets the highest priority: its few workgroups must be placed as soon as a GEMM block
+        // retires, not after the (long) GEMM grid of the compute stream has been dispatched
+        int least = 0, greatest = 0;
+        NK_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        NK_HIP(hipStreamCreateWithPriority(&d->comm, hipStreamNonBlocking, greatest));
+    }
     NK_HIP(hipStreamCreateWithFlags(&d->copy, hipStreamNonBlocking));
     NK_HIP(hipEventCreateWithFlags(&d->fork, hipEventDisableTiming));
     NK_HIP(hipEventCreateWithFlags(&d->join, hipEventDisableTiming));

@@ -610,3 +610,32 @@ def test_rccl_single_rank_and_gradient_sync(nk, tdev):
     loss.backward_sync(1.0, sync); sync.join()
     for p, w in zip(params, want):
         close(p.grad(), w, 1e-6, 1e-7)
+
+
+@pytest.mark.gpu
+def test_gradient_sync_piecewise_exchange(nk, tdev):
+    """The C4-sized weight gradient is produced and handed to the exchange in two row blocks (only half of the last
+    gradient stays exposed behind the backward pass).  With one rank the sum is the identity, so the gradients must
+    equal those of a plain backward bit for bit, and the hook must have issued 2 pieces + 1 bias per layer."""
+    tcomm = nk.dp.Communicator(tdev, 1, 0, nk.dp.Communicator.unique_id())
+    lins = [nk.nn.Linear(tdev, 4096, 4096, s) for s in (1, 3)]
+    params = [p for l in lins for p in (l.weight, l.bias)]
+    X, T = nk.rand(tdev, [256, 4096], 5), nk.rand(tdev, [256, 4096], 6)
+    loss = lins[1].forward(lins[0].forward(X).relu()).mse(T, nk.Reduction.Mean)
+    loss.forward(); loss.backward(0.5)
+    want = [p.grad().copy() for p in params]
+    sync = nk.dp.GradientSync(tcomm, params)
+    sync.set_force_exchange(True)
+    for rep in range(2):
+        for p in params:
+            p.zero_grad()
+        loss.no_grad(); loss.with_grad()
+        loss.backward_sync(0.5, sync); sync.join()
+        assert sync.exchanges_issued() == 6 * (rep + 1)        # per layer: 2 halves of dW + db
+        for p, w in zip(params, want):
+            assert np.array_equal(p.grad(), w)
+    small = nk.nn.Linear(tdev, 64, 64, 9)                      # below the threshold: one exchange per gradient
+    s2 = nk.dp.GradientSync(tcomm, [small.weight, small.bias]); s2.set_force_exchange(True)
+    l2 = small.forward(nk.rand(tdev, [8, 64], 1)).sum()
+    l2.forward(); l2.backward_sync(1.0, s2); s2.join()
+    assert s2.exchanges_issued() == 2
