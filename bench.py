@@ -34,6 +34,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# RCCL's intra-node P2P needs dmabuf IPC on this driver stack (the image exports this already; keep it for any launcher
+# that builds its own environment).  Must be set before the HIP runtime is loaded.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 MFMA_F32_PEAK = 157.3e12   # /opt/skills/guides/MI355X_MICROARCH.md: f32-in MFMA, dense
 HBM_PEAK = 8.0e12
