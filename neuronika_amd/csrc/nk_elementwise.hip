@@ -103,7 +103,7 @@ __global__ void binary_fwd_kernel(float* __restrict__ out, const float* __restri
             const float4 a = ld4(l, lo, b.ls[b.nd - 1]), c = ld4(r, ro, b.rs[b.nd - 1]);
             float4 o;
             o.x = bin<OP>(a.x, c.x); o.y = bin<OP>(a.y, c.y); o.z = bin<OP>(a.z, c.z); o.w = bin<OP>(a.w, c.w);
-            *reinterpret_cast<float4*>(out + g * 4) = o;
+            nk_store_stream(reinterpret_cast<float4*>(out + g * 4), o);
         } else {
             out[g] = bin<OP>(l[lo], r[ro]);
         }
@@ -159,7 +159,7 @@ __global__ void binary_bwd_same_kernel(float* __restrict__ d, const float* __res
             dv.y += local_grad<MODE>(gv.y, ov.y, qv.y);
             dv.z += local_grad<MODE>(gv.z, ov.z, qv.z);
             dv.w += local_grad<MODE>(gv.w, ov.w, qv.w);
-            *reinterpret_cast<float4*>(d + i * 4) = dv;
+            nk_store_stream(reinterpret_cast<float4*>(d + i * 4), dv);
         } else {
             d[i] += local_grad<MODE>(g[i], MODE >= 2 ? o[oo] : 0.f, MODE == 4 ? q[qo] : 1.f);
         }
@@ -446,7 +446,7 @@ generic: {
 __global__ void fill_kernel(float* __restrict__ p, size_t n, float v) {
     const size_t n4 = n / 4;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x)
-        reinterpret_cast<float4*>(p)[i] = make_float4(v, v, v, v);
+        nk_store_stream(reinterpret_cast<float4*>(p) + i, make_float4(v, v, v, v));
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) p[n4 * 4 + threadIdx.x] = v;
 }
 
@@ -457,7 +457,7 @@ __global__ void relu_fwd_kernel(const float* __restrict__ x, float* __restrict__
         for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
             float4 v = reinterpret_cast<const float4*>(x)[i];
             v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-            reinterpret_cast<float4*>(y)[i] = v;
+            nk_store_stream(reinterpret_cast<float4*>(y) + i, v);
         }
         if (blockIdx.x == 0 && threadIdx.x < (n & 3)) y[n4 * 4 + threadIdx.x] = fmaxf(x[n4 * 4 + threadIdx.x], 0.f);
     } else {
@@ -476,7 +476,7 @@ __global__ void relu_bwd_kernel(float* __restrict__ dx, const float* __restrict_
             float4 d = assign ? make_float4(0.f, 0.f, 0.f, 0.f) : reinterpret_cast<float4*>(dx)[i];
             d.x += xv.x > 0.f ? gv.x : 0.f * gv.x; d.y += xv.y > 0.f ? gv.y : 0.f * gv.y;
             d.z += xv.z > 0.f ? gv.z : 0.f * gv.z; d.w += xv.w > 0.f ? gv.w : 0.f * gv.w;
-            reinterpret_cast<float4*>(dx)[i] = d;
+            nk_store_stream(reinterpret_cast<float4*>(dx) + i, d);
         }
         if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
             const size_t i = n4 * 4 + threadIdx.x;
@@ -530,7 +530,7 @@ __global__ void unary_fwd_kernel(const float* __restrict__ x, float* __restrict_
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         float4 v = reinterpret_cast<const float4*>(x)[i];
         v.x = unary_f<OP>(v.x, e); v.y = unary_f<OP>(v.y, e); v.z = unary_f<OP>(v.z, e); v.w = unary_f<OP>(v.w, e);
-        reinterpret_cast<float4*>(y)[i] = v;
+        nk_store_stream(reinterpret_cast<float4*>(y) + i, v);
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) y[n4 * 4 + threadIdx.x] = unary_f<OP>(x[n4 * 4 + threadIdx.x], e);
 }
@@ -545,7 +545,7 @@ __global__ void unary_bwd_kernel(float* __restrict__ dx, const float* __restrict
         if (OP != NK_NEG) rv = reinterpret_cast<const float4*>(r)[i];
         d.x += unary_df<OP>(gv.x, rv.x, e); d.y += unary_df<OP>(gv.y, rv.y, e);
         d.z += unary_df<OP>(gv.z, rv.z, e); d.w += unary_df<OP>(gv.w, rv.w, e);
-        reinterpret_cast<float4*>(dx)[i] = d;
+        nk_store_stream(reinterpret_cast<float4*>(dx) + i, d);
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
         const size_t i = n4 * 4 + threadIdx.x;

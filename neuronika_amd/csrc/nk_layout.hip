@@ -26,8 +26,8 @@ __global__ void dropout_fwd_kernel(const float* __restrict__ x, float* __restric
             const float4 xv = reinterpret_cast<const float4*>(x)[i];
             float4 o;
             o.x = (xv.x * nz.x) / scale; o.y = (xv.y * nz.y) / scale; o.z = (xv.z * nz.z) / scale; o.w = (xv.w * nz.w) / scale;
-            reinterpret_cast<float4*>(y)[i] = o;
-            reinterpret_cast<float4*>(noise)[i] = nz;
+            nk_store_stream(reinterpret_cast<float4*>(y) + i, o);
+            nk_store_stream(reinterpret_cast<float4*>(noise) + i, nz);
         } else {
             const float nn[4] = {nz.x, nz.y, nz.z, nz.w};
             for (int c = 0; c < 4; ++c) {
@@ -50,7 +50,7 @@ __global__ void dropout_bwd_kernel(float* __restrict__ dx, const float* __restri
             const float4 nz = reinterpret_cast<const float4*>(noise)[i];
             d.x += gv.x * nz.x; d.y += gv.y * nz.y; d.z += gv.z * nz.z; d.w += gv.w * nz.w;
         }
-        reinterpret_cast<float4*>(dx)[i] = d;
+        nk_store_stream(reinterpret_cast<float4*>(dx) + i, d);
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
         const size_t i = n4 * 4 + threadIdx.x;
@@ -87,11 +87,11 @@ __global__ void subblock_kernel(float* __restrict__ small, float* __restrict__ b
             if (DIR == 0) {
                 float4 v = *bp;
                 if (ACC) { const float4 d = *sp; v.x += d.x; v.y += d.y; v.z += d.z; v.w += d.w; }
-                *sp = v;
+                nk_store_stream(sp, v);
             } else {
                 float4 v = *sp;
                 if (ACC) { const float4 d = *bp; v.x += d.x; v.y += d.y; v.z += d.z; v.w += d.w; }
-                *bp = v;
+                nk_store_stream(bp, v);
             }
         } else {
             if (DIR == 0) small[i] = ACC ? small[i] + big[bo] : big[bo];
@@ -345,7 +345,7 @@ __global__ void heads_kernel(float* __restrict__ flat, float* __restrict__ heads
             float4 v = TO_HEADS ? *fp : *hp;
             float4* dst = TO_HEADS ? hp : fp;
             if (ACC) { const float4 d = *dst; v.x += d.x; v.y += d.y; v.z += d.z; v.w += d.w; }
-            *dst = v;
+            nk_store_stream(dst, v);
         } else {
             const float v = TO_HEADS ? flat[fo] : heads[ho];
             float* dst = TO_HEADS ? &heads[ho] : &flat[fo];

@@ -102,7 +102,7 @@ __global__ void loss_bwd_kernel(float* __restrict__ dx, const float* __restrict_
         if (LOSS != NK_LOSS_KLDIV) v = reinterpret_cast<const float4*>(x)[i];
         d.x += loss_dterm<LOSS, MEAN>(v.x, w.x, g, den); d.y += loss_dterm<LOSS, MEAN>(v.y, w.y, g, den);
         d.z += loss_dterm<LOSS, MEAN>(v.z, w.z, g, den); d.w += loss_dterm<LOSS, MEAN>(v.w, w.w, g, den);
-        reinterpret_cast<float4*>(dx)[i] = d;
+        nk_store_stream(reinterpret_cast<float4*>(dx) + i, d);
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
         const size_t i = n4 * 4 + threadIdx.x;

@@ -69,7 +69,7 @@ __global__ void scalar_bwd_kernel(float* __restrict__ dx, const float* __restric
                 d.z += (2.f * (xv.z - tv.z)) * g; d.w += (2.f * (xv.w - tv.w)) * g;
             }
         }
-        reinterpret_cast<float4*>(dx)[i] = d;
+        nk_store_stream(reinterpret_cast<float4*>(dx) + i, d);
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
         const size_t i = n4 * 4 + threadIdx.x;
@@ -154,7 +154,7 @@ __global__ void softmax_fwd_row_kernel(const float* __restrict__ x, float* __res
             float4 o;
             if (LOG) { o.x = v[i].x - lse - m; o.y = v[i].y - lse - m; o.z = v[i].z - lse - m; o.w = v[i].w - lse - m; }
             else { o.x = v[i].x / s; o.y = v[i].y / s; o.z = v[i].z / s; o.w = v[i].w / s; }
-            *reinterpret_cast<float4*>(yr + c) = o;
+            nk_store_stream(reinterpret_cast<float4*>(yr + c), o);
         }
     }
 }
@@ -194,7 +194,7 @@ __global__ void softmax_bwd_row_kernel(float* __restrict__ dx, const float* __re
                 d.x += yv[i].x * (gv[i].x - s); d.y += yv[i].y * (gv[i].y - s);
                 d.z += yv[i].z * (gv[i].z - s); d.w += yv[i].w * (gv[i].w - s);
             }
-            *reinterpret_cast<float4*>(dr + c) = d;
+            nk_store_stream(reinterpret_cast<float4*>(dr + c), d);
         }
     }
 }
@@ -305,18 +305,18 @@ __global__ void attn_probs_fwd_kernel(const float* __restrict__ s, float* __rest
         if (c < L) {
             float4 y;
             y.x = v[i].x / sum; y.y = v[i].y / sum; y.z = v[i].z / sum; y.w = v[i].w / sum;   // Softmax node
-            if (probs) *reinterpret_cast<float4*>(probs + rb + c) = y;  // not stored when the backward pass recomputes it
+            if (probs) nk_store_stream(reinterpret_cast<float4*>(probs + rb + c), y);  // not stored when the backward pass recomputes it
             float4 o = y;
             if (MASK == 1) {                                                                   // Dropout node
                 const unsigned long long ctr = (unsigned long long)(rb + c) / 4 + offset;
                 const uint4 r = philox4x32_10(make_uint4((unsigned)ctr, (unsigned)(ctr >> 32), 0u, 0u), key);
                 const float4 nz = make_float4(keep_bit(r.x, keep), keep_bit(r.y, keep), keep_bit(r.z, keep), keep_bit(r.w, keep));
                 o.x = (y.x * nz.x) / dscale; o.y = (y.y * nz.y) / dscale; o.z = (y.z * nz.z) / dscale; o.w = (y.w * nz.w) / dscale;
-                if (STORE_NOISE) *reinterpret_cast<float4*>(noise + rb + c) = nz;
+                if (STORE_NOISE) nk_store_stream(reinterpret_cast<float4*>(noise + rb + c), nz);
             } else if (MASK == 2) {
                 o = make_float4(0.f, 0.f, 0.f, 0.f);
             }
-            *reinterpret_cast<float4*>(out + rb + c) = o;
+            nk_store_stream(reinterpret_cast<float4*>(out + rb + c), o);
         }
     }
 }
@@ -396,7 +396,7 @@ __global__ void attn_probs_bwd_kernel(float* __restrict__ ds, const float* __res
             d.y += (y[i].y * (gp[i].y - dot)) * scale;
             d.z += (y[i].z * (gp[i].z - dot)) * scale;
             d.w += (y[i].w * (gp[i].w - dot)) * scale;
-            *reinterpret_cast<float4*>(ds + rb + c) = d;
+            nk_store_stream(reinterpret_cast<float4*>(ds + rb + c), d);
         }
     }
 }
