@@ -66,6 +66,8 @@ class Dist:
         from neuronika_amd.rendezvous import Rendezvous
         self.rv = Rendezvous()
         self.rank, self.world, self.local = self.rv.rank, self.rv.world, self.rv.local
+        if "NK_BENCH_FORCE_DEVICE" in os.environ:   # debugging aid: several ranks on one GPU (RCCL permitting)
+            self.local = int(os.environ["NK_BENCH_FORCE_DEVICE"])
         if want != self.world and self.rank == 0:
             print(f"[bench] --gpus {want} but WORLD_SIZE={self.world}: running on {self.world} process(es)", file=sys.stderr)
 
