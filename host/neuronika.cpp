@@ -188,15 +188,16 @@ struct BinaryBwd : Backward {  // <Op>Backward{Left,Right}; either side may be a
     Shared<HipArray> l, r;
     void backward() const override {
         const HipArray& G = g->borrow();
+        bool assign = false;
         if (lg) {
-            HipArray& d = lg->borrow();
-            check(nk_binary_bwd_left(D(l), op, d.ptr(), d.shape().data(), (int)d.shape().size(), G.ptr(),
+            HipArray& d = lg->borrow_first_write(assign);
+            check((assign ? nk_binary_bwd_left_assign : nk_binary_bwd_left)(D(l), op, d.ptr(), d.shape().data(), (int)d.shape().size(), G.ptr(),
                                      G.shape().data(), (int)G.shape().size(), r->ptr(), r->shape().data(),
                                      (int)r->shape().size()));
         }
         if (rg) {
-            HipArray& d = rg->borrow();
-            check(nk_binary_bwd_right(D(l), op, d.ptr(), d.shape().data(), (int)d.shape().size(), G.ptr(),
+            HipArray& d = rg->borrow_first_write(assign);
+            check((assign ? nk_binary_bwd_right_assign : nk_binary_bwd_right)(D(l), op, d.ptr(), d.shape().data(), (int)d.shape().size(), G.ptr(),
                                       G.shape().data(), (int)G.shape().size(), l->ptr(), l->shape().data(),
                                       (int)l->shape().size(), r->ptr()));
         }
@@ -248,12 +249,18 @@ struct UnaryBwd : Backward {
             else check((assign ? nk_mean_bwd_assign : nk_mean_bwd)(d.device()->raw(), d.ptr(), d.len(), G.ptr()));
             return;
         }
+        if (kind == Unary::Softmax || kind == Unary::LogSoftmax) {
+            bool assign = false;
+            HipArray& d = dx->borrow_first_write(assign);
+            auto fn = kind == Unary::Softmax ? (assign ? nk_softmax_bwd_assign : nk_softmax_bwd)
+                                             : (assign ? nk_log_softmax_bwd_assign : nk_log_softmax_bwd);
+            check(fn(D(y), d.ptr(), G.ptr(), y->ptr(), d.shape().data(), (int)d.shape().size(), axis));
+            return;
+        }
         HipArray& d = dx->borrow();
         const int nd = (int)d.shape().size();
         switch (kind) {
-            case Unary::Relu: break;
-            case Unary::Softmax: check(nk_softmax_bwd(D(y), d.ptr(), G.ptr(), y->ptr(), d.shape().data(), nd, axis)); break;
-            case Unary::LogSoftmax: check(nk_log_softmax_bwd(D(y), d.ptr(), G.ptr(), y->ptr(), d.shape().data(), nd, axis)); break;
+            case Unary::Relu: case Unary::Softmax: case Unary::LogSoftmax: break;
             case Unary::Transpose: check(nk_transpose_bwd(d.device()->raw(), d.ptr(), G.ptr(), d.shape().data(), nd)); break;
             case Unary::Sum: case Unary::Mean: break;
         }
@@ -381,9 +388,9 @@ struct ConvBwd : Backward {  // ConvolutionBackward{Input,Kernel}  :357-510
                                                                             x->shape().data(), stride.data(), dilation.data(), groups));
         }
         if (db) {  // AdditionBackwardRight of the bias: sum of G over every axis the (Cout,1,..) bias lacks
-            HipArray& d = db->borrow();
-            check(nk_unbroadcast_add(D(x), d.ptr(), d.shape().data(), (int)d.shape().size(), G.ptr(), G.shape().data(),
-                                     (int)G.shape().size()));
+            HipArray& d = db->borrow_first_write(assign);
+            check((assign ? nk_unbroadcast_assign : nk_unbroadcast_add)(D(x), d.ptr(), d.shape().data(), (int)d.shape().size(), G.ptr(),
+                                                                        G.shape().data(), (int)G.shape().size()));
         }
     }
     void targets(std::vector<const Gradient*>& out) const override {
@@ -441,8 +448,10 @@ struct DropoutBwd : Backward {
     double p;
     Shared<bool> status;
     void backward() const override {
-        HipArray& d = dx->borrow();
-        check(nk_dropout_bwd(d.device()->raw(), d.ptr(), g->borrow().ptr(), noise->ptr(), d.len(), p, *status ? 1 : 0));
+        bool assign = false;
+        HipArray& d = dx->borrow_first_write(assign);
+        check((assign ? nk_dropout_bwd_assign : nk_dropout_bwd)(d.device()->raw(), d.ptr(), g->borrow().ptr(), noise->ptr(), d.len(), p,
+                                                                *status ? 1 : 0));
     }
     void targets(std::vector<const Gradient*>& out) const override { out.push_back(dx.get()); }
 };
@@ -499,8 +508,10 @@ struct PointwiseBwd : Backward {
     Shared<Gradient> dx, g;
     Shared<HipArray> ref;  // the buffer the reference node keeps: operand data or node data
     void backward() const override {
-        HipArray& d = dx->borrow();
-        check(nk_unary_bwd(d.device()->raw(), op, d.ptr(), g->borrow().ptr(), ref ? ref->ptr() : nullptr, d.len(), iparam));
+        bool assign = false;
+        HipArray& d = dx->borrow_first_write(assign);
+        check((assign ? nk_unary_bwd_assign : nk_unary_bwd)(d.device()->raw(), op, d.ptr(), g->borrow().ptr(), ref ? ref->ptr() : nullptr,
+                                                            d.len(), iparam));
     }
     void targets(std::vector<const Gradient*>& out) const override { out.push_back(dx.get()); }
 };
@@ -669,7 +680,11 @@ struct LinearBwd : Backward {
             }
         }
         const int gs[2] = {n, o};
-        check(nk_unbroadcast_add(dev, db->borrow().ptr(), &o, 1, G.ptr(), gs, 2));
+        {
+            bool assign = false;
+            HipArray& d = db->borrow_first_write(assign);
+            check((assign ? nk_unbroadcast_assign : nk_unbroadcast_add)(dev, d.ptr(), &o, 1, G.ptr(), gs, 2));
+        }
     }
     void targets(std::vector<const Gradient*>& out) const override {
         if (dx) out.push_back(dx.get());

@@ -256,6 +256,22 @@ int nk_conv_bwd_input_assign(nk_device* dev, int nd, float* dx, const int* x_sha
 int nk_conv_bwd_kernel_assign(nk_device* dev, int nd, float* dw, const int* w_shape, const float* g,
                               const float* x, const int* x_shape, const int* stride,
                               const int* dilation, int groups);
+int nk_binary_bwd_left_assign(nk_device* dev, int op, float* d_left, const int* l_shape, int l_nd,
+                              const float* g, const int* g_shape, int g_nd, const float* r,
+                              const int* r_shape, int r_nd);
+int nk_binary_bwd_right_assign(nk_device* dev, int op, float* d_right, const int* r_shape, int r_nd,
+                               const float* g, const int* g_shape, int g_nd, const float* l,
+                               const int* l_shape, int l_nd, const float* r);
+int nk_unbroadcast_assign(nk_device* dev, float* dst, const int* dst_shape, int dst_nd,
+                          const float* src, const int* src_shape, int src_nd);
+int nk_unary_bwd_assign(nk_device* dev, int op, float* dx, const float* g, const float* ref, size_t n,
+                        int iparam);
+int nk_softmax_bwd_assign(nk_device* dev, float* dx, const float* g, const float* y, const int* shape,
+                          int nd, int axis);
+int nk_log_softmax_bwd_assign(nk_device* dev, float* dx, const float* g, const float* y,
+                              const int* shape, int nd, int axis);
+int nk_dropout_bwd_assign(nk_device* dev, float* dx, const float* g, const float* noise, size_t n,
+                          double p, int train);
 int nk_sum_bwd_assign(nk_device* dev, float* dx, size_t n, const float* g);
 int nk_mean_bwd_assign(nk_device* dev, float* dx, size_t n, const float* g);
 int nk_relu_bwd_assign(nk_device* dev, float* dx, const float* g, const float* x, size_t n);

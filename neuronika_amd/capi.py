@@ -104,6 +104,13 @@ _SIGS = {
     "nk_mean_bwd": [VP, VP, C.c_size_t, VP],
     "nk_mse_fwd": [VP, VP, VP, C.c_size_t, C.c_int, VP],
     "nk_mse_bwd": [VP, VP, VP, VP, VP, C.c_size_t, C.c_int],
+    "nk_binary_bwd_left_assign": [VP, C.c_int, VP, c_intp, C.c_int, VP, c_intp, C.c_int, VP, c_intp, C.c_int],
+    "nk_binary_bwd_right_assign": [VP, C.c_int, VP, c_intp, C.c_int, VP, c_intp, C.c_int, VP, c_intp, C.c_int, VP],
+    "nk_unbroadcast_assign": [VP, VP, c_intp, C.c_int, VP, c_intp, C.c_int],
+    "nk_unary_bwd_assign": [VP, C.c_int, VP, VP, VP, C.c_size_t, C.c_int],
+    "nk_softmax_bwd_assign": [VP, VP, VP, VP, c_intp, C.c_int, C.c_int],
+    "nk_log_softmax_bwd_assign": [VP, VP, VP, VP, c_intp, C.c_int, C.c_int],
+    "nk_dropout_bwd_assign": [VP, VP, VP, VP, C.c_size_t, C.c_double, C.c_int],
     "nk_sum_bwd_assign": [VP, VP, C.c_size_t, VP],
     "nk_mean_bwd_assign": [VP, VP, C.c_size_t, VP],
     "nk_relu_bwd_assign": [VP, VP, VP, VP, C.c_size_t],
@@ -392,19 +399,19 @@ def binary_fwd(dev, op, out, l, r):
     check(lib.nk_binary_fwd(dev.h, OPS[op], out.p, out.shape_c(), out.ndim, l.p, l.shape_c(), l.ndim, r.p, r.shape_c(), r.ndim))
 
 
-def binary_bwd_left(dev, op, d_left, g, r=None):
+def binary_bwd_left(dev, op, d_left, g, r=None, assign=False):
     rp, rs, rn = (r.p, r.shape_c(), r.ndim) if r is not None else (None, ints([]), 0)
-    check(lib.nk_binary_bwd_left(dev.h, OPS[op], d_left.p, d_left.shape_c(), d_left.ndim, g.p, g.shape_c(), g.ndim, rp, rs, rn))
+    check((lib.nk_binary_bwd_left_assign if assign else lib.nk_binary_bwd_left)(dev.h, OPS[op], d_left.p, d_left.shape_c(), d_left.ndim, g.p, g.shape_c(), g.ndim, rp, rs, rn))
 
 
-def binary_bwd_right(dev, op, d_right, g, l=None, r=None):
+def binary_bwd_right(dev, op, d_right, g, l=None, r=None, assign=False):
     lp, ls, ln = (l.p, l.shape_c(), l.ndim) if l is not None else (None, ints([]), 0)
-    check(lib.nk_binary_bwd_right(dev.h, OPS[op], d_right.p, d_right.shape_c(), d_right.ndim, g.p, g.shape_c(), g.ndim,
+    check((lib.nk_binary_bwd_right_assign if assign else lib.nk_binary_bwd_right)(dev.h, OPS[op], d_right.p, d_right.shape_c(), d_right.ndim, g.p, g.shape_c(), g.ndim,
                                   lp, ls, ln, r.p if r is not None else None))
 
 
-def unbroadcast_add(dev, dst, src):
-    check(lib.nk_unbroadcast_add(dev.h, dst.p, dst.shape_c(), dst.ndim, src.p, src.shape_c(), src.ndim))
+def unbroadcast_add(dev, dst, src, assign=False):
+    check((lib.nk_unbroadcast_assign if assign else lib.nk_unbroadcast_add)(dev.h, dst.p, dst.shape_c(), dst.ndim, src.p, src.shape_c(), src.ndim))
 
 
 UNARY = {"neg": 0, "exp": 1, "ln": 2, "sqrt": 3, "sigmoid": 4, "tanh": 5, "softplus": 6, "leaky_relu": 7, "pow": 8}
@@ -414,8 +421,8 @@ def unary_fwd(dev, op, x, y, iparam=0):
     check(lib.nk_unary_fwd(dev.h, UNARY[op], x.p, y.p, x.size, iparam))
 
 
-def unary_bwd(dev, op, dx, g, ref=None, iparam=0):
-    check(lib.nk_unary_bwd(dev.h, UNARY[op], dx.p, g.p, ref.p if ref is not None else None, dx.size, iparam))
+def unary_bwd(dev, op, dx, g, ref=None, iparam=0, assign=False):
+    check((lib.nk_unary_bwd_assign if assign else lib.nk_unary_bwd)(dev.h, UNARY[op], dx.p, g.p, ref.p if ref is not None else None, dx.size, iparam))
 
 
 def relu_fwd(dev, x, y):
@@ -506,24 +513,24 @@ def softmax_fwd(dev, x, y, axis):
     check(lib.nk_softmax_fwd(dev.h, x.p, y.p, x.shape_c(), x.ndim, axis))
 
 
-def softmax_bwd(dev, dx, g, y, axis):
-    check(lib.nk_softmax_bwd(dev.h, dx.p, g.p, y.p, y.shape_c(), y.ndim, axis))
+def softmax_bwd(dev, dx, g, y, axis, assign=False):
+    check((lib.nk_softmax_bwd_assign if assign else lib.nk_softmax_bwd)(dev.h, dx.p, g.p, y.p, y.shape_c(), y.ndim, axis))
 
 
 def log_softmax_fwd(dev, x, y, axis):
     check(lib.nk_log_softmax_fwd(dev.h, x.p, y.p, x.shape_c(), x.ndim, axis))
 
 
-def log_softmax_bwd(dev, dx, g, y, axis):
-    check(lib.nk_log_softmax_bwd(dev.h, dx.p, g.p, y.p, y.shape_c(), y.ndim, axis))
+def log_softmax_bwd(dev, dx, g, y, axis, assign=False):
+    check((lib.nk_log_softmax_bwd_assign if assign else lib.nk_log_softmax_bwd)(dev.h, dx.p, g.p, y.p, y.shape_c(), y.ndim, axis))
 
 
 def dropout_fwd(dev, x, y, noise, p, train=True, seed=0, offset=0):
     check(lib.nk_dropout_fwd(dev.h, x.p, y.p, noise.p if noise is not None else None, x.size, float(p), int(train), seed, offset))
 
 
-def dropout_bwd(dev, dx, g, noise, p, train=True):
-    check(lib.nk_dropout_bwd(dev.h, dx.p, g.p, noise.p if noise is not None else None, dx.size, float(p), int(train)))
+def dropout_bwd(dev, dx, g, noise, p, train=True, assign=False):
+    check((lib.nk_dropout_bwd_assign if assign else lib.nk_dropout_bwd)(dev.h, dx.p, g.p, noise.p if noise is not None else None, dx.size, float(p), int(train)))
 
 
 def scale_softmax_dropout_fwd(dev, scores, probs, out, noise, scale, p, train=True, seed=0, offset=0):

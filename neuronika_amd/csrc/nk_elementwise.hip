@@ -133,7 +133,7 @@ struct Bcast3 {
 template <int MODE, bool VEC>
 __global__ void binary_bwd_same_kernel(float* __restrict__ d, const float* __restrict__ g,
                                        const float* __restrict__ o, const float* __restrict__ q,
-                                       Bcast3 b, long long total) {
+                                       Bcast3 b, long long total, int assign) {
     constexpr int W = VEC ? 4 : 1;
     const long long groups = total / W;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < groups;
@@ -151,7 +151,7 @@ __global__ void binary_bwd_same_kernel(float* __restrict__ d, const float* __res
         }
         if (VEC) {
             const float4 gv = *reinterpret_cast<const float4*>(g + i * 4);
-            float4 dv = *reinterpret_cast<float4*>(d + i * 4);
+            float4 dv = assign ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<float4*>(d + i * 4);
             float4 ov = make_float4(0, 0, 0, 0), qv = make_float4(1, 1, 1, 1);
             if (MODE >= 2) ov = ld4(o, oo, b.os[b.nd - 1]);
             if (MODE == 4) qv = ld4(q, qo, b.qs[b.nd - 1]);
@@ -161,7 +161,7 @@ __global__ void binary_bwd_same_kernel(float* __restrict__ d, const float* __res
             dv.w += local_grad<MODE>(gv.w, ov.w, qv.w);
             nk_store_stream(reinterpret_cast<float4*>(d + i * 4), dv);
         } else {
-            d[i] += local_grad<MODE>(g[i], MODE >= 2 ? o[oo] : 0.f, MODE == 4 ? q[qo] : 1.f);
+            d[i] = (assign ? 0.f : d[i]) + local_grad<MODE>(g[i], MODE >= 2 ? o[oo] : 0.f, MODE == 4 ? q[qo] : 1.f);
         }
     }
 }
@@ -270,7 +270,7 @@ __global__ void reduce_rkr_kernel(float* __restrict__ part, const float* __restr
 // d[k] += sum_c part[c][k].  A block is 64 columns x 4 chunk-lanes (lane j sums chunks j, j+4, ... with four
 // independent accumulators), folded through LDS in a fixed order: K/64 blocks and chunks/4 loads deep instead of
 // K/256 blocks and `chunks` dependent loads deep (that serial form cost 20-60 us for a few hundred KB).
-__global__ void reduce_finish_kernel(float* __restrict__ d, const float* __restrict__ part, int K, int chunks) {
+__global__ void reduce_finish_kernel(float* __restrict__ d, const float* __restrict__ part, int K, int chunks, int assign) {
     __shared__ float red[4][64];
     const int col = threadIdx.x & 63, lane = threadIdx.x >> 6;
     const int k = blockIdx.x * 64 + col;
@@ -287,7 +287,7 @@ __global__ void reduce_finish_kernel(float* __restrict__ d, const float* __restr
     }
     red[lane][col] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (lane == 0 && k < K) d[k] += (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+    if (lane == 0 && k < K) d[k] = (assign ? 0.f : d[k]) + ((red[0][col] + red[1][col]) + (red[2][col] + red[3][col]));
 }
 
 // Fallback for reduction patterns with more than three collapsed groups: one thread per kept
@@ -303,7 +303,7 @@ struct Gen {
 template <int MODE>
 __global__ void reduce_generic_kernel(float* __restrict__ d, const float* __restrict__ g,
                                       const float* __restrict__ o, const float* __restrict__ q, Gen p,
-                                      long long kept, long long reduced) {
+                                      long long kept, long long reduced, int assign) {
     for (long long ki = blockIdx.x * (long long)blockDim.x + threadIdx.x; ki < kept;
          ki += (long long)gridDim.x * blockDim.x) {
         // decode kept coordinate
@@ -325,7 +325,7 @@ __global__ void reduce_generic_kernel(float* __restrict__ d, const float* __rest
             }
             acc += local_grad<MODE>(g[go], MODE >= 2 ? o[oo] : 0.f, MODE == 4 ? q[qo] : 1.f);
         }
-        d[dofs] += acc;
+        d[dofs] = (assign ? 0.f : d[dofs]) + acc;
     }
 }
 
@@ -335,7 +335,7 @@ bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 template <int MODE>
 int bwd_dispatch(nk_device* dev, float* d, const int* t_shape, int t_nd, const float* g, const int* g_shape,
                  int g_nd, const float* o, const int* o_shape, int o_nd, const float* q, const int* q_shape,
-                 int q_nd) {
+                 int q_nd, int assign = 0) {
     NK_USE(dev);
     NK_CHECK(d && g, "null gradient pointer");
     int rc = check_bcast(g_shape, g_nd, t_shape, t_nd, "target");
@@ -364,8 +364,8 @@ int bwd_dispatch(nk_device* dev, float* d, const int* t_shape, int t_nd, const f
         const bool vec = (cshape[nd - 1] % 4 == 0) && al16(d) && al16(g) &&
                          (MODE < 2 || (os[nd - 1] <= 1 && al16(o))) && (MODE != 4 || (qs[nd - 1] <= 1 && al16(q)));
         const int grid = nk_stream_grid((size_t)(total / (vec ? 4 : 1)), 256);
-        if (vec) hipLaunchKernelGGL((binary_bwd_same_kernel<MODE, true>), dim3(grid), dim3(256), 0, dev->compute, d, g, o, q, b, total);
-        else hipLaunchKernelGGL((binary_bwd_same_kernel<MODE, false>), dim3(grid), dim3(256), 0, dev->compute, d, g, o, q, b, total);
+        if (vec) hipLaunchKernelGGL((binary_bwd_same_kernel<MODE, true>), dim3(grid), dim3(256), 0, dev->compute, d, g, o, q, b, total, assign);
+        else hipLaunchKernelGGL((binary_bwd_same_kernel<MODE, false>), dim3(grid), dim3(256), 0, dev->compute, d, g, o, q, b, total, assign);
         NK_LAUNCH_CHECK();
         return NK_OK;
     }
@@ -424,7 +424,7 @@ int bwd_dispatch(nk_device* dev, float* d, const int* t_shape, int t_nd, const f
         else
             hipLaunchKernelGGL((reduce_rkr_kernel<MODE>), dim3(p.K, chunks), dim3(256), 0, dev->compute, part, g, o, q, p);
         NK_LAUNCH_CHECK();
-        hipLaunchKernelGGL(reduce_finish_kernel, dim3((p.K + 63) / 64), dim3(256), 0, dev->compute, d, part, p.K, chunks);
+        hipLaunchKernelGGL(reduce_finish_kernel, dim3((p.K + 63) / 64), dim3(256), 0, dev->compute, d, part, p.K, chunks, assign);
         NK_LAUNCH_CHECK();
         return NK_OK;
     }
@@ -437,7 +437,7 @@ generic: {
             if (ts[i] == 0) reduced *= cshape[i]; else kept *= cshape[i];
         }
         hipLaunchKernelGGL((reduce_generic_kernel<MODE>), dim3(nk_stream_grid((size_t)kept, 64)), dim3(64), 0,
-                           dev->compute, d, g, o, q, p, kept, reduced);
+                           dev->compute, d, g, o, q, p, kept, reduced, assign);
         NK_LAUNCH_CHECK();
         return NK_OK;
     }
@@ -536,10 +536,10 @@ __global__ void unary_fwd_kernel(const float* __restrict__ x, float* __restrict_
 }
 template <int OP>
 __global__ void unary_bwd_kernel(float* __restrict__ dx, const float* __restrict__ g, const float* __restrict__ r,
-                                 size_t n, int e) {
+                                 size_t n, int e, int assign) {
     const size_t n4 = n / 4;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-        float4 d = reinterpret_cast<float4*>(dx)[i];
+        float4 d = assign ? make_float4(0.f, 0.f, 0.f, 0.f) : reinterpret_cast<float4*>(dx)[i];
         const float4 gv = reinterpret_cast<const float4*>(g)[i];
         float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
         if (OP != NK_NEG) rv = reinterpret_cast<const float4*>(r)[i];
@@ -549,7 +549,7 @@ __global__ void unary_bwd_kernel(float* __restrict__ dx, const float* __restrict
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
         const size_t i = n4 * 4 + threadIdx.x;
-        dx[i] += unary_df<OP>(g[i], OP != NK_NEG ? r[i] : 0.f, e);
+        dx[i] = (assign ? 0.f : dx[i]) + unary_df<OP>(g[i], OP != NK_NEG ? r[i] : 0.f, e);
     }
 }
 
@@ -702,34 +702,55 @@ int nk_binary_fwd(nk_device* dev, int op, float* out, const int* out_shape, int 
     return NK_OK;
 }
 
-int nk_binary_bwd_left(nk_device* dev, int op, float* d_left, const int* l_shape, int l_nd, const float* g,
-                       const int* g_shape, int g_nd, const float* r, const int* r_shape, int r_nd) {
+static int binary_bwd_left(nk_device* dev, int op, float* d_left, const int* l_shape, int l_nd, const float* g,
+                           const int* g_shape, int g_nd, const float* r, const int* r_shape, int r_nd, int assign) {
     switch (op) {
         case NK_ADD:
-        case NK_SUB: return bwd_dispatch<0>(dev, d_left, l_shape, l_nd, g, g_shape, g_nd, nullptr, nullptr, 0, nullptr, nullptr, 0);
-        case NK_MUL: return bwd_dispatch<2>(dev, d_left, l_shape, l_nd, g, g_shape, g_nd, r, r_shape, r_nd, nullptr, nullptr, 0);
-        case NK_DIV: return bwd_dispatch<3>(dev, d_left, l_shape, l_nd, g, g_shape, g_nd, r, r_shape, r_nd, nullptr, nullptr, 0);
+        case NK_SUB: return bwd_dispatch<0>(dev, d_left, l_shape, l_nd, g, g_shape, g_nd, nullptr, nullptr, 0, nullptr, nullptr, 0, assign);
+        case NK_MUL: return bwd_dispatch<2>(dev, d_left, l_shape, l_nd, g, g_shape, g_nd, r, r_shape, r_nd, nullptr, nullptr, 0, assign);
+        case NK_DIV: return bwd_dispatch<3>(dev, d_left, l_shape, l_nd, g, g_shape, g_nd, r, r_shape, r_nd, nullptr, nullptr, 0, assign);
     }
     nk_set_error("unknown binary op %d", op);
     return NK_ERR_INVALID;
 }
-
-int nk_binary_bwd_right(nk_device* dev, int op, float* d_right, const int* r_shape, int r_nd, const float* g,
-                        const int* g_shape, int g_nd, const float* l, const int* l_shape, int l_nd,
-                        const float* r) {
+static int binary_bwd_right(nk_device* dev, int op, float* d_right, const int* r_shape, int r_nd, const float* g,
+                            const int* g_shape, int g_nd, const float* l, const int* l_shape, int l_nd,
+                            const float* r, int assign) {
     switch (op) {
-        case NK_ADD: return bwd_dispatch<0>(dev, d_right, r_shape, r_nd, g, g_shape, g_nd, nullptr, nullptr, 0, nullptr, nullptr, 0);
-        case NK_SUB: return bwd_dispatch<1>(dev, d_right, r_shape, r_nd, g, g_shape, g_nd, nullptr, nullptr, 0, nullptr, nullptr, 0);
-        case NK_MUL: return bwd_dispatch<2>(dev, d_right, r_shape, r_nd, g, g_shape, g_nd, l, l_shape, l_nd, nullptr, nullptr, 0);
-        case NK_DIV: return bwd_dispatch<4>(dev, d_right, r_shape, r_nd, g, g_shape, g_nd, l, l_shape, l_nd, r, r_shape, r_nd);
+        case NK_ADD: return bwd_dispatch<0>(dev, d_right, r_shape, r_nd, g, g_shape, g_nd, nullptr, nullptr, 0, nullptr, nullptr, 0, assign);
+        case NK_SUB: return bwd_dispatch<1>(dev, d_right, r_shape, r_nd, g, g_shape, g_nd, nullptr, nullptr, 0, nullptr, nullptr, 0, assign);
+        case NK_MUL: return bwd_dispatch<2>(dev, d_right, r_shape, r_nd, g, g_shape, g_nd, l, l_shape, l_nd, nullptr, nullptr, 0, assign);
+        case NK_DIV: return bwd_dispatch<4>(dev, d_right, r_shape, r_nd, g, g_shape, g_nd, l, l_shape, l_nd, r, r_shape, r_nd, assign);
     }
     nk_set_error("unknown binary op %d", op);
     return NK_ERR_INVALID;
+}
+int nk_binary_bwd_left(nk_device* dev, int op, float* d_left, const int* l_shape, int l_nd, const float* g,
+                       const int* g_shape, int g_nd, const float* r, const int* r_shape, int r_nd) {
+    return binary_bwd_left(dev, op, d_left, l_shape, l_nd, g, g_shape, g_nd, r, r_shape, r_nd, 0);
+}
+int nk_binary_bwd_left_assign(nk_device* dev, int op, float* d_left, const int* l_shape, int l_nd, const float* g,
+                              const int* g_shape, int g_nd, const float* r, const int* r_shape, int r_nd) {
+    return binary_bwd_left(dev, op, d_left, l_shape, l_nd, g, g_shape, g_nd, r, r_shape, r_nd, 1);
+}
+int nk_binary_bwd_right(nk_device* dev, int op, float* d_right, const int* r_shape, int r_nd, const float* g,
+                        const int* g_shape, int g_nd, const float* l, const int* l_shape, int l_nd,
+                        const float* r) {
+    return binary_bwd_right(dev, op, d_right, r_shape, r_nd, g, g_shape, g_nd, l, l_shape, l_nd, r, 0);
+}
+int nk_binary_bwd_right_assign(nk_device* dev, int op, float* d_right, const int* r_shape, int r_nd, const float* g,
+                               const int* g_shape, int g_nd, const float* l, const int* l_shape, int l_nd,
+                               const float* r) {
+    return binary_bwd_right(dev, op, d_right, r_shape, r_nd, g, g_shape, g_nd, l, l_shape, l_nd, r, 1);
 }
 
 int nk_unbroadcast_add(nk_device* dev, float* dst, const int* dst_shape, int dst_nd, const float* src,
                        const int* src_shape, int src_nd) {
     return bwd_dispatch<0>(dev, dst, dst_shape, dst_nd, src, src_shape, src_nd, nullptr, nullptr, 0, nullptr, nullptr, 0);
+}
+int nk_unbroadcast_assign(nk_device* dev, float* dst, const int* dst_shape, int dst_nd, const float* src,
+                          const int* src_shape, int src_nd) {
+    return bwd_dispatch<0>(dev, dst, dst_shape, dst_nd, src, src_shape, src_nd, nullptr, nullptr, 0, nullptr, nullptr, 0, 1);
 }
 
 int nk_unary_fwd(nk_device* dev, int op, const float* x, float* y, size_t n, int iparam) {
@@ -745,18 +766,25 @@ int nk_unary_fwd(nk_device* dev, int op, const float* x, float* y, size_t n, int
     return NK_OK;
 }
 
-int nk_unary_bwd(nk_device* dev, int op, float* dx, const float* g, const float* ref, size_t n, int iparam) {
+static int unary_bwd(nk_device* dev, int op, float* dx, const float* g, const float* ref, size_t n, int iparam, int assign) {
     NK_USE(dev);
     NK_CHECK(op >= NK_NEG && op <= NK_POW, "unknown unary op %d", op);
     if (n == 0) return NK_OK;
     NK_CHECK(dx && g && al16(dx) && al16(g), "nk_unary_bwd: null or unaligned pointer");
     NK_CHECK(op == NK_NEG || (ref && al16(ref)), "nk_unary_bwd: the node's kept buffer is required");
     const dim3 grid(nk_stream_grid(n / 4 + 1, 256)), block(256);
-#define NK_U(OP) case OP: hipLaunchKernelGGL((unary_bwd_kernel<OP>), grid, block, 0, dev->compute, dx, g, ref, n, iparam); break;
+#define NK_U(OP) case OP: hipLaunchKernelGGL((unary_bwd_kernel<OP>), grid, block, 0, dev->compute, dx, g, ref, n, iparam, assign); break;
     switch (op) { NK_U(NK_NEG) NK_U(NK_EXP) NK_U(NK_LN) NK_U(NK_SQRT) NK_U(NK_SIGMOID) NK_U(NK_TANH) NK_U(NK_SOFTPLUS) NK_U(NK_LEAKY_RELU) NK_U(NK_POW) }
 #undef NK_U
     NK_LAUNCH_CHECK();
     return NK_OK;
+}
+
+int nk_unary_bwd(nk_device* dev, int op, float* dx, const float* g, const float* ref, size_t n, int iparam) {
+    return unary_bwd(dev, op, dx, g, ref, n, iparam, 0);
+}
+int nk_unary_bwd_assign(nk_device* dev, int op, float* dx, const float* g, const float* ref, size_t n, int iparam) {
+    return unary_bwd(dev, op, dx, g, ref, n, iparam, 1);
 }
 
 int nk_relu_fwd(nk_device* dev, const float* x, float* y, size_t n) {

@@ -40,10 +40,11 @@ __global__ void dropout_fwd_kernel(const float* __restrict__ x, float* __restric
 
 // MODE 0: dx += g ; MODE 1: dx += g * noise
 template <int MODE>
-__global__ void dropout_bwd_kernel(float* __restrict__ dx, const float* __restrict__ g, const float* __restrict__ noise, size_t n) {
+__global__ void dropout_bwd_kernel(float* __restrict__ dx, const float* __restrict__ g, const float* __restrict__ noise, size_t n,
+                                   int assign) {
     const size_t n4 = n / 4;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-        float4 d = reinterpret_cast<float4*>(dx)[i];
+        float4 d = assign ? make_float4(0.f, 0.f, 0.f, 0.f) : reinterpret_cast<float4*>(dx)[i];
         const float4 gv = reinterpret_cast<const float4*>(g)[i];
         if (MODE == 0) { d.x += gv.x; d.y += gv.y; d.z += gv.z; d.w += gv.w; }
         else {
@@ -54,7 +55,7 @@ __global__ void dropout_bwd_kernel(float* __restrict__ dx, const float* __restri
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
         const size_t i = n4 * 4 + threadIdx.x;
-        dx[i] += MODE == 0 ? g[i] : g[i] * noise[i];
+        dx[i] = (assign ? 0.f : dx[i]) + (MODE == 0 ? g[i] : g[i] * noise[i]);
     }
 }
 
@@ -442,7 +443,7 @@ int nk_dropout_fwd(nk_device* dev, const float* x, float* y, float* noise, size_
     return NK_OK;
 }
 
-int nk_dropout_bwd(nk_device* dev, float* dx, const float* g, const float* noise, size_t n, double p, int train) {
+static int dropout_bwd(nk_device* dev, float* dx, const float* g, const float* noise, size_t n, double p, int train, int assign) {
     NK_USE(dev);
     NK_CHECK(p >= 0.0 && p <= 1.0, "Wrong probability received: %g.", p);
     if (n == 0) return NK_OK;
@@ -450,13 +451,19 @@ int nk_dropout_bwd(nk_device* dev, float* dx, const float* g, const float* noise
     NK_CHECK(al16(dx) && al16(g), "dropout buffers must be 16-byte aligned");
     const int grid = nk_stream_grid(n / 4 + 1, 256);
     if (!train || p == 0.0) {
-        hipLaunchKernelGGL((dropout_bwd_kernel<0>), dim3(grid), dim3(256), 0, dev->compute, dx, g, noise, n);
+        hipLaunchKernelGGL((dropout_bwd_kernel<0>), dim3(grid), dim3(256), 0, dev->compute, dx, g, noise, n, assign);
     } else {
         NK_CHECK(noise != nullptr && al16(noise), "noise buffer required in training mode");
-        hipLaunchKernelGGL((dropout_bwd_kernel<1>), dim3(grid), dim3(256), 0, dev->compute, dx, g, noise, n);
+        hipLaunchKernelGGL((dropout_bwd_kernel<1>), dim3(grid), dim3(256), 0, dev->compute, dx, g, noise, n, assign);
     }
     NK_LAUNCH_CHECK();
     return NK_OK;
+}
+int nk_dropout_bwd(nk_device* dev, float* dx, const float* g, const float* noise, size_t n, double p, int train) {
+    return dropout_bwd(dev, dx, g, noise, n, p, train, 0);
+}
+int nk_dropout_bwd_assign(nk_device* dev, float* dx, const float* g, const float* noise, size_t n, double p, int train) {
+    return dropout_bwd(dev, dx, g, noise, n, p, train, 1);
 }
 
 int nk_pad_const_fwd(nk_device* dev, int nd, const float* x, const int* x_shape, float* y, const int* padding, float value) {

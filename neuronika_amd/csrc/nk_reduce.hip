@@ -161,7 +161,7 @@ __global__ void softmax_fwd_row_kernel(const float* __restrict__ x, float* __res
 
 // softmax: dx += y*(g - sum(g*y)) ; log-softmax: dx += g - exp(y)*sum(g)
 template <int V, bool LOG>
-__global__ void softmax_bwd_row_kernel(float* __restrict__ dx, const float* __restrict__ g, const float* __restrict__ y,
+__global__ void softmax_bwd_row_kernel(int assign, float* __restrict__ dx, const float* __restrict__ g, const float* __restrict__ y,
                                        long long rows, int L) {
     const int lane = threadIdx.x & 63;
     const long long row = blockIdx.x * (long long)(blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -186,7 +186,7 @@ __global__ void softmax_bwd_row_kernel(float* __restrict__ dx, const float* __re
     for (int i = 0; i < V; ++i) {
         const int c = (i * 64 + lane) * 4;
         if (c < L) {
-            float4 d = *reinterpret_cast<float4*>(dr + c);
+            float4 d = assign ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<float4*>(dr + c);
             if (LOG) {
                 d.x += gv[i].x - expf(yv[i].x) * s; d.y += gv[i].y - expf(yv[i].y) * s;
                 d.z += gv[i].z - expf(yv[i].z) * s; d.w += gv[i].w - expf(yv[i].w) * s;
@@ -218,14 +218,14 @@ __global__ void softmax_fwd_block_kernel(const float* __restrict__ x, float* __r
 }
 
 template <bool LOG>
-__global__ void softmax_bwd_block_kernel(float* __restrict__ dx, const float* __restrict__ g, const float* __restrict__ y, int L) {
+__global__ void softmax_bwd_block_kernel(int assign, float* __restrict__ dx, const float* __restrict__ g, const float* __restrict__ y, int L) {
     __shared__ float red[4];
     const long long o = (long long)blockIdx.x * L;
     float s = 0.f;
     for (int c = threadIdx.x; c < L; c += blockDim.x) s += LOG ? g[o + c] : g[o + c] * y[o + c];
     s = nk_block_sum<256>(s, red);
     for (int c = threadIdx.x; c < L; c += blockDim.x)
-        dx[o + c] += LOG ? g[o + c] - expf(y[o + c]) * s : y[o + c] * (g[o + c] - s);
+        dx[o + c] = (assign ? 0.f : dx[o + c]) + (LOG ? g[o + c] - expf(y[o + c]) * s : y[o + c] * (g[o + c] - s));
 }
 
 template <bool LOG>
@@ -247,7 +247,7 @@ __global__ void softmax_fwd_strided_kernel(const float* __restrict__ x, float* _
 }
 
 template <bool LOG>
-__global__ void softmax_bwd_strided_kernel(float* __restrict__ dx, const float* __restrict__ g, const float* __restrict__ y,
+__global__ void softmax_bwd_strided_kernel(int assign, float* __restrict__ dx, const float* __restrict__ g, const float* __restrict__ y,
                                            long long lanes, int L, long long inner) {
     for (long long id = blockIdx.x * (long long)blockDim.x + threadIdx.x; id < lanes;
          id += (long long)gridDim.x * blockDim.x) {
@@ -256,7 +256,7 @@ __global__ void softmax_bwd_strided_kernel(float* __restrict__ dx, const float* 
         for (int c = 0; c < L; ++c) s += LOG ? g[base + c * inner] : g[base + c * inner] * y[base + c * inner];
         for (int c = 0; c < L; ++c) {
             const long long o = base + c * inner;
-            dx[o] += LOG ? g[o] - expf(y[o]) * s : y[o] * (g[o] - s);
+            dx[o] = (assign ? 0.f : dx[o]) + (LOG ? g[o] - expf(y[o]) * s : y[o] * (g[o] - s));
         }
     }
 }
@@ -441,7 +441,7 @@ int softmax_fwd(nk_device* dev, const float* x, float* y, const int* shape, int 
 }
 
 template <bool LOG>
-int softmax_bwd(nk_device* dev, float* dx, const float* g, const float* y, const int* shape, int nd, int axis) {
+int softmax_bwd(nk_device* dev, float* dx, const float* g, const float* y, const int* shape, int nd, int axis, int assign = 0) {
     NK_USE(dev);
     long long outer, inner; int L;
     int rc = lane_geometry(shape, nd, axis, &outer, &L, &inner);
@@ -453,17 +453,17 @@ int softmax_bwd(nk_device* dev, float* dx, const float* g, const float* y, const
         if (vec) {
             const int wpb = 4;
             const dim3 grid((unsigned)((outer + wpb - 1) / wpb)), block(64 * wpb);
-            if (L <= 256) hipLaunchKernelGGL((softmax_bwd_row_kernel<1, LOG>), grid, block, 0, dev->compute, dx, g, y, outer, L);
-            else if (L <= 512) hipLaunchKernelGGL((softmax_bwd_row_kernel<2, LOG>), grid, block, 0, dev->compute, dx, g, y, outer, L);
-            else if (L <= 1024) hipLaunchKernelGGL((softmax_bwd_row_kernel<4, LOG>), grid, block, 0, dev->compute, dx, g, y, outer, L);
-            else hipLaunchKernelGGL((softmax_bwd_row_kernel<8, LOG>), grid, block, 0, dev->compute, dx, g, y, outer, L);
+            if (L <= 256) hipLaunchKernelGGL((softmax_bwd_row_kernel<1, LOG>), grid, block, 0, dev->compute, assign, dx, g, y, outer, L);
+            else if (L <= 512) hipLaunchKernelGGL((softmax_bwd_row_kernel<2, LOG>), grid, block, 0, dev->compute, assign, dx, g, y, outer, L);
+            else if (L <= 1024) hipLaunchKernelGGL((softmax_bwd_row_kernel<4, LOG>), grid, block, 0, dev->compute, assign, dx, g, y, outer, L);
+            else hipLaunchKernelGGL((softmax_bwd_row_kernel<8, LOG>), grid, block, 0, dev->compute, assign, dx, g, y, outer, L);
         } else {
-            hipLaunchKernelGGL((softmax_bwd_block_kernel<LOG>), dim3((unsigned)outer), dim3(256), 0, dev->compute, dx, g, y, L);
+            hipLaunchKernelGGL((softmax_bwd_block_kernel<LOG>), dim3((unsigned)outer), dim3(256), 0, dev->compute, assign, dx, g, y, L);
         }
     } else {
         const long long lanes = outer * inner;
         hipLaunchKernelGGL((softmax_bwd_strided_kernel<LOG>), dim3(nk_stream_grid((size_t)lanes, 256)), dim3(256), 0,
-                           dev->compute, dx, g, y, lanes, L, inner);
+                           dev->compute, assign, dx, g, y, lanes, L, inner);
     }
     NK_LAUNCH_CHECK();
     return NK_OK;
@@ -505,6 +505,12 @@ int nk_softmax_fwd(nk_device* dev, const float* x, float* y, const int* shape, i
 }
 int nk_softmax_bwd(nk_device* dev, float* dx, const float* g, const float* y, const int* shape, int nd, int axis) {
     return softmax_bwd<false>(dev, dx, g, y, shape, nd, axis);
+}
+int nk_softmax_bwd_assign(nk_device* dev, float* dx, const float* g, const float* y, const int* shape, int nd, int axis) {
+    return softmax_bwd<false>(dev, dx, g, y, shape, nd, axis, 1);
+}
+int nk_log_softmax_bwd_assign(nk_device* dev, float* dx, const float* g, const float* y, const int* shape, int nd, int axis) {
+    return softmax_bwd<true>(dev, dx, g, y, shape, nd, axis, 1);
 }
 int nk_log_softmax_fwd(nk_device* dev, const float* x, float* y, const int* shape, int nd, int axis) {
     return softmax_fwd<true>(dev, x, y, shape, nd, axis);

@@ -604,6 +604,33 @@ def test_assign_variants_equal_accumulate_into_zeros(dev):
         A, Z = nan(x.shape), dev.zeros(x.shape)
         c.mse_bwd(dev, A, gs, X, T, red, assign=True); c.mse_bwd(dev, Z, gs, X, T, red)
         assert np.array_equal(A.numpy(), Z.numpy())
+    for op in ("add", "sub", "mul", "div"):                       # same shape, row-broadcast (column reduction), scalar
+        for oshape in (x.shape, (129,), (67, 1), ()):
+            o = rnd(20, oshape, 0.5, 1.5); Oo = dev.array(o)
+            A, Z = nan(oshape), dev.zeros(oshape)
+            c.binary_bwd_right(dev, op, A, G, X, Oo, assign=True); c.binary_bwd_right(dev, op, Z, G, X, Oo)
+            assert np.array_equal(A.numpy(), Z.numpy()), (op, oshape)
+            A, Z = nan(oshape), dev.zeros(oshape)
+            c.binary_bwd_left(dev, op, A, G, X, assign=True); c.binary_bwd_left(dev, op, Z, G, X)
+            assert np.array_equal(A.numpy(), Z.numpy()), (op, oshape)
+    A, Z = nan((129,)), dev.zeros((129,))
+    c.unbroadcast_add(dev, A, G, assign=True); c.unbroadcast_add(dev, Z, G)
+    assert np.array_equal(A.numpy(), Z.numpy())
+    for op in ("neg", "exp", "sigmoid", "tanh", "leaky_relu", "pow"):
+        A, Z = nan(x.shape), dev.zeros(x.shape)
+        c.unary_bwd(dev, op, A, G, X, 3, assign=True); c.unary_bwd(dev, op, Z, G, X, 3)
+        assert np.array_equal(A.numpy(), Z.numpy())
+    for shape, axis in (((67, 129), 1), ((67, 129), 0), ((5, 1024), 1), ((3, 7, 5), 1)):
+        yy, gg = rnd(21, shape, 0.01, 1.0), rnd(22, shape, -1, 1)
+        Yy, Gg = dev.array(yy), dev.array(gg)
+        for fn in (c.softmax_bwd, c.log_softmax_bwd):
+            A, Z = nan(shape), dev.zeros(shape)
+            fn(dev, A, Gg, Yy, axis, assign=True); fn(dev, Z, Gg, Yy, axis)
+            assert np.array_equal(A.numpy(), Z.numpy())
+    for train, p in ((True, 0.3), (False, 0.3), (True, 0.0)):
+        A, Z = nan(x.shape), dev.zeros(x.shape)
+        c.dropout_bwd(dev, A, G, T, p, train, assign=True); c.dropout_bwd(dev, Z, G, T, p, train)
+        assert np.array_equal(A.numpy(), Z.numpy())
     gp = rnd(4, (3, 4, 9, 14))
     A, Z = nan((3, 4, 7, 8)), dev.zeros((3, 4, 7, 8))
     c.pad_bwd(dev, A, dev.array(gp), (1, 3), assign=True); c.pad_bwd(dev, Z, dev.array(gp), (1, 3))
