@@ -181,6 +181,54 @@ def test_sgemm_random(dev, M, N, K, ta, tb):
     contraction_ok(Cd.numpy(), (opa @ opb) * 1.5, ref64 * 1.5, K, 1.5, 1.0)
 
 
+HEUR_SHAPES = [  # one or more shapes per branch of the tile / split-K selection (nk_gemm.hip), all four layouts cycled
+    (3072, 3072, 160), (3072, 1536, 96),      # >= 512 blocks of 128x128 but a ragged last wave -> smaller tiles
+    (1536, 1536, 1536), (1024, 1024, 8192),   # < 512 blocks: 128x128 kept with split-K (>= 16 k-tiles per split)
+    (512, 512, 4096), (256, 256, 2048), (768, 768, 768), (64, 2048, 4096), (2048, 64, 1024),   # 64x64 (+ split)
+    (192, 320, 1100), (129, 65, 515), (1000, 1000, 1000), (33, 4097, 70), (4099, 31, 260),     # ragged / unaligned
+    (2048, 2048, 96), (640, 640, 640), (1, 1, 1), (1, 700, 3), (700, 1, 5000)]
+
+
+@pytest.mark.parametrize("idx", range(len(HEUR_SHAPES)))
+def test_sgemm_heuristic_branches(dev, idx):
+    """Every (tile, split-K) selection path gives the same product: checked against f64 at sampled rows/cols (full
+    reference for the small ones), beta = 0 then beta = 1, layout cycling NN/NT/TN/TT with the shape index."""
+    c = capi()
+    M, N, K = HEUR_SHAPES[idx]
+    ta, tb = (idx >> 1) & 1, idx & 1
+    a = rnd(30 + idx, (K, M) if ta else (M, K), -1, 1)
+    b = rnd(60 + idx, (N, K) if tb else (K, N), -1, 1)
+    opa, opb = (a.T if ta else a).astype(np.float64), (b.T if tb else b).astype(np.float64)
+    A, B, Cd = dev.array(a), dev.array(b), dev.full((M, N), 7.0)
+    c.sgemm(dev, ta, tb, M, N, K, 1.0, A, a.shape[1], B, b.shape[1], 0.0, Cd, N)
+    got = Cd.numpy().astype(np.float64)
+    rows = np.unique(np.r_[0, M - 1, np.random.default_rng(idx).integers(0, M, 24)])
+    cols = np.unique(np.r_[0, N - 1, np.random.default_rng(idx + 1).integers(0, N, 24)])
+    tol = 2e-6 * K + 1e-6
+    assert np.abs(got[rows] - opa[rows] @ opb).max() <= tol
+    assert np.abs(got[:, cols] - opa @ opb[:, cols]).max() <= tol
+    c.sgemm(dev, ta, tb, M, N, K, -0.5, A, a.shape[1], B, b.shape[1], 1.0, Cd, N)       # accumulate: 0.5 * product
+    got2 = Cd.numpy().astype(np.float64)
+    assert np.abs(got2[rows] - 0.5 * (opa[rows] @ opb)).max() <= tol
+    assert np.abs(got2[:, cols] - 0.5 * (opa @ opb[:, cols])).max() <= tol
+
+
+@pytest.mark.parametrize("n,m,o", [(64, 8192, 64), (256, 4096, 512), (1536, 1536, 1536), (3072, 128, 3072)])
+def test_linear_fwd_split_and_small_tiles(dev, n, m, o):
+    """nk_linear_fwd on shapes that take the split-K second pass (bias applied there) and the 64-wide tiles."""
+    c = capi()
+    x, w, b = rnd(1, (n, m), -1, 1), rnd(2, (o, m), -1, 1), rnd(3, (o,), -1, 1)
+    X, W, Bv = dev.array(x), dev.array(w), dev.array(b)
+    Y0, Y1, Y2 = dev.zeros((n, o)), dev.zeros((n, o)), dev.full((n, o), 3.0)
+    c.mm_t_fwd(dev, X, W, Y0)
+    c.binary_fwd(dev, "add", Y1, Y0, Bv)
+    c.linear_fwd(dev, X, W, Bv, Y2)
+    assert np.array_equal(Y1.numpy(), Y2.numpy())
+    rows = np.random.default_rng(0).integers(0, n, 16)
+    ref = x[rows].astype(np.float64) @ w.astype(np.float64).T + b
+    assert np.abs(Y2.numpy()[rows] - ref).max() <= 2e-6 * m
+
+
 def test_sgemm_batched_strided(dev):
     """Two-level batch with the attention strides: Q_bh is a strided view of (B*S, H*dh)."""
     c = capi()
