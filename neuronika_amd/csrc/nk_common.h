@@ -101,15 +101,7 @@ __device__ __forceinline__ void nk_store_stream(float4* p, const float4& v) {
     __builtin_nontemporal_store(t, reinterpret_cast<nk_v4f*>(p));
 #endif
 }
-// streaming 16-byte load of data the kernel touches exactly once
-__device__ __forceinline__ float4 nk_load_stream(const float4* p) {
-#ifdef NK_AB_NT_LOAD
-    const nk_v4f t = __builtin_nontemporal_load(reinterpret_cast<const nk_v4f*>(p));
-    return make_float4(t.x, t.y, t.z, t.w);
-#else
-    return *p;
-#endif
-}
+
 
 constexpr int NK_WAVE = 64;
 

@@ -61,11 +61,7 @@ struct Stage<2> {
     float4 v0, v1;
 };
 
-#ifdef NK_AB_KC_LINEAR  // A/B switch for benchmarks/ab_build.py only
-__device__ __forceinline__ int kc_row(int idx) { return idx >> 3; }
-#else
 __device__ __forceinline__ int kc_row(int idx) { return ((idx >> 7) << 4) + (((idx >> 3) & 1) << 3) + ((idx >> 4) & 7); }
-#endif
 __device__ __forceinline__ int kc_q(int idx) { return idx & 7; }
 
 template <bool KC, int R>
