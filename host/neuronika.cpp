@@ -249,6 +249,12 @@ struct UnaryBwd : Backward {
             else check((assign ? nk_mean_bwd_assign : nk_mean_bwd)(d.device()->raw(), d.ptr(), d.len(), G.ptr()));
             return;
         }
+        if (kind == Unary::Transpose) {
+            bool assign = false;
+            HipArray& d = dx->borrow_first_write(assign);
+            check((assign ? nk_transpose_bwd_assign : nk_transpose_bwd)(d.device()->raw(), d.ptr(), G.ptr(), d.shape().data(), (int)d.shape().size()));
+            return;
+        }
         if (kind == Unary::Softmax || kind == Unary::LogSoftmax) {
             bool assign = false;
             HipArray& d = dx->borrow_first_write(assign);
@@ -261,7 +267,7 @@ struct UnaryBwd : Backward {
         const int nd = (int)d.shape().size();
         switch (kind) {
             case Unary::Relu: case Unary::Softmax: case Unary::LogSoftmax: break;
-            case Unary::Transpose: check(nk_transpose_bwd(d.device()->raw(), d.ptr(), G.ptr(), d.shape().data(), nd)); break;
+            case Unary::Transpose: break;
             case Unary::Sum: case Unary::Mean: break;
         }
     }
@@ -571,9 +577,10 @@ struct CatBwd : Backward {
         const HipArray& G = g->borrow();
         int off = 0;
         for (const auto& o : operands) {
-            HipArray& d = o->borrow();
+            bool assign = false;
+            HipArray& d = o->borrow_first_write(assign);
             const int len = stack ? 1 : d.shape()[axis];
-            check(nk_concat_bwd_part(d.device()->raw(), d.ptr(), G.ptr(), G.shape().data(), (int)G.shape().size(), axis, off, len));
+            check((assign ? nk_concat_bwd_part_assign : nk_concat_bwd_part)(d.device()->raw(), d.ptr(), G.ptr(), G.shape().data(), (int)G.shape().size(), axis, off, len));
             off += len;
         }
     }

@@ -248,7 +248,8 @@ int nk_mse_bwd(nk_device* dev, float* dx, const float* g, const float* x, const 
 /* The reference allocates every gradient zeroed (gradient.rs:47-54) and every backward node `+=`s into it.
  * For the FIRST node writing into a gradient of the current pass, `0 + v` needs neither the memset nor the
  * read of the destination: the `_assign` variants compute exactly what their `+=` twin computes on an all-zero
- * destination, writing without reading (the GEMM-shaped nodes get the same through nk_sgemm's beta = 0).
+ * destination, writing without reading (the GEMM-shaped nodes get the same through nk_sgemm's beta = 0).  Only nodes
+ * whose backward covers the WHOLE destination have a twin (not Chunk's tile update or NLL's scatter).
  * The tape (host `Gradient`) keeps the zero fill pending and hands it to the first writer. */
 int nk_conv_bwd_input_assign(nk_device* dev, int nd, float* dx, const int* x_shape, const float* g,
                              const float* w, const int* w_shape, const int* stride,
@@ -272,6 +273,9 @@ int nk_log_softmax_bwd_assign(nk_device* dev, float* dx, const float* g, const f
                               const int* shape, int nd, int axis);
 int nk_dropout_bwd_assign(nk_device* dev, float* dx, const float* g, const float* noise, size_t n,
                           double p, int train);
+int nk_concat_bwd_part_assign(nk_device* dev, float* d_operand, const float* g, const int* g_shape,
+                              int nd, int axis, int offset, int op_len);
+int nk_transpose_bwd_assign(nk_device* dev, float* dx, const float* g, const int* x_shape, int nd);
 int nk_sum_bwd_assign(nk_device* dev, float* dx, size_t n, const float* g);
 int nk_mean_bwd_assign(nk_device* dev, float* dx, size_t n, const float* g);
 int nk_relu_bwd_assign(nk_device* dev, float* dx, const float* g, const float* x, size_t n);

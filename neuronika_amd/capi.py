@@ -111,6 +111,8 @@ _SIGS = {
     "nk_softmax_bwd_assign": [VP, VP, VP, VP, c_intp, C.c_int, C.c_int],
     "nk_log_softmax_bwd_assign": [VP, VP, VP, VP, c_intp, C.c_int, C.c_int],
     "nk_dropout_bwd_assign": [VP, VP, VP, VP, C.c_size_t, C.c_double, C.c_int],
+    "nk_concat_bwd_part_assign": [VP, VP, VP, c_intp, C.c_int, C.c_int, C.c_int, C.c_int],
+    "nk_transpose_bwd_assign": [VP, VP, VP, c_intp, C.c_int],
     "nk_sum_bwd_assign": [VP, VP, C.c_size_t, VP],
     "nk_mean_bwd_assign": [VP, VP, C.c_size_t, VP],
     "nk_relu_bwd_assign": [VP, VP, VP, VP, C.c_size_t],
@@ -566,10 +568,10 @@ def concat_fwd(dev, operands, out, axis):
         off += o.shape[axis]
 
 
-def concat_bwd(dev, d_operands, g, axis):
+def concat_bwd(dev, d_operands, g, axis, assign=False):
     off = 0
     for d in d_operands:
-        check(lib.nk_concat_bwd_part(dev.h, d.p, g.p, g.shape_c(), g.ndim, axis, off, d.shape[axis]))
+        check((lib.nk_concat_bwd_part_assign if assign else lib.nk_concat_bwd_part)(dev.h, d.p, g.p, g.shape_c(), g.ndim, axis, off, d.shape[axis]))
         off += d.shape[axis]
 
 
@@ -577,8 +579,8 @@ def transpose_fwd(dev, x, y):
     check(lib.nk_transpose_fwd(dev.h, x.p, y.p, x.shape_c(), x.ndim))
 
 
-def transpose_bwd(dev, dx, g):
-    check(lib.nk_transpose_bwd(dev.h, dx.p, g.p, dx.shape_c(), dx.ndim))
+def transpose_bwd(dev, dx, g, assign=False):
+    check((lib.nk_transpose_bwd_assign if assign else lib.nk_transpose_bwd)(dev.h, dx.p, g.p, dx.shape_c(), dx.ndim))
 
 
 def split_heads_fwd(dev, x, y, B, S, H, dh):

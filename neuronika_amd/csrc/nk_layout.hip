@@ -524,6 +524,15 @@ int nk_concat_bwd_part(nk_device* dev, float* d_operand, const float* g, const i
     origin[axis] = offset;
     return subblock<0, true>(dev, d_operand, s, const_cast<float*>(g), g_shape, origin, nd);
 }
+int nk_concat_bwd_part_assign(nk_device* dev, float* d_operand, const float* g, const int* g_shape, int nd, int axis,
+                              int offset, int op_len) {
+    NK_CHECK(nd >= 1 && nd <= NK_MAX_DIMS && axis >= 0 && axis < nd, "bad rank/axis");
+    int s[NK_MAX_DIMS], origin[NK_MAX_DIMS] = {0};
+    for (int i = 0; i < nd; ++i) s[i] = g_shape[i];
+    s[axis] = op_len;
+    origin[axis] = offset;
+    return subblock<0, false>(dev, d_operand, s, const_cast<float*>(g), g_shape, origin, nd);
+}
 
 int nk_transpose_fwd(nk_device* dev, const float* x, float* y, const int* x_shape, int nd) {
     return transpose<false>(dev, x, y, x_shape, nd);
@@ -534,6 +543,12 @@ int nk_transpose_bwd(nk_device* dev, float* dx, const float* g, const int* x_sha
     NK_CHECK(nd >= 1 && nd <= NK_MAX_DIMS, "bad rank %d", nd);
     for (int i = 0; i < nd; ++i) gs[i] = x_shape[nd - 1 - i];
     return transpose<true>(dev, g, dx, gs, nd);
+}
+int nk_transpose_bwd_assign(nk_device* dev, float* dx, const float* g, const int* x_shape, int nd) {
+    int gs[NK_MAX_DIMS];
+    NK_CHECK(nd >= 1 && nd <= NK_MAX_DIMS, "bad rank %d", nd);
+    for (int i = 0; i < nd; ++i) gs[i] = x_shape[nd - 1 - i];
+    return transpose<false>(dev, g, dx, gs, nd);
 }
 
 int nk_split_heads_fwd(nk_device* dev, const float* x, float* y, int B, int S, int H, int dh) {

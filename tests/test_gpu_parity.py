@@ -679,6 +679,14 @@ def test_assign_variants_equal_accumulate_into_zeros(dev):
         A, Z = nan(x.shape), dev.zeros(x.shape)
         c.dropout_bwd(dev, A, G, T, p, train, assign=True); c.dropout_bwd(dev, Z, G, T, p, train)
         assert np.array_equal(A.numpy(), Z.numpy())
+    gt = rnd(23, (129, 67), -1, 1)
+    A, Z = nan(x.shape), dev.zeros(x.shape)
+    c.transpose_bwd(dev, A, dev.array(gt), assign=True); c.transpose_bwd(dev, Z, dev.array(gt))
+    assert np.array_equal(A.numpy(), Z.numpy())
+    gc = rnd(24, (67, 300), -1, 1)
+    As, Zs = [nan((67, 129)), nan((67, 171))], [dev.zeros((67, 129)), dev.zeros((67, 171))]
+    c.concat_bwd(dev, As, dev.array(gc), 1, assign=True); c.concat_bwd(dev, Zs, dev.array(gc), 1)
+    assert all(np.array_equal(a.numpy(), z.numpy()) for a, z in zip(As, Zs))
     gp = rnd(4, (3, 4, 9, 14))
     A, Z = nan((3, 4, 7, 8)), dev.zeros((3, 4, 7, 8))
     c.pad_bwd(dev, A, dev.array(gp), (1, 3), assign=True); c.pad_bwd(dev, Z, dev.array(gp), (1, 3))
