@@ -639,3 +639,14 @@ def test_gradient_sync_piecewise_exchange(nk, tdev):
     l2 = small.forward(nk.rand(tdev, [8, 64], 1)).sum()
     l2.forward(); l2.backward_sync(1.0, s2); s2.join()
     assert s2.exchanges_issued() == 2
+
+
+@pytest.mark.gpu
+def test_quickstart_example_trains(nk, tdev):
+    """examples/quickstart.py (= the reference's examples/quickstart.rs, config C1) runs end to end - CSV loader,
+    serde model, Linear/ReLU graph rebuilt per batch, MSE, SGD - and the epoch loss goes down."""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("quickstart", os.path.join(os.path.dirname(os.path.dirname(__file__)), "examples", "quickstart.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    losses = mod.main(epochs=5, seed=1)
+    assert len(losses) == 5 and all(np.isfinite(losses)) and losses[-1] < losses[0]
