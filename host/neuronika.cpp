@@ -1300,6 +1300,46 @@ Var rand(DevicePtr dev, const Shape& shape, uint64_t seed) {
     return from_host(std::move(dev), shape, v.data());
 }
 
+// ndarray's `Linspace`: element i = start + step * i with step = (end - start) / (n - 1)
+static std::vector<float> linspace_host(float start, float end, int n) {
+    if (n < 0) panic("linspace: negative length");
+    std::vector<float> v((size_t)n);
+    const float step = n > 1 ? (end - start) / (float)(n - 1) : 0.f;
+    for (int i = 0; i < n; ++i) v[(size_t)i] = start + step * (float)i;
+    return v;
+}
+Var eye(DevicePtr dev, int n) {
+    if (n < 0) panic("eye: negative size");
+    std::vector<float> h((size_t)n * n, 0.f);
+    for (int i = 0; i < n; ++i) h[(size_t)i * n + i] = 1.f;
+    return from_host(std::move(dev), Shape{n, n}, h.data());
+}
+Var linspace(DevicePtr dev, float start, float end, int n) {
+    const auto v = linspace_host(start, end, n);
+    return from_host(std::move(dev), Shape{n}, v.data());
+}
+Var logspace(DevicePtr dev, float base, float start, float end, int n) {
+    auto v = linspace_host(start, end, n);
+    const float sign = base < 0.f ? -1.f : 1.f, b = std::fabs(base);
+    for (float& e : v) e = sign * std::pow(b, e);
+    return from_host(std::move(dev), Shape{n}, v.data());
+}
+Var geomspace(DevicePtr dev, float start, float end, int n) {
+    if (start == 0.f || end == 0.f || (start < 0.f) != (end < 0.f))
+        panic("geomspace: the reference returns None (an endpoint is zero or the endpoints differ in sign)");
+    auto v = linspace_host(std::log(std::fabs(start)), std::log(std::fabs(end)), n);
+    const float sign = start < 0.f ? -1.f : 1.f;
+    for (float& e : v) e = sign * std::exp(e);
+    return from_host(std::move(dev), Shape{n}, v.data());
+}
+Var range(DevicePtr dev, float start, float end, float step) {
+    const float cnt = std::ceil((end - start) / step);
+    const int n = (cnt > 0.f && std::isfinite(cnt)) ? (int)cnt : 0;  // `as usize` saturates negatives / NaN to 0
+    std::vector<float> v((size_t)n);
+    for (int i = 0; i < n; ++i) v[(size_t)i] = start + step * (float)i;
+    return from_host(std::move(dev), Shape{n}, v.data());
+}
+
 // =================================================================================================
 // nn
 // =================================================================================================

@@ -380,6 +380,13 @@ NK_DECLARE_BINARY(/)
 
 // leaf constructors (lib.rs:51-143)
 Var from_host(DevicePtr dev, const Shape& shape, const float* host);  // `from_ndarray`
+// lib.rs:160-240: `eye`, `linspace` (end inclusive), `logspace` (base^linspace, negative base -> negative values),
+// `geomspace` (panics where the reference returns None: zero endpoint or endpoints of different sign), `range` (half open)
+Var eye(DevicePtr dev, int n);
+Var linspace(DevicePtr dev, float start, float end, int n);
+Var logspace(DevicePtr dev, float base, float start, float end, int n);
+Var geomspace(DevicePtr dev, float start, float end, int n);
+Var range(DevicePtr dev, float start, float end, float step);
 Var zeros(DevicePtr dev, const Shape& shape);
 Var ones(DevicePtr dev, const Shape& shape);
 Var full(DevicePtr dev, const Shape& shape, float value);

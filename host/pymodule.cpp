@@ -145,6 +145,8 @@ PYBIND11_MODULE(_tape, m) {
     m.def("ones", &ones);
     m.def("full", &full);
     m.def("rand", &neuronika::rand);
+    m.def("eye", &eye); m.def("linspace", &linspace); m.def("logspace", &logspace); m.def("geomspace", &geomspace);
+    m.def("range", &neuronika::range);
 
     {   // neuronika-data mirror + device input pipeline
         namespace nd = neuronika::data;

@@ -93,6 +93,13 @@ def build_tape(force: bool = False, verbose: bool = True) -> str:
         raise RuntimeError(f"host tape build failed:\n{r.stdout}\n{r.stderr}")
     if r.stderr.strip():
         sys.stderr.write(r.stderr)
+    # a shared object links fine with undefined symbols: load it once so that a declared-but-undefined function fails
+    # the build here, not the first test on the GPU box
+    chk = subprocess.run([sys.executable, "-c", "import importlib.util,sys; s=importlib.util.spec_from_file_location('neuronika_amd._tape', sys.argv[1]); m=importlib.util.module_from_spec(s); s.loader.exec_module(m)", out],
+                         capture_output=True, text=True)
+    if chk.returncode != 0:
+        os.remove(out)
+        raise RuntimeError(f"host tape module does not load:\n{chk.stderr}")
     if verbose:
         print(f"[neuronika_amd.build] {out} (rebuilt)")
     return out

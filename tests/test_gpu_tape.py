@@ -650,3 +650,22 @@ def test_quickstart_example_trains(nk, tdev):
     mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
     losses = mod.main(epochs=5, seed=1)
     assert len(losses) == 5 and all(np.isfinite(losses)) and losses[-1] < losses[0]
+
+
+@pytest.mark.gpu
+def test_free_constructors(nk, tdev):
+    """lib.rs:160-240: eye / linspace / logspace / geomspace / range with ndarray's element formulas (f32)."""
+    f = np.float32
+    assert np.array_equal(nk.eye(tdev, 4).data(), np.eye(4, dtype=f))
+    lin = lambda a, b, n: f(a) + (f(b) - f(a)) / f(n - 1) * np.arange(n, dtype=f)
+    assert np.array_equal(nk.linspace(tdev, -4.0, 4.0, 9).data(), lin(-4, 4, 9))
+    assert np.array_equal(nk.linspace(tdev, 2.0, 5.0, 1).data(), np.array([2.0], f))
+    close(nk.logspace(tdev, 10.0, 0.0, 3.0, 4).data(), [1, 10, 100, 1000], 1e-6)
+    close(nk.logspace(tdev, -2.0, 0.0, 3.0, 4).data(), [-1, -2, -4, -8], 1e-6)
+    close(nk.geomspace(tdev, 1.0, 1000.0, 4).data(), [1, 10, 100, 1000], 2e-6)
+    close(nk.geomspace(tdev, -1.0, -16.0, 5).data(), [-1, -2, -4, -8, -16], 2e-6)
+    with pytest.raises(RuntimeError, match="geomspace"):
+        nk.geomspace(tdev, -1.0, 4.0, 3)
+    assert np.array_equal(nk.range(tdev, 0.0, 5.0, 1.0).data(), np.arange(5, dtype=f))
+    assert np.array_equal(nk.range(tdev, 1.0, 2.0, 0.25).data(), np.array([1.0, 1.25, 1.5, 1.75], f))
+    assert nk.range(tdev, 3.0, 1.0, 1.0).shape == [0]
