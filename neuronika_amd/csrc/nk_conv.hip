@@ -517,6 +517,11 @@ struct FastFwdArgs {
     float* y;
     const int* tapoff;
     int tiles_m, tiles_n;
+    // Tail balancing: the first `full_blocks` tiles (whole waves of resident blocks) are computed by one block each;
+    // every remaining tile is split over `tail_splits` blocks of `tail_kts` k-tiles that write partial tiles to
+    // `slabs` ([tail tile][split][BM][BN]); conv_tail_reduce_kernel sums them in split order.  tail_splits == 0: off.
+    int full_blocks, tail_splits, tail_kts;
+    float* slabs;
 };
 
 // requires Cg % 32 == 0, stride[2] == 1, out[2] % 4 == 0, per-tensor element counts < 2^31
@@ -528,10 +533,22 @@ __global__ __launch_bounds__(NT, 2) void conv_fwd_fast_kernel(FastFwdArgs p) {
     const ConvGeom& g = p.g;
     const int t = threadIdx.x, lane = t & 63, wid = t >> 6, wr = wid >> 1, wc = wid & 1;
     int tm, tn;
-    tile_coords(blockIdx.x, gridDim.x, p.tiles_m, p.tiles_n, tm, tn);
+    const int K = g.Cg * g.KK, tpt = g.Cg / BK;  // k-tiles per tap
+    int kt0 = 0, nt = K / BK;
+    float* slab = nullptr;
+    if (p.tail_splits == 0) {
+        tile_coords(blockIdx.x, gridDim.x, p.tiles_m, p.tiles_n, tm, tn);
+    } else if ((int)blockIdx.x < p.full_blocks) {
+        tile_of_seq(xcd_chunk(blockIdx.x, p.full_blocks), p.tiles_m, p.tiles_n, tm, tn);
+    } else {
+        const int tb = blockIdx.x - p.full_blocks, tail_tile = tb / p.tail_splits, split = tb - tail_tile * p.tail_splits;
+        tile_of_seq(p.full_blocks + tail_tile, p.tiles_m, p.tiles_n, tm, tn);
+        kt0 = split * p.tail_kts;
+        nt = min(nt - kt0, p.tail_kts);
+        slab = p.slabs + ((long long)(blockIdx.z * (p.tiles_m * p.tiles_n - p.full_blocks) + tail_tile) * p.tail_splits + split) * (BM * BN);
+    }
     const int grp = blockIdx.z;
     const int m0 = tm * BM, n0 = tn * BN;
-    const int K = g.Cg * g.KK, nt = K / BK, tpt = g.Cg / BK;  // k-tiles per tap
     const long long cols = (long long)g.N * g.L;
     const float* W = p.wp + (long long)grp * g.Mg * K;
     const float* X = p.x + (long long)grp * g.Cg * g.inplane;
@@ -548,6 +565,7 @@ __global__ __launch_bounds__(NT, 2) void conv_fwd_fast_kernel(FastFwdArgs p) {
     }
     const int jstep = 8 * g.inplane;
     auto gather = [&](int kt) {
+        kt += kt0;
         const int tap = kt / tpt, ci0 = (kt - tap * tpt) * BK;
         const float* src = X + (p.tapoff[tap] + ci0 * g.inplane);
         Stage<4> r;
@@ -566,7 +584,7 @@ __global__ __launch_bounds__(NT, 2) void conv_fwd_fast_kernel(FastFwdArgs p) {
     f32x16 acc[TI][TJ];
     acc_zero<TI, TJ>(acc);
     TileLoader<true, BM> la;
-    la.init(W, K, m0, 0, g.Mg, K, t);
+    la.init(W, K, m0, kt0 * BK, g.Mg, K, t);
     Stage<BM / 32> ra;
     Stage<4> rb;
     ra = la.template load<ALIGNED_A>(t);
@@ -585,9 +603,13 @@ __global__ __launch_bounds__(NT, 2) void conv_fwd_fast_kernel(FastFwdArgs p) {
         stage_store<false, BN>(nxt + TA_FLOATS, rb, t);
         __syncthreads();
     }
-    {
+    if (nt > 0) {
         float* cur = smem + ((nt - 1) & 1) * STAGE;
         mma_tile<true, false, TI, TJ>(cur, cur + TA_FLOATS, acc, wr, wc, lane);
+    }
+    if (slab) {  // partial tile of a split tail tile
+        acc_foreach<TI, TJ>(acc, wr, wc, lane, [&](int r, int c, float v) { slab[r * BN + c] = v; });
+        return;
     }
     float* Y = p.y;
     const float* bias = g.bias;
@@ -600,6 +622,32 @@ __global__ __launch_bounds__(NT, 2) void conv_fwd_fast_kernel(FastFwdArgs p) {
             Y[((long long)n * Cout + grp * Mg + co) * L + l] = bias ? v + bias[grp * Mg + co] : v;
         }
     });
+}
+
+// Y[tail tiles] = sum over splits (fixed order) of the partial tiles (+ bias)
+template <int BM>
+__global__ void conv_fwd_tail_reduce_kernel(FastFwdArgs p) {
+    constexpr int BN = 128;
+    const ConvGeom& g = p.g;
+    const int ntail = p.tiles_m * p.tiles_n - p.full_blocks;
+    const int tail_tile = blockIdx.x, grp = blockIdx.z;
+    int tm, tn;
+    tile_of_seq(p.full_blocks + tail_tile, p.tiles_m, p.tiles_n, tm, tn);
+    const float* base = p.slabs + ((long long)(grp * ntail + tail_tile) * p.tail_splits) * (BM * BN);
+    const int cols = g.N * g.L;  // < 2^31 on the fast path
+    // blockIdx.y: a 1024-element slice of the tile (8 rows x 128 columns); consecutive threads = consecutive columns
+    const int e = blockIdx.y * 1024 + threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ee = e + i * 256;
+        const int r = ee / BN, c = ee - r * BN;
+        const int co = tm * BM + r, cc = tn * BN + c;
+        if (co >= g.Mg || cc >= cols) continue;
+        float s = 0.f;
+        for (int k = 0; k < p.tail_splits; ++k) s += base[(long long)k * (BM * BN) + ee];
+        const int n = cc / g.L, l = cc - n * g.L;
+        p.y[((long long)n * g.Cout + grp * g.Mg + co) * g.L + l] = g.bias ? s + g.bias[grp * g.Mg + co] : s;
+    }
 }
 
 struct FastBwdInArgs {
@@ -760,23 +808,46 @@ int conv_fwd(nk_device* dev, int nd, const float* x, const int* x_shape, const f
     if (g.Cg % BK == 0 && g.stride[2] == 1 && g.out[2] % 4 == 0 && x_elems < 0x7fffffffLL && y_elems < 0x7fffffffLL) {
         const size_t wp_bytes = round256((size_t)g.Cout * K * sizeof(float));
         const size_t to_bytes = round256((size_t)g.KK * sizeof(int));
-        void* wsf = nullptr;
-        rc = nk_workspace(dev, wp_bytes + to_bytes + round256((size_t)g.KK * sizeof(int4)), &wsf);
-        if (rc) return rc;
-        float* wp = (float*)wsf;
-        int* tapoff = (int*)((char*)wsf + wp_bytes);
-        int4* tapd = (int4*)((char*)wsf + wp_bytes + to_bytes);
-        hipLaunchKernelGGL(conv_wp_kernel, dim3(nk_stream_grid((size_t)g.Cout * K, 256)), dim3(256), 0, dev->compute, wp, w, g);
-        NK_LAUNCH_CHECK();
-        hipLaunchKernelGGL(conv_tapoff_kernel, dim3(1), dim3(64), 0, dev->compute, tapoff, tapd, g);
-        NK_LAUNCH_CHECK();
+        const size_t tables = wp_bytes + to_bytes + round256((size_t)g.KK * sizeof(int4));
         FastFwdArgs fp{};
-        fp.g = g; fp.x = x; fp.wp = wp; fp.y = y; fp.tapoff = tapoff;
         const int fti = g.Mg <= 64 || (g.Mg % 128 != 0 && g.Mg % 64 == 0) ? 1 : 2;
         fp.tiles_m = (g.Mg + 64 * fti - 1) / (64 * fti);
         fp.tiles_n = (int)(((long long)g.N * g.L + 127) / 128);
         const bool al = g.Mg % (64 * fti) == 0;
-        dim3 fgrid(fp.tiles_m * fp.tiles_n, 1, groups);
+        // tail balancing: tiles beyond the last whole wave of resident blocks (2 per CU) are split along k
+        const int tiles = fp.tiles_m * fp.tiles_n, slots = 2 * dev->num_cus, nkt = K / BK;
+        int nblocks = tiles;
+        size_t slab_bytes = 0;
+        fp.full_blocks = tiles;
+#ifndef NK_AB_NO_TAIL
+        const int tail = tiles % slots;
+        if (groups == 1 && tiles > slots && tail > 0 && tail * 2 <= slots && nkt >= 4) {
+            int S = slots / tail;
+            if (S > nkt / 2) S = nkt / 2;
+            const int kts = (nkt + S - 1) / S;
+            S = (nkt + kts - 1) / kts;
+            if (S >= 2) {
+                fp.full_blocks = tiles - tail;
+                fp.tail_splits = S;
+                fp.tail_kts = kts;
+                nblocks = fp.full_blocks + tail * S;
+                slab_bytes = (size_t)tail * S * (64 * fti) * 128 * sizeof(float);
+            }
+        }
+#endif
+        void* wsf = nullptr;
+        rc = nk_workspace(dev, tables + slab_bytes, &wsf);
+        if (rc) return rc;
+        float* wp = (float*)wsf;
+        int* tapoff = (int*)((char*)wsf + wp_bytes);
+        int4* tapd = (int4*)((char*)wsf + wp_bytes + to_bytes);
+        if (slab_bytes) fp.slabs = (float*)((char*)wsf + tables);
+        hipLaunchKernelGGL(conv_wp_kernel, dim3(nk_stream_grid((size_t)g.Cout * K, 256)), dim3(256), 0, dev->compute, wp, w, g);
+        NK_LAUNCH_CHECK();
+        hipLaunchKernelGGL(conv_tapoff_kernel, dim3(1), dim3(64), 0, dev->compute, tapoff, tapd, g);
+        NK_LAUNCH_CHECK();
+        fp.g = g; fp.x = x; fp.wp = wp; fp.y = y; fp.tapoff = tapoff;
+        dim3 fgrid(nblocks, 1, groups);
         rc = nk_prof_start(dev, NK_KERNEL_CONV, 2.0 * g.N * (double)g.Cout * g.L * g.Cg * g.KK);
         if (rc) return rc;
         if (al && fti == 2) hipLaunchKernelGGL((conv_fwd_fast_kernel<true, 2>), fgrid, dim3(NT), 0, dev->compute, fp);
@@ -784,6 +855,12 @@ int conv_fwd(nk_device* dev, int nd, const float* x, const int* x_shape, const f
         else if (fti == 2) hipLaunchKernelGGL((conv_fwd_fast_kernel<false, 2>), fgrid, dim3(NT), 0, dev->compute, fp);
         else hipLaunchKernelGGL((conv_fwd_fast_kernel<false, 1>), fgrid, dim3(NT), 0, dev->compute, fp);
         NK_LAUNCH_CHECK();
+        if (fp.tail_splits) {
+            const dim3 rgrid(tiles - fp.full_blocks, (64 * fti * 128) / 1024, groups);
+            if (fti == 2) hipLaunchKernelGGL(conv_fwd_tail_reduce_kernel<128>, rgrid, dim3(256), 0, dev->compute, fp);
+            else hipLaunchKernelGGL(conv_fwd_tail_reduce_kernel<64>, rgrid, dim3(256), 0, dev->compute, fp);
+            NK_LAUNCH_CHECK();
+        }
         return nk_prof_stop(dev);
     }
     void* ws = nullptr;

@@ -216,6 +216,24 @@ __device__ __forceinline__ void acc_foreach(const f32x16 (&acc)[TI][TJ], int wr,
 // of the tile sequence, and order the sequence in column-major groups of GROUP_M tile rows so
 // that the tiles resident on one XCD at a time share A row-panels and B column-panels in its
 // private 4 MiB L2 (cdna_hip_programming.md T1; bijective form).
+// first half of tile_coords: block id -> position in the tile sequence (each XCD gets a contiguous chunk)
+__device__ __forceinline__ int xcd_chunk(int bid, int nblk) {
+    constexpr int NXCD = 8;
+    const int q = nblk / NXCD, rem = nblk % NXCD;
+    const int xcd = bid % NXCD, loc = bid / NXCD;
+    return (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + loc;
+}
+// second half: position in the sequence -> tile (column-major groups of GROUP_M tile rows)
+__device__ __forceinline__ void tile_of_seq(int swz, int tiles_m, int tiles_n, int& tm, int& tn) {
+    constexpr int GROUP_M = 8;
+    const int per_group = GROUP_M * tiles_n;
+    const int group = swz / per_group;
+    const int first_m = group * GROUP_M;
+    const int gsize = min(tiles_m - first_m, GROUP_M);
+    const int in_group = swz % per_group;
+    tm = first_m + in_group % gsize;
+    tn = in_group / gsize;
+}
 __device__ __forceinline__ void tile_coords(int bid, int nblk, int tiles_m, int tiles_n, int& tm, int& tn) {
     constexpr int NXCD = 8;
     const int q = nblk / NXCD, rem = nblk % NXCD;
