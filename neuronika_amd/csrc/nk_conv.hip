@@ -172,14 +172,18 @@ __global__ __launch_bounds__(NT, 2) void conv_fwd_kernel(FwdArgs p) {
     float* Y = p.y;
     const float* bias = g.bias;
     const int Mg = g.Mg, L = g.L, Cout = g.Cout;
-    acc_foreach<TI, TJ>(acc, wr, wc, lane, [&](int r, int c, float v) {
-        const int co = m0 + r;
-        const long long cc = (long long)n0 + c;
-        if (co < Mg && cc < cols) {
-            const int n = (int)(cc / L), l = (int)(cc % L);
-            Y[((long long)n * Cout + grp * Mg + co) * L + l] = bias ? v + bias[grp * Mg + co] : v;
-        }
-    });
+    // one (n, l) decode per owned column instead of one per element
+    acc_foreach_cols<TI, TJ>(acc, wr, wc, lane,
+        [&](int c) -> long long {
+            const long long cc = (long long)n0 + c;
+            if (cc >= cols) return -1;
+            const long long n = cc / L;
+            return (n * Cout + grp * Mg) * L + (cc - n * L);
+        },
+        [&](int r, long long base, float v) {
+            const int co = m0 + r;
+            if (co < Mg && base >= 0) Y[base + (long long)co * L] = bias ? v + bias[grp * Mg + co] : v;
+        });
 }
 
 // =================================================================================================
@@ -296,15 +300,20 @@ __global__ __launch_bounds__(NT, 2) void conv_bwd_input_kernel(BwdInArgs p) {
     float* DX = p.dx;
     const int assign = g.assign;
     const int Cg = g.Cg, Cin = g.Cin, inplane = g.inplane;
-    acc_foreach<TI, TJ>(acc, wr, wc, lane, [&](int r, int c, float v) {
-        const int ci = m0 + r;
-        const long long cc = (long long)n0 + c;
-        if (ci < Cg && cc < cols) {
-            const int n = (int)(cc / inplane), q = (int)(cc % inplane);
-            float* d = &DX[((long long)n * Cin + grp * Cg + ci) * inplane + q];
-            *d = assign ? v : *d + v;
-        }
-    });
+    acc_foreach_cols<TI, TJ>(acc, wr, wc, lane,
+        [&](int c) -> long long {
+            const long long cc = (long long)n0 + c;
+            if (cc >= cols) return -1;
+            const long long n = cc / inplane;
+            return (n * Cin + grp * Cg) * inplane + (cc - n * inplane);
+        },
+        [&](int r, long long base, float v) {
+            const int ci = m0 + r;
+            if (ci < Cg && base >= 0) {
+                float* d = &DX[base + (long long)ci * inplane];
+                *d = assign ? v : *d + v;
+            }
+        });
 }
 
 // =================================================================================================
@@ -614,14 +623,18 @@ __global__ __launch_bounds__(NT, 2) void conv_fwd_fast_kernel(FastFwdArgs p) {
     float* Y = p.y;
     const float* bias = g.bias;
     const int Mg = g.Mg, L = g.L, Cout = g.Cout;
-    acc_foreach<TI, TJ>(acc, wr, wc, lane, [&](int r, int c, float v) {
-        const int co = m0 + r;
-        const long long cc = (long long)n0 + c;
-        if (co < Mg && cc < cols) {
-            const int n = (int)(cc / L), l = (int)(cc % L);
-            Y[((long long)n * Cout + grp * Mg + co) * L + l] = bias ? v + bias[grp * Mg + co] : v;
-        }
-    });
+    // one (n, l) decode per owned column instead of one per element
+    acc_foreach_cols<TI, TJ>(acc, wr, wc, lane,
+        [&](int c) -> long long {
+            const long long cc = (long long)n0 + c;
+            if (cc >= cols) return -1;
+            const long long n = cc / L;
+            return (n * Cout + grp * Mg) * L + (cc - n * L);
+        },
+        [&](int r, long long base, float v) {
+            const int co = m0 + r;
+            if (co < Mg && base >= 0) Y[base + (long long)co * L] = bias ? v + bias[grp * Mg + co] : v;
+        });
 }
 
 // Y[tail tiles] = sum over splits (fixed order) of the partial tiles (+ bias)
@@ -753,15 +766,20 @@ __global__ __launch_bounds__(NT, 2) void conv_bwd_input_fast_kernel(FastBwdInArg
     float* DX = p.dx;
     const int assign = g.assign;
     const int Cg = g.Cg, Cin = g.Cin, inplane = g.inplane;
-    acc_foreach<TI, TJ>(acc, wr, wc, lane, [&](int r, int c, float v) {
-        const int ci = m0 + r;
-        const long long cc = (long long)n0 + c;
-        if (ci < Cg && cc < cols) {
-            const int n = (int)(cc / inplane), q = (int)(cc % inplane);
-            float* d = &DX[((long long)n * Cin + grp * Cg + ci) * inplane + q];
-            *d = assign ? v : *d + v;
-        }
-    });
+    acc_foreach_cols<TI, TJ>(acc, wr, wc, lane,
+        [&](int c) -> long long {
+            const long long cc = (long long)n0 + c;
+            if (cc >= cols) return -1;
+            const long long n = cc / inplane;
+            return (n * Cin + grp * Cg) * inplane + (cc - n * inplane);
+        },
+        [&](int r, long long base, float v) {
+            const int ci = m0 + r;
+            if (ci < Cg && base >= 0) {
+                float* d = &DX[base + (long long)ci * inplane];
+                *d = assign ? v : *d + v;
+            }
+        });
 }
 
 // ---- host side ------------------------------------------------------------------------------------

@@ -211,6 +211,21 @@ __device__ __forceinline__ void acc_foreach(const f32x16 (&acc)[TI][TJ], int wr,
             }
 }
 
+// Same walk, column first: `fc(col)` is evaluated once per owned column (a lane owns TJ columns and 16*TI rows of each),
+// `fe(row, ctx, value)` per element - for epilogues whose column -> address decode is expensive (integer divisions).
+template <int TI, int TJ, class FC, class FE>
+__device__ __forceinline__ void acc_foreach_cols(const f32x16 (&acc)[TI][TJ], int wr, int wc, int lane, FC&& fc, FE&& fe) {
+    const int c = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+        const auto ctx = fc((wc * TJ + j) * 32 + c);
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) fe((wr * TI + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h, ctx, acc[i][j][e]);
+    }
+}
+
 // XCD-aware, L2-friendly block -> tile mapping.  Blocks are dispatched round-robin over the 8
 // XCDs (block b -> XCD b%8, observed; used for speed only): give each XCD a contiguous chunk
 // of the tile sequence, and order the sequence in column-major groups of GROUP_M tile rows so
