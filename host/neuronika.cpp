@@ -51,6 +51,15 @@ float* Device::alloc_zeroed(size_t n) {
     in_use_ += n * sizeof(float);
     return p;
 }
+void Device::graph_begin() { check(nk_graph_begin(h_)); }
+std::shared_ptr<Graph> Device::graph_end() {
+    nk_graph* g = nullptr;
+    check(nk_graph_end(h_, &g));
+    return std::make_shared<Graph>(g);
+}
+Graph::~Graph() { (void)nk_graph_destroy(g_); }
+void Graph::launch() const { check(nk_graph_launch(g_)); }
+
 float* Device::alloc_uninit(size_t n) {
     auto it = pool_.find(n);
     float* p = nullptr;

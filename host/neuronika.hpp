@@ -66,6 +66,9 @@ class Device : public std::enable_shared_from_this<Device> {
     float* alloc_uninit(size_t n);  // contents undefined (a gradient whose zero fill is still pending)
     void release(float* p, size_t n);
     size_t bytes_in_use() const { return in_use_; }
+    // hipGraph capture of a launch-bound step (see nk_graph_begin in the C header for the rules)
+    void graph_begin();
+    std::shared_ptr<class Graph> graph_end();
 
    private:
     Device() = default;
@@ -75,6 +78,18 @@ class Device : public std::enable_shared_from_this<Device> {
     size_t in_use_ = 0;
 };
 using DevicePtr = std::shared_ptr<Device>;
+
+class Graph {  // a captured, replayable sequence of launches on one device
+   public:
+    explicit Graph(nk_graph* g) : g_(g) {}
+    ~Graph();
+    Graph(const Graph&) = delete;
+    Graph& operator=(const Graph&) = delete;
+    void launch() const;
+
+   private:
+    nk_graph* g_;
+};
 
 class HipArray {
    public:

@@ -33,10 +33,13 @@ PYBIND11_MODULE(_tape, m) {
     m.doc() = "C++ mirror of neuronika's Var/VarDiff tape on the HIP backend";
     py::register_exception<Panic>(m, "Panic", PyExc_RuntimeError);
 
+    py::class_<Graph, std::shared_ptr<Graph>>(m, "Graph").def("launch", &Graph::launch);
     py::class_<Device, std::shared_ptr<Device>>(m, "Device")
         .def(py::init(&Device::create), py::arg("idx") = 0)
         .def("sync", &Device::sync)
         .def("bytes_in_use", &Device::bytes_in_use)
+        .def("graph_begin", &Device::graph_begin)
+        .def("graph_end", &Device::graph_end)
         .def_property_readonly("index", &Device::index)
         .def("raw", [](const Device& d) { return (uintptr_t)d.raw(); });
 

@@ -101,6 +101,19 @@ int nk_event_sync(nk_event* ev);
 int nk_event_elapsed_ms(nk_event* start, nk_event* stop, float* ms);
 int nk_stream_wait_event(nk_device* dev, int on_comm_stream, nk_event* ev);
 
+/* ------------------------------------------------------------------ graph capture ------ */
+/* Small graphs (the reference's quickstart MLP: 64x3 inputs) are launch-bound: tens of kernels of a few
+ * microseconds each.  Everything a tape step enqueues on the compute stream between nk_graph_begin and nk_graph_end
+ * is recorded into a hipGraph instead of executed; nk_graph_launch replays it with one submission.  The captured
+ * region must not synchronise with the host (no nk_download / nk_device_sync / item()) nor grow an allocation, and
+ * it replays the SAME launches: scalars baked into kernel arguments (learning rate, the dropout Philox offset) stay
+ * what they were at capture time - capture steady-state steps of dropout-free graphs. */
+typedef struct nk_graph nk_graph;
+int nk_graph_begin(nk_device* dev);
+int nk_graph_end(nk_device* dev, nk_graph** out);
+int nk_graph_launch(nk_graph* graph);
+int nk_graph_destroy(nk_graph* graph);
+
 /* ------------------------------------------------------------------ kernel timing ------ */
 /* Bench instrumentation: between nk_profile_begin and nk_profile_end every launch of the
  * MFMA kernels is bracketed by a HIP event pair on the compute stream.  nk_profile_end

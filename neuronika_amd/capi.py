@@ -55,6 +55,10 @@ _SIGS = {
     "nk_alloc_zeroed": [VP, C.c_size_t, C.POINTER(VP)],
     "nk_free": [VP, VP],
     "nk_upload": [VP, VP, VP, C.c_size_t],
+    "nk_graph_begin": [VP],
+    "nk_graph_end": [VP, C.POINTER(C.c_void_p)],
+    "nk_graph_launch": [VP],
+    "nk_graph_destroy": [VP],
     "nk_host_alloc": [C.c_size_t, C.POINTER(C.c_void_p)],
     "nk_host_free": [VP],
     "nk_upload_async": [VP, VP, VP, C.c_size_t],

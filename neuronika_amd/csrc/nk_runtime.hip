@@ -177,6 +177,53 @@ int nk_upload(nk_device* dev, float* dst, const float* host_src, size_t n) {
     return NK_OK;
 }
 
+// ---- hipGraph capture of a launch-bound step -------------------------------------------------------
+struct nk_graph {
+    int idx;
+    hipStream_t stream;
+    hipGraph_t graph;
+    hipGraphExec_t exec;
+};
+
+int nk_graph_begin(nk_device* dev) {
+    NK_USE(dev);
+    NK_HIP(hipStreamBeginCapture(dev->compute, hipStreamCaptureModeRelaxed));
+    return NK_OK;
+}
+
+int nk_graph_end(nk_device* dev, nk_graph** out) {
+    NK_USE(dev);
+    NK_CHECK(out != nullptr, "null out pointer");
+    *out = nullptr;
+    hipGraph_t g = nullptr;
+    NK_HIP(hipStreamEndCapture(dev->compute, &g));
+    NK_CHECK(g != nullptr, "stream capture produced no graph (a synchronising call inside the captured region?)");
+    hipGraphExec_t exec = nullptr;
+    hipError_t e = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
+    if (e != hipSuccess) {
+        (void)hipGraphDestroy(g);
+        return nk_fail_hip(e, "hipGraphInstantiate", __FILE__, __LINE__);
+    }
+    *out = new nk_graph{dev->idx, dev->compute, g, exec};
+    return NK_OK;
+}
+
+int nk_graph_launch(nk_graph* g) {
+    NK_CHECK(g != nullptr, "null graph");
+    NK_HIP(hipSetDevice(g->idx));
+    NK_HIP(hipGraphLaunch(g->exec, g->stream));
+    return NK_OK;
+}
+
+int nk_graph_destroy(nk_graph* g) {
+    if (!g) return NK_OK;
+    (void)hipSetDevice(g->idx);
+    (void)hipGraphExecDestroy(g->exec);
+    (void)hipGraphDestroy(g->graph);
+    delete g;
+    return NK_OK;
+}
+
 int nk_host_alloc(size_t bytes, void** out) {
     NK_CHECK(out != nullptr, "null out pointer");
     *out = nullptr;
