@@ -285,6 +285,8 @@ def run_mha(a, dist):
     cdev = capi.Device(handle=tdev.raw())
     B, S, d, H = 32, 1024, 1024, 16
     mha = t.nn.MultiheadAttention(tdev, d, H, 0.1, 1)
+    if "NK_MHA_STRIDED" in os.environ:               # A/B aid: heads addressed in place (1) or split/merge copies (0)
+        mha.strided_heads = os.environ["NK_MHA_STRIDED"] == "1"
     X = t.from_ndarray(tdev, np.random.default_rng(0).random((B * S, d), dtype=np.float32)).requires_grad()
     G = t.from_ndarray(tdev, np.random.default_rng(5).random((B * S, d), dtype=np.float32))
     loss = (mha.forward(X, B) * G).sum()

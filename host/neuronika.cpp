@@ -631,6 +631,74 @@ struct MseBwd : Backward {
     void targets(std::vector<const Gradient*>& out) const override { out.push_back(dx.get()); }
 };
 
+// Per-(batch, head) attention products on the (B*S, H*dh) projection layout: the B*H Chunk((S,dh)) tiles of the composed
+// module (SURVEY 8a note) are addressed as strided GEMM operands instead of being copied out and back.
+struct HeadsGeom {
+    int B, S, H, dh;
+    int d() const { return H * dh; }
+    long long so() const { return (long long)S * H * dh; }  // sample stride in the flat layout
+    long long po() const { return (long long)H * S * S; }   // sample stride of the (B*H, S, S) tensor
+    long long pi() const { return (long long)S * S; }
+};
+struct HeadsScoresFwd : Forward {  // C_bh(S,S) = Q_bh(S,dh) . K_bh(S,dh)^T
+    HeadsGeom hg;
+    Shared<HipArray> q, k, c;
+    void forward() const override {
+        check(nk_sgemm_batched(D(q), 0, 1, hg.S, hg.S, hg.dh, 1.f, q->ptr(), hg.d(), hg.so(), hg.dh, k->ptr(), hg.d(), hg.so(), hg.dh, 0.f,
+                               c->ptr(), hg.S, hg.po(), hg.pi(), hg.B, hg.H));
+    }
+};
+struct HeadsScoresBwd : Backward {
+    HeadsGeom hg;
+    Shared<HipArray> q, k;
+    Shared<Gradient> dq, dk, g;
+    void backward() const override {
+        const HipArray& G = g->borrow();
+        nk_device* dev = D(q);
+        float beta;
+        {   // dQ_bh += G_bh . K_bh      (every element of dQ belongs to exactly one head block: a first write may assign)
+            float* d = first_write(dq, beta);
+            check(nk_sgemm_batched(dev, 0, 0, hg.S, hg.dh, hg.S, 1.f, G.ptr(), hg.S, hg.po(), hg.pi(), k->ptr(), hg.d(), hg.so(), hg.dh, beta,
+                                   d, hg.d(), hg.so(), hg.dh, hg.B, hg.H));
+        }
+        {   // dK_bh += G_bh^T . Q_bh
+            float* d = first_write(dk, beta);
+            check(nk_sgemm_batched(dev, 1, 0, hg.S, hg.dh, hg.S, 1.f, G.ptr(), hg.S, hg.po(), hg.pi(), q->ptr(), hg.d(), hg.so(), hg.dh, beta,
+                                   d, hg.d(), hg.so(), hg.dh, hg.B, hg.H));
+        }
+    }
+    void targets(std::vector<const Gradient*>& out) const override { out.push_back(dq.get()); out.push_back(dk.get()); }
+};
+struct HeadsContextFwd : Forward {  // O_bh(S,dh) = P_bh(S,S) . V_bh(S,dh), written into the flat layout
+    HeadsGeom hg;
+    Shared<HipArray> p, v, o;
+    void forward() const override {
+        check(nk_sgemm_batched(D(p), 0, 0, hg.S, hg.dh, hg.S, 1.f, p->ptr(), hg.S, hg.po(), hg.pi(), v->ptr(), hg.d(), hg.so(), hg.dh, 0.f,
+                               o->ptr(), hg.d(), hg.so(), hg.dh, hg.B, hg.H));
+    }
+};
+struct HeadsContextBwd : Backward {
+    HeadsGeom hg;
+    Shared<HipArray> p, v;
+    Shared<Gradient> dp, dv, g;
+    void backward() const override {
+        const HipArray& G = g->borrow();  // dO, flat layout
+        nk_device* dev = D(p);
+        float beta;
+        {   // dP_bh += dO_bh . V_bh^T
+            float* d = first_write(dp, beta);
+            check(nk_sgemm_batched(dev, 0, 1, hg.S, hg.S, hg.dh, 1.f, G.ptr(), hg.d(), hg.so(), hg.dh, v->ptr(), hg.d(), hg.so(), hg.dh, beta,
+                                   d, hg.S, hg.po(), hg.pi(), hg.B, hg.H));
+        }
+        {   // dV_bh += P_bh^T . dO_bh
+            float* d = first_write(dv, beta);
+            check(nk_sgemm_batched(dev, 1, 0, hg.S, hg.dh, hg.S, 1.f, p->ptr(), hg.S, hg.po(), hg.pi(), G.ptr(), hg.d(), hg.so(), hg.dh, beta,
+                                   d, hg.d(), hg.so(), hg.dh, hg.B, hg.H));
+        }
+    }
+    void targets(std::vector<const Gradient*>& out) const override { out.push_back(dp.get()); out.push_back(dv.get()); }
+};
+
 // Scalar criteria: node/{absolute_error,bce,bce_with_logits,kldiv,nll}/mod.rs.  kind -1 = NLL.
 struct LossFwd : Forward {
     int kind;
@@ -1009,6 +1077,48 @@ Var Var::mm(const Var& rhs) const { return matmul_var(0, *this, rhs); }
 VarDiff Var::mm(const VarDiff& rhs) const { return matmul_diff(0, *this, nullptr, nullptr, rhs.var, rhs.grad, &rhs.history); }
 Var Var::mm_t(const Var& rhs) const { return matmul_var(1, *this, rhs); }
 VarDiff Var::mm_t(const VarDiff& rhs) const { return matmul_diff(1, *this, nullptr, nullptr, rhs.var, rhs.grad, &rhs.history); }
+static void check_heads(const Shape& flat, const Shape& cube, int B, int S, int H, int dh, bool with_cube) {
+    if (B <= 0 || S <= 0 || H <= 0 || dh <= 0) panic("heads: non-positive geometry");
+    if (flat != Shape{B * S, H * dh}) panic("heads: the projection operand must have shape (B*S, H*dh)");
+    if (with_cube && cube != Shape{B * H, S, S}) panic("heads: the probabilities must have shape (B*H, S, S)");
+}
+Var Var::heads_scores(const Var& keys, int B, int S, int H, int dh) const {
+    check_heads(shape(), {}, B, S, H, dh, false);
+    check_heads(keys.shape(), {}, B, S, H, dh, false);
+    History<ForwardEntry> h = history;
+    h.merge(keys.history);
+    auto op = std::make_shared<HeadsScoresFwd>();
+    op->hg = {B, S, H, dh}; op->q = data; op->k = keys.data; op->c = zeros_like(data, Shape{B * H, S, S});
+    auto y = op->c;
+    return Var::node(y, op, std::move(h));
+}
+Var Var::heads_context(const Var& values, int B, int S, int H, int dh) const {
+    check_heads(values.shape(), shape(), B, S, H, dh, true);
+    History<ForwardEntry> h = history;
+    h.merge(values.history);
+    auto op = std::make_shared<HeadsContextFwd>();
+    op->hg = {B, S, H, dh}; op->p = data; op->v = values.data; op->o = zeros_like(data, Shape{B * S, H * dh});
+    auto y = op->o;
+    return Var::node(y, op, std::move(h));
+}
+VarDiff VarDiff::heads_scores(const VarDiff& keys, int B, int S, int H, int dh) const {
+    Var out = var.heads_scores(keys.var, B, S, H, dh);
+    History<BackwardEntry> h = history;
+    h.merge(keys.history);
+    auto g = std::make_shared<Gradient>(out.device(), out.shape());
+    auto bw = std::make_shared<HeadsScoresBwd>();
+    bw->hg = {B, S, H, dh}; bw->q = var.data; bw->k = keys.var.data; bw->dq = grad; bw->dk = keys.grad; bw->g = g;
+    return VarDiff::node(std::move(out), g, entry(bw, g), std::move(h));
+}
+VarDiff VarDiff::heads_context(const VarDiff& values, int B, int S, int H, int dh) const {
+    Var out = var.heads_context(values.var, B, S, H, dh);
+    History<BackwardEntry> h = history;
+    h.merge(values.history);
+    auto g = std::make_shared<Gradient>(out.device(), out.shape());
+    auto bw = std::make_shared<HeadsContextBwd>();
+    bw->hg = {B, S, H, dh}; bw->p = var.data; bw->v = values.var.data; bw->dp = grad; bw->dv = values.grad; bw->g = g;
+    return VarDiff::node(std::move(out), g, entry(bw, g), std::move(h));
+}
 Var Var::bmm(const Var& rhs) const { return matmul_var(2, *this, rhs); }
 Var Var::bmm_t(const Var& rhs) const { return matmul_var(3, *this, rhs); }
 Var Var::attention_probs(float scale, double p, Shared<bool> status, bool store_probs) const {
@@ -1538,10 +1648,17 @@ MultiheadAttention::MultiheadAttention(DevicePtr dev, int d_model_, int heads_, 
 VarDiff MultiheadAttention::forward(const VarDiff& x, int batch) const {
     const int rows = x.shape()[0], S = rows / batch, dh = d_model / heads;
     if (rows % batch != 0 || x.shape()[1] != d_model) panic("MultiheadAttention: bad input shape");
+    const float scale = 1.f / std::sqrt((float)dh);
+    if (strided_heads && dh % 4 == 0) {  // attention GEMMs address the heads inside the projection layout: no copies
+        const VarDiff Qf = q.forward(x), Kf = k.forward(x), Vf = v.forward(x);
+        const VarDiff scores = Qf.heads_scores(Kf, batch, S, heads, dh);
+        const VarDiff P = (fused && S % 4 == 0 && S <= 2048) ? scores.attention_probs(scale, drop.p, drop.status)
+                                                             : drop.forward((scores * scale).softmax(2));
+        return o.forward(P.heads_context(Vf, batch, S, heads, dh));
+    }
     const VarDiff Q = q.forward(x).split_heads(batch, S, heads, dh);
     const VarDiff K = k.forward(x).split_heads(batch, S, heads, dh);
     const VarDiff V = v.forward(x).split_heads(batch, S, heads, dh);
-    const float scale = 1.f / std::sqrt((float)dh);
     const VarDiff P = (fused && S % 4 == 0 && S <= 2048)
                           ? Q.bmm_t(K).attention_probs(scale, drop.p, drop.status)
                           : drop.forward((Q.bmm_t(K) * scale).softmax(2));

@@ -299,6 +299,12 @@ class Var {
     // batched (b,h) matrix products over [B*H, S, *] tiles = B*H `mm` / `mm_t` nodes
     Var bmm(const Var& rhs) const;
     Var bmm_t(const Var& rhs) const;
+    // the same per-(batch, head) products taken DIRECTLY on the (B*S, H*dh) projection layout (strided GEMM operands:
+    // row stride H*dh, head offset h*dh) - no head split / merge copies:
+    //   heads_scores : self = Q (B*S, H*dh), keys K (B*S, H*dh)      -> (B*H, S, S)   Q_bh . K_bh^T
+    //   heads_context: self = P (B*H, S, S), values V (B*S, H*dh)    -> (B*S, H*dh)   P_bh . V_bh
+    Var heads_scores(const Var& keys, int B, int S, int H, int dh) const;
+    Var heads_context(const Var& values, int B, int S, int H, int dh) const;
     // dropout(softmax(self * scale, last axis), p): the Multiplication + Softmax + Dropout nodes of
     // the attention probabilities as ONE node (same values, one pass over the score tensor)
     // (store_probs = false: the backward pass recomputes the probabilities from the scores, bit-identically)
@@ -375,6 +381,8 @@ class VarDiff {
     VarDiff merge_heads(int B, int S, int H, int dh) const;
     VarDiff bmm(const VarDiff& rhs) const;
     VarDiff bmm_t(const VarDiff& rhs) const;
+    VarDiff heads_scores(const VarDiff& keys, int B, int S, int H, int dh) const;
+    VarDiff heads_context(const VarDiff& values, int B, int S, int H, int dh) const;
     VarDiff attention_probs(float scale, double p, Shared<bool> status, bool store_probs = false) const;
 };
 
@@ -508,6 +516,7 @@ struct MultiheadAttention {
     int d_model, heads;
     Dropout drop;
     bool fused = true;  // scale + softmax + dropout as one node (false: three reference nodes)
+    bool strided_heads = true;  // attention GEMMs read Q/K/V and write O in the projection layout (false: split/merge copies)
     MultiheadAttention(DevicePtr dev, int d_model, int heads, double p, uint64_t seed);
     VarDiff forward(const VarDiff& x, int batch) const;  // x: (batch*seq, d_model)
 };

@@ -301,6 +301,7 @@ PYBIND11_MODULE(_tape, m) {
         .def_readonly("o", &nn::MultiheadAttention::o)
         .def_readonly("drop", &nn::MultiheadAttention::drop)
         .def_readwrite("fused", &nn::MultiheadAttention::fused)
+        .def_readwrite("strided_heads", &nn::MultiheadAttention::strided_heads)
         .def("forward", &nn::MultiheadAttention::forward);
 
     py::module_ optim = m.def_submodule("optim");

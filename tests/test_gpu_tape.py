@@ -706,3 +706,24 @@ def test_hipgraph_training_step(nk, tdev):
     for p, w in zip(pg, want):
         assert np.array_equal(p.data(), w)
     assert np.isfinite(loss_g.item()) and loss_g.item() == loss_e.item()
+
+
+@pytest.mark.gpu
+def test_mha_strided_heads_equals_split_merge(nk, tdev):
+    """Attention GEMMs addressing the heads inside the (B*S, H*dh) projection layout (no split / merge copies) give
+    bit-identical outputs and gradients to the Chunk/cat formulation."""
+    B, S, d, H = 2, 64, 128, 4
+    x, g = rnd(0, (B * S, d), -1, 1), rnd(5, (B * S, d), -1, 1)
+    outs = []
+    for strided in (True, False):
+        mha = nk.nn.MultiheadAttention(tdev, d, H, 0.0, 11)
+        mha.strided_heads = strided
+        X = nk.from_ndarray(tdev, x).requires_grad()
+        y = mha.forward(X, B)
+        loss = (y * nk.from_ndarray(tdev, g)).sum()
+        n_nodes = loss.history_len()
+        loss.forward(); loss.backward(1.0)
+        outs.append([y.data(), X.grad()] + [getattr(getattr(mha, n), w).grad() for n in "qkvo" for w in ("weight", "bias")] + [n_nodes])
+    assert outs[0][-1] == outs[1][-1] - 4                      # 3 split + 1 merge nodes gone
+    for a, b in zip(outs[0][:-1], outs[1][:-1]):
+        assert np.array_equal(a, b)
