@@ -162,3 +162,41 @@ def test_random_graph(nk, tdev, seed):
     out.backward(1.0)
     for l, g in zip(leaves, g1):
         np.testing.assert_allclose(np.asarray(l.grad()), g, rtol=1e-6, atol=1e-6)
+
+
+def test_partial_coverage_and_fanout(nk, tdev):
+    """Nodes whose backward covers only part of a gradient (Chunk) or that feed one gradient from several nodes must
+    leave exact zeros / exact sums behind the lazily zeroed buffers."""
+    rng = np.random.default_rng(7)
+    x = rng.uniform(-1, 1, (6, 8)).astype(np.float32)
+    X = nk.from_ndarray(tdev, x).requires_grad()
+    parts = X.chunks([3, 4])                                  # 4 tiles; only tiles 1 and 2 are used
+    y = (parts[1] * 2.0).sum() + (parts[2].t().t() * 3.0).sum()
+    y.forward(); y.backward(1.0)
+    want = np.zeros_like(x); want[0:3, 4:8] = 2.0; want[3:6, 0:4] = 3.0
+    assert np.array_equal(X.grad(), want)
+    # one leaf feeding: a padded conv input, a stack, a cat, a transpose and a plain product
+    w = rng.uniform(-1, 1, (2, 1, 3, 3)).astype(np.float32)
+    img = rng.uniform(-1, 1, (2, 1, 6, 8)).astype(np.float32)
+    I, W = nk.from_ndarray(tdev, img).requires_grad(), nk.from_ndarray(tdev, w).requires_grad()
+    conv = W.convolution(I.pad([1, 1], 0.0), [1, 1], [1, 1], 1).sum()
+    stk = I.stack([I], 0).sum() * 0.5
+    cat = I.cat([I * 2.0], 1).sum() * 0.25
+    tot = conv + stk + cat + (I * I).sum()
+    tot.forward(); tot.backward(1.0)
+    i64, w64 = img.astype(np.float64), w.astype(np.float64)
+    g = np.zeros_like(i64)
+    pad = np.pad(i64, ((0, 0), (0, 0), (1, 1), (1, 1)))
+    gp = np.zeros_like(pad)
+    for co in range(2):
+        for a in range(3):
+            for b in range(3):
+                gp[:, 0, a:a + 6, b:b + 8] += w64[co, 0, a, b]
+    g += gp[:, :, 1:-1, 1:-1]
+    g += 0.5 * 2 + 0.25 * (1 + 2) + 2 * i64
+    np.testing.assert_allclose(I.grad(), g, rtol=1e-5, atol=1e-5)
+    gw = np.zeros_like(w64)
+    for a in range(3):
+        for b in range(3):
+            gw[:, 0, a, b] = pad[:, 0, a:a + 6, b:b + 8].sum()
+    np.testing.assert_allclose(W.grad(), gw, rtol=1e-5, atol=1e-4)
