@@ -194,7 +194,7 @@ def run_mlp(a, dist):
             "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"C4: 3-layer MLP Linear({H},{H})x3 + ReLU, MSE mean, batch {B}/GPU, data-parallel "
-                                   f"gradient all-reduce (RCCL, side stream)", "global_batch": B * world, "hidden": H,
+                                   f"gradient all-reduce (RCCL, side stream)", "global_batch": B * world,
                        "parallelism": f"dp{world}", "optimizer_step_in_timed_region": not a.no_optimizer,
                        "allreduce_bytes_per_step": 0 if world == 1 else 3 * (H * H + H) * 4},
             "roofline": {"bound": "mfma", "kernel": "sgemm_kernel (f32 MFMA 32x32x2, 128x128x32 tiles)",
