@@ -685,54 +685,56 @@ __global__ __launch_bounds__(NT, 2) void conv_bwd_input_fast_kernel(FastBwdInArg
     const int grp = blockIdx.z;
     const int m0 = tm * BM, n0 = tn * BN;
     const int K = g.Mg * g.KK, nt = K / BK;
-    const long long cols = (long long)g.N * g.inplane;
+    // Columns are (n, a, b, c') with the innermost input row padded to W4 = a multiple of 4, so that the quad a thread
+    // stages never straddles two rows: for every tap its four gradient elements are then contiguous in memory and ONE
+    // 16-byte load per staged row serves interior and border quads alike (start clamped into the row, elements picked
+    // by a shift, outside ones masked) - no divergent scalar path.  Cost: W4/in[2] - 1 dummy columns (3.4 % at C3).
+    const int W4 = (g.in[2] + 3) & ~3, rows_per_n = g.in[0] * g.in[1];
+    const int cols = g.N * rows_per_n * W4;  // < 2^31 (checked by the host)
     const float* Wq = p.wq + (long long)grp * g.Cg * K;
     const float* G = p.gy + (long long)grp * g.Mg * g.L;
 
     const int cq = t & 31, krow = t >> 5;
-    int gb[4], pa[4], pb[4], pc[4];
-    bool cv[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const long long cc = (long long)n0 + cq * 4 + i;
-        cv[i] = cc < cols;
-        const int n = cv[i] ? (int)(cc / g.inplane) : 0;
-        int q = cv[i] ? (int)(cc % g.inplane) : 0;
-        pc[i] = q % g.in[2]; q /= g.in[2];
-        pb[i] = q % g.in[1];
-        pa[i] = q / g.in[1];
-        gb[i] = n * g.Cout * g.L + krow * g.L;
+    const int cc0 = n0 + cq * 4;
+    const bool valid = cc0 < cols;
+    int qa = 0, qb = 0, qc = 0, gbase = 0;
+    if (valid) {
+        const int rowid = cc0 / W4;
+        qc = cc0 - rowid * W4;
+        const int n = rowid / rows_per_n, ab = rowid - n * rows_per_n;
+        qa = ab / g.in[1];
+        qb = ab - qa * g.in[1];
+        gbase = n * g.Cout * g.L + krow * g.L;
     }
-    const bool rowquad = cv[3] && gb[3] == gb[0] && pa[3] == pa[0] && pb[3] == pb[0] && pc[3] == pc[0] + 3;
     const int jstep = 8 * g.L;
+    auto pick = [](const f32x4u& q, int idx) { return idx == 0 ? q.x : (idx == 1 ? q.y : (idx == 2 ? q.z : q.w)); };
     auto gather = [&](int kt) {
         const int chunk = kt / g.KK, tap = kt - chunk * g.KK, co0 = chunk * BK;  // taps inside a 32-channel chunk
         const int4 d = p.tapd[tap];
         const float* src = G + co0 * g.L;
-        // output position each column reads for this tap (-1: outside -> contributes 0)
-        int pos[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int a = pa[i] - d.x, b = pb[i] - d.y, c = pc[i] - d.z;
-            const bool ok = cv[i] && a >= 0 && a < g.out[0] && b >= 0 && b < g.out[1] && c >= 0 && c < g.out[2];
-            pos[i] = ok ? gb[i] + (a * g.out[1] + b) * g.out[2] + c : -1;
-        }
+        const int a = qa - d.x, b = qb - d.y, c = qc - d.z;  // output coordinates of the quad's first element
+        const bool row_ok = valid && a >= 0 && a < g.out[0] && b >= 0 && b < g.out[1];
+        const int ac = min(max(a, 0), g.out[0] - 1), bc = min(max(b, 0), g.out[1] - 1);
+        const int cs = min(max(c, 0), g.out[2] - 4), sh = c - cs;  // load start clamped into the row, shift of element 0
+        const float* ptr = src + (gbase + (ac * g.out[1] + bc) * g.out[2] + cs);
+        const f32x4u q0 = *reinterpret_cast<const f32x4u*>(ptr);
+        const f32x4u q1 = *reinterpret_cast<const f32x4u*>(ptr + jstep);
+        const f32x4u q2 = *reinterpret_cast<const f32x4u*>(ptr + 2 * jstep);
+        const f32x4u q3 = *reinterpret_cast<const f32x4u*>(ptr + 3 * jstep);
         Stage<4> r;
-        if (rowquad && pos[0] >= 0 && pos[3] >= 0) {  // whole quad inside: one 16-B load per row
-            const f32x4u q0 = *reinterpret_cast<const f32x4u*>(src + pos[0]);
-            const f32x4u q1 = *reinterpret_cast<const f32x4u*>(src + pos[0] + jstep);
-            const f32x4u q2 = *reinterpret_cast<const f32x4u*>(src + pos[0] + 2 * jstep);
-            const f32x4u q3 = *reinterpret_cast<const f32x4u*>(src + pos[0] + 3 * jstep);
-            r.v0 = make_float4(q0.x, q0.y, q0.z, q0.w);
-            r.v1 = make_float4(q1.x, q1.y, q1.z, q1.w);
-            r.v2 = make_float4(q2.x, q2.y, q2.z, q2.w);
-            r.v3 = make_float4(q3.x, q3.y, q3.z, q3.w);
+        if (sh == 0) {  // interior quad (the common case): the loaded vector is the quad
+            r.v0 = row_ok ? make_float4(q0.x, q0.y, q0.z, q0.w) : make_float4(0.f, 0.f, 0.f, 0.f);
+            r.v1 = row_ok ? make_float4(q1.x, q1.y, q1.z, q1.w) : make_float4(0.f, 0.f, 0.f, 0.f);
+            r.v2 = row_ok ? make_float4(q2.x, q2.y, q2.z, q2.w) : make_float4(0.f, 0.f, 0.f, 0.f);
+            r.v3 = row_ok ? make_float4(q3.x, q3.y, q3.z, q3.w) : make_float4(0.f, 0.f, 0.f, 0.f);
         } else {
-#define NK_ROWS(j, V)                                                                              \
-    V = make_float4(pos[0] >= 0 ? src[pos[0] + j * jstep] : 0.f, pos[1] >= 0 ? src[pos[1] + j * jstep] : 0.f, \
-                    pos[2] >= 0 ? src[pos[2] + j * jstep] : 0.f, pos[3] >= 0 ? src[pos[3] + j * jstep] : 0.f);
-            NK_ROWS(0, r.v0) NK_ROWS(1, r.v1) NK_ROWS(2, r.v2) NK_ROWS(3, r.v3)
-#undef NK_ROWS
+            bool in[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) in[i] = row_ok && c + i >= 0 && c + i < g.out[2];
+#define NK_SEL(Q) make_float4(in[0] ? pick(Q, sh) : 0.f, in[1] ? pick(Q, 1 + sh) : 0.f, in[2] ? pick(Q, 2 + sh) : 0.f, \
+                              in[3] ? pick(Q, 3 + sh) : 0.f)
+            r.v0 = NK_SEL(q0); r.v1 = NK_SEL(q1); r.v2 = NK_SEL(q2); r.v3 = NK_SEL(q3);
+#undef NK_SEL
         }
         return r;
     };
@@ -768,10 +770,12 @@ __global__ __launch_bounds__(NT, 2) void conv_bwd_input_fast_kernel(FastBwdInArg
     const int Cg = g.Cg, Cin = g.Cin, inplane = g.inplane;
     acc_foreach_cols<TI, TJ>(acc, wr, wc, lane,
         [&](int c) -> long long {
-            const long long cc = (long long)n0 + c;
+            const int cc = n0 + c;
             if (cc >= cols) return -1;
-            const long long n = cc / inplane;
-            return (n * Cin + grp * Cg) * inplane + (cc - n * inplane);
+            const int rowid = cc / W4, cpos = cc - rowid * W4;
+            if (cpos >= g.in[2]) return -1;  // padding column of the row
+            const int n = rowid / rows_per_n;
+            return ((long long)n * Cin + grp * Cg) * inplane + (long long)(rowid - n * rows_per_n) * g.in[2] + cpos;
         },
         [&](int r, long long base, float v) {
             const int ci = m0 + r;
@@ -918,7 +922,9 @@ int conv_bwd_input(nk_device* dev, int nd, float* dx, const int* x_shape, const 
     {
         const long long x_elems = (long long)g.N * g.Cin * g.inplane, y_elems = (long long)g.N * g.Cout * g.L;
         const bool unit_all = g.stride[0] == 1 && g.stride[1] == 1 && g.stride[2] == 1;
-        if (unit_all && g.Mg % BK == 0 && x_elems < 0x7fffffffLL && y_elems < 0x7fffffffLL) {
+        const int W4 = (g.in[2] + 3) & ~3;
+        const long long fcols = (long long)g.N * g.in[0] * g.in[1] * W4;  // row-padded column space of the fast kernel
+        if (unit_all && g.Mg % BK == 0 && g.out[2] >= 4 && x_elems < 0x7fffffffLL && y_elems < 0x7fffffffLL && fcols < 0x7fffff00LL) {
             const size_t wq_bytes = round256((size_t)g.Cout * g.Cg * g.KK * sizeof(float));
             const size_t to_bytes = round256((size_t)g.KK * sizeof(int));
             void* wsf = nullptr;
@@ -935,7 +941,7 @@ int conv_bwd_input(nk_device* dev, int nd, float* dx, const int* x_shape, const 
             fp.g = g; fp.dx = dx; fp.gy = gy; fp.wq = wq; fp.tapd = tapd;
             const int fti = g.Cg <= 64 || (g.Cg % 128 != 0 && g.Cg % 64 == 0) ? 1 : 2;
             fp.tiles_m = (g.Cg + 64 * fti - 1) / (64 * fti);
-            fp.tiles_n = (int)(((long long)g.N * g.inplane + 127) / 128);
+            fp.tiles_n = (int)((fcols + 127) / 128);
             const bool al = g.Cg % (64 * fti) == 0;
             dim3 fgrid(fp.tiles_m * fp.tiles_n, 1, groups);
             rc = nk_prof_start(dev, NK_KERNEL_CONV, 2.0 * g.N * (double)g.Cout * g.L * g.Cg * g.KK);

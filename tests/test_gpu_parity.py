@@ -89,6 +89,10 @@ CONV_RANDOM = [
     ((2, 32, 40), (32, 32, 5), (1,), (1,), 1),                    # 1-d fast
     ((1, 32, 4, 6, 10), (32, 32, 2, 3, 3), (1, 1, 1), (1, 1, 1), 1),  # 3-d fast
     ((5, 32, 9, 9), (32, 32, 2, 2), (1, 1), (1, 1), 1),           # columns not a multiple of 128 / quads at the tail
+    ((2, 32, 7, 13), (32, 32, 3, 5), (1, 1), (1, 1), 1),          # row length 13 (padded to 16), taps shifted by up to 4
+    ((3, 32, 6, 11), (64, 32, 2, 3), (1, 1), (1, 3), 1),          # dilation 3 on the innermost axis, width 11
+    ((2, 32, 5, 6, 7), (32, 32, 2, 2, 3), (1, 1, 1), (1, 2, 1), 1),   # 3-d, width 7
+    ((2, 32, 23), (32, 32, 4), (1,), (2,), 1),                    # 1-d, width 23, dilation 2
 ]
 
 
