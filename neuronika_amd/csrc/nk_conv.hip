@@ -461,11 +461,26 @@ __global__ __launch_bounds__(NT, 2) void conv_bwd_kernel_kernel(BwdKArgs p) {
     });
 }
 
-// dW[i] += sum_s slabs[s][i]  (fixed order -> deterministic)
+// dW[i] += sum_s slabs[s][i].  64 elements x 4 split-lanes per block (lane j sums splits j, j+4, ... with two independent
+// accumulators), folded through LDS in a fixed order: `splits/4` loads deep instead of `splits` (the serial form took 28 us
+// for 30 MB at C3).  Deterministic.
 __global__ void conv_dw_reduce_kernel(float* __restrict__ dw, const float* __restrict__ slabs, long long n, int splits, int assign) {
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        float s = 0.f;
-        for (int k = 0; k < splits; ++k) s += slabs[(long long)k * n + i];
+    __shared__ float red[4][64];
+    const int col = threadIdx.x & 63, lane = threadIdx.x >> 6;
+    const long long i = (long long)blockIdx.x * 64 + col;
+    float s0 = 0.f, s1 = 0.f;
+    if (i < n) {
+        int k = lane;
+        for (; k + 4 < splits; k += 8) {
+            s0 += slabs[(long long)k * n + i];
+            s1 += slabs[(long long)(k + 4) * n + i];
+        }
+        if (k < splits) s0 += slabs[(long long)k * n + i];
+    }
+    red[lane][col] = s0 + s1;
+    __syncthreads();
+    if (lane == 0 && i < n) {
+        const float s = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
         dw[i] = assign ? s : dw[i] + s;
     }
 }
@@ -1060,7 +1075,7 @@ int conv_bwd_kernel(nk_device* dev, int nd, float* dw, const int* w_shape, const
     }
 #undef NK_LAUNCH_BWK
     NK_LAUNCH_CHECK();
-    hipLaunchKernelGGL(conv_dw_reduce_kernel, dim3(nk_stream_grid((size_t)dw_elems, 256)), dim3(256), 0, dev->compute, dw,
+    hipLaunchKernelGGL(conv_dw_reduce_kernel, dim3((unsigned)((dw_elems + 63) / 64)), dim3(256), 0, dev->compute, dw,
                        p.slabs, dw_elems, (int)splits, assign);
     NK_LAUNCH_CHECK();
     return nk_prof_stop(dev);
