@@ -381,6 +381,7 @@ struct ConvBwd : Backward {  // ConvolutionBackward{Input,Kernel}  :357-510
     Shared<HipArray> x, w;
     Shared<Gradient> dx, dw, db, g;  // dx may be null (input is a non-differentiable Var); db only for the fused module node
     std::vector<int> stride, dilation;
+    std::vector<int> padding;  // fused module node with Zero padding: x is the padded input, dx the UNPADDED input's gradient
     int groups;
     void backward() const override {
         const HipArray& G = g->borrow();
@@ -388,8 +389,13 @@ struct ConvBwd : Backward {  // ConvolutionBackward{Input,Kernel}  :357-510
         bool assign = false;
         if (dx) {
             HipArray& d = dx->borrow_first_write(assign);
-            check((assign ? nk_conv_bwd_input_assign : nk_conv_bwd_input)(D(x), nd, d.ptr(), x->shape().data(), G.ptr(), w->ptr(),
-                                                                          w->shape().data(), stride.data(), dilation.data(), groups));
+            if (!padding.empty())  // ConvolutionBackwardInput + PadBackward in one kernel
+                check((assign ? nk_conv_bwd_input_padded_assign : nk_conv_bwd_input_padded)(
+                    D(x), nd, d.ptr(), d.shape().data(), padding.data(), G.ptr(), w->ptr(), w->shape().data(), stride.data(),
+                    dilation.data(), groups));
+            else
+                check((assign ? nk_conv_bwd_input_assign : nk_conv_bwd_input)(D(x), nd, d.ptr(), x->shape().data(), G.ptr(), w->ptr(),
+                                                                              w->shape().data(), stride.data(), dilation.data(), groups));
         }
         if (dw) {
             HipArray& d = dw->borrow_first_write(assign);
@@ -1338,7 +1344,8 @@ VarDiff VarDiff::attention_probs(float scale, double p, Shared<bool> status, boo
 }
 static VarDiff conv_diff(const VarDiff& kernel, const Var& input, const Shared<Gradient>& dx,
                          const History<BackwardEntry>* hx, const std::vector<int>& stride,
-                         const std::vector<int>& dilation, int groups, const VarDiff* bias = nullptr) {
+                         const std::vector<int>& dilation, int groups, const VarDiff* bias = nullptr,
+                         const std::vector<int>* crop = nullptr) {
     Var out = kernel.var.convolution(input, stride, dilation, groups);
     History<BackwardEntry> h = kernel.history;
     if (hx) h.merge(*hx);
@@ -1355,6 +1362,7 @@ static VarDiff conv_diff(const VarDiff& kernel, const Var& input, const Shared<G
     auto bw = std::make_shared<ConvBwd>();
     bw->x = input.data; bw->w = kernel.var.data; bw->dx = dx; bw->dw = kernel.grad; bw->g = g;
     if (bias) bw->db = bias->grad;
+    if (crop) bw->padding = *crop;  // `input` is the zero-padded copy of the Var whose gradient is dx
     bw->stride = stride; bw->dilation = dilation; bw->groups = groups;
     return VarDiff::node(std::move(out), g, entry(bw, g), std::move(h));
 }
@@ -1635,6 +1643,14 @@ VarDiff ConvNd::forward(const Var& input) const {
     return conv_diff(weight, padded, nullptr, nullptr, stride, dilation, groups, &bias);
 }
 VarDiff ConvNd::forward(const VarDiff& input) const {
+    bool any_pad = false;
+    for (int p : padding) any_pad = any_pad || p != 0;
+    if (fused && any_pad && (padding_mode.kind == PaddingMode::Zero || (padding_mode.kind == PaddingMode::Constant && padding_mode.value == 0.f))) {
+        // pad -> convolution -> + bias with the Pad node's backward folded into the convolution's: the padded copy is a
+        // forward-only node, the convolution's input gradient lands in input.grad directly (no padded gradient buffer)
+        const Var padded = input.var.pad(padding, padding_mode);
+        return conv_diff(weight, padded, input.grad, &input.history, stride, dilation, groups, &bias, &padding);
+    }
     const VarDiff padded = input.pad(padding, padding_mode);
     if (!fused) return weight.convolution(padded, stride, dilation, groups) + bias;
     return conv_diff(weight, padded.var, padded.grad, &padded.history, stride, dilation, groups, &bias);

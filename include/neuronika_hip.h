@@ -182,6 +182,19 @@ int nk_conv_bwd_kernel(nk_device* dev, int nd, float* dw, const int* w_shape, co
 int nk_conv_bias_fwd(nk_device* dev, int nd, const float* x, const int* x_shape, const float* w,
                      const int* w_shape, const float* bias, float* y, const int* stride,
                      const int* dilation, int groups);
+/* `Conv{1,2,3}d` module backward towards its input when the module's padding mode is Zero (lib.rs:630-916: pad ->
+ * convolution): ConvolutionBackwardInput (convolution/mod.rs:146-189) followed by PadBackward (pad/mod.rs:131-181, the
+ * centre block of the padded gradient is accumulated into dx) as ONE kernel.  x_shape is the UNPADDED input
+ * [N, Cin, in...], `padding[i]` the symmetric zero padding of spatial axis i the forward convolution saw; only the
+ * columns dx needs are computed and the padded gradient is never stored.  Same values as the two-node form.  `_assign`:
+ * see the first-write variants below. */
+int nk_conv_bwd_input_padded(nk_device* dev, int nd, float* dx, const int* x_shape, const int* padding,
+                             const float* g, const float* w, const int* w_shape, const int* stride,
+                             const int* dilation, int groups);
+int nk_conv_bwd_input_padded_assign(nk_device* dev, int nd, float* dx, const int* x_shape,
+                                    const int* padding, const float* g, const float* w,
+                                    const int* w_shape, const int* stride, const int* dilation,
+                                    int groups);
 /* Pad<Constant|Zero>::forward  node/pad/mod.rs:97-129 + pad/constant/mod.rs:14-39;
  * symmetric `padding[i]` on both sides of spatial axis i.  x_shape = [N, C, in...]. */
 int nk_pad_const_fwd(nk_device* dev, int nd, const float* x, const int* x_shape, float* y,

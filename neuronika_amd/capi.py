@@ -89,6 +89,8 @@ _SIGS = {
     "nk_conv_bwd_input_assign": [VP, C.c_int, VP, c_intp, VP, VP, c_intp, c_intp, c_intp, C.c_int],
     "nk_conv_bwd_kernel_assign": [VP, C.c_int, VP, c_intp, VP, VP, c_intp, c_intp, c_intp, C.c_int],
     "nk_conv_bwd_input": [VP, C.c_int, VP, c_intp, VP, VP, c_intp, c_intp, c_intp, C.c_int],
+    "nk_conv_bwd_input_padded": [VP, C.c_int, VP, c_intp, c_intp, VP, VP, c_intp, c_intp, c_intp, C.c_int],
+    "nk_conv_bwd_input_padded_assign": [VP, C.c_int, VP, c_intp, c_intp, VP, VP, c_intp, c_intp, c_intp, C.c_int],
     "nk_conv_bwd_kernel": [VP, C.c_int, VP, c_intp, VP, VP, c_intp, c_intp, c_intp, C.c_int],
     "nk_pad_const_fwd": [VP, C.c_int, VP, c_intp, VP, c_intp, C.c_float],
     "nk_pad_reflective_fwd": [VP, C.c_int, VP, c_intp, VP, c_intp],
@@ -374,8 +376,13 @@ def conv_fwd(dev, x, w, y, stride, dilation, groups=1, bias=None):
         check(lib.nk_conv_fwd(dev.h, nd, x.p, x.shape_c(), w.p, w.shape_c(), y.p, ints(stride), ints(dilation), groups))
 
 
-def conv_bwd_input(dev, dx, g, w, stride, dilation, groups=1, assign=False):
+def conv_bwd_input(dev, dx, g, w, stride, dilation, groups=1, assign=False, padding=None):
+    """`padding`: dx is the gradient of the UNPADDED input of a zero Pad node that fed the convolution."""
     nd = dx.ndim - 2
+    if padding is not None:
+        fn = lib.nk_conv_bwd_input_padded_assign if assign else lib.nk_conv_bwd_input_padded
+        check(fn(dev.h, nd, dx.p, dx.shape_c(), ints(padding), g.p, w.p, w.shape_c(), ints(stride), ints(dilation), groups))
+        return
     check((lib.nk_conv_bwd_input_assign if assign else lib.nk_conv_bwd_input)(dev.h, nd, dx.p, dx.shape_c(), g.p, w.p, w.shape_c(), ints(stride), ints(dilation), groups))
 
 

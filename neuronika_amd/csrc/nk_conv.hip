@@ -24,6 +24,9 @@ struct ConvGeom {
     int inplane, L, KK;                           // prod(in), prod(out), prod(k)
     const float* bias;                            // forward: optional per-output-channel bias added in the epilogue
     int assign;                                   // backward: write instead of `+=` (destination's zero fill pending)
+    // backward-input through a zero Pad node: dX has the UNPADDED extents `uin` and input coordinate q of dX is
+    // coordinate q + pad of the (virtual) padded input `in`.  pad = 0, uin = in otherwise.
+    int uin[3], pad[3], uinplane;
 };
 
 // ---- tables (tiny pre-kernels into the device workspace) ---------------------------------------
@@ -210,7 +213,7 @@ __global__ __launch_bounds__(NT, 2) void conv_bwd_input_kernel(BwdInArgs p) {
     const int grp = blockIdx.z;
     const int m0 = tm * BM, n0 = tn * BN;
     const int K = g.Mg * g.KK;
-    const long long cols = (long long)g.N * g.inplane;
+    const long long cols = (long long)g.N * g.uinplane;
     const float* Wt = p.wt + (long long)grp * g.Cg * K;
     const float* G = p.gy + (long long)grp * g.Mg * g.L;
     const int nt = (K + BK - 1) / BK;
@@ -226,11 +229,11 @@ __global__ __launch_bounds__(NT, 2) void conv_bwd_input_kernel(BwdInArgs p) {
     {                                                                                   \
         const long long cc = c + i;                                                     \
         V = cc < cols;                                                                  \
-        const int n = V ? (int)(cc / g.inplane) : 0;                                    \
-        int q = V ? (int)(cc % g.inplane) : 0;                                          \
-        PC = q % g.in[2]; q /= g.in[2];                                                 \
-        PB = q % g.in[1];                                                               \
-        PA = q / g.in[1];                                                               \
+        const int n = V ? (int)(cc / g.uinplane) : 0;                                   \
+        int q = V ? (int)(cc % g.uinplane) : 0;                                         \
+        PC = q % g.uin[2] + g.pad[2]; q /= g.uin[2];                                    \
+        PB = q % g.uin[1] + g.pad[1];                                                   \
+        PA = q / g.uin[1] + g.pad[0];                                                   \
         GB = (long long)n * g.Cout * g.L;                                               \
     }
         NK_COL(0, gb0, pa0, pb0, pc0, v0) NK_COL(1, gb1, pa1, pb1, pc1, v1)
@@ -299,7 +302,7 @@ __global__ __launch_bounds__(NT, 2) void conv_bwd_input_kernel(BwdInArgs p) {
     // dX[n][grp*Cg + ci][pos] += acc
     float* DX = p.dx;
     const int assign = g.assign;
-    const int Cg = g.Cg, Cin = g.Cin, inplane = g.inplane;
+    const int Cg = g.Cg, Cin = g.Cin, inplane = g.uinplane;
     acc_foreach_cols<TI, TJ>(acc, wr, wc, lane,
         [&](int c) -> long long {
             const long long cc = (long long)n0 + c;
@@ -704,7 +707,7 @@ __global__ __launch_bounds__(NT, 2) void conv_bwd_input_fast_kernel(FastBwdInArg
     // stages never straddles two rows: for every tap its four gradient elements are then contiguous in memory and ONE
     // 16-byte load per staged row serves interior and border quads alike (start clamped into the row, elements picked
     // by a shift, outside ones masked) - no divergent scalar path.  Cost: W4/in[2] - 1 dummy columns (3.4 % at C3).
-    const int W4 = (g.in[2] + 3) & ~3, rows_per_n = g.in[0] * g.in[1];
+    const int W4 = (g.uin[2] + 3) & ~3, rows_per_n = g.uin[0] * g.uin[1];
     const int cols = g.N * rows_per_n * W4;  // < 2^31 (checked by the host)
     const float* Wq = p.wq + (long long)grp * g.Cg * K;
     const float* G = p.gy + (long long)grp * g.Mg * g.L;
@@ -715,10 +718,11 @@ __global__ __launch_bounds__(NT, 2) void conv_bwd_input_fast_kernel(FastBwdInArg
     int qa = 0, qb = 0, qc = 0, gbase = 0;
     if (valid) {
         const int rowid = cc0 / W4;
-        qc = cc0 - rowid * W4;
+        qc = cc0 - rowid * W4 + g.pad[2];
         const int n = rowid / rows_per_n, ab = rowid - n * rows_per_n;
-        qa = ab / g.in[1];
-        qb = ab - qa * g.in[1];
+        qa = ab / g.uin[1];
+        qb = ab - qa * g.uin[1] + g.pad[1];
+        qa += g.pad[0];
         gbase = n * g.Cout * g.L + krow * g.L;
     }
     const int jstep = 8 * g.L;
@@ -782,15 +786,15 @@ __global__ __launch_bounds__(NT, 2) void conv_bwd_input_fast_kernel(FastBwdInArg
     }
     float* DX = p.dx;
     const int assign = g.assign;
-    const int Cg = g.Cg, Cin = g.Cin, inplane = g.inplane;
+    const int Cg = g.Cg, Cin = g.Cin, inplane = g.uinplane;
     acc_foreach_cols<TI, TJ>(acc, wr, wc, lane,
         [&](int c) -> long long {
             const int cc = n0 + c;
             if (cc >= cols) return -1;
             const int rowid = cc / W4, cpos = cc - rowid * W4;
-            if (cpos >= g.in[2]) return -1;  // padding column of the row
+            if (cpos >= g.uin[2]) return -1;  // padding column of the row
             const int n = rowid / rows_per_n;
-            return ((long long)n * Cin + grp * Cg) * inplane + (long long)(rowid - n * rows_per_n) * g.in[2] + cpos;
+            return ((long long)n * Cin + grp * Cg) * inplane + (long long)(rowid - n * rows_per_n) * g.uin[2] + cpos;
         },
         [&](int r, long long base, float v) {
             const int ci = m0 + r;
@@ -824,6 +828,8 @@ int make_geom(int nd, const int* x_shape, const int* w_shape, const int* stride,
     }
     NK_CHECK((long long)g.Cin * g.inplane < 0x7fffffffLL && (long long)g.Cout * g.L < 0x7fffffffLL,
              "one sample exceeds 2^31 elements");
+    for (int d = 0; d < 3; ++d) { g.uin[d] = g.in[d]; g.pad[d] = 0; }
+    g.uinplane = g.inplane;
     *out = g;
     return NK_OK;
 }
@@ -924,21 +930,42 @@ int conv_fwd(nk_device* dev, int nd, const float* x, const int* x_shape, const f
     return nk_prof_stop(dev);
 }
 
-int conv_bwd_input(nk_device* dev, int nd, float* dx, const int* x_shape, const float* gy, const float* w,
+// `padding` (may be null): x_shape is the input of a zero Pad node whose output the convolution read; dX gets the centre
+// block of the padded input's gradient (PadBackward folded into the gather, the padded gradient is never stored).
+int conv_bwd_input(nk_device* dev, int nd, float* dx, const int* x_shape, const int* padding, const float* gy, const float* w,
                    const int* w_shape, const int* stride, const int* dilation, int groups, int assign) {
     NK_USE(dev);
+    NK_CHECK(nd >= 1 && nd <= 3, "Invalid convolution dimension %d (1, 2 or 3 supported)", nd);
     ConvGeom g;
-    int rc = make_geom(nd, x_shape, w_shape, stride, dilation, groups, &g);
+    int pshape[5] = {x_shape[0], x_shape[1], 1, 1, 1};
+    for (int d = 0; d < nd; ++d) {
+        NK_CHECK(!padding || padding[d] >= 0, "negative padding on axis %d", d);
+        pshape[2 + d] = x_shape[2 + d] + (padding ? 2 * padding[d] : 0);
+    }
+    int rc = make_geom(nd, pshape, w_shape, stride, dilation, groups, &g);
     if (rc) return rc;
     g.assign = assign;
-    if ((long long)g.N * g.Cin * g.inplane == 0 || (long long)g.Cout * g.L == 0) return NK_OK;
+    if (padding) {
+        g.uinplane = 1;
+        for (int d = 0; d < nd; ++d) {
+            const int q = 3 - nd + d;
+            g.pad[q] = padding[d];
+            g.uin[q] = x_shape[2 + d];
+            g.uinplane *= g.uin[q];
+        }
+    }
+    if ((long long)g.N * g.Cin * g.uinplane == 0) return NK_OK;
+    if ((long long)g.Cout * g.L == 0) {  // no output positions: the gradient is zero
+        if (assign) NK_HIP(hipMemsetAsync(dx, 0, (size_t)g.N * g.Cin * g.uinplane * sizeof(float), dev->compute));
+        return NK_OK;
+    }
     NK_CHECK(dx && gy && w, "null pointer in nk_conv_bwd_input");
     const int K = g.Mg * g.KK;
     {
         const long long x_elems = (long long)g.N * g.Cin * g.inplane, y_elems = (long long)g.N * g.Cout * g.L;
         const bool unit_all = g.stride[0] == 1 && g.stride[1] == 1 && g.stride[2] == 1;
-        const int W4 = (g.in[2] + 3) & ~3;
-        const long long fcols = (long long)g.N * g.in[0] * g.in[1] * W4;  // row-padded column space of the fast kernel
+        const int W4 = (g.uin[2] + 3) & ~3;
+        const long long fcols = (long long)g.N * g.uin[0] * g.uin[1] * W4;  // row-padded column space of the fast kernel
         if (unit_all && g.Mg % BK == 0 && g.out[2] >= 4 && x_elems < 0x7fffffffLL && y_elems < 0x7fffffffLL && fcols < 0x7fffff00LL) {
             const size_t wq_bytes = round256((size_t)g.Cout * g.Cg * g.KK * sizeof(float));
             const size_t to_bytes = round256((size_t)g.KK * sizeof(int));
@@ -985,7 +1012,7 @@ int conv_bwd_input(nk_device* dev, int nd, float* dx, const int* x_shape, const 
     const int ti = g.Cg <= 64 || (g.Cg % 128 != 0 && g.Cg % 64 == 0) ? 1 : 2;
     const int BM = 64 * ti, BN = 128;
     p.tiles_m = (g.Cg + BM - 1) / BM;
-    const long long cols = (long long)g.N * g.inplane;
+    const long long cols = (long long)g.N * g.uinplane;
     p.tiles_n = (int)((cols + BN - 1) / BN);
     const bool aligned_a = (g.Cg % BM == 0) && (K % BK == 0);
     const bool unit = g.stride[0] == 1 && g.stride[1] == 1 && g.stride[2] == 1;
@@ -1096,11 +1123,21 @@ int nk_conv_bias_fwd(nk_device* dev, int nd, const float* x, const int* x_shape,
 }
 int nk_conv_bwd_input(nk_device* dev, int nd, float* dx, const int* x_shape, const float* gy, const float* w,
                       const int* w_shape, const int* stride, const int* dilation, int groups) {
-    return conv_bwd_input(dev, nd, dx, x_shape, gy, w, w_shape, stride, dilation, groups, 0);
+    return conv_bwd_input(dev, nd, dx, x_shape, nullptr, gy, w, w_shape, stride, dilation, groups, 0);
 }
 int nk_conv_bwd_input_assign(nk_device* dev, int nd, float* dx, const int* x_shape, const float* gy, const float* w,
                              const int* w_shape, const int* stride, const int* dilation, int groups) {
-    return conv_bwd_input(dev, nd, dx, x_shape, gy, w, w_shape, stride, dilation, groups, 1);
+    return conv_bwd_input(dev, nd, dx, x_shape, nullptr, gy, w, w_shape, stride, dilation, groups, 1);
+}
+int nk_conv_bwd_input_padded(nk_device* dev, int nd, float* dx, const int* x_shape, const int* padding, const float* gy,
+                             const float* w, const int* w_shape, const int* stride, const int* dilation, int groups) {
+    NK_CHECK(padding != nullptr, "null padding");
+    return conv_bwd_input(dev, nd, dx, x_shape, padding, gy, w, w_shape, stride, dilation, groups, 0);
+}
+int nk_conv_bwd_input_padded_assign(nk_device* dev, int nd, float* dx, const int* x_shape, const int* padding, const float* gy,
+                                    const float* w, const int* w_shape, const int* stride, const int* dilation, int groups) {
+    NK_CHECK(padding != nullptr, "null padding");
+    return conv_bwd_input(dev, nd, dx, x_shape, padding, gy, w, w_shape, stride, dilation, groups, 1);
 }
 int nk_conv_bwd_kernel(nk_device* dev, int nd, float* dw, const int* w_shape, const float* gy, const float* x,
                        const int* x_shape, const int* stride, const int* dilation, int groups) {

@@ -121,6 +121,54 @@ def test_conv_random_vs_oracle(dev, xs, ws, s, d, g):
     contraction_ok(DW.numpy(), dw32, dw64, xs[0] * int(np.prod(oshape[2:])), 1.0, 1.0)
 
 
+CONV_PADDED = [
+    # unpadded x shape, w shape, padding, stride, dilation, groups
+    ((2, 64, 16, 16), (128, 64, 3, 3), (1, 1), (1, 1), (1, 1), 1),     # C3-shaped, fast kernel
+    ((3, 64, 10, 14), (64, 32, 3, 3), (1, 1), (1, 1), (1, 1), 2),      # grouped, fast kernel
+    ((2, 32, 7, 13), (32, 32, 3, 5), (2, 1), (1, 1), (1, 1), 1),       # width 13 -> row padded to 16, asymmetric pads
+    ((2, 32, 6, 9), (32, 32, 3, 3), (3, 4), (1, 1), (2, 2), 1),        # padding wider than the dilated kernel reach
+    ((2, 32, 30), (32, 32, 5), (2,), (1,), (1,), 1),                   # 1-d fast
+    ((1, 32, 4, 6, 10), (32, 32, 2, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1), 1),  # 3-d fast
+    ((2, 8, 10, 10), (16, 8, 3, 3), (1, 1), (1, 1), (1, 1), 1),        # generic kernel
+    ((3, 6, 11, 9), (8, 3, 3, 2), (2, 1), (2, 1), (1, 2), 2),          # generic, stride, dilation, groups
+    ((2, 4, 20), (6, 4, 5), (3,), (3,), (2,), 1),
+    ((1, 4, 6, 7, 8), (4, 2, 2, 3, 2), (0, 2, 1), (1, 2, 1), (2, 1, 2), 2),
+    ((2, 32, 8, 8), (32, 32, 3, 3), (0, 0), (1, 1), (1, 1), 1),        # zero padding == the unpadded entry point
+]
+
+
+@pytest.mark.parametrize("xs,ws,pad,s,d,g", CONV_PADDED)
+def test_conv_bwd_input_padded_vs_oracle(dev, xs, ws, pad, s, d, g):
+    """nk_conv_bwd_input_padded == ConvolutionBackwardInput on the padded shape followed by PadBackward (centre block),
+    bit-identical to our own two-kernel form, `+=` and first-write variants."""
+    c = capi()
+    w = rnd(1, ws, -1, 1)
+    ps = tuple(xs[:2]) + tuple(n + 2 * p for n, p in zip(xs[2:], pad))
+    oshape = O.conv_out_shape(ps, ws, s, d)
+    go = rnd(2, oshape)
+    W, G = dev.array(w), dev.array(go)
+    dx0 = rnd(3, xs)
+    DX = dev.array(dx0)
+    c.conv_bwd_input(dev, DX, G, W, s, d, g, padding=pad)
+    # oracle: gradient of the padded input, centre block accumulated
+    dxp32 = np.zeros(ps, np.float32); O.convolution_backward_input(dxp32, go, w, s, d, g)
+    dxp64 = np.zeros(ps, np.float64); O.convolution_backward_input(dxp64, go.astype(np.float64), w.astype(np.float64), s, d, g)
+    dx32 = dx0.copy(); O.pad_backward(dx32, dxp32, pad)
+    dx64 = dx0.astype(np.float64); O.pad_backward(dx64, dxp64, pad)
+    contraction_ok(DX.numpy(), dx32, dx64, ws[0] // g * int(np.prod(ws[2:])), 1.0, 1.0)
+    # our two-kernel form: same k order per element -> identical bits
+    DXP = dev.zeros(ps)
+    c.conv_bwd_input(dev, DXP, G, W, s, d, g, assign=True)
+    DX2 = dev.array(dx0)
+    c.pad_bwd(dev, DX2, DXP, pad)
+    assert np.array_equal(DX.numpy(), DX2.numpy())
+    A = dev.array(rnd(5, xs))                     # stale contents must be overwritten
+    c.conv_bwd_input(dev, A, G, W, s, d, g, assign=True, padding=pad)
+    Z = dev.zeros(xs)
+    c.conv_bwd_input(dev, Z, G, W, s, d, g, padding=pad)
+    assert np.array_equal(A.numpy(), Z.numpy())
+
+
 def test_conv_arg_errors(dev):
     c = capi()
     X, W, Y = dev.zeros((1, 2, 4, 4)), dev.zeros((1, 2, 5, 5)), dev.zeros((1, 1, 1, 1))

@@ -220,9 +220,43 @@ def test_conv_module_fused_equals_two_nodes(nk, tdev):
         X = nk.from_ndarray(tdev, x).requires_grad()
         y = conv.forward(X)
         s = (y * y).sum(); s.forward(); s.backward(1.0)
-        res[fused] = [y.data(), X.grad(), conv.weight.grad(), conv.bias.grad(), s.history_len()]
-    assert res[True][4] == res[False][4] - 1
+        res[fused] = [y.data(), X.grad(), conv.weight.grad(), conv.bias.grad(), s.history_len(), s.forward_history_len()]
+    # forward: pad, conv(+bias) instead of pad, conv, add; backward: the Pad node's backward is folded into the
+    # convolution's as well (zero padding), so two nodes fewer
+    assert res[True][5] == res[False][5] - 1
+    assert res[True][4] == res[False][4] - 2
     for a, b in zip(res[True][:4], res[False][:4]):
+        assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("nd,cin,cout,k,pad,stride,dil,groups", [
+    (2, 32, 64, [3, 3], [1, 1], [1, 1], [1, 1], 1),      # fast backward-input kernel, crop fused
+    (2, 32, 32, [3, 5], [2, 3], [1, 1], [1, 1], 1),      # wider padding than the kernel needs
+    (2, 6, 4, [3, 3], [1, 2], [2, 1], [1, 1], 2),        # generic kernel, stride, groups
+    (1, 32, 32, [5], [4], [1], [2], 1),
+    (3, 4, 4, [2, 3, 2], [1, 0, 2], [1, 1, 1], [1, 1, 2], 1),
+])
+def test_conv_module_padded_backward_matches_two_nodes(nk, tdev, nd, cin, cout, k, pad, stride, dil, groups):
+    """Zero padding: the fused module node writes the unpadded input gradient directly (nk_conv_bwd_input_padded) and
+    accumulates into a gradient that another node wrote first; values equal the pad -> conv -> add graph's."""
+    spatial = {1: (23,), 2: (9, 13), 3: (5, 6, 7)}[nd]
+    x = rnd(7, (2, cin) + spatial, -1, 1)
+    ctor = {1: nk.nn.Conv1d, 2: nk.nn.Conv2d, 3: nk.nn.Conv3d}[nd]
+    res = {}
+    for fused in (True, False):
+        if nd == 1:
+            conv = ctor(tdev, cin, cout, k[0], pad[0], nk.PaddingMode.zero(), stride[0], dil[0], groups, 9)
+        elif nd == 2:
+            conv = ctor(tdev, cin, cout, k, pad, stride, dil, groups, 9)
+        else:
+            conv = ctor(tdev, cin, cout, k, pad, nk.PaddingMode.zero(), stride, dil, groups, 9)
+        conv.fused = fused
+        X = nk.from_ndarray(tdev, x).requires_grad()
+        y = conv.forward(X)
+        s = (y * y).sum() + (X * 3.0).sum()          # a second consumer of X: one of the two writes accumulates
+        s.forward(); s.backward(1.0)
+        res[fused] = [y.data(), X.grad(), conv.weight.grad(), conv.bias.grad()]
+    for a, b in zip(res[True], res[False]):
         assert np.array_equal(a, b)
 
 
