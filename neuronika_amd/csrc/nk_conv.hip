@@ -175,6 +175,25 @@ __global__ __launch_bounds__(NT, 2) void conv_fwd_kernel(FwdArgs p) {
     float* Y = p.y;
     const float* bias = g.bias;
     const int Mg = g.Mg, L = g.L, Cout = g.Cout;
+    // the bias of the 16*TI rows this lane owns, loaded before the first store (a load between stores waits for them)
+    float bv[TI][16];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int co = m0 + (wr * TI + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+            bv[i][e] = (bias && co < Mg) ? bias[grp * Mg + co] : 0.f;
+        }
+    // ... and added in registers before the (per-element conditional) stores: with loads still pending when the store
+    // blocks are entered, each of them gets its own vmcnt(0), which also waits for the PREVIOUS STORE to be acknowledged
+    if (bias) {
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] += bv[i][e];
+    }
     // one (n, l) decode per owned column instead of one per element
     acc_foreach_cols<TI, TJ>(acc, wr, wc, lane,
         [&](int c) -> long long {
@@ -185,9 +204,27 @@ __global__ __launch_bounds__(NT, 2) void conv_fwd_kernel(FwdArgs p) {
         },
         [&](int r, long long base, float v) {
             const int co = m0 + r;
-            if (co < Mg && base >= 0) Y[base + (long long)co * L] = bias ? v + bias[grp * Mg + co] : v;
+            if (co < Mg && base >= 0) Y[base + (long long)co * L] = v;
         });
 }
+
+// dX[cbase[j] + ci * inplane] (+)= acc.  `+=`: every old value is loaded and added in registers before the first store (a
+// one-walk `*d += v` is 16*TI*TJ serialised load -> store round trips per lane, the store may alias the next load).
+#define NK_BWD_INPUT_EPILOGUE                                                                                        \
+    if (!assign) {                                                                                                   \
+        float old[TI][TJ][16];                                                                                       \
+        acc_foreach_idx<TI, TJ>(acc, wr, wc, lane, [&](int i, int j, int e, int r, int, float) {                     \
+            const int ci = m0 + r;                                                                                   \
+            old[i][j][e] = (ci < Cg && cbase[j] >= 0) ? DX[cbase[j] + (long long)ci * inplane] : 0.f;                \
+        });                                                                                                          \
+        _Pragma("unroll") for (int i = 0; i < TI; ++i)                                                               \
+            _Pragma("unroll") for (int j = 0; j < TJ; ++j)                                                           \
+                _Pragma("unroll") for (int e = 0; e < 16; ++e) acc[i][j][e] += old[i][j][e];                         \
+    }                                                                                                                \
+    acc_foreach_idx<TI, TJ>(acc, wr, wc, lane, [&](int, int j, int, int r, int, float v) {                           \
+        const int ci = m0 + r;                                                                                       \
+        if (ci < Cg && cbase[j] >= 0) DX[cbase[j] + (long long)ci * inplane] = v;                                    \
+    });
 
 // =================================================================================================
 // backward w.r.t. the input (gather form)
@@ -303,20 +340,14 @@ __global__ __launch_bounds__(NT, 2) void conv_bwd_input_kernel(BwdInArgs p) {
     float* DX = p.dx;
     const int assign = g.assign;
     const int Cg = g.Cg, Cin = g.Cin, inplane = g.uinplane;
-    acc_foreach_cols<TI, TJ>(acc, wr, wc, lane,
-        [&](int c) -> long long {
-            const long long cc = (long long)n0 + c;
-            if (cc >= cols) return -1;
-            const long long n = cc / inplane;
-            return (n * Cin + grp * Cg) * inplane + (cc - n * inplane);
-        },
-        [&](int r, long long base, float v) {
-            const int ci = m0 + r;
-            if (ci < Cg && base >= 0) {
-                float* d = &DX[base + (long long)ci * inplane];
-                *d = assign ? v : *d + v;
-            }
-        });
+    long long cbase[TJ];  // one (n, pos) decode per owned column
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+        const long long cc = (long long)n0 + (wc * TJ + j) * 32 + (lane & 31);
+        const long long n = cc / inplane;
+        cbase[j] = cc < cols ? (n * Cin + grp * Cg) * inplane + (cc - n * inplane) : -1;
+    }
+    NK_BWD_INPUT_EPILOGUE
 }
 
 // =================================================================================================
@@ -384,33 +415,57 @@ __global__ __launch_bounds__(NT, 2) void conv_bwd_kernel_kernel(BwdKArgs p) {
         q1 = l % g.out[1];
         q0 = l / g.out[1];
     }
-    auto load_both = [&](long long r0) {
+    // QUADR: branch-free staging.  Every load is unconditional at an address clamped into the tensor (row / column / quad
+    // offsets of masked lanes are 0) and masked lanes select zeros afterwards: conditional loads whose two arms write the
+    // same registers made the compiler wait (vmcnt(0)) before each of the eight loads of a k-tile, i.e. eight serialised
+    // memory round trips per k-tile instead of one hidden behind the MFMAs.
+    const long long aro0 = av0 ? (long long)(m0 + row) * g.L : 0, aro1 = av1 ? (long long)(m0 + row + 32) * g.L : 0,
+                    aro2 = av2 ? (long long)(m0 + row + 64) * g.L : 0, aro3 = av3 ? (long long)(m0 + row + 96) * g.L : 0;
+    bool qv = false;  // the quad staged last lies inside [rbeg, rend)
+    auto load_quad = [&](long long r0) {
+        const bool v = r0 + rq * 4 < rend;
+        qv = v;
+        const long long x0 = v ? (long long)qn * g.Cin * g.inplane + ((q0 * g.stride[0] * g.in[1] + q1 * g.stride[1]) * g.in[2] + q2) : 0;
+        const long long g0 = v ? (long long)qn * g.Cout * g.L + ((q0 * g.out[1] + q1) * g.out[2] + q2) : 0;
+        q2 += BK;  // next k-tile: 32 positions further along the flattened (n, out) index
+        while (q2 >= g.out[2]) { q2 -= g.out[2]; ++q1; }
+        while (q1 >= g.out[1]) { q1 -= g.out[1]; ++q0; }
+        while (q0 >= g.out[0]) { q0 -= g.out[0]; ++qn; }
+        ra.v0 = *reinterpret_cast<const float4*>(G + g0 + aro0);
+        ra.v1 = *reinterpret_cast<const float4*>(G + g0 + aro1);
+        if constexpr (TI == 2) {
+            ra.v2 = *reinterpret_cast<const float4*>(G + g0 + aro2);
+            ra.v3 = *reinterpret_cast<const float4*>(G + g0 + aro3);
+        }
+#define NK_LDU(V, OFF) { const f32x4u q = *reinterpret_cast<const f32x4u*>(X + x0 + OFF); V = make_float4(q.x, q.y, q.z, q.w); }
+        NK_LDU(rb.v0, ko0) NK_LDU(rb.v1, ko1)
+        if constexpr (TJ == 2) { NK_LDU(rb.v2, ko2) NK_LDU(rb.v3, ko3) }
+#undef NK_LDU
+    };
+    // applied AFTER the MFMAs of the current k-tile (touching the loaded registers earlier would wait for the loads)
+    auto mask_quad = [&]() {
+        // component-wise selects: `cond ? vecA : vecB` on the vector CLASS selects between two addresses and sends both
+        // through scratch memory
+        auto keep = [](float4& q, bool k) { q.x = k ? q.x : 0.f; q.y = k ? q.y : 0.f; q.z = k ? q.z : 0.f; q.w = k ? q.w : 0.f; };
+        keep(ra.v0, qv && av0); keep(ra.v1, qv && av1);
+        if constexpr (TI == 2) { keep(ra.v2, qv && av2); keep(ra.v3, qv && av3); }
+        keep(rb.v0, qv && cv0); keep(rb.v1, qv && cv1);
+        if constexpr (TJ == 2) { keep(rb.v2, qv && cv2); keep(rb.v3, qv && cv3); }
+    };
+    auto load_scalar = [&](long long r0) {
         // decompose the 4 consecutive reduction indices r0 + 4*rq + {0..3} -> (n, l)
         long long xo[4], go[4];
         bool rv[4];
-        if (QUADR) {
-            const bool v = r0 + rq * 4 < rend;
-            const long long x0 = (long long)qn * g.Cin * g.inplane +
-                                 ((q0 * g.stride[0] * g.in[1] + q1 * g.stride[1]) * g.in[2] + q2);
-            const long long g0 = (long long)qn * g.Cout * g.L + ((q0 * g.out[1] + q1) * g.out[2] + q2);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) { rv[c] = v; xo[c] = v ? x0 + c : 0; go[c] = v ? g0 + c : 0; }
-            q2 += BK;  // next k-tile: 32 positions further along the flattened (n, out) index
-            while (q2 >= g.out[2]) { q2 -= g.out[2]; ++q1; }
-            while (q1 >= g.out[1]) { q1 -= g.out[1]; ++q0; }
-            while (q0 >= g.out[0]) { q0 -= g.out[0]; ++qn; }
-        } else {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const long long r = r0 + rq * 4 + c;
-                rv[c] = r < rend;
-                const int n = rv[c] ? (int)(r / g.L) : 0, l = rv[c] ? (int)(r % g.L) : 0;
-                xo[c] = (long long)n * g.Cin * g.inplane + window_origin(g, l);
-                go[c] = (long long)n * g.Cout * g.L + l;
-            }
+        for (int c = 0; c < 4; ++c) {
+            const long long r = r0 + rq * 4 + c;
+            rv[c] = r < rend;
+            const int n = rv[c] ? (int)(r / g.L) : 0, l = rv[c] ? (int)(r % g.L) : 0;
+            xo[c] = (long long)n * g.Cin * g.inplane + window_origin(g, l);
+            go[c] = (long long)n * g.Cout * g.L + l;
         }
         // the four reduction indices are neighbours in one output row (unit stride)
-        const bool quad = QUADR ? rv[0] : (rv[3] && xo[1] == xo[0] + 1 && xo[2] == xo[0] + 2 && xo[3] == xo[0] + 3);
+        const bool quad = rv[3] && xo[1] == xo[0] + 1 && xo[2] == xo[0] + 2 && xo[3] == xo[0] + 3;
 #define NK_A(j, V, AV)                                                                       \
     {                                                                                        \
         const long long rowoff = (long long)(m0 + row + 32 * j) * g.L;                       \
@@ -433,11 +488,16 @@ __global__ __launch_bounds__(NT, 2) void conv_bwd_kernel_kernel(BwdKArgs p) {
         if constexpr (TJ == 2) { NK_B(rb.v2, ko2, cv2) NK_B(rb.v3, ko3, cv3) }
 #undef NK_B
     };
+    auto load_both = [&](long long r0) {
+        if constexpr (QUADR) load_quad(r0);
+        else load_scalar(r0);
+    };
 
     f32x16 acc[TI][TJ];
     acc_zero<TI, TJ>(acc);
     if (nt > 0) {
         load_both(rbeg);
+        if constexpr (QUADR) mask_quad();
         stage_store<true, BM>(smem, ra, t);
         stage_store<true, BN>(smem + TA_FLOATS, rb, t);
     }
@@ -448,6 +508,7 @@ __global__ __launch_bounds__(NT, 2) void conv_bwd_kernel_kernel(BwdKArgs p) {
         load_both(rbeg + (long long)(it + 1) * BK);
         __builtin_amdgcn_sched_barrier(0);
         mma_tile<true, true, TI, TJ>(cur, cur + TA_FLOATS, acc, wr, wc, lane);
+        if constexpr (QUADR) mask_quad();
         stage_store<true, BM>(nxt, ra, t);
         stage_store<true, BN>(nxt + TA_FLOATS, rb, t);
         __syncthreads();
@@ -641,6 +702,25 @@ __global__ __launch_bounds__(NT, 2) void conv_fwd_fast_kernel(FastFwdArgs p) {
     float* Y = p.y;
     const float* bias = g.bias;
     const int Mg = g.Mg, L = g.L, Cout = g.Cout;
+    // the bias of the 16*TI rows this lane owns, loaded before the first store (a load between stores waits for them)
+    float bv[TI][16];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int co = m0 + (wr * TI + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+            bv[i][e] = (bias && co < Mg) ? bias[grp * Mg + co] : 0.f;
+        }
+    // ... and added in registers before the (per-element conditional) stores: with loads still pending when the store
+    // blocks are entered, each of them gets its own vmcnt(0), which also waits for the PREVIOUS STORE to be acknowledged
+    if (bias) {
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] += bv[i][e];
+    }
     // one (n, l) decode per owned column instead of one per element
     acc_foreach_cols<TI, TJ>(acc, wr, wc, lane,
         [&](int c) -> long long {
@@ -651,7 +731,7 @@ __global__ __launch_bounds__(NT, 2) void conv_fwd_fast_kernel(FastFwdArgs p) {
         },
         [&](int r, long long base, float v) {
             const int co = m0 + r;
-            if (co < Mg && base >= 0) Y[base + (long long)co * L] = bias ? v + bias[grp * Mg + co] : v;
+            if (co < Mg && base >= 0) Y[base + (long long)co * L] = v;
         });
 }
 
@@ -726,36 +806,50 @@ __global__ __launch_bounds__(NT, 2) void conv_bwd_input_fast_kernel(FastBwdInArg
         gbase = n * g.Cout * g.L + krow * g.L;
     }
     const int jstep = 8 * g.L;
-    auto pick = [](const f32x4u& q, int idx) { return idx == 0 ? q.x : (idx == 1 ? q.y : (idx == 2 ? q.z : q.w)); };
+    // Two halves: `gather` only ISSUES the four 16-byte loads of the next k-tile (before the MFMAs of the current one);
+    // `gather_finish` picks / masks the elements and runs AFTER the MFMAs - touching the loaded registers any earlier
+    // makes the wave wait for its loads with nothing to hide them behind.
+    Stage<4> rb;
+    int g_sh = 0, g_c = 0;
+    bool g_ok = false;
     auto gather = [&](int kt) {
         const int chunk = kt / g.KK, tap = kt - chunk * g.KK, co0 = chunk * BK;  // taps inside a 32-channel chunk
         const int4 d = p.tapd[tap];
         const float* src = G + co0 * g.L;
         const int a = qa - d.x, b = qb - d.y, c = qc - d.z;  // output coordinates of the quad's first element
-        const bool row_ok = valid && a >= 0 && a < g.out[0] && b >= 0 && b < g.out[1];
+        g_ok = valid && a >= 0 && a < g.out[0] && b >= 0 && b < g.out[1];
         const int ac = min(max(a, 0), g.out[0] - 1), bc = min(max(b, 0), g.out[1] - 1);
-        const int cs = min(max(c, 0), g.out[2] - 4), sh = c - cs;  // load start clamped into the row, shift of element 0
+        const int cs = min(max(c, 0), g.out[2] - 4);  // load start clamped into the row
+        g_sh = c - cs;                                  // shift of element 0 inside the loaded vector
+        g_c = c;
         const float* ptr = src + (gbase + (ac * g.out[1] + bc) * g.out[2] + cs);
-        const f32x4u q0 = *reinterpret_cast<const f32x4u*>(ptr);
-        const f32x4u q1 = *reinterpret_cast<const f32x4u*>(ptr + jstep);
-        const f32x4u q2 = *reinterpret_cast<const f32x4u*>(ptr + 2 * jstep);
-        const f32x4u q3 = *reinterpret_cast<const f32x4u*>(ptr + 3 * jstep);
-        Stage<4> r;
+#define NK_LDU(V, P) { const f32x4u q = *reinterpret_cast<const f32x4u*>(P); V = make_float4(q.x, q.y, q.z, q.w); }
+        NK_LDU(rb.v0, ptr) NK_LDU(rb.v1, ptr + jstep) NK_LDU(rb.v2, ptr + 2 * jstep) NK_LDU(rb.v3, ptr + 3 * jstep)
+#undef NK_LDU
+    };
+    auto gather_finish = [&]() {
+        const int sh = g_sh;
         if (sh == 0) {  // interior quad (the common case): the loaded vector is the quad
-            r.v0 = row_ok ? make_float4(q0.x, q0.y, q0.z, q0.w) : make_float4(0.f, 0.f, 0.f, 0.f);
-            r.v1 = row_ok ? make_float4(q1.x, q1.y, q1.z, q1.w) : make_float4(0.f, 0.f, 0.f, 0.f);
-            r.v2 = row_ok ? make_float4(q2.x, q2.y, q2.z, q2.w) : make_float4(0.f, 0.f, 0.f, 0.f);
-            r.v3 = row_ok ? make_float4(q3.x, q3.y, q3.z, q3.w) : make_float4(0.f, 0.f, 0.f, 0.f);
+            auto keep = [](float4& q, bool k) { q.x = k ? q.x : 0.f; q.y = k ? q.y : 0.f; q.z = k ? q.z : 0.f; q.w = k ? q.w : 0.f; };
+            keep(rb.v0, g_ok); keep(rb.v1, g_ok); keep(rb.v2, g_ok); keep(rb.v3, g_ok);
         } else {
-            bool in[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) in[i] = row_ok && c + i >= 0 && c + i < g.out[2];
-#define NK_SEL(Q) make_float4(in[0] ? pick(Q, sh) : 0.f, in[1] ? pick(Q, 1 + sh) : 0.f, in[2] ? pick(Q, 2 + sh) : 0.f, \
-                              in[3] ? pick(Q, 3 + sh) : 0.f)
-            r.v0 = NK_SEL(q0); r.v1 = NK_SEL(q1); r.v2 = NK_SEL(q2); r.v3 = NK_SEL(q3);
-#undef NK_SEL
+            const bool in0 = g_ok && g_c >= 0 && g_c < g.out[2], in1 = g_ok && g_c + 1 >= 0 && g_c + 1 < g.out[2],
+                       in2 = g_ok && g_c + 2 >= 0 && g_c + 2 < g.out[2], in3 = g_ok && g_c + 3 >= 0 && g_c + 3 < g.out[2];
+            // element i of the quad = element i + sh of the loaded vector: a barrel shifter of register selects (a pick by
+            // dynamic index makes the compiler index the vector through scratch memory); elements shifted in from outside
+            // the vector are always masked by in0..in3
+            const int sl = max(sh, 0), sr = max(-sh, 0);
+            const bool l1 = sl & 1, l2 = sl & 2, r1 = sr & 1, r2 = sr & 2;
+            auto sel = [&](float4& q) {
+                float e0 = q.x, e1 = q.y, e2 = q.z, e3 = q.w;
+                e0 = l1 ? e1 : e0; e1 = l1 ? e2 : e1; e2 = l1 ? e3 : e2;
+                e0 = l2 ? e2 : e0; e1 = l2 ? e3 : e1;
+                e3 = r1 ? e2 : e3; e2 = r1 ? e1 : e2; e1 = r1 ? e0 : e1;
+                e3 = r2 ? e1 : e3; e2 = r2 ? e0 : e2;
+                q.x = in0 ? e0 : 0.f; q.y = in1 ? e1 : 0.f; q.z = in2 ? e2 : 0.f; q.w = in3 ? e3 : 0.f;
+            };
+            sel(rb.v0); sel(rb.v1); sel(rb.v2); sel(rb.v3);
         }
-        return r;
     };
 
     f32x16 acc[TI][TJ];
@@ -763,9 +857,9 @@ __global__ __launch_bounds__(NT, 2) void conv_bwd_input_fast_kernel(FastBwdInArg
     TileLoader<true, BM> la;
     la.init(Wq, K, m0, 0, g.Cg, K, t);
     Stage<BM / 32> ra;
-    Stage<4> rb;
     ra = la.template load<ALIGNED_A>(t);
-    rb = gather(0);
+    gather(0);
+    gather_finish();
     stage_store<true, BM>(smem, ra, t);
     stage_store<false, BN>(smem + TA_FLOATS, rb, t);
     __syncthreads();
@@ -773,9 +867,10 @@ __global__ __launch_bounds__(NT, 2) void conv_bwd_input_fast_kernel(FastBwdInArg
         float* cur = smem + (it & 1) * STAGE;
         float* nxt = smem + ((it + 1) & 1) * STAGE;
         ra = la.template load<ALIGNED_A>(t);
-        rb = gather(it + 1);
+        gather(it + 1);
         __builtin_amdgcn_sched_barrier(0);
         mma_tile<true, false, TI, TJ>(cur, cur + TA_FLOATS, acc, wr, wc, lane);
+        gather_finish();
         stage_store<true, BM>(nxt, ra, t);
         stage_store<false, BN>(nxt + TA_FLOATS, rb, t);
         __syncthreads();
@@ -787,22 +882,17 @@ __global__ __launch_bounds__(NT, 2) void conv_bwd_input_fast_kernel(FastBwdInArg
     float* DX = p.dx;
     const int assign = g.assign;
     const int Cg = g.Cg, Cin = g.Cin, inplane = g.uinplane;
-    acc_foreach_cols<TI, TJ>(acc, wr, wc, lane,
-        [&](int c) -> long long {
-            const int cc = n0 + c;
-            if (cc >= cols) return -1;
-            const int rowid = cc / W4, cpos = cc - rowid * W4;
-            if (cpos >= g.uin[2]) return -1;  // padding column of the row
-            const int n = rowid / rows_per_n;
-            return ((long long)n * Cin + grp * Cg) * inplane + (long long)(rowid - n * rows_per_n) * g.uin[2] + cpos;
-        },
-        [&](int r, long long base, float v) {
-            const int ci = m0 + r;
-            if (ci < Cg && base >= 0) {
-                float* d = &DX[base + (long long)ci * inplane];
-                *d = assign ? v : *d + v;
-            }
-        });
+    long long cbase[TJ];  // one (n, row, c') decode per owned column
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+        const int cc = n0 + (wc * TJ + j) * 32 + (lane & 31);
+        const int rowid = cc / W4, cpos = cc - rowid * W4;
+        const int n = rowid / rows_per_n;
+        cbase[j] = (cc < cols && cpos < g.uin[2])  // not a padding column of the row
+                       ? ((long long)n * Cin + grp * Cg) * inplane + (long long)(rowid - n * rows_per_n) * g.uin[2] + cpos
+                       : -1;
+    }
+    NK_BWD_INPUT_EPILOGUE
 }
 
 // ---- host side ------------------------------------------------------------------------------------

@@ -98,30 +98,37 @@ __global__ __launch_bounds__(NT, (min_waves<TI, TJ>())) void sgemm_kernel(GemmAr
     const float alpha = p.alpha, beta = p.beta;
     const int M = p.M, N = p.N;
     const long long ldc = p.ldc;
-    if (p.bias != nullptr) {  // Linear: fl(acc + bias[col]) == the separate Addition node applied to the GEMM result
-        const float* bias = p.bias;
-        acc_foreach<TI, TJ>(acc, wr, wc, lane, [&](int r, int c, float v) {
-            const int row = m0 + r, col = n0 + c;
-            if (ALIGNED || (row < M && col < N)) {
-                float* q = &C[row * ldc + col];
-                const float o = alpha * v + bias[col];
-                *q = beta == 0.f ? o : fmaf(beta, *q, o);
-            }
-        });
-    } else if (beta == 0.f) {
-        acc_foreach<TI, TJ>(acc, wr, wc, lane, [&](int r, int c, float v) {
-            const int row = m0 + r, col = n0 + c;
-            if (ALIGNED || (row < M && col < N)) C[row * ldc + col] = alpha * v;
-        });
-    } else {
-        acc_foreach<TI, TJ>(acc, wr, wc, lane, [&](int r, int c, float v) {
-            const int row = m0 + r, col = n0 + c;
-            if (ALIGNED || (row < M && col < N)) {
-                float* q = &C[row * ldc + col];
-                *q = fmaf(beta, *q, alpha * v);
-            }
-        });
+    // Every load (bias, old C) is issued first and folded into the accumulators in registers; the stores come last.  (A
+    // one-walk `*q = f(*q)` serialises 16*TI*TJ load -> store round trips per lane, and loads still pending when the
+    // per-element conditional store blocks are entered make each of them wait for the previous store as well.)
+    if (p.bias != nullptr || beta != 0.f || alpha != 1.f) {
+        float old[TI][TJ][16];
+        if (beta != 0.f)
+            acc_foreach_idx<TI, TJ>(acc, wr, wc, lane, [&](int i, int j, int e, int r, int c, float) {
+                const int row = m0 + r, col = n0 + c;
+                old[i][j][e] = (ALIGNED || (row < M && col < N)) ? C[row * ldc + col] : 0.f;
+            });
+        float bv[TJ];  // a lane owns TJ columns
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            const int col = n0 + (wc * TJ + j) * 32 + (lane & 31);
+            bv[j] = (p.bias != nullptr && (ALIGNED || col < N)) ? p.bias[col] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    float o = alpha * acc[i][j][e];
+                    if (p.bias != nullptr) o += bv[j];  // Linear: fl(acc + bias[col]) == the separate Addition node
+                    acc[i][j][e] = beta == 0.f ? o : fmaf(beta, old[i][j][e], o);
+                }
     }
+    acc_foreach<TI, TJ>(acc, wr, wc, lane, [&](int r, int c, float v) {
+        const int row = m0 + r, col = n0 + c;
+        if (ALIGNED || (row < M && col < N)) C[row * ldc + col] = v;
+    });
 }
 
 // Second pass of split-K: C = alpha * sum_s slab[s] + beta * C, fixed summation order.

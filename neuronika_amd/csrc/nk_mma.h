@@ -226,6 +226,34 @@ __device__ __forceinline__ void acc_foreach_cols(const f32x16 (&acc)[TI][TJ], in
     }
 }
 
+// Index-passing forms: f(i, j, e, row, col, value) / fe(i, j, e, row, ctx, value) with i, j, e compile-time constants after
+// unrolling, so an epilogue can keep per-element state in a register array filled by a FIRST walk (all loads issued) and
+// consumed by a SECOND walk (stores).  A one-walk read-modify-write (`*q = f(*q)`) or a bias load between stores
+// serialises 16*TI*TJ load -> store round trips per lane: a store may alias the next load, so the compiler keeps the order.
+template <int TI, int TJ, class F>
+__device__ __forceinline__ void acc_foreach_idx(const f32x16 (&acc)[TI][TJ], int wr, int wc, int lane, F&& f) {
+    const int c = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                f(i, j, e, (wr * TI + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h, (wc * TJ + j) * 32 + c, acc[i][j][e]);
+}
+template <int TI, int TJ, class FC, class FE>
+__device__ __forceinline__ void acc_foreach_cols_idx(const f32x16 (&acc)[TI][TJ], int wr, int wc, int lane, FC&& fc, FE&& fe) {
+    const int c = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+        const auto ctx = fc((wc * TJ + j) * 32 + c);
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) fe(i, j, e, (wr * TI + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h, ctx, acc[i][j][e]);
+    }
+}
+
 // XCD-aware, L2-friendly block -> tile mapping.  Blocks are dispatched round-robin over the 8
 // XCDs (block b -> XCD b%8, observed; used for speed only): give each XCD a contiguous chunk
 // of the tile sequence, and order the sequence in column-major groups of GROUP_M tile rows so
