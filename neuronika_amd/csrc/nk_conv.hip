@@ -363,9 +363,11 @@ struct BwdKArgs {
     long long r_per_split;  // multiple of BK
 };
 
-// QUADR: out[2] % 4 == 0, unit stride on the innermost axis, L % 4 == 0 -> the four consecutive
-// reduction indices a thread stages are one output-row quad: one (incremental, division-free)
-// decode per k-tile and one 16-B load per staged row.
+// QUADR (unit stride on the innermost axis, out[2] >= 4): the reduction runs over (n, o0, o1, c') with the innermost output
+// row padded to W4 = a multiple of 4, so the four consecutive reduction indices a thread stages are one output-row quad:
+// one (incremental, division-free) decode per k-tile and one 16-byte load per staged row.  A quad that would run past the
+// row end (out[2] % 4 != 0) is loaded `dup` elements earlier - for BOTH operands, a reduction does not care where in the
+// k-tile an element sits - and its first `dup` elements, already counted by the previous quad, are masked.
 template <bool VEC_G, int TI, int TJ, bool QUADR>
 __global__ __launch_bounds__(NT, 2) void conv_bwd_kernel_kernel(BwdKArgs p) {
     constexpr int BM = 64 * TI, BN = 64 * TJ;
@@ -384,7 +386,8 @@ __global__ __launch_bounds__(NT, 2) void conv_bwd_kernel_kernel(BwdKArgs p) {
     const int grp = blockIdx.z;
     const int m0 = tm * BM, n0 = tn * BN;
     const int Kc = g.Cg * g.KK;  // columns of dW
-    const long long R = (long long)g.N * g.L;
+    const int W4 = (g.out[2] + 3) & ~3;
+    const long long R = QUADR ? (long long)g.N * g.out[0] * g.out[1] * W4 : (long long)g.N * g.L;
     const long long rbeg = split * p.r_per_split;
     const long long rend = rbeg + p.r_per_split < R ? rbeg + p.r_per_split : R;
     const int nt = rend > rbeg ? (int)((rend - rbeg + BK - 1) / BK) : 0;
@@ -409,11 +412,11 @@ __global__ __launch_bounds__(NT, 2) void conv_bwd_kernel_kernel(BwdKArgs p) {
     int qn = 0, q0 = 0, q1 = 0, q2 = 0;
     if (QUADR) {
         const long long r = rbeg + rq * 4;
-        qn = (int)(r / g.L);
-        int l = (int)(r % g.L);
-        q2 = l % g.out[2]; l /= g.out[2];
-        q1 = l % g.out[1];
-        q0 = l / g.out[1];
+        long long rowid = r / W4;
+        q2 = (int)(r - rowid * W4);
+        q1 = (int)(rowid % g.out[1]); rowid /= g.out[1];
+        q0 = (int)(rowid % g.out[0]);
+        qn = (int)(rowid / g.out[0]);
     }
     // QUADR: branch-free staging.  Every load is unconditional at an address clamped into the tensor (row / column / quad
     // offsets of masked lanes are 0) and masked lanes select zeros afterwards: conditional loads whose two arms write the
@@ -422,71 +425,77 @@ __global__ __launch_bounds__(NT, 2) void conv_bwd_kernel_kernel(BwdKArgs p) {
     const long long aro0 = av0 ? (long long)(m0 + row) * g.L : 0, aro1 = av1 ? (long long)(m0 + row + 32) * g.L : 0,
                     aro2 = av2 ? (long long)(m0 + row + 64) * g.L : 0, aro3 = av3 ? (long long)(m0 + row + 96) * g.L : 0;
     bool qv = false;  // the quad staged last lies inside [rbeg, rend)
+    int qdup = 0;     // its first `qdup` elements belong to the previous quad of the row
     auto load_quad = [&](long long r0) {
         const bool v = r0 + rq * 4 < rend;
         qv = v;
-        const long long x0 = v ? (long long)qn * g.Cin * g.inplane + ((q0 * g.stride[0] * g.in[1] + q1 * g.stride[1]) * g.in[2] + q2) : 0;
-        const long long g0 = v ? (long long)qn * g.Cout * g.L + ((q0 * g.out[1] + q1) * g.out[2] + q2) : 0;
-        q2 += BK;  // next k-tile: 32 positions further along the flattened (n, out) index
-        while (q2 >= g.out[2]) { q2 -= g.out[2]; ++q1; }
+        const int cs = min(q2, g.out[2] - 4);  // start clamped so that the quad ends inside the row
+        qdup = q2 - cs;
+        const long long x0 = v ? (long long)qn * g.Cin * g.inplane + ((q0 * g.stride[0] * g.in[1] + q1 * g.stride[1]) * g.in[2] + cs) : 0;
+        const long long g0 = v ? (long long)qn * g.Cout * g.L + ((q0 * g.out[1] + q1) * g.out[2] + cs) : 0;
+        q2 += BK;  // next k-tile: 32 positions further along the (row-padded) reduction index
+        while (q2 >= W4) { q2 -= W4; ++q1; }
         while (q1 >= g.out[1]) { q1 -= g.out[1]; ++q0; }
         while (q0 >= g.out[0]) { q0 -= g.out[0]; ++qn; }
-        ra.v0 = *reinterpret_cast<const float4*>(G + g0 + aro0);
-        ra.v1 = *reinterpret_cast<const float4*>(G + g0 + aro1);
-        if constexpr (TI == 2) {
-            ra.v2 = *reinterpret_cast<const float4*>(G + g0 + aro2);
-            ra.v3 = *reinterpret_cast<const float4*>(G + g0 + aro3);
-        }
-#define NK_LDU(V, OFF) { const f32x4u q = *reinterpret_cast<const f32x4u*>(X + x0 + OFF); V = make_float4(q.x, q.y, q.z, q.w); }
-        NK_LDU(rb.v0, ko0) NK_LDU(rb.v1, ko1)
-        if constexpr (TJ == 2) { NK_LDU(rb.v2, ko2) NK_LDU(rb.v3, ko3) }
+#define NK_LDU(V, P) { const f32x4u q = *reinterpret_cast<const f32x4u*>(P); V = make_float4(q.x, q.y, q.z, q.w); }
+        NK_LDU(ra.v0, G + g0 + aro0) NK_LDU(ra.v1, G + g0 + aro1)
+        if constexpr (TI == 2) { NK_LDU(ra.v2, G + g0 + aro2) NK_LDU(ra.v3, G + g0 + aro3) }
+        NK_LDU(rb.v0, X + x0 + ko0) NK_LDU(rb.v1, X + x0 + ko1)
+        if constexpr (TJ == 2) { NK_LDU(rb.v2, X + x0 + ko2) NK_LDU(rb.v3, X + x0 + ko3) }
 #undef NK_LDU
     };
     // applied AFTER the MFMAs of the current k-tile (touching the loaded registers earlier would wait for the loads)
     auto mask_quad = [&]() {
         // component-wise selects: `cond ? vecA : vecB` on the vector CLASS selects between two addresses and sends both
         // through scratch memory
-        auto keep = [](float4& q, bool k) { q.x = k ? q.x : 0.f; q.y = k ? q.y : 0.f; q.z = k ? q.z : 0.f; q.w = k ? q.w : 0.f; };
+        const bool d0 = qdup <= 0, d1 = qdup <= 1, d2 = qdup <= 2;  // element i is new when i >= qdup (qdup <= 3)
+        auto keep = [&](float4& q, bool k) {
+            q.x = k && d0 ? q.x : 0.f; q.y = k && d1 ? q.y : 0.f; q.z = k && d2 ? q.z : 0.f; q.w = k ? q.w : 0.f;
+        };
         keep(ra.v0, qv && av0); keep(ra.v1, qv && av1);
         if constexpr (TI == 2) { keep(ra.v2, qv && av2); keep(ra.v3, qv && av3); }
         keep(rb.v0, qv && cv0); keep(rb.v1, qv && cv1);
         if constexpr (TJ == 2) { keep(rb.v2, qv && cv2); keep(rb.v3, qv && cv3); }
     };
+    // General form (strided innermost axis or rows shorter than 4): per-element decode, scalar gathers - still branch-free
+    // (offsets of masked elements are 0, masks applied after the MFMAs).
+    int smask = 0;  // bit c: reduction index r0 + 4*rq + c lies inside [rbeg, rend)
     auto load_scalar = [&](long long r0) {
-        // decompose the 4 consecutive reduction indices r0 + 4*rq + {0..3} -> (n, l)
         long long xo[4], go[4];
-        bool rv[4];
+        int m = 0;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const long long r = r0 + rq * 4 + c;
-            rv[c] = r < rend;
-            const int n = rv[c] ? (int)(r / g.L) : 0, l = rv[c] ? (int)(r % g.L) : 0;
+            const bool ok = r < rend;
+            const int n = ok ? (int)(r / g.L) : 0, l = ok ? (int)(r % g.L) : 0;
             xo[c] = (long long)n * g.Cin * g.inplane + window_origin(g, l);
             go[c] = (long long)n * g.Cout * g.L + l;
+            m |= (ok ? 1 : 0) << c;
         }
-        // the four reduction indices are neighbours in one output row (unit stride)
-        const bool quad = rv[3] && xo[1] == xo[0] + 1 && xo[2] == xo[0] + 2 && xo[3] == xo[0] + 3;
-#define NK_A(j, V, AV)                                                                       \
-    {                                                                                        \
-        const long long rowoff = (long long)(m0 + row + 32 * j) * g.L;                       \
-        if (VEC_G && AV && rv[3]) V = *reinterpret_cast<const float4*>(&G[go[0] + rowoff]);  \
-        else V = make_float4(AV && rv[0] ? G[go[0] + rowoff] : 0.f, AV && rv[1] ? G[go[1] + rowoff] : 0.f, \
-                             AV && rv[2] ? G[go[2] + rowoff] : 0.f, AV && rv[3] ? G[go[3] + rowoff] : 0.f); \
+        smask = m;
+#define NK_A(V, ARO)                                                                                        \
+    if constexpr (VEC_G) { /* L % 4 == 0: the four indices are one aligned quad of one sample */           \
+        V = *reinterpret_cast<const float4*>(G + go[0] + ARO);                                              \
+    } else {                                                                                                \
+        V = make_float4(G[go[0] + ARO], G[go[1] + ARO], G[go[2] + ARO], G[go[3] + ARO]);                    \
     }
-        NK_A(0, ra.v0, av0) NK_A(1, ra.v1, av1)
-        if constexpr (TI == 2) { NK_A(2, ra.v2, av2) NK_A(3, ra.v3, av3) }
+        NK_A(ra.v0, aro0) NK_A(ra.v1, aro1)
+        if constexpr (TI == 2) { NK_A(ra.v2, aro2) NK_A(ra.v3, aro3) }
 #undef NK_A
-#define NK_B(V, KO, CV)                                                                      \
-    if (quad && CV) {                                                                        \
-        const f32x4u q = *reinterpret_cast<const f32x4u*>(X + xo[0] + KO);                   \
-        V = make_float4(q.x, q.y, q.z, q.w);                                                 \
-    } else {                                                                                 \
-        V = make_float4(CV && rv[0] ? X[xo[0] + KO] : 0.f, CV && rv[1] ? X[xo[1] + KO] : 0.f, \
-                        CV && rv[2] ? X[xo[2] + KO] : 0.f, CV && rv[3] ? X[xo[3] + KO] : 0.f); \
-    }
-        NK_B(rb.v0, ko0, cv0) NK_B(rb.v1, ko1, cv1)
-        if constexpr (TJ == 2) { NK_B(rb.v2, ko2, cv2) NK_B(rb.v3, ko3, cv3) }
+#define NK_B(V, KO) V = make_float4(X[xo[0] + KO], X[xo[1] + KO], X[xo[2] + KO], X[xo[3] + KO]);
+        NK_B(rb.v0, ko0) NK_B(rb.v1, ko1)
+        if constexpr (TJ == 2) { NK_B(rb.v2, ko2) NK_B(rb.v3, ko3) }
 #undef NK_B
+    };
+    auto mask_scalar = [&]() {
+        const bool m0_ = smask & 1, m1_ = smask & 2, m2_ = smask & 4, m3_ = smask & 8;
+        auto keep = [&](float4& q, bool k) {
+            q.x = k && m0_ ? q.x : 0.f; q.y = k && m1_ ? q.y : 0.f; q.z = k && m2_ ? q.z : 0.f; q.w = k && m3_ ? q.w : 0.f;
+        };
+        keep(ra.v0, av0); keep(ra.v1, av1);
+        if constexpr (TI == 2) { keep(ra.v2, av2); keep(ra.v3, av3); }
+        keep(rb.v0, cv0); keep(rb.v1, cv1);
+        if constexpr (TJ == 2) { keep(rb.v2, cv2); keep(rb.v3, cv3); }
     };
     auto load_both = [&](long long r0) {
         if constexpr (QUADR) load_quad(r0);
@@ -498,6 +507,7 @@ __global__ __launch_bounds__(NT, 2) void conv_bwd_kernel_kernel(BwdKArgs p) {
     if (nt > 0) {
         load_both(rbeg);
         if constexpr (QUADR) mask_quad();
+        else mask_scalar();
         stage_store<true, BM>(smem, ra, t);
         stage_store<true, BN>(smem + TA_FLOATS, rb, t);
     }
@@ -509,6 +519,7 @@ __global__ __launch_bounds__(NT, 2) void conv_bwd_kernel_kernel(BwdKArgs p) {
         __builtin_amdgcn_sched_barrier(0);
         mma_tile<true, true, TI, TJ>(cur, cur + TA_FLOATS, acc, wr, wc, lane);
         if constexpr (QUADR) mask_quad();
+        else mask_scalar();
         stage_store<true, BM>(nxt, ra, t);
         stage_store<true, BN>(nxt + TA_FLOATS, rb, t);
         __syncthreads();
@@ -612,8 +623,12 @@ struct FastFwdArgs {
     float* slabs;
 };
 
-// requires Cg % 32 == 0, stride[2] == 1, out[2] % 4 == 0, per-tensor element counts < 2^31
-template <bool ALIGNED_A, int TI>
+// requires Cg % 32 == 0, stride[2] == 1, out[2] >= 4, per-tensor element counts < 2^31.
+// Columns are (n, o0, o1, c') with the innermost output row padded to W4 = a multiple of 4, so the quad a thread stages is
+// four consecutive positions of ONE output row = one unaligned 16-byte load per staged row.  RP (out[2] % 4 != 0): the
+// last quad of a row is loaded `dup` elements earlier (so that it ends inside the input row) and shifted left by `dup`
+// behind the MFMAs; its trailing `dup` columns are dummies whose accumulators are never stored.
+template <bool ALIGNED_A, int TI, bool RP>
 __global__ __launch_bounds__(NT, 2) void conv_fwd_fast_kernel(FastFwdArgs p) {
     constexpr int TJ = 2, BM = 64 * TI, BN = 64 * TJ;
     constexpr int TA_FLOATS = tile_floats<true, BM>(), STAGE = TA_FLOATS + tile_floats<false, BN>();
@@ -637,19 +652,24 @@ __global__ __launch_bounds__(NT, 2) void conv_fwd_fast_kernel(FastFwdArgs p) {
     }
     const int grp = blockIdx.z;
     const int m0 = tm * BM, n0 = tn * BN;
-    const long long cols = (long long)g.N * g.L;
+    const int W4 = (g.out[2] + 3) & ~3, rows_per_n = g.out[0] * g.out[1];
+    const int cols = g.N * rows_per_n * W4;  // < 2^31 (checked by the host)
     const float* W = p.wp + (long long)grp * g.Mg * K;
     const float* X = p.x + (long long)grp * g.Cg * g.inplane;
 
     // this thread stages the column quad n0 + 4*cq .. +3 (one output row) for channel rows
     // (t>>5) + 8*j of every k-tile
     const int cq = t & 31, krow = t >> 5;
-    const long long c0 = (long long)n0 + cq * 4;
+    const int c0 = n0 + cq * 4;
     const bool valid = c0 < cols;
-    int xb = 0;
+    int xb = 0, dup = 0;
     if (valid) {
-        const int n = (int)(c0 / g.L), l = (int)(c0 % g.L);
-        xb = n * g.Cin * g.inplane + window_origin(g, l) + krow * g.inplane;
+        const int rowid = c0 / W4, oc = c0 - rowid * W4;
+        const int n = rowid / rows_per_n, ab = rowid - n * rows_per_n;
+        const int oa = ab / g.out[1], ob = ab - oa * g.out[1];
+        const int cs = RP ? min(oc, g.out[2] - 4) : oc;
+        dup = oc - cs;
+        xb = n * g.Cin * g.inplane + (oa * g.stride[0] * g.in[1] + ob * g.stride[1]) * g.in[2] + cs + krow * g.inplane;
     }
     const int jstep = 8 * g.inplane;
     auto gather = [&](int kt) {
@@ -668,6 +688,17 @@ __global__ __launch_bounds__(NT, 2) void conv_fwd_fast_kernel(FastFwdArgs p) {
         r.v3 = make_float4(q3.x, q3.y, q3.z, q3.w);
         return r;
     };
+    // RP: element i of the quad = element i + dup of the loaded vector (register selects, after the MFMAs)
+    const bool l1 = dup & 1, l2 = dup & 2;
+    auto shift = [&](Stage<4>& r) {
+        auto sh = [&](float4& q) {
+            float e0 = q.x, e1 = q.y, e2 = q.z, e3 = q.w;
+            e0 = l1 ? e1 : e0; e1 = l1 ? e2 : e1; e2 = l1 ? e3 : e2;
+            e0 = l2 ? e2 : e0; e1 = l2 ? e3 : e1;
+            q.x = e0; q.y = e1; q.z = e2; q.w = e3;
+        };
+        sh(r.v0); sh(r.v1); sh(r.v2); sh(r.v3);
+    };
 
     f32x16 acc[TI][TJ];
     acc_zero<TI, TJ>(acc);
@@ -677,6 +708,7 @@ __global__ __launch_bounds__(NT, 2) void conv_fwd_fast_kernel(FastFwdArgs p) {
     Stage<4> rb;
     ra = la.template load<ALIGNED_A>(t);
     rb = gather(0);
+    if constexpr (RP) shift(rb);
     stage_store<true, BM>(smem, ra, t);
     stage_store<false, BN>(smem + TA_FLOATS, rb, t);
     __syncthreads();
@@ -687,6 +719,7 @@ __global__ __launch_bounds__(NT, 2) void conv_fwd_fast_kernel(FastFwdArgs p) {
         rb = gather(it + 1);
         __builtin_amdgcn_sched_barrier(0);
         mma_tile<true, false, TI, TJ>(cur, cur + TA_FLOATS, acc, wr, wc, lane);
+        if constexpr (RP) shift(rb);
         stage_store<true, BM>(nxt, ra, t);
         stage_store<false, BN>(nxt + TA_FLOATS, rb, t);
         __syncthreads();
@@ -724,10 +757,12 @@ __global__ __launch_bounds__(NT, 2) void conv_fwd_fast_kernel(FastFwdArgs p) {
     // one (n, l) decode per owned column instead of one per element
     acc_foreach_cols<TI, TJ>(acc, wr, wc, lane,
         [&](int c) -> long long {
-            const long long cc = (long long)n0 + c;
+            const int cc = n0 + c;
             if (cc >= cols) return -1;
-            const long long n = cc / L;
-            return (n * Cout + grp * Mg) * L + (cc - n * L);
+            const int rowid = cc / W4, cpos = cc - rowid * W4;
+            if (cpos >= g.out[2]) return -1;  // padding column of the row
+            const int n = rowid / rows_per_n;
+            return ((long long)n * Cout + grp * Mg) * L + (long long)(rowid - n * rows_per_n) * g.out[2] + cpos;
         },
         [&](int r, long long base, float v) {
             const int co = m0 + r;
@@ -745,7 +780,8 @@ __global__ void conv_fwd_tail_reduce_kernel(FastFwdArgs p) {
     int tm, tn;
     tile_of_seq(p.full_blocks + tail_tile, p.tiles_m, p.tiles_n, tm, tn);
     const float* base = p.slabs + ((long long)(grp * ntail + tail_tile) * p.tail_splits) * (BM * BN);
-    const int cols = g.N * g.L;  // < 2^31 on the fast path
+    const int W4 = (g.out[2] + 3) & ~3, rows_per_n = g.out[0] * g.out[1];
+    const int cols = g.N * rows_per_n * W4;  // row-padded column space of the fast kernel, < 2^31
     // blockIdx.y: a 1024-element slice of the tile (8 rows x 128 columns); consecutive threads = consecutive columns
     const int e = blockIdx.y * 1024 + threadIdx.x;
 #pragma unroll
@@ -756,7 +792,9 @@ __global__ void conv_fwd_tail_reduce_kernel(FastFwdArgs p) {
         if (co >= g.Mg || cc >= cols) continue;
         float s = 0.f;
         for (int k = 0; k < p.tail_splits; ++k) s += base[(long long)k * (BM * BN) + ee];
-        const int n = cc / g.L, l = cc - n * g.L;
+        const int rowid = cc / W4, cpos = cc - rowid * W4;
+        if (cpos >= g.out[2]) continue;
+        const int n = rowid / rows_per_n, l = (rowid - n * rows_per_n) * g.out[2] + cpos;
         p.y[((long long)n * g.Cout + grp * g.Mg + co) * g.L + l] = g.bias ? s + g.bias[grp * g.Mg + co] : s;
     }
 }
@@ -938,14 +976,15 @@ int conv_fwd(nk_device* dev, int nd, const float* x, const int* x_shape, const f
     NK_CHECK(x && w && y, "null pointer in nk_conv_fwd");
     const int K = g.Cg * g.KK;
     const long long x_elems = (long long)g.N * g.Cin * g.inplane, y_elems = (long long)g.N * g.Cout * g.L;
-    if (g.Cg % BK == 0 && g.stride[2] == 1 && g.out[2] % 4 == 0 && x_elems < 0x7fffffffLL && y_elems < 0x7fffffffLL) {
+    const long long fcols = (long long)g.N * g.out[0] * g.out[1] * ((g.out[2] + 3) & ~3);  // row-padded column space
+    if (g.Cg % BK == 0 && g.stride[2] == 1 && g.out[2] >= 4 && x_elems < 0x7fffffffLL && y_elems < 0x7fffffffLL && fcols < 0x7fffff00LL) {
         const size_t wp_bytes = round256((size_t)g.Cout * K * sizeof(float));
         const size_t to_bytes = round256((size_t)g.KK * sizeof(int));
         const size_t tables = wp_bytes + to_bytes + round256((size_t)g.KK * sizeof(int4));
         FastFwdArgs fp{};
         const int fti = g.Mg <= 64 || (g.Mg % 128 != 0 && g.Mg % 64 == 0) ? 1 : 2;
         fp.tiles_m = (g.Mg + 64 * fti - 1) / (64 * fti);
-        fp.tiles_n = (int)(((long long)g.N * g.L + 127) / 128);
+        fp.tiles_n = (int)((fcols + 127) / 128);
         const bool al = g.Mg % (64 * fti) == 0;
         // tail balancing: tiles beyond the last whole wave of resident blocks (2 per CU) are split along k
         const int tiles = fp.tiles_m * fp.tiles_n, slots = 2 * dev->num_cus, nkt = K / BK;
@@ -983,10 +1022,19 @@ int conv_fwd(nk_device* dev, int nd, const float* x, const int* x_shape, const f
         dim3 fgrid(nblocks, 1, groups);
         rc = nk_prof_start(dev, NK_KERNEL_CONV, 2.0 * g.N * (double)g.Cout * g.L * g.Cg * g.KK);
         if (rc) return rc;
-        if (al && fti == 2) hipLaunchKernelGGL((conv_fwd_fast_kernel<true, 2>), fgrid, dim3(NT), 0, dev->compute, fp);
-        else if (al) hipLaunchKernelGGL((conv_fwd_fast_kernel<true, 1>), fgrid, dim3(NT), 0, dev->compute, fp);
-        else if (fti == 2) hipLaunchKernelGGL((conv_fwd_fast_kernel<false, 2>), fgrid, dim3(NT), 0, dev->compute, fp);
-        else hipLaunchKernelGGL((conv_fwd_fast_kernel<false, 1>), fgrid, dim3(NT), 0, dev->compute, fp);
+#define NK_LAUNCH_FF(AL, TI_, RP_) hipLaunchKernelGGL((conv_fwd_fast_kernel<AL, TI_, RP_>), fgrid, dim3(NT), 0, dev->compute, fp)
+        if (g.out[2] % 4 == 0) {
+            if (al && fti == 2) NK_LAUNCH_FF(true, 2, false);
+            else if (al) NK_LAUNCH_FF(true, 1, false);
+            else if (fti == 2) NK_LAUNCH_FF(false, 2, false);
+            else NK_LAUNCH_FF(false, 1, false);
+        } else {
+            if (al && fti == 2) NK_LAUNCH_FF(true, 2, true);
+            else if (al) NK_LAUNCH_FF(true, 1, true);
+            else if (fti == 2) NK_LAUNCH_FF(false, 2, true);
+            else NK_LAUNCH_FF(false, 1, true);
+        }
+#undef NK_LAUNCH_FF
         NK_LAUNCH_CHECK();
         if (fp.tail_splits) {
             const dim3 rgrid(tiles - fp.full_blocks, (64 * fti * 128) / 1024, groups);
@@ -1132,10 +1180,15 @@ int conv_bwd_kernel(nk_device* dev, int nd, float* dw, const int* w_shape, const
     ConvGeom g;
     int rc = make_geom(nd, x_shape, w_shape, stride, dilation, groups, &g);
     if (rc) return rc;
-    const long long R = (long long)g.N * g.L;
+    const bool quadr = g.stride[2] == 1 && g.out[2] >= 4;  // row-padded quad staging (see the kernel)
+    const long long R = quadr ? (long long)g.N * g.out[0] * g.out[1] * ((g.out[2] + 3) & ~3) : (long long)g.N * g.L;
     const int Kc = g.Cg * g.KK;
-    if ((long long)g.Cout * Kc == 0 || R == 0) return NK_OK;
+    if ((long long)g.Cout * Kc == 0) return NK_OK;
     NK_CHECK(dw && gy && x, "null pointer in nk_conv_bwd_kernel");
+    if (R == 0) {  // empty batch: the gradient is zero
+        if (assign) NK_HIP(hipMemsetAsync(dw, 0, (size_t)g.Cout * Kc * sizeof(float), dev->compute));
+        return NK_OK;
+    }
     BwdKArgs p{};
     p.g = g; p.gy = gy; p.x = x;
     const int ti = g.Mg <= 64 || (g.Mg % 128 != 0 && g.Mg % 64 == 0) ? 1 : 2;
@@ -1172,7 +1225,6 @@ int conv_bwd_kernel(nk_device* dev, int nd, float* dw, const int* w_shape, const
     const bool vec_g = (g.L % 4 == 0) && al16(gy);
     rc = nk_prof_start(dev, NK_KERNEL_CONV, 2.0 * g.N * (double)g.Cout * g.L * g.Cg * g.KK);
     if (rc) return rc;
-    const bool quadr = vec_g && g.out[2] % 4 == 0 && g.stride[2] == 1;
 #define NK_LAUNCH_BWK(VG, TI_, TJ_, Q) hipLaunchKernelGGL((conv_bwd_kernel_kernel<VG, TI_, TJ_, Q>), grid, dim3(NT), 0, dev->compute, p)
     if (quadr) {
         if (ti == 2 && tj == 2) NK_LAUNCH_BWK(true, 2, 2, true);

@@ -93,6 +93,11 @@ CONV_RANDOM = [
     ((3, 32, 6, 11), (64, 32, 2, 3), (1, 1), (1, 3), 1),          # dilation 3 on the innermost axis, width 11
     ((2, 32, 5, 6, 7), (32, 32, 2, 2, 3), (1, 1, 1), (1, 2, 1), 1),   # 3-d, width 7
     ((2, 32, 23), (32, 32, 4), (1,), (2,), 1),                    # 1-d, width 23, dilation 2
+    ((2, 32, 6, 7), (32, 32, 3, 3), (1, 1), (1, 1), 1),           # output 4 x 5: row-padded quads, 3 dummy columns per row
+    ((2, 32, 5, 5), (32, 32, 3, 3), (1, 1), (1, 1), 1),           # output 3 x 3: rows shorter than a quad -> generic paths
+    ((2, 32, 9, 12), (32, 32, 3, 3), (1, 2), (1, 1), 1),          # stride on the innermost axis: scalar gathers
+    ((3, 32, 16, 16), (64, 32, 3, 3), (1, 1), (1, 1), 1),         # output 14 x 14 (ResNet-style), row padded to 16
+    ((2, 64, 9, 9), (64, 64, 3, 3), (1, 1), (1, 1), 1),           # output 7 x 7, row padded to 8
 ]
 
 
