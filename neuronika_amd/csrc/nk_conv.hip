@@ -591,21 +591,67 @@ __global__ void conv_wp_kernel(float* __restrict__ wp, const float* __restrict__
         wp[i] = w[(co * g.Cg + ci) * g.KK + tap];
     }
 }
-// Wq[grp][ci][chunk][tap][c32] = W[grp*Mg + chunk*32 + c32][ci][tap]   (backward-input A operand).  k runs over
-// 32-channel chunks of co with the taps INSIDE a chunk: the 32 x (tile + halo) slab of the gradient that one chunk
-// needs is then re-read by all taps back to back (L2 hits) instead of once per tap across all of co (PMC: 1.7 GB
-// fetched per launch at C3 with the tap-major order, 9x the gradient).
-__global__ void conv_wq_kernel(float* __restrict__ wq, const float* __restrict__ w, ConvGeom g) {
+// ---- backward-input: stride phases ------------------------------------------------------------------------------
+// Input coordinate a (in the padded frame) receives kernel tap k only when (a - k*dil) is a multiple of the stride, i.e.
+// for the taps with k*dil = a (mod stride).  The input positions therefore fall into prod(stride) residue classes
+// ("phases"), each with its own subset of the taps; inside one phase, stepping the input coordinate by `stride` steps
+// the output coordinate by 1, so every phase is a UNIT-stride gather over the gradient: out = q + e(tap) with
+// q = (a - r)/stride and e = (r - k*dil)/stride.  Unit stride is the one-phase case (all taps, e = -k*dil).
+constexpr int MAX_PHASES = 16;
+struct BwdInPhase {
+    int first[3];   // first UNPADDED input coordinate of the class on each axis
+    int count[3];   // number of input coordinates of the class on each axis (0: the class is empty)
+    int q0[3];      // class-local coordinate i (input coordinate first + i*stride) <-> output-frame coordinate q0 + i
+    int tap_begin, ntaps;  // its taps in the phase-sorted tap table
+    int tile_begin;        // first column tile of the phase in the launch
+};
+struct BwdInPhaseTable { BwdInPhase ph[MAX_PHASES]; };
+// by-value table -> device memory (indexing a by-value array with a run-time index would spill it to scratch; a kernel
+// instead of a host copy keeps the call capturable in a hipGraph)
+__global__ void conv_phase_table_kernel(BwdInPhase* __restrict__ out, BwdInPhaseTable tbl) {
+#pragma unroll
+    for (int i = 0; i < MAX_PHASES; ++i) out[i] = tbl.ph[i];
+}
+__device__ __forceinline__ int tap_phase(const ConvGeom& g, int tap, int* kd) {
+    int rem = tap;
+    kd[2] = (rem % g.k[2]) * g.dil[2]; rem /= g.k[2];
+    kd[1] = (rem % g.k[1]) * g.dil[1];
+    kd[0] = (rem / g.k[1]) * g.dil[0];
+    return ((kd[0] % g.stride[0]) * g.stride[1] + kd[1] % g.stride[1]) * g.stride[2] + kd[2] % g.stride[2];
+}
+// tapd[position in phase order] = {d0, d1, d2, tap} with out = q - d (d = (k*dil - r)/stride >= 0);
+// tappos[tap] = {first position of its phase, taps in its phase, its rank inside the phase, phase id}
+__global__ void conv_phase_taps_kernel(int4* __restrict__ tapd, int4* __restrict__ tappos, ConvGeom g) {
+    for (int tap = blockIdx.x * blockDim.x + threadIdx.x; tap < g.KK; tap += gridDim.x * blockDim.x) {
+        int kd[3], kd2[3];
+        const int pid = tap_phase(g, tap, kd);
+        int begin = 0, cnt = 0, rank = 0;
+        for (int t2 = 0; t2 < g.KK; ++t2) {
+            const int pid2 = tap_phase(g, t2, kd2);
+            if (pid2 < pid) ++begin;
+            else if (pid2 == pid) { ++cnt; if (t2 < tap) ++rank; }
+        }
+        tapd[begin + rank] = make_int4((kd[0] - kd[0] % g.stride[0]) / g.stride[0], (kd[1] - kd[1] % g.stride[1]) / g.stride[1],
+                                       (kd[2] - kd[2] % g.stride[2]) / g.stride[2], tap);
+        tappos[tap] = make_int4(begin, cnt, rank, pid);
+    }
+}
+// Wq[grp][ci][phase][chunk][tap in phase][c32] = W[grp*Mg + chunk*32 + c32][ci][tap]   (backward-input A operand).  Per
+// phase, k runs over 32-channel chunks of co with the taps INSIDE a chunk: the 32 x (tile + halo) slab of the gradient
+// that one chunk needs is then re-read by all taps back to back (L2 hits) instead of once per tap across all of co (PMC:
+// 1.7 GB fetched per launch at C3 with the tap-major order, 9x the gradient).
+__global__ void conv_wq_kernel(float* __restrict__ wq, const float* __restrict__ w, const int4* __restrict__ tappos, ConvGeom g) {
     const long long total = (long long)g.Cout * g.Cg * g.KK;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
-         i += (long long)gridDim.x * blockDim.x) {
-        const int c32 = (int)(i % BK);
-        long long rem = i / BK;
-        const int tap = (int)(rem % g.KK); rem /= g.KK;
-        const int chunk = (int)(rem % (g.Mg / BK)); rem /= (g.Mg / BK);
-        const int ci = (int)(rem % g.Cg);
-        const int grp = (int)(rem / g.Cg);
-        wq[i] = w[((long long)(grp * g.Mg + chunk * BK + c32) * g.Cg + ci) * g.KK + tap];
+         i += (long long)gridDim.x * blockDim.x) {  // i = source index ((grp*Mg + co)*Cg + ci)*KK + tap
+        const int tap = (int)(i % g.KK);
+        long long rem = i / g.KK;
+        const int ci = (int)(rem % g.Cg); rem /= g.Cg;
+        const int co = (int)(rem % g.Mg);
+        const int grp = (int)(rem / g.Mg);
+        const int4 tp = tappos[tap];
+        const int chunk = co / BK, c32 = co - chunk * BK;
+        wq[((long long)grp * g.Cg + ci) * ((long long)g.Mg * g.KK) + (long long)g.Mg * tp.x + (chunk * tp.y + tp.z) * BK + c32] = w[i];
     }
 }
 
@@ -803,12 +849,14 @@ struct FastBwdInArgs {
     ConvGeom g;
     float* dx;
     const float* gy;
-    const float* wq;  // [groups][Cg][KK*Mg]
+    const float* wq;  // [groups][Cg][KK*Mg], phase-sorted (conv_wq_kernel)
     const int4* tapd;
-    int tiles_m, tiles_n;
+    const BwdInPhase* phases;
+    int nphase;
+    int tiles_m, tiles_n;  // tiles_n: column tiles of all phases together
 };
 
-// requires unit stride on every axis, Mg % 32 == 0, per-tensor element counts < 2^31
+// requires Mg % 32 == 0, out[2] >= 4, at most MAX_PHASES stride phases, per-tensor element counts < 2^31
 template <bool ALIGNED_A, int TI>
 __global__ __launch_bounds__(NT, 2) void conv_bwd_input_fast_kernel(FastBwdInArgs p) {
     constexpr int TJ = 2, BM = 64 * TI, BN = 64 * TJ;
@@ -818,17 +866,25 @@ __global__ __launch_bounds__(NT, 2) void conv_bwd_input_fast_kernel(FastBwdInArg
     const int t = threadIdx.x, lane = t & 63, wid = t >> 6, wr = wid >> 1, wc = wid & 1;
     int tm, tn;
     tile_coords(blockIdx.x, gridDim.x, p.tiles_m, p.tiles_n, tm, tn);
+    int pid = 0;  // the stride phase this column tile belongs to (block-uniform)
+    for (int i = 1; i < p.nphase; ++i)
+        if (tn >= p.phases[i].tile_begin) pid = i;
+    const BwdInPhase ph = p.phases[pid];
+    tn -= ph.tile_begin;
     const int grp = blockIdx.z;
     const int m0 = tm * BM, n0 = tn * BN;
-    const int K = g.Mg * g.KK, nt = K / BK;
-    // Columns are (n, a, b, c') with the innermost input row padded to W4 = a multiple of 4, so that the quad a thread
-    // stages never straddles two rows: for every tap its four gradient elements are then contiguous in memory and ONE
-    // 16-byte load per staged row serves interior and border quads alike (start clamped into the row, elements picked
-    // by a shift, outside ones masked) - no divergent scalar path.  Cost: W4/in[2] - 1 dummy columns (3.4 % at C3).
-    const int W4 = (g.uin[2] + 3) & ~3, rows_per_n = g.uin[0] * g.uin[1];
+    const int K = g.Mg * g.KK, nt = g.Mg * ph.ntaps / BK;  // K: row length of Wq; this phase reduces over Mg * ntaps
+    // Columns are the phase's input positions (n, i0, i1, i2') with the innermost extent padded to W4 = a multiple of 4,
+    // so that the quad a thread stages never straddles two rows: for every tap its four gradient elements are then
+    // contiguous in memory and ONE 16-byte load per staged row serves interior and border quads alike (start clamped
+    // into the row, elements picked by a shift, outside ones masked) - no divergent scalar path.  Cost: W4/count[2] - 1
+    // dummy columns.
+    const int W4 = (ph.count[2] + 3) & ~3, rows_per_n = ph.count[0] * ph.count[1];
     const int cols = g.N * rows_per_n * W4;  // < 2^31 (checked by the host)
-    const float* Wq = p.wq + (long long)grp * g.Cg * K;
+    const float* Wq = p.wq + (long long)grp * g.Cg * K + (long long)g.Mg * ph.tap_begin;
     const float* G = p.gy + (long long)grp * g.Mg * g.L;
+    const int4* tapd = p.tapd + ph.tap_begin;
+    const int ntaps = ph.ntaps;
 
     const int cq = t & 31, krow = t >> 5;
     const int cc0 = n0 + cq * 4;
@@ -836,11 +892,11 @@ __global__ __launch_bounds__(NT, 2) void conv_bwd_input_fast_kernel(FastBwdInArg
     int qa = 0, qb = 0, qc = 0, gbase = 0;
     if (valid) {
         const int rowid = cc0 / W4;
-        qc = cc0 - rowid * W4 + g.pad[2];
+        qc = cc0 - rowid * W4 + ph.q0[2];
         const int n = rowid / rows_per_n, ab = rowid - n * rows_per_n;
-        qa = ab / g.uin[1];
-        qb = ab - qa * g.uin[1] + g.pad[1];
-        qa += g.pad[0];
+        qa = ab / ph.count[1];
+        qb = ab - qa * ph.count[1] + ph.q0[1];
+        qa += ph.q0[0];
         gbase = n * g.Cout * g.L + krow * g.L;
     }
     const int jstep = 8 * g.L;
@@ -851,8 +907,8 @@ __global__ __launch_bounds__(NT, 2) void conv_bwd_input_fast_kernel(FastBwdInArg
     int g_sh = 0, g_c = 0;
     bool g_ok = false;
     auto gather = [&](int kt) {
-        const int chunk = kt / g.KK, tap = kt - chunk * g.KK, co0 = chunk * BK;  // taps inside a 32-channel chunk
-        const int4 d = p.tapd[tap];
+        const int chunk = kt / ntaps, tap = kt - chunk * ntaps, co0 = chunk * BK;  // taps inside a 32-channel chunk
+        const int4 d = tapd[tap];
         const float* src = G + co0 * g.L;
         const int a = qa - d.x, b = qb - d.y, c = qc - d.z;  // output coordinates of the quad's first element
         g_ok = valid && a >= 0 && a < g.out[0] && b >= 0 && b < g.out[1];
@@ -893,13 +949,15 @@ __global__ __launch_bounds__(NT, 2) void conv_bwd_input_fast_kernel(FastBwdInArg
     f32x16 acc[TI][TJ];
     acc_zero<TI, TJ>(acc);
     TileLoader<true, BM> la;
-    la.init(Wq, K, m0, 0, g.Cg, K, t);
+    la.init(Wq, K, m0, 0, g.Cg, nt * BK, t);
     Stage<BM / 32> ra;
-    ra = la.template load<ALIGNED_A>(t);
-    gather(0);
-    gather_finish();
-    stage_store<true, BM>(smem, ra, t);
-    stage_store<false, BN>(smem + TA_FLOATS, rb, t);
+    if (nt > 0) {  // a phase without taps (e.g. a 1x1 kernel with stride 2) only has zeros to write
+        ra = la.template load<ALIGNED_A>(t);
+        gather(0);
+        gather_finish();
+        stage_store<true, BM>(smem, ra, t);
+        stage_store<false, BN>(smem + TA_FLOATS, rb, t);
+    }
     __syncthreads();
     for (int it = 0; it + 1 < nt; ++it) {
         float* cur = smem + (it & 1) * STAGE;
@@ -913,21 +971,24 @@ __global__ __launch_bounds__(NT, 2) void conv_bwd_input_fast_kernel(FastBwdInArg
         stage_store<false, BN>(nxt + TA_FLOATS, rb, t);
         __syncthreads();
     }
-    {
+    if (nt > 0) {
         float* cur = smem + ((nt - 1) & 1) * STAGE;
         mma_tile<true, false, TI, TJ>(cur, cur + TA_FLOATS, acc, wr, wc, lane);
     }
     float* DX = p.dx;
     const int assign = g.assign;
     const int Cg = g.Cg, Cin = g.Cin, inplane = g.uinplane;
-    long long cbase[TJ];  // one (n, row, c') decode per owned column
+    long long cbase[TJ];  // one (n, i0, i1, i2) decode per owned column
 #pragma unroll
     for (int j = 0; j < TJ; ++j) {
         const int cc = n0 + (wc * TJ + j) * 32 + (lane & 31);
         const int rowid = cc / W4, cpos = cc - rowid * W4;
-        const int n = rowid / rows_per_n;
-        cbase[j] = (cc < cols && cpos < g.uin[2])  // not a padding column of the row
-                       ? ((long long)n * Cin + grp * Cg) * inplane + (long long)(rowid - n * rows_per_n) * g.uin[2] + cpos
+        const int n = rowid / rows_per_n, ab = rowid - n * rows_per_n;
+        const int i0 = ab / ph.count[1], i1 = ab - i0 * ph.count[1];
+        cbase[j] = (cc < cols && cpos < ph.count[2])  // not a padding column of the row
+                       ? ((long long)n * Cin + grp * Cg) * inplane +
+                             ((long long)(ph.first[0] + i0 * g.stride[0]) * g.uin[1] + ph.first[1] + i1 * g.stride[1]) * g.uin[2] +
+                             ph.first[2] + cpos * g.stride[2]
                        : -1;
     }
     NK_BWD_INPUT_EPILOGUE
@@ -1101,27 +1162,61 @@ int conv_bwd_input(nk_device* dev, int nd, float* dx, const int* x_shape, const 
     const int K = g.Mg * g.KK;
     {
         const long long x_elems = (long long)g.N * g.Cin * g.inplane, y_elems = (long long)g.N * g.Cout * g.L;
-        const bool unit_all = g.stride[0] == 1 && g.stride[1] == 1 && g.stride[2] == 1;
-        const int W4 = (g.uin[2] + 3) & ~3;
-        const long long fcols = (long long)g.N * g.uin[0] * g.uin[1] * W4;  // row-padded column space of the fast kernel
-        if (unit_all && g.Mg % BK == 0 && g.out[2] >= 4 && x_elems < 0x7fffffffLL && y_elems < 0x7fffffffLL && fcols < 0x7fffff00LL) {
+        // stride phases (see BwdInPhase): residue classes of the padded input coordinate, each with its taps and columns
+        const int nphase = g.stride[0] * g.stride[1] * g.stride[2];
+        BwdInPhaseTable tbl{};
+        long long tiles_n = 0, max_cols = 0;
+        bool fits = nphase <= MAX_PHASES && g.Mg % BK == 0 && g.out[2] >= 4 && x_elems < 0x7fffffffLL && y_elems < 0x7fffffffLL;
+        if (fits) {
+            int tap_begin = 0;
+            for (int pid = 0; pid < nphase; ++pid) {
+                BwdInPhase& ph = tbl.ph[pid];
+                const int r[3] = {pid / (g.stride[1] * g.stride[2]), (pid / g.stride[2]) % g.stride[1], pid % g.stride[2]};
+                long long cols = g.N;
+                for (int d = 0; d < 3; ++d) {
+                    const int sd = g.stride[d];
+                    ph.first[d] = ((r[d] - g.pad[d]) % sd + sd) % sd;
+                    ph.count[d] = ph.first[d] < g.uin[d] ? (g.uin[d] - ph.first[d] + sd - 1) / sd : 0;
+                    ph.q0[d] = (ph.first[d] + g.pad[d] - r[d]) / sd;
+                    cols *= d == 2 ? (ph.count[d] + 3) & ~3 : ph.count[d];
+                }
+                int ntaps = 0;
+                for (int k0 = 0; k0 < g.k[0]; ++k0)
+                    for (int k1 = 0; k1 < g.k[1]; ++k1)
+                        for (int k2 = 0; k2 < g.k[2]; ++k2)
+                            ntaps += (k0 * g.dil[0]) % g.stride[0] == r[0] && (k1 * g.dil[1]) % g.stride[1] == r[1] &&
+                                     (k2 * g.dil[2]) % g.stride[2] == r[2];
+                ph.tap_begin = tap_begin; ph.ntaps = ntaps;
+                tap_begin += ntaps;
+                ph.tile_begin = (int)tiles_n;
+                tiles_n += (cols + 127) / 128;
+                if (cols > max_cols) max_cols = cols;
+            }
+            for (int pid = nphase; pid < MAX_PHASES; ++pid) tbl.ph[pid].tile_begin = 0x7fffffff;
+            fits = max_cols < 0x7fffff00LL && tiles_n < 0x7fffffffLL;
+        }
+        if (fits) {
             const size_t wq_bytes = round256((size_t)g.Cout * g.Cg * g.KK * sizeof(float));
-            const size_t to_bytes = round256((size_t)g.KK * sizeof(int));
+            const size_t td_bytes = round256((size_t)g.KK * sizeof(int4));
+            const size_t ph_bytes = round256(sizeof(BwdInPhaseTable));
             void* wsf = nullptr;
-            rc = nk_workspace(dev, wq_bytes + to_bytes + round256((size_t)g.KK * sizeof(int4)), &wsf);
+            rc = nk_workspace(dev, wq_bytes + 2 * td_bytes + ph_bytes, &wsf);
             if (rc) return rc;
             float* wq = (float*)wsf;
-            int* tapoff = (int*)((char*)wsf + wq_bytes);
-            int4* tapd = (int4*)((char*)wsf + wq_bytes + to_bytes);
-            hipLaunchKernelGGL(conv_wq_kernel, dim3(nk_stream_grid((size_t)g.Cout * g.Cg * g.KK, 256)), dim3(256), 0, dev->compute, wq, w, g);
+            int4* tapd = (int4*)((char*)wsf + wq_bytes);
+            int4* tappos = (int4*)((char*)wsf + wq_bytes + td_bytes);
+            BwdInPhase* phases = (BwdInPhase*)((char*)wsf + wq_bytes + 2 * td_bytes);
+            hipLaunchKernelGGL(conv_phase_taps_kernel, dim3((g.KK + 63) / 64), dim3(64), 0, dev->compute, tapd, tappos, g);
             NK_LAUNCH_CHECK();
-            hipLaunchKernelGGL(conv_tapoff_kernel, dim3(1), dim3(64), 0, dev->compute, tapoff, tapd, g);
+            hipLaunchKernelGGL(conv_phase_table_kernel, dim3(1), dim3(1), 0, dev->compute, phases, tbl);
+            NK_LAUNCH_CHECK();
+            hipLaunchKernelGGL(conv_wq_kernel, dim3(nk_stream_grid((size_t)g.Cout * g.Cg * g.KK, 256)), dim3(256), 0, dev->compute, wq, w, tappos, g);
             NK_LAUNCH_CHECK();
             FastBwdInArgs fp{};
-            fp.g = g; fp.dx = dx; fp.gy = gy; fp.wq = wq; fp.tapd = tapd;
+            fp.g = g; fp.dx = dx; fp.gy = gy; fp.wq = wq; fp.tapd = tapd; fp.phases = phases; fp.nphase = nphase;
             const int fti = g.Cg <= 64 || (g.Cg % 128 != 0 && g.Cg % 64 == 0) ? 1 : 2;
             fp.tiles_m = (g.Cg + 64 * fti - 1) / (64 * fti);
-            fp.tiles_n = (int)((fcols + 127) / 128);
+            fp.tiles_n = (int)tiles_n;
             const bool al = g.Cg % (64 * fti) == 0;
             dim3 fgrid(fp.tiles_m * fp.tiles_n, 1, groups);
             rc = nk_prof_start(dev, NK_KERNEL_CONV, 2.0 * g.N * (double)g.Cout * g.L * g.Cg * g.KK);

@@ -98,6 +98,14 @@ CONV_RANDOM = [
     ((2, 32, 9, 12), (32, 32, 3, 3), (1, 2), (1, 1), 1),          # stride on the innermost axis: scalar gathers
     ((3, 32, 16, 16), (64, 32, 3, 3), (1, 1), (1, 1), 1),         # output 14 x 14 (ResNet-style), row padded to 16
     ((2, 64, 9, 9), (64, 64, 3, 3), (1, 1), (1, 1), 1),           # output 7 x 7, row padded to 8
+    ((2, 32, 13, 14), (32, 32, 3, 3), (2, 2), (1, 1), 1),         # stride 2 x 2: four backward-input phases (4/2/2/1 taps)
+    ((2, 32, 17, 19), (32, 32, 3, 3), (2, 2), (2, 2), 1),         # ... dilation 2: every tap in phase (0,0), three phases write zeros
+    ((2, 32, 12, 11), (64, 32, 1, 1), (2, 2), (1, 1), 1),         # 1 x 1 kernel, stride 2 (projection shortcut)
+    ((2, 32, 40), (32, 32, 5), (3,), (1,), 1),                    # 1-d stride 3
+    ((1, 32, 9, 10, 11), (32, 32, 2, 3, 3), (2, 2, 2), (1, 1, 1), 1),  # 3-d, 8 phases
+    ((2, 32, 21, 22), (32, 32, 5, 5), (4, 4), (1, 1), 1),         # 16 phases
+    ((2, 32, 26, 27), (32, 32, 6, 6), (5, 5), (1, 1), 1),         # 25 phases > the table: generic kernel
+    ((2, 64, 15, 17), (64, 32, 3, 3), (2, 2), (1, 1), 2),         # grouped, stride 2
 ]
 
 
@@ -139,6 +147,11 @@ CONV_PADDED = [
     ((2, 4, 20), (6, 4, 5), (3,), (3,), (2,), 1),
     ((1, 4, 6, 7, 8), (4, 2, 2, 3, 2), (0, 2, 1), (1, 2, 1), (2, 1, 2), 2),
     ((2, 32, 8, 8), (32, 32, 3, 3), (0, 0), (1, 1), (1, 1), 1),        # zero padding == the unpadded entry point
+    ((2, 32, 12, 13), (32, 32, 3, 3), (1, 1), (2, 2), (1, 1), 1),      # stride 2 with the crop: phases start at odd coordinates
+    ((2, 32, 12, 13), (32, 32, 3, 3), (2, 1), (2, 2), (1, 1), 1),
+    ((2, 32, 14, 15), (64, 32, 7, 7), (3, 3), (2, 2), (1, 1), 1),      # 7 x 7 stride 2 pad 3 (stem-shaped)
+    ((2, 32, 30), (32, 32, 4), (2,), (3,), (2,), 1),                   # 1-d stride 3 dilation 2
+    ((1, 32, 6, 7, 9), (32, 32, 3, 3, 3), (1, 1, 1), (2, 1, 2), (1, 1, 1), 1),   # 3-d mixed strides
 ]
 
 
