@@ -116,22 +116,32 @@ int scalar_bwd(nk_device* dev, float* dx, const float* g, const float* x, const 
 // LOG: log-softmax.   The max fold starts from f32::MIN (finite), softmax/mod.rs:45.
 constexpr float F32_MIN = -3.40282347e+38f;
 
+// The V quads of a lane's row slice, ALL issued before any is used: a load inside `if (c < L) { load; use; }` gets its
+// own vmcnt(0), i.e. V serialised memory round trips per row.  Lanes beyond the row re-read its first quad (a row has
+// at least one) and are masked by the `c < L` tests of the compute loops.
+template <int V>
+__device__ __forceinline__ void row_load(float4 (&v)[V], const float* __restrict__ row, int lane, int L) {
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        v[i] = *reinterpret_cast<const float4*>(row + (c < L ? c : 0));
+    }
+}
+
 template <int V, bool LOG>
-__global__ void softmax_fwd_row_kernel(const float* __restrict__ x, float* __restrict__ y, long long rows, int L) {
+__global__ __launch_bounds__(256) void softmax_fwd_row_kernel(const float* __restrict__ x, float* __restrict__ y, long long rows, int L) {
     const int lane = threadIdx.x & 63;
     const long long row = blockIdx.x * (long long)(blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= rows) return;
     const float* xr = x + row * L;
     float* yr = y + row * L;
     float4 v[V];
+    row_load<V>(v, xr, lane, L);
     float m = F32_MIN;
 #pragma unroll
     for (int i = 0; i < V; ++i) {
         const int c = (i * 64 + lane) * 4;
-        if (c < L) {
-            v[i] = *reinterpret_cast<const float4*>(xr + c);
-            m = fmaxf(m, fmaxf(fmaxf(v[i].x, v[i].y), fmaxf(v[i].z, v[i].w)));
-        }
+        if (c < L) m = fmaxf(m, fmaxf(fmaxf(v[i].x, v[i].y), fmaxf(v[i].z, v[i].w)));
     }
     m = nk_wave_max(m);
     float s = 0.f;
@@ -161,7 +171,7 @@ __global__ void softmax_fwd_row_kernel(const float* __restrict__ x, float* __res
 
 // softmax: dx += y*(g - sum(g*y)) ; log-softmax: dx += g - exp(y)*sum(g)
 template <int V, bool LOG>
-__global__ void softmax_bwd_row_kernel(int assign, float* __restrict__ dx, const float* __restrict__ g, const float* __restrict__ y,
+__global__ __launch_bounds__(256) void softmax_bwd_row_kernel(int assign, float* __restrict__ dx, const float* __restrict__ g, const float* __restrict__ y,
                                        long long rows, int L) {
     const int lane = threadIdx.x & 63;
     const long long row = blockIdx.x * (long long)(blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -169,14 +179,15 @@ __global__ void softmax_bwd_row_kernel(int assign, float* __restrict__ dx, const
     const float* gr = g + row * L;
     const float* yr = y + row * L;
     float* dr = dx + row * L;
-    float4 gv[V], yv[V];
+    float4 gv[V], yv[V], dv[V];
+    row_load<V>(gv, gr, lane, L);
+    row_load<V>(yv, yr, lane, L);
+    if (!assign) row_load<V>(dv, dr, lane, L);
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < V; ++i) {
         const int c = (i * 64 + lane) * 4;
         if (c < L) {
-            gv[i] = *reinterpret_cast<const float4*>(gr + c);
-            yv[i] = *reinterpret_cast<const float4*>(yr + c);
             if (LOG) s += (gv[i].x + gv[i].y) + (gv[i].z + gv[i].w);
             else s += (gv[i].x * yv[i].x + gv[i].y * yv[i].y) + (gv[i].z * yv[i].z + gv[i].w * yv[i].w);
         }
@@ -186,7 +197,8 @@ __global__ void softmax_bwd_row_kernel(int assign, float* __restrict__ dx, const
     for (int i = 0; i < V; ++i) {
         const int c = (i * 64 + lane) * 4;
         if (c < L) {
-            float4 d = assign ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<float4*>(dr + c);
+            float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!assign) { d.x = dv[i].x; d.y = dv[i].y; d.z = dv[i].z; d.w = dv[i].w; }
             if (LOG) {
                 d.x += gv[i].x - expf(yv[i].x) * s; d.y += gv[i].y - expf(yv[i].y) * s;
                 d.z += gv[i].z - expf(yv[i].z) * s; d.w += gv[i].w - expf(yv[i].w) * s;
@@ -266,23 +278,29 @@ __global__ void softmax_bwd_strided_kernel(int assign, float* __restrict__ dx, c
 // Philox mask, dropout — scores are read once, probs / out written once.  MASK: 0 = no dropout
 // (eval / p == 0: out = probs), 1 = Bernoulli mask, 2 = p == 1 (out = 0).
 template <int V, int MASK, bool STORE_NOISE>
-__global__ void attn_probs_fwd_kernel(const float* __restrict__ s, float* __restrict__ probs, float* __restrict__ out,
+__global__ __launch_bounds__(256) void attn_probs_fwd_kernel(const float* __restrict__ s, float* __restrict__ probs, float* __restrict__ out,
                                       float* __restrict__ noise, long long rows, int L, float scale, float keep,
                                       float dscale, unsigned long long seed, unsigned long long offset) {
+    // No fma contraction: which products get fused depends on the instantiation (MASK / RECOMP / ...), and the stored-
+    // probabilities and recomputed-probabilities paths must produce the same bits; it is also what the reference's
+    // separately rounded node-by-node arithmetic does.
+#pragma clang fp contract(off)
     const int lane = threadIdx.x & 63;
     const long long row = blockIdx.x * (long long)(blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= rows) return;
     const long long rb = row * L;
     float4 v[V];
+    row_load<V>(v, s + rb, lane, L);
     float m = F32_MIN;
 #pragma unroll
     for (int i = 0; i < V; ++i) {
         const int c = (i * 64 + lane) * 4;
         if (c < L) {
-            float4 x = *reinterpret_cast<const float4*>(s + rb + c);
-            x.x *= scale; x.y *= scale; x.z *= scale; x.w *= scale;   // Multiplication node
-            v[i] = x;
-            m = fmaxf(m, fmaxf(fmaxf(x.x, x.y), fmaxf(x.z, x.w)));
+            // Multiplication node: a separately ROUNDED product (no fma with the `- m` below) - the reference's node
+            // boundary, and what keeps this kernel and the recomputing backward kernel bit-identical
+            v[i].x = __fmul_rn(v[i].x, scale); v[i].y = __fmul_rn(v[i].y, scale);
+            v[i].z = __fmul_rn(v[i].z, scale); v[i].w = __fmul_rn(v[i].w, scale);
+            m = fmaxf(m, fmaxf(fmaxf(v[i].x, v[i].y), fmaxf(v[i].z, v[i].w)));
         }
     }
     m = nk_wave_max(m);
@@ -292,7 +310,8 @@ __global__ void attn_probs_fwd_kernel(const float* __restrict__ s, float* __rest
         const int c = (i * 64 + lane) * 4;
         if (c < L) {
             float4 e;
-            e.x = expf(v[i].x - m); e.y = expf(v[i].y - m); e.z = expf(v[i].z - m); e.w = expf(v[i].w - m);
+            e.x = expf(__fsub_rn(v[i].x, m)); e.y = expf(__fsub_rn(v[i].y, m));
+            e.z = expf(__fsub_rn(v[i].z, m)); e.w = expf(__fsub_rn(v[i].w, m));
             sum += (e.x + e.y) + (e.z + e.w);
             v[i] = e;
         }
@@ -325,25 +344,32 @@ __global__ void attn_probs_fwd_kernel(const float* __restrict__ s, float* __rest
 // RECOMP: `probs` holds the SCORES; the probabilities are recomputed with the forward kernel's exact sequence
 // (scale, wave max, expf, wave sum, divide) instead of being read back - the forward then never writes them.
 template <int V, int MASK, bool LOAD_NOISE, bool RECOMP>
-__global__ void attn_probs_bwd_kernel(float* __restrict__ ds, const float* __restrict__ g, const float* __restrict__ probs,
+__global__ __launch_bounds__(256) void attn_probs_bwd_kernel(float* __restrict__ ds, const float* __restrict__ g, const float* __restrict__ probs,
                                       const float* __restrict__ noise, long long rows, int L, float scale, float keep,
                                       unsigned long long seed, unsigned long long offset, int assign) {
+    // No fma contraction: which products get fused depends on the instantiation (MASK / RECOMP / ...), and the stored-
+    // probabilities and recomputed-probabilities paths must produce the same bits; it is also what the reference's
+    // separately rounded node-by-node arithmetic does.
+#pragma clang fp contract(off)
     const int lane = threadIdx.x & 63;
     const long long row = blockIdx.x * (long long)(blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= rows) return;
     const long long rb = row * L;
     const uint2 key = make_uint2((unsigned)seed, (unsigned)(seed >> 32));
-    float4 gp[V], y[V];
+    float4 gp[V], y[V], nzv[V], dv[V];
+    row_load<V>(y, probs + rb, lane, L);  // probabilities, or the scores they are recomputed from
+    row_load<V>(gp, g + rb, lane, L);
+    if (MASK == 1 && LOAD_NOISE) row_load<V>(nzv, noise + rb, lane, L);
+    if (!assign) row_load<V>(dv, ds + rb, lane, L);
     if (RECOMP) {
         float m = F32_MIN;
 #pragma unroll
         for (int i = 0; i < V; ++i) {
             const int c = (i * 64 + lane) * 4;
             if (c < L) {
-                float4 x = *reinterpret_cast<const float4*>(probs + rb + c);
-                x.x *= scale; x.y *= scale; x.z *= scale; x.w *= scale;
-                y[i] = x;
-                m = fmaxf(m, fmaxf(fmaxf(x.x, x.y), fmaxf(x.z, x.w)));
+                y[i].x = __fmul_rn(y[i].x, scale); y[i].y = __fmul_rn(y[i].y, scale);   // as in the forward kernel
+                y[i].z = __fmul_rn(y[i].z, scale); y[i].w = __fmul_rn(y[i].w, scale);
+                m = fmaxf(m, fmaxf(fmaxf(y[i].x, y[i].y), fmaxf(y[i].z, y[i].w)));
             }
         }
         m = nk_wave_max(m);
@@ -353,7 +379,8 @@ __global__ void attn_probs_bwd_kernel(float* __restrict__ ds, const float* __res
             const int c = (i * 64 + lane) * 4;
             if (c < L) {
                 float4 e;
-                e.x = expf(y[i].x - m); e.y = expf(y[i].y - m); e.z = expf(y[i].z - m); e.w = expf(y[i].w - m);
+                e.x = expf(__fsub_rn(y[i].x, m)); e.y = expf(__fsub_rn(y[i].y, m));
+                e.z = expf(__fsub_rn(y[i].z, m)); e.w = expf(__fsub_rn(y[i].w, m));
                 sum += (e.x + e.y) + (e.z + e.w);
                 y[i] = e;
             }
@@ -370,11 +397,10 @@ __global__ void attn_probs_bwd_kernel(float* __restrict__ ds, const float* __res
     for (int i = 0; i < V; ++i) {
         const int c = (i * 64 + lane) * 4;
         if (c < L) {
-            float4 gv = *reinterpret_cast<const float4*>(g + rb + c);
-            if (!RECOMP) y[i] = *reinterpret_cast<const float4*>(probs + rb + c);
+            float4 gv = gp[i];
             if (MASK == 1) {                                                                   // DropoutBackward
                 float4 nz;
-                if (LOAD_NOISE) nz = *reinterpret_cast<const float4*>(noise + rb + c);
+                if (LOAD_NOISE) nz = nzv[i];
                 else {
                     const unsigned long long ctr = (unsigned long long)(rb + c) / 4 + offset;
                     const uint4 r = philox4x32_10(make_uint4((unsigned)ctr, (unsigned)(ctr >> 32), 0u, 0u), key);
@@ -391,7 +417,8 @@ __global__ void attn_probs_bwd_kernel(float* __restrict__ ds, const float* __res
     for (int i = 0; i < V; ++i) {
         const int c = (i * 64 + lane) * 4;
         if (c < L) {
-            float4 d = assign ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<float4*>(ds + rb + c);
+            float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!assign) { d.x = dv[i].x; d.y = dv[i].y; d.z = dv[i].z; d.w = dv[i].w; }
             d.x += (y[i].x * (gp[i].x - dot)) * scale;   // SoftmaxBackward then MultiplicationBackwardLeft
             d.y += (y[i].y * (gp[i].y - dot)) * scale;
             d.z += (y[i].z * (gp[i].z - dot)) * scale;
