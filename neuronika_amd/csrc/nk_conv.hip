@@ -90,7 +90,12 @@ struct FwdArgs {
     int tiles_m, tiles_n;
 };
 
-template <bool ALIGNED_A, int TI>
+// QUADV: unit stride on the innermost axis and out[2] % 4 == 0 - the four columns a thread stages are neighbours in one
+// output row for EVERY thread, so a staged row is one unaligned 16-byte load; otherwise four scalar loads.  Either way the
+// staging is branch-free: loads are unconditional at addresses clamped into the tensor, the masks (k beyond K, columns
+// beyond the batch) are applied after the MFMAs, and the koff entries of a k-tile are fetched one k-tile ahead so that the
+// gathers never wait for their own offsets.
+template <bool ALIGNED_A, int TI, bool QUADV>
 __global__ __launch_bounds__(NT, 2) void conv_fwd_kernel(FwdArgs p) {
     constexpr int TJ = 2, BM = 64 * TI, BN = 64 * TJ;
     constexpr int TA_FLOATS = tile_floats<true, BM>(), STAGE = TA_FLOATS + tile_floats<false, BN>();
@@ -123,26 +128,35 @@ __global__ __launch_bounds__(NT, 2) void conv_fwd_kernel(FwdArgs p) {
         NK_COL(0, b0, v0) NK_COL(1, b1, v1) NK_COL(2, b2, v2) NK_COL(3, b3, v3)
 #undef NK_COL
     }
-    // the four columns are neighbours in one output row (unit stride): one 16-B load per k
-    const bool quad = v3 && b1 == b0 + 1 && b2 == b0 + 2 && b3 == b0 + 3;
+    int offn0, offn1, offn2, offn3;  // koff of the rows of the k-tile staged NEXT
+    auto load_off = [&](int k0) {
+        const int k = k0 + krow;
+        offn0 = p.koff[min(k, K - 1)]; offn1 = p.koff[min(k + 8, K - 1)];
+        offn2 = p.koff[min(k + 16, K - 1)]; offn3 = p.koff[min(k + 24, K - 1)];
+    };
+    Stage<4> rb;
+    int kbase = 0;  // first k of the tile in rb
     auto gather = [&](int k0) {
-        Stage<4> r;
-#define NK_ROW(j, V)                                                                  \
-    {                                                                                 \
-        const int k = k0 + krow + 8 * j;                                              \
-        const bool kv = k < K;                                                        \
-        const int off = kv ? p.koff[k] : 0;                                           \
-        if (quad) {                                                                   \
-            const f32x4u q = kv ? *reinterpret_cast<const f32x4u*>(X + b0 + off) : f32x4u{0.f, 0.f, 0.f, 0.f}; \
-            V = make_float4(q.x, q.y, q.z, q.w);                                      \
-        } else {                                                                      \
-            V = make_float4(kv && v0 ? X[b0 + off] : 0.f, kv && v1 ? X[b1 + off] : 0.f, \
-                            kv && v2 ? X[b2 + off] : 0.f, kv && v3 ? X[b3 + off] : 0.f); \
-        }                                                                             \
-    }
-        NK_ROW(0, r.v0) NK_ROW(1, r.v1) NK_ROW(2, r.v2) NK_ROW(3, r.v3)
-#undef NK_ROW
-        return r;
+        kbase = k0;
+        const int o0 = offn0, o1 = offn1, o2 = offn2, o3 = offn3;
+        if constexpr (QUADV) {
+#define NK_LDU(V, O) { const f32x4u q = *reinterpret_cast<const f32x4u*>(X + b0 + O); V = make_float4(q.x, q.y, q.z, q.w); }
+            NK_LDU(rb.v0, o0) NK_LDU(rb.v1, o1) NK_LDU(rb.v2, o2) NK_LDU(rb.v3, o3)
+#undef NK_LDU
+        } else {
+#define NK_LDS(V, O) V = make_float4(X[b0 + O], X[b1 + O], X[b2 + O], X[b3 + O]);
+            NK_LDS(rb.v0, o0) NK_LDS(rb.v1, o1) NK_LDS(rb.v2, o2) NK_LDS(rb.v3, o3)
+#undef NK_LDS
+        }
+        load_off(k0 + BK);
+    };
+    auto gather_finish = [&]() {  // after the MFMAs
+        pin_regs(rb.v0); pin_regs(rb.v1); pin_regs(rb.v2); pin_regs(rb.v3);
+        const int k = kbase + krow;
+        auto keep = [&](float4& q, bool kv) {
+            q.x = kv && v0 ? q.x : 0.f; q.y = kv && v1 ? q.y : 0.f; q.z = kv && v2 ? q.z : 0.f; q.w = kv && v3 ? q.w : 0.f;
+        };
+        keep(rb.v0, k < K); keep(rb.v1, k + 8 < K); keep(rb.v2, k + 16 < K); keep(rb.v3, k + 24 < K);
     };
 
     f32x16 acc[TI][TJ];
@@ -150,9 +164,10 @@ __global__ __launch_bounds__(NT, 2) void conv_fwd_kernel(FwdArgs p) {
     TileLoader<true, BM> la;
     la.init(W, K, m0, 0, g.Mg, K, t);
     Stage<BM / 32> ra;
-    Stage<4> rb;
     ra = la.template load<ALIGNED_A>(t);
-    rb = gather(0);
+    load_off(0);
+    gather(0);
+    gather_finish();
     stage_store<true, BM>(smem, ra, t);
     stage_store<false, BN>(smem + TA_FLOATS, rb, t);
     __syncthreads();
@@ -160,9 +175,10 @@ __global__ __launch_bounds__(NT, 2) void conv_fwd_kernel(FwdArgs p) {
         float* cur = smem + (it & 1) * STAGE;
         float* nxt = smem + ((it + 1) & 1) * STAGE;
         ra = la.template load<ALIGNED_A>(t);
-        rb = gather((it + 1) * BK);
+        gather((it + 1) * BK);
         __builtin_amdgcn_sched_barrier(0);
         mma_tile<true, false, TI, TJ>(cur, cur + TA_FLOATS, acc, wr, wc, lane);
+        gather_finish();
         stage_store<true, BM>(nxt, ra, t);
         stage_store<false, BN>(nxt + TA_FLOATS, rb, t);
         __syncthreads();
@@ -277,37 +293,49 @@ __global__ __launch_bounds__(NT, 2) void conv_bwd_input_kernel(BwdInArgs p) {
         NK_COL(2, gb2, pa2, pb2, pc2, v2) NK_COL(3, gb3, pa3, pb3, pc3, v3)
 #undef NK_COL
     }
-    // the four columns are neighbours in one input row of one sample
-    const bool rowquad = UNIT_STRIDE && v3 && gb3 == gb0 && pa3 == pa0 && pb3 == pb0 && pc3 == pc0 + 3;
-    auto one = [&](const int4 kt, bool kv, long long gb, int pa, int pb, int pc, bool v) -> float {
+    // Branch-free staging: the ktab entries of a k-tile are fetched one k-tile ahead, the 16 gradient elements a thread
+    // stages per k-tile are loaded unconditionally (offset 0 when the (column, tap) pair has no output position) and the
+    // validity bits are applied after the MFMAs.
+    int4 ktn0, ktn1, ktn2, ktn3;  // ktab rows of the k-tile staged NEXT
+    auto load_kt = [&](int k0) {
+        const int k = k0 + krow;
+        ktn0 = p.ktab[min(k, K - 1)]; ktn1 = p.ktab[min(k + 8, K - 1)];
+        ktn2 = p.ktab[min(k + 16, K - 1)]; ktn3 = p.ktab[min(k + 24, K - 1)];
+    };
+    Stage<4> rb;
+    unsigned okbits = 0;  // bit 4*j + i: element (row j, column i) of rb is a real gradient element
+    auto elem = [&](const int4 kt, bool kv, long long gb, int pa, int pb, int pc, bool v, bool& ok) -> long long {
         int a = pa - kt.y, b = pb - kt.z, c = pc - kt.w;
-        bool ok = kv && v && a >= 0 && b >= 0 && c >= 0;
+        ok = kv && v && a >= 0 && b >= 0 && c >= 0;
         if (!UNIT_STRIDE) {
             ok = ok && (a % g.stride[0] == 0) && (b % g.stride[1] == 0) && (c % g.stride[2] == 0);
             a /= g.stride[0]; b /= g.stride[1]; c /= g.stride[2];
         }
         ok = ok && a < g.out[0] && b < g.out[1] && c < g.out[2];
-        return ok ? G[gb + kt.x + (a * g.out[1] + b) * g.out[2] + c] : 0.f;
+        return ok ? gb + kt.x + (a * g.out[1] + b) * g.out[2] + c : 0;
     };
     auto gather = [&](int k0) {
-        Stage<4> r;
-#define NK_ROW(j, V)                                                                    \
+        unsigned bits = 0;
+#define NK_ROW(j, V, KT)                                                                \
     {                                                                                   \
-        const int k = k0 + krow + 8 * j;                                                \
-        const bool kv = k < K;                                                          \
-        const int4 kt = kv ? p.ktab[k] : make_int4(0, 0, 0, 0);                         \
-        const int a = pa0 - kt.y, b = pb0 - kt.z, c = pc0 - kt.w;                       \
-        if (rowquad && kv && a >= 0 && a < g.out[0] && b >= 0 && b < g.out[1] && c >= 0 && c + 3 < g.out[2]) { \
-            const f32x4u q = *reinterpret_cast<const f32x4u*>(G + gb0 + kt.x + (a * g.out[1] + b) * g.out[2] + c); \
-            V = make_float4(q.x, q.y, q.z, q.w);                                        \
-        } else {                                                                        \
-            V = make_float4(one(kt, kv, gb0, pa0, pb0, pc0, v0), one(kt, kv, gb1, pa1, pb1, pc1, v1), \
-                            one(kt, kv, gb2, pa2, pb2, pc2, v2), one(kt, kv, gb3, pa3, pb3, pc3, v3)); \
-        }                                                                               \
+        const bool kv = k0 + krow + 8 * j < K;                                          \
+        bool o0, o1, o2, o3;                                                            \
+        const long long e0 = elem(KT, kv, gb0, pa0, pb0, pc0, v0, o0), e1 = elem(KT, kv, gb1, pa1, pb1, pc1, v1, o1), \
+                        e2 = elem(KT, kv, gb2, pa2, pb2, pc2, v2, o2), e3 = elem(KT, kv, gb3, pa3, pb3, pc3, v3, o3); \
+        V = make_float4(G[e0], G[e1], G[e2], G[e3]);                                    \
+        bits |= ((o0 ? 1u : 0u) | (o1 ? 2u : 0u) | (o2 ? 4u : 0u) | (o3 ? 8u : 0u)) << (4 * j); \
     }
-        NK_ROW(0, r.v0) NK_ROW(1, r.v1) NK_ROW(2, r.v2) NK_ROW(3, r.v3)
+        NK_ROW(0, rb.v0, ktn0) NK_ROW(1, rb.v1, ktn1) NK_ROW(2, rb.v2, ktn2) NK_ROW(3, rb.v3, ktn3)
 #undef NK_ROW
-        return r;
+        okbits = bits;
+        load_kt(k0 + BK);
+    };
+    auto gather_finish = [&]() {  // after the MFMAs
+        pin_regs(rb.v0); pin_regs(rb.v1); pin_regs(rb.v2); pin_regs(rb.v3);
+        auto keep = [&](float4& q, unsigned m) {
+            q.x = (m & 1u) ? q.x : 0.f; q.y = (m & 2u) ? q.y : 0.f; q.z = (m & 4u) ? q.z : 0.f; q.w = (m & 8u) ? q.w : 0.f;
+        };
+        keep(rb.v0, okbits); keep(rb.v1, okbits >> 4); keep(rb.v2, okbits >> 8); keep(rb.v3, okbits >> 12);
     };
 
     f32x16 acc[TI][TJ];
@@ -315,9 +343,10 @@ __global__ __launch_bounds__(NT, 2) void conv_bwd_input_kernel(BwdInArgs p) {
     TileLoader<true, BM> la;
     la.init(Wt, K, m0, 0, g.Cg, K, t);
     Stage<BM / 32> ra;
-    Stage<4> rb;
     ra = la.template load<ALIGNED_A>(t);
-    rb = gather(0);
+    load_kt(0);
+    gather(0);
+    gather_finish();
     stage_store<true, BM>(smem, ra, t);
     stage_store<false, BN>(smem + TA_FLOATS, rb, t);
     __syncthreads();
@@ -325,9 +354,10 @@ __global__ __launch_bounds__(NT, 2) void conv_bwd_input_kernel(BwdInArgs p) {
         float* cur = smem + (it & 1) * STAGE;
         float* nxt = smem + ((it + 1) & 1) * STAGE;
         ra = la.template load<ALIGNED_A>(t);
-        rb = gather((it + 1) * BK);
+        gather((it + 1) * BK);
         __builtin_amdgcn_sched_barrier(0);
         mma_tile<true, false, TI, TJ>(cur, cur + TA_FLOATS, acc, wr, wc, lane);
+        gather_finish();
         stage_store<true, BM>(nxt, ra, t);
         stage_store<false, BN>(nxt + TA_FLOATS, rb, t);
         __syncthreads();
@@ -1121,10 +1151,19 @@ int conv_fwd(nk_device* dev, int nd, const float* x, const int* x_shape, const f
     dim3 grid(p.tiles_m * p.tiles_n, 1, groups);
     rc = nk_prof_start(dev, NK_KERNEL_CONV, 2.0 * g.N * (double)g.Cout * g.L * g.Cg * g.KK);
     if (rc) return rc;
-    if (aligned_a && ti == 2) hipLaunchKernelGGL((conv_fwd_kernel<true, 2>), grid, dim3(NT), 0, dev->compute, p);
-    else if (aligned_a) hipLaunchKernelGGL((conv_fwd_kernel<true, 1>), grid, dim3(NT), 0, dev->compute, p);
-    else if (ti == 2) hipLaunchKernelGGL((conv_fwd_kernel<false, 2>), grid, dim3(NT), 0, dev->compute, p);
-    else hipLaunchKernelGGL((conv_fwd_kernel<false, 1>), grid, dim3(NT), 0, dev->compute, p);
+#define NK_LAUNCH_FG(AL, TI_, QV) hipLaunchKernelGGL((conv_fwd_kernel<AL, TI_, QV>), grid, dim3(NT), 0, dev->compute, p)
+    if (g.stride[2] == 1 && g.out[2] % 4 == 0) {  // every staged column quad lies in one output row
+        if (aligned_a && ti == 2) NK_LAUNCH_FG(true, 2, true);
+        else if (aligned_a) NK_LAUNCH_FG(true, 1, true);
+        else if (ti == 2) NK_LAUNCH_FG(false, 2, true);
+        else NK_LAUNCH_FG(false, 1, true);
+    } else {
+        if (aligned_a && ti == 2) NK_LAUNCH_FG(true, 2, false);
+        else if (aligned_a) NK_LAUNCH_FG(true, 1, false);
+        else if (ti == 2) NK_LAUNCH_FG(false, 2, false);
+        else NK_LAUNCH_FG(false, 1, false);
+    }
+#undef NK_LAUNCH_FG
     NK_LAUNCH_CHECK();
     return nk_prof_stop(dev);
 }

@@ -226,6 +226,13 @@ __device__ __forceinline__ void acc_foreach_cols(const f32x16 (&acc)[TI][TJ], in
     }
 }
 
+// Pins the point where loaded registers may first be touched: an empty asm that "modifies" them.  Masks / selects written
+// after it cannot be hoisted above it by the optimiser (they are pure, and __builtin_amdgcn_sched_barrier only constrains
+// the machine scheduler), so the wait for the loads lands behind whatever precedes the pin (the MFMA block).  Only where
+// the ISA shows the hoisting: a pin is a full wait at one point and costs 2-4 % where the compiler already interleaves the
+// progressive waits and the selects with the MFMA tail by itself (measured on the fast conv kernels).
+__device__ __forceinline__ void pin_regs(float4& q) { asm volatile("" : "+v"(q.x), "+v"(q.y), "+v"(q.z), "+v"(q.w)); }
+
 // Index-passing forms: f(i, j, e, row, col, value) / fe(i, j, e, row, ctx, value) with i, j, e compile-time constants after
 // unrolling, so an epilogue can keep per-element state in a register array filled by a FIRST walk (all loads issued) and
 // consumed by a SECOND walk (stores).  A one-walk read-modify-write (`*q = f(*q)`) or a bias load between stores
