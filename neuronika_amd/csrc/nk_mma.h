@@ -87,14 +87,16 @@ struct TileLoader {
     const float* base;  // &X[tile origin] for the current k-tile (wave-uniform)
     long long kstep;    // elements to advance per k-tile
     unsigned o0, o1, o2, o3;
-    // slow-path state
+    // guarded-path state (problems that are not tile / 16-byte aligned)
     const float* X;
     long long ld;
     int row0, rows, kend, k0;
+    bool interior;  // every row of the tile exists (block-uniform): whole k-tiles take unaligned 16-byte loads
 
     __device__ __forceinline__ void init(const float* X_, long long ld_, int row0_, int k0_, int rows_,
                                          int kend_, int t) {
         X = X_; ld = ld_; row0 = row0_; rows = rows_; kend = kend_; k0 = k0_;
+        interior = row0_ + R <= rows_;
         base = KC ? X_ + (long long)row0_ * ld_ + k0_ : X_ + (long long)k0_ * ld_ + row0_;
         kstep = KC ? BK : (long long)BK * ld_;
         o0 = off(t, ld_); o1 = off(t + NT, ld_); o2 = off(t + 2 * NT, ld_); o3 = off(t + 3 * NT, ld_);
@@ -128,6 +130,15 @@ struct TileLoader {
                 r.v3 = *reinterpret_cast<const float4*>(base + o3);
             }
             base += kstep;
+        } else if (interior && k0 + BK <= kend) {
+            // ragged problem, but this tile and this k-tile are whole: 16-byte loads that only need 4-byte alignment
+            // (an odd leading dimension or base pointer costs a few split cache lines, not the 32 guarded scalar loads)
+#define NK_LDU(V, O) { const f32x4u q = *reinterpret_cast<const f32x4u*>(base + O); V = make_float4(q.x, q.y, q.z, q.w); }
+            NK_LDU(r.v0, o0) NK_LDU(r.v1, o1)
+            if constexpr (R == 128) { NK_LDU(r.v2, o2) NK_LDU(r.v3, o3) }
+#undef NK_LDU
+            base += kstep;
+            k0 += BK;
         } else {
             r.v0 = guarded(t);
             r.v1 = guarded(t + NT);
@@ -135,6 +146,7 @@ struct TileLoader {
                 r.v2 = guarded(t + 2 * NT);
                 r.v3 = guarded(t + 3 * NT);
             }
+            base += kstep;
             k0 += BK;
         }
         return r;
