@@ -19,6 +19,7 @@ SHAPES = [
     ("3x3 s1 256->256 @14", (128, 256, 16, 16), (256, 256, 3, 3), (1, 1), (1, 1), 1),
     ("3x3 s1 512->512 @7", (128, 512, 9, 9), (512, 512, 3, 3), (1, 1), (1, 1), 1),
     ("depthwise-ish g=32 3x3 128->128 @28", (128, 128, 30, 30), (128, 4, 3, 3), (1, 1), (1, 1), 32),
+    ("depthwise 3x3 256 ch @28", (128, 256, 30, 30), (256, 1, 3, 3), (1, 1), (1, 1), 256),
     ("1-d k=9 64->64 L=4096", (64, 64, 4104), (64, 64, 9), (1,), (1,), 1),
 ]
 only = sys.argv[1:] and sys.argv[1]

@@ -1024,6 +1024,209 @@ __global__ __launch_bounds__(NT, 2) void conv_bwd_input_fast_kernel(FastBwdInArg
     NK_BWD_INPUT_EPILOGUE
 }
 
+// =================================================================================================
+// Direct kernels for FEW channels per group (depthwise and small grouped convolutions).  With Mg or Cg of a handful an
+// implicit GEMM fills 4 of the 64 rows of an MFMA tile (measured 2-4 TFLOP/s at 4 channels per group); the work per
+// output element is only Cg * prod(k) multiply-adds, so the pass is HBM-bound and one thread per element with the taps in
+// registers / L1 is the right shape.  Accumulation order: k = (ci, kernel idx) ascending, the reference's im2col order.
+// =================================================================================================
+constexpr int DIRECT_MAX_CH = 16;  // both Cin/g and Cout/g at most this many
+
+// Block = 256 positions of ONE (sample, channel) plane, so the channel - and with it every weight address - is
+// block-uniform: the weights come through scalar loads, the only vector loads are the activations.
+// A thread owns PT positions 256 apart: the tap loops have run-time bounds and do not unroll, so one position per thread is
+// one dependent load -> fma chain per iteration (latency-bound: 277 us for 12.8 M outputs x 36 taps); PT independent chains
+// per iteration share the scalar weight load and keep PT activations in flight.
+// y[n][co][l] = sum_{ci, tap} w[co][ci][tap] * x[n][grp*Cg + ci][origin(l) + tap]  (+ bias[co])
+// TK1 x TK2: compile-time extents of the two innermost kernel axes (0 = run-time): the tap loops then unroll and a whole
+// channel's TK1*TK2*PT activations are in flight at once instead of PT.
+template <int PT, int TK1, int TK2>
+__global__ __launch_bounds__(256) void conv_direct_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              float* __restrict__ y, ConvGeom g) {
+    const int K1 = TK1 ? TK1 : g.k[1], K2 = TK2 ? TK2 : g.k[2];
+    const int nc = blockIdx.x, co = nc % g.Cout, n = nc / g.Cout, grp = co / g.Mg;
+    const int l0 = blockIdx.y * (256 * PT) + threadIdx.x;
+    const float* xp = x + ((long long)n * g.Cin + (long long)grp * g.Cg) * g.inplane;
+    int org[PT];
+    float acc[PT];
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+        const int l = l0 + 256 * i;
+        org[i] = window_origin(g, l < g.L ? l : 0);  // positions beyond the plane recompute position 0 and are not stored
+        acc[i] = 0.f;
+    }
+    const float* ws = w + (long long)co * g.Cg * g.KK;
+    for (int ci = 0; ci < g.Cg; ++ci) {
+        const float* xc = xp + (long long)ci * g.inplane;
+        const float* wc = ws + ci * g.KK;
+        for (int k0 = 0; k0 < g.k[0]; ++k0)
+#pragma unroll
+            for (int k1 = 0; k1 < K1; ++k1) {
+                const int roff = (k0 * g.dil[0] * g.in[1] + k1 * g.dil[1]) * g.in[2];
+                const float* wr = wc + (k0 * K1 + k1) * K2;
+#pragma unroll
+                for (int k2 = 0; k2 < K2; ++k2) {
+                    const float wv = wr[k2];
+                    const int off = roff + k2 * g.dil[2];
+#pragma unroll
+                    for (int i = 0; i < PT; ++i) acc[i] = fmaf(wv, xc[org[i] + off], acc[i]);
+                }
+            }
+    }
+    const float bv = g.bias ? g.bias[co] : 0.f;
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+        const int l = l0 + 256 * i;
+        if (l < g.L) y[(long long)nc * g.L + l] = g.bias ? acc[i] + bv : acc[i];
+    }
+}
+
+// dx[n][grp*Cg + ci][pos] (+)= sum_{co in group, tap} w[co][ci][tap] * gy[n][co][(pos + pad - tap*dil) / stride]
+template <bool UNIT_STRIDE, int PT, int TK1, int TK2>
+__global__ __launch_bounds__(256) void conv_direct_bwd_input_kernel(float* __restrict__ dx, const float* __restrict__ gy,
+                                                                    const float* __restrict__ w, ConvGeom g) {
+    const int K1 = TK1 ? TK1 : g.k[1], K2 = TK2 ? TK2 : g.k[2];
+    const int nc = blockIdx.x, cabs = nc % g.Cin, n = nc / g.Cin, grp = cabs / g.Cg, ci = cabs - grp * g.Cg;
+    const int p0 = blockIdx.y * (256 * PT) + threadIdx.x;
+    int pa[PT], pb[PT], pc[PT];
+    float acc[PT];
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+        int pos = p0 + 256 * i;
+        pos = pos < g.uinplane ? pos : 0;
+        pc[i] = pos % g.uin[2] + g.pad[2]; pos /= g.uin[2];
+        pb[i] = pos % g.uin[1] + g.pad[1];
+        pa[i] = pos / g.uin[1] + g.pad[0];
+        acc[i] = 0.f;
+    }
+    const float* gs = gy + ((long long)n * g.Cout + (long long)grp * g.Mg) * g.L;
+    for (int m = 0; m < g.Mg; ++m) {
+        const float* gc = gs + (long long)m * g.L;
+        const float* wc = w + ((long long)(grp * g.Mg + m) * g.Cg + ci) * g.KK;
+        for (int k0 = 0; k0 < g.k[0]; ++k0) {
+            int ra[PT];  // output coordinate on axis 0, or -1 when this tap row has none for the position
+#pragma unroll
+            for (int i = 0; i < PT; ++i) {
+                int a = pa[i] - k0 * g.dil[0];
+                bool ok = a >= 0;
+                if (!UNIT_STRIDE) { ok = ok && a % g.stride[0] == 0; a /= g.stride[0]; }
+                ra[i] = ok && a < g.out[0] ? a : -1;
+            }
+#pragma unroll
+            for (int k1 = 0; k1 < K1; ++k1) {
+                const float* wr = wc + (k0 * K1 + k1) * K2;
+                int rbase[PT];  // offset of the gradient row, or -1
+#pragma unroll
+                for (int i = 0; i < PT; ++i) {
+                    int b = pb[i] - k1 * g.dil[1];
+                    bool ok = ra[i] >= 0 && b >= 0;
+                    if (!UNIT_STRIDE) { ok = ok && b % g.stride[1] == 0; b /= g.stride[1]; }
+                    rbase[i] = ok && b < g.out[1] ? (ra[i] * g.out[1] + b) * g.out[2] : -1;
+                }
+#pragma unroll
+                for (int k2 = 0; k2 < K2; ++k2) {
+                    const float wv = wr[k2];
+#pragma unroll
+                    for (int i = 0; i < PT; ++i) {  // branch-free: a clamped (always valid) address, the product masked
+                        int c = pc[i] - k2 * g.dil[2];
+                        bool ok = rbase[i] >= 0 && c >= 0;
+                        if (!UNIT_STRIDE) { ok = ok && c % g.stride[2] == 0; c /= g.stride[2]; }
+                        ok = ok && c < g.out[2];
+                        const float gv = gc[ok ? rbase[i] + c : 0];
+                        acc[i] = fmaf(wv, ok ? gv : 0.f, acc[i]);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+        const int pos = p0 + 256 * i;
+        if (pos < g.uinplane) {
+            const long long o = (long long)nc * g.uinplane + pos;
+            dx[o] = g.assign ? acc[i] : dx[o] + acc[i];
+        }
+    }
+}
+
+// slab[split][co][ci][tap] = sum over the split's samples and all l of gy[n][co][l] * x[n][grp*Cg + ci][origin(l) + tap]:
+// one block per (co, ci, tap); a thread keeps its output positions (one window decode each) and walks the samples;
+// fixed-order block reduction, conv_dw_reduce_kernel sums the splits in order.
+__global__ __launch_bounds__(256) void conv_direct_bwd_kernel_kernel(float* __restrict__ slabs, const float* __restrict__ gy,
+                                                                     const float* __restrict__ x, ConvGeom g, int n_per_split) {
+    __shared__ float red[256];
+    const int e = blockIdx.x;  // (co*Cg + ci)*KK + tap
+    const int tap = e % g.KK, cc = e / g.KK, ci = cc % g.Cg, co = cc / g.Cg, grp = co / g.Mg;
+    int rem = tap;
+    const int k2 = rem % g.k[2]; rem /= g.k[2];
+    const int k1 = rem % g.k[1], k0 = rem / g.k[1];
+    const int toff = (k0 * g.dil[0] * g.in[1] + k1 * g.dil[1]) * g.in[2] + k2 * g.dil[2];
+    const int nbeg = blockIdx.y * n_per_split, nend = min(g.N, nbeg + n_per_split);
+    const long long gstep = (long long)g.Cout * g.L, xstep = (long long)g.Cin * g.inplane;
+    float acc = 0.f;
+    for (int l = threadIdx.x; l < g.L; l += 256) {
+        const float* gp = gy + ((long long)nbeg * g.Cout + co) * g.L + l;
+        const float* xp = x + ((long long)nbeg * g.Cin + (long long)grp * g.Cg + ci) * g.inplane + window_origin(g, l) + toff;
+#pragma unroll 8
+        for (int n = nbeg; n < nend; ++n) {  // unrolled: eight independent load pairs in flight per trip
+            acc = fmaf(*gp, *xp, acc);
+            gp += gstep; xp += xstep;
+        }
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int sft = 128; sft > 0; sft >>= 1) {
+        if ((int)threadIdx.x < sft) red[threadIdx.x] += red[threadIdx.x + sft];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) slabs[(long long)blockIdx.y * gridDim.x + e] = red[0];
+}
+
+// Same, all TK1*TK2 taps of one (co, ci) pair in one block (k[0] == 1): the gradient element is loaded once per (n, l) and
+// the TK1*TK2 activations around it come from L1, instead of one block per tap re-reading both planes.
+template <int TK1, int TK2>
+__global__ __launch_bounds__(256) void conv_direct_bwd_kernel_taps_kernel(float* __restrict__ slabs, const float* __restrict__ gy,
+                                                                          const float* __restrict__ x, ConvGeom g, int n_per_split) {
+    constexpr int KK = TK1 * TK2;
+    __shared__ float red[256];
+    const int cc = blockIdx.x, ci = cc % g.Cg, co = cc / g.Cg, grp = co / g.Mg;
+    const int nbeg = blockIdx.y * n_per_split, nend = min(g.N, nbeg + n_per_split);
+    const long long gstep = (long long)g.Cout * g.L, xstep = (long long)g.Cin * g.inplane;
+    float acc[KK];
+#pragma unroll
+    for (int k = 0; k < KK; ++k) acc[k] = 0.f;
+    for (int l = threadIdx.x; l < g.L; l += 256) {
+        const float* gp = gy + ((long long)nbeg * g.Cout + co) * g.L + l;
+        const float* xp = x + ((long long)nbeg * g.Cin + (long long)grp * g.Cg + ci) * g.inplane + window_origin(g, l);
+#pragma unroll 2
+        for (int n = nbeg; n < nend; ++n) {
+            const float gv = *gp;
+#pragma unroll
+            for (int k1 = 0; k1 < TK1; ++k1)
+#pragma unroll
+                for (int k2 = 0; k2 < TK2; ++k2)
+                    acc[k1 * TK2 + k2] = fmaf(gv, xp[k1 * g.dil[1] * g.in[2] + k2 * g.dil[2]], acc[k1 * TK2 + k2]);
+            gp += gstep; xp += xstep;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < KK; ++k) {  // fixed-order block reduction, one tap at a time
+        red[threadIdx.x] = acc[k];
+        __syncthreads();
+        for (int sft = 128; sft > 0; sft >>= 1) {
+            if ((int)threadIdx.x < sft) red[threadIdx.x] += red[threadIdx.x + sft];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) slabs[((long long)blockIdx.y * gridDim.x + cc) * KK + k] = red[0];
+        __syncthreads();
+    }
+}
+
+bool use_direct(const ConvGeom& g) {
+    return g.Cg <= DIRECT_MAX_CH && g.Mg <= DIRECT_MAX_CH && (long long)g.N * g.Cout < 0x7fffffffLL &&
+           (long long)g.N * g.Cin < 0x7fffffffLL && (long long)g.Cout * g.Cg * g.KK < 0x7fffffffLL;
+}
+
 // ---- host side ------------------------------------------------------------------------------------
 int make_geom(int nd, const int* x_shape, const int* w_shape, const int* stride, const int* dilation, int groups,
               ConvGeom* out) {
@@ -1065,6 +1268,21 @@ int conv_fwd(nk_device* dev, int nd, const float* x, const int* x_shape, const f
     g.bias = bias;
     if ((long long)g.N * g.Cout * g.L == 0) return NK_OK;
     NK_CHECK(x && w && y, "null pointer in nk_conv_fwd");
+    if (use_direct(g)) {
+        const long long total = (long long)g.N * g.Cout * g.L;
+        rc = nk_prof_start(dev, NK_KERNEL_CONV, 2.0 * g.N * (double)g.Cout * g.L * g.Cg * g.KK);
+        if (rc) return rc;
+        (void)total;
+        const int pt = g.L >= 512 ? 4 : 1;
+        const dim3 dgrid((unsigned)(g.N * g.Cout), (unsigned)((g.L + 256 * pt - 1) / (256 * pt)));
+#define NK_DF(PT_, A, B) hipLaunchKernelGGL((conv_direct_fwd_kernel<PT_, A, B>), dgrid, dim3(256), 0, dev->compute, x, w, y, g)
+        if (g.k[1] == 3 && g.k[2] == 3) { if (pt == 4) NK_DF(4, 3, 3); else NK_DF(1, 3, 3); }
+        else if (g.k[1] == 5 && g.k[2] == 5) { if (pt == 4) NK_DF(4, 5, 5); else NK_DF(1, 5, 5); }
+        else { if (pt == 4) NK_DF(4, 0, 0); else NK_DF(1, 0, 0); }
+#undef NK_DF
+        NK_LAUNCH_CHECK();
+        return nk_prof_stop(dev);
+    }
     const int K = g.Cg * g.KK;
     const long long x_elems = (long long)g.N * g.Cin * g.inplane, y_elems = (long long)g.N * g.Cout * g.L;
     const long long fcols = (long long)g.N * g.out[0] * g.out[1] * ((g.out[2] + 3) & ~3);  // row-padded column space
@@ -1198,6 +1416,26 @@ int conv_bwd_input(nk_device* dev, int nd, float* dx, const int* x_shape, const 
         return NK_OK;
     }
     NK_CHECK(dx && gy && w, "null pointer in nk_conv_bwd_input");
+    if (use_direct(g)) {
+        const long long total = (long long)g.N * g.Cin * g.uinplane;
+        rc = nk_prof_start(dev, NK_KERNEL_CONV, 2.0 * g.N * (double)g.Cout * g.L * g.Cg * g.KK);
+        if (rc) return rc;
+        (void)total;
+        const bool unit = g.stride[0] == 1 && g.stride[1] == 1 && g.stride[2] == 1;
+        const int pt = g.uinplane >= 512 ? 4 : 1;
+        const dim3 dgrid((unsigned)(g.N * g.Cin), (unsigned)((g.uinplane + 256 * pt - 1) / (256 * pt)));
+#define NK_DI(U, PT_, A, B) hipLaunchKernelGGL((conv_direct_bwd_input_kernel<U, PT_, A, B>), dgrid, dim3(256), 0, dev->compute, dx, gy, w, g)
+        if (g.k[1] == 3 && g.k[2] == 3) {
+            if (unit) { if (pt == 4) NK_DI(true, 4, 3, 3); else NK_DI(true, 1, 3, 3); }
+            else { if (pt == 4) NK_DI(false, 4, 3, 3); else NK_DI(false, 1, 3, 3); }
+        } else {
+            if (unit) { if (pt == 4) NK_DI(true, 4, 0, 0); else NK_DI(true, 1, 0, 0); }
+            else { if (pt == 4) NK_DI(false, 4, 0, 0); else NK_DI(false, 1, 0, 0); }
+        }
+#undef NK_DI
+        NK_LAUNCH_CHECK();
+        return nk_prof_stop(dev);
+    }
     const int K = g.Mg * g.KK;
     {
         const long long x_elems = (long long)g.N * g.Cin * g.inplane, y_elems = (long long)g.N * g.Cout * g.L;
@@ -1322,6 +1560,34 @@ int conv_bwd_kernel(nk_device* dev, int nd, float* dw, const int* w_shape, const
     if (R == 0) {  // empty batch: the gradient is zero
         if (assign) NK_HIP(hipMemsetAsync(dw, 0, (size_t)g.Cout * Kc * sizeof(float), dev->compute));
         return NK_OK;
+    }
+    if (use_direct(g)) {  // few channels per group: one block per (co, ci, tap) dot product, split over (n, l)
+        const long long dw_n = (long long)g.Cout * Kc;
+        const bool taps_in_regs = g.k[0] == 1 && ((g.k[1] == 3 && g.k[2] == 3) || (g.k[1] == 5 && g.k[2] == 5));
+        const long long dblocks = taps_in_regs ? (long long)g.Cout * g.Cg : dw_n;
+        long long dsplits = (4096 + dblocks - 1) / dblocks;  // ~4096 blocks, split over the samples
+        if (dsplits > g.N) dsplits = g.N;
+        if (dsplits < 1) dsplits = 1;
+        const int rps = (int)((g.N + dsplits - 1) / dsplits);  // samples per split
+        dsplits = (g.N + rps - 1) / rps;
+        void* wsd = nullptr;
+        rc = nk_workspace(dev, (size_t)dsplits * dw_n * sizeof(float), &wsd);
+        if (rc) return rc;
+        rc = nk_prof_start(dev, NK_KERNEL_CONV, 2.0 * g.N * (double)g.Cout * g.L * g.Cg * g.KK);
+        if (rc) return rc;
+        const dim3 tgrid((unsigned)(g.Cout * g.Cg), (unsigned)dsplits);  // all taps of a (co, ci) pair per block
+        if (g.k[0] == 1 && g.k[1] == 3 && g.k[2] == 3)
+            hipLaunchKernelGGL((conv_direct_bwd_kernel_taps_kernel<3, 3>), tgrid, dim3(256), 0, dev->compute, (float*)wsd, gy, x, g, rps);
+        else if (g.k[0] == 1 && g.k[1] == 5 && g.k[2] == 5)
+            hipLaunchKernelGGL((conv_direct_bwd_kernel_taps_kernel<5, 5>), tgrid, dim3(256), 0, dev->compute, (float*)wsd, gy, x, g, rps);
+        else
+            hipLaunchKernelGGL(conv_direct_bwd_kernel_kernel, dim3((unsigned)dw_n, (unsigned)dsplits), dim3(256), 0, dev->compute,
+                               (float*)wsd, gy, x, g, rps);
+        NK_LAUNCH_CHECK();
+        hipLaunchKernelGGL(conv_dw_reduce_kernel, dim3((unsigned)((dw_n + 63) / 64)), dim3(256), 0, dev->compute, dw, (const float*)wsd,
+                           dw_n, (int)dsplits, assign);
+        NK_LAUNCH_CHECK();
+        return nk_prof_stop(dev);
     }
     BwdKArgs p{};
     p.g = g; p.gy = gy; p.x = x;

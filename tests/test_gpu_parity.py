@@ -106,6 +106,23 @@ CONV_RANDOM = [
     ((2, 32, 21, 22), (32, 32, 5, 5), (4, 4), (1, 1), 1),         # 16 phases
     ((2, 32, 26, 27), (32, 32, 6, 6), (5, 5), (1, 1), 1),         # 25 phases > the table: generic kernel
     ((2, 64, 15, 17), (64, 32, 3, 3), (2, 2), (1, 1), 2),         # grouped, stride 2
+    # 17..31 channels per group: the generic implicit-GEMM kernels (<= 16 goes to the direct kernels, multiples of 32 to the fast ones)
+    ((2, 20, 10, 14), (24, 20, 3, 3), (1, 1), (1, 1), 1),         # output 8 x 12: vector gathers (QUADV)
+    ((2, 20, 10, 13), (24, 20, 3, 3), (1, 1), (1, 1), 1),         # output 8 x 11: scalar gathers
+    ((2, 20, 11, 13), (24, 20, 3, 3), (2, 2), (1, 1), 1),         # strided: divisibility tests in the backward-input gather
+    ((2, 3, 20, 22), (64, 3, 5, 5), (2, 2), (1, 1), 1),           # stem-shaped: 3 input channels, 64 output channels
+    ((3, 40, 9, 9), (40, 20, 3, 3), (1, 1), (1, 1), 2),           # grouped, 20 channels per group both ways
+    ((2, 24, 30), (20, 24, 4), (2,), (2,), 1),                    # 1-d strided dilated
+    # direct kernels (few channels per group)
+    ((2, 8, 9, 10), (8, 1, 3, 3), (1, 1), (1, 1), 8),             # depthwise
+    ((2, 8, 9, 10), (16, 1, 3, 3), (2, 1), (1, 2), 8),            # depthwise, channel multiplier 2, stride / dilation
+    ((3, 12, 14), (6, 4, 5), (2,), (2,), 3),                      # 1-d grouped
+    ((1, 6, 5, 6, 7), (6, 2, 2, 3, 2), (1, 2, 1), (2, 1, 2), 3),  # 3-d grouped
+    ((2, 16, 12, 12), (16, 16, 3, 3), (1, 1), (1, 1), 1),         # 16 x 16 channels: the largest direct case
+    ((2, 8, 26, 27), (8, 1, 3, 3), (1, 1), (1, 1), 8),            # planes >= 512 positions: four positions per thread
+    ((2, 8, 49, 50), (16, 1, 3, 3), (2, 2), (1, 1), 8),           # ... strided
+    ((2, 6, 28, 30), (6, 2, 5, 5), (1, 1), (1, 1), 3),            # 5 x 5 taps unrolled
+    ((2, 6, 28, 30), (6, 2, 4, 2), (1, 1), (2, 1), 3),            # run-time kernel extents, dilation
 ]
 
 
@@ -152,6 +169,13 @@ CONV_PADDED = [
     ((2, 32, 14, 15), (64, 32, 7, 7), (3, 3), (2, 2), (1, 1), 1),      # 7 x 7 stride 2 pad 3 (stem-shaped)
     ((2, 32, 30), (32, 32, 4), (2,), (3,), (2,), 1),                   # 1-d stride 3 dilation 2
     ((1, 32, 6, 7, 9), (32, 32, 3, 3, 3), (1, 1, 1), (2, 1, 2), (1, 1, 1), 1),   # 3-d mixed strides
+    ((2, 8, 9, 10), (8, 1, 3, 3), (1, 1), (1, 1), (1, 1), 8),          # depthwise (direct kernel) with the crop
+    ((2, 8, 9, 10), (16, 1, 3, 3), (2, 1), (2, 2), (1, 1), 8),
+    ((2, 20, 9, 10), (24, 20, 3, 3), (1, 2), (1, 1), (1, 1), 1),       # generic kernel, 20 -> 24 channels
+    ((2, 20, 9, 10), (24, 20, 3, 3), (1, 1), (2, 1), (1, 1), 1),
+    ((2, 8, 24, 25), (8, 1, 3, 3), (1, 1), (1, 1), (1, 1), 8),         # direct kernel, planes >= 512 positions
+    ((2, 8, 47, 48), (8, 1, 3, 3), (1, 1), (2, 2), (1, 1), 8),
+    ((2, 6, 26, 28), (6, 2, 5, 5), (2, 2), (1, 1), (1, 1), 3),
 ]
 
 
