@@ -1043,6 +1043,7 @@ constexpr int DIRECT_MAX_CH = 16;  // both Cin/g and Cout/g at most this many
 template <int PT, int TK1, int TK2>
 __global__ __launch_bounds__(256) void conv_direct_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                               float* __restrict__ y, ConvGeom g) {
+    constexpr int UNROLL1 = TK1 ? TK1 : 1, UNROLL2 = TK2 ? TK2 : 1;  // full unroll for compile-time extents only
     const int K1 = TK1 ? TK1 : g.k[1], K2 = TK2 ? TK2 : g.k[2];
     const int nc = blockIdx.x, co = nc % g.Cout, n = nc / g.Cout, grp = co / g.Mg;
     const int l0 = blockIdx.y * (256 * PT) + threadIdx.x;
@@ -1060,11 +1061,11 @@ __global__ __launch_bounds__(256) void conv_direct_fwd_kernel(const float* __res
         const float* xc = xp + (long long)ci * g.inplane;
         const float* wc = ws + ci * g.KK;
         for (int k0 = 0; k0 < g.k[0]; ++k0)
-#pragma unroll
+#pragma unroll UNROLL1
             for (int k1 = 0; k1 < K1; ++k1) {
                 const int roff = (k0 * g.dil[0] * g.in[1] + k1 * g.dil[1]) * g.in[2];
                 const float* wr = wc + (k0 * K1 + k1) * K2;
-#pragma unroll
+#pragma unroll UNROLL2
                 for (int k2 = 0; k2 < K2; ++k2) {
                     const float wv = wr[k2];
                     const int off = roff + k2 * g.dil[2];
@@ -1085,6 +1086,7 @@ __global__ __launch_bounds__(256) void conv_direct_fwd_kernel(const float* __res
 template <bool UNIT_STRIDE, int PT, int TK1, int TK2>
 __global__ __launch_bounds__(256) void conv_direct_bwd_input_kernel(float* __restrict__ dx, const float* __restrict__ gy,
                                                                     const float* __restrict__ w, ConvGeom g) {
+    constexpr int UNROLL1 = TK1 ? TK1 : 1, UNROLL2 = TK2 ? TK2 : 1;  // full unroll for compile-time extents only
     const int K1 = TK1 ? TK1 : g.k[1], K2 = TK2 ? TK2 : g.k[2];
     const int nc = blockIdx.x, cabs = nc % g.Cin, n = nc / g.Cin, grp = cabs / g.Cg, ci = cabs - grp * g.Cg;
     const int p0 = blockIdx.y * (256 * PT) + threadIdx.x;
@@ -1112,7 +1114,7 @@ __global__ __launch_bounds__(256) void conv_direct_bwd_input_kernel(float* __res
                 if (!UNIT_STRIDE) { ok = ok && a % g.stride[0] == 0; a /= g.stride[0]; }
                 ra[i] = ok && a < g.out[0] ? a : -1;
             }
-#pragma unroll
+#pragma unroll UNROLL1
             for (int k1 = 0; k1 < K1; ++k1) {
                 const float* wr = wc + (k0 * K1 + k1) * K2;
                 int rbase[PT];  // offset of the gradient row, or -1
@@ -1123,7 +1125,7 @@ __global__ __launch_bounds__(256) void conv_direct_bwd_input_kernel(float* __res
                     if (!UNIT_STRIDE) { ok = ok && b % g.stride[1] == 0; b /= g.stride[1]; }
                     rbase[i] = ok && b < g.out[1] ? (ra[i] * g.out[1] + b) * g.out[2] : -1;
                 }
-#pragma unroll
+#pragma unroll UNROLL2
                 for (int k2 = 0; k2 < K2; ++k2) {
                     const float wv = wr[k2];
 #pragma unroll
@@ -1269,10 +1271,8 @@ int conv_fwd(nk_device* dev, int nd, const float* x, const int* x_shape, const f
     if ((long long)g.N * g.Cout * g.L == 0) return NK_OK;
     NK_CHECK(x && w && y, "null pointer in nk_conv_fwd");
     if (use_direct(g)) {
-        const long long total = (long long)g.N * g.Cout * g.L;
         rc = nk_prof_start(dev, NK_KERNEL_CONV, 2.0 * g.N * (double)g.Cout * g.L * g.Cg * g.KK);
         if (rc) return rc;
-        (void)total;
         const int pt = g.L >= 512 ? 4 : 1;
         const dim3 dgrid((unsigned)(g.N * g.Cout), (unsigned)((g.L + 256 * pt - 1) / (256 * pt)));
 #define NK_DF(PT_, A, B) hipLaunchKernelGGL((conv_direct_fwd_kernel<PT_, A, B>), dgrid, dim3(256), 0, dev->compute, x, w, y, g)
@@ -1417,10 +1417,8 @@ int conv_bwd_input(nk_device* dev, int nd, float* dx, const int* x_shape, const 
     }
     NK_CHECK(dx && gy && w, "null pointer in nk_conv_bwd_input");
     if (use_direct(g)) {
-        const long long total = (long long)g.N * g.Cin * g.uinplane;
         rc = nk_prof_start(dev, NK_KERNEL_CONV, 2.0 * g.N * (double)g.Cout * g.L * g.Cg * g.KK);
         if (rc) return rc;
-        (void)total;
         const bool unit = g.stride[0] == 1 && g.stride[1] == 1 && g.stride[2] == 1;
         const int pt = g.uinplane >= 512 ? 4 : 1;
         const dim3 dgrid((unsigned)(g.N * g.Cin), (unsigned)((g.uinplane + 256 * pt - 1) / (256 * pt)));
