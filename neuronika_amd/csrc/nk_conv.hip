@@ -1226,7 +1226,8 @@ __global__ __launch_bounds__(256) void conv_direct_bwd_kernel_taps_kernel(float*
 
 bool use_direct(const ConvGeom& g) {
     return g.Cg <= DIRECT_MAX_CH && g.Mg <= DIRECT_MAX_CH && (long long)g.N * g.Cout < 0x7fffffffLL &&
-           (long long)g.N * g.Cin < 0x7fffffffLL && (long long)g.Cout * g.Cg * g.KK < 0x7fffffffLL;
+           (long long)g.N * g.Cin < 0x7fffffffLL && (long long)g.Cout * g.Cg * g.KK < 0x7fffffffLL &&
+           g.L / 256 < 65535 && g.uinplane / 256 < 65535;  // grid.y carries the position blocks
 }
 
 // ---- host side ------------------------------------------------------------------------------------

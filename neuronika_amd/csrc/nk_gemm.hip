@@ -60,6 +60,74 @@ __global__ __launch_bounds__(NT, (min_waves<TI, TJ>())) void sgemm_kernel(GemmAr
     TileLoader<BKC, BN> lb;
     la.init(A, p.lda, m0, kbeg, p.M, kend, t);
     lb.init(B, p.ldb, n0, kbeg, p.N, kend, t);
+    // Same-box A/B at 4096^3 (benchmarks/ab_gemm.py): NT +2.9 %, NN +1.2 %, TN -1.0 % (its A operand is read k-major,
+    // the loads land early anyway); short reductions lose to the longer prologue (NT 4096x3072x1024: -2 %).  So: row-major
+    // A only, aligned problems only (the guarded loader's state does not fit next to P and Q), at least 48 k-tiles.
+#ifndef NK_AB_NO_PF2
+    constexpr bool PF2 = ALIGNED && !TA;
+#else
+    constexpr bool PF2 = false;
+#endif
+    if (PF2 && nt >= 48) {
+    // Two k-tiles of look-ahead in registers: tile it+1 (P, loaded during the previous trip) goes to LDS at the START of a
+    // trip, the loads of tile it+2 (Q) are issued in front of it and have a whole trip plus to land.  The end of a trip is
+    // then MFMAs -> barrier, instead of MFMAs -> wait for this trip's own loads -> 8 LDS writes -> barrier.  Unrolled by
+    // two so that P / Q and the LDS buffers are static (even tiles in buf0, odd tiles in buf1).
+    float* const buf0 = smem;
+    float* const buf1 = smem + STAGE;
+    Stage<BM / 32> pa, qa;
+    Stage<BN / 32> pb, qb;
+    if (nt > 0) {
+        pa = la.template load<ALIGNED>(t);
+        pb = lb.template load<ALIGNED>(t);
+        stage_store<AKC, BM>(buf0, pa, t);
+        stage_store<BKC, BN>(buf0 + TA_FLOATS, pb, t);
+    }
+    __syncthreads();
+    if (nt > 1) {  // tile 1 -> P
+        pa = la.template load<ALIGNED>(t);
+        pb = lb.template load<ALIGNED>(t);
+    }
+    int it = 0;  // invariant: tile `it` (even) is in buf0, tile it+1 in P
+    for (; it + 3 < nt; it += 2) {
+        qa = la.template load<ALIGNED>(t);  // tile it+2
+        qb = lb.template load<ALIGNED>(t);
+        stage_store<AKC, BM>(buf1, pa, t);
+        stage_store<BKC, BN>(buf1 + TA_FLOATS, pb, t);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_tile<AKC, BKC, TI, TJ>(buf0, buf0 + TA_FLOATS, acc, wr, wc, lane);
+        __syncthreads();
+        pa = la.template load<ALIGNED>(t);  // tile it+3
+        pb = lb.template load<ALIGNED>(t);
+        stage_store<AKC, BM>(buf0, qa, t);
+        stage_store<BKC, BN>(buf0 + TA_FLOATS, qb, t);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_tile<AKC, BKC, TI, TJ>(buf1, buf1 + TA_FLOATS, acc, wr, wc, lane);
+        __syncthreads();
+    }
+    const int left = nt - it;  // 0 (nt == 0), 1, 2 or 3 tiles: `it` in buf0, it+1 in P
+    if (left == 3) {
+        qa = la.template load<ALIGNED>(t);
+        qb = lb.template load<ALIGNED>(t);
+    }
+    if (left >= 2) {
+        stage_store<AKC, BM>(buf1, pa, t);
+        stage_store<BKC, BN>(buf1 + TA_FLOATS, pb, t);
+    }
+    if (left >= 1) mma_tile<AKC, BKC, TI, TJ>(buf0, buf0 + TA_FLOATS, acc, wr, wc, lane);
+    if (left >= 2) {
+        __syncthreads();
+        if (left == 3) {
+            stage_store<AKC, BM>(buf0, qa, t);
+            stage_store<BKC, BN>(buf0 + TA_FLOATS, qb, t);
+        }
+        mma_tile<AKC, BKC, TI, TJ>(buf1, buf1 + TA_FLOATS, acc, wr, wc, lane);
+        if (left == 3) {
+            __syncthreads();
+            mma_tile<AKC, BKC, TI, TJ>(buf0, buf0 + TA_FLOATS, acc, wr, wc, lane);
+        }
+    }
+    } else {
     if (nt > 0) {
         ra = la.template load<ALIGNED>(t);
         rb = lb.template load<ALIGNED>(t);
@@ -83,6 +151,8 @@ __global__ __launch_bounds__(NT, (min_waves<TI, TJ>())) void sgemm_kernel(GemmAr
     if (nt > 0) {
         float* cur = smem + ((nt - 1) & 1) * STAGE;
         mma_tile<AKC, BKC, TI, TJ>(cur, cur + TA_FLOATS, acc, wr, wc, lane);
+    }
+
     }
 
     if (p.splits > 1) {
