@@ -1,0 +1,81 @@
+"""Seeded random GEMM problems through nk_sgemm / nk_sgemm_batched: ragged and aligned shapes, leading dimensions larger
+than the rows, every layout, alpha / beta, two-level batch strides, and reduction lengths on both sides of the look-ahead
+threshold (48 k-tiles, even and odd counts) - against f64 NumPy with the contraction tolerance of test_gpu_parity."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def capi():
+    from neuronika_amd import capi as c
+    return c
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return capi().Device(0)
+
+
+def case(seed):
+    rng = np.random.default_rng(5000 + seed)
+    kind = seed % 4
+    if kind == 0:      # small ragged
+        M, N, K = (int(rng.integers(1, 300)) for _ in range(3))
+    elif kind == 1:    # aligned tiles, long reductions around the look-ahead threshold
+        M, N = 128 * int(rng.integers(1, 4)), 128 * int(rng.integers(1, 4))
+        K = 32 * int(rng.integers(44, 56))
+    elif kind == 2:    # aligned rows, ragged K (interior tiles on unaligned 16-byte loads, last k-tile guarded)
+        M, N = 64 * int(rng.integers(1, 6)), 64 * int(rng.integers(1, 6))
+        K = int(rng.integers(33, 700))
+    else:              # tall / wide
+        M, N, K = int(rng.choice([1, 7, 64, 1000])), int(rng.choice([1, 5, 64, 777])), int(rng.integers(1, 2100))
+    ta, tb = int(rng.integers(0, 2)), int(rng.integers(0, 2))
+    pad_a, pad_b, pad_c = (int(rng.choice([0, 0, 4, 3])) for _ in range(3))
+    alpha = float(rng.choice([1.0, 1.0, -0.5, 2.0]))
+    beta = float(rng.choice([0.0, 1.0, 0.25]))
+    return M, N, K, ta, tb, pad_a, pad_b, pad_c, alpha, beta
+
+
+@pytest.mark.parametrize("seed", range(120))
+def test_sgemm_random_problem(dev, seed):
+    c = capi()
+    M, N, K, ta, tb, pa, pb, pc, alpha, beta = case(seed)
+    rng = np.random.default_rng(seed)
+    ar, ac = (K, M) if ta else (M, K)
+    br, bc = (N, K) if tb else (K, N)
+    a_full = (rng.random((ar, ac + pa), dtype=np.float32) * 2 - 1)
+    b_full = (rng.random((br, bc + pb), dtype=np.float32) * 2 - 1)
+    c_full = (rng.random((M, N + pc), dtype=np.float32) * 2 - 1)
+    a, b = a_full[:, :ac], b_full[:, :bc]
+    opa, opb = (a.T if ta else a).astype(np.float64), (b.T if tb else b).astype(np.float64)
+    A, B, Cd = dev.array(a_full), dev.array(b_full), dev.array(c_full)
+    c.sgemm(dev, ta, tb, M, N, K, alpha, A, ac + pa, B, bc + pb, beta, Cd, N + pc)
+    got = Cd.numpy()
+    ref = alpha * (opa @ opb) + beta * c_full[:, :N].astype(np.float64)
+    tol = 2e-6 * K * abs(alpha) + 2e-6 * abs(beta) + 1e-6
+    assert np.abs(got[:, :N].astype(np.float64) - ref).max() <= tol
+    assert np.array_equal(got[:, N:], c_full[:, N:])            # the padding columns of C are not touched
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_sgemm_batched_random_strides(dev, seed):
+    """Two-level batch strides (outer x inner), operands addressed inside larger buffers - the per-head attention form."""
+    c = capi()
+    rng = np.random.default_rng(9000 + seed)
+    bo, bi = int(rng.integers(1, 4)), int(rng.integers(1, 5))
+    M, N, K = (int(rng.choice([1, 16, 64, 100, 128])) for _ in range(3))
+    ta, tb = int(rng.integers(0, 2)), int(rng.integers(0, 2))
+    beta = float(rng.choice([0.0, 1.0]))
+    ar, ac = (K, M) if ta else (M, K)
+    br, bc = (N, K) if tb else (K, N)
+    a = (rng.random((bo, bi, ar, ac), dtype=np.float32) * 2 - 1)
+    b = (rng.random((bo, bi, br, bc), dtype=np.float32) * 2 - 1)
+    c0 = (rng.random((bo, bi, M, N), dtype=np.float32) * 2 - 1)
+    A, B, Cd = dev.array(a), dev.array(b), dev.array(c0)
+    c.sgemm_batched(dev, ta, tb, M, N, K, 1.0, A, ac, bi * ar * ac, ar * ac, B, bc, bi * br * bc, br * bc, beta, Cd, N,
+                    bi * M * N, M * N, bo, bi)
+    opa = np.swapaxes(a, 2, 3) if ta else a
+    opb = np.swapaxes(b, 2, 3) if tb else b
+    ref = opa.astype(np.float64) @ opb.astype(np.float64) + beta * c0.astype(np.float64)
+    assert np.abs(Cd.numpy().astype(np.float64) - ref).max() <= 2e-6 * K + 3e-6
