@@ -738,7 +738,7 @@ __global__ __launch_bounds__(NT, 2) void conv_fwd_fast_kernel(FastFwdArgs p) {
     const int cq = t & 31, krow = t >> 5;
     const int c0 = n0 + cq * 4;
     const bool valid = c0 < cols;
-    int xb = 0, dup = 0;
+    int xb = krow * g.inplane, dup = 0;
     if (valid) {
         const int rowid = c0 / W4, oc = c0 - rowid * W4;
         const int n = rowid / rows_per_n, ab = rowid - n * rows_per_n;
@@ -753,11 +753,12 @@ __global__ __launch_bounds__(NT, 2) void conv_fwd_fast_kernel(FastFwdArgs p) {
         const int tap = kt / tpt, ci0 = (kt - tap * tpt) * BK;
         const float* src = X + (p.tapoff[tap] + ci0 * g.inplane);
         Stage<4> r;
-        const f32x4u z = {0.f, 0.f, 0.f, 0.f};
-        const f32x4u q0 = valid ? *reinterpret_cast<const f32x4u*>(src + xb) : z;
-        const f32x4u q1 = valid ? *reinterpret_cast<const f32x4u*>(src + xb + jstep) : z;
-        const f32x4u q2 = valid ? *reinterpret_cast<const f32x4u*>(src + xb + 2 * jstep) : z;
-        const f32x4u q3 = valid ? *reinterpret_cast<const f32x4u*>(src + xb + 3 * jstep) : z;
+        // unconditional: a quad beyond the last column (xb = krow * inplane) reads real memory and feeds accumulators that
+        // are never stored - no branch, no mask
+        const f32x4u q0 = *reinterpret_cast<const f32x4u*>(src + xb);
+        const f32x4u q1 = *reinterpret_cast<const f32x4u*>(src + xb + jstep);
+        const f32x4u q2 = *reinterpret_cast<const f32x4u*>(src + xb + 2 * jstep);
+        const f32x4u q3 = *reinterpret_cast<const f32x4u*>(src + xb + 3 * jstep);
         r.v0 = make_float4(q0.x, q0.y, q0.z, q0.w);
         r.v1 = make_float4(q1.x, q1.y, q1.z, q1.w);
         r.v2 = make_float4(q2.x, q2.y, q2.z, q2.w);
