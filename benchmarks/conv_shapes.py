@@ -41,5 +41,9 @@ for name, xs, ws, s, d, g in SHAPES:
                     ("bwd_kernel", lambda: c.conv_bwd_kernel(dev, DW, G, X, s, d, g, assign=True))):
         ms = timeit(dev, fn, 10)
         out[key] = [round(ms * 1e3, 1), round(flop / ms / 1e9, 1)]   # us, TFLOP/s
+    if g > 1 and all(v == 1 for v in s) and len(xs) == 4:  # grouped: also the module's form (zero padding 1 cropped away)
+        DU = dev.zeros((xs[0], xs[1], xs[2] - 2, xs[3] - 2))
+        ms = timeit(dev, lambda: c.conv_bwd_input(dev, DU, G, W, s, d, g, assign=True, padding=(1, 1)), 10)
+        out["bwd_input_cropped"] = [round(ms * 1e3, 1), round(flop / ms / 1e9, 1)]
     print(json.dumps(out), flush=True)
     del X, W, G, Y, DX, DW

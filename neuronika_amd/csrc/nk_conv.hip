@@ -1083,6 +1083,44 @@ __global__ __launch_bounds__(256) void conv_direct_fwd_kernel(const float* __res
     }
 }
 
+// Row-blocked forward for the common depthwise / small-group case (k[0] == 1, unit stride and dilation on the innermost
+// axis, out[2] % 4 == 0, 16-byte aligned y): a thread computes FOUR adjacent outputs of a row, so a kernel row needs one
+// 4 + TK2 - 1 element segment of the input row (one unaligned 16-byte load + TK2 - 1 scalars) instead of 4 * TK2 scalar
+// loads, and the result goes out as one 16-byte store: a third of the load instructions and half the L1 bytes per output.
+template <int TK1, int TK2>
+__global__ __launch_bounds__(256) void conv_direct_fwd_rows_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                   float* __restrict__ y, ConvGeom g) {
+    const int nc = blockIdx.x, co = nc % g.Cout, n = nc / g.Cout, grp = co / g.Mg;
+    const int qpr = g.out[2] / 4;  // quads per output row
+    const int q = blockIdx.y * 256 + threadIdx.x;
+    if (q >= g.out[1] * qpr) return;
+    const int oh = q / qpr, ow = (q - oh * qpr) * 4;
+    const float* xp = x + ((long long)n * g.Cin + (long long)grp * g.Cg) * g.inplane + (oh * g.stride[1]) * g.in[2] + ow;
+    const float* ws = w + (long long)co * g.Cg * (TK1 * TK2);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int ci = 0; ci < g.Cg; ++ci) {
+        const float* xc = xp + (long long)ci * g.inplane;
+        const float* wc = ws + ci * (TK1 * TK2);
+#pragma unroll
+        for (int k1 = 0; k1 < TK1; ++k1) {
+            const float* xr = xc + k1 * g.dil[1] * g.in[2];
+            float seg[4 + TK2 - 1];
+            const f32x4u v = *reinterpret_cast<const f32x4u*>(xr);
+            seg[0] = v.x; seg[1] = v.y; seg[2] = v.z; seg[3] = v.w;
+#pragma unroll
+            for (int j = 4; j < 4 + TK2 - 1; ++j) seg[j] = xr[j];
+#pragma unroll
+            for (int k2 = 0; k2 < TK2; ++k2) {  // same (ci, k1, k2) accumulation order as the one-output kernel
+                const float wv = wc[k1 * TK2 + k2];
+                a0 = fmaf(wv, seg[k2], a0); a1 = fmaf(wv, seg[k2 + 1], a1);
+                a2 = fmaf(wv, seg[k2 + 2], a2); a3 = fmaf(wv, seg[k2 + 3], a3);
+            }
+        }
+    }
+    if (g.bias) { const float bv = g.bias[co]; a0 += bv; a1 += bv; a2 += bv; a3 += bv; }
+    *reinterpret_cast<float4*>(y + (long long)nc * g.L + oh * g.out[2] + ow) = make_float4(a0, a1, a2, a3);
+}
+
 // dx[n][grp*Cg + ci][pos] (+)= sum_{co in group, tap} w[co][ci][tap] * gy[n][co][(pos + pad - tap*dil) / stride]
 template <bool UNIT_STRIDE, int PT, int TK1, int TK2>
 __global__ __launch_bounds__(256) void conv_direct_bwd_input_kernel(float* __restrict__ dx, const float* __restrict__ gy,
@@ -1149,6 +1187,54 @@ __global__ __launch_bounds__(256) void conv_direct_bwd_input_kernel(float* __res
             const long long o = (long long)nc * g.uinplane + pos;
             dx[o] = g.assign ? acc[i] : dx[o] + acc[i];
         }
+    }
+}
+
+// Row-blocked backward-input, same idea (unit stride on every axis, unit dilation on the innermost one, k[0] == 1,
+// uin[2] % 4 == 0, 16-byte aligned dx): four adjacent input positions share one 4 + TK2 - 1 element segment of each
+// gradient row; positions outside the gradient read a clamped address and are masked.  Same (m, k1, k2) accumulation
+// order per element as the one-position kernel.
+template <int TK1, int TK2>
+__global__ __launch_bounds__(256) void conv_direct_bwd_input_rows_kernel(float* __restrict__ dx, const float* __restrict__ gy,
+                                                                         const float* __restrict__ w, ConvGeom g) {
+    const int nc = blockIdx.x, cabs = nc % g.Cin, n = nc / g.Cin, grp = cabs / g.Cg, ci = cabs - grp * g.Cg;
+    const int qpr = g.uin[2] / 4;
+    const int q = blockIdx.y * 256 + threadIdx.x;
+    if (q >= g.uin[1] * qpr) return;
+    const int a = q / qpr, b = (q - a * qpr) * 4;
+    const int pa = a + g.pad[1], c0 = b + g.pad[2] - (TK2 - 1);  // gradient column of segment element 0
+    const float* gs = gy + ((long long)n * g.Cout + (long long)grp * g.Mg) * g.L;
+    float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
+    for (int m = 0; m < g.Mg; ++m) {
+        const float* gc = gs + (long long)m * g.L;
+        const float* wc = w + ((long long)(grp * g.Mg + m) * g.Cg + ci) * (TK1 * TK2);
+#pragma unroll
+        for (int k1 = 0; k1 < TK1; ++k1) {
+            const int ra = pa - k1 * g.dil[1];
+            const bool rowok = ra >= 0 && ra < g.out[1];
+            const float* gr = gc + (rowok ? ra : 0) * g.out[2];
+            float seg[4 + TK2 - 1];
+#pragma unroll
+            for (int j = 0; j < 4 + TK2 - 1; ++j) {
+                const int col = c0 + j;
+                const bool ok = rowok && col >= 0 && col < g.out[2];
+                const float v = gr[ok ? col : 0];
+                seg[j] = ok ? v : 0.f;
+            }
+#pragma unroll
+            for (int k2 = 0; k2 < TK2; ++k2) {
+                const float wv = wc[k1 * TK2 + k2];
+                d0 = fmaf(wv, seg[TK2 - 1 - k2], d0); d1 = fmaf(wv, seg[TK2 - k2], d1);
+                d2 = fmaf(wv, seg[TK2 + 1 - k2], d2); d3 = fmaf(wv, seg[TK2 + 2 - k2], d3);
+            }
+        }
+    }
+    float4* out = reinterpret_cast<float4*>(dx + (long long)nc * g.uinplane + a * g.uin[2] + b);
+    if (g.assign) {
+        *out = make_float4(d0, d1, d2, d3);
+    } else {
+        const float4 o = *out;
+        *out = make_float4(o.x + d0, o.y + d1, o.z + d2, o.w + d3);
     }
 }
 
@@ -1275,6 +1361,16 @@ int conv_fwd(nk_device* dev, int nd, const float* x, const int* x_shape, const f
     if (use_direct(g)) {
         rc = nk_prof_start(dev, NK_KERNEL_CONV, 2.0 * g.N * (double)g.Cout * g.L * g.Cg * g.KK);
         if (rc) return rc;
+        const bool rows_ok = g.k[0] == 1 && g.out[0] == 1 && g.stride[2] == 1 && g.dil[2] == 1 && g.out[2] % 4 == 0 && al16(y) &&
+                             ((g.k[1] == 3 && g.k[2] == 3) || (g.k[1] == 5 && g.k[2] == 5) || (g.k[1] == 1 && g.k[2] == 3));
+        if (rows_ok) {
+            const dim3 rgrid((unsigned)(g.N * g.Cout), (unsigned)((g.out[1] * (g.out[2] / 4) + 255) / 256));
+            if (g.k[1] == 3) hipLaunchKernelGGL((conv_direct_fwd_rows_kernel<3, 3>), rgrid, dim3(256), 0, dev->compute, x, w, y, g);
+            else if (g.k[1] == 5) hipLaunchKernelGGL((conv_direct_fwd_rows_kernel<5, 5>), rgrid, dim3(256), 0, dev->compute, x, w, y, g);
+            else hipLaunchKernelGGL((conv_direct_fwd_rows_kernel<1, 3>), rgrid, dim3(256), 0, dev->compute, x, w, y, g);
+            NK_LAUNCH_CHECK();
+            return nk_prof_stop(dev);
+        }
         const int pt = g.L >= 512 ? 4 : 1;
         const dim3 dgrid((unsigned)(g.N * g.Cout), (unsigned)((g.L + 256 * pt - 1) / (256 * pt)));
 #define NK_DF(PT_, A, B) hipLaunchKernelGGL((conv_direct_fwd_kernel<PT_, A, B>), dgrid, dim3(256), 0, dev->compute, x, w, y, g)
@@ -1422,6 +1518,16 @@ int conv_bwd_input(nk_device* dev, int nd, float* dx, const int* x_shape, const 
         rc = nk_prof_start(dev, NK_KERNEL_CONV, 2.0 * g.N * (double)g.Cout * g.L * g.Cg * g.KK);
         if (rc) return rc;
         const bool unit = g.stride[0] == 1 && g.stride[1] == 1 && g.stride[2] == 1;
+        const bool rows_ok = unit && g.k[0] == 1 && g.uin[0] == 1 && g.pad[0] == 0 && g.dil[2] == 1 && g.uin[2] % 4 == 0 && al16(dx) &&
+                             ((g.k[1] == 3 && g.k[2] == 3) || (g.k[1] == 5 && g.k[2] == 5) || (g.k[1] == 1 && g.k[2] == 3));
+        if (rows_ok) {
+            const dim3 rgrid((unsigned)(g.N * g.Cin), (unsigned)((g.uin[1] * (g.uin[2] / 4) + 255) / 256));
+            if (g.k[1] == 3) hipLaunchKernelGGL((conv_direct_bwd_input_rows_kernel<3, 3>), rgrid, dim3(256), 0, dev->compute, dx, gy, w, g);
+            else if (g.k[1] == 5) hipLaunchKernelGGL((conv_direct_bwd_input_rows_kernel<5, 5>), rgrid, dim3(256), 0, dev->compute, dx, gy, w, g);
+            else hipLaunchKernelGGL((conv_direct_bwd_input_rows_kernel<1, 3>), rgrid, dim3(256), 0, dev->compute, dx, gy, w, g);
+            NK_LAUNCH_CHECK();
+            return nk_prof_stop(dev);
+        }
         const int pt = g.uinplane >= 512 ? 4 : 1;
         const dim3 dgrid((unsigned)(g.N * g.Cin), (unsigned)((g.uinplane + 256 * pt - 1) / (256 * pt)));
 #define NK_DI(U, PT_, A, B) hipLaunchKernelGGL((conv_direct_bwd_input_kernel<U, PT_, A, B>), dgrid, dim3(256), 0, dev->compute, dx, gy, w, g)

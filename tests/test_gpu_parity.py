@@ -123,6 +123,10 @@ CONV_RANDOM = [
     ((2, 8, 49, 50), (16, 1, 3, 3), (2, 2), (1, 1), 8),           # ... strided
     ((2, 6, 28, 30), (6, 2, 5, 5), (1, 1), (1, 1), 3),            # 5 x 5 taps unrolled
     ((2, 6, 28, 30), (6, 2, 4, 2), (1, 1), (2, 1), 3),            # run-time kernel extents, dilation
+    ((2, 8, 14, 18), (8, 1, 3, 3), (1, 1), (1, 1), 8),            # output 12 x 16: row-blocked direct forward (4 outputs per thread)
+    ((2, 8, 30, 18), (16, 1, 3, 3), (2, 1), (2, 1), 8),           # ... strided / dilated rows
+    ((2, 6, 12, 16), (6, 2, 5, 5), (1, 1), (1, 1), 3),            # ... 5 x 5
+    ((2, 8, 18), (8, 1, 3), (1,), (1,), 8),                       # ... 1-d
 ]
 
 
@@ -176,6 +180,11 @@ CONV_PADDED = [
     ((2, 8, 24, 25), (8, 1, 3, 3), (1, 1), (1, 1), (1, 1), 8),         # direct kernel, planes >= 512 positions
     ((2, 8, 47, 48), (8, 1, 3, 3), (1, 1), (2, 2), (1, 1), 8),
     ((2, 6, 26, 28), (6, 2, 5, 5), (2, 2), (1, 1), (1, 1), 3),
+    ((2, 8, 12, 16), (8, 1, 3, 3), (1, 1), (1, 1), (1, 1), 8),         # row-blocked direct backward-input (width % 4 == 0)
+    ((2, 8, 12, 16), (8, 1, 3, 3), (2, 2), (1, 1), (2, 1), 8),         # ... dilated rows, wider padding
+    ((2, 6, 12, 16), (6, 2, 5, 5), (2, 2), (1, 1), (1, 1), 3),         # ... 5 x 5
+    ((2, 8, 20), (8, 1, 3), (1,), (1,), (1,), 8),                      # ... 1-d
+    ((2, 8, 12, 16), (16, 1, 3, 3), (0, 0), (1, 1), (1, 1), 8),        # ... no padding (borders masked)
 ]
 
 
