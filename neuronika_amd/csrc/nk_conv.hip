@@ -12,6 +12,13 @@
 //   forward     : M = Cout/g   cols = (n, out pos)   k = (ci, kernel idx)
 //   bwd-input   : M = Cin/g    cols = (n, in pos)    k = (co, kernel idx)   [W pre-transposed]
 //   bwd-kernel  : M = Cout/g   cols = (ci, kernel idx)   k = (n, out pos)   [split over k]
+// Three kernel families, chosen per call by the channel counts per group:
+//   multiples of 32  -> "fast" kernels: tap-major k (one k-tile = 32 channels of ONE kernel tap), 16-byte gathers of
+//                       row-padded column quads, stride phases in the input-gradient pass;
+//   other counts     -> "generic" kernels: offset tables fetched one k-tile ahead, scalar / vector gathers;
+//   <= 16 both ways  -> direct (non-MFMA, HBM-bound) kernels: depthwise and small grouped convolutions.
+// All staging is branch-free (unconditional loads at clamped addresses, masks applied behind the MFMAs): see DESIGN.md
+// 4.1 for what a conditional load costs.
 #include "nk_mma.h"
 
 using namespace nkmma;
