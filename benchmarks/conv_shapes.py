@@ -7,7 +7,11 @@ import sys
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from neuronika_amd import capi as c  # noqa: E402
 from benchmarks.microbench import timeit, rand  # noqa: E402
-from oracle.neuronika_oracle import conv_out_shape  # noqa: E402  (shape arithmetic only)
+
+
+def conv_out_shape(xs, ws, stride, dilation):   # utils.rs:207-237
+    return (xs[0], ws[0]) + tuple((i - d * (k - 1) - 1) // s + 1 for i, k, s, d in zip(xs[2:], ws[2:], stride, dilation))
+
 
 dev = c.Device(0)
 SHAPES = [
