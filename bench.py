@@ -1,9 +1,15 @@
 #!/usr/bin/env python3
 """Benchmark of the neuronika HIP backend on MI355X.
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 1 --steps 200 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N            # no launcher: spawns the N ranks itself (one process per GPU)
+
+`--gpus N` without a launcher's WORLD_SIZE in the environment makes this process the launcher: it
+checks that the node has N GPUs (error otherwise, never a silent single-rank run), spawns N
+workers of itself with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, relays rank
+0's JSON line and fails if any rank fails.
 
 Default workload = BASELINE.json's metric, "training-step samples/sec (fwd+bwd+allreduce)", on
 the configuration it is quoted on (configs[3], "C4"): a 3-layer MLP, hidden = 4096,
@@ -18,7 +24,14 @@ the dominant kernel (the f32 MFMA GEMM): achieved = algorithmic flop of the GEMM
 the timed region / their summed HIP-event durations (events on the compute stream, recorded
 inside the library around every launch).  `cpu_baseline` = the CPU oracle (a NumPy/OpenBLAS
 restatement of the reference's ndarray path; the Rust reference cannot be built here) timed
-on this host on a bounded sample, rank 0, N = 1 only.
+on this host on a bounded sample, rank 0, N = 1 only, in the two variants BASELINE.md section 4
+names: "reference-default" (1 BLAS thread for mm / mm_t = the single-threaded matrixmultiply
+sgemm of the default features, neuronika-variable/Cargo.toml:25-29; all cores for the
+convolution, which is rayon batch-parallel, node/convolution/mod.rs:110-122) and
+"reference+blas" (OpenBLAS on all cores = the `blas` feature).  The default line also carries
+`matmul_4096` (the second half of BASELINE.json's metric: C2 at N = 4096, fwd+bwd, TFLOP/s and
+fraction of the f32 MFMA peak), `rccl_ranks`, `allreduce_bytes_per_step` and `exposed_comm_ms`
+(step time minus the step time of the same loop with the gradient exchange switched off).
 
 Other workloads (parity-test configurations, not the headline): --workload matmul | conv | mha.
 """
@@ -27,6 +40,9 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import secrets
+import socket
+import subprocess
 import sys
 import time
 
@@ -45,8 +61,8 @@ HBM_PEAK = 8.0e12
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="mlp", choices=["mlp", "matmul", "conv", "mha"])
     ap.add_argument("--hidden", type=int, default=4096)
     ap.add_argument("--batch", type=int, default=4096, help="rows per GPU (mlp)")
@@ -68,8 +84,8 @@ class Dist:
         self.rank, self.world, self.local = self.rv.rank, self.rv.world, self.rv.local
         if "NK_BENCH_FORCE_DEVICE" in os.environ:   # debugging aid: several ranks on one GPU (RCCL permitting)
             self.local = int(os.environ["NK_BENCH_FORCE_DEVICE"])
-        if want != self.world and self.rank == 0:
-            print(f"[bench] --gpus {want} but WORLD_SIZE={self.world}: running on {self.world} process(es)", file=sys.stderr)
+        if want != self.world:   # never degrade silently: a record with the wrong n_gpus is worthless
+            raise SystemExit(f"[bench] --gpus {want} but the launcher started WORLD_SIZE={self.world} rank(s)")
 
     def barrier(self):
         self.rv.barrier()
@@ -123,28 +139,134 @@ def read_traffic(kernel):
         return None
 
 
-def cpu_baseline_mlp(hidden, sample_rows):
-    """The CPU oracle timed on this host: one full training step (fwd+bwd) of the same MLP on
-    `sample_rows` rows, 1 BLAS thread = the reference's default (single-threaded matrixmultiply
-    sgemm for mm/mm_t, neuronika-variable/Cargo.toml:25-29)."""
+# ------------------------------------------------------------------------------------------------
+# cpu_baseline: the CPU oracle on this host's cores (reported beside the GPU number, not a target)
+# ------------------------------------------------------------------------------------------------
+def _time_cpu(fn, min_s, max_reps):
+    """Whole repetitions of `fn` until >= min_s seconds of CPU work (a bounded sample); the first repetition (page
+    faults, BLAS thread start-up) is dropped when others follow."""
+    ts, t_start = [], time.perf_counter()
+    while True:
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+        if time.perf_counter() - t_start >= min_s or len(ts) >= max_reps:
+            break
+    if len(ts) > 1:
+        ts = ts[1:]
+    return len(ts), sum(ts)
+
+
+def _blas_threads():
+    from threadpoolctl import threadpool_info
+    n = [i.get("num_threads", 1) for i in threadpool_info() if i.get("user_api") == "blas"]
+    return max(n) if n else 1
+
+
+def cpu_baseline(unit, units_per_rep, fn, what, default_all_cores=False, min_s=6.0, scaled_from=None):
+    """Both BASELINE.md section-4 variants of the oracle closure `fn` (one repetition = `units_per_rep` units).
+    The flat fields describe the reference's DEFAULT build for this path; `variants` holds both."""
     from threadpoolctl import threadpool_limits
+    out = []
+    for name, limit in (("1 BLAS thread", 1), ("all cores (OpenBLAS)", None)):
+        with threadpool_limits(limits=limit):
+            cores = _blas_threads()
+            reps, dt = _time_cpu(fn, min_s, 64)
+        out.append({"value": round(reps * units_per_rep / dt, 3), "unit": unit, "cores": cores, "kind": "port",
+                    "sample": f"{reps} x {what}, NumPy/OpenBLAS oracle, {name}, {dt:.2f} s; host has {os.cpu_count()} cores"})
+    out[0]["variant"] = "reference+blas feature off (single-threaded matrixmultiply sgemm)"
+    out[1]["variant"] = "reference+blas (OpenBLAS, all cores)"
+    main = dict(out[1] if default_all_cores else out[0])
+    main["variant"] = "reference-default: " + ("convolution is rayon batch-parallel over all cores" if default_all_cores
+                                                else "mm / mm_t run on one thread")
+    if scaled_from:
+        main["scaled_from"] = scaled_from
+    main["variants"] = out
+    return main
+
+
+def cpu_baseline_mlp(hidden, rows):
     from oracle import neuronika_oracle as O
     rng = np.random.default_rng(0)
     k = 1.0 / np.sqrt(hidden)
-    x, t = rng.random((sample_rows, hidden), dtype=np.float32), rng.random((sample_rows, hidden), dtype=np.float32)
+    x, t = rng.random((rows, hidden), dtype=np.float32), rng.random((rows, hidden), dtype=np.float32)
     params = [((rng.random((hidden, hidden), dtype=np.float32) * 2 - 1) * k, (rng.random(hidden, dtype=np.float32) * 2 - 1) * k) for _ in range(3)]
-    with threadpool_limits(limits=1):
-        O.mlp_step(x[:64], t[:64], params)  # warm-up
-        reps, t0 = 0, time.perf_counter()
-        while True:                           # whole steps until >= 10 s of CPU work (bounded sample of the same workload)
-            O.mlp_step(x, t, params)
-            reps += 1
-            dt = time.perf_counter() - t0
-            if dt >= 10.0 or reps >= 8:
-                break
-    return {"value": round(reps * sample_rows / dt, 2), "unit": "samples/s", "cores": 1, "kind": "port",
-            "sample": f"{reps} fwd+bwd step(s) of the same 3x Linear({hidden},{hidden}) MLP on {sample_rows} of the 4096 rows, "
-                      f"NumPy/OpenBLAS oracle, 1 BLAS thread, {dt:.2f} s; host has {os.cpu_count()} cores"}
+    return cpu_baseline("samples/s", rows, lambda: O.mlp_step(x, t, params),
+                        f"fwd+bwd step of the same 3x Linear({hidden},{hidden}) MLP on all {rows} rows of the batch")
+
+
+def cpu_baseline_matmul(n):
+    from oracle import neuronika_oracle as O
+    mk = lambda s: np.random.default_rng(s).random((n, n), dtype=np.float32)
+    A, B, G = mk(0), mk(1), mk(2)
+    Cm, dA, dB = np.zeros_like(A), np.zeros_like(A), np.zeros_like(A)
+
+    def fn():
+        O.mm_forward(A, B, Cm); O.mm_backward_left(dA, G, B); O.mm_backward_right(dB, G, A)
+    return cpu_baseline("TFLOP/s", 6.0 * n ** 3 / 1e12, fn, f"mm forward + both backward GEMMs at N={n}")
+
+
+def cpu_baseline_conv(n_sample):
+    from oracle import neuronika_oracle as O
+    x = np.random.default_rng(0).random((n_sample, 64, 56, 56), dtype=np.float32)
+    k = 1.0 / np.sqrt(576.0)
+    w = ((np.random.default_rng(1).random((128, 64, 3, 3), dtype=np.float32) * 2 - 1) * k).astype(np.float32)
+    g = np.random.default_rng(2).random((n_sample, 128, 56, 56), dtype=np.float32)
+
+    def fn():
+        xp = np.zeros((n_sample, 64, 58, 58), np.float32)
+        O.pad_constant_forward(x, xp, (1, 1), 0.0)
+        y = np.zeros((n_sample, 128, 56, 56), np.float32)
+        O.convolution_forward(xp, w, y, (1, 1), (1, 1), 1)
+        dxp, dw = np.zeros_like(xp), np.zeros_like(w)
+        O.convolution_backward_input(dxp, g, w, (1, 1), (1, 1), 1)
+        O.convolution_backward_kernel(dw, g, xp, (1, 1), (1, 1), 1)
+    return cpu_baseline("samples/s", n_sample, fn, f"pad + conv fwd + bwd-input + bwd-kernel on {n_sample} of the 128 samples",
+                        default_all_cores=True, min_s=5.0, scaled_from=f"{n_sample} of 128 samples (per-sample work is independent)")
+
+
+def cpu_baseline_mha(b_sample, S, d, H, p):
+    from oracle import neuronika_oracle as O
+    rng = np.random.default_rng(0)
+    x = rng.random((b_sample * S, d), dtype=np.float32)
+    k = 1.0 / np.sqrt(d)
+    ws = [((rng.random((d, d), dtype=np.float32) * 2 - 1) * k, (rng.random(d, dtype=np.float32) * 2 - 1) * k) for _ in range(4)]
+    g = rng.random((b_sample * S, d), dtype=np.float32)
+    noise = O.dropout_noise(b_sample * H * S * S, p, 7, 0).reshape(b_sample * H, S, S)   # drawn outside the timed region
+
+    def fn():
+        O.mha_forward_backward(x, ws[0][0], ws[0][1], ws[1][0], ws[1][1], ws[2][0], ws[2][1], ws[3][0], ws[3][1], H, b_sample, p, noise, g)
+    return cpu_baseline("sequences/s", b_sample, fn, f"MHA fwd+bwd on {b_sample} of the 32 sequences (mask pre-drawn)", min_s=5.0,
+                        scaled_from=f"{b_sample} of 32 sequences (per-sequence work is independent except the weight-gradient sums)")
+
+
+# ------------------------------------------------------------------------------------------------
+# workloads
+# ------------------------------------------------------------------------------------------------
+def roofline_mfma(gemm_stats, kernel, traffic):
+    n_launch, ms, flop = gemm_stats
+    achieved = flop / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    return {"bound": "mfma", "kernel": kernel, "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s",
+            "frac": round(achieved * 1e12 / MFMA_F32_PEAK, 4), "traffic": traffic, "launches": n_launch,
+            "avg_launch_ms": round(ms / max(1, n_launch), 4), "algorithmic_flop_per_launch": flop / max(1, n_launch)}
+
+
+class _CapiSync:  # adapt capi.Device to the `sync()` interface of the tape's Device
+    def __init__(self, dev): self.dev = dev
+    def sync(self): self.dev.sync()
+
+
+def matmul_fwd_bwd(dist, dev, n, steps, warmup):
+    """C2 on device `dev` (capi.Device): C = A.B, dA += G.B^T, dB += A^T.G.  Returns (seconds max over ranks, gemm stats)."""
+    from neuronika_amd import capi as c
+    mk = lambda s: dev.array(np.random.default_rng(s).random((n, n), dtype=np.float32))
+    A, B, G = mk(0), mk(1), mk(2)
+    Cm, dA, dB = dev.zeros((n, n)), dev.zeros((n, n)), dev.zeros((n, n))
+
+    def step():
+        c.mm_fwd(dev, A, B, Cm); c.mm_bwd_left(dev, dA, G, B); c.mm_bwd_right(dev, dB, A, G)
+    dt, _, gemm, _ = timed_steps(dist, _CapiSync(dev), dev, step, steps, warmup)
+    return dt, gemm
 
 
 def run_mlp(a, dist):
@@ -171,13 +293,16 @@ def run_mlp(a, dist):
     if world > 1:
         uid = dist.bcast_bytes(t.dp.Communicator.unique_id() if dist.rank == 0 else None)
         comm = t.dp.Communicator(tdev, world, dist.rank, uid)
+        if comm.size != world:
+            raise SystemExit(f"[bench] RCCL communicator has {comm.size} ranks, expected {world}")
         sync = t.dp.GradientSync(comm, params)
     seed = 1.0 / world
+    exchange = [True]
 
     def step():
         loss.forward()
         loss.no_grad(); loss.with_grad()          # drop + re-create (zero) the intermediate gradients
-        if sync is not None:
+        if sync is not None and exchange[0]:
             loss.backward_sync(seed, sync)
             sync.join()
         else:
@@ -188,10 +313,18 @@ def run_mlp(a, dist):
 
     dt, ev_ms, gemm, _ = timed_steps(dist, tdev, cdev, step, a.steps, a.warmup)
     loss_val = loss.item()
-    n_launch, gemm_ms, gemm_flop = gemm
+    n_exch = sync.exchanges_issued() if sync is not None else 0
+    exposed = 0.0
+    if sync is not None:                           # the same loop with the exchange switched off: what the all-reduce costs
+        exchange[0] = False
+        dt_off, _, _, _ = timed_steps(dist, tdev, cdev, step, a.steps, 2)
+        exposed = (dt - dt_off) / a.steps * 1e3
+    mm_n = 4096                                    # second half of BASELINE.json's metric: MatMul MFMA %peak (C2, N = 4096)
+    mm_steps = 20
+    mm_dt, mm_gemm = matmul_fwd_bwd(dist, cdev, mm_n, mm_steps, 3)
     res = None
     if dist.rank == 0:
-        achieved = gemm_flop / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        mm_roof = roofline_mfma(mm_gemm, "sgemm_kernel", None)
         res = {
             "metric": "training-step samples/sec (fwd+bwd+allreduce)", "value": round(B * world * a.steps / dt, 2),
             "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -199,18 +332,22 @@ def run_mlp(a, dist):
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"C4: 3-layer MLP Linear({H},{H})x3 + ReLU, MSE mean, batch {B}/GPU, data-parallel "
                                    f"gradient all-reduce (RCCL, side stream)", "global_batch": B * world,
-                       "parallelism": f"dp{world}", "optimizer_step_in_timed_region": not a.no_optimizer,
-                       "allreduce_bytes_per_step": 0 if world == 1 else 3 * (H * H + H) * 4},
-            "roofline": {"bound": "mfma", "kernel": "sgemm_kernel (f32 MFMA 32x32x2, 128x128x32 tiles)",
-                         "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s",
-                         "frac": round(achieved * 1e12 / MFMA_F32_PEAK, 4), "traffic": read_traffic("sgemm_kernel"),
-                         "launches": n_launch, "avg_launch_ms": round(gemm_ms / max(1, n_launch), 4),
-                         "algorithmic_flop_per_launch": gemm_flop / max(1, n_launch)},
+                       "parallelism": f"dp{world}", "optimizer_step_in_timed_region": not a.no_optimizer},
+            "rccl_ranks": comm.size if comm is not None else 1,
+            "allreduce_bytes_per_step": sync.bytes_per_step() if sync is not None else 0,
+            "allreduce_launches_per_step": n_exch // (a.steps + a.warmup) if sync is not None else 0,
+            "exposed_comm_ms": round(exposed, 4),
+            "roofline": roofline_mfma(gemm, "sgemm_kernel (f32 MFMA 32x32x2, 128x128x32 tiles)", read_traffic("sgemm_kernel")),
+            "matmul_4096": {"workload": f"C2: mm fwd + bwd-left + bwd-right, N={mm_n}, {mm_steps} steps",
+                            "tflops": round(6.0 * mm_n ** 3 * mm_steps / mm_dt / 1e12, 2),
+                            "frac_of_mfma_peak": round(6.0 * mm_n ** 3 * mm_steps / mm_dt / MFMA_F32_PEAK, 4),
+                            "kernel_tflops": mm_roof["achieved"], "kernel_frac": mm_roof["frac"],
+                            "ms_per_step": round(mm_dt / mm_steps * 1e3, 4)},
             "device_ms_per_step": round(ev_ms / a.steps, 4), "loss": loss_val,
-            "gemm_share_of_step": round(gemm_ms / ev_ms, 4) if ev_ms > 0 else None,
+            "gemm_share_of_step": round(gemm[1] / ev_ms, 4) if ev_ms > 0 else None,
         }
         if world == 1 and not a.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline_mlp(H, 2048 if H >= 2048 else B)
+            res["cpu_baseline"] = cpu_baseline_mlp(H, B)
     if comm is not None:
         tdev.sync()
     return res
@@ -221,31 +358,23 @@ def run_matmul(a, dist):
     from neuronika_amd import capi as c
     dev = c.Device(dist.local)
     n = a.n
-    mk = lambda s: dev.array(np.random.default_rng(s).random((n, n), dtype=np.float32))
-    A, B, G = mk(0), mk(1), mk(2)
-    Cm, dA, dB = dev.zeros((n, n)), dev.zeros((n, n)), dev.zeros((n, n))
-
-    def step():
-        c.mm_fwd(dev, A, B, Cm); c.mm_bwd_left(dev, dA, G, B); c.mm_bwd_right(dev, dB, A, G)
-
-    class TD:  # adapt capi.Device to the sync interface
-        def sync(self): dev.sync()
-    dt, ev_ms, gemm, _ = timed_steps(dist, TD(), dev, step, a.steps, a.warmup)
-    n_launch, gemm_ms, gemm_flop = gemm
+    dt, gemm = matmul_fwd_bwd(dist, dev, n, a.steps, a.warmup)
     if dist.rank != 0:
         return None
-    achieved = gemm_flop / (gemm_ms * 1e-3) / 1e12
-    return {"metric": "MatMul fwd+bwd TFLOP/s (MFMA %peak)", "value": round(6.0 * n ** 3 * a.steps / dt / 1e12 * dist.world, 2),
-            "unit": "TFLOP/s", "n_gpus": dist.world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic", "config": {"workload": f"C2: matmul fwd+bwd, square N={n}", "n": n},
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s",
-                         "frac": round(achieved * 1e12 / MFMA_F32_PEAK, 4), "traffic": read_traffic("sgemm_kernel"),
-                         "launches": n_launch, "avg_launch_ms": round(gemm_ms / max(1, n_launch), 4)}}
+    res = {"metric": "MatMul fwd+bwd TFLOP/s (MFMA %peak)", "value": round(6.0 * n ** 3 * a.steps / dt / 1e12 * dist.world, 2),
+           "unit": "TFLOP/s", "n_gpus": dist.world, "steps": a.steps, "warmup": a.warmup,
+           "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32", "data": "synthetic", "config": {"workload": f"C2: matmul fwd+bwd, square N={n}", "n": n},
+           "roofline": roofline_mfma(gemm, "sgemm_kernel", read_traffic("sgemm_kernel") if n == 4096 else None)}
+    if dist.world == 1 and not a.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline_matmul(n)
+    return res
 
 
 def run_conv(a, dist):
-    """C3: zero-pad(1) -> Conv2d 3x3 s1, NCHW 128x64x56x56 -> 128 channels, fwd + both backward passes."""
+    """C3: zero-pad(1) -> Conv2d 3x3 s1, NCHW 128x64x56x56 -> 128 channels, fwd + both backward passes.  The upstream
+    gradient dY is seeded directly into the convolution output's gradient (`backward_from`), so the timed step holds the
+    module's own nodes only."""
     import neuronika_amd
     from neuronika_amd import capi
     t = neuronika_amd.tape
@@ -257,27 +386,26 @@ def run_conv(a, dist):
     X = t.from_ndarray(tdev, x).requires_grad()
     y = conv.forward(X)
     G = t.from_ndarray(tdev, np.random.default_rng(2).random((N, 128, 56, 56), dtype=np.float32))
-    loss = (y * G).sum()
 
     def step():
-        loss.forward()
-        loss.no_grad(); loss.with_grad()
-        loss.backward(1.0)
+        y.forward()
+        y.no_grad(); y.with_grad()
+        y.backward_from(G)
         X.zero_grad(); conv.weight.zero_grad(); conv.bias.zero_grad()
 
     dt, ev_ms, _, conv_stats = timed_steps(dist, tdev, cdev, step, a.steps, a.warmup)
-    n_launch, ms, flop = conv_stats
     if dist.rank != 0:
         return None
-    achieved = flop / (ms * 1e-3) / 1e12
-    return {"metric": "Conv2d fwd+bwd samples/s", "value": round(N * a.steps / dt, 2), "unit": "samples/s",
-            "n_gpus": dist.world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "C3: pad(1) -> conv 3x3 s1 d1 g1, x 128x64x56x56 -> 128 ch, +bias, fwd+bwd-input+bwd-kernel"},
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s",
-                         "frac": round(achieved * 1e12 / MFMA_F32_PEAK, 4), "traffic": read_traffic("conv"),
-                         "launches": n_launch, "avg_launch_ms": round(ms / max(1, n_launch), 4)},
-            "conv_share_of_step": round(ms / ev_ms, 4)}
+    res = {"metric": "Conv2d fwd+bwd samples/s", "value": round(N * a.steps / dt, 2), "unit": "samples/s",
+           "n_gpus": dist.world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "C3: pad(1) -> conv 3x3 s1 d1 g1, x 128x64x56x56 -> 128 ch, +bias, fwd+bwd-input+bwd-kernel"},
+           "roofline": roofline_mfma(conv_stats, "conv_fwd_fast / conv_bwd_input_fast / conv_bwd_kernel (implicit GEMM, f32 MFMA)",
+                                     read_traffic("conv")),
+           "conv_share_of_step": round(conv_stats[1] / ev_ms, 4)}
+    if dist.world == 1 and not a.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline_conv(8)
+    return res
 
 
 def run_mha(a, dist):
@@ -293,33 +421,93 @@ def run_mha(a, dist):
         mha.strided_heads = os.environ["NK_MHA_STRIDED"] == "1"
     X = t.from_ndarray(tdev, np.random.default_rng(0).random((B * S, d), dtype=np.float32)).requires_grad()
     G = t.from_ndarray(tdev, np.random.default_rng(5).random((B * S, d), dtype=np.float32))
-    loss = (mha.forward(X, B) * G).sum()
+    y = mha.forward(X, B)
     leaves = [X] + [getattr(getattr(mha, n), w) for n in "qkvo" for w in ("weight", "bias")]
 
     def step():
-        loss.forward()
-        loss.no_grad(); loss.with_grad()
-        loss.backward(1.0)
+        y.forward()
+        y.no_grad(); y.with_grad()
+        y.backward_from(G)
         for p in leaves:
             p.zero_grad()
 
     dt, ev_ms, gemm, _ = timed_steps(dist, tdev, cdev, step, a.steps, a.warmup)
-    n_launch, ms, flop = gemm
     if dist.rank != 0:
         return None
-    achieved = flop / (ms * 1e-3) / 1e12
-    return {"metric": "MultiheadAttention fwd+bwd sequences/s", "value": round(B * a.steps / dt, 2), "unit": "sequences/s",
-            "n_gpus": dist.world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "C5: MHA d_model=1024 heads=16 seq=1024 batch=32 dropout=0.1, composed from reference ops"},
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s",
-                         "frac": round(achieved * 1e12 / MFMA_F32_PEAK, 4), "traffic": None, "launches": n_launch,
-                         "avg_launch_ms": round(ms / max(1, n_launch), 4)},
-            "gemm_share_of_step": round(ms / ev_ms, 4)}
+    res = {"metric": "MultiheadAttention fwd+bwd sequences/s", "value": round(B * a.steps / dt, 2), "unit": "sequences/s",
+           "n_gpus": dist.world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "C5: MHA d_model=1024 heads=16 seq=1024 batch=32 dropout=0.1, composed from reference ops"},
+           "roofline": roofline_mfma(gemm, "sgemm_kernel (projections, scores, context and their gradients)", read_traffic("mha_gemm")),
+           "gemm_share_of_step": round(gemm[1] / ev_ms, 4)}
+    if dist.world == 1 and not a.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline_mha(2, S, d, H, 0.1)
+    return res
+
+
+# ------------------------------------------------------------------------------------------------
+# launcher
+# ------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n, cmd=None, have=None):
+    """`--gpus N` with no launcher: become the launcher.  One worker process per GPU (LOCAL_RANK = device index),
+    TCP rendezvous on 127.0.0.1; rank 0 prints the JSON line on our stdout.  Returns the exit code.
+    (`cmd` / `have`: the worker command line and the GPU count, overridable so the launcher itself can be tested
+    on a box without GPUs.)"""
+    if have is None:
+        from neuronika_amd import capi
+        have = capi.device_count()
+    if cmd is None:
+        cmd = [sys.executable, os.path.abspath(__file__), *sys.argv[1:]]
+    if have < n:
+        print(f"[bench] --gpus {n} requested but this node has {have} GPU(s): refusing to run fewer ranks than asked", file=sys.stderr)
+        return 2
+    env = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               NK_RV_SECRET=secrets.token_hex(16), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen(cmd, env=e))
+    rc = 0
+    try:
+        pending = set(range(n))
+        while pending:
+            for r in sorted(pending):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                pending.discard(r)
+                if code != 0:
+                    print(f"[bench] rank {r} exited with code {code}", file=sys.stderr)
+                    rc = rc or (code if code > 0 else 1)
+            if rc and pending:          # one rank failed: the others would wait for it forever
+                break
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    return rc
 
 
 def main():
     a = parse()
+    if a.gpus < 1:
+        raise SystemExit("[bench] --gpus must be >= 1")
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(a.gpus))
     dist = Dist(a.gpus)
     try:
         res = {"mlp": run_mlp, "matmul": run_matmul, "conv": run_conv, "mha": run_mha}[a.workload](a, dist)

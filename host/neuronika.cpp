@@ -744,17 +744,26 @@ struct LinearBwd : Backward {
         const HipArray& G = g->borrow();
         nk_device* dev = D(x);
         const int n = x->shape()[0], m = x->shape()[1], o = w->shape()[0];
-        // same order as MatrixMatrixMulTBackward (left, right) followed by AdditionBackwardRight
+        // MatrixMatrixMulTBackward (left, right) and AdditionBackwardRight write three different buffers, so their
+        // order is free: the bias gradient goes first (the data-parallel exchange then sends the small gradients of
+        // the whole model as one group while the last weight-gradient GEMMs still run), the weight gradient last
         float beta;  // nk_mm_t_bwd_left / nk_mm_t_bwd_right, with beta 0 when the gradient's zero fill is still pending
         if (dx) { float* d = first_write(dx, beta); check(nk_sgemm(dev, 0, 0, n, m, o, 1.f, G.ptr(), o, w->ptr(), m, beta, d, m)); }
         {
+            const int gs[2] = {n, o};
+            bool assign = false;
+            HipArray& d = db->borrow_first_write(assign);
+            check((assign ? nk_unbroadcast_assign : nk_unbroadcast_add)(dev, d.ptr(), &o, 1, G.ptr(), gs, 2));
+            if (BackwardHook* hook = parts_hook(db.get())) hook->grad_part_ready(db.get(), 0, (size_t)o);
+        }
+        {
             float* d = first_write(dw, beta);
-            BackwardHook* hook = active_backward_hook();
+            BackwardHook* hook = parts_hook(dw.get());  // null unless this node is the last writer of dW
             // data-parallel exchange at row-block granularity: each half of dW (still >= 512 tiles of 128x128, a full
             // wave of resident blocks) goes to the all-reduce as soon as it is issued, so only half a gradient's
             // exchange is left exposed behind the last GEMM of the backward pass
             const int h = o / 2;
-            if (hook && hook->wants_parts(dw.get()) && o % 256 == 0 && (long long)(h / 128) * ((m + 127) / 128) >= 512) {
+            if (hook && o % 256 == 0 && (long long)(h / 128) * ((m + 127) / 128) >= 512) {
                 for (int r0 = 0; r0 < o; r0 += h) {
                     check(nk_sgemm(dev, 1, 0, h, m, n, 1.f, G.ptr() + r0, o, x->ptr(), m, beta, d + (size_t)r0 * m, m));
                     hook->grad_part_ready(dw.get(), (size_t)r0 * m, (size_t)h * m);
@@ -762,12 +771,6 @@ struct LinearBwd : Backward {
             } else {
                 check(nk_sgemm(dev, 1, 0, o, m, n, 1.f, G.ptr(), o, x->ptr(), m, beta, d, m));
             }
-        }
-        const int gs[2] = {n, o};
-        {
-            bool assign = false;
-            HipArray& d = db->borrow_first_write(assign);
-            check((assign ? nk_unbroadcast_assign : nk_unbroadcast_add)(dev, d.ptr(), &o, 1, G.ptr(), gs, 2));
         }
     }
     void targets(std::vector<const Gradient*>& out) const override {
@@ -1191,11 +1194,17 @@ void VarDiff::forward() const {
     if (buffer.empty()) buffer = history.to_vec();
 }
 static thread_local BackwardHook* g_active_hook = nullptr;
-BackwardHook* active_backward_hook() { return g_active_hook; }
+// gradients whose LAST writer on the tape is the node whose backward() is running now
+static thread_local const std::vector<const Gradient*>* g_final_here = nullptr;
+BackwardHook* parts_hook(const Gradient* g) {
+    if (!g_active_hook || !g_final_here) return nullptr;
+    if (std::find(g_final_here->begin(), g_final_here->end(), g) == g_final_here->end()) return nullptr;
+    return g_active_hook->wants_parts(g) ? g_active_hook : nullptr;
+}
 namespace {
 struct ActiveHookScope {
     explicit ActiveHookScope(BackwardHook* h) { g_active_hook = h; }
-    ~ActiveHookScope() { g_active_hook = nullptr; }
+    ~ActiveHookScope() { g_active_hook = nullptr; g_final_here = nullptr; }
 };
 }  // namespace
 
@@ -1205,6 +1214,19 @@ void VarDiff::backward(float seed, BackwardHook* hook) const {
         bool assign = false;
         grad->borrow_first_write(assign).fill(seed);  // `grad_mut().fill(seed)` vardiff.rs:133
     }
+    run_backward(hook);
+}
+void VarDiff::backward_from(const Var& seed, BackwardHook* hook) const {
+    if (var.history.len() != var.history.buffer_len()) panic("Perhaps you forgot to call .forward()?");
+    if (seed.shape() != shape()) panic("backward_from: the seed must have the shape of the root");
+    {
+        bool assign = false;
+        HipArray& g = grad->borrow_first_write(assign);
+        check(nk_copy(device()->raw(), g.ptr(), seed.data->ptr(), g.len()));
+    }
+    run_backward(hook);
+}
+void VarDiff::run_backward(BackwardHook* hook) const {
     auto& buffer = history.buffer_mut();
     if (!hook) {
         for (auto it = buffer.rbegin(); it != buffer.rend(); ++it) it->op->backward();
@@ -1213,7 +1235,7 @@ void VarDiff::backward(float seed, BackwardHook* hook) const {
     ActiveHookScope scope(hook);
     // a gradient is final once the last node (in reverse order) that accumulates into it ran
     std::unordered_map<const Gradient*, size_t> last;
-    std::vector<const Gradient*> ts;
+    std::vector<const Gradient*> ts, final_here;
     for (size_t i = 0; i < buffer.size(); ++i) {  // reverse execution order: index 0 runs last
         ts.clear();
         buffer[i].op->targets(ts);
@@ -1221,11 +1243,15 @@ void VarDiff::backward(float seed, BackwardHook* hook) const {
             if (!last.count(g)) last[g] = i;  // smallest index = last to run
     }
     for (size_t k = buffer.size(); k-- > 0;) {
-        buffer[k].op->backward();
         ts.clear();
         buffer[k].op->targets(ts);
+        final_here.clear();
         for (const Gradient* g : ts)
-            if (last[g] == k) hook->grad_ready(g);
+            if (last[g] == k && std::find(final_here.begin(), final_here.end(), g) == final_here.end()) final_here.push_back(g);
+        g_final_here = &final_here;  // what `parts_hook` answers for while this node runs
+        buffer[k].op->backward();
+        g_final_here = nullptr;
+        for (const Gradient* g : final_here) hook->grad_ready(g);
     }
 }
 void VarDiff::no_grad() const {
@@ -1930,35 +1956,68 @@ Communicator::Communicator(DevicePtr dev, int nranks, int rank, const std::strin
     if (id.size() != NK_COMM_ID_BYTES) panic("communicator id must be 128 bytes");
     check(nk_comm_init_rank(dev_->raw(), nranks, rank, id.data(), &h_));
 }
+Communicator::Communicator(DevicePtr dev, int nranks) : dev_(std::move(dev)), rank_(0), size_(nranks) {
+    check(nk_comm_init_replicas(dev_->raw(), nranks, &h_));
+}
+std::shared_ptr<Communicator> Communicator::replicas(DevicePtr dev, int nranks) {
+    return std::shared_ptr<Communicator>(new Communicator(std::move(dev), nranks));
+}
 Communicator::~Communicator() { nk_comm_destroy(h_); }
 
-GradientSync::GradientSync(std::shared_ptr<Communicator> comm, const std::vector<VarDiff>& params) : comm_(std::move(comm)) {
+GradientSync::GradientSync(std::shared_ptr<Communicator> comm, const std::vector<VarDiff>& params, size_t small_elems)
+    : comm_(std::move(comm)), small_elems_(small_elems) {
     for (const VarDiff& p : params) {
-        params_[p.grad.get()] = p.grad;
-        bytes_ += numel(p.shape()) * sizeof(float);
+        if (!params_.emplace(p.grad.get(), p.grad).second) continue;  // registered twice: one exchange
+        const size_t len = numel(p.shape());
+        bytes_ += len * sizeof(float);
+        n_small_ += len < small_elems_;
         for (int k = 0; k < 2; ++k) {  // up to two pieces per gradient in flight
             nk_event* ev = nullptr;
             check(nk_event_create(comm_->device()->raw(), &ev));
             events_.push_back(ev);
         }
     }
+    nk_event* ev = nullptr;  // one more for the group of small gradients
+    check(nk_event_create(comm_->device()->raw(), &ev));
+    events_.push_back(ev);
 }
 GradientSync::~GradientSync() {
     for (nk_event* e : events_) nk_event_destroy(e);
 }
-bool GradientSync::wants_parts(const Gradient* g) const {
-    auto it = params_.find(g);
-    return it != params_.end() && active() && numel(it->second->shape()) >= (size_t)(4u << 20);  // >= 16 MB
+bool GradientSync::wants_parts(const Gradient* g) const { return active() && params_.count(g) != 0; }
+void GradientSync::flush_small() {
+    if (small_pending_.empty()) return;
+    std::vector<float*> bufs;
+    std::vector<size_t> counts;
+    for (const Gradient* g : small_pending_) {
+        HipArray& a = params_.at(g)->borrow();
+        bufs.push_back(a.ptr());
+        counts.push_back(a.len());
+        elems_ += a.len();
+    }
+    small_pending_.clear();
+    nk_event* ev = events_[next_event_++ % events_.size()];
+    check(nk_event_record(ev, 0));  // every pending small gradient was final before this point of the compute stream
+    check(nk_allreduce_sum_group_async(comm_->raw(), bufs.data(), counts.data(), (int)bufs.size(), ev));
+    ++issued_;
 }
 void GradientSync::grad_part_ready(const Gradient* g, size_t offset, size_t count) {
     auto it = params_.find(g);
-    if (it == params_.end() || !active()) return;
+    if (it == params_.end() || !active() || count == 0) return;
     HipArray& a = it->second->borrow();
     if (offset + count > a.len()) panic("grad_part_ready: piece exceeds the gradient");
+    if (parts_done_[g] + count > a.len()) panic("grad_part_ready: pieces overlap");
+    parts_done_[g] += count;
+    if (a.len() < small_elems_) {  // a small gradient travels whole, with the group
+        if (count != a.len()) panic("grad_part_ready: a small gradient must be handed over whole");
+        small_pending_.push_back(g);
+        if (small_pending_.size() == n_small_) flush_small();
+        return;
+    }
     nk_event* ev = events_[next_event_++ % events_.size()];
     check(nk_event_record(ev, 0));  // everything up to the launch that finished this piece
     check(nk_allreduce_sum_async(comm_->raw(), a.ptr() + offset, count, ev));
-    parts_done_[g] += count;
+    elems_ += count;
     ++issued_;
 }
 void GradientSync::grad_ready(const Gradient* g) {
@@ -1970,16 +2029,16 @@ void GradientSync::grad_ready(const Gradient* g) {
     if (pd != parts_done_.end() && pd->second != 0) {
         const size_t done = pd->second;
         pd->second = 0;
-        if (done == a.len()) return;  // already exchanged piece by piece
+        if (done == a.len()) return;  // already handed over piece by piece
         panic("GradientSync: a gradient was only partly exchanged piecewise");
     }
-    nk_event* ev = events_[next_event_++ % events_.size()];
-    check(nk_event_record(ev, 0));  // everything up to the node that finalised g
-    check(nk_allreduce_sum_async(comm_->raw(), a.ptr(), a.len(), ev));
-    ++issued_;
+    grad_part_ready(g, 0, a.len());
+    parts_done_[g] = 0;
 }
 void GradientSync::join() {
+    flush_small();  // small gradients of parameters some of whose siblings never became final this pass
     next_event_ = 0;
+    for (auto& kv : parts_done_) kv.second = 0;
     if (active()) check(nk_comm_join(comm_->raw()));
 }
 

@@ -138,14 +138,17 @@ struct Backward {
 struct BackwardHook {
     virtual ~BackwardHook() = default;
     virtual void grad_ready(const Gradient* g) = 0;
-    // Optional finer grain: a node that produces a large gradient in several launches (Linear's weight gradient, as
-    // row blocks) asks `wants_parts` and reports each finished contiguous piece, so its exchange starts before the
-    // whole gradient is done.  `grad_ready` still follows once the node has been issued.
+    // Optional finer grain: a node that finishes a gradient before its own `backward()` returns (Linear: the bias
+    // gradient first, then the weight gradient in row blocks) reports each finished contiguous piece, so the exchange
+    // starts while the node is still issuing launches.  A node obtains the hook through `parts_hook(g)` only, which
+    // answers null unless THIS node is the last writer of g on the tape (a shared / tied parameter keeps accumulating
+    // in a later node; its exchange must wait for `grad_ready`).  `grad_ready` still follows once the node is done.
     virtual bool wants_parts(const Gradient*) const { return false; }
     virtual void grad_part_ready(const Gradient*, size_t /*offset*/, size_t /*count*/) {}
 };
-// the hook of the backward pass currently being issued on this thread (null outside `backward(seed, hook)`)
-BackwardHook* active_backward_hook();
+// The hook of the backward pass being issued on this thread if it wants pieces of `g` AND the node now running is
+// the last tape node that writes g; null otherwise (also outside `backward(seed, hook)`).
+BackwardHook* parts_hook(const Gradient* g);
 struct NoGrad {
     virtual ~NoGrad() = default;
     virtual void no_grad() = 0;
@@ -315,6 +318,8 @@ class Var {
 // vardiff.rs — differentiable variable
 // ---------------------------------------------------------------------------------------------
 class VarDiff {
+    void run_backward(BackwardHook* hook) const;
+
    public:
     Var var;
     Shared<Gradient> grad;
@@ -329,6 +334,10 @@ class VarDiff {
     void zero_grad() const;         // vardiff.rs:100
     void forward() const;           // vardiff.rs:106-116
     void backward(float seed, BackwardHook* hook = nullptr) const;  // vardiff.rs:125-141
+    // The same pass seeded with an upstream gradient TENSOR (root gradient = `seed`, same shape) instead of a
+    // scalar fill: what an enclosing graph would hand to this sub-graph's root.  Lets a benchmark time a module's
+    // own backward nodes without `(y * G).sum()` scaffolding.
+    void backward_from(const Var& seed, BackwardHook* hook = nullptr) const;
     void no_grad() const;           // vardiff.rs:145
     void with_grad() const;         // vardiff.rs:157
     float item() const { return var.item(); }
@@ -709,6 +718,8 @@ class Communicator {
    public:
     static std::string unique_id();  // 128 raw bytes, create on rank 0
     Communicator(DevicePtr dev, int nranks, int rank, const std::string& id);
+    // `nranks` virtual ranks holding this rank's values (nk_comm_init_replicas): sum all-reduce = multiply by nranks
+    static std::shared_ptr<Communicator> replicas(DevicePtr dev, int nranks);
     ~Communicator();
     int rank() const { return rank_; }
     int size() const { return size_; }
@@ -716,6 +727,7 @@ class Communicator {
     DevicePtr device() const { return dev_; }
 
    private:
+    Communicator(DevicePtr dev, int nranks);
     DevicePtr dev_;
     nk_comm* h_ = nullptr;
     int rank_, size_;
@@ -724,10 +736,13 @@ class Communicator {
 // Overlapped exchange: pass to `loss.backward(1/world, &sync)`; each registered parameter's
 // gradient is all-reduced (sum) on the side stream as soon as the last backward node writing it
 // has been issued (reverse layer order), while the remaining backward GEMMs keep the compute
-// stream busy.  `join()` makes the compute stream wait for the exchange (no host sync).
+// stream busy.  Gradients below `small_elems` (biases: latency-bound) are collected and sent as
+// ONE RCCL group as soon as the last of them is final.  `join()` makes the compute stream wait
+// for the exchange (no host sync).  Every rank must run the same tape: the order of the
+// collectives is the order in which backward finalises the gradients.
 class GradientSync : public BackwardHook {
    public:
-    GradientSync(std::shared_ptr<Communicator> comm, const std::vector<VarDiff>& params);
+    GradientSync(std::shared_ptr<Communicator> comm, const std::vector<VarDiff>& params, size_t small_elems = 65536);
     ~GradientSync() override;
     void grad_ready(const Gradient* g) override;
     bool wants_parts(const Gradient* g) const override;
@@ -736,16 +751,22 @@ class GradientSync : public BackwardHook {
     size_t bytes_per_step() const { return bytes_; }
     // run the exchange even with a single rank (RCCL then copies in place): lets one GPU exercise every code path
     void set_force_exchange(bool on) { force_ = on; }
-    size_t exchanges_issued() const { return issued_; }
+    size_t exchanges_issued() const { return issued_; }  // collective launches so far (a group counts once)
+    size_t elements_exchanged() const { return elems_; }
 
    private:
+    void flush_small();
     std::shared_ptr<Communicator> comm_;
     std::unordered_map<const Gradient*, Shared<Gradient>> params_;
-    std::unordered_map<const Gradient*, size_t> parts_done_;  // elements already exchanged piecewise this pass
+    std::unordered_map<const Gradient*, size_t> parts_done_;  // elements already handed over piecewise this pass
+    std::vector<const Gradient*> small_pending_;               // small gradients that are final, not yet sent
     std::vector<nk_event*> events_;
     size_t next_event_ = 0;
     size_t bytes_ = 0;
     size_t issued_ = 0;
+    size_t elems_ = 0;
+    size_t small_elems_;
+    size_t n_small_ = 0;
     bool force_ = false;
     bool active() const { return comm_->size() > 1 || force_; }
 };

@@ -95,6 +95,7 @@ PYBIND11_MODULE(_tape, m) {
         .def_property_readonly("shape", [](const VarDiff& v) { return v.shape(); })
         .def("forward", &VarDiff::forward)
         .def("backward", [](const VarDiff& v, float seed) { v.backward(seed); }, py::arg("seed") = 1.f)
+        .def("backward_from", [](const VarDiff& v, const Var& seed) { v.backward_from(seed); }, py::arg("seed"))
         .def("backward_sync", [](const VarDiff& v, float seed, dp::GradientSync& s) { v.backward(seed, &s); })
         .def("zero_grad", &VarDiff::zero_grad)
         .def("no_grad", &VarDiff::no_grad)
@@ -362,13 +363,16 @@ PYBIND11_MODULE(_tape, m) {
         .def(py::init([](DevicePtr dev, int nranks, int rank, py::bytes id) {
             return std::make_shared<dp::Communicator>(std::move(dev), nranks, rank, std::string(id));
         }))
+        .def_static("replicas", &dp::Communicator::replicas, py::arg("device"), py::arg("nranks"))
         .def_property_readonly("rank", &dp::Communicator::rank)
         .def_property_readonly("size", &dp::Communicator::size);
     py::class_<dp::GradientSync>(dpm, "GradientSync")
-        .def(py::init<std::shared_ptr<dp::Communicator>, const std::vector<VarDiff>&>())
+        .def(py::init<std::shared_ptr<dp::Communicator>, const std::vector<VarDiff>&, size_t>(), py::arg("comm"), py::arg("params"),
+             py::arg("small_elems") = (size_t)65536)
         .def("join", &dp::GradientSync::join)
         .def("bytes_per_step", &dp::GradientSync::bytes_per_step)
         .def("set_force_exchange", &dp::GradientSync::set_force_exchange)
-        .def("exchanges_issued", &dp::GradientSync::exchanges_issued);
+        .def("exchanges_issued", &dp::GradientSync::exchanges_issued)
+        .def("elements_exchanged", &dp::GradientSync::elements_exchanged);
     dpm.def("all_reduce_gradients", &dp::all_reduce_gradients);
 }

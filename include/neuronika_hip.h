@@ -457,11 +457,21 @@ int nk_rmsprop_step(nk_device* dev, float* w, float* grad, float* square_avg, fl
 int nk_comm_unique_id(char id[NK_COMM_ID_BYTES]);
 int nk_comm_init_rank(nk_device* dev, int nranks, int rank, const char id[NK_COMM_ID_BYTES],
                       nk_comm** out);
+/* A communicator of `nranks` virtual ranks that all hold THIS rank's values (no RCCL, no peers):
+ * its sum all-reduce multiplies the buffer by nranks on the side stream, with the same stream
+ * ordering as the real one.  Lets a single GPU check that an exchange schedule covers every
+ * element of every gradient exactly once (a sum over ONE real rank is the identity and would
+ * hide a wrong offset or count) and price the schedule without fabric traffic. */
+int nk_comm_init_replicas(nk_device* dev, int nranks, nk_comm** out);
 int nk_comm_destroy(nk_comm* comm);
 /* In-place sum all-reduce of buf[0..n) on the device's SIDE stream.  The side stream first
  * waits for `after` (an event recorded on the compute stream once the bucket's gradients are
  * final; NULL: waits for everything enqueued on the compute stream so far). */
 int nk_allreduce_sum_async(nk_comm* comm, float* buf, size_t n, nk_event* after);
+/* The same for a list of buffers as ONE RCCL group (one fused launch): for the small,
+ * latency-bound gradients (biases) of a step. */
+int nk_allreduce_sum_group_async(nk_comm* comm, float* const* bufs, const size_t* counts, int nbufs,
+                                 nk_event* after);
 /* Make the compute stream wait for all all-reduces issued so far (no host sync). */
 int nk_comm_join(nk_comm* comm);
 int nk_comm_rank(const nk_comm* comm);

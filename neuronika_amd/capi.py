@@ -164,8 +164,10 @@ _SIGS = {
     "nk_rmsprop_step": [VP, VP, VP, VP, VP, VP, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float],
     "nk_comm_unique_id": [C.c_char_p],
     "nk_comm_init_rank": [VP, C.c_int, C.c_int, C.c_char_p, C.POINTER(VP)],
+    "nk_comm_init_replicas": [VP, C.c_int, C.POINTER(VP)],
     "nk_comm_destroy": [VP],
     "nk_allreduce_sum_async": [VP, VP, C.c_size_t, VP],
+    "nk_allreduce_sum_group_async": [VP, C.POINTER(VP), C.POINTER(C.c_size_t), C.c_int, VP],
     "nk_comm_join": [VP],
     "nk_comm_rank": [VP],
     "nk_comm_size": [VP],
@@ -643,14 +645,23 @@ class Comm:
         check(lib.nk_comm_unique_id(buf))
         return buf.raw
 
-    def __init__(self, dev: Device, nranks: int, rank: int, uid: bytes):
-        assert len(uid) == COMM_ID_BYTES
+    def __init__(self, dev: Device, nranks: int, rank: int, uid: bytes | None):
+        """uid = None: a replica communicator (nk_comm_init_replicas) of `nranks` virtual ranks."""
         h = VP()
-        check(lib.nk_comm_init_rank(dev.h, nranks, rank, uid, C.byref(h)))
+        if uid is None:
+            check(lib.nk_comm_init_replicas(dev.h, nranks, C.byref(h)))
+        else:
+            assert len(uid) == COMM_ID_BYTES
+            check(lib.nk_comm_init_rank(dev.h, nranks, rank, uid, C.byref(h)))
         self.h, self.dev, self.rank, self.size = h, dev, rank, nranks
 
     def allreduce_sum_async(self, buf: HipArray, after: Event | None = None, n: int | None = None):
         check(lib.nk_allreduce_sum_async(self.h, buf.p, buf.size if n is None else n, after.h if after else None))
+
+    def allreduce_sum_group_async(self, bufs, after: Event | None = None):
+        ptrs = (VP * len(bufs))(*[b.p for b in bufs])
+        cnts = (C.c_size_t * len(bufs))(*[b.size for b in bufs])
+        check(lib.nk_allreduce_sum_group_async(self.h, ptrs, cnts, len(bufs), after.h if after else None))
 
     def join(self):
         check(lib.nk_comm_join(self.h))

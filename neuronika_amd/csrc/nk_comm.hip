@@ -10,9 +10,15 @@
 
 struct nk_comm {
     nk_device* dev;
-    ncclComm_t comm;
+    ncclComm_t comm;  // null for a replica communicator (nk_comm_init_replicas)
     int rank, size;
 };
+
+// The sum over `size` ranks that all hold the same values: what a replica communicator "exchanges".
+__global__ void __launch_bounds__(256) replica_sum_kernel(float* __restrict__ x, size_t n, float ranks) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) x[i] *= ranks;
+}
 
 static int fail_rccl(ncclResult_t r, const char* what) {
     nk_set_error("RCCL error %d (%s) in `%s`", (int)r, ncclGetErrorString(r), what);
@@ -49,29 +55,69 @@ int nk_comm_init_rank(nk_device* dev, int nranks, int rank, const char id[NK_COM
     return NK_OK;
 }
 
+int nk_comm_init_replicas(nk_device* dev, int nranks, nk_comm** out) {
+    NK_USE(dev);
+    NK_CHECK(out != nullptr, "null argument");
+    NK_CHECK(nranks >= 1, "bad replica count %d", nranks);
+    *out = new nk_comm{dev, nullptr, 0, nranks};
+    return NK_OK;
+}
+
 int nk_comm_destroy(nk_comm* comm) {
     if (!comm) return NK_OK;
     (void)hipSetDevice(comm->dev->idx);
     (void)hipStreamSynchronize(comm->dev->comm);
-    (void)ncclCommDestroy(comm->comm);
+    if (comm->comm) (void)ncclCommDestroy(comm->comm);
     delete comm;
     return NK_OK;
 }
 
-int nk_allreduce_sum_async(nk_comm* comm, float* buf, size_t n, nk_event* after) {
-    NK_CHECK(comm != nullptr, "null communicator");
-    nk_device* dev = comm->dev;
-    NK_USE(dev);
-    if (n == 0) return NK_OK;
-    NK_CHECK(buf != nullptr, "null buffer");
+// side stream waits for `after` (or for everything on the compute stream so far)
+static int order_after(nk_device* dev, nk_event* after) {
     if (after) {
         NK_HIP(hipStreamWaitEvent(dev->comm, after->ev, 0));
     } else {
         NK_HIP(hipEventRecord(dev->fork, dev->compute));
         NK_HIP(hipStreamWaitEvent(dev->comm, dev->fork, 0));
     }
-    NK_RCCL(ncclAllReduce(buf, buf, n, ncclFloat32, ncclSum, comm->comm, dev->comm));
     return NK_OK;
+}
+
+int nk_allreduce_sum_group_async(nk_comm* comm, float* const* bufs, const size_t* counts, int nbufs, nk_event* after) {
+    NK_CHECK(comm != nullptr, "null communicator");
+    nk_device* dev = comm->dev;
+    NK_USE(dev);
+    NK_CHECK(nbufs >= 0 && (nbufs == 0 || (bufs && counts)), "bad buffer list");
+    int live = 0;
+    for (int i = 0; i < nbufs; ++i) {
+        NK_CHECK(counts[i] == 0 || bufs[i] != nullptr, "null buffer %d", i);
+        live += counts[i] != 0;
+    }
+    if (live == 0) return NK_OK;
+    if (int rc = order_after(dev, after)) return rc;
+    if (!comm->comm) {  // replica communicator: every virtual rank holds this rank's values
+        for (int i = 0; i < nbufs; ++i) {
+            if (counts[i] == 0) continue;
+            replica_sum_kernel<<<nk_stream_grid(counts[i], 256), 256, 0, dev->comm>>>(bufs[i], counts[i], (float)comm->size);
+            NK_LAUNCH_CHECK();
+        }
+        return NK_OK;
+    }
+    // one RCCL group = one fused launch for the whole list (latency-bound small gradients)
+    if (live > 1) NK_RCCL(ncclGroupStart());
+    ncclResult_t r = ncclSuccess;
+    for (int i = 0; i < nbufs && r == ncclSuccess; ++i)
+        if (counts[i]) r = ncclAllReduce(bufs[i], bufs[i], counts[i], ncclFloat32, ncclSum, comm->comm, dev->comm);
+    if (live > 1) {
+        ncclResult_t e = ncclGroupEnd();
+        if (r == ncclSuccess) r = e;
+    }
+    if (r != ncclSuccess) return fail_rccl(r, "ncclAllReduce (group)");
+    return NK_OK;
+}
+
+int nk_allreduce_sum_async(nk_comm* comm, float* buf, size_t n, nk_event* after) {
+    return nk_allreduce_sum_group_async(comm, &buf, &n, 1, after);
 }
 
 int nk_comm_join(nk_comm* comm) {

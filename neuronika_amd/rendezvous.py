@@ -1,42 +1,101 @@
 """Control plane for one-process-per-GPU launches (rendezvous, barrier, small broadcasts and
 max-reductions) over plain TCP, using the RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT
-environment that `python -m torch.distributed.run` provides.
+environment that `python -m torch.distributed.run` (or bench.py's own spawner) provides.
 
 Why not torch.distributed here: the PyTorch wheel bundles its OWN libamdhip64 / libhsa-runtime64
 / librccl; importing torch into the process that also loads libneuronika_hip.so (linked against
 /opt/rocm) puts two HIP+HSA runtimes in one address space, which corrupts the heap at exit
 (observed: "double free or corruption" and a hung rocprofv3).  The data path (gradient
 all-reduce) is RCCL inside the HIP library; only a few bytes of control traffic flow here.
+
+Wire format (nothing received from the network is ever unpickled or evaluated):
+
+    frame   = u32 length (big endian, <= MAX_FRAME) | u8 tag | payload
+    tag 'N' = None (empty payload)      tag 'F' = one IEEE double (8 bytes, big endian)
+    tag 'I' = one signed 64-bit int     tag 'B' = raw bytes
+
+Authentication is a mutual HMAC-SHA256 challenge on fixed-length raw bytes BEFORE any frame is
+parsed: the server sends a 32-byte nonce, the client answers HMAC(secret, nonce | "client"), the
+server verifies with `hmac.compare_digest` and answers HMAC(secret, nonce | "server"), which the
+client verifies.  The secret is NK_RV_SECRET (bench.py's spawner draws it from os.urandom) or,
+under torchrun, derived from TORCHELASTIC_RUN_ID and the world size.
 """
 from __future__ import annotations
 
+import hashlib
+import hmac
 import os
-import pickle
 import socket
 import struct
 import time
 
+MAX_FRAME = 64 * 1024
+_NONCE = 32
+_MAC = 32
 
-def _send(sock, obj):
-    b = pickle.dumps(obj)
-    sock.sendall(struct.pack("!I", len(b)) + b)
 
-
-def _recv(sock):
-    hdr = b""
-    while len(hdr) < 4:
-        chunk = sock.recv(4 - len(hdr))
-        if not chunk:
-            raise ConnectionError("peer closed")
-        hdr += chunk
-    n = struct.unpack("!I", hdr)[0]
+def _recv_exact(sock, n):
     buf = b""
     while len(buf) < n:
         chunk = sock.recv(n - len(buf))
         if not chunk:
             raise ConnectionError("peer closed")
         buf += chunk
-    return pickle.loads(buf)
+    return buf
+
+
+def _encode(obj) -> bytes:
+    if obj is None:
+        return b"N"
+    if isinstance(obj, bool):
+        raise TypeError("bool is not a control-plane value")
+    if isinstance(obj, int):
+        return b"I" + struct.pack("!q", obj)
+    if isinstance(obj, float):
+        return b"F" + struct.pack("!d", obj)
+    if isinstance(obj, (bytes, bytearray)):
+        return b"B" + bytes(obj)
+    raise TypeError(f"control plane carries None / int / float / bytes only, not {type(obj).__name__}")
+
+
+def _decode(body: bytes):
+    if not body:
+        raise ConnectionError("empty frame")
+    tag, payload = body[:1], body[1:]
+    if tag == b"N" and not payload:
+        return None
+    if tag == b"I" and len(payload) == 8:
+        return struct.unpack("!q", payload)[0]
+    if tag == b"F" and len(payload) == 8:
+        return struct.unpack("!d", payload)[0]
+    if tag == b"B":
+        return payload
+    raise ConnectionError("malformed frame")
+
+
+def _send(sock, obj):
+    b = _encode(obj)
+    if len(b) > MAX_FRAME:
+        raise ValueError(f"control-plane message of {len(b)} bytes exceeds {MAX_FRAME}")
+    sock.sendall(struct.pack("!I", len(b)) + b)
+
+
+def _recv(sock):
+    n = struct.unpack("!I", _recv_exact(sock, 4))[0]
+    if n == 0 or n > MAX_FRAME:
+        raise ConnectionError(f"frame length {n} out of range")
+    return _decode(_recv_exact(sock, n))
+
+
+def _secret(world: int) -> bytes:
+    s = os.environ.get("NK_RV_SECRET")
+    if s:
+        return hashlib.sha256(s.encode()).digest()
+    return hashlib.sha256(("NKRV:" + os.environ.get("TORCHELASTIC_RUN_ID", "static") + f":{world}").encode()).digest()
+
+
+def _mac(secret: bytes, nonce: bytes, role: bytes) -> bytes:
+    return hmac.new(secret, nonce + role, hashlib.sha256).digest()
 
 
 class Rendezvous:
@@ -55,10 +114,9 @@ class Rendezvous:
             addr = "127.0.0.1"
         base = int(port or os.environ.get("MASTER_PORT", "29512"))
         # torchrun's agent already owns MASTER_PORT (its TCPStore); use the next free port of a
-        # short, deterministic range and authenticate with a token so that every rank finds the
-        # same server.
+        # short, deterministic range; the HMAC challenge makes every rank find the same server.
         ports = [base + 1 + i for i in range(32)]
-        token = ("NKRV:" + os.environ.get("TORCHELASTIC_RUN_ID", "static") + f":{self.world}").encode()
+        secret = _secret(self.world)
         if self.rank == 0:
             srv = None
             for p in ports:
@@ -79,12 +137,17 @@ class Rendezvous:
                 c, _ = srv.accept()
                 c.settimeout(10.0)
                 try:
-                    if _recv(c) != token:
+                    nonce = os.urandom(_NONCE)
+                    c.sendall(nonce)
+                    if not hmac.compare_digest(_recv_exact(c, _MAC), _mac(secret, nonce, b"client")):
                         c.close()
                         continue
-                    _send(c, token)
+                    c.sendall(_mac(secret, nonce, b"server"))
                     r = _recv(c)
-                except (OSError, ConnectionError, pickle.UnpicklingError):
+                    if not isinstance(r, int) or not 1 <= r < self.world or r in peers:
+                        c.close()
+                        continue
+                except (OSError, ConnectionError, struct.error):
                     c.close()
                     continue
                 c.settimeout(None)
@@ -97,15 +160,19 @@ class Rendezvous:
             s = None
             while s is None:
                 for p in ports:
+                    c = None
                     try:
                         c = socket.create_connection((addr, p), timeout=2.0)
                         c.settimeout(5.0)
-                        _send(c, token)
-                        if _recv(c) == token:
+                        nonce = _recv_exact(c, _NONCE)
+                        c.sendall(_mac(secret, nonce, b"client"))
+                        if hmac.compare_digest(_recv_exact(c, _MAC), _mac(secret, nonce, b"server")):
                             s = c
                             break
                         c.close()
-                    except (OSError, ConnectionError, pickle.UnpicklingError, struct.error, EOFError):
+                    except (OSError, ConnectionError, struct.error):
+                        if c is not None:
+                            c.close()
                         continue
                 if s is None:
                     if time.time() > deadline:
@@ -113,7 +180,7 @@ class Rendezvous:
                     time.sleep(0.1)
             s.settimeout(None)
             s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-            _send(s, self.rank)
+            _send(s, int(self.rank))
             self.sock = s
 
     def _collective(self, value, reduce_fn):
@@ -132,7 +199,7 @@ class Rendezvous:
         self._collective(None, lambda v: None)
 
     def broadcast(self, obj):
-        """Value of rank 0 on every rank."""
+        """Value of rank 0 (None / int / float / bytes up to 64 KiB) on every rank."""
         return self._collective(obj if self.rank == 0 else None, lambda v: v[0])
 
     def max(self, x: float) -> float:

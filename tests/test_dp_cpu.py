@@ -74,6 +74,126 @@ def test_tcp_rendezvous(world):
         assert rank == r and uid == b"\x01" * 128 and mx == 10.0 + world - 1 and sm == float(world)
 
 
+def _hostile(port, n_tries=6):
+    """A peer that does not know the secret: garbage instead of the HMAC answer, a huge length prefix, a pickle."""
+    import pickle, struct, time
+    payloads = [b"\x00" * 32, struct.pack("!I", 0xFFFFFFFF) + b"x" * 28, pickle.dumps(("boom",))[:32].ljust(32, b"."),
+                b"", b"A" * 100000]
+    sent = 0
+    deadline = time.time() + 20
+    while sent < n_tries and time.time() < deadline:
+        for off in range(1, 33):
+            try:
+                c = socket.create_connection(("127.0.0.1", port + off), timeout=0.5)
+            except OSError:
+                continue
+            try:
+                c.settimeout(2.0)
+                c.recv(32)                                   # the nonce
+                c.sendall(payloads[sent % len(payloads)])
+                c.recv(64)
+            except OSError:
+                pass
+            finally:
+                c.close()
+            sent += 1
+            break
+        else:
+            time.sleep(0.05)
+
+
+def test_tcp_rendezvous_ignores_unauthenticated_peers():
+    """Connections that fail the HMAC challenge are dropped before anything they send is parsed (nothing on this
+    channel is ever unpickled) and do not disturb the rendezvous of the real ranks."""
+    import threading
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    th = threading.Thread(target=_hostile, args=(port,), daemon=True)
+    ps = [ctx.Process(target=_rv_worker, args=(0, world, port, q))]
+    ps[0].start()
+    th.start()
+    import time; time.sleep(1.0)                            # the hostile peer talks to rank 0 first
+    ps.append(ctx.Process(target=_rv_worker, args=(1, world, port, q)))
+    ps[1].start()
+    res = sorted(q.get(timeout=60) for _ in range(world))
+    [p.join(30) for p in ps]
+    th.join(25)
+    assert [r[0] for r in res] == [0, 1] and all(r[1] == b"\x01" * 128 for r in res)
+
+
+def test_control_plane_wire_format():
+    from neuronika_amd import rendezvous as rz
+    for v in (None, 0, -5, 2 ** 40, 1.5, float("inf"), b"", b"\x00\xff" * 64):
+        assert rz._decode(rz._encode(v)) == v
+    for bad in ("text", [1], {"a": 1}, True, (1, 2)):
+        with pytest.raises(TypeError):
+            rz._encode(bad)
+    for body in (b"", b"Z", b"I123", b"F1", b"Nx"):
+        with pytest.raises(ConnectionError):
+            rz._decode(body)
+    a, b = socket.socketpair()
+    with pytest.raises(ValueError):
+        rz._send(a, b"x" * (rz.MAX_FRAME + 1))
+    import struct
+    a.sendall(struct.pack("!I", rz.MAX_FRAME + 1))          # an oversized length prefix is refused before any allocation
+    with pytest.raises(ConnectionError):
+        rz._recv(b)
+    src = open(rz.__file__).read()
+    assert "import pickle" not in src and "pickle.loads" not in src
+    a.close(); b.close()
+
+
+def test_bench_refuses_ranks_without_gpus():
+    """`python bench.py --gpus 2` with no launcher must spawn the ranks itself or fail loudly; on a box with fewer
+    than two GPUs that means a non-zero exit and no JSON line (never a silent single-rank run)."""
+    import subprocess, sys
+    from neuronika_amd import capi
+    if capi.device_count() >= 2:
+        pytest.skip("two GPUs present: covered by tests/test_gpu_multi.py")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True,
+                       text=True, timeout=120, env=env)
+    assert r.returncode != 0 and r.stdout.strip() == "" and "refusing" in r.stderr
+    # a launcher that started a different number of ranks than --gpus asks for is an error as well
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "1"], capture_output=True,
+                       text=True, timeout=120, env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
+    assert r.returncode != 0 and r.stdout.strip() == "" and "WORLD_SIZE=1" in r.stderr
+
+
+_SPAWN_WORKER = """
+import os, sys
+sys.path.insert(0, {root!r})
+from neuronika_amd.rendezvous import Rendezvous
+rv = Rendezvous()
+assert rv.world == int(os.environ["WORLD_SIZE"]) and rv.local == rv.rank and os.environ["MASTER_ADDR"] == "127.0.0.1"
+uid = rv.broadcast(b"u" * 128 if rv.rank == 0 else None)
+tot = rv.sum(float(rv.rank + 1))
+rv.barrier()
+if rv.rank == {fail_rank}:
+    sys.exit(3)
+if rv.rank == 0:
+    print("OK", rv.world, tot, len(uid), flush=True)
+rv.close()
+"""
+
+
+def test_bench_launcher_spawns_and_relays(tmp_path, capfd):
+    """The launcher half of `bench.py --gpus N` (environment, rendezvous, rank 0's line on our stdout, failure of any
+    rank = failure of the job), driven with a stand-in worker so it runs without GPUs."""
+    import importlib.util, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("nk_bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    ok = tmp_path / "ok.py"; ok.write_text(_SPAWN_WORKER.format(root=root, fail_rank=-1))
+    assert bench.spawn_ranks(3, cmd=[sys.executable, str(ok)], have=3) == 0
+    assert "OK 3 6.0 128" in capfd.readouterr().out
+    bad = tmp_path / "bad.py"; bad.write_text(_SPAWN_WORKER.format(root=root, fail_rank=1))
+    assert bench.spawn_ranks(2, cmd=[sys.executable, str(bad)], have=2) == 3
+    assert bench.spawn_ranks(4, cmd=[sys.executable, str(ok)], have=2) == 2      # fewer GPUs than ranks: refused
+
+
 def test_bench_is_torch_free():
     """bench.py must not import torch in-process (second HIP runtime; see rendezvous.py)."""
     src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")).read()

@@ -649,8 +649,9 @@ def test_rccl_single_rank_and_gradient_sync(nk, tdev):
 @pytest.mark.gpu
 def test_gradient_sync_piecewise_exchange(nk, tdev):
     """The C4-sized weight gradient is produced and handed to the exchange in two row blocks (only half of the last
-    gradient stays exposed behind the backward pass).  With one rank the sum is the identity, so the gradients must
-    equal those of a plain backward bit for bit, and the hook must have issued 2 pieces + 1 bias per layer."""
+    gradient stays exposed behind the backward pass); the bias gradients of the whole model travel as ONE group, sent
+    as soon as the last of them is final.  With one rank the sum is the identity, so the gradients must equal those of
+    a plain backward bit for bit, and the hook must have issued 2 pieces per layer + 1 group."""
     tcomm = nk.dp.Communicator(tdev, 1, 0, nk.dp.Communicator.unique_id())
     lins = [nk.nn.Linear(tdev, 4096, 4096, s) for s in (1, 3)]
     params = [p for l in lins for p in (l.weight, l.bias)]
@@ -660,19 +661,80 @@ def test_gradient_sync_piecewise_exchange(nk, tdev):
     want = [p.grad().copy() for p in params]
     sync = nk.dp.GradientSync(tcomm, params)
     sync.set_force_exchange(True)
+    total = sum(int(np.prod(p.shape)) for p in params)
     for rep in range(2):
         for p in params:
             p.zero_grad()
         loss.no_grad(); loss.with_grad()
         loss.backward_sync(0.5, sync); sync.join()
-        assert sync.exchanges_issued() == 6 * (rep + 1)        # per layer: 2 halves of dW + db
+        assert sync.exchanges_issued() == 5 * (rep + 1)        # per layer: 2 halves of dW; + one group of both biases
+        assert sync.elements_exchanged() == total * (rep + 1)
         for p, w in zip(params, want):
             assert np.array_equal(p.grad(), w)
-    small = nk.nn.Linear(tdev, 64, 64, 9)                      # below the threshold: one exchange per gradient
+    small = nk.nn.Linear(tdev, 64, 64, 9)                      # everything below the threshold: one group
     s2 = nk.dp.GradientSync(tcomm, [small.weight, small.bias]); s2.set_force_exchange(True)
     l2 = small.forward(nk.rand(tdev, [8, 64], 1)).sum()
     l2.forward(); l2.backward_sync(1.0, s2); s2.join()
-    assert s2.exchanges_issued() == 2
+    assert s2.exchanges_issued() == 1
+    s3 = nk.dp.GradientSync(tcomm, [small.weight, small.bias], small_elems=0); s3.set_force_exchange(True)   # no grouping
+    small.weight.zero_grad(); small.bias.zero_grad(); l2.no_grad(); l2.with_grad()
+    l2.backward_sync(1.0, s3); s3.join()
+    assert s3.exchanges_issued() == 2
+
+
+def _replica_check(nk, tdev, ranks, build, seed=1.0):
+    """Run `build()`'s loss once plainly and once through GradientSync over a replica communicator of `ranks` virtual
+    ranks that all hold this rank's values: every element of every registered gradient must come back multiplied by
+    `ranks` exactly once - an element skipped, sent twice or sent before its last writer ran shows up as a mismatch
+    (a sum over ONE real rank is the identity and would hide all three)."""
+    loss, params = build()
+    loss.forward(); loss.backward(seed)
+    want = [p.grad().copy() for p in params]
+    comm = nk.dp.Communicator.replicas(tdev, ranks)
+    assert comm.size == ranks
+    sync = nk.dp.GradientSync(comm, params)
+    for rep in range(2):
+        for p in params:
+            p.zero_grad()
+        loss.no_grad(); loss.with_grad()
+        loss.backward_sync(seed, sync); sync.join()
+        for p, w in zip(params, want):
+            assert np.array_equal(p.grad(), w * np.float32(ranks)), p.shape
+    assert sync.elements_exchanged() == 2 * sum(int(np.prod(p.shape)) for p in params)
+    return sync
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ranks", [2, 8])
+def test_gradient_sync_covers_every_element_once(nk, tdev, ranks):
+    def mlp():                                                 # C4-shaped: piecewise weight gradients + grouped biases
+        lins = [nk.nn.Linear(tdev, 4096, 4096, s) for s in (1, 3, 5)]
+        X, T = nk.rand(tdev, [128, 4096], 5), nk.rand(tdev, [128, 4096], 6)
+        loss = lins[2].forward(lins[1].forward(lins[0].forward(X).relu()).relu()).mse(T, nk.Reduction.Mean)
+        return loss, [p for l in lins for p in (l.weight, l.bias)]
+    sync = _replica_check(nk, tdev, ranks, mlp, 1.0 / ranks)
+    assert sync.exchanges_issued() == 2 * (3 * 2 + 1)
+
+    def ragged():                                              # below the split threshold, odd sizes, a mid-sized weight
+        l1, l2 = nk.nn.Linear(tdev, 300, 700, 1), nk.nn.Linear(tdev, 700, 129, 2)
+        loss = l2.forward(l1.forward(nk.rand(tdev, [37, 300], 3)).relu()).sum()
+        return loss, [l1.weight, l1.bias, l2.weight, l2.bias]
+    _replica_check(nk, tdev, ranks, ragged)
+
+
+@pytest.mark.gpu
+def test_gradient_sync_shared_linear(nk, tdev):
+    """A Linear applied twice (tied weights, an unrolled recurrence): its weight gradient has two writers on the tape.
+    The piecewise hand-over must wait for the LAST writer - the first one keeps the single-GEMM path and the exchange
+    happens once, after the second accumulation (it used to start on the first node's rows while the second node was
+    still accumulating into the same buffer on the compute stream, and to reduce those rows twice)."""
+    def tied():
+        lin = nk.nn.Linear(tdev, 4096, 4096, 1)
+        X = nk.rand(tdev, [128, 4096], 5)
+        loss = lin.forward(lin.forward(X).relu()).mse(nk.rand(tdev, [128, 4096], 6), nk.Reduction.Mean)
+        return loss, [lin.weight, lin.bias]
+    sync = _replica_check(nk, tdev, 2, tied)
+    assert sync.exchanges_issued() == 2 * (2 + 1)              # the last writer's two halves + the bias group, per pass
 
 
 @pytest.mark.gpu
