@@ -159,6 +159,18 @@ template class History<BackwardEntry>;
 // =================================================================================================
 // helpers
 // =================================================================================================
+// Philox key of the next random node (Dropout, fused attention probabilities).  The reference draws from
+// `rand::thread_rng()` (dropout/mod.rs:68-70), seeded by the OS; here every node gets its own key from one per-thread
+// sequence that `manual_seed` restarts, so a run is reproducible and data-parallel ranks can decorrelate their masks
+// (`manual_seed(base + rank)`).
+static thread_local uint64_t g_node_seed = 0x9E3779B97F4A7C15ull;
+void manual_seed(uint64_t seed) { g_node_seed = seed; }
+static uint64_t next_node_seed() {
+    const uint64_t s = g_node_seed;
+    g_node_seed += 0x632BE59BD9B4E019ull;
+    return s;
+}
+
 namespace {
 
 nk_device* D(const Shared<HipArray>& a) { return a->device()->raw(); }
@@ -961,8 +973,7 @@ Var Var::dropout(double p, Shared<bool> status) const {
     auto op = std::make_shared<DropoutFwd>();
     op->x = data; op->y = zeros_like(data, shape()); op->noise = zeros_like(data, shape());
     op->p = p; op->status = std::move(status);
-    static uint64_t next_seed = 0x9E3779B97F4A7C15ull;
-    op->seed = next_seed; next_seed += 0x632BE59BD9B4E019ull;
+    op->seed = next_node_seed();
     op->calls = std::make_shared<uint64_t>(0);
     auto y = op->y;
     return Var::node(y, op, history);
@@ -1137,8 +1148,7 @@ Var Var::attention_probs(float scale, double p, Shared<bool> status, bool store_
     op->x = data; op->out = zeros_like(data, shape());
     if (store_probs) op->probs = zeros_like(data, shape());
     op->scale = scale; op->p = p; op->status = std::move(status);
-    static uint64_t next_seed = 0xD1B54A32D192ED03ull;
-    op->seed = next_seed; next_seed += 0x9E3779B97F4A7C15ull;
+    op->seed = next_node_seed();
     op->calls = std::make_shared<uint64_t>(0);
     op->last_offset = std::make_shared<uint64_t>(0);
     auto y = op->out;

@@ -427,6 +427,10 @@ Var rand(DevicePtr dev, const Shape& shape, uint64_t seed);  // U[0,1) (host RNG
 // ---------------------------------------------------------------------------------------------
 // neuronika-nn
 // ---------------------------------------------------------------------------------------------
+// Restart the per-thread sequence of Philox keys handed to random nodes: the next Dropout / attention-probabilities
+// node built on this thread uses key `seed`, the one after it seed + 0x632BE59BD9B4E019, ...
+void manual_seed(uint64_t seed);
+
 namespace nn {
 
 // neuronika-nn/src/init.rs: parameter initialisers.  Values are produced on the host and uploaded (one-off work at

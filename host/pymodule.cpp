@@ -149,6 +149,7 @@ PYBIND11_MODULE(_tape, m) {
     m.def("ones", &ones);
     m.def("full", &full);
     m.def("rand", &neuronika::rand);
+    m.def("manual_seed", &neuronika::manual_seed, py::arg("seed"));
     m.def("eye", &eye); m.def("linspace", &linspace); m.def("logspace", &logspace); m.def("geomspace", &geomspace);
     m.def("range", &neuronika::range);
 

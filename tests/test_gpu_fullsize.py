@@ -125,3 +125,59 @@ def test_C5_attention_full_size(nk):
     assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max()
     gx = X.grad()[rows]
     assert np.abs(gx - grads["x"]).max() <= 2e-5 * np.abs(grads["x"]).max()
+
+
+def _mha_oracle64(mha, x, g, H, B, p, noise):
+    dt = np.float64
+    W = {n: (getattr(mha, n).weight.data().astype(dt), getattr(mha, n).bias.data().astype(dt)) for n in "qkvo"}
+    return O.mha_forward_backward(x.astype(dt), *W["q"], *W["k"], *W["v"], *W["o"], H, B, p, noise, g.astype(dt))
+
+
+def test_C5_attention_full_size_with_dropout(nk):
+    """C5 exactly as benchmarked (d=1024, h=16, S=1024, B=32, dropout 0.1, fused probabilities recomputed in the
+    backward pass): output rows and input gradients of ONE sample against the f64 oracle of that sample, fed the
+    Philox mask of that sample's slice of the (B*H, S, S) probabilities (key from manual_seed, counter offset
+    b*H*S*S/4).  Attention does not couple samples, so one sample pins the activations path at full size; the
+    parameter gradients (sums over the batch) are pinned at this geometry by the 4-sample test below."""
+    dev = nk.Device(0)
+    B, S, d, H, p, seed = 32, 1024, 1024, 16, 0.1, 7
+    nk.manual_seed(seed)
+    mha = nk.nn.MultiheadAttention(dev, d, H, p, 1)
+    x = rnd(0, (B * S, d)); g = rnd(5, (B * S, d))
+    X = nk.from_ndarray(dev, x).requires_grad()
+    out = mha.forward(X, B)
+    out.forward(); out.backward_from(nk.from_ndarray(dev, g))
+    b = 29
+    rows = slice(b * S, (b + 1) * S)
+    noise = O.dropout_noise(H * S * S, p, seed, b * H * S * S // 4).reshape(H, S, S).astype(np.float64)
+    ref, grads = _mha_oracle64(mha, x[rows], g[rows], H, 1, p, noise)
+    got = out.data()[rows]
+    assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max()
+    gx = X.grad()[rows]
+    assert np.abs(gx - grads["x"]).max() <= 2e-5 * np.abs(grads["x"]).max()
+    # a different mask must NOT match (the check has teeth): the neighbouring sample's mask
+    wrong = O.dropout_noise(H * S * S, p, seed, (b - 1) * H * S * S // 4).reshape(H, S, S).astype(np.float64)
+    ref_w, _ = _mha_oracle64(mha, x[rows], g[rows], H, 1, p, wrong)
+    assert np.abs(got - ref_w).max() > 1e-3 * np.abs(ref).max()
+
+
+def test_C5_geometry_parameter_gradients_with_dropout(nk):
+    """The C5 layer shape (d=1024, h=16, S=1024, dropout 0.1: the L = 1024 instances of the fused probability
+    kernels, the K = 64 attention GEMMs, the 1024 x 1024 x (B*S) weight-gradient GEMMs) on a 4-sample batch the f64
+    oracle can replay whole: output, input gradient and ALL EIGHT parameter gradients (which sum over samples)."""
+    dev = nk.Device(0)
+    B, S, d, H, p, seed = 4, 1024, 1024, 16, 0.1, 99
+    nk.manual_seed(seed)
+    mha = nk.nn.MultiheadAttention(dev, d, H, p, 1)
+    x = rnd(0, (B * S, d), -1, 1); g = rnd(5, (B * S, d), -1, 1)
+    X = nk.from_ndarray(dev, x).requires_grad()
+    out = mha.forward(X, B)
+    out.forward(); out.backward_from(nk.from_ndarray(dev, g))
+    noise = O.dropout_noise(B * H * S * S, p, seed, 0).reshape(B * H, S, S).astype(np.float64)
+    ref, grads = _mha_oracle64(mha, x, g, H, B, p, noise)
+    rel = lambda a, b: np.abs(a - b).max() / np.abs(b).max()
+    assert rel(out.data(), ref) <= 1e-5
+    assert rel(X.grad(), grads["x"]) <= 2e-5
+    for n in "qkvo":
+        assert rel(getattr(mha, n).weight.grad(), grads["w" + n]) <= 2e-5, n      # K = B*S = 4096 f32 fma chains
+        assert rel(getattr(mha, n).bias.grad(), grads["b" + n]) <= 2e-5, n

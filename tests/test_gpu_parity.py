@@ -836,6 +836,49 @@ def test_assign_variants_equal_accumulate_into_zeros(dev):
         assert np.array_equal(R.numpy(), Z.numpy())
 
 
+@pytest.mark.parametrize("rows,L", [(512, 1024), (96, 2048), (300, 516), (64, 128)])
+def test_attention_probs_paths_agree_at_benchmark_width(dev, rows, L):
+    """At the row lengths the C5 bench runs (L = 1024: a different template instance from the L = 64 case above):
+    probabilities stored by the forward and recomputed from the scores in the backward (what the bench runs) agree
+    BIT for bit; the three reference nodes Multiplication(scalar) -> Softmax -> Dropout through the C ABI give the
+    same keep/drop pattern exactly and the same values to f32 rounding; all match the oracle fed the same Philox mask."""
+    c = capi()
+    p, scale, seed, off = 0.1, 0.125, 77, 1000
+    sc, g = rnd(7, (rows, L), -3, 3), rnd(8, (rows, L), -1, 1)
+    Sx, Gs = dev.array(sc), dev.array(g)
+    P, O1, O2 = dev.zeros(sc.shape), dev.zeros(sc.shape), dev.zeros(sc.shape)
+    c.scale_softmax_dropout_fwd(dev, Sx, P, O1, None, scale, p, True, seed, off)
+    c.scale_softmax_dropout_fwd(dev, Sx, None, O2, None, scale, p, True, seed, off)
+    assert np.array_equal(O1.numpy(), O2.numpy())
+    D1, D2 = dev.zeros(sc.shape), dev.zeros(sc.shape)
+    c.scale_softmax_dropout_bwd(dev, D1, Gs, P, None, scale, p, True, seed, off)
+    c.scale_softmax_dropout_bwd_from_scores(dev, D2, Gs, Sx, None, scale, p, True, seed, off, assign=False)
+    assert np.array_equal(D1.numpy(), D2.numpy())
+    # three reference nodes through the C ABI
+    Ssc, Psm, Od, Nz = dev.zeros(sc.shape), dev.zeros(sc.shape), dev.zeros(sc.shape), dev.zeros(sc.shape)
+    c.binary_fwd(dev, "mul", Ssc, Sx, dev.array(np.float32(scale).reshape(())))
+    c.softmax_fwd(dev, Ssc, Psm, 1)
+    c.dropout_fwd(dev, Psm, Od, Nz, p, True, seed, off)
+    noise = O.dropout_noise(rows * L, p, seed, off).reshape(rows, L)
+    assert np.array_equal(Nz.numpy(), noise)                                   # the mask, bit for bit
+    assert np.array_equal(O1.numpy() != 0, (noise != 0) & (P.numpy() != 0))    # fused node drops exactly the same elements
+    np.testing.assert_allclose(Psm.numpy(), P.numpy(), rtol=2e-6, atol=1e-30)
+    np.testing.assert_allclose(Od.numpy(), O1.numpy(), rtol=2e-6, atol=1e-30)
+    Dp, Dsm, Dsc = dev.zeros(sc.shape), dev.zeros(sc.shape), dev.zeros(sc.shape)
+    c.dropout_bwd(dev, Dp, Gs, Nz, p, True)
+    c.softmax_bwd(dev, Dsm, Dp, Psm, 1)
+    c.binary_bwd_left(dev, "mul", Dsc, Dsm, dev.array(np.float32(scale).reshape(())))
+    np.testing.assert_allclose(Dsc.numpy(), D1.numpy(), rtol=1e-5, atol=1e-7)
+    # and the oracle (f64) on the same mask
+    s64 = sc.astype(np.float64) * np.float64(np.float32(scale))
+    pr = np.zeros_like(s64); O.softmax_forward(s64, pr, 1)
+    od = np.zeros_like(pr); O.dropout_forward(pr, od, noise.astype(np.float64), p, True)
+    np.testing.assert_allclose(O1.numpy(), od, rtol=2e-5, atol=1e-9)
+    dpr = np.zeros_like(pr); O.dropout_backward(dpr, g.astype(np.float64), noise.astype(np.float64), p, True)
+    dsm = np.zeros_like(pr); O.softmax_backward(dsm, dpr, pr, 1)
+    np.testing.assert_allclose(D1.numpy(), dsm * np.float64(np.float32(scale)), rtol=1e-4, atol=2e-7)
+
+
 # ------------------------------------------------------------------------------ fused Linear forward
 @pytest.mark.parametrize("n,m,o", [(64, 3, 5), (4, 8, 1), (128, 128, 128), (300, 77, 200), (8, 4096, 64), (512, 256, 384)])
 def test_linear_fwd_equals_mm_t_plus_bias(dev, n, m, o):

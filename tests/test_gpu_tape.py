@@ -609,6 +609,54 @@ def test_mha_fused_equals_unfused_with_dropout(nk, tdev):
     close(ev, o0.data(), 1e-6, 1e-7)                         # eval mode == no dropout
 
 
+def _mha_oracle(mha, x, g, H, B, p, noise, dt=np.float64):
+    W = [getattr(mha, n).weight.data().astype(dt) for n in "qkvo"]
+    Bs = [getattr(mha, n).bias.data().astype(dt) for n in "qkvo"]
+    return O.mha_forward_backward(x.astype(dt), W[0], Bs[0], W[1], Bs[1], W[2], Bs[2], W[3], Bs[3], H, B, p,
+                                  noise.astype(dt), g.astype(dt))
+
+
+@pytest.mark.parametrize("fused,strided", [(True, True), (False, True), (True, False), (False, False)])
+@pytest.mark.parametrize("p", [0.1, 0.5])
+def test_mha_with_dropout_equals_oracle(nk, tdev, fused, strided, p):
+    """The module AS BENCHMARKED (dropout in training mode) end to end against the oracle composition of SURVEY.md
+    section 8a: the oracle is fed the Philox mask the device draws (`O.dropout_noise` with the node's key and offset,
+    key fixed by `manual_seed`), and the output, the input gradient and all eight parameter gradients must agree -
+    for the fused node (stored and recomputed probabilities), the three reference nodes, and both head layouts.
+    A second forward resamples the mask (offset advances) and is checked the same way."""
+    B, S, d, H = 2, 64, 128, 4
+    x, g = rnd(0, (B * S, d), -1, 1), rnd(5, (B * S, d), -1, 1)
+    seed = 1234567
+    nk.manual_seed(seed)
+    mha = nk.nn.MultiheadAttention(tdev, d, H, p, 3)
+    mha.fused, mha.strided_heads = fused, strided
+    X = nk.from_ndarray(tdev, x).requires_grad()
+    y = mha.forward(X, B)
+    G = nk.from_ndarray(tdev, g)
+    leaves = [X] + [getattr(getattr(mha, n), w) for n in "qkvo" for w in ("weight", "bias")]
+    n = B * H * S * S
+    for call in range(2):
+        noise = O.dropout_noise(n, p, seed, call * ((n + 3) // 4)).reshape(B * H, S, S)
+        assert 0.5 * (1 - p) < noise.mean() < min(1.0, 1.5 * (1 - p))
+        for v in leaves:
+            v.zero_grad()
+        y.forward(); y.no_grad(); y.with_grad()
+        y.backward_from(G)
+        ref, grads = _mha_oracle(mha, x, g, H, B, p, noise)
+        ref32, grads32 = _mha_oracle(mha, x, g, H, B, p, noise, np.float32)
+        def check(got, want, want32, what):
+            scale = np.abs(want).max()
+            err_gpu, err_cpu = np.abs(got - want).max(), np.abs(want32 - want).max()
+            assert err_gpu <= max(4 * err_cpu, 2e-6 * scale), (what, call, err_gpu, err_cpu, scale)
+        check(y.data(), ref, ref32, "out")
+        check(X.grad(), grads["x"], grads32["x"], "dx")
+        for nme in "qkvo":
+            check(getattr(mha, nme).weight.grad(), grads["w" + nme], grads32["w" + nme], "dw" + nme)
+            check(getattr(mha, nme).bias.grad(), grads["b" + nme], grads32["b" + nme], "db" + nme)
+    if call == 1:                                    # the two forwards drew different masks
+        assert not np.array_equal(O.dropout_noise(n, p, seed, 0), noise.reshape(-1))
+
+
 def test_rccl_single_rank_and_gradient_sync(nk, tdev):
     """Exercise the RCCL entry points on the GPU box (1 GPU => world of one): unique id,
     communicator, side-stream all-reduce ordered after a compute-stream event, join; and the
