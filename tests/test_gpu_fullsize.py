@@ -180,4 +180,8 @@ def test_C5_geometry_parameter_gradients_with_dropout(nk):
     assert rel(X.grad(), grads["x"]) <= 2e-5
     for n in "qkvo":
         assert rel(getattr(mha, n).weight.grad(), grads["w" + n]) <= 2e-5, n      # K = B*S = 4096 f32 fma chains
-        assert rel(getattr(mha, n).bias.grad(), grads["b" + n]) <= 2e-5, n
+        # bias gradient = column sums of the same dZ the weight gradient contracts; the key bias gradient is exactly
+        # zero in exact arithmetic (softmax is shift-invariant along the key axis), so the yardstick is the size of the
+        # terms summed, taken from the weight gradient, not the (vanishing) result
+        scale = max(np.abs(grads["b" + n]).max(), np.abs(grads["w" + n]).max())
+        assert np.abs(getattr(mha, n).bias.grad() - grads["b" + n]).max() <= 2e-5 * scale, n
