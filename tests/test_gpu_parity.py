@@ -367,6 +367,36 @@ def test_sgemm_large_rowsum_identity(dev):
             assert abs(got[i, j] - opa[i] @ opb[:, j]) <= 1e-6 * n
 
 
+@pytest.mark.parametrize("n", [1024, 2048, 8192])
+def test_C2_matmul_fwd_bwd_every_benchmark_size(dev, n):
+    """BASELINE config 2 at its other sizes (4096 is the test above): the node entry points the C2 bench times
+    (`nk_mm_fwd` NN, `nk_mm_bwd_left` NT `+=`, `nk_mm_bwd_right` TN `+=`) at N = 1024 / 2048 (small grids: the 64x64
+    and split-K branches) and N = 8192 (1 GiB of operands: tile count, XCD chunking, look-ahead path), each checked
+    through 96 sampled entries against f64 dot products of the operand rows/columns and through the row-sum identity
+    (A.B).1 == A.(B.1) over the whole result.  Gradients start from a non-zero value so `+=` is exercised."""
+    c = capi()
+    a, b, g = rnd(0, (n, n)), rnd(1, (n, n)), rnd(2, (n, n))
+    A, B, G = dev.array(a), dev.array(b), dev.array(g)
+    Cm, dA, dB = dev.zeros((n, n)), dev.full((n, n), 0.5), dev.full((n, n), -0.25)
+    c.mm_fwd(dev, A, B, Cm); c.mm_bwd_left(dev, dA, G, B); c.mm_bwd_right(dev, dB, A, G)
+    rng = np.random.default_rng(5)
+    idx = list(zip(rng.integers(0, n, 96), rng.integers(0, n, 96)))
+    ones = np.ones(n)
+    a64 = b64 = g64 = None
+    for name, got_d, init, left, right, tl, tr in (("C", Cm, 0.0, a, b, False, False), ("dA", dA, 0.5, g, b, False, True),
+                                                   ("dB", dB, -0.25, a, g, True, False)):
+        got = got_d.numpy()
+        for i, j in idx:
+            row = (left[:, i] if tl else left[i]).astype(np.float64)
+            col = (right[j] if tr else right[:, j]).astype(np.float64)
+            assert abs(got[i, j] - (init + row @ col)) <= 1e-6 * n, (name, i, j)
+        # (L.R).1 = L.(R.1): f64 on the host costs two matrix-vector products
+        opr1 = (right.astype(np.float64).sum(axis=0) if tr else right.astype(np.float64) @ ones)
+        want_rows = (left.astype(np.float64).T @ opr1 if tl else left.astype(np.float64) @ opr1) + init * n
+        np.testing.assert_allclose(got.sum(axis=1, dtype=np.float64), want_rows, rtol=3e-6, err_msg=name)
+        del got
+
+
 # ------------------------------------------------------------------------------ binaries
 BCAST = [((64, 96), (96,)), ((96,), (64, 96)), ((2, 2, 3), (1, 3)), ((1, 3), (2, 2, 3)), ((4, 8, 5, 6), (8, 1, 1)),
          ((7, 5), ()), ((33, 1), (1, 17)), ((2, 3, 1, 5, 2), (3, 4, 1, 2)), ((512, 1024), (512, 1024)), ((5, 7), (5, 7))]
