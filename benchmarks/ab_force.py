@@ -1,4 +1,4 @@
-"""Calibration sweep: every (ti, tj, splits) candidate for a few GEMM shapes (needs the NK_AB_GEMM_FORCE build)."""
+"""Calibration sweep: every (ti, tj, splits) candidate for a few GEMM shapes (NK_GEMM_FORCE="ti,tj,splits[,chunk]" is read by the library at run time)."""
 import json, os, subprocess, sys
 ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 if len(sys.argv) > 1:
@@ -15,7 +15,7 @@ if len(sys.argv) > 1:
     sys.exit(0)
 shapes = [(0, 0, 1024, 1024, 1024), (0, 0, 1536, 1536, 1536), (0, 0, 2048, 2048, 2048), (0, 0, 512, 512, 8192), (1, 0, 1024, 1024, 32768),
           (0, 1, 64, 4096, 4096), (0, 0, 256, 256, 4096), (0, 0, 768, 768, 768), (0, 0, 4096, 256, 1024)]
-env = dict(os.environ, NEURONIKA_HIP_LIB=os.path.join(ROOT, "benchmarks", "_ab", "force.so"))
+env = dict(os.environ)
 for sh in shapes:
     res = {}
     for ti, tj in ((2, 2), (2, 1), (1, 2), (1, 1)):

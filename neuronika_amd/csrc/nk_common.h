@@ -81,11 +81,7 @@ static inline size_t nk_numel(const int* shape, int nd) {
 static inline int nk_stream_grid(size_t work_items, int block) {
     size_t b = (work_items + block - 1) / block;
     if (b < 1) b = 1;
-#ifdef NK_AB_GRID
-    if (b > NK_AB_GRID) b = NK_AB_GRID;
-#else
     if (b > 8192) b = 8192;
-#endif
     return (int)b;
 }
 
@@ -94,12 +90,8 @@ static inline int nk_stream_grid(size_t work_items, int block) {
 // (dropout fwd 5.1 -> 6.9 TB/s) against plain stores.
 typedef float nk_v4f __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void nk_store_stream(float4* p, const float4& v) {
-#ifdef NK_AB_NO_NT
-    *p = v;
-#else
     nk_v4f t = {v.x, v.y, v.z, v.w};
     __builtin_nontemporal_store(t, reinterpret_cast<nk_v4f*>(p));
-#endif
 }
 
 

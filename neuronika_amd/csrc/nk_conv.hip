@@ -110,7 +110,6 @@ int conv_fwd(nk_device* dev, int nd, const float* x, const int* x_shape, const f
         int nblocks = tiles;
         size_t slab_bytes = 0;
         fp.full_blocks = tiles;
-#ifndef NK_AB_NO_TAIL
         const int tail = tiles % slots;
         if (groups == 1 && tiles > slots && tail > 0 && tail * 2 <= slots && nkt >= 4) {
             int S = slots / tail;
@@ -125,7 +124,6 @@ int conv_fwd(nk_device* dev, int nd, const float* x, const int* x_shape, const f
                 slab_bytes = (size_t)tail * S * (64 * fti) * 128 * sizeof(float);
             }
         }
-#endif
         void* wsf = nullptr;
         rc = nk_workspace(dev, tables + slab_bytes, &wsf);
         if (rc) return rc;

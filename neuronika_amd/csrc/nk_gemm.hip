@@ -11,6 +11,8 @@
 
 using namespace nkmma;
 
+constexpr int PF2_MIN_KTILES = 48;  // reductions at least this long take the two-k-tile look-ahead loop
+
 struct GemmArgs {
     const float* A;
     const float* B;
@@ -27,10 +29,64 @@ struct GemmArgs {
     int k_per_split;  // multiple of BK
     float* slabs;     // [splits][batch][M][N] partials when splits > 1
     int tiles_m, tiles_n;
+    // Short reductions (attention's K = 64: two k-tiles per output tile): a block walks `chunk` consecutive tiles of the
+    // tile sequence and loads the first k-tile of the next one before the last MFMA block of the current one, so the
+    // per-tile launch / first-load / store-drain bubble (~7 us, as long as the whole K = 64 tile) is paid once per chunk.
+    int chunk;        // >= 1 tiles per block (1: one tile per block, the classic grid)
 };
 
+// C tile <- accumulators (or the split's slab).  Every load (bias, old C) is issued first and folded into the accumulators
+// in registers; the stores come last.  (A one-walk `*q = f(*q)` serialises 16*TI*TJ load -> store round trips per lane,
+// and loads still pending when the per-element conditional store blocks are entered make each of them wait for the
+// previous store as well.)
+template <bool ALIGNED, int TI, int TJ>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[TI][TJ], int m0, int n0, int bo, int bi, int split,
+                                              int batch, int wr, int wc, int lane) {
+    if (p.splits > 1) {
+        float* S = p.slabs + ((long long)split * gridDim.z + batch) * (long long)p.M * p.N;
+        const int M = p.M, N = p.N;
+        acc_foreach<TI, TJ>(acc, wr, wc, lane, [&](int r, int c, float v) {
+            const int row = m0 + r, col = n0 + c;
+            if (ALIGNED || (row < M && col < N)) S[(long long)row * N + col] = v;
+        });
+        return;
+    }
+    float* C = p.C + bo * p.sCo + bi * p.sCi;
+    const float alpha = p.alpha, beta = p.beta;
+    const int M = p.M, N = p.N;
+    const long long ldc = p.ldc;
+    if (p.bias != nullptr || beta != 0.f || alpha != 1.f) {
+        float old[TI][TJ][16];
+        if (beta != 0.f)
+            acc_foreach_idx<TI, TJ>(acc, wr, wc, lane, [&](int i, int j, int e, int r, int c, float) {
+                const int row = m0 + r, col = n0 + c;
+                old[i][j][e] = (ALIGNED || (row < M && col < N)) ? C[row * ldc + col] : 0.f;
+            });
+        float bv[TJ];  // a lane owns TJ columns
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            const int col = n0 + (wc * TJ + j) * 32 + (lane & 31);
+            bv[j] = (p.bias != nullptr && (ALIGNED || col < N)) ? p.bias[col] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    float o = alpha * acc[i][j][e];
+                    if (p.bias != nullptr) o += bv[j];  // Linear: fl(acc + bias[col]) == the separate Addition node
+                    acc[i][j][e] = beta == 0.f ? o : fmaf(beta, old[i][j][e], o);
+                }
+    }
+    acc_foreach<TI, TJ>(acc, wr, wc, lane, [&](int r, int c, float v) {
+        const int row = m0 + r, col = n0 + c;
+        if (ALIGNED || (row < M && col < N)) C[row * ldc + col] = v;
+    });
+}
+
 template <bool TA, bool TB, bool ALIGNED, int TI, int TJ>
-__global__ __launch_bounds__(NT, (min_waves<TI, TJ>())) void sgemm_kernel(GemmArgs p) {
+__global__ __launch_bounds__(NT, (min_waves<TI, TJ, !TA && TB>())) void sgemm_kernel(GemmArgs p) {
     constexpr int BM = 64 * TI, BN = 64 * TJ;
     constexpr bool AKC = !TA;  // A (M x K): k-contiguous unless stored transposed
     constexpr bool BKC = TB;   // B (K x N) stored as N x K when transposed -> k-contiguous
@@ -39,9 +95,12 @@ __global__ __launch_bounds__(NT, (min_waves<TI, TJ>())) void sgemm_kernel(GemmAr
 
     const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
     const int wr = wid >> 1, wc = wid & 1;
+    // this block's tiles: positions [seq, seq_end) of the tile sequence (each XCD gets a contiguous range of chunks)
+    int seq = xcd_chunk(blockIdx.x, gridDim.x) * p.chunk;
+    const int seq_end = min(p.tiles_m * p.tiles_n, seq + p.chunk);
     int tm, tn;
-    tile_coords(blockIdx.x, gridDim.x, p.tiles_m, p.tiles_n, tm, tn);
-    const int m0 = tm * BM, n0 = tn * BN;
+    tile_of_seq(seq, p.tiles_m, p.tiles_n, tm, tn);
+    int m0 = tm * BM, n0 = tn * BN;
     const int batch = blockIdx.z, split = blockIdx.y;
     const int bo = batch / p.batch_inner, bi = batch % p.batch_inner;
     const float* A = p.A + bo * p.sAo + bi * p.sAi;
@@ -63,12 +122,8 @@ __global__ __launch_bounds__(NT, (min_waves<TI, TJ>())) void sgemm_kernel(GemmAr
     // Same-box A/B at 4096^3 (benchmarks/ab_gemm.py): NT +2.9 %, NN +1.2 %, TN -1.0 % (its A operand is read k-major,
     // the loads land early anyway); short reductions lose to the longer prologue (NT 4096x3072x1024: -2 %).  So: row-major
     // A only, aligned problems only (the guarded loader's state does not fit next to P and Q), at least 48 k-tiles.
-#ifndef NK_AB_NO_PF2
     constexpr bool PF2 = ALIGNED && !TA;
-#else
-    constexpr bool PF2 = false;
-#endif
-    if (PF2 && nt >= 48) {
+    if (PF2 && nt >= PF2_MIN_KTILES) {  // (the host launches these one tile per block: chunk == 1)
     // Two k-tiles of look-ahead in registers: tile it+1 (P, loaded during the previous trip) goes to LDS at the START of a
     // trip, the loads of tile it+2 (Q) are issued in front of it and have a whole trip plus to land.  The end of a trip is
     // then MFMAs -> barrier, instead of MFMAs -> wait for this trip's own loads -> 8 LDS writes -> barrier.  Unrolled by
@@ -128,6 +183,8 @@ __global__ __launch_bounds__(NT, (min_waves<TI, TJ>())) void sgemm_kernel(GemmAr
         }
     }
     } else {
+    // One k-tile of look-ahead, over the block's whole chunk of tiles: the loads issued in front of the LAST MFMA block
+    // of a tile are the first k-tile of the NEXT tile.
     if (nt > 0) {
         ra = la.template load<ALIGNED>(t);
         rb = lb.template load<ALIGNED>(t);
@@ -135,70 +192,51 @@ __global__ __launch_bounds__(NT, (min_waves<TI, TJ>())) void sgemm_kernel(GemmAr
         stage_store<BKC, BN>(smem + TA_FLOATS, rb, t);
     }
     __syncthreads();
-    for (int it = 0; it + 1 < nt; ++it) {
-        float* cur = smem + (it & 1) * STAGE;
-        float* nxt = smem + ((it + 1) & 1) * STAGE;
-        // issue the next tile's HBM/L2 loads before the MFMAs (their latency hides under them),
-        // write them to the other LDS buffer behind the MFMAs: one barrier per k-tile
-        ra = la.template load<ALIGNED>(t);
-        rb = lb.template load<ALIGNED>(t);
-        __builtin_amdgcn_sched_barrier(0);
-        mma_tile<AKC, BKC, TI, TJ>(cur, cur + TA_FLOATS, acc, wr, wc, lane);
-        stage_store<AKC, BM>(nxt, ra, t);
-        stage_store<BKC, BN>(nxt + TA_FLOATS, rb, t);
-        __syncthreads();
-    }
-    if (nt > 0) {
-        float* cur = smem + ((nt - 1) & 1) * STAGE;
-        mma_tile<AKC, BKC, TI, TJ>(cur, cur + TA_FLOATS, acc, wr, wc, lane);
-    }
-
-    }
-
-    if (p.splits > 1) {
-        float* S = p.slabs + ((long long)split * gridDim.z + batch) * (long long)p.M * p.N;
-        const int M = p.M, N = p.N;
-        acc_foreach<TI, TJ>(acc, wr, wc, lane, [&](int r, int c, float v) {
-            const int row = m0 + r, col = n0 + c;
-            if (ALIGNED || (row < M && col < N)) S[(long long)row * N + col] = v;
-        });
-        return;
-    }
-    float* C = p.C + bo * p.sCo + bi * p.sCi;
-    const float alpha = p.alpha, beta = p.beta;
-    const int M = p.M, N = p.N;
-    const long long ldc = p.ldc;
-    // Every load (bias, old C) is issued first and folded into the accumulators in registers; the stores come last.  (A
-    // one-walk `*q = f(*q)` serialises 16*TI*TJ load -> store round trips per lane, and loads still pending when the
-    // per-element conditional store blocks are entered make each of them wait for the previous store as well.)
-    if (p.bias != nullptr || beta != 0.f || alpha != 1.f) {
-        float old[TI][TJ][16];
-        if (beta != 0.f)
-            acc_foreach_idx<TI, TJ>(acc, wr, wc, lane, [&](int i, int j, int e, int r, int c, float) {
-                const int row = m0 + r, col = n0 + c;
-                old[i][j][e] = (ALIGNED || (row < M && col < N)) ? C[row * ldc + col] : 0.f;
-            });
-        float bv[TJ];  // a lane owns TJ columns
-#pragma unroll
-        for (int j = 0; j < TJ; ++j) {
-            const int col = n0 + (wc * TJ + j) * 32 + (lane & 31);
-            bv[j] = (p.bias != nullptr && (ALIGNED || col < N)) ? p.bias[col] : 0.f;
+    int par = 0;  // LDS buffer that holds the current k-tile
+    for (;;) {
+        for (int it = 0; it + 1 < nt; ++it) {
+            float* cur = smem + par * STAGE;
+            float* nxt = smem + (par ^ 1) * STAGE;
+            // issue the next tile's HBM/L2 loads before the MFMAs (their latency hides under them),
+            // write them to the other LDS buffer behind the MFMAs: one barrier per k-tile
+            ra = la.template load<ALIGNED>(t);
+            rb = lb.template load<ALIGNED>(t);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_tile<AKC, BKC, TI, TJ>(cur, cur + TA_FLOATS, acc, wr, wc, lane);
+            stage_store<AKC, BM>(nxt, ra, t);
+            stage_store<BKC, BN>(nxt + TA_FLOATS, rb, t);
+            __syncthreads();
+            par ^= 1;
         }
-#pragma unroll
-        for (int i = 0; i < TI; ++i)
-#pragma unroll
-            for (int j = 0; j < TJ; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    float o = alpha * acc[i][j][e];
-                    if (p.bias != nullptr) o += bv[j];  // Linear: fl(acc + bias[col]) == the separate Addition node
-                    acc[i][j][e] = beta == 0.f ? o : fmaf(beta, old[i][j][e], o);
-                }
+        const bool more = seq + 1 < seq_end && nt > 0;
+        int tm2 = 0, tn2 = 0;
+        if (more) {
+            tile_of_seq(seq + 1, p.tiles_m, p.tiles_n, tm2, tn2);
+            la.init(A, p.lda, tm2 * BM, kbeg, p.M, kend, t);
+            lb.init(B, p.ldb, tn2 * BN, kbeg, p.N, kend, t);
+            ra = la.template load<ALIGNED>(t);
+            rb = lb.template load<ALIGNED>(t);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (nt > 0) {
+            float* cur = smem + par * STAGE;
+            mma_tile<AKC, BKC, TI, TJ>(cur, cur + TA_FLOATS, acc, wr, wc, lane);
+        }
+        if (more) {
+            float* nxt = smem + (par ^ 1) * STAGE;
+            stage_store<AKC, BM>(nxt, ra, t);
+            stage_store<BKC, BN>(nxt + TA_FLOATS, rb, t);
+        }
+        gemm_epilogue<ALIGNED, TI, TJ>(p, acc, m0, n0, bo, bi, split, batch, wr, wc, lane);
+        if (!more) return;
+        __syncthreads();  // the next tile's first k-tile is in LDS, everybody is done with the current buffer
+        par ^= 1;
+        acc_zero<TI, TJ>(acc);
+        ++seq;
+        m0 = tm2 * BM; n0 = tn2 * BN;
     }
-    acc_foreach<TI, TJ>(acc, wr, wc, lane, [&](int r, int c, float v) {
-        const int row = m0 + r, col = n0 + c;
-        if (ALIGNED || (row < M && col < N)) C[row * ldc + col] = v;
-    });
+    }
+    gemm_epilogue<ALIGNED, TI, TJ>(p, acc, m0, n0, bo, bi, split, batch, wr, wc, lane);
 }
 
 // Second pass of split-K: C = alpha * sum_s slab[s] + beta * C, fixed summation order.
@@ -246,7 +284,7 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 template <bool TA, bool TB, int TI, int TJ>
 static int launch_tile(nk_device* dev, const GemmArgs& p, int nbatch, bool aligned) {
-    dim3 grid(p.tiles_m * p.tiles_n, p.splits, nbatch), block(NT);
+    dim3 grid((p.tiles_m * p.tiles_n + p.chunk - 1) / p.chunk, p.splits, nbatch), block(NT);
     if (aligned)
         hipLaunchKernelGGL((sgemm_kernel<TA, TB, true, TI, TJ>), grid, block, 0, dev->compute, p);
     else
@@ -335,22 +373,36 @@ static int gemm_impl(nk_device* dev, int transA, int transB, int M, int N, int K
     }
     p.tiles_m = (M + 64 * ti - 1) / (64 * ti);
     p.tiles_n = (N + 64 * tj - 1) / (64 * tj);
-#ifdef NK_AB_GEMM_FORCE  // benchmarks/ab_build.py only: NK_GEMM_FORCE="ti,tj,splits" overrides the heuristic
-    if (const char* f = getenv("NK_GEMM_FORCE")) {
-        int a = 0, b = 0, c = 0;
-        if (sscanf(f, "%d,%d,%d", &a, &b, &c) == 3) {
+    int force_chunk = 0;
+    if (const char* f = getenv("NK_GEMM_FORCE")) {  // tuning sweeps (benchmarks/ab_force.py): "ti,tj,splits[,chunk]" overrides the rules
+        int a = 0, b = 0, c = 0, d = 0;
+        const int got = sscanf(f, "%d,%d,%d,%d", &a, &b, &c, &d);
+        if (got >= 3 && (a == 1 || a == 2) && (b == 1 || b == 2)) {
             ti = a; tj = b; splits = c < 1 ? 1 : c;
             p.tiles_m = (M + 64 * ti - 1) / (64 * ti);
             p.tiles_n = (N + 64 * tj - 1) / (64 * tj);
+            if (got == 4) force_chunk = d;
         }
     }
-#endif
     int kts = (ktiles + splits - 1) / splits;
     if (kts < 1) kts = 1;
     splits = (ktiles + kts - 1) / kts;
     if (splits < 1) splits = 1;
     p.splits = splits;
     p.k_per_split = kts * BK;
+    // Tiles per block: a short reduction (kts k-tiles of ~3.9 us) cannot amortise the ~7 us a block spends being
+    // dispatched, waiting for its first loads and draining its stores, so a block takes enough consecutive tiles of the
+    // sequence for ~32 k-tiles of work - as long as the grid keeps at least four waves of resident blocks.
+    {
+        const long long ntiles = (long long)p.tiles_m * p.tiles_n, slots = ti * tj == 4 ? 512 : (ti * tj == 2 ? 768 : 1024);
+        long long c = kts >= 16 ? 1 : (32 + kts - 1) / kts;
+        const long long cap = ntiles * splits * nbatch / (4 * slots);
+        if (c > cap) c = cap;
+        if (c > ntiles) c = ntiles;
+        if (force_chunk > 0) c = force_chunk;
+        if (c < 1 || kts >= PF2_MIN_KTILES) c = 1;
+        p.chunk = (int)c;
+    }
     if (p.splits > 1) {
         void* ws = nullptr;
         int rc = nk_workspace(dev, (size_t)p.splits * nbatch * M * N * sizeof(float), &ws);

@@ -40,9 +40,11 @@ constexpr int LDK = BK + 4;  // KC row stride (floats)
 // THREE blocks per CU: 2*(64*36 + 128*32)*4 B = 51,200 B  vs  55,296 B (> 160 KB / 3) for two padded images.
 template <bool KC, int R>
 constexpr int tile_floats() { return KC ? R * LDK : R * BK; }
-// blocks per CU the register/LDS budget is sized for -> min waves per SIMD for launch bounds
-template <int TI, int TJ>
-constexpr int min_waves() { return TI * TJ == 4 ? 2 : (TI * TJ == 2 ? 3 : 4); }
+// blocks per CU the register/LDS budget is sized for -> min waves per SIMD for launch bounds.  A 64x128 tile whose two
+// operands are BOTH k-contiguous has two padded images (55,296 B > 160 KB / 3): two blocks per CU by LDS, so its register
+// budget is the two-wave one as well (asking for three only made the compiler miss the target and warn).
+template <int TI, int TJ, bool BOTH_KC = false>
+constexpr int min_waves() { return TI * TJ == 4 ? 2 : (TI * TJ == 2 ? (BOTH_KC ? 2 : 3) : 4); }
 
 // ---- register staging of one operand tile: R/32 float4 per thread ------------------------------
 // KC: idx = t + 256*j -> kq = idx&7 (8 lanes cover one row's 128 B), row = kc_row(idx): lanes 8-15 of every
