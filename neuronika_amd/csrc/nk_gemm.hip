@@ -11,6 +11,7 @@
 
 using namespace nkmma;
 
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 constexpr int PF2_MIN_KTILES = 48;  // reductions at least this long take the two-k-tile look-ahead loop
 
 struct GemmArgs {
@@ -30,9 +31,15 @@ struct GemmArgs {
     float* slabs;     // [splits][batch][M][N] partials when splits > 1
     int tiles_m, tiles_n;
     // Short reductions (attention's K = 64: two k-tiles per output tile): a block walks `chunk` consecutive tiles of the
-    // tile sequence and loads the first k-tile of the next one before the last MFMA block of the current one, so the
-    // per-tile launch / first-load / store-drain bubble (~7 us, as long as the whole K = 64 tile) is paid once per chunk.
+    // tile sequence and loads the first k-tile of the next one before the last MFMA block of the current one: block
+    // dispatch and the first-load latency are paid once per chunk (scores GEMM of C5: 975 -> 865 us).  What is left is the
+    // output: 2.1 GB of C tiles leave at ~2.5 TB/s while the MFMA pipe is 55 % busy (rocprofv3: TCC_EA0_WRREQ 2.2 GB,
+    // L2 hit rate 0.62 because the C lines push Q / K out, effective clock 1.96 GHz).  Tried on top and dropped, measured:
+    // a second accumulator set with the previous tile's stores interleaved behind the MFMA groups of the next one, with
+    // transposed MFMA blocks so that they are 16-byte stores (bit-identical results, 880 - 970 us: not faster), and a
+    // row-major tile order so that one block writes whole 4 KB rows (no gain).
     int chunk;        // >= 1 tiles per block (1: one tile per block, the classic grid)
+    int group_m;      // tile order: column-major inside groups of `group_m` tile rows (1: row-major, tn fastest)
 };
 
 // C tile <- accumulators (or the split's slab).  Every load (bias, old C) is issued first and folded into the accumulators
@@ -99,7 +106,7 @@ __global__ __launch_bounds__(NT, (min_waves<TI, TJ, !TA && TB>())) void sgemm_ke
     int seq = xcd_chunk(blockIdx.x, gridDim.x) * p.chunk;
     const int seq_end = min(p.tiles_m * p.tiles_n, seq + p.chunk);
     int tm, tn;
-    tile_of_seq(seq, p.tiles_m, p.tiles_n, tm, tn);
+    tile_of_seq(seq, p.tiles_m, p.tiles_n, tm, tn, p.group_m);
     int m0 = tm * BM, n0 = tn * BN;
     const int batch = blockIdx.z, split = blockIdx.y;
     const int bo = batch / p.batch_inner, bi = batch % p.batch_inner;
@@ -211,7 +218,7 @@ __global__ __launch_bounds__(NT, (min_waves<TI, TJ, !TA && TB>())) void sgemm_ke
         const bool more = seq + 1 < seq_end && nt > 0;
         int tm2 = 0, tn2 = 0;
         if (more) {
-            tile_of_seq(seq + 1, p.tiles_m, p.tiles_n, tm2, tn2);
+            tile_of_seq(seq + 1, p.tiles_m, p.tiles_n, tm2, tn2, p.group_m);
             la.init(A, p.lda, tm2 * BM, kbeg, p.M, kend, t);
             lb.init(B, p.ldb, tn2 * BN, kbeg, p.N, kend, t);
             ra = la.template load<ALIGNED>(t);
@@ -280,7 +287,6 @@ __global__ void splitk_reduce_flat_kernel(const float* __restrict__ slabs, float
     }
 }
 
-static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 template <bool TA, bool TB, int TI, int TJ>
 static int launch_tile(nk_device* dev, const GemmArgs& p, int nbatch, bool aligned) {
@@ -373,15 +379,16 @@ static int gemm_impl(nk_device* dev, int transA, int transB, int M, int N, int K
     }
     p.tiles_m = (M + 64 * ti - 1) / (64 * ti);
     p.tiles_n = (N + 64 * tj - 1) / (64 * tj);
-    int force_chunk = 0;
+    int force_chunk = 0, force_group = 0;
     if (const char* f = getenv("NK_GEMM_FORCE")) {  // tuning sweeps (benchmarks/ab_force.py): "ti,tj,splits[,chunk]" overrides the rules
-        int a = 0, b = 0, c = 0, d = 0;
-        const int got = sscanf(f, "%d,%d,%d,%d", &a, &b, &c, &d);
+        int a = 0, b = 0, c = 0, d = 0, e = 0;
+        const int got = sscanf(f, "%d,%d,%d,%d,%d", &a, &b, &c, &d, &e);
         if (got >= 3 && (a == 1 || a == 2) && (b == 1 || b == 2)) {
             ti = a; tj = b; splits = c < 1 ? 1 : c;
             p.tiles_m = (M + 64 * ti - 1) / (64 * ti);
             p.tiles_n = (N + 64 * tj - 1) / (64 * tj);
-            if (got == 4) force_chunk = d;
+            if (got >= 4) force_chunk = d;
+            if (got >= 5) force_group = e;
         }
     }
     int kts = (ktiles + splits - 1) / splits;
@@ -392,10 +399,10 @@ static int gemm_impl(nk_device* dev, int transA, int transB, int M, int N, int K
     p.k_per_split = kts * BK;
     // Tiles per block: a short reduction (kts k-tiles of ~3.9 us) cannot amortise the ~7 us a block spends being
     // dispatched, waiting for its first loads and draining its stores, so a block takes enough consecutive tiles of the
-    // sequence for ~32 k-tiles of work - as long as the grid keeps at least four waves of resident blocks.
+    // sequence for ~16 k-tiles of work - as long as the grid keeps at least four waves of resident blocks.
     {
         const long long ntiles = (long long)p.tiles_m * p.tiles_n, slots = ti * tj == 4 ? 512 : (ti * tj == 2 ? 768 : 1024);
-        long long c = kts >= 16 ? 1 : (32 + kts - 1) / kts;
+        long long c = kts >= 16 ? 1 : (16 + kts - 1) / kts;
         const long long cap = ntiles * splits * nbatch / (4 * slots);
         if (c > cap) c = cap;
         if (c > ntiles) c = ntiles;
@@ -403,6 +410,7 @@ static int gemm_impl(nk_device* dev, int transA, int transB, int M, int N, int K
         if (c < 1 || kts >= PF2_MIN_KTILES) c = 1;
         p.chunk = (int)c;
     }
+    p.group_m = force_group > 0 ? force_group : 8;
     if (p.splits > 1) {
         void* ws = nullptr;
         int rc = nk_workspace(dev, (size_t)p.splits * nbatch * M * N * sizeof(float), &ws);

@@ -288,8 +288,7 @@ __device__ __forceinline__ int xcd_chunk(int bid, int nblk) {
     return (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + loc;
 }
 // second half: position in the sequence -> tile (column-major groups of GROUP_M tile rows)
-__device__ __forceinline__ void tile_of_seq(int swz, int tiles_m, int tiles_n, int& tm, int& tn) {
-    constexpr int GROUP_M = 8;
+__device__ __forceinline__ void tile_of_seq(int swz, int tiles_m, int tiles_n, int& tm, int& tn, int GROUP_M = 8) {
     const int per_group = GROUP_M * tiles_n;
     const int group = swz / per_group;
     const int first_m = group * GROUP_M;

@@ -346,6 +346,44 @@ def test_sgemm_batched_strided(dev):
     contraction_ok(Sc.numpy(), ref.astype(np.float32), ref, dh, 1.0, 1.0)
 
 
+@pytest.mark.parametrize("ta,tb", [(0, 1), (0, 0), (1, 0), (1, 1)])
+@pytest.mark.parametrize("K,chunk,splits", [(64, 2, 1), (64, 5, 1), (96, 3, 1), (160, 16, 1), (256, 3, 2), (64, 64, 1)])
+def test_sgemm_tile_chunks(dev, ta, tb, K, chunk, splits):
+    """Short reductions: a block walks `chunk` consecutive tiles, prefetching the next tile's first k-tile behind the
+    last MFMA block of the current one (nk_gemm.hip).  Must give the SAME BITS as one tile per block (same products,
+    same k order) for every layout and tile shape, batch strides, alpha / beta, chunks that do not divide the tile
+    count, and split-K slabs; and the result matches the f64 oracle."""
+    import os
+    c = capi()
+    M, N, nb_o, nb_i = 512, 384, 3, 2
+    nb = nb_o * nb_i
+    a = rnd(40, (nb, K, M) if ta else (nb, M, K), -1, 1)
+    b = rnd(41, (nb, N, K) if tb else (nb, K, N), -1, 1)
+    c0 = rnd(42, (nb, M, N), -1, 1)
+    A, B = dev.array(a), dev.array(b)
+    lda, ldb = a.shape[2], b.shape[2]
+    sa, sb, sc = a.shape[1] * lda, b.shape[1] * ldb, M * N
+    outs = {}
+    try:
+        for tiles in ("2,2", "1,2"):
+            for ch in (1, chunk):
+                for alpha, beta in ((1.0, 0.0), (-1.5, 0.5)):
+                    os.environ["NK_GEMM_FORCE"] = f"{tiles},{splits},{ch}"
+                    Cd = dev.array(c0)
+                    c.sgemm_batched(dev, ta, tb, M, N, K, alpha, A, lda, nb_i * sa, sa, B, ldb, nb_i * sb, sb, beta, Cd, N, nb_i * sc, sc, nb_o, nb_i)
+                    outs[(tiles, ch, alpha)] = Cd.numpy()
+    finally:
+        os.environ.pop("NK_GEMM_FORCE", None)
+    opa = (a.transpose(0, 2, 1) if ta else a).astype(np.float64)
+    opb = (b.transpose(0, 2, 1) if tb else b).astype(np.float64)
+    ref = opa @ opb
+    for tiles in ("2,2", "1,2"):
+        for alpha, beta in ((1.0, 0.0), (-1.5, 0.5)):
+            assert np.array_equal(outs[(tiles, 1, alpha)], outs[(tiles, chunk, alpha)]), (tiles, alpha)
+            want = alpha * ref + beta * c0
+            contraction_ok(outs[(tiles, chunk, alpha)], want.astype(np.float32), want, K, 1.5, 1.0)
+
+
 def test_sgemm_large_rowsum_identity(dev):
     """Size-independent check at the BASELINE size (4096^2): (A.B).1 == A.(B.1)."""
     c = capi()
