@@ -292,26 +292,47 @@ int conv_bwd_input(nk_device* dev, int nd, float* dx, const int* x_shape, const 
             const size_t wq_bytes = round256((size_t)g.Cout * g.Cg * g.KK * sizeof(float));
             const size_t td_bytes = round256((size_t)g.KK * sizeof(int4));
             const size_t ph_bytes = round256(sizeof(BwdInPhaseTable));
+            FastBwdInArgs fp{};
+            const int fti = g.Cg <= 64 || (g.Cg % 128 != 0 && g.Cg % 64 == 0) ? 1 : 2;
+            fp.tiles_m = (g.Cg + 64 * fti - 1) / (64 * fti);
+            fp.tiles_n = (int)tiles_n;
+            // tail balancing: tiles beyond the last whole wave of resident blocks (3 per CU for the 64-row tile, 2 for the
+            // 128-row one) are split along k (C3: 3136 tiles over 768 slots = 4.08 waves, i.e. a fifth wave 8 % full)
+            const int tiles = fp.tiles_m * fp.tiles_n, slots = (fti == 1 ? 3 : 2) * dev->num_cus, nkt = g.Mg * g.KK / BK;
+            int nblocks = tiles;
+            size_t slab_bytes = 0;
+            fp.full_blocks = tiles;
+            const int tail = tiles % slots;
+            if (groups == 1 && nphase == 1 && tiles > slots && tail > 0 && tail * 2 <= slots && nkt >= 4) {
+                int S = slots / tail;
+                if (S > nkt / 2) S = nkt / 2;
+                const int kts = (nkt + S - 1) / S;
+                S = (nkt + kts - 1) / kts;
+                if (S >= 2) {
+                    fp.full_blocks = tiles - tail;
+                    fp.tail_splits = S;
+                    fp.tail_kts = kts;
+                    nblocks = fp.full_blocks + tail * S;
+                    slab_bytes = (size_t)tail * S * (64 * fti) * 128 * sizeof(float);
+                }
+            }
             void* wsf = nullptr;
-            rc = nk_workspace(dev, wq_bytes + 2 * td_bytes + ph_bytes, &wsf);
+            rc = nk_workspace(dev, wq_bytes + 2 * td_bytes + ph_bytes + slab_bytes, &wsf);
             if (rc) return rc;
             float* wq = (float*)wsf;
             int4* tapd = (int4*)((char*)wsf + wq_bytes);
             int4* tappos = (int4*)((char*)wsf + wq_bytes + td_bytes);
             BwdInPhase* phases = (BwdInPhase*)((char*)wsf + wq_bytes + 2 * td_bytes);
+            if (slab_bytes) fp.slabs = (float*)((char*)wsf + wq_bytes + 2 * td_bytes + ph_bytes);
             hipLaunchKernelGGL(conv_phase_taps_kernel, dim3((g.KK + 63) / 64), dim3(64), 0, dev->compute, tapd, tappos, g);
             NK_LAUNCH_CHECK();
             hipLaunchKernelGGL(conv_phase_table_kernel, dim3(1), dim3(1), 0, dev->compute, phases, tbl);
             NK_LAUNCH_CHECK();
             hipLaunchKernelGGL(conv_wq_kernel, dim3(nk_stream_grid((size_t)g.Cout * g.Cg * g.KK, 256)), dim3(256), 0, dev->compute, wq, w, tappos, g);
             NK_LAUNCH_CHECK();
-            FastBwdInArgs fp{};
             fp.g = g; fp.dx = dx; fp.gy = gy; fp.wq = wq; fp.tapd = tapd; fp.phases = phases; fp.nphase = nphase;
-            const int fti = g.Cg <= 64 || (g.Cg % 128 != 0 && g.Cg % 64 == 0) ? 1 : 2;
-            fp.tiles_m = (g.Cg + 64 * fti - 1) / (64 * fti);
-            fp.tiles_n = (int)tiles_n;
             const bool al = g.Cg % (64 * fti) == 0;
-            dim3 fgrid(fp.tiles_m * fp.tiles_n, 1, groups);
+            dim3 fgrid(nblocks, 1, groups);
             rc = nk_prof_start(dev, NK_KERNEL_CONV, 2.0 * g.N * (double)g.Cout * g.L * g.Cg * g.KK);
             if (rc) return rc;
             if (al && fti == 2) hipLaunchKernelGGL((conv_bwd_input_fast_kernel<true, 2>), fgrid, dim3(NT), 0, dev->compute, fp);
@@ -319,6 +340,12 @@ int conv_bwd_input(nk_device* dev, int nd, float* dx, const int* x_shape, const 
             else if (fti == 2) hipLaunchKernelGGL((conv_bwd_input_fast_kernel<false, 2>), fgrid, dim3(NT), 0, dev->compute, fp);
             else hipLaunchKernelGGL((conv_bwd_input_fast_kernel<false, 1>), fgrid, dim3(NT), 0, dev->compute, fp);
             NK_LAUNCH_CHECK();
+            if (fp.tail_splits) {
+                const dim3 rgrid(tiles - fp.full_blocks, (64 * fti * 128) / 1024, 1);
+                if (fti == 2) hipLaunchKernelGGL((conv_bwd_input_tail_reduce_kernel<128>), rgrid, dim3(256), 0, dev->compute, fp);
+                else hipLaunchKernelGGL((conv_bwd_input_tail_reduce_kernel<64>), rgrid, dim3(256), 0, dev->compute, fp);
+                NK_LAUNCH_CHECK();
+            }
             return nk_prof_stop(dev);
         }
     }
@@ -415,7 +442,12 @@ int conv_bwd_kernel(nk_device* dev, int nd, float* dw, const int* w_shape, const
     const long long tiles = (long long)p.tiles_m * p.tiles_n * groups;
     const long long rtiles = (R + BK - 1) / BK;
     // whole "waves" of blocks: the kernel keeps 2 blocks per CU resident, so the grid is sized to
-    // (a multiple of) 2 * CUs blocks — a ragged second wave would idle most of the chip
+    // (a multiple of) 2 * CUs blocks — a ragged second wave would idle most of the chip.
+    // (Measured and dropped in round 2: running the last column tile of C3 - Kc = 576 = 4 * 128 + 64 - through the 64-wide
+    // body, i.e. issuing none of the 11 % of MFMAs that fall on padding columns, did not change the launch time with
+    // one block per tile (565 -> 566 us) and LOST 3 % once those blocks were given twice the reduction range to even
+    // out the work (584 us): the launch is bound by the per-k-tile chain gathers -> wait -> mask -> LDS store -> barrier
+    // (~1 us per k-tile more than the dense GEMM's), not by MFMA issue.)
     const long long slots = 2LL * dev->num_cus;
     long long waves = (tiles * ((rtiles + 127) / 128) + slots - 1) / slots;  // <= ~128 k-tiles per block ...
     if (waves < 1) waves = 1;

@@ -297,6 +297,12 @@ struct FastBwdInArgs {
     const BwdInPhase* phases;
     int nphase;
     int tiles_m, tiles_n;  // tiles_n: column tiles of all phases together
+    // Tail balancing (single phase, one group), as in the forward pass: the first `full_blocks` tiles (whole waves of
+    // resident blocks) are computed by one block each; every remaining tile is split over `tail_splits` blocks of
+    // `tail_kts` k-tiles that write partial tiles to `slabs` ([tail tile][split][BM][BN]);
+    // conv_bwd_input_tail_reduce_kernel sums them in split order into dX.  tail_splits == 0: off.
+    int full_blocks, tail_splits, tail_kts;
+    float* slabs;
 };
 
 // requires Mg % 32 == 0, out[2] >= 4, at most MAX_PHASES stride phases, per-tensor element counts < 2^31
@@ -308,7 +314,19 @@ __global__ __launch_bounds__(NT, 2) void conv_bwd_input_fast_kernel(FastBwdInArg
     const ConvGeom& g = p.g;
     const int t = threadIdx.x, lane = t & 63, wid = t >> 6, wr = wid >> 1, wc = wid & 1;
     int tm, tn;
-    tile_coords(blockIdx.x, gridDim.x, p.tiles_m, p.tiles_n, tm, tn);
+    int kt0 = 0, tail_nt = -1;
+    float* slab = nullptr;
+    if (p.tail_splits == 0) {
+        tile_coords(blockIdx.x, gridDim.x, p.tiles_m, p.tiles_n, tm, tn);
+    } else if ((int)blockIdx.x < p.full_blocks) {
+        tile_of_seq(xcd_chunk(blockIdx.x, p.full_blocks), p.tiles_m, p.tiles_n, tm, tn);
+    } else {
+        const int tb = blockIdx.x - p.full_blocks, tail_tile = tb / p.tail_splits, split = tb - tail_tile * p.tail_splits;
+        tile_of_seq(p.full_blocks + tail_tile, p.tiles_m, p.tiles_n, tm, tn);
+        kt0 = split * p.tail_kts;
+        tail_nt = p.tail_kts;
+        slab = p.slabs + ((long long)tail_tile * p.tail_splits + split) * (BM * BN);
+    }
     int pid = 0;  // the stride phase this column tile belongs to (block-uniform)
     for (int i = 1; i < p.nphase; ++i)
         if (tn >= p.phases[i].tile_begin) pid = i;
@@ -316,7 +334,8 @@ __global__ __launch_bounds__(NT, 2) void conv_bwd_input_fast_kernel(FastBwdInArg
     tn -= ph.tile_begin;
     const int grp = blockIdx.z;
     const int m0 = tm * BM, n0 = tn * BN;
-    const int K = g.Mg * g.KK, nt = g.Mg * ph.ntaps / BK;  // K: row length of Wq; this phase reduces over Mg * ntaps
+    const int K = g.Mg * g.KK;  // K: row length of Wq; this phase reduces over Mg * ntaps
+    const int nt_all = g.Mg * ph.ntaps / BK, nt = tail_nt < 0 ? nt_all : min(tail_nt, nt_all - kt0);
     // Columns are the phase's input positions (n, i0, i1, i2') with the innermost extent padded to W4 = a multiple of 4,
     // so that the quad a thread stages never straddles two rows: for every tap its four gradient elements are then
     // contiguous in memory and ONE 16-byte load per staged row serves interior and border quads alike (start clamped
@@ -350,6 +369,7 @@ __global__ __launch_bounds__(NT, 2) void conv_bwd_input_fast_kernel(FastBwdInArg
     int g_sh = 0, g_c = 0;
     bool g_ok = false;
     auto gather = [&](int kt) {
+        kt += kt0;
         const int chunk = kt / ntaps, tap = kt - chunk * ntaps, co0 = chunk * BK;  // taps inside a 32-channel chunk
         const int4 d = tapd[tap];
         const float* src = G + co0 * g.L;
@@ -392,7 +412,7 @@ __global__ __launch_bounds__(NT, 2) void conv_bwd_input_fast_kernel(FastBwdInArg
     f32x16 acc[TI][TJ];
     acc_zero<TI, TJ>(acc);
     TileLoader<true, BM> la;
-    la.init(Wq, K, m0, 0, g.Cg, nt * BK, t);
+    la.init(Wq, K, m0, kt0 * BK, g.Cg, (kt0 + nt) * BK, t);
     Stage<BM / 32> ra;
     if (nt > 0) {  // a phase without taps (e.g. a 1x1 kernel with stride 2) only has zeros to write
         ra = la.template load<ALIGNED_A>(t);
@@ -418,6 +438,10 @@ __global__ __launch_bounds__(NT, 2) void conv_bwd_input_fast_kernel(FastBwdInArg
         float* cur = smem + ((nt - 1) & 1) * STAGE;
         mma_tile<true, false, TI, TJ>(cur, cur + TA_FLOATS, acc, wr, wc, lane);
     }
+    if (slab) {  // partial tile of a split tail tile
+        acc_foreach<TI, TJ>(acc, wr, wc, lane, [&](int r, int c, float v) { slab[r * BN + c] = v; });
+        return;
+    }
     float* DX = p.dx;
     const int assign = g.assign;
     const int Cg = g.Cg, Cin = g.Cin, inplane = g.uinplane;
@@ -437,3 +461,36 @@ __global__ __launch_bounds__(NT, 2) void conv_bwd_input_fast_kernel(FastBwdInArg
     NK_BWD_INPUT_EPILOGUE
 }
 
+
+// dX[tail tiles] (+)= sum over splits (fixed order) of the partial tiles.  Single phase, one group.
+template <int BM>
+__global__ void conv_bwd_input_tail_reduce_kernel(FastBwdInArgs p) {
+    constexpr int BN = 128;
+    const ConvGeom& g = p.g;
+    const BwdInPhase ph = p.phases[0];
+    const int tail_tile = blockIdx.x;
+    int tm, tn;
+    tile_of_seq(p.full_blocks + tail_tile, p.tiles_m, p.tiles_n, tm, tn);
+    const float* base = p.slabs + ((long long)tail_tile * p.tail_splits) * (BM * BN);
+    const int W4 = (ph.count[2] + 3) & ~3, rows_per_n = ph.count[0] * ph.count[1];
+    const int cols = g.N * rows_per_n * W4;
+    // blockIdx.y: a 1024-element slice of the tile (8 rows x 128 columns); consecutive threads = consecutive columns
+    const int e = blockIdx.y * 1024 + threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ee = e + i * 256;
+        const int r = ee / BN, c = ee - r * BN;
+        const int ci = tm * BM + r, cc = tn * BN + c;
+        if (ci >= g.Cg || cc >= cols) continue;
+        const int rowid = cc / W4, cpos = cc - rowid * W4;
+        if (cpos >= ph.count[2]) continue;  // padding column of the row
+        float s = 0.f;
+        for (int k = 0; k < p.tail_splits; ++k) s += base[(long long)k * (BM * BN) + ee];
+        const int n = rowid / rows_per_n, ab = rowid - n * rows_per_n;
+        const int i0 = ab / ph.count[1], i1 = ab - i0 * ph.count[1];
+        float* d = p.dx + ((long long)n * g.Cin + ci) * g.uinplane +
+                   ((long long)(ph.first[0] + i0 * g.stride[0]) * g.uin[1] + ph.first[1] + i1 * g.stride[1]) * g.uin[2] + ph.first[2] +
+                   cpos * g.stride[2];
+        *d = g.assign ? s : *d + s;
+    }
+}

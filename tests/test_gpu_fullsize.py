@@ -63,6 +63,20 @@ def test_C3_conv_full_size(dev):
     DX = dev.zeros(x.shape)
     c.pad_bwd(dev, DX, DXP, (1, 1))
     assert np.array_equal(DX.numpy(), dxp[:, :, 1:-1, 1:-1])
+    # the module's form (Pad folded into the input-gradient kernel: 56 x 56 columns = 3136 tiles, whose last partial wave
+    # of tiles is split along k and summed by a second kernel): `+=` onto a non-zero start, then the assigning form
+    dx0 = rnd(7, x.shape, -1, 1)
+    DX2 = dev.array(dx0)
+    c.conv_bwd_input(dev, DX2, G, W, (1, 1), (1, 1), 1, padding=(1, 1))
+    got = DX2.numpy() - dx0
+    ref = dxp[:, :, 1:-1, 1:-1]
+    assert np.abs(got - ref).max() <= 1e-6 * 1152 + 1e-6          # same sums; split tail tiles add in another order
+    DX3 = dev.full(x.shape, np.nan)
+    c.conv_bwd_input(dev, DX3, G, W, (1, 1), (1, 1), 1, assign=True, padding=(1, 1))
+    assert np.abs(DX3.numpy() - ref).max() <= 1e-6 * 1152
+    DX4 = dev.full(x.shape, np.nan)
+    c.conv_bwd_input(dev, DX4, G, W, (1, 1), (1, 1), 1, assign=True, padding=(1, 1))
+    assert np.array_equal(DX3.numpy(), DX4.numpy())                 # run-to-run deterministic
 
 
 def test_C4_mlp_full_size(nk):
