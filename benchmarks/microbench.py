@@ -96,6 +96,8 @@ def bench_softmax(dev, iters):
         ("log_softmax_fwd", lambda: c.log_softmax_fwd(dev, X, Y, 1), 8 * n),
         ("dropout_fwd", lambda: c.dropout_fwd(dev, X, Y, NZ, 0.1, True, 7, 0), 12 * n),
         ("dropout_bwd", lambda: c.dropout_bwd(dev, D, G, NZ, 0.1, True), 16 * n),
+        ("attn_probs_fwd", lambda: c.scale_softmax_dropout_fwd(dev, X, None, Y, None, 0.125, 0.1, True, 7, 0), 8 * n),
+        ("attn_probs_bwd_from_scores", lambda: c.scale_softmax_dropout_bwd_from_scores(dev, D, G, X, None, 0.125, 0.1, True, 7, 0, assign=True), 12 * n),
     ]
     for name, fn, nbytes in cases:
         ms = timeit(dev, fn, iters)

@@ -317,20 +317,27 @@ __global__ __launch_bounds__(256) void attn_probs_fwd_kernel(const float* __rest
         }
     }
     sum = nk_wave_sum(sum);
+    // ONE IEEE division per row, a multiplication per element (and the dropout scale as a multiplication by the host's
+    // 1 / (1 - p)): the two per-element divisions of the node-by-node form (e / sum, then / (1 - p)) were ~20 of the
+    // kernel's ~60 VALU instructions per element and made it VALU-bound at 4.8 TB/s.  Each replaced division differs by
+    // at most one rounding from the reference's node arithmetic - inside the stated f32 tolerance (rtol 1e-5), checked
+    // against the oracle; the recomputing backward kernel uses the identical sequence, so forward and backward still see
+    // the same probabilities bit for bit.
+    const float inv_sum = 1.f / sum;
     const uint2 key = make_uint2((unsigned)seed, (unsigned)(seed >> 32));
 #pragma unroll
     for (int i = 0; i < V; ++i) {
         const int c = (i * 64 + lane) * 4;
         if (c < L) {
             float4 y;
-            y.x = v[i].x / sum; y.y = v[i].y / sum; y.z = v[i].z / sum; y.w = v[i].w / sum;   // Softmax node
+            y.x = v[i].x * inv_sum; y.y = v[i].y * inv_sum; y.z = v[i].z * inv_sum; y.w = v[i].w * inv_sum;   // Softmax node
             if (probs) nk_store_stream(reinterpret_cast<float4*>(probs + rb + c), y);  // not stored when the backward pass recomputes it
             float4 o = y;
             if (MASK == 1) {                                                                   // Dropout node
                 const unsigned long long ctr = (unsigned long long)(rb + c) / 4 + offset;
                 const uint4 r = philox4x32_10(make_uint4((unsigned)ctr, (unsigned)(ctr >> 32), 0u, 0u), key);
                 const float4 nz = make_float4(keep_bit(r.x, keep), keep_bit(r.y, keep), keep_bit(r.z, keep), keep_bit(r.w, keep));
-                o.x = (y.x * nz.x) / dscale; o.y = (y.y * nz.y) / dscale; o.z = (y.z * nz.z) / dscale; o.w = (y.w * nz.w) / dscale;
+                o.x = (y.x * nz.x) * dscale; o.y = (y.y * nz.y) * dscale; o.z = (y.z * nz.z) * dscale; o.w = (y.w * nz.w) * dscale;
                 if (STORE_NOISE) nk_store_stream(reinterpret_cast<float4*>(noise + rb + c), nz);
             } else if (MASK == 2) {
                 o = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -386,10 +393,11 @@ __global__ __launch_bounds__(256) void attn_probs_bwd_kernel(float* __restrict__
             }
         }
         sum = nk_wave_sum(sum);
+        const float inv_sum = 1.f / sum;  // as in the forward kernel
 #pragma unroll
         for (int i = 0; i < V; ++i) {
             const int c = (i * 64 + lane) * 4;
-            if (c < L) { y[i].x /= sum; y[i].y /= sum; y[i].z /= sum; y[i].w /= sum; }
+            if (c < L) { y[i].x *= inv_sum; y[i].y *= inv_sum; y[i].z *= inv_sum; y[i].w *= inv_sum; }
         }
     }
     float dot = 0.f;
@@ -557,7 +565,7 @@ int nk_scale_softmax_dropout_fwd(nk_device* dev, const float* scores, float* pro
     NK_CHECK(L % 4 == 0 && L <= 2048 && al16(scores) && (!probs || al16(probs)) && al16(out) && (!noise || al16(noise)),
              "fused attention probabilities need L %% 4 == 0, L <= 2048 and 16-byte aligned buffers (L=%d)", L);
     const int mask = (!train || p == 0.0) ? 0 : (1.0 - p == 0.0 ? 2 : 1);
-    const float keep = (float)(1.0 - p), dscale = 1.f - (float)p;
+    const float keep = (float)(1.0 - p), dscale = 1.f / (1.f - (float)p);  // multiplied in: 1 / (1 - p) rounded once on the host
     const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
 #define NK_AP(V)                                                                                                   \
     do {                                                                                                           \
