@@ -1,0 +1,20 @@
+//! Node bodies: each `forward()` / `backward()` is one call of the C ABI (`include/neuronika_hip.h` cites, per entry
+//! point, the reference method it replaces).  The structs hold the same `Shared` operand / output handles as the
+//! reference's ndarray nodes (`node/*/mod.rs`), so graph construction code is unchanged.
+mod binary_op;
+mod matrix_matrix_mul_t;
+
+pub(crate) use binary_op::*;
+pub(crate) use matrix_matrix_mul_t::*;
+
+use crate::autograd::Backward;
+
+/// Two backward halves registered as one tape entry (`MatrixMatrixMulTBackward`, `node/matrix_matrix_mul_t/mod.rs:107-140`).
+pub(crate) struct Pair<L: Backward, R: Backward>(pub(crate) L, pub(crate) R);
+
+impl<L: Backward, R: Backward> Backward for Pair<L, R> {
+    fn backward(&self) {
+        self.0.backward();
+        self.1.backward();
+    }
+}
