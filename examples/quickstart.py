@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The reference's `examples/quickstart.rs` (BASELINE config C1) on the MI355X backend, line for line:
 a 3 -> 5 -> 5 -> 1 MLP loaded from the model JSON embedded in that example (ndarray's serde wire format,
-here read from tests/golden/reference_fixtures.json), a four-row labelled CSV, SGD(lr = 0.01), five epochs of
+here read from examples/quickstart_model.json), a four-row labelled CSV, SGD(lr = 0.01), five epochs of
 shuffled batches of two with `drop_last`, MSE (mean) loss.
 
     python examples/quickstart.py            # needs an MI355X; prints the loss per epoch
@@ -23,12 +23,8 @@ LABELS = {"Dog": 1.0, "Cat": 2.0}          # anything else -> 3.0 (quickstart.rs
 
 def load_model(nk, dev):
     """`serde_json::from_str::<NeuralNetwork>` of quickstart.rs:53-169."""
-    q = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_fixtures.json")))["quickstart_mlp"]
-    layers = []
-    for name in ("lin1", "lin2", "lin3"):
-        text = json.dumps({p: {"v": 1, "dim": q[f"{name}.{p}"]["dim"], "data": q[f"{name}.{p}"]["data"]} for p in ("weight", "bias")})
-        layers.append(nk.serde.linear_from_json(dev, text))
-    return layers
+    model = json.load(open(os.path.join(ROOT, "examples", "quickstart_model.json")))["model"]
+    return [nk.serde.linear_from_json(dev, json.dumps(model[name])) for name in ("lin1", "lin2", "lin3")]
 
 
 def forward(layers, x):

@@ -293,10 +293,15 @@ size_t DeviceLoader::next_into(const Var& x, const Var* y) {
     if (labeled_ != (y != nullptr)) fail("DeviceLoader: labels destination does not match the dataset kind");
     check(nk_stream_wait_event(dev_->raw(), 0, ready_[slot]));
     check(nk_copy(dev_->raw(), x.data->ptr(), stage_x_[slot]->ptr(), nx));
+    // a short last batch (drop_last = false) into a full-size leaf: the rows beyond it are ZEROED, never left holding the
+    // previous batch's records (the reference's iterator yields a correctly sized view, neuronika-data/src/lib.rs:570;
+    // a graph built for the full batch has to be rebuilt or masked by the caller for the ragged one)
+    if (x.data->len() > nx) check(nk_fill(dev_->raw(), x.data->ptr() + nx, x.data->len() - nx, 0.f));
     if (labeled_) {
         const size_t ny = r.rows * labels_.row_len();
         if (y->data->len() < ny) fail("DeviceLoader: destination smaller than a batch of labels");
         check(nk_copy(dev_->raw(), y->data->ptr(), stage_y_[slot]->ptr(), ny));
+        if (y->data->len() > ny) check(nk_fill(dev_->raw(), y->data->ptr() + ny, y->data->len() - ny, 0.f));
     }
     check(nk_event_record(freed_[slot], 0));
     freed_valid_[slot] = true;

@@ -127,7 +127,8 @@ class DeviceLoader {
     DeviceLoader& operator=(const DeviceLoader&) = delete;
     size_t batches() const { return ranges_.size(); }
     // Copies the next batch into x (and y).  Returns the number of rows (0 = epoch finished; the next
-    // call starts the following epoch).  A short last batch fills only its rows.
+    // call starts the following epoch).  A short last batch fills its rows and ZEROES the rest of the destination: the
+    // caller must still use the returned row count (rebuild or mask the graph) - stale samples are never left behind.
     size_t next_into(const Var& x, const Var* y = nullptr);
     // Fresh leaves holding the next batch; `rows == 0` marks the end of the epoch.
     struct Batch {

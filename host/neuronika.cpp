@@ -55,9 +55,9 @@ void Device::graph_begin() { check(nk_graph_begin(h_)); }
 std::shared_ptr<Graph> Device::graph_end() {
     nk_graph* g = nullptr;
     check(nk_graph_end(h_, &g));
-    return std::make_shared<Graph>(g);
+    return std::make_shared<Graph>(g, shared_from_this());
 }
-Graph::~Graph() { (void)nk_graph_destroy(g_); }
+Graph::~Graph() { (void)nk_graph_destroy(g_); }  // dev_ (a member) is released after this body: the device outlives its graphs
 void Graph::launch() const { check(nk_graph_launch(g_)); }
 
 float* Device::alloc_uninit(size_t n) {

@@ -81,13 +81,14 @@ using DevicePtr = std::shared_ptr<Device>;
 
 class Graph {  // a captured, replayable sequence of launches on one device
    public:
-    explicit Graph(nk_graph* g) : g_(g) {}
+    Graph(nk_graph* g, std::shared_ptr<Device> dev) : dev_(std::move(dev)), g_(g) {}
     ~Graph();
     Graph(const Graph&) = delete;
     Graph& operator=(const Graph&) = delete;
     void launch() const;
 
    private:
+    std::shared_ptr<Device> dev_;  // a graph keeps its device alive (captured kernels hold the device's workspace addresses)
     nk_graph* g_;
 };
 

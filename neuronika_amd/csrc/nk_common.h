@@ -25,6 +25,8 @@ struct nk_device {
     hipEvent_t join = nullptr;      // comm -> compute ordering helper
     void* workspace = nullptr;      // stream-ordered scratch (split-K slabs, reduction partials)
     size_t workspace_bytes = 0;
+    int graphs_alive = 0;           // nk_graph objects of this device: their kernels have workspace pointers baked in
+    std::vector<void*> workspace_retired;  // outgrown workspaces kept while any graph may still replay into them
     int num_cus = 256;
     // bench instrumentation (nk_profile_begin/end)
     bool prof_on = false;

@@ -822,12 +822,22 @@ int nk_sgd_step(nk_device* dev, float* w, float* grad, float* velocity, size_t n
     return NK_OK;
 }
 
+// Step-dependent host scalars become kernel ARGUMENTS: a hipGraph replay would freeze them at the captured step and the
+// optimizer would silently stop following its schedule, so such a step refuses to be captured.
+static int refuse_capture(nk_device* dev, const char* what) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    NK_HIP(hipStreamIsCapturing(dev->compute, &cs));
+    NK_CHECK(cs == hipStreamCaptureStatusNone, "%s would be frozen at the captured step by a graph replay: issue this optimizer step outside the captured region", what);
+    return NK_OK;
+}
+
 int nk_adam_step(nk_device* dev, float* w, float* grad, float* exp_avg, float* exp_avg_sq, float* max_exp_avg_sq,
                  size_t n, float lr, float beta1, float beta2, float eps, int step, float l1, float l2) {
     NK_USE(dev);
     if (n == 0) return NK_OK;
     NK_CHECK(w && grad && exp_avg && exp_avg_sq, "null pointer in nk_adam_step");
     NK_CHECK(step >= 1, "step must be >= 1");
+    if (int rc = refuse_capture(dev, "nk_adam_step: the bias corrections 1 - beta^step")) return rc;
     const float bc1 = 1.f - powi_f32(beta1, step), bc2 = 1.f - powi_f32(beta2, step);
     hipLaunchKernelGGL(adam_kernel, dim3(nk_stream_grid(n, 256)), dim3(256), 0, dev->compute, w, grad, exp_avg, exp_avg_sq,
                        max_exp_avg_sq, n, lr, beta1, beta2, eps, bc1, bc2, l1, l2);
@@ -841,6 +851,8 @@ int nk_adagrad_step(nk_device* dev, float* w, float* grad, float* grad_sq, size_
     if (n == 0) return NK_OK;
     NK_CHECK(w && grad && grad_sq, "null pointer in nk_adagrad_step");
     NK_CHECK(step >= 1, "step must be >= 1");
+    if (lr_decay != 0.f)
+        if (int rc = refuse_capture(dev, "nk_adagrad_step: the decayed learning rate lr / (1 + (step-1) * lr_decay)")) return rc;
     const float clr = lr / (1.f + (float)(step - 1) * lr_decay);
     hipLaunchKernelGGL(adagrad_kernel, dim3(nk_stream_grid(n, 256)), dim3(256), 0, dev->compute, w, grad, grad_sq, n, clr,
                        eps, l1, l2);

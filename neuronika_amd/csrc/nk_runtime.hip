@@ -23,8 +23,18 @@ int nk_workspace(nk_device* dev, size_t bytes, void** out) {
     if (bytes > dev->workspace_bytes) {
         size_t want = bytes < (size_t(64) << 20) ? (size_t(64) << 20) : bytes;
         if (dev->workspace) {
-            NK_HIP(hipDeviceSynchronize());
-            NK_HIP(hipFree(dev->workspace));
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            NK_HIP(hipStreamIsCapturing(dev->compute, &cs));
+            NK_CHECK(cs == hipStreamCaptureStatusNone,
+                     "the device workspace would have to grow (%zu -> %zu bytes) inside a captured region: run one eager step first", dev->workspace_bytes, bytes);
+            if (dev->graphs_alive > 0) {
+                // a captured graph has the old pointer baked into its kernel arguments (split-K slabs, reduction partials,
+                // conv tables): keep the block until the last graph of this device is destroyed
+                dev->workspace_retired.push_back(dev->workspace);
+            } else {
+                NK_HIP(hipDeviceSynchronize());
+                NK_HIP(hipFree(dev->workspace));
+            }
             dev->workspace = nullptr;
             dev->workspace_bytes = 0;
         }
@@ -126,6 +136,7 @@ int nk_device_destroy(nk_device* dev) {
     NK_HIP(hipSetDevice(dev->idx));
     NK_HIP(hipDeviceSynchronize());
     if (dev->workspace) (void)hipFree(dev->workspace);
+    for (void* w : dev->workspace_retired) (void)hipFree(w);
     for (auto* v : {&dev->prof, &dev->prof_free})
         for (auto& r : *v) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
     (void)hipEventDestroy(dev->fork);
@@ -179,6 +190,7 @@ int nk_upload(nk_device* dev, float* dst, const float* host_src, size_t n) {
 
 // ---- hipGraph capture of a launch-bound step -------------------------------------------------------
 struct nk_graph {
+    nk_device* dev;  // must outlive the graph (its workspace pointers are baked into the captured kernel arguments)
     int idx;
     hipStream_t stream;
     hipGraph_t graph;
@@ -204,7 +216,8 @@ int nk_graph_end(nk_device* dev, nk_graph** out) {
         (void)hipGraphDestroy(g);
         return nk_fail_hip(e, "hipGraphInstantiate", __FILE__, __LINE__);
     }
-    *out = new nk_graph{dev->idx, dev->compute, g, exec};
+    *out = new nk_graph{dev, dev->idx, dev->compute, g, exec};
+    ++dev->graphs_alive;
     return NK_OK;
 }
 
@@ -220,6 +233,11 @@ int nk_graph_destroy(nk_graph* g) {
     (void)hipSetDevice(g->idx);
     (void)hipGraphExecDestroy(g->exec);
     (void)hipGraphDestroy(g->graph);
+    if (--g->dev->graphs_alive == 0 && !g->dev->workspace_retired.empty()) {  // nobody can replay into the outgrown blocks now
+        (void)hipDeviceSynchronize();
+        for (void* w : g->dev->workspace_retired) (void)hipFree(w);
+        g->dev->workspace_retired.clear();
+    }
     delete g;
     return NK_OK;
 }

@@ -43,3 +43,19 @@ def test_product_path_does_not_import_oracle():
                     if re.search(r"^\s*(from|import)\s+oracle|neuronika_oracle", txt, re.M):
                         bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_examples_do_not_depend_on_test_infrastructure():
+    """examples/ ships its own data: the quickstart model JSON (the serialized network of the reference's
+    examples/quickstart.rs:53-169) lives next to the example and equals the vectors the extractor took from the
+    reference; nothing under examples/ reads tests/ or the oracle."""
+    import json
+    for f in os.listdir(os.path.join(ROOT, "examples")):
+        if f.endswith(".py"):
+            txt = open(os.path.join(ROOT, "examples", f)).read()
+            assert '"tests"' not in txt and "tests/" not in txt and "oracle" not in txt, f
+    model = json.load(open(os.path.join(ROOT, "examples", "quickstart_model.json")))["model"]
+    q = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_fixtures.json")))["quickstart_mlp"]
+    for name in ("lin1", "lin2", "lin3"):
+        for p in ("weight", "bias"):
+            assert model[name][p]["dim"] == q[f"{name}.{p}"]["dim"] and model[name][p]["data"] == q[f"{name}.{p}"]["data"]

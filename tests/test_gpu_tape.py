@@ -398,6 +398,7 @@ def test_device_loader_pipeline(nk, tdev):
                 assert ld.next_into(X, Y) == rows
                 assert np.array_equal(X.data()[:rows], rec[start:start + rows])
                 assert np.array_equal(Y.data()[:rows], lab[start:start + rows])
+                assert not X.data()[rows:].any() and not Y.data()[rows:].any()   # a ragged tail never keeps the previous batch
             assert ld.next_into(X, Y) == 0                                   # end of the epoch
     ld = nk.data.DeviceLoader(tdev, nk.data.Dataset(rec), 32, False)
     seen = []
@@ -851,6 +852,36 @@ def test_hipgraph_training_step(nk, tdev):
     for p, w in zip(pg, want):
         assert np.array_equal(p.data(), w)
     assert np.isfinite(loss_g.item()) and loss_g.item() == loss_e.item()
+
+
+@pytest.mark.gpu
+def test_hipgraph_refuses_step_dependent_optimizers_and_keeps_workspaces(nk, tdev):
+    """An Adam step bakes 1 - beta^step into its kernel arguments: capturing it would freeze the bias correction, so it
+    refuses (the SGD step of the test above captures).  And a workspace outgrown AFTER a capture stays valid for the
+    graph that has its address baked in: replaying the graph after a much larger reduction gives the same result."""
+    lin = nk.nn.Linear(tdev, 8, 8, 1)
+    X, T = nk.rand(tdev, [16, 8], 7), nk.rand(tdev, [16, 8], 8)
+    loss = lin.forward(X).mse(T, nk.Reduction.Mean)
+    adam = nk.optim.Adam(0.01)
+    adam.register(lin.weight); adam.register(lin.bias)
+    loss.forward(); loss.backward(1.0); adam.step(); adam.zero_grad()
+    tdev.graph_begin()
+    loss.forward(); loss.no_grad(); loss.with_grad(); loss.backward(1.0)
+    with pytest.raises(RuntimeError, match="captured"):
+        adam.step()
+    g = tdev.graph_end()
+    del g
+    # workspace: capture a split-K GEMM (uses slabs in the device workspace), then force the workspace to grow
+    a, b = nk.rand(tdev, [64, 8192], 1), nk.rand(tdev, [8192, 64], 2)
+    c = a.mm(b)
+    c.forward()
+    want = c.data().copy()
+    tdev.graph_begin(); c.forward(); graph = tdev.graph_end()
+    big_a, big_b = nk.rand(tdev, [512, 65536], 3), nk.rand(tdev, [65536, 512], 4)     # 64 splits x 1 MB slabs > 64 MB
+    big = big_a.mm(big_b); big.forward()
+    for _ in range(3):
+        graph.launch()
+    assert np.array_equal(c.data(), want)
 
 
 @pytest.mark.gpu
