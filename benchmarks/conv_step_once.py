@@ -15,11 +15,11 @@ N = 128
 conv = t.nn.Conv2d(dev, 64, 128, [3, 3], [1, 1], [1, 1], [1, 1], 1, 1)
 X = t.from_ndarray(dev, np.random.default_rng(0).random((N, 64, 56, 56), dtype=np.float32)).requires_grad()
 G = t.from_ndarray(dev, np.random.default_rng(2).random((N, 128, 56, 56), dtype=np.float32))
-loss = (conv.forward(X) * G).sum()
+y = conv.forward(X)
 for _ in range(2):
-    loss.forward()
-    loss.no_grad(); loss.with_grad()
-    loss.backward(1.0)
+    y.forward()
+    y.no_grad(); y.with_grad()
+    y.backward_from(G)
     X.zero_grad(); conv.weight.zero_grad(); conv.bias.zero_grad()
 dev.sync()
-print("ok", loss.item())
+print("ok")
