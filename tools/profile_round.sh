@@ -1,0 +1,16 @@
+#!/bin/bash
+# Round profile set: bench lines of the four workloads, rocprofv3 --kernel-trace of each (summarised by
+# tools/rocpd_kernel_stats.py), micro-benchmarks.   bash tools/profile_round.sh OUTDIR TAG     (on the GPU box)
+set -u
+out=$1; tag=$2
+root=${GRAFT_REPO_ROOT:-/root/repo}
+mkdir -p "$root/$out"
+cd /tmp && export TMPDIR=/tmp
+for w in mlp matmul conv mha; do
+  timeout -k 5 300 python "$root/bench.py" --workload $w > "$root/$out/${tag}_bench_$w.json" 2> "$root/$out/${tag}_bench_$w.err"
+  timeout -k 5 200 rocprofv3 --kernel-trace --stats -d "$root/$out/prof_$w" -o r -- python "$root/bench.py" --workload $w --steps 10 --warmup 2 --no-cpu-baseline > "$root/$out/prof_$w.log" 2>&1
+  db=$(find "$root/$out/prof_$w" -name "*_results.db" | head -1)
+  [ -n "$db" ] && python "$root/tools/rocpd_kernel_stats.py" "$db" > "$root/$out/${tag}_${w}_step_kernel_stats.md"
+done
+timeout -k 5 300 python "$root/benchmarks/microbench.py" > "$root/$out/${tag}_microbench.jsonl" 2>&1
+find "$root/$out" -name "*.db" -delete
