@@ -44,18 +44,18 @@ __global__ void dropout_bwd_kernel(float* __restrict__ dx, const float* __restri
                                    int assign) {
     const size_t n4 = n / 4;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-        float4 d = assign ? make_float4(0.f, 0.f, 0.f, 0.f) : reinterpret_cast<float4*>(dx)[i];
-        const float4 gv = reinterpret_cast<const float4*>(g)[i];
+        float4 d = (assign & 1) ? make_float4(0.f, 0.f, 0.f, 0.f) : nk_load_stream(reinterpret_cast<const float4*>(dx) + i, assign & 2);
+        const float4 gv = nk_load_stream(reinterpret_cast<const float4*>(g) + i, assign & 2);
         if (MODE == 0) { d.x += gv.x; d.y += gv.y; d.z += gv.z; d.w += gv.w; }
         else {
-            const float4 nz = reinterpret_cast<const float4*>(noise)[i];
+            const float4 nz = nk_load_stream(reinterpret_cast<const float4*>(noise) + i, assign & 2);
             d.x += gv.x * nz.x; d.y += gv.y * nz.y; d.z += gv.z * nz.z; d.w += gv.w * nz.w;
         }
         nk_store_stream(reinterpret_cast<float4*>(dx) + i, d);
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
         const size_t i = n4 * 4 + threadIdx.x;
-        dx[i] = (assign ? 0.f : dx[i]) + (MODE == 0 ? g[i] : g[i] * noise[i]);
+        dx[i] = ((assign & 1) ? 0.f : dx[i]) + (MODE == 0 ? g[i] : g[i] * noise[i]);
     }
 }
 
@@ -450,6 +450,7 @@ static int dropout_bwd(nk_device* dev, float* dx, const float* g, const float* n
     NK_CHECK(dx && g, "null pointer in nk_dropout_bwd");
     NK_CHECK(al16(dx) && al16(g), "dropout buffers must be 16-byte aligned");
     const int grid = nk_stream_grid(n / 4 + 1, 256);
+    assign |= nk_streams_past_cache(n * 16) ? 2 : 0;  // bit 1: `nt` loads (g, noise, dx beyond the Infinity Cache)
     if (!train || p == 0.0) {
         hipLaunchKernelGGL((dropout_bwd_kernel<0>), dim3(grid), dim3(256), 0, dev->compute, dx, g, noise, n, assign);
     } else {

@@ -116,15 +116,16 @@ int scalar_bwd(nk_device* dev, float* dx, const float* g, const float* x, const 
 // LOG: log-softmax.   The max fold starts from f32::MIN (finite), softmax/mod.rs:45.
 constexpr float F32_MIN = -3.40282347e+38f;
 
+
 // The V quads of a lane's row slice, ALL issued before any is used: a load inside `if (c < L) { load; use; }` gets its
 // own vmcnt(0), i.e. V serialised memory round trips per row.  Lanes beyond the row re-read its first quad (a row has
 // at least one) and are masked by the `c < L` tests of the compute loops.
 template <int V>
-__device__ __forceinline__ void row_load(float4 (&v)[V], const float* __restrict__ row, int lane, int L) {
+__device__ __forceinline__ void row_load(float4 (&v)[V], const float* __restrict__ row, int lane, int L, bool stream = false) {
 #pragma unroll
     for (int i = 0; i < V; ++i) {
         const int c = (i * 64 + lane) * 4;
-        v[i] = *reinterpret_cast<const float4*>(row + (c < L ? c : 0));
+        v[i] = nk_load_stream(reinterpret_cast<const float4*>(row + (c < L ? c : 0)), stream);  // nk_common.h: `nt` past the cache
     }
 }
 
@@ -180,9 +181,11 @@ __global__ __launch_bounds__(256) void softmax_bwd_row_kernel(int assign, float*
     const float* yr = y + row * L;
     float* dr = dx + row * L;
     float4 gv[V], yv[V], dv[V];
-    row_load<V>(gv, gr, lane, L);
-    row_load<V>(yv, yr, lane, L);
-    if (!assign) row_load<V>(dv, dr, lane, L);
+    const bool nt = assign & 2;  // bit 1 of `assign`: operands beyond the Infinity Cache (launch-time choice)
+    assign &= 1;
+    row_load<V>(gv, gr, lane, L, nt);
+    row_load<V>(yv, yr, lane, L, nt);
+    if (!assign) row_load<V>(dv, dr, lane, L, nt);
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < V; ++i) {
@@ -364,10 +367,12 @@ __global__ __launch_bounds__(256) void attn_probs_bwd_kernel(float* __restrict__
     const long long rb = row * L;
     const uint2 key = make_uint2((unsigned)seed, (unsigned)(seed >> 32));
     float4 gp[V], y[V], nzv[V], dv[V];
-    row_load<V>(y, probs + rb, lane, L);  // probabilities, or the scores they are recomputed from
-    row_load<V>(gp, g + rb, lane, L);
-    if (MASK == 1 && LOAD_NOISE) row_load<V>(nzv, noise + rb, lane, L);
-    if (!assign) row_load<V>(dv, ds + rb, lane, L);
+    const bool nt = assign & 2;  // bit 1 of `assign`: operands beyond the Infinity Cache (launch-time choice)
+    assign &= 1;
+    row_load<V>(y, probs + rb, lane, L, nt);  // probabilities, or the scores they are recomputed from
+    row_load<V>(gp, g + rb, lane, L, nt);
+    if (MASK == 1 && LOAD_NOISE) row_load<V>(nzv, noise + rb, lane, L, nt);
+    if (!assign) row_load<V>(dv, ds + rb, lane, L, nt);
     if (RECOMP) {
         float m = F32_MIN;
 #pragma unroll
@@ -488,10 +493,11 @@ int softmax_bwd(nk_device* dev, float* dx, const float* g, const float* y, const
         if (vec) {
             const int wpb = 4;
             const dim3 grid((unsigned)((outer + wpb - 1) / wpb)), block(64 * wpb);
-            if (L <= 256) hipLaunchKernelGGL((softmax_bwd_row_kernel<1, LOG>), grid, block, 0, dev->compute, assign, dx, g, y, outer, L);
-            else if (L <= 512) hipLaunchKernelGGL((softmax_bwd_row_kernel<2, LOG>), grid, block, 0, dev->compute, assign, dx, g, y, outer, L);
-            else if (L <= 1024) hipLaunchKernelGGL((softmax_bwd_row_kernel<4, LOG>), grid, block, 0, dev->compute, assign, dx, g, y, outer, L);
-            else hipLaunchKernelGGL((softmax_bwd_row_kernel<8, LOG>), grid, block, 0, dev->compute, assign, dx, g, y, outer, L);
+            const int nt2 = nk_streams_past_cache((size_t)outer * L * 12) ? 2 : 0;  // g, y (, dx) read once, dx written
+            if (L <= 256) hipLaunchKernelGGL((softmax_bwd_row_kernel<1, LOG>), grid, block, 0, dev->compute, assign | nt2, dx, g, y, outer, L);
+            else if (L <= 512) hipLaunchKernelGGL((softmax_bwd_row_kernel<2, LOG>), grid, block, 0, dev->compute, assign | nt2, dx, g, y, outer, L);
+            else if (L <= 1024) hipLaunchKernelGGL((softmax_bwd_row_kernel<4, LOG>), grid, block, 0, dev->compute, assign | nt2, dx, g, y, outer, L);
+            else hipLaunchKernelGGL((softmax_bwd_row_kernel<8, LOG>), grid, block, 0, dev->compute, assign | nt2, dx, g, y, outer, L);
         } else {
             hipLaunchKernelGGL((softmax_bwd_block_kernel<LOG>), dim3((unsigned)outer), dim3(256), 0, dev->compute, assign, dx, g, y, L);
         }
@@ -596,6 +602,7 @@ static int attn_probs_bwd(nk_device* dev, float* d_scores, const float* g_out, c
     const bool masked = train && p != 0.0;
     const float keep = (1.0 - p == 0.0) ? -1.f : (float)(1.0 - p);  // keep < 0: every draw is "dropped"
     const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    assign |= nk_streams_past_cache((size_t)rows * L * 12) ? 2 : 0;  // bit 1: `nt` loads (operands beyond the Infinity Cache)
 #define NK_AP(V)                                                                                                   \
     do {                                                                                                           \
         if (recompute) {                                                                                           \
