@@ -45,6 +45,16 @@ def one(what):
 
 
 def sweep():
+    if os.environ.get("NK_SWEEP") == "pf2":
+        pts = [(op, f) for op in ("context", "dV", "proj_fwd", "proj_dx", "proj_dw") for f in (None, "2,1,1,1,8,0,8", "2,1,1,1,8,0,16", "2,2,1,1,8,0,16", "2,2,1,1,8,0,24")]
+        pts = [(op, f) for op, f in pts if not (op in ("context", "dV") and f and f.startswith("2,2")) and not (op.startswith("proj") and f and f.startswith("2,1"))]
+        for op, force in pts:
+            env = dict(os.environ)
+            env.pop("NK_GEMM_FORCE", None)
+            if force:
+                env["NK_GEMM_FORCE"] = force
+            subprocess.run([sys.executable, os.path.abspath(__file__), op], env=env)
+        return
     pts = [("scores", f) for f in (None, "2,2,1,1", "2,2,1,1,1", "2,2,1,8,1", "2,2,1,8,2", "2,2,1,16,1", "2,2,1,4,1", "1,2,1,8,1", "1,1,1,8,1", "1,1,1,1,1")]
     pts += [("scores_samec", f) for f in (None, "2,2,1,1", "2,2,1,8,1")]
     pts += [("dP", f) for f in (None, "2,2,1,8,1")]

@@ -12,7 +12,7 @@
 using namespace nkmma;
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
-constexpr int PF2_MIN_KTILES = 48;  // reductions at least this long take the two-k-tile look-ahead loop
+constexpr int PF2_MIN_KTILES = 48;  // default threshold of the two-k-tile look-ahead loop (per-layout rules in gemm_impl)
 
 struct GemmArgs {
     const float* A;
@@ -40,6 +40,7 @@ struct GemmArgs {
     // row-major tile order so that one block writes whole 4 KB rows (no gain).
     int chunk;        // >= 1 tiles per block (1: one tile per block, the classic grid)
     int group_m;      // tile order: column-major inside groups of `group_m` tile rows (1: row-major, tn fastest)
+    int pf2_min;      // reductions of at least this many k-tiles take the two-k-tile look-ahead loop
 };
 
 // C tile <- accumulators (or the split's slab).  Every load (bias, old C) is issued first and folded into the accumulators
@@ -129,8 +130,8 @@ __global__ __launch_bounds__(NT, (min_waves<TI, TJ, !TA && TB>())) void sgemm_ke
     // Same-box A/B at 4096^3 (benchmarks/ab_gemm.py): NT +2.9 %, NN +1.2 %, TN -1.0 % (its A operand is read k-major,
     // the loads land early anyway); short reductions lose to the longer prologue (NT 4096x3072x1024: -2 %).  So: row-major
     // A only, aligned problems only (the guarded loader's state does not fit next to P and Q), at least 48 k-tiles.
-    constexpr bool PF2 = ALIGNED && !TA;
-    if (PF2 && nt >= PF2_MIN_KTILES) {  // (the host launches these one tile per block: chunk == 1)
+    constexpr bool PF2 = ALIGNED;
+    if (PF2 && nt >= p.pf2_min) {  // (the host launches these one tile per block: chunk == 1)
     // Two k-tiles of look-ahead in registers: tile it+1 (P, loaded during the previous trip) goes to LDS at the START of a
     // trip, the loads of tile it+2 (Q) are issued in front of it and have a whole trip plus to land.  The end of a trip is
     // then MFMAs -> barrier, instead of MFMAs -> wait for this trip's own loads -> 8 LDS writes -> barrier.  Unrolled by
@@ -365,7 +366,11 @@ static int gemm_impl(nk_device* dev, int transA, int transB, int M, int N, int K
         const long long nb = blocks(ti, tj);
         long long s = (512 + nb - 1) / nb;
         if (s > ktiles / 16) s = ktiles / 16;
-        if (ti * tj > 1 && s >= 1 && nb * s >= 384) {
+        if (ti * tj == 4 && nb >= 256 && ktiles >= PF2_MIN_KTILES) {
+            // one 128x128 block per CU and a reduction long enough for the two-k-tile look-ahead: unsplit beats
+            // split-K 2 + second pass (2048^3: NN 97 -> 111, NT 110 -> 113, TN 107.6 -> 110.3 TFLOP/s)
+            splits = 1;
+        } else if (ti * tj > 1 && s >= 1 && nb * s >= 384) {
             splits = (int)s;
         } else {
             ti = tj = 1;
@@ -379,16 +384,17 @@ static int gemm_impl(nk_device* dev, int transA, int transB, int M, int N, int K
     }
     p.tiles_m = (M + 64 * ti - 1) / (64 * ti);
     p.tiles_n = (N + 64 * tj - 1) / (64 * tj);
-    int force_chunk = 0, force_group = 0;
-    if (const char* f = getenv("NK_GEMM_FORCE")) {  // tuning sweeps (benchmarks/ab_force.py): "ti,tj,splits[,chunk]" overrides the rules
-        int a = 0, b = 0, c = 0, d = 0, e = 0;
-        const int got = sscanf(f, "%d,%d,%d,%d,%d", &a, &b, &c, &d, &e);
+    int force_chunk = 0, force_group = 0, force_pf2 = 0;
+    if (const char* f = getenv("NK_GEMM_FORCE")) {  // tuning sweeps (benchmarks/ab_force.py): "ti,tj,splits[,chunk[,group_m[,lookahead_min]]]" overrides the rules
+        int a = 0, b = 0, c = 0, d = 0, e = 0, pf = 0;
+        const int got = sscanf(f, "%d,%d,%d,%d,%d,%d", &a, &b, &c, &d, &e, &pf);
         if (got >= 3 && (a == 1 || a == 2) && (b == 1 || b == 2)) {
             ti = a; tj = b; splits = c < 1 ? 1 : c;
             p.tiles_m = (M + 64 * ti - 1) / (64 * ti);
             p.tiles_n = (N + 64 * tj - 1) / (64 * tj);
             if (got >= 4) force_chunk = d;
             if (got >= 5) force_group = e;
+            if (got >= 6) force_pf2 = pf;
         }
     }
     int kts = (ktiles + splits - 1) / splits;
@@ -407,10 +413,22 @@ static int gemm_impl(nk_device* dev, int transA, int transB, int M, int N, int K
         if (c > cap) c = cap;
         if (c > ntiles) c = ntiles;
         if (force_chunk > 0) c = force_chunk;
-        if (c < 1 || kts >= PF2_MIN_KTILES) c = 1;
+        if (c < 1 || kts >= 8) c = 1;  // (8 = the smallest look-ahead threshold: the two loops are alternatives)
         p.chunk = (int)c;
     }
     p.group_m = force_group > 0 ? force_group : 8;
+    // Two k-tiles of look-ahead (the loop that ends a trip MFMAs -> barrier): from a same-box sweep of every layout
+    // (benchmarks/ab_force.py with NK_GEMM_FORCE's sixth field; U[0,1) operands):
+    //   64x64 tiles (a k-tile is only 16 MFMAs per wave, less than an L2 round trip): from 8 k-tiles on, every layout
+    //     (1024^3: NN 80.8 -> 84, NT 81.7 -> 88, TN 78.9 -> 83 TFLOP/s);
+    //   NN (both operands row-major: the B tile is read k-major, its loads land last): from 16 k-tiles on
+    //     (4096^3 116 -> 137 without / with; 4096 x 4096 x 1024 112 -> 122; 32768 x 1024 x 1024 109 -> 118);
+    //   NT / TN / TT: from 48 k-tiles on (TN 4096^3 133.6 -> 137.1; NT loses 3 % below that: 119 -> 116 at K = 1024).
+    // C4 step, same box: 8.75 ms with the look-ahead off, 8.50 with these rules.  (What a k-tile of 64x64 needs is time
+    // for its loads, not more waves: a 512-thread variant with two wave groups on alternating k-tiles of one tile -
+    // two waves per SIMD where 1024^3 has one - measured 78.7 vs 80.1 TFLOP/s and was dropped.)
+    const int pf2_rule = ti * tj == 1 ? 8 : ((!transA && !transB) ? 16 : PF2_MIN_KTILES);
+    p.pf2_min = force_pf2 > 0 ? force_pf2 : pf2_rule;
     if (p.splits > 1) {
         void* ws = nullptr;
         int rc = nk_workspace(dev, (size_t)p.splits * nbatch * M * N * sizeof(float), &ws);

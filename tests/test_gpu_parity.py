@@ -384,6 +384,38 @@ def test_sgemm_tile_chunks(dev, ta, tb, K, chunk, splits):
             contraction_ok(outs[(tiles, chunk, alpha)], want.astype(np.float32), want, K, 1.5, 1.0)
 
 
+@pytest.mark.parametrize("ta,tb", [(0, 1), (0, 0), (1, 0), (1, 1)])
+@pytest.mark.parametrize("tiles", ["1,1", "2,2", "1,2", "2,1"])
+def test_sgemm_lookahead_loop_is_bit_identical(dev, ta, tb, tiles):
+    """The two-k-tile look-ahead loop (taken per layout / tile shape from a k-tile threshold on, nk_gemm.hip) and the
+    one-k-tile loop accumulate in the same order: forcing either for every reduction length from 1 to 7 k-tiles (all
+    the loop's tail cases) and around the thresholds gives the same bits, for every layout and tile shape, with
+    alpha / beta; and the result matches the f64 oracle."""
+    import os
+    c = capi()
+    M, N = 256, 384
+    try:
+        for kt in (1, 2, 3, 4, 5, 6, 7, 8, 9, 15, 16, 17, 47, 48, 49):
+            K = 32 * kt
+            a = rnd(60 + kt, (K, M) if ta else (M, K), -1, 1)
+            b = rnd(61 + kt, (N, K) if tb else (K, N), -1, 1)
+            c0 = rnd(62, (M, N), -1, 1)
+            A, B = dev.array(a), dev.array(b)
+            outs = {}
+            for la in (1, 9999):
+                os.environ["NK_GEMM_FORCE"] = f"{tiles},1,1,8,{la}"
+                Cd = dev.array(c0)
+                c.sgemm(dev, ta, tb, M, N, K, -1.5, A, a.shape[1], B, b.shape[1], 0.5, Cd, N)
+                outs[la] = Cd.numpy()
+            assert np.array_equal(outs[1], outs[9999]), (kt,)
+            if kt in (1, 7, 49):
+                opa, opb = (a.T if ta else a).astype(np.float64), (b.T if tb else b).astype(np.float64)
+                want = -1.5 * (opa @ opb) + 0.5 * c0
+                contraction_ok(outs[1], want.astype(np.float32), want, K, 1.5, 1.0)
+    finally:
+        os.environ.pop("NK_GEMM_FORCE", None)
+
+
 def test_sgemm_large_rowsum_identity(dev):
     """Size-independent check at the BASELINE size (4096^2): (A.B).1 == A.(B.1)."""
     c = capi()
