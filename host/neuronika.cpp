@@ -108,6 +108,13 @@ HipArray& Gradient::borrow() const {
     }
     return *array_;
 }
+Shared<HipArray> Gradient::exchange_array(Shared<HipArray> external) {
+    if (!array_) panic("Trying to get a de-allocated gradient. Switch on the gradients first by using `.with_grad()`");
+    if (external->len() != array_->len()) panic("exchange_array: extent mismatch");
+    std::swap(array_, external);
+    pending_zero_ = false;
+    return external;
+}
 HipArray& Gradient::borrow_first_write(bool& assign) const {
     if (!array_)
         panic("Trying to get a de-allocated gradient. Switch on the gradients first by using `.with_grad()`");
@@ -1229,11 +1236,13 @@ void VarDiff::backward(float seed, BackwardHook* hook) const {
 void VarDiff::backward_from(const Var& seed, BackwardHook* hook) const {
     if (var.history.len() != var.history.buffer_len()) panic("Perhaps you forgot to call .forward()?");
     if (seed.shape() != shape()) panic("backward_from: the seed must have the shape of the root");
-    {
-        bool assign = false;
-        HipArray& g = grad->borrow_first_write(assign);
-        check(nk_copy(device()->raw(), g.ptr(), seed.data->ptr(), g.len()));
-    }
+    // the root's backward nodes read the root gradient through `borrow()` when they run: let them see the seed's buffer
+    const bool was_pending = grad->zero_pending();
+    Shared<HipArray> own = grad->exchange_array(seed.data);
+    struct Restore {
+        const Shared<Gradient>& g; Shared<HipArray>& own; bool pending;
+        ~Restore() { g->exchange_array(own); if (pending) g->zero(); }
+    } restore{grad, own, was_pending};
     run_backward(hook);
 }
 void VarDiff::run_backward(BackwardHook* hook) const {

@@ -168,6 +168,10 @@ class Gradient : public NoGrad {
     void zero();                           // `zero_grad` (vardiff.rs:100-102), lazily
     bool zero_pending() const { return pending_zero_; }
     Shared<HipArray> array() const { return array_; }
+    // Stand `external` in for this gradient's buffer (returns the previous one) without touching device memory: how
+    // `VarDiff::backward_from` presents an upstream gradient tensor to the root's backward nodes (they read through
+    // `borrow()` at run time).  The buffer counts as written.
+    Shared<HipArray> exchange_array(Shared<HipArray> external);
     const Shape& shape() const { return shape_; }
     void no_grad() override;
     void with_grad() override;
@@ -337,7 +341,8 @@ class VarDiff {
     void backward(float seed, BackwardHook* hook = nullptr) const;  // vardiff.rs:125-141
     // The same pass seeded with an upstream gradient TENSOR (root gradient = `seed`, same shape) instead of a
     // scalar fill: what an enclosing graph would hand to this sub-graph's root.  Lets a benchmark time a module's
-    // own backward nodes without `(y * G).sum()` scaffolding.
+    // own backward nodes without `(y * G).sum()` scaffolding.  The seed's buffer stands in for the root gradient while
+    // the tape runs (no copy); afterwards the root gradient is its own buffer again, holding what it held before.
     void backward_from(const Var& seed, BackwardHook* hook = nullptr) const;
     void no_grad() const;           // vardiff.rs:145
     void with_grad() const;         // vardiff.rs:157

@@ -659,6 +659,32 @@ def test_mha_with_dropout_equals_oracle(nk, tdev, fused, strided, p):
         assert not np.array_equal(O.dropout_noise(n, p, seed, 0), noise.reshape(-1))
 
 
+def test_backward_from_equals_weighted_sum_scaffolding(nk, tdev):
+    """`y.backward_from(G)` (the upstream gradient tensor stands in for the root gradient while the tape runs - no copy,
+    no extra nodes) gives bit-identical leaf gradients to the scaffolding `(y * G).sum().backward(1.0)`; the seed is left
+    untouched, the root gradient is its own buffer again afterwards, and a second call accumulates like backward()."""
+    x, g = rnd(1, (24, 40), -1, 1), rnd(2, (24, 16), -1, 1)
+    def leaves():
+        lin = nk.nn.Linear(tdev, 40, 16, 5)
+        X = nk.from_ndarray(tdev, x).requires_grad()
+        return lin, X, lin.forward(X).relu()
+    lin1, X1, y1 = leaves()
+    loss = (y1 * nk.from_ndarray(tdev, g)).sum()
+    loss.forward(); loss.backward(1.0)
+    lin2, X2, y2 = leaves()
+    G = nk.from_ndarray(tdev, g)
+    y2.forward(); y2.backward_from(G)
+    assert np.array_equal(X2.grad(), X1.grad()) and np.array_equal(lin2.weight.grad(), lin1.weight.grad())
+    assert np.array_equal(lin2.bias.grad(), lin1.bias.grad())
+    assert np.array_equal(G.data(), g)                         # the seed tensor is only read
+    assert not y2.grad().any()                                 # the root gradient's own buffer is back (still zero)
+    y2.no_grad(); y2.with_grad()                               # re-arm the intermediate gradients (never re-zeroed by backward)
+    y2.backward_from(G)                                        # leaves accumulate (vardiff.rs:125-141 semantics)
+    assert np.array_equal(X2.grad(), 2 * X1.grad())
+    with pytest.raises(RuntimeError, match="shape"):
+        y2.backward_from(nk.zeros(tdev, [24, 15]))
+
+
 def test_rccl_single_rank_and_gradient_sync(nk, tdev):
     """Exercise the RCCL entry points on the GPU box (1 GPU => world of one): unique id,
     communicator, side-stream all-reduce ordered after a compute-stream event, join; and the
