@@ -261,6 +261,45 @@ __global__ void pad_fwd_plane_kernel(const float* __restrict__ x, float* __restr
     }
 }
 
+// Constant / zero padding with an even padded row length (the common `k/2` padding of an even-width image): a thread
+// writes TWO neighbouring outputs with one 8-byte store (a padded plane has an even element count, so every pair is 8-byte
+// aligned) - half the store instructions of the element-wise plane kernel (C3: 58 -> ~40 us for 103 MB in, 110 MB out).
+__global__ void pad_const_pairs_kernel(const float* __restrict__ x, float* __restrict__ y, PadDesc p, long long planes,
+                                       int out_plane, int in_plane, float value) {
+    const int o1 = p.out[p.nd - 1], h1 = o1 >> 1, o2 = p.nd >= 2 ? p.out[p.nd - 2] : 1;
+    const float invh = 1.f / (float)h1, inv2 = 1.f / (float)o2;
+    const int pairs = out_plane >> 1;
+    for (long long pl = blockIdx.x; pl < planes; pl += gridDim.x) {
+        const float* xp = x + pl * in_plane;
+        float2* yp = reinterpret_cast<float2*>(y + pl * out_plane);
+        for (int i = threadIdx.x; i < pairs; i += blockDim.x) {
+            int c[3] = {0, 0, 0};
+            int rem = fast_div(i, h1, invh);
+            const int cw = (i - rem * h1) * 2 - p.pad[p.nd - 1];  // input column of the pair's first element
+            if (p.nd >= 2) {
+                const int r2 = fast_div(rem, o2, inv2);
+                c[p.nd - 2] = rem - r2 * o2;
+                if (p.nd == 3) c[0] = r2;
+            }
+            int src = 0;
+            bool inside = true;
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {  // the outer axes (the innermost one is handled per element below)
+                if (d < p.nd - 1) {
+                    const int v = c[d] - p.pad[d];
+                    if (v < 0 || v >= p.in[d]) inside = false;
+                    src = src * p.in[d] + (inside ? v : 0);
+                }
+            }
+            const int w = p.in[p.nd - 1];
+            src = src * w;
+            const bool in0 = inside && cw >= 0 && cw < w, in1 = inside && cw + 1 >= 0 && cw + 1 < w;
+            const float a = xp[in0 ? src + cw : 0], b = xp[in1 ? src + cw + 1 : 0];  // clamped addresses, masked values
+            yp[i] = make_float2(in0 ? a : value, in1 ? b : value);
+        }
+    }
+}
+
 // ------------------------------------------------------------------ transpose -------------------
 // 2-D: 32x32 tiles through LDS (+1 padding: conflict-free column reads), both sides coalesced.
 template <bool ACC>
@@ -406,6 +445,12 @@ static int pad_fwd(nk_device* dev, int nd, const float* x, const int* x_shape, f
     if (planes * out_plane == 0) return NK_OK;
     NK_CHECK(x && y, "null pointer in pad forward");
     if (out_plane < (1 << 23)) {
+        if (MODE == 0 && p.out[nd - 1] % 2 == 0 && in_plane > 0 && (reinterpret_cast<uintptr_t>(y) & 7) == 0) {
+            hipLaunchKernelGGL(pad_const_pairs_kernel, dim3((unsigned)(planes < 8192 ? planes : 8192)), dim3(256), 0, dev->compute, x, y,
+                               p, planes, (int)out_plane, (int)in_plane, value);
+            NK_LAUNCH_CHECK();
+            return NK_OK;
+        }
         hipLaunchKernelGGL(pad_fwd_plane_kernel<MODE>, dim3((unsigned)(planes < 8192 ? planes : 8192)), dim3(256), 0, dev->compute, x,
                            y, p, planes, (int)out_plane, (int)in_plane, value);
         NK_LAUNCH_CHECK();
