@@ -362,6 +362,7 @@ __global__ __launch_bounds__(NT, 2) void conv_bwd_input_fast_kernel(FastBwdInArg
         gbase = n * g.Cout * g.L + krow * g.L;
     }
     const int jstep = 8 * g.L;
+    const long long gy_elems = (long long)g.N * g.Cout * g.L;
     // Two halves: `gather` only ISSUES the four 16-byte loads of the next k-tile (before the MFMAs of the current one);
     // `gather_finish` picks / masks the elements and runs AFTER the MFMAs - touching the loaded registers any earlier
     // makes the wave wait for its loads with nothing to hide them behind.
@@ -376,8 +377,14 @@ __global__ __launch_bounds__(NT, 2) void conv_bwd_input_fast_kernel(FastBwdInArg
         const int a = qa - d.x, b = qb - d.y, c = qc - d.z;  // output coordinates of the quad's first element
         g_ok = valid && a >= 0 && a < g.out[0] && b >= 0 && b < g.out[1];
         const int ac = min(max(a, 0), g.out[0] - 1), bc = min(max(b, 0), g.out[1] - 1);
-        const int cs = min(max(c, 0), g.out[2] - 4);  // load start clamped into the row
-        g_sh = c - cs;                                  // shift of element 0 inside the loaded vector
+        // The load starts AT the quad (element i of the vector = element i of the quad, no shift): a quad that sticks out
+        // of its gradient row reads the neighbouring row's elements, which the per-element masks zero.  Only a load that
+        // would leave the TENSOR (before the first / behind the last element of gy: a handful of lanes per launch) is
+        // pulled back into its row and takes the shifting path.
+        const long long e0 = (long long)(src - p.gy) + gbase + (ac * g.out[1] + bc) * g.out[2] + c;
+        const bool edge = e0 < 0 || e0 + 3LL * jstep + 4 > gy_elems;
+        const int cs = edge ? min(max(c, 0), g.out[2] - 4) : c;
+        g_sh = c - cs;                                  // shift of element 0 inside the loaded vector (0 unless `edge`)
         g_c = c;
         const float* ptr = src + (gbase + (ac * g.out[1] + bc) * g.out[2] + cs);
 #define NK_LDU(V, P) { const f32x4u q = *reinterpret_cast<const f32x4u*>(P); V = make_float4(q.x, q.y, q.z, q.w); }
@@ -386,9 +393,11 @@ __global__ __launch_bounds__(NT, 2) void conv_bwd_input_fast_kernel(FastBwdInArg
     };
     auto gather_finish = [&]() {
         const int sh = g_sh;
-        if (sh == 0) {  // interior quad (the common case): the loaded vector is the quad
-            auto keep = [](float4& q, bool k) { q.x = k ? q.x : 0.f; q.y = k ? q.y : 0.f; q.z = k ? q.z : 0.f; q.w = k ? q.w : 0.f; };
-            keep(rb.v0, g_ok); keep(rb.v1, g_ok); keep(rb.v2, g_ok); keep(rb.v3, g_ok);
+        if (sh == 0) {  // the loaded vector is the quad (every lane but the few at the tensor's ends): mask per element
+            const bool k0 = g_ok && g_c >= 0 && g_c < g.out[2], k1 = g_ok && g_c + 1 >= 0 && g_c + 1 < g.out[2],
+                       k2 = g_ok && g_c + 2 >= 0 && g_c + 2 < g.out[2], k3 = g_ok && g_c + 3 >= 0 && g_c + 3 < g.out[2];
+            auto keep = [&](float4& q) { q.x = k0 ? q.x : 0.f; q.y = k1 ? q.y : 0.f; q.z = k2 ? q.z : 0.f; q.w = k3 ? q.w : 0.f; };
+            keep(rb.v0); keep(rb.v1); keep(rb.v2); keep(rb.v3);
         } else {
             const bool in0 = g_ok && g_c >= 0 && g_c < g.out[2], in1 = g_ok && g_c + 1 >= 0 && g_c + 1 < g.out[2],
                        in2 = g_ok && g_c + 2 >= 0 && g_c + 2 < g.out[2], in3 = g_ok && g_c + 3 >= 0 && g_c + 3 < g.out[2];
