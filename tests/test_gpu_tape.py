@@ -799,6 +799,27 @@ def test_gradient_sync_covers_every_element_once(nk, tdev, ranks):
 
 
 @pytest.mark.gpu
+def test_gradient_sync_covers_conv_and_attention_parameters(nk, tdev):
+    """Parameters whose gradients come from nodes that do NOT hand over pieces early (convolution kernel / bias
+    gradients, the attention module's eight parameters whose weight gradients are split-K GEMMs) are exchanged whole
+    when their last writer has run - each element exactly once, also when a module is applied twice."""
+    def conv_net():
+        c1 = nk.nn.Conv2d(tdev, 8, 32, [3, 3], [1, 1], [1, 1], [1, 1], 1, 1)
+        c2 = nk.nn.Conv2d(tdev, 32, 32, [3, 3], [1, 1], [1, 1], [1, 1], 1, 3)
+        X = nk.rand(tdev, [4, 8, 12, 12], 5)
+        y = c2.forward(c2.forward(c1.forward(X).relu()).relu())          # c2 applied twice: two writers of its gradients
+        return y.sum(), [c1.weight, c1.bias, c2.weight, c2.bias]
+    _replica_check(nk, tdev, 2, conv_net)
+
+    def attention():
+        mha = nk.nn.MultiheadAttention(tdev, 128, 4, 0.0, 11)
+        X = nk.rand(tdev, [2 * 64, 128], 3).requires_grad()
+        loss = mha.forward(X, 2).mse(nk.rand(tdev, [2 * 64, 128], 4), nk.Reduction.Mean)
+        return loss, [getattr(getattr(mha, n), w) for n in "qkvo" for w in ("weight", "bias")]
+    _replica_check(nk, tdev, 4, attention, 0.25)
+
+
+@pytest.mark.gpu
 def test_gradient_sync_shared_linear(nk, tdev):
     """A Linear applied twice (tied weights, an unrolled recurrence): its weight gradient has two writers on the tape.
     The piecewise hand-over must wait for the LAST writer - the first one keeps the single-GEMM path and the exchange
