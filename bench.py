@@ -306,13 +306,20 @@ def run_mlp(a, dist):
     for p in params:
         opt.register(p)
     comm = sync = None
+    replicas = int(os.environ.get("NK_BENCH_REPLICAS", "0")) if world == 1 else 0
     if world > 1:
         uid = dist.bcast_bytes(t.dp.Communicator.unique_id() if dist.rank == 0 else None)
         comm = t.dp.Communicator(tdev, world, dist.rank, uid)
         if comm.size != world:
             raise SystemExit(f"[bench] RCCL communicator has {comm.size} ranks, expected {world}")
         sync = t.dp.GradientSync(comm, params)
-    seed = 1.0 / world
+    elif replicas > 1:
+        # debugging aid for 1-GPU boxes: the whole N > 1 code path of this function (hook, piecewise hand-over, grouped
+        # small gradients, join, the exposed-communication loop) over a replica communicator - `replicas` virtual ranks
+        # holding this rank's values, no fabric traffic.  The line is labelled; it is not a multi-GPU measurement.
+        comm = t.dp.Communicator.replicas(tdev, replicas)
+        sync = t.dp.GradientSync(comm, params)
+    seed = 1.0 / (replicas if replicas > 1 else world)
     exchange = [True]
 
     def step():
@@ -349,7 +356,8 @@ def run_mlp(a, dist):
             "config": {"workload": f"C4: 3-layer MLP Linear({H},{H})x3 + ReLU, MSE mean, batch {B}/GPU, data-parallel "
                                    f"gradient all-reduce (RCCL, side stream)", "global_batch": B * world,
                        "parallelism": f"dp{world}", "optimizer_step_in_timed_region": not a.no_optimizer},
-            "rccl_ranks": comm.size if comm is not None else 1,
+            "rccl_ranks": comm.size if (comm is not None and replicas <= 1) else 1,
+            **({"replica_ranks_debug": replicas} if replicas > 1 else {}),
             "allreduce_bytes_per_step": sync.bytes_per_step() if sync is not None else 0,
             "allreduce_launches_per_step": n_exch // (a.steps + a.warmup) if sync is not None else 0,
             "exposed_comm_ms": round(exposed, 4),
