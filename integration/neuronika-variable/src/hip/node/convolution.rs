@@ -1,0 +1,95 @@
+use std::rc::Rc;
+
+use ndarray::Dimension;
+
+use crate::{
+    autograd::{Backward, Forward},
+    gradient::Gradient,
+    hip::{ffi, hiparray::HipArray},
+    utils::Shared,
+};
+
+/// `Convolution::forward` (`node/convolution/mod.rs:296-355`, kernels `:85-144`): cross-correlation, no internal padding,
+/// `groups` splits input and output channels.  The im2col + sgemm of the reference becomes one implicit-GEMM launch.
+pub(crate) struct Convolution<D>
+where
+    D: Dimension,
+{
+    input_data: Shared<HipArray<D>>,
+    kernel_data: Shared<HipArray<D>>,
+    data: Shared<HipArray<D>>,
+    stride: Vec<i32>,
+    dilation: Vec<i32>,
+    groups: i32,
+}
+
+impl<D> Forward for Convolution<D>
+where
+    D: Dimension,
+{
+    fn forward(&self) {
+        let (x, w) = (self.input_data.borrow(), self.kernel_data.borrow());
+        let mut y = self.data.borrow_mut();
+        let (xs, ws) = (x.shape_c(), w.shape_c());
+        ffi::check(unsafe {
+            ffi::nk_conv_fwd(x.device().as_raw(), xs.len() as i32 - 2, x.as_ptr(), xs.as_ptr(), w.as_ptr(), ws.as_ptr(), y.as_mut_ptr(),
+                             self.stride.as_ptr(), self.dilation.as_ptr(), self.groups)
+        });
+    }
+}
+
+/// `ConvolutionBackwardInput::backward` (`:390-449`, kernel `:146-189`): `dX +=` gather form of col2im (deterministic).
+pub(crate) struct ConvolutionBackwardInput<D>
+where
+    D: Dimension,
+{
+    kernel_data: Shared<HipArray<D>>,
+    input_gradient: Rc<Gradient<HipArray<D>, D>>,
+    gradient: Rc<Gradient<HipArray<D>, D>>,
+    stride: Vec<i32>,
+    dilation: Vec<i32>,
+    groups: i32,
+}
+
+impl<D> Backward for ConvolutionBackwardInput<D>
+where
+    D: Dimension,
+{
+    fn backward(&self) {
+        let (g, w) = (self.gradient.borrow(), self.kernel_data.borrow());
+        let mut dx = self.input_gradient.borrow_mut();
+        let (xs, ws) = (dx.shape_c(), w.shape_c());
+        ffi::check(unsafe {
+            ffi::nk_conv_bwd_input(g.device().as_raw(), xs.len() as i32 - 2, dx.as_mut_ptr(), xs.as_ptr(), g.as_ptr(), w.as_ptr(), ws.as_ptr(),
+                                   self.stride.as_ptr(), self.dilation.as_ptr(), self.groups)
+        });
+    }
+}
+
+/// `ConvolutionBackwardKernel::backward` (`:451-510`, kernel `:191-226`): `dW +=`, a reduction over (sample, position).
+pub(crate) struct ConvolutionBackwardKernel<D>
+where
+    D: Dimension,
+{
+    input_data: Shared<HipArray<D>>,
+    kernel_gradient: Rc<Gradient<HipArray<D>, D>>,
+    gradient: Rc<Gradient<HipArray<D>, D>>,
+    stride: Vec<i32>,
+    dilation: Vec<i32>,
+    groups: i32,
+}
+
+impl<D> Backward for ConvolutionBackwardKernel<D>
+where
+    D: Dimension,
+{
+    fn backward(&self) {
+        let (g, x) = (self.gradient.borrow(), self.input_data.borrow());
+        let mut dw = self.kernel_gradient.borrow_mut();
+        let (ws, xs) = (dw.shape_c(), x.shape_c());
+        ffi::check(unsafe {
+            ffi::nk_conv_bwd_kernel(g.device().as_raw(), xs.len() as i32 - 2, dw.as_mut_ptr(), ws.as_ptr(), g.as_ptr(), x.as_ptr(), xs.as_ptr(),
+                                    self.stride.as_ptr(), self.dilation.as_ptr(), self.groups)
+        });
+    }
+}

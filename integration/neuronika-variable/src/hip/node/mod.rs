@@ -1,11 +1,21 @@
 //! Node bodies: each `forward()` / `backward()` is one call of the C ABI (`include/neuronika_hip.h` cites, per entry
 //! point, the reference method it replaces).  The structs hold the same `Shared` operand / output handles as the
-//! reference's ndarray nodes (`node/*/mod.rs`), so graph construction code is unchanged.
+//! reference's ndarray nodes (`node/*/mod.rs`), so graph construction code is unchanged.  Written here: the nodes of
+//! the BASELINE configurations (MatMul / MatMulT, Convolution, broadcast binaries, ReLU, Softmax, Dropout, Sum,
+//! SquaredError); the remaining ones follow the same two-line pattern.
 mod binary_op;
+mod convolution;
+mod matrix_matrix_mul;
 mod matrix_matrix_mul_t;
+mod pointwise;
+mod reduction;
 
 pub(crate) use binary_op::*;
+pub(crate) use convolution::*;
+pub(crate) use matrix_matrix_mul::*;
 pub(crate) use matrix_matrix_mul_t::*;
+pub(crate) use pointwise::*;
+pub(crate) use reduction::*;
 
 use crate::autograd::Backward;
 

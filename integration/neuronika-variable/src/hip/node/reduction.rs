@@ -1,0 +1,75 @@
+use std::rc::Rc;
+
+use ndarray::{Dimension, Ix0};
+
+use crate::{
+    autograd::{Backward, Forward},
+    gradient::Gradient,
+    hip::{ffi, hiparray::HipArray},
+    utils::Shared,
+    Reduction,
+};
+
+/// `Sum::forward` (`node/sum/mod.rs:28-35`): full reduction to a scalar (two-pass, fixed order: deterministic).
+pub(crate) struct Sum<D: Dimension> {
+    operand_data: Shared<HipArray<D>>,
+    data: Shared<HipArray<Ix0>>,
+}
+
+impl<D: Dimension> Forward for Sum<D> {
+    fn forward(&self) {
+        let x = self.operand_data.borrow();
+        let mut out = self.data.borrow_mut();
+        ffi::check(unsafe { ffi::nk_sum_fwd(x.device().as_raw(), x.as_ptr(), x.len(), out.as_mut_ptr()) });
+    }
+}
+
+/// `SumBackward::backward` (`:60-67`): `dx += g`.
+pub(crate) struct SumBackward<D: Dimension> {
+    operand_gradient: Rc<Gradient<HipArray<D>, D>>,
+    gradient: Rc<Gradient<HipArray<Ix0>, Ix0>>,
+}
+
+impl<D: Dimension> Backward for SumBackward<D> {
+    fn backward(&self) {
+        let g = self.gradient.borrow();
+        let mut dx = self.operand_gradient.borrow_mut();
+        let n = dx.len();
+        ffi::check(unsafe { ffi::nk_sum_bwd(g.device().as_raw(), dx.as_mut_ptr(), n, g.as_ptr()) });
+    }
+}
+
+/// `SquaredError::forward` (`node/squared_error/mod.rs:42-59`): `sum((x - t)^2)` (/ n for `Reduction::Mean`).
+pub(crate) struct SquaredError<D: Dimension> {
+    input_data: Shared<HipArray<D>>,
+    target_data: Shared<HipArray<D>>,
+    data: Shared<HipArray<Ix0>>,
+    reduction: Reduction,
+}
+
+impl<D: Dimension> Forward for SquaredError<D> {
+    fn forward(&self) {
+        let (x, t) = (self.input_data.borrow(), self.target_data.borrow());
+        let mut out = self.data.borrow_mut();
+        let red = matches!(self.reduction, Reduction::Mean) as i32;
+        ffi::check(unsafe { ffi::nk_mse_fwd(x.device().as_raw(), x.as_ptr(), t.as_ptr(), x.len(), red, out.as_mut_ptr()) });
+    }
+}
+
+/// `SquaredErrorBackward::backward` (`:94-123`): `dx += 2 (x - t) g (/ n)`.
+pub(crate) struct SquaredErrorBackward<D: Dimension> {
+    input_data: Shared<HipArray<D>>,
+    target_data: Shared<HipArray<D>>,
+    input_gradient: Rc<Gradient<HipArray<D>, D>>,
+    gradient: Rc<Gradient<HipArray<Ix0>, Ix0>>,
+    reduction: Reduction,
+}
+
+impl<D: Dimension> Backward for SquaredErrorBackward<D> {
+    fn backward(&self) {
+        let (g, x, t) = (self.gradient.borrow(), self.input_data.borrow(), self.target_data.borrow());
+        let mut dx = self.input_gradient.borrow_mut();
+        let red = matches!(self.reduction, Reduction::Mean) as i32;
+        ffi::check(unsafe { ffi::nk_mse_bwd(g.device().as_raw(), dx.as_mut_ptr(), g.as_ptr(), x.as_ptr(), t.as_ptr(), x.len(), red) });
+    }
+}

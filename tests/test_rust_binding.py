@@ -71,6 +71,8 @@ def test_handwritten_modules_call_the_abi_consistently():
                 calls += 1
     assert calls >= 20
     # the module list names files that exist
-    mods = re.findall(r"^mod (\w+);", open(os.path.join(HIP, "mod.rs")).read(), re.M)
-    for mname in mods:
-        assert os.path.exists(os.path.join(HIP, mname + ".rs")) or os.path.exists(os.path.join(HIP, mname, "mod.rs")), mname
+    for d in (HIP, os.path.join(HIP, "node")):
+        mods = re.findall(r"^mod (\w+);", open(os.path.join(d, "mod.rs")).read(), re.M)
+        assert mods
+        for mname in mods:
+            assert os.path.exists(os.path.join(d, mname + ".rs")) or os.path.exists(os.path.join(d, mname, "mod.rs")), mname
