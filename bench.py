@@ -440,6 +440,7 @@ def run_mha(a, dist):
     tdev = t.Device(dist.local)
     cdev = capi.Device(handle=tdev.raw())
     B, S, d, H = 32, 1024, 1024, 16
+    t.manual_seed(7 + dist.rank)                     # Philox key of the dropout node: per-rank, so shards draw different masks
     mha = t.nn.MultiheadAttention(tdev, d, H, 0.1, 1)
     if "NK_MHA_STRIDED" in os.environ:               # A/B aid: heads addressed in place (1) or split/merge copies (0)
         mha.strided_heads = os.environ["NK_MHA_STRIDED"] == "1"
