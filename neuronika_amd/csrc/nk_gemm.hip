@@ -423,13 +423,14 @@ static int gemm_impl(nk_device* dev, int transA, int transB, int M, int N, int K
     // (benchmarks/ab_force.py with NK_GEMM_FORCE's sixth field; U[0,1) operands):
     //   64x64 tiles (a k-tile is only 16 MFMAs per wave, less than an L2 round trip): from 8 k-tiles on, every layout
     //     (1024^3: NN 80.8 -> 84, NT 81.7 -> 88, TN 78.9 -> 83 TFLOP/s);
-    //   NN (both operands row-major: the B tile is read k-major, its loads land last): from 16 k-tiles on
-    //     (4096^3 116 -> 137 without / with; 4096 x 4096 x 1024 112 -> 122; 32768 x 1024 x 1024 109 -> 118);
+    //   NN (both operands row-major: the B tile is read k-major, its loads land last): from 32 k-tiles on
+    //     (4096^3 116 -> 137 without / with; 4096 x 4096 x 1024 112 -> 122; 32768 x 1024 x 1024 109 -> 118; but the
+    //     convolution-like 128 x 401408 x 576, 18 k-tiles and a single tile row, LOSES 7 %: 110 -> 103);
     //   NT / TN / TT: from 48 k-tiles on (TN 4096^3 133.6 -> 137.1; NT loses 3 % below that: 119 -> 116 at K = 1024).
     // C4 step, same box: 8.75 ms with the look-ahead off, 8.50 with these rules.  (What a k-tile of 64x64 needs is time
     // for its loads, not more waves: a 512-thread variant with two wave groups on alternating k-tiles of one tile -
     // two waves per SIMD where 1024^3 has one - measured 78.7 vs 80.1 TFLOP/s and was dropped.)
-    const int pf2_rule = ti * tj == 1 ? 8 : ((!transA && !transB) ? 16 : PF2_MIN_KTILES);
+    const int pf2_rule = ti * tj == 1 ? 8 : ((!transA && !transB) ? 32 : PF2_MIN_KTILES);
     p.pf2_min = force_pf2 > 0 ? force_pf2 : pf2_rule;
     // attention's P . V / P^T . dO / dS . K / dS^T . Q: a >= 1 GB operand that is read exactly once next to a small,
     // re-read one - streaming (`nt`) loads for the former keep the latter in L2 (context 822 -> 797 us, dV 778 -> 762;
