@@ -405,6 +405,7 @@ static int gemm_impl(nk_device* dev, int transA, int transB, int M, int N, int K
     if (splits < 1) splits = 1;
     p.splits = splits;
     p.k_per_split = kts * BK;
+    const int pf2_rule_for_chunk = ti * tj == 1 ? 8 : ((!transA && !transB) ? 32 : PF2_MIN_KTILES);
     // Tiles per block: a short reduction (kts k-tiles of ~3.9 us) cannot amortise the ~7 us a block spends being
     // dispatched, waiting for its first loads and draining its stores, so a block takes enough consecutive tiles of the
     // sequence for ~16 k-tiles of work - as long as the grid keeps at least four waves of resident blocks.
@@ -414,8 +415,8 @@ static int gemm_impl(nk_device* dev, int transA, int transB, int M, int N, int K
         const long long cap = ntiles * splits * nbatch / (4 * slots);
         if (c > cap) c = cap;
         if (c > ntiles) c = ntiles;
-        if (force_chunk > 0) c = force_chunk;
         if (c < 1 || kts >= 8) c = 1;  // (8 = the smallest look-ahead threshold: the two loops are alternatives)
+        if (force_chunk > 0 && kts < (force_pf2 > 0 ? force_pf2 : pf2_rule_for_chunk)) c = force_chunk;
         p.chunk = (int)c;
     }
     p.group_m = force_group > 0 ? force_group : 8;
