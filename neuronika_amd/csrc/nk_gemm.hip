@@ -41,7 +41,6 @@ struct GemmArgs {
     int chunk;        // >= 1 tiles per block (1: one tile per block, the classic grid)
     int group_m;      // tile order: column-major inside groups of `group_m` tile rows (1: row-major, tn fastest)
     int pf2_min;      // reductions of at least this many k-tiles take the two-k-tile look-ahead loop
-    int stream_a;     // A is read once and dwarfs the caches while B is small and re-read (attention's P . V): `nt` loads for A
 };
 
 // C tile <- accumulators (or the split's slab).  Every load (bias, old C) is issued first and folded into the accumulators
@@ -128,7 +127,6 @@ __global__ __launch_bounds__(NT, (min_waves<TI, TJ, !TA && TB>())) void sgemm_ke
     TileLoader<BKC, BN> lb;
     la.init(A, p.lda, m0, kbeg, p.M, kend, t);
     lb.init(B, p.ldb, n0, kbeg, p.N, kend, t);
-    la.stream = p.stream_a;
     // Same-box A/B at 4096^3 (benchmarks/ab_gemm.py): NT +2.9 %, NN +1.2 %, TN -1.0 % (its A operand is read k-major,
     // the loads land early anyway); short reductions lose to the longer prologue (NT 4096x3072x1024: -2 %).  So: row-major
     // A only, aligned problems only (the guarded loader's state does not fit next to P and Q), at least 48 k-tiles.
@@ -433,10 +431,6 @@ static int gemm_impl(nk_device* dev, int transA, int transB, int M, int N, int K
     // two waves per SIMD where 1024^3 has one - measured 78.7 vs 80.1 TFLOP/s and was dropped.)
     const int pf2_rule = ti * tj == 1 ? 8 : ((!transA && !transB) ? 32 : PF2_MIN_KTILES);
     p.pf2_min = force_pf2 > 0 ? force_pf2 : pf2_rule;
-    // attention's P . V / P^T . dO / dS . K / dS^T . Q: a >= 1 GB operand that is read exactly once next to a small,
-    // re-read one - streaming (`nt`) loads for the former keep the latter in L2 (context 822 -> 797 us, dV 778 -> 762;
-    // C5 step 14.07 - 14.17 -> 14.00 ms in a same-box A/B on a slow box)
-    p.stream_a = (size_t)M * K * nbatch * sizeof(float) >= (size_t(1) << 30) && (size_t)N * K * sizeof(float) <= (size_t(4) << 20);
     if (p.splits > 1) {
         void* ws = nullptr;
         int rc = nk_workspace(dev, (size_t)p.splits * nbatch * M * N * sizeof(float), &ws);

@@ -94,7 +94,6 @@ struct TileLoader {
     long long ld;
     int row0, rows, kend, k0;
     bool interior;  // every row of the tile exists (block-uniform): whole k-tiles take unaligned 16-byte loads
-    bool stream = false;  // this operand is read once and is far larger than the caches: `global_load_dwordx4 ... nt`
 
     __device__ __forceinline__ void init(const float* X_, long long ld_, int row0_, int k0_, int rows_,
                                          int kend_, int t) {
@@ -126,11 +125,11 @@ struct TileLoader {
     __device__ __forceinline__ Stage<R / 32> load(int t) {
         Stage<R / 32> r;
         if (ALIGNED) {
-            r.v0 = nk_load_stream(reinterpret_cast<const float4*>(base + o0), stream);
-            r.v1 = nk_load_stream(reinterpret_cast<const float4*>(base + o1), stream);
+            r.v0 = *reinterpret_cast<const float4*>(base + o0);
+            r.v1 = *reinterpret_cast<const float4*>(base + o1);
             if constexpr (R == 128) {
-                r.v2 = nk_load_stream(reinterpret_cast<const float4*>(base + o2), stream);
-                r.v3 = nk_load_stream(reinterpret_cast<const float4*>(base + o3), stream);
+                r.v2 = *reinterpret_cast<const float4*>(base + o2);
+                r.v3 = *reinterpret_cast<const float4*>(base + o3);
             }
             base += kstep;
         } else if (interior && k0 + BK <= kend) {
