@@ -126,8 +126,12 @@ def timed_steps(dist, tdev, cdev, step, steps, warmup):
     dt = time.perf_counter() - t0
     gemm = cdev.profile_end(capi.KERNEL_SGEMM)
     conv = cdev.profile_end(capi.KERNEL_CONV)
+    EXTRA_STATS["attention"] = cdev.profile_end(capi.KERNEL_ATTENTION)
     ev_ms = e0.elapsed_ms(e1)
     return dist.max(dt), ev_ms, gemm, conv
+
+
+EXTRA_STATS = {}  # kernel classes only one workload has (the fused attention core of C5), from the last timed_steps()
 
 
 def read_traffic(kernel):
@@ -444,6 +448,8 @@ def run_mha(a, dist):
     mha = t.nn.MultiheadAttention(tdev, d, H, 0.1, 1)
     if "NK_MHA_STRIDED" in os.environ:               # A/B aid: heads addressed in place (1) or split/merge copies (0)
         mha.strided_heads = os.environ["NK_MHA_STRIDED"] == "1"
+    if "NK_MHA_CORE" in os.environ:                  # A/B aid: fused attention kernels (1) or GEMM -> row kernel -> GEMM (0)
+        mha.fused_core = os.environ["NK_MHA_CORE"] == "1"
     X = t.from_ndarray(tdev, np.random.default_rng(0).random((B * S, d), dtype=np.float32)).requires_grad()
     G = t.from_ndarray(tdev, np.random.default_rng(5).random((B * S, d), dtype=np.float32))
     y = mha.forward(X, B)
@@ -465,6 +471,10 @@ def run_mha(a, dist):
            "config": {"workload": "C5: MHA d_model=1024 heads=16 seq=1024 batch=32 dropout=0.1, composed from reference ops"},
            "roofline": roofline_mfma(gemm, "sgemm_kernel (projections, scores, context and their gradients)", read_traffic("mha_gemm")),
            "gemm_share_of_step": round(gemm[1] / ev_ms, 4)}
+    att = EXTRA_STATS.get("attention")
+    if att and att[0]:   # nk_attention_fwd / nk_attention_bwd: 4*B*H*S*S*dh flop each (two MFMA products per score tile)
+        res["attention_core"] = dict(roofline_mfma(att, "attention_kernel (scores -> softmax -> dropout -> context, and its backward)", read_traffic("attention")),
+                                     share_of_step=round(att[1] / ev_ms, 4))
     if dist.world == 1 and not a.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline_mha(2, S, d, H, 0.1)
     return res

@@ -724,6 +724,58 @@ struct HeadsContextBwd : Backward {
     void targets(std::vector<const Gradient*>& out) const override { out.push_back(dp.get()); out.push_back(dv.get()); }
 };
 
+// heads_scores -> attention_probs -> heads_context as one node (nk_attention_fwd / nk_attention_bwd)
+struct HeadsAttentionFwd : Forward {
+    HeadsGeom hg;
+    Shared<HipArray> q, k, v, scores, stats, o;
+    float scale;
+    double p;
+    Shared<bool> status;
+    uint64_t seed;
+    Shared<uint64_t> calls, last_offset;  // as AttnProbsFwd: the backward node regenerates the mask of the LAST forward
+    void forward() const override {
+        const uint64_t offset = (*calls) * ((scores->len() + 3) / 4);
+        ++(*calls);
+        *last_offset = offset;
+        check(nk_attention_fwd(D(q), q->ptr(), k->ptr(), v->ptr(), scores->ptr(), stats->ptr(), o->ptr(), hg.B, hg.S, hg.H, hg.dh,
+                               scale, p, *status ? 1 : 0, seed, offset));
+    }
+};
+struct HeadsAttentionBwd : Backward {
+    HeadsGeom hg;
+    Shared<HipArray> q, k, v, scores, stats, o;
+    Shared<HipArray> ds, dropped;  // (B*H, S, S) scratch written by the first kernel, read by the dK / dV products
+    Shared<Gradient> dq, dk, dv, g;
+    float scale;
+    double p;
+    Shared<bool> status;
+    uint64_t seed;
+    Shared<uint64_t> last_offset;
+    void backward() const override {
+        const HipArray& G = g->borrow();  // dO, flat layout
+        nk_device* dev = D(q);
+        float beta;
+        {   // dS, Pd, and dQ_bh += dS_bh . K_bh
+            float* d = first_write(dq, beta);
+            check(nk_attention_bwd(dev, d, ds->ptr(), dropped->ptr(), G.ptr(), o->ptr(), scores->ptr(), stats->ptr(), k->ptr(), v->ptr(),
+                                   hg.B, hg.S, hg.H, hg.dh, scale, p, *status ? 1 : 0, seed, *last_offset, beta == 0.f ? 1 : 0));
+        }
+        {   // dK_bh += dS_bh^T . Q_bh
+            float* d = first_write(dk, beta);
+            check(nk_sgemm_batched(dev, 1, 0, hg.S, hg.dh, hg.S, 1.f, ds->ptr(), hg.S, hg.po(), hg.pi(), q->ptr(), hg.d(), hg.so(), hg.dh, beta,
+                                   d, hg.d(), hg.so(), hg.dh, hg.B, hg.H));
+        }
+        {   // dV_bh += Pd_bh^T . dO_bh
+            float* d = first_write(dv, beta);
+            check(nk_sgemm_batched(dev, 1, 0, hg.S, hg.dh, hg.S, 1.f, dropped->ptr(), hg.S, hg.po(), hg.pi(), G.ptr(), hg.d(), hg.so(), hg.dh, beta,
+                                   d, hg.d(), hg.so(), hg.dh, hg.B, hg.H));
+        }
+    }
+    void targets(std::vector<const Gradient*>& out) const override {
+        out.push_back(dq.get()); out.push_back(dk.get()); out.push_back(dv.get());
+    }
+};
+
 // Scalar criteria: node/{absolute_error,bce,bce_with_logits,kldiv,nll}/mod.rs.  kind -1 = NLL.
 struct LossFwd : Forward {
     int kind;
@@ -1144,6 +1196,45 @@ VarDiff VarDiff::heads_context(const VarDiff& values, int B, int S, int H, int d
     auto g = std::make_shared<Gradient>(out.device(), out.shape());
     auto bw = std::make_shared<HeadsContextBwd>();
     bw->hg = {B, S, H, dh}; bw->p = var.data; bw->v = values.var.data; bw->dp = grad; bw->dv = values.grad; bw->g = g;
+    return VarDiff::node(std::move(out), g, entry(bw, g), std::move(h));
+}
+bool Var::attention_core_supported(int S, int dh, double p) { return nk_attention_supported(S, dh, p, 1) != 0; }
+Var Var::heads_attention(const Var& keys, const Var& values, int B, int S, int H, int dh, float scale, double p,
+                         Shared<bool> status) const {
+    if (!(p >= 0.0 && p <= 1.0)) panic("Wrong probability received: " + std::to_string(p) + ".");
+    check_heads(shape(), {}, B, S, H, dh, false);
+    check_heads(keys.shape(), {}, B, S, H, dh, false);
+    check_heads(values.shape(), {}, B, S, H, dh, false);
+    if (!attention_core_supported(S, dh, p)) panic("heads_attention: the fused kernels take dh == 64, S % 32 == 0 and p < 1");
+    History<ForwardEntry> h = history;
+    h.merge(keys.history);
+    h.merge(values.history);
+    auto op = std::make_shared<HeadsAttentionFwd>();
+    op->hg = {B, S, H, dh}; op->q = data; op->k = keys.data; op->v = values.data;
+    op->scores = zeros_like(data, Shape{B * H, S, S});
+    op->stats = zeros_like(data, Shape{B * H, S, 2});
+    op->o = zeros_like(data, Shape{B * S, H * dh});
+    op->scale = scale; op->p = p; op->status = std::move(status);
+    op->seed = next_node_seed();
+    op->calls = std::make_shared<uint64_t>(0);
+    op->last_offset = std::make_shared<uint64_t>(0);
+    auto y = op->o;
+    return Var::node(y, op, std::move(h));
+}
+VarDiff VarDiff::heads_attention(const VarDiff& keys, const VarDiff& values, int B, int S, int H, int dh, float scale, double p,
+                                 Shared<bool> status) const {
+    Var out = var.heads_attention(keys.var, values.var, B, S, H, dh, scale, p, status);
+    auto fwd = std::dynamic_pointer_cast<HeadsAttentionFwd>(out.history.to_vec().back().op);
+    History<BackwardEntry> h = history;
+    h.merge(keys.history);
+    h.merge(values.history);
+    auto g = std::make_shared<Gradient>(out.device(), out.shape());
+    auto bw = std::make_shared<HeadsAttentionBwd>();
+    bw->hg = fwd->hg; bw->q = fwd->q; bw->k = fwd->k; bw->v = fwd->v; bw->scores = fwd->scores; bw->stats = fwd->stats; bw->o = fwd->o;
+    bw->ds = zeros_like(fwd->scores, fwd->scores->shape());
+    bw->dropped = zeros_like(fwd->scores, fwd->scores->shape());
+    bw->dq = grad; bw->dk = keys.grad; bw->dv = values.grad; bw->g = g;
+    bw->scale = scale; bw->p = p; bw->status = status; bw->seed = fwd->seed; bw->last_offset = fwd->last_offset;
     return VarDiff::node(std::move(out), g, entry(bw, g), std::move(h));
 }
 Var Var::bmm(const Var& rhs) const { return matmul_var(2, *this, rhs); }
@@ -1712,6 +1803,8 @@ VarDiff MultiheadAttention::forward(const VarDiff& x, int batch) const {
     const float scale = 1.f / std::sqrt((float)dh);
     if (strided_heads && dh % 4 == 0) {  // attention GEMMs address the heads inside the projection layout: no copies
         const VarDiff Qf = q.forward(x), Kf = k.forward(x), Vf = v.forward(x);
+        if (fused && fused_core && Var::attention_core_supported(S, dh, drop.p))
+            return o.forward(Qf.heads_attention(Kf, Vf, batch, S, heads, dh, scale, drop.p, drop.status));
         const VarDiff scores = Qf.heads_scores(Kf, batch, S, heads, dh);
         const VarDiff P = (fused && S % 4 == 0 && S <= 2048) ? scores.attention_probs(scale, drop.p, drop.status)
                                                              : drop.forward((scores * scale).softmax(2));

@@ -317,6 +317,12 @@ class Var {
     // the attention probabilities as ONE node (same values, one pass over the score tensor)
     // (store_probs = false: the backward pass recomputes the probabilities from the scores, bit-identically)
     Var attention_probs(float scale, double p, Shared<bool> status, bool store_probs = false) const;
+    // the whole per-(sample, head) chain heads_scores -> attention_probs -> heads_context as ONE node on the fused
+    // attention kernels (nk_attention_fwd): self = Q, all three operands (B*S, H*dh) -> (B*S, H*dh).  The score tile
+    // stays on chip between the two products; see attention_core_supported() for the shapes it takes.
+    Var heads_attention(const Var& keys, const Var& values, int B, int S, int H, int dh, float scale, double p,
+                        Shared<bool> status) const;
+    static bool attention_core_supported(int S, int dh, double p);
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -399,6 +405,8 @@ class VarDiff {
     VarDiff heads_scores(const VarDiff& keys, int B, int S, int H, int dh) const;
     VarDiff heads_context(const VarDiff& values, int B, int S, int H, int dh) const;
     VarDiff attention_probs(float scale, double p, Shared<bool> status, bool store_probs = false) const;
+    VarDiff heads_attention(const VarDiff& keys, const VarDiff& values, int B, int S, int H, int dh, float scale, double p,
+                            Shared<bool> status) const;
 };
 
 // `Add/Sub/Mul/Div` with NumPy broadcasting, all four differentiability combinations
@@ -536,6 +544,7 @@ struct MultiheadAttention {
     Dropout drop;
     bool fused = true;  // scale + softmax + dropout as one node (false: three reference nodes)
     bool strided_heads = true;  // attention GEMMs read Q/K/V and write O in the projection layout (false: split/merge copies)
+    bool fused_core = true;     // scores -> probabilities -> context as one node on the fused attention kernels (dh = 64, S % 32 = 0)
     MultiheadAttention(DevicePtr dev, int d_model, int heads, double p, uint64_t seed);
     VarDiff forward(const VarDiff& x, int batch) const;  // x: (batch*seq, d_model)
 };

@@ -124,7 +124,7 @@ int nk_graph_destroy(nk_graph* graph);
  * synchronises and returns, for one kernel class, the number of launches, the sum of their
  * durations and the algorithmic flop they performed (2*M*N*K per GEMM; 2*N*Cout*L*K per conv
  * pass). */
-enum nk_kernel_class { NK_KERNEL_SGEMM = 0, NK_KERNEL_CONV = 1 };
+enum nk_kernel_class { NK_KERNEL_SGEMM = 0, NK_KERNEL_CONV = 1, NK_KERNEL_ATTENTION = 2 };
 int nk_profile_begin(nk_device* dev);
 int nk_profile_end(nk_device* dev, int kernel_class, int* launches, double* total_ms, double* total_flop);
 
@@ -390,6 +390,27 @@ int nk_scale_softmax_dropout_bwd_from_scores(nk_device* dev, float* d_scores, co
                                              const float* scores, const float* noise, long long rows,
                                              int L, float scale, double p, int train, uint64_t seed,
                                              uint64_t offset, int assign);
+
+/* ------------------------------------------------------------------ fused attention core ---
+ * The composed multi-head attention's per-(sample, head) chain in one kernel per direction (SURVEY.md 8a note; the
+ * composition is MatrixMatrixMulT node/matrix_matrix_mul_t/mod.rs:31-41, Multiplication node/multiplication/mod.rs:39-50,
+ * Softmax node/softmax/mod.rs:37-53, Dropout node/dropout/mod.rs:53-79, MatrixMatrixMul node/matrix_matrix_mul/mod.rs:31-41):
+ *   S_bh = Q_bh.K_bh^T ; P = softmax(S*scale, axis 1) ; Pd = dropout(P) ; O_bh = Pd.V_bh
+ * Q, K, V, O, dO, dQ are the (B*S) x (H*dh) projection layout (head h = columns h*dh .. h*dh+dh-1, sample b = rows
+ * b*S ..); scores / dS / dropped are (B*H, S, S); stats is (B*H, S, 2) = row max of the scaled scores, 1 / row sum.
+ * The score tile stays on chip between the two products (online softmax forward, recomputed probabilities backward).
+ * Dropout mask: the Philox stream of nk_scale_softmax_dropout_fwd (same seed / offset -> same mask).
+ * nk_attention_supported: dh == 64, S % 32 == 0, not (train and p == 1); callers fall back to the node-by-node path. */
+int nk_attention_supported(int S, int dh, double p, int train);
+/* forward: writes the raw scores (for the backward pass), the row statistics and O */
+int nk_attention_fwd(nk_device* dev, const float* Q, const float* K, const float* V, float* scores, float* stats, float* O,
+                     int B, int S, int H, int dh, float scale, double p, int train, uint64_t seed, uint64_t offset);
+/* backward, first part: dS and Pd are WRITTEN (scratch the caller owns; dK_bh += dS_bh^T.Q_bh and dV_bh += Pd_bh^T.dO_bh
+ * are nk_sgemm_batched calls on them), dQ_bh (+)= dS_bh.K_bh (`assign_dq` != 0: first write).
+ * DropoutBackward multiplies by the 0/1 mask only (node/dropout/mod.rs:113-128), SoftmaxBackward node/softmax/mod.rs:84-104. */
+int nk_attention_bwd(nk_device* dev, float* dQ, float* dS, float* dropped, const float* dO, const float* O,
+                     const float* scores, const float* stats, const float* K, const float* V, int B, int S, int H, int dh,
+                     float scale, double p, int train, uint64_t seed, uint64_t offset, int assign_dq);
 
 /* ------------------------------------------------------------------ dropout ------------ */
 /* Dropout::forward node/dropout/mod.rs:53-79.  train && 0<p<1: noise ~ Bernoulli(1-p) in

@@ -1,0 +1,393 @@
+// Fused attention core of the composed multi-head attention (note below the table: the module is a
+// composition of MatrixMatrixMulT a-2, Multiplication a-4, Softmax a-7, Dropout a-8, MatrixMatrixMul a-1 per (sample, head)):
+//
+//   forward   S = Q_bh . K_bh^T ;  P = softmax(S * scale, axis 1) ;  Pd = dropout(P) ;  O_bh = Pd . V_bh
+//   backward  dPd = dO_bh . V_bh^T ;  dP = dPd * noise            (DropoutBackward, node/dropout/mod.rs:113-128: mask only)
+//             dS  = P * (dP - sum_k dP * P) * scale               (SoftmaxBackward :84-104, MultiplicationBackwardLeft)
+//             dQ_bh += dS . K_bh          [dK_bh += dS^T . Q_bh and dV_bh += Pd^T . dO_bh stay batched GEMMs on dS / Pd]
+//
+// Why one kernel per direction: composed from GEMMs and row kernels the (B*H, S, S) tensors cross HBM 11 times per step
+// (2.1 GB each at C5) and the K = 64 GEMMs that write them run at half the MFMA rate because 2.1 GB of C stores queue
+// behind 64-deep reductions.  Here a block owns 128 queries of one (sample, head), walks the keys in tiles of 32 and keeps
+// the 32 x 32 score tile ON CHIP between the two MFMA products; the big tensors cross HBM 6 times (forward writes S;
+// backward reads S, writes dS and Pd; the two remaining GEMMs read dS and Pd).
+//
+// Layout trick (what keeps the score tile in registers): the tile is computed TRANSPOSED, C[key][query] = X1 . Bq^T, so a
+// lane owns one query (column = lane & 31) and 16 keys of it.  Row statistics (max, sum, the backward dot) are then
+// per-lane scalars plus one cross-half shuffle, and the C registers are directly the B operand of the second product
+// out^T[dh][query] = X2^T . C (the MFMA wants B[k][n] with n = lane & 31, k chosen by the lane half: exactly what C holds
+// when MFMA step e pairs key 16*0 + e with key 16*1 + e).  Rows of the MFMA tile are permuted so that a lane's 16
+// registers are 16 CONSECUTIVE keys: the Philox counter of the existing row kernels (4 consecutive elements per draw)
+// and 64-byte runs towards HBM fall out of that.
+//
+// The forward uses the online softmax (running max / sum, the out accumulator rescaled when the max moves) and stores the
+// final row max and 1 / sum; the backward recomputes P = exp(S * scale - max) / sum from the stored scores with those.
+// Against the node-by-node composition this changes the order of the row sum and replaces two divisions by a reciprocal
+// and a product - inside the f32 tolerance of SURVEY.md 8c (ii), checked against the oracle, not bit-equal to the
+// three-node path.
+#include <cmath>
+#include <cstdlib>
+
+#include "nk_mma.h"
+
+namespace {
+
+using nkmma::f32x16;
+
+constexpr int A_DH = 64;    // head dimension the kernels are built for (2 MFMA column tiles, 8 b128 k-groups)
+constexpr int A_NT = 256;   // 4 waves, 32 queries each
+constexpr int A_QB = 128;   // queries per block
+constexpr int X1_LD = 68;   // pass-1 operand image [mfma row][dh], padded: b128 fragment reads of 16 rows hit 16 distinct slots
+constexpr int X2_LD = 64;   // pass-2 operand image [key][dh rotated by 32 for keys >= 16]: the two lane halves read disjoint banks
+constexpr int SCR_LD = 36;  // per-wave 32 x 32 transposition scratch
+constexpr float A_F32_MIN = -3.40282347e+38f;
+
+struct AttnArgs {
+    const float* x1;   // pass-1 operand, flat (B*S) x (H*dh) layout: forward K, backward V
+    const float* x2;   // pass-2 operand:                               forward V, backward K
+    const float* bq;   // per-query operand:                            forward Q, backward dO
+    const float* ctx;  // backward only: the forward output O (for sum_k dP * P = keep * dO . O)
+    float* out;        // forward O, backward dQ
+    float* scores;     // (B*H, S, S) raw scores: written forward, read backward
+    float* ds;         // backward: dS
+    float* dropped;    // backward: Pd
+    float* stats;      // (B*H, S, 2): row max of the scaled scores, 1 / row sum of exp
+    int S, H, ld, nqb, ntile;
+    float scale, keep, dscale;
+    unsigned keep_lt;  // Philox word w is kept iff w < keep_lt  (== keep_bit(w, keep): (w >> 8) * 2^-24 < keep, exactly)
+    unsigned long long seed, offset;
+    int assign;        // backward: dQ = (1) or += (0)
+};
+
+// Wave-private LDS round trip: every lane's ds_write is issued before any lane's ds_read (LDS is in-order per wave); the
+// fences keep the compiler from reordering across the hand-over.
+__device__ __forceinline__ void wave_lds_handover() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// registers (lane = query q, half h, 16 consecutive keys 16h..16h+15) -> 32 x 32 tile of a row-major (.., S) tensor, as
+// 128-byte row segments (8 lanes x 16 B) instead of 64 scattered 16-byte pieces per store instruction
+__device__ __forceinline__ void tile_store(float* scrw, const float (&v)[16], float* g /* &T[row0][kt*32] */, int S, int lane) {
+    const int q = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+        *reinterpret_cast<float4*>(&scrw[q * SCR_LD + 16 * h + 4 * c]) = make_float4(v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]);
+    wave_lds_handover();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = 8 * i + (lane >> 3), c = 4 * (lane & 7);
+        const float4 t = *reinterpret_cast<const float4*>(&scrw[r * SCR_LD + c]);
+        nk_store_stream(reinterpret_cast<float4*>(g + (long long)r * S + c), t);
+    }
+    wave_lds_handover();
+}
+
+// FULL: S is a multiple of 128, every wave of every block has queries.  Not a micro-optimisation: with a run-time `on`
+// the loop body sits under a branch, the compiler's wait-count bookkeeping merges the two paths at the join and waits for
+// ALL outstanding vector memory operations (the tile stores just issued included) before the staged tile may go to LDS;
+// with the branch gone it waits for exactly the staging loads and the stores drain under the next tile's MFMAs.
+template <bool BWD, bool MASKED, bool FULL, int OCC>
+__global__ __launch_bounds__(A_NT, OCC) void attention_kernel(const AttnArgs p) {
+    __shared__ __attribute__((aligned(16))) float x1s[2][32 * X1_LD];
+    __shared__ __attribute__((aligned(16))) float x2s[2][32 * X2_LD];
+    __shared__ __attribute__((aligned(16))) float scr[A_NT / 64][32 * SCR_LD];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int q = lane & 31, h = lane >> 5;
+    // blocks of one (sample, head) are consecutive in the sequence and one XCD takes a contiguous chunk of it: the 512 KB
+    // of K and V a head's blocks share stay in that XCD's L2
+    const int seq = nkmma::xcd_chunk(blockIdx.x, gridDim.x);
+    const int bh = seq / p.nqb, qb = seq % p.nqb;
+    const long long flat0 = (long long)(bh / p.H) * p.S * p.ld + (long long)(bh % p.H) * A_DH;
+    const int q0 = qb * A_QB + w * 32;
+    const bool on = FULL ? true : q0 < p.S;  // wave-uniform: S is a multiple of 32, not necessarily of 128
+    const float* x1 = p.x1 + flat0;
+    const float* x2 = p.x2 + flat0;
+
+    // ---- cooperative staging of one key tile (32 keys x 64 dh of each operand): 2 + 2 float4 per thread -------------
+    unsigned goff[2], s1[2], s2[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int idx = tid + A_NT * r, key = idx >> 4, c4 = idx & 15;
+        goff[r] = (unsigned)(key * p.ld + 4 * c4);
+        // mfma row i supplies key 16*((i>>2)&1) + 4*(i>>3) + (i&3); its inverse places key 16a + 4b + c in row 8b + 4a + c
+        s1[r] = (unsigned)((8 * ((key >> 2) & 3) + 4 * (key >> 4) + (key & 3)) * X1_LD + 4 * c4);
+        s2[r] = (unsigned)(key * X2_LD + ((4 * c4 + 32 * (key >> 4)) & 63));
+    }
+    // (named registers and macros, not arrays captured by lambdas: those end up in scratch memory)
+    float4 st10, st11, st20, st21;
+#define A_STAGE_LOAD(KT)                                                         \
+    do {                                                                         \
+        const long long t0_ = (long long)(KT) * 32 * p.ld;                       \
+        st10 = *reinterpret_cast<const float4*>(x1 + t0_ + goff[0]);            \
+        st11 = *reinterpret_cast<const float4*>(x1 + t0_ + goff[1]);            \
+        st20 = *reinterpret_cast<const float4*>(x2 + t0_ + goff[0]);            \
+        st21 = *reinterpret_cast<const float4*>(x2 + t0_ + goff[1]);            \
+    } while (0)
+#define A_STAGE_STORE(BUF)                                                       \
+    do {                                                                         \
+        *reinterpret_cast<float4*>(&x1s[BUF][s1[0]]) = st10;                     \
+        *reinterpret_cast<float4*>(&x1s[BUF][s1[1]]) = st11;                     \
+        *reinterpret_cast<float4*>(&x2s[BUF][s2[0]]) = st20;                     \
+        *reinterpret_cast<float4*>(&x2s[BUF][s2[1]]) = st21;                     \
+    } while (0)
+
+    // ---- per-query state ----------------------------------------------------------------------------------------
+    const int row = on ? q0 + q : 0;
+    float4 bq[8];  // B operand of pass 1: element (query, dh = 8j + 4h + c)
+    {
+        const float* b = p.bq + flat0 + (long long)row * p.ld + 4 * h;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bq[j] = *reinterpret_cast<const float4*>(b + 8 * j);
+    }
+    float m_run = A_F32_MIN, l_run = 0.f;  // forward: online softmax; backward: the stored row max and 1 / sum
+    float dot = 0.f;
+    if (BWD) {
+        const float2 ms = *reinterpret_cast<const float2*>(p.stats + ((long long)bh * p.S + row) * 2);
+        m_run = ms.x; l_run = ms.y;
+        const float* o = p.ctx + flat0 + (long long)row * p.ld + 4 * h;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float4 ov = *reinterpret_cast<const float4*>(o + 8 * j);
+            dot += (bq[j].x * ov.x + bq[j].y * ov.y) + (bq[j].z * ov.z + bq[j].w * ov.w);
+        }
+        dot += __shfl_xor(dot, 32, 64);
+        // sum_k dP_k P_k with dP = dPd * noise, while dO . O = sum_k dPd_k P_k noise_k / keep
+        if (MASKED) dot *= p.keep;
+    }
+    f32x16 o0, o1;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { o0[e] = 0.f; o1[e] = 0.f; }
+
+    const long long rowbase = ((long long)bh * p.S + (on ? q0 : 0)) * p.S;  // element index of (row q0, key 0) in the (B*H, S, S) tensors
+    const uint2 key = make_uint2((unsigned)p.seed, (unsigned)(p.seed >> 32));
+    const unsigned long long ctr0 = (unsigned long long)(rowbase + (long long)q * p.S) / 4 + 4 * h + p.offset;
+    float* scrw = scr[w];
+    // backward: the score tile of the NEXT iteration, in the coalesced load layout (lane -> rows 8i + lane/8, 16 B each)
+    float4 sn0, sn1, sn2, sn3;
+    const float* sload = p.scores + rowbase + (long long)(lane >> 3) * p.S + 4 * (lane & 7);
+#define A_SCORES_LOAD(KT)                                                                        \
+    do {                                                                                         \
+        sn0 = *reinterpret_cast<const float4*>(sload + (KT) * 32);                               \
+        sn1 = *reinterpret_cast<const float4*>(sload + (long long)8 * p.S + (KT) * 32);          \
+        sn2 = *reinterpret_cast<const float4*>(sload + (long long)16 * p.S + (KT) * 32);         \
+        sn3 = *reinterpret_cast<const float4*>(sload + (long long)24 * p.S + (KT) * 32);         \
+    } while (0)
+
+    A_STAGE_LOAD(0);
+    if (BWD && on) A_SCORES_LOAD(0);
+    A_STAGE_STORE(0);
+    // every prologue load has landed: without this the compiler's wait-count bookkeeping carries the per-query operand's
+    // loads into the loop and waits for the NEXT tile's staging loads in the middle of pass 1, every iteration
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    __syncthreads();
+
+    for (int kt = 0; kt < p.ntile; ++kt) {
+        const int cur = kt & 1;
+        const bool more = kt + 1 < p.ntile;
+        if (more) A_STAGE_LOAD(kt + 1);
+        if (on) {
+            float sv[16];
+            if (BWD) {  // score tile -> lane layout, then fetch the next one
+                float* sw = &scrw[(lane >> 3) * SCR_LD + 4 * (lane & 7)];
+                *reinterpret_cast<float4*>(sw) = sn0;
+                *reinterpret_cast<float4*>(sw + 8 * SCR_LD) = sn1;
+                *reinterpret_cast<float4*>(sw + 16 * SCR_LD) = sn2;
+                *reinterpret_cast<float4*>(sw + 24 * SCR_LD) = sn3;
+                wave_lds_handover();
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float4 t = *reinterpret_cast<const float4*>(&scrw[q * SCR_LD + 16 * h + 4 * c]);
+                    sv[4 * c] = t.x; sv[4 * c + 1] = t.y; sv[4 * c + 2] = t.z; sv[4 * c + 3] = t.w;
+                }
+                wave_lds_handover();
+                if (more) A_SCORES_LOAD(kt + 1);
+            }
+            // ---- pass 1: C[key][query] = X1 . Bq^T  (forward: scores; backward: dPd) -------------------------------
+            f32x16 acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+            {
+                const float* a1 = &x1s[cur][q * X1_LD + 4 * h];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float4 a = *reinterpret_cast<const float4*>(a1 + 8 * j);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bq[j].x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bq[j].y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bq[j].z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bq[j].w, acc, 0, 0, 0);
+                }
+            }
+            bool kp[16];  // Bernoulli(1 - p) draws of this lane's 16 keys: 4 Philox calls, 4 consecutive keys each
+            if (MASKED) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const unsigned long long ctr = ctr0 + (unsigned long long)(kt * 8 + c);
+                    const uint4 r = philox4x32_10(make_uint4((unsigned)ctr, (unsigned)(ctr >> 32), 0u, 0u), key);
+                    kp[4 * c] = r.x < p.keep_lt; kp[4 * c + 1] = r.y < p.keep_lt;
+                    kp[4 * c + 2] = r.z < p.keep_lt; kp[4 * c + 3] = r.w < p.keep_lt;
+                }
+            }
+            float bv[16];  // B operand of pass 2
+            if (!BWD) {
+                float raw[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) raw[e] = acc[e];
+                tile_store(scrw, raw, p.scores + rowbase + kt * 32, p.S, lane);
+                float tm = A_F32_MIN;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { sv[e] = raw[e] * p.scale; tm = fmaxf(tm, sv[e]); }
+                tm = fmaxf(tm, __shfl_xor(tm, 32, 64));
+                const float m_new = fmaxf(m_run, tm);
+                const float alpha = __expf(m_run - m_new);
+                float ps = 0.f;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { sv[e] = __expf(sv[e] - m_new); ps += sv[e]; }
+                ps += __shfl_xor(ps, 32, 64);
+                l_run = l_run * alpha + ps;
+                m_run = m_new;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { o0[e] *= alpha; o1[e] *= alpha; }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) bv[e] = MASKED ? (kp[e] ? sv[e] * p.dscale : 0.f) : sv[e];   // (y * noise) * 1/(1-p)
+            } else {
+                float pd[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float y = __expf(sv[e] * p.scale - m_run) * l_run;   // P, with the forward's final statistics
+                    const float gv = MASKED ? (kp[e] ? acc[e] : 0.f) : acc[e];  // DropoutBackward: g * noise
+                    bv[e] = (y * (gv - dot)) * p.scale;                          // SoftmaxBackward, MultiplicationBackwardLeft
+                    pd[e] = MASKED ? (kp[e] ? y * p.dscale : 0.f) : y;          // Dropout forward (for dV = Pd^T . dO)
+                }
+                tile_store(scrw, bv, p.ds + rowbase + kt * 32, p.S, lane);
+                tile_store(scrw, pd, p.dropped + rowbase + kt * 32, p.S, lane);
+            }
+            // ---- pass 2: out^T[dh][query] += X2^T . C ----------------------------------------------------------------
+            {
+                const float* a20 = &x2s[cur][(16 * h) * X2_LD + ((q + 32 * h) & 63)];
+                const float* a21 = &x2s[cur][(16 * h) * X2_LD + ((q + 32 * (1 ^ h)) & 63)];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a20[e * X2_LD], bv[e], o0, 0, 0, 0);
+                    o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a21[e * X2_LD], bv[e], o1, 0, 0, 0);
+                }
+            }
+        }
+        if (more) A_STAGE_STORE(cur ^ 1);
+        __syncthreads();
+    }
+#undef A_STAGE_LOAD
+#undef A_STAGE_STORE
+#undef A_SCORES_LOAD
+    if (!on) return;
+    // ---- epilogue: lane (query q, half h) owns dh = 32 d + 8 c + 4 h + {0..3} ----------------------------------------
+    float* orow = p.out + flat0 + (long long)row * p.ld + 4 * h;
+    if (!BWD) {
+        const float inv = 1.f / l_run;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            *reinterpret_cast<float4*>(orow + 8 * c) = make_float4(o0[4 * c] * inv, o0[4 * c + 1] * inv, o0[4 * c + 2] * inv, o0[4 * c + 3] * inv);
+            *reinterpret_cast<float4*>(orow + 32 + 8 * c) = make_float4(o1[4 * c] * inv, o1[4 * c + 1] * inv, o1[4 * c + 2] * inv, o1[4 * c + 3] * inv);
+        }
+        if (h == 0) *reinterpret_cast<float2*>(p.stats + ((long long)bh * p.S + row) * 2) = make_float2(m_run, inv);
+    } else {
+        float4 old[8];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            old[c] = p.assign ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(orow + 8 * c);
+            old[4 + c] = p.assign ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(orow + 32 + 8 * c);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            *reinterpret_cast<float4*>(orow + 8 * c) = make_float4(old[c].x + o0[4 * c], old[c].y + o0[4 * c + 1], old[c].z + o0[4 * c + 2], old[c].w + o0[4 * c + 3]);
+            *reinterpret_cast<float4*>(orow + 32 + 8 * c) = make_float4(old[4 + c].x + o1[4 * c], old[4 + c].y + o1[4 * c + 1], old[4 + c].z + o1[4 * c + 2], old[4 + c].w + o1[4 * c + 3]);
+        }
+    }
+}
+
+// keep_bit(w, keep) = ((w >> 8) * 2^-24 < keep) with both sides exact in f32  <=>  (w >> 8) < ceil(keep * 2^24)  <=>
+// w < ceil(keep * 2^24) * 256   (keep < 1 here: p > 0 in the masked instantiation)
+unsigned keep_threshold(float keep) {
+    const double t = std::ceil((double)keep * 16777216.0);
+    return t >= 16777216.0 ? 0xFFFFFFFFu : (unsigned)t * 256u;
+}
+
+bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+int attention_check(int B, int S, int H, int dh, double p, int train) {
+    NK_CHECK(p >= 0.0 && p <= 1.0, "Wrong probability received: %g.", p);
+    NK_CHECK(B > 0 && S > 0 && H > 0, "attention: non-positive geometry");
+    NK_CHECK(nk_attention_supported(S, dh, p, train), "fused attention needs dh == 64, S %% 32 == 0 and p < 1 in training (S=%d dh=%d p=%g)", S, dh, p);
+    NK_CHECK((long long)B * S * H * dh < (1ll << 31), "attention: the projection layout exceeds 2^31 elements");
+    return NK_OK;
+}
+
+template <bool BWD>
+int attention_launch(nk_device* dev, AttnArgs& a, int B, int S, int H, double p, int train, uint64_t seed, uint64_t offset, float scale) {
+    a.S = S; a.H = H; a.ld = H * A_DH; a.nqb = (S + A_QB - 1) / A_QB; a.ntile = S / 32;
+    a.scale = scale; a.keep = (float)(1.0 - p); a.dscale = 1.f / (1.f - (float)p);  // as nk_scale_softmax_dropout_fwd
+    a.seed = seed; a.offset = offset;
+    a.keep_lt = keep_threshold(a.keep);
+    const bool masked = train && p != 0.0;
+    const dim3 grid((unsigned)(B * H * a.nqb)), block(A_NT);
+    const bool full = S % A_QB == 0;
+    // OCC = blocks per CU the register budget is sized for (52 KB of LDS per block allows three): the forward fits 168
+    // VGPRs without spilling, the backward (two more 16-register tiles live) does not
+    static const int occ_env = [] { const char* e = getenv("NK_ATTN_OCC"); return e ? atoi(e) : 0; }();   // tuning aid
+    constexpr int OCC_DEFAULT = BWD ? 2 : 3;
+    const int occ = BWD ? 2 : (occ_env == 2 || occ_env == 3 ? occ_env : OCC_DEFAULT);
+#define NK_ATT(M, F)                                                                                                       \
+    do {                                                                                                                   \
+        if (!BWD && occ == 3) hipLaunchKernelGGL((attention_kernel<BWD, M, F, BWD ? 2 : 3>), grid, block, 0, dev->compute, a); \
+        else hipLaunchKernelGGL((attention_kernel<BWD, M, F, 2>), grid, block, 0, dev->compute, a);                        \
+    } while (0)
+    if (masked && full) NK_ATT(true, true);
+    else if (masked) NK_ATT(true, false);
+    else if (full) NK_ATT(false, true);
+    else NK_ATT(false, false);
+#undef NK_ATT
+    NK_LAUNCH_CHECK();
+    return NK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int nk_attention_supported(int S, int dh, double p, int train) {
+    return dh == A_DH && S > 0 && S % 32 == 0 && !(train && 1.0 - p == 0.0);
+}
+
+int nk_attention_fwd(nk_device* dev, const float* Q, const float* K, const float* V, float* scores, float* stats, float* O,
+                     int B, int S, int H, int dh, float scale, double p, int train, uint64_t seed, uint64_t offset) {
+    NK_USE(dev);
+    if (int rc = attention_check(B, S, H, dh, p, train)) return rc;
+    NK_CHECK(Q && K && V && scores && stats && O, "null pointer in nk_attention_fwd");
+    NK_CHECK(al16(Q) && al16(K) && al16(V) && al16(scores) && al16(O) && al16(stats), "nk_attention_fwd needs 16-byte aligned buffers");
+    nk_prof_start(dev, NK_KERNEL_ATTENTION, 4.0 * B * H * (double)S * S * dh);
+    AttnArgs a{};
+    a.x1 = K; a.x2 = V; a.bq = Q; a.out = O; a.scores = scores; a.stats = stats;
+    const int rc = attention_launch<false>(dev, a, B, S, H, p, train, seed, offset, scale);
+    nk_prof_stop(dev);
+    return rc;
+}
+
+int nk_attention_bwd(nk_device* dev, float* dQ, float* dS, float* dropped, const float* dO, const float* O, const float* scores,
+                     const float* stats, const float* K, const float* V, int B, int S, int H, int dh, float scale, double p,
+                     int train, uint64_t seed, uint64_t offset, int assign_dq) {
+    NK_USE(dev);
+    if (int rc = attention_check(B, S, H, dh, p, train)) return rc;
+    NK_CHECK(dQ && dS && dropped && dO && O && scores && stats && K && V, "null pointer in nk_attention_bwd");
+    NK_CHECK(al16(dQ) && al16(dS) && al16(dropped) && al16(dO) && al16(O) && al16(scores) && al16(stats) && al16(K) && al16(V),
+             "nk_attention_bwd needs 16-byte aligned buffers");
+    nk_prof_start(dev, NK_KERNEL_ATTENTION, 4.0 * B * H * (double)S * S * dh);
+    AttnArgs a{};
+    a.x1 = V; a.x2 = K; a.bq = dO; a.ctx = O; a.out = dQ; a.scores = const_cast<float*>(scores); a.ds = dS; a.dropped = dropped;
+    a.stats = const_cast<float*>(stats); a.assign = assign_dq ? 1 : 0;
+    const int rc = attention_launch<true>(dev, a, B, S, H, p, train, seed, offset, scale);
+    nk_prof_stop(dev);
+    return rc;
+}
+
+}  // extern "C"

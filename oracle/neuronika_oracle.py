@@ -867,6 +867,50 @@ def numeric_grad(f, x, eps=1e-6):
     return g
 
 
+def _heads_split(t, batch, heads):  # (B*S, d) -> (B*H, S, dh)   chunks((S,dh)) row-major order (var.rs:401-417)
+    bs, d = t.shape
+    s, dh = bs // batch, d // heads
+    return np.ascontiguousarray(t.reshape(batch, s, heads, dh).transpose(0, 2, 1, 3)).reshape(batch * heads, s, dh)
+
+
+def _heads_merge(t, batch, heads):  # cat(axis 1) per batch then cat(axis 0)  (var.rs:564-584)
+    bh, s, dh = t.shape
+    return np.ascontiguousarray(t.reshape(batch, heads, s, dh).transpose(0, 2, 1, 3)).reshape(batch * s, heads * dh)
+
+
+def attention_core_forward(q, k, v, heads, batch, p, noise):
+    """The per-(sample, head) chain of the composed MHA on the (B*S, H*dh) projection layout: a-2 `mm_t`
+    (node/matrix_matrix_mul_t/mod.rs:31-41), a-4 scalar Multiplication, a-7 Softmax (node/softmax/mod.rs:37-53), a-8
+    Dropout (node/dropout/mod.rs:53-79), a-1 `mm`, with Chunk / MultiConcatenate as the head split and merge.
+    `noise` is (batch*heads, S, S).  Returns (context, cache for attention_core_backward)."""
+    dt = q.dtype
+    scale = dt.type(1.0 / np.sqrt(q.shape[1] // heads))
+    qh, kh, vh = (_heads_split(t, batch, heads) for t in (q, k, v))
+    sc = np.matmul(qh, kh.transpose(0, 2, 1))
+    scs = sc * scale
+    pr = np.zeros_like(scs)
+    softmax_forward(scs, pr, axis=2)
+    pd = np.zeros_like(pr)
+    dropout_forward(pr, pd, noise, p, True)
+    o = _heads_merge(np.matmul(pd, vh), batch, heads)
+    return o, dict(qh=qh, kh=kh, vh=vh, scores=sc, probs=pr, dropped=pd, noise=noise, p=p, scale=scale, heads=heads, batch=batch)
+
+
+def attention_core_backward(cache, g):
+    """Backward nodes of attention_core_forward for the context gradient `g`: MatrixMatrixMulBackward{Left,Right},
+    DropoutBackward (mask only, node/dropout/mod.rs:113-128), SoftmaxBackward (node/softmax/mod.rs:84-104),
+    MultiplicationBackwardLeft, MatrixMatrixMulTBackward{Left,Right}.  Returns dict(d_scores, dq, dk, dv)."""
+    c = cache
+    doh = _heads_split(g, c["batch"], c["heads"])
+    dpd = np.matmul(doh, c["vh"].transpose(0, 2, 1))
+    dvh = np.matmul(c["dropped"].transpose(0, 2, 1), doh)
+    dpr = np.zeros_like(dpd); dropout_backward(dpr, dpd, c["noise"], c["p"], True)
+    dscs = np.zeros_like(dpd); softmax_backward(dscs, dpr, c["probs"], axis=2)
+    dsc = dscs * c["scale"]
+    m = lambda t: _heads_merge(t, c["batch"], c["heads"])
+    return dict(d_scores=dsc, dq=m(np.matmul(dsc, c["kh"])), dk=m(np.matmul(dsc.transpose(0, 2, 1), c["qh"])), dv=m(dvh))
+
+
 def mha_forward_backward(x, wq, bq, wk, bk, wv, bv, wo, bo, heads, batch, p, noise, g_out):
     """The composed MHA of SURVEY.md section 8a (module absent from the reference; oracle =
     composition of a-2, a-4, a-7, a-8, a-1, a-10):
@@ -881,21 +925,7 @@ def mha_forward_backward(x, wq, bq, wk, bk, wv, bv, wo, bo, heads, batch, p, noi
     scale = dt.type(1.0 / np.sqrt(dh))
     q, k, v = linear_forward(x, wq, bq), linear_forward(x, wk, bk), linear_forward(x, wv, bv)
 
-    def split(t):  # (B*S, d) -> (B*H, S, dh)   chunks((S,dh)) row-major order (var.rs:401-417)
-        return np.ascontiguousarray(t.reshape(batch, s, heads, dh).transpose(0, 2, 1, 3)).reshape(batch * heads, s, dh)
-
-    def merge(t):  # cat(axis 1) per batch then cat(axis 0)
-        return np.ascontiguousarray(t.reshape(batch, heads, s, dh).transpose(0, 2, 1, 3)).reshape(bs, d)
-
-    qh, kh, vh = split(q), split(k), split(v)
-    sc = np.matmul(qh, kh.transpose(0, 2, 1))
-    scs = sc * scale
-    pr = np.zeros_like(scs)
-    softmax_forward(scs, pr, axis=2)
-    pd = np.zeros_like(pr)
-    dropout_forward(pr, pd, noise, p, True)
-    oh = np.matmul(pd, vh)
-    o = merge(oh)
+    o, cache = attention_core_forward(q, k, v, heads, batch, p, noise)
     out = linear_forward(o, wo, bo)
 
     # backward
@@ -903,15 +933,8 @@ def mha_forward_backward(x, wq, bq, wk, bk, wv, bv, wo, bo, heads, batch, p, noi
     dbo = np.zeros_like(bo); accumulate(dbo, g)
     dwo = np.zeros_like(wo); mm_t_backward_right(dwo, g, o)
     do = np.zeros_like(o); mm_t_backward_left(do, g, wo)
-    doh = split(do)
-    dpd = np.matmul(doh, vh.transpose(0, 2, 1))
-    dvh = np.matmul(pd.transpose(0, 2, 1), doh)
-    dpr = np.zeros_like(pr); dropout_backward(dpr, dpd, noise, p, True)
-    dscs = np.zeros_like(scs); softmax_backward(dscs, dpr, pr, axis=2)
-    dsc = dscs * scale
-    dqh = np.matmul(dsc, kh)
-    dkh = np.matmul(dsc.transpose(0, 2, 1), qh)
-    dq, dk, dv = merge(dqh), merge(dkh), merge(dvh)
+    core = attention_core_backward(cache, do)
+    dq, dk, dv = core["dq"], core["dk"], core["dv"]
     grads = {}
     dx = np.zeros_like(x)
     for name, w, b, dz in (("q", wq, bq, dq), ("k", wk, bk, dk), ("v", wv, bv, dv)):

@@ -1,0 +1,115 @@
+"""GPU parity of the fused attention core (nk_attention_fwd / nk_attention_bwd, the per-(sample, head) chain of the
+composed multi-head attention, SURVEY.md 8a note) against the oracle's node-by-node composition
+`attention_core_forward/backward`, through the C ABI.
+
+Tolerance (SURVEY.md 8c ii): the kernels and the f32 oracle are both measured against the f64 oracle fed the SAME Philox
+mask; pass iff err_gpu <= max(4 * err_cpu32, 2e-6 * max|reference|) per tensor.  The raw scores come out of the same MFMA
+k-order as nk_sgemm_batched and must equal it bit for bit; the dropped-probability tensor must have exactly the mask's
+zero pattern."""
+import numpy as np
+import pytest
+
+from oracle import neuronika_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def capi():
+    from neuronika_amd import capi as c
+    return c
+
+
+def rnd(seed, shape, lo, hi):
+    a = np.random.default_rng(seed).random(shape, dtype=np.float32)
+    return np.asarray(a * np.float32(hi - lo) + np.float32(lo), dtype=np.float32)
+
+
+def _check(got, want64, want32, what, floor=0.0):
+    scale = max(np.abs(want64).max(), floor)
+    err_gpu, err_cpu = np.abs(got - want64).max(), np.abs(want32 - want64).max()
+    assert err_gpu <= max(4 * err_cpu, 2e-6 * scale), (what, err_gpu, err_cpu, scale)
+
+
+def _run(dev, B, S, H, p, train, seed, offset, assign, q, k, v, g, dq0):
+    c = capi()
+    dh = 64
+    scale = float(np.float32(1.0 / np.sqrt(dh)))
+    Q, K, V, G = (dev.array(t) for t in (q, k, v, g))
+    scores, stats, out = dev.zeros((B * H, S, S)), dev.zeros((B * H, S, 2)), dev.zeros((B * S, H * dh))
+    c.attention_fwd(dev, Q, K, V, scores, stats, out, B, S, H, dh, scale, p, train, seed, offset)
+    dS, dropped, dQ = dev.zeros((B * H, S, S)), dev.zeros((B * H, S, S)), dev.array(dq0)
+    c.attention_bwd(dev, dQ, dS, dropped, G, out, scores, stats, K, V, B, S, H, dh, scale, p, train, seed, offset, assign)
+    # the two products that stay batched GEMMs, as the tape node issues them
+    dK, dV = dev.zeros((B * S, H * dh)), dev.zeros((B * S, H * dh))
+    d, so, po, pi = H * dh, S * H * dh, H * S * S, S * S
+    c.sgemm_batched(dev, 1, 0, S, dh, S, 1.0, dS, S, po, pi, Q, d, so, dh, 0.0, dK, d, so, dh, B, H)
+    c.sgemm_batched(dev, 1, 0, S, dh, S, 1.0, dropped, S, po, pi, G, d, so, dh, 0.0, dV, d, so, dh, B, H)
+    return dict(scores=scores.numpy(), stats=stats.numpy(), out=out.numpy(), d_scores=dS.numpy(), dropped=dropped.numpy(),
+                dq=dQ.numpy(), dk=dK.numpy(), dv=dV.numpy()), (Q, K)
+
+
+@pytest.mark.parametrize("B,S,H", [(2, 128, 2), (1, 160, 3), (3, 32, 1), (1, 256, 2), (2, 96, 2)])
+@pytest.mark.parametrize("p,train", [(0.1, True), (0.0, True), (0.35, False), (0.5, True)])
+def test_attention_core_equals_oracle(dev, B, S, H, p, train):
+    c = capi()
+    dh, seed, offset = 64, 0x1234567890ABCDEF, 4242
+    q, k, v, g = (rnd(s, (B * S, H * dh), -1, 1) for s in (1, 2, 3, 4))
+    dq0 = rnd(9, (B * S, H * dh), -1, 1)
+    got, (Q, K) = _run(dev, B, S, H, p, train, seed, offset, False, q, k, v, g, dq0)
+    n = B * H * S * S
+    masked = train and p != 0.0
+    noise = O.dropout_noise(n, p, seed, offset).reshape(B * H, S, S) if masked else np.ones((B * H, S, S), np.float32)
+    pe = p if masked else 0.0
+    ref, ref32 = {}, {}
+    for dt, dst in ((np.float64, ref), (np.float32, ref32)):
+        o, cache = O.attention_core_forward(q.astype(dt), k.astype(dt), v.astype(dt), H, B, pe, noise.astype(dt))
+        dst.update(O.attention_core_backward(cache, g.astype(dt)), out=o, scores=cache["scores"], dropped=cache["dropped"])
+    # raw scores: same MFMA reduction order as the batched GEMM -> identical bits
+    ref_scores = dev.zeros((B * H, S, S))
+    c.sgemm_batched(dev, 0, 1, S, S, dh, 1.0, Q, H * dh, S * H * dh, dh, K, H * dh, S * H * dh, dh, 0.0, ref_scores, S, H * S * S, S * S, B, H)
+    assert np.array_equal(got["scores"], ref_scores.numpy())
+    _check(got["scores"], ref["scores"], ref32["scores"], "scores")
+    assert np.array_equal(got["dropped"] == 0, noise == 0)   # dropped exactly where the mask says (no probability underflows here)
+    for name in ("out", "dropped", "d_scores", "dk", "dv"):
+        _check(got[name], ref[name], ref32[name], name)
+    _check(got["dq"] - dq0, ref["dq"], ref32["dq"], "dq (accumulated)", floor=np.abs(dq0).max())
+    # row statistics: max of the scaled scores, reciprocal of the row sum
+    sc = ref["scores"] * np.float64(np.float32(1.0 / np.sqrt(dh)))
+    np.testing.assert_allclose(got["stats"][..., 0], sc.max(2), rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(got["stats"][..., 1], 1.0 / np.exp(sc - sc.max(2, keepdims=True)).sum(2), rtol=1e-5)
+    # first-write form: dQ assigned, whatever the buffer held
+    got2, _ = _run(dev, B, S, H, p, train, seed, offset, True, q, k, v, g, dq0)
+    assert np.array_equal(got2["dq"] + dq0, got["dq"]) or np.abs(got2["dq"] + dq0 - got["dq"]).max() <= 1e-6 * np.abs(dq0).max()
+    _check(got2["dq"], ref["dq"], ref32["dq"], "dq (assigned)")
+
+
+def test_attention_core_mask_is_the_row_kernels_mask(dev):
+    """Same seed / offset -> the fused core drops exactly the elements nk_scale_softmax_dropout_fwd drops, and its output
+    equals the node-by-node device path (batched GEMM -> fused probabilities -> batched GEMM) to f32 rounding."""
+    c = capi()
+    B, S, H, dh, p, seed, offset = 2, 128, 2, 64, 0.2, 99, 17
+    scale = float(np.float32(0.125))
+    q, k, v, g = (rnd(s, (B * S, H * dh), -1, 1) for s in (11, 12, 13, 14))
+    got, (Q, K) = _run(dev, B, S, H, p, True, seed, offset, True, q, k, v, g, np.zeros((B * S, H * dh), np.float32))
+    V = dev.array(v)
+    sc, pd, ctx = dev.zeros((B * H, S, S)), dev.zeros((B * H, S, S)), dev.zeros((B * S, H * dh))
+    d, so, po, pi = H * dh, S * H * dh, H * S * S, S * S
+    c.sgemm_batched(dev, 0, 1, S, S, dh, 1.0, Q, d, so, dh, K, d, so, dh, 0.0, sc, S, po, pi, B, H)
+    c.scale_softmax_dropout_fwd(dev, sc, None, pd, None, scale, p, True, seed, offset)
+    c.sgemm_batched(dev, 0, 0, S, dh, S, 1.0, pd, S, po, pi, V, d, so, dh, 0.0, ctx, d, so, dh, B, H)
+    assert np.array_equal(got["dropped"] == 0, pd.numpy() == 0)
+    np.testing.assert_allclose(got["dropped"], pd.numpy(), rtol=1e-5, atol=1e-9)
+    np.testing.assert_allclose(got["out"], ctx.numpy(), rtol=1e-4, atol=2e-6)
+
+
+def test_attention_core_rejects_what_it_cannot_do(dev):
+    c = capi()
+    assert c.attention_supported(1024, 64, 0.1) and c.attention_supported(32, 64, 0.0)
+    assert not c.attention_supported(1024, 32, 0.1) and not c.attention_supported(100, 64, 0.1)
+    assert not c.attention_supported(64, 64, 1.0, True) and c.attention_supported(64, 64, 1.0, False)
+    z = dev.zeros((64, 32))
+    sc, st = dev.zeros((1, 64, 64)), dev.zeros((1, 64, 2))
+    with pytest.raises(RuntimeError, match="fused attention needs"):
+        c.attention_fwd(dev, z, z, z, sc, st, z, 1, 64, 1, 32, 0.1, 0.0)
+    with pytest.raises(RuntimeError, match="Wrong probability"):
+        c.attention_fwd(dev, z, z, z, sc, st, z, 1, 64, 1, 64, 0.1, 1.5)

@@ -659,6 +659,54 @@ def test_mha_with_dropout_equals_oracle(nk, tdev, fused, strided, p):
         assert not np.array_equal(O.dropout_noise(n, p, seed, 0), noise.reshape(-1))
 
 
+@pytest.mark.parametrize("core", [True, False])
+@pytest.mark.parametrize("p,S", [(0.1, 96), (0.0, 64), (0.3, 160)])
+def test_mha_fused_attention_core_equals_oracle(nk, tdev, core, p, S):
+    """Head dimension 64 (the C5 geometry): the module routes scores -> probabilities -> context through the fused
+    attention kernels (`fused_core`, one node instead of three).  Same check as above - the oracle composition fed the
+    device's Philox mask, output, input gradient and all eight parameter gradients, two forwards (the mask is
+    resampled) - for the fused core and for the node-by-node path it replaces, which must also agree with each other."""
+    B, d, H = 2, 128, 2
+    x, g = rnd(0, (B * S, d), -1, 1), rnd(5, (B * S, d), -1, 1)
+    seed = 7654321
+    nk.manual_seed(seed)
+    mha = nk.nn.MultiheadAttention(tdev, d, H, p, 3)
+    mha.fused_core = core
+    X = nk.from_ndarray(tdev, x).requires_grad()
+    y = mha.forward(X, B)
+    other = nk.nn.MultiheadAttention(tdev, d, H, p, 3)
+    other.fused_core = not core
+    assert y.history_len() == other.forward(nk.from_ndarray(tdev, x).requires_grad(), B).history_len() + (-2 if core else 2)
+    G = nk.from_ndarray(tdev, g)
+    leaves = [X] + [getattr(getattr(mha, n), w) for n in "qkvo" for w in ("weight", "bias")]
+    n = B * H * S * S
+    for call in range(2):
+        noise = O.dropout_noise(n, p, seed, call * ((n + 3) // 4)).reshape(B * H, S, S) if p else np.ones((B * H, S, S), np.float32)
+        for v in leaves:
+            v.zero_grad()
+        y.forward(); y.no_grad(); y.with_grad()
+        y.backward_from(G)
+        ref, grads = _mha_oracle(mha, x, g, H, B, p, noise)
+        ref32, grads32 = _mha_oracle(mha, x, g, H, B, p, noise, np.float32)
+        def check(got, want, want32, what, floor=0.0):
+            scale = max(np.abs(want).max(), floor)
+            err_gpu, err_cpu = np.abs(got - want).max(), np.abs(want32 - want).max()
+            assert err_gpu <= max(4 * err_cpu, 2e-6 * scale), (what, call, err_gpu, err_cpu, scale)
+        check(y.data(), ref, ref32, "out")
+        check(X.grad(), grads["x"], grads32["x"], "dx")
+        for nme in "qkvo":
+            check(getattr(mha, nme).weight.grad(), grads["w" + nme], grads32["w" + nme], "dw" + nme)
+            check(getattr(mha, nme).bias.grad(), grads["b" + nme], grads32["b" + nme], "db" + nme, np.abs(grads["w" + nme]).max())
+    # eval mode: no mask
+    mha.drop.eval()
+    for v in leaves:
+        v.zero_grad()
+    y.forward(); y.no_grad(); y.with_grad(); y.backward_from(G)
+    ref, grads = _mha_oracle(mha, x, g, H, B, 0.0, np.ones((B * H, S, S), np.float32))
+    np.testing.assert_allclose(y.data(), ref, rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(X.grad(), grads["x"], rtol=1e-3, atol=2e-6 * np.abs(grads["x"]).max() + 1e-7)
+
+
 def test_backward_from_equals_weighted_sum_scaffolding(nk, tdev):
     """`y.backward_from(G)` (the upstream gradient tensor stands in for the root gradient while the tape runs - no copy,
     no extra nodes) gives bit-identical leaf gradients to the scaffolding `(y * G).sum().backward(1.0)`; the seed is left
