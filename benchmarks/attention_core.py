@@ -24,14 +24,15 @@ def main():
     big = lambda: dev.zeros((B * H, S, S))
     scores, probs_d, dP, dS = big(), big(), big(), big()
     stats, out, dQ = dev.zeros((B * H, S, 2)), dev.zeros((B * S, H * dh)), dev.zeros((B * S, H * dh))
+    bits = dev.zeros((B * H, S, S // 32))
     d, so, po, pi = H * dh, S * H * dh, H * S * S, S * S
     flop = 4.0 * B * H * S * S * dh
 
     def fused_fwd():
-        c.attention_fwd(dev, Q, K, V, scores, stats, out, B, S, H, dh, scale, p, True, seed, 0)
+        c.attention_fwd(dev, Q, K, V, scores, stats, bits, out, B, S, H, dh, scale, p, True, seed, 0)
 
     def fused_bwd():
-        c.attention_bwd(dev, dQ, dS, probs_d, G, out, scores, stats, K, V, B, S, H, dh, scale, p, True, seed, 0, True)
+        c.attention_bwd(dev, dQ, dS, probs_d, G, out, scores, stats, bits, K, V, B, S, H, dh, scale, p, True, True)
 
     def nodes_fwd():
         c.sgemm_batched(dev, 0, 1, S, S, dh, 1.0, Q, d, so, dh, K, d, so, dh, 0.0, scores, S, po, pi, B, H)

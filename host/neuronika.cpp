@@ -727,38 +727,36 @@ struct HeadsContextBwd : Backward {
 // heads_scores -> attention_probs -> heads_context as one node (nk_attention_fwd / nk_attention_bwd)
 struct HeadsAttentionFwd : Forward {
     HeadsGeom hg;
-    Shared<HipArray> q, k, v, scores, stats, o;
+    Shared<HipArray> q, k, v, scores, stats, mask, o;  // mask: the dropout draws, 1 bit per score (u32 words in an f32 array)
     float scale;
     double p;
     Shared<bool> status;
     uint64_t seed;
-    Shared<uint64_t> calls, last_offset;  // as AttnProbsFwd: the backward node regenerates the mask of the LAST forward
+    Shared<uint64_t> calls;  // each forward draws a fresh mask (the Philox offset advances), as AttnProbsFwd
     void forward() const override {
         const uint64_t offset = (*calls) * ((scores->len() + 3) / 4);
         ++(*calls);
-        *last_offset = offset;
-        check(nk_attention_fwd(D(q), q->ptr(), k->ptr(), v->ptr(), scores->ptr(), stats->ptr(), o->ptr(), hg.B, hg.S, hg.H, hg.dh,
-                               scale, p, *status ? 1 : 0, seed, offset));
+        check(nk_attention_fwd(D(q), q->ptr(), k->ptr(), v->ptr(), scores->ptr(), stats->ptr(), reinterpret_cast<uint32_t*>(mask->ptr()),
+                               o->ptr(), hg.B, hg.S, hg.H, hg.dh, scale, p, *status ? 1 : 0, seed, offset));
     }
 };
 struct HeadsAttentionBwd : Backward {
     HeadsGeom hg;
-    Shared<HipArray> q, k, v, scores, stats, o;
+    Shared<HipArray> q, k, v, scores, stats, mask, o;
     Shared<HipArray> ds, dropped;  // (B*H, S, S) scratch written by the first kernel, read by the dK / dV products
     Shared<Gradient> dq, dk, dv, g;
     float scale;
     double p;
     Shared<bool> status;
-    uint64_t seed;
-    Shared<uint64_t> last_offset;
     void backward() const override {
         const HipArray& G = g->borrow();  // dO, flat layout
         nk_device* dev = D(q);
         float beta;
         {   // dS, Pd, and dQ_bh += dS_bh . K_bh
             float* d = first_write(dq, beta);
-            check(nk_attention_bwd(dev, d, ds->ptr(), dropped->ptr(), G.ptr(), o->ptr(), scores->ptr(), stats->ptr(), k->ptr(), v->ptr(),
-                                   hg.B, hg.S, hg.H, hg.dh, scale, p, *status ? 1 : 0, seed, *last_offset, beta == 0.f ? 1 : 0));
+            check(nk_attention_bwd(dev, d, ds->ptr(), dropped->ptr(), G.ptr(), o->ptr(), scores->ptr(), stats->ptr(),
+                                   reinterpret_cast<const uint32_t*>(mask->ptr()), k->ptr(), v->ptr(), hg.B, hg.S, hg.H, hg.dh, scale, p,
+                                   *status ? 1 : 0, beta == 0.f ? 1 : 0));
         }
         {   // dK_bh += dS_bh^T . Q_bh
             float* d = first_write(dk, beta);
@@ -1213,11 +1211,11 @@ Var Var::heads_attention(const Var& keys, const Var& values, int B, int S, int H
     op->hg = {B, S, H, dh}; op->q = data; op->k = keys.data; op->v = values.data;
     op->scores = zeros_like(data, Shape{B * H, S, S});
     op->stats = zeros_like(data, Shape{B * H, S, 2});
+    op->mask = zeros_like(data, Shape{B * H, S, S / 32});
     op->o = zeros_like(data, Shape{B * S, H * dh});
     op->scale = scale; op->p = p; op->status = std::move(status);
     op->seed = next_node_seed();
     op->calls = std::make_shared<uint64_t>(0);
-    op->last_offset = std::make_shared<uint64_t>(0);
     auto y = op->o;
     return Var::node(y, op, std::move(h));
 }
@@ -1230,11 +1228,11 @@ VarDiff VarDiff::heads_attention(const VarDiff& keys, const VarDiff& values, int
     h.merge(values.history);
     auto g = std::make_shared<Gradient>(out.device(), out.shape());
     auto bw = std::make_shared<HeadsAttentionBwd>();
-    bw->hg = fwd->hg; bw->q = fwd->q; bw->k = fwd->k; bw->v = fwd->v; bw->scores = fwd->scores; bw->stats = fwd->stats; bw->o = fwd->o;
+    bw->hg = fwd->hg; bw->q = fwd->q; bw->k = fwd->k; bw->v = fwd->v; bw->scores = fwd->scores; bw->stats = fwd->stats; bw->mask = fwd->mask; bw->o = fwd->o;
     bw->ds = zeros_like(fwd->scores, fwd->scores->shape());
     bw->dropped = zeros_like(fwd->scores, fwd->scores->shape());
     bw->dq = grad; bw->dk = keys.grad; bw->dv = values.grad; bw->g = g;
-    bw->scale = scale; bw->p = p; bw->status = status; bw->seed = fwd->seed; bw->last_offset = fwd->last_offset;
+    bw->scale = scale; bw->p = p; bw->status = status;
     return VarDiff::node(std::move(out), g, entry(bw, g), std::move(h));
 }
 Var Var::bmm(const Var& rhs) const { return matmul_var(2, *this, rhs); }

@@ -397,20 +397,24 @@ int nk_scale_softmax_dropout_bwd_from_scores(nk_device* dev, float* d_scores, co
  * Softmax node/softmax/mod.rs:37-53, Dropout node/dropout/mod.rs:53-79, MatrixMatrixMul node/matrix_matrix_mul/mod.rs:31-41):
  *   S_bh = Q_bh.K_bh^T ; P = softmax(S*scale, axis 1) ; Pd = dropout(P) ; O_bh = Pd.V_bh
  * Q, K, V, O, dO, dQ are the (B*S) x (H*dh) projection layout (head h = columns h*dh .. h*dh+dh-1, sample b = rows
- * b*S ..); scores / dS / dropped are (B*H, S, S); stats is (B*H, S, 2) = row max of the scaled scores, 1 / row sum.
+ * b*S ..); scores / dS / dropped are (B*H, S, S); stats is (B*H, S, 2) = (m2, 1 / sum_k exp2(S*c1 - m2)) per row with
+ * c1 = scale*log2(e) and m2 an upper bound (within 2^6) of the row's S*c1: P = exp2(S*c1 - m2) * stats[..,1].  scale > 0.
  * The score tile stays on chip between the two products (online softmax forward, recomputed probabilities backward).
  * Dropout mask: the Philox stream of nk_scale_softmax_dropout_fwd (same seed / offset -> same mask).
  * nk_attention_supported: dh == 64, S % 32 == 0, not (train and p == 1); callers fall back to the node-by-node path. */
 int nk_attention_supported(int S, int dh, double p, int train);
-/* forward: writes the raw scores (for the backward pass), the row statistics and O */
-int nk_attention_fwd(nk_device* dev, const float* Q, const float* K, const float* V, float* scores, float* stats, float* O,
-                     int B, int S, int H, int dh, float scale, double p, int train, uint64_t seed, uint64_t offset);
+/* forward: writes the raw scores (for the backward pass), the row statistics, the dropout draws (1 bit per score,
+ * (B*H, S, S/32) words; may be NULL when dropout is inactive) and O */
+int nk_attention_fwd(nk_device* dev, const float* Q, const float* K, const float* V, float* scores, float* stats,
+                     uint32_t* mask_bits, float* O, int B, int S, int H, int dh, float scale, double p, int train,
+                     uint64_t seed, uint64_t offset);
 /* backward, first part: dS and Pd are WRITTEN (scratch the caller owns; dK_bh += dS_bh^T.Q_bh and dV_bh += Pd_bh^T.dO_bh
- * are nk_sgemm_batched calls on them), dQ_bh (+)= dS_bh.K_bh (`assign_dq` != 0: first write).
+ * are nk_sgemm_batched calls on them), dQ_bh (+)= dS_bh.K_bh (`assign_dq` != 0: first write).  The mask is the forward's
+ * (`mask_bits`), as the reference's backward node reads the forward's noise buffer.
  * DropoutBackward multiplies by the 0/1 mask only (node/dropout/mod.rs:113-128), SoftmaxBackward node/softmax/mod.rs:84-104. */
 int nk_attention_bwd(nk_device* dev, float* dQ, float* dS, float* dropped, const float* dO, const float* O,
-                     const float* scores, const float* stats, const float* K, const float* V, int B, int S, int H, int dh,
-                     float scale, double p, int train, uint64_t seed, uint64_t offset, int assign_dq);
+                     const float* scores, const float* stats, const uint32_t* mask_bits, const float* K, const float* V,
+                     int B, int S, int H, int dh, float scale, double p, int train, int assign_dq);
 
 /* ------------------------------------------------------------------ dropout ------------ */
 /* Dropout::forward node/dropout/mod.rs:53-79.  train && 0<p<1: noise ~ Bernoulli(1-p) in

@@ -145,9 +145,9 @@ _SIGS = {
     "nk_log_softmax_fwd": [VP, VP, VP, c_intp, C.c_int, C.c_int],
     "nk_log_softmax_bwd": [VP, VP, VP, VP, c_intp, C.c_int, C.c_int],
     "nk_attention_supported": [C.c_int, C.c_int, C.c_double, C.c_int],
-    "nk_attention_fwd": [VP, VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_double, C.c_int, C.c_uint64, C.c_uint64],
-    "nk_attention_bwd": [VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_double, C.c_int,
-                         C.c_uint64, C.c_uint64, C.c_int],
+    "nk_attention_fwd": [VP, VP, VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_double, C.c_int, C.c_uint64, C.c_uint64],
+    "nk_attention_bwd": [VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_double, C.c_int,
+                         C.c_int],
     "nk_scale_softmax_dropout_fwd": [VP, VP, VP, VP, VP, C.c_longlong, C.c_int, C.c_float, C.c_double, C.c_int, C.c_uint64, C.c_uint64],
     "nk_scale_softmax_dropout_bwd": [VP, VP, VP, VP, VP, C.c_longlong, C.c_int, C.c_float, C.c_double, C.c_int, C.c_uint64, C.c_uint64],
     "nk_dropout_fwd": [VP, VP, VP, VP, C.c_size_t, C.c_double, C.c_int, C.c_uint64, C.c_uint64],
@@ -574,15 +574,18 @@ def attention_supported(S, dh, p, train=True):
     return bool(lib.nk_attention_supported(S, dh, float(p), int(train)))
 
 
-def attention_fwd(dev, Q, K, V, scores, stats, out, B, S, H, dh, scale, p, train=True, seed=0, offset=0):
-    """Fused attention core: scores (B*H,S,S), stats (B*H,S,2) and out (B*S,H*dh) are written."""
-    check(lib.nk_attention_fwd(dev.h, Q.p, K.p, V.p, scores.p, stats.p, out.p, B, S, H, dh, scale, float(p), int(train), seed, offset))
+def attention_fwd(dev, Q, K, V, scores, stats, mask_bits, out, B, S, H, dh, scale, p, train=True, seed=0, offset=0):
+    """Fused attention core: scores (B*H,S,S), stats (B*H,S,2), mask_bits (B*H,S,S/32 words held in an f32 array; None
+    when dropout is inactive) and out (B*S,H*dh) are written."""
+    check(lib.nk_attention_fwd(dev.h, Q.p, K.p, V.p, scores.p, stats.p, mask_bits.p if mask_bits is not None else None, out.p,
+                               B, S, H, dh, scale, float(p), int(train), seed, offset))
 
 
-def attention_bwd(dev, dQ, dS, dropped, dO, out, scores, stats, K, V, B, S, H, dh, scale, p, train=True, seed=0, offset=0, assign=False):
+def attention_bwd(dev, dQ, dS, dropped, dO, out, scores, stats, mask_bits, K, V, B, S, H, dh, scale, p, train=True, assign=False):
     """dS and dropped (B*H,S,S) are written; dQ (+)= dS.K per (sample, head)."""
-    check(lib.nk_attention_bwd(dev.h, dQ.p, dS.p, dropped.p, dO.p, out.p, scores.p, stats.p, K.p, V.p, B, S, H, dh, scale, float(p),
-                               int(train), seed, offset, int(assign)))
+    check(lib.nk_attention_bwd(dev.h, dQ.p, dS.p, dropped.p, dO.p, out.p, scores.p, stats.p,
+                               mask_bits.p if mask_bits is not None else None, K.p, V.p, B, S, H, dh, scale, float(p),
+                               int(train), int(assign)))
 
 
 def chunk_fwd(dev, x, y, chunk_no):

@@ -40,7 +40,6 @@ constexpr int A_QB = 128;   // queries per block
 constexpr int X1_LD = 68;   // pass-1 operand image [mfma row][dh], padded: b128 fragment reads of 16 rows hit 16 distinct slots
 constexpr int X2_LD = 64;   // pass-2 operand image [key][dh rotated by 32 for keys >= 16]: the two lane halves read disjoint banks
 constexpr int SCR_LD = 36;  // per-wave 32 x 32 transposition scratch
-constexpr float A_F32_MIN = -3.40282347e+38f;
 
 struct AttnArgs {
     const float* x1;   // pass-1 operand, flat (B*S) x (H*dh) layout: forward K, backward V
@@ -51,9 +50,11 @@ struct AttnArgs {
     float* scores;     // (B*H, S, S) raw scores: written forward, read backward
     float* ds;         // backward: dS
     float* dropped;    // backward: Pd
-    float* stats;      // (B*H, S, 2): row max of the scaled scores, 1 / row sum of exp
+    unsigned* maskbits;  // (B*H, S, S/32): the dropout draws, 1 bit per score (bit 16h + e of word kt = key 32 kt + 16 h + e kept): written forward, read backward
+    float* stats;      // (B*H, S, 2): the shift m2 (an upper bound of the scaled scores, in log2 units) and 1 / sum_k exp2(s*c1 - m2)
     int S, H, ld, nqb, ntile;
     float scale, keep, dscale;
+    float c1;          // scale * log2(e): exponents are taken in base 2
     unsigned keep_lt;  // Philox word w is kept iff w < keep_lt  (== keep_bit(w, keep): (w >> 8) * 2^-24 < keep, exactly)
     unsigned long long seed, offset;
     int assign;        // backward: dQ = (1) or += (0)
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(A_NT, OCC) void attention_kernel(const AttnArgs p) 
 #pragma unroll
         for (int j = 0; j < 8; ++j) bq[j] = *reinterpret_cast<const float4*>(b + 8 * j);
     }
-    float m_run = A_F32_MIN, l_run = 0.f;  // forward: online softmax; backward: the stored row max and 1 / sum
+    float m_run = -1e30f, l_run = 0.f;  // forward: online softmax (shift, sum); backward: the stored shift and 1 / sum
     float dot = 0.f;
     if (BWD) {
         const float2 ms = *reinterpret_cast<const float2*>(p.stats + ((long long)bh * p.S + row) * 2);
@@ -166,6 +167,8 @@ __global__ __launch_bounds__(A_NT, OCC) void attention_kernel(const AttnArgs p) 
     float* scrw = scr[w];
     // backward: the score tile of the NEXT iteration, in the coalesced load layout (lane -> rows 8i + lane/8, 16 B each)
     float4 sn0, sn1, sn2, sn3;
+    unsigned mkn = 0;  // and this row's 32 dropout bits of that tile
+    const unsigned* mload = (BWD && MASKED) ? p.maskbits + ((long long)bh * p.S + row) * p.ntile : nullptr;
     const float* sload = p.scores + rowbase + (long long)(lane >> 3) * p.S + 4 * (lane & 7);
 #define A_SCORES_LOAD(KT)                                                                        \
     do {                                                                                         \
@@ -173,6 +176,7 @@ __global__ __launch_bounds__(A_NT, OCC) void attention_kernel(const AttnArgs p) 
         sn1 = *reinterpret_cast<const float4*>(sload + (long long)8 * p.S + (KT) * 32);          \
         sn2 = *reinterpret_cast<const float4*>(sload + (long long)16 * p.S + (KT) * 32);         \
         sn3 = *reinterpret_cast<const float4*>(sload + (long long)24 * p.S + (KT) * 32);         \
+        if (MASKED) mkn = mload[KT];                                                             \
     } while (0)
 
     A_STAGE_LOAD(0);
@@ -189,7 +193,9 @@ __global__ __launch_bounds__(A_NT, OCC) void attention_kernel(const AttnArgs p) 
         if (more) A_STAGE_LOAD(kt + 1);
         if (on) {
             float sv[16];
+            unsigned mybits = 0;
             if (BWD) {  // score tile -> lane layout, then fetch the next one
+                if (MASKED) mybits = mkn >> (16 * h);
                 float* sw = &scrw[(lane >> 3) * SCR_LD + 4 * (lane & 7)];
                 *reinterpret_cast<float4*>(sw) = sn0;
                 *reinterpret_cast<float4*>(sw + 8 * SCR_LD) = sn1;
@@ -219,8 +225,14 @@ __global__ __launch_bounds__(A_NT, OCC) void attention_kernel(const AttnArgs p) 
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bq[j].w, acc, 0, 0, 0);
                 }
             }
-            bool kp[16];  // Bernoulli(1 - p) draws of this lane's 16 keys: 4 Philox calls, 4 consecutive keys each
-            if (MASKED) {
+            // Bernoulli(1 - p) draws of this lane's 16 keys.  Forward: 4 Philox calls (4 consecutive keys each, the counter
+            // layout of nk_scale_softmax_dropout_fwd), packed to one bit per score for the backward pass - the Philox rounds
+            // are ~2000 of the ~6500 issue cycles of a masked tile (v_mad_u64_u32 is quarter rate), paid once, not twice;
+            // and the backward mask is the forward's by construction (the reference shares the noise buffer the same way,
+            // node/dropout/mod.rs:113-128).
+            bool kp[16];
+            if (MASKED && !BWD) {
+                unsigned bits = 0;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const unsigned long long ctr = ctr0 + (unsigned long long)(kt * 8 + c);
@@ -228,6 +240,14 @@ __global__ __launch_bounds__(A_NT, OCC) void attention_kernel(const AttnArgs p) 
                     kp[4 * c] = r.x < p.keep_lt; kp[4 * c + 1] = r.y < p.keep_lt;
                     kp[4 * c + 2] = r.z < p.keep_lt; kp[4 * c + 3] = r.w < p.keep_lt;
                 }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) bits |= kp[e] ? (1u << e) : 0u;
+                const unsigned other = (unsigned)__shfl_xor((int)bits, 32, 64);
+                if (h == 0) p.maskbits[((long long)bh * p.S + row) * p.ntile + kt] = bits | (other << 16);
+            }
+            if (MASKED && BWD) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) kp[e] = (mybits >> e) & 1u;
             }
             float bv[16];  // B operand of pass 2
             if (!BWD) {
@@ -235,30 +255,45 @@ __global__ __launch_bounds__(A_NT, OCC) void attention_kernel(const AttnArgs p) 
 #pragma unroll
                 for (int e = 0; e < 16; ++e) raw[e] = acc[e];
                 tile_store(scrw, raw, p.scores + rowbase + kt * 32, p.S, lane);
-                float tm = A_F32_MIN;
+                // Online softmax in the base-2 exponent domain: exp(s*scale - m) = exp2(s*c1 - m2), c1 = scale*log2(e), one fma
+                // and one v_exp_f32 per element.  f32 MFMA and VALU instructions do NOT overlap on a SIMD (measured,
+                // benchmarks/native/mfma_valu_overlap.hip: both run on the f32 lanes), so every VALU instruction here is
+                // paid in full on top of the 64 MFMAs of the tile.
+                float rmax = raw[0];
 #pragma unroll
-                for (int e = 0; e < 16; ++e) { sv[e] = raw[e] * p.scale; tm = fmaxf(tm, sv[e]); }
-                tm = fmaxf(tm, __shfl_xor(tm, 32, 64));
-                const float m_new = fmaxf(m_run, tm);
-                const float alpha = __expf(m_run - m_new);
+                for (int e = 1; e < 16; ++e) rmax = fmaxf(rmax, raw[e]);   // scale > 0: max of the scaled = scaled max
+                rmax = fmaxf(rmax, __shfl_xor(rmax, 32, 64));
+                const float tm2 = rmax * p.c1;
+                // The running max only has to bound the exponents, not equal the true max: it moves when a tile exceeds it by
+                // more than 2^6 (terms stay <= 64, sums <= 2^16), i.e. after the first tile practically never, and the rescale
+                // of the 32 accumulator registers is skipped (wave-uniform test).  Softmax is invariant to the shift, and the
+                // backward pass recomputes the probabilities with the stored (shift, 1 / sum) pair.
+                if (__any(tm2 > m_run + 6.f)) {
+                    const float m_new = fmaxf(m_run, tm2);
+                    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+                    l_run *= alpha;
+                    m_run = m_new;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) { o0[e] *= alpha; o1[e] *= alpha; }
+                }
                 float ps = 0.f;
 #pragma unroll
-                for (int e = 0; e < 16; ++e) { sv[e] = __expf(sv[e] - m_new); ps += sv[e]; }
+                for (int e = 0; e < 16; ++e) { sv[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(raw[e], p.c1, -m_run)); ps += sv[e]; }
                 ps += __shfl_xor(ps, 32, 64);
-                l_run = l_run * alpha + ps;
-                m_run = m_new;
+                l_run += ps;
+                // Dropout: the 1 / (1 - p) factor is applied once, with the normalisation, in the epilogue
 #pragma unroll
-                for (int e = 0; e < 16; ++e) { o0[e] *= alpha; o1[e] *= alpha; }
-#pragma unroll
-                for (int e = 0; e < 16; ++e) bv[e] = MASKED ? (kp[e] ? sv[e] * p.dscale : 0.f) : sv[e];   // (y * noise) * 1/(1-p)
+                for (int e = 0; e < 16; ++e) bv[e] = MASKED ? (kp[e] ? sv[e] : 0.f) : sv[e];
             } else {
                 float pd[16];
+                const float inv_s = l_run * p.scale;                      // P * scale = e * (1/sum * scale)
+                const float inv_d = MASKED ? l_run * p.dscale : l_run;    // Pd = e * (1/sum * 1/(1-p)) where kept
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const float y = __expf(sv[e] * p.scale - m_run) * l_run;   // P, with the forward's final statistics
+                    const float ev = __builtin_amdgcn_exp2f(__builtin_fmaf(sv[e], p.c1, -m_run));  // exp(s*scale - shift), as the forward
                     const float gv = MASKED ? (kp[e] ? acc[e] : 0.f) : acc[e];  // DropoutBackward: g * noise
-                    bv[e] = (y * (gv - dot)) * p.scale;                          // SoftmaxBackward, MultiplicationBackwardLeft
-                    pd[e] = MASKED ? (kp[e] ? y * p.dscale : 0.f) : y;          // Dropout forward (for dV = Pd^T . dO)
+                    bv[e] = (ev * inv_s) * (gv - dot);                           // SoftmaxBackward, MultiplicationBackwardLeft
+                    pd[e] = MASKED ? (kp[e] ? ev * inv_d : 0.f) : ev * inv_d;    // Dropout forward (for dV = Pd^T . dO)
                 }
                 tile_store(scrw, bv, p.ds + rowbase + kt * 32, p.S, lane);
                 tile_store(scrw, pd, p.dropped + rowbase + kt * 32, p.S, lane);
@@ -285,10 +320,11 @@ __global__ __launch_bounds__(A_NT, OCC) void attention_kernel(const AttnArgs p) 
     float* orow = p.out + flat0 + (long long)row * p.ld + 4 * h;
     if (!BWD) {
         const float inv = 1.f / l_run;
+        const float io = MASKED ? inv * p.dscale : inv;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            *reinterpret_cast<float4*>(orow + 8 * c) = make_float4(o0[4 * c] * inv, o0[4 * c + 1] * inv, o0[4 * c + 2] * inv, o0[4 * c + 3] * inv);
-            *reinterpret_cast<float4*>(orow + 32 + 8 * c) = make_float4(o1[4 * c] * inv, o1[4 * c + 1] * inv, o1[4 * c + 2] * inv, o1[4 * c + 3] * inv);
+            *reinterpret_cast<float4*>(orow + 8 * c) = make_float4(o0[4 * c] * io, o0[4 * c + 1] * io, o0[4 * c + 2] * io, o0[4 * c + 3] * io);
+            *reinterpret_cast<float4*>(orow + 32 + 8 * c) = make_float4(o1[4 * c] * io, o1[4 * c + 1] * io, o1[4 * c + 2] * io, o1[4 * c + 3] * io);
         }
         if (h == 0) *reinterpret_cast<float2*>(p.stats + ((long long)bh * p.S + row) * 2) = make_float2(m_run, inv);
     } else {
@@ -315,8 +351,9 @@ unsigned keep_threshold(float keep) {
 
 bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-int attention_check(int B, int S, int H, int dh, double p, int train) {
+int attention_check(int B, int S, int H, int dh, double p, int train, float scale) {
     NK_CHECK(p >= 0.0 && p <= 1.0, "Wrong probability received: %g.", p);
+    NK_CHECK(scale > 0.f && scale < 1e30f, "fused attention needs a positive finite scale (the row max is taken before scaling), got %g", (double)scale);
     NK_CHECK(B > 0 && S > 0 && H > 0, "attention: non-positive geometry");
     NK_CHECK(nk_attention_supported(S, dh, p, train), "fused attention needs dh == 64, S %% 32 == 0 and p < 1 in training (S=%d dh=%d p=%g)", S, dh, p);
     NK_CHECK((long long)B * S * H * dh < (1ll << 31), "attention: the projection layout exceeds 2^31 elements");
@@ -326,7 +363,7 @@ int attention_check(int B, int S, int H, int dh, double p, int train) {
 template <bool BWD>
 int attention_launch(nk_device* dev, AttnArgs& a, int B, int S, int H, double p, int train, uint64_t seed, uint64_t offset, float scale) {
     a.S = S; a.H = H; a.ld = H * A_DH; a.nqb = (S + A_QB - 1) / A_QB; a.ntile = S / 32;
-    a.scale = scale; a.keep = (float)(1.0 - p); a.dscale = 1.f / (1.f - (float)p);  // as nk_scale_softmax_dropout_fwd
+    a.scale = scale; a.c1 = scale * 1.44269504088896341f; a.keep = (float)(1.0 - p); a.dscale = 1.f / (1.f - (float)p);  // as nk_scale_softmax_dropout_fwd
     a.seed = seed; a.offset = offset;
     a.keep_lt = keep_threshold(a.keep);
     const bool masked = train && p != 0.0;
@@ -359,33 +396,36 @@ int nk_attention_supported(int S, int dh, double p, int train) {
     return dh == A_DH && S > 0 && S % 32 == 0 && !(train && 1.0 - p == 0.0);
 }
 
-int nk_attention_fwd(nk_device* dev, const float* Q, const float* K, const float* V, float* scores, float* stats, float* O,
-                     int B, int S, int H, int dh, float scale, double p, int train, uint64_t seed, uint64_t offset) {
+int nk_attention_fwd(nk_device* dev, const float* Q, const float* K, const float* V, float* scores, float* stats,
+                     uint32_t* mask_bits, float* O, int B, int S, int H, int dh, float scale, double p, int train, uint64_t seed,
+                     uint64_t offset) {
     NK_USE(dev);
-    if (int rc = attention_check(B, S, H, dh, p, train)) return rc;
+    if (int rc = attention_check(B, S, H, dh, p, train, scale)) return rc;
     NK_CHECK(Q && K && V && scores && stats && O, "null pointer in nk_attention_fwd");
+    NK_CHECK(mask_bits || !(train && p != 0.0), "nk_attention_fwd: dropout is active, the mask_bits buffer is needed");
     NK_CHECK(al16(Q) && al16(K) && al16(V) && al16(scores) && al16(O) && al16(stats), "nk_attention_fwd needs 16-byte aligned buffers");
     nk_prof_start(dev, NK_KERNEL_ATTENTION, 4.0 * B * H * (double)S * S * dh);
     AttnArgs a{};
-    a.x1 = K; a.x2 = V; a.bq = Q; a.out = O; a.scores = scores; a.stats = stats;
+    a.x1 = K; a.x2 = V; a.bq = Q; a.out = O; a.scores = scores; a.stats = stats; a.maskbits = mask_bits;
     const int rc = attention_launch<false>(dev, a, B, S, H, p, train, seed, offset, scale);
     nk_prof_stop(dev);
     return rc;
 }
 
 int nk_attention_bwd(nk_device* dev, float* dQ, float* dS, float* dropped, const float* dO, const float* O, const float* scores,
-                     const float* stats, const float* K, const float* V, int B, int S, int H, int dh, float scale, double p,
-                     int train, uint64_t seed, uint64_t offset, int assign_dq) {
+                     const float* stats, const uint32_t* mask_bits, const float* K, const float* V, int B, int S, int H, int dh,
+                     float scale, double p, int train, int assign_dq) {
     NK_USE(dev);
-    if (int rc = attention_check(B, S, H, dh, p, train)) return rc;
+    if (int rc = attention_check(B, S, H, dh, p, train, scale)) return rc;
     NK_CHECK(dQ && dS && dropped && dO && O && scores && stats && K && V, "null pointer in nk_attention_bwd");
+    NK_CHECK(mask_bits || !(train && p != 0.0), "nk_attention_bwd: dropout is active, the forward's mask_bits are needed");
     NK_CHECK(al16(dQ) && al16(dS) && al16(dropped) && al16(dO) && al16(O) && al16(scores) && al16(stats) && al16(K) && al16(V),
              "nk_attention_bwd needs 16-byte aligned buffers");
     nk_prof_start(dev, NK_KERNEL_ATTENTION, 4.0 * B * H * (double)S * S * dh);
     AttnArgs a{};
     a.x1 = V; a.x2 = K; a.bq = dO; a.ctx = O; a.out = dQ; a.scores = const_cast<float*>(scores); a.ds = dS; a.dropped = dropped;
-    a.stats = const_cast<float*>(stats); a.assign = assign_dq ? 1 : 0;
-    const int rc = attention_launch<true>(dev, a, B, S, H, p, train, seed, offset, scale);
+    a.stats = const_cast<float*>(stats); a.maskbits = const_cast<uint32_t*>(mask_bits); a.assign = assign_dq ? 1 : 0;
+    const int rc = attention_launch<true>(dev, a, B, S, H, p, train, 0, 0, scale);
     nk_prof_stop(dev);
     return rc;
 }

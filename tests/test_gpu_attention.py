@@ -36,15 +36,16 @@ def _run(dev, B, S, H, p, train, seed, offset, assign, q, k, v, g, dq0):
     scale = float(np.float32(1.0 / np.sqrt(dh)))
     Q, K, V, G = (dev.array(t) for t in (q, k, v, g))
     scores, stats, out = dev.zeros((B * H, S, S)), dev.zeros((B * H, S, 2)), dev.zeros((B * S, H * dh))
-    c.attention_fwd(dev, Q, K, V, scores, stats, out, B, S, H, dh, scale, p, train, seed, offset)
+    bits = dev.zeros((B * H, S, S // 32))
+    c.attention_fwd(dev, Q, K, V, scores, stats, bits, out, B, S, H, dh, scale, p, train, seed, offset)
     dS, dropped, dQ = dev.zeros((B * H, S, S)), dev.zeros((B * H, S, S)), dev.array(dq0)
-    c.attention_bwd(dev, dQ, dS, dropped, G, out, scores, stats, K, V, B, S, H, dh, scale, p, train, seed, offset, assign)
+    c.attention_bwd(dev, dQ, dS, dropped, G, out, scores, stats, bits, K, V, B, S, H, dh, scale, p, train, assign)
     # the two products that stay batched GEMMs, as the tape node issues them
     dK, dV = dev.zeros((B * S, H * dh)), dev.zeros((B * S, H * dh))
     d, so, po, pi = H * dh, S * H * dh, H * S * S, S * S
     c.sgemm_batched(dev, 1, 0, S, dh, S, 1.0, dS, S, po, pi, Q, d, so, dh, 0.0, dK, d, so, dh, B, H)
     c.sgemm_batched(dev, 1, 0, S, dh, S, 1.0, dropped, S, po, pi, G, d, so, dh, 0.0, dV, d, so, dh, B, H)
-    return dict(scores=scores.numpy(), stats=stats.numpy(), out=out.numpy(), d_scores=dS.numpy(), dropped=dropped.numpy(),
+    return dict(scores=scores.numpy(), stats=stats.numpy(), out=out.numpy(), bits=bits.numpy().view(np.uint32), d_scores=dS.numpy(), dropped=dropped.numpy(),
                 dq=dQ.numpy(), dk=dK.numpy(), dv=dV.numpy()), (Q, K)
 
 
@@ -70,13 +71,20 @@ def test_attention_core_equals_oracle(dev, B, S, H, p, train):
     assert np.array_equal(got["scores"], ref_scores.numpy())
     _check(got["scores"], ref["scores"], ref32["scores"], "scores")
     assert np.array_equal(got["dropped"] == 0, noise == 0)   # dropped exactly where the mask says (no probability underflows here)
+    if masked:   # the packed draws the backward kernel reads: bit j of word t of a row = key 32 t + j kept
+        unpacked = ((got["bits"][..., None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(B * H, S, S)
+        assert np.array_equal(unpacked, noise != 0)
     for name in ("out", "dropped", "d_scores", "dk", "dv"):
         _check(got[name], ref[name], ref32[name], name)
     _check(got["dq"] - dq0, ref["dq"], ref32["dq"], "dq (accumulated)", floor=np.abs(dq0).max())
-    # row statistics: max of the scaled scores, reciprocal of the row sum
-    sc = ref["scores"] * np.float64(np.float32(1.0 / np.sqrt(dh)))
-    np.testing.assert_allclose(got["stats"][..., 0], sc.max(2), rtol=1e-6, atol=1e-6)
-    np.testing.assert_allclose(got["stats"][..., 1], 1.0 / np.exp(sc - sc.max(2, keepdims=True)).sum(2), rtol=1e-5)
+    # row statistics (shift m2 in log2 units, 1 / sum): together with the scores they reproduce the softmax
+    c1 = np.float64(np.float32(1.0 / np.sqrt(dh))) * np.log2(np.e)
+    sc2 = ref["scores"] * c1
+    m2, inv = got["stats"][..., 0].astype(np.float64), got["stats"][..., 1].astype(np.float64)
+    assert (m2 >= sc2.max(2) - 6.0 - 1e-4).all() and (m2 <= sc2.max(2) + 1e-4).all()     # a bound within 2^6, never above the max
+    z = ref["scores"] * np.float64(np.float32(1.0 / np.sqrt(dh)))
+    soft = np.exp(z - z.max(2, keepdims=True)); soft /= soft.sum(2, keepdims=True)
+    np.testing.assert_allclose(np.exp2(sc2 - m2[..., None]) * inv[..., None], soft, rtol=2e-5, atol=1e-9)
     # first-write form: dQ assigned, whatever the buffer held
     got2, _ = _run(dev, B, S, H, p, train, seed, offset, True, q, k, v, g, dq0)
     assert np.array_equal(got2["dq"] + dq0, got["dq"]) or np.abs(got2["dq"] + dq0 - got["dq"]).max() <= 1e-6 * np.abs(dq0).max()
@@ -110,6 +118,11 @@ def test_attention_core_rejects_what_it_cannot_do(dev):
     z = dev.zeros((64, 32))
     sc, st = dev.zeros((1, 64, 64)), dev.zeros((1, 64, 2))
     with pytest.raises(RuntimeError, match="fused attention needs"):
-        c.attention_fwd(dev, z, z, z, sc, st, z, 1, 64, 1, 32, 0.1, 0.0)
+        c.attention_fwd(dev, z, z, z, sc, st, None, z, 1, 64, 1, 32, 0.1, 0.0)
     with pytest.raises(RuntimeError, match="Wrong probability"):
-        c.attention_fwd(dev, z, z, z, sc, st, z, 1, 64, 1, 64, 0.1, 1.5)
+        c.attention_fwd(dev, z, z, z, sc, st, None, z, 1, 64, 1, 64, 0.1, 1.5)
+    z64 = dev.zeros((64, 64))
+    with pytest.raises(RuntimeError, match="mask_bits buffer is needed"):
+        c.attention_fwd(dev, z64, z64, z64, sc, st, None, z64, 1, 64, 1, 64, 0.1, 0.5)
+    with pytest.raises(RuntimeError, match="positive finite scale"):
+        c.attention_fwd(dev, z64, z64, z64, sc, st, None, z64, 1, 64, 1, 64, -0.1, 0.0)

@@ -54,12 +54,14 @@ def main():
         "_note": "HBM/fabric bytes per launch from rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in KB, separate runs; FETCH doubled "
                  "per MI355X_MICROARCH.md's gfx950 wide-read correction), launch-weighted means. sgemm_kernel: 4096^3, the NT / NN / TN "
                  "launches of benchmarks/gemm_once.py; conv: the three passes of the C3 module step (benchmarks/conv_step_once.py); "
-                 "mha_gemm: every sgemm_kernel launch of one C5 step (benchmarks/mha_step_once.py). Regenerate after a GEMM / conv "
+                 "mha_gemm: every sgemm_kernel launch of one C5 step (benchmarks/mha_step_once.py), attention: the forward and backward "
+                 "launches of the fused attention core in the same step. Regenerate after a GEMM / conv "
                  "change: bash tools/traffic_pmc.sh DIR && python tools/make_roofline_traffic.py DIR",
         "_measured_at_commit": commit,
         "sgemm_kernel": family("gemm_once", lambda k: k.startswith("sgemm_kernel")),
         "conv": family("conv_step_once", lambda k: k.startswith(("conv_fwd_fast", "conv_bwd_input_fast", "conv_bwd_kernel_kernel"))),
         "mha_gemm": family("mha_step_once", lambda k: k.startswith("sgemm_kernel")),
+        "attention": family("mha_step_once", lambda k: k.startswith("attention_kernel")),
     }
     json.dump(traffic, open(os.path.join(ROOT, "profiles", "roofline_traffic.json"), "w"), indent=1)
     print("| run | kernel | dispatches | fetched (x2) MB | written MB |\n|---|---|---:|---:|---:|")
