@@ -69,20 +69,23 @@ __device__ __forceinline__ void wave_lds_handover() {
 }
 
 // registers (lane = query q, half h, 16 consecutive keys 16h..16h+15) -> 32 x 32 tile of a row-major (.., S) tensor, as
-// 128-byte row segments (8 lanes x 16 B) instead of 64 scattered 16-byte pieces per store instruction
-__device__ __forceinline__ void tile_store(float* scrw, const float (&v)[16], float* g /* &T[row0][kt*32] */, int S, int lane) {
+// 128-byte row segments (8 lanes x 16 B) instead of 64 scattered 16-byte pieces per store instruction.  Two halves, issued
+// far apart: the tile goes to the wave's LDS scratch as soon as it is computed, and is read back and stored to HBM after
+// the second MFMA product of the iteration - the ds_write -> ds_read round trip (a few hundred cycles, and there are only
+// two or three waves per SIMD to hide it) then runs under 32 MFMAs instead of stalling the wave.
+__device__ __forceinline__ void tile_write(float* scrw, const float (&v)[16], int lane) {
     const int q = lane & 31, h = lane >> 5;
 #pragma unroll
     for (int c = 0; c < 4; ++c)
         *reinterpret_cast<float4*>(&scrw[q * SCR_LD + 16 * h + 4 * c]) = make_float4(v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]);
-    wave_lds_handover();
+}
+__device__ __forceinline__ void tile_flush(const float* scrw, float* g /* &T[row0][kt*32] */, int S, int lane) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = 8 * i + (lane >> 3), c = 4 * (lane & 7);
         const float4 t = *reinterpret_cast<const float4*>(&scrw[r * SCR_LD + c]);
         nk_store_stream(reinterpret_cast<float4*>(g + (long long)r * S + c), t);
     }
-    wave_lds_handover();
 }
 
 // FULL: S is a multiple of 128, every wave of every block has queries.  Not a micro-optimisation: with a run-time `on`
@@ -93,7 +96,7 @@ template <bool BWD, bool MASKED, bool FULL, int OCC>
 __global__ __launch_bounds__(A_NT, OCC) void attention_kernel(const AttnArgs p) {
     __shared__ __attribute__((aligned(16))) float x1s[2][32 * X1_LD];
     __shared__ __attribute__((aligned(16))) float x2s[2][32 * X2_LD];
-    __shared__ __attribute__((aligned(16))) float scr[A_NT / 64][32 * SCR_LD];
+    __shared__ __attribute__((aligned(16))) float scr[A_NT / 64][(BWD ? 2 : 1) * 32 * SCR_LD];  // per wave: tile scratch (backward: dS | Pd)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int q = lane & 31, h = lane >> 5;
     // blocks of one (sample, head) are consecutive in the sequence and one XCD takes a contiguous chunk of it: the 512 KB
@@ -165,6 +168,7 @@ __global__ __launch_bounds__(A_NT, OCC) void attention_kernel(const AttnArgs p) 
     const uint2 key = make_uint2((unsigned)p.seed, (unsigned)(p.seed >> 32));
     const unsigned long long ctr0 = (unsigned long long)(rowbase + (long long)q * p.S) / 4 + 4 * h + p.offset;
     float* scrw = scr[w];
+    float* scrb = scrw + (BWD ? 32 * SCR_LD : 0);
     // backward: the score tile of the NEXT iteration, in the coalesced load layout (lane -> rows 8i + lane/8, 16 B each)
     float4 sn0, sn1, sn2, sn3;
     unsigned mkn = 0;  // and this row's 32 dropout bits of that tile
@@ -179,9 +183,18 @@ __global__ __launch_bounds__(A_NT, OCC) void attention_kernel(const AttnArgs p) 
         if (MASKED) mkn = mload[KT];                                                             \
     } while (0)
 
+#define A_SCORES_TO_LDS()                                                                        \
+    do {                                                                                         \
+        float* sw_ = &scrw[(lane >> 3) * SCR_LD + 4 * (lane & 7)];                               \
+        *reinterpret_cast<float4*>(sw_) = sn0;                                                   \
+        *reinterpret_cast<float4*>(sw_ + 8 * SCR_LD) = sn1;                                      \
+        *reinterpret_cast<float4*>(sw_ + 16 * SCR_LD) = sn2;                                     \
+        *reinterpret_cast<float4*>(sw_ + 24 * SCR_LD) = sn3;                                     \
+    } while (0)
     A_STAGE_LOAD(0);
     if (BWD && on) A_SCORES_LOAD(0);
     A_STAGE_STORE(0);
+    if (BWD && on) A_SCORES_TO_LDS();
     // every prologue load has landed: without this the compiler's wait-count bookkeeping carries the per-query operand's
     // loads into the loop and waits for the NEXT tile's staging loads in the middle of pass 1, every iteration
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
@@ -194,20 +207,13 @@ __global__ __launch_bounds__(A_NT, OCC) void attention_kernel(const AttnArgs p) 
         if (on) {
             float sv[16];
             unsigned mybits = 0;
-            if (BWD) {  // score tile -> lane layout, then fetch the next one
+            if (BWD) {  // score tile (put into the scratch at the end of the previous iteration) -> lane layout; fetch the next one
                 if (MASKED) mybits = mkn >> (16 * h);
-                float* sw = &scrw[(lane >> 3) * SCR_LD + 4 * (lane & 7)];
-                *reinterpret_cast<float4*>(sw) = sn0;
-                *reinterpret_cast<float4*>(sw + 8 * SCR_LD) = sn1;
-                *reinterpret_cast<float4*>(sw + 16 * SCR_LD) = sn2;
-                *reinterpret_cast<float4*>(sw + 24 * SCR_LD) = sn3;
-                wave_lds_handover();
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const float4 t = *reinterpret_cast<const float4*>(&scrw[q * SCR_LD + 16 * h + 4 * c]);
                     sv[4 * c] = t.x; sv[4 * c + 1] = t.y; sv[4 * c + 2] = t.z; sv[4 * c + 3] = t.w;
                 }
-                wave_lds_handover();
                 if (more) A_SCORES_LOAD(kt + 1);
             }
             // ---- pass 1: C[key][query] = X1 . Bq^T  (forward: scores; backward: dPd) -------------------------------
@@ -254,7 +260,7 @@ __global__ __launch_bounds__(A_NT, OCC) void attention_kernel(const AttnArgs p) 
                 float raw[16];
 #pragma unroll
                 for (int e = 0; e < 16; ++e) raw[e] = acc[e];
-                tile_store(scrw, raw, p.scores + rowbase + kt * 32, p.S, lane);
+                tile_write(scrw, raw, lane);
                 // Online softmax in the base-2 exponent domain: exp(s*scale - m) = exp2(s*c1 - m2), c1 = scale*log2(e), one fma
                 // and one v_exp_f32 per element.  f32 MFMA and VALU instructions do NOT overlap on a SIMD (measured,
                 // benchmarks/native/mfma_valu_overlap.hip: both run on the f32 lanes), so every VALU instruction here is
@@ -295,8 +301,8 @@ __global__ __launch_bounds__(A_NT, OCC) void attention_kernel(const AttnArgs p) 
                     bv[e] = (ev * inv_s) * (gv - dot);                           // SoftmaxBackward, MultiplicationBackwardLeft
                     pd[e] = MASKED ? (kp[e] ? ev * inv_d : 0.f) : ev * inv_d;    // Dropout forward (for dV = Pd^T . dO)
                 }
-                tile_store(scrw, bv, p.ds + rowbase + kt * 32, p.S, lane);
-                tile_store(scrw, pd, p.dropped + rowbase + kt * 32, p.S, lane);
+                tile_write(scrw, bv, lane);   // (the score tile was read out of this region at the top of the iteration)
+                tile_write(scrb, pd, lane);
             }
             // ---- pass 2: out^T[dh][query] += X2^T . C ----------------------------------------------------------------
             {
@@ -308,6 +314,17 @@ __global__ __launch_bounds__(A_NT, OCC) void attention_kernel(const AttnArgs p) 
                     o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a21[e * X2_LD], bv[e], o1, 0, 0, 0);
                 }
             }
+            // ---- the tiles written to the scratch before pass 2 go to HBM now (machine scheduler pinned: hoisting the
+            //      ds_reads above the MFMAs would put the LDS round trip back on the critical path) ---------------------
+            __builtin_amdgcn_sched_barrier(0);
+            wave_lds_handover();
+            if (!BWD) {
+                tile_flush(scrw, p.scores + rowbase + kt * 32, p.S, lane);
+            } else {
+                tile_flush(scrw, p.ds + rowbase + kt * 32, p.S, lane);
+                tile_flush(scrb, p.dropped + rowbase + kt * 32, p.S, lane);
+                if (more) { wave_lds_handover(); A_SCORES_TO_LDS(); }   // next tile's scores (loaded during this iteration)
+            }
         }
         if (more) A_STAGE_STORE(cur ^ 1);
         __syncthreads();
@@ -315,6 +332,7 @@ __global__ __launch_bounds__(A_NT, OCC) void attention_kernel(const AttnArgs p) 
 #undef A_STAGE_LOAD
 #undef A_STAGE_STORE
 #undef A_SCORES_LOAD
+#undef A_SCORES_TO_LDS
     if (!on) return;
     // ---- epilogue: lane (query q, half h) owns dh = 32 d + 8 c + 4 h + {0..3} ----------------------------------------
     float* orow = p.out + flat0 + (long long)row * p.ld + 4 * h;
@@ -369,8 +387,9 @@ int attention_launch(nk_device* dev, AttnArgs& a, int B, int S, int H, double p,
     const bool masked = train && p != 0.0;
     const dim3 grid((unsigned)(B * H * a.nqb)), block(A_NT);
     const bool full = S % A_QB == 0;
-    // OCC = blocks per CU the register budget is sized for (52 KB of LDS per block allows three): the forward fits 168
-    // VGPRs without spilling, the backward (two more 16-register tiles live) does not
+    // OCC = blocks per CU the register budget is sized for.  Three forward blocks fit by LDS (52 KB each) at <= 168 VGPRs:
+    // the masked forward then spills five registers and is still 5 % faster than two blocks at 200 VGPRs (1.42 vs 1.50 ms
+    // at C5); the backward holds 70 KB of LDS per block, two blocks per CU.
     static const int occ_env = [] { const char* e = getenv("NK_ATTN_OCC"); return e ? atoi(e) : 0; }();   // tuning aid
     constexpr int OCC_DEFAULT = BWD ? 2 : 3;
     const int occ = BWD ? 2 : (occ_env == 2 || occ_env == 3 ? occ_env : OCC_DEFAULT);
