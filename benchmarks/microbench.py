@@ -22,10 +22,24 @@ MFMA_F32_PEAK = 157.3e12
 HBM_PEAK = 8.0e12
 
 
-def timeit(dev, fn, iters, warmup=3):
-    for _ in range(warmup):
-        fn()
+def timeit(dev, fn, iters, warmup=3, settle_ms=80.0, min_ms=40.0):
+    """ms per call.  An MI355X that has been idle needs ~50 ms of load before its clocks settle - a measurement taken right
+    after a pause (or after a different, lighter kernel) reads 10 - 15 % slow (benchmarks/nn_via_nt.py: the same 4096^3
+    launch 1094 us measured first, 1000 us measured last) - so every measurement first runs the kernel for `settle_ms`,
+    then times at least `iters` calls and at least `min_ms` of work."""
     e0, e1 = dev.event(), dev.event()
+    e0.record()
+    calls = 0
+    while True:
+        for _ in range(max(1, warmup)):
+            fn()
+        calls += max(1, warmup)
+        e1.record()
+        e1.sync()
+        spent = e0.elapsed_ms(e1)
+        if spent >= settle_ms:
+            break
+    iters = max(iters, int(min_ms / max(spent / calls, 1e-4)) + 1)
     e0.record()
     for _ in range(iters):
         fn()
