@@ -6,6 +6,7 @@ set -u
 out=$1
 cd /tmp && export TMPDIR=/tmp
 root=${GRAFT_REPO_ROOT:-/root/repo}
+mkdir -p "$root/$out"
 for tgt in gemm_once conv_step_once mha_step_once; do
   for c in FETCH_SIZE WRITE_SIZE; do
     timeout -k 5 120 rocprofv3 --pmc $c --kernel-trace -d "$root/$out/$tgt/$c" -o r -- python "$root/benchmarks/$tgt.py" > "$root/$out/${tgt}_$c.log" 2>&1 || echo "FAILED $tgt $c"
