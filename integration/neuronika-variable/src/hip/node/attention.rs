@@ -1,0 +1,128 @@
+use std::cell::Cell;
+use std::rc::Rc;
+
+use ndarray::{Ix2, Ix3};
+
+use crate::{
+    autograd::{Backward, Forward},
+    gradient::Gradient,
+    hip::{ffi, hiparray::HipArray},
+    utils::Shared,
+};
+
+/// Geometry of the composed multi-head attention (SURVEY.md 8a note): `batch` samples of `seq` rows, `heads` heads of
+/// `dh` columns inside the `(batch*seq, heads*dh)` projection layout.
+#[derive(Clone, Copy)]
+pub(crate) struct Heads {
+    pub batch: i32,
+    pub seq: i32,
+    pub heads: i32,
+    pub dh: i32,
+}
+
+/// Buffers the forward and backward node share, like `Dropout`'s noise buffer (`var.rs:375-393`).
+pub(crate) struct AttentionState {
+    pub scores: Shared<HipArray<Ix3>>,    // (batch*heads, seq, seq) raw scores
+    pub stats: Shared<HipArray<Ix3>>,     // (batch*heads, seq, 2)
+    pub mask_bits: Shared<HipArray<Ix3>>, // (batch*heads, seq, seq/32) u32 words in an f32 buffer
+    pub calls: Cell<u64>,                 // forwards so far: each one draws a fresh Philox range
+}
+
+/// One node for `mm_t` -> scalar `multiplication` -> `softmax` -> `dropout` -> `mm` per (sample, head):
+/// `nk_attention_fwd`.  Use `ffi::nk_attention_supported(seq, dh, p, 1) != 0` to decide between this node and the five
+/// reference nodes on `chunk` tiles.
+pub(crate) struct HeadsAttention {
+    geometry: Heads,
+    queries: Shared<HipArray<Ix2>>,
+    keys: Shared<HipArray<Ix2>>,
+    values: Shared<HipArray<Ix2>>,
+    state: Rc<AttentionState>,
+    data: Shared<HipArray<Ix2>>,
+    scale: f32,
+    p: f64,
+    status: Rc<Cell<bool>>,
+    seed: u64,
+}
+
+impl HeadsAttention {
+    #[allow(clippy::too_many_arguments)]
+    pub(crate) fn new(geometry: Heads, queries: Shared<HipArray<Ix2>>, keys: Shared<HipArray<Ix2>>, values: Shared<HipArray<Ix2>>,
+                      state: Rc<AttentionState>, data: Shared<HipArray<Ix2>>, scale: f32, p: f64, status: Rc<Cell<bool>>,
+                      seed: u64) -> Self {
+        if !(0. ..=1.).contains(&p) {
+            panic!("Wrong probability received: {}.", p);
+        }
+        Self { geometry, queries, keys, values, state, data, scale, p, status, seed }
+    }
+}
+
+impl Forward for HeadsAttention {
+    fn forward(&self) {
+        let (q, k, v) = (self.queries.borrow(), self.keys.borrow(), self.values.borrow());
+        let (mut scores, mut stats, mut bits) = (self.state.scores.borrow_mut(), self.state.stats.borrow_mut(), self.state.mask_bits.borrow_mut());
+        let mut out = self.data.borrow_mut();
+        let h = self.geometry;
+        let elems = (h.batch as u64) * (h.heads as u64) * (h.seq as u64) * (h.seq as u64);
+        let offset = self.state.calls.get() * ((elems + 3) / 4);
+        self.state.calls.set(self.state.calls.get() + 1);
+        ffi::check(unsafe {
+            ffi::nk_attention_fwd(q.device().as_raw(), q.as_ptr(), k.as_ptr(), v.as_ptr(), scores.as_mut_ptr(), stats.as_mut_ptr(),
+                                  bits.as_mut_ptr() as *mut u32, out.as_mut_ptr(), h.batch, h.seq, h.heads, h.dh, self.scale, self.p,
+                                  self.status.get() as i32, self.seed, offset)
+        });
+    }
+}
+
+/// The matching backward entry: `nk_attention_bwd` (dS, Pd, dQ) and the two products that reduce over the queries,
+/// `dK_bh += dS_bh^T . Q_bh` and `dV_bh += Pd_bh^T . dO_bh`, as strided batched GEMMs on the projection layout.
+pub(crate) struct HeadsAttentionBackward {
+    geometry: Heads,
+    queries: Shared<HipArray<Ix2>>,
+    keys: Shared<HipArray<Ix2>>,
+    values: Shared<HipArray<Ix2>>,
+    output: Shared<HipArray<Ix2>>,
+    state: Rc<AttentionState>,
+    d_scores: Shared<HipArray<Ix3>>, // scratch written here
+    dropped: Shared<HipArray<Ix3>>,  // scratch written here
+    queries_gradient: Rc<Gradient<HipArray<Ix2>, Ix2>>,
+    keys_gradient: Rc<Gradient<HipArray<Ix2>, Ix2>>,
+    values_gradient: Rc<Gradient<HipArray<Ix2>, Ix2>>,
+    gradient: Rc<Gradient<HipArray<Ix2>, Ix2>>,
+    scale: f32,
+    p: f64,
+    status: Rc<Cell<bool>>,
+}
+
+impl Backward for HeadsAttentionBackward {
+    fn backward(&self) {
+        let g = self.gradient.borrow();
+        let (q, k, v, o) = (self.queries.borrow(), self.keys.borrow(), self.values.borrow(), self.output.borrow());
+        let (scores, stats, bits) = (self.state.scores.borrow(), self.state.stats.borrow(), self.state.mask_bits.borrow());
+        let (mut ds, mut pd) = (self.d_scores.borrow_mut(), self.dropped.borrow_mut());
+        let h = self.geometry;
+        let dev = g.device().as_raw();
+        let (d, so, po, pi) = (h.heads * h.dh, (h.seq * h.heads * h.dh) as i64, (h.heads * h.seq * h.seq) as i64, (h.seq * h.seq) as i64);
+        {
+            let mut dq = self.queries_gradient.borrow_mut();
+            ffi::check(unsafe {
+                ffi::nk_attention_bwd(dev, dq.as_mut_ptr(), ds.as_mut_ptr(), pd.as_mut_ptr(), g.as_ptr(), o.as_ptr(), scores.as_ptr(),
+                                      stats.as_ptr(), bits.as_ptr() as *const u32, k.as_ptr(), v.as_ptr(), h.batch, h.seq, h.heads, h.dh,
+                                      self.scale, self.p, self.status.get() as i32, 0)
+            });
+        }
+        {
+            let mut dk = self.keys_gradient.borrow_mut();
+            ffi::check(unsafe {
+                ffi::nk_sgemm_batched(dev, 1, 0, h.seq, h.dh, h.seq, 1., ds.as_ptr(), h.seq, po, pi, q.as_ptr(), d, so, h.dh as i64, 1.,
+                                      dk.as_mut_ptr(), d, so, h.dh as i64, h.batch, h.heads)
+            });
+        }
+        {
+            let mut dv = self.values_gradient.borrow_mut();
+            ffi::check(unsafe {
+                ffi::nk_sgemm_batched(dev, 1, 0, h.seq, h.dh, h.seq, 1., pd.as_ptr(), h.seq, po, pi, g.as_ptr(), d, so, h.dh as i64, 1.,
+                                      dv.as_mut_ptr(), d, so, h.dh as i64, h.batch, h.heads)
+            });
+        }
+    }
+}

@@ -2,7 +2,8 @@
 //! point, the reference method it replaces).  The structs hold the same `Shared` operand / output handles as the
 //! reference's ndarray nodes (`node/*/mod.rs`), so graph construction code is unchanged.  Written here: the nodes of
 //! the BASELINE configurations (MatMul / MatMulT, Convolution, broadcast binaries, ReLU, Softmax, Dropout, Sum,
-//! SquaredError); the remaining ones follow the same two-line pattern.
+//! SquaredError, and the fused attention core of the composed MHA); the remaining ones follow the same two-line pattern.
+mod attention;
 mod binary_op;
 mod convolution;
 mod matrix_matrix_mul;
@@ -10,6 +11,7 @@ mod matrix_matrix_mul_t;
 mod pointwise;
 mod reduction;
 
+pub(crate) use attention::*;
 pub(crate) use binary_op::*;
 pub(crate) use convolution::*;
 pub(crate) use matrix_matrix_mul::*;
