@@ -398,7 +398,7 @@ int nk_scale_softmax_dropout_bwd_from_scores(nk_device* dev, float* d_scores, co
  *   S_bh = Q_bh.K_bh^T ; P = softmax(S*scale, axis 1) ; Pd = dropout(P) ; O_bh = Pd.V_bh
  * Q, K, V, O, dO, dQ are the (B*S) x (H*dh) projection layout (head h = columns h*dh .. h*dh+dh-1, sample b = rows
  * b*S ..); scores / dS / dropped are (B*H, S, S); stats is (B*H, S, 2) = (m2, 1 / sum_k exp2(S*c1 - m2)) per row with
- * c1 = scale*log2(e) and m2 an upper bound (within 2^6) of the row's S*c1: P = exp2(S*c1 - m2) * stats[..,1].  scale > 0.
+ * c1 = scale*log2(e) and the shift m2 in [max_k S*c1 - 6, max_k S*c1]: P = exp2(S*c1 - m2) * stats[..,1].  scale > 0.
  * The score tile stays on chip between the two products (online softmax forward, recomputed probabilities backward).
  * Dropout mask: the Philox stream of nk_scale_softmax_dropout_fwd (same seed / offset -> same mask).
  * nk_attention_supported: dh == 64, S % 32 == 0, not (train and p == 1); callers fall back to the node-by-node path. */

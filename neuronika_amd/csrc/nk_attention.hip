@@ -20,11 +20,12 @@
 // registers are 16 CONSECUTIVE keys: the Philox counter of the existing row kernels (4 consecutive elements per draw)
 // and 64-byte runs towards HBM fall out of that.
 //
-// The forward uses the online softmax (running max / sum, the out accumulator rescaled when the max moves) and stores the
-// final row max and 1 / sum; the backward recomputes P = exp(S * scale - max) / sum from the stored scores with those.
-// Against the node-by-node composition this changes the order of the row sum and replaces two divisions by a reciprocal
-// and a product - inside the f32 tolerance of SURVEY.md 8c (ii), checked against the oracle, not bit-equal to the
-// three-node path.
+// The forward uses the online softmax in the base-2 exponent domain (running shift m2 and sum of exp2(s*c1 - m2), c1 =
+// scale * log2(e); the shift follows the running maximum lazily - it only has to keep the exponents <= 6 - and the out
+// accumulator is rescaled when it moves) and stores (m2, 1 / sum) per row; the backward recomputes
+// P = exp2(S * c1 - m2) / sum from the stored scores with those.  Against the node-by-node composition this changes the order
+// of the row sum and replaces two divisions by a reciprocal and a product - inside the f32 tolerance of SURVEY.md 8c (ii),
+// checked against the oracle, not bit-equal to the three-node path.
 #include <cmath>
 #include <cstdlib>
 
@@ -51,7 +52,7 @@ struct AttnArgs {
     float* ds;         // backward: dS
     float* dropped;    // backward: Pd
     unsigned* maskbits;  // (B*H, S, S/32): the dropout draws, 1 bit per score (bit 16h + e of word kt = key 32 kt + 16 h + e kept): written forward, read backward
-    float* stats;      // (B*H, S, 2): the shift m2 (an upper bound of the scaled scores, in log2 units) and 1 / sum_k exp2(s*c1 - m2)
+    float* stats;      // (B*H, S, 2): the shift m2 (log2 units; row max of s*c1 minus at most 6) and 1 / sum_k exp2(s*c1 - m2)
     int S, H, ld, nqb, ntile;
     float scale, keep, dscale;
     float c1;          // scale * log2(e): exponents are taken in base 2
