@@ -734,10 +734,12 @@ struct HeadsAttentionFwd : Forward {
     uint64_t seed;
     Shared<uint64_t> calls;  // each forward draws a fresh mask (the Philox offset advances), as AttnProbsFwd
     void forward() const override {
-        const uint64_t offset = (*calls) * ((scores->len() + 3) / 4);
+        const uint64_t offset = (*calls) * (((uint64_t)hg.B * hg.H * hg.S * hg.S + 3) / 4);  // (B*H, S, S) draws per forward
         ++(*calls);
-        check(nk_attention_fwd(D(q), q->ptr(), k->ptr(), v->ptr(), scores->ptr(), stats->ptr(), reinterpret_cast<uint32_t*>(mask->ptr()),
-                               o->ptr(), hg.B, hg.S, hg.H, hg.dh, scale, p, *status ? 1 : 0, seed, offset));
+        // scores / stats / mask are null in a graph without gradients: nothing is kept, no (B*H, S, S) tensor exists
+        check(nk_attention_fwd(D(q), q->ptr(), k->ptr(), v->ptr(), scores ? scores->ptr() : nullptr, stats ? stats->ptr() : nullptr,
+                               mask ? reinterpret_cast<uint32_t*>(mask->ptr()) : nullptr, o->ptr(), hg.B, hg.S, hg.H, hg.dh, scale, p,
+                               *status ? 1 : 0, seed, offset));
     }
 };
 struct HeadsAttentionBwd : Backward {
@@ -1197,31 +1199,37 @@ VarDiff VarDiff::heads_context(const VarDiff& values, int B, int S, int H, int d
     return VarDiff::node(std::move(out), g, entry(bw, g), std::move(h));
 }
 bool Var::attention_core_supported(int S, int dh, double p) { return nk_attention_supported(S, dh, p, 1) != 0; }
-Var Var::heads_attention(const Var& keys, const Var& values, int B, int S, int H, int dh, float scale, double p,
-                         Shared<bool> status) const {
+static Var heads_attention_node(const Var& q, const Var& keys, const Var& values, int B, int S, int H, int dh, float scale, double p,
+                                Shared<bool> status, bool keep) {
     if (!(p >= 0.0 && p <= 1.0)) panic("Wrong probability received: " + std::to_string(p) + ".");
-    check_heads(shape(), {}, B, S, H, dh, false);
+    check_heads(q.shape(), {}, B, S, H, dh, false);
     check_heads(keys.shape(), {}, B, S, H, dh, false);
     check_heads(values.shape(), {}, B, S, H, dh, false);
-    if (!attention_core_supported(S, dh, p)) panic("heads_attention: the fused kernels take dh == 64, S % 32 == 0 and p < 1");
-    History<ForwardEntry> h = history;
+    if (!Var::attention_core_supported(S, dh, p)) panic("heads_attention: the fused kernels take dh == 64, S % 32 == 0 and p < 1");
+    History<ForwardEntry> h = q.history;
     h.merge(keys.history);
     h.merge(values.history);
     auto op = std::make_shared<HeadsAttentionFwd>();
-    op->hg = {B, S, H, dh}; op->q = data; op->k = keys.data; op->v = values.data;
-    op->scores = zeros_like(data, Shape{B * H, S, S});
-    op->stats = zeros_like(data, Shape{B * H, S, 2});
-    op->mask = zeros_like(data, Shape{B * H, S, S / 32});
-    op->o = zeros_like(data, Shape{B * S, H * dh});
+    op->hg = {B, S, H, dh}; op->q = q.data; op->k = keys.data; op->v = values.data;
+    if (keep) {  // what the backward node reads; a graph without gradients keeps nothing
+        op->scores = zeros_like(q.data, Shape{B * H, S, S});
+        op->stats = zeros_like(q.data, Shape{B * H, S, 2});
+        op->mask = zeros_like(q.data, Shape{B * H, S, S / 32});
+    }
+    op->o = zeros_like(q.data, Shape{B * S, H * dh});
     op->scale = scale; op->p = p; op->status = std::move(status);
     op->seed = next_node_seed();
     op->calls = std::make_shared<uint64_t>(0);
     auto y = op->o;
     return Var::node(y, op, std::move(h));
 }
+Var Var::heads_attention(const Var& keys, const Var& values, int B, int S, int H, int dh, float scale, double p,
+                         Shared<bool> status) const {
+    return heads_attention_node(*this, keys, values, B, S, H, dh, scale, p, std::move(status), false);
+}
 VarDiff VarDiff::heads_attention(const VarDiff& keys, const VarDiff& values, int B, int S, int H, int dh, float scale, double p,
                                  Shared<bool> status) const {
-    Var out = var.heads_attention(keys.var, values.var, B, S, H, dh, scale, p, status);
+    Var out = heads_attention_node(var, keys.var, values.var, B, S, H, dh, scale, p, status, true);
     auto fwd = std::dynamic_pointer_cast<HeadsAttentionFwd>(out.history.to_vec().back().op);
     History<BackwardEntry> h = history;
     h.merge(keys.history);

@@ -77,6 +77,9 @@ PYBIND11_MODULE(_tape, m) {
         .def("mm", py::overload_cast<const VarDiff&>(&Var::mm, py::const_))
         .def("mm_t", py::overload_cast<const Var&>(&Var::mm_t, py::const_))
         .def("mm_t", py::overload_cast<const VarDiff&>(&Var::mm_t, py::const_))
+        .def("heads_attention", [](const Var& q, const Var& k, const Var& v, int B, int S, int H, int dh, float scale, double p, const Status& s) {
+            return q.heads_attention(k, v, B, S, H, dh, scale, p, s.flag); })
+        .def_static("attention_core_supported", &Var::attention_core_supported)
         .def("convolution", &Var::convolution)
         .def("__add__", [](const Var& a, const Var& b) { return a + b; })
         .def("__add__", [](const Var& a, const VarDiff& b) { return a + b; })
@@ -129,6 +132,8 @@ PYBIND11_MODULE(_tape, m) {
         .def("mm", py::overload_cast<const VarDiff&>(&VarDiff::mm, py::const_))
         .def("mm_t", py::overload_cast<const Var&>(&VarDiff::mm_t, py::const_))
         .def("mm_t", py::overload_cast<const VarDiff&>(&VarDiff::mm_t, py::const_))
+        .def("heads_attention", [](const VarDiff& q, const VarDiff& k, const VarDiff& v, int B, int S, int H, int dh, float scale, double p, const Status& s) {
+            return q.heads_attention(k, v, B, S, H, dh, scale, p, s.flag); })
         .def("convolution", py::overload_cast<const Var&, const std::vector<int>&, const std::vector<int>&, int>(&VarDiff::convolution, py::const_))
         .def("convolution", py::overload_cast<const VarDiff&, const std::vector<int>&, const std::vector<int>&, int>(&VarDiff::convolution, py::const_))
         .def("__add__", [](const VarDiff& a, const Var& b) { return a + b; })

@@ -404,7 +404,8 @@ int nk_scale_softmax_dropout_bwd_from_scores(nk_device* dev, float* d_scores, co
  * nk_attention_supported: dh == 64, S % 32 == 0, not (train and p == 1); callers fall back to the node-by-node path. */
 int nk_attention_supported(int S, int dh, double p, int train);
 /* forward: writes the raw scores (for the backward pass), the row statistics, the dropout draws (1 bit per score,
- * (B*H, S, S/32) words; may be NULL when dropout is inactive) and O */
+ * (B*H, S, S/32) words; may be NULL when dropout is inactive) and O.  `scores` = `stats` = NULL: inference, nothing is
+ * kept for a backward pass (O only: no (B*H, S, S) tensor exists at all). */
 int nk_attention_fwd(nk_device* dev, const float* Q, const float* K, const float* V, float* scores, float* stats,
                      uint32_t* mask_bits, float* O, int B, int S, int H, int dh, float scale, double p, int train,
                      uint64_t seed, uint64_t offset);

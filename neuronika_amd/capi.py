@@ -576,8 +576,9 @@ def attention_supported(S, dh, p, train=True):
 
 def attention_fwd(dev, Q, K, V, scores, stats, mask_bits, out, B, S, H, dh, scale, p, train=True, seed=0, offset=0):
     """Fused attention core: scores (B*H,S,S), stats (B*H,S,2), mask_bits (B*H,S,S/32 words held in an f32 array; None
-    when dropout is inactive) and out (B*S,H*dh) are written."""
-    check(lib.nk_attention_fwd(dev.h, Q.p, K.p, V.p, scores.p, stats.p, mask_bits.p if mask_bits is not None else None, out.p,
+    when dropout is inactive) and out (B*S,H*dh) are written.  scores = stats = None: inference (out only)."""
+    check(lib.nk_attention_fwd(dev.h, Q.p, K.p, V.p, scores.p if scores is not None else None, stats.p if stats is not None else None,
+                               mask_bits.p if mask_bits is not None else None, out.p,
                                B, S, H, dh, scale, float(p), int(train), seed, offset))
 
 

@@ -93,7 +93,9 @@ __device__ __forceinline__ void tile_flush(const float* scrw, float* g /* &T[row
 // the loop body sits under a branch, the compiler's wait-count bookkeeping merges the two paths at the join and waits for
 // ALL outstanding vector memory operations (the tile stores just issued included) before the staged tile may go to LDS;
 // with the branch gone it waits for exactly the staging loads and the stores drain under the next tile's MFMAs.
-template <bool BWD, bool MASKED, bool FULL, int OCC>
+// KEEP (forward only): write what the backward pass needs (scores, row statistics, dropout bits).  false = inference: O only,
+// 2.1 GB of stores and the buffers themselves disappear.
+template <bool BWD, bool MASKED, bool FULL, int OCC, bool KEEP = true>
 __global__ __launch_bounds__(A_NT, OCC) void attention_kernel(const AttnArgs p) {
     __shared__ __attribute__((aligned(16))) float x1s[2][32 * X1_LD];
     __shared__ __attribute__((aligned(16))) float x2s[2][32 * X2_LD];
@@ -250,7 +252,7 @@ __global__ __launch_bounds__(A_NT, OCC) void attention_kernel(const AttnArgs p) 
 #pragma unroll
                 for (int e = 0; e < 16; ++e) bits |= kp[e] ? (1u << e) : 0u;
                 const unsigned other = (unsigned)__shfl_xor((int)bits, 32, 64);
-                if (h == 0) p.maskbits[((long long)bh * p.S + row) * p.ntile + kt] = bits | (other << 16);
+                if (KEEP && h == 0) p.maskbits[((long long)bh * p.S + row) * p.ntile + kt] = bits | (other << 16);
             }
             if (MASKED && BWD) {
 #pragma unroll
@@ -261,7 +263,7 @@ __global__ __launch_bounds__(A_NT, OCC) void attention_kernel(const AttnArgs p) 
                 float raw[16];
 #pragma unroll
                 for (int e = 0; e < 16; ++e) raw[e] = acc[e];
-                tile_write(scrw, raw, lane);
+                if (KEEP) tile_write(scrw, raw, lane);
                 // Online softmax in the base-2 exponent domain: exp(s*scale - m) = exp2(s*c1 - m2), c1 = scale*log2(e), one fma
                 // and one v_exp_f32 per element.  f32 MFMA and VALU instructions do NOT overlap on a SIMD (measured,
                 // benchmarks/native/mfma_valu_overlap.hip: both run on the f32 lanes), so every VALU instruction here is
@@ -320,7 +322,7 @@ __global__ __launch_bounds__(A_NT, OCC) void attention_kernel(const AttnArgs p) 
             __builtin_amdgcn_sched_barrier(0);
             wave_lds_handover();
             if (!BWD) {
-                tile_flush(scrw, p.scores + rowbase + kt * 32, p.S, lane);
+                if (KEEP) tile_flush(scrw, p.scores + rowbase + kt * 32, p.S, lane);
             } else {
                 tile_flush(scrw, p.ds + rowbase + kt * 32, p.S, lane);
                 tile_flush(scrb, p.dropped + rowbase + kt * 32, p.S, lane);
@@ -345,7 +347,7 @@ __global__ __launch_bounds__(A_NT, OCC) void attention_kernel(const AttnArgs p) 
             *reinterpret_cast<float4*>(orow + 8 * c) = make_float4(o0[4 * c] * io, o0[4 * c + 1] * io, o0[4 * c + 2] * io, o0[4 * c + 3] * io);
             *reinterpret_cast<float4*>(orow + 32 + 8 * c) = make_float4(o1[4 * c] * io, o1[4 * c + 1] * io, o1[4 * c + 2] * io, o1[4 * c + 3] * io);
         }
-        if (h == 0) *reinterpret_cast<float2*>(p.stats + ((long long)bh * p.S + row) * 2) = make_float2(m_run, inv);
+        if (KEEP && h == 0) *reinterpret_cast<float2*>(p.stats + ((long long)bh * p.S + row) * 2) = make_float2(m_run, inv);
     } else {
         float4 old[8];
 #pragma unroll
@@ -396,7 +398,9 @@ int attention_launch(nk_device* dev, AttnArgs& a, int B, int S, int H, double p,
     const int occ = BWD ? 2 : (occ_env == 2 || occ_env == 3 ? occ_env : OCC_DEFAULT);
 #define NK_ATT(M, F)                                                                                                       \
     do {                                                                                                                   \
-        if (!BWD && occ == 3) hipLaunchKernelGGL((attention_kernel<BWD, M, F, BWD ? 2 : 3>), grid, block, 0, dev->compute, a); \
+        /* inference forward: KEEP = false (spelled `BWD`, false on the only path that reaches this line) */             \
+        if (!BWD && !a.scores) hipLaunchKernelGGL((attention_kernel<BWD, M, F, BWD ? 2 : 3, BWD>), grid, block, 0, dev->compute, a); \
+        else if (!BWD && occ == 3) hipLaunchKernelGGL((attention_kernel<BWD, M, F, BWD ? 2 : 3>), grid, block, 0, dev->compute, a); \
         else hipLaunchKernelGGL((attention_kernel<BWD, M, F, 2>), grid, block, 0, dev->compute, a);                        \
     } while (0)
     if (masked && full) NK_ATT(true, true);
@@ -421,8 +425,9 @@ int nk_attention_fwd(nk_device* dev, const float* Q, const float* K, const float
                      uint64_t offset) {
     NK_USE(dev);
     if (int rc = attention_check(B, S, H, dh, p, train, scale)) return rc;
-    NK_CHECK(Q && K && V && scores && stats && O, "null pointer in nk_attention_fwd");
-    NK_CHECK(mask_bits || !(train && p != 0.0), "nk_attention_fwd: dropout is active, the mask_bits buffer is needed");
+    NK_CHECK(Q && K && V && O, "null pointer in nk_attention_fwd");
+    NK_CHECK((scores != nullptr) == (stats != nullptr), "nk_attention_fwd: scores and stats are kept together or not at all");
+    NK_CHECK(!scores || mask_bits || !(train && p != 0.0), "nk_attention_fwd: dropout is active, the mask_bits buffer is needed");
     NK_CHECK(al16(Q) && al16(K) && al16(V) && al16(scores) && al16(O) && al16(stats), "nk_attention_fwd needs 16-byte aligned buffers");
     nk_prof_start(dev, NK_KERNEL_ATTENTION, 4.0 * B * H * (double)S * S * dh);
     AttnArgs a{};

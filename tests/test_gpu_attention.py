@@ -110,6 +110,24 @@ def test_attention_core_mask_is_the_row_kernels_mask(dev):
     np.testing.assert_allclose(got["out"], ctx.numpy(), rtol=1e-4, atol=2e-6)
 
 
+@pytest.mark.parametrize("S,p", [(128, 0.2), (96, 0.0), (256, 0.4)])
+def test_attention_forward_without_kept_state_is_the_same_forward(dev, S, p):
+    """Inference form (scores = stats = mask_bits = NULL: no (B*H, S, S) tensor exists): the output is bit-identical to
+    the training-graph form's, dropout included (same Philox stream)."""
+    c = capi()
+    B, H, dh, seed, offset = 2, 2, 64, 31337, 9
+    scale = float(np.float32(0.125))
+    q, k, v = (rnd(s_, (B * S, H * dh), -1, 1) for s_ in (21, 22, 23))
+    Q, K, V = dev.array(q), dev.array(k), dev.array(v)
+    scores, stats, bits = dev.zeros((B * H, S, S)), dev.zeros((B * H, S, 2)), dev.zeros((B * H, S, S // 32))
+    kept, lean = dev.zeros((B * S, H * dh)), dev.zeros((B * S, H * dh))
+    c.attention_fwd(dev, Q, K, V, scores, stats, bits, kept, B, S, H, dh, scale, p, True, seed, offset)
+    c.attention_fwd(dev, Q, K, V, None, None, None, lean, B, S, H, dh, scale, p, True, seed, offset)
+    assert np.array_equal(kept.numpy(), lean.numpy())
+    with pytest.raises(RuntimeError, match="kept together"):
+        c.attention_fwd(dev, Q, K, V, scores, None, None, lean, B, S, H, dh, scale, p, True, seed, offset)
+
+
 def test_attention_core_rejects_what_it_cannot_do(dev):
     c = capi()
     assert c.attention_supported(1024, 64, 0.1) and c.attention_supported(32, 64, 0.0)

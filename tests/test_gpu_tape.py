@@ -707,6 +707,26 @@ def test_mha_fused_attention_core_equals_oracle(nk, tdev, core, p, S):
     np.testing.assert_allclose(X.grad(), grads["x"], rtol=1e-3, atol=2e-6 * np.abs(grads["x"]).max() + 1e-7)
 
 
+def test_heads_attention_node_without_gradients_keeps_nothing(nk, tdev):
+    """`Var::heads_attention` (a graph without gradients: inference) gives the output of the `VarDiff` node bit for bit
+    and adds ONE forward node; the shapes the fused kernels do not take are refused with the reason."""
+    B, S, H, dh = 2, 64, 2, 64
+    q, k, v = (rnd(s_, (B * S, H * dh), -1, 1) for s_ in (1, 2, 3))
+    st = nk.Status()
+    nk.manual_seed(99)
+    a = nk.from_ndarray(tdev, q).heads_attention(nk.from_ndarray(tdev, k), nk.from_ndarray(tdev, v), B, S, H, dh, 0.125, 0.1, st)
+    nk.manual_seed(99)
+    b = nk.from_ndarray(tdev, q).requires_grad().heads_attention(nk.from_ndarray(tdev, k).requires_grad(),
+                                                                 nk.from_ndarray(tdev, v).requires_grad(), B, S, H, dh, 0.125, 0.1, st)
+    assert a.history_len() == 1
+    a.forward(); b.forward()
+    assert np.array_equal(a.data(), b.data())
+    assert nk.Var.attention_core_supported(1024, 64, 0.1) and not nk.Var.attention_core_supported(1024, 32, 0.1)
+    with pytest.raises(RuntimeError, match="dh == 64"):
+        nk.from_ndarray(tdev, rnd(4, (64, 64), -1, 1)).heads_attention(nk.from_ndarray(tdev, rnd(5, (64, 64), -1, 1)),
+                                                                        nk.from_ndarray(tdev, rnd(6, (64, 64), -1, 1)), 1, 64, 2, 32, 0.1, 0.0, st)
+
+
 def test_backward_from_equals_weighted_sum_scaffolding(nk, tdev):
     """`y.backward_from(G)` (the upstream gradient tensor stands in for the root gradient while the tape runs - no copy,
     no extra nodes) gives bit-identical leaf gradients to the scaffolding `(y * G).sum().backward(1.0)`; the seed is left
