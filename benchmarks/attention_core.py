@@ -1,7 +1,7 @@
 """C5 attention core, fused kernels vs the node-by-node device path they replace (same box, same buffers).
     python benchmarks/attention_core.py [B S H] [reps]
 Prints one JSON line per variant: ms per call and TFLOP/s on the 4*B*H*S*S*dh algorithmic flop of each direction's two
-MFMA products (the node-by-node backward also runs them: dP and dQ; dK / dV are common to both paths and not timed)."""
+MFMA products; both backward variants include the dK / dV products (4 products = 8*B*H*S*S*dh flop, reported on 4*...)."""
 import json
 import os
 import sys
@@ -24,6 +24,7 @@ def main():
     big = lambda: dev.zeros((B * H, S, S))
     scores, probs_d, dP, dS = big(), big(), big(), big()
     stats, out, dQ = dev.zeros((B * H, S, 2)), dev.zeros((B * S, H * dh)), dev.zeros((B * S, H * dh))
+    dK, dV = dev.zeros((B * S, H * dh)), dev.zeros((B * S, H * dh))
     bits = dev.zeros((B * H, S, S // 32))
     d, so, po, pi = H * dh, S * H * dh, H * S * S, S * S
     flop = 4.0 * B * H * S * S * dh
@@ -32,7 +33,7 @@ def main():
         c.attention_fwd(dev, Q, K, V, scores, stats, bits, out, B, S, H, dh, scale, p, True, seed, 0)
 
     def fused_bwd():
-        c.attention_bwd(dev, dQ, dS, probs_d, G, out, scores, stats, bits, K, V, B, S, H, dh, scale, p, True, True)
+        c.attention_bwd(dev, dQ, dK, dV, dS, probs_d, G, out, scores, stats, bits, Q, K, V, B, S, H, dh, scale, p, True, (True, True, True))
 
     def nodes_fwd():
         c.sgemm_batched(dev, 0, 1, S, S, dh, 1.0, Q, d, so, dh, K, d, so, dh, 0.0, scores, S, po, pi, B, H)
@@ -43,6 +44,8 @@ def main():
         c.sgemm_batched(dev, 0, 1, S, S, dh, 1.0, G, d, so, dh, V, d, so, dh, 0.0, dP, S, po, pi, B, H)
         c.scale_softmax_dropout_bwd_from_scores(dev, dS, dP, scores, None, scale, p, True, seed, 0, assign=True)
         c.sgemm_batched(dev, 0, 0, S, dh, S, 1.0, dS, S, po, pi, K, d, so, dh, 0.0, dQ, d, so, dh, B, H)
+        c.sgemm_batched(dev, 1, 0, S, dh, S, 1.0, dS, S, po, pi, Q, d, so, dh, 0.0, dK, d, so, dh, B, H)
+        c.sgemm_batched(dev, 1, 0, S, dh, S, 1.0, probs_d, S, po, pi, G, d, so, dh, 0.0, dV, d, so, dh, B, H)
 
     for name, fn in (("fused_fwd", fused_fwd), ("fused_bwd", fused_bwd), ("nodes_fwd", nodes_fwd), ("nodes_bwd", nodes_bwd),
                      ("fused_fwd", fused_fwd), ("fused_bwd", fused_bwd)):

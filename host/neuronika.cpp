@@ -753,23 +753,14 @@ struct HeadsAttentionBwd : Backward {
     void backward() const override {
         const HipArray& G = g->borrow();  // dO, flat layout
         nk_device* dev = D(q);
-        float beta;
-        {   // dS, Pd, and dQ_bh += dS_bh . K_bh
-            float* d = first_write(dq, beta);
-            check(nk_attention_bwd(dev, d, ds->ptr(), dropped->ptr(), G.ptr(), o->ptr(), scores->ptr(), stats->ptr(),
-                                   reinterpret_cast<const uint32_t*>(mask->ptr()), k->ptr(), v->ptr(), hg.B, hg.S, hg.H, hg.dh, scale, p,
-                                   *status ? 1 : 0, beta == 0.f ? 1 : 0));
-        }
-        {   // dK_bh += dS_bh^T . Q_bh
-            float* d = first_write(dk, beta);
-            check(nk_sgemm_batched(dev, 1, 0, hg.S, hg.dh, hg.S, 1.f, ds->ptr(), hg.S, hg.po(), hg.pi(), q->ptr(), hg.d(), hg.so(), hg.dh, beta,
-                                   d, hg.d(), hg.so(), hg.dh, hg.B, hg.H));
-        }
-        {   // dV_bh += Pd_bh^T . dO_bh
-            float* d = first_write(dv, beta);
-            check(nk_sgemm_batched(dev, 1, 0, hg.S, hg.dh, hg.S, 1.f, dropped->ptr(), hg.S, hg.po(), hg.pi(), G.ptr(), hg.d(), hg.so(), hg.dh, beta,
-                                   d, hg.d(), hg.so(), hg.dh, hg.B, hg.H));
-        }
+        float bq, bk, bv;
+        float* gq = first_write(dq, bq);
+        float* gk = first_write(dk, bk);
+        float* gv = first_write(dv, bv);
+        // dS and Pd are written by the fused kernel, dQ comes out of it; dK / dV are the two batched products on dS / Pd
+        check(nk_attention_bwd(dev, gq, gk, gv, ds->ptr(), dropped->ptr(), G.ptr(), o->ptr(), scores->ptr(), stats->ptr(),
+                               reinterpret_cast<const uint32_t*>(mask->ptr()), q->ptr(), k->ptr(), v->ptr(), hg.B, hg.S, hg.H, hg.dh, scale,
+                               p, *status ? 1 : 0, bq == 0.f ? 1 : 0, bk == 0.f ? 1 : 0, bv == 0.f ? 1 : 0));
     }
     void targets(std::vector<const Gradient*>& out) const override {
         out.push_back(dq.get()); out.push_back(dk.get()); out.push_back(dv.get());

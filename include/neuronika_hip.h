@@ -409,14 +409,15 @@ int nk_attention_supported(int S, int dh, double p, int train);
 int nk_attention_fwd(nk_device* dev, const float* Q, const float* K, const float* V, float* scores, float* stats,
                      uint32_t* mask_bits, float* O, int B, int S, int H, int dh, float scale, double p, int train,
                      uint64_t seed, uint64_t offset);
-/* backward, first part: dS and Pd are WRITTEN (scratch the caller owns; dK_bh += dS_bh^T.Q_bh and dV_bh += Pd_bh^T.dO_bh
- * are nk_sgemm_batched calls on them), dQ_bh (+)= dS_bh.K_bh (`assign_dq` != 0: first write).  The mask is the forward's
- * (`mask_bits`), as the reference's backward node reads the forward's noise buffer.
- * DropoutBackward multiplies by the 0/1 mask only (node/dropout/mod.rs:113-128), SoftmaxBackward node/softmax/mod.rs:84-104. */
-int nk_attention_bwd(nk_device* dev, float* dQ, float* dS, float* dropped, const float* dO, const float* O,
-                     const float* scores, const float* stats, const uint32_t* mask_bits, const float* K, const float* V,
-                     int B, int S, int H, int dh, float scale, double p, int train, int assign_dq);
-
+/* backward: dQ_bh (+)= dS_bh.K_bh, dK_bh (+)= dS_bh^T.Q_bh, dV_bh (+)= Pd_bh^T.dO_bh (`assign_*` != 0: first write).  dS and
+ * Pd ((B*H, S, S) each) are scratch the caller owns; they are WRITTEN by the fused kernel and read by the two batched
+ * products this call issues after it.  The mask is the forward's (`mask_bits`), as the reference's backward node reads the
+ * forward's noise buffer.  DropoutBackward multiplies by the 0/1 mask only (node/dropout/mod.rs:113-128), SoftmaxBackward
+ * node/softmax/mod.rs:84-104, MatrixMatrixMul(T)Backward node/matrix_matrix_mul{,_t}/mod.rs:63-105. */
+int nk_attention_bwd(nk_device* dev, float* dQ, float* dK, float* dV, float* dS, float* dropped, const float* dO,
+                     const float* O, const float* scores, const float* stats, const uint32_t* mask_bits, const float* Q,
+                     const float* K, const float* V, int B, int S, int H, int dh, float scale, double p, int train,
+                     int assign_dq, int assign_dk, int assign_dv);
 /* ------------------------------------------------------------------ dropout ------------ */
 /* Dropout::forward node/dropout/mod.rs:53-79.  train && 0<p<1: noise ~ Bernoulli(1-p) in
  * {0,1} is (re)drawn from Philox4x32-10(seed, offset) and written to `noise` (f32, like the

@@ -73,8 +73,9 @@ impl Forward for HeadsAttention {
     }
 }
 
-/// The matching backward entry: `nk_attention_bwd` (dS, Pd, dQ) and the two products that reduce over the queries,
-/// `dK_bh += dS_bh^T . Q_bh` and `dV_bh += Pd_bh^T . dO_bh`, as strided batched GEMMs on the projection layout.
+/// The matching backward entry: ONE call, `nk_attention_bwd` - the fused kernel (dS, Pd, dQ) and, inside the library, the two
+/// products that reduce over the queries (`dK_bh += dS_bh^T . Q_bh`, `dV_bh += Pd_bh^T . dO_bh`).  `d_scores` / `dropped` are
+/// scratch; nothing on this side reads them.
 pub(crate) struct HeadsAttentionBackward {
     geometry: Heads,
     queries: Shared<HipArray<Ix2>>,
@@ -101,28 +102,11 @@ impl Backward for HeadsAttentionBackward {
         let (mut ds, mut pd) = (self.d_scores.borrow_mut(), self.dropped.borrow_mut());
         let h = self.geometry;
         let dev = g.device().as_raw();
-        let (d, so, po, pi) = (h.heads * h.dh, (h.seq * h.heads * h.dh) as i64, (h.heads * h.seq * h.seq) as i64, (h.seq * h.seq) as i64);
-        {
-            let mut dq = self.queries_gradient.borrow_mut();
-            ffi::check(unsafe {
-                ffi::nk_attention_bwd(dev, dq.as_mut_ptr(), ds.as_mut_ptr(), pd.as_mut_ptr(), g.as_ptr(), o.as_ptr(), scores.as_ptr(),
-                                      stats.as_ptr(), bits.as_ptr() as *const u32, k.as_ptr(), v.as_ptr(), h.batch, h.seq, h.heads, h.dh,
-                                      self.scale, self.p, self.status.get() as i32, 0)
-            });
-        }
-        {
-            let mut dk = self.keys_gradient.borrow_mut();
-            ffi::check(unsafe {
-                ffi::nk_sgemm_batched(dev, 1, 0, h.seq, h.dh, h.seq, 1., ds.as_ptr(), h.seq, po, pi, q.as_ptr(), d, so, h.dh as i64, 1.,
-                                      dk.as_mut_ptr(), d, so, h.dh as i64, h.batch, h.heads)
-            });
-        }
-        {
-            let mut dv = self.values_gradient.borrow_mut();
-            ffi::check(unsafe {
-                ffi::nk_sgemm_batched(dev, 1, 0, h.seq, h.dh, h.seq, 1., pd.as_ptr(), h.seq, po, pi, g.as_ptr(), d, so, h.dh as i64, 1.,
-                                      dv.as_mut_ptr(), d, so, h.dh as i64, h.batch, h.heads)
-            });
-        }
+        let (mut dq, mut dk, mut dv) = (self.queries_gradient.borrow_mut(), self.keys_gradient.borrow_mut(), self.values_gradient.borrow_mut());
+        ffi::check(unsafe {
+            ffi::nk_attention_bwd(dev, dq.as_mut_ptr(), dk.as_mut_ptr(), dv.as_mut_ptr(), ds.as_mut_ptr(), pd.as_mut_ptr(), g.as_ptr(),
+                                  o.as_ptr(), scores.as_ptr(), stats.as_ptr(), bits.as_ptr() as *const u32, q.as_ptr(), k.as_ptr(),
+                                  v.as_ptr(), h.batch, h.seq, h.heads, h.dh, self.scale, self.p, self.status.get() as i32, 0, 0, 0)
+        });
     }
 }

@@ -146,8 +146,8 @@ _SIGS = {
     "nk_log_softmax_bwd": [VP, VP, VP, VP, c_intp, C.c_int, C.c_int],
     "nk_attention_supported": [C.c_int, C.c_int, C.c_double, C.c_int],
     "nk_attention_fwd": [VP, VP, VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_double, C.c_int, C.c_uint64, C.c_uint64],
-    "nk_attention_bwd": [VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_double, C.c_int,
-                         C.c_int],
+    "nk_attention_bwd": [VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_double,
+                         C.c_int, C.c_int, C.c_int, C.c_int],
     "nk_scale_softmax_dropout_fwd": [VP, VP, VP, VP, VP, C.c_longlong, C.c_int, C.c_float, C.c_double, C.c_int, C.c_uint64, C.c_uint64],
     "nk_scale_softmax_dropout_bwd": [VP, VP, VP, VP, VP, C.c_longlong, C.c_int, C.c_float, C.c_double, C.c_int, C.c_uint64, C.c_uint64],
     "nk_dropout_fwd": [VP, VP, VP, VP, C.c_size_t, C.c_double, C.c_int, C.c_uint64, C.c_uint64],
@@ -582,11 +582,12 @@ def attention_fwd(dev, Q, K, V, scores, stats, mask_bits, out, B, S, H, dh, scal
                                B, S, H, dh, scale, float(p), int(train), seed, offset))
 
 
-def attention_bwd(dev, dQ, dS, dropped, dO, out, scores, stats, mask_bits, K, V, B, S, H, dh, scale, p, train=True, assign=False):
-    """dS and dropped (B*H,S,S) are written; dQ (+)= dS.K per (sample, head)."""
-    check(lib.nk_attention_bwd(dev.h, dQ.p, dS.p, dropped.p, dO.p, out.p, scores.p, stats.p,
-                               mask_bits.p if mask_bits is not None else None, K.p, V.p, B, S, H, dh, scale, float(p),
-                               int(train), int(assign)))
+def attention_bwd(dev, dQ, dK, dV, dS, dropped, dO, out, scores, stats, mask_bits, Q, K, V, B, S, H, dh, scale, p, train=True,
+                  assign=(False, False, False)):
+    """dS and dropped (B*H,S,S elements, scratch) are written; dQ / dK / dV (+)= the three input gradients per (sample, head)."""
+    check(lib.nk_attention_bwd(dev.h, dQ.p, dK.p, dV.p, dS.p, dropped.p, dO.p, out.p, scores.p, stats.p,
+                               mask_bits.p if mask_bits is not None else None, Q.p, K.p, V.p, B, S, H, dh, scale, float(p),
+                               int(train), int(assign[0]), int(assign[1]), int(assign[2])))
 
 
 def chunk_fwd(dev, x, y, chunk_no):

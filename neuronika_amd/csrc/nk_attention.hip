@@ -437,22 +437,32 @@ int nk_attention_fwd(nk_device* dev, const float* Q, const float* K, const float
     return rc;
 }
 
-int nk_attention_bwd(nk_device* dev, float* dQ, float* dS, float* dropped, const float* dO, const float* O, const float* scores,
-                     const float* stats, const uint32_t* mask_bits, const float* K, const float* V, int B, int S, int H, int dh,
-                     float scale, double p, int train, int assign_dq) {
+int nk_attention_bwd(nk_device* dev, float* dQ, float* dK, float* dV, float* dS, float* dropped, const float* dO, const float* O,
+                     const float* scores, const float* stats, const uint32_t* mask_bits, const float* Q, const float* K,
+                     const float* V, int B, int S, int H, int dh, float scale, double p, int train, int assign_dq, int assign_dk,
+                     int assign_dv) {
     NK_USE(dev);
     if (int rc = attention_check(B, S, H, dh, p, train, scale)) return rc;
-    NK_CHECK(dQ && dS && dropped && dO && O && scores && stats && K && V, "null pointer in nk_attention_bwd");
+    NK_CHECK(dQ && dK && dV && dS && dropped && dO && O && scores && stats && Q && K && V, "null pointer in nk_attention_bwd");
     NK_CHECK(mask_bits || !(train && p != 0.0), "nk_attention_bwd: dropout is active, the forward's mask_bits are needed");
-    NK_CHECK(al16(dQ) && al16(dS) && al16(dropped) && al16(dO) && al16(O) && al16(scores) && al16(stats) && al16(K) && al16(V),
+    NK_CHECK(al16(dQ) && al16(dK) && al16(dV) && al16(dS) && al16(dropped) && al16(dO) && al16(O) && al16(scores) && al16(stats) &&
+                 al16(Q) && al16(K) && al16(V),
              "nk_attention_bwd needs 16-byte aligned buffers");
     nk_prof_start(dev, NK_KERNEL_ATTENTION, 4.0 * B * H * (double)S * S * dh);
     AttnArgs a{};
     a.x1 = V; a.x2 = K; a.bq = dO; a.ctx = O; a.out = dQ; a.scores = const_cast<float*>(scores); a.ds = dS; a.dropped = dropped;
     a.stats = const_cast<float*>(stats); a.maskbits = const_cast<uint32_t*>(mask_bits); a.assign = assign_dq ? 1 : 0;
-    const int rc = attention_launch<true>(dev, a, B, S, H, p, train, 0, 0, scale);
+    int rc = attention_launch<true>(dev, a, B, S, H, p, train, 0, 0, scale);
     nk_prof_stop(dev);
-    return rc;
+    if (rc) return rc;
+    // dK_bh (+)= dS_bh^T . Q_bh and dV_bh (+)= Pd_bh^T . dO_bh: reductions over the queries, i.e. across the blocks above.
+    // (Keeping dS / Pd in the kernels' own tile order - no LDS transposition in the kernel, a k-contiguous A operand whose
+    // 128 x 32 tiles are single 16 KB runs for these products - was built and measured: kernel and products unchanged.)
+    const int d = H * dh;
+    const long long so = (long long)S * d, po = (long long)H * S * S, pi = (long long)S * S;
+    rc = nk_sgemm_batched(dev, 1, 0, S, dh, S, 1.f, dS, S, po, pi, Q, d, so, dh, assign_dk ? 0.f : 1.f, dK, d, so, dh, B, H);
+    if (rc) return rc;
+    return nk_sgemm_batched(dev, 1, 0, S, dh, S, 1.f, dropped, S, po, pi, dO, d, so, dh, assign_dv ? 0.f : 1.f, dV, d, so, dh, B, H);
 }
 
 }  // extern "C"
