@@ -366,16 +366,14 @@ __global__ __launch_bounds__(NT, 2) void conv_bwd_input_fast_kernel(FastBwdInArg
     // Two halves: `gather` only ISSUES the four 16-byte loads of the next k-tile (before the MFMAs of the current one);
     // `gather_finish` picks / masks the elements and runs AFTER the MFMAs - touching the loaded registers any earlier
     // makes the wave wait for its loads with nothing to hide them behind.
-    Stage<4> rb;
-    int g_sh = 0, g_c = 0;
-    bool g_ok = false;
-    auto gather = [&](int kt) {
+    struct GatherState { int sh = 0, c = 0; bool ok = false; };  // what gather_finish needs to know about the loads it completes
+    auto gather_into = [&](int kt, Stage<4>& rb, GatherState& st) {
         kt += kt0;
         const int chunk = kt / ntaps, tap = kt - chunk * ntaps, co0 = chunk * BK;  // taps inside a 32-channel chunk
         const int4 d = tapd[tap];
         const float* src = G + co0 * g.L;
         const int a = qa - d.x, b = qb - d.y, c = qc - d.z;  // output coordinates of the quad's first element
-        g_ok = valid && a >= 0 && a < g.out[0] && b >= 0 && b < g.out[1];
+        st.ok = valid && a >= 0 && a < g.out[0] && b >= 0 && b < g.out[1];
         const int ac = min(max(a, 0), g.out[0] - 1), bc = min(max(b, 0), g.out[1] - 1);
         // The load starts AT the quad (element i of the vector = element i of the quad, no shift): a quad that sticks out
         // of its gradient row reads the neighbouring row's elements, which the per-element masks zero.  Only a load that
@@ -384,15 +382,16 @@ __global__ __launch_bounds__(NT, 2) void conv_bwd_input_fast_kernel(FastBwdInArg
         const long long e0 = (long long)(src - p.gy) + gbase + (ac * g.out[1] + bc) * g.out[2] + c;
         const bool edge = e0 < 0 || e0 + 3LL * jstep + 4 > gy_elems;
         const int cs = edge ? min(max(c, 0), g.out[2] - 4) : c;
-        g_sh = c - cs;                                  // shift of element 0 inside the loaded vector (0 unless `edge`)
-        g_c = c;
+        st.sh = c - cs;                                  // shift of element 0 inside the loaded vector (0 unless `edge`)
+        st.c = c;
         const float* ptr = src + (gbase + (ac * g.out[1] + bc) * g.out[2] + cs);
 #define NK_LDU(V, P) { const f32x4u q = *reinterpret_cast<const f32x4u*>(P); V = make_float4(q.x, q.y, q.z, q.w); }
         NK_LDU(rb.v0, ptr) NK_LDU(rb.v1, ptr + jstep) NK_LDU(rb.v2, ptr + 2 * jstep) NK_LDU(rb.v3, ptr + 3 * jstep)
 #undef NK_LDU
     };
-    auto gather_finish = [&]() {
-        const int sh = g_sh;
+    auto finish_of = [&](Stage<4>& rb, const GatherState& st) {
+        const int sh = st.sh, g_c = st.c;
+        const bool g_ok = st.ok;
         if (sh == 0) {  // the loaded vector is the quad (every lane but the few at the tensor's ends): mask per element
             const bool k0 = g_ok && g_c >= 0 && g_c < g.out[2], k1 = g_ok && g_c + 1 >= 0 && g_c + 1 < g.out[2],
                        k2 = g_ok && g_c + 2 >= 0 && g_c + 2 < g.out[2], k3 = g_ok && g_c + 3 >= 0 && g_c + 3 < g.out[2];
@@ -418,11 +417,73 @@ __global__ __launch_bounds__(NT, 2) void conv_bwd_input_fast_kernel(FastBwdInArg
         }
     };
 
+    Stage<4> rb;
+    GatherState gs;
+    auto gather = [&](int kt) { gather_into(kt, rb, gs); };
+    auto gather_finish = [&]() { finish_of(rb, gs); };
+
     f32x16 acc[TI][TJ];
     acc_zero<TI, TJ>(acc);
     TileLoader<true, BM> la;
     la.init(Wq, K, m0, kt0 * BK, g.Cg, (kt0 + nt) * BK, t);
     Stage<BM / 32> ra;
+    // TI == 1 (Cin = 64: a k-tile is 32 MFMAs per wave, ~2000 cycles - less than a load round trip through L2): two k-tiles
+    // of look-ahead as in sgemm_kernel.  Tile it+1 (P, gathered during the previous trip) is masked and goes to LDS at the
+    // START of a trip, the loads of tile it+2 (Q) are issued in front of it; a trip ends MFMAs -> barrier.
+    if (TI == 1 && nt >= 8) {
+        float* const buf0 = smem;
+        float* const buf1 = smem + STAGE;
+        Stage<BM / 32> pa, qa2;
+        Stage<4> pb, qb2;
+        GatherState ps, qs;
+        pa = la.template load<ALIGNED_A>(t);
+        gather_into(0, pb, ps);
+        finish_of(pb, ps);
+        stage_store<true, BM>(buf0, pa, t);
+        stage_store<false, BN>(buf0 + TA_FLOATS, pb, t);
+        __syncthreads();
+        pa = la.template load<ALIGNED_A>(t);  // tile 1 -> P
+        gather_into(1, pb, ps);
+        int it = 0;  // invariant: tile `it` (even) is in buf0, tile it+1 in P
+        for (; it + 3 < nt; it += 2) {
+            qa2 = la.template load<ALIGNED_A>(t);  // tile it+2
+            gather_into(it + 2, qb2, qs);
+            finish_of(pb, ps);
+            stage_store<true, BM>(buf1, pa, t);
+            stage_store<false, BN>(buf1 + TA_FLOATS, pb, t);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_tile<true, false, TI, TJ>(buf0, buf0 + TA_FLOATS, acc, wr, wc, lane);
+            __syncthreads();
+            pa = la.template load<ALIGNED_A>(t);  // tile it+3
+            gather_into(it + 3, pb, ps);
+            finish_of(qb2, qs);
+            stage_store<true, BM>(buf0, qa2, t);
+            stage_store<false, BN>(buf0 + TA_FLOATS, qb2, t);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_tile<true, false, TI, TJ>(buf1, buf1 + TA_FLOATS, acc, wr, wc, lane);
+            __syncthreads();
+        }
+        const int left = nt - it;  // 2 or 3 tiles: `it` in buf0, it+1 in P
+        if (left == 3) {
+            qa2 = la.template load<ALIGNED_A>(t);
+            gather_into(it + 2, qb2, qs);
+        }
+        finish_of(pb, ps);
+        stage_store<true, BM>(buf1, pa, t);
+        stage_store<false, BN>(buf1 + TA_FLOATS, pb, t);
+        mma_tile<true, false, TI, TJ>(buf0, buf0 + TA_FLOATS, acc, wr, wc, lane);
+        __syncthreads();
+        if (left == 3) {
+            finish_of(qb2, qs);
+            stage_store<true, BM>(buf0, qa2, t);
+            stage_store<false, BN>(buf0 + TA_FLOATS, qb2, t);
+        }
+        mma_tile<true, false, TI, TJ>(buf1, buf1 + TA_FLOATS, acc, wr, wc, lane);
+        if (left == 3) {
+            __syncthreads();
+            mma_tile<true, false, TI, TJ>(buf0, buf0 + TA_FLOATS, acc, wr, wc, lane);
+        }
+    } else {
     if (nt > 0) {  // a phase without taps (e.g. a 1x1 kernel with stride 2) only has zeros to write
         ra = la.template load<ALIGNED_A>(t);
         gather(0);
@@ -446,6 +507,7 @@ __global__ __launch_bounds__(NT, 2) void conv_bwd_input_fast_kernel(FastBwdInArg
     if (nt > 0) {
         float* cur = smem + ((nt - 1) & 1) * STAGE;
         mma_tile<true, false, TI, TJ>(cur, cur + TA_FLOATS, acc, wr, wc, lane);
+    }
     }
     if (slab) {  // partial tile of a split tail tile
         acc_foreach<TI, TJ>(acc, wr, wc, lane, [&](int r, int c, float v) { slab[r * BN + c] = v; });
