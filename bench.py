@@ -358,6 +358,7 @@ def run_mlp(a, dist):
         opt.zero_grad()
 
     dt, ev_ms, gemm, _ = timed_steps(dist, tdev, cdev, step, a.steps, a.warmup)
+    settle = EXTRA_STATS["settle_steps"]           # (the later timed_steps calls of this function overwrite it)
     loss_val = loss.item()
     n_exch = sync.exchanges_issued() if sync is not None else 0
     exposed = 0.0
@@ -382,7 +383,8 @@ def run_mlp(a, dist):
             "rccl_ranks": comm.size if (comm is not None and replicas <= 1) else 1,
             **({"replica_ranks_debug": replicas} if replicas > 1 else {}),
             "allreduce_bytes_per_step": sync.bytes_per_step() if sync is not None else 0,
-            "allreduce_launches_per_step": n_exch // (a.steps + a.warmup) if sync is not None else 0,
+            "allreduce_launches_per_step": n_exch // (a.steps + a.warmup + settle) if sync is not None else 0,
+            "clock_settle_steps": settle,
             "exposed_comm_ms": round(exposed, 4),
             "roofline": roofline_mfma(gemm, "sgemm_kernel (f32 MFMA 32x32x2, 128x128x32 tiles)", read_traffic("sgemm_kernel")),
             "matmul_4096": {"workload": f"C2: mm fwd + bwd-left + bwd-right, N={mm_n}, {mm_steps} steps",
@@ -566,7 +568,7 @@ def main():
     try:
         res = {"mlp": run_mlp, "matmul": run_matmul, "conv": run_conv, "mha": run_mha}[a.workload](a, dist)
         if dist.rank == 0 and res is not None:
-            res["clock_settle_steps"] = EXTRA_STATS.get("settle_steps", 0)   # untimed steps beyond --warmup (see timed_steps)
+            res.setdefault("clock_settle_steps", EXTRA_STATS.get("settle_steps", 0))   # untimed steps beyond --warmup (see timed_steps)
             print(json.dumps(res), flush=True)
     finally:
         dist.close()
