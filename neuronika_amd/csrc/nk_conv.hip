@@ -131,9 +131,7 @@ int conv_fwd(nk_device* dev, int nd, const float* x, const int* x_shape, const f
         int* tapoff = (int*)((char*)wsf + wp_bytes);
         int4* tapd = (int4*)((char*)wsf + wp_bytes + to_bytes);
         if (slab_bytes) fp.slabs = (float*)((char*)wsf + tables);
-        hipLaunchKernelGGL(conv_wp_kernel, dim3(nk_stream_grid((size_t)g.Cout * K, 256)), dim3(256), 0, dev->compute, wp, w, g);
-        NK_LAUNCH_CHECK();
-        hipLaunchKernelGGL(conv_tapoff_kernel, dim3(1), dim3(64), 0, dev->compute, tapoff, tapd, g);
+        hipLaunchKernelGGL(conv_wp_kernel, dim3(nk_stream_grid((size_t)g.Cout * K, 256)), dim3(256), 0, dev->compute, wp, w, g, tapoff, tapd);
         NK_LAUNCH_CHECK();
         fp.g = g; fp.x = x; fp.wp = wp; fp.y = y; fp.tapoff = tapoff;
         dim3 fgrid(nblocks, 1, groups);
@@ -321,18 +319,14 @@ int conv_bwd_input(nk_device* dev, int nd, float* dx, const int* x_shape, const 
                 }
             }
             void* wsf = nullptr;
-            rc = nk_workspace(dev, wq_bytes + 2 * td_bytes + ph_bytes + slab_bytes, &wsf);
+            rc = nk_workspace(dev, wq_bytes + td_bytes + ph_bytes + slab_bytes, &wsf);
             if (rc) return rc;
             float* wq = (float*)wsf;
             int4* tapd = (int4*)((char*)wsf + wq_bytes);
-            int4* tappos = (int4*)((char*)wsf + wq_bytes + td_bytes);
-            BwdInPhase* phases = (BwdInPhase*)((char*)wsf + wq_bytes + 2 * td_bytes);
-            if (slab_bytes) fp.slabs = (float*)((char*)wsf + wq_bytes + 2 * td_bytes + ph_bytes);
-            hipLaunchKernelGGL(conv_phase_taps_kernel, dim3((g.KK + 63) / 64), dim3(64), 0, dev->compute, tapd, tappos, g);
-            NK_LAUNCH_CHECK();
-            hipLaunchKernelGGL(conv_phase_table_kernel, dim3(1), dim3(1), 0, dev->compute, phases, tbl);
-            NK_LAUNCH_CHECK();
-            hipLaunchKernelGGL(conv_wq_kernel, dim3(nk_stream_grid((size_t)g.Cout * g.Cg * g.KK, 256)), dim3(256), 0, dev->compute, wq, w, tappos, g);
+            BwdInPhase* phases = (BwdInPhase*)((char*)wsf + wq_bytes + td_bytes);
+            if (slab_bytes) fp.slabs = (float*)((char*)wsf + wq_bytes + td_bytes + ph_bytes);
+            hipLaunchKernelGGL(conv_wq_tables_kernel, dim3(nk_stream_grid((size_t)g.Cout * g.Cg * g.KK, 256)), dim3(256), 0, dev->compute,
+                               wq, w, tapd, phases, tbl, g);
             NK_LAUNCH_CHECK();
             fp.g = g; fp.dx = dx; fp.gy = gy; fp.wq = wq; fp.tapd = tapd; fp.phases = phases; fp.nphase = nphase;
             const bool al = g.Cg % (64 * fti) == 0;
@@ -463,16 +457,11 @@ int conv_bwd_kernel(nk_device* dev, int nd, float* dw, const int* w_shape, const
     long long rts = (rtiles + splits - 1) / splits;
     splits = (rtiles + rts - 1) / rts;
     p.r_per_split = rts * BK;
-    const size_t ko_bytes = round256((size_t)Kc * sizeof(int));
     const long long dw_elems = (long long)g.Cout * Kc;
     void* ws = nullptr;
-    rc = nk_workspace(dev, ko_bytes + (size_t)splits * dw_elems * sizeof(float), &ws);
+    rc = nk_workspace(dev, (size_t)splits * dw_elems * sizeof(float), &ws);
     if (rc) return rc;
-    int* koff = (int*)ws;
-    p.koff = koff;
-    p.slabs = (float*)((char*)ws + ko_bytes);
-    hipLaunchKernelGGL(conv_koff_kernel, dim3((Kc + 255) / 256), dim3(256), 0, dev->compute, koff, g);
-    NK_LAUNCH_CHECK();
+    p.slabs = (float*)ws;
     dim3 grid((unsigned)(p.tiles_m * p.tiles_n * splits), 1, groups);
     const bool vec_g = (g.L % 4 == 0) && al16(gy);
     rc = nk_prof_start(dev, NK_KERNEL_CONV, 2.0 * g.N * (double)g.Cout * g.L * g.Cg * g.KK);

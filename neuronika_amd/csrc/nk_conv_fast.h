@@ -10,19 +10,21 @@
 // thread stages are one unaligned 16-B load.  The weights are re-ordered once per call by a
 // tiny pre-kernel (they are KBs to MBs; the activations are hundreds of MBs).
 // =================================================================================================
-// tapoff[tap] = input offset of kernel tap `tap` relative to the window origin
-__global__ void conv_tapoff_kernel(int* __restrict__ tapoff, int4* __restrict__ tapd, ConvGeom g) {
-    for (int tap = blockIdx.x * blockDim.x + threadIdx.x; tap < g.KK; tap += gridDim.x * blockDim.x) {
-        int rem = tap;
-        const int k2 = rem % g.k[2]; rem /= g.k[2];
-        const int k1 = rem % g.k[1];
-        const int k0 = rem / g.k[1];
-        tapoff[tap] = (k0 * g.dil[0] * g.in[1] + k1 * g.dil[1]) * g.in[2] + k2 * g.dil[2];
-        tapd[tap] = make_int4(k0 * g.dil[0], k1 * g.dil[1], k2 * g.dil[2], 0);
+// Wp[grp][co][tap][ci] = W[grp*Mg + co][ci][tap]   (forward A operand, k = tap*Cg + ci); the first block also writes the tap
+// tables (one launch in front of every forward pass): tapoff[tap] = input offset of kernel tap `tap` relative to the window
+// origin, tapd[tap] = its (dilated) coordinates
+__global__ void conv_wp_kernel(float* __restrict__ wp, const float* __restrict__ w, ConvGeom g, int* __restrict__ tapoff = nullptr,
+                               int4* __restrict__ tapd = nullptr) {
+    if (tapoff && blockIdx.x == 0) {
+        for (int tap = threadIdx.x; tap < g.KK; tap += blockDim.x) {
+            int rem = tap;
+            const int k2 = rem % g.k[2]; rem /= g.k[2];
+            const int k1 = rem % g.k[1];
+            const int k0 = rem / g.k[1];
+            tapoff[tap] = (k0 * g.dil[0] * g.in[1] + k1 * g.dil[1]) * g.in[2] + k2 * g.dil[2];
+            tapd[tap] = make_int4(k0 * g.dil[0], k1 * g.dil[1], k2 * g.dil[2], 0);
+        }
     }
-}
-// Wp[grp][co][tap][ci] = W[grp*Mg + co][ci][tap]   (forward A operand, k = tap*Cg + ci)
-__global__ void conv_wp_kernel(float* __restrict__ wp, const float* __restrict__ w, ConvGeom g) {
     const long long total = (long long)g.Cout * g.Cg * g.KK;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {
@@ -48,12 +50,8 @@ struct BwdInPhase {
     int tile_begin;        // first column tile of the phase in the launch
 };
 struct BwdInPhaseTable { BwdInPhase ph[MAX_PHASES]; };
-// by-value table -> device memory (indexing a by-value array with a run-time index would spill it to scratch; a kernel
-// instead of a host copy keeps the call capturable in a hipGraph)
-__global__ void conv_phase_table_kernel(BwdInPhase* __restrict__ out, BwdInPhaseTable tbl) {
-#pragma unroll
-    for (int i = 0; i < MAX_PHASES; ++i) out[i] = tbl.ph[i];
-}
+// (the by-value table goes to device memory in conv_wq_tables_kernel: indexing a by-value array with a run-time index would
+// spill it to scratch; a kernel instead of a host copy keeps the call capturable in a hipGraph)
 __device__ __forceinline__ int tap_phase(const ConvGeom& g, int tap, int* kd) {
     int rem = tap;
     kd[2] = (rem % g.k[2]) * g.dil[2]; rem /= g.k[2];
@@ -61,28 +59,39 @@ __device__ __forceinline__ int tap_phase(const ConvGeom& g, int tap, int* kd) {
     kd[0] = (rem / g.k[1]) * g.dil[0];
     return ((kd[0] % g.stride[0]) * g.stride[1] + kd[1] % g.stride[1]) * g.stride[2] + kd[2] % g.stride[2];
 }
-// tapd[position in phase order] = {d0, d1, d2, tap} with out = q - d (d = (k*dil - r)/stride >= 0);
-// tappos[tap] = {first position of its phase, taps in its phase, its rank inside the phase, phase id}
-__global__ void conv_phase_taps_kernel(int4* __restrict__ tapd, int4* __restrict__ tappos, ConvGeom g) {
-    for (int tap = blockIdx.x * blockDim.x + threadIdx.x; tap < g.KK; tap += gridDim.x * blockDim.x) {
-        int kd[3], kd2[3];
-        const int pid = tap_phase(g, tap, kd);
-        int begin = 0, cnt = 0, rank = 0;
-        for (int t2 = 0; t2 < g.KK; ++t2) {
-            const int pid2 = tap_phase(g, t2, kd2);
-            if (pid2 < pid) ++begin;
-            else if (pid2 == pid) { ++cnt; if (t2 < tap) ++rank; }
-        }
-        tapd[begin + rank] = make_int4((kd[0] - kd[0] % g.stride[0]) / g.stride[0], (kd[1] - kd[1] % g.stride[1]) / g.stride[1],
-                                       (kd[2] - kd[2] % g.stride[2]) / g.stride[2], tap);
-        tappos[tap] = make_int4(begin, cnt, rank, pid);
-    }
-}
 // Wq[grp][ci][phase][chunk][tap in phase][c32] = W[grp*Mg + chunk*32 + c32][ci][tap]   (backward-input A operand).  Per
 // phase, k runs over 32-channel chunks of co with the taps INSIDE a chunk: the 32 x (tile + halo) slab of the gradient
 // that one chunk needs is then re-read by all taps back to back (L2 hits) instead of once per tap across all of co (PMC:
 // 1.7 GB fetched per launch at C3 with the tap-major order, 9x the gradient).
-__global__ void conv_wq_kernel(float* __restrict__ wq, const float* __restrict__ w, const int4* __restrict__ tappos, ConvGeom g) {
+// (begin, count, rank, phase) of a tap among the taps sorted by phase
+__device__ __forceinline__ int4 tap_position(const ConvGeom& g, int tap, int* kd) {
+    int kd2[3];
+    const int pid = tap_phase(g, tap, kd);
+    int begin = 0, cnt = 0, rank = 0;
+    for (int t2 = 0; t2 < g.KK; ++t2) {
+        const int pid2 = tap_phase(g, t2, kd2);
+        if (pid2 < pid) ++begin;
+        else if (pid2 == pid) { ++cnt; if (t2 < tap) ++rank; }
+    }
+    return make_int4(begin, cnt, rank, pid);
+}
+// One launch in front of the input-gradient pass: the first block writes the tap table - tapd[position in phase order] =
+// {d0, d1, d2, tap} with out = q - d (d = (k*dil - r)/stride >= 0) - and the phase table, every block re-lays its share of the weights, each thread working out its own
+// tap's position among the phases (a loop over the KK taps: nothing next to a global load).
+__global__ void conv_wq_tables_kernel(float* __restrict__ wq, const float* __restrict__ w, int4* __restrict__ tapd,
+                                      BwdInPhase* __restrict__ phases, BwdInPhaseTable tbl, ConvGeom g) {
+    if (blockIdx.x == 0) {
+        for (int tap = threadIdx.x; tap < g.KK; tap += blockDim.x) {
+            int kd[3];
+            const int4 tp = tap_position(g, tap, kd);
+            tapd[tp.x + tp.z] = make_int4((kd[0] - kd[0] % g.stride[0]) / g.stride[0], (kd[1] - kd[1] % g.stride[1]) / g.stride[1],
+                                          (kd[2] - kd[2] % g.stride[2]) / g.stride[2], tap);
+        }
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int i = 0; i < MAX_PHASES; ++i) phases[i] = tbl.ph[i];
+        }
+    }
     const long long total = (long long)g.Cout * g.Cg * g.KK;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {  // i = source index ((grp*Mg + co)*Cg + ci)*KK + tap
@@ -91,7 +100,8 @@ __global__ void conv_wq_kernel(float* __restrict__ wq, const float* __restrict__
         const int ci = (int)(rem % g.Cg); rem /= g.Cg;
         const int co = (int)(rem % g.Mg);
         const int grp = (int)(rem / g.Mg);
-        const int4 tp = tappos[tap];
+        int kd[3];
+        const int4 tp = tap_position(g, tap, kd);
         const int chunk = co / BK, c32 = co - chunk * BK;
         wq[((long long)grp * g.Cg + ci) * ((long long)g.Mg * g.KK) + (long long)g.Mg * tp.x + (chunk * tp.y + tp.z) * BK + c32] = w[i];
     }
@@ -292,7 +302,7 @@ struct FastBwdInArgs {
     ConvGeom g;
     float* dx;
     const float* gy;
-    const float* wq;  // [groups][Cg][KK*Mg], phase-sorted (conv_wq_kernel)
+    const float* wq;  // [groups][Cg][KK*Mg], phase-sorted (conv_wq_tables_kernel)
     const int4* tapd;
     const BwdInPhase* phases;
     int nphase;

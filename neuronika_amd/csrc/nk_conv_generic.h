@@ -311,7 +311,6 @@ struct BwdKArgs {
     ConvGeom g;
     const float* gy;
     const float* x;
-    const int* koff;
     float* slabs;        // [splits][groups][Mg][Cg*KK]
     int tiles_m, tiles_n;
     long long r_per_split;  // multiple of BK
@@ -353,7 +352,7 @@ __global__ __launch_bounds__(NT, 2) void conv_bwd_kernel_kernel(BwdKArgs p) {
     // B: columns n0 + row + 32*j -> koff (fixed over the k loop)
     int ko0, ko1, ko2 = 0, ko3 = 0;
     bool cv0, cv1, cv2 = false, cv3 = false;
-#define NK_KO(j, KO, CV) { const int c = n0 + row + 32 * j; CV = c < Kc; KO = CV ? p.koff[c] : 0; }
+#define NK_KO(j, KO, CV) { const int c = n0 + row + 32 * j; CV = c < Kc; KO = CV ? conv_koff(g, c) : 0; }  // (once per thread: no table)
     NK_KO(0, ko0, cv0) NK_KO(1, ko1, cv1)
     if constexpr (TJ == 2) { NK_KO(2, ko2, cv2) NK_KO(3, ko3, cv3) }
 #undef NK_KO

@@ -15,17 +15,18 @@ struct ConvGeom {
 };
 
 // ---- tables (tiny pre-kernels into the device workspace) ---------------------------------------
-// koff[k], k = ci*KK + kidx : input offset of kernel element k relative to the window origin
+// koff(k), k = ci*KK + kidx : input offset of kernel element k relative to the window origin
+__device__ __forceinline__ int conv_koff(const ConvGeom& g, int k) {
+    const int ci = k / g.KK;
+    int rem = k % g.KK;
+    const int k2 = rem % g.k[2]; rem /= g.k[2];
+    const int k1 = rem % g.k[1];
+    const int k0 = rem / g.k[1];
+    return ci * g.inplane + (k0 * g.dil[0] * g.in[1] + k1 * g.dil[1]) * g.in[2] + k2 * g.dil[2];
+}
 __global__ void conv_koff_kernel(int* __restrict__ koff, ConvGeom g) {
     const int K = g.Cg * g.KK;
-    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < K; k += gridDim.x * blockDim.x) {
-        const int ci = k / g.KK;
-        int rem = k % g.KK;
-        const int k2 = rem % g.k[2]; rem /= g.k[2];
-        const int k1 = rem % g.k[1];
-        const int k0 = rem / g.k[1];
-        koff[k] = ci * g.inplane + (k0 * g.dil[0] * g.in[1] + k1 * g.dil[1]) * g.in[2] + k2 * g.dil[2];
-    }
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < K; k += gridDim.x * blockDim.x) koff[k] = conv_koff(g, k);
 }
 // ktab[k'], k' = co*KK + kidx : {co*L, k0*dil0, k1*dil1, k2*dil2}
 __global__ void conv_ktab_kernel(int4* __restrict__ ktab, ConvGeom g) {
