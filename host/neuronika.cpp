@@ -416,12 +416,17 @@ struct ConvBwd : Backward {  // ConvolutionBackward{Input,Kernel}  :357-510
                 check((assign ? nk_conv_bwd_input_assign : nk_conv_bwd_input)(D(x), nd, d.ptr(), x->shape().data(), G.ptr(), w->ptr(),
                                                                               w->shape().data(), stride.data(), dilation.data(), groups));
         }
-        if (dw) {
+        if (dw && db) {  // kernel and bias gradient of the fused module node in one pass over G
+            bool assign_b = false;
+            HipArray& d = dw->borrow_first_write(assign);
+            HipArray& b = db->borrow_first_write(assign_b);
+            check(nk_conv_bwd_kernel_bias(D(x), nd, d.ptr(), b.ptr(), w->shape().data(), G.ptr(), x->ptr(), x->shape().data(), stride.data(),
+                                          dilation.data(), groups, assign ? 1 : 0, assign_b ? 1 : 0));
+        } else if (dw) {
             HipArray& d = dw->borrow_first_write(assign);
             check((assign ? nk_conv_bwd_kernel_assign : nk_conv_bwd_kernel)(D(x), nd, d.ptr(), w->shape().data(), G.ptr(), x->ptr(),
                                                                             x->shape().data(), stride.data(), dilation.data(), groups));
-        }
-        if (db) {  // AdditionBackwardRight of the bias: sum of G over every axis the (Cout,1,..) bias lacks
+        } else if (db) {  // AdditionBackwardRight of the bias: sum of G over every axis the (Cout,1,..) bias lacks
             HipArray& d = db->borrow_first_write(assign);
             check((assign ? nk_unbroadcast_assign : nk_unbroadcast_add)(D(x), d.ptr(), d.shape().data(), (int)d.shape().size(), G.ptr(),
                                                                         G.shape().data(), (int)G.shape().size()));

@@ -186,6 +186,13 @@ int nk_conv_bwd_kernel(nk_device* dev, int nd, float* dw, const int* w_shape, co
 int nk_conv_bias_fwd(nk_device* dev, int nd, const float* x, const int* x_shape, const float* w,
                      const int* w_shape, const float* bias, float* y, const int* stride,
                      const int* dilation, int groups);
+/* The same module's backward towards its kernel AND its bias in one pass: ConvolutionBackwardKernel (convolution/mod.rs:
+ * 191-226) plus AdditionBackwardRight of the (Cout,1,..) bias (addition/mod.rs:109-135), db[co] (+)= sum of g over samples
+ * and positions.  The implicit-GEMM pass stages g as its A operand anyway and sums it on the way (no separate 200 MB
+ * reduction at C3); geometries that take other kernels run the reduction behind the scenes.  `assign_*` != 0: first write. */
+int nk_conv_bwd_kernel_bias(nk_device* dev, int nd, float* dw, float* db, const int* w_shape, const float* g,
+                            const float* x, const int* x_shape, const int* stride, const int* dilation, int groups,
+                            int assign_dw, int assign_db);
 /* `Conv{1,2,3}d` module backward towards its input when the module's padding mode is Zero (lib.rs:630-916: pad ->
  * convolution): ConvolutionBackwardInput (convolution/mod.rs:146-189) followed by PadBackward (pad/mod.rs:131-181, the
  * centre block of the padded gradient is accumulated into dx) as ONE kernel.  x_shape is the UNPADDED input

@@ -92,6 +92,7 @@ _SIGS = {
     "nk_conv_bwd_input_padded": [VP, C.c_int, VP, c_intp, c_intp, VP, VP, c_intp, c_intp, c_intp, C.c_int],
     "nk_conv_bwd_input_padded_assign": [VP, C.c_int, VP, c_intp, c_intp, VP, VP, c_intp, c_intp, c_intp, C.c_int],
     "nk_conv_bwd_kernel": [VP, C.c_int, VP, c_intp, VP, VP, c_intp, c_intp, c_intp, C.c_int],
+    "nk_conv_bwd_kernel_bias": [VP, C.c_int, VP, VP, c_intp, VP, VP, c_intp, c_intp, c_intp, C.c_int, C.c_int, C.c_int],
     "nk_pad_const_fwd": [VP, C.c_int, VP, c_intp, VP, c_intp, C.c_float],
     "nk_pad_reflective_fwd": [VP, C.c_int, VP, c_intp, VP, c_intp],
     "nk_pad_replicative_fwd": [VP, C.c_int, VP, c_intp, VP, c_intp],
@@ -395,6 +396,13 @@ def conv_bwd_input(dev, dx, g, w, stride, dilation, groups=1, assign=False, padd
 def conv_bwd_kernel(dev, dw, g, x, stride, dilation, groups=1, assign=False):
     nd = x.ndim - 2
     check((lib.nk_conv_bwd_kernel_assign if assign else lib.nk_conv_bwd_kernel)(dev.h, nd, dw.p, dw.shape_c(), g.p, x.p, x.shape_c(), ints(stride), ints(dilation), groups))
+
+
+def conv_bwd_kernel_bias(dev, dw, db, g, x, stride, dilation, groups=1, assign=(False, False)):
+    """dw (+)= ConvolutionBackwardKernel and db (+)= the (Cout,1,..) bias gradient (sum of g over samples and positions), one pass."""
+    nd = x.ndim - 2
+    check(lib.nk_conv_bwd_kernel_bias(dev.h, nd, dw.p, db.p, dw.shape_c(), g.p, x.p, x.shape_c(), ints(stride), ints(dilation), groups,
+                                      int(assign[0]), int(assign[1])))
 
 
 def linear_fwd(dev, X, W, bias, Y):

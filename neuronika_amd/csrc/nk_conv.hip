@@ -387,19 +387,30 @@ int conv_bwd_input(nk_device* dev, int nd, float* dx, const int* x_shape, const 
     return nk_prof_stop(dev);
 }
 
+// `db` (optional, with `assign_b`): the conv module's bias gradient, db[co] (+)= sum of gy over samples and positions.  The MFMA
+// pass with quad staging produces it from the operand it stages anyway; the other paths run the un-broadcast reduction.
 int conv_bwd_kernel(nk_device* dev, int nd, float* dw, const int* w_shape, const float* gy, const float* x,
-                    const int* x_shape, const int* stride, const int* dilation, int groups, int assign) {
+                    const int* x_shape, const int* stride, const int* dilation, int groups, int assign, float* db = nullptr,
+                    int assign_b = 0) {
     NK_USE(dev);
     ConvGeom g;
     int rc = make_geom(nd, x_shape, w_shape, stride, dilation, groups, &g);
     if (rc) return rc;
+    auto bias_by_reduction = [&]() -> int {  // AdditionBackwardRight of the (Cout,1,..) bias as its own reduction
+        if (!db) return NK_OK;
+        int gshape[NK_MAX_DIMS], bshape[NK_MAX_DIMS];
+        gshape[0] = g.N; gshape[1] = g.Cout; bshape[0] = g.Cout;
+        for (int i = 0; i < nd; ++i) { gshape[2 + i] = g.out[3 - nd + i]; bshape[1 + i] = 1; }
+        return (assign_b ? nk_unbroadcast_assign : nk_unbroadcast_add)(dev, db, bshape, nd + 1, gy, gshape, nd + 2);
+    };
     const bool quadr = g.stride[2] == 1 && g.out[2] >= 4;  // row-padded quad staging (see the kernel)
     const long long R = quadr ? (long long)g.N * g.out[0] * g.out[1] * ((g.out[2] + 3) & ~3) : (long long)g.N * g.L;
     const int Kc = g.Cg * g.KK;
-    if ((long long)g.Cout * Kc == 0) return NK_OK;
+    if ((long long)g.Cout * Kc == 0) return bias_by_reduction();
     NK_CHECK(dw && gy && x, "null pointer in nk_conv_bwd_kernel");
     if (R == 0) {  // empty batch: the gradient is zero
         if (assign) NK_HIP(hipMemsetAsync(dw, 0, (size_t)g.Cout * Kc * sizeof(float), dev->compute));
+        if (db && assign_b) NK_HIP(hipMemsetAsync(db, 0, (size_t)g.Cout * sizeof(float), dev->compute));
         return NK_OK;
     }
     if (use_direct(g)) {  // few channels per group: one block per (co, ci, tap) dot product, split over (n, l)
@@ -428,7 +439,8 @@ int conv_bwd_kernel(nk_device* dev, int nd, float* dw, const int* w_shape, const
         hipLaunchKernelGGL(conv_dw_reduce_kernel, dim3((unsigned)((dw_n + 63) / 64)), dim3(256), 0, dev->compute, dw, (const float*)wsd,
                            dw_n, (int)dsplits, assign);
         NK_LAUNCH_CHECK();
-        return nk_prof_stop(dev);
+        rc = nk_prof_stop(dev);
+        return rc ? rc : bias_by_reduction();
     }
     BwdKArgs p{};
     p.g = g; p.gy = gy; p.x = x;
@@ -458,10 +470,13 @@ int conv_bwd_kernel(nk_device* dev, int nd, float* dw, const int* w_shape, const
     splits = (rtiles + rts - 1) / rts;
     p.r_per_split = rts * BK;
     const long long dw_elems = (long long)g.Cout * Kc;
+    const bool fused_bias = db && quadr;
+    const size_t slab_bytes = round256((size_t)splits * dw_elems * sizeof(float));
     void* ws = nullptr;
-    rc = nk_workspace(dev, (size_t)splits * dw_elems * sizeof(float), &ws);
+    rc = nk_workspace(dev, slab_bytes + (fused_bias ? (size_t)splits * g.Cout * sizeof(float) : 0), &ws);
     if (rc) return rc;
     p.slabs = (float*)ws;
+    p.bias_slabs = fused_bias ? (float*)((char*)ws + slab_bytes) : nullptr;
     dim3 grid((unsigned)(p.tiles_m * p.tiles_n * splits), 1, groups);
     const bool vec_g = (g.L % 4 == 0) && al16(gy);
     rc = nk_prof_start(dev, NK_KERNEL_CONV, 2.0 * g.N * (double)g.Cout * g.L * g.Cg * g.KK);
@@ -488,7 +503,14 @@ int conv_bwd_kernel(nk_device* dev, int nd, float* dw, const int* w_shape, const
     hipLaunchKernelGGL(conv_dw_reduce_kernel, dim3((unsigned)((dw_elems + 63) / 64)), dim3(256), 0, dev->compute, dw,
                        p.slabs, dw_elems, (int)splits, assign);
     NK_LAUNCH_CHECK();
-    return nk_prof_stop(dev);
+    if (fused_bias) {  // db[co] (+)= sum over splits (fixed order) of the per-split sums
+        hipLaunchKernelGGL(conv_dw_reduce_kernel, dim3((unsigned)((g.Cout + 63) / 64)), dim3(256), 0, dev->compute, db, p.bias_slabs,
+                           (long long)g.Cout, (int)splits, assign_b);
+        NK_LAUNCH_CHECK();
+    }
+    rc = nk_prof_stop(dev);
+    if (rc) return rc;
+    return fused_bias ? NK_OK : bias_by_reduction();
 }
 
 }  // namespace
@@ -529,6 +551,11 @@ int nk_conv_bwd_kernel(nk_device* dev, int nd, float* dw, const int* w_shape, co
 int nk_conv_bwd_kernel_assign(nk_device* dev, int nd, float* dw, const int* w_shape, const float* gy, const float* x,
                               const int* x_shape, const int* stride, const int* dilation, int groups) {
     return conv_bwd_kernel(dev, nd, dw, w_shape, gy, x, x_shape, stride, dilation, groups, 1);
+}
+int nk_conv_bwd_kernel_bias(nk_device* dev, int nd, float* dw, float* db, const int* w_shape, const float* gy, const float* x,
+                            const int* x_shape, const int* stride, const int* dilation, int groups, int assign_dw, int assign_db) {
+    NK_CHECK(db, "null bias gradient in nk_conv_bwd_kernel_bias");
+    return conv_bwd_kernel(dev, nd, dw, w_shape, gy, x, x_shape, stride, dilation, groups, assign_dw ? 1 : 0, db, assign_db ? 1 : 0);
 }
 
 }  // extern "C"

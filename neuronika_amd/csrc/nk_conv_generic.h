@@ -312,6 +312,7 @@ struct BwdKArgs {
     const float* gy;
     const float* x;
     float* slabs;        // [splits][groups][Mg][Cg*KK]
+    float* bias_slabs;   // optional [splits][groups][Mg]: per-split sums of G over the reduction range (the conv module's bias gradient)
     int tiles_m, tiles_n;
     long long r_per_split;  // multiple of BK
 };
@@ -455,11 +456,23 @@ __global__ __launch_bounds__(NT, 2) void conv_bwd_kernel_kernel(BwdKArgs p) {
         else load_scalar(r0);
     };
 
+    // Bias gradient of the conv module (sum of G over samples and positions per output channel), for free: the masked A
+    // operand IS G, every thread adds its staged quads of its rows (16 adds per k-tile, no branch in the loop - a wave-uniform
+    // `tn == 0` test there costs more than the adds, section 4.2 of DESIGN.md); the column-tile-0 blocks write the sums.
+    float bs0 = 0.f, bs1 = 0.f, bs2 = 0.f, bs3 = 0.f;
+    auto bias_acc = [&]() {
+        bs0 += (ra.v0.x + ra.v0.y) + (ra.v0.z + ra.v0.w);
+        bs1 += (ra.v1.x + ra.v1.y) + (ra.v1.z + ra.v1.w);
+        if constexpr (TI == 2) {
+            bs2 += (ra.v2.x + ra.v2.y) + (ra.v2.z + ra.v2.w);
+            bs3 += (ra.v3.x + ra.v3.y) + (ra.v3.z + ra.v3.w);
+        }
+    };
     f32x16 acc[TI][TJ];
     acc_zero<TI, TJ>(acc);
     if (nt > 0) {
         load_both(rbeg);
-        if constexpr (QUADR) mask_quad();
+        if constexpr (QUADR) { mask_quad(); bias_acc(); }
         else mask_scalar();
         stage_store<true, BM>(smem, ra, t);
         stage_store<true, BN>(smem + TA_FLOATS, rb, t);
@@ -471,7 +484,7 @@ __global__ __launch_bounds__(NT, 2) void conv_bwd_kernel_kernel(BwdKArgs p) {
         load_both(rbeg + (long long)(it + 1) * BK);
         __builtin_amdgcn_sched_barrier(0);
         mma_tile<true, true, TI, TJ>(cur, cur + TA_FLOATS, acc, wr, wc, lane);
-        if constexpr (QUADR) mask_quad();
+        if constexpr (QUADR) { mask_quad(); bias_acc(); }
         else mask_scalar();
         stage_store<true, BM>(nxt, ra, t);
         stage_store<true, BN>(nxt + TA_FLOATS, rb, t);
@@ -480,6 +493,20 @@ __global__ __launch_bounds__(NT, 2) void conv_bwd_kernel_kernel(BwdKArgs p) {
     if (nt > 0) {
         float* cur = smem + ((nt - 1) & 1) * STAGE;
         mma_tile<true, true, TI, TJ>(cur, cur + TA_FLOATS, acc, wr, wc, lane);
+    }
+    if (QUADR && p.bias_slabs && tn == 0) {  // the 8 lanes that staged one row (k-quads 0..7) are neighbours: fold, lane 0 writes
+        float* Bsl = p.bias_slabs + ((long long)split * g.groups + grp) * g.Mg;
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) {
+            bs0 += __shfl_xor(bs0, o, 64); bs1 += __shfl_xor(bs1, o, 64);
+            bs2 += __shfl_xor(bs2, o, 64); bs3 += __shfl_xor(bs3, o, 64);
+        }
+        if (rq == 0) {
+            if (av0) Bsl[m0 + row] = bs0;
+            if (av1) Bsl[m0 + row + 32] = bs1;
+            if (TI == 2 && av2) Bsl[m0 + row + 64] = bs2;
+            if (TI == 2 && av3) Bsl[m0 + row + 96] = bs3;
+        }
     }
     float* S = p.slabs + ((long long)split * g.groups + grp) * (long long)g.Mg * Kc;
     const int Mg = g.Mg;

@@ -155,6 +155,35 @@ def test_conv_random_vs_oracle(dev, xs, ws, s, d, g):
     contraction_ok(DW.numpy(), dw32, dw64, xs[0] * int(np.prod(oshape[2:])), 1.0, 1.0)
 
 
+@pytest.mark.parametrize("xs,ws,s,d,g", CONV_RANDOM)
+def test_conv_kernel_and_bias_gradient_in_one_pass(dev, xs, ws, s, d, g):
+    """nk_conv_bwd_kernel_bias: the kernel gradient is BIT-identical to nk_conv_bwd_kernel's (same pass), the bias gradient -
+    AdditionBackwardRight of the module's (Cout,1,..) bias, summed on the way by the implicit-GEMM pass or by the reduction
+    behind the scenes for the other kernel families - matches the oracle's un-broadcast sum; `+=` and first-write forms."""
+    c = capi()
+    x, w = rnd(0, xs), rnd(1, ws, -1, 1)
+    oshape = O.conv_out_shape(xs, ws, s, d)
+    go = rnd(2, oshape, -1, 1)
+    X, G = dev.array(x), dev.array(go)
+    dw0, db0 = rnd(4, ws), rnd(5, (ws[0],) + (1,) * (len(xs) - 2))
+    ref_dw = dev.array(dw0)
+    c.conv_bwd_kernel(dev, ref_dw, G, X, s, d, g)
+    DW, DB = dev.array(dw0), dev.array(db0)
+    c.conv_bwd_kernel_bias(dev, DW, DB, G, X, s, d, g)
+    assert np.array_equal(DW.numpy(), ref_dw.numpy())
+    axes = (0,) + tuple(range(2, len(oshape)))
+    sum64 = go.astype(np.float64).sum(axis=axes).reshape(db0.shape)
+    sum32 = np.zeros(db0.shape, np.float32); O.accumulate(sum32, go)
+    n_terms = go.size // ws[0]
+    err_gpu, err_cpu = np.abs(DB.numpy() - (db0 + sum64)).max(), np.abs(sum32 - sum64).max()
+    assert err_gpu <= max(4 * err_cpu, 1e-6 * n_terms ** 0.5 * np.abs(go).max() + 2e-7 * np.abs(db0 + sum64).max()), (err_gpu, err_cpu)
+    DW2, DB2 = dev.array(dw0), dev.array(db0)       # first-write form: the buffers' contents do not matter
+    c.conv_bwd_kernel_bias(dev, DW2, DB2, G, X, s, d, g, assign=(True, True))
+    ref2 = dev.array(dw0); c.conv_bwd_kernel(dev, ref2, G, X, s, d, g, assign=True)
+    assert np.array_equal(DW2.numpy(), ref2.numpy())
+    np.testing.assert_allclose(DB2.numpy(), DB.numpy() - db0, rtol=1e-5, atol=1e-5 * np.abs(sum64).max() + 1e-6)
+
+
 CONV_PADDED = [
     # unpadded x shape, w shape, padding, stride, dilation, groups
     ((2, 64, 16, 16), (128, 64, 3, 3), (1, 1), (1, 1), (1, 1), 1),     # C3-shaped, fast kernel
