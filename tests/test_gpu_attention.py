@@ -126,6 +126,23 @@ def test_attention_forward_without_kept_state_is_the_same_forward(dev, S, p):
         c.attention_fwd(dev, Q, K, V, scores, None, None, lean, B, S, H, dh, scale, p, True, seed, offset)
 
 
+def test_attention_core_is_deterministic_at_benchmark_width(dev):
+    """S = 1024 (the C5 width: 32 key tiles per block, 8 blocks per head): two runs on the same inputs agree BIT for bit in
+    every output - scores, statistics, dropout bits, O, dS, Pd, dQ, dK, dV - (no atomics anywhere: the query-block
+    reduction of dK / dV is two batched products in a fixed order), and a different Philox offset changes the mask."""
+    B, S, H, p, seed = 1, 1024, 2, 0.1, 4711
+    q, k, v, g = (rnd(s_, (B * S, H * 64), -1, 1) for s_ in (31, 32, 33, 34))
+    dq0 = np.zeros((B * S, H * 64), np.float32)
+    a, _ = _run(dev, B, S, H, p, True, seed, 0, True, q, k, v, g, dq0)
+    b, _ = _run(dev, B, S, H, p, True, seed, 0, True, q, k, v, g, dq0)
+    for name in a:
+        assert np.array_equal(a[name], b[name]), name
+    c2, _ = _run(dev, B, S, H, p, True, seed, 1 << 20, True, q, k, v, g, dq0)
+    assert not np.array_equal(a["bits"], c2["bits"])
+    keep = np.unpackbits(a["bits"].view(np.uint8)).mean()
+    assert abs(keep - (1 - p)) < 2e-3          # 2 M draws: the keep rate is 1 - p to three digits
+
+
 def test_attention_core_rejects_what_it_cannot_do(dev):
     c = capi()
     assert c.attention_supported(1024, 64, 0.1) and c.attention_supported(32, 64, 0.0)
