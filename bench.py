@@ -33,17 +33,33 @@ convolution, which is rayon batch-parallel, node/convolution/mod.rs:110-122) and
 fraction of the f32 MFMA peak), `rccl_ranks`, `allreduce_bytes_per_step` and `exposed_comm_ms`
 (step time minus the step time of the same loop with the gradient exchange switched off).
 
+At N = 1 the default line additionally carries every other BASELINE configuration as a sub-record of the same shape
+(value, ms_per_step, roofline{achieved, frac, launches, avg_launch_ms}), SUB_STEPS timed steps each after the clock
+settle phase: `matmul_1024 / _2048 / _4096 / _8192` (C2), `conv_c3` (C3) and `mha_c5` (C5, with `attention_core`) -
+about 3 s of GPU time in total - so that one driver-run record holds all headline numbers.
+
+At N > 1 the line is self-diagnosing: per-rank device ms/step (`per_rank_device_ms_per_step`, min / max), a stand-alone
+all-reduce of the step's gradient bytes before the timed loop (`allreduce_alone`: ms, algorithm and bus GB/s, also at
+the bucket sizes the step uses), `exposed_comm_ms`, the GEMM launch time with and without the overlapped exchange
+(`gemm_contention`), and what RCCL chose (`rccl`: version, channels, algorithm / protocol per message size, parsed from
+rank 0's NCCL_DEBUG=INFO log).  Every rank arms a watchdog (NK_BENCH_TIMEOUT_S, default 600 s) that dumps the Python
+stack of a hung rank and exits; the self-spawning launcher has an overall timeout and relays the last 2 KB of every
+rank's stderr when the job fails.
+
 Other workloads (parity-test configurations, not the headline): --workload matmul | conv | mha.
 """
 from __future__ import annotations
 
 import argparse
+import faulthandler
 import json
 import os
+import re
 import secrets
 import socket
 import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -56,6 +72,15 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 MFMA_F32_PEAK = 157.3e12   # /opt/skills/guides/MI355X_MICROARCH.md: f32-in MFMA, dense
 HBM_PEAK = 8.0e12
+XGMI_LINK_GBS = 153.0      # same guide: per xGMI link and direction
+SUB_STEPS, SUB_WARMUP = 20, 3   # timed / warm-up steps of the C2 / C3 / C5 sub-records of the default line
+T_START = time.perf_counter()
+
+
+def _log(msg):
+    """Progress marker on stderr (multi-rank runs, or NK_BENCH_VERBOSE): a hung run shows where it stopped."""
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("NK_BENCH_VERBOSE"):
+        print(f"[bench r{os.environ.get('RANK', '0')} +{time.perf_counter() - T_START:6.1f}s] {msg}", file=sys.stderr, flush=True)
 
 
 def parse():
@@ -95,6 +120,10 @@ class Dist:
 
     def max(self, v: float) -> float:
         return self.rv.max(v)
+
+    def gather(self, v: float):
+        """Every rank's value, in rank order, on every rank."""
+        return self.rv.gather(v)
 
     def close(self):
         self.rv.close()
@@ -154,12 +183,15 @@ EXTRA_STATS = {}  # kernel classes only one workload has (the fused attention co
 
 
 def read_traffic(kernel):
-    """HBM bytes per launch from the committed rocprofv3 PMC summary (profiles/), if any."""
+    """(HBM bytes per launch, commit it was measured at) from the committed rocprofv3 PMC summary (profiles/), if any.
+    The counters cannot be collected inside this run (PMC passes replay every kernel under rocprofv3): the value is the
+    one tools/traffic_pmc.sh + tools/make_roofline_traffic.py wrote, and the line echoes the commit it belongs to."""
     p = os.path.join(ROOT, "profiles", "roofline_traffic.json")
     try:
-        return json.load(open(p)).get(kernel)
+        d = json.load(open(p))
+        return d.get(kernel), d.get("_measured_at_commit")
     except Exception:
-        return None
+        return None, None
 
 
 # ------------------------------------------------------------------------------------------------
@@ -282,12 +314,16 @@ def cpu_baseline_mha(b_sample, S, d, H, p):
 # ------------------------------------------------------------------------------------------------
 # workloads
 # ------------------------------------------------------------------------------------------------
-def roofline_mfma(gemm_stats, kernel, traffic):
+def roofline_mfma(gemm_stats, kernel, traffic_key=None):
     n_launch, ms, flop = gemm_stats
     achieved = flop / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-    return {"bound": "mfma", "kernel": kernel, "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s",
-            "frac": round(achieved * 1e12 / MFMA_F32_PEAK, 4), "traffic": traffic, "launches": n_launch,
-            "avg_launch_ms": round(ms / max(1, n_launch), 4), "algorithmic_flop_per_launch": flop / max(1, n_launch)}
+    traffic, at = read_traffic(traffic_key) if traffic_key else (None, None)
+    out = {"bound": "mfma", "kernel": kernel, "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s",
+           "frac": round(achieved * 1e12 / MFMA_F32_PEAK, 4), "traffic": traffic, "launches": n_launch,
+           "avg_launch_ms": round(ms / max(1, n_launch), 4), "algorithmic_flop_per_launch": flop / max(1, n_launch)}
+    if traffic is not None:
+        out["traffic_measured_at_commit"] = at
+    return out
 
 
 class _CapiSync:  # adapt capi.Device to the `sync()` interface of the tape's Device
@@ -306,6 +342,146 @@ def matmul_fwd_bwd(dist, dev, n, steps, warmup):
         c.mm_fwd(dev, A, B, Cm); c.mm_bwd_left(dev, dA, G, B); c.mm_bwd_right(dev, dB, A, G)
     dt, _, gemm, _ = timed_steps(dist, _CapiSync(dev), dev, step, steps, warmup)
     return dt, gemm
+
+
+def matmul_record(dist, dev, n, steps, warmup):
+    """One C2 size as a record: value = whole fwd+bwd TFLOP/s (host clock over the timed steps), roofline = the GEMM
+    launches themselves (HIP events around every launch)."""
+    dt, gemm = matmul_fwd_bwd(dist, dev, n, steps, warmup)
+    tf = 6.0 * n ** 3 * steps / dt / 1e12
+    roof = roofline_mfma(gemm, "sgemm_kernel", "sgemm_kernel" if n == 4096 else None)
+    return {"workload": f"C2: mm fwd + bwd-left + bwd-right, N={n}, {steps} steps", "value": round(tf, 2), "unit": "TFLOP/s",
+            "tflops": round(tf, 2), "frac_of_mfma_peak": round(tf * 1e12 / MFMA_F32_PEAK, 4),
+            "kernel_tflops": roof["achieved"], "kernel_frac": roof["frac"], "steps": steps,
+            "ms_per_step": round(dt / steps * 1e3, 4), "roofline": roof}
+
+
+def measure_conv(dist, tdev, cdev, steps, warmup):
+    """C3: zero-pad(1) -> Conv2d 3x3 s1, NCHW 128x64x56x56 -> 128 channels, fwd + both backward passes.  The upstream
+    gradient dY is seeded directly into the convolution output's gradient (`backward_from`), so the timed step holds the
+    module's own nodes only."""
+    import neuronika_amd
+    t = neuronika_amd.tape
+    N = 128
+    x = np.random.default_rng(0).random((N, 64, 56, 56), dtype=np.float32)
+    conv = t.nn.Conv2d(tdev, 64, 128, [3, 3], [1, 1], [1, 1], [1, 1], 1, 1)
+    X = t.from_ndarray(tdev, x).requires_grad()
+    y = conv.forward(X)
+    G = t.from_ndarray(tdev, np.random.default_rng(2).random((N, 128, 56, 56), dtype=np.float32))
+
+    def step():
+        y.forward()
+        y.no_grad(); y.with_grad()
+        y.backward_from(G)
+        X.zero_grad(); conv.weight.zero_grad(); conv.bias.zero_grad()
+
+    dt, ev_ms, _, conv_stats = timed_steps(dist, tdev, cdev, step, steps, warmup)
+    return {"workload": "C3: pad(1) -> conv 3x3 s1 d1 g1, x 128x64x56x56 -> 128 ch, +bias, fwd+bwd-input+bwd-kernel",
+            "value": round(N * steps * dist.world / dt, 2), "unit": "samples/s", "steps": steps,
+            "ms_per_step": round(dt / steps * 1e3, 4),
+            "step_tflops": round(3 * 2.0 * N * 128 * 56 * 56 * 64 * 9 * steps / dt / 1e12, 2),
+            "roofline": roofline_mfma(conv_stats, "conv_fwd_fast / conv_bwd_input_fast / conv_bwd_kernel (implicit GEMM, f32 MFMA)", "conv"),
+            "conv_share_of_step": round(conv_stats[1] / ev_ms, 4) if ev_ms > 0 else None}
+
+
+def measure_mha(dist, tdev, cdev, steps, warmup):
+    """C5: composed multi-head attention d=1024 h=16 S=1024 B=32, dropout 0.1, fwd+bwd."""
+    import neuronika_amd
+    t = neuronika_amd.tape
+    B, S, d, H = 32, 1024, 1024, 16
+    t.manual_seed(7 + dist.rank)                     # Philox key of the dropout node: per-rank, so shards draw different masks
+    mha = t.nn.MultiheadAttention(tdev, d, H, 0.1, 1)
+    if "NK_MHA_STRIDED" in os.environ:               # A/B aid: heads addressed in place (1) or split/merge copies (0)
+        mha.strided_heads = os.environ["NK_MHA_STRIDED"] == "1"
+    if "NK_MHA_CORE" in os.environ:                  # A/B aid: fused attention kernels (1) or GEMM -> row kernel -> GEMM (0)
+        mha.fused_core = os.environ["NK_MHA_CORE"] == "1"
+    X = t.from_ndarray(tdev, np.random.default_rng(0).random((B * S, d), dtype=np.float32)).requires_grad()
+    G = t.from_ndarray(tdev, np.random.default_rng(5).random((B * S, d), dtype=np.float32))
+    y = mha.forward(X, B)
+    leaves = [X] + [getattr(getattr(mha, n), w) for n in "qkvo" for w in ("weight", "bias")]
+
+    def step():
+        y.forward()
+        y.no_grad(); y.with_grad()
+        y.backward_from(G)
+        for p in leaves:
+            p.zero_grad()
+
+    dt, ev_ms, gemm, _ = timed_steps(dist, tdev, cdev, step, steps, warmup)
+    rec = {"workload": "C5: MHA d_model=1024 heads=16 seq=1024 batch=32 dropout=0.1, composed from reference ops",
+           "value": round(B * steps * dist.world / dt, 2), "unit": "sequences/s", "steps": steps,
+           "ms_per_step": round(dt / steps * 1e3, 4),
+           "step_tflops": round(1.237e12 * steps / dt / 1e12, 2),   # SURVEY 8d: 412.3 GFLOP forward, twice that backward
+           "roofline": roofline_mfma(gemm, "sgemm_kernel (projections and their gradients, dK / dV)", "mha_gemm"),
+           "gemm_share_of_step": round(gemm[1] / ev_ms, 4) if ev_ms > 0 else None}
+    att = EXTRA_STATS.get("attention")
+    if att and att[0]:   # nk_attention_fwd / nk_attention_bwd: 4*B*H*S*S*dh flop each (two MFMA products per score tile)
+        rec["attention_core"] = dict(roofline_mfma(att, "attention_kernel (scores -> softmax -> dropout -> context, and its backward)", "attention"),
+                                     share_of_step=round(att[1] / ev_ms, 4))
+    return rec
+
+
+# ---- what RCCL chose, from rank 0's NCCL_DEBUG=INFO log ---------------------------------------------------------------
+_RCCL_ALGO = {0: "Tree", 1: "Ring", 2: "CollNetDirect", 3: "CollNetChain", 4: "NVLS", 5: "NVLSTree"}
+_RCCL_PROTO = {0: "LL", 1: "LL128", 2: "Simple"}
+
+
+def parse_rccl_log(text, max_excerpt=16):
+    """Version, channel count and the algorithm / protocol per message size out of an NCCL_DEBUG=INFO log (subsystems
+    INIT + TUNING).  Tolerant: every field is optional, unmatched logs give an excerpt only."""
+    out = {"version": None, "channels": None, "choices": [], "env_overrides": [], "warnings": 0}
+    m = re.search(r"(?:RCCL|NCCL) version\s*:?\s*([0-9][^\s]*)", text)
+    if m:
+        out["version"] = m.group(1)
+    m = re.search(r"(\d+) coll channels", text)
+    if m:
+        out["channels"] = int(m.group(1))
+    else:
+        ch = [int(x) for x in re.findall(r"Channel \d+/(\d+)", text)]
+        if ch:
+            out["channels"] = max(ch)
+    seen = {}
+    for coll, nbytes, algo, proto in re.findall(r"(\w+): (\d+) Bytes -> Algo (\d+) proto (\d+)", text):
+        key = (coll, int(nbytes), int(algo), int(proto))
+        seen[key] = seen.get(key, 0) + 1
+    out["choices"] = [{"coll": c, "bytes": b, "algo": _RCCL_ALGO.get(a, str(a)), "proto": _RCCL_PROTO.get(pr, str(pr)), "calls": n}
+                      for (c, b, a, pr), n in sorted(seen.items(), key=lambda kv: -kv[0][1])][:12]
+    out["env_overrides"] = sorted(set(re.findall(r"((?:NCCL|RCCL)_[A-Z0-9_]+) set by environment to ([^\s]+)", text)))[:16]
+    out["env_overrides"] = [f"{k}={v}" for k, v in out["env_overrides"]]
+    out["warnings"] = len(re.findall(r" NCCL WARN ", text))
+    keep = [ln.strip()[-200:] for ln in text.splitlines()
+            if re.search(r"version|coll channels|Channel 00|Ring 00|Trees|Connected all|comm 0x.*nranks|WARN|P2P|XGMI|threadThresholds", ln)]
+    out["excerpt"] = keep[:max_excerpt]
+    return out
+
+
+def allreduce_alone(dist, tdev, cdev, comm_raw, sizes, reps=20):
+    """Stand-alone sum all-reduce of flat f32 buffers (no compute in flight): time per call (max over ranks), algorithm
+    bandwidth = bytes / time and bus bandwidth = 2 (p - 1) / p x that (the per-link figure a ring is bound by)."""
+    from neuronika_amd import capi
+    import ctypes as C
+    world, out = dist.world, []
+    for nbytes in sizes:
+        n = nbytes // 4
+        buf = cdev.zeros((n,))
+        h = C.c_void_p(comm_raw)
+
+        def ar():
+            capi.check(capi.lib.nk_allreduce_sum_async(h, buf.p, n, None))
+            capi.check(capi.lib.nk_comm_join(h))
+        for _ in range(3):
+            ar()
+        tdev.sync(); dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            ar()
+        tdev.sync()
+        dt = dist.max(time.perf_counter() - t0) / reps
+        alg = nbytes / dt / 1e9
+        out.append({"bytes": nbytes, "ms": round(dt * 1e3, 4), "algbw_GBps": round(alg, 2),
+                    "busbw_GBps": round(alg * 2 * (world - 1) / world, 2)})
+        del buf
+    return out
 
 
 def run_mlp(a, dist):
@@ -328,20 +504,29 @@ def run_mlp(a, dist):
     opt = t.optim.SGD(1e-3)
     for p in params:
         opt.register(p)
+    _log("graph built")
     comm = sync = None
     replicas = int(os.environ.get("NK_BENCH_REPLICAS", "0")) if world == 1 else 0
-    if world > 1:
+    single_rank_rccl = world == 1 and os.environ.get("NK_BENCH_FORCE_RCCL") == "1"
+    if world > 1 or single_rank_rccl:
+        # (NK_BENCH_FORCE_RCCL=1 on one GPU: a one-rank RCCL communicator with the exchange forced on - every line of
+        # the N > 1 path below, including the RCCL log capture, runs on a 1-GPU box; the record is labelled.)
         uid = dist.bcast_bytes(t.dp.Communicator.unique_id() if dist.rank == 0 else None)
+        _log("RCCL unique id broadcast, ncclCommInitRank ...")
         comm = t.dp.Communicator(tdev, world, dist.rank, uid)
+        _log(f"communicator up: {comm.size} ranks")
         if comm.size != world:
             raise SystemExit(f"[bench] RCCL communicator has {comm.size} ranks, expected {world}")
         sync = t.dp.GradientSync(comm, params)
+        if single_rank_rccl:
+            sync.set_force_exchange(True)
     elif replicas > 1:
         # debugging aid for 1-GPU boxes: the whole N > 1 code path of this function (hook, piecewise hand-over, grouped
         # small gradients, join, the exposed-communication loop) over a replica communicator - `replicas` virtual ranks
         # holding this rank's values, no fabric traffic.  The line is labelled; it is not a multi-GPU measurement.
         comm = t.dp.Communicator.replicas(tdev, replicas)
         sync = t.dp.GradientSync(comm, params)
+    real_rccl = comm is not None and replicas <= 1
     seed = 1.0 / (replicas if replicas > 1 else world)
     exchange = [True]
 
@@ -357,147 +542,144 @@ def run_mlp(a, dist):
             opt.step()
         opt.zero_grad()
 
+    alone = None
+    if real_rccl:   # before the timed loop: what the fabric gives an all-reduce with nothing else running
+        total = sync.bytes_per_step()
+        sizes = sorted({total, 4 * H * H, 2 * H * H}, reverse=True)   # everything / one weight gradient / the half the step hands over
+        alone = allreduce_alone(dist, tdev, cdev, comm.raw(), sizes)
+        _log(f"stand-alone all-reduce: {alone[0]['ms']} ms for {alone[0]['bytes']} B")
+
     dt, ev_ms, gemm, _ = timed_steps(dist, tdev, cdev, step, a.steps, a.warmup)
+    _log(f"timed loop done: {dt / a.steps * 1e3:.3f} ms/step")
     settle = EXTRA_STATS["settle_steps"]           # (the later timed_steps calls of this function overwrite it)
     loss_val = loss.item()
     n_exch = sync.exchanges_issued() if sync is not None else 0
-    exposed = 0.0
+    per_rank = dist.gather(ev_ms / a.steps)
+    exposed, gemm_off = 0.0, None
     if sync is not None:                           # the same loop with the exchange switched off: what the all-reduce costs
         exchange[0] = False
-        dt_off, _, _, _ = timed_steps(dist, tdev, cdev, step, a.steps, 2)
+        dt_off, _, gemm_off, _ = timed_steps(dist, tdev, cdev, step, a.steps, 2)
         exposed = (dt - dt_off) / a.steps * 1e3
-    mm_n = 4096                                    # second half of BASELINE.json's metric: MatMul MFMA %peak (C2, N = 4096)
-    mm_steps = 20
-    mm_dt, mm_gemm = matmul_fwd_bwd(dist, cdev, mm_n, mm_steps, 3)
+        _log(f"exchange off: {dt_off / a.steps * 1e3:.3f} ms/step")
+    subs = {}
+    if world == 1 and not os.environ.get("NK_BENCH_NO_SUBRECORDS"):
+        # every other BASELINE configuration, same record shape, SUB_STEPS timed steps each (C2 at 4096: the second
+        # half of BASELINE.json's metric, "MatMul MFMA %peak")
+        for n in (1024, 2048, 4096, 8192):
+            subs[f"matmul_{n}"] = matmul_record(dist, cdev, n, SUB_STEPS, SUB_WARMUP)
+        subs["conv_c3"] = measure_conv(dist, tdev, cdev, SUB_STEPS, SUB_WARMUP)
+        subs["mha_c5"] = measure_mha(dist, tdev, cdev, SUB_STEPS, SUB_WARMUP)
+    else:
+        subs["matmul_4096"] = matmul_record(dist, cdev, 4096, SUB_STEPS, SUB_WARMUP)
     res = None
     if dist.rank == 0:
-        mm_roof = roofline_mfma(mm_gemm, "sgemm_kernel", None)
+        debug_run = replicas > 1 or single_rank_rccl
         res = {
-            "metric": "training-step samples/sec (fwd+bwd+allreduce)", "value": round(B * world * a.steps / dt, 2),
+            "metric": "training-step samples/sec (fwd+bwd+allreduce)" if not debug_run else
+                      "DEBUG RUN of the N > 1 code path on one GPU (no fabric traffic): not a multi-GPU measurement",
+            "value": round(B * world * a.steps / dt, 2),
             "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"C4: 3-layer MLP Linear({H},{H})x3 + ReLU, MSE mean, batch {B}/GPU, data-parallel "
                                    f"gradient all-reduce (RCCL, side stream)", "global_batch": B * world,
                        "parallelism": f"dp{world}", "optimizer_step_in_timed_region": not a.no_optimizer},
-            "rccl_ranks": comm.size if (comm is not None and replicas <= 1) else 1,
+            "rccl_ranks": comm.size if real_rccl else 1,
             **({"replica_ranks_debug": replicas} if replicas > 1 else {}),
+            **({"rccl_single_rank_debug": True} if single_rank_rccl else {}),
             "allreduce_bytes_per_step": sync.bytes_per_step() if sync is not None else 0,
             "allreduce_launches_per_step": n_exch // (a.steps + a.warmup + settle) if sync is not None else 0,
             "clock_settle_steps": settle,
-            "exposed_comm_ms": round(exposed, 4),
-            "roofline": roofline_mfma(gemm, "sgemm_kernel (f32 MFMA 32x32x2, 128x128x32 tiles)", read_traffic("sgemm_kernel")),
-            "matmul_4096": {"workload": f"C2: mm fwd + bwd-left + bwd-right, N={mm_n}, {mm_steps} steps",
-                            "tflops": round(6.0 * mm_n ** 3 * mm_steps / mm_dt / 1e12, 2),
-                            "frac_of_mfma_peak": round(6.0 * mm_n ** 3 * mm_steps / mm_dt / MFMA_F32_PEAK, 4),
-                            "kernel_tflops": mm_roof["achieved"], "kernel_frac": mm_roof["frac"],
-                            "ms_per_step": round(mm_dt / mm_steps * 1e3, 4)},
+            # (a replica communicator moves nothing over the fabric: its "exposed communication" is not one)
+            "exposed_comm_ms": None if replicas > 1 else round(exposed, 4),
+            "roofline": roofline_mfma(gemm, "sgemm_kernel (f32 MFMA 32x32x2, 128x128x32 tiles)", "sgemm_kernel"),
+            **subs,
             "device_ms_per_step": round(ev_ms / a.steps, 4), "loss": loss_val,
             "gemm_share_of_step": round(gemm[1] / ev_ms, 4) if ev_ms > 0 else None,
         }
-        if world == 1 and not a.no_cpu_baseline:
+        if sync is not None:
+            res["per_rank_device_ms_per_step"] = [round(v, 4) for v in per_rank]
+            res["per_rank_device_ms_min_max"] = [round(min(per_rank), 4), round(max(per_rank), 4)]
+            res["gemm_contention"] = {   # the same GEMM launches with the exchange running beside them and without
+                "avg_launch_ms_overlapped": round(gemm[1] / max(1, gemm[0]), 4),
+                "avg_launch_ms_no_exchange": round(gemm_off[1] / max(1, gemm_off[0]), 4),
+                "slowdown": round((gemm[1] / max(1, gemm[0])) / max(1e-9, gemm_off[1] / max(1, gemm_off[0])), 4)}
+        if alone is not None:
+            ring_ms = 2 * (world - 1) / world * alone[0]["bytes"] / (XGMI_LINK_GBS * 1e9) * 1e3 if world > 1 else 0.0
+            res["allreduce_alone"] = {"ms": alone[0]["ms"], "bytes": alone[0]["bytes"], "algbw_GBps": alone[0]["algbw_GBps"],
+                                      "busbw_GBps": alone[0]["busbw_GBps"], "by_size": alone,
+                                      "one_link_ring_floor_ms": round(ring_ms, 4)}
+            res["rccl"] = read_rccl_log()
+        if world == 1 and not debug_run and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline_mlp(H, B)
     if comm is not None:
         tdev.sync()
     return res
 
 
+def read_rccl_log():
+    path = os.environ.get("NK_BENCH_RCCL_LOG")
+    if not path:
+        return {"note": "NCCL_DEBUG was set by the caller: RCCL's log went where the caller sent it"}
+    try:
+        with open(path, errors="replace") as f:
+            text = f.read()
+    except OSError as e:
+        return {"note": f"no RCCL log at {path}: {e}"}
+    return parse_rccl_log(text)
+
+
+def _headline(res, rec, metric, config_extra=None):
+    """A sub-record (measure_*) as a top-level line of its own workload."""
+    out = {"metric": metric, "value": rec["value"], "unit": rec["unit"], "n_gpus": res["n_gpus"], "steps": rec["steps"],
+           "warmup": res["warmup"], "ms_per_step": rec["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": {"workload": rec["workload"], **(config_extra or {})}}
+    out.update({k: v for k, v in rec.items() if k not in ("value", "unit", "steps", "ms_per_step", "workload")})
+    return out
+
+
 def run_matmul(a, dist):
     """C2: C = A.B forward + dA += G.B^T, dB += A^T.G, f32 N x N."""
     from neuronika_amd import capi as c
     dev = c.Device(dist.local)
-    n = a.n
-    dt, gemm = matmul_fwd_bwd(dist, dev, n, a.steps, a.warmup)
+    rec = matmul_record(dist, dev, a.n, a.steps, a.warmup)
     if dist.rank != 0:
         return None
-    res = {"metric": "MatMul fwd+bwd TFLOP/s (MFMA %peak)", "value": round(6.0 * n ** 3 * a.steps / dt / 1e12 * dist.world, 2),
-           "unit": "TFLOP/s", "n_gpus": dist.world, "steps": a.steps, "warmup": a.warmup,
-           "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": "f32", "data": "synthetic", "config": {"workload": f"C2: matmul fwd+bwd, square N={n}", "n": n},
-           "roofline": roofline_mfma(gemm, "sgemm_kernel", read_traffic("sgemm_kernel") if n == 4096 else None)}
+    rec["value"] = round(rec["value"] * dist.world, 2)
+    res = _headline({"n_gpus": dist.world, "warmup": a.warmup}, rec, "MatMul fwd+bwd TFLOP/s (MFMA %peak)", {"n": a.n})
+    for k in ("tflops", "frac_of_mfma_peak", "kernel_tflops", "kernel_frac"):
+        res.pop(k, None)
     if dist.world == 1 and not a.no_cpu_baseline:
-        res["cpu_baseline"] = cpu_baseline_matmul(n)
+        res["cpu_baseline"] = cpu_baseline_matmul(a.n)
     return res
 
 
-def run_conv(a, dist):
-    """C3: zero-pad(1) -> Conv2d 3x3 s1, NCHW 128x64x56x56 -> 128 channels, fwd + both backward passes.  The upstream
-    gradient dY is seeded directly into the convolution output's gradient (`backward_from`), so the timed step holds the
-    module's own nodes only."""
+def _tape_devices(dist):
     import neuronika_amd
     from neuronika_amd import capi
-    t = neuronika_amd.tape
-    tdev = t.Device(dist.local)
-    cdev = capi.Device(handle=tdev.raw())
-    N = 128
-    x = np.random.default_rng(0).random((N, 64, 56, 56), dtype=np.float32)
-    conv = t.nn.Conv2d(tdev, 64, 128, [3, 3], [1, 1], [1, 1], [1, 1], 1, 1)
-    X = t.from_ndarray(tdev, x).requires_grad()
-    y = conv.forward(X)
-    G = t.from_ndarray(tdev, np.random.default_rng(2).random((N, 128, 56, 56), dtype=np.float32))
+    tdev = neuronika_amd.tape.Device(dist.local)
+    return tdev, capi.Device(handle=tdev.raw())
 
-    def step():
-        y.forward()
-        y.no_grad(); y.with_grad()
-        y.backward_from(G)
-        X.zero_grad(); conv.weight.zero_grad(); conv.bias.zero_grad()
 
-    dt, ev_ms, _, conv_stats = timed_steps(dist, tdev, cdev, step, a.steps, a.warmup)
+def run_conv(a, dist):
+    tdev, cdev = _tape_devices(dist)
+    rec = measure_conv(dist, tdev, cdev, a.steps, a.warmup)
     if dist.rank != 0:
         return None
-    res = {"metric": "Conv2d fwd+bwd samples/s", "value": round(N * a.steps / dt, 2), "unit": "samples/s",
-           "n_gpus": dist.world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4),
-           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-           "config": {"workload": "C3: pad(1) -> conv 3x3 s1 d1 g1, x 128x64x56x56 -> 128 ch, +bias, fwd+bwd-input+bwd-kernel"},
-           "roofline": roofline_mfma(conv_stats, "conv_fwd_fast / conv_bwd_input_fast / conv_bwd_kernel (implicit GEMM, f32 MFMA)",
-                                     read_traffic("conv")),
-           "conv_share_of_step": round(conv_stats[1] / ev_ms, 4)}
+    res = _headline({"n_gpus": dist.world, "warmup": a.warmup}, rec, "Conv2d fwd+bwd samples/s")
     if dist.world == 1 and not a.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline_conv(128)
     return res
 
 
 def run_mha(a, dist):
-    """C5: composed multi-head attention d=1024 h=16 S=1024 B=32, dropout 0.1, fwd+bwd."""
-    import neuronika_amd
-    from neuronika_amd import capi
-    t = neuronika_amd.tape
-    tdev = t.Device(dist.local)
-    cdev = capi.Device(handle=tdev.raw())
-    B, S, d, H = 32, 1024, 1024, 16
-    t.manual_seed(7 + dist.rank)                     # Philox key of the dropout node: per-rank, so shards draw different masks
-    mha = t.nn.MultiheadAttention(tdev, d, H, 0.1, 1)
-    if "NK_MHA_STRIDED" in os.environ:               # A/B aid: heads addressed in place (1) or split/merge copies (0)
-        mha.strided_heads = os.environ["NK_MHA_STRIDED"] == "1"
-    if "NK_MHA_CORE" in os.environ:                  # A/B aid: fused attention kernels (1) or GEMM -> row kernel -> GEMM (0)
-        mha.fused_core = os.environ["NK_MHA_CORE"] == "1"
-    X = t.from_ndarray(tdev, np.random.default_rng(0).random((B * S, d), dtype=np.float32)).requires_grad()
-    G = t.from_ndarray(tdev, np.random.default_rng(5).random((B * S, d), dtype=np.float32))
-    y = mha.forward(X, B)
-    leaves = [X] + [getattr(getattr(mha, n), w) for n in "qkvo" for w in ("weight", "bias")]
-
-    def step():
-        y.forward()
-        y.no_grad(); y.with_grad()
-        y.backward_from(G)
-        for p in leaves:
-            p.zero_grad()
-
-    dt, ev_ms, gemm, _ = timed_steps(dist, tdev, cdev, step, a.steps, a.warmup)
+    tdev, cdev = _tape_devices(dist)
+    rec = measure_mha(dist, tdev, cdev, a.steps, a.warmup)
     if dist.rank != 0:
         return None
-    res = {"metric": "MultiheadAttention fwd+bwd sequences/s", "value": round(B * a.steps / dt, 2), "unit": "sequences/s",
-           "n_gpus": dist.world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4),
-           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-           "config": {"workload": "C5: MHA d_model=1024 heads=16 seq=1024 batch=32 dropout=0.1, composed from reference ops"},
-           "roofline": roofline_mfma(gemm, "sgemm_kernel (projections, scores, context and their gradients)", read_traffic("mha_gemm")),
-           "gemm_share_of_step": round(gemm[1] / ev_ms, 4)}
-    att = EXTRA_STATS.get("attention")
-    if att and att[0]:   # nk_attention_fwd / nk_attention_bwd: 4*B*H*S*S*dh flop each (two MFMA products per score tile)
-        res["attention_core"] = dict(roofline_mfma(att, "attention_kernel (scores -> softmax -> dropout -> context, and its backward)", read_traffic("attention")),
-                                     share_of_step=round(att[1] / ev_ms, 4))
+    res = _headline({"n_gpus": dist.world, "warmup": a.warmup}, rec, "MultiheadAttention fwd+bwd sequences/s")
     if dist.world == 1 and not a.no_cpu_baseline:
-        res["cpu_baseline"] = cpu_baseline_mha(2, S, d, H, 0.1)
+        res["cpu_baseline"] = cpu_baseline_mha(2, 1024, 1024, 16, 0.1)
     return res
 
 
@@ -512,9 +694,22 @@ def _free_port():
     return p
 
 
-def spawn_ranks(n, cmd=None, have=None):
+def _tail(path, nbytes=2048):
+    try:
+        with open(path, "rb") as f:
+            f.seek(0, 2)
+            f.seek(max(0, f.tell() - nbytes))
+            return f.read().decode(errors="replace")
+    except OSError:
+        return ""
+
+
+def spawn_ranks(n, cmd=None, have=None, timeout_s=None):
     """`--gpus N` with no launcher: become the launcher.  One worker process per GPU (LOCAL_RANK = device index),
     TCP rendezvous on 127.0.0.1; rank 0 prints the JSON line on our stdout.  Returns the exit code.
+    Every rank's stderr goes to a file of its own; when the job fails or exceeds `timeout_s` (NK_BENCH_TIMEOUT_S + 60
+    by default: the ranks' own watchdogs fire first and leave a stack dump), the last 2 KB of EVERY rank's stderr are
+    relayed, so a hung `ncclCommInitRank` or a crashed rank is visible in the caller's log.
     (`cmd` / `have`: the worker command line and the GPU count, overridable so the launcher itself can be tested
     on a box without GPUs.)"""
     if have is None:
@@ -525,13 +720,18 @@ def spawn_ranks(n, cmd=None, have=None):
     if have < n:
         print(f"[bench] --gpus {n} requested but this node has {have} GPU(s): refusing to run fewer ranks than asked", file=sys.stderr)
         return 2
+    if timeout_s is None:
+        timeout_s = float(os.environ.get("NK_BENCH_TIMEOUT_S", "600")) + 60.0
     env = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
                NK_RV_SECRET=secrets.token_hex(16), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    procs = []
+    logdir = tempfile.mkdtemp(prefix="nk_bench_")
+    procs, logs = [], []
     for r in range(n):
         e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
-        procs.append(subprocess.Popen(cmd, env=e))
-    rc = 0
+        logs.append(os.path.join(logdir, f"rank{r}.stderr"))
+        procs.append(subprocess.Popen(cmd, env=e, stderr=open(logs[-1], "wb")))
+    rc, why = 0, ""
+    t0 = time.time()
     try:
         pending = set(range(n))
         while pending:
@@ -541,9 +741,12 @@ def spawn_ranks(n, cmd=None, have=None):
                     continue
                 pending.discard(r)
                 if code != 0:
-                    print(f"[bench] rank {r} exited with code {code}", file=sys.stderr)
+                    why = why or f"rank {r} exited with code {code}"
                     rc = rc or (code if code > 0 else 1)
             if rc and pending:          # one rank failed: the others would wait for it forever
+                break
+            if pending and time.time() - t0 > timeout_s:
+                why, rc = f"no result after {timeout_s:.0f} s (ranks still running: {sorted(pending)})", 124
                 break
             time.sleep(0.05)
     finally:
@@ -555,6 +758,13 @@ def spawn_ranks(n, cmd=None, have=None):
                 p.wait(timeout=10)
             except subprocess.TimeoutExpired:
                 p.kill()
+    if rc:
+        print(f"[bench] {why}; last 2 KB of every rank's stderr follow", file=sys.stderr)
+        for r in range(n):
+            print(f"[bench] ---- rank {r} (exit code {procs[r].returncode}) ----\n{_tail(logs[r])}", file=sys.stderr)
+    else:
+        sys.stderr.write(_tail(logs[0]))   # rank 0's progress markers / warnings
+    sys.stderr.flush()
     return rc
 
 
@@ -564,7 +774,20 @@ def main():
         raise SystemExit("[bench] --gpus must be >= 1")
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(a.gpus))
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world > 1 or os.environ.get("NK_BENCH_FORCE_RCCL") == "1":
+        # a rank that hangs (rendezvous, ncclCommInitRank, a collective nobody else entered) dumps every thread's Python
+        # stack on stderr and exits instead of waiting for the driver's kill with an empty tail
+        faulthandler.dump_traceback_later(float(os.environ.get("NK_BENCH_TIMEOUT_S", "600")), exit=True)
+        if rank == 0 and "NCCL_DEBUG" not in os.environ:
+            # what RCCL chose (channels, algorithm / protocol per size) goes into the record: rank 0 logs INIT + TUNING
+            # to a file of its own, parsed after the run (read_rccl_log)
+            fd, path = tempfile.mkstemp(prefix="nk_rccl_rank0_", suffix=".log")
+            os.close(fd)
+            os.environ.update(NCCL_DEBUG="INFO", NCCL_DEBUG_SUBSYS="INIT,TUNING,ENV", NCCL_DEBUG_FILE=path, NK_BENCH_RCCL_LOG=path)
+    _log(f"start: world {world}, workload {a.workload}")
     dist = Dist(a.gpus)
+    _log("rendezvous complete")
     try:
         res = {"mlp": run_mlp, "matmul": run_matmul, "conv": run_conv, "mha": run_mha}[a.workload](a, dist)
         if dist.rank == 0 and res is not None:
@@ -572,6 +795,7 @@ def main():
             print(json.dumps(res), flush=True)
     finally:
         dist.close()
+        faulthandler.cancel_dump_traceback_later()
 
 
 if __name__ == "__main__":

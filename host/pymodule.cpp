@@ -371,6 +371,7 @@ PYBIND11_MODULE(_tape, m) {
             return std::make_shared<dp::Communicator>(std::move(dev), nranks, rank, std::string(id));
         }))
         .def_static("replicas", &dp::Communicator::replicas, py::arg("device"), py::arg("nranks"))
+        .def("raw", [](const dp::Communicator& c) { return (uintptr_t)c.raw(); })  // nk_comm* for the raw C ABI (bench diagnostics)
         .def_property_readonly("rank", &dp::Communicator::rank)
         .def_property_readonly("size", &dp::Communicator::size);
     py::class_<dp::GradientSync>(dpm, "GradientSync")

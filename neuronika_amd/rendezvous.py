@@ -18,7 +18,8 @@ Authentication is a mutual HMAC-SHA256 challenge on fixed-length raw bytes BEFOR
 parsed: the server sends a 32-byte nonce, the client answers HMAC(secret, nonce | "client"), the
 server verifies with `hmac.compare_digest` and answers HMAC(secret, nonce | "server"), which the
 client verifies.  The secret is NK_RV_SECRET (bench.py's spawner draws it from os.urandom) or,
-under torchrun, derived from TORCHELASTIC_RUN_ID and the world size.
+under torchrun ON LOOPBACK ONLY, derived from TORCHELASTIC_RUN_ID and the world size; a routable
+MASTER_ADDR without NK_RV_SECRET is refused.
 """
 from __future__ import annotations
 
@@ -87,10 +88,20 @@ def _recv(sock):
     return _decode(_recv_exact(sock, n))
 
 
-def _secret(world: int) -> bytes:
+def _is_loopback(addr: str) -> bool:
+    return addr in ("localhost", "::1") or addr.startswith("127.")
+
+
+def _secret(world: int, addr: str = "127.0.0.1") -> bytes:
+    """NK_RV_SECRET when given.  The fallback (run id + world size) is guessable by anyone who knows the run id, so it
+    is accepted only when the rendezvous address is loopback (single-node launches: torchrun --master-addr 127.0.0.1,
+    bench.py's own spawner); a routable MASTER_ADDR without NK_RV_SECRET fails closed."""
     s = os.environ.get("NK_RV_SECRET")
     if s:
         return hashlib.sha256(s.encode()).digest()
+    if not _is_loopback(addr):
+        raise PermissionError(f"rendezvous on the routable address {addr} needs NK_RV_SECRET (a shared random string) in every "
+                              "rank's environment: the derived fallback secret is only accepted on loopback")
     return hashlib.sha256(("NKRV:" + os.environ.get("TORCHELASTIC_RUN_ID", "static") + f":{world}").encode()).digest()
 
 
@@ -116,7 +127,7 @@ class Rendezvous:
         # torchrun's agent already owns MASTER_PORT (its TCPStore); use the next free port of a
         # short, deterministic range; the HMAC challenge makes every rank find the same server.
         ports = [base + 1 + i for i in range(32)]
-        secret = _secret(self.world)
+        secret = _secret(self.world, addr)
         if self.rank == 0:
             srv = None
             for p in ports:
@@ -207,6 +218,11 @@ class Rendezvous:
 
     def sum(self, x: float) -> float:
         return self._collective(float(x), sum)
+
+    def gather(self, x: float):
+        """Every rank's float, in rank order, on every rank (at most MAX_FRAME / 8 ranks)."""
+        b = self._collective(float(x), lambda v: struct.pack(f"!{len(v)}d", *v))
+        return list(struct.unpack(f"!{len(b) // 8}d", b))
 
     def close(self):
         for p in self.peers:

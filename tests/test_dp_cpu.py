@@ -56,6 +56,7 @@ def _rv_worker(rank, world, port, q):
     rv = Rendezvous(rank, world, "127.0.0.1", port)
     rv.barrier()
     out = (rank, rv.broadcast(b"\x01" * 128 if rank == 0 else None), rv.max(10.0 + rank), rv.sum(1.0))
+    assert rv.gather(0.5 + rank) == [0.5 + r for r in range(world)]
     rv.barrier()
     rv.close()
     q.put(out)
@@ -192,6 +193,76 @@ def test_bench_launcher_spawns_and_relays(tmp_path, capfd):
     bad = tmp_path / "bad.py"; bad.write_text(_SPAWN_WORKER.format(root=root, fail_rank=1))
     assert bench.spawn_ranks(2, cmd=[sys.executable, str(bad)], have=2) == 3
     assert bench.spawn_ranks(4, cmd=[sys.executable, str(ok)], have=2) == 2      # fewer GPUs than ranks: refused
+
+
+_HANG_WORKER = """
+import os, sys, time
+print("rank", os.environ["RANK"], "alive", file=sys.stderr, flush=True)
+if os.environ["RANK"] == "1":
+    print("rank 1 is stuck in ncclCommInitRank", file=sys.stderr, flush=True)
+    time.sleep(600)
+time.sleep(600)
+"""
+
+
+def test_bench_launcher_times_out_and_relays_every_ranks_stderr(tmp_path, capfd):
+    """A job that hangs (e.g. in ncclCommInitRank on its first multi-GPU run) ends at the launcher's timeout with exit
+    code 124 and the tail of EVERY rank's stderr, not as a silent kill; a rank that dies reports its own tail too."""
+    import importlib.util, sys, time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("nk_bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    hang = tmp_path / "hang.py"; hang.write_text(_HANG_WORKER)
+    t0 = time.time()
+    assert bench.spawn_ranks(2, cmd=[sys.executable, str(hang)], have=2, timeout_s=2.0) == 124
+    assert time.time() - t0 < 30
+    err = capfd.readouterr().err
+    assert "no result after 2 s" in err and "rank 0 alive" in err and "rank 1 is stuck in ncclCommInitRank" in err
+    bad = tmp_path / "bad.py"; bad.write_text(_SPAWN_WORKER.format(root=root, fail_rank=1).replace("sys.exit(3)", "sys.stderr.write('boom on rank 1\\n'); sys.exit(3)"))
+    assert bench.spawn_ranks(2, cmd=[sys.executable, str(bad)], have=2) == 3
+    err = capfd.readouterr().err
+    assert "rank 1 exited with code 3" in err and "boom on rank 1" in err
+
+
+_RCCL_LOG = """
+host:101:101 [0] NCCL INFO RCCL version : 2.26.6-HEAD:1234
+host:101:101 [0] NCCL INFO NCCL_MAX_NCHANNELS set by environment to 32.
+host:101:120 [0] NCCL INFO Channel 00/32 : 0 1 2 3 4 5 6 7
+host:101:120 [0] NCCL INFO Channel 31/32 : 0 7 6 5 4 3 2 1
+host:101:120 [0] NCCL INFO Trees [0] 1/-1/-1->0->-1 [1] 1/-1/-1->0->-1
+host:101:120 [0] NCCL INFO Connected all rings
+host:101:120 [0] NCCL INFO 32 coll channels, 0 collnet channels, 0 nvls channels, 32 p2p channels, 2 p2p channels per peer
+host:101:101 [0] NCCL INFO AllReduce: 33554432 Bytes -> Algo 1 proto 2 time 412.0
+host:101:101 [0] NCCL INFO AllReduce: 33554432 Bytes -> Algo 1 proto 2 time 412.0
+host:101:101 [0] NCCL INFO AllReduce: 49152 Bytes -> Algo 0 proto 0 time 21.5
+host:101:101 [0] NCCL WARN something odd
+"""
+
+
+def test_bench_parses_what_rccl_chose():
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("nk_bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    r = bench.parse_rccl_log(_RCCL_LOG)
+    assert r["version"].startswith("2.26.6") and r["channels"] == 32 and r["warnings"] == 1
+    assert r["choices"][0] == {"coll": "AllReduce", "bytes": 33554432, "algo": "Ring", "proto": "Simple", "calls": 2}
+    assert r["choices"][1]["algo"] == "Tree" and r["choices"][1]["proto"] == "LL"
+    assert r["env_overrides"] == ["NCCL_MAX_NCHANNELS=32."] or r["env_overrides"] == ["NCCL_MAX_NCHANNELS=32"]
+    assert any("coll channels" in ln for ln in r["excerpt"])
+    empty = bench.parse_rccl_log("nothing useful")
+    assert empty["channels"] is None and empty["choices"] == [] and empty["excerpt"] == []
+
+
+def test_rendezvous_fallback_secret_is_loopback_only(monkeypatch):
+    """the derived secret (run id + world) is guessable; a routable MASTER_ADDR must bring NK_RV_SECRET."""
+    from neuronika_amd import rendezvous as rz
+    monkeypatch.delenv("NK_RV_SECRET", raising=False)
+    assert len(rz._secret(2, "127.0.0.1")) == 32
+    with pytest.raises(PermissionError):
+        rz._secret(2, "10.1.2.3")
+    monkeypatch.setenv("NK_RV_SECRET", "s3cret")
+    assert len(rz._secret(2, "10.1.2.3")) == 32
 
 
 def test_bench_is_torch_free():

@@ -112,3 +112,116 @@ def test_two_rank_gradient_sync_equals_full_batch(tmp_path, hidden, batch):
     assert all(p.returncode == 0 for p in procs), [o[1][-1500:] for o in outs]
     worst = float([l for l in outs[0][0].splitlines() if l.startswith("WORST")][-1].split()[1])
     assert worst < 2e-5, worst       # f32 sums in a different order (two shards of B rows vs one pass over 2B rows)
+
+
+def _bench_line(args, env_extra=None, timeout=900):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "NCCL_DEBUG")}
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=timeout, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1]), r.stderr
+
+
+def test_bench_default_line_carries_every_baseline_config():
+    """The ONE driver-run record holds all headline numbers: C4 at the top level, C2 at 1024 / 2048 / 4096 / 8192,
+    C3 and C5 as sub-records of the same shape (value, ms_per_step, roofline{achieved, frac, launches, avg_launch_ms})."""
+    res, _ = _bench_line(["--steps", "3", "--warmup", "1", "--no-cpu-baseline"])
+    assert res["n_gpus"] == 1 and res["roofline"]["frac"] > 0 and res["roofline"]["traffic_measured_at_commit"]
+    for key, unit in [("matmul_1024", "TFLOP/s"), ("matmul_2048", "TFLOP/s"), ("matmul_4096", "TFLOP/s"), ("matmul_8192", "TFLOP/s"),
+                      ("conv_c3", "samples/s"), ("mha_c5", "sequences/s")]:
+        rec = res[key]
+        assert rec["unit"] == unit and rec["value"] > 0 and rec["ms_per_step"] > 0 and rec["steps"] == 20, key
+        roof = rec["roofline"]
+        assert 0 < roof["frac"] < 1 and roof["launches"] > 0 and roof["avg_launch_ms"] > 0 and roof["achieved"] > 0, key
+    assert res["matmul_4096"]["roofline"]["launches"] == 3 * 20
+    assert res["conv_c3"]["roofline"]["launches"] == 3 * 20           # one launch record per conv pass
+    att = res["mha_c5"]["attention_core"]
+    assert att["launches"] == 2 * 20 and 0 < att["frac"] < 1
+
+
+def test_bench_multi_rank_record_is_self_diagnosing():
+    """Every line of bench.py's N > 1 path on ONE GPU: a one-rank RCCL communicator with the exchange forced on
+    (NK_BENCH_FORCE_RCCL=1).  The record must carry the diagnostics the first real multi-GPU run will be tuned from and
+    must not be readable as a measurement."""
+    res, err = _bench_line(["--steps", "3", "--warmup", "1", "--hidden", "1024", "--batch", "512", "--no-cpu-baseline"],
+                           {"NK_BENCH_FORCE_RCCL": "1", "NK_BENCH_VERBOSE": "1"})
+    assert res["rccl_single_rank_debug"] is True and res["metric"].startswith("DEBUG RUN")
+    assert res["rccl_ranks"] == 1 and res["allreduce_bytes_per_step"] == 3 * (1024 * 1024 + 1024) * 4
+    assert res["allreduce_launches_per_step"] >= 4
+    assert len(res["per_rank_device_ms_per_step"]) == 1 and res["per_rank_device_ms_min_max"][0] > 0
+    alone = res["allreduce_alone"]
+    assert alone["bytes"] == res["allreduce_bytes_per_step"] and alone["ms"] > 0 and len(alone["by_size"]) == 3
+    g = res["gemm_contention"]
+    assert g["avg_launch_ms_overlapped"] > 0 and g["avg_launch_ms_no_exchange"] > 0 and 0.5 < g["slowdown"] < 2.0
+    assert isinstance(res["exposed_comm_ms"], float)
+    rccl = res["rccl"]
+    assert "excerpt" in rccl, rccl                 # the NCCL_DEBUG=INFO log of rank 0 was found and parsed
+    assert rccl["version"] or rccl["excerpt"], rccl
+    assert "communicator up" in err and "timed loop done" in err      # progress markers
+
+
+def test_replica_debug_run_is_not_readable_as_a_measurement():
+    res, _ = _bench_line(["--steps", "2", "--warmup", "1", "--hidden", "1024", "--batch", "512", "--no-cpu-baseline"],
+                         {"NK_BENCH_REPLICAS": "4", "NK_BENCH_NO_SUBRECORDS": "1"})
+    assert res["metric"].startswith("DEBUG RUN") and res["exposed_comm_ms"] is None and res["replica_ranks_debug"] == 4
+
+
+_THREAD_WORKER = """
+def run(idx, out):
+    # one host thread per GPU, each with its own device handle (the shape a Rust host takes: the graph is !Send,
+    # neuronika-variable/src/utils.rs:9, so one thread owns one device's tape)
+    import numpy as np
+    from neuronika_amd import capi
+    dev = capi.Device(idx)
+    rng = np.random.default_rng(idx)
+    a, b = rng.random((384, 256), dtype=np.float32), rng.random((256, 320), dtype=np.float32)
+    A, B, Cm = dev.array(a), dev.array(b), dev.zeros((384, 320))
+    for _ in range(50):
+        capi.mm_fwd(dev, A, B, Cm)
+    x = rng.random((64, 512), dtype=np.float32)
+    Y = dev.zeros(x.shape)
+    capi.softmax_fwd(dev, dev.array(x), Y, 1)
+    try:                                          # an error on this thread's device must not show up on the other thread
+        capi.softmax_fwd(dev, dev.array(x), Y, 7)
+        out[idx] = "no error raised"
+        return
+    except capi.NeuronikaHipError as e:
+        msg = str(e)
+    out[idx] = (Cm.numpy(), a @ b, Y.numpy(), x, msg)
+"""
+
+
+@pytest.mark.skipif(_ngpu() < 2, reason="needs two GPUs")
+def test_two_threads_drive_two_devices():
+    """Thread-per-GPU use of the C ABI (thread-safe ACROSS devices): two host threads, one device handle
+    each, concurrently; results per device are right and the thread-local error state does not leak."""
+    import threading
+    ns = {}
+    exec(_THREAD_WORKER, ns)
+    out = {}
+    ths = [threading.Thread(target=ns["run"], args=(i, out)) for i in range(2)]
+    [t.start() for t in ths]
+    [t.join(300) for t in ths]
+    for i in range(2):
+        assert not isinstance(out.get(i), str), out.get(i)
+        c, ref, y, x, msg = out[i]
+        np.testing.assert_allclose(c, ref, rtol=2e-5)
+        e = np.exp(x - x.max(1, keepdims=True))
+        np.testing.assert_allclose(y, e / e.sum(1, keepdims=True), rtol=1e-5)
+        assert "axis" in msg.lower() or msg
+
+
+def test_two_threads_share_one_gpu_through_two_handles():
+    """The same thread-per-handle shape on a 1-GPU box: two handles (own streams, own workspace) of device 0 driven from
+    two threads at once."""
+    import threading
+    ns = {}
+    exec(_THREAD_WORKER.replace("capi.Device(idx)", "capi.Device(0)"), ns)
+    out = {}
+    ths = [threading.Thread(target=ns["run"], args=(i, out)) for i in range(2)]
+    [t.start() for t in ths]
+    [t.join(300) for t in ths]
+    for i in range(2):
+        assert not isinstance(out.get(i), str), out.get(i)
+        c, ref, y, x, msg = out[i]
+        np.testing.assert_allclose(c, ref, rtol=2e-5)
