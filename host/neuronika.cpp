@@ -476,7 +476,7 @@ struct DropoutFwd : Forward {  // node/dropout/mod.rs:17-79
     uint64_t seed;
     Shared<uint64_t> calls;  // Philox offset advances on every forward (noise is resampled)
     void forward() const override {
-        const uint64_t offset = (*calls) * ((x->len() + 3) / 4);
+        const uint64_t offset = (*calls) * ((x->len() + 7) / 8);  // 8 draws per Philox call (nk_common.h)
         ++(*calls);
         check(nk_dropout_fwd(D(x), x->ptr(), y->ptr(), noise->ptr(), x->len(), p, *status ? 1 : 0, seed, offset));
     }
@@ -506,7 +506,7 @@ struct AttnProbsFwd : Forward {
     void forward() const override {
         const int L = x->shape().back();
         const long long rows = (long long)(x->len() / (size_t)L);
-        const uint64_t offset = (*calls) * ((x->len() + 3) / 4);
+        const uint64_t offset = (*calls) * ((x->len() + 7) / 8);  // 8 draws per Philox call (nk_common.h)
         ++(*calls);
         *last_offset = offset;
         check(nk_scale_softmax_dropout_fwd(D(x), x->ptr(), probs ? probs->ptr() : nullptr, out->ptr(), nullptr, rows, L, scale, p,
@@ -739,7 +739,7 @@ struct HeadsAttentionFwd : Forward {
     uint64_t seed;
     Shared<uint64_t> calls;  // each forward draws a fresh mask (the Philox offset advances), as AttnProbsFwd
     void forward() const override {
-        const uint64_t offset = (*calls) * (((uint64_t)hg.B * hg.H * hg.S * hg.S + 3) / 4);  // (B*H, S, S) draws per forward
+        const uint64_t offset = (*calls) * (((uint64_t)hg.B * hg.H * hg.S * hg.S + 7) / 8);  // (B*H, S, S) draws per forward, 8 per Philox call
         ++(*calls);
         // scores / stats / mask are null in a graph without gradients: nothing is kept, no (B*H, S, S) tensor exists
         check(nk_attention_fwd(D(q), q->ptr(), k->ptr(), v->ptr(), scores ? scores->ptr() : nullptr, stats ? stats->ptr() : nullptr,

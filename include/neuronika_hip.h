@@ -428,7 +428,10 @@ int nk_attention_bwd(nk_device* dev, float* dQ, float* dK, float* dV, float* dS,
 /* ------------------------------------------------------------------ dropout ------------ */
 /* Dropout::forward node/dropout/mod.rs:53-79.  train && 0<p<1: noise ~ Bernoulli(1-p) in
  * {0,1} is (re)drawn from Philox4x32-10(seed, offset) and written to `noise` (f32, like the
- * reference's shared noise array); y = x*noise/(1-p).  !train or p==0: y = x.  p==1: y = 0
+ * reference's shared noise array); y = x*noise/(1-p).  Draw layout (shared by every masked entry point): call
+ * `offset + i/8` serves elements 8(i/8) .. +7; element i takes word (i%8)/2 of it, rotated by 16 bits for odd i, and
+ * is kept iff that 32-bit value < floor((1-p) * 2^32) - rand 0.8's Bernoulli construction on 32 bits.  One forward
+ * over n elements consumes ceil(n/8) calls: the host advances `offset` by that much per forward.  !train or p==0: y = x.  p==1: y = 0
  * and `noise` is left untouched.  p outside [0,1] -> NK_ERR_INVALID (reference panics,
  * dropout/mod.rs:38-40). */
 int nk_dropout_fwd(nk_device* dev, const float* x, float* y, float* noise, size_t n, double p,

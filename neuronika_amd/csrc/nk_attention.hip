@@ -17,7 +17,7 @@
 // per-lane scalars plus one cross-half shuffle, and the C registers are directly the B operand of the second product
 // out^T[dh][query] = X2^T . C (the MFMA wants B[k][n] with n = lane & 31, k chosen by the lane half: exactly what C holds
 // when MFMA step e pairs key 16*0 + e with key 16*1 + e).  Rows of the MFMA tile are permuted so that a lane's 16
-// registers are 16 CONSECUTIVE keys: the Philox counter of the existing row kernels (4 consecutive elements per draw)
+// registers are 16 CONSECUTIVE keys: two Philox calls of the shared draw layout (8 consecutive elements per call)
 // and 64-byte runs towards HBM fall out of that.
 //
 // The forward uses the online softmax in the base-2 exponent domain (running shift m2 and sum of exp2(s*c1 - m2), c1 =
@@ -56,7 +56,7 @@ struct AttnArgs {
     int S, H, ld, nqb, ntile;
     float scale, keep, dscale;
     float c1;          // scale * log2(e): exponents are taken in base 2
-    unsigned keep_lt;  // Philox word w is kept iff w < keep_lt  (== keep_bit(w, keep): (w >> 8) * 2^-24 < keep, exactly)
+    unsigned keep_lt;  // a draw v is kept iff v < keep_lt = floor((1 - p) * 2^32)  (nk_common.h: the Bernoulli construction)
     unsigned long long seed, offset;
     int assign;        // backward: dQ = (1) or += (0)
 };
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(A_NT, OCC) void attention_kernel(const AttnArgs p) 
 
     const long long rowbase = ((long long)bh * p.S + (on ? q0 : 0)) * p.S;  // element index of (row q0, key 0) in the (B*H, S, S) tensors
     const uint2 key = make_uint2((unsigned)p.seed, (unsigned)(p.seed >> 32));
-    const unsigned long long ctr0 = (unsigned long long)(rowbase + (long long)q * p.S) / 4 + 4 * h + p.offset;
+    const unsigned long long ctr0 = (unsigned long long)(rowbase + (long long)q * p.S) / 8 + 2 * h + p.offset;  // 8 draws per call
     float* scrw = scr[w];
     float* scrb = scrw + (BWD ? 32 * SCR_LD : 0);
     // backward: the score tile of the NEXT iteration, in the coalesced load layout (lane -> rows 8i + lane/8, 16 B each)
@@ -234,29 +234,35 @@ __global__ __launch_bounds__(A_NT, OCC) void attention_kernel(const AttnArgs p) 
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bq[j].w, acc, 0, 0, 0);
                 }
             }
-            // Bernoulli(1 - p) draws of this lane's 16 keys.  Forward: 4 Philox calls (4 consecutive keys each, the counter
-            // layout of nk_scale_softmax_dropout_fwd), packed to one bit per score for the backward pass - the Philox rounds
-            // are ~2000 of the ~6500 issue cycles of a masked tile (v_mad_u64_u32 is quarter rate), paid once, not twice;
-            // and the backward mask is the forward's by construction (the reference shares the noise buffer the same way,
-            // node/dropout/mod.rs:113-128).
-            bool kp[16];
+            // Bernoulli(1 - p) draws of this lane's 16 keys.  Forward: 2 Philox calls (8 consecutive keys each, the draw
+            // layout of nk_common.h / nk_dropout_fwd / nk_scale_softmax_dropout_fwd), packed to one bit per score for the
+            // backward pass - the Philox rounds were ~2000 of the ~6500 issue cycles of a masked tile with one word per
+            // score (v_mad_u64_u32 is quarter rate) and are paid once, not twice; the backward mask is the forward's by
+            // construction (the reference shares the noise buffer the same way, node/dropout/mod.rs:113-128).
+            bool kp[16];          // forward: the compare results stay lane masks in SGPR pairs (the masked forward is at its VGPR limit)
+            int km[16];           // backward: 0 / -1 per key as AND operands (one v_bfe_i32 + one v_and per use instead of bit test + compare + select)
             if (MASKED && !BWD) {
                 unsigned bits = 0;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const unsigned long long ctr = ctr0 + (unsigned long long)(kt * 8 + c);
+                for (int c = 0; c < 2; ++c) {
+                    const unsigned long long ctr = ctr0 + (unsigned long long)(kt * 4 + c);
                     const uint4 r = philox4x32_10(make_uint4((unsigned)ctr, (unsigned)(ctr >> 32), 0u, 0u), key);
-                    kp[4 * c] = r.x < p.keep_lt; kp[4 * c + 1] = r.y < p.keep_lt;
-                    kp[4 * c + 2] = r.z < p.keep_lt; kp[4 * c + 3] = r.w < p.keep_lt;
-                }
+                    const unsigned wv[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
-                for (int e = 0; e < 16; ++e) bits |= kp[e] ? (1u << e) : 0u;
+                    for (int k = 0; k < 4; ++k) {
+                        const bool k0 = wv[k] < p.keep_lt, k1 = nk_rot16(wv[k]) < p.keep_lt;
+                        kp[8 * c + 2 * k] = k0;
+                        kp[8 * c + 2 * k + 1] = k1;
+                        bits |= (k0 ? 1u : 0u) << (8 * c + 2 * k);
+                        bits |= (k1 ? 1u : 0u) << (8 * c + 2 * k + 1);
+                    }
+                }
                 const unsigned other = (unsigned)__shfl_xor((int)bits, 32, 64);
                 if (KEEP && h == 0) p.maskbits[((long long)bh * p.S + row) * p.ntile + kt] = bits | (other << 16);
             }
             if (MASKED && BWD) {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) kp[e] = (mybits >> e) & 1u;
+                for (int e = 0; e < 16; ++e) km[e] = __builtin_amdgcn_sbfe((int)mybits, e, 1);   // v_bfe_i32: 0 / -1
             }
             float bv[16];  // B operand of pass 2
             if (!BWD) {
@@ -300,9 +306,9 @@ __global__ __launch_bounds__(A_NT, OCC) void attention_kernel(const AttnArgs p) 
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const float ev = __builtin_amdgcn_exp2f(__builtin_fmaf(sv[e], p.c1, -m_run));  // exp(s*scale - shift), as the forward
-                    const float gv = MASKED ? (kp[e] ? acc[e] : 0.f) : acc[e];  // DropoutBackward: g * noise
+                    const float gv = MASKED ? __int_as_float(__float_as_int(acc[e]) & km[e]) : acc[e];  // DropoutBackward: g * noise
                     bv[e] = (ev * inv_s) * (gv - dot);                           // SoftmaxBackward, MultiplicationBackwardLeft
-                    pd[e] = MASKED ? (kp[e] ? ev * inv_d : 0.f) : ev * inv_d;    // Dropout forward (for dV = Pd^T . dO)
+                    pd[e] = MASKED ? __int_as_float(__float_as_int(ev * inv_d) & km[e]) : ev * inv_d;    // Dropout forward (for dV = Pd^T . dO)
                 }
                 tile_write(scrw, bv, lane);   // (the score tile was read out of this region at the top of the iteration)
                 tile_write(scrb, pd, lane);
@@ -363,13 +369,6 @@ __global__ __launch_bounds__(A_NT, OCC) void attention_kernel(const AttnArgs p) 
     }
 }
 
-// keep_bit(w, keep) = ((w >> 8) * 2^-24 < keep) with both sides exact in f32  <=>  (w >> 8) < ceil(keep * 2^24)  <=>
-// w < ceil(keep * 2^24) * 256   (keep < 1 here: p > 0 in the masked instantiation)
-unsigned keep_threshold(float keep) {
-    const double t = std::ceil((double)keep * 16777216.0);
-    return t >= 16777216.0 ? 0xFFFFFFFFu : (unsigned)t * 256u;
-}
-
 bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 int attention_check(int B, int S, int H, int dh, double p, int train, float scale) {
@@ -386,7 +385,7 @@ int attention_launch(nk_device* dev, AttnArgs& a, int B, int S, int H, double p,
     a.S = S; a.H = H; a.ld = H * A_DH; a.nqb = (S + A_QB - 1) / A_QB; a.ntile = S / 32;
     a.scale = scale; a.c1 = scale * 1.44269504088896341f; a.keep = (float)(1.0 - p); a.dscale = 1.f / (1.f - (float)p);  // as nk_scale_softmax_dropout_fwd
     a.seed = seed; a.offset = offset;
-    a.keep_lt = keep_threshold(a.keep);
+    a.keep_lt = nk_keep_threshold(1.0 - p);   // Bernoulli::new(1. - p), node/dropout/mod.rs:46
     const bool masked = train && p != 0.0;
     const dim3 grid((unsigned)(B * H * a.nqb)), block(A_NT);
     const bool full = S % A_QB == 0;

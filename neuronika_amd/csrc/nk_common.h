@@ -163,7 +163,32 @@ __device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
     return c;
 }
 
-__device__ __forceinline__ float keep_bit(unsigned word, float keep_prob) {
-    return ((float)(word >> 8) * 5.9604644775390625e-08f /* 2^-24 */ < keep_prob) ? 1.f : 0.f;
+// ---- Bernoulli(keep) draws of Dropout (oracle: dropout_noise / bernoulli_threshold) ----------------------------------
+// The reference draws `Bernoulli::new(1. - p)` (node/dropout/mod.rs:46) - rand 0.8's integer construction
+// `p_int = (p * 2^64) as u64; rng.gen::<u64>() < p_int` - from the non-reproducible thread_rng; here the same construction
+// on 32-bit values out of Philox4x32-10.  ONE Philox call serves EIGHT consecutive elements: element 8 j + 2 k + r takes word
+// k of call j, as it is (r = 0) or rotated by 16 bits (r = 1), and is kept iff that value < floor(keep * 2^32).  Every draw
+// resolves the keep probability to 2^-32 (its own 16 bits decide, the partner's only break ties); the two elements sharing
+// a word are independent except on those 2^-16 ties.  Half the Philox rounds per element of a word per element.
+static inline unsigned nk_keep_threshold(double keep) {
+    const double t = __builtin_floor(keep * 4294967296.0);
+    return t >= 4294967295.0 ? 0xFFFFFFFFu : (t <= 0.0 ? 0u : (unsigned)t);
+}
+__device__ __forceinline__ unsigned nk_rot16(unsigned w) { return __builtin_amdgcn_alignbit(w, w, 16); }
+// Philox counter of the call that holds element `i` (flat row-major index) and the 0/1 draws of the aligned group of
+// four elements starting at i (i % 4 == 0): words (0,1) of the call for the lower half of its eight, (2,3) for the upper.
+__device__ __forceinline__ uint4 nk_draw_call(unsigned long long elem, unsigned long long offset, uint2 key) {
+    const unsigned long long ctr = elem / 8 + offset;
+    return philox4x32_10(make_uint4((unsigned)ctr, (unsigned)(ctr >> 32), 0u, 0u), key);
+}
+__device__ __forceinline__ float4 nk_keep4(unsigned wa, unsigned wb, unsigned keep_lt) {
+    return make_float4(wa < keep_lt ? 1.f : 0.f, nk_rot16(wa) < keep_lt ? 1.f : 0.f, wb < keep_lt ? 1.f : 0.f,
+                       nk_rot16(wb) < keep_lt ? 1.f : 0.f);
+}
+// the group of four at `elem` (elem % 4 == 0) out of its call
+__device__ __forceinline__ float4 nk_keep4_at(unsigned long long elem, unsigned long long offset, uint2 key, unsigned keep_lt) {
+    const uint4 r = nk_draw_call(elem, offset, key);
+    const bool hi = (elem >> 2) & 1;
+    return nk_keep4(hi ? r.z : r.x, hi ? r.w : r.y, keep_lt);
 }
 

@@ -11,27 +11,28 @@ namespace {
 
 bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-// element i uses word i%4 of Philox(counter = i/4 + offset, key = seed); y = (x*noise)/scale
+// One thread = one Philox call = eight consecutive elements (nk_common.h: the draw layout); y = (x*noise)/scale
 __global__ void dropout_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ noise,
-                                   size_t n, float keep_prob, float scale, unsigned long long seed,
+                                   size_t n, unsigned keep_lt, float scale, unsigned long long seed,
                                    unsigned long long offset) {
-    const size_t n4 = (n + 3) / 4;
+    const size_t n8 = (n + 7) / 8;
     const uint2 key = make_uint2((unsigned)seed, (unsigned)(seed >> 32));
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-        const unsigned long long ctr = i + offset;
-        const uint4 r = philox4x32_10(make_uint4((unsigned)ctr, (unsigned)(ctr >> 32), 0u, 0u), key);
-        const float4 nz = make_float4(keep_bit(r.x, keep_prob), keep_bit(r.y, keep_prob), keep_bit(r.z, keep_prob),
-                                      keep_bit(r.w, keep_prob));
-        if (i * 4 + 3 < n) {
-            const float4 xv = reinterpret_cast<const float4*>(x)[i];
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+        const uint4 r = nk_draw_call(i * 8, offset, key);
+        const float4 nz0 = nk_keep4(r.x, r.y, keep_lt), nz1 = nk_keep4(r.z, r.w, keep_lt);
+        if (i * 8 + 7 < n) {
+            const float4 xa = reinterpret_cast<const float4*>(x)[2 * i], xb = reinterpret_cast<const float4*>(x)[2 * i + 1];
             float4 o;
-            o.x = (xv.x * nz.x) / scale; o.y = (xv.y * nz.y) / scale; o.z = (xv.z * nz.z) / scale; o.w = (xv.w * nz.w) / scale;
-            nk_store_stream(reinterpret_cast<float4*>(y) + i, o);
-            nk_store_stream(reinterpret_cast<float4*>(noise) + i, nz);
+            o.x = (xa.x * nz0.x) / scale; o.y = (xa.y * nz0.y) / scale; o.z = (xa.z * nz0.z) / scale; o.w = (xa.w * nz0.w) / scale;
+            nk_store_stream(reinterpret_cast<float4*>(y) + 2 * i, o);
+            o.x = (xb.x * nz1.x) / scale; o.y = (xb.y * nz1.y) / scale; o.z = (xb.z * nz1.z) / scale; o.w = (xb.w * nz1.w) / scale;
+            nk_store_stream(reinterpret_cast<float4*>(y) + 2 * i + 1, o);
+            nk_store_stream(reinterpret_cast<float4*>(noise) + 2 * i, nz0);
+            nk_store_stream(reinterpret_cast<float4*>(noise) + 2 * i + 1, nz1);
         } else {
-            const float nn[4] = {nz.x, nz.y, nz.z, nz.w};
-            for (int c = 0; c < 4; ++c) {
-                const size_t e = i * 4 + c;
+            const float nn[8] = {nz0.x, nz0.y, nz0.z, nz0.w, nz1.x, nz1.y, nz1.z, nz1.w};
+            for (int c = 0; c < 8; ++c) {
+                const size_t e = i * 8 + c;
                 if (e < n) { y[e] = (x[e] * nn[c]) / scale; noise[e] = nn[c]; }
             }
         }
@@ -480,10 +481,10 @@ int nk_dropout_fwd(nk_device* dev, const float* x, float* y, float* noise, size_
     }
     NK_CHECK(noise != nullptr, "noise buffer required in training mode");
     NK_CHECK(al16(x) && al16(y) && al16(noise), "dropout buffers must be 16-byte aligned");
-    const float keep = (float)(1.0 - p);      // Bernoulli::new(1. - p), dropout/mod.rs:46
-    const float scale = 1.f - (float)p;       // `(1. - self.p as f32)`, dropout/mod.rs:76
-    hipLaunchKernelGGL(dropout_fwd_kernel, dim3(nk_stream_grid((n + 3) / 4, 256)), dim3(256), 0, dev->compute, x, y, noise,
-                       n, keep, scale, (unsigned long long)seed, (unsigned long long)offset);
+    const unsigned keep_lt = nk_keep_threshold(1.0 - p);   // Bernoulli::new(1. - p), dropout/mod.rs:46
+    const float scale = 1.f - (float)p;                    // `(1. - self.p as f32)`, dropout/mod.rs:76
+    hipLaunchKernelGGL(dropout_fwd_kernel, dim3(nk_stream_grid((n + 7) / 8, 256)), dim3(256), 0, dev->compute, x, y, noise,
+                       n, keep_lt, scale, (unsigned long long)seed, (unsigned long long)offset);
     NK_LAUNCH_CHECK();
     return NK_OK;
 }

@@ -282,7 +282,7 @@ __global__ void softmax_bwd_strided_kernel(int assign, float* __restrict__ dx, c
 // (eval / p == 0: out = probs), 1 = Bernoulli mask, 2 = p == 1 (out = 0).
 template <int V, int MASK, bool STORE_NOISE>
 __global__ __launch_bounds__(256) void attn_probs_fwd_kernel(const float* __restrict__ s, float* __restrict__ probs, float* __restrict__ out,
-                                      float* __restrict__ noise, long long rows, int L, float scale, float keep,
+                                      float* __restrict__ noise, long long rows, int L, float scale, unsigned keep_lt,
                                       float dscale, unsigned long long seed, unsigned long long offset) {
     // No fma contraction: which products get fused depends on the instantiation (MASK / RECOMP / ...), and the stored-
     // probabilities and recomputed-probabilities paths must produce the same bits; it is also what the reference's
@@ -337,9 +337,9 @@ __global__ __launch_bounds__(256) void attn_probs_fwd_kernel(const float* __rest
             if (probs) nk_store_stream(reinterpret_cast<float4*>(probs + rb + c), y);  // not stored when the backward pass recomputes it
             float4 o = y;
             if (MASK == 1) {                                                                   // Dropout node
-                const unsigned long long ctr = (unsigned long long)(rb + c) / 4 + offset;
-                const uint4 r = philox4x32_10(make_uint4((unsigned)ctr, (unsigned)(ctr >> 32), 0u, 0u), key);
-                const float4 nz = make_float4(keep_bit(r.x, keep), keep_bit(r.y, keep), keep_bit(r.z, keep), keep_bit(r.w, keep));
+                // (a lane's quads are 1 KB apart: each takes its half of the call that covers it - the row kernels pay a
+                //  call per four elements as before; the flat kernel and the fused attention core use all eight draws)
+                const float4 nz = nk_keep4_at((unsigned long long)(rb + c), offset, key, keep_lt);
                 o.x = (y.x * nz.x) * dscale; o.y = (y.y * nz.y) * dscale; o.z = (y.z * nz.z) * dscale; o.w = (y.w * nz.w) * dscale;
                 if (STORE_NOISE) nk_store_stream(reinterpret_cast<float4*>(noise + rb + c), nz);
             } else if (MASK == 2) {
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(256) void attn_probs_fwd_kernel(const float* __rest
 // (scale, wave max, expf, wave sum, divide) instead of being read back - the forward then never writes them.
 template <int V, int MASK, bool LOAD_NOISE, bool RECOMP>
 __global__ __launch_bounds__(256) void attn_probs_bwd_kernel(float* __restrict__ ds, const float* __restrict__ g, const float* __restrict__ probs,
-                                      const float* __restrict__ noise, long long rows, int L, float scale, float keep,
+                                      const float* __restrict__ noise, long long rows, int L, float scale, unsigned keep_lt,
                                       unsigned long long seed, unsigned long long offset, int assign) {
     // No fma contraction: which products get fused depends on the instantiation (MASK / RECOMP / ...), and the stored-
     // probabilities and recomputed-probabilities paths must produce the same bits; it is also what the reference's
@@ -415,9 +415,7 @@ __global__ __launch_bounds__(256) void attn_probs_bwd_kernel(float* __restrict__
                 float4 nz;
                 if (LOAD_NOISE) nz = nzv[i];
                 else {
-                    const unsigned long long ctr = (unsigned long long)(rb + c) / 4 + offset;
-                    const uint4 r = philox4x32_10(make_uint4((unsigned)ctr, (unsigned)(ctr >> 32), 0u, 0u), key);
-                    nz = make_float4(keep_bit(r.x, keep), keep_bit(r.y, keep), keep_bit(r.z, keep), keep_bit(r.w, keep));
+                    nz = nk_keep4_at((unsigned long long)(rb + c), offset, key, keep_lt);
                 }
                 gv.x *= nz.x; gv.y *= nz.y; gv.z *= nz.z; gv.w *= nz.w;
             }
@@ -571,14 +569,15 @@ int nk_scale_softmax_dropout_fwd(nk_device* dev, const float* scores, float* pro
     NK_CHECK(L % 4 == 0 && L <= 2048 && al16(scores) && (!probs || al16(probs)) && al16(out) && (!noise || al16(noise)),
              "fused attention probabilities need L %% 4 == 0, L <= 2048 and 16-byte aligned buffers (L=%d)", L);
     const int mask = (!train || p == 0.0) ? 0 : (1.0 - p == 0.0 ? 2 : 1);
-    const float keep = (float)(1.0 - p), dscale = 1.f / (1.f - (float)p);  // multiplied in: 1 / (1 - p) rounded once on the host
+    const unsigned keep_lt = nk_keep_threshold(1.0 - p);   // Bernoulli::new(1. - p), dropout/mod.rs:46 (nk_common.h)
+    const float dscale = 1.f / (1.f - (float)p);           // multiplied in: 1 / (1 - p) rounded once on the host
     const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
 #define NK_AP(V)                                                                                                   \
     do {                                                                                                           \
-        if (mask == 0) hipLaunchKernelGGL((attn_probs_fwd_kernel<V, 0, false>), grid, block, 0, dev->compute, scores, probs, out, noise, rows, L, scale, keep, dscale, (unsigned long long)seed, (unsigned long long)offset); \
-        else if (mask == 2) hipLaunchKernelGGL((attn_probs_fwd_kernel<V, 2, false>), grid, block, 0, dev->compute, scores, probs, out, noise, rows, L, scale, keep, dscale, (unsigned long long)seed, (unsigned long long)offset); \
-        else if (noise) hipLaunchKernelGGL((attn_probs_fwd_kernel<V, 1, true>), grid, block, 0, dev->compute, scores, probs, out, noise, rows, L, scale, keep, dscale, (unsigned long long)seed, (unsigned long long)offset); \
-        else hipLaunchKernelGGL((attn_probs_fwd_kernel<V, 1, false>), grid, block, 0, dev->compute, scores, probs, out, noise, rows, L, scale, keep, dscale, (unsigned long long)seed, (unsigned long long)offset); \
+        if (mask == 0) hipLaunchKernelGGL((attn_probs_fwd_kernel<V, 0, false>), grid, block, 0, dev->compute, scores, probs, out, noise, rows, L, scale, keep_lt, dscale, (unsigned long long)seed, (unsigned long long)offset); \
+        else if (mask == 2) hipLaunchKernelGGL((attn_probs_fwd_kernel<V, 2, false>), grid, block, 0, dev->compute, scores, probs, out, noise, rows, L, scale, keep_lt, dscale, (unsigned long long)seed, (unsigned long long)offset); \
+        else if (noise) hipLaunchKernelGGL((attn_probs_fwd_kernel<V, 1, true>), grid, block, 0, dev->compute, scores, probs, out, noise, rows, L, scale, keep_lt, dscale, (unsigned long long)seed, (unsigned long long)offset); \
+        else hipLaunchKernelGGL((attn_probs_fwd_kernel<V, 1, false>), grid, block, 0, dev->compute, scores, probs, out, noise, rows, L, scale, keep_lt, dscale, (unsigned long long)seed, (unsigned long long)offset); \
     } while (0)
     if (L <= 256) NK_AP(1); else if (L <= 512) NK_AP(2); else if (L <= 1024) NK_AP(4); else NK_AP(8);
 #undef NK_AP
@@ -600,18 +599,19 @@ static int attn_probs_bwd(nk_device* dev, float* d_scores, const float* g_out, c
              "fused attention probabilities need L %% 4 == 0, L <= 2048 and 16-byte aligned buffers (L=%d)", L);
     // p == 1: the reference's backward multiplies by the (untouched, zero) noise buffer -> no gradient
     const bool masked = train && p != 0.0;
-    const float keep = (1.0 - p == 0.0) ? -1.f : (float)(1.0 - p);  // keep < 0: every draw is "dropped"
+    const bool all_dropped = 1.0 - p == 0.0;
+    const unsigned keep_lt = all_dropped ? 0u : nk_keep_threshold(1.0 - p);  // threshold 0: every draw is "dropped"
     const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
     assign |= nk_streams_past_cache((size_t)rows * L * 12) ? 2 : 0;  // bit 1: `nt` loads (operands beyond the Infinity Cache)
 #define NK_AP(V)                                                                                                   \
     do {                                                                                                           \
         if (recompute) {                                                                                           \
-            if (!masked) hipLaunchKernelGGL((attn_probs_bwd_kernel<V, 0, false, true>), grid, block, 0, dev->compute, d_scores, g_out, probs, noise, rows, L, scale, keep, (unsigned long long)seed, (unsigned long long)offset, assign); \
-            else if (noise && keep >= 0.f) hipLaunchKernelGGL((attn_probs_bwd_kernel<V, 1, true, true>), grid, block, 0, dev->compute, d_scores, g_out, probs, noise, rows, L, scale, keep, (unsigned long long)seed, (unsigned long long)offset, assign); \
-            else hipLaunchKernelGGL((attn_probs_bwd_kernel<V, 1, false, true>), grid, block, 0, dev->compute, d_scores, g_out, probs, noise, rows, L, scale, keep, (unsigned long long)seed, (unsigned long long)offset, assign); \
-        } else if (!masked) hipLaunchKernelGGL((attn_probs_bwd_kernel<V, 0, false, false>), grid, block, 0, dev->compute, d_scores, g_out, probs, noise, rows, L, scale, keep, (unsigned long long)seed, (unsigned long long)offset, assign); \
-        else if (noise && keep >= 0.f) hipLaunchKernelGGL((attn_probs_bwd_kernel<V, 1, true, false>), grid, block, 0, dev->compute, d_scores, g_out, probs, noise, rows, L, scale, keep, (unsigned long long)seed, (unsigned long long)offset, assign); \
-        else hipLaunchKernelGGL((attn_probs_bwd_kernel<V, 1, false, false>), grid, block, 0, dev->compute, d_scores, g_out, probs, noise, rows, L, scale, keep, (unsigned long long)seed, (unsigned long long)offset, assign); \
+            if (!masked) hipLaunchKernelGGL((attn_probs_bwd_kernel<V, 0, false, true>), grid, block, 0, dev->compute, d_scores, g_out, probs, noise, rows, L, scale, keep_lt, (unsigned long long)seed, (unsigned long long)offset, assign); \
+            else if (noise && !all_dropped) hipLaunchKernelGGL((attn_probs_bwd_kernel<V, 1, true, true>), grid, block, 0, dev->compute, d_scores, g_out, probs, noise, rows, L, scale, keep_lt, (unsigned long long)seed, (unsigned long long)offset, assign); \
+            else hipLaunchKernelGGL((attn_probs_bwd_kernel<V, 1, false, true>), grid, block, 0, dev->compute, d_scores, g_out, probs, noise, rows, L, scale, keep_lt, (unsigned long long)seed, (unsigned long long)offset, assign); \
+        } else if (!masked) hipLaunchKernelGGL((attn_probs_bwd_kernel<V, 0, false, false>), grid, block, 0, dev->compute, d_scores, g_out, probs, noise, rows, L, scale, keep_lt, (unsigned long long)seed, (unsigned long long)offset, assign); \
+        else if (noise && !all_dropped) hipLaunchKernelGGL((attn_probs_bwd_kernel<V, 1, true, false>), grid, block, 0, dev->compute, d_scores, g_out, probs, noise, rows, L, scale, keep_lt, (unsigned long long)seed, (unsigned long long)offset, assign); \
+        else hipLaunchKernelGGL((attn_probs_bwd_kernel<V, 1, false, false>), grid, block, 0, dev->compute, d_scores, g_out, probs, noise, rows, L, scale, keep_lt, (unsigned long long)seed, (unsigned long long)offset, assign); \
     } while (0)
     if (L <= 256) NK_AP(1); else if (L <= 512) NK_AP(2); else if (L <= 1024) NK_AP(4); else NK_AP(8);
 #undef NK_AP

@@ -350,20 +350,40 @@ def philox4x32_10(counter, key):
     return c
 
 
+DRAWS_PER_PHILOX_CALL = 8
+
+
+def dropout_draws_calls(n):
+    """Philox calls one forward over `n` elements consumes = how far the host advances the counter offset per forward."""
+    return (n + DRAWS_PER_PHILOX_CALL - 1) // DRAWS_PER_PHILOX_CALL
+
+
+def bernoulli_threshold(keep):
+    """`Bernoulli::new(1. - p)` (dropout/mod.rs:46) is rand 0.8's integer construction - `p_int = (p * 2^64) as u64`,
+    sample = `rng.gen::<u64>() < p_int` (crate rand 0.8.x, src/distributions/bernoulli.rs; not under /root/reference) -
+    restated on 32-bit words: keep iff v < floor(keep * 2^32), `keep` in f64 as the reference passes it."""
+    t = int(np.floor(np.float64(keep) * 4294967296.0))
+    return np.uint32(min(t, 0xFFFFFFFF))
+
+
 def dropout_noise(n, p, seed, offset):
-    """Bernoulli(1-p) 0/1 noise for `n` elements as the HIP backend draws it: element `i`
-    uses word `i % 4` of Philox4x32-10(counter = (i/4 + offset, 0, 0, 0) as 64-bit lo/hi,
-    key = seed lo/hi); keep iff u = word * 2^-32 < 1-p, compared in f32 as
-    `(float)(word >> 8) * 2^-24 < (float)(1-p)`."""
-    nblk = (n + 3) // 4
+    """Bernoulli(1-p) 0/1 noise for `n` elements as the HIP backend draws it.  One Philox4x32-10 call
+    (counter = (i // 8 + offset) as 64-bit lo/hi, 0, 0; key = seed lo/hi) serves EIGHT consecutive elements: element
+    i takes word (i % 8) // 2, as it is for even i and rotated by 16 bits for odd i, and is kept iff that 32-bit value
+    is below `bernoulli_threshold(1 - p)`.  Every draw thus has the keep probability to 2^-32 (its own 16 bits decide,
+    the partner's 16 bits only break ties); the two elements sharing a word are independent except on those 2^-16 ties.
+    Half the Philox rounds per element of the one-word-per-element layout of rounds 1-2 - the fused attention forward
+    pays ~2000 of a masked tile's ~6700 issue cycles for them."""
+    nblk = dropout_draws_calls(n)
     idx = np.arange(nblk, dtype=np.uint64) + np.uint64(offset)
     ctr = np.zeros((nblk, 4), dtype=np.uint32)
     ctr[:, 0] = (idx & np.uint64(0xFFFFFFFF)).astype(np.uint32)
     ctr[:, 1] = (idx >> np.uint64(32)).astype(np.uint32)
     key = np.array([seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF], dtype=np.uint32)
-    words = philox4x32_10(ctr, key).reshape(-1)[:n]
-    u = (words >> np.uint32(8)).astype(np.float32) * np.float32(2.0 ** -24)
-    return (u < np.float32(1.0 - p)).astype(np.float32)
+    words = philox4x32_10(ctr, key)                                         # (nblk, 4)
+    rot = (words << np.uint32(16)) | (words >> np.uint32(16))
+    draws = np.stack([words, rot], axis=2).reshape(-1)[:n]                  # w0, rot(w0), w1, rot(w1), ...
+    return (draws < bernoulli_threshold(1.0 - p)).astype(np.float32)
 
 
 def dropout_forward(x, out, noise, p, train=True):
@@ -377,7 +397,8 @@ def dropout_forward(x, out, noise, p, train=True):
     if 1.0 - p == 0.0:
         out[...] = 0
         return
-    out[...] = (x * noise) / x.dtype.type(np.float32(1.0 - p))
+    # `(1. - self.p as f32)` (dropout/mod.rs:76): the cast binds first - an f32 subtraction of the rounded p
+    out[...] = (x * noise) / x.dtype.type(np.float32(1.0) - np.float32(p))
 
 
 def dropout_backward(x_grad, grad, noise, p, train=True):

@@ -37,3 +37,34 @@ def dev():
     d = capi.Device(0)
     yield d
     d.sync()
+
+
+# ---- measured tolerance margins -------------------------------------------------------------------------------------
+# The parity bound for contractions is  err_gpu <= max(k * err_cpu32, a * K * |a| * |b|)  against the f64 oracle
+# (SURVEY.md 8c ii states k = 2, a = 1e-6; the attention / full-size tests use k = 4, a = 2e-6 - DESIGN.md section 5
+# records why and how close to either bound the kernels actually run).  Every such check reports here; the session
+# writes gpurun_out/tolerance_margins.json = per label the worst  err_gpu / (2 * err_cpu32)  and  err_gpu / abs_term(1e-6).
+_MARGINS = {}
+
+
+def record_margin(label, err_gpu, err_cpu32, abs_term_1e6):
+    """abs_term_1e6: the absolute term of the STATED policy (1e-6 * K * |a| * |b|, or 1e-6 * scale)."""
+    m = _MARGINS.setdefault(label, {"n": 0, "vs_2x_cpu32": 0.0, "vs_abs_1e-6": 0.0, "vs_stated_policy": 0.0})
+    r_cpu = float(err_gpu) / (2.0 * float(err_cpu32)) if err_cpu32 > 0 else float("inf")
+    r_abs = float(err_gpu) / float(abs_term_1e6) if abs_term_1e6 > 0 else float("inf")
+    m["n"] += 1
+    m["vs_2x_cpu32"] = max(m["vs_2x_cpu32"], r_cpu if r_cpu != float("inf") else 0.0)
+    m["vs_abs_1e-6"] = max(m["vs_abs_1e-6"], r_abs if r_abs != float("inf") else 0.0)
+    m["vs_stated_policy"] = max(m["vs_stated_policy"], min(r_cpu, r_abs))   # <= 1: inside the stated 2x / 1e-6 policy
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if not _MARGINS:
+        return
+    out = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "tolerance_margins.json"), "w") as f:
+            json.dump(_MARGINS, f, indent=1, sort_keys=True)
+    except OSError:
+        pass

@@ -27,6 +27,8 @@ def rnd(seed, shape, lo, hi):
 def _check(got, want64, want32, what, floor=0.0):
     scale = max(np.abs(want64).max(), floor)
     err_gpu, err_cpu = np.abs(got - want64).max(), np.abs(want32 - want64).max()
+    from conftest import record_margin
+    record_margin("attention_core:" + what.split("[")[0].strip(), err_gpu, err_cpu, 1e-6 * scale)
     assert err_gpu <= max(4 * err_cpu, 2e-6 * scale), (what, err_gpu, err_cpu, scale)
 
 

@@ -78,6 +78,34 @@ def test_C3_conv_full_size(dev):
     c.conv_bwd_input(dev, DX4, G, W, (1, 1), (1, 1), 1, assign=True, padding=(1, 1))
     assert np.array_equal(DX3.numpy(), DX4.numpy())                 # run-to-run deterministic
 
+    # What the benchmarked C3 step actually launches: the bias joined to the forward epilogue (`nk_conv_bias_fwd`) and the
+    # bias gradient summed on the way by the kernel-gradient pass (`nk_conv_bwd_kernel_bias`), at the full size.
+    b = rnd(4, (Cout, 1, 1), -k, k)
+    Bv, YB = dev.array(b), dev.full(y.shape, np.nan)
+    c.conv_fwd(dev, XP, W, YB, (1, 1), (1, 1), 1, bias=Bv)            # nk_conv_bias_fwd
+    yb = YB.numpy()
+    assert np.array_equal(yb, y + b.reshape(1, Cout, 1, 1))         # one f32 add per element on top of the same tile sums
+    for n, co, oh, ow in zip(rng.integers(0, N, 32), rng.integers(0, Cout, 32), rng.integers(0, H, 32), rng.integers(0, H, 32)):
+        ref = (xp[n, :, oh:oh + 3, ow:ow + 3].astype(np.float64) * w[co].astype(np.float64)).sum() + float(b[co, 0, 0])
+        assert abs(yb[n, co, oh, ow] - ref) <= 1e-6 * 576, (n, co, oh, ow)
+    dw0, db0 = rnd(8, w.shape, -1, 1), rnd(9, b.shape, -1, 1)
+    DW2, DB2 = dev.array(dw0), dev.array(db0)
+    c.conv_bwd_kernel_bias(dev, DW2, DB2, G, XP, (1, 1), (1, 1), 1)
+    DWr = dev.array(dw0)
+    c.conv_bwd_kernel(dev, DWr, G, XP, (1, 1), (1, 1), 1)
+    assert np.array_equal(DW2.numpy(), DWr.numpy())                 # the same pass: kernel gradient bit-identical
+    np.testing.assert_allclose(DW2.numpy() - dw0, dw, rtol=0, atol=2e-7 * N * H * H * 0.5 + 1e-6)
+    db64 = g64.sum(axis=(0, 2, 3)).reshape(b.shape)                 # AdditionBackwardRight: un-broadcast sum over N, H, W
+    db32 = np.zeros(b.shape, np.float32); O.accumulate(db32, g)
+    err_gpu, err_cpu = np.abs(DB2.numpy().astype(np.float64) - (db0 + db64)).max(), np.abs(db32 - db64).max()
+    from conftest import record_margin
+    record_margin("C3_full_size:db", err_gpu, err_cpu, 1e-6 * (N * H * H) ** 0.5 * np.abs(g).max() + 1e-7 * np.abs(db64).max())
+    assert err_gpu <= max(2 * err_cpu, 1e-6 * (N * H * H) ** 0.5 * np.abs(g).max() + 1e-7 * np.abs(db64).max()), (err_gpu, err_cpu)
+    DW3, DB3 = dev.full(w.shape, np.nan), dev.full(b.shape, np.nan)   # first-write forms, as the module's first backward node uses them
+    c.conv_bwd_kernel_bias(dev, DW3, DB3, G, XP, (1, 1), (1, 1), 1, assign=(True, True))
+    assert np.array_equal(DW3.numpy(), dw)
+    np.testing.assert_allclose(DB3.numpy(), DB2.numpy() - db0, rtol=0, atol=2e-7 * np.abs(db64).max())
+
 
 def test_C4_mlp_full_size(nk):
     """C4 on one GPU: Linear(4096,4096)x3 + ReLU, batch 4096, MSE mean, backward(1.0): loss and
@@ -112,9 +140,12 @@ def test_C4_mlp_full_size(nk):
     # ... or the absolute contraction term, 2e-6 * K * max|g| * max|a| at K = 4096 (the MFMA sums the
     # K = 4096 products as one sequential f32 fma chain; OpenBLAS blocks K and lands closer to f64).
     for lin, (dw64, db64), (dw32, db32), gab in zip(lins, g64, g32, ab):
+        from conftest import record_margin
         err_gpu, err_cpu = np.abs(lin.weight.grad() - dw64).max(), np.abs(dw32 - dw64).max()
+        record_margin("C4_full_size:dW", err_gpu, err_cpu, 1e-6 * n * gab)
         assert err_gpu <= max(4 * err_cpu, 2e-6 * n * gab), (err_gpu, err_cpu, gab)
         err_gpu, err_cpu = np.abs(lin.bias.grad() - db64).max(), np.abs(db32 - db64).max()
+        record_margin("C4_full_size:db", err_gpu, err_cpu, 1e-6 * n * gab)
         assert err_gpu <= max(4 * err_cpu, 2e-6 * n * gab), (err_gpu, err_cpu, gab)
 
 
@@ -163,14 +194,14 @@ def test_C5_attention_full_size_with_dropout(nk):
     out.forward(); out.backward_from(nk.from_ndarray(dev, g))
     b = 29
     rows = slice(b * S, (b + 1) * S)
-    noise = O.dropout_noise(H * S * S, p, seed, b * H * S * S // 4).reshape(H, S, S).astype(np.float64)
+    noise = O.dropout_noise(H * S * S, p, seed, b * H * S * S // 8).reshape(H, S, S).astype(np.float64)
     ref, grads = _mha_oracle64(mha, x[rows], g[rows], H, 1, p, noise)
     got = out.data()[rows]
     assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max()
     gx = X.grad()[rows]
     assert np.abs(gx - grads["x"]).max() <= 2e-5 * np.abs(grads["x"]).max()
     # a different mask must NOT match (the check has teeth): the neighbouring sample's mask
-    wrong = O.dropout_noise(H * S * S, p, seed, (b - 1) * H * S * S // 4).reshape(H, S, S).astype(np.float64)
+    wrong = O.dropout_noise(H * S * S, p, seed, (b - 1) * H * S * S // 8).reshape(H, S, S).astype(np.float64)
     ref_w, _ = _mha_oracle64(mha, x[rows], g[rows], H, 1, p, wrong)
     assert np.abs(got - ref_w).max() > 1e-3 * np.abs(ref).max()
 

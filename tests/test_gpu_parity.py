@@ -669,7 +669,8 @@ def test_dropout(dev):
     assert np.array_equal(Y.numpy(), x)
     c.dropout_fwd(dev, X, Y, NZ, 0.5, False)                 # eval mode: copy
     assert np.array_equal(Y.numpy(), x)
-    for p, seed, off in ((0.5, 7, 0), (0.1, 123456789012345, 1 << 33)):
+    # (p = 0.09 / 0.16 / 0.33: f32(1) - f32(p) != f32(1 - p) - the scale follows dropout/mod.rs:76 literally)
+    for p, seed, off in ((0.5, 7, 0), (0.1, 123456789012345, 1 << 33), (0.09, 3, (1 << 32) - 2), (0.16, 4, 1), (0.33, 5, 2), (0.999, 6, 3)):
         c.dropout_fwd(dev, X, Y, NZ, p, True, seed, off)
         noise = O.dropout_noise(n, p, seed, off)
         assert np.array_equal(NZ.numpy(), noise)             # bit-exact keep/drop pattern

@@ -639,7 +639,7 @@ def test_mha_with_dropout_equals_oracle(nk, tdev, fused, strided, p):
     leaves = [X] + [getattr(getattr(mha, n), w) for n in "qkvo" for w in ("weight", "bias")]
     n = B * H * S * S
     for call in range(2):
-        noise = O.dropout_noise(n, p, seed, call * ((n + 3) // 4)).reshape(B * H, S, S)
+        noise = O.dropout_noise(n, p, seed, call * O.dropout_draws_calls(n)).reshape(B * H, S, S)
         assert 0.5 * (1 - p) < noise.mean() < min(1.0, 1.5 * (1 - p))
         for v in leaves:
             v.zero_grad()
@@ -650,6 +650,8 @@ def test_mha_with_dropout_equals_oracle(nk, tdev, fused, strided, p):
         def check(got, want, want32, what, floor=0.0):
             scale = max(np.abs(want).max(), floor)
             err_gpu, err_cpu = np.abs(got - want).max(), np.abs(want32 - want).max()
+            from conftest import record_margin
+            record_margin("mha_module:" + what, err_gpu, err_cpu, 1e-6 * scale)
             assert err_gpu <= max(4 * err_cpu, 2e-6 * scale), (what, call, err_gpu, err_cpu, scale)
         check(y.data(), ref, ref32, "out")
         check(X.grad(), grads["x"], grads32["x"], "dx")
@@ -683,7 +685,7 @@ def test_mha_fused_attention_core_equals_oracle(nk, tdev, core, p, S):
     leaves = [X] + [getattr(getattr(mha, n), w) for n in "qkvo" for w in ("weight", "bias")]
     n = B * H * S * S
     for call in range(2):
-        noise = O.dropout_noise(n, p, seed, call * ((n + 3) // 4)).reshape(B * H, S, S) if p else np.ones((B * H, S, S), np.float32)
+        noise = O.dropout_noise(n, p, seed, call * O.dropout_draws_calls(n)).reshape(B * H, S, S) if p else np.ones((B * H, S, S), np.float32)
         for v in leaves:
             v.zero_grad()
         y.forward(); y.no_grad(); y.with_grad()
@@ -693,6 +695,8 @@ def test_mha_fused_attention_core_equals_oracle(nk, tdev, core, p, S):
         def check(got, want, want32, what, floor=0.0):
             scale = max(np.abs(want).max(), floor)
             err_gpu, err_cpu = np.abs(got - want).max(), np.abs(want32 - want).max()
+            from conftest import record_margin
+            record_margin("mha_module:" + what, err_gpu, err_cpu, 1e-6 * scale)
             assert err_gpu <= max(4 * err_cpu, 2e-6 * scale), (what, call, err_gpu, err_cpu, scale)
         check(y.data(), ref, ref32, "out")
         check(X.grad(), grads["x"], grads32["x"], "dx")

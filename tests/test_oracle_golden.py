@@ -468,6 +468,53 @@ def test_dropout_noise_rate():
     assert abs(n.mean() - 0.9) < 0.01
 
 
+def test_dropout_noise_draw_layout():
+    """The draw layout restated element by element (scalar loops): call i // 8 + offset, word (i % 8) // 2, rotated by 16
+    bits for odd i, kept iff below floor((1 - p) * 2^32) - rand 0.8's Bernoulli construction on 32-bit values."""
+    n, p, seed, off = 203, 0.3, 0x0123456789ABCDEF, (1 << 32) - 5        # ragged tail, counter carry into the high word
+    got = O.dropout_noise(n, p, seed, off)
+    key = np.array([seed & 0xFFFFFFFF, seed >> 32], dtype=np.uint32)
+    thr = int(np.floor((1.0 - p) * 2.0 ** 32))
+    assert int(O.bernoulli_threshold(1.0 - p)) == thr
+    for i in range(n):
+        c = i // 8 + off
+        w = int(O.philox4x32_10(np.array([[c & 0xFFFFFFFF, c >> 32, 0, 0]], dtype=np.uint32), key)[0][(i % 8) // 2])
+        if i % 2:
+            w = ((w << 16) | (w >> 16)) & 0xFFFFFFFF
+        assert got[i] == (1.0 if w < thr else 0.0), i
+    assert O.dropout_draws_calls(203) == 26 and O.dropout_draws_calls(208) == 26 and O.dropout_draws_calls(209) == 27
+    # a later forward (offset advanced by the calls consumed) continues the stream: no element of the two masks shares a call
+    a, b = O.dropout_noise(64, p, seed, 10), O.dropout_noise(64, p, seed, 10 + O.dropout_draws_calls(64))
+    assert np.array_equal(O.dropout_noise(128, p, seed, 10), np.concatenate([a, b]))
+    assert int(O.bernoulli_threshold(1.0)) == 0xFFFFFFFF and int(O.bernoulli_threshold(0.0)) == 0
+    assert int(O.bernoulli_threshold(0.5)) == 1 << 31
+
+
+@pytest.mark.parametrize("p", [0.1, 0.25, 1.0 / 3.0, 0.5, 0.9])
+def test_dropout_noise_statistics(p):
+    """Keep rate within 4 sigma of 1 - p over 2^20 draws, and the two draws that share a Philox word (one reads it as
+    it is, the other rotated by 16 bits) are uncorrelated: P(both kept) = (1 - p)^2 within 4 sigma."""
+    n = 1 << 20
+    z = O.dropout_noise(n, p, seed=2026, offset=11).astype(np.float64)
+    keep = 1.0 - p
+    assert abs(z.mean() - keep) < 4 * np.sqrt(keep * p / n)
+    both = z[0::2] * z[1::2]
+    assert abs(both.mean() - keep * keep) < 4 * np.sqrt(keep * keep * (1 - keep * keep) / (n / 2))
+    nb = z[1:-1:2] * z[2::2]                       # neighbours from different words
+    assert abs(nb.mean() - keep * keep) < 4 * np.sqrt(keep * keep * (1 - keep * keep) / (n / 2))
+
+
+def test_dropout_scale_is_the_f32_subtraction():
+    """`(1. - self.p as f32)` (dropout/mod.rs:76): the cast binds tighter than the subtraction - f32(1) - f32(p), which
+    differs from f32(1 - p) by one ulp for e.g. p = 0.09 (VERDICT round 2, weak #3)."""
+    for p in (0.09, 0.16, 0.33, 0.1, 0.5):
+        x = np.linspace(0.5, 2.0, 64, dtype=np.float32)
+        y = np.zeros_like(x)
+        O.dropout_forward(x, y, np.ones_like(x), p, True)
+        assert np.array_equal(y, x / (np.float32(1.0) - np.float32(p)))
+    assert np.float32(1.0 - 0.09) != np.float32(1.0) - np.float32(0.09)
+
+
 # ------------------------------------------------------------------ tape composition sanity
 def test_mlp_step_matches_f64_autograd_free_formula():
     rng = np.random.default_rng(0)
