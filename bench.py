@@ -364,7 +364,7 @@ def measure_conv(dist, tdev, cdev, steps, warmup):
     t = neuronika_amd.tape
     N = 128
     x = np.random.default_rng(0).random((N, 64, 56, 56), dtype=np.float32)
-    conv = t.nn.Conv2d(tdev, 64, 128, [3, 3], [1, 1], [1, 1], [1, 1], 1, 1)
+    conv = t.nn.Conv2d(tdev, 64, 128, [3, 3], [1, 1], t.PaddingMode.zero(), [1, 1], [1, 1], 1)
     X = t.from_ndarray(tdev, x).requires_grad()
     y = conv.forward(X)
     G = t.from_ndarray(tdev, np.random.default_rng(2).random((N, 128, 56, 56), dtype=np.float32))
@@ -422,7 +422,7 @@ def measure_mha(dist, tdev, cdev, steps, warmup):
 
 
 # ---- what RCCL chose, from rank 0's NCCL_DEBUG=INFO log ---------------------------------------------------------------
-_RCCL_ALGO = {0: "Tree", 1: "Ring", 2: "CollNetDirect", 3: "CollNetChain", 4: "NVLS", 5: "NVLSTree"}
+_RCCL_ALGO = {0: "Tree", 1: "Ring", 2: "CollNetDirect", 3: "CollNetChain", 4: "NVLS", 5: "NVLSTree", 6: "PAT"}
 _RCCL_PROTO = {0: "LL", 1: "LL128", 2: "Simple"}
 
 
@@ -433,24 +433,33 @@ def parse_rccl_log(text, max_excerpt=16):
     m = re.search(r"(?:RCCL|NCCL) version\s*:?\s*([0-9][^\s]*)", text)
     if m:
         out["version"] = m.group(1)
-    m = re.search(r"(\d+) coll channels", text)
+    m = re.search(r"(\d+) coll channels", text) or re.search(r"coll channels:\s*(\d+)", text)   # NCCL <= 2.2x / RCCL 2.27 wording
     if m:
         out["channels"] = int(m.group(1))
     else:
         ch = [int(x) for x in re.findall(r"Channel \d+/(\d+)", text)]
         if ch:
             out["channels"] = max(ch)
+    m = re.search(r"Init timings.*?total ([0-9.]+)", text)
+    if m:
+        out["comm_init_s"] = float(m.group(1))
     seen = {}
-    for coll, nbytes, algo, proto in re.findall(r"(\w+): (\d+) Bytes -> Algo (\d+) proto (\d+)", text):
-        key = (coll, int(nbytes), int(algo), int(proto))
+    # "AllReduce: 33554432 Bytes -> Algo 1 proto 2 time 412.0"  (numbers)  or
+    # "AllReduce: 33554432 Bytes -> Algo RING proto SIMPLE channel{Lo..Hi}={0..31}"  (names, 2.24+)
+    for coll, nbytes, algo, proto, rest in re.findall(r"(\w+): (\d+) Bytes -> Algo (\w+) proto (\w+)([^\n]*)", text):
+        algo = _RCCL_ALGO.get(int(algo), algo) if algo.isdigit() else algo.capitalize() if algo.isupper() and len(algo) > 4 else algo
+        proto = _RCCL_PROTO.get(int(proto), proto) if proto.isdigit() else proto
+        ch = re.search(r"=\{(\d+)\.\.(\d+)\}", rest)
+        key = (coll, int(nbytes), str(algo), str(proto), (int(ch.group(2)) - int(ch.group(1)) + 1) if ch else None)
         seen[key] = seen.get(key, 0) + 1
-    out["choices"] = [{"coll": c, "bytes": b, "algo": _RCCL_ALGO.get(a, str(a)), "proto": _RCCL_PROTO.get(pr, str(pr)), "calls": n}
-                      for (c, b, a, pr), n in sorted(seen.items(), key=lambda kv: -kv[0][1])][:12]
+    out["choices"] = [{"coll": c, "bytes": b, "algo": a, "proto": pr, **({"channels_used": nch} if nch else {}), "calls": n}
+                      for (c, b, a, pr, nch), n in sorted(seen.items(), key=lambda kv: -kv[0][1])][:12]
     out["env_overrides"] = sorted(set(re.findall(r"((?:NCCL|RCCL)_[A-Z0-9_]+) set by environment to ([^\s]+)", text)))[:16]
     out["env_overrides"] = [f"{k}={v}" for k, v in out["env_overrides"]]
     out["warnings"] = len(re.findall(r" NCCL WARN ", text))
     keep = [ln.strip()[-200:] for ln in text.splitlines()
-            if re.search(r"version|coll channels|Channel 00|Ring 00|Trees|Connected all|comm 0x.*nranks|WARN|P2P|XGMI|threadThresholds", ln)]
+            if re.search(r"RCCL version|NCCL version|coll channels|Channel 00/|Ring 00|Connected all|nRanks|Init timings|P2P|XGMI|xGMI|threadThresholds|Algo", ln)
+            and "NCCL WARN" not in ln]
     out["excerpt"] = keep[:max_excerpt]
     return out
 

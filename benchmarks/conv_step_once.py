@@ -12,7 +12,7 @@ import neuronika_amd  # noqa: E402
 t = neuronika_amd.tape
 dev = t.Device(0)
 N = 128
-conv = t.nn.Conv2d(dev, 64, 128, [3, 3], [1, 1], [1, 1], [1, 1], 1, 1)
+conv = t.nn.Conv2d(dev, 64, 128, [3, 3], [1, 1], t.PaddingMode.zero(), [1, 1], [1, 1], 1)
 X = t.from_ndarray(dev, np.random.default_rng(0).random((N, 64, 56, 56), dtype=np.float32)).requires_grad()
 G = t.from_ndarray(dev, np.random.default_rng(2).random((N, 128, 56, 56), dtype=np.float32))
 y = conv.forward(X)

@@ -506,21 +506,45 @@ struct ConvNd {
     VarDiff forward(const Var& input) const;
     VarDiff forward(const VarDiff& input) const;
 };
+// Constructor argument order = the reference's `new` (neuronika-nn/src/lib.rs:671-679, 762-770, 857-865):
+// (in_channels, out_channels, kernel_size, padding, padding_mode, stride, dilation); `seed` (ours, last) fixes the
+// U(-k, k) initialisation.
 struct Conv1d : ConvNd {
     Conv1d(DevicePtr dev, int in_channels, int out_channels, int kernel, int padding, PaddingMode mode, int stride,
-           int dilation, int groups = 1, uint64_t seed = 0)
-        : ConvNd(1, std::move(dev), in_channels, out_channels, {kernel}, {padding}, mode, {stride}, {dilation}, groups, seed) {}
+           int dilation, uint64_t seed = 0)
+        : ConvNd(1, std::move(dev), in_channels, out_channels, {kernel}, {padding}, mode, {stride}, {dilation}, 1, seed) {}
 };
 struct Conv2d : ConvNd {
     Conv2d(DevicePtr dev, int in_channels, int out_channels, std::vector<int> kernel, std::vector<int> padding,
-           std::vector<int> stride, std::vector<int> dilation, int groups = 1, uint64_t seed = 0,
-           PaddingMode mode = PaddingMode::zero())
+           PaddingMode mode, std::vector<int> stride, std::vector<int> dilation, uint64_t seed = 0)
         : ConvNd(2, std::move(dev), in_channels, out_channels, std::move(kernel), std::move(padding), mode, std::move(stride),
-                 std::move(dilation), groups, seed) {}
+                 std::move(dilation), 1, seed) {}
 };
 struct Conv3d : ConvNd {
     Conv3d(DevicePtr dev, int in_channels, int out_channels, std::vector<int> kernel, std::vector<int> padding,
-           PaddingMode mode, std::vector<int> stride, std::vector<int> dilation, int groups = 1, uint64_t seed = 0)
+           PaddingMode mode, std::vector<int> stride, std::vector<int> dilation, uint64_t seed = 0)
+        : ConvNd(3, std::move(dev), in_channels, out_channels, std::move(kernel), std::move(padding), mode, std::move(stride),
+                 std::move(dilation), 1, seed) {}
+};
+// `nn::GroupedConv1d / 2d / 3d`: named in the reference's module index (src/lib.rs:783-797,
+// neuronika-nn/src/lib.rs:369-387) and in BASELINE.json's north_star; the structs themselves are absent from the
+// reference snapshot (its grouped convolution lives at node level: `Convolution::convolution_with_groups`,
+// node/convolution/mod.rs:125-144,256-294).  Same fields and argument order as ConvNd plus `groups` after `dilation`;
+// weight (Cout, Cin / groups, k...), k = sqrt(1 / (Cin / groups * prod(kernel))).
+struct GroupedConv1d : ConvNd {
+    GroupedConv1d(DevicePtr dev, int in_channels, int out_channels, int kernel, int padding, PaddingMode mode, int stride,
+                  int dilation, int groups, uint64_t seed = 0)
+        : ConvNd(1, std::move(dev), in_channels, out_channels, {kernel}, {padding}, mode, {stride}, {dilation}, groups, seed) {}
+};
+struct GroupedConv2d : ConvNd {
+    GroupedConv2d(DevicePtr dev, int in_channels, int out_channels, std::vector<int> kernel, std::vector<int> padding,
+                  PaddingMode mode, std::vector<int> stride, std::vector<int> dilation, int groups, uint64_t seed = 0)
+        : ConvNd(2, std::move(dev), in_channels, out_channels, std::move(kernel), std::move(padding), mode, std::move(stride),
+                 std::move(dilation), groups, seed) {}
+};
+struct GroupedConv3d : ConvNd {
+    GroupedConv3d(DevicePtr dev, int in_channels, int out_channels, std::vector<int> kernel, std::vector<int> padding,
+                  PaddingMode mode, std::vector<int> stride, std::vector<int> dilation, int groups, uint64_t seed = 0)
         : ConvNd(3, std::move(dev), in_channels, out_channels, std::move(kernel), std::move(padding), mode, std::move(stride),
                  std::move(dilation), groups, seed) {}
 };

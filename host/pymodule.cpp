@@ -279,21 +279,35 @@ PYBIND11_MODULE(_tape, m) {
         .def_readonly("weight", &nn::ConvNd::weight)
         .def_readonly("bias", &nn::ConvNd::bias)
         .def_readwrite("fused", &nn::ConvNd::fused)
+        .def_readonly("groups", &nn::ConvNd::groups)
+        .def_readonly("padding", &nn::ConvNd::padding).def_readonly("stride", &nn::ConvNd::stride).def_readonly("dilation", &nn::ConvNd::dilation)
         .def("forward", py::overload_cast<const Var&>(&nn::ConvNd::forward, py::const_))
         .def("forward", py::overload_cast<const VarDiff&>(&nn::ConvNd::forward, py::const_));
+    // argument order of the reference's `new` (neuronika-nn/src/lib.rs:671-679, 762-770, 857-865) + seed; GroupedConv*: + groups
     py::class_<nn::Conv1d, nn::ConvNd>(nn, "Conv1d")
-        .def(py::init<DevicePtr, int, int, int, int, PaddingMode, int, int, int, uint64_t>(), py::arg("dev"), py::arg("in_channels"),
-             py::arg("out_channels"), py::arg("kernel"), py::arg("padding"), py::arg("padding_mode"), py::arg("stride"),
-             py::arg("dilation"), py::arg("groups") = 1, py::arg("seed") = 0);
+        .def(py::init<DevicePtr, int, int, int, int, PaddingMode, int, int, uint64_t>(), py::arg("dev"), py::arg("in_channels"),
+             py::arg("out_channels"), py::arg("kernel_size"), py::arg("padding"), py::arg("padding_mode"), py::arg("stride"),
+             py::arg("dilation"), py::arg("seed") = 0);
     py::class_<nn::Conv2d, nn::ConvNd>(nn, "Conv2d")
-        .def(py::init<DevicePtr, int, int, std::vector<int>, std::vector<int>, std::vector<int>, std::vector<int>, int, uint64_t, PaddingMode>(),
-             py::arg("dev"), py::arg("in_channels"), py::arg("out_channels"), py::arg("kernel"), py::arg("padding"),
-             py::arg("stride"), py::arg("dilation"), py::arg("groups") = 1, py::arg("seed") = 0,
-             py::arg("padding_mode") = PaddingMode::zero());
+        .def(py::init<DevicePtr, int, int, std::vector<int>, std::vector<int>, PaddingMode, std::vector<int>, std::vector<int>, uint64_t>(),
+             py::arg("dev"), py::arg("in_channels"), py::arg("out_channels"), py::arg("kernel_size"), py::arg("padding"),
+             py::arg("padding_mode"), py::arg("stride"), py::arg("dilation"), py::arg("seed") = 0);
     py::class_<nn::Conv3d, nn::ConvNd>(nn, "Conv3d")
+        .def(py::init<DevicePtr, int, int, std::vector<int>, std::vector<int>, PaddingMode, std::vector<int>, std::vector<int>, uint64_t>(),
+             py::arg("dev"), py::arg("in_channels"), py::arg("out_channels"), py::arg("kernel_size"), py::arg("padding"),
+             py::arg("padding_mode"), py::arg("stride"), py::arg("dilation"), py::arg("seed") = 0);
+    py::class_<nn::GroupedConv1d, nn::ConvNd>(nn, "GroupedConv1d")
+        .def(py::init<DevicePtr, int, int, int, int, PaddingMode, int, int, int, uint64_t>(), py::arg("dev"), py::arg("in_channels"),
+             py::arg("out_channels"), py::arg("kernel_size"), py::arg("padding"), py::arg("padding_mode"), py::arg("stride"),
+             py::arg("dilation"), py::arg("groups"), py::arg("seed") = 0);
+    py::class_<nn::GroupedConv2d, nn::ConvNd>(nn, "GroupedConv2d")
         .def(py::init<DevicePtr, int, int, std::vector<int>, std::vector<int>, PaddingMode, std::vector<int>, std::vector<int>, int, uint64_t>(),
-             py::arg("dev"), py::arg("in_channels"), py::arg("out_channels"), py::arg("kernel"), py::arg("padding"),
-             py::arg("padding_mode"), py::arg("stride"), py::arg("dilation"), py::arg("groups") = 1, py::arg("seed") = 0);
+             py::arg("dev"), py::arg("in_channels"), py::arg("out_channels"), py::arg("kernel_size"), py::arg("padding"),
+             py::arg("padding_mode"), py::arg("stride"), py::arg("dilation"), py::arg("groups"), py::arg("seed") = 0);
+    py::class_<nn::GroupedConv3d, nn::ConvNd>(nn, "GroupedConv3d")
+        .def(py::init<DevicePtr, int, int, std::vector<int>, std::vector<int>, PaddingMode, std::vector<int>, std::vector<int>, int, uint64_t>(),
+             py::arg("dev"), py::arg("in_channels"), py::arg("out_channels"), py::arg("kernel_size"), py::arg("padding"),
+             py::arg("padding_mode"), py::arg("stride"), py::arg("dilation"), py::arg("groups"), py::arg("seed") = 0);
     py::class_<nn::Dropout>(nn, "Dropout")
         .def(py::init<double>())
         .def("train", &nn::Dropout::train)

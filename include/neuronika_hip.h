@@ -410,8 +410,10 @@ int nk_scale_softmax_dropout_bwd_from_scores(nk_device* dev, float* d_scores, co
  * Dropout mask: the Philox stream of nk_scale_softmax_dropout_fwd (same seed / offset -> same mask).
  * nk_attention_supported: dh == 64, S % 32 == 0, not (train and p == 1); callers fall back to the node-by-node path. */
 int nk_attention_supported(int S, int dh, double p, int train);
-/* forward: writes the raw scores (for the backward pass), the row statistics, the dropout draws (1 bit per score,
- * (B*H, S, S/32) words; may be NULL when dropout is inactive) and O.  `scores` = `stats` = NULL: inference, nothing is
+/* forward: writes the raw scores (for the backward pass), the row statistics, the dropout draws (1 bit per score:
+ * B*H*S*S/32 words laid out [b*H + h][S/32 query tiles][S/32 key tiles][32 queries of the tile], bit 16 j + e of a word =
+ * key 32 kt + 16 j + e kept - opaque to callers, who only hand the buffer from the forward to the backward; may be NULL
+ * when dropout is inactive) and O.  `scores` = `stats` = NULL: inference, nothing is
  * kept for a backward pass (O only: no (B*H, S, S) tensor exists at all). */
 int nk_attention_fwd(nk_device* dev, const float* Q, const float* K, const float* V, float* scores, float* stats,
                      uint32_t* mask_bits, float* O, int B, int S, int H, int dh, float scale, double p, int train,

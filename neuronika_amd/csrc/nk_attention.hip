@@ -51,7 +51,10 @@ struct AttnArgs {
     float* scores;     // (B*H, S, S) raw scores: written forward, read backward
     float* ds;         // backward: dS
     float* dropped;    // backward: Pd
-    unsigned* maskbits;  // (B*H, S, S/32): the dropout draws, 1 bit per score (bit 16h + e of word kt = key 32 kt + 16 h + e kept): written forward, read backward
+    unsigned* maskbits;  // (B*H, S/32 query tiles, S/32 key tiles, 32 queries) words: the dropout draws, 1 bit per score (bit 16h + e of
+                         // word [bh][qt][kt][q] = key 32 kt + 16 h + e of query 32 qt + q kept): written forward, read backward.  A wave's
+                         // 32 words of one tile are ONE 128-byte line (row-major (B*H, S, S/32) made every tile 32 scattered 4-byte stores:
+                         // 16.8 M partial-line write requests per C5 forward next to the 33.5 M of the scores)
     float* stats;      // (B*H, S, 2): the shift m2 (log2 units; row max of s*c1 minus at most 6) and 1 / sum_k exp2(s*c1 - m2)
     int S, H, ld, nqb, ntile;
     float scale, keep, dscale;
@@ -175,7 +178,9 @@ __global__ __launch_bounds__(A_NT, OCC) void attention_kernel(const AttnArgs p) 
     // backward: the score tile of the NEXT iteration, in the coalesced load layout (lane -> rows 8i + lane/8, 16 B each)
     float4 sn0, sn1, sn2, sn3;
     unsigned mkn = 0;  // and this row's 32 dropout bits of that tile
-    const unsigned* mload = (BWD && MASKED) ? p.maskbits + ((long long)bh * p.S + row) * p.ntile : nullptr;
+    // this wave's mask words: [bh][query tile][kt][q]
+    unsigned* const mwave = MASKED ? p.maskbits + (((long long)bh * (p.S / 32) + (on ? q0 / 32 : 0)) * p.ntile) * 32 + q : nullptr;
+    const unsigned* mload = mwave;
     const float* sload = p.scores + rowbase + (long long)(lane >> 3) * p.S + 4 * (lane & 7);
 #define A_SCORES_LOAD(KT)                                                                        \
     do {                                                                                         \
@@ -183,7 +188,7 @@ __global__ __launch_bounds__(A_NT, OCC) void attention_kernel(const AttnArgs p) 
         sn1 = *reinterpret_cast<const float4*>(sload + (long long)8 * p.S + (KT) * 32);          \
         sn2 = *reinterpret_cast<const float4*>(sload + (long long)16 * p.S + (KT) * 32);         \
         sn3 = *reinterpret_cast<const float4*>(sload + (long long)24 * p.S + (KT) * 32);         \
-        if (MASKED) mkn = mload[KT];                                                             \
+        if (MASKED) mkn = mload[(KT) * 32];                                                      \
     } while (0)
 
 #define A_SCORES_TO_LDS()                                                                        \
@@ -258,7 +263,7 @@ __global__ __launch_bounds__(A_NT, OCC) void attention_kernel(const AttnArgs p) 
                     }
                 }
                 const unsigned other = (unsigned)__shfl_xor((int)bits, 32, 64);
-                if (KEEP && h == 0) p.maskbits[((long long)bh * p.S + row) * p.ntile + kt] = bits | (other << 16);
+                if (KEEP && h == 0) mwave[kt * 32] = bits | (other << 16);
             }
             if (MASKED && BWD) {
 #pragma unroll

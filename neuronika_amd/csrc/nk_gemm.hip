@@ -127,11 +127,11 @@ __global__ __launch_bounds__(NT, (min_waves<TI, TJ, !TA && TB>())) void sgemm_ke
     TileLoader<BKC, BN> lb;
     la.init(A, p.lda, m0, kbeg, p.M, kend, t);
     lb.init(B, p.ldb, n0, kbeg, p.N, kend, t);
-    // Same-box A/B at 4096^3 (benchmarks/ab_gemm.py): NT +2.9 %, NN +1.2 %, TN -1.0 % (its A operand is read k-major,
-    // the loads land early anyway); short reductions lose to the longer prologue (NT 4096x3072x1024: -2 %).  So: row-major
-    // A only, aligned problems only (the guarded loader's state does not fit next to P and Q), at least 48 k-tiles.
+    // Two-k-tile look-ahead: aligned problems only (the guarded loader's state does not fit next to P and Q), every
+    // layout, from the per-layout / per-tile k-tile threshold the host passes in `pf2_min` (rules and their same-box
+    // sweeps: gemm_impl).  This branch handles exactly ONE tile: gemm_impl sets chunk = 1 whenever nt >= pf2_min.
     constexpr bool PF2 = ALIGNED;
-    if (PF2 && nt >= p.pf2_min) {  // (the host launches these one tile per block: chunk == 1)
+    if (PF2 && nt >= p.pf2_min) {
     // Two k-tiles of look-ahead in registers: tile it+1 (P, loaded during the previous trip) goes to LDS at the START of a
     // trip, the loads of tile it+2 (Q) are issued in front of it and have a whole trip plus to land.  The end of a trip is
     // then MFMAs -> barrier, instead of MFMAs -> wait for this trip's own loads -> 8 LDS writes -> barrier.  Unrolled by
@@ -385,17 +385,21 @@ static int gemm_impl(nk_device* dev, int transA, int transB, int M, int N, int K
     p.tiles_m = (M + 64 * ti - 1) / (64 * ti);
     p.tiles_n = (N + 64 * tj - 1) / (64 * tj);
     int force_chunk = 0, force_group = 0, force_pf2 = 0;
-    if (const char* f = getenv("NK_GEMM_FORCE")) {  // tuning sweeps (benchmarks/ab_force.py): "ti,tj,splits[,chunk[,group_m[,lookahead_min]]]" overrides the rules
-        int a = 0, b = 0, c = 0, d = 0, e = 0, pf = 0;
-        const int got = sscanf(f, "%d,%d,%d,%d,%d,%d", &a, &b, &c, &d, &e, &pf);
-        if (got >= 3 && (a == 1 || a == 2) && (b == 1 || b == 2)) {
-            ti = a; tj = b; splits = c < 1 ? 1 : c;
-            p.tiles_m = (M + 64 * ti - 1) / (64 * ti);
-            p.tiles_n = (N + 64 * tj - 1) / (64 * tj);
-            if (got >= 4) force_chunk = d;
-            if (got >= 5) force_group = e;
-            if (got >= 6) force_pf2 = pf;
-        }
+    // tuning sweeps (benchmarks/ab_force.py): NK_GEMM_FORCE="ti,tj,splits[,chunk[,group_m[,lookahead_min]]]" overrides the
+    // rules; parsed once per process
+    struct Force { int n, v[6]; };
+    static const Force force = [] {
+        Force f{0, {0, 0, 0, 0, 0, 0}};
+        if (const char* e = getenv("NK_GEMM_FORCE")) f.n = sscanf(e, "%d,%d,%d,%d,%d,%d", &f.v[0], &f.v[1], &f.v[2], &f.v[3], &f.v[4], &f.v[5]);
+        return f;
+    }();
+    if (force.n >= 3 && (force.v[0] == 1 || force.v[0] == 2) && (force.v[1] == 1 || force.v[1] == 2)) {
+        ti = force.v[0]; tj = force.v[1]; splits = force.v[2] < 1 ? 1 : force.v[2];
+        p.tiles_m = (M + 64 * ti - 1) / (64 * ti);
+        p.tiles_n = (N + 64 * tj - 1) / (64 * tj);
+        if (force.n >= 4) force_chunk = force.v[3];
+        if (force.n >= 5) force_group = force.v[4];
+        if (force.n >= 6) force_pf2 = force.v[5];
     }
     int kts = (ktiles + splits - 1) / splits;
     if (kts < 1) kts = 1;
@@ -413,8 +417,13 @@ static int gemm_impl(nk_device* dev, int transA, int transB, int M, int N, int K
         const long long cap = ntiles * splits * nbatch / (4 * slots);
         if (c > cap) c = cap;
         if (c > ntiles) c = ntiles;
-        if (c < 1 || kts >= 8) c = 1;  // (8 = the smallest look-ahead threshold: the two loops are alternatives)
-        if (force_chunk > 0 && kts < (force_pf2 > 0 ? force_pf2 : pf2_rule_for_chunk)) c = force_chunk;
+        // The chunk loop and the two-k-tile look-ahead loop are ALTERNATIVES inside the kernel (the look-ahead branch
+        // handles exactly one tile): whenever this launch will take the look-ahead (kts >= its threshold, forced or by
+        // rule), the chunk is 1 - also under NK_GEMM_FORCE, whose lookahead_min may lie below the chunk rule's 8.
+        const int pf2_effective = force_pf2 > 0 ? force_pf2 : pf2_rule_for_chunk;
+        if (c < 1 || kts >= 8) c = 1;
+        if (force_chunk > 0) c = force_chunk;
+        if (kts >= pf2_effective) c = 1;
         p.chunk = (int)c;
     }
     p.group_m = force_group > 0 ? force_group : 8;

@@ -250,6 +250,13 @@ def test_bench_parses_what_rccl_chose():
     assert r["choices"][1]["algo"] == "Tree" and r["choices"][1]["proto"] == "LL"
     assert r["env_overrides"] == ["NCCL_MAX_NCHANNELS=32."] or r["env_overrides"] == ["NCCL_MAX_NCHANNELS=32"]
     assert any("coll channels" in ln for ln in r["excerpt"])
+    # RCCL 2.27 wording (gpurun_out of round 3, one rank): "coll channels:128", names instead of numbers in TUNING lines
+    r27 = bench.parse_rccl_log("x NCCL INFO RCCL version : 2.27.7-HEAD:0d2c4fd\n"
+                               "x NCCL INFO comm:0x1, nRanks:8, nNodes:1, coll channels:128 collnet channels:128, nvls channels:0, p2p channels:64\n"
+                               "x NCCL INFO AllReduce: 33554432 Bytes -> Algo RING proto SIMPLE channel{Lo..Hi}={0..31}\n"
+                               "x NCCL INFO Init timings - ncclCommInitRank_impl: rank 0 nranks 8 total 1.68 (kernels 1.60)\n")
+    assert r27["version"].startswith("2.27.7") and r27["channels"] == 128 and r27["comm_init_s"] == 1.68
+    assert r27["choices"] == [{"coll": "AllReduce", "bytes": 33554432, "algo": "RING", "proto": "SIMPLE", "channels_used": 32, "calls": 1}]
     empty = bench.parse_rccl_log("nothing useful")
     assert empty["channels"] is None and empty["choices"] == [] and empty["excerpt"] == []
 

@@ -3,7 +3,8 @@ composed multi-head attention, SURVEY.md 8a note) against the oracle's node-by-n
 `attention_core_forward/backward`, through the C ABI.
 
 Tolerance (SURVEY.md 8c ii): the kernels and the f32 oracle are both measured against the f64 oracle fed the SAME Philox
-mask; pass iff err_gpu <= max(4 * err_cpu32, 2e-6 * max|reference|) per tensor.  The raw scores come out of the same MFMA
+mask; pass iff err_gpu <= max(2 * err_cpu32, 1e-6 * max|reference|) per tensor (SURVEY 8c ii as stated; measured margins:
+gpurun_out/tolerance_margins.json -> DESIGN.md section 5).  The raw scores come out of the same MFMA
 k-order as nk_sgemm_batched and must equal it bit for bit; the dropped-probability tensor must have exactly the mask's
 zero pattern."""
 import numpy as np
@@ -29,7 +30,7 @@ def _check(got, want64, want32, what, floor=0.0):
     err_gpu, err_cpu = np.abs(got - want64).max(), np.abs(want32 - want64).max()
     from conftest import record_margin
     record_margin("attention_core:" + what.split("[")[0].strip(), err_gpu, err_cpu, 1e-6 * scale)
-    assert err_gpu <= max(4 * err_cpu, 2e-6 * scale), (what, err_gpu, err_cpu, scale)
+    assert err_gpu <= max(2 * err_cpu, 1e-6 * scale), (what, err_gpu, err_cpu, scale)   # SURVEY 8c (ii) as stated
 
 
 def _run(dev, B, S, H, p, train, seed, offset, assign, q, k, v, g, dq0):
@@ -72,7 +73,9 @@ def test_attention_core_equals_oracle(dev, B, S, H, p, train):
     _check(got["scores"], ref["scores"], ref32["scores"], "scores")
     assert np.array_equal(got["dropped"] == 0, noise == 0)   # dropped exactly where the mask says (no probability underflows here)
     if masked:   # the packed draws the backward kernel reads: bit j of word t of a row = key 32 t + j kept
-        unpacked = ((got["bits"][..., None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(B * H, S, S)
+        # words are laid out [bh][query tile][key tile][query in tile] (one 128-byte line per wave and tile)
+        w = got["bits"].reshape(B * H, S // 32, S // 32, 32).transpose(0, 1, 3, 2).reshape(B * H, S, S // 32)
+        unpacked = ((w[..., None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(B * H, S, S)
         assert np.array_equal(unpacked, noise != 0)
     for name in ("out", "dropped", "d_scores", "dk", "dv"):
         _check(got[name], ref[name], ref32[name], name)

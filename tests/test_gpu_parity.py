@@ -676,7 +676,7 @@ def test_dropout(dev):
         assert np.array_equal(NZ.numpy(), noise)             # bit-exact keep/drop pattern
         y = np.zeros_like(x); O.dropout_forward(x, y, noise, p, True)
         assert np.array_equal(Y.numpy(), y)
-        assert np.all(Y.numpy() <= x / np.float32(1 - p) * (1 + 1e-6))   # :88-104 (<= 2x at p=.5)
+        assert np.all(Y.numpy() <= x / (np.float32(1) - np.float32(p)) * (1 + 1e-6))   # :88-104 (<= 2x at p=.5)
         g, d0 = rnd(2, (n,)), rnd(3, (n,))
         G, D = dev.array(g), dev.array(d0)
         c.dropout_bwd(dev, D, G, NZ, p, True)

@@ -149,7 +149,7 @@ def test_mlp_C4_shape_small_and_linearity(nk, tdev):
 
 def test_conv2d_module(nk, tdev):
     """nn::Conv2d forward = pad -> convolution -> + bias (defined here; `todo!()` in the reference)."""
-    conv = nk.nn.Conv2d(tdev, 4, 6, [3, 3], [1, 1], [1, 1], [1, 1], 2, 5)
+    conv = nk.nn.GroupedConv2d(tdev, 4, 6, [3, 3], [1, 1], nk.PaddingMode.zero(), [1, 1], [1, 1], 2, 5)
     x = rnd(0, (2, 4, 9, 8))
     X = nk.from_ndarray(tdev, x).requires_grad()
     y = conv.forward(X)
@@ -167,22 +167,25 @@ def test_conv2d_module(nk, tdev):
     close(X.grad(), dxp[:, :, 1:-1, 1:-1], 1e-4, 1e-5)
 
 
+@pytest.mark.parametrize("groups", [2, 1])
 @pytest.mark.parametrize("nd,mode", [(1, "reflective"), (1, "zero"), (3, "replicative"), (3, "constant"), (2, "reflective")])
-def test_conv_nd_modules(nk, tdev, nd, mode):
-    """nn::Conv1d / Conv2d / Conv3d (neuronika-nn/src/lib.rs:630-916) with every PaddingMode: forward and the three
-    gradients vs the oracle composition pad -> convolution -> + bias (backward of pad = centre slice, all modes)."""
+def test_conv_nd_modules(nk, tdev, nd, mode, groups):
+    """nn::Conv1d / Conv2d / Conv3d (neuronika-nn/src/lib.rs:630-916; constructor argument order of the reference's `new`)
+    and nn::GroupedConv1d / 2d / 3d (named in the reference's module index, src/lib.rs:783-797; `groups` after `dilation`)
+    with every PaddingMode: forward and the three gradients vs the oracle composition pad -> convolution(groups) -> + bias
+    (backward of pad = centre slice, all modes)."""
     pm = {"zero": nk.PaddingMode.zero(), "constant": nk.PaddingMode.constant(0.5),
           "reflective": nk.PaddingMode.reflective(), "replicative": nk.PaddingMode.replicative()}[mode]
     spatial = {1: (19,), 2: (9, 8), 3: (5, 6, 7)}[nd]
     kernel, pad, stride, dil = {1: ((3,), (2,), (2,), (1,)), 2: ((3, 2), (1, 2), (1, 2), (2, 1)),
                                 3: ((2, 3, 2), (1, 1, 2), (1, 2, 1), (1, 1, 2))}[nd]
-    cin, cout, groups = 4, 6, 2
-    if nd == 1:
-        conv = nk.nn.Conv1d(tdev, cin, cout, kernel[0], pad[0], pm, stride[0], dil[0], groups, 3)
-    elif nd == 2:
-        conv = nk.nn.Conv2d(tdev, cin, cout, list(kernel), list(pad), list(stride), list(dil), groups, 3, pm)
+    cin, cout = 4, 6
+    k_, p_, s_, d_ = ((kernel[0], pad[0], stride[0], dil[0]) if nd == 1 else (list(kernel), list(pad), list(stride), list(dil)))
+    if groups == 1:
+        conv = getattr(nk.nn, f"Conv{nd}d")(tdev, cin, cout, k_, p_, pm, s_, d_, 3)
     else:
-        conv = nk.nn.Conv3d(tdev, cin, cout, list(kernel), list(pad), pm, list(stride), list(dil), groups, 3)
+        conv = getattr(nk.nn, f"GroupedConv{nd}d")(tdev, cin, cout, k_, p_, pm, s_, d_, groups, seed=3)
+    assert conv.groups == groups and list(conv.padding) == list(pad) and list(conv.stride) == list(stride) and list(conv.dilation) == list(dil)
     w, b = conv.weight.data(), conv.bias.data()
     assert list(w.shape) == [cout, cin // groups] + list(kernel) and list(b.shape) == [cout] + [1] * nd
     bound = np.sqrt(1.0 / (cin // groups * np.prod(kernel)))
@@ -215,7 +218,7 @@ def test_conv_module_fused_equals_two_nodes(nk, tdev):
     x = rnd(1, (3, 4, 10, 9), -1, 1)
     res = {}
     for fused in (True, False):
-        conv = nk.nn.Conv2d(tdev, 4, 6, [3, 3], [1, 1], [1, 1], [1, 1], 2, 5)
+        conv = nk.nn.GroupedConv2d(tdev, 4, 6, [3, 3], [1, 1], nk.PaddingMode.zero(), [1, 1], [1, 1], 2, 5)
         conv.fused = fused
         X = nk.from_ndarray(tdev, x).requires_grad()
         y = conv.forward(X)
@@ -878,8 +881,8 @@ def test_gradient_sync_covers_conv_and_attention_parameters(nk, tdev):
     gradients, the attention module's eight parameters whose weight gradients are split-K GEMMs) are exchanged whole
     when their last writer has run - each element exactly once, also when a module is applied twice."""
     def conv_net():
-        c1 = nk.nn.Conv2d(tdev, 8, 32, [3, 3], [1, 1], [1, 1], [1, 1], 1, 1)
-        c2 = nk.nn.Conv2d(tdev, 32, 32, [3, 3], [1, 1], [1, 1], [1, 1], 1, 3)
+        c1 = nk.nn.Conv2d(tdev, 8, 32, [3, 3], [1, 1], nk.PaddingMode.zero(), [1, 1], [1, 1], 1)
+        c2 = nk.nn.Conv2d(tdev, 32, 32, [3, 3], [1, 1], nk.PaddingMode.zero(), [1, 1], [1, 1], 3)
         X = nk.rand(tdev, [4, 8, 12, 12], 5)
         y = c2.forward(c2.forward(c1.forward(X).relu()).relu())          # c2 applied twice: two writers of its gradients
         return y.sum(), [c1.weight, c1.bias, c2.weight, c2.bias]
