@@ -1,7 +1,8 @@
 """One kernel family per invocation, a few launches with nothing else around them: the target of the rocprofv3 PMC passes
 (tools/pmc_profile.sh).
 
-    python benchmarks/pmc_targets.py proj_fwd | gemm4k_k1024 | gemm4k | scores | context | conv_fwd | conv_bwd_input | conv_bwd_kernel
+    python benchmarks/pmc_targets.py proj_fwd | gemm4k_k1024 | gemm4k | scores | context | attn_fwd | attn_fwd_nodrop | attn_bwd |
+                                     conv_fwd | conv_bwd_input | conv_bwd_kernel
 """
 import os
 import sys
@@ -33,6 +34,19 @@ elif what in ("scores", "context"):
     else:
         P, V, O = rand(dev, (BH, S, S), 2, 0, 1), rand(dev, (BH, S, D), 1), dev.zeros((BH, S, D))
         f = lambda: c.sgemm_batched(dev, 0, 0, S, D, S, 1.0, P, S, S * S, 0, V, D, S * D, 0, 0.0, O, D, S * D, 0, BH, 1)
+elif what in ("attn_fwd", "attn_fwd_nodrop", "attn_bwd"):
+    B, S, H, dh = 32, 1024, 16, 64
+    p = 0.0 if what == "attn_fwd_nodrop" else 0.1
+    Q, Kk, V, G = (rand(dev, (B * S, H * dh), i, -0.5, 0.5) for i in range(4))
+    scores, dS, Pd = dev.zeros((B * H, S, S)), dev.zeros((B * H, S, S)), dev.zeros((B * H, S, S))
+    stats, bits, out = dev.zeros((B * H, S, 2)), dev.zeros((B * H, S, S // 32)), dev.zeros((B * S, H * dh))
+    dQ, dK, dV = dev.zeros((B * S, H * dh)), dev.zeros((B * S, H * dh)), dev.zeros((B * S, H * dh))
+    fwd = lambda: c.attention_fwd(dev, Q, Kk, V, scores, stats, bits, out, B, S, H, dh, 0.125, p, True, 7, 0)
+    if what == "attn_bwd":
+        fwd()
+        f = lambda: c.attention_bwd(dev, dQ, dK, dV, dS, Pd, G, out, scores, stats, bits, Q, Kk, V, B, S, H, dh, 0.125, p, True, (True, True, True))
+    else:
+        f = fwd
 else:
     batch = 128
     x = rand(dev, (batch, 64, 56, 56), 0, 0, 1)

@@ -6,18 +6,43 @@
 // parameters registered with the optimizer (optimizer.rs:70-77).
 #include <rccl/rccl.h>
 
+#include <cstdlib>
+
 #include "nk_common.h"
 
 struct nk_comm {
     nk_device* dev;
     ncclComm_t comm;  // null for a replica communicator (nk_comm_init_replicas)
     int rank, size;
+    // replica communicator only - the overlap PROJECTION of benchmarks/overlap_projection.py: the stand-in "all-reduce"
+    // occupies `channels` workgroups (what RCCL's channels occupy next to the GEMMs) and paces its pass over the buffer to
+    // `gbps` of algorithm bandwidth (what the fabric would give).  0 / 0: an unthrottled streaming pass (coverage tests).
+    int channels = 0;
+    double gbps = 0.0;
 };
 
 // The sum over `size` ranks that all hold the same values: what a replica communicator "exchanges".
 __global__ void __launch_bounds__(256) replica_sum_kernel(float* __restrict__ x, size_t n, float ranks) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) x[i] *= ranks;
+}
+
+// The paced stand-in: `gridDim.x` workgroups (one per emulated RCCL channel), each owning a contiguous slice, walk the
+// buffer in steps of 4 KB per workgroup and do not start step i before  t0 + i * ticks_per_step  of the constant-rate
+// wall clock (100 MHz, s_memrealtime): the launch lasts bytes / gbps and holds `channels` workgroup slots for that long.
+__global__ void __launch_bounds__(256) replica_sum_paced_kernel(float* __restrict__ x, size_t n, float ranks, double ticks_per_step) {
+    const size_t per = (n + gridDim.x - 1) / gridDim.x, lo = per * blockIdx.x, hi = lo + per < n ? lo + per : n;
+    const unsigned long long t0 = wall_clock64();
+    size_t step = 0;
+    for (size_t base = lo; base < hi; base += 1024, ++step) {
+        const unsigned long long due = t0 + (unsigned long long)(ticks_per_step * (double)step);
+        while (wall_clock64() < due) __builtin_amdgcn_s_sleep(8);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const size_t i = base + j * 256 + threadIdx.x;
+            if (i < hi) x[i] *= ranks;
+        }
+    }
 }
 
 static int fail_rccl(ncclResult_t r, const char* what) {
@@ -59,7 +84,11 @@ int nk_comm_init_replicas(nk_device* dev, int nranks, nk_comm** out) {
     NK_USE(dev);
     NK_CHECK(out != nullptr, "null argument");
     NK_CHECK(nranks >= 1, "bad replica count %d", nranks);
-    *out = new nk_comm{dev, nullptr, 0, nranks};
+    nk_comm* c = new nk_comm{dev, nullptr, 0, nranks};
+    if (const char* e = getenv("NK_REPLICA_CHANNELS")) c->channels = atoi(e);
+    if (const char* e = getenv("NK_REPLICA_GBPS")) c->gbps = atof(e);
+    NK_CHECK(c->channels >= 0 && c->channels <= 1024 && c->gbps >= 0.0, "bad NK_REPLICA_CHANNELS / NK_REPLICA_GBPS");
+    *out = c;
     return NK_OK;
 }
 
@@ -98,7 +127,14 @@ int nk_allreduce_sum_group_async(nk_comm* comm, float* const* bufs, const size_t
     if (!comm->comm) {  // replica communicator: every virtual rank holds this rank's values
         for (int i = 0; i < nbufs; ++i) {
             if (counts[i] == 0) continue;
-            replica_sum_kernel<<<nk_stream_grid(counts[i], 256), 256, 0, dev->comm>>>(bufs[i], counts[i], (float)comm->size);
+            if (comm->channels > 0) {
+                // seconds for this buffer at the emulated algorithm bandwidth, spread over the 4 KB steps of one workgroup
+                const size_t per = (counts[i] + comm->channels - 1) / comm->channels, steps = (per + 1023) / 1024;
+                const double ticks = comm->gbps > 0.0 ? (counts[i] * 4.0 / (comm->gbps * 1e9)) * 1e8 / (double)(steps ? steps : 1) : 0.0;
+                replica_sum_paced_kernel<<<comm->channels, 256, 0, dev->comm>>>(bufs[i], counts[i], (float)comm->size, ticks);
+            } else {
+                replica_sum_kernel<<<nk_stream_grid(counts[i], 256), 256, 0, dev->comm>>>(bufs[i], counts[i], (float)comm->size);
+            }
             NK_LAUNCH_CHECK();
         }
         return NK_OK;
