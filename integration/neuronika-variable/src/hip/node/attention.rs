@@ -24,7 +24,7 @@ pub(crate) struct Heads {
 pub(crate) struct AttentionState {
     pub scores: Shared<HipArray<Ix3>>,    // (batch*heads, seq, seq) raw scores
     pub stats: Shared<HipArray<Ix3>>,     // (batch*heads, seq, 2)
-    pub mask_bits: Shared<HipArray<Ix3>>, // (batch*heads, seq, seq/32) u32 words in an f32 buffer
+    pub mask_bits: Shared<HipArray<Ix3>>, // batch*heads*seq*seq/32 u32 words in an f32 buffer (layout: include/neuronika_hip.h, opaque here)
     pub calls: Cell<u64>,                 // forwards so far: each one draws a fresh Philox range
 }
 
@@ -63,7 +63,7 @@ impl Forward for HeadsAttention {
         let mut out = self.data.borrow_mut();
         let h = self.geometry;
         let elems = (h.batch as u64) * (h.heads as u64) * (h.seq as u64) * (h.seq as u64);
-        let offset = self.state.calls.get() * ((elems + 3) / 4);
+        let offset = self.state.calls.get() * ((elems + 7) / 8); // 8 draws per Philox call
         self.state.calls.set(self.state.calls.get() + 1);
         ffi::check(unsafe {
             ffi::nk_attention_fwd(q.device().as_raw(), q.as_ptr(), k.as_ptr(), v.as_ptr(), scores.as_mut_ptr(), stats.as_mut_ptr(),
@@ -92,6 +92,23 @@ pub(crate) struct HeadsAttentionBackward {
     scale: f32,
     p: f64,
     status: Rc<Cell<bool>>,
+}
+
+impl HeadsAttentionBackward {
+    /// Panics if two of the three operand gradients are the same buffer (self-attention built as `x.heads_attention(x, x)`):
+    /// `backward` holds the three `borrow_mut`s at once.  Project first (`q = x.mm_t(wq)` ...) as `nn::MultiheadAttention` does.
+    #[allow(clippy::too_many_arguments)]
+    pub(crate) fn new(geometry: Heads, queries: Shared<HipArray<Ix2>>, keys: Shared<HipArray<Ix2>>, values: Shared<HipArray<Ix2>>,
+                      output: Shared<HipArray<Ix2>>, state: Rc<AttentionState>, d_scores: Shared<HipArray<Ix3>>, dropped: Shared<HipArray<Ix3>>,
+                      queries_gradient: Rc<Gradient<HipArray<Ix2>, Ix2>>, keys_gradient: Rc<Gradient<HipArray<Ix2>, Ix2>>,
+                      values_gradient: Rc<Gradient<HipArray<Ix2>, Ix2>>, gradient: Rc<Gradient<HipArray<Ix2>, Ix2>>, scale: f32, p: f64,
+                      status: Rc<Cell<bool>>) -> Self {
+        assert!(!Rc::ptr_eq(&queries_gradient, &keys_gradient) && !Rc::ptr_eq(&queries_gradient, &values_gradient)
+                    && !Rc::ptr_eq(&keys_gradient, &values_gradient),
+                "heads_attention: queries, keys and values must be three different differentiable variables");
+        Self { geometry, queries, keys, values, output, state, d_scores, dropped, queries_gradient, keys_gradient, values_gradient, gradient,
+               scale, p, status }
+    }
 }
 
 impl Backward for HeadsAttentionBackward {

@@ -71,6 +71,15 @@ where
     gradient: Rc<Gradient<HipArray<Broadcast<D, E>>, Broadcast<D, E>>>,
 }
 
+impl<D, E> BinaryOperationBackwardLeft<D, E>
+where
+    D: Dimension + DimMax<E>,
+    E: Dimension, {
+    pub(crate) fn new(op: BinaryOp, right_data: Shared<HipArray<E>>, left_gradient: Rc<Gradient<HipArray<D>, D>>, gradient: Rc<Gradient<HipArray<Broadcast<D, E>>, Broadcast<D, E>>>) -> Self {
+        Self { op, right_data, left_gradient, gradient }
+    }
+}
+
 impl<D, E> Backward for BinaryOperationBackwardLeft<D, E>
 where
     D: Dimension + DimMax<E>,
@@ -98,6 +107,15 @@ where
     right_data: Shared<HipArray<E>>,
     right_gradient: Rc<Gradient<HipArray<E>, E>>,
     gradient: Rc<Gradient<HipArray<Broadcast<D, E>>, Broadcast<D, E>>>,
+}
+
+impl<D, E> BinaryOperationBackwardRight<D, E>
+where
+    D: Dimension + DimMax<E>,
+    E: Dimension, {
+    pub(crate) fn new(op: BinaryOp, left_data: Shared<HipArray<D>>, right_data: Shared<HipArray<E>>, right_gradient: Rc<Gradient<HipArray<E>, E>>, gradient: Rc<Gradient<HipArray<Broadcast<D, E>>, Broadcast<D, E>>>) -> Self {
+        Self { op, left_data, right_data, right_gradient, gradient }
+    }
 }
 
 impl<D, E> Backward for BinaryOperationBackwardRight<D, E>

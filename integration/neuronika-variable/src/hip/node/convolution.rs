@@ -23,6 +23,14 @@ where
     groups: i32,
 }
 
+impl<D> Convolution<D>
+where
+    D: Dimension, {
+    pub(crate) fn new(input_data: Shared<HipArray<D>>, kernel_data: Shared<HipArray<D>>, data: Shared<HipArray<D>>, stride: Vec<i32>, dilation: Vec<i32>, groups: i32) -> Self {
+        Self { input_data, kernel_data, data, stride, dilation, groups }
+    }
+}
+
 impl<D> Forward for Convolution<D>
 where
     D: Dimension,
@@ -51,6 +59,14 @@ where
     groups: i32,
 }
 
+impl<D> ConvolutionBackwardInput<D>
+where
+    D: Dimension, {
+    pub(crate) fn new(kernel_data: Shared<HipArray<D>>, input_gradient: Rc<Gradient<HipArray<D>, D>>, gradient: Rc<Gradient<HipArray<D>, D>>, stride: Vec<i32>, dilation: Vec<i32>, groups: i32) -> Self {
+        Self { kernel_data, input_gradient, gradient, stride, dilation, groups }
+    }
+}
+
 impl<D> Backward for ConvolutionBackwardInput<D>
 where
     D: Dimension,
@@ -77,6 +93,14 @@ where
     stride: Vec<i32>,
     dilation: Vec<i32>,
     groups: i32,
+}
+
+impl<D> ConvolutionBackwardKernel<D>
+where
+    D: Dimension, {
+    pub(crate) fn new(input_data: Shared<HipArray<D>>, kernel_gradient: Rc<Gradient<HipArray<D>, D>>, gradient: Rc<Gradient<HipArray<D>, D>>, stride: Vec<i32>, dilation: Vec<i32>, groups: i32) -> Self {
+        Self { input_data, kernel_gradient, gradient, stride, dilation, groups }
+    }
 }
 
 impl<D> Backward for ConvolutionBackwardKernel<D>

@@ -38,6 +38,12 @@ pub(crate) struct MatrixMatrixMulBackwardLeft {
     gradient: Rc<Gradient<HipArray<Ix2>, Ix2>>,
 }
 
+impl MatrixMatrixMulBackwardLeft {
+    pub(crate) fn new(right_data: Shared<HipArray<Ix2>>, left_gradient: Rc<Gradient<HipArray<Ix2>, Ix2>>, gradient: Rc<Gradient<HipArray<Ix2>, Ix2>>) -> Self {
+        Self { right_data, left_gradient, gradient }
+    }
+}
+
 impl Backward for MatrixMatrixMulBackwardLeft {
     fn backward(&self) {
         let (g, b) = (self.gradient.borrow(), self.right_data.borrow());
@@ -52,6 +58,12 @@ pub(crate) struct MatrixMatrixMulBackwardRight {
     left_data: Shared<HipArray<Ix2>>,
     right_gradient: Rc<Gradient<HipArray<Ix2>, Ix2>>,
     gradient: Rc<Gradient<HipArray<Ix2>, Ix2>>,
+}
+
+impl MatrixMatrixMulBackwardRight {
+    pub(crate) fn new(left_data: Shared<HipArray<Ix2>>, right_gradient: Rc<Gradient<HipArray<Ix2>, Ix2>>, gradient: Rc<Gradient<HipArray<Ix2>, Ix2>>) -> Self {
+        Self { left_data, right_gradient, gradient }
+    }
 }
 
 impl Backward for MatrixMatrixMulBackwardRight {

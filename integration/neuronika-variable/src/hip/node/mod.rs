@@ -2,20 +2,25 @@
 //! point, the reference method it replaces).  The structs hold the same `Shared` operand / output handles as the
 //! reference's ndarray nodes (`node/*/mod.rs`), so graph construction code is unchanged.  Written here: the nodes of
 //! the BASELINE configurations (MatMul / MatMulT, Convolution, broadcast binaries, ReLU, Softmax, Dropout, Sum,
-//! SquaredError, and the fused attention core of the composed MHA); the remaining ones follow the same two-line pattern.
+//! SquaredError, the fused attention core of the composed MHA) and their glue (LogSoftmax, Mean, Pad in all four modes, Chunk,
+//! MultiConcatenate, Transpose, the SGD / Adam steps).  Every node is constructed by a `HipVar` / `HipVarDiff` method (`hipvar.rs`).
 mod attention;
 mod binary_op;
 mod convolution;
+mod layout;
 mod matrix_matrix_mul;
 mod matrix_matrix_mul_t;
+mod optim;
 mod pointwise;
 mod reduction;
 
 pub(crate) use attention::*;
 pub(crate) use binary_op::*;
 pub(crate) use convolution::*;
+pub(crate) use layout::*;
 pub(crate) use matrix_matrix_mul::*;
 pub(crate) use matrix_matrix_mul_t::*;
+pub(crate) use optim::*;
 pub(crate) use pointwise::*;
 pub(crate) use reduction::*;
 

@@ -16,6 +16,12 @@ pub(crate) struct Sum<D: Dimension> {
     data: Shared<HipArray<Ix0>>,
 }
 
+impl<D: Dimension> Sum<D> {
+    pub(crate) fn new(operand_data: Shared<HipArray<D>>, data: Shared<HipArray<Ix0>>) -> Self {
+        Self { operand_data, data }
+    }
+}
+
 impl<D: Dimension> Forward for Sum<D> {
     fn forward(&self) {
         let x = self.operand_data.borrow();
@@ -28,6 +34,12 @@ impl<D: Dimension> Forward for Sum<D> {
 pub(crate) struct SumBackward<D: Dimension> {
     operand_gradient: Rc<Gradient<HipArray<D>, D>>,
     gradient: Rc<Gradient<HipArray<Ix0>, Ix0>>,
+}
+
+impl<D: Dimension> SumBackward<D> {
+    pub(crate) fn new(operand_gradient: Rc<Gradient<HipArray<D>, D>>, gradient: Rc<Gradient<HipArray<Ix0>, Ix0>>) -> Self {
+        Self { operand_gradient, gradient }
+    }
 }
 
 impl<D: Dimension> Backward for SumBackward<D> {
@@ -45,6 +57,12 @@ pub(crate) struct SquaredError<D: Dimension> {
     target_data: Shared<HipArray<D>>,
     data: Shared<HipArray<Ix0>>,
     reduction: Reduction,
+}
+
+impl<D: Dimension> SquaredError<D> {
+    pub(crate) fn new(input_data: Shared<HipArray<D>>, target_data: Shared<HipArray<D>>, data: Shared<HipArray<Ix0>>, reduction: Reduction) -> Self {
+        Self { input_data, target_data, data, reduction }
+    }
 }
 
 impl<D: Dimension> Forward for SquaredError<D> {
@@ -65,11 +83,58 @@ pub(crate) struct SquaredErrorBackward<D: Dimension> {
     reduction: Reduction,
 }
 
+impl<D: Dimension> SquaredErrorBackward<D> {
+    pub(crate) fn new(input_data: Shared<HipArray<D>>, target_data: Shared<HipArray<D>>, input_gradient: Rc<Gradient<HipArray<D>, D>>, gradient: Rc<Gradient<HipArray<Ix0>, Ix0>>, reduction: Reduction) -> Self {
+        Self { input_data, target_data, input_gradient, gradient, reduction }
+    }
+}
+
 impl<D: Dimension> Backward for SquaredErrorBackward<D> {
     fn backward(&self) {
         let (g, x, t) = (self.gradient.borrow(), self.input_data.borrow(), self.target_data.borrow());
         let mut dx = self.input_gradient.borrow_mut();
         let red = matches!(self.reduction, Reduction::Mean) as i32;
         ffi::check(unsafe { ffi::nk_mse_bwd(g.device().as_raw(), dx.as_mut_ptr(), g.as_ptr(), x.as_ptr(), t.as_ptr(), x.len(), red) });
+    }
+}
+
+/// `Mean::forward` (`node/mean/mod.rs:28-35`): `sum / len`.
+pub(crate) struct Mean<D: Dimension> {
+    operand_data: Shared<HipArray<D>>,
+    data: Shared<HipArray<Ix0>>,
+}
+
+impl<D: Dimension> Mean<D> {
+    pub(crate) fn new(operand_data: Shared<HipArray<D>>, data: Shared<HipArray<Ix0>>) -> Self {
+        Self { operand_data, data }
+    }
+}
+
+impl<D: Dimension> Forward for Mean<D> {
+    fn forward(&self) {
+        let x = self.operand_data.borrow();
+        let mut out = self.data.borrow_mut();
+        ffi::check(unsafe { ffi::nk_mean_fwd(x.device().as_raw(), x.as_ptr(), x.len(), out.as_mut_ptr()) });
+    }
+}
+
+/// `MeanBackward::backward` (`:60-72`): `dx += g / len`.
+pub(crate) struct MeanBackward<D: Dimension> {
+    operand_gradient: Rc<Gradient<HipArray<D>, D>>,
+    gradient: Rc<Gradient<HipArray<Ix0>, Ix0>>,
+}
+
+impl<D: Dimension> MeanBackward<D> {
+    pub(crate) fn new(operand_gradient: Rc<Gradient<HipArray<D>, D>>, gradient: Rc<Gradient<HipArray<Ix0>, Ix0>>) -> Self {
+        Self { operand_gradient, gradient }
+    }
+}
+
+impl<D: Dimension> Backward for MeanBackward<D> {
+    fn backward(&self) {
+        let g = self.gradient.borrow();
+        let mut dx = self.operand_gradient.borrow_mut();
+        let n = dx.len();
+        ffi::check(unsafe { ffi::nk_mean_bwd(g.device().as_raw(), dx.as_mut_ptr(), n, g.as_ptr()) });
     }
 }

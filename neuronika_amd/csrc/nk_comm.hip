@@ -28,21 +28,32 @@ __global__ void __launch_bounds__(256) replica_sum_kernel(float* __restrict__ x,
 }
 
 // The paced stand-in: `gridDim.x` workgroups (one per emulated RCCL channel), each owning a contiguous slice, walk the
-// buffer in steps of 4 KB per workgroup and do not start step i before  t0 + i * ticks_per_step  of the constant-rate
-// wall clock (100 MHz, s_memrealtime): the launch lasts bytes / gbps and holds `channels` workgroup slots for that long.
+// buffer in steps of 16 KB per workgroup (4 x 16 B per lane in flight: one workgroup sustains tens of GB/s, as a RCCL channel
+// does) and do not start step i before  t0 + i * ticks_per_step  of the constant-rate wall clock (100 MHz, s_memrealtime): the
+// launch lasts bytes / gbps - unless `channels` workgroups cannot move that much, which is then what the projection shows -
+// and holds `channels` workgroup slots for that long.
 __global__ void __launch_bounds__(256) replica_sum_paced_kernel(float* __restrict__ x, size_t n, float ranks, double ticks_per_step) {
-    const size_t per = (n + gridDim.x - 1) / gridDim.x, lo = per * blockIdx.x, hi = lo + per < n ? lo + per : n;
+    const size_t n4 = n / 4;                                   // whole float4s (the tail is handled by block 0 below)
+    const size_t per = (n4 + gridDim.x - 1) / gridDim.x, lo = per * blockIdx.x, hi = lo + per < n4 ? lo + per : n4;
+    float4* x4 = reinterpret_cast<float4*>(x);
     const unsigned long long t0 = wall_clock64();
     size_t step = 0;
     for (size_t base = lo; base < hi; base += 1024, ++step) {
         const unsigned long long due = t0 + (unsigned long long)(ticks_per_step * (double)step);
-        while (wall_clock64() < due) __builtin_amdgcn_s_sleep(8);
+        while (wall_clock64() < due) __builtin_amdgcn_s_sleep(4);
+        float4 v[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const size_t i = base + j * 256 + threadIdx.x;
-            if (i < hi) x[i] *= ranks;
+            if (i < hi) v[j] = x4[i];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const size_t i = base + j * 256 + threadIdx.x;
+            if (i < hi) x4[i] = make_float4(v[j].x * ranks, v[j].y * ranks, v[j].z * ranks, v[j].w * ranks);
         }
     }
+    if (blockIdx.x == 0 && threadIdx.x < n - n4 * 4) x[n4 * 4 + threadIdx.x] *= ranks;
 }
 
 static int fail_rccl(ncclResult_t r, const char* what) {
@@ -129,7 +140,7 @@ int nk_allreduce_sum_group_async(nk_comm* comm, float* const* bufs, const size_t
             if (counts[i] == 0) continue;
             if (comm->channels > 0) {
                 // seconds for this buffer at the emulated algorithm bandwidth, spread over the 4 KB steps of one workgroup
-                const size_t per = (counts[i] + comm->channels - 1) / comm->channels, steps = (per + 1023) / 1024;
+                const size_t per = (counts[i] / 4 + comm->channels - 1) / comm->channels, steps = (per + 1023) / 1024;  // float4s, 16 KB steps
                 const double ticks = comm->gbps > 0.0 ? (counts[i] * 4.0 / (comm->gbps * 1e9)) * 1e8 / (double)(steps ? steps : 1) : 0.0;
                 replica_sum_paced_kernel<<<comm->channels, 256, 0, dev->comm>>>(bufs[i], counts[i], (float)comm->size, ticks);
             } else {

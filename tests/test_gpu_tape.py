@@ -244,15 +244,13 @@ def test_conv_module_padded_backward_matches_two_nodes(nk, tdev, nd, cin, cout, 
     accumulates into a gradient that another node wrote first; values equal the pad -> conv -> add graph's."""
     spatial = {1: (23,), 2: (9, 13), 3: (5, 6, 7)}[nd]
     x = rnd(7, (2, cin) + spatial, -1, 1)
-    ctor = {1: nk.nn.Conv1d, 2: nk.nn.Conv2d, 3: nk.nn.Conv3d}[nd]
     res = {}
     for fused in (True, False):
-        if nd == 1:
-            conv = ctor(tdev, cin, cout, k[0], pad[0], nk.PaddingMode.zero(), stride[0], dil[0], groups, 9)
-        elif nd == 2:
-            conv = ctor(tdev, cin, cout, k, pad, stride, dil, groups, 9)
+        k_, p_, s_, d_ = (k[0], pad[0], stride[0], dil[0]) if nd == 1 else (k, pad, stride, dil)
+        if groups == 1:
+            conv = getattr(nk.nn, f"Conv{nd}d")(tdev, cin, cout, k_, p_, nk.PaddingMode.zero(), s_, d_, 9)
         else:
-            conv = ctor(tdev, cin, cout, k, pad, nk.PaddingMode.zero(), stride, dil, groups, 9)
+            conv = getattr(nk.nn, f"GroupedConv{nd}d")(tdev, cin, cout, k_, p_, nk.PaddingMode.zero(), s_, d_, groups, 9)
         conv.fused = fused
         X = nk.from_ndarray(tdev, x).requires_grad()
         y = conv.forward(X)
@@ -873,6 +871,20 @@ def test_gradient_sync_covers_every_element_once(nk, tdev, ranks):
         loss = l2.forward(l1.forward(nk.rand(tdev, [37, 300], 3)).relu()).sum()
         return loss, [l1.weight, l1.bias, l2.weight, l2.bias]
     _replica_check(nk, tdev, ranks, ragged)
+
+
+@pytest.mark.gpu
+def test_paced_replica_exchange_covers_every_element_once(nk, tdev, monkeypatch):
+    """The overlap projection's stand-in (NK_REPLICA_CHANNELS workgroups pacing their pass to NK_REPLICA_GBPS,
+    benchmarks/overlap_projection.py) is the same coverage-checked exchange: odd sizes, tails that are not whole float4s."""
+    monkeypatch.setenv("NK_REPLICA_CHANNELS", "3")
+    monkeypatch.setenv("NK_REPLICA_GBPS", "50")
+
+    def ragged():
+        l1, l2 = nk.nn.Linear(tdev, 301, 703, 1), nk.nn.Linear(tdev, 703, 129, 2)
+        loss = l2.forward(l1.forward(nk.rand(tdev, [37, 301], 3)).relu()).sum()
+        return loss, [l1.weight, l1.bias, l2.weight, l2.bias]
+    _replica_check(nk, tdev, 4, ragged)
 
 
 @pytest.mark.gpu

@@ -15,6 +15,7 @@ G[c]="TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum"
 G[d]="TCP_PENDING_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum"
 G[e]="SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INST_CYCLES_VMEM_RD SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_WAVES"
 groups=${PMC_GROUPS:-"a b c d"}
+mkdir -p "$root/$out"
 for tgt in "$@"; do
   for g in $groups; do
     timeout -k 5 90 rocprofv3 --pmc ${G[$g]} --kernel-trace -d "$root/$out/$tgt/$g" -o r -- python "$root/benchmarks/pmc_targets.py" $tgt 3 > "$root/$out/${tgt}_$g.log" 2>&1 || echo "FAILED $tgt $g" 
