@@ -45,9 +45,15 @@ struct Bucket {
     event: *mut ffi::nk_event,
 }
 
-/// Overlapped exchange of the registered parameter gradients.  `VarDiff::backward` calls `grad_ready(i)` right after
-/// issuing the LAST tape node that accumulates into parameter `i` (reverse layer order); small gradients are sent as one
-/// RCCL group.  `join()` makes the compute stream wait for the side stream - no host synchronisation.
+/// Exchange of the registered parameter gradients.  Two ways to drive it:
+/// * `all_reduce()` after `HipVarDiff::backward` has ISSUED the tape: every gradient is final in stream order, the side
+///   stream waits for an event recorded behind the last backward kernel, small gradients travel as one RCCL group;
+/// * `grad_ready(i)` right after issuing the LAST tape node that accumulates into parameter `i` (reverse layer order) -
+///   the overlapped form.  Deciding "last writer" needs each backward node to name the gradients it writes: the
+///   `targets()` extension of `Backward` that this repository's C++ tape carries (`host/neuronika.cpp`: `run_backward`,
+///   `BackwardHook`); the reference's trait (`autograd.rs:17-25`) has no such method, so `HipVarDiff::backward` as written
+///   does not call it.
+/// `join()` makes the compute stream wait for the side stream - no host synchronisation.
 pub struct GradientSync {
     comm: Rc<Communicator>,
     buckets: Vec<Bucket>,
@@ -83,6 +89,13 @@ impl GradientSync {
         let b = &self.buckets[i];
         ffi::check(unsafe { ffi::nk_event_record(b.event, 0) }); // everything up to the node that finalised this gradient
         ffi::check(unsafe { ffi::nk_allreduce_sum_async(self.comm.raw, b.ptr, b.len, b.event) });
+    }
+
+    /// Non-overlapped form: every registered gradient, in registration order, after backward has been issued.
+    pub fn all_reduce(&mut self) {
+        for i in 0..self.buckets.len() {
+            self.grad_ready(i);
+        }
     }
 
     fn flush_small(&mut self) {

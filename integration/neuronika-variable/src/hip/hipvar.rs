@@ -1,21 +1,60 @@
+//! `HipVar` / `HipVarDiff`: the device twins of `Var` / `VarDiff` (`var.rs:34-40`, `vardiff.rs:35-42`), shaped like the
+//! reference's own accelerator template (`CuVar`, `cuda/cuvar.rs:19-100`).  Every method below builds the same tape entry as
+//! its reference counterpart - same operand handles, same `History` merge, outputs and gradients allocated zeroed at
+//! graph-build time - with a node whose body is one call of the C ABI (`node/*.rs`).  Shape rules stay on the host
+//! (`cobroadcast`, `conv_out_shape`, `check_conv_args`: `utils.rs:46-55,97-125,207-237,427-497`).
 use std::{
     cell::{Cell, RefCell},
     rc::Rc,
 };
 
-use ndarray::{DimMax, Dimension, Ix2};
+use ndarray::{DimMax, Dimension, IntoDimension, Ix0, Ix2, Ix3, RemoveAxis};
 
 use super::{
+    device::Device,
     hiparray::HipArray,
-    node::{BinaryOp, BinaryOperation, BinaryOperationBackwardLeft, BinaryOperationBackwardRight, MatrixMatrixMulT,
-           MatrixMatrixMulTBackwardLeft, MatrixMatrixMulTBackwardRight},
+    node::{
+        AttentionState, BinaryOp, BinaryOperation, BinaryOperationBackwardLeft, BinaryOperationBackwardRight, Chunk, ChunkBackward,
+        Convolution, ConvolutionBackwardInput, ConvolutionBackwardKernel, Dropout, DropoutBackward, Heads, HeadsAttention,
+        HeadsAttentionBackward, LogSoftmax, LogSoftmaxBackward, MatrixMatrixMul, MatrixMatrixMulBackwardLeft,
+        MatrixMatrixMulBackwardRight, MatrixMatrixMulT, MatrixMatrixMulTBackwardLeft, MatrixMatrixMulTBackwardRight, Mean, MeanBackward,
+        MultiConcatenate, MultiConcatenateBackward, Pad, PadBackward, PadMode, Pair, ReLU, ReLUBackward, Softmax, SoftmaxBackward,
+        SquaredError, SquaredErrorBackward, Sum, SumBackward, Transpose, TransposeBackward,
+    },
 };
 use crate::{
     autograd::{Backward, Forward},
     gradient::{Gradient, NoGrad},
     history::History,
-    utils::{cobroadcast, Broadcast, Shared},
+    utils::{check_conv_args, check_groups_args, cobroadcast, conv_out_shape, Broadcast, Shared},
+    Reduction,
 };
+
+type Fwd = History<(Rc<dyn Forward>, Cell<bool>)>;
+type Bwd = History<(Rc<dyn Backward>, Rc<dyn NoGrad>)>;
+
+fn shared<D: Dimension>(dim: D, device: &Device) -> Shared<HipArray<D>> {
+    Rc::new(RefCell::new(HipArray::zeroed(dim, device.clone())))
+}
+
+/// Seed of the next random node (dropout): the Philox key.  `thread_rng` in the reference (`node/dropout/mod.rs:70`) is
+/// non-reproducible by design; a counter-based generator keyed per node keeps masks reproducible and per-rank distinct.
+thread_local! {
+    static NEXT_SEED: Cell<u64> = Cell::new(0x9E37_79B9_7F4A_7C15);
+}
+
+/// Fixes the key of the next random node created on this thread (each node advances it).
+pub fn manual_seed(seed: u64) {
+    NEXT_SEED.with(|s| s.set(seed));
+}
+
+fn next_seed() -> u64 {
+    NEXT_SEED.with(|s| {
+        let v = s.get();
+        s.set(v.wrapping_add(0x9E37_79B9_7F4A_7C15));
+        v
+    })
+}
 
 /// A non-differentiable variable with data in HBM.  Same fields and tape as `Var<D>` (`var.rs:34-40`) /
 /// `CuVar<D>` (`cuda/cuvar.rs:19-46`): only the array type differs.
@@ -24,20 +63,41 @@ where
     D: Dimension,
 {
     pub(crate) data: Shared<HipArray<D>>,
-    pub(crate) history: History<(Rc<dyn Forward>, Cell<bool>)>,
+    pub(crate) history: Fwd,
+}
+
+impl<D: Dimension> Clone for HipVar<D> {
+    fn clone(&self) -> Self {
+        Self { data: self.data.clone(), history: self.history.clone() }
+    }
 }
 
 impl<D> HipVar<D>
 where
-    D: Dimension,
+    D: 'static + Dimension,
 {
     pub(crate) fn leaf(array: HipArray<D>) -> Self {
         Self { data: Rc::new(RefCell::new(array)), history: History::default() }
     }
 
-    pub(crate) fn node(data: Shared<HipArray<D>>, op: Rc<dyn Forward>, mut history: History<(Rc<dyn Forward>, Cell<bool>)>) -> Self {
+    /// Uploads a host array (`CuVar::from_ndarray`-style entry; `neuronika::from_ndarray`, `lib.rs`).
+    pub fn from_ndarray(array: &ndarray::Array<f32, D>, device: Device) -> Self {
+        Self::leaf(HipArray::from_ndarray(array, device))
+    }
+
+    pub(crate) fn node(data: Shared<HipArray<D>>, op: Rc<dyn Forward>, mut history: Fwd) -> Self {
         history.insert(Rc::as_ptr(&op) as *const () as usize, (op, Cell::default()));
         Self { data, history }
+    }
+
+    fn device(&self) -> Device {
+        self.data.borrow().device().clone()
+    }
+
+    /// Promotes to a differentiable leaf (`Var::requires_grad`, `var.rs:138-148`).
+    pub fn requires_grad(self) -> HipVarDiff<D> {
+        let (dim, device) = (self.data.borrow().dimension(), self.device());
+        HipVarDiff { var: self, grad: Rc::new(Gradient::hip_zeros(dim, device)), history: History::default() }
     }
 
     /// `Var::forward` (`var.rs:110-128`), verbatim logic: the ops are enqueued on the device's compute stream in
@@ -55,18 +115,172 @@ where
         });
     }
 
+    /// Host copy of the data (synchronises), `Var::data` (`var.rs:131-136`).
+    pub fn data(&self) -> ndarray::Array<f32, D> {
+        self.data.borrow().as_ndarray()
+    }
+
     /// Broadcast binary (`Addition` ... `Division`): shape rule `cobroadcast` (`utils.rs:97-125`) stays on the host.
     pub(crate) fn binary<E>(mut self, op: BinaryOp, rhs: HipVar<E>) -> HipVar<Broadcast<D, E>>
     where
-        D: 'static + DimMax<E>,
+        D: DimMax<E>,
         E: 'static + Dimension,
     {
         self.history.merge(rhs.history);
         let dim = cobroadcast(self.data.borrow().dimension(), rhs.data.borrow().dimension());
-        let device = self.data.borrow().device().clone();
-        let data = Rc::new(RefCell::new(HipArray::zeroed(dim, device)));
+        let data = shared(dim, &self.device());
         let node = Rc::new(BinaryOperation::new(op, self.data, rhs.data, data.clone()));
         HipVar::node(data, node, self.history)
+    }
+
+    /// `Var::sum` (`var.rs:201-207`).
+    pub fn sum(self) -> HipVar<Ix0> {
+        let data = shared(ndarray::Dim(()), &self.device());
+        let op = Sum::new(self.data, data.clone());
+        HipVar::node(data, Rc::new(op), self.history)
+    }
+
+    /// `Var::mean` (`var.rs:209-214`).
+    pub fn mean(self) -> HipVar<Ix0> {
+        let data = shared(ndarray::Dim(()), &self.device());
+        let op = Mean::new(self.data, data.clone());
+        HipVar::node(data, Rc::new(op), self.history)
+    }
+
+    /// `Var::relu` (`var.rs:243-249`).
+    pub fn relu(self) -> HipVar<D> {
+        let data = shared(self.data.borrow().dimension(), &self.device());
+        let op = ReLU::new(self.data, data.clone());
+        HipVar::node(data, Rc::new(op), self.history)
+    }
+
+    /// `Var::softmax` (`var.rs:318-330`).
+    pub fn softmax(self, axis: usize) -> HipVar<D> {
+        let data = shared(self.data.borrow().dimension(), &self.device());
+        let op = Softmax::new(self.data, data.clone(), axis);
+        HipVar::node(data, Rc::new(op), self.history)
+    }
+
+    /// `Var::log_softmax` (`var.rs:332-344`).
+    pub fn log_softmax(self, axis: usize) -> HipVar<D> {
+        let data = shared(self.data.borrow().dimension(), &self.device());
+        let op = LogSoftmax::new(self.data, data.clone(), axis);
+        HipVar::node(data, Rc::new(op), self.history)
+    }
+
+    /// `Var::t` (`var.rs:346-352`): dimensions reversed.
+    pub fn t(self) -> HipVar<D> {
+        let mut dim = self.data.borrow().dimension();
+        dim.slice_mut().reverse();
+        let data = shared(dim, &self.device());
+        let op = Transpose::new(self.data, data.clone());
+        HipVar::node(data, Rc::new(op), self.history)
+    }
+
+    /// `Var::dropout` (`var.rs:375-393`): the noise buffer is shared with the backward node when there is one.
+    pub fn dropout(self, p: f64, status: Rc<Cell<bool>>) -> HipVar<D> {
+        let noise = shared(self.data.borrow().dimension(), &self.device());
+        self.dropout_with_noise(p, noise, status)
+    }
+
+    pub(crate) fn dropout_with_noise(self, p: f64, noise: Shared<HipArray<D>>, status: Rc<Cell<bool>>) -> HipVar<D> {
+        let data = shared(self.data.borrow().dimension(), &self.device());
+        let op = Dropout::new(self.data, data.clone(), p, noise, status, next_seed());
+        HipVar::node(data, Rc::new(op), self.history)
+    }
+
+    /// `Var::chunks` (`var.rs:401-417`): `exact_chunks(chunk_size)` in row-major chunk order, remainders skipped.
+    pub fn chunks<E>(self, chunk_size: E) -> Vec<HipVar<D>>
+    where
+        E: IntoDimension<Dim = D>,
+    {
+        let chunk = chunk_size.into_dimension();
+        let count: usize = self.data.borrow().dimension().slice().iter().zip(chunk.slice()).map(|(n, c)| n / c).product();
+        (0..count)
+            .map(|i| {
+                let data = shared(chunk.clone(), &self.device());
+                let op = Chunk::new(self.data.clone(), data.clone(), i);
+                HipVar::node(data, Rc::new(op), self.history.clone())
+            })
+            .collect()
+    }
+
+    /// `Var::cat` (`var.rs:564-584`): `self` followed by `variables` along `axis`.
+    pub fn cat(mut self, variables: &[Self], axis: usize) -> HipVar<D> {
+        let mut dim = self.data.borrow().dimension();
+        let mut operands_data = vec![self.data.clone()];
+        variables.iter().cloned().for_each(|variable| {
+            dim.slice_mut()[axis] += variable.data.borrow().dimension().slice()[axis];
+            self.history.merge(variable.history);
+            operands_data.push(variable.data);
+        });
+        let data = shared(dim, &self.device());
+        let op = MultiConcatenate::new(operands_data, data.clone(), axis);
+        HipVar::node(data, Rc::new(op), self.history)
+    }
+
+    /// `Var::mse` (`var.rs:454-459`).
+    pub fn mse(mut self, target: HipVar<D>, reduction: Reduction) -> HipVar<Ix0> {
+        self.history.merge(target.history);
+        let data = shared(ndarray::Dim(()), &self.device());
+        let op = SquaredError::new(self.data, target.data, data.clone(), reduction);
+        HipVar::node(data, Rc::new(op), self.history)
+    }
+
+    /// `Var::pad` (`var.rs:726-744`) for the four modes of `node/pad/`: `padding[i]` on both sides of spatial axis `i`.
+    pub(crate) fn pad_with(self, padding: &[usize], mode: PadMode) -> HipVar<D> {
+        let mut dim = self.data.borrow().dimension();
+        dim.slice_mut().iter_mut().skip(2).zip(padding).for_each(|(n, p)| *n += 2 * p);
+        let data = shared(dim, &self.device());
+        let op = Pad::new(self.data, data.clone(), mode, padding.iter().map(|&p| p as i32).collect());
+        HipVar::node(data, Rc::new(op), self.history)
+    }
+
+    /// Zero padding (`PaddingMode` `Zero`, `node/pad/zero/mod.rs`).
+    pub fn pad_zero(self, padding: &[usize]) -> HipVar<D> {
+        self.pad_with(padding, PadMode::Constant(0.))
+    }
+}
+
+impl<D> HipVar<D>
+where
+    D: 'static + Dimension + RemoveAxis,
+{
+    /// `Convolution::convolution` for `Var` kernels (`var.rs:1296-1371`): `self` is the KERNEL, as in the reference; checks
+    /// and the output shape come from the host-side helpers unchanged.
+    pub fn convolution(mut self, input: HipVar<D>, stride: &[usize], dilation: &[usize], groups: usize) -> HipVar<D> {
+        self.history.merge(input.history);
+        let shape: D = {
+            let (x, w) = (input.data.borrow(), self.data.borrow());
+            let (xs, ws): (Vec<usize>, Vec<usize>) = (x.dimension().slice().to_vec(), w.dimension().slice().to_vec());
+            check_conv_args(&xs, &ws, stride, dilation);
+            check_groups_args(&xs, &ws, groups);
+            conv_out_shape(&xs, &ws, stride, dilation)
+        };
+        let data = shared(shape, &self.device());
+        let to_i32 = |v: &[usize]| v.iter().map(|&s| s as i32).collect::<Vec<_>>();
+        let op = Convolution::new(input.data, self.data, data.clone(), to_i32(stride), to_i32(dilation), groups as i32);
+        HipVar::node(data, Rc::new(op), self.history)
+    }
+}
+
+impl HipVar<Ix2> {
+    /// `Var::mm` (`var.rs:1034-1061`).
+    pub fn mm(mut self, rhs: HipVar<Ix2>) -> HipVar<Ix2> {
+        self.history.merge(rhs.history);
+        let (n, o) = (self.data.borrow().dimension()[0], rhs.data.borrow().dimension()[1]);
+        let data = shared(ndarray::Dim([n, o]), &self.device());
+        let op = MatrixMatrixMul::new(self.data, rhs.data, data.clone());
+        HipVar::node(data, Rc::new(op), self.history)
+    }
+
+    /// `Var::mm_t` (`var.rs:1065-1094`).
+    pub fn mm_t(mut self, rhs: HipVar<Ix2>) -> HipVar<Ix2> {
+        self.history.merge(rhs.history);
+        let (n, o) = (self.data.borrow().dimension()[0], rhs.data.borrow().dimension()[0]);
+        let data = shared(ndarray::Dim([n, o]), &self.device());
+        let op = MatrixMatrixMulT::new(self.data, rhs.data, data.clone());
+        HipVar::node(data, Rc::new(op), self.history)
     }
 }
 
@@ -77,17 +291,26 @@ where
 {
     pub(crate) var: HipVar<D>,
     pub(crate) grad: Rc<Gradient<HipArray<D>, D>>,
-    pub(crate) history: History<(Rc<dyn Backward>, Rc<dyn NoGrad>)>,
+    pub(crate) history: Bwd,
+}
+
+impl<D: Dimension> Clone for HipVarDiff<D> {
+    fn clone(&self) -> Self {
+        Self { var: self.var.clone(), grad: self.grad.clone(), history: self.history.clone() }
+    }
 }
 
 impl<D> HipVarDiff<D>
 where
     D: 'static + Dimension,
 {
-    pub(crate) fn node(var: HipVar<D>, grad: Rc<Gradient<HipArray<D>, D>>, op: (Rc<dyn Backward>, Rc<dyn NoGrad>),
-                       mut history: History<(Rc<dyn Backward>, Rc<dyn NoGrad>)>) -> Self {
+    pub(crate) fn node(var: HipVar<D>, grad: Rc<Gradient<HipArray<D>, D>>, op: (Rc<dyn Backward>, Rc<dyn NoGrad>), mut history: Bwd) -> Self {
         history.insert(Rc::as_ptr(&op.0) as *const () as usize, op);
         Self { var, grad, history }
+    }
+
+    fn new_grad<E: Dimension>(&self, dim: E) -> Rc<Gradient<HipArray<E>, E>> {
+        Rc::new(Gradient::hip_zeros(dim, self.var.device()))
     }
 
     pub fn forward(&self) {
@@ -95,8 +318,10 @@ where
     }
 
     /// `VarDiff::backward` (`vardiff.rs:125-141`): seed the root gradient, run the tape in reverse.  Launches are
-    /// asynchronous; the data-parallel hook (`dp::GradientSync`) is handed each leaf gradient as soon as the last node
-    /// writing it has been issued.
+    /// asynchronous.  For the data-parallel step call `dp::GradientSync::all_reduce` after this (every registered gradient
+    /// is final once the tape has been ISSUED; the side stream orders itself after the compute stream) and `join()` before
+    /// the optimizer; handing each gradient over as soon as its last writer has been issued needs the `targets()` extension
+    /// of the `Backward` trait that this repository's C++ tape carries (`host/neuronika.cpp: run_backward`).
     pub fn backward(&self, seed: f32) {
         debug_assert_eq!(self.var.history.len(), self.var.history.buffer_len(), "Perhaps you forgot to call .forward()?");
         self.grad.borrow_mut().fill(seed);
@@ -106,34 +331,252 @@ where
         }
         buffer.iter().rev().for_each(|(op, _)| op.backward());
     }
+
+    /// `VarDiff::zero_grad` (`vardiff.rs:100-102`).
+    pub fn zero_grad(&self) {
+        self.grad.borrow_mut().fill(0.);
+    }
+
+    /// Host copy of the gradient (synchronises), `VarDiff::grad` (`vardiff.rs:144-150`).
+    pub fn grad(&self) -> ndarray::Array<f32, D> {
+        self.grad.borrow().as_ndarray()
+    }
+
+    /// `VarDiff::sum` (`vardiff.rs:238-245`).
+    pub fn sum(self) -> HipVarDiff<Ix0> {
+        let grad = self.new_grad(ndarray::Dim(()));
+        let op = SumBackward::new(self.grad.clone(), grad.clone());
+        let var = self.var.sum();
+        HipVarDiff::node(var, grad.clone(), (Rc::new(op), grad), self.history)
+    }
+
+    /// `VarDiff::mean` (`vardiff.rs:247-253`).
+    pub fn mean(self) -> HipVarDiff<Ix0> {
+        let grad = self.new_grad(ndarray::Dim(()));
+        let op = MeanBackward::new(self.grad.clone(), grad.clone());
+        let var = self.var.mean();
+        HipVarDiff::node(var, grad.clone(), (Rc::new(op), grad), self.history)
+    }
+
+    /// `VarDiff::relu` (`vardiff.rs:282-288`).
+    pub fn relu(self) -> HipVarDiff<D> {
+        let grad = self.new_grad(self.grad.shape());
+        let op = ReLUBackward::new(self.grad.clone(), self.var.data.clone(), grad.clone());
+        let var = self.var.relu();
+        HipVarDiff::node(var, grad.clone(), (Rc::new(op), grad), self.history)
+    }
+
+    /// `VarDiff::softmax` (`vardiff.rs:359-365`).
+    pub fn softmax(self, axis: usize) -> HipVarDiff<D> {
+        let grad = self.new_grad(self.grad.shape());
+        let var = self.var.softmax(axis);
+        let op = SoftmaxBackward::new(self.grad.clone(), var.data.clone(), grad.clone(), axis);
+        HipVarDiff::node(var, grad.clone(), (Rc::new(op), grad), self.history)
+    }
+
+    /// `VarDiff::log_softmax` (`vardiff.rs:381-387`).
+    pub fn log_softmax(self, axis: usize) -> HipVarDiff<D> {
+        let grad = self.new_grad(self.grad.shape());
+        let var = self.var.log_softmax(axis);
+        let op = LogSoftmaxBackward::new(self.grad.clone(), var.data.clone(), grad.clone(), axis);
+        HipVarDiff::node(var, grad.clone(), (Rc::new(op), grad), self.history)
+    }
+
+    /// `VarDiff::t` (`vardiff.rs:390-396`).
+    pub fn t(self) -> HipVarDiff<D> {
+        let var = self.var.t();
+        let grad = Rc::new(Gradient::hip_zeros(var.data.borrow().dimension(), var.device()));
+        let op = TransposeBackward::new(self.grad.clone(), grad.clone());
+        HipVarDiff::node(var, grad.clone(), (Rc::new(op), grad), self.history)
+    }
+
+    /// `VarDiff::dropout` (`vardiff.rs:418-427`): forward and backward node share the noise buffer; the backward node does
+    /// NOT divide by `1 - p` (`node/dropout/mod.rs:123-126`, kept).
+    pub fn dropout(self, p: f64, status: Rc<Cell<bool>>) -> HipVarDiff<D> {
+        let grad = self.new_grad(self.grad.shape());
+        let noise = shared(self.grad.shape(), &self.var.device());
+        let var = self.var.dropout_with_noise(p, noise.clone(), status.clone());
+        let op = DropoutBackward::new(self.grad.clone(), grad.clone(), p, noise, status);
+        HipVarDiff::node(var, grad.clone(), (Rc::new(op), grad), self.history)
+    }
+
+    /// `VarDiff::chunks` (`vardiff.rs:435-452`).
+    pub fn chunks<E>(self, chunk_size: E) -> Vec<HipVarDiff<D>>
+    where
+        E: IntoDimension<Dim = D>,
+    {
+        self.var
+            .chunks(chunk_size)
+            .into_iter()
+            .enumerate()
+            .map(|(i, var)| {
+                let grad = Rc::new(Gradient::hip_zeros(var.data.borrow().dimension(), var.device()));
+                let op = ChunkBackward::new(self.grad.clone(), grad.clone(), i);
+                HipVarDiff::node(var, grad.clone(), (Rc::new(op), grad), self.history.clone())
+            })
+            .collect()
+    }
+
+    /// `VarDiff::cat` (`vardiff.rs:627-650`).
+    pub fn cat(mut self, vars: &[Self], axis: usize) -> HipVarDiff<D> {
+        let mut operands_gradients = vec![self.grad.clone()];
+        let mut operands = Vec::with_capacity(vars.len());
+        vars.iter().cloned().for_each(|v| {
+            self.history.merge(v.history);
+            operands_gradients.push(v.grad);
+            operands.push(v.var);
+        });
+        let var = self.var.cat(&operands, axis);
+        let grad = Rc::new(Gradient::hip_zeros(var.data.borrow().dimension(), var.device()));
+        let op = MultiConcatenateBackward::new(operands_gradients, grad.clone(), axis);
+        HipVarDiff::node(var, grad.clone(), (Rc::new(op), grad), self.history)
+    }
+
+    /// `VarDiff::mse` (`vardiff.rs:495-506`).
+    pub fn mse(self, target: HipVar<D>, reduction: Reduction) -> HipVarDiff<Ix0> {
+        let grad = self.new_grad(ndarray::Dim(()));
+        let op = SquaredErrorBackward::new(self.var.data.clone(), target.data.clone(), self.grad.clone(), grad.clone(), reduction.clone());
+        let var = self.var.mse(target, reduction);
+        HipVarDiff::node(var, grad.clone(), (Rc::new(op), grad), self.history)
+    }
+
+    /// `VarDiff::pad` (`vardiff.rs:746-766`), zero mode; `pad_with` takes the other three modes.
+    pub fn pad_zero(self, padding: &[usize]) -> HipVarDiff<D> {
+        self.pad_with(padding, PadMode::Constant(0.))
+    }
+
+    pub(crate) fn pad_with(self, padding: &[usize], mode: PadMode) -> HipVarDiff<D> {
+        let var = self.var.pad_with(padding, mode);
+        let grad = Rc::new(Gradient::hip_zeros(var.data.borrow().dimension(), var.device()));
+        let op = PadBackward::new(self.grad.clone(), grad.clone(), padding.iter().map(|&p| p as i32).collect());
+        HipVarDiff::node(var, grad.clone(), (Rc::new(op), grad), self.history)
+    }
+
+    /// Broadcast binary with two differentiable operands (`vardiff.rs:766-862` and the operator impls): forward node +
+    /// the two fused un-broadcast backward nodes as one tape entry.
+    pub(crate) fn binary<E>(mut self, op: BinaryOp, rhs: HipVarDiff<E>) -> HipVarDiff<Broadcast<D, E>>
+    where
+        D: DimMax<E>,
+        E: 'static + Dimension,
+    {
+        self.history.merge(rhs.history);
+        let (left_data, right_data) = (self.var.data.clone(), rhs.var.data.clone());
+        let var = self.var.binary(op, rhs.var);
+        let grad = Rc::new(Gradient::hip_zeros(var.data.borrow().dimension(), var.device()));
+        let left = BinaryOperationBackwardLeft::new(op, right_data.clone(), self.grad.clone(), grad.clone());
+        let right = BinaryOperationBackwardRight::new(op, left_data, right_data, rhs.grad.clone(), grad.clone());
+        let node: Rc<dyn Backward> = Rc::new(Pair(left, right));
+        HipVarDiff::node(var, grad.clone(), (node, grad), self.history)
+    }
+}
+
+impl<D> HipVarDiff<D>
+where
+    D: 'static + Dimension + RemoveAxis,
+{
+    /// `Convolution::convolution` for a differentiable kernel and input (`vardiff.rs:1357-1431`): `self` is the KERNEL.
+    /// One forward node; `ConvolutionBackwardInput` + `ConvolutionBackwardKernel` as one tape entry (`ConvolutionBackward`,
+    /// `node/convolution/mod.rs:357-388`).
+    pub fn convolution(mut self, input: HipVarDiff<D>, stride: &[usize], dilation: &[usize], groups: usize) -> HipVarDiff<D> {
+        self.history.merge(input.history);
+        let (input_data, kernel_data) = (input.var.data.clone(), self.var.data.clone());
+        let var = self.var.convolution(input.var, stride, dilation, groups);
+        let grad = Rc::new(Gradient::hip_zeros(var.data.borrow().dimension(), var.device()));
+        let to_i32 = |v: &[usize]| v.iter().map(|&s| s as i32).collect::<Vec<_>>();
+        let bwd_input = ConvolutionBackwardInput::new(kernel_data, input.grad.clone(), grad.clone(), to_i32(stride), to_i32(dilation), groups as i32);
+        let bwd_kernel = ConvolutionBackwardKernel::new(input_data, self.grad.clone(), grad.clone(), to_i32(stride), to_i32(dilation), groups as i32);
+        let node: Rc<dyn Backward> = Rc::new(Pair(bwd_input, bwd_kernel));
+        HipVarDiff::node(var, grad.clone(), (node, grad), self.history)
+    }
 }
 
 impl HipVarDiff<Ix2> {
+    /// `mm` (`vardiff.rs:1073-1106`).
+    pub fn mm(mut self, rhs: HipVarDiff<Ix2>) -> HipVarDiff<Ix2> {
+        self.history.merge(rhs.history);
+        let (left_data, right_data) = (self.var.data.clone(), rhs.var.data.clone());
+        let var = self.var.mm(rhs.var);
+        let grad = Rc::new(Gradient::hip_zeros(var.data.borrow().dimension(), var.device()));
+        let left = MatrixMatrixMulBackwardLeft::new(right_data, self.grad.clone(), grad.clone());
+        let right = MatrixMatrixMulBackwardRight::new(left_data, rhs.grad.clone(), grad.clone());
+        let op: Rc<dyn Backward> = Rc::new(Pair(left, right));
+        HipVarDiff::node(var, grad.clone(), (op, grad), self.history)
+    }
+
     /// `mm_t` (`vardiff.rs:1110-1143`): the node `nn::Linear::forward` is made of (`neuronika-nn/src/lib.rs:443-446`).
     pub fn mm_t(mut self, rhs: HipVarDiff<Ix2>) -> HipVarDiff<Ix2> {
-        self.var.history.merge(rhs.var.history);
         self.history.merge(rhs.history);
-        let (n, o) = (self.var.data.borrow().dimension()[0], rhs.var.data.borrow().dimension()[0]);
+        let (left_data, right_data) = (self.var.data.clone(), rhs.var.data.clone());
+        let var = self.var.mm_t(rhs.var);
+        let grad = Rc::new(Gradient::hip_zeros(var.data.borrow().dimension(), var.device()));
+        let left = MatrixMatrixMulTBackwardLeft::new(right_data, self.grad.clone(), grad.clone());
+        let right = MatrixMatrixMulTBackwardRight::new(left_data, rhs.grad.clone(), grad.clone());
+        let op: Rc<dyn Backward> = Rc::new(Pair(left, right));
+        HipVarDiff::node(var, grad.clone(), (op, grad), self.history)
+    }
+
+    /// The composed multi-head attention's per-(sample, head) chain `mm_t -> * scale -> softmax(1) -> dropout -> mm` as ONE
+    /// node on the fused kernels (SURVEY.md 8a note; `self` = queries in the `(batch*seq, heads*dh)` projection layout).
+    /// Callers check `ffi::nk_attention_supported` first and compose the five reference nodes on `chunks` otherwise.
+    #[allow(clippy::too_many_arguments)]
+    pub fn heads_attention(mut self, keys: HipVarDiff<Ix2>, values: HipVarDiff<Ix2>, batch: usize, seq: usize, heads: usize, dh: usize,
+                           scale: f32, p: f64, status: Rc<Cell<bool>>) -> HipVarDiff<Ix2> {
+        self.history.merge(keys.history);
+        self.history.merge(values.history);
+        let mut fwd_history = self.var.history;
+        fwd_history.merge(keys.var.history);
+        fwd_history.merge(values.var.history);
         let device = self.var.data.borrow().device().clone();
-        let data = Rc::new(RefCell::new(HipArray::zeroed(ndarray::Dim([n, o]), device.clone())));
-        let fwd = Rc::new(MatrixMatrixMulT::new(self.var.data.clone(), rhs.var.data.clone(), data.clone()));
-        let var = HipVar::node(data, fwd, self.var.history);
-        let grad = Rc::new(Gradient::hip_zeros(ndarray::Dim([n, o]), device));
-        let left = MatrixMatrixMulTBackwardLeft::new(rhs.var.data.clone(), self.grad.clone(), grad.clone());
-        let right = MatrixMatrixMulTBackwardRight::new(self.var.data.clone(), rhs.grad.clone(), grad.clone());
-        let op: Rc<dyn Backward> = Rc::new(super::node::Pair(left, right));
+        let geometry = Heads { batch: batch as i32, seq: seq as i32, heads: heads as i32, dh: dh as i32 };
+        let big = |last: usize| shared(ndarray::Dim([batch * heads, seq, last]), &device);
+        let state = Rc::new(AttentionState { scores: big(seq), stats: big(2), mask_bits: big(seq / 32), calls: Cell::new(0) });
+        let dim = self.var.data.borrow().dimension();
+        let data = shared(dim, &device);
+        let fwd = HeadsAttention::new(geometry, self.var.data.clone(), keys.var.data.clone(), values.var.data.clone(), state.clone(),
+                                      data.clone(), scale, p, status.clone(), next_seed());
+        let var = HipVar::node(data.clone(), Rc::new(fwd), fwd_history);
+        let grad = Rc::new(Gradient::hip_zeros(dim, device));
+        let bwd = HeadsAttentionBackward::new(geometry, self.var.data, keys.var.data, values.var.data, data, state, big(seq), big(seq),
+                                              self.grad, keys.grad, values.grad, grad.clone(), scale, p, status);
+        let op: Rc<dyn Backward> = Rc::new(bwd);
         HipVarDiff::node(var, grad.clone(), (op, grad), self.history)
     }
 }
 
-impl<D, E> std::ops::Add<HipVar<E>> for HipVar<D>
-where
-    D: 'static + DimMax<E>,
-    E: 'static + Dimension,
-{
-    type Output = HipVar<Broadcast<D, E>>;
+// Operators: `+ - * /` between device variables (`var.rs:746-838`, `vardiff.rs:766-862` and their `std::ops` impls).
+macro_rules! impl_binary {
+    ($trait:ident, $fun:ident, $op:expr) => {
+        impl<D, E> std::ops::$trait<HipVar<E>> for HipVar<D>
+        where
+            D: 'static + DimMax<E>,
+            E: 'static + Dimension,
+        {
+            type Output = HipVar<Broadcast<D, E>>;
 
-    fn add(self, rhs: HipVar<E>) -> Self::Output {
-        self.binary(BinaryOp::Add, rhs)
-    }
+            fn $fun(self, rhs: HipVar<E>) -> Self::Output {
+                self.binary($op, rhs)
+            }
+        }
+
+        impl<D, E> std::ops::$trait<HipVarDiff<E>> for HipVarDiff<D>
+        where
+            D: 'static + DimMax<E>,
+            E: 'static + Dimension,
+        {
+            type Output = HipVarDiff<Broadcast<D, E>>;
+
+            fn $fun(self, rhs: HipVarDiff<E>) -> Self::Output {
+                self.binary($op, rhs)
+            }
+        }
+    };
 }
+
+impl_binary!(Add, add, BinaryOp::Add);
+impl_binary!(Sub, sub, BinaryOp::Sub);
+impl_binary!(Mul, mul, BinaryOp::Mul);
+impl_binary!(Div, div, BinaryOp::Div);
+
+/// The unused-import guard of `Ix3` (attention buffers are `Ix3`, built through `shared`).
+#[allow(dead_code)]
+type AttentionBuffer = HipArray<Ix3>;

@@ -11,5 +11,5 @@ pub use {
     device::Device,
     dp::{Communicator, GradientSync},
     hiparray::HipArray,
-    hipvar::{HipVar, HipVarDiff},
+    hipvar::{manual_seed, HipVar, HipVarDiff},
 };
