@@ -272,6 +272,21 @@ def test_rendezvous_fallback_secret_is_loopback_only(monkeypatch):
     assert len(rz._secret(2, "10.1.2.3")) == 32
 
 
+def test_rendezvous_under_torch_distributed_run(tmp_path):
+    """The driver launches the multi-GPU bench as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py ...`: the control plane must come up from THAT environment (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_*, secret derived from the run id on loopback, ports next to the agent's store)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    w = tmp_path / "w.py"
+    w.write_text(_SPAWN_WORKER.format(root=root, fail_rank=-1))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "NK_RV_SECRET")}
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), str(w)], capture_output=True, text=True, timeout=180, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "OK 3 6.0 128" in r.stdout
+
+
 def test_bench_is_torch_free():
     """bench.py must not import torch in-process (second HIP runtime; see rendezvous.py)."""
     src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")).read()
