@@ -609,10 +609,15 @@ def run_mlp(a, dist):
         if sync is not None:
             res["per_rank_device_ms_per_step"] = [round(v, 4) for v in per_rank]
             res["per_rank_device_ms_min_max"] = [round(min(per_rank), 4), round(max(per_rank), 4)]
-            res["gemm_contention"] = {   # the same GEMM launches with the exchange running beside them and without
-                "avg_launch_ms_overlapped": round(gemm[1] / max(1, gemm[0]), 4),
-                "avg_launch_ms_no_exchange": round(gemm_off[1] / max(1, gemm_off[0]), 4),
-                "slowdown": round((gemm[1] / max(1, gemm[0])) / max(1e-9, gemm_off[1] / max(1, gemm_off[0])), 4)}
+            # the same GEMM work per step with the exchange running beside it and without (sums of the HIP-event durations
+            # of the step's GEMM launches: with the exchange on, the weight-gradient GEMMs are issued as two row blocks, so
+            # launch counts differ and per-launch averages are not comparable)
+            g_on, g_off = gemm[1] / a.steps, gemm_off[1] / a.steps
+            res["gemm_contention"] = {"gemm_ms_per_step_overlapped": round(g_on, 4), "gemm_launches_per_step_overlapped": gemm[0] // a.steps,
+                                      "gemm_ms_per_step_no_exchange": round(g_off, 4), "gemm_launches_per_step_no_exchange": gemm_off[0] // a.steps,
+                                      "slowdown": round(g_on / max(1e-9, g_off), 4)}
+            if replicas > 1:
+                res["replica_step_overhead_ms"] = round(exposed, 4)   # step with the stand-in exchange minus step without: a projection input, not a measurement
         if alone is not None:
             ring_ms = 2 * (world - 1) / world * alone[0]["bytes"] / (XGMI_LINK_GBS * 1e9) * 1e3 if world > 1 else 0.0
             res["allreduce_alone"] = {"ms": alone[0]["ms"], "bytes": alone[0]["bytes"], "algbw_GBps": alone[0]["algbw_GBps"],

@@ -372,7 +372,8 @@ __global__ __launch_bounds__(NT, 2) void conv_bwd_input_fast_kernel(FastBwdInArg
         gbase = n * g.Cout * g.L + krow * g.L;
     }
     const int jstep = 8 * g.L;
-    const long long gy_elems = (long long)g.N * g.Cout * g.L;
+    // last element index at which a lane's four 16-byte loads (rows 0, 8, 16, 24 of the k-tile) may start
+    const unsigned gy_last_start = (unsigned)((long long)g.N * g.Cout * g.L - 3LL * jstep - 4);
     // Two halves: `gather` only ISSUES the four 16-byte loads of the next k-tile (before the MFMAs of the current one);
     // `gather_finish` picks / masks the elements and runs AFTER the MFMAs - touching the loaded registers any earlier
     // makes the wave wait for its loads with nothing to hide them behind.
@@ -389,8 +390,10 @@ __global__ __launch_bounds__(NT, 2) void conv_bwd_input_fast_kernel(FastBwdInArg
         // of its gradient row reads the neighbouring row's elements, which the per-element masks zero.  Only a load that
         // would leave the TENSOR (before the first / behind the last element of gy: a handful of lanes per launch) is
         // pulled back into its row and takes the shifting path.
-        const long long e0 = (long long)(src - p.gy) + gbase + (ac * g.out[1] + bc) * g.out[2] + c;
-        const bool edge = e0 < 0 || e0 + 3LL * jstep + 4 > gy_elems;
+        // (32-bit: every tensor has fewer than 2^31 elements, checked by the host; one unsigned compare covers both ends -
+        //  a start before the tensor wraps to a huge value)
+        const int e0 = (int)(src - p.gy) + gbase + (ac * g.out[1] + bc) * g.out[2] + c;
+        const bool edge = (unsigned)e0 > gy_last_start;
         const int cs = edge ? min(max(c, 0), g.out[2] - 4) : c;
         st.sh = c - cs;                                  // shift of element 0 inside the loaded vector (0 unless `edge`)
         st.c = c;
@@ -402,17 +405,16 @@ __global__ __launch_bounds__(NT, 2) void conv_bwd_input_fast_kernel(FastBwdInArg
     auto finish_of = [&](Stage<4>& rb, const GatherState& st) {
         const int sh = st.sh, g_c = st.c;
         const bool g_ok = st.ok;
-        if (sh == 0) {  // the loaded vector is the quad (every lane but the few at the tensor's ends): mask per element
-            const bool k0 = g_ok && g_c >= 0 && g_c < g.out[2], k1 = g_ok && g_c + 1 >= 0 && g_c + 1 < g.out[2],
-                       k2 = g_ok && g_c + 2 >= 0 && g_c + 2 < g.out[2], k3 = g_ok && g_c + 3 >= 0 && g_c + 3 < g.out[2];
-            auto keep = [&](float4& q) { q.x = k0 ? q.x : 0.f; q.y = k1 ? q.y : 0.f; q.z = k2 ? q.z : 0.f; q.w = k3 ? q.w : 0.f; };
-            keep(rb.v0); keep(rb.v1); keep(rb.v2); keep(rb.v3);
-        } else {
-            const bool in0 = g_ok && g_c >= 0 && g_c < g.out[2], in1 = g_ok && g_c + 1 >= 0 && g_c + 1 < g.out[2],
-                       in2 = g_ok && g_c + 2 >= 0 && g_c + 2 < g.out[2], in3 = g_ok && g_c + 3 >= 0 && g_c + 3 < g.out[2];
-            // element i of the quad = element i + sh of the loaded vector: a barrel shifter of register selects (a pick by
-            // dynamic index makes the compiler index the vector through scratch memory); elements shifted in from outside
-            // the vector are always masked by in0..in3
+        // element i of the quad lies in its gradient row: one unsigned compare each
+        const bool in0 = g_ok && (unsigned)g_c < (unsigned)g.out[2], in1 = g_ok && (unsigned)(g_c + 1) < (unsigned)g.out[2],
+                   in2 = g_ok && (unsigned)(g_c + 2) < (unsigned)g.out[2], in3 = g_ok && (unsigned)(g_c + 3) < (unsigned)g.out[2];
+        // A wave in which some lane's load was pulled back into its row (sh != 0: the quad would have left the TENSOR - a
+        // handful of lanes per launch) shifts first: element i of the quad = element i + sh of the loaded vector, a barrel
+        // shifter of register selects (a pick by dynamic index makes the compiler index the vector through scratch
+        // memory).  Wave-uniform branch with no memory operation in either arm (the wait-count bookkeeping is the same on
+        // both paths): every other wave skips the 44 selects - they were 40 % of the pass's VALU instructions, and f32 MFMA
+        // and VALU share the issue slots.
+        if (__any(sh != 0)) {
             const int sl = max(sh, 0), sr = max(-sh, 0);
             const bool l1 = sl & 1, l2 = sl & 2, r1 = sr & 1, r2 = sr & 2;
             auto sel = [&](float4& q) {
@@ -421,10 +423,12 @@ __global__ __launch_bounds__(NT, 2) void conv_bwd_input_fast_kernel(FastBwdInArg
                 e0 = l2 ? e2 : e0; e1 = l2 ? e3 : e1;
                 e3 = r1 ? e2 : e3; e2 = r1 ? e1 : e2; e1 = r1 ? e0 : e1;
                 e3 = r2 ? e1 : e3; e2 = r2 ? e0 : e2;
-                q.x = in0 ? e0 : 0.f; q.y = in1 ? e1 : 0.f; q.z = in2 ? e2 : 0.f; q.w = in3 ? e3 : 0.f;
+                q.x = e0; q.y = e1; q.z = e2; q.w = e3;
             };
             sel(rb.v0); sel(rb.v1); sel(rb.v2); sel(rb.v3);
         }
+        auto keep = [&](float4& q) { q.x = in0 ? q.x : 0.f; q.y = in1 ? q.y : 0.f; q.z = in2 ? q.z : 0.f; q.w = in3 ? q.w : 0.f; };
+        keep(rb.v0); keep(rb.v1); keep(rb.v2); keep(rb.v3);
     };
 
     Stage<4> rb;

@@ -11,28 +11,27 @@ namespace {
 
 bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-// One thread = one Philox call = eight consecutive elements (nk_common.h: the draw layout); y = (x*noise)/scale
+// One thread = one aligned quad of elements = its half of the Philox call that covers it (nk_common.h: the draw layout);
+// y = (x*noise)/scale.  A thread that took the whole call (two adjacent quads, half the Philox work) was measured at HALF the
+// bandwidth: a lane's 32 contiguous bytes make every 16-byte load / store instruction touch each 128-byte line half-filled
+// (3.3 vs 6.5 TB/s at 1 GB); the kernel is HBM-bound, the second half of the call is cheaper than the lost coalescing.
 __global__ void dropout_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ noise,
                                    size_t n, unsigned keep_lt, float scale, unsigned long long seed,
                                    unsigned long long offset) {
-    const size_t n8 = (n + 7) / 8;
+    const size_t n4 = (n + 3) / 4;
     const uint2 key = make_uint2((unsigned)seed, (unsigned)(seed >> 32));
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
-        const uint4 r = nk_draw_call(i * 8, offset, key);
-        const float4 nz0 = nk_keep4(r.x, r.y, keep_lt), nz1 = nk_keep4(r.z, r.w, keep_lt);
-        if (i * 8 + 7 < n) {
-            const float4 xa = reinterpret_cast<const float4*>(x)[2 * i], xb = reinterpret_cast<const float4*>(x)[2 * i + 1];
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 nz = nk_keep4_at((unsigned long long)i * 4, offset, key, keep_lt);
+        if (i * 4 + 3 < n) {
+            const float4 xv = reinterpret_cast<const float4*>(x)[i];
             float4 o;
-            o.x = (xa.x * nz0.x) / scale; o.y = (xa.y * nz0.y) / scale; o.z = (xa.z * nz0.z) / scale; o.w = (xa.w * nz0.w) / scale;
-            nk_store_stream(reinterpret_cast<float4*>(y) + 2 * i, o);
-            o.x = (xb.x * nz1.x) / scale; o.y = (xb.y * nz1.y) / scale; o.z = (xb.z * nz1.z) / scale; o.w = (xb.w * nz1.w) / scale;
-            nk_store_stream(reinterpret_cast<float4*>(y) + 2 * i + 1, o);
-            nk_store_stream(reinterpret_cast<float4*>(noise) + 2 * i, nz0);
-            nk_store_stream(reinterpret_cast<float4*>(noise) + 2 * i + 1, nz1);
+            o.x = (xv.x * nz.x) / scale; o.y = (xv.y * nz.y) / scale; o.z = (xv.z * nz.z) / scale; o.w = (xv.w * nz.w) / scale;
+            nk_store_stream(reinterpret_cast<float4*>(y) + i, o);
+            nk_store_stream(reinterpret_cast<float4*>(noise) + i, nz);
         } else {
-            const float nn[8] = {nz0.x, nz0.y, nz0.z, nz0.w, nz1.x, nz1.y, nz1.z, nz1.w};
-            for (int c = 0; c < 8; ++c) {
-                const size_t e = i * 8 + c;
+            const float nn[4] = {nz.x, nz.y, nz.z, nz.w};
+            for (int c = 0; c < 4; ++c) {
+                const size_t e = i * 4 + c;
                 if (e < n) { y[e] = (x[e] * nn[c]) / scale; noise[e] = nn[c]; }
             }
         }
@@ -43,37 +42,18 @@ __global__ void dropout_fwd_kernel(const float* __restrict__ x, float* __restric
 template <int MODE>
 __global__ void dropout_bwd_kernel(float* __restrict__ dx, const float* __restrict__ g, const float* __restrict__ noise, size_t n,
                                    int assign) {
-    const size_t n4 = n / 4, stride = (size_t)gridDim.x * blockDim.x;
-    const bool fresh = assign & 1;
-    auto one = [&](float4 d, const float4& gv, const float4& nz) {
+    const size_t n4 = n / 4;
+    // (two quads per trip - six loads in flight per lane - measured SLOWER: 4.7 - 5.1 vs 5.6 TB/s at 1 GB, same box, round 3)
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 d = (assign & 1) ? make_float4(0.f, 0.f, 0.f, 0.f) : nk_load_stream(reinterpret_cast<const float4*>(dx) + i, assign & 2);
+        const float4 gv = nk_load_stream(reinterpret_cast<const float4*>(g) + i, assign & 2);
         if (MODE == 0) { d.x += gv.x; d.y += gv.y; d.z += gv.z; d.w += gv.w; }
-        else { d.x += gv.x * nz.x; d.y += gv.y * nz.y; d.z += gv.z * nz.z; d.w += gv.w * nz.w; }
-        return d;
-    };
-    // Two independent quads per trip: six 16-byte loads in flight per lane before the first use (a three-stream read at one
-    // quad per trip ran at 5.2 TB/s against 6.1 for the two-stream kernels).  The `nt` choice (operands beyond the Infinity
-    // Cache, nk_streams_past_cache) selects one of two copies of the WHOLE loop: a per-load `nt ? load_nt : load` is a
-    // two-armed load, and the wait-count bookkeeping at its join serialises the loads it is meant to overlap.
-    auto pass = [&](auto ld) {
-        const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-        size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-        for (; i + stride < n4; i += 2 * stride) {
-            const float4 g0 = ld(reinterpret_cast<const float4*>(g) + i), g1 = ld(reinterpret_cast<const float4*>(g) + i + stride);
-            float4 z0 = zero, z1 = zero, d0 = zero, d1 = zero;
-            if (MODE == 1) { z0 = ld(reinterpret_cast<const float4*>(noise) + i); z1 = ld(reinterpret_cast<const float4*>(noise) + i + stride); }
-            if (!fresh) { d0 = ld(reinterpret_cast<const float4*>(dx) + i); d1 = ld(reinterpret_cast<const float4*>(dx) + i + stride); }
-            nk_store_stream(reinterpret_cast<float4*>(dx) + i, one(d0, g0, z0));
-            nk_store_stream(reinterpret_cast<float4*>(dx) + i + stride, one(d1, g1, z1));
+        else {
+            const float4 nz = nk_load_stream(reinterpret_cast<const float4*>(noise) + i, assign & 2);
+            d.x += gv.x * nz.x; d.y += gv.y * nz.y; d.z += gv.z * nz.z; d.w += gv.w * nz.w;
         }
-        for (; i < n4; i += stride) {
-            const float4 d = fresh ? zero : ld(reinterpret_cast<const float4*>(dx) + i);
-            const float4 gv = ld(reinterpret_cast<const float4*>(g) + i);
-            const float4 nz = MODE == 1 ? ld(reinterpret_cast<const float4*>(noise) + i) : zero;
-            nk_store_stream(reinterpret_cast<float4*>(dx) + i, one(d, gv, nz));
-        }
-    };
-    if (assign & 2) pass([](const float4* q) { return nk_load_stream(q, true); });
-    else pass([](const float4* q) { return nk_load_stream(q, false); });
+        nk_store_stream(reinterpret_cast<float4*>(dx) + i, d);
+    }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
         const size_t i = n4 * 4 + threadIdx.x;
         dx[i] = ((assign & 1) ? 0.f : dx[i]) + (MODE == 0 ? g[i] : g[i] * noise[i]);
@@ -503,7 +483,7 @@ int nk_dropout_fwd(nk_device* dev, const float* x, float* y, float* noise, size_
     NK_CHECK(al16(x) && al16(y) && al16(noise), "dropout buffers must be 16-byte aligned");
     const unsigned keep_lt = nk_keep_threshold(1.0 - p);   // Bernoulli::new(1. - p), dropout/mod.rs:46
     const float scale = 1.f - (float)p;                    // `(1. - self.p as f32)`, dropout/mod.rs:76
-    hipLaunchKernelGGL(dropout_fwd_kernel, dim3(nk_stream_grid((n + 7) / 8, 256)), dim3(256), 0, dev->compute, x, y, noise,
+    hipLaunchKernelGGL(dropout_fwd_kernel, dim3(nk_stream_grid((n + 3) / 4, 256)), dim3(256), 0, dev->compute, x, y, noise,
                        n, keep_lt, scale, (unsigned long long)seed, (unsigned long long)offset);
     NK_LAUNCH_CHECK();
     return NK_OK;

@@ -152,7 +152,7 @@ def test_bench_multi_rank_record_is_self_diagnosing():
     alone = res["allreduce_alone"]
     assert alone["bytes"] == res["allreduce_bytes_per_step"] and alone["ms"] > 0 and len(alone["by_size"]) == 3
     g = res["gemm_contention"]
-    assert g["avg_launch_ms_overlapped"] > 0 and g["avg_launch_ms_no_exchange"] > 0 and 0.5 < g["slowdown"] < 2.0
+    assert g["gemm_ms_per_step_overlapped"] > 0 and g["gemm_ms_per_step_no_exchange"] > 0 and 0.5 < g["slowdown"] < 2.0
     assert isinstance(res["exposed_comm_ms"], float)
     rccl = res["rccl"]
     assert "excerpt" in rccl, rccl                 # the NCCL_DEBUG=INFO log of rank 0 was found and parsed
