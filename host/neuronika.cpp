@@ -3,6 +3,8 @@
 // on the device's compute stream in tape order.
 #include "neuronika.hpp"
 
+#include <cstdlib>
+
 #include <algorithm>
 #include <charconv>
 #include <cstring>
@@ -2094,11 +2096,25 @@ GradientSync::GradientSync(std::shared_ptr<Communicator> comm, const std::vector
     nk_event* ev = nullptr;  // one more for the group of small gradients
     check(nk_event_create(comm_->device()->raw(), &ev));
     events_.push_back(ev);
+    if (const char* e = std::getenv("NK_DP_PARTS")) {
+        const std::string v(e);
+        if (v == "all") parts_ = Parts::All;
+        else if (v == "none") parts_ = Parts::None;
+        else if (v == "last") parts_ = Parts::LastOnly;
+        else panic("NK_DP_PARTS must be all, last or none");
+    }
 }
 GradientSync::~GradientSync() {
     for (nk_event* e : events_) nk_event_destroy(e);
 }
-bool GradientSync::wants_parts(const Gradient* g) const { return active() && params_.count(g) != 0; }
+bool GradientSync::wants_parts(const Gradient* g) const {
+    if (!active() || params_.count(g) == 0) return false;
+    switch (parts_) {
+        case Parts::All: return true;
+        case Parts::None: return false;
+        default: return g == split_next_;
+    }
+}
 void GradientSync::flush_small() {
     if (small_pending_.empty()) return;
     std::vector<float*> bufs;
@@ -2128,6 +2144,7 @@ void GradientSync::grad_part_ready(const Gradient* g, size_t offset, size_t coun
         if (small_pending_.size() == n_small_) flush_small();
         return;
     }
+    last_large_ = g;
     nk_event* ev = events_[next_event_++ % events_.size()];
     check(nk_event_record(ev, 0));  // everything up to the launch that finished this piece
     check(nk_allreduce_sum_async(comm_->raw(), a.ptr() + offset, count, ev));
@@ -2151,6 +2168,8 @@ void GradientSync::grad_ready(const Gradient* g) {
 }
 void GradientSync::join() {
     flush_small();  // small gradients of parameters some of whose siblings never became final this pass
+    split_next_ = last_large_;  // (every rank runs the same tape: the same gradient on every rank, so the collectives still pair up)
+    last_large_ = nullptr;
     next_event_ = 0;
     for (auto& kv : parts_done_) kv.second = 0;
     if (active()) check(nk_comm_join(comm_->raw()));

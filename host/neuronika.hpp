@@ -796,6 +796,15 @@ class GradientSync : public BackwardHook {
     void set_force_exchange(bool on) { force_ = on; }
     size_t exchanges_issued() const { return issued_; }  // collective launches so far (a group counts once)
     size_t elements_exchanged() const { return elems_; }
+    // Which weight gradients are handed over in row blocks (two launches of the weight-gradient GEMM instead of one):
+    //   All       every large gradient (rounds 1 - 2);
+    //   LastOnly  only the large gradient that became final LAST in the previous backward pass - the one whose exchange is
+    //             exposed behind the pass; the others have the rest of backward to hide behind and keep the single GEMM
+    //             launch (a split weight-gradient GEMM pays its prologue / drain twice: profiles/r03_overlap_projection.md);
+    //   None      never.
+    // Default LastOnly; NK_DP_PARTS=all|last|none overrides (measurement aid).  The first pass of LastOnly splits nothing.
+    enum class Parts { All, LastOnly, None };
+    void set_parts(Parts p) { parts_ = p; }
 
    private:
     void flush_small();
@@ -811,6 +820,9 @@ class GradientSync : public BackwardHook {
     size_t small_elems_;
     size_t n_small_ = 0;
     bool force_ = false;
+    Parts parts_ = Parts::LastOnly;
+    const Gradient* last_large_ = nullptr;       // large gradient handed over last in the current pass
+    const Gradient* split_next_ = nullptr;       // ... in the previous pass: the one LastOnly splits
     bool active() const { return comm_->size() > 1 || force_; }
 };
 

@@ -394,6 +394,12 @@ PYBIND11_MODULE(_tape, m) {
         .def("join", &dp::GradientSync::join)
         .def("bytes_per_step", &dp::GradientSync::bytes_per_step)
         .def("set_force_exchange", &dp::GradientSync::set_force_exchange)
+        .def("set_parts", [](dp::GradientSync& s, const std::string& mode) {
+            if (mode == "all") s.set_parts(dp::GradientSync::Parts::All);
+            else if (mode == "last") s.set_parts(dp::GradientSync::Parts::LastOnly);
+            else if (mode == "none") s.set_parts(dp::GradientSync::Parts::None);
+            else throw std::invalid_argument("set_parts: all | last | none");
+        })
         .def("exchanges_issued", &dp::GradientSync::exchanges_issued)
         .def("elements_exchanged", &dp::GradientSync::elements_exchanged);
     dpm.def("all_reduce_gradients", &dp::all_reduce_gradients);

@@ -812,6 +812,7 @@ def test_gradient_sync_piecewise_exchange(nk, tdev):
     want = [p.grad().copy() for p in params]
     sync = nk.dp.GradientSync(tcomm, params)
     sync.set_force_exchange(True)
+    sync.set_parts("all")                                      # (the default splits only the gradient that was final last)
     total = sum(int(np.prod(p.shape)) for p in params)
     for rep in range(2):
         for p in params:
@@ -833,7 +834,7 @@ def test_gradient_sync_piecewise_exchange(nk, tdev):
     assert s3.exchanges_issued() == 2
 
 
-def _replica_check(nk, tdev, ranks, build, seed=1.0):
+def _replica_check(nk, tdev, ranks, build, seed=1.0, parts=None):
     """Run `build()`'s loss once plainly and once through GradientSync over a replica communicator of `ranks` virtual
     ranks that all hold this rank's values: every element of every registered gradient must come back multiplied by
     `ranks` exactly once - an element skipped, sent twice or sent before its last writer ran shows up as a mismatch
@@ -844,6 +845,8 @@ def _replica_check(nk, tdev, ranks, build, seed=1.0):
     comm = nk.dp.Communicator.replicas(tdev, ranks)
     assert comm.size == ranks
     sync = nk.dp.GradientSync(comm, params)
+    if parts is not None:
+        sync.set_parts(parts)
     for rep in range(2):
         for p in params:
             p.zero_grad()
@@ -856,21 +859,23 @@ def _replica_check(nk, tdev, ranks, build, seed=1.0):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("ranks", [2, 8])
-def test_gradient_sync_covers_every_element_once(nk, tdev, ranks):
+@pytest.mark.parametrize("ranks,parts,launches", [(2, "all", 2 * (3 * 2 + 1)), (8, "all", 14), (8, "none", 2 * (3 + 1)), (8, "last", (3 + 1) + (4 + 1)), (2, None, 9)])
+def test_gradient_sync_covers_every_element_once(nk, tdev, ranks, parts, launches):
+    """`parts`: which weight gradients are handed over in two row blocks - all of them, only the one that was final last
+    in the previous pass (the default: its exchange is the exposed one; the first pass splits nothing), or none."""
     def mlp():                                                 # C4-shaped: piecewise weight gradients + grouped biases
         lins = [nk.nn.Linear(tdev, 4096, 4096, s) for s in (1, 3, 5)]
         X, T = nk.rand(tdev, [128, 4096], 5), nk.rand(tdev, [128, 4096], 6)
         loss = lins[2].forward(lins[1].forward(lins[0].forward(X).relu()).relu()).mse(T, nk.Reduction.Mean)
         return loss, [p for l in lins for p in (l.weight, l.bias)]
-    sync = _replica_check(nk, tdev, ranks, mlp, 1.0 / ranks)
-    assert sync.exchanges_issued() == 2 * (3 * 2 + 1)
+    sync = _replica_check(nk, tdev, ranks, mlp, 1.0 / ranks, parts)
+    assert sync.exchanges_issued() == launches
 
     def ragged():                                              # below the split threshold, odd sizes, a mid-sized weight
         l1, l2 = nk.nn.Linear(tdev, 300, 700, 1), nk.nn.Linear(tdev, 700, 129, 2)
         loss = l2.forward(l1.forward(nk.rand(tdev, [37, 300], 3)).relu()).sum()
         return loss, [l1.weight, l1.bias, l2.weight, l2.bias]
-    _replica_check(nk, tdev, ranks, ragged)
+    _replica_check(nk, tdev, ranks, ragged, 1.0, parts)
 
 
 @pytest.mark.gpu
@@ -919,8 +924,10 @@ def test_gradient_sync_shared_linear(nk, tdev):
         X = nk.rand(tdev, [128, 4096], 5)
         loss = lin.forward(lin.forward(X).relu()).mse(nk.rand(tdev, [128, 4096], 6), nk.Reduction.Mean)
         return loss, [lin.weight, lin.bias]
-    sync = _replica_check(nk, tdev, 2, tied)
+    sync = _replica_check(nk, tdev, 2, tied, 1.0, "all")
     assert sync.exchanges_issued() == 2 * (2 + 1)              # the last writer's two halves + the bias group, per pass
+    sync = _replica_check(nk, tdev, 2, tied)                   # default policy: pass 1 whole, pass 2 the (only) weight gradient in halves
+    assert sync.exchanges_issued() == (1 + 1) + (2 + 1)
 
 
 @pytest.mark.gpu
