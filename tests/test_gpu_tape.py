@@ -653,7 +653,7 @@ def test_mha_with_dropout_equals_oracle(nk, tdev, fused, strided, p):
             err_gpu, err_cpu = np.abs(got - want).max(), np.abs(want32 - want).max()
             from conftest import record_margin
             record_margin("mha_module:" + what, err_gpu, err_cpu, 1e-6 * scale)
-            assert err_gpu <= max(4 * err_cpu, 2e-6 * scale), (what, call, err_gpu, err_cpu, scale)
+            assert err_gpu <= max(2 * err_cpu, 1e-6 * scale), (what, call, err_gpu, err_cpu, scale)   # SURVEY 8c (ii) as stated
         check(y.data(), ref, ref32, "out")
         check(X.grad(), grads["x"], grads32["x"], "dx")
         for nme in "qkvo":
@@ -698,7 +698,7 @@ def test_mha_fused_attention_core_equals_oracle(nk, tdev, core, p, S):
             err_gpu, err_cpu = np.abs(got - want).max(), np.abs(want32 - want).max()
             from conftest import record_margin
             record_margin("mha_module:" + what, err_gpu, err_cpu, 1e-6 * scale)
-            assert err_gpu <= max(4 * err_cpu, 2e-6 * scale), (what, call, err_gpu, err_cpu, scale)
+            assert err_gpu <= max(2 * err_cpu, 1e-6 * scale), (what, call, err_gpu, err_cpu, scale)   # SURVEY 8c (ii) as stated
         check(y.data(), ref, ref32, "out")
         check(X.grad(), grads["x"], grads32["x"], "dx")
         for nme in "qkvo":
