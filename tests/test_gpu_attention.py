@@ -4,7 +4,7 @@ composed multi-head attention, SURVEY.md 8a note) against the oracle's node-by-n
 
 Tolerance (SURVEY.md 8c ii): the kernels and the f32 oracle are both measured against the f64 oracle fed the SAME Philox
 mask; pass iff err_gpu <= max(2 * err_cpu32, 1e-6 * max|reference|) per tensor (SURVEY 8c ii as stated; measured margins:
-gpurun_out/tolerance_margins.json -> DESIGN.md section 5).  The raw scores come out of the same MFMA
+profiles/r03_tolerance_margins.json).  The raw scores come out of the same MFMA
 k-order as nk_sgemm_batched and must equal it bit for bit; the dropped-probability tensor must have exactly the mask's
 zero pattern."""
 import numpy as np
