@@ -1203,7 +1203,7 @@ static Var heads_attention_node(const Var& q, const Var& keys, const Var& values
     check_heads(q.shape(), {}, B, S, H, dh, false);
     check_heads(keys.shape(), {}, B, S, H, dh, false);
     check_heads(values.shape(), {}, B, S, H, dh, false);
-    if (!Var::attention_core_supported(S, dh, p)) panic("heads_attention: the fused kernels take dh == 64, S % 32 == 0 and p < 1");
+    if (!Var::attention_core_supported(S, dh, p)) panic("heads_attention: the fused kernels take dh in {32, 64, 128}, S % 32 == 0 and p < 1");
     History<ForwardEntry> h = q.history;
     h.merge(keys.history);
     h.merge(values.history);

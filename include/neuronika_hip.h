@@ -408,7 +408,7 @@ int nk_scale_softmax_dropout_bwd_from_scores(nk_device* dev, float* d_scores, co
  * c1 = scale*log2(e) and the shift m2 in [max_k S*c1 - 6, max_k S*c1]: P = exp2(S*c1 - m2) * stats[..,1].  scale > 0.
  * The score tile stays on chip between the two products (online softmax forward, recomputed probabilities backward).
  * Dropout mask: the Philox stream of nk_scale_softmax_dropout_fwd (same seed / offset -> same mask).
- * nk_attention_supported: dh == 64, S % 32 == 0, not (train and p == 1); callers fall back to the node-by-node path. */
+ * nk_attention_supported: dh in {32, 64, 128}, S % 32 == 0, not (train and p == 1); callers fall back to the node-by-node path. */
 int nk_attention_supported(int S, int dh, double p, int train);
 /* forward: writes the raw scores (for the backward pass), the row statistics, the dropout draws (1 bit per score:
  * B*H*S*S/32 words laid out [b*H + h][S/32 query tiles][S/32 key tiles][32 queries of the tile], bit 16 j + e of a word =

@@ -35,12 +35,18 @@ namespace {
 
 using nkmma::f32x16;
 
-constexpr int A_DH = 64;    // head dimension the kernels are built for (2 MFMA column tiles, 8 b128 k-groups)
+// Head dimension DH in {32, 64, 128} (template parameter): DH / 32 MFMA column tiles of the output, DH / 8 b128 k-groups of the
+// score product.  64 is the C5 geometry the register / LDS budgets were tuned for (three forward blocks per CU); 128 holds 64 + 64
+// VGPRs of per-query operand and output accumulators and 66 KB of staged K / V per block - one block per CU, still one kernel per
+// direction instead of the node-by-node path; 32 halves everything.
 constexpr int A_NT = 256;   // 4 waves, 32 queries each
 constexpr int A_QB = 128;   // queries per block
-constexpr int X1_LD = 68;   // pass-1 operand image [mfma row][dh], padded: b128 fragment reads of 16 rows hit 16 distinct slots
-constexpr int X2_LD = 64;   // pass-2 operand image [key][dh rotated by 32 for keys >= 16]: the two lane halves read disjoint banks
 constexpr int SCR_LD = 36;  // per-wave 32 x 32 transposition scratch
+// pass-1 operand image [mfma row][dh], padded by 4: b128 fragment reads of 16 rows hit 16 distinct slots
+constexpr int x1_ld(int dh) { return dh + 4; }
+// pass-2 operand image [key][dh rotated by 32 for keys >= 16]: the two lane halves read disjoint banks (DH = 32: no rotation
+// possible, the halves share banks - a two-way conflict on 16 of the tile's LDS reads)
+constexpr int x2_ld(int dh) { return dh; }
 
 struct AttnArgs {
     const float* x1;   // pass-1 operand, flat (B*S) x (H*dh) layout: forward K, backward V
@@ -98,8 +104,12 @@ __device__ __forceinline__ void tile_flush(const float* scrw, float* g /* &T[row
 // with the branch gone it waits for exactly the staging loads and the stores drain under the next tile's MFMAs.
 // KEEP (forward only): write what the backward pass needs (scores, row statistics, dropout bits).  false = inference: O only,
 // 2.1 GB of stores and the buffers themselves disappear.
-template <bool BWD, bool MASKED, bool FULL, int OCC, bool KEEP = true>
+template <bool BWD, bool MASKED, bool FULL, int OCC, bool KEEP = true, int DH = 64>
 __global__ __launch_bounds__(A_NT, OCC) void attention_kernel(const AttnArgs p) {
+    constexpr int X1_LD = x1_ld(DH), X2_LD = x2_ld(DH);
+    constexpr int ND = DH / 32;   // output column tiles
+    constexpr int NR = DH / 32;   // float4 per thread and operand of a staged key tile (32 keys x DH)
+    constexpr int C4 = DH / 4;    // float4 per key row
     __shared__ __attribute__((aligned(16))) float x1s[2][32 * X1_LD];
     __shared__ __attribute__((aligned(16))) float x2s[2][32 * X2_LD];
     __shared__ __attribute__((aligned(16))) float scr[A_NT / 64][(BWD ? 2 : 1) * 32 * SCR_LD];  // per wave: tile scratch (backward: dS | Pd)
@@ -109,47 +119,57 @@ __global__ __launch_bounds__(A_NT, OCC) void attention_kernel(const AttnArgs p) 
     // of K and V a head's blocks share stay in that XCD's L2
     const int seq = nkmma::xcd_chunk(blockIdx.x, gridDim.x);
     const int bh = seq / p.nqb, qb = seq % p.nqb;
-    const long long flat0 = (long long)(bh / p.H) * p.S * p.ld + (long long)(bh % p.H) * A_DH;
+    const long long flat0 = (long long)(bh / p.H) * p.S * p.ld + (long long)(bh % p.H) * DH;
     const int q0 = qb * A_QB + w * 32;
     const bool on = FULL ? true : q0 < p.S;  // wave-uniform: S is a multiple of 32, not necessarily of 128
     const float* x1 = p.x1 + flat0;
     const float* x2 = p.x2 + flat0;
 
-    // ---- cooperative staging of one key tile (32 keys x 64 dh of each operand): 2 + 2 float4 per thread -------------
-    unsigned goff[2], s1[2], s2[2];
+    // ---- cooperative staging of one key tile (32 keys x DH of each operand): NR + NR float4 per thread ------------------
+    unsigned goff[NR], s1[NR], s2[NR];
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const int idx = tid + A_NT * r, key = idx >> 4, c4 = idx & 15;
+    for (int r = 0; r < NR; ++r) {
+        const int idx = tid + A_NT * r, key = idx / C4, c4 = idx % C4;
         goff[r] = (unsigned)(key * p.ld + 4 * c4);
         // mfma row i supplies key 16*((i>>2)&1) + 4*(i>>3) + (i&3); its inverse places key 16a + 4b + c in row 8b + 4a + c
         s1[r] = (unsigned)((8 * ((key >> 2) & 3) + 4 * (key >> 4) + (key & 3)) * X1_LD + 4 * c4);
-        s2[r] = (unsigned)(key * X2_LD + ((4 * c4 + 32 * (key >> 4)) & 63));
+        s2[r] = (unsigned)(key * X2_LD + ((4 * c4 + 32 * (key >> 4)) & (DH - 1)));
     }
-    // (named registers and macros, not arrays captured by lambdas: those end up in scratch memory)
-    float4 st10, st11, st20, st21;
-#define A_STAGE_LOAD(KT)                                                         \
-    do {                                                                         \
-        const long long t0_ = (long long)(KT) * 32 * p.ld;                       \
-        st10 = *reinterpret_cast<const float4*>(x1 + t0_ + goff[0]);            \
-        st11 = *reinterpret_cast<const float4*>(x1 + t0_ + goff[1]);            \
-        st20 = *reinterpret_cast<const float4*>(x2 + t0_ + goff[0]);            \
-        st21 = *reinterpret_cast<const float4*>(x2 + t0_ + goff[1]);            \
+    // NAMED registers (up to four float4 per operand), not arrays: `float4 st[NR]` written under `if (more)` and read a loop
+    // body later is kept in scratch memory by the compiler (measured: 64 bytes of private segment, four scratch stores and
+    // loads per tile), and so is a small array of LDS pointers.
+    float4 sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3;
+#define A_STAGE_LOAD(KT)                                                                                         \
+    do {                                                                                                         \
+        const long long t0_ = (long long)(KT) * 32 * p.ld;                                                       \
+        sa0 = *reinterpret_cast<const float4*>(x1 + t0_ + goff[0]);                                             \
+        if constexpr (NR > 1) sa1 = *reinterpret_cast<const float4*>(x1 + t0_ + goff[NR > 1 ? 1 : 0]);          \
+        if constexpr (NR > 2) { sa2 = *reinterpret_cast<const float4*>(x1 + t0_ + goff[NR > 2 ? 2 : 0]);        \
+                                sa3 = *reinterpret_cast<const float4*>(x1 + t0_ + goff[NR > 2 ? 3 : 0]); }      \
+        sb0 = *reinterpret_cast<const float4*>(x2 + t0_ + goff[0]);                                             \
+        if constexpr (NR > 1) sb1 = *reinterpret_cast<const float4*>(x2 + t0_ + goff[NR > 1 ? 1 : 0]);          \
+        if constexpr (NR > 2) { sb2 = *reinterpret_cast<const float4*>(x2 + t0_ + goff[NR > 2 ? 2 : 0]);        \
+                                sb3 = *reinterpret_cast<const float4*>(x2 + t0_ + goff[NR > 2 ? 3 : 0]); }      \
     } while (0)
-#define A_STAGE_STORE(BUF)                                                       \
-    do {                                                                         \
-        *reinterpret_cast<float4*>(&x1s[BUF][s1[0]]) = st10;                     \
-        *reinterpret_cast<float4*>(&x1s[BUF][s1[1]]) = st11;                     \
-        *reinterpret_cast<float4*>(&x2s[BUF][s2[0]]) = st20;                     \
-        *reinterpret_cast<float4*>(&x2s[BUF][s2[1]]) = st21;                     \
+#define A_STAGE_STORE(BUF)                                                                                       \
+    do {                                                                                                         \
+        *reinterpret_cast<float4*>(&x1s[BUF][s1[0]]) = sa0;                                                      \
+        if constexpr (NR > 1) *reinterpret_cast<float4*>(&x1s[BUF][s1[NR > 1 ? 1 : 0]]) = sa1;                   \
+        if constexpr (NR > 2) { *reinterpret_cast<float4*>(&x1s[BUF][s1[NR > 2 ? 2 : 0]]) = sa2;                 \
+                                *reinterpret_cast<float4*>(&x1s[BUF][s1[NR > 2 ? 3 : 0]]) = sa3; }               \
+        *reinterpret_cast<float4*>(&x2s[BUF][s2[0]]) = sb0;                                                      \
+        if constexpr (NR > 1) *reinterpret_cast<float4*>(&x2s[BUF][s2[NR > 1 ? 1 : 0]]) = sb1;                   \
+        if constexpr (NR > 2) { *reinterpret_cast<float4*>(&x2s[BUF][s2[NR > 2 ? 2 : 0]]) = sb2;                 \
+                                *reinterpret_cast<float4*>(&x2s[BUF][s2[NR > 2 ? 3 : 0]]) = sb3; }               \
     } while (0)
 
     // ---- per-query state ----------------------------------------------------------------------------------------
     const int row = on ? q0 + q : 0;
-    float4 bq[8];  // B operand of pass 1: element (query, dh = 8j + 4h + c)
+    float4 bq[DH / 8];  // B operand of pass 1: element (query, dh = 8j + 4h + c)
     {
         const float* b = p.bq + flat0 + (long long)row * p.ld + 4 * h;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) bq[j] = *reinterpret_cast<const float4*>(b + 8 * j);
+        for (int j = 0; j < DH / 8; ++j) bq[j] = *reinterpret_cast<const float4*>(b + 8 * j);
     }
     float m_run = -1e30f, l_run = 0.f;  // forward: online softmax (shift, sum); backward: the stored shift and 1 / sum
     float dot = 0.f;
@@ -158,7 +178,7 @@ __global__ __launch_bounds__(A_NT, OCC) void attention_kernel(const AttnArgs p) 
         m_run = ms.x; l_run = ms.y;
         const float* o = p.ctx + flat0 + (long long)row * p.ld + 4 * h;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < DH / 8; ++j) {
             const float4 ov = *reinterpret_cast<const float4*>(o + 8 * j);
             dot += (bq[j].x * ov.x + bq[j].y * ov.y) + (bq[j].z * ov.z + bq[j].w * ov.w);
         }
@@ -166,9 +186,11 @@ __global__ __launch_bounds__(A_NT, OCC) void attention_kernel(const AttnArgs p) 
         // sum_k dP_k P_k with dP = dPd * noise, while dO . O = sum_k dPd_k P_k noise_k / keep
         if (MASKED) dot *= p.keep;
     }
-    f32x16 o0, o1;
+    f32x16 oacc[ND];  // out^T tiles: oacc[d] holds dh 32 d .. 32 d + 31 of this lane's query
 #pragma unroll
-    for (int e = 0; e < 16; ++e) { o0[e] = 0.f; o1[e] = 0.f; }
+    for (int d = 0; d < ND; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) oacc[d][e] = 0.f;
 
     const long long rowbase = ((long long)bh * p.S + (on ? q0 : 0)) * p.S;  // element index of (row q0, key 0) in the (B*H, S, S) tensors
     const uint2 key = make_uint2((unsigned)p.seed, (unsigned)(p.seed >> 32));
@@ -231,7 +253,7 @@ __global__ __launch_bounds__(A_NT, OCC) void attention_kernel(const AttnArgs p) 
             {
                 const float* a1 = &x1s[cur][q * X1_LD + 4 * h];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
+                for (int j = 0; j < DH / 8; ++j) {
                     const float4 a = *reinterpret_cast<const float4*>(a1 + 8 * j);
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bq[j].x, acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bq[j].y, acc, 0, 0, 0);
@@ -294,7 +316,9 @@ __global__ __launch_bounds__(A_NT, OCC) void attention_kernel(const AttnArgs p) 
                     l_run *= alpha;
                     m_run = m_new;
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) { o0[e] *= alpha; o1[e] *= alpha; }
+                    for (int d = 0; d < ND; ++d)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) oacc[d][e] *= alpha;
                 }
                 float ps = 0.f;
 #pragma unroll
@@ -320,13 +344,20 @@ __global__ __launch_bounds__(A_NT, OCC) void attention_kernel(const AttnArgs p) 
             }
             // ---- pass 2: out^T[dh][query] += X2^T . C ----------------------------------------------------------------
             {
-                const float* a20 = &x2s[cur][(16 * h) * X2_LD + ((q + 32 * h) & 63)];
-                const float* a21 = &x2s[cur][(16 * h) * X2_LD + ((q + 32 * (1 ^ h)) & 63)];
+                // column tile d of the output reads dh column 32 d + q of the key rows 16 h + e, stored rotated by 32 h
+                const float* const a2b = &x2s[cur][(16 * h) * X2_LD];
+                const int c0 = (q + 32 * h) & (DH - 1), c1 = (q + 32 + 32 * h) & (DH - 1), c2 = (q + 64 + 32 * h) & (DH - 1),
+                          c3 = (q + 96 + 32 * h) & (DH - 1);
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a20[e * X2_LD], bv[e], o0, 0, 0, 0);
-                    o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a21[e * X2_LD], bv[e], o1, 0, 0, 0);
+                    oacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2b[e * X2_LD + c0], bv[e], oacc[0], 0, 0, 0);
+                    if constexpr (ND > 1) oacc[ND > 1 ? 1 : 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2b[e * X2_LD + c1], bv[e], oacc[ND > 1 ? 1 : 0], 0, 0, 0);
+                    if constexpr (ND > 2) {
+                        oacc[ND > 2 ? 2 : 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2b[e * X2_LD + c2], bv[e], oacc[ND > 2 ? 2 : 0], 0, 0, 0);
+                        oacc[ND > 2 ? 3 : 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2b[e * X2_LD + c3], bv[e], oacc[ND > 2 ? 3 : 0], 0, 0, 0);
+                    }
                 }
+                (void)c1; (void)c2; (void)c3;
             }
             // ---- the tiles written to the scratch before pass 2 go to HBM now (machine scheduler pinned: hoisting the
             //      ds_reads above the MFMAs would put the LDS round trip back on the critical path) ---------------------
@@ -354,23 +385,27 @@ __global__ __launch_bounds__(A_NT, OCC) void attention_kernel(const AttnArgs p) 
         const float inv = 1.f / l_run;
         const float io = MASKED ? inv * p.dscale : inv;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            *reinterpret_cast<float4*>(orow + 8 * c) = make_float4(o0[4 * c] * io, o0[4 * c + 1] * io, o0[4 * c + 2] * io, o0[4 * c + 3] * io);
-            *reinterpret_cast<float4*>(orow + 32 + 8 * c) = make_float4(o1[4 * c] * io, o1[4 * c + 1] * io, o1[4 * c + 2] * io, o1[4 * c + 3] * io);
-        }
+        for (int d = 0; d < ND; ++d)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                *reinterpret_cast<float4*>(orow + 32 * d + 8 * c) =
+                    make_float4(oacc[d][4 * c] * io, oacc[d][4 * c + 1] * io, oacc[d][4 * c + 2] * io, oacc[d][4 * c + 3] * io);
         if (KEEP && h == 0) *reinterpret_cast<float2*>(p.stats + ((long long)bh * p.S + row) * 2) = make_float2(m_run, inv);
     } else {
-        float4 old[8];
+        // every old value is loaded before the first store (a store may alias the next load: a one-walk `+=` serialises)
+        float4 old[ND][4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            old[c] = p.assign ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(orow + 8 * c);
-            old[4 + c] = p.assign ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(orow + 32 + 8 * c);
-        }
+        for (int d = 0; d < ND; ++d)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            *reinterpret_cast<float4*>(orow + 8 * c) = make_float4(old[c].x + o0[4 * c], old[c].y + o0[4 * c + 1], old[c].z + o0[4 * c + 2], old[c].w + o0[4 * c + 3]);
-            *reinterpret_cast<float4*>(orow + 32 + 8 * c) = make_float4(old[4 + c].x + o1[4 * c], old[4 + c].y + o1[4 * c + 1], old[4 + c].z + o1[4 * c + 2], old[4 + c].w + o1[4 * c + 3]);
-        }
+            for (int c = 0; c < 4; ++c)
+                old[d][c] = p.assign ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(orow + 32 * d + 8 * c);
+#pragma unroll
+        for (int d = 0; d < ND; ++d)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                *reinterpret_cast<float4*>(orow + 32 * d + 8 * c) =
+                    make_float4(old[d][c].x + oacc[d][4 * c], old[d][c].y + oacc[d][4 * c + 1], old[d][c].z + oacc[d][4 * c + 2],
+                                old[d][c].w + oacc[d][4 * c + 3]);
     }
 }
 
@@ -380,32 +415,35 @@ int attention_check(int B, int S, int H, int dh, double p, int train, float scal
     NK_CHECK(p >= 0.0 && p <= 1.0, "Wrong probability received: %g.", p);
     NK_CHECK(scale > 0.f && scale < 1e30f, "fused attention needs a positive finite scale (the row max is taken before scaling), got %g", (double)scale);
     NK_CHECK(B > 0 && S > 0 && H > 0, "attention: non-positive geometry");
-    NK_CHECK(nk_attention_supported(S, dh, p, train), "fused attention needs dh == 64, S %% 32 == 0 and p < 1 in training (S=%d dh=%d p=%g)", S, dh, p);
+    NK_CHECK(nk_attention_supported(S, dh, p, train), "fused attention needs dh in {32, 64, 128}, S %% 32 == 0 and p < 1 in training (S=%d dh=%d p=%g)", S, dh, p);
     NK_CHECK((long long)B * S * H * dh < (1ll << 31), "attention: the projection layout exceeds 2^31 elements");
     return NK_OK;
 }
 
-template <bool BWD>
-int attention_launch(nk_device* dev, AttnArgs& a, int B, int S, int H, double p, int train, uint64_t seed, uint64_t offset, float scale) {
-    a.S = S; a.H = H; a.ld = H * A_DH; a.nqb = (S + A_QB - 1) / A_QB; a.ntile = S / 32;
+template <bool BWD, int DH>
+int attention_launch_dh(nk_device* dev, AttnArgs& a, int B, int S, int H, double p, int train, uint64_t seed, uint64_t offset, float scale) {
+    a.S = S; a.H = H; a.ld = H * DH; a.nqb = (S + A_QB - 1) / A_QB; a.ntile = S / 32;
     a.scale = scale; a.c1 = scale * 1.44269504088896341f; a.keep = (float)(1.0 - p); a.dscale = 1.f / (1.f - (float)p);  // as nk_scale_softmax_dropout_fwd
     a.seed = seed; a.offset = offset;
     a.keep_lt = nk_keep_threshold(1.0 - p);   // Bernoulli::new(1. - p), node/dropout/mod.rs:46
     const bool masked = train && p != 0.0;
     const dim3 grid((unsigned)(B * H * a.nqb)), block(A_NT);
     const bool full = S % A_QB == 0;
-    // OCC = blocks per CU the register budget is sized for.  Three forward blocks fit by LDS (52 KB each) at <= 168 VGPRs:
-    // the masked forward then spills five registers and is still 5 % faster than two blocks at 200 VGPRs (1.42 vs 1.50 ms
-    // at C5); the backward holds 70 KB of LDS per block, two blocks per CU.
+    // OCC = blocks per CU the register budget is sized for.  DH = 64: three forward blocks fit by LDS (52 KB each) at <= 168
+    // VGPRs - the masked forward then spills a few registers and is still faster than two blocks without spills (1.36 vs
+    // 1.37 - 1.41 ms at C5, round 3) - and the backward holds 70 KB of LDS per block: two blocks per CU.  DH = 128: 85 / 103 KB
+    // of LDS and ~240 / ~290 registers per lane: one block per CU (a wave may then use the whole unified register file).
+    // DH = 32: the DH = 64 budgets.
     static const int occ_env = [] { const char* e = getenv("NK_ATTN_OCC"); return e ? atoi(e) : 0; }();   // tuning aid
-    constexpr int OCC_DEFAULT = BWD ? 2 : 3;
-    const int occ = BWD ? 2 : (occ_env == 2 || occ_env == 3 ? occ_env : OCC_DEFAULT);
+    constexpr int OCC_F = DH == 128 ? 1 : 3, OCC_B = DH == 128 ? 1 : 2;   // forward / backward blocks per CU
+    constexpr int OCC_DEFAULT = BWD ? OCC_B : OCC_F;
+    const bool occ2 = !BWD && DH != 128 && occ_env == 2;
 #define NK_ATT(M, F)                                                                                                       \
     do {                                                                                                                   \
         /* inference forward: KEEP = false (spelled `BWD`, false on the only path that reaches this line) */             \
-        if (!BWD && !a.scores) hipLaunchKernelGGL((attention_kernel<BWD, M, F, BWD ? 2 : 3, BWD>), grid, block, 0, dev->compute, a); \
-        else if (!BWD && occ == 3) hipLaunchKernelGGL((attention_kernel<BWD, M, F, BWD ? 2 : 3>), grid, block, 0, dev->compute, a); \
-        else hipLaunchKernelGGL((attention_kernel<BWD, M, F, 2>), grid, block, 0, dev->compute, a);                        \
+        if (!BWD && !a.scores) hipLaunchKernelGGL((attention_kernel<BWD, M, F, OCC_DEFAULT, BWD, DH>), grid, block, 0, dev->compute, a); \
+        else if (occ2) hipLaunchKernelGGL((attention_kernel<BWD, M, F, (DH == 128 ? 1 : 2), true, DH>), grid, block, 0, dev->compute, a); \
+        else hipLaunchKernelGGL((attention_kernel<BWD, M, F, OCC_DEFAULT, true, DH>), grid, block, 0, dev->compute, a);    \
     } while (0)
     if (masked && full) NK_ATT(true, true);
     else if (masked) NK_ATT(true, false);
@@ -416,12 +454,19 @@ int attention_launch(nk_device* dev, AttnArgs& a, int B, int S, int H, double p,
     return NK_OK;
 }
 
+template <bool BWD>
+int attention_launch(nk_device* dev, AttnArgs& a, int B, int S, int H, int dh, double p, int train, uint64_t seed, uint64_t offset, float scale) {
+    if (dh == 32) return attention_launch_dh<BWD, 32>(dev, a, B, S, H, p, train, seed, offset, scale);
+    if (dh == 128) return attention_launch_dh<BWD, 128>(dev, a, B, S, H, p, train, seed, offset, scale);
+    return attention_launch_dh<BWD, 64>(dev, a, B, S, H, p, train, seed, offset, scale);
+}
+
 }  // namespace
 
 extern "C" {
 
 int nk_attention_supported(int S, int dh, double p, int train) {
-    return dh == A_DH && S > 0 && S % 32 == 0 && !(train && 1.0 - p == 0.0);
+    return (dh == 32 || dh == 64 || dh == 128) && S > 0 && S % 32 == 0 && !(train && 1.0 - p == 0.0);
 }
 
 int nk_attention_fwd(nk_device* dev, const float* Q, const float* K, const float* V, float* scores, float* stats,
@@ -436,7 +481,7 @@ int nk_attention_fwd(nk_device* dev, const float* Q, const float* K, const float
     nk_prof_start(dev, NK_KERNEL_ATTENTION, 4.0 * B * H * (double)S * S * dh);
     AttnArgs a{};
     a.x1 = K; a.x2 = V; a.bq = Q; a.out = O; a.scores = scores; a.stats = stats; a.maskbits = mask_bits;
-    const int rc = attention_launch<false>(dev, a, B, S, H, p, train, seed, offset, scale);
+    const int rc = attention_launch<false>(dev, a, B, S, H, dh, p, train, seed, offset, scale);
     nk_prof_stop(dev);
     return rc;
 }
@@ -456,7 +501,7 @@ int nk_attention_bwd(nk_device* dev, float* dQ, float* dK, float* dV, float* dS,
     AttnArgs a{};
     a.x1 = V; a.x2 = K; a.bq = dO; a.ctx = O; a.out = dQ; a.scores = const_cast<float*>(scores); a.ds = dS; a.dropped = dropped;
     a.stats = const_cast<float*>(stats); a.maskbits = const_cast<uint32_t*>(mask_bits); a.assign = assign_dq ? 1 : 0;
-    int rc = attention_launch<true>(dev, a, B, S, H, p, train, 0, 0, scale);
+    int rc = attention_launch<true>(dev, a, B, S, H, dh, p, train, 0, 0, scale);
     nk_prof_stop(dev);
     if (rc) return rc;
     // dK_bh (+)= dS_bh^T . Q_bh and dV_bh (+)= Pd_bh^T . dO_bh: reductions over the queries, i.e. across the blocks above.

@@ -33,9 +33,8 @@ def _check(got, want64, want32, what, floor=0.0):
     assert err_gpu <= max(2 * err_cpu, 1e-6 * scale), (what, err_gpu, err_cpu, scale)   # SURVEY 8c (ii) as stated
 
 
-def _run(dev, B, S, H, p, train, seed, offset, assign, q, k, v, g, dq0):
+def _run(dev, B, S, H, p, train, seed, offset, assign, q, k, v, g, dq0, dh=64):
     c = capi()
-    dh = 64
     scale = float(np.float32(1.0 / np.sqrt(dh)))
     Q, K, V, G = (dev.array(t) for t in (q, k, v, g))
     scores, stats, out = dev.zeros((B * H, S, S)), dev.zeros((B * H, S, 2)), dev.zeros((B * S, H * dh))
@@ -50,14 +49,17 @@ def _run(dev, B, S, H, p, train, seed, offset, assign, q, k, v, g, dq0):
                 dropped=rows(dropped), dq=dQ.numpy(), dk=dK.numpy(), dv=dV.numpy()), (Q, K)
 
 
-@pytest.mark.parametrize("B,S,H", [(2, 128, 2), (1, 160, 3), (3, 32, 1), (1, 256, 2), (2, 96, 2), (1, 384, 1)])
+# head dimension 64 (C5) at six geometries; 32 and 128 (the kernels' other two instantiations: one / four output column tiles,
+# one / four staged float4 per thread and operand) at three each
+@pytest.mark.parametrize("B,S,H,dh", [(2, 128, 2, 64), (1, 160, 3, 64), (3, 32, 1, 64), (1, 256, 2, 64), (2, 96, 2, 64), (1, 384, 1, 64),
+                                       (2, 128, 2, 32), (1, 160, 3, 32), (1, 32, 1, 32), (2, 128, 2, 128), (1, 160, 3, 128), (1, 32, 1, 128)])
 @pytest.mark.parametrize("p,train", [(0.1, True), (0.0, True), (0.35, False), (0.5, True)])
-def test_attention_core_equals_oracle(dev, B, S, H, p, train):
+def test_attention_core_equals_oracle(dev, B, S, H, dh, p, train):
     c = capi()
-    dh, seed, offset = 64, 0x1234567890ABCDEF, 4242
+    seed, offset = 0x1234567890ABCDEF, 4242
     q, k, v, g = (rnd(s, (B * S, H * dh), -1, 1) for s in (1, 2, 3, 4))
     dq0 = rnd(9, (B * S, H * dh), -1, 1)
-    got, (Q, K) = _run(dev, B, S, H, p, train, seed, offset, False, q, k, v, g, dq0)
+    got, (Q, K) = _run(dev, B, S, H, p, train, seed, offset, False, q, k, v, g, dq0, dh)
     n = B * H * S * S
     masked = train and p != 0.0
     noise = O.dropout_noise(n, p, seed, offset).reshape(B * H, S, S) if masked else np.ones((B * H, S, S), np.float32)
@@ -89,19 +91,20 @@ def test_attention_core_equals_oracle(dev, B, S, H, p, train):
     soft = np.exp(z - z.max(2, keepdims=True)); soft /= soft.sum(2, keepdims=True)
     np.testing.assert_allclose(np.exp2(sc2 - m2[..., None]) * inv[..., None], soft, rtol=2e-5, atol=1e-9)
     # first-write form: dQ assigned, whatever the buffer held
-    got2, _ = _run(dev, B, S, H, p, train, seed, offset, True, q, k, v, g, dq0)
+    got2, _ = _run(dev, B, S, H, p, train, seed, offset, True, q, k, v, g, dq0, dh)
     assert np.array_equal(got2["dq"] + dq0, got["dq"]) or np.abs(got2["dq"] + dq0 - got["dq"]).max() <= 1e-6 * np.abs(dq0).max()
     _check(got2["dq"], ref["dq"], ref32["dq"], "dq (assigned)")
 
 
-def test_attention_core_mask_is_the_row_kernels_mask(dev):
+@pytest.mark.parametrize("dh", [64, 32, 128])
+def test_attention_core_mask_is_the_row_kernels_mask(dev, dh):
     """Same seed / offset -> the fused core drops exactly the elements nk_scale_softmax_dropout_fwd drops, and its output
     equals the node-by-node device path (batched GEMM -> fused probabilities -> batched GEMM) to f32 rounding."""
     c = capi()
-    B, S, H, dh, p, seed, offset = 2, 128, 2, 64, 0.2, 99, 17
-    scale = float(np.float32(0.125))
+    B, S, H, p, seed, offset = 2, 128, 2, 0.2, 99, 17
+    scale = float(np.float32(1.0 / np.sqrt(dh)))
     q, k, v, g = (rnd(s, (B * S, H * dh), -1, 1) for s in (11, 12, 13, 14))
-    got, (Q, K) = _run(dev, B, S, H, p, True, seed, offset, True, q, k, v, g, np.zeros((B * S, H * dh), np.float32))
+    got, (Q, K) = _run(dev, B, S, H, p, True, seed, offset, True, q, k, v, g, np.zeros((B * S, H * dh), np.float32), dh)
     V = dev.array(v)
     sc, pd, ctx = dev.zeros((B * H, S, S)), dev.zeros((B * H, S, S)), dev.zeros((B * S, H * dh))
     d, so, po, pi = H * dh, S * H * dh, H * S * S, S * S
@@ -113,13 +116,13 @@ def test_attention_core_mask_is_the_row_kernels_mask(dev):
     np.testing.assert_allclose(got["out"], ctx.numpy(), rtol=1e-4, atol=2e-6)
 
 
-@pytest.mark.parametrize("S,p", [(128, 0.2), (96, 0.0), (256, 0.4)])
-def test_attention_forward_without_kept_state_is_the_same_forward(dev, S, p):
+@pytest.mark.parametrize("S,p,dh", [(128, 0.2, 64), (96, 0.0, 64), (256, 0.4, 64), (128, 0.2, 32), (96, 0.3, 128)])
+def test_attention_forward_without_kept_state_is_the_same_forward(dev, S, p, dh):
     """Inference form (scores = stats = mask_bits = NULL: no (B*H, S, S) tensor exists): the output is bit-identical to
     the training-graph form's, dropout included (same Philox stream)."""
     c = capi()
-    B, H, dh, seed, offset = 2, 2, 64, 31337, 9
-    scale = float(np.float32(0.125))
+    B, H, seed, offset = 2, 2, 31337, 9
+    scale = float(np.float32(1.0 / np.sqrt(dh)))
     q, k, v = (rnd(s_, (B * S, H * dh), -1, 1) for s_ in (21, 22, 23))
     Q, K, V = dev.array(q), dev.array(k), dev.array(v)
     scores, stats, bits = dev.zeros((B * H, S, S)), dev.zeros((B * H, S, 2)), dev.zeros((B * H, S, S // 32))
@@ -151,12 +154,13 @@ def test_attention_core_is_deterministic_at_benchmark_width(dev):
 def test_attention_core_rejects_what_it_cannot_do(dev):
     c = capi()
     assert c.attention_supported(1024, 64, 0.1) and c.attention_supported(32, 64, 0.0)
-    assert not c.attention_supported(1024, 32, 0.1) and not c.attention_supported(100, 64, 0.1)
+    assert c.attention_supported(1024, 32, 0.1) and c.attention_supported(1024, 128, 0.1)
+    assert not c.attention_supported(1024, 96, 0.1) and not c.attention_supported(1024, 256, 0.1) and not c.attention_supported(100, 64, 0.1)
     assert not c.attention_supported(64, 64, 1.0, True) and c.attention_supported(64, 64, 1.0, False)
-    z = dev.zeros((64, 32))
+    z = dev.zeros((64, 96))
     sc, st = dev.zeros((1, 64, 64)), dev.zeros((1, 64, 2))
     with pytest.raises(RuntimeError, match="fused attention needs"):
-        c.attention_fwd(dev, z, z, z, sc, st, None, z, 1, 64, 1, 32, 0.1, 0.0)
+        c.attention_fwd(dev, z, z, z, sc, st, None, z, 1, 64, 1, 96, 0.1, 0.0)
     with pytest.raises(RuntimeError, match="Wrong probability"):
         c.attention_fwd(dev, z, z, z, sc, st, None, z, 1, 64, 1, 64, 0.1, 1.5)
     z64 = dev.zeros((64, 64))

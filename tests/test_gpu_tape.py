@@ -665,13 +665,14 @@ def test_mha_with_dropout_equals_oracle(nk, tdev, fused, strided, p):
 
 
 @pytest.mark.parametrize("core", [True, False])
-@pytest.mark.parametrize("p,S", [(0.1, 96), (0.0, 64), (0.3, 160)])
-def test_mha_fused_attention_core_equals_oracle(nk, tdev, core, p, S):
+@pytest.mark.parametrize("p,S,d,H", [(0.1, 96, 128, 2), (0.0, 64, 128, 2), (0.3, 160, 128, 2), (0.1, 96, 128, 4), (0.2, 64, 256, 2)])   # dh = 64, 64, 64, 32, 128
+def test_mha_fused_attention_core_equals_oracle(nk, tdev, core, p, S, d, H):
     """Head dimension 64 (the C5 geometry): the module routes scores -> probabilities -> context through the fused
     attention kernels (`fused_core`, one node instead of three).  Same check as above - the oracle composition fed the
     device's Philox mask, output, input gradient and all eight parameter gradients, two forwards (the mask is
-    resampled) - for the fused core and for the node-by-node path it replaces, which must also agree with each other."""
-    B, d, H = 2, 128, 2
+    resampled) - for the fused core and for the node-by-node path it replaces, which must also agree with each other.
+    Head dimensions 64 (the C5 geometry), 32 and 128: the three instantiations of the fused kernels."""
+    B = 2
     x, g = rnd(0, (B * S, d), -1, 1), rnd(5, (B * S, d), -1, 1)
     seed = 7654321
     nk.manual_seed(seed)
@@ -728,10 +729,11 @@ def test_heads_attention_node_without_gradients_keeps_nothing(nk, tdev):
     assert a.history_len() == 1
     a.forward(); b.forward()
     assert np.array_equal(a.data(), b.data())
-    assert nk.Var.attention_core_supported(1024, 64, 0.1) and not nk.Var.attention_core_supported(1024, 32, 0.1)
-    with pytest.raises(RuntimeError, match="dh == 64"):
-        nk.from_ndarray(tdev, rnd(4, (64, 64), -1, 1)).heads_attention(nk.from_ndarray(tdev, rnd(5, (64, 64), -1, 1)),
-                                                                        nk.from_ndarray(tdev, rnd(6, (64, 64), -1, 1)), 1, 64, 2, 32, 0.1, 0.0, st)
+    assert nk.Var.attention_core_supported(1024, 64, 0.1) and nk.Var.attention_core_supported(1024, 32, 0.1)
+    assert nk.Var.attention_core_supported(1024, 128, 0.1) and not nk.Var.attention_core_supported(1024, 16, 0.1)
+    with pytest.raises(RuntimeError, match="dh in"):
+        nk.from_ndarray(tdev, rnd(4, (64, 32), -1, 1)).heads_attention(nk.from_ndarray(tdev, rnd(5, (64, 32), -1, 1)),
+                                                                        nk.from_ndarray(tdev, rnd(6, (64, 32), -1, 1)), 1, 64, 2, 16, 0.1, 0.0, st)
 
 
 def test_backward_from_equals_weighted_sum_scaffolding(nk, tdev):
