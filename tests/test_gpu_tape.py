@@ -591,7 +591,7 @@ def test_mha_fused_equals_unfused_with_dropout(nk, tdev):
     outs = []
     for fused in (True, False):
         mha = nk.nn.MultiheadAttention(tdev, d, H, 0.0, 11)
-        mha.fused = fused
+        mha.fused, mha.fused_core = fused, False               # (the node-by-node paths: dh = 32 would take the fused core)
         X = nk.from_ndarray(tdev, x).requires_grad()
         loss = (mha.forward(X, B) * nk.from_ndarray(tdev, g)).sum()
         n_nodes = loss.history_len()
@@ -633,7 +633,7 @@ def test_mha_with_dropout_equals_oracle(nk, tdev, fused, strided, p):
     seed = 1234567
     nk.manual_seed(seed)
     mha = nk.nn.MultiheadAttention(tdev, d, H, p, 3)
-    mha.fused, mha.strided_heads = fused, strided
+    mha.fused, mha.strided_heads, mha.fused_core = fused, strided, False   # the paths BESIDE the fused core (tested below)
     X = nk.from_ndarray(tdev, x).requires_grad()
     y = mha.forward(X, B)
     G = nk.from_ndarray(tdev, g)
@@ -1038,7 +1038,7 @@ def test_mha_strided_heads_equals_split_merge(nk, tdev):
     outs = []
     for strided in (True, False):
         mha = nk.nn.MultiheadAttention(tdev, d, H, 0.0, 11)
-        mha.strided_heads = strided
+        mha.strided_heads, mha.fused_core = strided, False
         X = nk.from_ndarray(tdev, x).requires_grad()
         y = mha.forward(X, B)
         loss = (y * nk.from_ndarray(tdev, g)).sum()
