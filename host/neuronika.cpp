@@ -825,7 +825,8 @@ struct LinearBwd : Backward {
         BackwardHook* hook_w = parts_hook(dw.get());  // null unless this node is the last writer of dW and the hook wants pieces
         const int h = o / 2;
         const bool split = hook_w && o % 256 == 0 && (long long)(h / 128) * ((m + 127) / 128) >= 512;
-        if (split) {
+        static const bool separate_db = [] { const char* e = std::getenv("NK_LINEAR_SEPARATE_DB"); return e && e[0] == '1'; }();  // A/B aid
+        if (split || separate_db) {
             // the bias gradient first and on its own: the exchange sends the small gradients of the whole model as one
             // group as soon as the last of them is final - here, in front of the two weight-gradient GEMMs, not behind them
             const int gs[2] = {n, o};
@@ -834,7 +835,8 @@ struct LinearBwd : Backward {
             check((assign ? nk_unbroadcast_assign : nk_unbroadcast_add)(dev, d.ptr(), &o, 1, G.ptr(), gs, 2));
             if (BackwardHook* hook = parts_hook(db.get())) hook->grad_part_ready(db.get(), 0, (size_t)o);
             float* dwp = first_write(dw, beta);
-            for (int r0 = 0; r0 < o; r0 += h) {
+            if (!split) check(nk_sgemm(dev, 1, 0, o, m, n, 1.f, G.ptr(), o, x->ptr(), m, beta, dwp, m));
+            for (int r0 = 0; split && r0 < o; r0 += h) {
                 check(nk_sgemm(dev, 1, 0, h, m, n, 1.f, G.ptr() + r0, o, x->ptr(), m, beta, dwp + (size_t)r0 * m, m));
                 hook_w->grad_part_ready(dw.get(), (size_t)r0 * m, (size_t)h * m);
             }
