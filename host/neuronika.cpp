@@ -818,36 +818,33 @@ struct LinearBwd : Backward {
         // the whole model as one group while the last weight-gradient GEMMs still run), the weight gradient last
         float beta;  // nk_mm_t_bwd_left / nk_mm_t_bwd_right, with beta 0 when the gradient's zero fill is still pending
         if (dx) { float* d = first_write(dx, beta); check(nk_sgemm(dev, 0, 0, n, m, o, 1.f, G.ptr(), o, w->ptr(), m, beta, d, m)); }
-        // Data-parallel exchange at row-block granularity (only for the weight gradient the hook asks for - by default the
-        // one that becomes final last): each half of dW (still >= 512 tiles of 128x128, a full wave of resident blocks) goes
-        // to the all-reduce as soon as it is issued, so only half a gradient's exchange is left exposed behind the last
-        // GEMM of the backward pass.
-        BackwardHook* hook_w = parts_hook(dw.get());  // null unless this node is the last writer of dW and the hook wants pieces
-        const int h = o / 2;
-        const bool split = hook_w && o % 256 == 0 && (long long)(h / 128) * ((m + 127) / 128) >= 512;
-        static const bool separate_db = [] { const char* e = std::getenv("NK_LINEAR_SEPARATE_DB"); return e && e[0] == '1'; }();  // A/B aid
-        if (split || separate_db) {
-            // the bias gradient first and on its own: the exchange sends the small gradients of the whole model as one
-            // group as soon as the last of them is final - here, in front of the two weight-gradient GEMMs, not behind them
+        {
+            // (the bias gradient goes first and on its own: under the data-parallel hook the small gradients of the whole model
+            //  leave as one group as soon as the last of them is final - in front of this layer's weight-gradient GEMMs.
+            //  Summing it on the way in the weight-gradient GEMM - its A operand is G - was built and measured in round 3:
+            //  the 16 adds per k-tile cost the TN GEMM 4 %, more than the 12 us reduction they replace)
             const int gs[2] = {n, o};
             bool assign = false;
             HipArray& d = db->borrow_first_write(assign);
             check((assign ? nk_unbroadcast_assign : nk_unbroadcast_add)(dev, d.ptr(), &o, 1, G.ptr(), gs, 2));
             if (BackwardHook* hook = parts_hook(db.get())) hook->grad_part_ready(db.get(), 0, (size_t)o);
-            float* dwp = first_write(dw, beta);
-            if (!split) check(nk_sgemm(dev, 1, 0, o, m, n, 1.f, G.ptr(), o, x->ptr(), m, beta, dwp, m));
-            for (int r0 = 0; split && r0 < o; r0 += h) {
-                check(nk_sgemm(dev, 1, 0, h, m, n, 1.f, G.ptr() + r0, o, x->ptr(), m, beta, dwp + (size_t)r0 * m, m));
-                hook_w->grad_part_ready(dw.get(), (size_t)r0 * m, (size_t)h * m);
+        }
+        {
+            float* d = first_write(dw, beta);
+            BackwardHook* hook = parts_hook(dw.get());  // null unless this node is the last writer of dW and the hook wants pieces
+            // data-parallel exchange at row-block granularity (only for the weight gradient the hook asks for - by default
+            // the one that becomes final last): each half of dW (still >= 512 tiles of 128x128, a full wave of resident
+            // blocks) goes to the all-reduce as soon as it is issued, so only half a gradient's exchange is left exposed
+            // behind the last GEMM of the backward pass
+            const int h = o / 2;
+            if (hook && o % 256 == 0 && (long long)(h / 128) * ((m + 127) / 128) >= 512) {
+                for (int r0 = 0; r0 < o; r0 += h) {
+                    check(nk_sgemm(dev, 1, 0, h, m, n, 1.f, G.ptr() + r0, o, x->ptr(), m, beta, d + (size_t)r0 * m, m));
+                    hook->grad_part_ready(dw.get(), (size_t)r0 * m, (size_t)h * m);
+                }
+            } else {
+                check(nk_sgemm(dev, 1, 0, o, m, n, 1.f, G.ptr(), o, x->ptr(), m, beta, d, m));
             }
-        } else {
-            // MatrixMatrixMulTBackwardRight and AdditionBackwardRight in ONE pass over G: the weight-gradient GEMM's A operand
-            // is G, its column sums are the bias gradient (nk_linear_bwd_weight_bias) - no second read of G, no reduction
-            // launches (C4: 3 x 12 us, C5: 4 x 28 us per step)
-            bool assign_b = false;
-            HipArray& d = db->borrow_first_write(assign_b);
-            float* dwp = first_write(dw, beta);
-            check(nk_linear_bwd_weight_bias(dev, dwp, d.ptr(), G.ptr(), x->ptr(), n, m, o, 0, o, beta == 0.f ? 1 : 0, assign_b ? 1 : 0));
         }
     }
     void targets(std::vector<const Gradient*>& out) const override {

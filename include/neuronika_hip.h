@@ -161,16 +161,8 @@ int nk_mm_t_bwd_right(nk_device* dev, float* dB, const float* G, const float* A,
 /* `Linear::forward` neuronika-nn/src/lib.rs:425-447  Y(n,o) = X(n,m).W(o,m)^T + b(o): the MatrixMatrixMulT node
  * (matrix_matrix_mul_t/mod.rs:31-41) and the broadcast Addition node (addition/mod.rs:39-50) as ONE kernel - the
  * bias is added to the f32 accumulator in the GEMM epilogue, bit-identical to the two-node result.  Its backward is
- * nk_mm_t_bwd_left (dX += G.W), nk_mm_t_bwd_right (dW += G^T.X) and nk_unbroadcast_add (db += column sums of G) - or
- * nk_linear_bwd_weight_bias for the last two in one pass. */
+ * nk_mm_t_bwd_left (dX += G.W), nk_mm_t_bwd_right (dW += G^T.X) and nk_unbroadcast_add (db += column sums of G). */
 int nk_linear_fwd(nk_device* dev, const float* X, const float* W, const float* bias, float* Y, int n, int m, int o);
-/* nn::Linear's backward for its parameters in ONE pass over the output gradient G (n x o): rows [row0, row0 + rows) of
- * dW (+)= G^T . X  (MatrixMatrixMulTBackwardRight, node/matrix_matrix_mul_t/mod.rs:95-105) and the same rows of
- * db (+)= sum over the batch of G  (AdditionBackwardRight, node/addition/mod.rs:108-135: the un-broadcast sum) - the TN product's
- * A operand IS G, so its column sums ride along; a second read of G (67 MB per C4 layer) and its launch disappear.
- * assign_* != 0: first-write forms.  Deterministic (fixed-order partial sums). */
-int nk_linear_bwd_weight_bias(nk_device* dev, float* dW, float* db, const float* G, const float* X, int n, int m,
-                              int o, int row0, int rows, int assign_dw, int assign_db);
 
 /* ------------------------------------------------------------------ convolution -------- */
 /* N-d (nd = 1,2,3) cross-correlation without internal padding, NC[D]HW layout.

@@ -85,7 +85,6 @@ _SIGS = {
     "nk_mm_t_bwd_right": [VP, VP, VP, VP, C.c_int, C.c_int, C.c_int],
     "nk_linear_fwd": [VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int],
     "nk_conv_fwd": [VP, C.c_int, VP, c_intp, VP, c_intp, VP, c_intp, c_intp, C.c_int],
-    "nk_linear_bwd_weight_bias": [VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int],
     "nk_conv_bias_fwd": [VP, C.c_int, VP, c_intp, VP, c_intp, VP, VP, c_intp, c_intp, C.c_int],
     "nk_conv_bwd_input_assign": [VP, C.c_int, VP, c_intp, VP, VP, c_intp, c_intp, c_intp, C.c_int],
     "nk_conv_bwd_kernel_assign": [VP, C.c_int, VP, c_intp, VP, VP, c_intp, c_intp, c_intp, C.c_int],
@@ -404,13 +403,6 @@ def conv_bwd_kernel_bias(dev, dw, db, g, x, stride, dilation, groups=1, assign=(
     nd = x.ndim - 2
     check(lib.nk_conv_bwd_kernel_bias(dev.h, nd, dw.p, db.p, dw.shape_c(), g.p, x.p, x.shape_c(), ints(stride), ints(dilation), groups,
                                       int(assign[0]), int(assign[1])))
-
-
-def linear_bwd_weight_bias(dev, dW, db, G, X, row0=0, rows=None, assign=(False, False)):
-    """dW[row0:row0+rows] (+)= G^T.X and db[row0:row0+rows] (+)= column sums of G, one pass over G (n x o)."""
-    n, m, o = X.shape[0], X.shape[1], G.shape[1]
-    check(lib.nk_linear_bwd_weight_bias(dev.h, dW.p, db.p, G.p, X.p, n, m, o, row0, o - row0 if rows is None else rows,
-                                        int(assign[0]), int(assign[1])))
 
 
 def linear_fwd(dev, X, W, bias, Y):

@@ -40,10 +40,6 @@ struct GemmArgs {
     // row-major tile order so that one block writes whole 4 KB rows (no gain).
     int chunk;        // >= 1 tiles per block (1: one tile per block, the classic grid)
     int group_m;      // tile order: column-major inside groups of `group_m` tile rows (1: row-major, tn fastest)
-    // COLSUM instantiations (TN only): colsum[m] (+)= sum_k A[k][m] - nn::Linear's bias gradient (the A operand of its weight-
-    // gradient GEMM IS the output gradient) summed on the way by the column-tile-0 blocks; splits > 1: per-split partials
-    float* colsum;        // splits == 1: destination (length M);  splits > 1: slabs [splits][batch][M]
-    int colsum_assign;    // splits == 1 only: = instead of +=
     int pf2_min;      // reductions of at least this many k-tiles take the two-k-tile look-ahead loop
 };
 
@@ -97,9 +93,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
     });
 }
 
-template <bool TA, bool TB, bool ALIGNED, int TI, int TJ, bool COLSUM = false>
+template <bool TA, bool TB, bool ALIGNED, int TI, int TJ>
 __global__ __launch_bounds__(NT, (min_waves<TI, TJ, !TA && TB>())) void sgemm_kernel(GemmArgs p) {
-    static_assert(!COLSUM || (TA && !TB), "the column sum rides on a row-contiguous A operand (TN)");
     constexpr int BM = 64 * TI, BN = 64 * TJ;
     constexpr bool AKC = !TA;  // A (M x K): k-contiguous unless stored transposed
     constexpr bool BKC = TB;   // B (K x N) stored as N x K when transposed -> k-contiguous
@@ -125,22 +120,6 @@ __global__ __launch_bounds__(NT, (min_waves<TI, TJ, !TA && TB>())) void sgemm_ke
 
     f32x16 acc[TI][TJ];
     acc_zero<TI, TJ>(acc);
-    // COLSUM: a thread's staged A quads all cover the same four rows m (RC staging: idx -> k = idx / (BM/4), m-quad = idx % (BM/4),
-    // and 256 is a multiple of BM/4), so their component-wise sum over every k-tile is this thread's share of colsum[m..m+3].
-    // Added where the quads go to LDS anyway (behind the MFMAs: touching loaded registers earlier would wait for the loads).
-    float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
-#define NK_STORE_A(BUF, REGS)                                                                              \
-    do {                                                                                                   \
-        stage_store<AKC, BM>(BUF, REGS, t);                                                                \
-        if constexpr (COLSUM) {                                                                            \
-            cs.x += REGS.v0.x + REGS.v1.x; cs.y += REGS.v0.y + REGS.v1.y;                                  \
-            cs.z += REGS.v0.z + REGS.v1.z; cs.w += REGS.v0.w + REGS.v1.w;                                  \
-            if constexpr (BM == 128) {                                                                     \
-                cs.x += REGS.v2.x + REGS.v3.x; cs.y += REGS.v2.y + REGS.v3.y;                              \
-                cs.z += REGS.v2.z + REGS.v3.z; cs.w += REGS.v2.w + REGS.v3.w;                              \
-            }                                                                                              \
-        }                                                                                                  \
-    } while (0)
 
     Stage<BM / 32> ra;
     Stage<BN / 32> rb;
@@ -164,7 +143,7 @@ __global__ __launch_bounds__(NT, (min_waves<TI, TJ, !TA && TB>())) void sgemm_ke
     if (nt > 0) {
         pa = la.template load<ALIGNED>(t);
         pb = lb.template load<ALIGNED>(t);
-        NK_STORE_A(buf0, pa);
+        stage_store<AKC, BM>(buf0, pa, t);
         stage_store<BKC, BN>(buf0 + TA_FLOATS, pb, t);
     }
     __syncthreads();
@@ -176,14 +155,14 @@ __global__ __launch_bounds__(NT, (min_waves<TI, TJ, !TA && TB>())) void sgemm_ke
     for (; it + 3 < nt; it += 2) {
         qa = la.template load<ALIGNED>(t);  // tile it+2
         qb = lb.template load<ALIGNED>(t);
-        NK_STORE_A(buf1, pa);
+        stage_store<AKC, BM>(buf1, pa, t);
         stage_store<BKC, BN>(buf1 + TA_FLOATS, pb, t);
         __builtin_amdgcn_sched_barrier(0);
         mma_tile<AKC, BKC, TI, TJ>(buf0, buf0 + TA_FLOATS, acc, wr, wc, lane);
         __syncthreads();
         pa = la.template load<ALIGNED>(t);  // tile it+3
         pb = lb.template load<ALIGNED>(t);
-        NK_STORE_A(buf0, qa);
+        stage_store<AKC, BM>(buf0, qa, t);
         stage_store<BKC, BN>(buf0 + TA_FLOATS, qb, t);
         __builtin_amdgcn_sched_barrier(0);
         mma_tile<AKC, BKC, TI, TJ>(buf1, buf1 + TA_FLOATS, acc, wr, wc, lane);
@@ -195,14 +174,14 @@ __global__ __launch_bounds__(NT, (min_waves<TI, TJ, !TA && TB>())) void sgemm_ke
         qb = lb.template load<ALIGNED>(t);
     }
     if (left >= 2) {
-        NK_STORE_A(buf1, pa);
+        stage_store<AKC, BM>(buf1, pa, t);
         stage_store<BKC, BN>(buf1 + TA_FLOATS, pb, t);
     }
     if (left >= 1) mma_tile<AKC, BKC, TI, TJ>(buf0, buf0 + TA_FLOATS, acc, wr, wc, lane);
     if (left >= 2) {
         __syncthreads();
         if (left == 3) {
-            NK_STORE_A(buf0, qa);
+            stage_store<AKC, BM>(buf0, qa, t);
             stage_store<BKC, BN>(buf0 + TA_FLOATS, qb, t);
         }
         mma_tile<AKC, BKC, TI, TJ>(buf1, buf1 + TA_FLOATS, acc, wr, wc, lane);
@@ -217,7 +196,7 @@ __global__ __launch_bounds__(NT, (min_waves<TI, TJ, !TA && TB>())) void sgemm_ke
     if (nt > 0) {
         ra = la.template load<ALIGNED>(t);
         rb = lb.template load<ALIGNED>(t);
-        NK_STORE_A(smem, ra);
+        stage_store<AKC, BM>(smem, ra, t);
         stage_store<BKC, BN>(smem + TA_FLOATS, rb, t);
     }
     __syncthreads();
@@ -232,7 +211,7 @@ __global__ __launch_bounds__(NT, (min_waves<TI, TJ, !TA && TB>())) void sgemm_ke
             rb = lb.template load<ALIGNED>(t);
             __builtin_amdgcn_sched_barrier(0);
             mma_tile<AKC, BKC, TI, TJ>(cur, cur + TA_FLOATS, acc, wr, wc, lane);
-            NK_STORE_A(nxt, ra);
+            stage_store<AKC, BM>(nxt, ra, t);
             stage_store<BKC, BN>(nxt + TA_FLOATS, rb, t);
             __syncthreads();
             par ^= 1;
@@ -253,11 +232,11 @@ __global__ __launch_bounds__(NT, (min_waves<TI, TJ, !TA && TB>())) void sgemm_ke
         }
         if (more) {
             float* nxt = smem + (par ^ 1) * STAGE;
-            NK_STORE_A(nxt, ra);
+            stage_store<AKC, BM>(nxt, ra, t);
             stage_store<BKC, BN>(nxt + TA_FLOATS, rb, t);
         }
-        if (!more) break;  // the last (or only) tile's epilogue is the common one below
         gemm_epilogue<ALIGNED, TI, TJ>(p, acc, m0, n0, bo, bi, split, batch, wr, wc, lane);
+        if (!more) return;
         __syncthreads();  // the next tile's first k-tile is in LDS, everybody is done with the current buffer
         par ^= 1;
         acc_zero<TI, TJ>(acc);
@@ -266,41 +245,6 @@ __global__ __launch_bounds__(NT, (min_waves<TI, TJ, !TA && TB>())) void sgemm_ke
     }
     }
     gemm_epilogue<ALIGNED, TI, TJ>(p, acc, m0, n0, bo, bi, split, batch, wr, wc, lane);
-#undef NK_STORE_A
-    if constexpr (COLSUM) {
-        // (COLSUM launches run one tile per block and the look-ahead or the one-tile loop, both of which fall through to here)
-        if (tn != 0) return;               // block-uniform: only the first column tile of a tile row writes the sums
-        constexpr int QL = BM / 4;         // lanes that cover one k-row; threads t, t + QL, ... hold the same m-quad
-#pragma unroll
-        for (int o = QL; o < 64; o <<= 1) {
-            cs.x += __shfl_xor(cs.x, o, 64); cs.y += __shfl_xor(cs.y, o, 64);
-            cs.z += __shfl_xor(cs.z, o, 64); cs.w += __shfl_xor(cs.w, o, 64);
-        }
-        __syncthreads();                   // everybody is done with the last k-tile in LDS
-        float4* red = reinterpret_cast<float4*>(smem);
-        if (lane < QL) red[wid * QL + lane] = cs;
-        __syncthreads();
-        if (t < QL) {
-            const float4 a0 = red[t], a1 = red[QL + t], a2 = red[2 * QL + t], a3 = red[3 * QL + t];
-            float v[4] = {(a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y), (a0.z + a1.z) + (a2.z + a3.z),
-                          (a0.w + a1.w) + (a2.w + a3.w)};
-            float* dst = p.colsum + (p.splits > 1 ? ((long long)split * gridDim.z + batch) * p.M : 0);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int m = m0 + 4 * t + c;
-                if (m < p.M) dst[m] = (p.splits > 1 || p.colsum_assign) ? v[c] : dst[m] + v[c];
-            }
-        }
-    }
-}
-
-// colsum[m] (+)= sum over splits (fixed order) of the per-split column sums
-__global__ void colsum_reduce_kernel(float* __restrict__ out, const float* __restrict__ slabs, int M, int splits, int assign) {
-    const int m = blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= M) return;
-    float s = 0.f;
-    for (int k = 0; k < splits; ++k) s += slabs[(long long)k * M + m];
-    out[m] = assign ? s : out[m] + s;
 }
 
 // Second pass of split-K: C = alpha * sum_s slab[s] + beta * C, fixed summation order.
@@ -348,16 +292,6 @@ __global__ void splitk_reduce_flat_kernel(const float* __restrict__ slabs, float
 template <bool TA, bool TB, int TI, int TJ>
 static int launch_tile(nk_device* dev, const GemmArgs& p, int nbatch, bool aligned) {
     dim3 grid((p.tiles_m * p.tiles_n + p.chunk - 1) / p.chunk, p.splits, nbatch), block(NT);
-    if constexpr (TA && !TB) {
-        if (p.colsum) {  // nn::Linear's weight gradient with the bias gradient summed on the way (gemm_impl: chunk == 1)
-            if (aligned)
-                hipLaunchKernelGGL((sgemm_kernel<TA, TB, true, TI, TJ, true>), grid, block, 0, dev->compute, p);
-            else
-                hipLaunchKernelGGL((sgemm_kernel<TA, TB, false, TI, TJ, true>), grid, block, 0, dev->compute, p);
-            NK_LAUNCH_CHECK();
-            return NK_OK;
-        }
-    }
     if (aligned)
         hipLaunchKernelGGL((sgemm_kernel<TA, TB, true, TI, TJ>), grid, block, 0, dev->compute, p);
     else
@@ -377,10 +311,8 @@ static int launch(nk_device* dev, const GemmArgs& p, int nbatch, bool aligned, i
 static int gemm_impl(nk_device* dev, int transA, int transB, int M, int N, int K, float alpha,
                      const float* A, int lda, long long sAo, long long sAi, const float* B, int ldb,
                      long long sBo, long long sBi, float beta, float* C, int ldc, long long sCo,
-                     long long sCi, int batch_outer, int batch_inner, const float* bias = nullptr, float* colsum = nullptr,
-                     int colsum_assign = 0) {
+                     long long sCi, int batch_outer, int batch_inner, const float* bias = nullptr) {
     NK_USE(dev);
-    NK_CHECK(!colsum || (transA && !transB && batch_outer * batch_inner == 1), "column sums ride on a single TN product");
     NK_CHECK(M >= 0 && N >= 0 && K >= 0 && batch_outer >= 0 && batch_inner >= 0, "negative GEMM extent");
     const int nbatch = batch_outer * batch_inner;
     if (M == 0 || N == 0 || nbatch == 0) return NK_OK;
@@ -492,7 +424,6 @@ static int gemm_impl(nk_device* dev, int transA, int transB, int M, int N, int K
         if (c < 1 || kts >= 8) c = 1;
         if (force_chunk > 0) c = force_chunk;
         if (kts >= pf2_effective) c = 1;
-        if (colsum) c = 1;  // the column sums are written by the block of a tile row's first column tile
         p.chunk = (int)c;
     }
     p.group_m = force_group > 0 ? force_group : 8;
@@ -509,15 +440,12 @@ static int gemm_impl(nk_device* dev, int transA, int transB, int M, int N, int K
     // two waves per SIMD where 1024^3 has one - measured 78.7 vs 80.1 TFLOP/s and was dropped.)
     const int pf2_rule = ti * tj == 1 ? 8 : ((!transA && !transB) ? 32 : PF2_MIN_KTILES);
     p.pf2_min = force_pf2 > 0 ? force_pf2 : pf2_rule;
-    const size_t slab_bytes = p.splits > 1 ? ((size_t)p.splits * nbatch * M * N * sizeof(float) + 255) & ~size_t(255) : 0;
     if (p.splits > 1) {
         void* ws = nullptr;
-        int rc = nk_workspace(dev, slab_bytes + (colsum ? (size_t)p.splits * M * sizeof(float) : 0), &ws);
+        int rc = nk_workspace(dev, (size_t)p.splits * nbatch * M * N * sizeof(float), &ws);
         if (rc) return rc;
         p.slabs = (float*)ws;
     }
-    p.colsum = colsum ? (p.splits > 1 ? (float*)((char*)p.slabs + slab_bytes) : colsum) : nullptr;
-    p.colsum_assign = colsum_assign;
 
     const int BM = 64 * ti, BN = 64 * tj;
     const bool aligned = (M % BM == 0) && (N % BN == 0) && (K % BK == 0) && (lda % 4 == 0) &&
@@ -542,11 +470,6 @@ static int gemm_impl(nk_device* dev, int transA, int transB, int M, int N, int K
                            dev->compute, p.slabs, C, M, N, (long long)ldc, p.splits, nbatch, batch_inner,
                            sCo, sCi, alpha, beta, bias);
         NK_LAUNCH_CHECK();
-        if (colsum) {
-            hipLaunchKernelGGL(colsum_reduce_kernel, dim3((M + 255) / 256), dim3(256), 0, dev->compute, colsum, p.colsum, M, p.splits,
-                               colsum_assign);
-            NK_LAUNCH_CHECK();
-        }
     }
     return nk_prof_stop(dev);
 }
@@ -582,18 +505,6 @@ int nk_mm_t_fwd(nk_device* dev, const float* A, const float* B, float* C, int n,
 int nk_linear_fwd(nk_device* dev, const float* X, const float* W, const float* bias, float* Y, int n, int m, int o) {
     NK_CHECK(bias != nullptr, "null bias");
     return gemm_impl(dev, 0, 1, n, o, m, 1.f, X, m, 0, 0, W, m, 0, 0, 0.f, Y, o, 0, 0, 1, 1, bias);  // Y = X . W^T + b
-}
-// LinearBwd (host/neuronika.cpp): MatrixMatrixMulTBackwardRight (node/matrix_matrix_mul_t/mod.rs:95-105) for rows
-// [row0, row0 + rows) of the weight gradient and AdditionBackwardRight of the bias (node/addition/mod.rs:108-135, un-broadcast
-// sum over the batch) in ONE pass over the output gradient G (n x o): the TN product's A operand is G, its column sums are
-// the bias gradient.
-int nk_linear_bwd_weight_bias(nk_device* dev, float* dW, float* db, const float* G, const float* X, int n, int m, int o, int row0,
-                              int rows, int assign_dw, int assign_db) {
-    NK_CHECK(dW && db && G && X, "null pointer in nk_linear_bwd_weight_bias");
-    NK_CHECK(row0 >= 0 && rows >= 0 && row0 + rows <= o, "row block [%d, %d) outside the %d output features", row0, row0 + rows, o);
-    if (rows == 0) return NK_OK;
-    return gemm_impl(dev, 1, 0, rows, m, n, 1.f, G + row0, o, 0, 0, X, m, 0, 0, assign_dw ? 0.f : 1.f, dW + (size_t)row0 * m, m, 0, 0, 1, 1,
-                     nullptr, db + row0, assign_db ? 1 : 0);
 }
 int nk_mm_t_bwd_left(nk_device* dev, float* dA, const float* G, const float* B, int n, int m, int o) {
     return nk_sgemm(dev, 0, 0, n, m, o, 1.f, G, o, B, m, 1.f, dA, m);  // dA += G . B

@@ -1238,41 +1238,3 @@ def test_mlp_step_through_c_abi(dev):
     c.mm_t_bwd_right(dev, dW1, dZ1, X)
     close(dW1.numpy(), grads[0][0], 1e-4, 1e-6); close(dB1.numpy(), grads[0][1], 1e-4, 1e-6)
     close(dW2.numpy(), grads[1][0], 1e-4, 1e-6); close(dB2.numpy(), grads[1][1], 1e-4, 1e-6)
-
-
-# ------------------------------------------------------------------ Linear backward: dW and db in one pass over G
-@pytest.mark.parametrize("n,m,o", [(256, 384, 512), (4096, 1024, 1024), (32768, 256, 256), (100, 37, 75), (513, 260, 130), (64, 64, 64)])
-def test_linear_bwd_weight_bias_in_one_pass(dev, n, m, o):
-    """nk_linear_bwd_weight_bias: the weight gradient is BIT-identical to nk_mm_t_bwd_right's (the same TN product; the column
-    sums only ride along - unsplit, split-K, ragged and unaligned shapes), the bias gradient matches the oracle's un-broadcast
-    sum (AdditionBackwardRight) within the stated contraction tolerance; `+=` and first-write forms; row blocks (what the
-    data-parallel hand-over uses) compose to the whole."""
-    c = capi()
-    g, x = rnd(1, (n, o), -1, 1), rnd(2, (n, m), -1, 1)
-    dw0, db0 = rnd(3, (o, m), -1, 1), rnd(4, (o,), -1, 1)
-    G, X = dev.array(g), dev.array(x)
-    ref = dev.array(dw0)
-    c.mm_t_bwd_right(dev, ref, G, X)
-    DW, DB = dev.array(dw0), dev.array(db0)
-    c.linear_bwd_weight_bias(dev, DW, DB, G, X)
-    assert np.array_equal(DW.numpy(), ref.numpy())
-    s64 = g.astype(np.float64).sum(axis=0)
-    s32 = np.zeros(o, np.float32); O.accumulate(s32, g)
-    contraction_ok(DB.numpy().astype(np.float64) - db0, s32, s64, n, 1.0, 1.0)
-    DW2, DB2 = dev.full((o, m), np.nan), dev.full((o,), np.nan)          # first-write forms
-    c.linear_bwd_weight_bias(dev, DW2, DB2, G, X, assign=(True, True))
-    ref2 = dev.full((o, m), np.nan)
-    c.sgemm(dev, 1, 0, o, m, n, 1.0, G, o, X, m, 0.0, ref2, m)
-    assert np.array_equal(DW2.numpy(), ref2.numpy())
-    contraction_ok(DB2.numpy(), s32, s64, n, 1.0, 1.0)
-    DB3 = dev.full((o,), np.nan)                                          # run-to-run deterministic
-    c.linear_bwd_weight_bias(dev, dev.full((o, m), np.nan), DB3, G, X, assign=(True, True))
-    assert np.array_equal(DB2.numpy(), DB3.numpy())
-    if o % 2 == 0:                                                       # two row blocks
-        DW4, DB4 = dev.full((o, m), np.nan), dev.full((o,), np.nan)
-        c.linear_bwd_weight_bias(dev, DW4, DB4, G, X, 0, o // 2, assign=(True, True))
-        c.linear_bwd_weight_bias(dev, DW4, DB4, G, X, o // 2, o // 2, assign=(True, True))
-        contraction_ok(DW4.numpy(), ref2.numpy(), (g.astype(np.float64).T @ x.astype(np.float64)), n, 1.0, 1.0)
-        contraction_ok(DB4.numpy(), s32, s64, n, 1.0, 1.0)
-    with pytest.raises(c.NeuronikaHipError, match="row block"):
-        c.linear_bwd_weight_bias(dev, DW, DB, G, X, o - 1, 2)

@@ -454,10 +454,8 @@ def test_serde_wire_format(nk, tdev, golden):
 
 
 def test_linear_fused_equals_two_nodes(nk, tdev):
-    """nn::Linear as one node (bias in the GEMM epilogue; backward: input gradient GEMM, then weight and bias gradient in one
-    pass over the output gradient) gives bit-identical values, input and weight gradients to the reference's mm_t + Addition
-    nodes; the bias gradient is the same column sum of the output gradient added up in another order (it rides on the
-    weight-gradient GEMM's A operand): equal to f32 rounding."""
+    """nn::Linear as one node (bias in the GEMM epilogue, backward = the three reference accumulations) gives
+    bit-identical values and gradients to the reference's mm_t + Addition nodes, for Var and VarDiff inputs."""
     x = rnd(1, (96, 40), -1, 1)
     res = {}
     for fused in (True, False):
@@ -467,11 +465,8 @@ def test_linear_fused_equals_two_nodes(nk, tdev):
         s = (y * y).sum(); s.forward(); s.backward(1.0)
         assert y.history_len() == (3 if fused else 5)                 # backward nodes: 2 Linear + ReLU | 2x(mm_t, +) + ReLU
         res[fused] = [y.data()] + [p.grad() for p in (l1.weight, l1.bias, l2.weight, l2.bias)]
-    for i, (a, b) in enumerate(zip(res[True], res[False])):
-        if i in (2, 4):                                               # l1.bias, l2.bias
-            np.testing.assert_allclose(a, b, rtol=2e-6, atol=2e-6 * np.abs(b).max())
-        else:
-            assert np.array_equal(a, b)
+    for a, b in zip(res[True], res[False]):
+        assert np.array_equal(a, b)
 
 
 def test_losses_gemv_stack_graph(nk, tdev):
