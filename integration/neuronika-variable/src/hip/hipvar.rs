@@ -284,6 +284,19 @@ impl HipVar<Ix2> {
     }
 }
 
+impl HipVar<Ix2> {
+    /// `Var::mm_t(VarDiff)` (`var.rs:1081-1094`): only the right operand is differentiable, so only
+    /// `MatrixMatrixMulTBackwardRight` goes on the tape - the input layer of C4, whose input-gradient GEMM the reference never
+    /// runs either.
+    pub fn mm_t_diff(self, rhs: HipVarDiff<Ix2>) -> HipVarDiff<Ix2> {
+        let left_data = self.data.clone();
+        let var = self.mm_t(rhs.var);
+        let grad = Rc::new(Gradient::hip_zeros(var.data.borrow().dimension(), var.device()));
+        let op: Rc<dyn Backward> = Rc::new(MatrixMatrixMulTBackwardRight::new(left_data, rhs.grad.clone(), grad.clone()));
+        HipVarDiff::node(var, grad.clone(), (op, grad), rhs.history)
+    }
+}
+
 /// A differentiable variable with data and gradient in HBM (`VarDiff<D>`, `vardiff.rs:35-42`).
 pub struct HipVarDiff<D>
 where
