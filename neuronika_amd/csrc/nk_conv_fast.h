@@ -80,6 +80,18 @@ __device__ __forceinline__ int4 tap_position(const ConvGeom& g, int tap, int* kd
 // tap's position among the phases (a loop over the KK taps: nothing next to a global load).
 __global__ void conv_wq_tables_kernel(float* __restrict__ wq, const float* __restrict__ w, int4* __restrict__ tapd,
                                       BwdInPhase* __restrict__ phases, BwdInPhaseTable tbl, ConvGeom g) {
+    // every block works out the KK taps' positions among the phases ONCE (tap_position loops over the taps with four integer
+    // divisions per step: done per weight element it made this 74 K-element re-layout a 10 us launch at C3) and keeps them in LDS
+    constexpr int MAX_TAPS = 512;
+    __shared__ int4 tpos[MAX_TAPS];
+    const bool cached = g.KK <= MAX_TAPS;
+    if (cached) {
+        for (int tap = threadIdx.x; tap < g.KK; tap += blockDim.x) {
+            int kd[3];
+            tpos[tap] = tap_position(g, tap, kd);
+        }
+        __syncthreads();
+    }
     if (blockIdx.x == 0) {
         for (int tap = threadIdx.x; tap < g.KK; tap += blockDim.x) {
             int kd[3];
@@ -101,7 +113,7 @@ __global__ void conv_wq_tables_kernel(float* __restrict__ wq, const float* __res
         const int co = (int)(rem % g.Mg);
         const int grp = (int)(rem / g.Mg);
         int kd[3];
-        const int4 tp = tap_position(g, tap, kd);
+        const int4 tp = cached ? tpos[tap] : tap_position(g, tap, kd);
         const int chunk = co / BK, c32 = co - chunk * BK;
         wq[((long long)grp * g.Cg + ci) * ((long long)g.Mg * g.KK) + (long long)g.Mg * tp.x + (chunk * tp.y + tp.z) * BK + c32] = w[i];
     }
@@ -269,6 +281,20 @@ __global__ __launch_bounds__(NT, 2) void conv_fwd_fast_kernel(FastFwdArgs p) {
         });
 }
 
+// sum over the splits of one element of a split tail tile, in split order (the SAME order as a plain loop: deterministic and
+// bit-identical to it), four loads in flight at a time - the one-load-per-trip loop ran at 1.4 TB/s (17.7 us for 25 MB at C3)
+__device__ __forceinline__ float tail_split_sum(const float* __restrict__ e, int splits, int stride) {
+    float s = 0.f;
+    int k = 0;
+    for (; k + 4 <= splits; k += 4) {
+        const float a = e[(long long)k * stride], b = e[(long long)(k + 1) * stride], c = e[(long long)(k + 2) * stride],
+                    d = e[(long long)(k + 3) * stride];
+        s += a; s += b; s += c; s += d;
+    }
+    for (; k < splits; ++k) s += e[(long long)k * stride];
+    return s;
+}
+
 // Y[tail tiles] = sum over splits (fixed order) of the partial tiles (+ bias)
 template <int BM>
 __global__ void conv_fwd_tail_reduce_kernel(FastFwdArgs p) {
@@ -289,8 +315,7 @@ __global__ void conv_fwd_tail_reduce_kernel(FastFwdArgs p) {
         const int r = ee / BN, c = ee - r * BN;
         const int co = tm * BM + r, cc = tn * BN + c;
         if (co >= g.Mg || cc >= cols) continue;
-        float s = 0.f;
-        for (int k = 0; k < p.tail_splits; ++k) s += base[(long long)k * (BM * BN) + ee];
+        const float s = tail_split_sum(base + ee, p.tail_splits, BM * BN);
         const int rowid = cc / W4, cpos = cc - rowid * W4;
         if (cpos >= g.out[2]) continue;
         const int n = rowid / rows_per_n, l = (rowid - n * rows_per_n) * g.out[2] + cpos;
@@ -569,8 +594,7 @@ __global__ void conv_bwd_input_tail_reduce_kernel(FastBwdInArgs p) {
         if (ci >= g.Cg || cc >= cols) continue;
         const int rowid = cc / W4, cpos = cc - rowid * W4;
         if (cpos >= ph.count[2]) continue;  // padding column of the row
-        float s = 0.f;
-        for (int k = 0; k < p.tail_splits; ++k) s += base[(long long)k * (BM * BN) + ee];
+        const float s = tail_split_sum(base + ee, p.tail_splits, BM * BN);
         const int n = rowid / rows_per_n, ab = rowid - n * rows_per_n;
         const int i0 = ab / ph.count[1], i1 = ab - i0 * ph.count[1];
         float* d = p.dx + ((long long)n * g.Cin + ci) * g.uinplane +
