@@ -80,18 +80,6 @@ __device__ __forceinline__ int4 tap_position(const ConvGeom& g, int tap, int* kd
 // tap's position among the phases (a loop over the KK taps: nothing next to a global load).
 __global__ void conv_wq_tables_kernel(float* __restrict__ wq, const float* __restrict__ w, int4* __restrict__ tapd,
                                       BwdInPhase* __restrict__ phases, BwdInPhaseTable tbl, ConvGeom g) {
-    // every block works out the KK taps' positions among the phases ONCE (tap_position loops over the taps with four integer
-    // divisions per step: done per weight element it made this 74 K-element re-layout a 10 us launch at C3) and keeps them in LDS
-    constexpr int MAX_TAPS = 512;
-    __shared__ int4 tpos[MAX_TAPS];
-    const bool cached = g.KK <= MAX_TAPS;
-    if (cached) {
-        for (int tap = threadIdx.x; tap < g.KK; tap += blockDim.x) {
-            int kd[3];
-            tpos[tap] = tap_position(g, tap, kd);
-        }
-        __syncthreads();
-    }
     if (blockIdx.x == 0) {
         for (int tap = threadIdx.x; tap < g.KK; tap += blockDim.x) {
             int kd[3];
@@ -113,7 +101,7 @@ __global__ void conv_wq_tables_kernel(float* __restrict__ wq, const float* __res
         const int co = (int)(rem % g.Mg);
         const int grp = (int)(rem / g.Mg);
         int kd[3];
-        const int4 tp = cached ? tpos[tap] : tap_position(g, tap, kd);
+        const int4 tp = tap_position(g, tap, kd);
         const int chunk = co / BK, c32 = co - chunk * BK;
         wq[((long long)grp * g.Cg + ci) * ((long long)g.Mg * g.KK) + (long long)g.Mg * tp.x + (chunk * tp.y + tp.z) * BK + c32] = w[i];
     }
