@@ -7,6 +7,10 @@
 // loads issued before the MFMAs of the current tile and written to LDS behind them (one barrier
 // per k-tile), XCD-aware tile order, split-K with a deterministic second pass when M*N alone
 // cannot fill the chip.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
 #include "nk_mma.h"
 
 using namespace nkmma;
@@ -41,6 +45,7 @@ struct GemmArgs {
     int chunk;        // >= 1 tiles per block (1: one tile per block, the classic grid)
     int group_m;      // tile order: column-major inside groups of `group_m` tile rows (1: row-major, tn fastest)
     int pf2_min;      // reductions of at least this many k-tiles take the two-k-tile look-ahead loop
+    int kskew;        // k-pair blocks: group 1 runs half a k-tile out of phase with group 0
 };
 
 // C tile <- accumulators (or the split's slab).  Every load (bias, old C) is issued first and folded into the accumulators
@@ -93,15 +98,24 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
     });
 }
 
-template <bool TA, bool TB, bool ALIGNED, int TI, int TJ>
-__global__ __launch_bounds__(NT, (min_waves<TI, TJ, !TA && TB>())) void sgemm_kernel(GemmArgs p) {
+// KG = 2 ("k-pair"): a 512-thread block whose two groups of four waves each run this loop over one HALF of the block's
+// reduction, with their own LDS images, and add the two accumulator sets through LDS in a fixed order before the epilogue.
+// For grids of at most one 128x128 block per CU (2048^3: 256 tiles): a CU then holds two waves per SIMD - what a 4096^3
+// launch gets from two resident blocks - without split-K's slabs and second pass.  The two groups share the block's
+// barriers (same trip count); with `kskew` group 1 issues the first half of a k-tile's MFMAs BEFORE its staging stores, so
+// that the two waves of a SIMD are not in their staging phase at the same time.
+template <bool TA, bool TB, bool ALIGNED, int TI, int TJ, int KG = 1>
+__global__ __launch_bounds__(NT * KG, (min_waves<TI, TJ, !TA && TB>())) void sgemm_kernel(GemmArgs p) {
     constexpr int BM = 64 * TI, BN = 64 * TJ;
     constexpr bool AKC = !TA;  // A (M x K): k-contiguous unless stored transposed
     constexpr bool BKC = TB;   // B (K x N) stored as N x K when transposed -> k-contiguous
     constexpr int TA_FLOATS = tile_floats<AKC, BM>(), STAGE = TA_FLOATS + tile_floats<BKC, BN>();
-    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];  // <= 73,728 B at 128x128
+    static_assert(KG == 1 || (ALIGNED && 2 * 2 * STAGE >= BM * BN), "k-pair: aligned problems; a group's images hold half a C tile");
+    __shared__ __attribute__((aligned(16))) float smem_all[KG * 2 * STAGE];  // <= 73,728 B at 128x128 (k-pair: twice that)
 
-    const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    const int grp = KG == 2 ? (int)(threadIdx.x >> 8) : 0;  // NT == 256
+    const int t = KG == 2 ? (int)(threadIdx.x & (NT - 1)) : (int)threadIdx.x, lane = t & 63, wid = t >> 6;
+    float* const smem = smem_all + grp * 2 * STAGE;
     const int wr = wid >> 1, wc = wid & 1;
     // this block's tiles: positions [seq, seq_end) of the tile sequence (each XCD gets a contiguous range of chunks)
     int seq = xcd_chunk(blockIdx.x, gridDim.x) * p.chunk;
@@ -114,8 +128,12 @@ __global__ __launch_bounds__(NT, (min_waves<TI, TJ, !TA && TB>())) void sgemm_ke
     const float* A = p.A + bo * p.sAo + bi * p.sAi;
     const float* B = p.B + bo * p.sBo + bi * p.sBi;
 
-    const int kbeg = split * p.k_per_split;
-    const int kend = min(p.K, kbeg + p.k_per_split);
+    int kbeg = split * p.k_per_split;
+    int kend = min(p.K, kbeg + p.k_per_split);
+    if (KG == 2) {  // group g takes the g-th half; the host only asks for the pair when that is a whole number of k-tiles
+        const int half = (kend - kbeg) >> 1;
+        if (grp) kbeg += half; else kend = kbeg + half;
+    }
     const int nt = (kend - kbeg + BK - 1) / BK;
 
     f32x16 acc[TI][TJ];
@@ -131,7 +149,8 @@ __global__ __launch_bounds__(NT, (min_waves<TI, TJ, !TA && TB>())) void sgemm_ke
     // layout, from the per-layout / per-tile k-tile threshold the host passes in `pf2_min` (rules and their same-box
     // sweeps: gemm_impl).  This branch handles exactly ONE tile: gemm_impl sets chunk = 1 whenever nt >= pf2_min.
     constexpr bool PF2 = ALIGNED;
-    if (PF2 && nt >= p.pf2_min) {
+    const bool skew = KG == 2 && grp != 0 && p.kskew != 0;  // wave-uniform
+    if (PF2 && (KG == 2 || nt >= p.pf2_min)) {
     // Two k-tiles of look-ahead in registers: tile it+1 (P, loaded during the previous trip) goes to LDS at the START of a
     // trip, the loads of tile it+2 (Q) are issued in front of it and have a whole trip plus to land.  The end of a trip is
     // then MFMAs -> barrier, instead of MFMAs -> wait for this trip's own loads -> 8 LDS writes -> barrier.  Unrolled by
@@ -153,19 +172,29 @@ __global__ __launch_bounds__(NT, (min_waves<TI, TJ, !TA && TB>())) void sgemm_ke
     }
     int it = 0;  // invariant: tile `it` (even) is in buf0, tile it+1 in P
     for (; it + 3 < nt; it += 2) {
+        if (KG == 2 && skew) {
+            mma_tile<AKC, BKC, TI, TJ, 0, BK / 16>(buf0, buf0 + TA_FLOATS, acc, wr, wc, lane);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         qa = la.template load<ALIGNED>(t);  // tile it+2
         qb = lb.template load<ALIGNED>(t);
         stage_store<AKC, BM>(buf1, pa, t);
         stage_store<BKC, BN>(buf1 + TA_FLOATS, pb, t);
         __builtin_amdgcn_sched_barrier(0);
-        mma_tile<AKC, BKC, TI, TJ>(buf0, buf0 + TA_FLOATS, acc, wr, wc, lane);
+        if (KG == 2 && skew) mma_tile<AKC, BKC, TI, TJ, BK / 16, BK / 8>(buf0, buf0 + TA_FLOATS, acc, wr, wc, lane);
+        else mma_tile<AKC, BKC, TI, TJ>(buf0, buf0 + TA_FLOATS, acc, wr, wc, lane);
         __syncthreads();
+        if (KG == 2 && skew) {
+            mma_tile<AKC, BKC, TI, TJ, 0, BK / 16>(buf1, buf1 + TA_FLOATS, acc, wr, wc, lane);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         pa = la.template load<ALIGNED>(t);  // tile it+3
         pb = lb.template load<ALIGNED>(t);
         stage_store<AKC, BM>(buf0, qa, t);
         stage_store<BKC, BN>(buf0 + TA_FLOATS, qb, t);
         __builtin_amdgcn_sched_barrier(0);
-        mma_tile<AKC, BKC, TI, TJ>(buf1, buf1 + TA_FLOATS, acc, wr, wc, lane);
+        if (KG == 2 && skew) mma_tile<AKC, BKC, TI, TJ, BK / 16, BK / 8>(buf1, buf1 + TA_FLOATS, acc, wr, wc, lane);
+        else mma_tile<AKC, BKC, TI, TJ>(buf1, buf1 + TA_FLOATS, acc, wr, wc, lane);
         __syncthreads();
     }
     const int left = nt - it;  // 0 (nt == 0), 1, 2 or 3 tiles: `it` in buf0, it+1 in P
@@ -190,7 +219,7 @@ __global__ __launch_bounds__(NT, (min_waves<TI, TJ, !TA && TB>())) void sgemm_ke
             mma_tile<AKC, BKC, TI, TJ>(buf0, buf0 + TA_FLOATS, acc, wr, wc, lane);
         }
     }
-    } else {
+    } else if constexpr (KG == 1) {
     // One k-tile of look-ahead, over the block's whole chunk of tiles: the loads issued in front of the LAST MFMA block
     // of a tile are the first k-tile of the NEXT tile.
     if (nt > 0) {
@@ -244,6 +273,35 @@ __global__ __launch_bounds__(NT, (min_waves<TI, TJ, !TA && TB>())) void sgemm_ke
         m0 = tm2 * BM; n0 = tn2 * BN;
     }
     }
+    if constexpr (KG == 2) {
+        // acc(group 0: first half of the reduction) + acc(group 1: second half).  The groups SWAP halves of the tile through
+        // LDS - group g keeps its MFMA tile row g, sends the other row - so that all eight waves share the epilogue (half the
+        // old-C loads and C stores per lane; the sum is the same bits in either operand order).  Each group writes into its
+        // own images: [wave][column tile][quad][lane] float4, lane-contiguous 16-byte slots.
+        static_assert(TI == 2, "k-pair: 128-row tiles");
+        __syncthreads();  // every wave has read its last k-tile
+        float4* const mine_out = reinterpret_cast<float4*>(smem) + wid * (TJ * 4 * 64) + lane;
+        const float4* const theirs_in = reinterpret_cast<const float4*>(smem_all + (grp ^ 1) * 2 * STAGE) + wid * (TJ * 4 * 64) + lane;
+        f32x16 keep[1][TJ];
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            const f32x16 send = grp ? acc[0][j] : acc[1][j];
+            keep[0][j] = grp ? acc[1][j] : acc[0][j];
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4)
+                mine_out[(j * 4 + q4) * 64] = make_float4(send[4 * q4], send[4 * q4 + 1], send[4 * q4 + 2], send[4 * q4 + 3]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const float4 v = theirs_in[(j * 4 + q4) * 64];
+                keep[0][j][4 * q4] += v.x; keep[0][j][4 * q4 + 1] += v.y; keep[0][j][4 * q4 + 2] += v.z; keep[0][j][4 * q4 + 3] += v.w;
+            }
+        gemm_epilogue<ALIGNED, 1, TJ>(p, keep, m0, n0, bo, bi, split, batch, wr * 2 + grp, wc, lane);
+        return;
+    }
     gemm_epilogue<ALIGNED, TI, TJ>(p, acc, m0, n0, bo, bi, split, batch, wr, wc, lane);
 }
 
@@ -289,9 +347,40 @@ __global__ void splitk_reduce_flat_kernel(const float* __restrict__ slabs, float
 }
 
 
+// An override variable's integers, parsed when its TEXT changes (one getenv + strcmp per GEMM call, no sscanf): the
+// benchmarks set the variable before the process starts, the tests flip it between calls.  Per thread: no shared state.
+struct EnvInts { int n, v[6]; };
+struct EnvCache {
+    const char* name;
+    bool seen = false;
+    char text[96] = {0};
+    EnvInts val{0, {0, 0, 0, 0, 0, 0}};
+    explicit EnvCache(const char* n) : name(n) {}
+    const EnvInts& get() {
+        const char* e = getenv(name);
+        if (!e) e = "";
+        if (!seen || strncmp(e, text, sizeof(text) - 1) != 0) {
+            seen = true;
+            strncpy(text, e, sizeof(text) - 1);
+            val = EnvInts{0, {0, 0, 0, 0, 0, 0}};
+            const int n = sscanf(text, "%d,%d,%d,%d,%d,%d", &val.v[0], &val.v[1], &val.v[2], &val.v[3], &val.v[4], &val.v[5]);
+            val.n = n > 0 ? n : 0;
+        }
+        return val;
+    }
+};
+static thread_local EnvCache env_force("NK_GEMM_FORCE"), env_kpair("NK_GEMM_KPAIR");
+
 template <bool TA, bool TB, int TI, int TJ>
-static int launch_tile(nk_device* dev, const GemmArgs& p, int nbatch, bool aligned) {
-    dim3 grid((p.tiles_m * p.tiles_n + p.chunk - 1) / p.chunk, p.splits, nbatch), block(NT);
+static int launch_tile(nk_device* dev, const GemmArgs& p, int nbatch, bool aligned, int kg = 1) {
+    dim3 grid((p.tiles_m * p.tiles_n + p.chunk - 1) / p.chunk, p.splits, nbatch), block(NT * kg);
+    if constexpr (TI * TJ == 4) {
+        if (kg == 2) {  // gemm_impl: aligned, one tile per block
+            hipLaunchKernelGGL((sgemm_kernel<TA, TB, true, TI, TJ, 2>), grid, block, 0, dev->compute, p);
+            NK_LAUNCH_CHECK();
+            return NK_OK;
+        }
+    }
     if (aligned)
         hipLaunchKernelGGL((sgemm_kernel<TA, TB, true, TI, TJ>), grid, block, 0, dev->compute, p);
     else
@@ -301,8 +390,8 @@ static int launch_tile(nk_device* dev, const GemmArgs& p, int nbatch, bool align
 }
 
 template <bool TA, bool TB>
-static int launch(nk_device* dev, const GemmArgs& p, int nbatch, bool aligned, int ti, int tj) {
-    if (ti == 2 && tj == 2) return launch_tile<TA, TB, 2, 2>(dev, p, nbatch, aligned);
+static int launch(nk_device* dev, const GemmArgs& p, int nbatch, bool aligned, int ti, int tj, int kg) {
+    if (ti == 2 && tj == 2) return launch_tile<TA, TB, 2, 2>(dev, p, nbatch, aligned, kg);
     if (ti == 2 && tj == 1) return launch_tile<TA, TB, 2, 1>(dev, p, nbatch, aligned);
     if (ti == 1 && tj == 2) return launch_tile<TA, TB, 1, 2>(dev, p, nbatch, aligned);
     return launch_tile<TA, TB, 1, 1>(dev, p, nbatch, aligned);
@@ -385,14 +474,9 @@ static int gemm_impl(nk_device* dev, int transA, int transB, int M, int N, int K
     p.tiles_m = (M + 64 * ti - 1) / (64 * ti);
     p.tiles_n = (N + 64 * tj - 1) / (64 * tj);
     int force_chunk = 0, force_group = 0, force_pf2 = 0;
-    // tuning sweeps (benchmarks/ab_force.py): NK_GEMM_FORCE="ti,tj,splits[,chunk[,group_m[,lookahead_min]]]" overrides the
-    // rules; parsed once per process
-    struct Force { int n, v[6]; };
-    static const Force force = [] {
-        Force f{0, {0, 0, 0, 0, 0, 0}};
-        if (const char* e = getenv("NK_GEMM_FORCE")) f.n = sscanf(e, "%d,%d,%d,%d,%d,%d", &f.v[0], &f.v[1], &f.v[2], &f.v[3], &f.v[4], &f.v[5]);
-        return f;
-    }();
+    // tuning sweeps (benchmarks/ab_force.py) and the parity tests that pit one schedule against another in ONE process:
+    // NK_GEMM_FORCE="ti,tj,splits[,chunk[,group_m[,lookahead_min]]]" overrides the rules
+    const EnvInts& force = env_force.get();
     if (force.n >= 3 && (force.v[0] == 1 || force.v[0] == 2) && (force.v[1] == 1 || force.v[1] == 2)) {
         ti = force.v[0]; tj = force.v[1]; splits = force.v[2] < 1 ? 1 : force.v[2];
         p.tiles_m = (M + 64 * ti - 1) / (64 * ti);
@@ -451,12 +535,27 @@ static int gemm_impl(nk_device* dev, int transA, int transB, int M, int N, int K
     const bool aligned = (M % BM == 0) && (N % BN == 0) && (K % BK == 0) && (lda % 4 == 0) &&
                          (ldb % 4 == 0) && aligned16(A) && aligned16(B) && (sAo % 4 == 0) &&
                          (sAi % 4 == 0) && (sBo % 4 == 0) && (sBi % 4 == 0);
+    // k-pair blocks (sgemm_kernel, KG = 2): 128x128 tiles, aligned, one tile per block, a whole number of k-tile pairs per
+    // block, and a grid of at most one block per CU - with more blocks than CUs two 256-thread blocks share a CU anyway.
+    // NK_GEMM_KPAIR = 0 (never) / 1 (lock-step groups) / 2 (group 1 half a k-tile out of phase) overrides for sweeps.
+    const EnvInts& kp = env_kpair.get();
+    const int kpair_env = kp.n >= 1 ? kp.v[0] : -1;
+    int kg = 1;
+    p.kskew = 1;
+    {
+        const long long nblk = (long long)p.tiles_m * p.tiles_n * p.splits * nbatch;
+        const bool can = ti * tj == 4 && aligned && p.chunk == 1 && kts % 2 == 0 && kts >= 8 && K % (2 * BK) == 0 &&
+                         (p.splits == 1 || p.k_per_split * p.splits == K);
+        const bool want = kpair_env >= 0 ? kpair_env > 0 : nblk <= 256 && kts >= 32;
+        if (can && want) kg = 2;
+        if (kpair_env == 1) p.kskew = 0;
+    }
     int rc = nk_prof_start(dev, NK_KERNEL_SGEMM, 2.0 * M * N * (double)K * nbatch);
     if (rc) return rc;
-    if (!transA && !transB) rc = launch<false, false>(dev, p, nbatch, aligned, ti, tj);
-    else if (!transA && transB) rc = launch<false, true>(dev, p, nbatch, aligned, ti, tj);
-    else if (transA && !transB) rc = launch<true, false>(dev, p, nbatch, aligned, ti, tj);
-    else rc = launch<true, true>(dev, p, nbatch, aligned, ti, tj);
+    if (!transA && !transB) rc = launch<false, false>(dev, p, nbatch, aligned, ti, tj, kg);
+    else if (!transA && transB) rc = launch<false, true>(dev, p, nbatch, aligned, ti, tj, kg);
+    else if (transA && !transB) rc = launch<true, false>(dev, p, nbatch, aligned, ti, tj, kg);
+    else rc = launch<true, true>(dev, p, nbatch, aligned, ti, tj, kg);
     if (rc) return rc;
     if (p.splits > 1) {
         const long long total = (long long)M * N * nbatch;

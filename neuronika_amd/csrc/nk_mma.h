@@ -170,18 +170,20 @@ __device__ __forceinline__ void frag_read(float (&f)[4], const float* Xs, int ro
 
 // Fragments of k-group g+1 are read from LDS BEFORE the MFMAs of group g are issued (the
 // sched_barrier pins that order), so the ds_read latency hides under the MFMA cycles.
-template <bool AKC, bool BKC, int TI, int TJ>
+// [G0, G1): the k-groups (8 k each) of the staged tile this call covers - the whole tile by default; the k-pair GEMM's
+// second wave group issues a tile in two halves around its staging stores.
+template <bool AKC, bool BKC, int TI, int TJ, int G0 = 0, int G1 = BK / 8>
 __device__ __forceinline__ void mma_tile(const float* As, const float* Bs, f32x16 (&acc)[TI][TJ], int wr, int wc,
                                          int lane) {
     float a[2][TI][4], b[2][TJ][4];  // [buffer][tile][step]
 #pragma unroll
-    for (int i = 0; i < TI; ++i) frag_read<AKC, 64 * TI>(a[0][i], As, (wr * TI + i) * 32, 0, lane);
+    for (int i = 0; i < TI; ++i) frag_read<AKC, 64 * TI>(a[G0 & 1][i], As, (wr * TI + i) * 32, G0 * 8, lane);
 #pragma unroll
-    for (int j = 0; j < TJ; ++j) frag_read<BKC, 64 * TJ>(b[0][j], Bs, (wc * TJ + j) * 32, 0, lane);
+    for (int j = 0; j < TJ; ++j) frag_read<BKC, 64 * TJ>(b[G0 & 1][j], Bs, (wc * TJ + j) * 32, G0 * 8, lane);
 #pragma unroll
-    for (int g = 0; g < BK / 8; ++g) {
+    for (int g = G0; g < G1; ++g) {
         const int cb = g & 1, nb = cb ^ 1;
-        if (g + 1 < BK / 8) {
+        if (g + 1 < G1) {
 #pragma unroll
             for (int i = 0; i < TI; ++i) frag_read<AKC, 64 * TI>(a[nb][i], As, (wr * TI + i) * 32, (g + 1) * 8, lane);
 #pragma unroll

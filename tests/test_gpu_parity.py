@@ -445,6 +445,69 @@ def test_sgemm_lookahead_loop_is_bit_identical(dev, ta, tb, tiles):
         os.environ.pop("NK_GEMM_FORCE", None)
 
 
+def test_gemm_override_variable_is_live(dev):
+    """The schedule tests above flip NK_GEMM_FORCE between calls of ONE process: the library must notice (it parses the variable
+    when its text changes).  Split-K 4 sums in another order than the unsplit product - different bits on random data."""
+    import os
+    c = capi()
+    M = N = 256
+    K = 1024
+    a, b = rnd(70, (M, K), -1, 1), rnd(71, (N, K), -1, 1)
+    A, B = dev.array(a), dev.array(b)
+    outs = {}
+    try:
+        for force in ("2,2,1", "2,2,4", "2,2,1"):
+            os.environ["NK_GEMM_FORCE"] = force
+            Cd = dev.zeros((M, N))
+            c.sgemm(dev, 0, 1, M, N, K, 1.0, A, K, B, K, 0.0, Cd, N)
+            outs.setdefault(force, []).append(Cd.numpy())
+    finally:
+        os.environ.pop("NK_GEMM_FORCE", None)
+    assert np.array_equal(outs["2,2,1"][0], outs["2,2,1"][1])
+    assert not np.array_equal(outs["2,2,1"][0], outs["2,2,4"][0])
+
+
+@pytest.mark.parametrize("ta,tb", [(0, 1), (0, 0), (1, 0), (1, 1)])
+def test_sgemm_kpair_blocks(dev, ta, tb):
+    """k-pair blocks (nk_gemm.hip, KG = 2: 512 threads, two wave groups on the two halves of the reduction, accumulators added
+    through LDS): group 0 + group 1 is the sum split-K 2's second pass forms, so the result must be BIT-identical to the
+    forced split-K 2 launch of plain blocks - for every layout, reductions whose halves hit every tail case of the
+    look-ahead loop, batches, alpha / beta; lock-step and skewed groups give the same bits; and it matches the f64 oracle."""
+    import os
+    c = capi()
+    M, N, nb = 256, 384, 2
+    try:
+        for K in (256, 320, 384, 448, 512, 2048):
+            a = rnd(80 + K, (nb, K, M) if ta else (nb, M, K), -1, 1)
+            b = rnd(81 + K, (nb, N, K) if tb else (nb, K, N), -1, 1)
+            c0 = rnd(82, (nb, M, N), -1, 1)
+            A, B = dev.array(a), dev.array(b)
+            lda, ldb = a.shape[2], b.shape[2]
+            sa, sb, sc = a.shape[1] * lda, b.shape[1] * ldb, M * N
+            for alpha, beta in ((1.0, 0.0), (-1.5, 0.5)):
+                outs = {}
+                for name, force, pair in (("split2", "2,2,2", "0"), ("pair", "2,2,1", "1"), ("pair_skewed", "2,2,1", "2"),
+                                          ("pair_skewed_again", "2,2,1", "2"), ("split2_pair", "2,2,2", "2")):
+                    if name == "split2_pair" and (K // 32) % 4 != 0:
+                        continue
+                    os.environ["NK_GEMM_FORCE"], os.environ["NK_GEMM_KPAIR"] = force, pair
+                    Cd = dev.array(c0)
+                    c.sgemm_batched(dev, ta, tb, M, N, K, alpha, A, lda, 0, sa, B, ldb, 0, sb, beta, Cd, N, 0, sc, 1, nb)
+                    outs[name] = Cd.numpy()
+                assert np.array_equal(outs["pair"], outs["split2"]), (K, alpha)
+                assert np.array_equal(outs["pair_skewed"], outs["split2"]), (K, alpha)
+                assert np.array_equal(outs["pair_skewed_again"], outs["pair_skewed"]), (K, alpha)
+                opa = (a.transpose(0, 2, 1) if ta else a).astype(np.float64)
+                opb = (b.transpose(0, 2, 1) if tb else b).astype(np.float64)
+                want = alpha * (opa @ opb) + beta * c0
+                for name in ("pair_skewed", "split2_pair"):
+                    if name in outs:
+                        contraction_ok(outs[name], want.astype(np.float32), want, K, 1.5, 1.0)
+    finally:
+        os.environ.pop("NK_GEMM_FORCE", None)
+        os.environ.pop("NK_GEMM_KPAIR", None)
+
+
 def test_sgemm_large_rowsum_identity(dev):
     """Size-independent check at the BASELINE size (4096^2): (A.B).1 == A.(B.1)."""
     c = capi()
