@@ -23,17 +23,20 @@ def main():
     Q, K, V, G = mk(), mk(), mk(), mk()
     big = lambda: dev.zeros((B * H, S, S))
     scores, probs_d, dP, dS = big(), big(), big(), big()
-    stats, out, dQ = dev.zeros((B * H, S, 2)), dev.zeros((B * S, H * dh)), dev.zeros((B * S, H * dh))
+    SP = c.attention_padded(S)   # the fused core's scratch tensors are whole 32 x 32 tiles (ragged S: its own, padded set)
+    fbig = lambda: dev.zeros((B * H, SP, SP))
+    f_scores, f_pd, f_ds = (scores, probs_d, dS) if SP == S else (fbig(), fbig(), fbig())
+    stats, out, dQ = dev.zeros((B * H, SP, 2)), dev.zeros((B * S, H * dh)), dev.zeros((B * S, H * dh))
     dK, dV = dev.zeros((B * S, H * dh)), dev.zeros((B * S, H * dh))
-    bits = dev.zeros((B * H, S, S // 32))
+    bits = dev.zeros((B * H, SP, SP // 32))
     d, so, po, pi = H * dh, S * H * dh, H * S * S, S * S
     flop = 4.0 * B * H * S * S * dh
 
     def fused_fwd():
-        c.attention_fwd(dev, Q, K, V, scores, stats, bits, out, B, S, H, dh, scale, p, True, seed, 0)
+        c.attention_fwd(dev, Q, K, V, f_scores, stats, bits, out, B, S, H, dh, scale, p, True, seed, 0)
 
     def fused_bwd():
-        c.attention_bwd(dev, dQ, dK, dV, dS, probs_d, G, out, scores, stats, bits, Q, K, V, B, S, H, dh, scale, p, True, (True, True, True))
+        c.attention_bwd(dev, dQ, dK, dV, f_ds, f_pd, G, out, f_scores, stats, bits, Q, K, V, B, S, H, dh, scale, p, True, (True, True, True))
 
     def nodes_fwd():
         c.sgemm_batched(dev, 0, 1, S, S, dh, 1.0, Q, d, so, dh, K, d, so, dh, 0.0, scores, S, po, pi, B, H)

@@ -741,7 +741,8 @@ struct HeadsAttentionFwd : Forward {
     uint64_t seed;
     Shared<uint64_t> calls;  // each forward draws a fresh mask (the Philox offset advances), as AttnProbsFwd
     void forward() const override {
-        const uint64_t offset = (*calls) * (((uint64_t)hg.B * hg.H * hg.S * hg.S + 7) / 8);  // (B*H, S, S) draws per forward, 8 per Philox call
+        const uint64_t sp = ((uint64_t)hg.S + 31) / 32 * 32;  // the draws are indexed in the padded (B*H, SP, SP) tensor (SP = S unless S is ragged)
+        const uint64_t offset = (*calls) * (((uint64_t)hg.B * hg.H * sp * sp + 7) / 8);  // draws per forward, 8 per Philox call
         ++(*calls);
         // scores / stats / mask are null in a graph without gradients: nothing is kept, no (B*H, S, S) tensor exists
         check(nk_attention_fwd(D(q), q->ptr(), k->ptr(), v->ptr(), scores ? scores->ptr() : nullptr, stats ? stats->ptr() : nullptr,
@@ -1208,16 +1209,17 @@ static Var heads_attention_node(const Var& q, const Var& keys, const Var& values
     check_heads(q.shape(), {}, B, S, H, dh, false);
     check_heads(keys.shape(), {}, B, S, H, dh, false);
     check_heads(values.shape(), {}, B, S, H, dh, false);
-    if (!Var::attention_core_supported(S, dh, p)) panic("heads_attention: the fused kernels take dh in {32, 64, 128}, S % 32 == 0 and p < 1");
+    if (!Var::attention_core_supported(S, dh, p)) panic("heads_attention: the fused kernels take dh in {32, 64, 128} and p < 1");
     History<ForwardEntry> h = q.history;
     h.merge(keys.history);
     h.merge(values.history);
     auto op = std::make_shared<HeadsAttentionFwd>();
     op->hg = {B, S, H, dh}; op->q = q.data; op->k = keys.data; op->v = values.data;
     if (keep) {  // what the backward node reads; a graph without gradients keeps nothing
-        op->scores = zeros_like(q.data, Shape{B * H, S, S});
-        op->stats = zeros_like(q.data, Shape{B * H, S, 2});
-        op->mask = zeros_like(q.data, Shape{B * H, S, S / 32});
+        const int SP = (S + 31) / 32 * 32;  // the scratch tensors are padded to whole 32 x 32 tiles (include/neuronika_hip.h)
+        op->scores = zeros_like(q.data, Shape{B * H, SP, SP});
+        op->stats = zeros_like(q.data, Shape{B * H, SP, 2});
+        op->mask = zeros_like(q.data, Shape{B * H, SP, SP / 32});
     }
     op->o = zeros_like(q.data, Shape{B * S, H * dh});
     op->scale = scale; op->p = p; op->status = std::move(status);

@@ -568,7 +568,7 @@ struct MultiheadAttention {
     Dropout drop;
     bool fused = true;  // scale + softmax + dropout as one node (false: three reference nodes)
     bool strided_heads = true;  // attention GEMMs read Q/K/V and write O in the projection layout (false: split/merge copies)
-    bool fused_core = true;     // scores -> probabilities -> context as one node on the fused attention kernels (dh = 64, S % 32 = 0)
+    bool fused_core = true;     // scores -> probabilities -> context as one node on the fused attention kernels (dh in {32, 64, 128}, any S)
     MultiheadAttention(DevicePtr dev, int d_model, int heads, double p, uint64_t seed);
     VarDiff forward(const VarDiff& x, int batch) const;  // x: (batch*seq, d_model)
 };

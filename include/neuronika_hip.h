@@ -404,22 +404,26 @@ int nk_scale_softmax_dropout_bwd_from_scores(nk_device* dev, float* d_scores, co
  * Softmax node/softmax/mod.rs:37-53, Dropout node/dropout/mod.rs:53-79, MatrixMatrixMul node/matrix_matrix_mul/mod.rs:31-41):
  *   S_bh = Q_bh.K_bh^T ; P = softmax(S*scale, axis 1) ; Pd = dropout(P) ; O_bh = Pd.V_bh
  * Q, K, V, O, dO, dQ are the (B*S) x (H*dh) projection layout (head h = columns h*dh .. h*dh+dh-1, sample b = rows
- * b*S ..); scores / dS / dropped are (B*H, S, S); stats is (B*H, S, 2) = (m2, 1 / sum_k exp2(S*c1 - m2)) per row with
+ * b*S ..); scores / dS / dropped are (B*H, SP, SP) with SP = S rounded up to a multiple of 32 (row stride SP; the entries of
+ * rows / columns >= S are scratch: padded keys hold a score of -inf and dS = Pd = 0); stats is (B*H, SP, 2) =
+ * (m2, 1 / sum_k exp2(S*c1 - m2)) per row with
  * c1 = scale*log2(e) and the shift m2 in [max_k S*c1 - 6, max_k S*c1]: P = exp2(S*c1 - m2) * stats[..,1].  scale > 0.
  * The score tile stays on chip between the two products (online softmax forward, recomputed probabilities backward).
- * Dropout mask: the Philox stream of nk_scale_softmax_dropout_fwd (same seed / offset -> same mask).
- * nk_attention_supported: dh in {32, 64, 128}, S % 32 == 0, not (train and p == 1); callers fall back to the node-by-node path. */
+ * Dropout mask: score (bh, r, k) takes draw (bh*SP + r)*SP + k of the layout documented at nk_dropout_fwd - for S % 32 == 0 the
+ * Philox stream of nk_scale_softmax_dropout_fwd on the (B*H, S, S) tensor (same seed / offset -> same mask); one forward
+ * consumes ceil(B*H*SP*SP / 8) calls.
+ * nk_attention_supported: dh in {32, 64, 128}, S >= 1, not (train and p == 1); callers fall back to the node-by-node path. */
 int nk_attention_supported(int S, int dh, double p, int train);
 /* forward: writes the raw scores (for the backward pass), the row statistics, the dropout draws (1 bit per score:
- * B*H*S*S/32 words laid out [b*H + h][S/32 query tiles][S/32 key tiles][32 queries of the tile], bit 16 j + e of a word =
+ * B*H*SP*SP/32 words laid out [b*H + h][SP/32 query tiles][SP/32 key tiles][32 queries of the tile], bit 16 j + e of a word =
  * key 32 kt + 16 j + e kept - opaque to callers, who only hand the buffer from the forward to the backward; may be NULL
  * when dropout is inactive) and O.  `scores` = `stats` = NULL: inference, nothing is
- * kept for a backward pass (O only: no (B*H, S, S) tensor exists at all). */
+ * kept for a backward pass (O only: no (B*H, SP, SP) tensor exists at all). */
 int nk_attention_fwd(nk_device* dev, const float* Q, const float* K, const float* V, float* scores, float* stats,
                      uint32_t* mask_bits, float* O, int B, int S, int H, int dh, float scale, double p, int train,
                      uint64_t seed, uint64_t offset);
 /* backward: dQ_bh (+)= dS_bh.K_bh, dK_bh (+)= dS_bh^T.Q_bh, dV_bh (+)= Pd_bh^T.dO_bh (`assign_*` != 0: first write).  dS and
- * Pd ((B*H, S, S) each) are scratch the caller owns; they are WRITTEN by the fused kernel and read by the two batched
+ * Pd ((B*H, SP, SP) each) are scratch the caller owns; they are WRITTEN by the fused kernel and read by the two batched
  * products this call issues after it.  The mask is the forward's (`mask_bits`), as the reference's backward node reads the
  * forward's noise buffer.  DropoutBackward multiplies by the 0/1 mask only (node/dropout/mod.rs:113-128), SoftmaxBackward
  * node/softmax/mod.rs:84-104, MatrixMatrixMul(T)Backward node/matrix_matrix_mul{,_t}/mod.rs:63-105. */

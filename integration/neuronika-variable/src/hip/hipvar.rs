@@ -541,15 +541,17 @@ impl HipVarDiff<Ix2> {
         fwd_history.merge(values.var.history);
         let device = self.var.data.borrow().device().clone();
         let geometry = Heads { batch: batch as i32, seq: seq as i32, heads: heads as i32, dh: dh as i32 };
-        let big = |last: usize| shared(ndarray::Dim([batch * heads, seq, last]), &device);
-        let state = Rc::new(AttentionState { scores: big(seq), stats: big(2), mask_bits: big(seq / 32), calls: Cell::new(0) });
+        // the scratch tensors are padded to whole 32 x 32 tiles: row count and row stride `sp` (include/neuronika_hip.h)
+        let sp = (seq + 31) / 32 * 32;
+        let big = |last: usize| shared(ndarray::Dim([batch * heads, sp, last]), &device);
+        let state = Rc::new(AttentionState { scores: big(sp), stats: big(2), mask_bits: big(sp / 32), calls: Cell::new(0) });
         let dim = self.var.data.borrow().dimension();
         let data = shared(dim, &device);
         let fwd = HeadsAttention::new(geometry, self.var.data.clone(), keys.var.data.clone(), values.var.data.clone(), state.clone(),
                                       data.clone(), scale, p, status.clone(), next_seed());
         let var = HipVar::node(data.clone(), Rc::new(fwd), fwd_history);
         let grad = Rc::new(Gradient::hip_zeros(dim, device));
-        let bwd = HeadsAttentionBackward::new(geometry, self.var.data, keys.var.data, values.var.data, data, state, big(seq), big(seq),
+        let bwd = HeadsAttentionBackward::new(geometry, self.var.data, keys.var.data, values.var.data, data, state, big(sp), big(sp),
                                               self.grad, keys.grad, values.grad, grad.clone(), scale, p, status);
         let op: Rc<dyn Backward> = Rc::new(bwd);
         HipVarDiff::node(var, grad.clone(), (op, grad), self.history)

@@ -22,9 +22,10 @@ pub(crate) struct Heads {
 
 /// Buffers the forward and backward node share, like `Dropout`'s noise buffer (`var.rs:375-393`).
 pub(crate) struct AttentionState {
-    pub scores: Shared<HipArray<Ix3>>,    // (batch*heads, seq, seq) raw scores
-    pub stats: Shared<HipArray<Ix3>>,     // (batch*heads, seq, 2)
-    pub mask_bits: Shared<HipArray<Ix3>>, // batch*heads*seq*seq/32 u32 words in an f32 buffer (layout: include/neuronika_hip.h, opaque here)
+    // sp = seq rounded up to a multiple of 32: the kernels work on whole 32 x 32 tiles of these tensors
+    pub scores: Shared<HipArray<Ix3>>,    // (batch*heads, sp, sp) raw scores
+    pub stats: Shared<HipArray<Ix3>>,     // (batch*heads, sp, 2)
+    pub mask_bits: Shared<HipArray<Ix3>>, // batch*heads*sp*sp/32 u32 words in an f32 buffer (layout: include/neuronika_hip.h, opaque here)
     pub calls: Cell<u64>,                 // forwards so far: each one draws a fresh Philox range
 }
 
@@ -62,7 +63,8 @@ impl Forward for HeadsAttention {
         let (mut scores, mut stats, mut bits) = (self.state.scores.borrow_mut(), self.state.stats.borrow_mut(), self.state.mask_bits.borrow_mut());
         let mut out = self.data.borrow_mut();
         let h = self.geometry;
-        let elems = (h.batch as u64) * (h.heads as u64) * (h.seq as u64) * (h.seq as u64);
+        let sp = ((h.seq as u64) + 31) / 32 * 32; // draws are indexed in the padded (batch*heads, sp, sp) tensor
+        let elems = (h.batch as u64) * (h.heads as u64) * sp * sp;
         let offset = self.state.calls.get() * ((elems + 7) / 8); // 8 draws per Philox call
         self.state.calls.set(self.state.calls.get() + 1);
         ffi::check(unsafe {

@@ -582,9 +582,15 @@ def attention_supported(S, dh, p, train=True):
     return bool(lib.nk_attention_supported(S, dh, float(p), int(train)))
 
 
+def attention_padded(S):
+    """Row count / row stride of the fused attention core's scratch tensors (include/neuronika_hip.h)."""
+    return (S + 31) // 32 * 32
+
+
 def attention_fwd(dev, Q, K, V, scores, stats, mask_bits, out, B, S, H, dh, scale, p, train=True, seed=0, offset=0):
-    """Fused attention core: scores (B*H,S,S), stats (B*H,S,2), mask_bits (B*H,S,S/32 words held in an f32 array; None
-    when dropout is inactive) and out (B*S,H*dh) are written.  scores = stats = None: inference (out only)."""
+    """Fused attention core: scores (B*H,SP,SP), stats (B*H,SP,2), mask_bits (B*H,SP,SP/32 words held in an f32 array; None
+    when dropout is inactive) and out (B*S,H*dh) are written, SP = S rounded up to a multiple of 32 (`attention_padded`).
+    scores = stats = None: inference (out only)."""
     check(lib.nk_attention_fwd(dev.h, Q.p, K.p, V.p, scores.p if scores is not None else None, stats.p if stats is not None else None,
                                mask_bits.p if mask_bits is not None else None, out.p,
                                B, S, H, dh, scale, float(p), int(train), seed, offset))
@@ -592,7 +598,7 @@ def attention_fwd(dev, Q, K, V, scores, stats, mask_bits, out, B, S, H, dh, scal
 
 def attention_bwd(dev, dQ, dK, dV, dS, dropped, dO, out, scores, stats, mask_bits, Q, K, V, B, S, H, dh, scale, p, train=True,
                   assign=(False, False, False)):
-    """dS and dropped (B*H,S,S elements, scratch) are written; dQ / dK / dV (+)= the three input gradients per (sample, head)."""
+    """dS and dropped (B*H,SP,SP elements, scratch) are written; dQ / dK / dV (+)= the three input gradients per (sample, head)."""
     check(lib.nk_attention_bwd(dev.h, dQ.p, dK.p, dV.p, dS.p, dropped.p, dO.p, out.p, scores.p, stats.p,
                                mask_bits.p if mask_bits is not None else None, Q.p, K.p, V.p, B, S, H, dh, scale, float(p),
                                int(train), int(assign[0]), int(assign[1]), int(assign[2])))

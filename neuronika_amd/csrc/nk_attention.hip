@@ -68,6 +68,8 @@ struct AttnArgs {
     unsigned keep_lt;  // a draw v is kept iff v < keep_lt = floor((1 - p) * 2^32)  (nk_common.h: the Bernoulli construction)
     unsigned long long seed, offset;
     int assign;        // backward: dQ = (1) or += (0)
+    int SP;            // S rounded up to a multiple of 32: row count and row stride of the (B*H, SP, SP) scratch tensors (scores, dS, Pd,
+                       // statistics, mask words).  SP == S except for ragged sequence lengths (read by the RAGGED instantiations only)
 };
 
 // Wave-private LDS round trip: every lane's ds_write is issued before any lane's ds_read (LDS is in-order per wave); the
@@ -104,8 +106,15 @@ __device__ __forceinline__ void tile_flush(const float* scrw, float* g /* &T[row
 // with the branch gone it waits for exactly the staging loads and the stores drain under the next tile's MFMAs.
 // KEEP (forward only): write what the backward pass needs (scores, row statistics, dropout bits).  false = inference: O only,
 // 2.1 GB of stores and the buffers themselves disappear.
-template <bool BWD, bool MASKED, bool FULL, int OCC, bool KEEP = true, int DH = 64>
+// RAGGED: S is not a multiple of 32.  The scratch tensors are padded to SP = ceil32(S) rows and columns, so every tile access to
+// them stays whole; what is left to guard is the caller's projection layout: key rows and query rows beyond S are CLAMPED to row
+// S - 1 when loaded (a sample's rows are followed by the next sample's, or by the end of the buffer), padded keys get a score of
+// -inf in the forward (probability exactly 0; the stored -inf makes the backward's recomputed probability, dS and Pd exactly 0 too),
+// padded queries compute a copy of row S - 1 that is never stored outside the scratch.  The dropout draws of score (bh, r, k) are
+// indexed in the PADDED tensor ((bh * SP + r) * SP + k), which keeps a lane's 16 keys on two whole Philox calls.
+template <bool BWD, bool MASKED, bool FULL, int OCC, bool KEEP = true, int DH = 64, bool RAGGED = false>
 __global__ __launch_bounds__(A_NT, OCC) void attention_kernel(const AttnArgs p) {
+    static_assert(!(RAGGED && FULL), "ragged sequence lengths take the guarded instantiation");
     constexpr int X1_LD = x1_ld(DH), X2_LD = x2_ld(DH);
     constexpr int ND = DH / 32;   // output column tiles
     constexpr int NR = DH / 32;   // float4 per thread and operand of a staged key tile (32 keys x DH)
@@ -121,16 +130,18 @@ __global__ __launch_bounds__(A_NT, OCC) void attention_kernel(const AttnArgs p) 
     const int bh = seq / p.nqb, qb = seq % p.nqb;
     const long long flat0 = (long long)(bh / p.H) * p.S * p.ld + (long long)(bh % p.H) * DH;
     const int q0 = qb * A_QB + w * 32;
-    const bool on = FULL ? true : q0 < p.S;  // wave-uniform: S is a multiple of 32, not necessarily of 128
+    const bool on = FULL ? true : q0 < p.S;  // wave-uniform: the wave has at least one query
+    const int SP = RAGGED ? p.SP : p.S;
     const float* x1 = p.x1 + flat0;
     const float* x2 = p.x2 + flat0;
 
     // ---- cooperative staging of one key tile (32 keys x DH of each operand): NR + NR float4 per thread ------------------
-    unsigned goff[NR], s1[NR], s2[NR];
+    unsigned goff[NR], goff_last[NR], s1[NR], s2[NR];
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
         const int idx = tid + A_NT * r, key = idx / C4, c4 = idx % C4;
         goff[r] = (unsigned)(key * p.ld + 4 * c4);
+        goff_last[r] = RAGGED ? (unsigned)(min(key, p.S - 1 - 32 * (p.ntile - 1)) * p.ld + 4 * c4) : goff[r];  // last key tile: rows clamped to S - 1
         // mfma row i supplies key 16*((i>>2)&1) + 4*(i>>3) + (i&3); its inverse places key 16a + 4b + c in row 8b + 4a + c
         s1[r] = (unsigned)((8 * ((key >> 2) & 3) + 4 * (key >> 4) + (key & 3)) * X1_LD + 4 * c4);
         s2[r] = (unsigned)(key * X2_LD + ((4 * c4 + 32 * (key >> 4)) & (DH - 1)));
@@ -142,14 +153,18 @@ __global__ __launch_bounds__(A_NT, OCC) void attention_kernel(const AttnArgs p) 
 #define A_STAGE_LOAD(KT)                                                                                         \
     do {                                                                                                         \
         const long long t0_ = (long long)(KT) * 32 * p.ld;                                                       \
-        sa0 = *reinterpret_cast<const float4*>(x1 + t0_ + goff[0]);                                             \
-        if constexpr (NR > 1) sa1 = *reinterpret_cast<const float4*>(x1 + t0_ + goff[NR > 1 ? 1 : 0]);          \
-        if constexpr (NR > 2) { sa2 = *reinterpret_cast<const float4*>(x1 + t0_ + goff[NR > 2 ? 2 : 0]);        \
-                                sa3 = *reinterpret_cast<const float4*>(x1 + t0_ + goff[NR > 2 ? 3 : 0]); }      \
-        sb0 = *reinterpret_cast<const float4*>(x2 + t0_ + goff[0]);                                             \
-        if constexpr (NR > 1) sb1 = *reinterpret_cast<const float4*>(x2 + t0_ + goff[NR > 1 ? 1 : 0]);          \
-        if constexpr (NR > 2) { sb2 = *reinterpret_cast<const float4*>(x2 + t0_ + goff[NR > 2 ? 2 : 0]);        \
-                                sb3 = *reinterpret_cast<const float4*>(x2 + t0_ + goff[NR > 2 ? 3 : 0]); }      \
+        const bool lt_ = RAGGED && (KT) == p.ntile - 1;   /* wave-uniform */                                     \
+        const unsigned g0_ = lt_ ? goff_last[0] : goff[0], g1_ = lt_ ? goff_last[NR > 1 ? 1 : 0] : goff[NR > 1 ? 1 : 0],         \
+                       g2_ = lt_ ? goff_last[NR > 2 ? 2 : 0] : goff[NR > 2 ? 2 : 0], g3_ = lt_ ? goff_last[NR > 2 ? 3 : 0] : goff[NR > 2 ? 3 : 0]; \
+        sa0 = *reinterpret_cast<const float4*>(x1 + t0_ + g0_);                                                 \
+        if constexpr (NR > 1) sa1 = *reinterpret_cast<const float4*>(x1 + t0_ + g1_);                           \
+        if constexpr (NR > 2) { sa2 = *reinterpret_cast<const float4*>(x1 + t0_ + g2_);                         \
+                                sa3 = *reinterpret_cast<const float4*>(x1 + t0_ + g3_); }                       \
+        sb0 = *reinterpret_cast<const float4*>(x2 + t0_ + g0_);                                                 \
+        if constexpr (NR > 1) sb1 = *reinterpret_cast<const float4*>(x2 + t0_ + g1_);                           \
+        if constexpr (NR > 2) { sb2 = *reinterpret_cast<const float4*>(x2 + t0_ + g2_);                         \
+                                sb3 = *reinterpret_cast<const float4*>(x2 + t0_ + g3_); }                       \
+        (void)g1_; (void)g2_; (void)g3_;                                                                         \
     } while (0)
 #define A_STAGE_STORE(BUF)                                                                                       \
     do {                                                                                                         \
@@ -164,7 +179,8 @@ __global__ __launch_bounds__(A_NT, OCC) void attention_kernel(const AttnArgs p) 
     } while (0)
 
     // ---- per-query state ----------------------------------------------------------------------------------------
-    const int row = on ? q0 + q : 0;
+    const int qrow = on ? q0 + q : 0;                        // row of the scratch tensors (padded rows exist there)
+    const int row = RAGGED ? min(qrow, p.S - 1) : qrow;      // row of the projection layout
     float4 bq[DH / 8];  // B operand of pass 1: element (query, dh = 8j + 4h + c)
     {
         const float* b = p.bq + flat0 + (long long)row * p.ld + 4 * h;
@@ -174,7 +190,7 @@ __global__ __launch_bounds__(A_NT, OCC) void attention_kernel(const AttnArgs p) 
     float m_run = -1e30f, l_run = 0.f;  // forward: online softmax (shift, sum); backward: the stored shift and 1 / sum
     float dot = 0.f;
     if (BWD) {
-        const float2 ms = *reinterpret_cast<const float2*>(p.stats + ((long long)bh * p.S + row) * 2);
+        const float2 ms = *reinterpret_cast<const float2*>(p.stats + ((long long)bh * SP + qrow) * 2);
         m_run = ms.x; l_run = ms.y;
         const float* o = p.ctx + flat0 + (long long)row * p.ld + 4 * h;
 #pragma unroll
@@ -192,24 +208,24 @@ __global__ __launch_bounds__(A_NT, OCC) void attention_kernel(const AttnArgs p) 
 #pragma unroll
         for (int e = 0; e < 16; ++e) oacc[d][e] = 0.f;
 
-    const long long rowbase = ((long long)bh * p.S + (on ? q0 : 0)) * p.S;  // element index of (row q0, key 0) in the (B*H, S, S) tensors
+    const long long rowbase = ((long long)bh * SP + (on ? q0 : 0)) * SP;  // element index of (row q0, key 0) in the (B*H, SP, SP) tensors
     const uint2 key = make_uint2((unsigned)p.seed, (unsigned)(p.seed >> 32));
-    const unsigned long long ctr0 = (unsigned long long)(rowbase + (long long)q * p.S) / 8 + 2 * h + p.offset;  // 8 draws per call
+    const unsigned long long ctr0 = (unsigned long long)(rowbase + (long long)q * SP) / 8 + 2 * h + p.offset;  // 8 draws per call
     float* scrw = scr[w];
     float* scrb = scrw + (BWD ? 32 * SCR_LD : 0);
     // backward: the score tile of the NEXT iteration, in the coalesced load layout (lane -> rows 8i + lane/8, 16 B each)
     float4 sn0, sn1, sn2, sn3;
     unsigned mkn = 0;  // and this row's 32 dropout bits of that tile
     // this wave's mask words: [bh][query tile][kt][q]
-    unsigned* const mwave = MASKED ? p.maskbits + (((long long)bh * (p.S / 32) + (on ? q0 / 32 : 0)) * p.ntile) * 32 + q : nullptr;
+    unsigned* const mwave = MASKED ? p.maskbits + (((long long)bh * (SP / 32) + (on ? q0 / 32 : 0)) * p.ntile) * 32 + q : nullptr;
     const unsigned* mload = mwave;
-    const float* sload = p.scores + rowbase + (long long)(lane >> 3) * p.S + 4 * (lane & 7);
+    const float* sload = p.scores + rowbase + (long long)(lane >> 3) * SP + 4 * (lane & 7);
 #define A_SCORES_LOAD(KT)                                                                        \
     do {                                                                                         \
         sn0 = *reinterpret_cast<const float4*>(sload + (KT) * 32);                               \
-        sn1 = *reinterpret_cast<const float4*>(sload + (long long)8 * p.S + (KT) * 32);          \
-        sn2 = *reinterpret_cast<const float4*>(sload + (long long)16 * p.S + (KT) * 32);         \
-        sn3 = *reinterpret_cast<const float4*>(sload + (long long)24 * p.S + (KT) * 32);         \
+        sn1 = *reinterpret_cast<const float4*>(sload + (long long)8 * SP + (KT) * 32);           \
+        sn2 = *reinterpret_cast<const float4*>(sload + (long long)16 * SP + (KT) * 32);          \
+        sn3 = *reinterpret_cast<const float4*>(sload + (long long)24 * SP + (KT) * 32);          \
         if (MASKED) mkn = mload[(KT) * 32];                                                      \
     } while (0)
 
@@ -296,6 +312,11 @@ __global__ __launch_bounds__(A_NT, OCC) void attention_kernel(const AttnArgs p) 
                 float raw[16];
 #pragma unroll
                 for (int e = 0; e < 16; ++e) raw[e] = acc[e];
+                if (RAGGED && kt == p.ntile - 1) {  // keys beyond S: probability exactly 0, here and (through the stored score) in the backward
+                    const int nvalid = p.S - 32 * kt - 16 * h;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) raw[e] = e < nvalid ? raw[e] : -INFINITY;
+                }
                 if (KEEP) tile_write(scrw, raw, lane);
                 // Online softmax in the base-2 exponent domain: exp(s*scale - m) = exp2(s*c1 - m2), c1 = scale*log2(e), one fma
                 // and one v_exp_f32 per element.  f32 MFMA and VALU instructions do NOT overlap on a SIMD (measured,
@@ -364,10 +385,10 @@ __global__ __launch_bounds__(A_NT, OCC) void attention_kernel(const AttnArgs p) 
             __builtin_amdgcn_sched_barrier(0);
             wave_lds_handover();
             if (!BWD) {
-                if (KEEP) tile_flush(scrw, p.scores + rowbase + kt * 32, p.S, lane);
+                if (KEEP) tile_flush(scrw, p.scores + rowbase + kt * 32, SP, lane);
             } else {
-                tile_flush(scrw, p.ds + rowbase + kt * 32, p.S, lane);
-                tile_flush(scrb, p.dropped + rowbase + kt * 32, p.S, lane);
+                tile_flush(scrw, p.ds + rowbase + kt * 32, SP, lane);
+                tile_flush(scrb, p.dropped + rowbase + kt * 32, SP, lane);
                 if (more) { wave_lds_handover(); A_SCORES_TO_LDS(); }   // next tile's scores (loaded during this iteration)
             }
         }
@@ -381,17 +402,20 @@ __global__ __launch_bounds__(A_NT, OCC) void attention_kernel(const AttnArgs p) 
     if (!on) return;
     // ---- epilogue: lane (query q, half h) owns dh = 32 d + 8 c + 4 h + {0..3} ----------------------------------------
     float* orow = p.out + flat0 + (long long)row * p.ld + 4 * h;
+    const bool qvalid = !RAGGED || qrow < p.S;  // a padded query's copy of row S - 1 stays in the scratch
     if (!BWD) {
         const float inv = 1.f / l_run;
         const float io = MASKED ? inv * p.dscale : inv;
+        if (qvalid) {
 #pragma unroll
-        for (int d = 0; d < ND; ++d)
+            for (int d = 0; d < ND; ++d)
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
-                *reinterpret_cast<float4*>(orow + 32 * d + 8 * c) =
-                    make_float4(oacc[d][4 * c] * io, oacc[d][4 * c + 1] * io, oacc[d][4 * c + 2] * io, oacc[d][4 * c + 3] * io);
-        if (KEEP && h == 0) *reinterpret_cast<float2*>(p.stats + ((long long)bh * p.S + row) * 2) = make_float2(m_run, inv);
-    } else {
+                for (int c = 0; c < 4; ++c)
+                    *reinterpret_cast<float4*>(orow + 32 * d + 8 * c) =
+                        make_float4(oacc[d][4 * c] * io, oacc[d][4 * c + 1] * io, oacc[d][4 * c + 2] * io, oacc[d][4 * c + 3] * io);
+        }
+        if (KEEP && h == 0) *reinterpret_cast<float2*>(p.stats + ((long long)bh * SP + qrow) * 2) = make_float2(m_run, inv);
+    } else if (qvalid) {
         // every old value is loaded before the first store (a store may alias the next load: a one-walk `+=` serialises)
         float4 old[ND][4];
 #pragma unroll
@@ -415,20 +439,21 @@ int attention_check(int B, int S, int H, int dh, double p, int train, float scal
     NK_CHECK(p >= 0.0 && p <= 1.0, "Wrong probability received: %g.", p);
     NK_CHECK(scale > 0.f && scale < 1e30f, "fused attention needs a positive finite scale (the row max is taken before scaling), got %g", (double)scale);
     NK_CHECK(B > 0 && S > 0 && H > 0, "attention: non-positive geometry");
-    NK_CHECK(nk_attention_supported(S, dh, p, train), "fused attention needs dh in {32, 64, 128}, S %% 32 == 0 and p < 1 in training (S=%d dh=%d p=%g)", S, dh, p);
+    NK_CHECK(nk_attention_supported(S, dh, p, train), "fused attention needs dh in {32, 64, 128} and p < 1 in training (S=%d dh=%d p=%g)", S, dh, p);
+    NK_CHECK((long long)B * H * ((S + 31) / 32) * ((S + 31) / 32) < (1ll << 31) / 32, "attention: the mask words exceed 2^31");
     NK_CHECK((long long)B * S * H * dh < (1ll << 31), "attention: the projection layout exceeds 2^31 elements");
     return NK_OK;
 }
 
 template <bool BWD, int DH>
 int attention_launch_dh(nk_device* dev, AttnArgs& a, int B, int S, int H, double p, int train, uint64_t seed, uint64_t offset, float scale) {
-    a.S = S; a.H = H; a.ld = H * DH; a.nqb = (S + A_QB - 1) / A_QB; a.ntile = S / 32;
+    a.S = S; a.H = H; a.ld = H * DH; a.nqb = (S + A_QB - 1) / A_QB; a.SP = (S + 31) / 32 * 32; a.ntile = a.SP / 32;
     a.scale = scale; a.c1 = scale * 1.44269504088896341f; a.keep = (float)(1.0 - p); a.dscale = 1.f / (1.f - (float)p);  // as nk_scale_softmax_dropout_fwd
     a.seed = seed; a.offset = offset;
     a.keep_lt = nk_keep_threshold(1.0 - p);   // Bernoulli::new(1. - p), node/dropout/mod.rs:46
     const bool masked = train && p != 0.0;
     const dim3 grid((unsigned)(B * H * a.nqb)), block(A_NT);
-    const bool full = S % A_QB == 0;
+    const bool full = S % A_QB == 0, ragged = S % 32 != 0;
     // OCC = blocks per CU the register budget is sized for.  DH = 64: three forward blocks fit by LDS (52 KB each) at <= 168
     // VGPRs - the masked forward then spills a few registers and is still faster than two blocks without spills (1.36 vs
     // 1.37 - 1.41 ms at C5, round 3) - and the backward holds 70 KB of LDS per block: two blocks per CU.  DH = 128: 85 / 103 KB
@@ -438,17 +463,18 @@ int attention_launch_dh(nk_device* dev, AttnArgs& a, int B, int S, int H, double
     constexpr int OCC_F = DH == 128 ? 1 : 3, OCC_B = DH == 128 ? 1 : 2;   // forward / backward blocks per CU
     constexpr int OCC_DEFAULT = BWD ? OCC_B : OCC_F;
     const bool occ2 = !BWD && DH != 128 && occ_env == 2;
-#define NK_ATT(M, F)                                                                                                       \
+#define NK_ATT(M, F, R)                                                                                                    \
     do {                                                                                                                   \
         /* inference forward: KEEP = false (spelled `BWD`, false on the only path that reaches this line) */             \
-        if (!BWD && !a.scores) hipLaunchKernelGGL((attention_kernel<BWD, M, F, OCC_DEFAULT, BWD, DH>), grid, block, 0, dev->compute, a); \
-        else if (occ2) hipLaunchKernelGGL((attention_kernel<BWD, M, F, (DH == 128 ? 1 : 2), true, DH>), grid, block, 0, dev->compute, a); \
-        else hipLaunchKernelGGL((attention_kernel<BWD, M, F, OCC_DEFAULT, true, DH>), grid, block, 0, dev->compute, a);    \
+        if (!BWD && !a.scores) hipLaunchKernelGGL((attention_kernel<BWD, M, F, OCC_DEFAULT, BWD, DH, R>), grid, block, 0, dev->compute, a); \
+        else if (occ2) hipLaunchKernelGGL((attention_kernel<BWD, M, F, (DH == 128 ? 1 : 2), true, DH, R>), grid, block, 0, dev->compute, a); \
+        else hipLaunchKernelGGL((attention_kernel<BWD, M, F, OCC_DEFAULT, true, DH, R>), grid, block, 0, dev->compute, a);    \
     } while (0)
-    if (masked && full) NK_ATT(true, true);
-    else if (masked) NK_ATT(true, false);
-    else if (full) NK_ATT(false, true);
-    else NK_ATT(false, false);
+    if (ragged) { if (masked) NK_ATT(true, false, true); else NK_ATT(false, false, true); }
+    else if (masked && full) NK_ATT(true, true, false);
+    else if (masked) NK_ATT(true, false, false);
+    else if (full) NK_ATT(false, true, false);
+    else NK_ATT(false, false, false);
 #undef NK_ATT
     NK_LAUNCH_CHECK();
     return NK_OK;
@@ -466,7 +492,7 @@ int attention_launch(nk_device* dev, AttnArgs& a, int B, int S, int H, int dh, d
 extern "C" {
 
 int nk_attention_supported(int S, int dh, double p, int train) {
-    return (dh == 32 || dh == 64 || dh == 128) && S > 0 && S % 32 == 0 && !(train && 1.0 - p == 0.0);
+    return (dh == 32 || dh == 64 || dh == 128) && S > 0 && !(train && 1.0 - p == 0.0);
 }
 
 int nk_attention_fwd(nk_device* dev, const float* Q, const float* K, const float* V, float* scores, float* stats,
@@ -507,11 +533,11 @@ int nk_attention_bwd(nk_device* dev, float* dQ, float* dK, float* dV, float* dS,
     // dK_bh (+)= dS_bh^T . Q_bh and dV_bh (+)= Pd_bh^T . dO_bh: reductions over the queries, i.e. across the blocks above.
     // (Keeping dS / Pd in the kernels' own tile order - no LDS transposition in the kernel, a k-contiguous A operand whose
     // 128 x 32 tiles are single 16 KB runs for these products - was built and measured: kernel and products unchanged.)
-    const int d = H * dh;
-    const long long so = (long long)S * d, po = (long long)H * S * S, pi = (long long)S * S;
-    rc = nk_sgemm_batched(dev, 1, 0, S, dh, S, 1.f, dS, S, po, pi, Q, d, so, dh, assign_dk ? 0.f : 1.f, dK, d, so, dh, B, H);
+    const int d = H * dh, SP = (S + 31) / 32 * 32;  // row stride of the scratch tensors (== S unless S is ragged)
+    const long long so = (long long)S * d, po = (long long)H * SP * SP, pi = (long long)SP * SP;
+    rc = nk_sgemm_batched(dev, 1, 0, S, dh, S, 1.f, dS, SP, po, pi, Q, d, so, dh, assign_dk ? 0.f : 1.f, dK, d, so, dh, B, H);
     if (rc) return rc;
-    return nk_sgemm_batched(dev, 1, 0, S, dh, S, 1.f, dropped, S, po, pi, dO, d, so, dh, assign_dv ? 0.f : 1.f, dV, d, so, dh, B, H);
+    return nk_sgemm_batched(dev, 1, 0, S, dh, S, 1.f, dropped, SP, po, pi, dO, d, so, dh, assign_dv ? 0.f : 1.f, dV, d, so, dh, B, H);
 }
 
 }  // extern "C"

@@ -34,25 +34,33 @@ def _check(got, want64, want32, what, floor=0.0):
 
 
 def _run(dev, B, S, H, p, train, seed, offset, assign, q, k, v, g, dq0, dh=64):
+    """Runs forward + backward; the (B*H, SP, SP) scratch tensors (SP = S rounded up to 32) come back cut to (B*H, S, S), the
+    padded part as `pad_*` for the ragged-length checks."""
     c = capi()
     scale = float(np.float32(1.0 / np.sqrt(dh)))
+    SP = c.attention_padded(S)
     Q, K, V, G = (dev.array(t) for t in (q, k, v, g))
-    scores, stats, out = dev.zeros((B * H, S, S)), dev.zeros((B * H, S, 2)), dev.zeros((B * S, H * dh))
-    bits = dev.zeros((B * H, S, S // 32))
+    scores, stats, out = dev.full((B * H, SP, SP), 7.0), dev.zeros((B * H, SP, 2)), dev.zeros((B * S, H * dh))
+    bits = dev.zeros((B * H, SP, SP // 32))
     c.attention_fwd(dev, Q, K, V, scores, stats, bits, out, B, S, H, dh, scale, p, train, seed, offset)
-    dS, dropped, dQ = dev.zeros((B * H, S, S)), dev.zeros((B * H, S, S)), dev.array(dq0)
+    dS, dropped, dQ = dev.full((B * H, SP, SP), 7.0), dev.full((B * H, SP, SP), 7.0), dev.array(dq0)
     dK, dV = dev.zeros((B * S, H * dh)), dev.zeros((B * S, H * dh))
     c.attention_bwd(dev, dQ, dK, dV, dS, dropped, G, out, scores, stats, bits, Q, K, V, B, S, H, dh, scale, p, train,
                     assign=(assign, True, True))
-    rows = lambda t: t.numpy()
-    return dict(scores=rows(scores), stats=stats.numpy(), out=out.numpy(), bits=bits.numpy().view(np.uint32), d_scores=rows(dS),
-                dropped=rows(dropped), dq=dQ.numpy(), dk=dK.numpy(), dv=dV.numpy()), (Q, K)
+    cut = lambda t: np.ascontiguousarray(t.numpy()[:, :S, :S])
+    pad = lambda t: t.numpy()[:, :S, S:]          # padded KEYS of the real queries
+    return dict(scores=cut(scores), stats=stats.numpy()[:, :S], out=out.numpy(), bits=bits.numpy().view(np.uint32), d_scores=cut(dS),
+                dropped=cut(dropped), dq=dQ.numpy(), dk=dK.numpy(), dv=dV.numpy(), pad_scores=pad(scores), pad_d_scores=pad(dS),
+                pad_dropped=pad(dropped)), (Q, K)
 
 
 # head dimension 64 (C5) at six geometries; 32 and 128 (the kernels' other two instantiations: one / four output column tiles,
 # one / four staged float4 per thread and operand) at three each
+# ragged sequence lengths (S % 32 != 0: padded scratch, clamped loads, -inf scores for the padded keys) for every head dimension (S = 1: test_attention_core_single_key)
 @pytest.mark.parametrize("B,S,H,dh", [(2, 128, 2, 64), (1, 160, 3, 64), (3, 32, 1, 64), (1, 256, 2, 64), (2, 96, 2, 64), (1, 384, 1, 64),
-                                       (2, 128, 2, 32), (1, 160, 3, 32), (1, 32, 1, 32), (2, 128, 2, 128), (1, 160, 3, 128), (1, 32, 1, 128)])
+                                       (2, 128, 2, 32), (1, 160, 3, 32), (1, 32, 1, 32), (2, 128, 2, 128), (1, 160, 3, 128), (1, 32, 1, 128),
+                                       (2, 40, 2, 64), (3, 100, 3, 64), (2, 129, 1, 64), (2, 7, 2, 64), (2, 2, 1, 64), (1, 197, 2, 64),
+                                       (2, 72, 2, 32), (2, 17, 1, 32), (2, 200, 2, 128), (3, 33, 1, 128), (1, 1000, 2, 64)])
 @pytest.mark.parametrize("p,train", [(0.1, True), (0.0, True), (0.35, False), (0.5, True)])
 def test_attention_core_equals_oracle(dev, B, S, H, dh, p, train):
     c = capi()
@@ -60,9 +68,11 @@ def test_attention_core_equals_oracle(dev, B, S, H, dh, p, train):
     q, k, v, g = (rnd(s, (B * S, H * dh), -1, 1) for s in (1, 2, 3, 4))
     dq0 = rnd(9, (B * S, H * dh), -1, 1)
     got, (Q, K) = _run(dev, B, S, H, p, train, seed, offset, False, q, k, v, g, dq0, dh)
-    n = B * H * S * S
+    SP = c.attention_padded(S)
     masked = train and p != 0.0
-    noise = O.dropout_noise(n, p, seed, offset).reshape(B * H, S, S) if masked else np.ones((B * H, S, S), np.float32)
+    # score (bh, r, k) takes draw (bh * SP + r) * SP + k of the shared layout (SP == S for whole tiles)
+    noise = (np.ascontiguousarray(O.dropout_noise(B * H * SP * SP, p, seed, offset).reshape(B * H, SP, SP)[:, :S, :S]) if masked
+             else np.ones((B * H, S, S), np.float32))
     pe = p if masked else 0.0
     ref, ref32 = {}, {}
     for dt, dst in ((np.float64, ref), (np.float32, ref32)):
@@ -76,9 +86,11 @@ def test_attention_core_equals_oracle(dev, B, S, H, dh, p, train):
     assert np.array_equal(got["dropped"] == 0, noise == 0)   # dropped exactly where the mask says (no probability underflows here)
     if masked:   # the packed draws the backward kernel reads: bit j of word t of a row = key 32 t + j kept
         # words are laid out [bh][query tile][key tile][query in tile] (one 128-byte line per wave and tile)
-        w = got["bits"].reshape(B * H, S // 32, S // 32, 32).transpose(0, 1, 3, 2).reshape(B * H, S, S // 32)
-        unpacked = ((w[..., None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(B * H, S, S)
+        w = got["bits"].reshape(B * H, SP // 32, SP // 32, 32).transpose(0, 1, 3, 2).reshape(B * H, SP, SP // 32)
+        unpacked = ((w[..., None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(B * H, SP, SP)[:, :S, :S]
         assert np.array_equal(unpacked, noise != 0)
+    if S % 32:   # padded keys: a score of -inf, probability and score gradient exactly 0
+        assert np.all(np.isneginf(got["pad_scores"])) and not got["pad_d_scores"].any() and not got["pad_dropped"].any()
     for name in ("out", "dropped", "d_scores", "dk", "dv"):
         _check(got[name], ref[name], ref32[name], name)
     _check(got["dq"] - dq0, ref["dq"], ref32["dq"], "dq (accumulated)", floor=np.abs(dq0).max())
@@ -94,6 +106,24 @@ def test_attention_core_equals_oracle(dev, B, S, H, dh, p, train):
     got2, _ = _run(dev, B, S, H, p, train, seed, offset, True, q, k, v, g, dq0, dh)
     assert np.array_equal(got2["dq"] + dq0, got["dq"]) or np.abs(got2["dq"] + dq0 - got["dq"]).max() <= 1e-6 * np.abs(dq0).max()
     _check(got2["dq"], ref["dq"], ref32["dq"], "dq (assigned)")
+
+
+@pytest.mark.parametrize("dh", [64, 32, 128])
+def test_attention_core_single_key(dev, dh):
+    """S = 1 (one valid key in a 32 x 32 tile, 31 padded keys and queries): P = 1, so O = V * noise / (1 - p), dV = Pd * dO, and the
+    score gradient cancels - dS = P * (dP - sum dP P) is exactly 0 in the oracle, here the rounding of dP (the kernel forms the sum
+    as keep * dO . O), and dQ / dK inherit it: measured against dP's size, the terms that cancel."""
+    B, H, p, seed, offset = 3, 2, 0.25, 5, 0
+    q, k, v, g = (rnd(s_, (B, H * dh), -1, 1) for s_ in (41, 42, 43, 44))
+    got, _ = _run(dev, B, 1, H, p, True, seed, offset, True, q, k, v, g, np.zeros((B, H * dh), np.float32), dh)
+    noise = O.dropout_noise(B * H * 32 * 32, p, seed, offset).reshape(B * H, 32, 32)[:, 0, 0]          # draw (bh * 32 + 0) * 32 + 0
+    keep = np.repeat(noise.reshape(B, H), dh, axis=1) / (np.float32(1) - np.float32(p))
+    np.testing.assert_allclose(got["out"], v * keep, rtol=2e-7, atol=0)
+    np.testing.assert_allclose(got["dv"], g * keep, rtol=2e-7, atol=0)
+    assert np.array_equal(got["dropped"].reshape(-1) != 0, noise != 0)
+    dp_max = np.abs((g.astype(np.float64) * v).reshape(B, H, dh).sum(2)).max() / (1 - p)
+    for name in ("d_scores", "dq", "dk"):
+        assert np.abs(got[name]).max() <= 1e-6 * max(dp_max, 1.0), (name, np.abs(got[name]).max(), dp_max)
 
 
 @pytest.mark.parametrize("dh", [64, 32, 128])
@@ -116,7 +146,7 @@ def test_attention_core_mask_is_the_row_kernels_mask(dev, dh):
     np.testing.assert_allclose(got["out"], ctx.numpy(), rtol=1e-4, atol=2e-6)
 
 
-@pytest.mark.parametrize("S,p,dh", [(128, 0.2, 64), (96, 0.0, 64), (256, 0.4, 64), (128, 0.2, 32), (96, 0.3, 128)])
+@pytest.mark.parametrize("S,p,dh", [(128, 0.2, 64), (96, 0.0, 64), (256, 0.4, 64), (128, 0.2, 32), (96, 0.3, 128), (100, 0.2, 64), (45, 0.0, 32), (70, 0.3, 128)])
 def test_attention_forward_without_kept_state_is_the_same_forward(dev, S, p, dh):
     """Inference form (scores = stats = mask_bits = NULL: no (B*H, S, S) tensor exists): the output is bit-identical to
     the training-graph form's, dropout included (same Philox stream)."""
@@ -125,7 +155,8 @@ def test_attention_forward_without_kept_state_is_the_same_forward(dev, S, p, dh)
     scale = float(np.float32(1.0 / np.sqrt(dh)))
     q, k, v = (rnd(s_, (B * S, H * dh), -1, 1) for s_ in (21, 22, 23))
     Q, K, V = dev.array(q), dev.array(k), dev.array(v)
-    scores, stats, bits = dev.zeros((B * H, S, S)), dev.zeros((B * H, S, 2)), dev.zeros((B * H, S, S // 32))
+    SP = c.attention_padded(S)
+    scores, stats, bits = dev.zeros((B * H, SP, SP)), dev.zeros((B * H, SP, 2)), dev.zeros((B * H, SP, SP // 32))
     kept, lean = dev.zeros((B * S, H * dh)), dev.zeros((B * S, H * dh))
     c.attention_fwd(dev, Q, K, V, scores, stats, bits, kept, B, S, H, dh, scale, p, True, seed, offset)
     c.attention_fwd(dev, Q, K, V, None, None, None, lean, B, S, H, dh, scale, p, True, seed, offset)
@@ -155,7 +186,7 @@ def test_attention_core_rejects_what_it_cannot_do(dev):
     c = capi()
     assert c.attention_supported(1024, 64, 0.1) and c.attention_supported(32, 64, 0.0)
     assert c.attention_supported(1024, 32, 0.1) and c.attention_supported(1024, 128, 0.1)
-    assert not c.attention_supported(1024, 96, 0.1) and not c.attention_supported(1024, 256, 0.1) and not c.attention_supported(100, 64, 0.1)
+    assert not c.attention_supported(1024, 96, 0.1) and not c.attention_supported(1024, 256, 0.1) and c.attention_supported(100, 64, 0.1)
     assert not c.attention_supported(64, 64, 1.0, True) and c.attention_supported(64, 64, 1.0, False)
     z = dev.zeros((64, 96))
     sc, st = dev.zeros((1, 64, 64)), dev.zeros((1, 64, 2))

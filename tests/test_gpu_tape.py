@@ -665,7 +665,8 @@ def test_mha_with_dropout_equals_oracle(nk, tdev, fused, strided, p):
 
 
 @pytest.mark.parametrize("core", [True, False])
-@pytest.mark.parametrize("p,S,d,H", [(0.1, 96, 128, 2), (0.0, 64, 128, 2), (0.3, 160, 128, 2), (0.1, 96, 128, 4), (0.2, 64, 256, 2)])   # dh = 64, 64, 64, 32, 128
+@pytest.mark.parametrize("p,S,d,H", [(0.1, 96, 128, 2), (0.0, 64, 128, 2), (0.3, 160, 128, 2), (0.1, 96, 128, 4), (0.2, 64, 256, 2),   # dh = 64, 64, 64, 32, 128
+                                     (0.1, 100, 128, 2), (0.25, 36, 128, 4), (0.0, 44, 256, 2)])   # ragged lengths: dh = 64, 32, 128
 def test_mha_fused_attention_core_equals_oracle(nk, tdev, core, p, S, d, H):
     """Head dimension 64 (the C5 geometry): the module routes scores -> probabilities -> context through the fused
     attention kernels (`fused_core`, one node instead of three).  Same check as above - the oracle composition fed the
@@ -685,9 +686,12 @@ def test_mha_fused_attention_core_equals_oracle(nk, tdev, core, p, S, d, H):
     assert y.history_len() == other.forward(nk.from_ndarray(tdev, x).requires_grad(), B).history_len() + (-2 if core else 2)
     G = nk.from_ndarray(tdev, g)
     leaves = [X] + [getattr(getattr(mha, n), w) for n in "qkvo" for w in ("weight", "bias")]
-    n = B * H * S * S
+    # the fused core indexes its draws in the score tensor padded to whole 32 x 32 tiles (include/neuronika_hip.h); the node path in (B*H, S, S)
+    SP = (S + 31) // 32 * 32 if core else S
+    n = B * H * SP * SP
     for call in range(2):
-        noise = O.dropout_noise(n, p, seed, call * O.dropout_draws_calls(n)).reshape(B * H, S, S) if p else np.ones((B * H, S, S), np.float32)
+        noise = (np.ascontiguousarray(O.dropout_noise(n, p, seed, call * O.dropout_draws_calls(n)).reshape(B * H, SP, SP)[:, :S, :S]) if p
+                 else np.ones((B * H, S, S), np.float32))
         for v in leaves:
             v.zero_grad()
         y.forward(); y.no_grad(); y.with_grad()
