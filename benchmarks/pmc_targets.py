@@ -1,7 +1,7 @@
 """One kernel family per invocation, a few launches with nothing else around them: the target of the rocprofv3 PMC passes
 (tools/pmc_profile.sh).
 
-    python benchmarks/pmc_targets.py proj_fwd | gemm4k_k1024 | gemm4k | scores | context | attn_fwd | attn_fwd_nodrop | attn_bwd |
+    python benchmarks/pmc_targets.py proj_fwd | gemm4k_k1024 | gemm4k | gemm2k | scores | context | attn_fwd | attn_fwd_nodrop | attn_bwd |
                                      conv_fwd | conv_bwd_input | conv_bwd_kernel
 """
 import os
@@ -21,9 +21,9 @@ if what == "proj_fwd":
     M, N, K = 32768, 1024, 1024
     X, W, Y = rand(dev, (M, K), 0), rand(dev, (N, K), 1), dev.zeros((M, N))
     f = lambda: c.mm_t_fwd(dev, X, W, Y)
-elif what in ("gemm4k_k1024", "gemm4k"):
-    M = N = 4096
-    K = 1024 if what == "gemm4k_k1024" else 4096
+elif what in ("gemm4k_k1024", "gemm4k", "gemm2k"):   # gemm2k: k-pair blocks (NK_GEMM_KPAIR=0 for the plain one-block-per-CU launch)
+    M = N = 2048 if what == "gemm2k" else 4096
+    K = 1024 if what == "gemm4k_k1024" else M
     X, W, Y = rand(dev, (M, K), 0), rand(dev, (N, K), 1), dev.zeros((M, N))
     f = lambda: c.mm_t_fwd(dev, X, W, Y)
 elif what in ("scores", "context"):
