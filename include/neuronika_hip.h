@@ -106,10 +106,12 @@ int nk_stream_wait_event(nk_device* dev, int on_comm_stream, nk_event* ev);
  * microseconds each.  Everything a tape step enqueues on the compute stream between nk_graph_begin and nk_graph_end
  * is recorded into a hipGraph instead of executed; nk_graph_launch replays it with one submission.  The captured
  * region must not synchronise with the host (no nk_download / nk_device_sync / item()) nor grow an allocation, and
- * it replays the SAME launches: scalars baked into kernel arguments (learning rate, the Philox offset of
- * nk_dropout_fwd / nk_scale_softmax_dropout_fwd / nk_attention_fwd) stay what they were at capture time - capture
- * steady-state steps of dropout-free graphs.  Optimizer steps whose kernel arguments depend on the step count (nk_adam_step: 1 - beta^step; nk_adagrad_step with lr_decay != 0) REFUSE to be
- * captured (NK_ERR_INVALID) instead of freezing their schedule; SGD / RMSProp steps capture fine.  A workspace the
+ * it replays the SAME launches: scalars baked into kernel arguments (the learning rate) stay what they were at capture
+ * time.  Calls whose kernel arguments must change from call to call REFUSE to be captured (NK_ERR_INVALID) instead of
+ * freezing them: optimizer steps that depend on the step count (nk_adam_step: 1 - beta^step; nk_adagrad_step with
+ * lr_decay != 0), and the forwards that draw a dropout mask (nk_dropout_fwd / nk_scale_softmax_dropout_fwd /
+ * nk_attention_fwd with train != 0 and 0 < p < 1: the Philox offset - every replay would drop the same elements).
+ * SGD / RMSProp steps, evaluation-mode and p = 0 dropout capture fine.  A workspace the
  * device outgrows later stays allocated while any nk_graph of that device exists (captured kernels keep its address);
  * destroy a device's graphs before the device. */
 typedef struct nk_graph nk_graph;

@@ -452,6 +452,9 @@ int attention_launch_dh(nk_device* dev, AttnArgs& a, int B, int S, int H, double
     a.seed = seed; a.offset = offset;
     a.keep_lt = nk_keep_threshold(1.0 - p);   // Bernoulli::new(1. - p), node/dropout/mod.rs:46
     const bool masked = train && p != 0.0;
+    if (!BWD && masked)   // (the backward reads the forward's stored bits: nothing of its own to freeze)
+        if (int rc = nk_refuse_capture(dev, "nk_attention_fwd: the Philox offset (every replay would draw the same mask)",
+                                       "run the training-mode dropout eagerly, or capture the evaluation graph")) return rc;
     const dim3 grid((unsigned)(B * H * a.nqb)), block(A_NT);
     const bool full = S % A_QB == 0, ragged = S % 32 != 0;
     // OCC = blocks per CU the register budget is sized for.  DH = 64: three forward blocks fit by LDS (52 KB each) at <= 168

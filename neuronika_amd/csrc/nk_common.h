@@ -72,6 +72,16 @@ int nk_workspace(nk_device* dev, size_t bytes, void** out);
 
 #define NK_LAUNCH_CHECK() NK_HIP(hipGetLastError())
 
+// Host scalars that change from call to call become kernel ARGUMENTS (an optimizer's step-dependent factors, the Philox offset of a
+// dropout forward): a hipGraph replay would freeze them at the captured call - the optimizer would silently leave its schedule, every
+// replay would drop the same elements - so such a call refuses to be captured.
+static inline int nk_refuse_capture(nk_device* dev, const char* what, const char* advice) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    NK_HIP(hipStreamIsCapturing(dev->compute, &cs));
+    NK_CHECK(cs == hipStreamCaptureStatusNone, "%s would be frozen at the captured call by a graph replay: %s", what, advice);
+    return NK_OK;
+}
+
 static inline size_t nk_numel(const int* shape, int nd) {
     size_t n = 1;
     for (int i = 0; i < nd; ++i) n *= (size_t)shape[i];

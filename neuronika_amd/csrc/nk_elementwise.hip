@@ -822,13 +822,8 @@ int nk_sgd_step(nk_device* dev, float* w, float* grad, float* velocity, size_t n
     return NK_OK;
 }
 
-// Step-dependent host scalars become kernel ARGUMENTS: a hipGraph replay would freeze them at the captured step and the
-// optimizer would silently stop following its schedule, so such a step refuses to be captured.
-static int refuse_capture(nk_device* dev, const char* what) {
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    NK_HIP(hipStreamIsCapturing(dev->compute, &cs));
-    NK_CHECK(cs == hipStreamCaptureStatusNone, "%s would be frozen at the captured step by a graph replay: issue this optimizer step outside the captured region", what);
-    return NK_OK;
+static int refuse_capture(nk_device* dev, const char* what) {   // nk_common.h: why
+    return nk_refuse_capture(dev, what, "issue this optimizer step outside the captured region");
 }
 
 int nk_adam_step(nk_device* dev, float* w, float* grad, float* exp_avg, float* exp_avg_sq, float* max_exp_avg_sq,

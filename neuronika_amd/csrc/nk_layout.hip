@@ -481,6 +481,8 @@ int nk_dropout_fwd(nk_device* dev, const float* x, float* y, float* noise, size_
     }
     NK_CHECK(noise != nullptr, "noise buffer required in training mode");
     NK_CHECK(al16(x) && al16(y) && al16(noise), "dropout buffers must be 16-byte aligned");
+    if (int rc = nk_refuse_capture(dev, "nk_dropout_fwd: the Philox offset (every replay would draw the same mask)",
+                                   "run the training-mode dropout eagerly, or capture the evaluation graph")) return rc;
     const unsigned keep_lt = nk_keep_threshold(1.0 - p);   // Bernoulli::new(1. - p), dropout/mod.rs:46
     const float scale = 1.f - (float)p;                    // `(1. - self.p as f32)`, dropout/mod.rs:76
     hipLaunchKernelGGL(dropout_fwd_kernel, dim3(nk_stream_grid((n + 3) / 4, 256)), dim3(256), 0, dev->compute, x, y, noise,

@@ -569,6 +569,9 @@ int nk_scale_softmax_dropout_fwd(nk_device* dev, const float* scores, float* pro
     NK_CHECK(L % 4 == 0 && L <= 2048 && al16(scores) && (!probs || al16(probs)) && al16(out) && (!noise || al16(noise)),
              "fused attention probabilities need L %% 4 == 0, L <= 2048 and 16-byte aligned buffers (L=%d)", L);
     const int mask = (!train || p == 0.0) ? 0 : (1.0 - p == 0.0 ? 2 : 1);
+    if (mask == 1)
+        if (int rc = nk_refuse_capture(dev, "nk_scale_softmax_dropout_fwd: the Philox offset (every replay would draw the same mask)",
+                                       "run the training-mode dropout eagerly, or capture the evaluation graph")) return rc;
     const unsigned keep_lt = nk_keep_threshold(1.0 - p);   // Bernoulli::new(1. - p), dropout/mod.rs:46 (nk_common.h)
     const float dscale = 1.f / (1.f - (float)p);           // multiplied in: 1 / (1 - p) rounded once on the host
     const dim3 grid((unsigned)((rows + 3) / 4)), block(256);

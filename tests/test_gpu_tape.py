@@ -1004,6 +1004,46 @@ def test_hipgraph_training_step(nk, tdev):
 
 
 @pytest.mark.gpu
+def test_hipgraph_refuses_to_freeze_a_dropout_mask(nk, tdev):
+    """A forward that draws a dropout mask bakes its Philox offset into the kernel arguments: a replayed graph would drop the
+    same elements every step.  Training-mode dropout (the plain node, the attention probabilities, the fused attention core)
+    refuses to be captured; evaluation mode and p = 0 capture and replay."""
+    x = nk.rand(tdev, [64, 64], 3)
+    for build in (lambda st: x.dropout(0.5, st),
+                  lambda st: x.heads_attention(x, x, 1, 64, 1, 64, 0.125, 0.5, st)):
+        st = nk.Status(True)
+        y, other = build(st), x.relu()
+        y.forward(); other.forward()
+        tdev.graph_begin()
+        other.forward()                    # (something to capture)
+        with pytest.raises(RuntimeError, match="same mask"):
+            y.forward()
+        g = tdev.graph_end()
+        del g
+        st.set(False)                      # evaluation mode: nothing is drawn, the step captures
+        y.forward(); want = y.data().copy()
+        tdev.graph_begin(); y.forward(); g = tdev.graph_end()
+        g.launch(); g.launch()
+        assert np.array_equal(y.data(), want)
+    # the attention-probabilities row kernel, through the C ABI
+    from neuronika_amd import capi as c
+    dev = c.Device(0)
+    sc, out = dev.array(np.random.default_rng(0).random((64, 64), dtype=np.float32)), dev.zeros((64, 64))
+    c.check(c.lib.nk_graph_begin(dev.h))
+    with pytest.raises(RuntimeError, match="same mask"):
+        c.scale_softmax_dropout_fwd(dev, sc, None, out, None, 0.125, 0.5, True, 1, 0)
+    c.scale_softmax_dropout_fwd(dev, sc, None, out, None, 0.125, 0.5, False, 1, 0)   # evaluation mode captures
+    import ctypes
+    gh = ctypes.c_void_p()
+    c.check(c.lib.nk_graph_end(dev.h, ctypes.byref(gh)))
+    c.check(c.lib.nk_graph_launch(gh)); dev.sync()
+    c.check(c.lib.nk_graph_destroy(gh))
+    z = sc.numpy().astype(np.float64) * 0.125
+    soft = np.exp(z - z.max(1, keepdims=True)); soft /= soft.sum(1, keepdims=True)
+    np.testing.assert_allclose(out.numpy(), soft, rtol=2e-6)
+
+
+@pytest.mark.gpu
 def test_hipgraph_refuses_step_dependent_optimizers_and_keeps_workspaces(nk, tdev):
     """An Adam step bakes 1 - beta^step into its kernel arguments: capturing it would freeze the bias correction, so it
     refuses (the SGD step of the test above captures).  And a workspace outgrown AFTER a capture stays valid for the
