@@ -2,7 +2,7 @@
 (tools/pmc_profile.sh).
 
     python benchmarks/pmc_targets.py proj_fwd | gemm4k_k1024 | gemm4k | gemm2k | scores | context | attn_fwd | attn_fwd_nodrop | attn_bwd |
-                                     conv_fwd | conv_bwd_input | conv_bwd_kernel
+                                     conv_fwd | conv_bwd_input | conv_bwd_input_on_padded | conv_bwd_kernel
 """
 import os
 import sys
@@ -54,10 +54,13 @@ else:
     W = rand(dev, (128, 64, 3, 3), 1, -k, k)
     XP = dev.zeros((batch, 64, 58, 58))
     Y, G = dev.zeros((batch, 128, 56, 56)), rand(dev, (batch, 128, 56, 56), 2, 0, 1)
-    DXP, DW = dev.zeros(XP.shape), dev.zeros(W.shape)
+    DXP, DX, DW = dev.zeros(XP.shape), dev.zeros(x.shape), dev.zeros(W.shape)
     c.pad_const_fwd(dev, x, XP, (1, 1), 0.0)
     f = {"conv_fwd": lambda: c.conv_fwd(dev, XP, W, Y, (1, 1), (1, 1), 1),
-         "conv_bwd_input": lambda: c.conv_bwd_input(dev, DXP, G, W, (1, 1), (1, 1), 1),
+         # what the C3 module step launches: the columns are the 56 x 56 UNPADDED input positions (nk_conv_bwd_input_padded), the gradient
+         # lands in the caller's tensor; conv_bwd_input_on_padded: the two-kernel form's convolution half, 58 x 60 columns per plane
+         "conv_bwd_input": lambda: c.conv_bwd_input(dev, DX, G, W, (1, 1), (1, 1), 1, assign=True, padding=(1, 1)),
+         "conv_bwd_input_on_padded": lambda: c.conv_bwd_input(dev, DXP, G, W, (1, 1), (1, 1), 1),
          "conv_bwd_kernel": lambda: c.conv_bwd_kernel(dev, DW, G, XP, (1, 1), (1, 1), 1)}[what]
 for _ in range(reps):
     f()
