@@ -457,7 +457,10 @@ int conv_bwd_kernel(nk_device* dev, int nd, float* dw, const int* w_shape, const
     // body, i.e. issuing none of the 11 % of MFMAs that fall on padding columns, did not change the launch time with
     // one block per tile (565 -> 566 us) and LOST 3 % once those blocks were given twice the reduction range to even
     // out the work (584 us): the launch is bound by the per-k-tile chain gathers -> wait -> mask -> LDS store -> barrier
-    // (~1 us per k-tile more than the dense GEMM's), not by MFMA issue.)
+    // (~1 us per k-tile more than the dense GEMM's), not by MFMA issue.  Round 3, with the pass at 0.89 of what its MFMA count
+    // allows: the narrow tile's blocks with their waves 4 x 1 on the 64 real columns (half the MFMAs per k-tile), listed last in
+    // every XCD's share of the grid, splits sized for 4.5 tile units (112 instead of 102): 527 -> 611 us.  A narrow block still
+    // pays the whole chain per k-tile, so it is not half a block, and 560 blocks no longer fit one wave of resident slots.)
     const long long slots = 2LL * dev->num_cus;
     long long waves = (tiles * ((rtiles + 127) / 128) + slots - 1) / slots;  // <= ~128 k-tiles per block ...
     if (waves < 1) waves = 1;
