@@ -96,7 +96,7 @@ int conv_fwd(nk_device* dev, int nd, const float* x, const int* x_shape, const f
     const int K = g.Cg * g.KK;
     const long long x_elems = (long long)g.N * g.Cin * g.inplane, y_elems = (long long)g.N * g.Cout * g.L;
     const long long fcols = (long long)g.N * g.out[0] * g.out[1] * ((g.out[2] + 3) & ~3);  // row-padded column space
-    if (g.Cg % BK == 0 && g.stride[2] == 1 && g.out[2] >= 4 && x_elems < 0x7fffffffLL && y_elems < 0x7fffffffLL && fcols < 0x7fffff00LL) {
+    if (g.Cg % BK == 0 && (g.stride[2] == 1 || g.stride[2] == 2) && g.out[2] >= 4 && x_elems < 0x7fffffffLL && y_elems < 0x7fffffffLL && fcols < 0x7fffff00LL) {
         const size_t wp_bytes = round256((size_t)g.Cout * K * sizeof(float));
         const size_t to_bytes = round256((size_t)g.KK * sizeof(int));
         const size_t tables = wp_bytes + to_bytes + round256((size_t)g.KK * sizeof(int4));
@@ -137,7 +137,11 @@ int conv_fwd(nk_device* dev, int nd, const float* x, const int* x_shape, const f
         dim3 fgrid(nblocks, 1, groups);
         rc = nk_prof_start(dev, NK_KERNEL_CONV, 2.0 * g.N * (double)g.Cout * g.L * g.Cg * g.KK);
         if (rc) return rc;
-#define NK_LAUNCH_FF(AL, TI_, RP_) hipLaunchKernelGGL((conv_fwd_fast_kernel<AL, TI_, RP_>), fgrid, dim3(NT), 0, dev->compute, fp)
+#define NK_LAUNCH_FF(AL, TI_, RP_)                                                                                          \
+    do {                                                                                                                    \
+        if (g.stride[2] == 2) hipLaunchKernelGGL((conv_fwd_fast_kernel<AL, TI_, RP_, 2>), fgrid, dim3(NT), 0, dev->compute, fp); \
+        else hipLaunchKernelGGL((conv_fwd_fast_kernel<AL, TI_, RP_, 1>), fgrid, dim3(NT), 0, dev->compute, fp);               \
+    } while (0)
         if (g.out[2] % 4 == 0) {
             if (al && fti == 2) NK_LAUNCH_FF(true, 2, false);
             else if (al) NK_LAUNCH_FF(true, 1, false);
@@ -403,7 +407,7 @@ int conv_bwd_kernel(nk_device* dev, int nd, float* dw, const int* w_shape, const
         for (int i = 0; i < nd; ++i) { gshape[2 + i] = g.out[3 - nd + i]; bshape[1 + i] = 1; }
         return (assign_b ? nk_unbroadcast_assign : nk_unbroadcast_add)(dev, db, bshape, nd + 1, gy, gshape, nd + 2);
     };
-    const bool quadr = g.stride[2] == 1 && g.out[2] >= 4;  // row-padded quad staging (see the kernel)
+    const bool quadr = (g.stride[2] == 1 || g.stride[2] == 2) && g.out[2] >= 4;  // row-padded quad staging (see the kernel)
     const long long R = quadr ? (long long)g.N * g.out[0] * g.out[1] * ((g.out[2] + 3) & ~3) : (long long)g.N * g.L;
     const int Kc = g.Cg * g.KK;
     if ((long long)g.Cout * Kc == 0) return bias_by_reduction();
@@ -485,7 +489,14 @@ int conv_bwd_kernel(nk_device* dev, int nd, float* dw, const int* w_shape, const
     rc = nk_prof_start(dev, NK_KERNEL_CONV, 2.0 * g.N * (double)g.Cout * g.L * g.Cg * g.KK);
     if (rc) return rc;
 #define NK_LAUNCH_BWK(VG, TI_, TJ_, Q) hipLaunchKernelGGL((conv_bwd_kernel_kernel<VG, TI_, TJ_, Q>), grid, dim3(NT), 0, dev->compute, p)
-    if (quadr) {
+    if (quadr && g.stride[2] == 2) {
+#define NK_LAUNCH_BWK2(TI_, TJ_) hipLaunchKernelGGL((conv_bwd_kernel_kernel<true, TI_, TJ_, true, 2>), grid, dim3(NT), 0, dev->compute, p)
+        if (ti == 2 && tj == 2) NK_LAUNCH_BWK2(2, 2);
+        else if (ti == 2) NK_LAUNCH_BWK2(2, 1);
+        else if (tj == 2) NK_LAUNCH_BWK2(1, 2);
+        else NK_LAUNCH_BWK2(1, 1);
+#undef NK_LAUNCH_BWK2
+    } else if (quadr) {
         if (ti == 2 && tj == 2) NK_LAUNCH_BWK(true, 2, 2, true);
         else if (ti == 2) NK_LAUNCH_BWK(true, 2, 1, true);
         else if (tj == 2) NK_LAUNCH_BWK(true, 1, 2, true);

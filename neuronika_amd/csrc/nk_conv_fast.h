@@ -121,12 +121,16 @@ struct FastFwdArgs {
     float* slabs;
 };
 
-// requires Cg % 32 == 0, stride[2] == 1, out[2] >= 4, per-tensor element counts < 2^31.
+// requires Cg % 32 == 0, stride[2] == 1 or 2 (SW), out[2] >= 4, per-tensor element counts < 2^31.
 // Columns are (n, o0, o1, c') with the innermost output row padded to W4 = a multiple of 4, so the quad a thread stages is
 // four consecutive positions of ONE output row = one unaligned 16-byte load per staged row.  RP (out[2] % 4 != 0): the
 // last quad of a row is loaded `dup` elements earlier (so that it ends inside the input row) and shifted left by `dup`
 // behind the MFMAs; its trailing `dup` columns are dummies whose accumulators are never stored.
-template <bool ALIGNED_A, int TI, bool RP>
+// SW = stride on the innermost axis, 1 or 2.  SW = 2 (the downsampling convolutions of a ResNet-style stack): the four consecutive
+// output positions of a quad read input positions 0, 2, 4, 6 from the quad's origin - two unaligned 16-byte loads per staged row,
+// at +0 (elements 0 and 2 are taken) and at +3 (elements 1 and 3, i.e. positions 4 and 6; a load at +4 would read one float past
+// the last position the convolution needs, which at the end of the tensor is past the allocation).
+template <bool ALIGNED_A, int TI, bool RP, int SW = 1>
 __global__ __launch_bounds__(NT, 2) void conv_fwd_fast_kernel(FastFwdArgs p) {
     constexpr int TJ = 2, BM = 64 * TI, BN = 64 * TJ;
     constexpr int TA_FLOATS = tile_floats<true, BM>(), STAGE = TA_FLOATS + tile_floats<false, BN>();
@@ -167,7 +171,7 @@ __global__ __launch_bounds__(NT, 2) void conv_fwd_fast_kernel(FastFwdArgs p) {
         const int oa = ab / g.out[1], ob = ab - oa * g.out[1];
         const int cs = RP ? min(oc, g.out[2] - 4) : oc;
         dup = oc - cs;
-        xb = n * g.Cin * g.inplane + (oa * g.stride[0] * g.in[1] + ob * g.stride[1]) * g.in[2] + cs + krow * g.inplane;
+        xb = n * g.Cin * g.inplane + (oa * g.stride[0] * g.in[1] + ob * g.stride[1]) * g.in[2] + cs * SW + krow * g.inplane;
     }
     const int jstep = 8 * g.inplane;
     auto gather = [&](int kt) {
@@ -181,6 +185,17 @@ __global__ __launch_bounds__(NT, 2) void conv_fwd_fast_kernel(FastFwdArgs p) {
         const f32x4u q1 = *reinterpret_cast<const f32x4u*>(src + xb + jstep);
         const f32x4u q2 = *reinterpret_cast<const f32x4u*>(src + xb + 2 * jstep);
         const f32x4u q3 = *reinterpret_cast<const f32x4u*>(src + xb + 3 * jstep);
+        if constexpr (SW == 2) {
+            const f32x4u h0 = *reinterpret_cast<const f32x4u*>(src + xb + 3);
+            const f32x4u h1 = *reinterpret_cast<const f32x4u*>(src + xb + jstep + 3);
+            const f32x4u h2 = *reinterpret_cast<const f32x4u*>(src + xb + 2 * jstep + 3);
+            const f32x4u h3 = *reinterpret_cast<const f32x4u*>(src + xb + 3 * jstep + 3);
+            r.v0 = make_float4(q0.x, q0.z, h0.y, h0.w);
+            r.v1 = make_float4(q1.x, q1.z, h1.y, h1.w);
+            r.v2 = make_float4(q2.x, q2.z, h2.y, h2.w);
+            r.v3 = make_float4(q3.x, q3.z, h3.y, h3.w);
+            return r;
+        }
         r.v0 = make_float4(q0.x, q0.y, q0.z, q0.w);
         r.v1 = make_float4(q1.x, q1.y, q1.z, q1.w);
         r.v2 = make_float4(q2.x, q2.y, q2.z, q2.w);

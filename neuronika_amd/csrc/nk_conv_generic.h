@@ -322,8 +322,11 @@ struct BwdKArgs {
 // one (incremental, division-free) decode per k-tile and one 16-byte load per staged row.  A quad that would run past the
 // row end (out[2] % 4 != 0) is loaded `dup` elements earlier - for BOTH operands, a reduction does not care where in the
 // k-tile an element sits - and its first `dup` elements, already counted by the previous quad, are masked.
-template <bool VEC_G, int TI, int TJ, bool QUADR>
+// SW (QUADR only): stride on the innermost axis, 1 or 2 - with 2 the X quad of four consecutive output positions is input positions
+// 0, 2, 4, 6 from its origin: two unaligned 16-byte loads per staged row (at +0 and +3, see conv_fwd_fast_kernel), G is unit-stride.
+template <bool VEC_G, int TI, int TJ, bool QUADR, int SW = 1>
 __global__ __launch_bounds__(NT, 2) void conv_bwd_kernel_kernel(BwdKArgs p) {
+    static_assert(SW == 1 || QUADR, "strided quads: the row-padded form only");
     constexpr int BM = 64 * TI, BN = 64 * TJ;
     constexpr int TA_FLOATS = tile_floats<true, BM>(), STAGE = TA_FLOATS + tile_floats<true, BN>();
     __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
@@ -385,7 +388,7 @@ __global__ __launch_bounds__(NT, 2) void conv_bwd_kernel_kernel(BwdKArgs p) {
         qv = v;
         const int cs = min(q2, g.out[2] - 4);  // start clamped so that the quad ends inside the row
         qdup = q2 - cs;
-        const long long x0 = v ? (long long)qn * g.Cin * g.inplane + ((q0 * g.stride[0] * g.in[1] + q1 * g.stride[1]) * g.in[2] + cs) : 0;
+        const long long x0 = v ? (long long)qn * g.Cin * g.inplane + ((q0 * g.stride[0] * g.in[1] + q1 * g.stride[1]) * g.in[2] + cs * SW) : 0;
         const long long g0 = v ? (long long)qn * g.Cout * g.L + ((q0 * g.out[1] + q1) * g.out[2] + cs) : 0;
         q2 += BK;  // next k-tile: 32 positions further along the (row-padded) reduction index
         while (q2 >= W4) { q2 -= W4; ++q1; }
@@ -394,8 +397,16 @@ __global__ __launch_bounds__(NT, 2) void conv_bwd_kernel_kernel(BwdKArgs p) {
 #define NK_LDU(V, P) { const f32x4u q = *reinterpret_cast<const f32x4u*>(P); V = make_float4(q.x, q.y, q.z, q.w); }
         NK_LDU(ra.v0, G + g0 + aro0) NK_LDU(ra.v1, G + g0 + aro1)
         if constexpr (TI == 2) { NK_LDU(ra.v2, G + g0 + aro2) NK_LDU(ra.v3, G + g0 + aro3) }
-        NK_LDU(rb.v0, X + x0 + ko0) NK_LDU(rb.v1, X + x0 + ko1)
-        if constexpr (TJ == 2) { NK_LDU(rb.v2, X + x0 + ko2) NK_LDU(rb.v3, X + x0 + ko3) }
+        if constexpr (SW == 2) {
+#define NK_LDS2(V, P) { const f32x4u lo = *reinterpret_cast<const f32x4u*>(P); const f32x4u hi = *reinterpret_cast<const f32x4u*>((P) + 3); \
+                        V = make_float4(lo.x, lo.z, hi.y, hi.w); }
+            NK_LDS2(rb.v0, X + x0 + ko0) NK_LDS2(rb.v1, X + x0 + ko1)
+            if constexpr (TJ == 2) { NK_LDS2(rb.v2, X + x0 + ko2) NK_LDS2(rb.v3, X + x0 + ko3) }
+#undef NK_LDS2
+        } else {
+            NK_LDU(rb.v0, X + x0 + ko0) NK_LDU(rb.v1, X + x0 + ko1)
+            if constexpr (TJ == 2) { NK_LDU(rb.v2, X + x0 + ko2) NK_LDU(rb.v3, X + x0 + ko3) }
+        }
 #undef NK_LDU
     };
     // applied AFTER the MFMAs of the current k-tile (touching the loaded registers earlier would wait for the loads)
