@@ -262,6 +262,7 @@ int conv_bwd_input(nk_device* dev, int nd, float* dx, const int* x_shape, const 
         BwdInPhaseTable tbl{};
         long long tiles_n = 0, max_cols = 0;
         bool fits = nphase <= MAX_PHASES && g.Mg % BK == 0 && g.out[2] >= 4 && x_elems < 0x7fffffffLL && y_elems < 0x7fffffffLL;
+        bool empty_phase = false;  // a residue class no tap reaches (1 x 1 kernel, stride 2: three of the four): its gradient is zero
         if (fits) {
             int tap_begin = 0;
             for (int pid = 0; pid < nphase; ++pid) {
@@ -284,13 +285,19 @@ int conv_bwd_input(nk_device* dev, int nd, float* dx, const int* x_shape, const 
                 ph.tap_begin = tap_begin; ph.ntaps = ntaps;
                 tap_begin += ntaps;
                 ph.tile_begin = (int)tiles_n;
+                if (ntaps == 0 && cols > 0) {  // no tiles: `+=` has nothing to add; a first write zeroes the tensor once (below)
+                    empty_phase = true;        // instead of storing zeros through the tile epilogue's interleaved 4-byte stores
+                    cols = 0;
+                }
                 tiles_n += (cols + 127) / 128;
                 if (cols > max_cols) max_cols = cols;
             }
             for (int pid = nphase; pid < MAX_PHASES; ++pid) tbl.ph[pid].tile_begin = 0x7fffffff;
-            fits = max_cols < 0x7fffff00LL && tiles_n < 0x7fffffffLL;
+            fits = max_cols < 0x7fffff00LL && tiles_n < 0x7fffffffLL && tiles_n > 0;
         }
         if (fits) {
+            if (empty_phase && g.assign)  // every position belongs to exactly one phase: the others assign theirs after this
+                NK_HIP(hipMemsetAsync(dx, 0, (size_t)g.N * g.Cin * g.uinplane * sizeof(float), dev->compute));
             const size_t wq_bytes = round256((size_t)g.Cout * g.Cg * g.KK * sizeof(float));
             const size_t td_bytes = round256((size_t)g.KK * sizeof(int4));
             const size_t ph_bytes = round256(sizeof(BwdInPhaseTable));

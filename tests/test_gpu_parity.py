@@ -1003,7 +1003,11 @@ def test_assign_variants_equal_accumulate_into_zeros(dev):
     c.merge_heads_bwd(dev, A, dev.array(gf), B, S, H, dh, assign=True); c.merge_heads_bwd(dev, Z, dev.array(gf), B, S, H, dh)
     assert np.array_equal(A.numpy(), Z.numpy())
     for xs, ws, st, dl, gr in [((3, 4, 9, 8), (6, 2, 3, 3), (1, 1), (1, 1), 2), ((2, 32, 12, 12), (32, 32, 3, 3), (1, 1), (1, 1), 1),
-                               ((2, 3, 11), (4, 3, 3), (2,), (1,), 1)]:
+                               ((2, 3, 11), (4, 3, 3), (2,), (1,), 1),
+                               # stride phases of the fast input-gradient pass: none / three of four / three of four without a tap (those
+                               # positions are zeroed by one memset on a first write and left alone by `+=`)
+                               ((2, 32, 13, 14), (32, 32, 3, 3), (2, 2), (1, 1), 1), ((2, 32, 12, 11), (64, 32, 1, 1), (2, 2), (1, 1), 1),
+                               ((2, 32, 17, 19), (32, 32, 3, 3), (2, 2), (2, 2), 1)]:
         xx, ww = rnd(9, xs, -1, 1), rnd(10, ws, -1, 1)
         osp = tuple((n - d * (k - 1) - 1) // s + 1 for n, k, s, d in zip(xs[2:], ws[2:], st, dl))
         gy = rnd(11, (xs[0], ws[0]) + osp, -1, 1)
