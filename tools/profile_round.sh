@@ -14,4 +14,5 @@ for w in mlp matmul conv mha; do
   [ -n "$db" ] && python "$root/tools/rocpd_kernel_stats.py" "$db" > "$root/$out/${tag}_${w}_step_kernel_stats.md"
 done
 timeout -k 5 300 python "$root/benchmarks/microbench.py" > "$root/$out/${tag}_microbench.jsonl" 2>&1
+timeout -k 5 300 python "$root/benchmarks/conv_shapes.py" > "$root/$out/${tag}_conv_shapes.jsonl" 2>&1
 find "$root/$out" -name "*.db" -delete
