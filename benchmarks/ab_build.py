@@ -2,7 +2,10 @@
 
     python benchmarks/ab_build.py kc_linear -DNK_AB_KC_LINEAR      -> benchmarks/_ab/kc_linear.so
     NEURONIKA_HIP_LIB=benchmarks/_ab/kc_linear.so python benchmarks/ab_gemm.py
+    python benchmarks/ab_build.py nofold --sed 's/KFOLD_TILES = 32;/KFOLD_TILES = 1 << 20;/' nk_gemm.hip
+        -> the same from a COPY of csrc/ with the sed expression applied to the named file (variants that are an edit, not a flag)
 """
+import shutil
 import os
 import subprocess
 import sys
@@ -16,12 +19,28 @@ def main():
     out_dir = os.path.join(ROOT, "benchmarks", "_ab")
     obj_dir = os.path.join(out_dir, "obj_" + name)
     os.makedirs(obj_dir, exist_ok=True)
+    csrc = CSRC
+    while "--sed" in flags:
+        i = flags.index("--sed")
+        expr, fname = flags[i + 1], flags[i + 2]
+        del flags[i:i + 3]
+        if csrc == CSRC:
+            csrc = os.path.join(out_dir, "src_" + name)
+            shutil.rmtree(csrc, ignore_errors=True)
+            shutil.copytree(CSRC, csrc)
+        before = open(os.path.join(csrc, fname)).read()
+        subprocess.run(["sed", "-i", expr, os.path.join(csrc, fname)], check=True)
+        if open(os.path.join(csrc, fname)).read() == before:
+            raise SystemExit(f"--sed {expr!r} changed nothing in {fname}")
     objs = []
-    for src in sorted(f for f in os.listdir(CSRC) if f.endswith(".hip")):
+    import concurrent.futures as cf
+    def one(src):
         obj = os.path.join(obj_dir, src.replace(".hip", ".o"))
         subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"),
-                        "-I" + CSRC, *flags, "-c", os.path.join(CSRC, src), "-o", obj], check=True, stderr=subprocess.DEVNULL)
-        objs.append(obj)
+                        "-I" + csrc, *flags, "-c", os.path.join(csrc, src), "-o", obj], check=True, stderr=subprocess.DEVNULL)
+        return obj
+    with cf.ThreadPoolExecutor(8) as ex:
+        objs = list(ex.map(one, sorted(f for f in os.listdir(csrc) if f.endswith(".hip"))))
     lib = os.path.join(out_dir, name + ".so")
     subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs, "-L/opt/rocm/lib", "-lrccl",
                     "-Wl,-rpath,/opt/rocm/lib"], check=True)

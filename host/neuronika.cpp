@@ -800,17 +800,26 @@ struct LossBwd : Backward {
     void targets(std::vector<const Gradient*>& out) const override { out.push_back(dx.get()); }
 };
 
-// `Linear::forward` as one node: mm_t + broadcast Addition (neuronika-nn/src/lib.rs:443-446)
+// `Linear::forward` as one node: mm_t + broadcast Addition (neuronika-nn/src/lib.rs:443-446); `relu`: followed by the ReLU
+// node (node/relu/mod.rs:29-38) in the same epilogue
 struct LinearFwd : Forward {
     Shared<HipArray> x, w, b, y;
+    bool relu = false;
     void forward() const override {
-        check(nk_linear_fwd(D(x), x->ptr(), w->ptr(), b->ptr(), y->ptr(), x->shape()[0], x->shape()[1], w->shape()[0]));
+        check((relu ? nk_linear_relu_fwd : nk_linear_fwd)(D(x), x->ptr(), w->ptr(), b->ptr(), y->ptr(), x->shape()[0], x->shape()[1], w->shape()[0]));
     }
 };
 struct LinearBwd : Backward {
     Shared<HipArray> x, w;
+    Shared<HipArray> y;              // set for the fused Linear+ReLU node: its output, the mask of its own gradient
     Shared<Gradient> dx, dw, db, g;  // dx null for a non-differentiable input
     void backward() const override {
+        // Linear+ReLU: g must hold dL/dz = (y > 0) * dL/dy.  When every writer of g on this tape applied the mask while
+        // storing (`premasked`, decided by VarDiff::run_backward), it already does; otherwise mask it in place now
+        if (y && !g->premasked()) {
+            HipArray& Gm = g->borrow();
+            check(nk_relu_mask_inplace(D(x), Gm.ptr(), y->ptr(), Gm.len()));
+        }
         const HipArray& G = g->borrow();
         nk_device* dev = D(x);
         const int n = x->shape()[0], m = x->shape()[1], o = w->shape()[0];
@@ -818,7 +827,13 @@ struct LinearBwd : Backward {
         // order is free: the bias gradient goes first (the data-parallel exchange then sends the small gradients of
         // the whole model as one group while the last weight-gradient GEMMs still run), the weight gradient last
         float beta;  // nk_mm_t_bwd_left / nk_mm_t_bwd_right, with beta 0 when the gradient's zero fill is still pending
-        if (dx) { float* d = first_write(dx, beta); check(nk_sgemm(dev, 0, 0, n, m, o, 1.f, G.ptr(), o, w->ptr(), m, beta, d, m)); }
+        if (dx) {
+            float* d = first_write(dx, beta);
+            if (dx->premasked())  // x is the output of a Linear+ReLU node: store (x > 0) * (G . W), its pre-activation gradient
+                check(nk_linear_bwd_input_relu(dev, d, G.ptr(), w->ptr(), x->ptr(), n, m, o, beta == 0.f ? 1 : 0));
+            else
+                check(nk_sgemm(dev, 0, 0, n, m, o, 1.f, G.ptr(), o, w->ptr(), m, beta, d, m));
+        }
         {
             // (the bias gradient goes first and on its own: under the data-parallel hook the small gradients of the whole model
             //  leave as one group as soon as the last of them is final - in front of this layer's weight-gradient GEMMs.
@@ -852,6 +867,10 @@ struct LinearBwd : Backward {
         if (dx) out.push_back(dx.get());
         out.push_back(dw.get());
         out.push_back(db.get());
+    }
+    void premask_targets(std::vector<const Gradient*>& out) const override {
+        // only when the mask source IS this node's input buffer (the gradient belongs to the node that produced x)
+        if (dx && dx->premask_source() && dx->premask_source().get() == x.get()) out.push_back(dx.get());
     }
 };
 
@@ -1338,6 +1357,14 @@ void VarDiff::backward(float seed, BackwardHook* hook) const {
 void VarDiff::backward_from(const Var& seed, BackwardHook* hook) const {
     if (var.history.len() != var.history.buffer_len()) panic("Perhaps you forgot to call .forward()?");
     if (seed.shape() != shape()) panic("backward_from: the seed must have the shape of the root");
+    if (grad->premask_source()) {
+        // a fused Linear+ReLU root masks its gradient buffer in place: give it a copy, not the caller's tensor
+        bool assign = false;
+        HipArray& own = grad->borrow_first_write(assign);
+        check(nk_copy(device()->raw(), own.ptr(), seed.data->ptr(), own.len()));
+        run_backward(hook);
+        return;
+    }
     // the root's backward nodes read the root gradient through `borrow()` when they run: let them see the seed's buffer
     const bool was_pending = grad->zero_pending();
     Shared<HipArray> own = grad->exchange_array(seed.data);
@@ -1347,8 +1374,27 @@ void VarDiff::backward_from(const Var& seed, BackwardHook* hook) const {
     } restore{grad, own, was_pending};
     run_backward(hook);
 }
+// Pre-masked gradients (fused Linear+ReLU): a gradient that names a mask source is written pre-masked in THIS pass iff
+// every tape node that writes it can do so.
+static void decide_premasked(const std::vector<BackwardEntry>& buffer) {
+    std::unordered_map<const Gradient*, std::pair<int, int>> count;  // gradient -> (writers, mask-capable writers)
+    std::vector<const Gradient*> ts;
+    for (const BackwardEntry& e : buffer) {
+        if (const auto* own = dynamic_cast<const Gradient*>(e.grad.get()))
+            if (own->premask_source()) count[own];  // a root has no writers: it is seeded with plain values
+        ts.clear();
+        e.op->targets(ts);
+        for (const Gradient* g : ts)
+            if (g->premask_source()) ++count[g].first;
+        ts.clear();
+        e.op->premask_targets(ts);
+        for (const Gradient* g : ts) ++count[g].second;
+    }
+    for (const auto& kv : count) kv.first->set_premasked(kv.second.first > 0 && kv.second.first == kv.second.second);
+}
 void VarDiff::run_backward(BackwardHook* hook) const {
     auto& buffer = history.buffer_mut();
+    decide_premasked(buffer);
     if (!hook) {
         for (auto it = buffer.rbegin(); it != buffer.rend(); ++it) it->op->backward();
         return;
@@ -1691,7 +1737,7 @@ void xavier_normal(const VarDiff& p, float gain, uint64_t seed) {
 Linear::Linear(DevicePtr dev, int in_features, int out_features, uint64_t seed)
     : weight(uniform_param(dev, {out_features, in_features}, 1.f / std::sqrt((float)in_features), seed)),
       bias(uniform_param(dev, {out_features}, 1.f / std::sqrt((float)in_features), seed + 1)) {}
-static VarDiff linear_node(const Linear& l, const Var& x, const Shared<Gradient>& dx, const History<BackwardEntry>* hx) {
+static VarDiff linear_node(const Linear& l, const Var& x, const Shared<Gradient>& dx, const History<BackwardEntry>* hx, bool relu = false) {
     const Shape& xs = x.shape();
     const Shape& ws = l.weight.shape();
     if (xs.size() != 2 || ws.size() != 2 || xs[1] != ws[1]) panic("Shapes are incompatible for matrix multiplication.");
@@ -1701,6 +1747,7 @@ static VarDiff linear_node(const Linear& l, const Var& x, const Shared<Gradient>
     h.merge(l.bias.var.history);
     auto fw = std::make_shared<LinearFwd>();
     fw->x = x.data; fw->w = l.weight.var.data; fw->b = l.bias.var.data; fw->y = zeros_like(x.data, Shape{xs[0], ws[0]});
+    fw->relu = relu;
     auto y = fw->y;
     Var var = Var::node(y, fw, std::move(h));
     History<BackwardEntry> hb;
@@ -1708,8 +1755,10 @@ static VarDiff linear_node(const Linear& l, const Var& x, const Shared<Gradient>
     hb.merge(l.weight.history);
     hb.merge(l.bias.history);
     auto g = std::make_shared<Gradient>(var.device(), var.shape());
+    if (relu) g->set_premask_source(y);
     auto bw = std::make_shared<LinearBwd>();
     bw->x = x.data; bw->w = l.weight.var.data; bw->dx = dx; bw->dw = l.weight.grad; bw->db = l.bias.grad; bw->g = g;
+    if (relu) bw->y = y;
     return VarDiff::node(std::move(var), g, entry(bw, g), std::move(hb));
 }
 VarDiff Linear::forward(const Var& input) const {
@@ -1717,6 +1766,12 @@ VarDiff Linear::forward(const Var& input) const {
 }
 VarDiff Linear::forward(const VarDiff& input) const {
     return fused ? linear_node(*this, input.var, input.grad, &input.history) : input.mm_t(weight) + bias;
+}
+VarDiff Linear::forward_relu(const Var& input) const {
+    return fused ? linear_node(*this, input, nullptr, nullptr, true) : (input.mm_t(weight) + bias).relu();
+}
+VarDiff Linear::forward_relu(const VarDiff& input) const {
+    return fused ? linear_node(*this, input.var, input.grad, &input.history, true) : (input.mm_t(weight) + bias).relu();
 }
 
 LSTMCell::LSTMCell(DevicePtr dev, int input_size, int hidden_size, uint64_t seed)
@@ -2008,6 +2063,27 @@ void Optimizer::zero_grad() const {
 
 SGD::SGD(float lr, Penalty penalty, float momentum, float dampening, bool nesterov)
     : Optimizer(lr, penalty, momentum > 1.1920929e-7f ? 1 : 0), momentum_(momentum), dampening_(dampening), nesterov_(nesterov) {}
+void SGD::step() {
+    // one launch per device for all registered parameters (their updates are independent; optimizer.rs:81-86)
+    std::vector<float*> w, g, v;
+    std::vector<size_t> n;
+    std::vector<bool> done(params_.size(), false);
+    for (size_t i = 0; i < params_.size(); ++i) {
+        if (done[i]) continue;
+        const DevicePtr dev = params_[i].device();
+        w.clear(); g.clear(); v.clear(); n.clear();
+        for (size_t k = i; k < params_.size(); ++k) {
+            if (done[k] || params_[k].device().get() != dev.get()) continue;
+            done[k] = true;
+            ++steps_[k];
+            HipArray& gr = params_[k].grad->borrow();
+            w.push_back(params_[k].var.data->ptr()); g.push_back(gr.ptr());
+            v.push_back(state_[k].empty() ? nullptr : state_[k][0]->ptr()); n.push_back(gr.len());
+        }
+        check(nk_sgd_step_multi(dev->raw(), (int)w.size(), w.data(), g.data(), v.data(), n.data(), lr_, momentum_, dampening_,
+                                nesterov_ ? 1 : 0, penalty_.l1, penalty_.l2));
+    }
+}
 void SGD::optimize(const VarDiff& p, std::vector<Shared<HipArray>>& st, int) {
     HipArray& g = p.grad->borrow();
     check(nk_sgd_step(p.device()->raw(), p.var.data->ptr(), g.ptr(), st.empty() ? nullptr : st[0]->ptr(), g.len(), lr_,

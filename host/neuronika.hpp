@@ -133,6 +133,9 @@ struct Backward {
     virtual void backward() const = 0;
     // gradients this node accumulates into (used to tell when a leaf gradient is final)
     virtual void targets(std::vector<const Gradient*>& out) const = 0;
+    // the subset of `targets` this node can write PRE-MASKED when the gradient asks for it (`Gradient::premask_source`):
+    // a Linear node's input gradient, whose GEMM epilogue applies the ReLU mask of the node that produced the input
+    virtual void premask_targets(std::vector<const Gradient*>&) const {}
 };
 // Called by VarDiff::backward right after the LAST tape node writing into a gradient has been
 // issued: the hook of the data-parallel exchange (dp::GradientSync).
@@ -175,12 +178,22 @@ class Gradient : public NoGrad {
     const Shape& shape() const { return shape_; }
     void no_grad() override;
     void with_grad() override;
+    // Fused Linear+ReLU (`nn::Linear::forward_relu`): the gradient of its output y holds dL/dz of the PRE-activation.  The
+    // node names y as the mask source; `VarDiff::backward` decides per pass (`set_premasked`) whether every node that
+    // writes this gradient on the tape can apply `(y > 0) *` itself while storing (`Backward::premask_targets`); if not,
+    // the writers store plain contributions and the owner masks the buffer in place before using it (idempotent).
+    void set_premask_source(Shared<HipArray> y) { premask_src_ = std::move(y); }
+    const Shared<HipArray>& premask_source() const { return premask_src_; }
+    void set_premasked(bool on) const { premasked_ = on; }
+    bool premasked() const { return premasked_; }
 
    private:
     DevicePtr dev_;
     Shape shape_;
     Shared<HipArray> array_;
     mutable bool pending_zero_ = true;
+    Shared<HipArray> premask_src_;
+    mutable bool premasked_ = false;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -471,6 +484,13 @@ struct Linear {
     Linear(VarDiff weight, VarDiff bias) : weight(std::move(weight)), bias(std::move(bias)) {}
     VarDiff forward(const Var& input) const;      // input.mm_t(W) + b
     VarDiff forward(const VarDiff& input) const;
+    // `forward(input).relu()` as ONE node (ours; the reference composes the two): max(input.W^T + b, 0) from the GEMM
+    // epilogue, the pre-activation never stored; in the backward pass the ReLU mask is applied by whichever GEMM produces
+    // this node's output gradient (a following Linear's input-gradient GEMM), or in place when another kind of node does.
+    // Same values and gradients as the two nodes, bit for bit; the one observable difference: after `backward`, the
+    // OUTPUT's `grad()` holds the gradient of the pre-activation, (y > 0) * dL/dy.
+    VarDiff forward_relu(const Var& input) const;
+    VarDiff forward_relu(const VarDiff& input) const;
 };
 
 // `LSTMCell` neuronika-nn/src/lib.rs:453-541.  Weights (4H,in)/(4H,H), biases (4H), U(-k,k), k = 1/sqrt(H).
@@ -622,7 +642,7 @@ class Optimizer {
    public:
     virtual ~Optimizer() = default;
     void register_param(const VarDiff& p);  // `register`
-    void step();
+    virtual void step();
     void zero_grad() const;
     float get_lr() const { return lr_; }
     void set_lr(float lr) { lr_ = lr; }
@@ -634,16 +654,19 @@ class Optimizer {
     float lr_;
     Penalty penalty_;
 
-   private:
-    int nstate_;
+   protected:
     std::vector<VarDiff> params_;
     std::vector<std::vector<Shared<HipArray>>> state_;
     std::vector<int> steps_;
+
+   private:
+    int nstate_;
 };
 
 class SGD : public Optimizer {  // sgd/mod.rs
    public:
     SGD(float lr, Penalty penalty = {}, float momentum = 0.f, float dampening = 0.f, bool nesterov = false);
+    void step() override;  // every registered parameter of a device in ONE launch (nk_sgd_step_multi)
 
    private:
     void optimize(const VarDiff& p, std::vector<Shared<HipArray>>& state, int step) override;

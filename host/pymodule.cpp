@@ -247,7 +247,9 @@ PYBIND11_MODULE(_tape, m) {
         .def_readonly("bias", &nn::Linear::bias)
         .def_readwrite("fused", &nn::Linear::fused)
         .def("forward", py::overload_cast<const Var&>(&nn::Linear::forward, py::const_))
-        .def("forward", py::overload_cast<const VarDiff&>(&nn::Linear::forward, py::const_));
+        .def("forward", py::overload_cast<const VarDiff&>(&nn::Linear::forward, py::const_))
+        .def("forward_relu", py::overload_cast<const Var&>(&nn::Linear::forward_relu, py::const_))
+        .def("forward_relu", py::overload_cast<const VarDiff&>(&nn::Linear::forward_relu, py::const_));
     {
         py::module_ im = nn.def_submodule("init");
         im.def("calculate_gain", &nn::init::calculate_gain);

@@ -165,6 +165,21 @@ int nk_mm_t_bwd_right(nk_device* dev, float* dB, const float* G, const float* A,
  * bias is added to the f32 accumulator in the GEMM epilogue, bit-identical to the two-node result.  Its backward is
  * nk_mm_t_bwd_left (dX += G.W), nk_mm_t_bwd_right (dW += G^T.X) and nk_unbroadcast_add (db += column sums of G). */
 int nk_linear_fwd(nk_device* dev, const float* X, const float* W, const float* bias, float* Y, int n, int m, int o);
+/* `Linear::forward` followed by `ReLU::forward` (node/relu/mod.rs:29-38) as ONE kernel: Y = max(X.W^T + b, 0), the ReLU
+ * applied to the f32 value the Linear epilogue would have stored (`o.max(0.)`: a NaN gives 0) - bit-identical to the two
+ * launches; the pre-activation is never written.  ReLU's backward needs only `x > 0`, and max(x, 0) > 0 <=> x > 0, so Y
+ * itself is the mask (nk_linear_bwd_input_relu, nk_relu_mask_inplace). */
+int nk_linear_relu_fwd(nk_device* dev, const float* X, const float* W, const float* bias, float* Y, int n, int m, int o);
+/* MatrixMatrixMulTBackwardLeft::backward (matrix_matrix_mul_t/mod.rs:63-73) followed by ReLUBackward::backward
+ * (relu/mod.rs:67-79) of the node that produced this Linear's input X(n,m) = max(Z, 0):
+ *   dZ(n,m) (+)= mask * (G(n,o).W(o,m)),  mask = ((X > 0.) as usize as f32)   (0 * inf = NaN, as the reference's product)
+ * applied when the GEMM tile is stored: the gradient w.r.t. X is never written.  assign != 0: dZ is a freshly zeroed
+ * gradient, written without being read. */
+int nk_linear_bwd_input_relu(nk_device* dev, float* dZ, const float* G, const float* W, const float* X, int n, int m, int o,
+                             int assign);
+/* ReLUBackward::backward in place: g = ((y > 0.) as f32) * g  (the fused Linear+ReLU node's fallback when a consumer other
+ * than nk_linear_bwd_input_relu wrote into its gradient; idempotent, so contributions that arrived masked stay as they are) */
+int nk_relu_mask_inplace(nk_device* dev, float* g, const float* y, size_t n);
 
 /* ------------------------------------------------------------------ convolution -------- */
 /* N-d (nd = 1,2,3) cross-correlation without internal padding, NC[D]HW layout.
@@ -485,6 +500,11 @@ int nk_merge_heads_bwd(nk_device* dev, float* dx, const float* g, int B, int S, 
  * nesterov: w -= (grad + buffer*momentum)*lr, else w -= buffer*lr. */
 int nk_sgd_step(nk_device* dev, float* w, float* grad, float* velocity, size_t n, float lr,
                 float momentum, float dampening, int nesterov, float l1, float l2);
+/* The same update for `count` parameters in ONE launch (`Optimizer::step`, optimizer.rs:81-86, walks the registered
+ * parameters; their updates are independent): w[i], grad[i], n[i] as above, velocity == NULL or velocity[i] == NULL without
+ * momentum.  Element for element the arithmetic of nk_sgd_step. */
+int nk_sgd_step_multi(nk_device* dev, int count, float* const* w, float* const* grad, float* const* velocity, const size_t* n,
+                      float lr, float momentum, float dampening, int nesterov, float l1, float l2);
 /* AdamParam::optimize adam/mod.rs:131-169 ; AMSGradParam::optimize amsgrad/mod.rs:163-205 when
  * max_exp_avg_sq != NULL.  `step` is the 1-based step count (bias corrections 1 - beta^step). */
 int nk_adam_step(nk_device* dev, float* w, float* grad, float* exp_avg, float* exp_avg_sq,

@@ -84,6 +84,9 @@ _SIGS = {
     "nk_mm_t_bwd_left": [VP, VP, VP, VP, C.c_int, C.c_int, C.c_int],
     "nk_mm_t_bwd_right": [VP, VP, VP, VP, C.c_int, C.c_int, C.c_int],
     "nk_linear_fwd": [VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int],
+    "nk_linear_relu_fwd": [VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int],
+    "nk_linear_bwd_input_relu": [VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int],
+    "nk_relu_mask_inplace": [VP, VP, VP, C.c_size_t],
     "nk_conv_fwd": [VP, C.c_int, VP, c_intp, VP, c_intp, VP, c_intp, c_intp, C.c_int],
     "nk_conv_bias_fwd": [VP, C.c_int, VP, c_intp, VP, c_intp, VP, VP, c_intp, c_intp, C.c_int],
     "nk_conv_bwd_input_assign": [VP, C.c_int, VP, c_intp, VP, VP, c_intp, c_intp, c_intp, C.c_int],
@@ -164,6 +167,7 @@ _SIGS = {
     "nk_merge_heads_fwd": [VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int],
     "nk_merge_heads_bwd": [VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int],
     "nk_sgd_step": [VP, VP, VP, VP, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_int, C.c_float, C.c_float],
+    "nk_sgd_step_multi": [VP, C.c_int, VP, VP, VP, VP, C.c_float, C.c_float, C.c_float, C.c_int, C.c_float, C.c_float],
     "nk_adam_step": [VP, VP, VP, VP, VP, VP, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_float, C.c_float],
     "nk_adagrad_step": [VP, VP, VP, VP, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_int, C.c_float, C.c_float],
     "nk_rmsprop_step": [VP, VP, VP, VP, VP, VP, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float],
@@ -407,6 +411,19 @@ def conv_bwd_kernel_bias(dev, dw, db, g, x, stride, dilation, groups=1, assign=(
 
 def linear_fwd(dev, X, W, bias, Y):
     check(lib.nk_linear_fwd(dev.h, X.p, W.p, bias.p, Y.p, X.shape[0], X.shape[1], W.shape[0]))
+
+
+def linear_relu_fwd(dev, X, W, bias, Y):
+    check(lib.nk_linear_relu_fwd(dev.h, X.p, W.p, bias.p, Y.p, X.shape[0], X.shape[1], W.shape[0]))
+
+
+def linear_bwd_input_relu(dev, dZ, G, W, X, assign=False):
+    """dZ (+)= (X > 0) * (G . W): G (n,o), W (o,m), X and dZ (n,m)."""
+    check(lib.nk_linear_bwd_input_relu(dev.h, dZ.p, G.p, W.p, X.p, X.shape[0], X.shape[1], W.shape[0], int(assign)))
+
+
+def relu_mask_inplace(dev, g, y):
+    check(lib.nk_relu_mask_inplace(dev.h, g.p, y.p, y.size))
 
 
 def pad_const_fwd(dev, x, y, padding, value=0.0):
@@ -656,6 +673,14 @@ def _p(a):
 
 def sgd_step(dev, w, grad, velocity=None, lr=0.01, momentum=0.0, dampening=0.0, nesterov=False, l1=0.0, l2=0.0):
     check(lib.nk_sgd_step(dev.h, w.p, grad.p, _p(velocity), w.size, lr, momentum, dampening, int(nesterov), l1, l2))
+
+
+def sgd_step_multi(dev, ws, grads, velocities=None, lr=0.01, momentum=0.0, dampening=0.0, nesterov=False, l1=0.0, l2=0.0):
+    n = len(ws)
+    PA = C.c_void_p * n
+    vel = PA(*[(_p(v) if v is not None else None) for v in velocities]) if velocities is not None else None
+    check(lib.nk_sgd_step_multi(dev.h, n, PA(*[w.p for w in ws]), PA(*[g.p for g in grads]), vel, (C.c_size_t * n)(*[w.size for w in ws]),
+                                lr, momentum, dampening, int(nesterov), l1, l2))
 
 
 def adam_step(dev, w, grad, exp_avg, exp_avg_sq, max_exp_avg_sq=None, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8,

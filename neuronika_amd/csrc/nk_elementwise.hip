@@ -488,6 +488,28 @@ __global__ void relu_bwd_kernel(float* __restrict__ dx, const float* __restrict_
     }
 }
 
+// g = ((y > 0) as f32) * g in place (one pointer for source and destination: no __restrict__ pair to alias)
+template <bool VEC>
+__global__ void relu_mask_inplace_kernel(float* g, const float* __restrict__ y, size_t n) {
+    if (VEC) {
+        const size_t n4 = n / 4;
+        for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+            const float4 yv = reinterpret_cast<const float4*>(y)[i];
+            float4 v = reinterpret_cast<float4*>(g)[i];
+            v.x = yv.x > 0.f ? v.x : 0.f * v.x; v.y = yv.y > 0.f ? v.y : 0.f * v.y;
+            v.z = yv.z > 0.f ? v.z : 0.f * v.z; v.w = yv.w > 0.f ? v.w : 0.f * v.w;
+            reinterpret_cast<float4*>(g)[i] = v;
+        }
+        if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+            const size_t i = n4 * 4 + threadIdx.x;
+            g[i] = y[i] > 0.f ? g[i] : 0.f * g[i];
+        }
+    } else {
+        for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+            g[i] = y[i] > 0.f ? g[i] : 0.f * g[i];
+    }
+}
+
 // ---- pointwise unary nodes (node/{negation,exp,logn,sqrt,sigmoid,tanh,softplus,leaky_relu,power}) --
 __device__ __forceinline__ float powi_dev(float b, int e) {  // Rust `f32::powi`
     float r = 1.f;
@@ -561,21 +583,72 @@ __device__ __forceinline__ float penalized(float w, float g, float l1, float l2)
     return g;
 }
 
+// one element of `SGDParam::optimize` (sgd/mod.rs:186-236); shared by the one-parameter and the multi-parameter kernel so
+// that both make the same contraction choices: their results are bit-identical (test_optimizer_steps)
+__device__ __forceinline__ float sgd_one(float wi, float& gi, float* vel, float lr, float momentum, float dampening, int nesterov,
+                                         float l1, float l2) {
+    gi = penalized(wi, gi, l1, l2);
+    if (vel == nullptr) return wi - gi * lr;
+    const float v = *vel * momentum + gi * (1.f - dampening);
+    *vel = v;
+    return wi - (nesterov ? (gi + v * momentum) * lr : v * lr);
+}
 __global__ void sgd_kernel(float* __restrict__ w, float* __restrict__ grad, float* __restrict__ vel, size_t n,
                            float lr, float momentum, float dampening, int nesterov, float l1, float l2) {
     const bool pen = l1 != 0.f || l2 != 0.f;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        float wi = w[i];
-        const float gi = penalized(wi, grad[i], l1, l2);
+        float gi = grad[i];
+        const float wi = sgd_one(w[i], gi, vel ? vel + i : nullptr, lr, momentum, dampening, nesterov, l1, l2);
         if (pen) grad[i] = gi;
-        if (vel == nullptr) {
-            wi -= gi * lr;
-        } else {
-            const float v = vel[i] * momentum + gi * (1.f - dampening);
-            vel[i] = v;
-            wi -= nesterov ? (gi + v * momentum) * lr : v * lr;
-        }
         w[i] = wi;
+    }
+}
+
+// `count` <= SGD_MULTI_MAX parameters in one launch: the blocks walk the concatenation of the parameters in chunks of
+// SGD_CHUNK elements (a chunk never straddles two parameters); 16-byte accesses where a parameter's three pointers allow.
+constexpr int SGD_MULTI_MAX = 8;
+constexpr int SGD_CHUNK = 4096;
+struct SgdMulti {
+    float* w[SGD_MULTI_MAX];
+    float* g[SGD_MULTI_MAX];
+    float* v[SGD_MULTI_MAX];
+    size_t n[SGD_MULTI_MAX];
+    unsigned first_chunk[SGD_MULTI_MAX + 1];  // prefix sums of ceil(n / SGD_CHUNK)
+    int count;
+};
+__global__ void sgd_multi_kernel(SgdMulti a, float lr, float momentum, float dampening, int nesterov, float l1, float l2) {
+    const bool pen = l1 != 0.f || l2 != 0.f;
+    const unsigned total = a.first_chunk[a.count];
+    for (unsigned ch = blockIdx.x; ch < total; ch += gridDim.x) {
+        int t = 0;
+#pragma unroll
+        for (int k = 1; k < SGD_MULTI_MAX; ++k) t += (k < a.count && ch >= a.first_chunk[k]) ? 1 : 0;
+        float* __restrict__ w = a.w[t];
+        float* __restrict__ g = a.g[t];
+        float* __restrict__ v = a.v[t];
+        const size_t n = a.n[t], base = (size_t)(ch - a.first_chunk[t]) * SGD_CHUNK;
+        const size_t end = base + SGD_CHUNK < n ? base + SGD_CHUNK : n;
+        const bool vec = ((reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(v)) & 15) == 0;
+        if (vec && end - base == SGD_CHUNK) {
+            for (size_t i = base + 4 * threadIdx.x; i < end; i += 4 * (size_t)blockDim.x) {
+                float4 wv = *reinterpret_cast<const float4*>(w + i), gv = *reinterpret_cast<const float4*>(g + i);
+                float4 vv = v ? *reinterpret_cast<const float4*>(v + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+                wv.x = sgd_one(wv.x, gv.x, v ? &vv.x : nullptr, lr, momentum, dampening, nesterov, l1, l2);
+                wv.y = sgd_one(wv.y, gv.y, v ? &vv.y : nullptr, lr, momentum, dampening, nesterov, l1, l2);
+                wv.z = sgd_one(wv.z, gv.z, v ? &vv.z : nullptr, lr, momentum, dampening, nesterov, l1, l2);
+                wv.w = sgd_one(wv.w, gv.w, v ? &vv.w : nullptr, lr, momentum, dampening, nesterov, l1, l2);
+                if (pen) *reinterpret_cast<float4*>(g + i) = gv;
+                if (v) *reinterpret_cast<float4*>(v + i) = vv;
+                *reinterpret_cast<float4*>(w + i) = wv;
+            }
+        } else {
+            for (size_t i = base + threadIdx.x; i < end; i += blockDim.x) {
+                float gi = g[i];
+                const float wi = sgd_one(w[i], gi, v ? v + i : nullptr, lr, momentum, dampening, nesterov, l1, l2);
+                if (pen) g[i] = gi;
+                w[i] = wi;
+            }
+        }
     }
 }
 
@@ -818,6 +891,44 @@ int nk_sgd_step(nk_device* dev, float* w, float* grad, float* velocity, size_t n
     NK_CHECK(w && grad, "null pointer in nk_sgd_step");
     hipLaunchKernelGGL(sgd_kernel, dim3(nk_stream_grid(n, 256)), dim3(256), 0, dev->compute, w, grad, velocity, n, lr,
                        momentum, dampening, nesterov, l1, l2);
+    NK_LAUNCH_CHECK();
+    return NK_OK;
+}
+
+int nk_sgd_step_multi(nk_device* dev, int count, float* const* w, float* const* grad, float* const* velocity, const size_t* n,
+                      float lr, float momentum, float dampening, int nesterov, float l1, float l2) {
+    NK_USE(dev);
+    NK_CHECK(count >= 0 && (count == 0 || (w && grad && n)), "null table in nk_sgd_step_multi");
+    for (int i = 0; i < count;) {
+        SgdMulti a{};
+        a.first_chunk[0] = 0;
+        int c = 0;
+        for (; i < count && c < SGD_MULTI_MAX; ++i) {  // the next (up to) SGD_MULTI_MAX non-empty parameters
+            if (n[i] == 0) continue;
+            NK_CHECK(w[i] && grad[i], "null pointer in nk_sgd_step_multi");
+            NK_CHECK((n[i] + SGD_CHUNK - 1) / SGD_CHUNK < (1u << 30), "parameter too large for nk_sgd_step_multi");
+            a.w[c] = w[i]; a.g[c] = grad[i]; a.v[c] = velocity ? velocity[i] : nullptr; a.n[c] = n[i];
+            a.first_chunk[c + 1] = a.first_chunk[c] + (unsigned)((n[i] + SGD_CHUNK - 1) / SGD_CHUNK);
+            ++c;
+        }
+        a.count = c;
+        if (c == 0) break;
+        for (int k = c + 1; k <= SGD_MULTI_MAX; ++k) a.first_chunk[k] = a.first_chunk[c];
+        const unsigned total = a.first_chunk[c];
+        const unsigned grid = total < 8192u ? total : 8192u;
+        hipLaunchKernelGGL(sgd_multi_kernel, dim3(grid), dim3(256), 0, dev->compute, a, lr, momentum, dampening, nesterov, l1, l2);
+        NK_LAUNCH_CHECK();
+    }
+    return NK_OK;
+}
+
+int nk_relu_mask_inplace(nk_device* dev, float* g, const float* y, size_t n) {
+    NK_USE(dev);
+    if (n == 0) return NK_OK;
+    NK_CHECK(g && y, "null pointer in nk_relu_mask_inplace");
+    const bool vec = ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
+    if (vec) hipLaunchKernelGGL((relu_mask_inplace_kernel<true>), dim3(nk_stream_grid(n / 4 + 1, 256)), dim3(256), 0, dev->compute, g, y, n);
+    else hipLaunchKernelGGL((relu_mask_inplace_kernel<false>), dim3(nk_stream_grid(n, 256)), dim3(256), 0, dev->compute, g, y, n);
     NK_LAUNCH_CHECK();
     return NK_OK;
 }

@@ -17,6 +17,18 @@ using namespace nkmma;
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 constexpr int PF2_MIN_KTILES = 48;  // default threshold of the two-k-tile look-ahead loop (per-layout rules in gemm_impl)
+// K-blocked accumulation.  The MFMA adds a tile's products as ONE f32 fma chain per output; the reference's sgemm (crate
+// matrixmultiply: K packed in blocks of kc = 256, each block's register sum added to C) and OpenBLAS never build a chain
+// longer than a few hundred products, and at K = 4096 the single chain is what put the C4 weight gradients 1.15x outside
+// the stated parity bound with the ReLU masks held equal (tools/c4_tolerance_model.py, profiles/r04_c4_tolerance_model.json:
+// the error grows with the chain length - one chain of 4096: 1.15 of the bound, chains of 2048: 0.6, of 1024: 0.30).
+// `sgemm_kernel<..., FOLD = true>` therefore ends a chain every KFOLD_TILES k-tiles (2048 products): the accumulators go
+// to a slab in the workspace (first time: stored; later: slab = slab + acc), restart from zero, and the epilogue begins with
+// `slab + acc`.  The slab, not a second register set: the 128x128 kernels have no 64 registers to spare - a register-resident
+// second set cost 2 - 20 % (NT / NN / TN 4096^3: 134.0 / 136.6 / 138.5 -> 131.6 / 131.8 / 110.2 TFLOP/s, round-4 session a),
+// whereas a cold block that runs once per 64 k-tiles leaves the loop's register allocation alone.  The host takes the FOLD
+// kernels for reductions of more than KFOLD_TILES k-tiles per accumulator set; shorter ones run the plain kernels.
+constexpr int KFOLD_TILES = 64;
 
 struct GemmArgs {
     const float* A;
@@ -26,6 +38,10 @@ struct GemmArgs {
     long long lda, ldb, ldc;
     float alpha, beta;
     const float* bias;  // optional column bias (length N) added in the epilogue: C = alpha*A.B + bias + beta*C
+    // Fused ReLU forms of `nn::Linear` (node/relu/mod.rs:29-38, 67-79 joined to the GEMM that produces their operand):
+    int relu;           // forward:  C = max(alpha*A.B + bias, 0)          (`o.max(0.)`: a NaN gives 0)
+    const float* mask;  // backward: C = beta*C + m(alpha*A.B), m(v) = v where mask[row][col] > 0, 0*v elsewhere (0 * inf = NaN,
+    long long ldm;      //           as `((x > 0.) as usize as f32) * g`); mask is M x N with leading dimension ldm
     // two-level batch
     int batch_inner;
     long long sAo, sAi, sBo, sBi, sCo, sCi;
@@ -46,6 +62,7 @@ struct GemmArgs {
     int group_m;      // tile order: column-major inside groups of `group_m` tile rows (1: row-major, tn fastest)
     int pf2_min;      // reductions of at least this many k-tiles take the two-k-tile look-ahead loop
     int kskew;        // k-pair blocks: group 1 runs half a k-tile out of phase with group 0
+    float* fold_slab; // FOLD kernels: [k-pair group][split][batch][M][N] partial sums of the chains that ended (see KFOLD_TILES)
 };
 
 // C tile <- accumulators (or the split's slab).  Every load (bias, old C) is issued first and folded into the accumulators
@@ -68,7 +85,34 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
     const float alpha = p.alpha, beta = p.beta;
     const int M = p.M, N = p.N;
     const long long ldc = p.ldc;
-    if (p.bias != nullptr || beta != 0.f || alpha != 1.f) {
+    if (p.mask != nullptr) {
+        // ReLU backward joined to the store (nk_linear_bwd_input_relu): C = beta * C + m(alpha * acc).  Its own block, so
+        // that the common epilogue below stays the code it was; two round trips (mask, then old C), 16 values at a time.
+        const float* Mk = p.mask;
+        const long long ldm = p.ldm;
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                float mv[16], old[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = m0 + (wr * TI + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5), col = n0 + (wc * TJ + j) * 32 + (lane & 31);
+                    const bool ok = ALIGNED || (row < M && col < N);
+                    mv[e] = ok ? Mk[row * ldm + col] : 0.f;
+                    old[e] = (ok && beta != 0.f) ? C[row * ldc + col] : 0.f;
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = m0 + (wr * TI + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5), col = n0 + (wc * TJ + j) * 32 + (lane & 31);
+                    float o = alpha * acc[i][j][e];
+                    o = mv[e] > 0.f ? o : 0.f * o;
+                    if (ALIGNED || (row < M && col < N)) C[row * ldc + col] = beta == 0.f ? o : fmaf(beta, old[e], o);
+                }
+            }
+        return;
+    }
+    if (p.bias != nullptr || beta != 0.f || alpha != 1.f || p.relu) {
         float old[TI][TJ][16];
         if (beta != 0.f)
             acc_foreach_idx<TI, TJ>(acc, wr, wc, lane, [&](int i, int j, int e, int r, int c, float) {
@@ -81,6 +125,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
             const int col = n0 + (wc * TJ + j) * 32 + (lane & 31);
             bv[j] = (p.bias != nullptr && (ALIGNED || col < N)) ? p.bias[col] : 0.f;
         }
+        const bool relu = p.relu != 0;
 #pragma unroll
         for (int i = 0; i < TI; ++i)
 #pragma unroll
@@ -89,6 +134,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
                 for (int e = 0; e < 16; ++e) {
                     float o = alpha * acc[i][j][e];
                     if (p.bias != nullptr) o += bv[j];  // Linear: fl(acc + bias[col]) == the separate Addition node
+                    o = relu ? fmaxf(o, 0.f) : o;       // ... followed by the ReLU node (`o.max(0.)`: a NaN gives 0)
                     acc[i][j][e] = beta == 0.f ? o : fmaf(beta, old[i][j][e], o);
                 }
     }
@@ -98,67 +144,24 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
     });
 }
 
-// KG = 2 ("k-pair"): a 512-thread block whose two groups of four waves each run this loop over one HALF of the block's
-// reduction, with their own LDS images, and add the two accumulator sets through LDS in a fixed order before the epilogue.
-// For grids of at most one 128x128 block per CU (2048^3: 256 tiles): a CU then holds two waves per SIMD - what a 4096^3
-// launch gets from two resident blocks - without split-K's slabs and second pass.  The two groups share the block's
-// barriers (same trip count); with `kskew` group 1 issues the first half of a k-tile's MFMAs BEFORE its staging stores, so
-// that the two waves of a SIMD are not in their staging phase at the same time.
-template <bool TA, bool TB, bool ALIGNED, int TI, int TJ, int KG = 1>
-__global__ __launch_bounds__(NT * KG, (min_waves<TI, TJ, !TA && TB>())) void sgemm_kernel(GemmArgs p) {
+// a wave-uniform pointer, as the scalar registers it belongs in
+__device__ __forceinline__ const float* uniform_ptr(const float* q) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(q);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return reinterpret_cast<const float*>(((unsigned long long)hi << 32) | lo);
+}
+
+// ---- the two k-loops of sgemm_kernel over ONE tile and one run of k-tiles ------------------------------------------
+// Two k-tiles of look-ahead in registers: tile it+1 (P, loaded during the previous trip) goes to LDS at the START of a
+// trip, the loads of tile it+2 (Q) are issued in front of it and have a whole trip plus to land.  The end of a trip is
+// then MFMAs -> barrier, instead of MFMAs -> wait for this trip's own loads -> 8 LDS writes -> barrier.  Unrolled by
+// two so that P / Q and the LDS buffers are static (even tiles in buf0, odd tiles in buf1).
+// `skew` (k-pair blocks, group 1): the first half of a k-tile's MFMAs is issued BEFORE the trip's staging stores.
+template <bool AKC, bool BKC, bool ALIGNED, int TI, int TJ, int KG>
+__device__ __forceinline__ void gemm_loop_lookahead2(TileLoader<AKC, 64 * TI>& la, TileLoader<BKC, 64 * TJ>& lb, f32x16 (&acc)[TI][TJ],
+                                                     float* smem, int nt, bool skew, int t, int wr, int wc, int lane) {
     constexpr int BM = 64 * TI, BN = 64 * TJ;
-    constexpr bool AKC = !TA;  // A (M x K): k-contiguous unless stored transposed
-    constexpr bool BKC = TB;   // B (K x N) stored as N x K when transposed -> k-contiguous
     constexpr int TA_FLOATS = tile_floats<AKC, BM>(), STAGE = TA_FLOATS + tile_floats<BKC, BN>();
-    static_assert(KG == 1 || (ALIGNED && 2 * 2 * STAGE >= BM * BN), "k-pair: aligned problems; a group's images hold half a C tile");
-    __shared__ __attribute__((aligned(16))) float smem_all[KG * 2 * STAGE];  // <= 73,728 B at 128x128 (k-pair: twice that)
-
-    const int grp = KG == 2 ? (int)(threadIdx.x >> 8) : 0;  // NT == 256
-    // (the mask is a no-op for the 256-thread blocks, but it tells the compiler the index has 8 bits - launch bounds do not: the
-    // address code of every instantiation came out 100 - 450 instructions shorter, TN 4096^3 137.8 -> 139.4 TFLOP/s in three
-    // alternating same-box runs, the other layouts and sizes within +-0.3 %; the same mask in the conv kernels LOSES 1.2 - 1.4 % on
-    // the forward and kernel-gradient passes and does nothing for the attention kernels: GEMM only)
-    const int t = (int)(threadIdx.x & (NT - 1)), lane = t & 63, wid = t >> 6;
-    float* const smem = smem_all + grp * 2 * STAGE;
-    const int wr = wid >> 1, wc = wid & 1;
-    // this block's tiles: positions [seq, seq_end) of the tile sequence (each XCD gets a contiguous range of chunks)
-    int seq = xcd_chunk(blockIdx.x, gridDim.x) * p.chunk;
-    const int seq_end = min(p.tiles_m * p.tiles_n, seq + p.chunk);
-    int tm, tn;
-    tile_of_seq(seq, p.tiles_m, p.tiles_n, tm, tn, p.group_m);
-    int m0 = tm * BM, n0 = tn * BN;
-    const int batch = blockIdx.z, split = blockIdx.y;
-    const int bo = batch / p.batch_inner, bi = batch % p.batch_inner;
-    const float* A = p.A + bo * p.sAo + bi * p.sAi;
-    const float* B = p.B + bo * p.sBo + bi * p.sBi;
-
-    int kbeg = split * p.k_per_split;
-    int kend = min(p.K, kbeg + p.k_per_split);
-    if (KG == 2) {  // group g takes the g-th half; the host only asks for the pair when that is a whole number of k-tiles
-        const int half = (kend - kbeg) >> 1;
-        if (grp) kbeg += half; else kend = kbeg + half;
-    }
-    const int nt = (kend - kbeg + BK - 1) / BK;
-
-    f32x16 acc[TI][TJ];
-    acc_zero<TI, TJ>(acc);
-
-    Stage<BM / 32> ra;
-    Stage<BN / 32> rb;
-    TileLoader<AKC, BM> la;
-    TileLoader<BKC, BN> lb;
-    la.init(A, p.lda, m0, kbeg, p.M, kend, t);
-    lb.init(B, p.ldb, n0, kbeg, p.N, kend, t);
-    // Two-k-tile look-ahead: aligned problems only (the guarded loader's state does not fit next to P and Q), every
-    // layout, from the per-layout / per-tile k-tile threshold the host passes in `pf2_min` (rules and their same-box
-    // sweeps: gemm_impl).  This branch handles exactly ONE tile: gemm_impl sets chunk = 1 whenever nt >= pf2_min.
-    constexpr bool PF2 = ALIGNED;
-    const bool skew = KG == 2 && grp != 0 && p.kskew != 0;  // wave-uniform
-    if (PF2 && (KG == 2 || nt >= p.pf2_min)) {
-    // Two k-tiles of look-ahead in registers: tile it+1 (P, loaded during the previous trip) goes to LDS at the START of a
-    // trip, the loads of tile it+2 (Q) are issued in front of it and have a whole trip plus to land.  The end of a trip is
-    // then MFMAs -> barrier, instead of MFMAs -> wait for this trip's own loads -> 8 LDS writes -> barrier.  Unrolled by
-    // two so that P / Q and the LDS buffers are static (even tiles in buf0, odd tiles in buf1).
     float* const buf0 = smem;
     float* const buf1 = smem + STAGE;
     Stage<BM / 32> pa, qa;
@@ -223,9 +226,191 @@ __global__ __launch_bounds__(NT * KG, (min_waves<TI, TJ, !TA && TB>())) void sge
             mma_tile<AKC, BKC, TI, TJ>(buf0, buf0 + TA_FLOATS, acc, wr, wc, lane);
         }
     }
+}
+
+// One k-tile of look-ahead over one run of k-tiles of one tile (the FOLD kernels' short or unaligned runs; the plain kernels
+// keep their own copy of this loop, which continues into the block's next tile).
+template <bool AKC, bool BKC, bool ALIGNED, int TI, int TJ>
+__device__ __forceinline__ void gemm_loop_lookahead1(TileLoader<AKC, 64 * TI>& la, TileLoader<BKC, 64 * TJ>& lb, f32x16 (&acc)[TI][TJ],
+                                                     float* smem, int nt, int t, int wr, int wc, int lane) {
+    constexpr int BM = 64 * TI, BN = 64 * TJ;
+    constexpr int TA_FLOATS = tile_floats<AKC, BM>(), STAGE = TA_FLOATS + tile_floats<BKC, BN>();
+    Stage<BM / 32> ra;
+    Stage<BN / 32> rb;
+    if (nt > 0) {
+        ra = la.template load<ALIGNED>(t);
+        rb = lb.template load<ALIGNED>(t);
+        stage_store<AKC, BM>(smem, ra, t);
+        stage_store<BKC, BN>(smem + TA_FLOATS, rb, t);
+    }
+    __syncthreads();
+    int par = 0;
+    for (int it = 0; it + 1 < nt; ++it) {
+        float* cur = smem + par * STAGE;
+        float* nxt = smem + (par ^ 1) * STAGE;
+        ra = la.template load<ALIGNED>(t);
+        rb = lb.template load<ALIGNED>(t);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_tile<AKC, BKC, TI, TJ>(cur, cur + TA_FLOATS, acc, wr, wc, lane);
+        stage_store<AKC, BM>(nxt, ra, t);
+        stage_store<BKC, BN>(nxt + TA_FLOATS, rb, t);
+        __syncthreads();
+        par ^= 1;
+    }
+    if (nt > 0) {
+        float* cur = smem + par * STAGE;
+        mma_tile<AKC, BKC, TI, TJ>(cur, cur + TA_FLOATS, acc, wr, wc, lane);
+    }
+}
+
+// KG = 2 ("k-pair"): a 512-thread block whose two groups of four waves each run this loop over one HALF of the block's
+// reduction, with their own LDS images, and add the two accumulator sets through LDS in a fixed order before the epilogue.
+// For grids of at most one 128x128 block per CU (2048^3: 256 tiles): a CU then holds two waves per SIMD - what a 4096^3
+// launch gets from two resident blocks - without split-K's slabs and second pass.  The two groups share the block's
+// barriers (same trip count); with `kskew` group 1 issues the first half of a k-tile's MFMAs BEFORE its staging stores, so
+// that the two waves of a SIMD are not in their staging phase at the same time.
+template <bool TA, bool TB, bool ALIGNED, int TI, int TJ, int KG = 1, bool FOLD = false>
+__global__ __launch_bounds__(NT * KG, (min_waves<TI, TJ, !TA && TB>())) void sgemm_kernel(GemmArgs p) {
+    constexpr int BM = 64 * TI, BN = 64 * TJ;
+    constexpr bool AKC = !TA;  // A (M x K): k-contiguous unless stored transposed
+    constexpr bool BKC = TB;   // B (K x N) stored as N x K when transposed -> k-contiguous
+    constexpr int TA_FLOATS = tile_floats<AKC, BM>(), STAGE = TA_FLOATS + tile_floats<BKC, BN>();
+    static_assert(KG == 1 || (ALIGNED && 2 * 2 * STAGE >= BM * BN), "k-pair: aligned problems; a group's images hold half a C tile");
+    __shared__ __attribute__((aligned(16))) float smem_all[KG * 2 * STAGE];  // <= 73,728 B at 128x128 (k-pair: twice that)
+
+    const int grp = KG == 2 ? (int)(threadIdx.x >> 8) : 0;  // NT == 256
+    // (the mask is a no-op for the 256-thread blocks, but it tells the compiler the index has 8 bits - launch bounds do not: the
+    // address code of every instantiation came out 100 - 450 instructions shorter, TN 4096^3 137.8 -> 139.4 TFLOP/s in three
+    // alternating same-box runs, the other layouts and sizes within +-0.3 %; the same mask in the conv kernels LOSES 1.2 - 1.4 % on
+    // the forward and kernel-gradient passes and does nothing for the attention kernels: GEMM only)
+    const int t = (int)(threadIdx.x & (NT - 1)), lane = t & 63, wid = t >> 6;
+    float* const smem = smem_all + grp * 2 * STAGE;
+    const int wr = wid >> 1, wc = wid & 1;
+    // this block's tiles: positions [seq, seq_end) of the tile sequence (each XCD gets a contiguous range of chunks)
+    int seq = xcd_chunk(blockIdx.x, gridDim.x) * p.chunk;
+    const int seq_end = min(p.tiles_m * p.tiles_n, seq + p.chunk);
+    int tm, tn;
+    tile_of_seq(seq, p.tiles_m, p.tiles_n, tm, tn, p.group_m);
+    int m0 = tm * BM, n0 = tn * BN;
+    const int batch = blockIdx.z, split = blockIdx.y;
+    const int bo = batch / p.batch_inner, bi = batch % p.batch_inner;
+    const float* A = p.A + bo * p.sAo + bi * p.sAi;
+    const float* B = p.B + bo * p.sBo + bi * p.sBi;
+
+    int kbeg = split * p.k_per_split;
+    int kend = min(p.K, kbeg + p.k_per_split);
+    if (KG == 2) {  // group g takes the g-th half; the host only asks for the pair when that is a whole number of k-tiles
+        const int half = (kend - kbeg) >> 1;
+        if (grp) kbeg += half; else kend = kbeg + half;
+    }
+    const int nt = (kend - kbeg + BK - 1) / BK;
+
+    f32x16 acc[TI][TJ];
+    acc_zero<TI, TJ>(acc);
+    // K-blocked accumulation (FOLD): the reduction is walked in RUNS of KFOLD_TILES k-tiles, counted from this accumulator
+    // set's first k-tile.  Between two runs the chain ends: its sum goes to the slab (first time: stored; later: slab =
+    // slab + acc) and `acc` restarts from zero; the epilogue begins with `slab + acc`.  A run is the whole software pipeline
+    // (prologue, loop, tail) of the plain kernel, so the k-loop's code and register allocation are the plain kernel's -
+    // a fold INSIDE the loop, as a register-resident second accumulator set or as a cold block behind a branch, cost
+    // 2 - 20 % (round-4 sessions a, b); what a run boundary costs is one pipeline drain and refill per 64 k-tiles.
+    // The slab is in REGISTER order - [k-pair group][split][batch][tile][wave][quad][lane] float4: a lane owns the same
+    // 16-byte slots at every fold (plain program order, no fences) and a wave's store is one contiguous 1 KB run.
+    int nfold = 0;   // folds so far (wave-uniform)
+    constexpr int FQ = TI * TJ * 4;  // float4 per lane
+    // (computed where it is used, from a laundered thread index: nothing of it stays alive across the k-loops)
+    auto fold_slot = [&]() {
+        int tr = t;
+        asm volatile("" : "+v"(tr));
+        return reinterpret_cast<float4*>(p.fold_slab) +
+               (((((long long)grp * gridDim.y + split) * gridDim.z + batch) * p.tiles_m * p.tiles_n + seq) * 4 + (tr >> 6)) * (FQ * 64) + (tr & 63);
+    };
+    auto fold = [&]() {
+        if constexpr (FOLD) {
+            float4* const fslab = fold_slot();
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        float4 v = make_float4(acc[i][j][4 * q4], acc[i][j][4 * q4 + 1], acc[i][j][4 * q4 + 2], acc[i][j][4 * q4 + 3]);
+                        float4* q = fslab + ((i * TJ + j) * 4 + q4) * 64;
+                        if (nfold != 0) { const float4 o = *q; v.x = o.x + v.x; v.y = o.y + v.y; v.z = o.z + v.z; v.w = o.w + v.w; }
+                        *q = v;
+                    }
+            acc_zero<TI, TJ>(acc);
+            ++nfold;
+        }
+    };
+    auto fold_finish = [&]() {
+        if constexpr (FOLD) {
+            if (nfold == 0) return;
+            const float4* const fslab = fold_slot();
+            float4 old[TI][TJ][4];
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) old[i][j][q4] = fslab[((i * TJ + j) * 4 + q4) * 64];
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        acc[i][j][4 * q4] = old[i][j][q4].x + acc[i][j][4 * q4]; acc[i][j][4 * q4 + 1] = old[i][j][q4].y + acc[i][j][4 * q4 + 1];
+                        acc[i][j][4 * q4 + 2] = old[i][j][q4].z + acc[i][j][4 * q4 + 2]; acc[i][j][4 * q4 + 3] = old[i][j][q4].w + acc[i][j][4 * q4 + 3];
+                    }
+        }
+    };
+
+    TileLoader<AKC, BM> la;
+    TileLoader<BKC, BN> lb;
+    // Two-k-tile look-ahead: aligned problems only (the guarded loader's state does not fit next to P and Q), every
+    // layout, from the per-layout / per-tile k-tile threshold the host passes in `pf2_min` (rules and their same-box
+    // sweeps: gemm_impl).  That loop handles exactly ONE tile: gemm_impl sets chunk = 1 whenever nt >= pf2_min.
+    constexpr bool PF2 = ALIGNED;
+    const bool skew = KG == 2 && grp != 0 && p.kskew != 0;  // wave-uniform
+    if constexpr (FOLD) {
+        // (gemm_impl: chunk == 1 - a reduction this long never shares a block with another tile)
+        const bool lookahead2 = PF2 && (KG == 2 || nt >= p.pf2_min);
+        for (int k0 = kbeg; k0 < kend; k0 += KFOLD_TILES * BK) {
+            const int k1 = min(kend, k0 + KFOLD_TILES * BK);
+            if (k0 != kbeg) {
+                fold();
+                __syncthreads();  // every wave has read the last k-tile of the run: its LDS images may be overwritten
+            }
+            // (the thread index passes through an empty asm: the run's address arithmetic - global offsets, LDS slots - then
+            //  depends on a value defined INSIDE this loop body and is recomputed per run; hoisted out of the run loop it stays
+            //  alive across it, spills, and is reloaded inside the k-loop: 21 - 32 scratch loads per trip in the ISA)
+            int tr = t;
+            asm volatile("" : "+v"(tr));
+            const int lane_r = tr & 63, wid_r = tr >> 6;
+            // (likewise the run's scalars: an opaque wave-uniform base pointer per run keeps the loads in the
+            //  `global_load v, voff32, s[base]` form of the plain kernel; as functions of the run loop's counter they turn
+            //  into 64-bit per-thread induction variables - 16 more live registers and a 64-bit add per load)
+            const float* Ar = uniform_ptr(A);
+            const float* Br = uniform_ptr(B);
+            int k0r = __builtin_amdgcn_readfirstlane(k0), k1r = __builtin_amdgcn_readfirstlane(k1);  // (k-pair: a group's own range)
+            asm volatile("" : "+s"(Ar), "+s"(Br), "+s"(k0r), "+s"(k1r));
+            la.init(Ar, p.lda, m0, k0r, p.M, k1r, tr);
+            lb.init(Br, p.ldb, n0, k0r, p.N, k1r, tr);
+            const int run = (k1r - k0r + BK - 1) / BK;
+            if (lookahead2) gemm_loop_lookahead2<AKC, BKC, ALIGNED, TI, TJ, KG>(la, lb, acc, smem, run, skew, tr, wid_r >> 1, wid_r & 1, lane_r);
+            else gemm_loop_lookahead1<AKC, BKC, ALIGNED, TI, TJ>(la, lb, acc, smem, run, tr, wid_r >> 1, wid_r & 1, lane_r);
+        }
+        fold_finish();
+    } else {
+    la.init(A, p.lda, m0, kbeg, p.M, kend, t);
+    lb.init(B, p.ldb, n0, kbeg, p.N, kend, t);
+    if (PF2 && (KG == 2 || nt >= p.pf2_min)) {
+        gemm_loop_lookahead2<AKC, BKC, ALIGNED, TI, TJ, KG>(la, lb, acc, smem, nt, skew, t, wr, wc, lane);
     } else if constexpr (KG == 1) {
     // One k-tile of look-ahead, over the block's whole chunk of tiles: the loads issued in front of the LAST MFMA block
     // of a tile are the first k-tile of the NEXT tile.
+    Stage<BM / 32> ra;
+    Stage<BN / 32> rb;
     if (nt > 0) {
         ra = la.template load<ALIGNED>(t);
         rb = lb.template load<ALIGNED>(t);
@@ -277,12 +462,15 @@ __global__ __launch_bounds__(NT * KG, (min_waves<TI, TJ, !TA && TB>())) void sge
         m0 = tm2 * BM; n0 = tn2 * BN;
     }
     }
+    }
     if constexpr (KG == 2) {
         // acc(group 0: first half of the reduction) + acc(group 1: second half).  The groups SWAP halves of the tile through
         // LDS - group g keeps its MFMA tile row g, sends the other row - so that all eight waves share the epilogue (half the
         // old-C loads and C stores per lane; the sum is the same bits in either operand order).  Each group writes into its
         // own images: [wave][column tile][quad][lane] float4, lane-contiguous 16-byte slots.
         static_assert(TI == 2, "k-pair: 128-row tiles");
+        // (FOLD: each group's half has its own chains and its own slab, finished above; the two halves are then added - what
+        //  split-K 2 computes)
         __syncthreads();  // every wave has read its last k-tile
         float4* const mine_out = reinterpret_cast<float4*>(smem) + wid * (TJ * 4 * 64) + lane;
         const float4* const theirs_in = reinterpret_cast<const float4*>(smem_all + (grp ^ 1) * 2 * STAGE) + wid * (TJ * 4 * 64) + lane;
@@ -313,7 +501,7 @@ __global__ __launch_bounds__(NT * KG, (min_waves<TI, TJ, !TA && TB>())) void sge
 __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ C, int M, int N,
                                      long long ldc, int splits, int nbatch, int batch_inner,
                                      long long sCo, long long sCi, float alpha, float beta,
-                                     const float* __restrict__ bias) {
+                                     const float* __restrict__ bias, int relu, const float* __restrict__ mask, long long ldm) {
     const long long per = (long long)M * N;
     const long long total = per * nbatch;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
@@ -324,14 +512,18 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, float* __r
         float s = 0.f;
         for (int k = 0; k < splits; ++k) s += slabs[((long long)k * nbatch + b) * per + e];
         float* q = C + (b / batch_inner) * sCo + (b % batch_inner) * sCi + row * ldc + col;
-        const float o = bias ? alpha * s + bias[col] : alpha * s;
+        float o = alpha * s;
+        if (mask) o = mask[row * ldm + col] > 0.f ? o : 0.f * o;  // (unbatched launches only: gemm_impl)
+        if (bias) o += bias[col];
+        if (relu) o = fmaxf(o, 0.f);
         *q = beta == 0.f ? o : fmaf(beta, *q, o);
     }
 }
 
 // Same, for a C that is one dense block (ldc == N, batches back to back): no index arithmetic, 16-byte accesses.
 __global__ void splitk_reduce_flat_kernel(const float* __restrict__ slabs, float* __restrict__ C, long long total4, int splits,
-                                          float alpha, float beta, const float* __restrict__ bias, int N) {
+                                          float alpha, float beta, const float* __restrict__ bias, int N, int relu,
+                                          const float* __restrict__ mask) {  // mask: dense like C (ldm == N)
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int k = 0; k < splits; ++k) {
@@ -339,11 +531,16 @@ __global__ void splitk_reduce_flat_kernel(const float* __restrict__ slabs, float
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
         float4 o = make_float4(alpha * s.x, alpha * s.y, alpha * s.z, alpha * s.w);
+        if (mask) {
+            const float4 m = reinterpret_cast<const float4*>(mask)[i];
+            o.x = m.x > 0.f ? o.x : 0.f * o.x; o.y = m.y > 0.f ? o.y : 0.f * o.y; o.z = m.z > 0.f ? o.z : 0.f * o.z; o.w = m.w > 0.f ? o.w : 0.f * o.w;
+        }
         if (bias) {
             const int col = (int)((i * 4) % N);  // N % 4 == 0: the four lanes stay in one row
             const float4 b = *reinterpret_cast<const float4*>(bias + col);
             o.x += b.x; o.y += b.y; o.z += b.z; o.w += b.w;
         }
+        if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
         float4* q = reinterpret_cast<float4*>(C) + i;
         if (beta != 0.f) { const float4 c = *q; o.x = fmaf(beta, c.x, o.x); o.y = fmaf(beta, c.y, o.y); o.z = fmaf(beta, c.z, o.z); o.w = fmaf(beta, c.w, o.w); }
         *q = o;
@@ -375,36 +572,42 @@ struct EnvCache {
 };
 static thread_local EnvCache env_force("NK_GEMM_FORCE"), env_kpair("NK_GEMM_KPAIR");
 
-template <bool TA, bool TB, int TI, int TJ>
+template <bool TA, bool TB, int TI, int TJ, bool FOLD>
 static int launch_tile(nk_device* dev, const GemmArgs& p, int nbatch, bool aligned, int kg = 1) {
     dim3 grid((p.tiles_m * p.tiles_n + p.chunk - 1) / p.chunk, p.splits, nbatch), block(NT * kg);
     if constexpr (TI * TJ == 4) {
         if (kg == 2) {  // gemm_impl: aligned, one tile per block
-            hipLaunchKernelGGL((sgemm_kernel<TA, TB, true, TI, TJ, 2>), grid, block, 0, dev->compute, p);
+            hipLaunchKernelGGL((sgemm_kernel<TA, TB, true, TI, TJ, 2, FOLD>), grid, block, 0, dev->compute, p);
             NK_LAUNCH_CHECK();
             return NK_OK;
         }
     }
     if (aligned)
-        hipLaunchKernelGGL((sgemm_kernel<TA, TB, true, TI, TJ>), grid, block, 0, dev->compute, p);
+        hipLaunchKernelGGL((sgemm_kernel<TA, TB, true, TI, TJ, 1, FOLD>), grid, block, 0, dev->compute, p);
     else
-        hipLaunchKernelGGL((sgemm_kernel<TA, TB, false, TI, TJ>), grid, block, 0, dev->compute, p);
+        hipLaunchKernelGGL((sgemm_kernel<TA, TB, false, TI, TJ, 1, FOLD>), grid, block, 0, dev->compute, p);
     NK_LAUNCH_CHECK();
     return NK_OK;
 }
 
+template <bool TA, bool TB, bool FOLD>
+static int launch_fold(nk_device* dev, const GemmArgs& p, int nbatch, bool aligned, int ti, int tj, int kg) {
+    if (ti == 2 && tj == 2) return launch_tile<TA, TB, 2, 2, FOLD>(dev, p, nbatch, aligned, kg);
+    if (ti == 2 && tj == 1) return launch_tile<TA, TB, 2, 1, FOLD>(dev, p, nbatch, aligned);
+    if (ti == 1 && tj == 2) return launch_tile<TA, TB, 1, 2, FOLD>(dev, p, nbatch, aligned);
+    return launch_tile<TA, TB, 1, 1, FOLD>(dev, p, nbatch, aligned);
+}
+// `fold`: some chain of this launch is longer than KFOLD_TILES k-tiles (per block: a split's share, a k-pair group's half)
 template <bool TA, bool TB>
-static int launch(nk_device* dev, const GemmArgs& p, int nbatch, bool aligned, int ti, int tj, int kg) {
-    if (ti == 2 && tj == 2) return launch_tile<TA, TB, 2, 2>(dev, p, nbatch, aligned, kg);
-    if (ti == 2 && tj == 1) return launch_tile<TA, TB, 2, 1>(dev, p, nbatch, aligned);
-    if (ti == 1 && tj == 2) return launch_tile<TA, TB, 1, 2>(dev, p, nbatch, aligned);
-    return launch_tile<TA, TB, 1, 1>(dev, p, nbatch, aligned);
+static int launch(nk_device* dev, const GemmArgs& p, int nbatch, bool aligned, int ti, int tj, int kg, bool fold) {
+    return fold ? launch_fold<TA, TB, true>(dev, p, nbatch, aligned, ti, tj, kg) : launch_fold<TA, TB, false>(dev, p, nbatch, aligned, ti, tj, kg);
 }
 
 static int gemm_impl(nk_device* dev, int transA, int transB, int M, int N, int K, float alpha,
                      const float* A, int lda, long long sAo, long long sAi, const float* B, int ldb,
                      long long sBo, long long sBi, float beta, float* C, int ldc, long long sCo,
-                     long long sCi, int batch_outer, int batch_inner, const float* bias = nullptr) {
+                     long long sCi, int batch_outer, int batch_inner, const float* bias = nullptr, int relu = 0,
+                     const float* mask = nullptr, long long ldm = 0) {
     NK_USE(dev);
     NK_CHECK(M >= 0 && N >= 0 && K >= 0 && batch_outer >= 0 && batch_inner >= 0, "negative GEMM extent");
     const int nbatch = batch_outer * batch_inner;
@@ -420,6 +623,8 @@ static int gemm_impl(nk_device* dev, int transA, int transB, int M, int N, int K
     p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.alpha = alpha; p.beta = beta;
     p.bias = bias;
+    p.relu = relu; p.mask = mask; p.ldm = ldm;
+    NK_CHECK(mask == nullptr || (nbatch == 1 && ldm >= N), "masked GEMM: one matrix, ldm >= N");
     p.batch_inner = batch_inner;
     p.sAo = sAo; p.sAi = sAi; p.sBo = sBo; p.sBi = sBi; p.sCo = sCo; p.sCi = sCi;
 
@@ -528,12 +733,6 @@ static int gemm_impl(nk_device* dev, int transA, int transB, int M, int N, int K
     // two waves per SIMD where 1024^3 has one - measured 78.7 vs 80.1 TFLOP/s and was dropped.)
     const int pf2_rule = ti * tj == 1 ? 8 : ((!transA && !transB) ? 32 : PF2_MIN_KTILES);
     p.pf2_min = force_pf2 > 0 ? force_pf2 : pf2_rule;
-    if (p.splits > 1) {
-        void* ws = nullptr;
-        int rc = nk_workspace(dev, (size_t)p.splits * nbatch * M * N * sizeof(float), &ws);
-        if (rc) return rc;
-        p.slabs = (float*)ws;
-    }
 
     const int BM = 64 * ti, BN = 64 * tj;
     const bool aligned = (M % BM == 0) && (N % BN == 0) && (K % BK == 0) && (lda % 4 == 0) &&
@@ -554,24 +753,37 @@ static int gemm_impl(nk_device* dev, int transA, int transB, int M, int N, int K
         if (can && want) kg = 2;
         if (kpair_env == 1) p.kskew = 0;
     }
+    const bool fold = kts / kg > KFOLD_TILES;  // k-tiles one accumulator set sees (a k-pair group takes half of the block's)
+    {
+        const size_t slab = (size_t)p.splits * nbatch * M * N;  // floats: split-K partials [split][batch][M][N] ...
+        const size_t fslab = (size_t)p.splits * nbatch * p.tiles_m * p.tiles_n * (64 * ti) * (64 * tj);  // ... then the chains' sums, whole tiles
+        const size_t need = (p.splits > 1 ? slab : 0) + (fold ? fslab * kg : 0);
+        if (need) {
+            void* ws = nullptr;
+            int rc = nk_workspace(dev, need * sizeof(float), &ws);
+            if (rc) return rc;
+            p.slabs = p.splits > 1 ? (float*)ws : nullptr;
+            p.fold_slab = fold ? (float*)ws + (p.splits > 1 ? slab : 0) : nullptr;
+        }
+    }
     int rc = nk_prof_start(dev, NK_KERNEL_SGEMM, 2.0 * M * N * (double)K * nbatch);
     if (rc) return rc;
-    if (!transA && !transB) rc = launch<false, false>(dev, p, nbatch, aligned, ti, tj, kg);
-    else if (!transA && transB) rc = launch<false, true>(dev, p, nbatch, aligned, ti, tj, kg);
-    else if (transA && !transB) rc = launch<true, false>(dev, p, nbatch, aligned, ti, tj, kg);
-    else rc = launch<true, true>(dev, p, nbatch, aligned, ti, tj, kg);
+    if (!transA && !transB) rc = launch<false, false>(dev, p, nbatch, aligned, ti, tj, kg, fold);
+    else if (!transA && transB) rc = launch<false, true>(dev, p, nbatch, aligned, ti, tj, kg, fold);
+    else if (transA && !transB) rc = launch<true, false>(dev, p, nbatch, aligned, ti, tj, kg, fold);
+    else rc = launch<true, true>(dev, p, nbatch, aligned, ti, tj, kg, fold);
     if (rc) return rc;
     if (p.splits > 1) {
         const long long total = (long long)M * N * nbatch;
-        const bool dense = ldc == N && N % 4 == 0 && aligned16(C) && (!bias || aligned16(bias)) &&
+        const bool dense = ldc == N && N % 4 == 0 && aligned16(C) && (!bias || aligned16(bias)) && (!mask || (ldm == N && aligned16(mask))) &&
                            (nbatch == 1 || (sCi == (long long)M * N && (batch_outer == 1 || sCo == (long long)batch_inner * M * N)));
         if (dense)
             hipLaunchKernelGGL(splitk_reduce_flat_kernel, dim3(nk_stream_grid((size_t)(total / 4), 256)), dim3(256), 0, dev->compute,
-                               p.slabs, C, total / 4, p.splits, alpha, beta, bias, N);
+                               p.slabs, C, total / 4, p.splits, alpha, beta, bias, N, relu, mask);
         else
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(nk_stream_grid((size_t)total, 256)), dim3(256), 0,
                            dev->compute, p.slabs, C, M, N, (long long)ldc, p.splits, nbatch, batch_inner,
-                           sCo, sCi, alpha, beta, bias);
+                           sCo, sCi, alpha, beta, bias, relu, mask, ldm);
         NK_LAUNCH_CHECK();
     }
     return nk_prof_stop(dev);
@@ -608,6 +820,15 @@ int nk_mm_t_fwd(nk_device* dev, const float* A, const float* B, float* C, int n,
 int nk_linear_fwd(nk_device* dev, const float* X, const float* W, const float* bias, float* Y, int n, int m, int o) {
     NK_CHECK(bias != nullptr, "null bias");
     return gemm_impl(dev, 0, 1, n, o, m, 1.f, X, m, 0, 0, W, m, 0, 0, 0.f, Y, o, 0, 0, 1, 1, bias);  // Y = X . W^T + b
+}
+int nk_linear_relu_fwd(nk_device* dev, const float* X, const float* W, const float* bias, float* Y, int n, int m, int o) {
+    NK_CHECK(bias != nullptr, "null bias");
+    return gemm_impl(dev, 0, 1, n, o, m, 1.f, X, m, 0, 0, W, m, 0, 0, 0.f, Y, o, 0, 0, 1, 1, bias, 1);  // Y = max(X . W^T + b, 0)
+}
+int nk_linear_bwd_input_relu(nk_device* dev, float* dX, const float* G, const float* W, const float* X, int n, int m, int o, int assign) {
+    NK_CHECK(X != nullptr, "null mask operand");
+    // dX (+)= (G . W) where X > 0, 0 * (G . W) elsewhere: MatrixMatrixMulTBackwardLeft followed by ReLUBackward of the node that made X
+    return gemm_impl(dev, 0, 0, n, m, o, 1.f, G, o, 0, 0, W, m, 0, 0, assign ? 0.f : 1.f, dX, m, 0, 0, 1, 1, nullptr, 0, X, m);
 }
 int nk_mm_t_bwd_left(nk_device* dev, float* dA, const float* G, const float* B, int n, int m, int o) {
     return nk_sgemm(dev, 0, 0, n, m, o, 1.f, G, o, B, m, 1.f, dA, m);  // dA += G . B

@@ -1,0 +1,1 @@
+# TEST INFRASTRUCTURE ONLY: the CPU oracle.  Nothing under neuronika_amd/, host/ or include/ may import it.

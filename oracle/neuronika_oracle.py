@@ -416,8 +416,9 @@ def dropout_backward(x_grad, grad, noise, p, train=True):
 
 
 def relu_forward(x, out):
-    """`ReLU::forward` (relu/mod.rs:29-38): max(x, 0)."""
-    np.maximum(x, 0, out=out)
+    """`ReLU::forward` (relu/mod.rs:29-38): `o.max(0.)`.  Rust's `f32::max` returns the other operand when one is NaN, so a
+    NaN input gives 0 (NumPy's `maximum` would propagate it); -inf -> 0, +inf -> +inf."""
+    out[...] = np.where(x > 0, x, x.dtype.type(0))
 
 
 def relu_backward(x_grad, grad, x):

@@ -108,45 +108,65 @@ def test_C3_conv_full_size(dev):
 
 
 def test_C4_mlp_full_size(nk):
-    """C4 on one GPU: Linear(4096,4096)x3 + ReLU, batch 4096, MSE mean, backward(1.0): loss and
-    sampled gradient entries against an f64 restatement (OpenBLAS on the host)."""
+    """C4 on one GPU: Linear(4096,4096)x3 + ReLU, batch 4096, MSE mean, backward(1.0): loss and every weight / bias gradient
+    against an f64 restatement (OpenBLAS on the host), next to the f32 restatement measured the same way, on the STATED
+    policy (SURVEY.md 8c ii): err_gpu <= max(2 * err_cpu32, 1e-6 * K * max|g| * max|a|).
+
+    Two things separate any two f32 evaluations of this network, and the test keeps them apart:
+      * ReLU mask flips - a pre-activation within rounding of 0 lands on different sides in different summation orders, and
+        one flipped unit moves gradient entries by O(|g|), hundreds of times the summation error (tools/c4_tolerance_model.py:
+        3-6 flips per layer between ANY two f32 orders, err 1e-8 against 1e-10).  The masks are index-like behaviour: they
+        are taken from the DEVICE (a > 0 on the downloaded activations) and imposed on both host restatements, and the
+        device's own masks are checked for consistency with the f64 pre-activations (a flip only where |z| is rounding noise);
+      * summation order - what is left, and what the bound is about.  `sgemm_kernel` ends its f32 chains every 2048
+        products (K-blocked accumulation, nk_gemm.hip), which is what keeps the K = 4096 contractions inside the bound."""
+    from conftest import record_margin
     dev = nk.Device(0)
     n = 4096
     x, t = rnd(100, (n, n)), rnd(200, (n, n))
     lins = [nk.nn.Linear(dev, n, n, s) for s in (1, 3, 5)]
     X, T = nk.from_ndarray(dev, x), nk.from_ndarray(dev, t)
-    loss = lins[2].forward(lins[1].forward(lins[0].forward(X).relu()).relu()).mse(T, nk.Reduction.Mean)
+    a1 = lins[0].forward(X).relu()
+    a2 = lins[1].forward(a1).relu()
+    loss = lins[2].forward(a2).mse(T, nk.Reduction.Mean)
     loss.forward(); loss.backward(1.0)
-    def reference(dt):
+    m1, m2 = a1.data() > 0, a2.data() > 0          # strict `>` on the input == `> 0` on max(z, 0)
+
+    def reference(dt, masks):
         W = [(l.weight.data().astype(dt), l.bias.data().astype(dt)) for l in lins]
         h0, tt = x.astype(dt), t.astype(dt)
-        z1 = h0 @ W[0][0].T + W[0][1]; a1 = np.maximum(z1, 0)
-        z2 = a1 @ W[1][0].T + W[1][1]; a2 = np.maximum(z2, 0)
+        z1 = h0 @ W[0][0].T + W[0][1]; k1 = (z1 > 0) if masks is None else masks[0]; a1 = np.where(k1, z1, 0).astype(dt)
+        z2 = a1 @ W[1][0].T + W[1][1]; k2 = (z2 > 0) if masks is None else masks[1]; a2 = np.where(k2, z2, 0).astype(dt)
         z3 = a2 @ W[2][0].T + W[2][1]
         ls = ((z3 - tt) ** 2).mean(dtype=dt)
         g3 = 2 * (z3 - tt) / dt(z3.size)
-        g2 = (g3 @ W[2][0]) * (z2 > 0)
-        g1 = (g2 @ W[1][0]) * (z1 > 0)
+        g2 = (g3 @ W[2][0]) * k2
+        g1 = (g2 @ W[1][0]) * k1
         bounds = [np.abs(g).max() * np.abs(a).max() for g, a in ((g1, h0), (g2, a1), (g3, a2))]
-        return ls, [(g1.T @ h0, g1.sum(0)), (g2.T @ a1, g2.sum(0)), (g3.T @ a2, g3.sum(0))], bounds
+        return ls, [(g1.T @ h0, g1.sum(0)), (g2.T @ a1, g2.sum(0)), (g3.T @ a2, g3.sum(0))], bounds, (z1, z2)
 
-    # Both f32 paths are measured against the f64 restatement.  At this size the error is dominated
-    # by ReLU mask flips of pre-activations within rounding of 0 (each flip moves a gradient entry by
-    # O(|g|)), which differ between ANY two f32 evaluation orders, so the bound is a small multiple of
-    # the CPU-f32 error rather than the pure accumulation bound.
-    l64, g64, ab = reference(np.float64)
-    l32, g32, _ = reference(np.float32)
+    l64, g64, ab, z64 = reference(np.float64, (m1, m2))
+    l32, g32, _, _ = reference(np.float32, (m1, m2))
     np.testing.assert_allclose(loss.item(), l64, rtol=2e-6)
-    # ... or the absolute contraction term, 2e-6 * K * max|g| * max|a| at K = 4096 (the MFMA sums the
-    # K = 4096 products as one sequential f32 fma chain; OpenBLAS blocks K and lands closer to f64).
+    # the device's masks against the f64 pre-activations: they may differ only where |z| is below the rounding error of a
+    # K = 4096 f32 contraction (1e-6 * K * max|a| * max|w| is far above it; the flips seen are at |z| ~ 1e-7)
+    for m, z, amax in ((m1, z64[0], 1.0), (m2, z64[1], float(np.abs(a1.data()).max()))):
+        flipped = m != (z > 0)
+        assert flipped.sum() <= 64, int(flipped.sum())
+        if flipped.any():
+            assert np.abs(z[flipped]).max() <= 1e-6 * n * amax / np.sqrt(n), float(np.abs(z[flipped]).max())
     for lin, (dw64, db64), (dw32, db32), gab in zip(lins, g64, g32, ab):
-        from conftest import record_margin
         err_gpu, err_cpu = np.abs(lin.weight.grad() - dw64).max(), np.abs(dw32 - dw64).max()
         record_margin("C4_full_size:dW", err_gpu, err_cpu, 1e-6 * n * gab)
-        assert err_gpu <= max(4 * err_cpu, 2e-6 * n * gab), (err_gpu, err_cpu, gab)
+        assert err_gpu <= max(2 * err_cpu, 1e-6 * n * gab), (err_gpu, err_cpu, gab)
         err_gpu, err_cpu = np.abs(lin.bias.grad() - db64).max(), np.abs(db32 - db64).max()
         record_margin("C4_full_size:db", err_gpu, err_cpu, 1e-6 * n * gab)
-        assert err_gpu <= max(4 * err_cpu, 2e-6 * n * gab), (err_gpu, err_cpu, gab)
+        assert err_gpu <= max(2 * err_cpu, 1e-6 * n * gab), (err_gpu, err_cpu, gab)
+    # for the record (not asserted: dominated by WHICH units flip): every evaluation with its own masks
+    _, g64o, abo, _ = reference(np.float64, None)
+    _, g32o, _, _ = reference(np.float32, None)
+    for lin, (dw64, _), (dw32, _), gab in zip(lins, g64o, g32o, abo):
+        record_margin("C4_full_size:dW_own_masks(not asserted)", np.abs(lin.weight.grad() - dw64).max(), np.abs(dw32 - dw64).max(), 1e-6 * n * gab)
 
 
 def test_C5_attention_full_size(nk):

@@ -469,6 +469,67 @@ def test_linear_fused_equals_two_nodes(nk, tdev):
         assert np.array_equal(a, b)
 
 
+def test_linear_forward_relu_equals_the_two_nodes(nk, tdev):
+    """`nn::Linear::forward_relu` (ReLU in the forward GEMM's epilogue, its backward mask applied by the GEMM that produces
+    the node's output gradient) gives bit-identical values and gradients to `forward(x).relu()`:
+      (a) a chain of Linear layers - every writer of the fused nodes' gradients is mask-capable, no ReLU kernel runs at all;
+      (b) the fused output feeds a NON-Linear consumer - the writers store plain values and the owner masks in place;
+      (c) a diamond: one Linear consumer and one other consumer of the same fused output (mixed writers -> fallback);
+      (d) the fused node is the root of `backward` / `backward_from` (seed plain; the caller's seed tensor stays untouched);
+      (e) a second pass after `no_grad(); with_grad()` (fresh intermediate gradients, as a training loop does) keeps
+          accumulating on the leaves exactly as the node-by-node graph does.  (Without that reset the reference ALSO keeps
+          stale sums in every intermediate gradient, vardiff.rs:125-141; a fused node has one such buffer fewer, so only
+          the fresh-gradient case is comparable - SURVEY.md 8c, "parity is defined for ... a fresh graph".)"""
+    x, t = rnd(1, (96, 40), -1, 1), rnd(2, (96, 24), -1, 1)
+    side = rnd(3, (96, 64), -1, 1)
+
+    def build(fused, case):
+        l1, l2, l3 = nk.nn.Linear(tdev, 40, 64, 7), nk.nn.Linear(tdev, 64, 64, 9), nk.nn.Linear(tdev, 64, 24, 11)
+        X = nk.from_ndarray(tdev, x).requires_grad()
+        act = (lambda l, v: l.forward_relu(v)) if fused else (lambda l, v: l.forward(v).relu())
+        a1 = act(l1, X)
+        if case == "chain":
+            root = l3.forward(act(l2, a1)).mse(nk.from_ndarray(tdev, t), nk.Reduction.Mean)
+        elif case == "other_consumer":
+            root = (a1 * nk.from_ndarray(tdev, side)).sum()
+        elif case == "diamond":
+            a2 = act(l2, a1)
+            root = (l3.forward(a2).mse(nk.from_ndarray(tdev, t), nk.Reduction.Sum) + (a1 * nk.from_ndarray(tdev, side)).sum()) + (a2 * a2).sum()
+        else:
+            root = a1
+        return root, X, [l1, l2, l3]
+
+    def grads(X, lins):
+        out = [X.grad()]
+        for l in lins:
+            for p in (l.weight, l.bias):
+                out.append(p.grad())
+        return out
+
+    for case in ("chain", "other_consumer", "diamond", "root"):
+        res = {}
+        for fused in (True, False):
+            root, X, lins = build(fused, case)
+            root.forward()
+            if case == "root":
+                seed = rnd(5, (96, 64), -1, 1)
+                S = nk.from_ndarray(tdev, seed)
+                root.backward_from(S)
+                assert np.array_equal(S.data(), seed)                  # the caller's tensor is not masked in place
+                used = [lins[0]]
+            else:
+                root.backward(0.5)
+                root.no_grad(); root.with_grad()                       # (e): fresh intermediates, the leaves keep accumulating
+                root.backward(0.25)
+                used = lins if case != "other_consumer" else [lins[0]]
+            res[fused] = [root.data()] + grads(X, used)
+        for i, (a, b) in enumerate(zip(res[True], res[False])):
+            assert np.array_equal(a, b), (case, i)
+    # (a) really runs without ReLU launches and without the pre-activation: 3 backward nodes, not 5
+    root, X, lins = build(True, "chain")
+    assert root.history_len() == 4                                     # 3 Linear(+ReLU) nodes + the loss
+
+
 def test_losses_gemv_stack_graph(nk, tdev):
     """Row f-4 through the tape: classifier head x.mm_t(W) -> log_softmax -> nll; bce / bce_with_logits / kldiv /
     mae heads; mv / vm / vv; stack — values and gradients against the oracle nodes."""
