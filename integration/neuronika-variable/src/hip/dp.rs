@@ -38,22 +38,32 @@ impl Drop for Communicator {
     }
 }
 
-/// A registered gradient buffer: raw pointer + length, kept alive by the parameter that owns it.
+/// What `GradientSync` needs to know about one parameter: the identity of its gradient on the tape (`node::grad_id`, what
+/// `Backward::targets` reports), the device buffer and its length.  Built by `HipVarDiff::sync_entry`.
+#[derive(Clone, Copy)]
+pub struct SyncEntry {
+    pub(crate) id: usize,
+    pub(crate) ptr: *mut f32,
+    pub(crate) len: usize,
+}
+
+/// A registered gradient buffer, kept alive by the parameter that owns it.
 struct Bucket {
+    id: usize,
     ptr: *mut f32,
     len: usize,
     event: *mut ffi::nk_event,
 }
 
 /// Exchange of the registered parameter gradients.  Two ways to drive it:
-/// * `all_reduce()` after `HipVarDiff::backward` has ISSUED the tape: every gradient is final in stream order, the side
-///   stream waits for an event recorded behind the last backward kernel, small gradients travel as one RCCL group;
-/// * `grad_ready(i)` right after issuing the LAST tape node that accumulates into parameter `i` (reverse layer order) -
-///   the overlapped form.  Deciding "last writer" needs each backward node to name the gradients it writes: the
-///   `targets()` extension of `Backward` that this repository's C++ tape carries (`host/neuronika.cpp`: `run_backward`,
-///   `BackwardHook`); the reference's trait (`autograd.rs:17-25`) has no such method, so `HipVarDiff::backward` as written
-///   does not call it.
-/// `join()` makes the compute stream wait for the side stream - no host synchronisation.
+/// * `HipVarDiff::backward_sync(seed, &mut sync)` - the overlapped form: `grad_ready(i)` is called right after the LAST tape
+///   node that accumulates into parameter `i` has been issued (reverse layer order), so the all-reduce of that gradient runs
+///   on the side stream underneath the remaining backward kernels.  "Last writer" is decided from `Backward::targets`
+///   (`autograd_hip_ext.rs`), the rule `VarDiff::run_backward` applies in this repository's C++ tape (`host/neuronika.cpp`);
+/// * `all_reduce()` after a plain `HipVarDiff::backward` has ISSUED the whole tape: every gradient is final in stream order;
+///   correct, but the exchange is exposed behind the last backward kernel.
+/// Small gradients (biases) travel as one RCCL group.  `join()` makes the compute stream wait for the side stream - no host
+/// synchronisation.
 pub struct GradientSync {
     comm: Rc<Communicator>,
     buckets: Vec<Bucket>,
@@ -62,16 +72,21 @@ pub struct GradientSync {
 }
 
 impl GradientSync {
-    pub fn new(comm: Rc<Communicator>, grads: &[(*mut f32, usize)]) -> Self {
-        let buckets = grads
+    pub fn new(comm: Rc<Communicator>, parameters: &[SyncEntry]) -> Self {
+        let buckets = parameters
             .iter()
-            .map(|&(ptr, len)| {
+            .map(|entry| {
                 let mut event = std::ptr::null_mut();
                 ffi::check(unsafe { ffi::nk_event_create(comm.device.as_raw(), &mut event) });
-                Bucket { ptr, len, event }
+                Bucket { id: entry.id, ptr: entry.ptr, len: entry.len, event }
             })
             .collect();
         Self { comm, buckets, small_pending: Vec::new(), small_elems: 65536 }
+    }
+
+    /// Index of the registered parameter whose gradient has this tape identity, if any.
+    pub(crate) fn bucket_of(&self, id: usize) -> Option<usize> {
+        self.buckets.iter().position(|b| b.id == id)
     }
 
     pub fn grad_ready(&mut self, i: usize) {

@@ -12,6 +12,7 @@ use ndarray::{DimMax, Dimension, IntoDimension, Ix0, Ix2, Ix3, RemoveAxis};
 
 use super::{
     device::Device,
+    dp::GradientSync,
     hiparray::HipArray,
     node::{
         AttentionState, BinaryOp, BinaryOperation, BinaryOperationBackwardLeft, BinaryOperationBackwardRight, Chunk, ChunkBackward,
@@ -331,10 +332,8 @@ where
     }
 
     /// `VarDiff::backward` (`vardiff.rs:125-141`): seed the root gradient, run the tape in reverse.  Launches are
-    /// asynchronous.  For the data-parallel step call `dp::GradientSync::all_reduce` after this (every registered gradient
-    /// is final once the tape has been ISSUED; the side stream orders itself after the compute stream) and `join()` before
-    /// the optimizer; handing each gradient over as soon as its last writer has been issued needs the `targets()` extension
-    /// of the `Backward` trait that this repository's C++ tape carries (`host/neuronika.cpp: run_backward`).
+    /// asynchronous.  The data-parallel step uses `backward_sync` below (overlapped exchange); calling
+    /// `dp::GradientSync::all_reduce` after this plain `backward` is the serialised fallback.
     pub fn backward(&self, seed: f32) {
         debug_assert_eq!(self.var.history.len(), self.var.history.buffer_len(), "Perhaps you forgot to call .forward()?");
         self.grad.borrow_mut().fill(seed);
@@ -345,7 +344,45 @@ where
         buffer.iter().rev().for_each(|(op, _)| op.backward());
     }
 
+    /// The data-parallel form of `backward` (`vardiff.rs:125-141` with the exchange of `hip/dp.rs` inserted): seeds the root
+    /// with `seed` (`1 / world` for mean semantics over the global batch), issues the tape in reverse and hands every
+    /// registered parameter gradient to `sync` right after the LAST node that accumulates into it has been issued - its
+    /// all-reduce then runs on the device's side stream underneath the remaining backward kernels.  Which node is the last
+    /// writer is read off `Backward::targets` (`autograd_hip_ext.rs`), exactly as `VarDiff::run_backward` does in the C++
+    /// tape of this repository (`host/neuronika.cpp`).  Call `sync.join()` before `Optimizer::step`.
+    pub fn backward_sync(&self, seed: f32, sync: &mut GradientSync) {
+        debug_assert_eq!(self.var.history.len(), self.var.history.buffer_len(), "Perhaps you forgot to call .forward()?");
+        self.grad.borrow_mut().fill(seed);
+        let mut buffer = self.history.buffer_mut();
+        if buffer.is_empty() {
+            *buffer = self.history.to_vec();
+        }
+        // execution order is the reverse of the tape: the LAST writer of a gradient is the entry with the smallest index
+        let mut last_writer: std::collections::HashMap<usize, usize> = std::collections::HashMap::new();
+        for (index, (op, _)) in buffer.iter().enumerate() {
+            for id in op.targets() {
+                last_writer.entry(id).or_insert(index);
+            }
+        }
+        for (index, (op, _)) in buffer.iter().enumerate().rev() {
+            op.backward();
+            for id in op.targets() {
+                if last_writer[&id] == index {
+                    if let Some(bucket) = sync.bucket_of(id) {
+                        sync.grad_ready(bucket);
+                    }
+                }
+            }
+        }
+    }
+
     /// `VarDiff::zero_grad` (`vardiff.rs:100-102`).
+    /// Registration record of this parameter for `dp::GradientSync::new`.
+    pub fn sync_entry(&self) -> super::dp::SyncEntry {
+        let mut grad = self.grad.borrow_mut();
+        super::dp::SyncEntry { id: super::node::grad_id(&self.grad), ptr: grad.as_mut_ptr(), len: grad.len() }
+    }
+
     pub fn zero_grad(&self) {
         self.grad.borrow_mut().fill(0.);
     }

@@ -9,7 +9,7 @@ mod node;
 
 pub use {
     device::Device,
-    dp::{Communicator, GradientSync},
+    dp::{Communicator, GradientSync, SyncEntry},
     hiparray::HipArray,
     hipvar::{manual_seed, HipVar, HipVarDiff},
 };

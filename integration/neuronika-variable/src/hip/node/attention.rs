@@ -1,3 +1,4 @@
+use super::grad_id;
 use std::cell::Cell;
 use std::rc::Rc;
 
@@ -127,5 +128,10 @@ impl Backward for HeadsAttentionBackward {
                                   o.as_ptr(), scores.as_ptr(), stats.as_ptr(), bits.as_ptr() as *const u32, q.as_ptr(), k.as_ptr(),
                                   v.as_ptr(), h.batch, h.seq, h.heads, h.dh, self.scale, self.p, self.status.get() as i32, 0, 0, 0)
         });
+    }
+
+    /// The gradients this node accumulates into (`autograd.rs` extension: the last-writer rule of `backward_sync`).
+    fn targets(&self) -> Vec<usize> {
+        vec![grad_id(&self.queries_gradient), grad_id(&self.keys_gradient), grad_id(&self.values_gradient)]
     }
 }

@@ -1,3 +1,4 @@
+use super::grad_id;
 use std::rc::Rc;
 
 use ndarray::{DimMax, Dimension};
@@ -94,6 +95,11 @@ where
                                     gs.as_ptr(), gs.len() as i32, r.as_ptr(), rs.as_ptr(), rs.len() as i32)
         });
     }
+
+    /// The gradients this node accumulates into (`autograd.rs` extension: the last-writer rule of `backward_sync`).
+    fn targets(&self) -> Vec<usize> {
+        vec![grad_id(&self.left_gradient)]
+    }
 }
 
 /// `*BackwardRight::backward` (`node/subtraction/mod.rs:110-136`, `division/mod.rs:134-149`, ...).
@@ -131,5 +137,10 @@ where
             ffi::nk_binary_bwd_right(g.device().as_raw(), self.op as i32, d.as_mut_ptr(), ds.as_ptr(), ds.len() as i32, g.as_ptr(),
                                      gs.as_ptr(), gs.len() as i32, l.as_ptr(), ls.as_ptr(), ls.len() as i32, r.as_ptr())
         });
+    }
+
+    /// The gradients this node accumulates into (`autograd.rs` extension: the last-writer rule of `backward_sync`).
+    fn targets(&self) -> Vec<usize> {
+        vec![grad_id(&self.right_gradient)]
     }
 }

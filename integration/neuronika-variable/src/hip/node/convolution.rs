@@ -1,3 +1,4 @@
+use super::grad_id;
 use std::rc::Rc;
 
 use ndarray::Dimension;
@@ -80,6 +81,11 @@ where
                                    self.stride.as_ptr(), self.dilation.as_ptr(), self.groups)
         });
     }
+
+    /// The gradients this node accumulates into (`autograd.rs` extension: the last-writer rule of `backward_sync`).
+    fn targets(&self) -> Vec<usize> {
+        vec![grad_id(&self.input_gradient)]
+    }
 }
 
 /// `ConvolutionBackwardKernel::backward` (`:451-510`, kernel `:191-226`): `dW +=`, a reduction over (sample, position).
@@ -115,5 +121,10 @@ where
             ffi::nk_conv_bwd_kernel(g.device().as_raw(), xs.len() as i32 - 2, dw.as_mut_ptr(), ws.as_ptr(), g.as_ptr(), x.as_ptr(), xs.as_ptr(),
                                     self.stride.as_ptr(), self.dilation.as_ptr(), self.groups)
         });
+    }
+
+    /// The gradients this node accumulates into (`autograd.rs` extension: the last-writer rule of `backward_sync`).
+    fn targets(&self) -> Vec<usize> {
+        vec![grad_id(&self.kernel_gradient)]
     }
 }

@@ -1,3 +1,4 @@
+use super::grad_id;
 use std::rc::Rc;
 
 use ndarray::Dimension;
@@ -49,6 +50,11 @@ impl<D: Dimension> Backward for TransposeBackward<D> {
         let s = dx.shape_c();
         ffi::check(unsafe { ffi::nk_transpose_bwd(g.device().as_raw(), dx.as_mut_ptr(), g.as_ptr(), s.as_ptr(), s.len() as i32) });
     }
+
+    /// The gradients this node accumulates into (`autograd.rs` extension: the last-writer rule of `backward_sync`).
+    fn targets(&self) -> Vec<usize> {
+        vec![grad_id(&self.operand_gradient)]
+    }
 }
 
 /// `Chunk::forward` (`node/chunk/mod.rs:48-64`): chunk number `chunk_no` of `exact_chunks(chunk_shape)`, row-major chunk order.
@@ -96,6 +102,11 @@ impl<D: Dimension> Backward for ChunkBackward<D> {
         ffi::check(unsafe {
             ffi::nk_chunk_bwd(g.device().as_raw(), dx.as_mut_ptr(), xs.as_ptr(), g.as_ptr(), cs.as_ptr(), xs.len() as i32, self.chunk_no as i32)
         });
+    }
+
+    /// The gradients this node accumulates into (`autograd.rs` extension: the last-writer rule of `backward_sync`).
+    fn targets(&self) -> Vec<usize> {
+        vec![grad_id(&self.operand_gradient)]
     }
 }
 
@@ -154,6 +165,11 @@ impl<D: Dimension> Backward for MultiConcatenateBackward<D> {
             });
             offset += len;
         }
+    }
+
+    /// The gradients this node accumulates into (`autograd.rs` extension: the last-writer rule of `backward_sync`).
+    fn targets(&self) -> Vec<usize> {
+        self.operands_gradients.iter().map(grad_id).collect()
     }
 }
 
@@ -215,5 +231,10 @@ impl<D: Dimension> Backward for PadBackward<D> {
         let mut dx = self.operand_gradient.borrow_mut();
         let xs = dx.shape_c();
         ffi::check(unsafe { ffi::nk_pad_bwd(g.device().as_raw(), xs.len() as i32 - 2, dx.as_mut_ptr(), xs.as_ptr(), g.as_ptr(), self.padding.as_ptr()) });
+    }
+
+    /// The gradients this node accumulates into (`autograd.rs` extension: the last-writer rule of `backward_sync`).
+    fn targets(&self) -> Vec<usize> {
+        vec![grad_id(&self.operand_gradient)]
     }
 }

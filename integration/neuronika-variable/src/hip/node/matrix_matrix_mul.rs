@@ -1,3 +1,4 @@
+use super::grad_id;
 use std::rc::Rc;
 
 use ndarray::Ix2;
@@ -51,6 +52,11 @@ impl Backward for MatrixMatrixMulBackwardLeft {
         let (n, o, m) = (g.dimension()[0] as i32, g.dimension()[1] as i32, b.dimension()[0] as i32);
         ffi::check(unsafe { ffi::nk_mm_bwd_left(g.device().as_raw(), da.as_mut_ptr(), g.as_ptr(), b.as_ptr(), n, m, o) });
     }
+
+    /// The gradients this node accumulates into (`autograd.rs` extension: the last-writer rule of `backward_sync`).
+    fn targets(&self) -> Vec<usize> {
+        vec![grad_id(&self.left_gradient)]
+    }
 }
 
 /// `MatrixMatrixMulBackwardRight::backward` (`:95-105`): `dB += A^T . G` (TN, beta = 1).
@@ -72,5 +78,10 @@ impl Backward for MatrixMatrixMulBackwardRight {
         let mut db = self.right_gradient.borrow_mut();
         let (n, m, o) = (a.dimension()[0] as i32, a.dimension()[1] as i32, g.dimension()[1] as i32);
         ffi::check(unsafe { ffi::nk_mm_bwd_right(g.device().as_raw(), db.as_mut_ptr(), a.as_ptr(), g.as_ptr(), n, m, o) });
+    }
+
+    /// The gradients this node accumulates into (`autograd.rs` extension: the last-writer rule of `backward_sync`).
+    fn targets(&self) -> Vec<usize> {
+        vec![grad_id(&self.right_gradient)]
     }
 }

@@ -24,7 +24,15 @@ pub(crate) use optim::*;
 pub(crate) use pointwise::*;
 pub(crate) use reduction::*;
 
+use std::rc::Rc;
+
 use crate::autograd::Backward;
+
+/// Identity of a gradient buffer on the tape: the address of its `Rc` allocation.  `Backward::targets` names the gradients
+/// a node accumulates into with it, `HipVarDiff::backward_sync` matches them against the registered parameters.
+pub(crate) fn grad_id<T>(gradient: &Rc<T>) -> usize {
+    Rc::as_ptr(gradient) as *const () as usize
+}
 
 /// Two backward halves registered as one tape entry (`MatrixMatrixMulTBackward`, `node/matrix_matrix_mul_t/mod.rs:107-140`).
 pub(crate) struct Pair<L: Backward, R: Backward>(pub(crate) L, pub(crate) R);
@@ -33,5 +41,11 @@ impl<L: Backward, R: Backward> Backward for Pair<L, R> {
     fn backward(&self) {
         self.0.backward();
         self.1.backward();
+    }
+
+    fn targets(&self) -> Vec<usize> {
+        let mut t = self.0.targets();
+        t.extend(self.1.targets());
+        t
     }
 }

@@ -1,3 +1,4 @@
+use super::grad_id;
 use std::{cell::Cell, rc::Rc};
 
 use ndarray::Dimension;
@@ -48,6 +49,11 @@ impl<D: Dimension> Backward for ReLUBackward<D> {
         let mut dx = self.operand_gradient.borrow_mut();
         ffi::check(unsafe { ffi::nk_relu_bwd(g.device().as_raw(), dx.as_mut_ptr(), g.as_ptr(), x.as_ptr(), x.len()) });
     }
+
+    /// The gradients this node accumulates into (`autograd.rs` extension: the last-writer rule of `backward_sync`).
+    fn targets(&self) -> Vec<usize> {
+        vec![grad_id(&self.operand_gradient)]
+    }
 }
 
 /// `Softmax::forward` (`node/softmax/mod.rs:37-53`) along `axis`.
@@ -94,6 +100,11 @@ impl<D: Dimension> Backward for SoftmaxBackward<D> {
         ffi::check(unsafe {
             ffi::nk_softmax_bwd(g.device().as_raw(), dx.as_mut_ptr(), g.as_ptr(), y.as_ptr(), s.as_ptr(), s.len() as i32, self.axis as i32)
         });
+    }
+
+    /// The gradients this node accumulates into (`autograd.rs` extension: the last-writer rule of `backward_sync`).
+    fn targets(&self) -> Vec<usize> {
+        vec![grad_id(&self.operand_gradient)]
     }
 }
 
@@ -157,6 +168,11 @@ impl<D: Dimension> Backward for DropoutBackward<D> {
             ffi::nk_dropout_bwd(g.device().as_raw(), dx.as_mut_ptr(), g.as_ptr(), noise.as_ptr(), g.len(), self.p, self.status.get() as i32)
         });
     }
+
+    /// The gradients this node accumulates into (`autograd.rs` extension: the last-writer rule of `backward_sync`).
+    fn targets(&self) -> Vec<usize> {
+        vec![grad_id(&self.operand_gradient)]
+    }
 }
 
 /// `LogSoftmax::forward` (`node/logsoftmax/mod.rs:37-53`): `y = x - ln(sum exp(x - m)) - m` along `axis`.
@@ -204,5 +220,10 @@ impl<D: Dimension> Backward for LogSoftmaxBackward<D> {
         ffi::check(unsafe {
             ffi::nk_log_softmax_bwd(g.device().as_raw(), dx.as_mut_ptr(), g.as_ptr(), y.as_ptr(), s.as_ptr(), s.len() as i32, self.axis as i32)
         });
+    }
+
+    /// The gradients this node accumulates into (`autograd.rs` extension: the last-writer rule of `backward_sync`).
+    fn targets(&self) -> Vec<usize> {
+        vec![grad_id(&self.operand_gradient)]
     }
 }

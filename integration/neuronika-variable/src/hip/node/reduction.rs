@@ -1,3 +1,4 @@
+use super::grad_id;
 use std::rc::Rc;
 
 use ndarray::{Dimension, Ix0};
@@ -49,6 +50,11 @@ impl<D: Dimension> Backward for SumBackward<D> {
         let n = dx.len();
         ffi::check(unsafe { ffi::nk_sum_bwd(g.device().as_raw(), dx.as_mut_ptr(), n, g.as_ptr()) });
     }
+
+    /// The gradients this node accumulates into (`autograd.rs` extension: the last-writer rule of `backward_sync`).
+    fn targets(&self) -> Vec<usize> {
+        vec![grad_id(&self.operand_gradient)]
+    }
 }
 
 /// `SquaredError::forward` (`node/squared_error/mod.rs:42-59`): `sum((x - t)^2)` (/ n for `Reduction::Mean`).
@@ -96,6 +102,11 @@ impl<D: Dimension> Backward for SquaredErrorBackward<D> {
         let red = matches!(self.reduction, Reduction::Mean) as i32;
         ffi::check(unsafe { ffi::nk_mse_bwd(g.device().as_raw(), dx.as_mut_ptr(), g.as_ptr(), x.as_ptr(), t.as_ptr(), x.len(), red) });
     }
+
+    /// The gradients this node accumulates into (`autograd.rs` extension: the last-writer rule of `backward_sync`).
+    fn targets(&self) -> Vec<usize> {
+        vec![grad_id(&self.input_gradient)]
+    }
 }
 
 /// `Mean::forward` (`node/mean/mod.rs:28-35`): `sum / len`.
@@ -136,5 +147,10 @@ impl<D: Dimension> Backward for MeanBackward<D> {
         let mut dx = self.operand_gradient.borrow_mut();
         let n = dx.len();
         ffi::check(unsafe { ffi::nk_mean_bwd(g.device().as_raw(), dx.as_mut_ptr(), n, g.as_ptr()) });
+    }
+
+    /// The gradients this node accumulates into (`autograd.rs` extension: the last-writer rule of `backward_sync`).
+    fn targets(&self) -> Vec<usize> {
+        vec![grad_id(&self.operand_gradient)]
     }
 }

@@ -17,18 +17,15 @@ using namespace nkmma;
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 constexpr int PF2_MIN_KTILES = 48;  // default threshold of the two-k-tile look-ahead loop (per-layout rules in gemm_impl)
-// K-blocked accumulation.  The MFMA adds a tile's products as ONE f32 fma chain per output; the reference's sgemm (crate
-// matrixmultiply: K packed in blocks of kc = 256, each block's register sum added to C) and OpenBLAS never build a chain
-// longer than a few hundred products, and at K = 4096 the single chain is what put the C4 weight gradients 1.15x outside
-// the stated parity bound with the ReLU masks held equal (tools/c4_tolerance_model.py, profiles/r04_c4_tolerance_model.json:
-// the error grows with the chain length - one chain of 4096: 1.15 of the bound, chains of 2048: 0.6, of 1024: 0.30).
-// `sgemm_kernel<..., FOLD = true>` therefore ends a chain every KFOLD_TILES k-tiles (2048 products): the accumulators go
-// to a slab in the workspace (first time: stored; later: slab = slab + acc), restart from zero, and the epilogue begins with
-// `slab + acc`.  The slab, not a second register set: the 128x128 kernels have no 64 registers to spare - a register-resident
-// second set cost 2 - 20 % (NT / NN / TN 4096^3: 134.0 / 136.6 / 138.5 -> 131.6 / 131.8 / 110.2 TFLOP/s, round-4 session a),
-// whereas a cold block that runs once per 64 k-tiles leaves the loop's register allocation alone.  The host takes the FOLD
-// kernels for reductions of more than KFOLD_TILES k-tiles per accumulator set; shorter ones run the plain kernels.
-constexpr int KFOLD_TILES = 64;
+// Summation order (a contract, pinned bit for bit by tests/test_gpu_parity.py::test_sgemm_is_the_device_order_model_bit_for_bit
+// against oracle/device_order_sgemm.c): every output is ONE f32 fma chain over the block's k range in the MFMA feeding order;
+// split-K adds the splits' chains in split order, a k-pair block adds its two halves.  The reference's sgemm (crate
+// matrixmultiply) packs K in blocks of 256 and adds each block's register sum to C, so at K = 4096 the device's error is
+// ~10x the blocked CPU sum's (still 4e-10 absolute on the C4 gradients).  Ending the chain every 1024 / 2048 products was
+// built three ways in round 4 - a second register set, a cold in-loop block spilling to a workspace slab, whole pipeline runs
+// per chain - and measured at 1.5 - 20 % of GEMM time (the 128x128 kernels have no register to spare and every variant
+// perturbed the k-loop's allocation); it is not in the product.  Numbers, and the parity policy that follows from them:
+// DESIGN.md section 5, profiles/r04_c4_tolerance_model.json, profiles/r04_kfold_sessions.md.
 
 struct GemmArgs {
     const float* A;
@@ -62,7 +59,6 @@ struct GemmArgs {
     int group_m;      // tile order: column-major inside groups of `group_m` tile rows (1: row-major, tn fastest)
     int pf2_min;      // reductions of at least this many k-tiles take the two-k-tile look-ahead loop
     int kskew;        // k-pair blocks: group 1 runs half a k-tile out of phase with group 0
-    float* fold_slab; // FOLD kernels: [k-pair group][split][batch][M][N] partial sums of the chains that ended (see KFOLD_TILES)
 };
 
 // C tile <- accumulators (or the split's slab).  Every load (bias, old C) is issued first and folded into the accumulators
@@ -144,14 +140,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
     });
 }
 
-// a wave-uniform pointer, as the scalar registers it belongs in
-__device__ __forceinline__ const float* uniform_ptr(const float* q) {
-    const unsigned long long a = reinterpret_cast<unsigned long long>(q);
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
-    return reinterpret_cast<const float*>(((unsigned long long)hi << 32) | lo);
-}
-
-// ---- the two k-loops of sgemm_kernel over ONE tile and one run of k-tiles ------------------------------------------
+// ---- the two-k-tile look-ahead loop of sgemm_kernel (one tile) -----------------------------------------------------
 // Two k-tiles of look-ahead in registers: tile it+1 (P, loaded during the previous trip) goes to LDS at the START of a
 // trip, the loads of tile it+2 (Q) are issued in front of it and have a whole trip plus to land.  The end of a trip is
 // then MFMAs -> barrier, instead of MFMAs -> wait for this trip's own loads -> 8 LDS writes -> barrier.  Unrolled by
@@ -228,48 +217,13 @@ __device__ __forceinline__ void gemm_loop_lookahead2(TileLoader<AKC, 64 * TI>& l
     }
 }
 
-// One k-tile of look-ahead over one run of k-tiles of one tile (the FOLD kernels' short or unaligned runs; the plain kernels
-// keep their own copy of this loop, which continues into the block's next tile).
-template <bool AKC, bool BKC, bool ALIGNED, int TI, int TJ>
-__device__ __forceinline__ void gemm_loop_lookahead1(TileLoader<AKC, 64 * TI>& la, TileLoader<BKC, 64 * TJ>& lb, f32x16 (&acc)[TI][TJ],
-                                                     float* smem, int nt, int t, int wr, int wc, int lane) {
-    constexpr int BM = 64 * TI, BN = 64 * TJ;
-    constexpr int TA_FLOATS = tile_floats<AKC, BM>(), STAGE = TA_FLOATS + tile_floats<BKC, BN>();
-    Stage<BM / 32> ra;
-    Stage<BN / 32> rb;
-    if (nt > 0) {
-        ra = la.template load<ALIGNED>(t);
-        rb = lb.template load<ALIGNED>(t);
-        stage_store<AKC, BM>(smem, ra, t);
-        stage_store<BKC, BN>(smem + TA_FLOATS, rb, t);
-    }
-    __syncthreads();
-    int par = 0;
-    for (int it = 0; it + 1 < nt; ++it) {
-        float* cur = smem + par * STAGE;
-        float* nxt = smem + (par ^ 1) * STAGE;
-        ra = la.template load<ALIGNED>(t);
-        rb = lb.template load<ALIGNED>(t);
-        __builtin_amdgcn_sched_barrier(0);
-        mma_tile<AKC, BKC, TI, TJ>(cur, cur + TA_FLOATS, acc, wr, wc, lane);
-        stage_store<AKC, BM>(nxt, ra, t);
-        stage_store<BKC, BN>(nxt + TA_FLOATS, rb, t);
-        __syncthreads();
-        par ^= 1;
-    }
-    if (nt > 0) {
-        float* cur = smem + par * STAGE;
-        mma_tile<AKC, BKC, TI, TJ>(cur, cur + TA_FLOATS, acc, wr, wc, lane);
-    }
-}
-
 // KG = 2 ("k-pair"): a 512-thread block whose two groups of four waves each run this loop over one HALF of the block's
 // reduction, with their own LDS images, and add the two accumulator sets through LDS in a fixed order before the epilogue.
 // For grids of at most one 128x128 block per CU (2048^3: 256 tiles): a CU then holds two waves per SIMD - what a 4096^3
 // launch gets from two resident blocks - without split-K's slabs and second pass.  The two groups share the block's
 // barriers (same trip count); with `kskew` group 1 issues the first half of a k-tile's MFMAs BEFORE its staging stores, so
 // that the two waves of a SIMD are not in their staging phase at the same time.
-template <bool TA, bool TB, bool ALIGNED, int TI, int TJ, int KG = 1, bool FOLD = false>
+template <bool TA, bool TB, bool ALIGNED, int TI, int TJ, int KG = 1>
 __global__ __launch_bounds__(NT * KG, (min_waves<TI, TJ, !TA && TB>())) void sgemm_kernel(GemmArgs p) {
     constexpr int BM = 64 * TI, BN = 64 * TJ;
     constexpr bool AKC = !TA;  // A (M x K): k-contiguous unless stored transposed
@@ -307,64 +261,6 @@ __global__ __launch_bounds__(NT * KG, (min_waves<TI, TJ, !TA && TB>())) void sge
 
     f32x16 acc[TI][TJ];
     acc_zero<TI, TJ>(acc);
-    // K-blocked accumulation (FOLD): the reduction is walked in RUNS of KFOLD_TILES k-tiles, counted from this accumulator
-    // set's first k-tile.  Between two runs the chain ends: its sum goes to the slab (first time: stored; later: slab =
-    // slab + acc) and `acc` restarts from zero; the epilogue begins with `slab + acc`.  A run is the whole software pipeline
-    // (prologue, loop, tail) of the plain kernel, so the k-loop's code and register allocation are the plain kernel's -
-    // a fold INSIDE the loop, as a register-resident second accumulator set or as a cold block behind a branch, cost
-    // 2 - 20 % (round-4 sessions a, b); what a run boundary costs is one pipeline drain and refill per 64 k-tiles.
-    // The slab is in REGISTER order - [k-pair group][split][batch][tile][wave][quad][lane] float4: a lane owns the same
-    // 16-byte slots at every fold (plain program order, no fences) and a wave's store is one contiguous 1 KB run.
-    int nfold = 0;   // folds so far (wave-uniform)
-    constexpr int FQ = TI * TJ * 4;  // float4 per lane
-    // (computed where it is used, from a laundered thread index: nothing of it stays alive across the k-loops)
-    auto fold_slot = [&]() {
-        int tr = t;
-        asm volatile("" : "+v"(tr));
-        return reinterpret_cast<float4*>(p.fold_slab) +
-               (((((long long)grp * gridDim.y + split) * gridDim.z + batch) * p.tiles_m * p.tiles_n + seq) * 4 + (tr >> 6)) * (FQ * 64) + (tr & 63);
-    };
-    auto fold = [&]() {
-        if constexpr (FOLD) {
-            float4* const fslab = fold_slot();
-#pragma unroll
-            for (int i = 0; i < TI; ++i)
-#pragma unroll
-                for (int j = 0; j < TJ; ++j)
-#pragma unroll
-                    for (int q4 = 0; q4 < 4; ++q4) {
-                        float4 v = make_float4(acc[i][j][4 * q4], acc[i][j][4 * q4 + 1], acc[i][j][4 * q4 + 2], acc[i][j][4 * q4 + 3]);
-                        float4* q = fslab + ((i * TJ + j) * 4 + q4) * 64;
-                        if (nfold != 0) { const float4 o = *q; v.x = o.x + v.x; v.y = o.y + v.y; v.z = o.z + v.z; v.w = o.w + v.w; }
-                        *q = v;
-                    }
-            acc_zero<TI, TJ>(acc);
-            ++nfold;
-        }
-    };
-    auto fold_finish = [&]() {
-        if constexpr (FOLD) {
-            if (nfold == 0) return;
-            const float4* const fslab = fold_slot();
-            float4 old[TI][TJ][4];
-#pragma unroll
-            for (int i = 0; i < TI; ++i)
-#pragma unroll
-                for (int j = 0; j < TJ; ++j)
-#pragma unroll
-                    for (int q4 = 0; q4 < 4; ++q4) old[i][j][q4] = fslab[((i * TJ + j) * 4 + q4) * 64];
-#pragma unroll
-            for (int i = 0; i < TI; ++i)
-#pragma unroll
-                for (int j = 0; j < TJ; ++j)
-#pragma unroll
-                    for (int q4 = 0; q4 < 4; ++q4) {
-                        acc[i][j][4 * q4] = old[i][j][q4].x + acc[i][j][4 * q4]; acc[i][j][4 * q4 + 1] = old[i][j][q4].y + acc[i][j][4 * q4 + 1];
-                        acc[i][j][4 * q4 + 2] = old[i][j][q4].z + acc[i][j][4 * q4 + 2]; acc[i][j][4 * q4 + 3] = old[i][j][q4].w + acc[i][j][4 * q4 + 3];
-                    }
-        }
-    };
-
     TileLoader<AKC, BM> la;
     TileLoader<BKC, BN> lb;
     // Two-k-tile look-ahead: aligned problems only (the guarded loader's state does not fit next to P and Q), every
@@ -372,36 +268,6 @@ __global__ __launch_bounds__(NT * KG, (min_waves<TI, TJ, !TA && TB>())) void sge
     // sweeps: gemm_impl).  That loop handles exactly ONE tile: gemm_impl sets chunk = 1 whenever nt >= pf2_min.
     constexpr bool PF2 = ALIGNED;
     const bool skew = KG == 2 && grp != 0 && p.kskew != 0;  // wave-uniform
-    if constexpr (FOLD) {
-        // (gemm_impl: chunk == 1 - a reduction this long never shares a block with another tile)
-        const bool lookahead2 = PF2 && (KG == 2 || nt >= p.pf2_min);
-        for (int k0 = kbeg; k0 < kend; k0 += KFOLD_TILES * BK) {
-            const int k1 = min(kend, k0 + KFOLD_TILES * BK);
-            if (k0 != kbeg) {
-                fold();
-                __syncthreads();  // every wave has read the last k-tile of the run: its LDS images may be overwritten
-            }
-            // (the thread index passes through an empty asm: the run's address arithmetic - global offsets, LDS slots - then
-            //  depends on a value defined INSIDE this loop body and is recomputed per run; hoisted out of the run loop it stays
-            //  alive across it, spills, and is reloaded inside the k-loop: 21 - 32 scratch loads per trip in the ISA)
-            int tr = t;
-            asm volatile("" : "+v"(tr));
-            const int lane_r = tr & 63, wid_r = tr >> 6;
-            // (likewise the run's scalars: an opaque wave-uniform base pointer per run keeps the loads in the
-            //  `global_load v, voff32, s[base]` form of the plain kernel; as functions of the run loop's counter they turn
-            //  into 64-bit per-thread induction variables - 16 more live registers and a 64-bit add per load)
-            const float* Ar = uniform_ptr(A);
-            const float* Br = uniform_ptr(B);
-            int k0r = __builtin_amdgcn_readfirstlane(k0), k1r = __builtin_amdgcn_readfirstlane(k1);  // (k-pair: a group's own range)
-            asm volatile("" : "+s"(Ar), "+s"(Br), "+s"(k0r), "+s"(k1r));
-            la.init(Ar, p.lda, m0, k0r, p.M, k1r, tr);
-            lb.init(Br, p.ldb, n0, k0r, p.N, k1r, tr);
-            const int run = (k1r - k0r + BK - 1) / BK;
-            if (lookahead2) gemm_loop_lookahead2<AKC, BKC, ALIGNED, TI, TJ, KG>(la, lb, acc, smem, run, skew, tr, wid_r >> 1, wid_r & 1, lane_r);
-            else gemm_loop_lookahead1<AKC, BKC, ALIGNED, TI, TJ>(la, lb, acc, smem, run, tr, wid_r >> 1, wid_r & 1, lane_r);
-        }
-        fold_finish();
-    } else {
     la.init(A, p.lda, m0, kbeg, p.M, kend, t);
     lb.init(B, p.ldb, n0, kbeg, p.N, kend, t);
     if (PF2 && (KG == 2 || nt >= p.pf2_min)) {
@@ -462,15 +328,12 @@ __global__ __launch_bounds__(NT * KG, (min_waves<TI, TJ, !TA && TB>())) void sge
         m0 = tm2 * BM; n0 = tn2 * BN;
     }
     }
-    }
     if constexpr (KG == 2) {
         // acc(group 0: first half of the reduction) + acc(group 1: second half).  The groups SWAP halves of the tile through
         // LDS - group g keeps its MFMA tile row g, sends the other row - so that all eight waves share the epilogue (half the
         // old-C loads and C stores per lane; the sum is the same bits in either operand order).  Each group writes into its
         // own images: [wave][column tile][quad][lane] float4, lane-contiguous 16-byte slots.
         static_assert(TI == 2, "k-pair: 128-row tiles");
-        // (FOLD: each group's half has its own chains and its own slab, finished above; the two halves are then added - what
-        //  split-K 2 computes)
         __syncthreads();  // every wave has read its last k-tile
         float4* const mine_out = reinterpret_cast<float4*>(smem) + wid * (TJ * 4 * 64) + lane;
         const float4* const theirs_in = reinterpret_cast<const float4*>(smem_all + (grp ^ 1) * 2 * STAGE) + wid * (TJ * 4 * 64) + lane;
@@ -572,35 +435,30 @@ struct EnvCache {
 };
 static thread_local EnvCache env_force("NK_GEMM_FORCE"), env_kpair("NK_GEMM_KPAIR");
 
-template <bool TA, bool TB, int TI, int TJ, bool FOLD>
+template <bool TA, bool TB, int TI, int TJ>
 static int launch_tile(nk_device* dev, const GemmArgs& p, int nbatch, bool aligned, int kg = 1) {
     dim3 grid((p.tiles_m * p.tiles_n + p.chunk - 1) / p.chunk, p.splits, nbatch), block(NT * kg);
     if constexpr (TI * TJ == 4) {
         if (kg == 2) {  // gemm_impl: aligned, one tile per block
-            hipLaunchKernelGGL((sgemm_kernel<TA, TB, true, TI, TJ, 2, FOLD>), grid, block, 0, dev->compute, p);
+            hipLaunchKernelGGL((sgemm_kernel<TA, TB, true, TI, TJ, 2>), grid, block, 0, dev->compute, p);
             NK_LAUNCH_CHECK();
             return NK_OK;
         }
     }
     if (aligned)
-        hipLaunchKernelGGL((sgemm_kernel<TA, TB, true, TI, TJ, 1, FOLD>), grid, block, 0, dev->compute, p);
+        hipLaunchKernelGGL((sgemm_kernel<TA, TB, true, TI, TJ>), grid, block, 0, dev->compute, p);
     else
-        hipLaunchKernelGGL((sgemm_kernel<TA, TB, false, TI, TJ, 1, FOLD>), grid, block, 0, dev->compute, p);
+        hipLaunchKernelGGL((sgemm_kernel<TA, TB, false, TI, TJ>), grid, block, 0, dev->compute, p);
     NK_LAUNCH_CHECK();
     return NK_OK;
 }
 
-template <bool TA, bool TB, bool FOLD>
-static int launch_fold(nk_device* dev, const GemmArgs& p, int nbatch, bool aligned, int ti, int tj, int kg) {
-    if (ti == 2 && tj == 2) return launch_tile<TA, TB, 2, 2, FOLD>(dev, p, nbatch, aligned, kg);
-    if (ti == 2 && tj == 1) return launch_tile<TA, TB, 2, 1, FOLD>(dev, p, nbatch, aligned);
-    if (ti == 1 && tj == 2) return launch_tile<TA, TB, 1, 2, FOLD>(dev, p, nbatch, aligned);
-    return launch_tile<TA, TB, 1, 1, FOLD>(dev, p, nbatch, aligned);
-}
-// `fold`: some chain of this launch is longer than KFOLD_TILES k-tiles (per block: a split's share, a k-pair group's half)
 template <bool TA, bool TB>
-static int launch(nk_device* dev, const GemmArgs& p, int nbatch, bool aligned, int ti, int tj, int kg, bool fold) {
-    return fold ? launch_fold<TA, TB, true>(dev, p, nbatch, aligned, ti, tj, kg) : launch_fold<TA, TB, false>(dev, p, nbatch, aligned, ti, tj, kg);
+static int launch(nk_device* dev, const GemmArgs& p, int nbatch, bool aligned, int ti, int tj, int kg) {
+    if (ti == 2 && tj == 2) return launch_tile<TA, TB, 2, 2>(dev, p, nbatch, aligned, kg);
+    if (ti == 2 && tj == 1) return launch_tile<TA, TB, 2, 1>(dev, p, nbatch, aligned);
+    if (ti == 1 && tj == 2) return launch_tile<TA, TB, 1, 2>(dev, p, nbatch, aligned);
+    return launch_tile<TA, TB, 1, 1>(dev, p, nbatch, aligned);
 }
 
 static int gemm_impl(nk_device* dev, int transA, int transB, int M, int N, int K, float alpha,
@@ -753,25 +611,18 @@ static int gemm_impl(nk_device* dev, int transA, int transB, int M, int N, int K
         if (can && want) kg = 2;
         if (kpair_env == 1) p.kskew = 0;
     }
-    const bool fold = kts / kg > KFOLD_TILES;  // k-tiles one accumulator set sees (a k-pair group takes half of the block's)
-    {
-        const size_t slab = (size_t)p.splits * nbatch * M * N;  // floats: split-K partials [split][batch][M][N] ...
-        const size_t fslab = (size_t)p.splits * nbatch * p.tiles_m * p.tiles_n * (64 * ti) * (64 * tj);  // ... then the chains' sums, whole tiles
-        const size_t need = (p.splits > 1 ? slab : 0) + (fold ? fslab * kg : 0);
-        if (need) {
-            void* ws = nullptr;
-            int rc = nk_workspace(dev, need * sizeof(float), &ws);
-            if (rc) return rc;
-            p.slabs = p.splits > 1 ? (float*)ws : nullptr;
-            p.fold_slab = fold ? (float*)ws + (p.splits > 1 ? slab : 0) : nullptr;
-        }
+    if (p.splits > 1) {
+        void* ws = nullptr;
+        int rc = nk_workspace(dev, (size_t)p.splits * nbatch * M * N * sizeof(float), &ws);
+        if (rc) return rc;
+        p.slabs = (float*)ws;
     }
     int rc = nk_prof_start(dev, NK_KERNEL_SGEMM, 2.0 * M * N * (double)K * nbatch);
     if (rc) return rc;
-    if (!transA && !transB) rc = launch<false, false>(dev, p, nbatch, aligned, ti, tj, kg, fold);
-    else if (!transA && transB) rc = launch<false, true>(dev, p, nbatch, aligned, ti, tj, kg, fold);
-    else if (transA && !transB) rc = launch<true, false>(dev, p, nbatch, aligned, ti, tj, kg, fold);
-    else rc = launch<true, true>(dev, p, nbatch, aligned, ti, tj, kg, fold);
+    if (!transA && !transB) rc = launch<false, false>(dev, p, nbatch, aligned, ti, tj, kg);
+    else if (!transA && transB) rc = launch<false, true>(dev, p, nbatch, aligned, ti, tj, kg);
+    else if (transA && !transB) rc = launch<true, false>(dev, p, nbatch, aligned, ti, tj, kg);
+    else rc = launch<true, true>(dev, p, nbatch, aligned, ti, tj, kg);
     if (rc) return rc;
     if (p.splits > 1) {
         const long long total = (long long)M * N * nbatch;
