@@ -58,8 +58,7 @@ def main():
     print(json.dumps({"variant": "no exchange", "ms_per_step": round(base, 4)}), flush=True)
     for gbps in (60.0, 120.0, 240.0):            # emulated algorithm bandwidth of the all-reduce (bytes of the buffer / time)
         for k in (8, 16, 32, 64, 128):
-            os.environ["NK_REPLICA_CHANNELS"], os.environ["NK_REPLICA_GBPS"] = str(k), str(gbps)
-            comm = t.dp.Communicator.replicas(dev, ranks)
+            comm = t.dp.Communicator.replicas(dev, ranks, int(k), float(gbps))
             sync = t.dp.GradientSync(comm, params)
             ms = run(sync)
             print(json.dumps({"variant": "paced replica exchange", "channels": k, "algbw_GBps": gbps,

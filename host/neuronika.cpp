@@ -479,8 +479,8 @@ struct DropoutFwd : Forward {  // node/dropout/mod.rs:17-79
     Shared<uint64_t> calls;  // Philox offset advances on every forward (noise is resampled)
     void forward() const override {
         const uint64_t offset = (*calls) * ((x->len() + 7) / 8);  // 8 draws per Philox call (nk_common.h)
-        ++(*calls);
         check(nk_dropout_fwd(D(x), x->ptr(), y->ptr(), noise->ptr(), x->len(), p, *status ? 1 : 0, seed, offset));
+        ++(*calls);  // only a forward that was issued consumes its Philox range (a refused capture throws above)
     }
 };
 struct DropoutBwd : Backward {
@@ -509,10 +509,10 @@ struct AttnProbsFwd : Forward {
         const int L = x->shape().back();
         const long long rows = (long long)(x->len() / (size_t)L);
         const uint64_t offset = (*calls) * ((x->len() + 7) / 8);  // 8 draws per Philox call (nk_common.h)
-        ++(*calls);
         *last_offset = offset;
         check(nk_scale_softmax_dropout_fwd(D(x), x->ptr(), probs ? probs->ptr() : nullptr, out->ptr(), nullptr, rows, L, scale, p,
                                            *status ? 1 : 0, seed, offset));
+        ++(*calls);  // only a forward that was issued consumes its Philox range (a refused capture throws above)
     }
 };
 struct AttnProbsBwd : Backward {
@@ -743,11 +743,11 @@ struct HeadsAttentionFwd : Forward {
     void forward() const override {
         const uint64_t sp = ((uint64_t)hg.S + 31) / 32 * 32;  // the draws are indexed in the padded (B*H, SP, SP) tensor (SP = S unless S is ragged)
         const uint64_t offset = (*calls) * (((uint64_t)hg.B * hg.H * sp * sp + 7) / 8);  // draws per forward, 8 per Philox call
-        ++(*calls);
         // scores / stats / mask are null in a graph without gradients: nothing is kept, no (B*H, S, S) tensor exists
         check(nk_attention_fwd(D(q), q->ptr(), k->ptr(), v->ptr(), scores ? scores->ptr() : nullptr, stats ? stats->ptr() : nullptr,
                                mask ? reinterpret_cast<uint32_t*>(mask->ptr()) : nullptr, o->ptr(), hg.B, hg.S, hg.H, hg.dh, scale, p,
                                *status ? 1 : 0, seed, offset));
+        ++(*calls);  // only a forward that was issued consumes its Philox range (a refused capture throws above)
     }
 };
 struct HeadsAttentionBwd : Backward {
@@ -2155,11 +2155,11 @@ Communicator::Communicator(DevicePtr dev, int nranks, int rank, const std::strin
     if (id.size() != NK_COMM_ID_BYTES) panic("communicator id must be 128 bytes");
     check(nk_comm_init_rank(dev_->raw(), nranks, rank, id.data(), &h_));
 }
-Communicator::Communicator(DevicePtr dev, int nranks) : dev_(std::move(dev)), rank_(0), size_(nranks) {
-    check(nk_comm_init_replicas(dev_->raw(), nranks, &h_));
+Communicator::Communicator(DevicePtr dev, int nranks, int channels, double gbps) : dev_(std::move(dev)), rank_(0), size_(nranks) {
+    check(nk_comm_init_replicas(dev_->raw(), nranks, channels, gbps, &h_));
 }
-std::shared_ptr<Communicator> Communicator::replicas(DevicePtr dev, int nranks) {
-    return std::shared_ptr<Communicator>(new Communicator(std::move(dev), nranks));
+std::shared_ptr<Communicator> Communicator::replicas(DevicePtr dev, int nranks, int channels, double gbps) {
+    return std::shared_ptr<Communicator>(new Communicator(std::move(dev), nranks, channels, gbps));
 }
 Communicator::~Communicator() { nk_comm_destroy(h_); }
 
@@ -2179,13 +2179,6 @@ GradientSync::GradientSync(std::shared_ptr<Communicator> comm, const std::vector
     nk_event* ev = nullptr;  // one more for the group of small gradients
     check(nk_event_create(comm_->device()->raw(), &ev));
     events_.push_back(ev);
-    if (const char* e = std::getenv("NK_DP_PARTS")) {
-        const std::string v(e);
-        if (v == "all") parts_ = Parts::All;
-        else if (v == "none") parts_ = Parts::None;
-        else if (v == "last") parts_ = Parts::LastOnly;
-        else panic("NK_DP_PARTS must be all, last or none");
-    }
 }
 GradientSync::~GradientSync() {
     for (nk_event* e : events_) nk_event_destroy(e);

@@ -785,7 +785,8 @@ class Communicator {
     static std::string unique_id();  // 128 raw bytes, create on rank 0
     Communicator(DevicePtr dev, int nranks, int rank, const std::string& id);
     // `nranks` virtual ranks holding this rank's values (nk_comm_init_replicas): sum all-reduce = multiply by nranks
-    static std::shared_ptr<Communicator> replicas(DevicePtr dev, int nranks);
+    // (channels, gbps: the paced stand-in of benchmarks/overlap_projection.py; 0, 0: an unthrottled streaming pass)
+    static std::shared_ptr<Communicator> replicas(DevicePtr dev, int nranks, int channels = 0, double gbps = 0.0);
     ~Communicator();
     int rank() const { return rank_; }
     int size() const { return size_; }
@@ -793,7 +794,7 @@ class Communicator {
     DevicePtr device() const { return dev_; }
 
    private:
-    Communicator(DevicePtr dev, int nranks);
+    Communicator(DevicePtr dev, int nranks, int channels, double gbps);
     DevicePtr dev_;
     nk_comm* h_ = nullptr;
     int rank_, size_;

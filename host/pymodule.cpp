@@ -386,7 +386,7 @@ PYBIND11_MODULE(_tape, m) {
         .def(py::init([](DevicePtr dev, int nranks, int rank, py::bytes id) {
             return std::make_shared<dp::Communicator>(std::move(dev), nranks, rank, std::string(id));
         }))
-        .def_static("replicas", &dp::Communicator::replicas, py::arg("device"), py::arg("nranks"))
+        .def_static("replicas", &dp::Communicator::replicas, py::arg("device"), py::arg("nranks"), py::arg("channels") = 0, py::arg("gbps") = 0.0)
         .def("raw", [](const dp::Communicator& c) { return (uintptr_t)c.raw(); })  // nk_comm* for the raw C ABI (bench diagnostics)
         .def_property_readonly("rank", &dp::Communicator::rank)
         .def_property_readonly("size", &dp::Communicator::size);

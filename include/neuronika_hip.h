@@ -70,6 +70,15 @@ void* nk_stream_compute(nk_device* dev); /* hipStream_t */
 void* nk_stream_comm(nk_device* dev);    /* hipStream_t */
 const char* nk_last_error(void);
 const char* nk_version(void);
+/* Development overrides of the kernels' launch heuristics, per device handle (the library reads NO environment variable):
+ *   NK_TUNE_GEMM_FORCE     values = ti, tj, splits[, tiles per block[, tile-order group height[, look-ahead threshold]]]
+ *                          (ti, tj in {1, 2}: 64- or 128-wide tile sides); n = 0 returns to the rules
+ *   NK_TUNE_GEMM_KPAIR     values[0] = -1 rule / 0 never / 1 k-pair blocks, lock-step groups / 2 skewed groups
+ *   NK_TUNE_ATTENTION_OCC  values[0] = 0 rule / 2: forward register budget sized for two blocks per CU
+ * For schedule sweeps (benchmarks/ab_*.py) and the tests that pit one schedule against another bit for bit; results never
+ * depend on them beyond summation order (split-K). */
+enum { NK_TUNE_GEMM_FORCE = 0, NK_TUNE_GEMM_KPAIR = 1, NK_TUNE_ATTENTION_OCC = 2 };
+int nk_dev_tune(nk_device* dev, int knob, const int* values, int n);
 
 /* ------------------------------------------------------------------ memory ------------- */
 /* `CuArray::zeroed` cuda/cuarray.rs:35-42; outputs and gradients are allocated zeroed at
@@ -526,12 +535,16 @@ int nk_rmsprop_step(nk_device* dev, float* w, float* grad, float* square_avg, fl
 int nk_comm_unique_id(char id[NK_COMM_ID_BYTES]);
 int nk_comm_init_rank(nk_device* dev, int nranks, int rank, const char id[NK_COMM_ID_BYTES],
                       nk_comm** out);
+/* Single process, one host thread per GPU: the communicators of `ndev` device handles of THIS process at
+ * once (ncclCommInitAll); out[i] belongs to devs[i] and is rank i of ndev.  Each thread then drives its own communicator
+ * with the calls below; no unique id has to travel. */
+int nk_comm_init_all(int ndev, nk_device* const* devs, nk_comm** out);
 /* A communicator of `nranks` virtual ranks that all hold THIS rank's values (no RCCL, no peers):
  * its sum all-reduce multiplies the buffer by nranks on the side stream, with the same stream
  * ordering as the real one.  Lets a single GPU check that an exchange schedule covers every
  * element of every gradient exactly once (a sum over ONE real rank is the identity and would
  * hide a wrong offset or count) and price the schedule without fabric traffic. */
-int nk_comm_init_replicas(nk_device* dev, int nranks, nk_comm** out);
+int nk_comm_init_replicas(nk_device* dev, int nranks, int channels, double gbps, nk_comm** out);
 int nk_comm_destroy(nk_comm* comm);
 /* In-place sum all-reduce of buf[0..n) on the device's SIDE stream.  The side stream first
  * waits for `after` (an event recorded on the compute stream once the bucket's gradients are

@@ -57,6 +57,26 @@ fn next_seed() -> u64 {
     })
 }
 
+/// The reference's padding modes (`node/pad/{zero,constant,reflective,replicative}/mod.rs`) as one value type.
+#[derive(Clone, Copy, Debug, PartialEq)]
+pub enum PaddingMode {
+    Zero,
+    Constant(f32),
+    Reflective,
+    Replicative,
+}
+
+impl From<PaddingMode> for PadMode {
+    fn from(mode: PaddingMode) -> Self {
+        match mode {
+            PaddingMode::Zero => PadMode::Constant(0.),
+            PaddingMode::Constant(value) => PadMode::Constant(value),
+            PaddingMode::Reflective => PadMode::Reflective,
+            PaddingMode::Replicative => PadMode::Replicative,
+        }
+    }
+}
+
 /// A non-differentiable variable with data in HBM.  Same fields and tape as `Var<D>` (`var.rs:34-40`) /
 /// `CuVar<D>` (`cuda/cuvar.rs:19-46`): only the array type differs.
 pub struct HipVar<D>
@@ -114,6 +134,11 @@ where
             op.forward();
             computed.set(true)
         });
+    }
+
+    /// Extents of the data, without touching the device.
+    pub fn shape(&self) -> Vec<usize> {
+        self.data.borrow().dimension().slice().to_vec()
     }
 
     /// Host copy of the data (synchronises), `Var::data` (`var.rs:131-136`).
@@ -377,6 +402,17 @@ where
     }
 
     /// `VarDiff::zero_grad` (`vardiff.rs:100-102`).
+    /// Extents of the data, without touching the device.
+    pub fn shape(&self) -> Vec<usize> {
+        self.var.shape()
+    }
+
+    /// A differentiable leaf holding `array` (parameter construction: `zeros(..).requires_grad()` + `init::uniform` in the
+    /// reference, `neuronika-nn/src/lib.rs:425-433`; here the values are drawn on the host and uploaded once).
+    pub fn parameter(array: &ndarray::Array<f32, D>, device: Device) -> Self {
+        HipVar::from_ndarray(array, device).requires_grad()
+    }
+
     /// Registration record of this parameter for `dp::GradientSync::new`.
     pub fn sync_entry(&self) -> super::dp::SyncEntry {
         let mut grad = self.grad.borrow_mut();
@@ -493,6 +529,12 @@ where
     /// `VarDiff::pad` (`vardiff.rs:746-766`), zero mode; `pad_with` takes the other three modes.
     pub fn pad_zero(self, padding: &[usize]) -> HipVarDiff<D> {
         self.pad_with(padding, PadMode::Constant(0.))
+    }
+
+    /// `VarDiff::pad(padding, mode)` with the mode as a value (`PaddingMode`: the reference's four marker types `Zero`,
+    /// `Constant`, `Reflective`, `Replicative`, `node/pad/`), which is how the `nn` convolution layers store it.
+    pub fn pad(self, padding: &[usize], mode: PaddingMode) -> HipVarDiff<D> {
+        self.pad_with(padding, mode.into())
     }
 
     pub(crate) fn pad_with(self, padding: &[usize], mode: PadMode) -> HipVarDiff<D> {

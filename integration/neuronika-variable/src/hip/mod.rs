@@ -11,5 +11,5 @@ pub use {
     device::Device,
     dp::{Communicator, GradientSync, SyncEntry},
     hiparray::HipArray,
-    hipvar::{manual_seed, HipVar, HipVarDiff},
+    hipvar::{manual_seed, HipVar, HipVarDiff, PaddingMode},
 };

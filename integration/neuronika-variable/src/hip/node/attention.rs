@@ -67,12 +67,12 @@ impl Forward for HeadsAttention {
         let sp = ((h.seq as u64) + 31) / 32 * 32; // draws are indexed in the padded (batch*heads, sp, sp) tensor
         let elems = (h.batch as u64) * (h.heads as u64) * sp * sp;
         let offset = self.state.calls.get() * ((elems + 7) / 8); // 8 draws per Philox call
-        self.state.calls.set(self.state.calls.get() + 1);
         ffi::check(unsafe {
             ffi::nk_attention_fwd(q.device().as_raw(), q.as_ptr(), k.as_ptr(), v.as_ptr(), scores.as_mut_ptr(), stats.as_mut_ptr(),
                                   bits.as_mut_ptr() as *mut u32, out.as_mut_ptr(), h.batch, h.seq, h.heads, h.dh, self.scale, self.p,
                                   self.status.get() as i32, self.seed, offset)
         });
+        self.state.calls.set(self.state.calls.get() + 1); // only a forward that was issued consumes its Philox range
     }
 }
 

@@ -137,11 +137,11 @@ impl<D: Dimension> Forward for Dropout<D> {
         let x = self.operand_data.borrow();
         let (mut y, mut noise) = (self.data.borrow_mut(), self.noise.borrow_mut());
         let offset = self.calls.get() * ((x.len() as u64 + 7) / 8); // one Philox call serves 8 draws (include/neuronika_hip.h, dropout)
-        self.calls.set(self.calls.get() + 1);
         ffi::check(unsafe {
             ffi::nk_dropout_fwd(x.device().as_raw(), x.as_ptr(), y.as_mut_ptr(), noise.as_mut_ptr(), x.len(), self.p,
                                 self.status.get() as i32, self.seed, offset)
         });
+        self.calls.set(self.calls.get() + 1); // only a forward that was issued consumes its Philox range (`check` panics on a refusal)
     }
 }
 

@@ -173,7 +173,9 @@ _SIGS = {
     "nk_rmsprop_step": [VP, VP, VP, VP, VP, VP, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float],
     "nk_comm_unique_id": [C.c_char_p],
     "nk_comm_init_rank": [VP, C.c_int, C.c_int, C.c_char_p, C.POINTER(VP)],
-    "nk_comm_init_replicas": [VP, C.c_int, C.POINTER(VP)],
+    "nk_comm_init_replicas": [VP, C.c_int, C.c_int, C.c_double, C.POINTER(VP)],
+    "nk_comm_init_all": [C.c_int, C.POINTER(VP), C.POINTER(VP)],
+    "nk_dev_tune": [VP, C.c_int, C.POINTER(C.c_int), C.c_int],
     "nk_comm_destroy": [VP],
     "nk_allreduce_sum_async": [VP, VP, C.c_size_t, VP],
     "nk_allreduce_sum_group_async": [VP, C.POINTER(VP), C.POINTER(C.c_size_t), C.c_int, VP],
@@ -236,6 +238,9 @@ class Event:
             pass
 
 
+TUNE_GEMM_FORCE, TUNE_GEMM_KPAIR, TUNE_ATTENTION_OCC = 0, 1, 2   # include/neuronika_hip.h: nk_dev_tune knobs
+
+
 class Device:
     """`Device::new(idx)` (cuda/device.rs:34-58): one GPU, its compute + communication streams."""
 
@@ -243,12 +248,33 @@ class Device:
         """`handle`: wrap an existing nk_device* (e.g. `tape.Device.raw()`) without owning it."""
         if handle is not None:
             self.h, self.idx, self._own = VP(handle), lib.nk_device_index(VP(handle)), False
-            return
-        h = VP()
-        check(lib.nk_device_create(idx, C.byref(h)))
-        self.h = h
-        self.idx = idx
-        self._own = True
+        else:
+            h = VP()
+            check(lib.nk_device_create(idx, C.byref(h)))
+            self.h, self.idx, self._own = h, idx, True
+        # The sweep scripts (benchmarks/ab_*.py, tools/sessions/*.sh) choose a schedule per process through environment
+        # variables; it is THIS harness that reads them and calls nk_dev_tune - the library itself reads none.
+        for var, knob in (("NK_GEMM_FORCE", TUNE_GEMM_FORCE), ("NK_GEMM_KPAIR", TUNE_GEMM_KPAIR), ("NK_ATTN_OCC", TUNE_ATTENTION_OCC)):
+            if os.environ.get(var):
+                self.tune(knob, os.environ[var])
+
+    def tune(self, knob: int, values=None):
+        """nk_dev_tune: `values` = None (back to the rules), an int, a sequence of ints or "a,b,c"."""
+        if values is None:
+            vals = []
+        elif isinstance(values, str):
+            vals = [int(v) for v in values.split(",") if v.strip()]
+        elif isinstance(values, (int, np.integer)):
+            vals = [int(values)]
+        else:
+            vals = [int(v) for v in values]
+        check(lib.nk_dev_tune(self.h, knob, (C.c_int * max(1, len(vals)))(*vals), len(vals)))
+
+    def gemm_force(self, values=None):
+        self.tune(TUNE_GEMM_FORCE, values)
+
+    def gemm_kpair(self, mode=None):
+        self.tune(TUNE_GEMM_KPAIR, mode)
 
     def sync(self):
         check(lib.nk_device_sync(self.h))
@@ -708,15 +734,28 @@ class Comm:
         check(lib.nk_comm_unique_id(buf))
         return buf.raw
 
-    def __init__(self, dev: Device, nranks: int, rank: int, uid: bytes | None):
+    def __init__(self, dev: Device, nranks: int, rank: int, uid: bytes | None, channels: int = 0, gbps: float = 0.0):
         """uid = None: a replica communicator (nk_comm_init_replicas) of `nranks` virtual ranks."""
         h = VP()
         if uid is None:
-            check(lib.nk_comm_init_replicas(dev.h, nranks, C.byref(h)))
+            check(lib.nk_comm_init_replicas(dev.h, nranks, int(channels), float(gbps), C.byref(h)))
         else:
             assert len(uid) == COMM_ID_BYTES
             check(lib.nk_comm_init_rank(dev.h, nranks, rank, uid, C.byref(h)))
         self.h, self.dev, self.rank, self.size = h, dev, rank, nranks
+
+    @classmethod
+    def init_all(cls, devs):
+        """nk_comm_init_all: one communicator per device handle of this process (thread-per-GPU use)."""
+        n = len(devs)
+        out = (VP * n)()
+        check(lib.nk_comm_init_all(n, (VP * n)(*[d.h for d in devs]), out))
+        comms = []
+        for i, d in enumerate(devs):
+            c = cls.__new__(cls)
+            c.h, c.dev, c.rank, c.size = VP(out[i]), d, i, n
+            comms.append(c)
+        return comms
 
     def allreduce_sum_async(self, buf: HipArray, after: Event | None = None, n: int | None = None):
         check(lib.nk_allreduce_sum_async(self.h, buf.p, buf.size if n is None else n, after.h if after else None))

@@ -462,10 +462,9 @@ int attention_launch_dh(nk_device* dev, AttnArgs& a, int B, int S, int H, double
     // 1.37 - 1.41 ms at C5, round 3) - and the backward holds 70 KB of LDS per block: two blocks per CU.  DH = 128: 85 / 103 KB
     // of LDS and ~240 / ~290 registers per lane: one block per CU (a wave may then use the whole unified register file).
     // DH = 32: the DH = 64 budgets.
-    static const int occ_env = [] { const char* e = getenv("NK_ATTN_OCC"); return e ? atoi(e) : 0; }();   // tuning aid
     constexpr int OCC_F = DH == 128 ? 1 : 3, OCC_B = DH == 128 ? 1 : 2;   // forward / backward blocks per CU
     constexpr int OCC_DEFAULT = BWD ? OCC_B : OCC_F;
-    const bool occ2 = !BWD && DH != 128 && occ_env == 2;
+    const bool occ2 = !BWD && DH != 128 && dev->tune_attn_occ == 2;   // (nk_dev_tune, NK_TUNE_ATTENTION_OCC: sweeps only)
 #define NK_ATT(M, F, R)                                                                                                    \
     do {                                                                                                                   \
         /* inference forward: KEEP = false (spelled `BWD`, false on the only path that reaches this line) */             \

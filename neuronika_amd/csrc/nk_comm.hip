@@ -6,7 +6,8 @@
 // parameters registered with the optimizer (optimizer.rs:70-77).
 #include <rccl/rccl.h>
 
-#include <cstdlib>
+#include <cstdint>
+#include <cstring>
 
 #include "nk_common.h"
 
@@ -91,14 +92,28 @@ int nk_comm_init_rank(nk_device* dev, int nranks, int rank, const char id[NK_COM
     return NK_OK;
 }
 
-int nk_comm_init_replicas(nk_device* dev, int nranks, nk_comm** out) {
+int nk_comm_init_all(int ndev, nk_device* const* devs, nk_comm** out) {
+    NK_CHECK(ndev >= 1 && ndev <= 64 && devs && out, "bad nk_comm_init_all arguments");
+    int ids[64];
+    ncclComm_t comms[64];
+    for (int i = 0; i < ndev; ++i) {
+        NK_CHECK(devs[i] != nullptr, "null device handle %d", i);
+        for (int j = 0; j < i; ++j) NK_CHECK(devs[j]->idx != devs[i]->idx, "nk_comm_init_all: GPU %d named twice", devs[i]->idx);
+        ids[i] = devs[i]->idx;
+    }
+    NK_RCCL(ncclCommInitAll(comms, ndev, ids));
+    for (int i = 0; i < ndev; ++i) out[i] = new nk_comm{devs[i], comms[i], i, ndev};
+    return NK_OK;
+}
+
+int nk_comm_init_replicas(nk_device* dev, int nranks, int channels, double gbps, nk_comm** out) {
     NK_USE(dev);
     NK_CHECK(out != nullptr, "null argument");
     NK_CHECK(nranks >= 1, "bad replica count %d", nranks);
+    NK_CHECK(channels >= 0 && channels <= 1024 && gbps >= 0.0, "bad replica pacing (channels %d, %g GB/s)", channels, gbps);
     nk_comm* c = new nk_comm{dev, nullptr, 0, nranks};
-    if (const char* e = getenv("NK_REPLICA_CHANNELS")) c->channels = atoi(e);
-    if (const char* e = getenv("NK_REPLICA_GBPS")) c->gbps = atof(e);
-    NK_CHECK(c->channels >= 0 && c->channels <= 1024 && c->gbps >= 0.0, "bad NK_REPLICA_CHANNELS / NK_REPLICA_GBPS");
+    c->channels = channels;
+    c->gbps = gbps;
     *out = c;
     return NK_OK;
 }
@@ -138,8 +153,8 @@ int nk_allreduce_sum_group_async(nk_comm* comm, float* const* bufs, const size_t
     if (!comm->comm) {  // replica communicator: every virtual rank holds this rank's values
         for (int i = 0; i < nbufs; ++i) {
             if (counts[i] == 0) continue;
-            if (comm->channels > 0) {
-                // seconds for this buffer at the emulated algorithm bandwidth, spread over the 4 KB steps of one workgroup
+            if (comm->channels > 0 && (reinterpret_cast<uintptr_t>(bufs[i]) & 15) == 0) {  // (the paced walk uses 16-byte accesses)
+                // seconds for this buffer at the emulated algorithm bandwidth, spread over the 16 KB steps of one workgroup
                 const size_t per = (counts[i] / 4 + comm->channels - 1) / comm->channels, steps = (per + 1023) / 1024;  // float4s, 16 KB steps
                 const double ticks = comm->gbps > 0.0 ? (counts[i] * 4.0 / (comm->gbps * 1e9)) * 1e8 / (double)(steps ? steps : 1) : 0.0;
                 replica_sum_paced_kernel<<<comm->channels, 256, 0, dev->comm>>>(bufs[i], counts[i], (float)comm->size, ticks);

@@ -28,6 +28,12 @@ struct nk_device {
     int graphs_alive = 0;           // nk_graph objects of this device: their kernels have workspace pointers baked in
     std::vector<void*> workspace_retired;  // outgrown workspaces kept while any graph may still replay into them
     int num_cus = 256;
+    // development overrides, set through nk_dev_tune (schedule sweeps, schedule-against-schedule parity tests); the library
+    // reads no environment variable
+    int tune_gemm[6] = {0, 0, 0, 0, 0, 0};  // ti, tj, splits[, tiles per block[, tile-order group height[, look-ahead threshold]]]
+    int tune_gemm_n = 0;                     // how many of them are set (< 3: the rules decide)
+    int tune_kpair = -1;                     // k-pair blocks: -1 rule, 0 never, 1 lock-step groups, 2 skewed groups
+    int tune_attn_occ = 0;                   // attention forward: 2 = size the register budget for two blocks per CU
     // bench instrumentation (nk_profile_begin/end)
     bool prof_on = false;
     std::vector<nk_prof_rec> prof;      // records of the current window

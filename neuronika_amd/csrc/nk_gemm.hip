@@ -7,10 +7,6 @@
 // loads issued before the MFMAs of the current tile and written to LDS behind them (one barrier
 // per k-tile), XCD-aware tile order, split-K with a deterministic second pass when M*N alone
 // cannot fill the chip.
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-
 #include "nk_mma.h"
 
 using namespace nkmma;
@@ -230,6 +226,7 @@ __global__ __launch_bounds__(NT * KG, (min_waves<TI, TJ, !TA && TB>())) void sge
     constexpr bool BKC = TB;   // B (K x N) stored as N x K when transposed -> k-contiguous
     constexpr int TA_FLOATS = tile_floats<AKC, BM>(), STAGE = TA_FLOATS + tile_floats<BKC, BN>();
     static_assert(KG == 1 || (ALIGNED && 2 * 2 * STAGE >= BM * BN), "k-pair: aligned problems; a group's images hold half a C tile");
+    static_assert(KG * 2 * STAGE * sizeof(float) <= 160 * 1024, "the block's LDS images must fit the 160 KB of a gfx950 CU");
     __shared__ __attribute__((aligned(16))) float smem_all[KG * 2 * STAGE];  // <= 73,728 B at 128x128 (k-pair: twice that)
 
     const int grp = KG == 2 ? (int)(threadIdx.x >> 8) : 0;  // NT == 256
@@ -411,30 +408,6 @@ __global__ void splitk_reduce_flat_kernel(const float* __restrict__ slabs, float
 }
 
 
-// An override variable's integers, parsed when its TEXT changes (one getenv + strcmp per GEMM call, no sscanf): the
-// benchmarks set the variable before the process starts, the tests flip it between calls.  Per thread: no shared state.
-struct EnvInts { int n, v[6]; };
-struct EnvCache {
-    const char* name;
-    bool seen = false;
-    char text[96] = {0};
-    EnvInts val{0, {0, 0, 0, 0, 0, 0}};
-    explicit EnvCache(const char* n) : name(n) {}
-    const EnvInts& get() {
-        const char* e = getenv(name);
-        if (!e) e = "";
-        if (!seen || strncmp(e, text, sizeof(text) - 1) != 0) {
-            seen = true;
-            strncpy(text, e, sizeof(text) - 1);
-            val = EnvInts{0, {0, 0, 0, 0, 0, 0}};
-            const int n = sscanf(text, "%d,%d,%d,%d,%d,%d", &val.v[0], &val.v[1], &val.v[2], &val.v[3], &val.v[4], &val.v[5]);
-            val.n = n > 0 ? n : 0;
-        }
-        return val;
-    }
-};
-static thread_local EnvCache env_force("NK_GEMM_FORCE"), env_kpair("NK_GEMM_KPAIR");
-
 template <bool TA, bool TB, int TI, int TJ>
 static int launch_tile(nk_device* dev, const GemmArgs& p, int nbatch, bool aligned, int kg = 1) {
     dim3 grid((p.tiles_m * p.tiles_n + p.chunk - 1) / p.chunk, p.splits, nbatch), block(NT * kg);
@@ -541,16 +514,15 @@ static int gemm_impl(nk_device* dev, int transA, int transB, int M, int N, int K
     p.tiles_m = (M + 64 * ti - 1) / (64 * ti);
     p.tiles_n = (N + 64 * tj - 1) / (64 * tj);
     int force_chunk = 0, force_group = 0, force_pf2 = 0;
-    // tuning sweeps (benchmarks/ab_force.py) and the parity tests that pit one schedule against another in ONE process:
-    // NK_GEMM_FORCE="ti,tj,splits[,chunk[,group_m[,lookahead_min]]]" overrides the rules
-    const EnvInts& force = env_force.get();
-    if (force.n >= 3 && (force.v[0] == 1 || force.v[0] == 2) && (force.v[1] == 1 || force.v[1] == 2)) {
-        ti = force.v[0]; tj = force.v[1]; splits = force.v[2] < 1 ? 1 : force.v[2];
+    // schedule sweeps (benchmarks/ab_force.py) and the parity tests that pit one schedule against another: the device handle's
+    // NK_TUNE_GEMM_FORCE values "ti, tj, splits[, chunk[, group_m[, lookahead_min]]]" override the rules (nk_dev_tune)
+    if (dev->tune_gemm_n >= 3 && (dev->tune_gemm[0] == 1 || dev->tune_gemm[0] == 2) && (dev->tune_gemm[1] == 1 || dev->tune_gemm[1] == 2)) {
+        ti = dev->tune_gemm[0]; tj = dev->tune_gemm[1]; splits = dev->tune_gemm[2] < 1 ? 1 : dev->tune_gemm[2];
         p.tiles_m = (M + 64 * ti - 1) / (64 * ti);
         p.tiles_n = (N + 64 * tj - 1) / (64 * tj);
-        if (force.n >= 4) force_chunk = force.v[3];
-        if (force.n >= 5) force_group = force.v[4];
-        if (force.n >= 6) force_pf2 = force.v[5];
+        if (dev->tune_gemm_n >= 4) force_chunk = dev->tune_gemm[3];
+        if (dev->tune_gemm_n >= 5) force_group = dev->tune_gemm[4];
+        if (dev->tune_gemm_n >= 6) force_pf2 = dev->tune_gemm[5];
     }
     int kts = (ktiles + splits - 1) / splits;
     if (kts < 1) kts = 1;
@@ -597,19 +569,19 @@ static int gemm_impl(nk_device* dev, int transA, int transB, int M, int N, int K
                          (ldb % 4 == 0) && aligned16(A) && aligned16(B) && (sAo % 4 == 0) &&
                          (sAi % 4 == 0) && (sBo % 4 == 0) && (sBi % 4 == 0);
     // k-pair blocks (sgemm_kernel, KG = 2): 128x128 tiles, aligned, one tile per block, a whole number of k-tile pairs per
-    // block, and a grid of at most one block per CU - with more blocks than CUs two 256-thread blocks share a CU anyway.
-    // NK_GEMM_KPAIR = 0 (never) / 1 (lock-step groups) / 2 (group 1 half a k-tile out of phase) overrides for sweeps.
-    const EnvInts& kp = env_kpair.get();
-    const int kpair_env = kp.n >= 1 ? kp.v[0] : -1;
+    // block, and a grid of at most ONE BLOCK PER CU - with more blocks than CUs two 256-thread blocks share a CU anyway.
+    // (its two groups' LDS images, 131 - 147 KB, assume the 160 KB of a gfx950 CU: static_assert in sgemm_kernel.)
+    // NK_TUNE_GEMM_KPAIR = 0 (never) / 1 (lock-step groups) / 2 (group 1 half a k-tile out of phase) overrides for sweeps.
+    const int kpair_tune = dev->tune_kpair;
     int kg = 1;
     p.kskew = 1;
     {
         const long long nblk = (long long)p.tiles_m * p.tiles_n * p.splits * nbatch;
         const bool can = ti * tj == 4 && aligned && p.chunk == 1 && kts % 2 == 0 && kts >= 8 && K % (2 * BK) == 0 &&
                          (p.splits == 1 || p.k_per_split * p.splits == K);
-        const bool want = kpair_env >= 0 ? kpair_env > 0 : nblk <= 256 && kts >= 32;
+        const bool want = kpair_tune >= 0 ? kpair_tune > 0 : nblk <= dev->num_cus && kts >= 32;
         if (can && want) kg = 2;
-        if (kpair_env == 1) p.kskew = 0;
+        if (kpair_tune == 1) p.kskew = 0;
     }
     if (p.splits > 1) {
         void* ws = nullptr;

@@ -148,6 +148,27 @@ int nk_device_destroy(nk_device* dev) {
     return NK_OK;
 }
 
+int nk_dev_tune(nk_device* dev, int knob, const int* values, int n) {
+    NK_CHECK(dev != nullptr && n >= 0 && (n == 0 || values != nullptr), "bad nk_dev_tune arguments");
+    switch (knob) {
+        case NK_TUNE_GEMM_FORCE:
+            NK_CHECK(n <= 6, "NK_TUNE_GEMM_FORCE takes at most 6 values");
+            for (int i = 0; i < 6; ++i) dev->tune_gemm[i] = i < n ? values[i] : 0;
+            dev->tune_gemm_n = n;
+            return NK_OK;
+        case NK_TUNE_GEMM_KPAIR:
+            NK_CHECK(n <= 1 && (n == 0 || (values[0] >= -1 && values[0] <= 2)), "NK_TUNE_GEMM_KPAIR: -1, 0, 1 or 2");
+            dev->tune_kpair = n ? values[0] : -1;
+            return NK_OK;
+        case NK_TUNE_ATTENTION_OCC:
+            NK_CHECK(n <= 1 && (n == 0 || values[0] == 0 || values[0] == 2), "NK_TUNE_ATTENTION_OCC: 0 or 2");
+            dev->tune_attn_occ = n ? values[0] : 0;
+            return NK_OK;
+    }
+    nk_set_error("unknown tuning knob %d", knob);
+    return NK_ERR_INVALID;
+}
+
 int nk_device_sync(nk_device* dev) {
     NK_USE(dev);
     NK_HIP(hipStreamSynchronize(dev->compute));

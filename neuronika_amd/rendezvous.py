@@ -24,6 +24,7 @@ MASTER_ADDR without NK_RV_SECRET is refused.
 from __future__ import annotations
 
 import hashlib
+import ipaddress
 import hmac
 import os
 import socket
@@ -89,7 +90,14 @@ def _recv(sock):
 
 
 def _is_loopback(addr: str) -> bool:
-    return addr in ("localhost", "::1") or addr.startswith("127.")
+    """The literal name `localhost` or an IP LITERAL inside 127.0.0.0/8 / ::1.  A host name is never loopback here (it
+    may resolve anywhere: "127.example.com"): anything that is not an IP literal needs NK_RV_SECRET."""
+    if addr == "localhost":
+        return True
+    try:
+        return ipaddress.ip_address(addr).is_loopback
+    except ValueError:
+        return False
 
 
 def _secret(world: int, addr: str = "127.0.0.1") -> bytes:

@@ -268,6 +268,10 @@ def test_rendezvous_fallback_secret_is_loopback_only(monkeypatch):
     assert len(rz._secret(2, "127.0.0.1")) == 32
     with pytest.raises(PermissionError):
         rz._secret(2, "10.1.2.3")
+    for name in ("127.example.com", "127.0.0.1.evil.org", "localhost.example.com", "2130706433", ""):   # not IP literals in 127/8
+        with pytest.raises(PermissionError):
+            rz._secret(2, name)
+    assert len(rz._secret(2, "127.8.9.10")) == 32 and len(rz._secret(2, "::1")) == 32 and len(rz._secret(2, "localhost")) == 32
     monkeypatch.setenv("NK_RV_SECRET", "s3cret")
     assert len(rz._secret(2, "10.1.2.3")) == 32
 

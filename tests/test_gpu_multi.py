@@ -211,6 +211,51 @@ def test_two_threads_drive_two_devices():
         assert "axis" in msg.lower() or msg
 
 
+@pytest.mark.skipif(_ngpu() < 2, reason="needs two GPUs")
+def test_comm_init_all_two_threads_all_reduce():
+    """nk_comm_init_all (ncclCommInitAll): the communicators of both GPUs of one process, each driven by its own host thread;
+    the sum all-reduce of rank-dependent data is the same on both and equals the host sum."""
+    import threading
+    from neuronika_amd import capi
+    devs = [capi.Device(0), capi.Device(1)]
+    comms = capi.Comm.init_all(devs)
+    assert [c.size for c in comms] == [2, 2] and [c.rank for c in comms] == [0, 1]
+    xs = [np.random.default_rng(40 + r).random(1 << 20, dtype=np.float32) for r in range(2)]
+    out = {}
+
+    def run(r):
+        try:
+            buf = devs[r].array(xs[r])
+            comms[r].allreduce_sum_async(buf)
+            comms[r].join()
+            out[r] = buf.numpy()
+        except Exception as e:                      # noqa: BLE001 - reported by the asserting thread
+            out[r] = repr(e)
+    ths = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+    [t.start() for t in ths]
+    [t.join(300) for t in ths]
+    for r in range(2):
+        assert not isinstance(out.get(r), str), out.get(r)
+        assert np.array_equal(out[r], xs[0] + xs[1])
+    [c.close() for c in comms]
+
+
+def test_comm_init_all_single_device():
+    """The same entry point with one device handle (runs on a 1-GPU box): a one-rank RCCL communicator, whose sum all-reduce is
+    the identity; a device named twice is refused."""
+    from neuronika_amd import capi
+    dev = capi.Device(0)
+    (comm,) = capi.Comm.init_all([dev])
+    assert comm.size == 1 and comm.rank == 0
+    x = np.random.default_rng(3).random(100003, dtype=np.float32)
+    buf = dev.array(x)
+    comm.allreduce_sum_async(buf); comm.join()
+    assert np.array_equal(buf.numpy(), x)
+    comm.close()
+    with pytest.raises(capi.NeuronikaHipError, match="named twice"):
+        capi.Comm.init_all([dev, capi.Device(0)])
+
+
 def test_two_threads_share_one_gpu_through_two_handles():
     """The same thread-per-handle shape on a 1-GPU box: two handles (own streams, own workspace) of device 0 driven from
     two threads at once."""

@@ -397,12 +397,12 @@ def test_sgemm_tile_chunks(dev, ta, tb, K, chunk, splits):
         for tiles in ("2,2", "1,2"):
             for ch in (1, chunk):
                 for alpha, beta in ((1.0, 0.0), (-1.5, 0.5)):
-                    os.environ["NK_GEMM_FORCE"] = f"{tiles},{splits},{ch}"
+                    dev.gemm_force(f"{tiles},{splits},{ch}")
                     Cd = dev.array(c0)
                     c.sgemm_batched(dev, ta, tb, M, N, K, alpha, A, lda, nb_i * sa, sa, B, ldb, nb_i * sb, sb, beta, Cd, N, nb_i * sc, sc, nb_o, nb_i)
                     outs[(tiles, ch, alpha)] = Cd.numpy()
     finally:
-        os.environ.pop("NK_GEMM_FORCE", None)
+        dev.gemm_force(None)
     opa = (a.transpose(0, 2, 1) if ta else a).astype(np.float64)
     opb = (b.transpose(0, 2, 1) if tb else b).astype(np.float64)
     ref = opa @ opb
@@ -432,7 +432,7 @@ def test_sgemm_lookahead_loop_is_bit_identical(dev, ta, tb, tiles):
             A, B = dev.array(a), dev.array(b)
             outs = {}
             for la in (1, 9999):
-                os.environ["NK_GEMM_FORCE"] = f"{tiles},1,1,8,{la}"
+                dev.gemm_force(f"{tiles},1,1,8,{la}")
                 Cd = dev.array(c0)
                 c.sgemm(dev, ta, tb, M, N, K, -1.5, A, a.shape[1], B, b.shape[1], 0.5, Cd, N)
                 outs[la] = Cd.numpy()
@@ -442,12 +442,14 @@ def test_sgemm_lookahead_loop_is_bit_identical(dev, ta, tb, tiles):
                 want = -1.5 * (opa @ opb) + 0.5 * c0
                 contraction_ok(outs[1], want.astype(np.float32), want, K, 1.5, 1.0)
     finally:
-        os.environ.pop("NK_GEMM_FORCE", None)
+        dev.gemm_force(None)
 
 
 def test_gemm_override_variable_is_live(dev):
-    """The schedule tests above flip NK_GEMM_FORCE between calls of ONE process: the library must notice (it parses the variable
-    when its text changes).  Split-K 4 sums in another order than the unsplit product - different bits on random data."""
+    """The schedule tests above flip the device handle's NK_TUNE_GEMM_FORCE override (nk_dev_tune) between calls of ONE process: it
+    must take effect at once and go away again.  Split-K 4 sums in another order than the unsplit product - different bits on
+    random data.  The library itself reads no environment variable: setting NK_GEMM_FORCE in the environment of a running
+    process changes nothing."""
     import os
     c = capi()
     M = N = 256
@@ -457,14 +459,25 @@ def test_gemm_override_variable_is_live(dev):
     outs = {}
     try:
         for force in ("2,2,1", "2,2,4", "2,2,1"):
-            os.environ["NK_GEMM_FORCE"] = force
+            dev.gemm_force(force)
             Cd = dev.zeros((M, N))
             c.sgemm(dev, 0, 1, M, N, K, 1.0, A, K, B, K, 0.0, Cd, N)
             outs.setdefault(force, []).append(Cd.numpy())
     finally:
-        os.environ.pop("NK_GEMM_FORCE", None)
+        dev.gemm_force(None)
     assert np.array_equal(outs["2,2,1"][0], outs["2,2,1"][1])
     assert not np.array_equal(outs["2,2,1"][0], outs["2,2,4"][0])
+    os.environ["NK_GEMM_FORCE"] = "2,2,2"                     # the environment of a running process: not consulted
+    try:                                                      # (the rules split this shape 4 ways: split 2 gives other bits)
+        Cd = dev.zeros((M, N))
+        c.sgemm(dev, 0, 1, M, N, K, 1.0, A, K, B, K, 0.0, Cd, N)
+        rules = Cd.numpy()
+        dev.gemm_force("2,2,2")
+        c.sgemm(dev, 0, 1, M, N, K, 1.0, A, K, B, K, 0.0, Cd, N)
+        assert not np.array_equal(rules, Cd.numpy())
+    finally:
+        os.environ.pop("NK_GEMM_FORCE", None)
+        dev.gemm_force(None)
 
 
 @pytest.mark.parametrize("ta,tb", [(0, 1), (0, 0), (1, 0), (1, 1)])
@@ -490,7 +503,7 @@ def test_sgemm_kpair_blocks(dev, ta, tb):
                                           ("pair_skewed_again", "2,2,1", "2"), ("split2_pair", "2,2,2", "2")):
                     if name == "split2_pair" and (K // 32) % 4 != 0:
                         continue
-                    os.environ["NK_GEMM_FORCE"], os.environ["NK_GEMM_KPAIR"] = force, pair
+                    dev.gemm_force(force); dev.gemm_kpair(int(pair))
                     Cd = dev.array(c0)
                     c.sgemm_batched(dev, ta, tb, M, N, K, alpha, A, lda, 0, sa, B, ldb, 0, sb, beta, Cd, N, 0, sc, 1, nb)
                     outs[name] = Cd.numpy()
@@ -504,8 +517,7 @@ def test_sgemm_kpair_blocks(dev, ta, tb):
                     if name in outs:
                         contraction_ok(outs[name], want.astype(np.float32), want, K, 1.5, 1.0)
     finally:
-        os.environ.pop("NK_GEMM_FORCE", None)
-        os.environ.pop("NK_GEMM_KPAIR", None)
+        dev.gemm_force(None); dev.gemm_kpair(None)
 
 
 @pytest.mark.parametrize("ta,tb", [(0, 1), (0, 0), (1, 0), (1, 1)])
@@ -530,7 +542,7 @@ def test_sgemm_is_the_device_order_model_bit_for_bit(dev, ta, tb):
             a = rnd(90 + K, (K, M) if ta else (M, K), -1, 1)
             b = rnd(91 + K, (N, K) if tb else (K, N), -1, 1)
             opa, opb = np.ascontiguousarray(a.T if ta else a), np.ascontiguousarray(b.T if tb else b)
-            os.environ["NK_GEMM_FORCE"], os.environ["NK_GEMM_KPAIR"] = force, pair
+            dev.gemm_force(force); dev.gemm_kpair(int(pair))
             A, B, Cd = dev.array(a), dev.array(b), dev.full((M, N), np.nan)
             c.sgemm(dev, ta, tb, M, N, K, 1.0, A, a.shape[1], B, b.shape[1], 0.0, Cd, N)
             got = Cd.numpy()
@@ -557,8 +569,7 @@ def test_sgemm_is_the_device_order_model_bit_for_bit(dev, ta, tb):
             if K >= 2048 and f[2] == 1 and pair == "0":      # the check has teeth: chains of 1024 give other bits
                 assert not np.array_equal(got, sgemm_device_order(opa, opb, 1024)), (K, force)
     finally:
-        os.environ.pop("NK_GEMM_FORCE", None)
-        os.environ.pop("NK_GEMM_KPAIR", None)
+        dev.gemm_force(None); dev.gemm_kpair(None)
 
 
 def test_sgemm_large_rowsum_identity(dev):

@@ -901,7 +901,7 @@ def test_gradient_sync_piecewise_exchange(nk, tdev):
     assert s3.exchanges_issued() == 2
 
 
-def _replica_check(nk, tdev, ranks, build, seed=1.0, parts=None):
+def _replica_check(nk, tdev, ranks, build, seed=1.0, parts=None, channels=0, gbps=0.0):
     """Run `build()`'s loss once plainly and once through GradientSync over a replica communicator of `ranks` virtual
     ranks that all hold this rank's values: every element of every registered gradient must come back multiplied by
     `ranks` exactly once - an element skipped, sent twice or sent before its last writer ran shows up as a mismatch
@@ -909,7 +909,7 @@ def _replica_check(nk, tdev, ranks, build, seed=1.0, parts=None):
     loss, params = build()
     loss.forward(); loss.backward(seed)
     want = [p.grad().copy() for p in params]
-    comm = nk.dp.Communicator.replicas(tdev, ranks)
+    comm = nk.dp.Communicator.replicas(tdev, ranks, channels, gbps)
     assert comm.size == ranks
     sync = nk.dp.GradientSync(comm, params)
     if parts is not None:
@@ -946,17 +946,16 @@ def test_gradient_sync_covers_every_element_once(nk, tdev, ranks, parts, launche
 
 
 @pytest.mark.gpu
-def test_paced_replica_exchange_covers_every_element_once(nk, tdev, monkeypatch):
-    """The overlap projection's stand-in (NK_REPLICA_CHANNELS workgroups pacing their pass to NK_REPLICA_GBPS,
-    benchmarks/overlap_projection.py) is the same coverage-checked exchange: odd sizes, tails that are not whole float4s."""
-    monkeypatch.setenv("NK_REPLICA_CHANNELS", "3")
-    monkeypatch.setenv("NK_REPLICA_GBPS", "50")
+def test_paced_replica_exchange_covers_every_element_once(nk, tdev):
+    """The overlap projection's stand-in (`channels` workgroups pacing their pass to `gbps`, benchmarks/overlap_projection.py)
+    is the same coverage-checked exchange: odd sizes, tails that are not whole float4s, buffers that are only 4-byte aligned
+    (row-block pieces of a weight gradient with an odd row length fall back to the unpaced kernel)."""
 
     def ragged():
         l1, l2 = nk.nn.Linear(tdev, 301, 703, 1), nk.nn.Linear(tdev, 703, 129, 2)
         loss = l2.forward(l1.forward(nk.rand(tdev, [37, 301], 3)).relu()).sum()
         return loss, [l1.weight, l1.bias, l2.weight, l2.bias]
-    _replica_check(nk, tdev, 4, ragged)
+    _replica_check(nk, tdev, 4, ragged, channels=3, gbps=50.0)
 
 
 @pytest.mark.gpu

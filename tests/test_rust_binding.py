@@ -185,3 +185,225 @@ def test_every_hot_path_entry_point_is_reachable_from_a_variable_method():
     # the dropout nodes advance the Philox offset by the calls one forward consumes: ceil(n / 8)
     assert "+ 7) / 8" in open(os.path.join(HIP, "node", "pointwise.rs")).read()
     assert "+ 7) / 8" in open(os.path.join(HIP, "node", "attention.rs")).read()
+
+
+# ---- static checks a never-compiled crate needs ---------------------------------------------------
+INTEGRATION = os.path.join(ROOT, "integration")
+NN = os.path.join(INTEGRATION, "neuronika-nn", "src", "hip.rs")
+
+
+def _rust_files():
+    out = []
+    for dp, _, fs in os.walk(INTEGRATION):
+        out += [os.path.join(dp, f) for f in fs if f.endswith(".rs")]
+    return sorted(out)
+
+
+def _strip(src):
+    """Source without comments, string literals and char literals (lifetimes survive: they contain no delimiters)."""
+    src = re.sub(r"//[^\n]*", "", src)
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r'"(?:\\.|[^"\\])*"', '""', src, flags=re.S)
+    src = re.sub(r"'(?:\\.|[^\\'])'", "' '", src)
+    return src
+
+
+def test_rust_sources_have_balanced_delimiters():
+    files = _rust_files()
+    assert len(files) >= 18
+    pairs = {")": "(", "]": "[", "}": "{"}
+    for path in files:
+        stack = []
+        for n, line in enumerate(_strip(open(path).read()).split("\n"), 1):
+            for ch in line:
+                if ch in "([{":
+                    stack.append((ch, n))
+                elif ch in ")]}":
+                    assert stack and stack[-1][0] == pairs[ch], (path, n, ch, stack[-1:] if stack else None)
+                    stack.pop()
+        assert not stack, (path, stack[-1])
+
+
+def _items(path):
+    """Names a Rust file defines or re-exports at any visibility: struct / enum / trait / fn / type / mod / macro + `pub use` leaves."""
+    src = _strip(open(path).read())
+    names = set(re.findall(r"\b(?:struct|enum|trait|fn|type|mod|union)\s+(\w+)", src))
+    names |= set(re.findall(r"macro_rules!\s*(\w+)", src))
+    for m in re.finditer(r"pub(?:\([^)]*\))?\s+use\s+([^;]+);", src, re.S):
+        names |= set(re.findall(r"(\w+)\s*(?:,|\}|$)", m.group(1)))
+        g = re.match(r"\s*(\w+)::\*\s*$", m.group(1))            # glob re-export of a sibling module: its items too
+        if g:
+            sub = _module_file(os.path.dirname(path), g.group(1))
+            if sub:
+                names |= _items(sub)
+    return names
+
+
+def _module_file(base_dir, name):
+    for cand in (os.path.join(base_dir, name + ".rs"), os.path.join(base_dir, name, "mod.rs")):
+        if os.path.exists(cand):
+            return cand
+    return None
+
+
+def _use_leaves(tree):
+    """`a::b::{c, d::{e, f}, g as h}` -> [[a, b, c], [a, b, d, e], [a, b, d, f], [a, b, g]]."""
+    tree = tree.strip()
+    m = re.match(r"^([\w:]*?)(?:::)?\{(.*)\}$", tree, re.S)
+    if not m:
+        return [[p for p in re.sub(r"\s+as\s+\w+", "", tree).split("::") if p]]
+    prefix = [p for p in m.group(1).split("::") if p]
+    parts, depth, cur = [], 0, ""
+    for ch in m.group(2):
+        if ch == "{":
+            depth += 1
+        elif ch == "}":
+            depth -= 1
+        if ch == "," and depth == 0:
+            parts.append(cur); cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        parts.append(cur)
+    out = []
+    for part in parts:
+        for leaf in _use_leaves(part):
+            out.append(prefix + leaf)
+    return out
+
+
+def test_rust_use_paths_resolve_inside_the_integration_tree():
+    """Every `use` of an item that lives in THIS tree (`super::`, `crate::hip::`, `neuronika_variable::hip::`) names a module
+    file that exists and an item that file defines or re-exports.  Paths into the reference crate (`crate::autograd`,
+    `crate::gradient`, `crate::utils`, ...) and into external crates are checked against a list of the names they are known
+    to export (read off /root/reference when this test was written)."""
+    hip_mod = os.path.join(HIP, "mod.rs")
+    reference = {"autograd": {"Backward", "Forward"}, "gradient": {"Gradient", "NoGrad"}, "history": {"History"},
+                 "utils": {"check_conv_args", "check_groups_args", "cobroadcast", "conv_out_shape", "Broadcast", "Shared"}}
+    checked = 0
+    for path in _rust_files():
+        if os.path.basename(path) in ("autograd_hip_ext.rs", "gradient_hip_impls.rs", "build.rs"):
+            continue
+        here = os.path.dirname(path)
+        src = _strip(open(path).read())
+        for m in re.finditer(r"^\s*(?:pub(?:\([^)]*\))?\s+)?use\s+([^;]+);", src, re.M | re.S):
+            for leaf in _use_leaves(re.sub(r"\s+", " ", m.group(1))):
+                if leaf[0] == "neuronika_variable" and leaf[1] == "hip":
+                    base, rest = HIP, leaf[2:]
+                    assert rest and rest[0] in _items(hip_mod), (path, leaf)
+                    checked += 1
+                    continue
+                if leaf[0] == "crate" and len(leaf) > 1 and leaf[1] == "hip":
+                    base, rest = HIP, leaf[2:]
+                elif leaf[0] == "super":
+                    base = here if os.path.basename(path) != "mod.rs" else os.path.dirname(here)
+                    base = os.path.dirname(path) if os.path.basename(path) != "mod.rs" else os.path.dirname(os.path.dirname(path))
+                    rest = leaf[1:]
+                    if os.path.basename(path) != "mod.rs":
+                        # `super` of hip/node/x.rs is hip/node/mod.rs; of hip/x.rs it is hip/mod.rs
+                        if len(rest) == 1:
+                            assert rest[0] in _items(os.path.join(os.path.dirname(path), "mod.rs")), (path, leaf)
+                            checked += 1
+                            continue
+                        base = os.path.dirname(path)
+                elif leaf[0] == "crate" and len(leaf) > 2 and leaf[1] in reference:
+                    assert leaf[2] in reference[leaf[1]], (path, leaf)
+                    checked += 1
+                    continue
+                else:
+                    continue                                    # std, ndarray, rand, crate::Reduction, ...
+                if not rest:
+                    continue
+                # walk module components, the last one is the item
+                cur = base
+                for comp in rest[:-1]:
+                    f = _module_file(cur, comp)
+                    assert f, (path, leaf, comp)
+                    cur = os.path.join(cur, comp) if os.path.isdir(os.path.join(cur, comp)) else cur
+                    last_file = f
+                if len(rest) == 1:
+                    f = _module_file(cur, rest[0])
+                    assert f or rest[0] in _items(os.path.join(cur, "mod.rs")), (path, leaf)
+                else:
+                    assert rest[-1] in _items(last_file) or rest[-1] == "*", (path, leaf)
+                checked += 1
+    assert checked >= 40, checked
+
+
+def _pub_methods(path):
+    """method name -> parameter count (without self) of every `pub fn` / `pub(crate) fn` in a file."""
+    src = _strip(open(path).read())
+    out = {}
+    for m in re.finditer(r"pub(?:\(crate\))?\s+fn\s+(\w+)(?:<[^(]*>)?\(", src):
+        i, depth = m.end(), 1
+        while depth:
+            depth += {"(": 1, ")": -1}.get(src[i], 0)
+            i += 1
+        params = src[m.end():i - 1]
+        n = _rust_params(params)
+        if re.match(r"\s*(?:mut\s+)?&?\s*(?:mut\s+)?self\b", params):
+            n -= 1
+        out.setdefault(m.group(1), set()).add(n)
+    return out
+
+
+def test_nn_layers_exist_and_call_variable_methods_that_exist():
+    """`neuronika_nn::hip`: every layer `north_star` names is a struct with the reference's fields, a `new` in the reference's
+    argument order (+ device) and a `forward`; every method the layers call on a device variable exists in hipvar.rs with
+    that many arguments."""
+    src = _strip(open(NN).read())
+    for layer in ("Linear", "Dropout", "MultiheadAttention"):
+        assert re.search(r"pub struct %s\b" % layer, src), layer
+        body = src[src.index("impl %s" % layer):]
+        assert "pub fn new(" in body and "pub fn forward" in body, layer
+    conv = re.findall(r"conv_layer!\((\w+), (\w+),", src)
+    assert conv == [("Conv1d", "GroupedConv1d"), ("Conv2d", "GroupedConv2d"), ("Conv3d", "GroupedConv3d")]
+    macro = src[src.index("macro_rules! conv_layer"):src.index("conv_layer!(Conv1d")]
+    for field in ("padding", "padding_mode", "stride", "dilation", "weight", "bias"):          # neuronika-nn/src/lib.rs:633-642
+        assert re.search(r"pub %s:" % field, macro), field
+    assert re.search(r"pub groups: usize", macro)
+    order = re.search(r"pub fn new\(in_channels: usize, out_channels: usize, kernel_size: \$size, padding: \$size, padding_mode: PaddingMode,\s*"
+                      r"stride: \$size, dilation: \$size, device: &Device\)", macro)
+    assert order, "Conv*::new argument order (neuronika-nn/src/lib.rs:671-679)"
+    assert re.search(r"pub weight: HipVarDiff<Ix2>,\s*pub bias: HipVarDiff<Ix1>", src)             # Linear fields, :406-409
+    methods = _pub_methods(os.path.join(HIP, "hipvar.rs"))
+    used = {"mm_t": 1, "mm_t_diff": 1, "pad": 2, "convolution": 4, "dropout": 2, "heads_attention": 9, "shape": 0, "parameter": 2}
+    for name, nargs in used.items():
+        assert re.search(r"[.:]%s\(" % name, src), name
+        assert name in methods and nargs in methods[name], (name, methods.get(name))
+    # call sites pass that many arguments
+    for m in re.finditer(r"\.(mm_t|mm_t_diff|pad|convolution|dropout|heads_attention)\(", src):
+        i, depth = m.end(), 1
+        while depth:
+            depth += {"(": 1, ")": -1}.get(src[i], 0)
+            i += 1
+        assert _top_level_args(src[m.end():i - 1]) == used[m.group(1)], m.group(1)
+
+
+def test_backward_sync_overlaps_the_exchange():
+    """Every device backward node names the gradients it writes (`targets`), `backward_sync` derives the last writer from
+    them and hands the gradient over (`grad_ready`) right after issuing that node - the overlapped exchange `north_star` asks
+    for, as `VarDiff::run_backward` in host/neuronika.cpp."""
+    node_dir = os.path.join(HIP, "node")
+    n_impl = n_targets = 0
+    for f in sorted(os.listdir(node_dir)):
+        src = _strip(open(os.path.join(node_dir, f)).read())
+        for m in re.finditer(r"impl(?:<[^{]*?>)? Backward for (\w+)", src):
+            b = src.index("{", m.end())
+            i, depth = b + 1, 1
+            while depth:
+                depth += {"{": 1, "}": -1}.get(src[i], 0)
+                i += 1
+            n_impl += 1
+            assert "fn targets(&self) -> Vec<usize>" in src[b:i], (f, m.group(1))
+            n_targets += 1
+    assert n_impl == n_targets >= 20
+    hv = _strip(open(os.path.join(HIP, "hipvar.rs")).read())
+    body = hv[hv.index("pub fn backward_sync("):]
+    body = body[:body.index("\n    }\n") + 7]
+    assert "op.targets()" in body and "sync.grad_ready(" in body and "last_writer" in body and ".rev()" in body
+    assert body.index("op.backward()") < body.index("sync.grad_ready(")           # issued first, handed over right after
+    ext = open(os.path.join(INTEGRATION, "neuronika-variable", "src", "autograd_hip_ext.rs")).read()
+    assert "fn targets(&self) -> Vec<usize>" in ext and "Vec::new()" in ext       # defaulted: CPU nodes compile unchanged
+    dp = _strip(open(os.path.join(HIP, "dp.rs")).read())
+    assert "pub(crate) fn bucket_of(" in dp and "pub struct SyncEntry" in dp

@@ -1,0 +1,46 @@
+#!/bin/bash
+# The first thing to run when a multi-GPU MI355X node is available (no round of this build has had one): the 2-rank parity
+# tests of the product path, then the weak-scaling bench at 2 / 4 / 8 GPUs, everything a post-mortem needs in one tarball.
+#     bash tools/first_multi_gpu.sh [OUTDIR]          (about 5 minutes on an 8-GPU node)
+# bench.py --gpus N spawns its own N ranks (one process per GPU, RCCL over xGMI, rendezvous on 127.0.0.1) and prints one JSON
+# line per run with per-rank device times, the stand-alone all-reduce, exposed communication and what RCCL chose.
+set -u
+root=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+out=${1:-$root/gpurun_out/first_multi_gpu}
+mkdir -p "$out"
+cd "$root"
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+ngpu=$(python -c "from neuronika_amd import capi; print(capi.device_count())")
+echo "GPUs visible: $ngpu" | tee "$out/summary.txt"
+rocm-smi --showtopo > "$out/topology.txt" 2>&1
+python -c "import __graft_entry__ as g; g.build()" > "$out/build.log" 2>&1 || { echo "build failed" | tee -a "$out/summary.txt"; }
+timeout -k 10 600 python -m pytest tests/test_gpu_multi.py -x -q > "$out/pytest_multi.log" 2>&1
+echo "pytest tests/test_gpu_multi.py rc=$?  $(tail -1 "$out/pytest_multi.log")" | tee -a "$out/summary.txt"
+for n in 1 2 4 8; do
+  [ "$n" -gt "$ngpu" ] && break
+  NCCL_DEBUG=INFO NCCL_DEBUG_FILE="$out/rccl_n${n}_%h_%p.log" timeout -k 10 600 python bench.py --gpus $n --steps 50 --warmup 5 \
+      > "$out/bench_n$n.json" 2> "$out/bench_n$n.err"
+  echo "bench --gpus $n rc=$?" | tee -a "$out/summary.txt"
+  python - "$out/bench_n$n.json" <<'P' | tee -a "$out/summary.txt"
+import json, sys
+try:
+    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    print("   ", d["n_gpus"], "GPUs:", d["value"], d["unit"], d["ms_per_step"], "ms/step, exposed comm", d.get("exposed_comm_ms"),
+          "ms, all-reduce alone", (d.get("allreduce_alone") or {}).get("ms"), "ms", (d.get("allreduce_alone") or {}).get("algbw_GBps"), "GB/s")
+except Exception as e:
+    print("    no record:", e)
+P
+done
+python - "$out" <<'P' | tee -a "$out/summary.txt"
+import json, os, sys
+vals = {}
+for n in (1, 2, 4, 8):
+    try:
+        vals[n] = json.loads(open(os.path.join(sys.argv[1], f"bench_n{n}.json")).read().strip().splitlines()[-1])["value"]
+    except Exception:
+        pass
+if 1 in vals:
+    for n, v in sorted(vals.items()):
+        print(f"weak-scaling efficiency at {n}: {v / (n * vals[1]):.3f}")
+P
+tar czf "$out.tgz" -C "$(dirname "$out")" "$(basename "$out")" && echo "wrote $out.tgz"
