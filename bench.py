@@ -405,6 +405,8 @@ def measure_mha(dist, tdev, cdev, steps, warmup):
         mha.strided_heads = os.environ["NK_MHA_STRIDED"] == "1"
     if "NK_MHA_CORE" in os.environ:                  # A/B aid: fused attention kernels (1) or GEMM -> row kernel -> GEMM (0)
         mha.fused_core = os.environ["NK_MHA_CORE"] == "1"
+    if os.environ.get("NK_BENCH_UNPACKED_QKV") == "1":   # A/B aid: three projection GEMMs each way instead of the packed one
+        mha.packed_qkv = False
     X = t.from_ndarray(tdev, np.random.default_rng(0).random((B * S, d), dtype=np.float32)).requires_grad()
     G = t.from_ndarray(tdev, np.random.default_rng(5).random((B * S, d), dtype=np.float32))
     y = mha.forward(X, B)

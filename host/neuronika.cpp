@@ -84,7 +84,13 @@ HipArray::HipArray(DevicePtr dev, Shape shape)
     : dev_(std::move(dev)), shape_(std::move(shape)), len_(numel(shape_)), ptr_(dev_->alloc_zeroed(len_)) {}
 HipArray::HipArray(DevicePtr dev, Shape shape, Uninit)
     : dev_(std::move(dev)), shape_(std::move(shape)), len_(numel(shape_)), ptr_(dev_->alloc_uninit(len_)) {}
-HipArray::~HipArray() { dev_->release(ptr_, len_); }
+HipArray::HipArray(std::shared_ptr<HipArray> parent, size_t offset, Shape shape)
+    : dev_(parent->device()), shape_(std::move(shape)), len_(numel(shape_)), ptr_(parent->ptr() + offset), parent_(std::move(parent)) {
+    if (offset + len_ > parent_->len()) panic("HipArray view: out of the parent's range");
+}
+HipArray::~HipArray() {
+    if (!parent_) dev_->release(ptr_, len_);
+}
 std::shared_ptr<HipArray> HipArray::from_host(DevicePtr dev, const Shape& shape, const float* host) {
     auto a = std::make_shared<HipArray>(std::move(dev), shape);
     a->upload(host);
@@ -101,6 +107,9 @@ void HipArray::fill(float v) { check(nk_fill(dev_->raw(), ptr_, len_, v)); }
 
 Gradient::Gradient(DevicePtr dev, Shape shape)
     : dev_(std::move(dev)), shape_(std::move(shape)), array_(std::make_shared<HipArray>(dev_, shape_, HipArray::Uninit{})) {}
+Gradient::Gradient(Shared<HipArray> storage, size_t offset, Shape shape)
+    : dev_(storage->device()), shape_(std::move(shape)), array_(std::make_shared<HipArray>(storage, offset, shape_)), storage_(std::move(storage)),
+      offset_(offset) {}
 HipArray& Gradient::borrow() const {
     if (!array_)
         panic("Trying to get a de-allocated gradient. Switch on the gradients first by using `.with_grad()`");
@@ -132,7 +141,7 @@ void Gradient::zero() {
 void Gradient::no_grad() { array_.reset(); }
 void Gradient::with_grad() {
     if (!array_) {
-        array_ = std::make_shared<HipArray>(dev_, shape_, HipArray::Uninit{});
+        array_ = storage_ ? std::make_shared<HipArray>(storage_, offset_, shape_) : std::make_shared<HipArray>(dev_, shape_, HipArray::Uninit{});
         pending_zero_ = true;
     }
 }
@@ -772,6 +781,76 @@ struct HeadsAttentionBwd : Backward {
     }
     void targets(std::vector<const Gradient*>& out) const override {
         out.push_back(dq.get()); out.push_back(dk.get()); out.push_back(dv.get());
+    }
+};
+
+// nn::MultiheadAttention with PACKED projections: x -> [Q | K | V] = x . [Wq; Wk; Wv]^T + [bq; bk; bv] (ONE GEMM, N = 3d) -> the
+// fused attention core reading Q, K, V as column blocks of that output -> context.  One forward and one backward node for what
+// the unpacked module runs as three Linear nodes + the attention node (same values bit for bit in the forward; the backward's
+// input gradient is one K = 3d chain instead of three K = d chains added up).
+struct QkvAttentionFwd : Forward {
+    HeadsGeom hg;
+    Shared<HipArray> x, w, b, qkv, scores, stats, mask, o;  // w (3d, d), b (3d): the packed storage; qkv (B*S, 3d)
+    float scale;
+    double p;
+    Shared<bool> status;
+    uint64_t seed;
+    Shared<uint64_t> calls;
+    void forward() const override {
+        const int n = hg.B * hg.S, d = hg.d();
+        check(nk_linear_fwd(D(x), x->ptr(), w->ptr(), b->ptr(), qkv->ptr(), n, d, 3 * d));
+        const uint64_t sp = ((uint64_t)hg.S + 31) / 32 * 32;
+        const uint64_t offset = (*calls) * (((uint64_t)hg.B * hg.H * sp * sp + 7) / 8);
+        check(nk_attention_qkv_fwd(D(x), qkv->ptr(), scores ? scores->ptr() : nullptr, stats ? stats->ptr() : nullptr,
+                                   mask ? reinterpret_cast<uint32_t*>(mask->ptr()) : nullptr, o->ptr(), hg.B, hg.S, hg.H, hg.dh, scale, p,
+                                   *status ? 1 : 0, seed, offset));
+        ++(*calls);
+    }
+};
+struct QkvAttentionBwd : Backward {
+    HeadsGeom hg;
+    Shared<HipArray> x, w, qkv, scores, stats, mask, o;
+    Shared<HipArray> dqkv, ds, dropped;  // scratch owned by the node: (B*S, 3d) and two (B*H, SP, SP)
+    Shared<HipArray> gw_all, gb_all;     // packed gradient storage: (3d, d), (3d)
+    Shared<Gradient> dx, gw[3], gb[3], g;  // dx null for a non-differentiable input; gw / gb: views of gw_all / gb_all
+    float scale;
+    double p;
+    Shared<bool> status;
+    // the three views are written by ONE kernel: it may assign only when all three still wait for their zero fill
+    static float packed_beta(const Shared<Gradient> (&v)[3]) {
+        bool all = true;
+        for (const auto& q : v) all = all && q->zero_pending();
+        bool assign = false;
+        for (const auto& q : v) {
+            if (all) (void)q->borrow_first_write(assign);  // hands the pending fill to the kernel below (beta = 0)
+            else (void)q->borrow();                        // materialises a pending view, the kernel accumulates
+        }
+        return all ? 0.f : 1.f;
+    }
+    void backward() const override {
+        const HipArray& G = g->borrow();  // dO (B*S, d)
+        nk_device* dev = D(x);
+        const int n = hg.B * hg.S, d = hg.d();
+        check(nk_attention_qkv_bwd(dev, dqkv->ptr(), ds->ptr(), dropped->ptr(), G.ptr(), o->ptr(), scores->ptr(), stats->ptr(),
+                                   reinterpret_cast<const uint32_t*>(mask->ptr()), qkv->ptr(), hg.B, hg.S, hg.H, hg.dh, scale, p,
+                                   *status ? 1 : 0, 1));
+        float beta;
+        if (dx) {  // dX (+)= [dQ | dK | dV] . [Wq; Wk; Wv]: one NN product, K = 3d
+            float* q = first_write(dx, beta);
+            check(nk_sgemm(dev, 0, 0, n, d, 3 * d, 1.f, dqkv->ptr(), 3 * d, w->ptr(), d, beta, q, d));
+        }
+        {
+            const int gs[2] = {n, 3 * d}, o3 = 3 * d;
+            const bool assign = packed_beta(gb) == 0.f;
+            check((assign ? nk_unbroadcast_assign : nk_unbroadcast_add)(dev, gb_all->ptr(), &o3, 1, dqkv->ptr(), gs, 2));
+        }
+        beta = packed_beta(gw);  // [dWq; dWk; dWv] (+)= [dQ | dK | dV]^T . x: one TN product, M = 3d
+        check(nk_sgemm(dev, 1, 0, 3 * d, d, n, 1.f, dqkv->ptr(), 3 * d, x->ptr(), d, beta, gw_all->ptr(), d));
+    }
+    void targets(std::vector<const Gradient*>& out) const override {
+        if (dx) out.push_back(dx.get());
+        for (const auto& q : gw) out.push_back(q.get());
+        for (const auto& q : gb) out.push_back(q.get());
     }
 };
 
@@ -1858,15 +1937,74 @@ VarDiff ConvNd::forward(const VarDiff& input) const {
     return conv_diff(weight, padded.var, padded.grad, &padded.history, stride, dilation, groups, &bias);
 }
 
+// a Linear whose weight / bias (and their gradients) are rows [row0, row0 + d) of the packed storage, initialised as
+// `Linear(dev, d, d, seed)` would be
+static Linear packed_linear(const Shared<HipArray>& w_all, const Shared<HipArray>& b_all, const Shared<HipArray>& gw_all,
+                            const Shared<HipArray>& gb_all, int row0, int d, uint64_t seed) {
+    const float k = 1.f / std::sqrt((float)d);
+    auto w = std::make_shared<HipArray>(w_all, (size_t)row0 * d, Shape{d, d});
+    auto b = std::make_shared<HipArray>(b_all, (size_t)row0, Shape{d});
+    w->upload(uniform((size_t)d * d, -k, k, seed).data());
+    b->upload(uniform((size_t)d, -k, k, seed + 1).data());
+    return Linear(VarDiff::leaf(Var::leaf(w), std::make_shared<Gradient>(gw_all, (size_t)row0 * d, Shape{d, d})),
+                  VarDiff::leaf(Var::leaf(b), std::make_shared<Gradient>(gb_all, (size_t)row0, Shape{d})));
+}
+static Linear placeholder_linear(const DevicePtr& dev) { return Linear(zeros(dev, {1, 1}).requires_grad(), zeros(dev, {1}).requires_grad()); }
 MultiheadAttention::MultiheadAttention(DevicePtr dev, int d_model_, int heads_, double p, uint64_t seed)
-    : q(dev, d_model_, d_model_, seed), k(dev, d_model_, d_model_, seed + 2), v(dev, d_model_, d_model_, seed + 4),
-      o(dev, d_model_, d_model_, seed + 6), d_model(d_model_), heads(heads_), drop(p) {
+    : q(placeholder_linear(dev)), k(placeholder_linear(dev)), v(placeholder_linear(dev)), o(dev, d_model_, d_model_, seed + 6),
+      d_model(d_model_), heads(heads_), drop(p) {
     if (d_model % heads != 0) panic("d_model must be divisible by heads");
+    wqkv_ = std::make_shared<HipArray>(dev, Shape{3 * d_model, d_model});
+    bqkv_ = std::make_shared<HipArray>(dev, Shape{3 * d_model});
+    gwqkv_ = std::make_shared<HipArray>(dev, Shape{3 * d_model, d_model}, HipArray::Uninit{});
+    gbqkv_ = std::make_shared<HipArray>(dev, Shape{3 * d_model}, HipArray::Uninit{});
+    q = packed_linear(wqkv_, bqkv_, gwqkv_, gbqkv_, 0, d_model, seed);
+    k = packed_linear(wqkv_, bqkv_, gwqkv_, gbqkv_, d_model, d_model, seed + 2);
+    v = packed_linear(wqkv_, bqkv_, gwqkv_, gbqkv_, 2 * d_model, d_model, seed + 4);
+}
+MultiheadAttention::MultiheadAttention(Linear q_, Linear k_, Linear v_, Linear o_, int heads_, double p)
+    : q(std::move(q_)), k(std::move(k_)), v(std::move(v_)), o(std::move(o_)), d_model(q.weight.shape()[1]), heads(heads_), drop(p) {
+    if (d_model % heads != 0) panic("d_model must be divisible by heads");
+    packed_qkv = false;
+}
+static VarDiff qkv_attention_node(const MultiheadAttention& m, const Shared<HipArray>& w, const Shared<HipArray>& b, const Shared<HipArray>& gw,
+                                  const Shared<HipArray>& gb, const VarDiff& x, int B, int S, int H, int dh, float scale) {
+    const int d = H * dh;
+    History<ForwardEntry> hf = x.var.history;
+    for (const Linear* l : {&m.q, &m.k, &m.v}) { hf.merge(l->weight.var.history); hf.merge(l->bias.var.history); }
+    auto fw = std::make_shared<QkvAttentionFwd>();
+    fw->hg = {B, S, H, dh}; fw->x = x.var.data; fw->w = w; fw->b = b;
+    fw->qkv = zeros_like(x.var.data, Shape{B * S, 3 * d});
+    const int SP = (S + 31) / 32 * 32;
+    fw->scores = zeros_like(x.var.data, Shape{B * H, SP, SP});
+    fw->stats = zeros_like(x.var.data, Shape{B * H, SP, 2});
+    fw->mask = zeros_like(x.var.data, Shape{B * H, SP, SP / 32});
+    fw->o = zeros_like(x.var.data, Shape{B * S, d});
+    fw->scale = scale; fw->p = m.drop.p; fw->status = m.drop.status;
+    fw->seed = next_node_seed();
+    fw->calls = std::make_shared<uint64_t>(0);
+    Var out = Var::node(fw->o, fw, std::move(hf));
+    History<BackwardEntry> hb = x.history;
+    for (const Linear* l : {&m.q, &m.k, &m.v}) { hb.merge(l->weight.history); hb.merge(l->bias.history); }
+    auto g = std::make_shared<Gradient>(out.device(), out.shape());
+    auto bw = std::make_shared<QkvAttentionBwd>();
+    bw->hg = fw->hg; bw->x = fw->x; bw->w = w; bw->qkv = fw->qkv; bw->scores = fw->scores; bw->stats = fw->stats; bw->mask = fw->mask; bw->o = fw->o;
+    bw->dqkv = zeros_like(fw->qkv, fw->qkv->shape());
+    bw->ds = zeros_like(fw->scores, fw->scores->shape());
+    bw->dropped = zeros_like(fw->scores, fw->scores->shape());
+    bw->gw_all = gw; bw->gb_all = gb;
+    bw->dx = x.grad;
+    const Linear* ls[3] = {&m.q, &m.k, &m.v};
+    for (int i = 0; i < 3; ++i) { bw->gw[i] = ls[i]->weight.grad; bw->gb[i] = ls[i]->bias.grad; }
+    bw->g = g; bw->scale = scale; bw->p = m.drop.p; bw->status = m.drop.status;
+    return VarDiff::node(std::move(out), g, entry(bw, g), std::move(hb));
 }
 VarDiff MultiheadAttention::forward(const VarDiff& x, int batch) const {
     const int rows = x.shape()[0], S = rows / batch, dh = d_model / heads;
     if (rows % batch != 0 || x.shape()[1] != d_model) panic("MultiheadAttention: bad input shape");
     const float scale = 1.f / std::sqrt((float)dh);
+    if (packed_qkv && wqkv_ && strided_heads && fused && fused_core && q.fused && k.fused && v.fused && Var::attention_core_supported(S, dh, drop.p))
+        return o.forward(qkv_attention_node(*this, wqkv_, bqkv_, gwqkv_, gbqkv_, x, batch, S, heads, dh, scale));
     if (strided_heads && dh % 4 == 0) {  // attention GEMMs address the heads inside the projection layout: no copies
         const VarDiff Qf = q.forward(x), Kf = k.forward(x), Vf = v.forward(x);
         if (fused && fused_core && Var::attention_core_supported(S, dh, drop.p))

@@ -97,6 +97,9 @@ class HipArray {
     HipArray(DevicePtr dev, Shape shape);  // `CuArray::zeroed`
     struct Uninit {};
     HipArray(DevicePtr dev, Shape shape, Uninit);  // undefined contents
+    // `shape` elements of `parent` starting `offset` elements in: shares the parent's buffer and keeps it alive (the packed
+    // projection weights of nn::MultiheadAttention: three parameters, one allocation)
+    HipArray(std::shared_ptr<HipArray> parent, size_t offset, Shape shape);
     ~HipArray();
     HipArray(const HipArray&) = delete;
     HipArray& operator=(const HipArray&) = delete;
@@ -116,6 +119,7 @@ class HipArray {
     Shape shape_;
     size_t len_;
     float* ptr_;
+    std::shared_ptr<HipArray> parent_;  // set for a view: the buffer belongs to the parent
 };
 template <class T>
 using Shared = std::shared_ptr<T>;  // utils.rs:9  `Shared<T> = Rc<RefCell<T>>`
@@ -166,6 +170,9 @@ class Gradient : public NoGrad {
     // zeros first; `borrow_first_write(assign)` hands a pending fill to a node that can ASSIGN instead of `+=`
     // (`0 + v`, same values, no memset and no read of the destination).
     Gradient(DevicePtr dev, Shape shape);
+    // A gradient whose buffer is `shape` elements of `storage` starting at `offset` (packed parameters: the gradients of
+    // several parameters in one allocation, so that ONE GEMM can write them all).  Same lazy zero fill, per view.
+    Gradient(Shared<HipArray> storage, size_t offset, Shape shape);
     HipArray& borrow() const;              // panics when de-allocated
     HipArray& borrow_first_write(bool& assign) const;
     void zero();                           // `zero_grad` (vardiff.rs:100-102), lazily
@@ -194,6 +201,8 @@ class Gradient : public NoGrad {
     mutable bool pending_zero_ = true;
     Shared<HipArray> premask_src_;
     mutable bool premasked_ = false;
+    Shared<HipArray> storage_;  // set for a view gradient
+    size_t offset_ = 0;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -589,8 +598,19 @@ struct MultiheadAttention {
     bool fused = true;  // scale + softmax + dropout as one node (false: three reference nodes)
     bool strided_heads = true;  // attention GEMMs read Q/K/V and write O in the projection layout (false: split/merge copies)
     bool fused_core = true;     // scores -> probabilities -> context as one node on the fused attention kernels (dh in {32, 64, 128}, any S)
+    // The three projection weights (and biases, and their gradients) are views of ONE (3*d_model, d_model) allocation, rows
+    // [Wq; Wk; Wv]: with `packed_qkv` the projections run as one GEMM with N = 3*d_model, their input gradient as one GEMM
+    // with K = 3*d_model, the weight gradients as one GEMM with M = 3*d_model, and the fused attention kernels read Q, K, V
+    // as column blocks of the packed output (`nk_attention_qkv_*`).  q / k / v stay ordinary `Linear`s over those views
+    // (optimizers, serde and the data-parallel exchange see three parameters as before).  false: three Linear nodes.
+    bool packed_qkv = true;
     MultiheadAttention(DevicePtr dev, int d_model, int heads, double p, uint64_t seed);
+    // four Linear layers built elsewhere (e.g. deserialised): their weights are NOT packed, `packed_qkv` is off
+    MultiheadAttention(Linear q, Linear k, Linear v, Linear o, int heads, double p);
     VarDiff forward(const VarDiff& x, int batch) const;  // x: (batch*seq, d_model)
+
+   private:
+    Shared<HipArray> wqkv_, bqkv_, gwqkv_, gbqkv_;  // packed storage (null when the layers were handed in)
 };
 
 }  // namespace nn

@@ -326,6 +326,7 @@ PYBIND11_MODULE(_tape, m) {
         .def_readwrite("fused", &nn::MultiheadAttention::fused)
         .def_readwrite("strided_heads", &nn::MultiheadAttention::strided_heads)
         .def_readwrite("fused_core", &nn::MultiheadAttention::fused_core)
+        .def_readwrite("packed_qkv", &nn::MultiheadAttention::packed_qkv)
         .def("forward", &nn::MultiheadAttention::forward);
 
     py::module_ optim = m.def_submodule("optim");

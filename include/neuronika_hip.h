@@ -457,6 +457,15 @@ int nk_attention_bwd(nk_device* dev, float* dQ, float* dK, float* dV, float* dS,
                      const float* O, const float* scores, const float* stats, const uint32_t* mask_bits, const float* Q,
                      const float* K, const float* V, int B, int S, int H, int dh, float scale, double p, int train,
                      int assign_dq, int assign_dk, int assign_dv);
+/* The same two entry points for Q, K, V (and dQ, dK, dV) that are the three column blocks of ONE (B*S, 3*H*dh) matrix - the
+ * output of a single Linear over the row-stacked projection weights [Wq; Wk; Wv] (`nn::MultiheadAttention`'s packed
+ * projections: one GEMM with N = 3*H*dh forward, one with K = 3*H*dh for the input gradient, instead of three each).  Row
+ * stride 3*H*dh, column offsets 0, H*dh, 2*H*dh; everything else as above.  `assign`: dQKV is a fresh gradient. */
+int nk_attention_qkv_fwd(nk_device* dev, const float* QKV, float* scores, float* stats, uint32_t* mask_bits, float* O, int B, int S,
+                         int H, int dh, float scale, double p, int train, uint64_t seed, uint64_t offset);
+int nk_attention_qkv_bwd(nk_device* dev, float* dQKV, float* dS, float* dropped, const float* dO, const float* O, const float* scores,
+                         const float* stats, const uint32_t* mask_bits, const float* QKV, int B, int S, int H, int dh, float scale,
+                         double p, int train, int assign);
 /* ------------------------------------------------------------------ dropout ------------ */
 /* Dropout::forward node/dropout/mod.rs:53-79.  train && 0<p<1: noise ~ Bernoulli(1-p) in
  * {0,1} is (re)drawn from Philox4x32-10(seed, offset) and written to `noise` (f32, like the

@@ -152,6 +152,8 @@ _SIGS = {
     "nk_attention_fwd": [VP, VP, VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_double, C.c_int, C.c_uint64, C.c_uint64],
     "nk_attention_bwd": [VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_double,
                          C.c_int, C.c_int, C.c_int, C.c_int],
+    "nk_attention_qkv_fwd": [VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_double, C.c_int, C.c_uint64, C.c_uint64],
+    "nk_attention_qkv_bwd": [VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_double, C.c_int, C.c_int],
     "nk_scale_softmax_dropout_fwd": [VP, VP, VP, VP, VP, C.c_longlong, C.c_int, C.c_float, C.c_double, C.c_int, C.c_uint64, C.c_uint64],
     "nk_scale_softmax_dropout_bwd": [VP, VP, VP, VP, VP, C.c_longlong, C.c_int, C.c_float, C.c_double, C.c_int, C.c_uint64, C.c_uint64],
     "nk_dropout_fwd": [VP, VP, VP, VP, C.c_size_t, C.c_double, C.c_int, C.c_uint64, C.c_uint64],
@@ -645,6 +647,17 @@ def attention_bwd(dev, dQ, dK, dV, dS, dropped, dO, out, scores, stats, mask_bit
     check(lib.nk_attention_bwd(dev.h, dQ.p, dK.p, dV.p, dS.p, dropped.p, dO.p, out.p, scores.p, stats.p,
                                mask_bits.p if mask_bits is not None else None, Q.p, K.p, V.p, B, S, H, dh, scale, float(p),
                                int(train), int(assign[0]), int(assign[1]), int(assign[2])))
+
+
+def attention_qkv_fwd(dev, QKV, scores, stats, mask_bits, out, B, S, H, dh, scale, p, train=True, seed=0, offset=0):
+    """attention_fwd with Q, K, V as the three column blocks of ONE (B*S, 3*H*dh) array."""
+    check(lib.nk_attention_qkv_fwd(dev.h, QKV.p, scores.p if scores is not None else None, stats.p if stats is not None else None,
+                                   mask_bits.p if mask_bits is not None else None, out.p, B, S, H, dh, scale, float(p), int(train), seed, offset))
+
+
+def attention_qkv_bwd(dev, dQKV, dS, dropped, dO, out, scores, stats, mask_bits, QKV, B, S, H, dh, scale, p, train=True, assign=False):
+    check(lib.nk_attention_qkv_bwd(dev.h, dQKV.p, dS.p, dropped.p, dO.p, out.p, scores.p, stats.p,
+                                   mask_bits.p if mask_bits is not None else None, QKV.p, B, S, H, dh, scale, float(p), int(train), int(assign)))
 
 
 def chunk_fwd(dev, x, y, chunk_no):

@@ -62,7 +62,13 @@ struct AttnArgs {
                          // 32 words of one tile are ONE 128-byte line (row-major (B*H, S, S/32) made every tile 32 scattered 4-byte stores:
                          // 16.8 M partial-line write requests per C5 forward next to the 33.5 M of the scores)
     float* stats;      // (B*H, S, 2): the shift m2 (log2 units; row max of s*c1 minus at most 6) and 1 / sum_k exp2(s*c1 - m2)
-    int S, H, ld, nqb, ntile;
+    int S, H, nqb, ntile;
+    // row strides (floats) of the projection-layout operands: a (B*S, H*dh) matrix of its own has ld = H*dh; Q, K, V (and dQ,
+    // dK, dV) that are column blocks of ONE packed (B*S, 3*H*dh) projection output have ld = 3*H*dh
+    int ldx;           // x1, x2
+    int ldq;           // bq
+    int ldc;           // ctx
+    int ldo;           // out
     float scale, keep, dscale;
     float c1;          // scale * log2(e): exponents are taken in base 2
     unsigned keep_lt;  // a draw v is kept iff v < keep_lt = floor((1 - p) * 2^32)  (nk_common.h: the Bernoulli construction)
@@ -128,7 +134,8 @@ __global__ __launch_bounds__(A_NT, OCC) void attention_kernel(const AttnArgs p) 
     // of K and V a head's blocks share stay in that XCD's L2
     const int seq = nkmma::xcd_chunk(blockIdx.x, gridDim.x);
     const int bh = seq / p.nqb, qb = seq % p.nqb;
-    const long long flat0 = (long long)(bh / p.H) * p.S * p.ld + (long long)(bh % p.H) * DH;
+    const long long samp = (long long)(bh / p.H) * p.S, hoff = (long long)(bh % p.H) * DH;
+    const long long flat0 = samp * p.ldx + hoff;   // (sample, head) origin in x1 / x2; bq, ctx and out have their own row strides
     const int q0 = qb * A_QB + w * 32;
     const bool on = FULL ? true : q0 < p.S;  // wave-uniform: the wave has at least one query
     const int SP = RAGGED ? p.SP : p.S;
@@ -140,8 +147,8 @@ __global__ __launch_bounds__(A_NT, OCC) void attention_kernel(const AttnArgs p) 
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
         const int idx = tid + A_NT * r, key = idx / C4, c4 = idx % C4;
-        goff[r] = (unsigned)(key * p.ld + 4 * c4);
-        goff_last[r] = RAGGED ? (unsigned)(min(key, p.S - 1 - 32 * (p.ntile - 1)) * p.ld + 4 * c4) : goff[r];  // last key tile: rows clamped to S - 1
+        goff[r] = (unsigned)(key * p.ldx + 4 * c4);
+        goff_last[r] = RAGGED ? (unsigned)(min(key, p.S - 1 - 32 * (p.ntile - 1)) * p.ldx + 4 * c4) : goff[r];  // last key tile: rows clamped to S - 1
         // mfma row i supplies key 16*((i>>2)&1) + 4*(i>>3) + (i&3); its inverse places key 16a + 4b + c in row 8b + 4a + c
         s1[r] = (unsigned)((8 * ((key >> 2) & 3) + 4 * (key >> 4) + (key & 3)) * X1_LD + 4 * c4);
         s2[r] = (unsigned)(key * X2_LD + ((4 * c4 + 32 * (key >> 4)) & (DH - 1)));
@@ -152,7 +159,7 @@ __global__ __launch_bounds__(A_NT, OCC) void attention_kernel(const AttnArgs p) 
     float4 sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3;
 #define A_STAGE_LOAD(KT)                                                                                         \
     do {                                                                                                         \
-        const long long t0_ = (long long)(KT) * 32 * p.ld;                                                       \
+        const long long t0_ = (long long)(KT) * 32 * p.ldx;                                                      \
         const bool lt_ = RAGGED && (KT) == p.ntile - 1;   /* wave-uniform */                                     \
         const unsigned g0_ = lt_ ? goff_last[0] : goff[0], g1_ = lt_ ? goff_last[NR > 1 ? 1 : 0] : goff[NR > 1 ? 1 : 0],         \
                        g2_ = lt_ ? goff_last[NR > 2 ? 2 : 0] : goff[NR > 2 ? 2 : 0], g3_ = lt_ ? goff_last[NR > 2 ? 3 : 0] : goff[NR > 2 ? 3 : 0]; \
@@ -183,7 +190,7 @@ __global__ __launch_bounds__(A_NT, OCC) void attention_kernel(const AttnArgs p) 
     const int row = RAGGED ? min(qrow, p.S - 1) : qrow;      // row of the projection layout
     float4 bq[DH / 8];  // B operand of pass 1: element (query, dh = 8j + 4h + c)
     {
-        const float* b = p.bq + flat0 + (long long)row * p.ld + 4 * h;
+        const float* b = p.bq + samp * p.ldq + hoff + (long long)row * p.ldq + 4 * h;
 #pragma unroll
         for (int j = 0; j < DH / 8; ++j) bq[j] = *reinterpret_cast<const float4*>(b + 8 * j);
     }
@@ -192,7 +199,7 @@ __global__ __launch_bounds__(A_NT, OCC) void attention_kernel(const AttnArgs p) 
     if (BWD) {
         const float2 ms = *reinterpret_cast<const float2*>(p.stats + ((long long)bh * SP + qrow) * 2);
         m_run = ms.x; l_run = ms.y;
-        const float* o = p.ctx + flat0 + (long long)row * p.ld + 4 * h;
+        const float* o = p.ctx + samp * p.ldc + hoff + (long long)row * p.ldc + 4 * h;
 #pragma unroll
         for (int j = 0; j < DH / 8; ++j) {
             const float4 ov = *reinterpret_cast<const float4*>(o + 8 * j);
@@ -401,7 +408,7 @@ __global__ __launch_bounds__(A_NT, OCC) void attention_kernel(const AttnArgs p) 
 #undef A_SCORES_TO_LDS
     if (!on) return;
     // ---- epilogue: lane (query q, half h) owns dh = 32 d + 8 c + 4 h + {0..3} ----------------------------------------
-    float* orow = p.out + flat0 + (long long)row * p.ld + 4 * h;
+    float* orow = p.out + samp * p.ldo + hoff + (long long)row * p.ldo + 4 * h;
     const bool qvalid = !RAGGED || qrow < p.S;  // a padded query's copy of row S - 1 stays in the scratch
     if (!BWD) {
         const float inv = 1.f / l_run;
@@ -447,7 +454,7 @@ int attention_check(int B, int S, int H, int dh, double p, int train, float scal
 
 template <bool BWD, int DH>
 int attention_launch_dh(nk_device* dev, AttnArgs& a, int B, int S, int H, double p, int train, uint64_t seed, uint64_t offset, float scale) {
-    a.S = S; a.H = H; a.ld = H * DH; a.nqb = (S + A_QB - 1) / A_QB; a.SP = (S + 31) / 32 * 32; a.ntile = a.SP / 32;
+    a.S = S; a.H = H; a.nqb = (S + A_QB - 1) / A_QB; a.SP = (S + 31) / 32 * 32; a.ntile = a.SP / 32;
     a.scale = scale; a.c1 = scale * 1.44269504088896341f; a.keep = (float)(1.0 - p); a.dscale = 1.f / (1.f - (float)p);  // as nk_scale_softmax_dropout_fwd
     a.seed = seed; a.offset = offset;
     a.keep_lt = nk_keep_threshold(1.0 - p);   // Bernoulli::new(1. - p), node/dropout/mod.rs:46
@@ -497,27 +504,40 @@ int nk_attention_supported(int S, int dh, double p, int train) {
     return (dh == 32 || dh == 64 || dh == 128) && S > 0 && !(train && 1.0 - p == 0.0);
 }
 
-int nk_attention_fwd(nk_device* dev, const float* Q, const float* K, const float* V, float* scores, float* stats,
-                     uint32_t* mask_bits, float* O, int B, int S, int H, int dh, float scale, double p, int train, uint64_t seed,
-                     uint64_t offset) {
+static int attention_fwd_impl(nk_device* dev, const float* Q, const float* K, const float* V, int ld_qkv, float* scores, float* stats,
+                              uint32_t* mask_bits, float* O, int B, int S, int H, int dh, float scale, double p, int train, uint64_t seed,
+                              uint64_t offset) {
     NK_USE(dev);
     if (int rc = attention_check(B, S, H, dh, p, train, scale)) return rc;
     NK_CHECK(Q && K && V && O, "null pointer in nk_attention_fwd");
     NK_CHECK((scores != nullptr) == (stats != nullptr), "nk_attention_fwd: scores and stats are kept together or not at all");
     NK_CHECK(!scores || mask_bits || !(train && p != 0.0), "nk_attention_fwd: dropout is active, the mask_bits buffer is needed");
     NK_CHECK(al16(Q) && al16(K) && al16(V) && al16(scores) && al16(O) && al16(stats), "nk_attention_fwd needs 16-byte aligned buffers");
+    NK_CHECK((long long)B * S * ld_qkv < (1ll << 31), "attention: the packed projection layout exceeds 2^31 elements");
     nk_prof_start(dev, NK_KERNEL_ATTENTION, 4.0 * B * H * (double)S * S * dh);
     AttnArgs a{};
     a.x1 = K; a.x2 = V; a.bq = Q; a.out = O; a.scores = scores; a.stats = stats; a.maskbits = mask_bits;
+    a.ldx = ld_qkv; a.ldq = ld_qkv; a.ldc = H * dh; a.ldo = H * dh;
     const int rc = attention_launch<false>(dev, a, B, S, H, dh, p, train, seed, offset, scale);
     nk_prof_stop(dev);
     return rc;
 }
+int nk_attention_fwd(nk_device* dev, const float* Q, const float* K, const float* V, float* scores, float* stats,
+                     uint32_t* mask_bits, float* O, int B, int S, int H, int dh, float scale, double p, int train, uint64_t seed,
+                     uint64_t offset) {
+    return attention_fwd_impl(dev, Q, K, V, H * dh, scores, stats, mask_bits, O, B, S, H, dh, scale, p, train, seed, offset);
+}
+int nk_attention_qkv_fwd(nk_device* dev, const float* QKV, float* scores, float* stats, uint32_t* mask_bits, float* O, int B, int S,
+                         int H, int dh, float scale, double p, int train, uint64_t seed, uint64_t offset) {
+    NK_CHECK(QKV != nullptr, "null pointer in nk_attention_qkv_fwd");
+    const int d = H * dh;
+    return attention_fwd_impl(dev, QKV, QKV + d, QKV + 2 * d, 3 * d, scores, stats, mask_bits, O, B, S, H, dh, scale, p, train, seed, offset);
+}
 
-int nk_attention_bwd(nk_device* dev, float* dQ, float* dK, float* dV, float* dS, float* dropped, const float* dO, const float* O,
-                     const float* scores, const float* stats, const uint32_t* mask_bits, const float* Q, const float* K,
-                     const float* V, int B, int S, int H, int dh, float scale, double p, int train, int assign_dq, int assign_dk,
-                     int assign_dv) {
+static int attention_bwd_impl(nk_device* dev, float* dQ, float* dK, float* dV, float* dS, float* dropped, const float* dO, const float* O,
+                              const float* scores, const float* stats, const uint32_t* mask_bits, const float* Q, const float* K,
+                              const float* V, int ld_qkv, int B, int S, int H, int dh, float scale, double p, int train, int assign_dq,
+                              int assign_dk, int assign_dv) {
     NK_USE(dev);
     if (int rc = attention_check(B, S, H, dh, p, train, scale)) return rc;
     NK_CHECK(dQ && dK && dV && dS && dropped && dO && O && scores && stats && Q && K && V, "null pointer in nk_attention_bwd");
@@ -525,10 +545,12 @@ int nk_attention_bwd(nk_device* dev, float* dQ, float* dK, float* dV, float* dS,
     NK_CHECK(al16(dQ) && al16(dK) && al16(dV) && al16(dS) && al16(dropped) && al16(dO) && al16(O) && al16(scores) && al16(stats) &&
                  al16(Q) && al16(K) && al16(V),
              "nk_attention_bwd needs 16-byte aligned buffers");
+    NK_CHECK((long long)B * S * ld_qkv < (1ll << 31), "attention: the packed projection layout exceeds 2^31 elements");
     nk_prof_start(dev, NK_KERNEL_ATTENTION, 4.0 * B * H * (double)S * S * dh);
     AttnArgs a{};
     a.x1 = V; a.x2 = K; a.bq = dO; a.ctx = O; a.out = dQ; a.scores = const_cast<float*>(scores); a.ds = dS; a.dropped = dropped;
     a.stats = const_cast<float*>(stats); a.maskbits = const_cast<uint32_t*>(mask_bits); a.assign = assign_dq ? 1 : 0;
+    a.ldx = ld_qkv; a.ldq = H * dh; a.ldc = H * dh; a.ldo = ld_qkv;
     int rc = attention_launch<true>(dev, a, B, S, H, dh, p, train, 0, 0, scale);
     nk_prof_stop(dev);
     if (rc) return rc;
@@ -536,10 +558,25 @@ int nk_attention_bwd(nk_device* dev, float* dQ, float* dK, float* dV, float* dS,
     // (Keeping dS / Pd in the kernels' own tile order - no LDS transposition in the kernel, a k-contiguous A operand whose
     // 128 x 32 tiles are single 16 KB runs for these products - was built and measured: kernel and products unchanged.)
     const int d = H * dh, SP = (S + 31) / 32 * 32;  // row stride of the scratch tensors (== S unless S is ragged)
-    const long long so = (long long)S * d, po = (long long)H * SP * SP, pi = (long long)SP * SP;
-    rc = nk_sgemm_batched(dev, 1, 0, S, dh, S, 1.f, dS, SP, po, pi, Q, d, so, dh, assign_dk ? 0.f : 1.f, dK, d, so, dh, B, H);
+    const long long so = (long long)S * d, sq = (long long)S * ld_qkv, po = (long long)H * SP * SP, pi = (long long)SP * SP;
+    rc = nk_sgemm_batched(dev, 1, 0, S, dh, S, 1.f, dS, SP, po, pi, Q, ld_qkv, sq, dh, assign_dk ? 0.f : 1.f, dK, ld_qkv, sq, dh, B, H);
     if (rc) return rc;
-    return nk_sgemm_batched(dev, 1, 0, S, dh, S, 1.f, dropped, SP, po, pi, dO, d, so, dh, assign_dv ? 0.f : 1.f, dV, d, so, dh, B, H);
+    return nk_sgemm_batched(dev, 1, 0, S, dh, S, 1.f, dropped, SP, po, pi, dO, d, so, dh, assign_dv ? 0.f : 1.f, dV, ld_qkv, sq, dh, B, H);
+}
+int nk_attention_bwd(nk_device* dev, float* dQ, float* dK, float* dV, float* dS, float* dropped, const float* dO, const float* O,
+                     const float* scores, const float* stats, const uint32_t* mask_bits, const float* Q, const float* K,
+                     const float* V, int B, int S, int H, int dh, float scale, double p, int train, int assign_dq, int assign_dk,
+                     int assign_dv) {
+    return attention_bwd_impl(dev, dQ, dK, dV, dS, dropped, dO, O, scores, stats, mask_bits, Q, K, V, H * dh, B, S, H, dh, scale, p, train,
+                              assign_dq, assign_dk, assign_dv);
+}
+int nk_attention_qkv_bwd(nk_device* dev, float* dQKV, float* dS, float* dropped, const float* dO, const float* O, const float* scores,
+                         const float* stats, const uint32_t* mask_bits, const float* QKV, int B, int S, int H, int dh, float scale,
+                         double p, int train, int assign) {
+    NK_CHECK(dQKV && QKV, "null pointer in nk_attention_qkv_bwd");
+    const int d = H * dh;
+    return attention_bwd_impl(dev, dQKV, dQKV + d, dQKV + 2 * d, dS, dropped, dO, O, scores, stats, mask_bits, QKV, QKV + d, QKV + 2 * d, 3 * d,
+                              B, S, H, dh, scale, p, train, assign, assign, assign);
 }
 
 }  // extern "C"

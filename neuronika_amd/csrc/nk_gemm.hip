@@ -524,6 +524,10 @@ static int gemm_impl(nk_device* dev, int transA, int transB, int M, int N, int K
         if (dev->tune_gemm_n >= 5) force_group = dev->tune_gemm[4];
         if (dev->tune_gemm_n >= 6) force_pf2 = dev->tune_gemm[5];
     }
+    // when the reduction is split anyway, no split takes more than 128 k-tiles: a chain of at most 4096 products per slab
+    // (the f32 chain's rounding error grows with its length; 3072 x 1024 x 32768 - the packed C5
+    // weight gradient - would otherwise run as 3 chains of 10944)
+    if (splits > 1 && dev->tune_gemm_n < 3 && splits < (ktiles + 127) / 128) splits = (ktiles + 127) / 128;
     int kts = (ktiles + splits - 1) / splits;
     if (kts < 1) kts = 1;
     splits = (ktiles + kts - 1) / kts;

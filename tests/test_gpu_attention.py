@@ -115,6 +115,40 @@ def test_attention_core_equals_oracle(dev, B, S, H, dh, p, train):
     _check(got2["dq"], ref["dq"], ref32["dq"], "dq (assigned)", floor=float(terms["dq"]))
 
 
+@pytest.mark.parametrize("B,S,H,dh", [(2, 128, 2, 64), (1, 160, 3, 32), (2, 100, 2, 64), (1, 96, 2, 128), (3, 33, 1, 64), (1, 1024, 16, 64)])
+@pytest.mark.parametrize("p", [0.0, 0.2])
+def test_attention_core_reads_packed_qkv_bit_for_bit(dev, B, S, H, dh, p):
+    """nk_attention_qkv_fwd / _bwd - Q, K, V (dQ, dK, dV) as the three column blocks of ONE (B*S, 3*H*dh) array, the output of
+    `nn::MultiheadAttention`'s packed projection GEMM - give the bits of nk_attention_fwd / _bwd on three separate arrays:
+    output, kept scores / statistics / mask words, dS, Pd and all three input gradients, whole and ragged sequence lengths."""
+    c = capi()
+    seed, offset = 77, 5
+    d = H * dh
+    q, k, v, g = (rnd(s_, (B * S, d), -1, 1) for s_ in (11, 12, 13, 14))
+    ref, _ = _run(dev, B, S, H, p, True, seed, offset, True, q, k, v, g, np.zeros((B * S, d), np.float32), dh)
+    scale = float(np.float32(1.0 / np.sqrt(dh)))
+    SP = c.attention_padded(S)
+    QKV, G = dev.array(np.concatenate([q, k, v], axis=1)), dev.array(g)
+    scores, stats, out = dev.full((B * H, SP, SP), 7.0), dev.zeros((B * H, SP, 2)), dev.zeros((B * S, d))
+    bits = dev.zeros((B * H, SP, SP // 32))
+    c.attention_qkv_fwd(dev, QKV, scores, stats, bits, out, B, S, H, dh, scale, p, True, seed, offset)
+    dS, dropped = dev.full((B * H, SP, SP), 7.0), dev.full((B * H, SP, SP), 7.0)
+    dQKV = dev.full((B * S, 3 * d), np.nan)
+    c.attention_qkv_bwd(dev, dQKV, dS, dropped, G, out, scores, stats, bits, QKV, B, S, H, dh, scale, p, True, assign=True)
+    cut = lambda t: np.ascontiguousarray(t.numpy()[:, :S, :S])
+    assert np.array_equal(out.numpy(), ref["out"]) and np.array_equal(cut(scores), ref["scores"])
+    assert np.array_equal(stats.numpy()[:, :S], ref["stats"]) and np.array_equal(bits.numpy().view(np.uint32), ref["bits"])
+    assert np.array_equal(cut(dS), ref["d_scores"]) and np.array_equal(cut(dropped), ref["dropped"])
+    dqkv = dQKV.numpy()
+    for i, name in enumerate(("dq", "dk", "dv")):
+        assert np.array_equal(dqkv[:, i * d:(i + 1) * d], ref[name]), name
+    # accumulating form: onto a non-zero start
+    start = rnd(15, (B * S, 3 * d), -1, 1)
+    D2 = dev.array(start)
+    c.attention_qkv_bwd(dev, D2, dS, dropped, G, out, scores, stats, bits, QKV, B, S, H, dh, scale, p, True, assign=False)
+    np.testing.assert_allclose(D2.numpy() - start, dqkv, rtol=0, atol=2e-6 * max(1.0, float(np.abs(dqkv).max())))
+
+
 @pytest.mark.parametrize("dh", [64, 32, 128])
 def test_attention_core_single_key(dev, dh):
     """S = 1 (one valid key in a 32 x 32 tile, 31 padded keys and queries): P = 1, so O = V * noise / (1 - p), dV = Pd * dO, and the

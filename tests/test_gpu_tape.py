@@ -530,6 +530,59 @@ def test_linear_forward_relu_equals_the_two_nodes(nk, tdev):
     assert root.history_len() == 4                                     # 3 Linear(+ReLU) nodes + the loss
 
 
+@pytest.mark.parametrize("B,S,H,d,p", [(2, 128, 2, 128, 0.0), (3, 100, 4, 128, 0.2), (2, 64, 2, 256, 0.1)])
+def test_mha_packed_projections_equal_three_linear_nodes(nk, tdev, B, S, H, d, p):
+    """`nn::MultiheadAttention` with packed Q / K / V projections (ONE GEMM with N = 3d, one input-gradient GEMM with K = 3d,
+    one weight-gradient GEMM with M = 3d, attention kernels reading the packed output) against the same module run as three
+    Linear nodes + the attention node (`packed_qkv = False`) on the same weights and the same dropout mask:
+      * q / k / v are ordinary parameters that happen to share one allocation (views): data(), grad(), optimizers work;
+      * output, dQ-side quantities and every PARAMETER gradient are bit-identical (same chains: the packing only moves tiles);
+      * the input gradient is one K = 3d chain instead of three K = d chains added up - equal to contraction tolerance;
+      * zero_grad + a second pass accumulates on the packed views exactly like the unpacked module."""
+    x, g = rnd(1, (B * S, d), -1, 1), rnd(2, (B * S, d), -1, 1)
+    res = {}
+    for packed in (True, False):
+        nk.manual_seed(123)
+        mha = nk.nn.MultiheadAttention(tdev, d, H, p, 5)
+        mha.packed_qkv = packed
+        X = nk.from_ndarray(tdev, x).requires_grad()
+        out = mha.forward(X, B)
+        assert out.history_len() == (2 if packed else 5)              # [projections + core] + out-projection | q, k, v, core, out
+        out.forward(); out.backward_from(nk.from_ndarray(tdev, g))
+        first = [getattr(mha, n).weight.grad().copy() for n in "qkvo"]
+        out.no_grad(); out.with_grad()
+        out.forward(); out.backward_from(nk.from_ndarray(tdev, g))    # leaves accumulate: 2x (fresh dropout mask in the second pass)
+        res[packed] = dict(out=out.data(), dx=X.grad(), first=first,
+                           w=[getattr(mha, n).weight.grad() for n in "qkvo"], b=[getattr(mha, n).bias.grad() for n in "qkvo"],
+                           data=[getattr(mha, n).weight.data() for n in "qkvo"])
+    a, b = res[True], res[False]
+    for u, v in zip(a["data"], b["data"]):
+        assert np.array_equal(u, v)                                    # same initialisation law, packed or not
+    assert np.array_equal(a["out"], b["out"])
+    for key in ("first", "w"):
+        for i, (u, v) in enumerate(zip(a[key], b[key])):
+            assert np.array_equal(u, v), (key, "qkvo"[i])
+    for i, (u, v) in enumerate(zip(a["b"], b["b"])):                   # column sums of a (n, 3d) / (n, d) matrix: the row partition of the
+        np.testing.assert_allclose(u, v, rtol=0, atol=1e-5 * max(1.0, float(np.abs(v).max())), err_msg="qkvo"[i])   # two-pass sum may differ
+    scale = np.abs(b["dx"]).max()
+    assert np.abs(a["dx"] - b["dx"]).max() <= 2e-6 * 3 * d * scale / np.sqrt(3 * d) + 1e-6 * scale
+    # an optimizer step on the views moves the packed storage
+    mha = nk.nn.MultiheadAttention(tdev, d, H, 0.0, 5)
+    X = nk.from_ndarray(tdev, x).requires_grad()
+    out = mha.forward(X, B)
+    loss = (out * out).sum(); loss.forward(); loss.backward(1.0)
+    opt = nk.optim.SGD(0.01)
+    for n in "qkvo":
+        opt.register(getattr(mha, n).weight); opt.register(getattr(mha, n).bias)
+    w0, g0 = mha.k.weight.data().copy(), mha.k.weight.grad().copy()
+    opt.step(); opt.zero_grad()
+    np.testing.assert_allclose(mha.k.weight.data(), w0 - np.float32(0.01) * g0, rtol=1e-6, atol=1e-7)   # (the kernel may contract w - g * lr into one fma)
+    assert not mha.k.weight.grad().any() and np.abs(mha.k.weight.data() - w0).max() > 0
+    out2_before = out.data().copy()
+    out.forward()
+    assert not np.array_equal(out.data(), out2_before)                # the forward GEMM reads the updated packed weights
+
+
 def test_losses_gemv_stack_graph(nk, tdev):
     """Row f-4 through the tape: classifier head x.mm_t(W) -> log_softmax -> nll; bce / bce_with_logits / kldiv /
     mae heads; mv / vm / vv; stack — values and gradients against the oracle nodes."""
