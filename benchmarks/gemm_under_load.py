@@ -1,0 +1,83 @@
+"""4096^3 GEMMs (NT / NN / TN, the C4 step's three layouts) next to a background stream of fabric traffic, one GPU.
+
+VERDICT r03 item 7: the GEMMs pull 3 - 4x their algorithmic bytes over the fabric (Infinity-Cache hits, harmless on an idle
+chip); an 8-GPU step adds xGMI traffic through the same fabric.  Does that traffic slow the GEMMs?  The load generator is the
+paced replica kernel of nk_comm.hip (K workgroups walking a buffer at a set algorithm bandwidth, read + write) on the side
+stream, (a) over device memory (HBM) and (b) over page-locked HOST memory - every byte of (b) crosses the IO die and the
+fabric the way peer traffic does.  Prints one JSON line per point: background GB/s asked / achieved, GEMM us per launch.
+
+    python benchmarks/gemm_under_load.py            (about 30 s on the GPU box)
+"""
+import ctypes as C
+import json
+import os
+import sys
+
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np  # noqa: E402
+
+from neuronika_amd import capi as c  # noqa: E402
+from benchmarks.microbench import rand  # noqa: E402
+
+
+class Raw:
+    """A float buffer by address (device or page-locked host memory)."""
+    def __init__(self, ptr, n):
+        self.p, self.size, self.shape = C.c_void_p(ptr), n, (n,)
+
+
+def main():
+    dev = c.Device(0)
+    n = 4096
+    A, B, Cm = rand(dev, (n, n), 0, 0, 1), rand(dev, (n, n), 1, 0, 1), dev.zeros((n, n))
+    layouts = (("NT", 0, 1), ("NN", 0, 0), ("TN", 1, 0))
+    big = dev.zeros((1 << 29,))                       # 2 GB of HBM for the background stream
+    host_n = 1 << 26                                  # 256 MB page-locked
+    hp = C.c_void_p()
+    c.check(c.lib.nk_host_alloc(host_n * 4, C.byref(hp)))
+    C.memset(hp, 0, host_n * 4)
+    host = Raw(hp.value, host_n)
+
+    def gemms(reps):
+        e0, e1 = dev.event(), dev.event()
+        out = {}
+        for name, ta, tb in layouts:
+            for _ in range(2):
+                c.sgemm(dev, ta, tb, n, n, n, 1.0, A, n, B, n, 0.0, Cm, n)
+            e0.record()
+            for _ in range(reps):
+                c.sgemm(dev, ta, tb, n, n, n, 1.0, A, n, B, n, 0.0, Cm, n)
+            e1.record()
+            e1.sync()
+            out[name] = round(e0.elapsed_ms(e1) / reps * 1e3, 1)
+        return out
+
+    for _ in range(2):
+        base = gemms(8)                               # clock settle
+    print(json.dumps({"background": "none", "gemm_us": base}), flush=True)
+    for where, buf, points in (("hbm", big, ((16, 50.0), (16, 100.0), (16, 200.0), (32, 400.0), (64, 800.0))),
+                               ("host-pinned", host, ((8, 10.0), (16, 25.0), (32, 50.0)))):
+        for channels, gbps in points:
+            comm = c.Comm(dev, 1, 0, None, channels=channels, gbps=gbps)     # one virtual rank: x *= 1, read + write of every byte
+            # size the pass so that it outlasts the GEMMs it runs beside: ~45 ms at the asked rate
+            count = min(buf.size, int(gbps * 1e9 * 0.045 / 4))
+            span = Raw(buf.p.value, count)
+            bg0, bg1 = dev.event(), dev.event()
+            bg0.record(comm_stream=True)
+            comm.allreduce_sum_async(span)
+            bg1.record(comm_stream=True)
+            t = gemms(4)                              # 3 layouts x (2 + 4) launches ~ 18 ms of GEMMs beside the pass
+            comm.join()
+            dev.sync()
+            achieved = count * 4 / (bg0.elapsed_ms(bg1) * 1e-3) / 1e9
+            print(json.dumps({"background": where, "channels": channels, "asked_GBps": gbps, "achieved_GBps": round(achieved, 1),
+                              "bytes_moved_each_way": count * 4, "gemm_us": t,
+                              "slowdown": {k: round(t[k] / base[k], 4) for k in t}}), flush=True)
+            comm.close()
+    base2 = gemms(8)
+    print(json.dumps({"background": "none (again)", "gemm_us": base2}), flush=True)
+    c.check(c.lib.nk_host_free(hp))
+
+
+if __name__ == "__main__":
+    main()

@@ -330,7 +330,31 @@ __global__ __launch_bounds__(NT * KG, (min_waves<TI, TJ, !TA && TB>())) void sge
         // LDS - group g keeps its MFMA tile row g, sends the other row - so that all eight waves share the epilogue (half the
         // old-C loads and C stores per lane; the sum is the same bits in either operand order).  Each group writes into its
         // own images: [wave][column tile][quad][lane] float4, lane-contiguous 16-byte slots.
-        static_assert(TI == 2, "k-pair: 128-row tiles");
+        if constexpr (TI == 1) {
+            // 64-wide tiles (one MFMA tile per wave and column tile): group 1 hands its accumulators over, group 0 adds them
+            // to its own - first half + second half, split-K 2's order - and stores the tile.
+            __syncthreads();  // every wave has read its last k-tile
+            float4* const slot = reinterpret_cast<float4*>(smem_all + 2 * STAGE) + wid * (TJ * 4 * 64) + lane;  // group 1's images
+            if (grp == 1) {
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4)
+                        slot[(j * 4 + q4) * 64] = make_float4(acc[0][j][4 * q4], acc[0][j][4 * q4 + 1], acc[0][j][4 * q4 + 2], acc[0][j][4 * q4 + 3]);
+            }
+            __syncthreads();
+            if (grp == 1) return;
+#pragma unroll
+            for (int j = 0; j < TJ; ++j)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const float4 v = slot[(j * 4 + q4) * 64];
+                    acc[0][j][4 * q4] += v.x; acc[0][j][4 * q4 + 1] += v.y; acc[0][j][4 * q4 + 2] += v.z; acc[0][j][4 * q4 + 3] += v.w;
+                }
+            gemm_epilogue<ALIGNED, TI, TJ>(p, acc, m0, n0, bo, bi, split, batch, wr, wc, lane);
+            return;
+        } else {
+        static_assert(TI == 2, "k-pair: 128-row tiles swap halves");
         __syncthreads();  // every wave has read its last k-tile
         float4* const mine_out = reinterpret_cast<float4*>(smem) + wid * (TJ * 4 * 64) + lane;
         const float4* const theirs_in = reinterpret_cast<const float4*>(smem_all + (grp ^ 1) * 2 * STAGE) + wid * (TJ * 4 * 64) + lane;
@@ -353,6 +377,7 @@ __global__ __launch_bounds__(NT * KG, (min_waves<TI, TJ, !TA && TB>())) void sge
             }
         gemm_epilogue<ALIGNED, 1, TJ>(p, keep, m0, n0, bo, bi, split, batch, wr * 2 + grp, wc, lane);
         return;
+        }
     }
     gemm_epilogue<ALIGNED, TI, TJ>(p, acc, m0, n0, bo, bi, split, batch, wr, wc, lane);
 }
@@ -411,7 +436,7 @@ __global__ void splitk_reduce_flat_kernel(const float* __restrict__ slabs, float
 template <bool TA, bool TB, int TI, int TJ>
 static int launch_tile(nk_device* dev, const GemmArgs& p, int nbatch, bool aligned, int kg = 1) {
     dim3 grid((p.tiles_m * p.tiles_n + p.chunk - 1) / p.chunk, p.splits, nbatch), block(NT * kg);
-    if constexpr (TI * TJ == 4) {
+    if constexpr (TI * TJ == 4 || TI * TJ == 1) {
         if (kg == 2) {  // gemm_impl: aligned, one tile per block
             hipLaunchKernelGGL((sgemm_kernel<TA, TB, true, TI, TJ, 2>), grid, block, 0, dev->compute, p);
             NK_LAUNCH_CHECK();
@@ -431,7 +456,7 @@ static int launch(nk_device* dev, const GemmArgs& p, int nbatch, bool aligned, i
     if (ti == 2 && tj == 2) return launch_tile<TA, TB, 2, 2>(dev, p, nbatch, aligned, kg);
     if (ti == 2 && tj == 1) return launch_tile<TA, TB, 2, 1>(dev, p, nbatch, aligned);
     if (ti == 1 && tj == 2) return launch_tile<TA, TB, 1, 2>(dev, p, nbatch, aligned);
-    return launch_tile<TA, TB, 1, 1>(dev, p, nbatch, aligned);
+    return launch_tile<TA, TB, 1, 1>(dev, p, nbatch, aligned, kg);
 }
 
 static int gemm_impl(nk_device* dev, int transA, int transB, int M, int N, int K, float alpha,
@@ -581,9 +606,10 @@ static int gemm_impl(nk_device* dev, int transA, int transB, int M, int N, int K
     p.kskew = 1;
     {
         const long long nblk = (long long)p.tiles_m * p.tiles_n * p.splits * nbatch;
-        const bool can = ti * tj == 4 && aligned && p.chunk == 1 && kts % 2 == 0 && kts >= 8 && K % (2 * BK) == 0 &&
+        const bool can = (ti * tj == 4 || ti * tj == 1) && aligned && p.chunk == 1 && kts % 2 == 0 && kts >= 8 && K % (2 * BK) == 0 &&
                          (p.splits == 1 || p.k_per_split * p.splits == K);
-        const bool want = kpair_tune >= 0 ? kpair_tune > 0 : nblk <= dev->num_cus && kts >= 32;
+        // 64x64 tiles (1024^3: 256 blocks, one wave per SIMD otherwise): from 16 k-tiles per block
+        const bool want = kpair_tune >= 0 ? kpair_tune > 0 : nblk <= dev->num_cus && kts >= (ti * tj == 4 ? 32 : 16);
         if (can && want) kg = 2;
         if (kpair_tune == 1) p.kskew = 0;
     }

@@ -500,7 +500,8 @@ def test_sgemm_kpair_blocks(dev, ta, tb):
             for alpha, beta in ((1.0, 0.0), (-1.5, 0.5)):
                 outs = {}
                 for name, force, pair in (("split2", "2,2,2", "0"), ("pair", "2,2,1", "1"), ("pair_skewed", "2,2,1", "2"),
-                                          ("pair_skewed_again", "2,2,1", "2"), ("split2_pair", "2,2,2", "2")):
+                                          ("pair_skewed_again", "2,2,1", "2"), ("split2_pair", "2,2,2", "2"),
+                                          ("split2_64", "1,1,2", "0"), ("pair_64", "1,1,1", "1"), ("pair_64_skewed", "1,1,1", "2")):
                     if name == "split2_pair" and (K // 32) % 4 != 0:
                         continue
                     dev.gemm_force(force); dev.gemm_kpair(int(pair))
@@ -510,6 +511,9 @@ def test_sgemm_kpair_blocks(dev, ta, tb):
                 assert np.array_equal(outs["pair"], outs["split2"]), (K, alpha)
                 assert np.array_equal(outs["pair_skewed"], outs["split2"]), (K, alpha)
                 assert np.array_equal(outs["pair_skewed_again"], outs["pair_skewed"]), (K, alpha)
+                # 64 x 64 tiles (group 1 hands its accumulators to group 0): the same sums, whatever the tile shape
+                assert np.array_equal(outs["split2_64"], outs["split2"]), (K, alpha)
+                assert np.array_equal(outs["pair_64"], outs["split2"]) and np.array_equal(outs["pair_64_skewed"], outs["split2"]), (K, alpha)
                 opa = (a.transpose(0, 2, 1) if ta else a).astype(np.float64)
                 opb = (b.transpose(0, 2, 1) if tb else b).astype(np.float64)
                 want = alpha * (opa @ opb) + beta * c0
@@ -538,7 +542,7 @@ def test_sgemm_is_the_device_order_model_bit_for_bit(dev, ta, tb):
         for K, force, pair in ((2048, "2,2,1", "0"), (2080, "2,2,1", "0"), (2112, "2,2,1", "0"), (2144, "2,2,1", "0"), (4096, "2,2,1", "0"),
                                (6333, "2,2,1", "0"), (2100, "1,1,1", "0"), (4096, "2,2,1,1,8,1000", "0"), (4160, "1,2,1", "0"),
                                (4160, "2,1,1", "0"), (3200, "1,1,1", "0"), (8320, "2,2,2", "0"), (4096, "2,2,1", "2"), (4224, "2,2,1", "1"),
-                               (8192, "2,2,2", "2"), (96, "2,2,1", "0"), (8, "2,2,1", "0")):
+                               (8192, "2,2,2", "2"), (4096, "1,1,1", "2"), (2112, "1,1,1", "1"), (96, "2,2,1", "0"), (8, "2,2,1", "0")):
             a = rnd(90 + K, (K, M) if ta else (M, K), -1, 1)
             b = rnd(91 + K, (N, K) if tb else (K, N), -1, 1)
             opa, opb = np.ascontiguousarray(a.T if ta else a), np.ascontiguousarray(b.T if tb else b)
