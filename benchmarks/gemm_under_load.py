@@ -74,6 +74,30 @@ def main():
                               "bytes_moved_each_way": count * 4, "gemm_us": t,
                               "slowdown": {k: round(t[k] / base[k], 4) for k in t}}), flush=True)
             comm.close()
+    # (c) traffic that occupies NO compute unit: page-locked host -> HBM copies by the SDMA engines on the copy stream, queued
+    # back to back underneath the GEMMs (PCIe Gen5 x16: the order of magnitude of one GPU's share of an 8-GPU all-reduce,
+    # ~350 MB per 8 ms step in each direction).  What (a) and (b) show is mostly the price of SHARING CUs with the generator's
+    # workgroups (it does not follow the rate); this row isolates the fabric.
+    dst = dev.zeros((host_n,))
+    for ncopies in (0, 6):
+        e0, e1 = dev.event(), dev.event()
+        dev.sync()
+        for _ in range(ncopies):
+            c.check(c.lib.nk_upload_async(dev.h, dst.p, hp, host_n))
+        t = gemms(4)
+        dev.sync()
+        print(json.dumps({"background": "sdma host->device copies" if ncopies else "none (before sdma)", "copies_of_256MB": ncopies, "gemm_us": t,
+                          "slowdown": {k: round(t[k] / base[k], 4) for k in t}}), flush=True)
+    # how long do those copies take alone (rate of the background stream)
+    e0, e1 = dev.event(), dev.event()
+    dev.sync()
+    import time
+    t0 = time.perf_counter()
+    for _ in range(6):
+        c.check(c.lib.nk_upload_async(dev.h, dst.p, hp, host_n))
+    dev.sync()
+    dt = time.perf_counter() - t0
+    print(json.dumps({"background": "sdma copies alone", "GBps": round(6 * host_n * 4 / dt / 1e9, 1), "ms": round(dt * 1e3, 2)}), flush=True)
     base2 = gemms(8)
     print(json.dumps({"background": "none (again)", "gemm_us": base2}), flush=True)
     c.check(c.lib.nk_host_free(hp))
