@@ -199,6 +199,25 @@ def read_traffic(kernel):
         return None, None
 
 
+def traffic_sources_match():
+    """True when the kernel sources of THIS tree hash to what profiles/roofline_traffic.json was measured with (sha256 over
+    neuronika_amd/csrc/*.{hip,h}, written by tools/make_roofline_traffic.py); None when the file carries no hash."""
+    import hashlib
+    try:
+        want = json.load(open(os.path.join(ROOT, "profiles", "roofline_traffic.json"))).get("_kernel_sources_sha16")
+    except Exception:
+        return None
+    if not want:
+        return None
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "neuronika_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(csrc, f), "rb").read())
+    return h.hexdigest()[:16] == want
+
+
 # ------------------------------------------------------------------------------------------------
 # cpu_baseline: the CPU oracle on this host's cores (reported beside the GPU number, not a target)
 # ------------------------------------------------------------------------------------------------
@@ -328,6 +347,7 @@ def roofline_mfma(gemm_stats, kernel, traffic_key=None):
            "avg_launch_ms": round(ms / max(1, n_launch), 4), "algorithmic_flop_per_launch": flop / max(1, n_launch)}
     if traffic is not None:
         out["traffic_measured_at_commit"] = at
+        out["traffic_kernel_sources_match"] = traffic_sources_match()   # false: a kernel source changed since the PMC passes
     return out
 
 

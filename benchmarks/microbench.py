@@ -79,25 +79,31 @@ def bench_gemm(dev, sizes, iters):
 
 
 def bench_stream(dev, iters):
-    n = 4096 * 4096
-    X, Y, Bv, G, D = rand(dev, (4096, 4096), 0), dev.zeros((4096, 4096)), rand(dev, (4096,), 1), rand(dev, (4096, 4096), 2), dev.zeros((4096, 4096))
-    Db = dev.zeros((4096,))
-    out = dev.zeros(())
-    cases = [
-        ("relu_fwd", lambda: c.relu_fwd(dev, X, Y), 8 * n),
-        ("relu_bwd", lambda: c.relu_bwd(dev, D, G, X), 16 * n),
-        ("bias_add_fwd", lambda: c.binary_fwd(dev, "add", Y, X, Bv), 8 * n),
-        ("add_bwd_left_same", lambda: c.binary_bwd_left(dev, "add", D, G), 12 * n),
-        ("bias_grad_colreduce", lambda: c.binary_bwd_right(dev, "add", Db, G), 4 * n),
-        ("mse_fwd", lambda: c.mse_fwd(dev, X, G, out, "mean"), 8 * n),
-        ("mse_bwd", lambda: c.mse_bwd(dev, D, out, X, G, "mean"), 16 * n),
-        ("fill0", lambda: D.fill(0.0), 4 * n),
-        ("sgd", lambda: c.sgd_step(dev, X, G, None, lr=1e-9), 12 * n),
-    ]
-    for name, fn, nbytes in cases:
-        ms = timeit(dev, fn, iters)
-        emit(kernel=name, bytes=nbytes, ms=round(ms, 4), gbps=round(nbytes / ms / 1e6, 1),
-             frac_hbm_peak=round(nbytes / (ms * 1e-3) / HBM_PEAK, 4))
+    # two sizes: the C4 tensors (4096 x 4096 = 64 MB each: a two-stream kernel moves 128 - 256 MB and partly lives in the 256 MB
+    # Infinity Cache - rates above the 6.3 TB/s copy ceiling are cache hits) and 16384 x 4096 (256 MB each: HBM)
+    for rows, label in ((4096, "C4 size, partly Infinity-Cache resident"), (16384, "256 MB tensors: HBM")):
+        n = rows * 4096
+        X, Y, Bv, G, D = rand(dev, (rows, 4096), 0), dev.zeros((rows, 4096)), rand(dev, (4096,), 1), rand(dev, (rows, 4096), 2), dev.zeros((rows, 4096))
+        Db = dev.zeros((4096,))
+        out = dev.zeros(())
+        cases = [
+            ("relu_fwd", lambda: c.relu_fwd(dev, X, Y), 8 * n),
+            ("relu_bwd", lambda: c.relu_bwd(dev, D, G, X), 16 * n),
+            ("relu_mask_inplace", lambda: c.relu_mask_inplace(dev, D, X), 12 * n),
+            ("bias_add_fwd", lambda: c.binary_fwd(dev, "add", Y, X, Bv), 8 * n),
+            ("add_bwd_left_same", lambda: c.binary_bwd_left(dev, "add", D, G), 12 * n),
+            ("bias_grad_colreduce", lambda: c.binary_bwd_right(dev, "add", Db, G), 4 * n),
+            ("mse_fwd", lambda: c.mse_fwd(dev, X, G, out, "mean"), 8 * n),
+            ("mse_bwd", lambda: c.mse_bwd(dev, D, out, X, G, "mean"), 16 * n),
+            ("fill0", lambda: D.fill(0.0), 4 * n),
+            ("sgd", lambda: c.sgd_step(dev, X, G, None, lr=1e-9), 12 * n),
+            ("sgd_multi(3 parameters)", lambda: c.sgd_step_multi(dev, [X, Y, D], [G, G, G], None, lr=1e-9), 3 * 12 * n),
+        ]
+        for name, fn, nbytes in cases:
+            ms = timeit(dev, fn, iters)
+            emit(kernel=name, size=label, bytes=nbytes, ms=round(ms, 4), gbps=round(nbytes / ms / 1e6, 1),
+                 frac_hbm_peak=round(nbytes / (ms * 1e-3) / HBM_PEAK, 4))
+        del X, Y, G, D
 
 
 def bench_softmax(dev, iters):

@@ -17,6 +17,17 @@ from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def kernel_sources_sha16():
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "neuronika_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(csrc, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def per_kernel(db):
     """kernel name -> [counter value summed over XCDs, per dispatch]"""
     c = sqlite3.connect(db)
@@ -58,6 +69,9 @@ def main():
                  "launches of the fused attention core in the same step. Regenerate after a GEMM / conv "
                  "change: bash tools/traffic_pmc.sh DIR && python tools/make_roofline_traffic.py DIR",
         "_measured_at_commit": commit,
+        # sha256 over the kernel sources the measured library was built from: bench.py hashes the sources it runs with and says
+        # in its line whether `roofline.traffic` still belongs to them
+        "_kernel_sources_sha16": kernel_sources_sha16(),
         "sgemm_kernel": family("gemm_once", lambda k: k.startswith("sgemm_kernel")),
         "conv": family("conv_step_once", lambda k: k.startswith(("conv_fwd_fast", "conv_bwd_input_fast", "conv_bwd_kernel_kernel"))),
         "mha_gemm": family("mha_step_once", lambda k: k.startswith("sgemm_kernel")),
