@@ -391,7 +391,10 @@ where
         }
         for (index, (op, _)) in buffer.iter().enumerate().rev() {
             op.backward();
-            for id in op.targets() {
+            let mut finished = op.targets();
+            finished.sort_unstable();
+            finished.dedup(); // `x * x` names the same gradient twice: one hand-over
+            for id in finished {
                 if last_writer[&id] == index {
                     if let Some(bucket) = sync.bucket_of(id) {
                         sync.grad_ready(bucket);
