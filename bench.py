@@ -163,12 +163,19 @@ def timed_steps(dist, tdev, cdev, step, steps, warmup, profile=True):
         per_step, elapsed, extra = d / n, elapsed + d, extra + n
     EXTRA_STATS["settle_steps"] = extra
     dist.barrier()
+    if os.environ.get("NK_BENCH_NO_LAUNCH_EVENTS") == "1":   # measurement aid: what the per-launch event pairs cost the step
+        profile = False
     e0, e1 = cdev.event(), cdev.event()
     if profile:
         cdev.profile_begin()
     t0 = time.perf_counter()
     e0.record()
-    for _ in range(steps):
+    for i in range(steps):
+        # The roofline's per-launch durations come from HIP event pairs around the MFMA launches of the TIMED steps - of every
+        # LAUNCH_EVENTS_EVERY-th one: a pair costs the stream ~10 us per launch (same box, C4 / C5 / C3 steps 8.41 / 10.76 / 1.625 ms
+        # with pairs on every step, 8.35 / 10.69 / 1.606 without any: profiles/r04_launch_event_cost.txt), a quarter of that now.
+        if profile:
+            cdev.profile_pause(i % LAUNCH_EVENTS_EVERY != 0)
         step()
     e1.record()
     device_sync(tdev)
@@ -177,13 +184,20 @@ def timed_steps(dist, tdev, cdev, step, steps, warmup, profile=True):
     ev_ms = e0.elapsed_ms(e1)
     if not profile:
         return dist.max(dt), ev_ms, (0, 0.0, 0.0), (0, 0.0, 0.0)
-    gemm = cdev.profile_end(capi.KERNEL_SGEMM)
-    conv = cdev.profile_end(capi.KERNEL_CONV)
-    EXTRA_STATS["attention"] = cdev.profile_end(capi.KERNEL_ATTENTION)
+    sampled = len(range(0, steps, LAUNCH_EVENTS_EVERY))
+    scale = steps / max(1, sampled)   # sums are reported per timed region, as if every step had been instrumented
+
+    def scaled(stats):
+        n, ms, flop = stats
+        return int(round(n * scale)), ms * scale, flop * scale
+    gemm = scaled(cdev.profile_end(capi.KERNEL_SGEMM))
+    conv = scaled(cdev.profile_end(capi.KERNEL_CONV))
+    EXTRA_STATS["attention"] = scaled(cdev.profile_end(capi.KERNEL_ATTENTION))
     return dist.max(dt), ev_ms, gemm, conv
 
 
 SETTLE_S = 0.15   # seconds of untimed load before the timed region (at least the W warm-up steps)
+LAUNCH_EVENTS_EVERY = 4   # timed steps whose MFMA launches carry HIP event pairs: every 4th (timed_steps)
 EXTRA_STATS = {}  # kernel classes only one workload has (the fused attention core of C5), from the last timed_steps()
 
 
@@ -344,6 +358,7 @@ def roofline_mfma(gemm_stats, kernel, traffic_key=None):
     traffic, at = read_traffic(traffic_key) if traffic_key else (None, None)
     out = {"bound": "mfma", "kernel": kernel, "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s",
            "frac": round(achieved * 1e12 / MFMA_F32_PEAK, 4), "traffic": traffic, "launches": n_launch,
+           "launch_events_on_every_nth_timed_step": LAUNCH_EVENTS_EVERY,
            "avg_launch_ms": round(ms / max(1, n_launch), 4), "algorithmic_flop_per_launch": flop / max(1, n_launch)}
     if traffic is not None:
         out["traffic_measured_at_commit"] = at
@@ -376,7 +391,8 @@ def matmul_fwd_bwd(dist, dev, n, steps, warmup):
 
 def matmul_record(dist, dev, n, steps, warmup):
     """One C2 size as a record: value = whole fwd+bwd TFLOP/s (host clock over the K timed steps, no per-launch events),
-    roofline = the GEMM launches themselves (HIP events around every launch of a second pass of K steps)."""
+    roofline = the GEMM launches themselves (HIP event pairs around the launches of a second pass of K steps, every
+    LAUNCH_EVENTS_EVERY-th step of it)."""
     dt, gemm = matmul_fwd_bwd(dist, dev, n, steps, warmup)
     tf = 6.0 * n ** 3 * steps / dt / 1e12
     roof = roofline_mfma(gemm, "sgemm_kernel", "sgemm_kernel" if n == 4096 else None)

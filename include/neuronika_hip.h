@@ -137,6 +137,9 @@ int nk_graph_destroy(nk_graph* graph);
  * pass). */
 enum nk_kernel_class { NK_KERNEL_SGEMM = 0, NK_KERNEL_CONV = 1, NK_KERNEL_ATTENTION = 2 };
 int nk_profile_begin(nk_device* dev);
+/* Suspends (paused != 0) / resumes the bracketing inside a window without dropping its records: an event pair costs the stream
+ * ~10 us per launch, so a harness may instrument every n-th step of its timed region instead of all of them. */
+int nk_profile_pause(nk_device* dev, int paused);
 int nk_profile_end(nk_device* dev, int kernel_class, int* launches, double* total_ms, double* total_flop);
 
 /* ------------------------------------------------------------------ GEMM (MFMA) -------- */

@@ -72,6 +72,7 @@ _SIGS = {
     "nk_event_elapsed_ms": [VP, VP, C.POINTER(C.c_float)],
     "nk_stream_wait_event": [VP, C.c_int, VP],
     "nk_profile_begin": [VP],
+    "nk_profile_pause": [VP, C.c_int],
     "nk_profile_end": [VP, C.c_int, c_intp, C.POINTER(C.c_double), C.POINTER(C.c_double)],
     "nk_sgemm": [VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, VP, C.c_int, VP, C.c_int, C.c_float, VP, C.c_int],
     "nk_sgemm_batched": [VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
@@ -306,6 +307,9 @@ class Device:
 
     def profile_begin(self):
         check(lib.nk_profile_begin(self.h))
+
+    def profile_pause(self, paused: bool):
+        check(lib.nk_profile_pause(self.h, int(bool(paused))))
 
     def profile_end(self, kernel_class: int = 0):
         """-> (launches, total_ms, total_flop) of one kernel class since profile_begin."""

@@ -77,6 +77,12 @@ int nk_profile_begin(nk_device* dev) {
     return NK_OK;
 }
 
+int nk_profile_pause(nk_device* dev, int paused) {
+    NK_USE(dev);
+    dev->prof_on = paused == 0;   // the records collected so far stay: nk_profile_end reads them
+    return NK_OK;
+}
+
 int nk_profile_end(nk_device* dev, int kernel_class, int* launches, double* total_ms, double* total_flop) {
     NK_USE(dev);
     NK_CHECK(launches && total_ms && total_flop, "null output");
