@@ -20,6 +20,10 @@ def main():
     obj_dir = os.path.join(out_dir, "obj_" + name)
     os.makedirs(obj_dir, exist_ok=True)
     csrc = CSRC
+    if "--src" in flags:          # a prepared copy of csrc/ (variants that are more than a one-line edit)
+        i = flags.index("--src")
+        csrc = os.path.abspath(flags[i + 1])
+        del flags[i:i + 2]
     while "--sed" in flags:
         i = flags.index("--sed")
         expr, fname = flags[i + 1], flags[i + 2]

@@ -61,7 +61,11 @@ struct GemmArgs {
 // in registers; the stores come last.  (A one-walk `*q = f(*q)` serialises 16*TI*TJ load -> store round trips per lane,
 // and loads still pending when the per-element conditional store blocks are entered make each of them wait for the
 // previous store as well.)
-template <bool ALIGNED, int TI, int TJ>
+// EPX ("extended"): the instantiation also carries the ReLU forms (`relu`, `mask`).  A template parameter and not just two
+// run-time flags because the mere presence of that code changes what the compiler makes of the WHOLE kernel: same box, 4096^3,
+// plain launches through a kernel with / without it - NT 135.7 / 133.5, NN 135.9 / 135.9, TN 133.2 / 137.5 TFLOP/s (round 4,
+// session l).  gemm_impl therefore takes the extended kernel where it is needed or faster (NT) and the plain one elsewhere.
+template <bool ALIGNED, int TI, int TJ, bool EPX>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[TI][TJ], int m0, int n0, int bo, int bi, int split,
                                               int batch, int wr, int wc, int lane) {
     if (p.splits > 1) {
@@ -77,7 +81,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
     const float alpha = p.alpha, beta = p.beta;
     const int M = p.M, N = p.N;
     const long long ldc = p.ldc;
-    if (p.mask != nullptr) {
+    if (EPX && p.mask != nullptr) {
         // ReLU backward joined to the store (nk_linear_bwd_input_relu): C = beta * C + m(alpha * acc).  Its own block, so
         // that the common epilogue below stays the code it was; two round trips (mask, then old C), 16 values at a time.
         const float* Mk = p.mask;
@@ -104,7 +108,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
             }
         return;
     }
-    if (p.bias != nullptr || beta != 0.f || alpha != 1.f || p.relu) {
+    if (p.bias != nullptr || beta != 0.f || alpha != 1.f || (EPX && p.relu)) {
         float old[TI][TJ][16];
         if (beta != 0.f)
             acc_foreach_idx<TI, TJ>(acc, wr, wc, lane, [&](int i, int j, int e, int r, int c, float) {
@@ -117,7 +121,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
             const int col = n0 + (wc * TJ + j) * 32 + (lane & 31);
             bv[j] = (p.bias != nullptr && (ALIGNED || col < N)) ? p.bias[col] : 0.f;
         }
-        const bool relu = p.relu != 0;
+        const bool relu = EPX && p.relu != 0;
 #pragma unroll
         for (int i = 0; i < TI; ++i)
 #pragma unroll
@@ -126,7 +130,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
                 for (int e = 0; e < 16; ++e) {
                     float o = alpha * acc[i][j][e];
                     if (p.bias != nullptr) o += bv[j];  // Linear: fl(acc + bias[col]) == the separate Addition node
-                    o = relu ? fmaxf(o, 0.f) : o;       // ... followed by the ReLU node (`o.max(0.)`: a NaN gives 0)
+                    if constexpr (EPX) o = relu ? fmaxf(o, 0.f) : o;  // ... followed by the ReLU node (`o.max(0.)`: a NaN gives 0)
                     acc[i][j][e] = beta == 0.f ? o : fmaf(beta, old[i][j][e], o);
                 }
     }
@@ -219,7 +223,7 @@ __device__ __forceinline__ void gemm_loop_lookahead2(TileLoader<AKC, 64 * TI>& l
 // launch gets from two resident blocks - without split-K's slabs and second pass.  The two groups share the block's
 // barriers (same trip count); with `kskew` group 1 issues the first half of a k-tile's MFMAs BEFORE its staging stores, so
 // that the two waves of a SIMD are not in their staging phase at the same time.
-template <bool TA, bool TB, bool ALIGNED, int TI, int TJ, int KG = 1>
+template <bool TA, bool TB, bool ALIGNED, int TI, int TJ, int KG = 1, bool EPX = false>
 __global__ __launch_bounds__(NT * KG, (min_waves<TI, TJ, !TA && TB>())) void sgemm_kernel(GemmArgs p) {
     constexpr int BM = 64 * TI, BN = 64 * TJ;
     constexpr bool AKC = !TA;  // A (M x K): k-contiguous unless stored transposed
@@ -316,7 +320,7 @@ __global__ __launch_bounds__(NT * KG, (min_waves<TI, TJ, !TA && TB>())) void sge
             stage_store<AKC, BM>(nxt, ra, t);
             stage_store<BKC, BN>(nxt + TA_FLOATS, rb, t);
         }
-        gemm_epilogue<ALIGNED, TI, TJ>(p, acc, m0, n0, bo, bi, split, batch, wr, wc, lane);
+        gemm_epilogue<ALIGNED, TI, TJ, EPX>(p, acc, m0, n0, bo, bi, split, batch, wr, wc, lane);
         if (!more) return;
         __syncthreads();  // the next tile's first k-tile is in LDS, everybody is done with the current buffer
         par ^= 1;
@@ -351,7 +355,7 @@ __global__ __launch_bounds__(NT * KG, (min_waves<TI, TJ, !TA && TB>())) void sge
                     const float4 v = slot[(j * 4 + q4) * 64];
                     acc[0][j][4 * q4] += v.x; acc[0][j][4 * q4 + 1] += v.y; acc[0][j][4 * q4 + 2] += v.z; acc[0][j][4 * q4 + 3] += v.w;
                 }
-            gemm_epilogue<ALIGNED, TI, TJ>(p, acc, m0, n0, bo, bi, split, batch, wr, wc, lane);
+            gemm_epilogue<ALIGNED, TI, TJ, EPX>(p, acc, m0, n0, bo, bi, split, batch, wr, wc, lane);
             return;
         } else {
         static_assert(TI == 2, "k-pair: 128-row tiles swap halves");
@@ -375,11 +379,11 @@ __global__ __launch_bounds__(NT * KG, (min_waves<TI, TJ, !TA && TB>())) void sge
                 const float4 v = theirs_in[(j * 4 + q4) * 64];
                 keep[0][j][4 * q4] += v.x; keep[0][j][4 * q4 + 1] += v.y; keep[0][j][4 * q4 + 2] += v.z; keep[0][j][4 * q4 + 3] += v.w;
             }
-        gemm_epilogue<ALIGNED, 1, TJ>(p, keep, m0, n0, bo, bi, split, batch, wr * 2 + grp, wc, lane);
+        gemm_epilogue<ALIGNED, 1, TJ, EPX>(p, keep, m0, n0, bo, bi, split, batch, wr * 2 + grp, wc, lane);
         return;
         }
     }
-    gemm_epilogue<ALIGNED, TI, TJ>(p, acc, m0, n0, bo, bi, split, batch, wr, wc, lane);
+    gemm_epilogue<ALIGNED, TI, TJ, EPX>(p, acc, m0, n0, bo, bi, split, batch, wr, wc, lane);
 }
 
 // Second pass of split-K: C = alpha * sum_s slab[s] + beta * C, fixed summation order.
@@ -433,30 +437,37 @@ __global__ void splitk_reduce_flat_kernel(const float* __restrict__ slabs, float
 }
 
 
-template <bool TA, bool TB, int TI, int TJ>
+template <bool TA, bool TB, int TI, int TJ, bool EPX>
 static int launch_tile(nk_device* dev, const GemmArgs& p, int nbatch, bool aligned, int kg = 1) {
     dim3 grid((p.tiles_m * p.tiles_n + p.chunk - 1) / p.chunk, p.splits, nbatch), block(NT * kg);
     if constexpr (TI * TJ == 4 || TI * TJ == 1) {
         if (kg == 2) {  // gemm_impl: aligned, one tile per block
-            hipLaunchKernelGGL((sgemm_kernel<TA, TB, true, TI, TJ, 2>), grid, block, 0, dev->compute, p);
+            hipLaunchKernelGGL((sgemm_kernel<TA, TB, true, TI, TJ, 2, EPX>), grid, block, 0, dev->compute, p);
             NK_LAUNCH_CHECK();
             return NK_OK;
         }
     }
     if (aligned)
-        hipLaunchKernelGGL((sgemm_kernel<TA, TB, true, TI, TJ>), grid, block, 0, dev->compute, p);
+        hipLaunchKernelGGL((sgemm_kernel<TA, TB, true, TI, TJ, 1, EPX>), grid, block, 0, dev->compute, p);
     else
-        hipLaunchKernelGGL((sgemm_kernel<TA, TB, false, TI, TJ>), grid, block, 0, dev->compute, p);
+        hipLaunchKernelGGL((sgemm_kernel<TA, TB, false, TI, TJ, 1, EPX>), grid, block, 0, dev->compute, p);
     NK_LAUNCH_CHECK();
     return NK_OK;
 }
 
+template <bool TA, bool TB, bool EPX>
+static int launch_epx(nk_device* dev, const GemmArgs& p, int nbatch, bool aligned, int ti, int tj, int kg) {
+    if (ti == 2 && tj == 2) return launch_tile<TA, TB, 2, 2, EPX>(dev, p, nbatch, aligned, kg);
+    if (ti == 2 && tj == 1) return launch_tile<TA, TB, 2, 1, EPX>(dev, p, nbatch, aligned);
+    if (ti == 1 && tj == 2) return launch_tile<TA, TB, 1, 2, EPX>(dev, p, nbatch, aligned);
+    return launch_tile<TA, TB, 1, 1, EPX>(dev, p, nbatch, aligned, kg);
+}
+// the extended-epilogue kernels (EPX, see gemm_epilogue) where the launch needs them - and for every NT launch, which they run
+// 1.6 % faster at 4096^3 than the plain kernel does; the plain kernels elsewhere (TN: +3.2 %)
 template <bool TA, bool TB>
 static int launch(nk_device* dev, const GemmArgs& p, int nbatch, bool aligned, int ti, int tj, int kg) {
-    if (ti == 2 && tj == 2) return launch_tile<TA, TB, 2, 2>(dev, p, nbatch, aligned, kg);
-    if (ti == 2 && tj == 1) return launch_tile<TA, TB, 2, 1>(dev, p, nbatch, aligned);
-    if (ti == 1 && tj == 2) return launch_tile<TA, TB, 1, 2>(dev, p, nbatch, aligned);
-    return launch_tile<TA, TB, 1, 1>(dev, p, nbatch, aligned, kg);
+    const bool epx = p.relu || p.mask != nullptr || (!TA && TB);
+    return epx ? launch_epx<TA, TB, true>(dev, p, nbatch, aligned, ti, tj, kg) : launch_epx<TA, TB, false>(dev, p, nbatch, aligned, ti, tj, kg);
 }
 
 static int gemm_impl(nk_device* dev, int transA, int transB, int M, int N, int K, float alpha,
