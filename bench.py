@@ -631,7 +631,7 @@ def run_mlp(a, dist):
             subs[f"matmul_{n}"] = matmul_record(dist, cdev, n, SUB_STEPS, SUB_WARMUP)
         subs["conv_c3"] = measure_conv(dist, tdev, cdev, SUB_STEPS, SUB_WARMUP)
         subs["mha_c5"] = measure_mha(dist, tdev, cdev, SUB_STEPS, SUB_WARMUP)
-    else:
+    elif os.environ.get("NK_BENCH_NO_SUBRECORDS") != "2":   # ("2": the C4 step alone - kernel traces of exactly this workload)
         subs["matmul_4096"] = matmul_record(dist, cdev, 4096, SUB_STEPS, SUB_WARMUP)
     res = None
     if dist.rank == 0:

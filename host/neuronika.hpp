@@ -846,7 +846,7 @@ class GradientSync : public BackwardHook {
     //             exposed behind the pass; the others have the rest of backward to hide behind and keep the single GEMM
     //             launch (a split weight-gradient GEMM pays its prologue / drain twice: profiles/r03_overlap_projection.md);
     //   None      never.
-    // Default LastOnly; NK_DP_PARTS=all|last|none overrides (measurement aid).  The first pass of LastOnly splits nothing.
+    // Default LastOnly; `set_parts` overrides (measurement aid).  The first pass of LastOnly splits nothing.
     enum class Parts { All, LastOnly, None };
     void set_parts(Parts p) { parts_ = p; }
 

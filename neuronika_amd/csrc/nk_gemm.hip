@@ -582,7 +582,7 @@ static int gemm_impl(nk_device* dev, int transA, int transB, int M, int N, int K
         if (c > ntiles) c = ntiles;
         // The chunk loop and the two-k-tile look-ahead loop are ALTERNATIVES inside the kernel (the look-ahead branch
         // handles exactly one tile): whenever this launch will take the look-ahead (kts >= its threshold, forced or by
-        // rule), the chunk is 1 - also under NK_GEMM_FORCE, whose lookahead_min may lie below the chunk rule's 8.
+        // rule), the chunk is 1 - also under a forced configuration (nk_dev_tune), whose lookahead_min may lie below the chunk rule's 8.
         const int pf2_effective = force_pf2 > 0 ? force_pf2 : pf2_rule_for_chunk;
         if (c < 1 || kts >= 8) c = 1;
         if (force_chunk > 0) c = force_chunk;
@@ -591,7 +591,7 @@ static int gemm_impl(nk_device* dev, int transA, int transB, int M, int N, int K
     }
     p.group_m = force_group > 0 ? force_group : 8;
     // Two k-tiles of look-ahead (the loop that ends a trip MFMAs -> barrier): from a same-box sweep of every layout
-    // (benchmarks/ab_force.py with NK_GEMM_FORCE's sixth field; U[0,1) operands):
+    // (benchmarks/ab_force.py with the sixth value of NK_TUNE_GEMM_FORCE; U[0,1) operands):
     //   64x64 tiles (a k-tile is only 16 MFMAs per wave, less than an L2 round trip): from 8 k-tiles on, every layout
     //     (1024^3: NN 80.8 -> 84, NT 81.7 -> 88, TN 78.9 -> 83 TFLOP/s);
     //   NN (both operands row-major: the B tile is read k-major, its loads land last): from 32 k-tiles on
