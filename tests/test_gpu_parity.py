@@ -1429,6 +1429,35 @@ def test_sgd_step_multi_equals_one_launch_per_parameter(dev):
             assert np.array_equal(r, g_), kw
 
 
+def test_round4_entry_points_reject_bad_arguments(dev):
+    """Status codes, not crashes: nk_dev_tune (unknown knob, too many values, out-of-range modes), nk_sgd_step_multi (null tables),
+    the fused Linear+ReLU forms (null bias / mask operand), nk_attention_qkv_* (null packed pointer)."""
+    import ctypes as C
+    c = capi()
+    E = c.NeuronikaHipError
+    with pytest.raises(E, match="unknown tuning knob"):
+        dev.tune(99, [1])
+    with pytest.raises(E, match="at most 6"):
+        dev.tune(c.TUNE_GEMM_FORCE, [2, 2, 1, 1, 8, 16, 3])
+    with pytest.raises(E, match="KPAIR"):
+        dev.tune(c.TUNE_GEMM_KPAIR, 7)
+    with pytest.raises(E, match="ATTENTION_OCC"):
+        dev.tune(c.TUNE_ATTENTION_OCC, 3)
+    dev.gemm_force(None); dev.gemm_kpair(None); dev.tune(c.TUNE_ATTENTION_OCC, None)
+    with pytest.raises(E, match="null table"):
+        c.check(c.lib.nk_sgd_step_multi(dev.h, 2, None, None, None, None, 0.1, 0.0, 0.0, 0, 0.0, 0.0))
+    c.check(c.lib.nk_sgd_step_multi(dev.h, 0, None, None, None, None, 0.1, 0.0, 0.0, 0, 0.0, 0.0))        # nothing to do
+    X, W, Y = dev.zeros((8, 8)), dev.zeros((8, 8)), dev.zeros((8, 8))
+    with pytest.raises(E, match="null bias"):
+        c.check(c.lib.nk_linear_relu_fwd(dev.h, X.p, W.p, None, Y.p, 8, 8, 8))
+    with pytest.raises(E, match="null mask"):
+        c.check(c.lib.nk_linear_bwd_input_relu(dev.h, Y.p, X.p, W.p, None, 8, 8, 8, 1))
+    with pytest.raises(E, match="null pointer"):
+        c.check(c.lib.nk_attention_qkv_fwd(dev.h, None, None, None, None, Y.p, 1, 8, 1, 64, 0.125, 0.0, 1, 0, 0))
+    with pytest.raises(E, match="bad nk_comm_init_all"):
+        c.check(c.lib.nk_comm_init_all(0, None, None))
+
+
 # ------------------------------------------------------------------------------ GEMV / dot (next row f-4)
 def test_gemv_dot_golden(dev, golden):
     c = capi(); n = golden["nodes"]
