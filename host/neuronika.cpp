@@ -352,11 +352,25 @@ struct MatMulBwd : Backward {
         } else if (kind == 0) {  // = nk_mm_bwd_left / nk_mm_bwd_right with beta 0 on a first write
             const int n = as[0], m = as[1], o = bs[1];
             float beta;
+            if (da && db && da != db) {  // MatrixMatrixMulBackward::backward: both products as one call (one launch at small sizes)
+                float beta_b;
+                float* d = first_write(da, beta);
+                float* e = first_write(db, beta_b);
+                check(nk_mm_bwd(dev, d, e, G.ptr(), a->ptr(), b->ptr(), n, m, o, beta == 0.f, beta_b == 0.f));
+                return;
+            }
             if (da) { float* d = first_write(da, beta); check(nk_sgemm(dev, 0, 1, n, m, o, 1.f, G.ptr(), o, b->ptr(), o, beta, d, m)); }
             if (db) { float* d = first_write(db, beta); check(nk_sgemm(dev, 1, 0, m, o, n, 1.f, a->ptr(), m, G.ptr(), o, beta, d, o)); }
         } else if (kind == 1) {  // = nk_mm_t_bwd_left / nk_mm_t_bwd_right
             const int n = as[0], m = as[1], o = bs[0];
             float beta;
+            if (da && db && da != db) {  // MatrixMatrixMulTBackward::backward as one call
+                float beta_b;
+                float* d = first_write(da, beta);
+                float* e = first_write(db, beta_b);
+                check(nk_mm_t_bwd(dev, d, e, G.ptr(), a->ptr(), b->ptr(), n, m, o, beta == 0.f, beta_b == 0.f));
+                return;
+            }
             if (da) { float* d = first_write(da, beta); check(nk_sgemm(dev, 0, 0, n, m, o, 1.f, G.ptr(), o, b->ptr(), m, beta, d, m)); }
             if (db) { float* d = first_write(db, beta); check(nk_sgemm(dev, 1, 0, o, m, n, 1.f, G.ptr(), o, a->ptr(), m, beta, d, m)); }
         } else if (kind == 2) {

@@ -75,9 +75,10 @@ const char* nk_version(void);
  *                          (ti, tj in {1, 2}: 64- or 128-wide tile sides); n = 0 returns to the rules
  *   NK_TUNE_GEMM_KPAIR     values[0] = -1 rule / 0 never / 1 k-pair blocks, lock-step groups / 2 skewed groups
  *   NK_TUNE_ATTENTION_OCC  values[0] = 0 rule / 2: forward register budget sized for two blocks per CU
+ *   NK_TUNE_GEMM_PAIR      values[0] = -1 rule / 0 nk_sgemm_pair always launches twice / 1 one launch whenever eligible
  * For schedule sweeps (benchmarks/ab_*.py) and the tests that pit one schedule against another bit for bit; results never
  * depend on them beyond summation order (split-K). */
-enum { NK_TUNE_GEMM_FORCE = 0, NK_TUNE_GEMM_KPAIR = 1, NK_TUNE_ATTENTION_OCC = 2 };
+enum { NK_TUNE_GEMM_FORCE = 0, NK_TUNE_GEMM_KPAIR = 1, NK_TUNE_ATTENTION_OCC = 2, NK_TUNE_GEMM_PAIR = 3 };
 int nk_dev_tune(nk_device* dev, int knob, const int* values, int n);
 
 /* ------------------------------------------------------------------ memory ------------- */
@@ -158,6 +159,27 @@ int nk_sgemm_batched(nk_device* dev, int transA, int transB, int M, int N, int K
                      float* C, int ldc, long long sCo, long long sCi,
                      int batch_outer, int batch_inner);
 
+/* Two independent products in ONE launch: C0 = op(A0).op(B0) + beta0*C0 and C1 = op(A1).op(B1) + beta1*C1 (alpha = 1).  When
+ * neither product fills the chip by itself (1024^3: 256 blocks, one per CU) the two grids run side by side - every CU gets the
+ * second resident block a large launch has, and launch boundary, dispatch ramp and tail are paid once; two large grids share
+ * their last, partly filled wave of resident blocks.  Taken by rule for aligned, unsplit (NN | NT | TN) + TN pairs of equal
+ * tile shape when it saves a wave of resident blocks; two ordinary launches otherwise (and whenever an output overlaps the other
+ * product's output or operands).  Every output is the fma chain nk_sgemm gives it without k-pair blocks (NK_TUNE_GEMM_KPAIR = 0):
+ * bit-identical to two calls under that setting. */
+int nk_sgemm_pair(nk_device* dev,
+                  int transA0, int transB0, int M0, int N0, int K0, const float* A0, int lda0, const float* B0, int ldb0,
+                  float beta0, float* C0, int ldc0,
+                  int transA1, int transB1, int M1, int N1, int K1, const float* A1, int lda1, const float* B1, int ldb1,
+                  float beta1, float* C1, int ldc1);
+/* ... over a two-level batch (nk_sgemm_batched's strides, per operand): the dK / dV products of the attention backward */
+int nk_sgemm_pair_batched(nk_device* dev, int batch_outer, int batch_inner,
+                          int transA0, int transB0, int M0, int N0, int K0, const float* A0, int lda0, long long sA0o, long long sA0i,
+                          const float* B0, int ldb0, long long sB0o, long long sB0i, float beta0, float* C0, int ldc0,
+                          long long sC0o, long long sC0i,
+                          int transA1, int transB1, int M1, int N1, int K1, const float* A1, int lda1, long long sA1o, long long sA1i,
+                          const float* B1, int ldb1, long long sB1o, long long sB1i, float beta1, float* C1, int ldc1,
+                          long long sC1o, long long sC1i);
+
 /* Node-level wrappers, one per reference forward()/backward() body. */
 /* MatrixMatrixMul::forward  node/matrix_matrix_mul/mod.rs:31-41   C(n,o) = A(n,m).B(m,o) */
 int nk_mm_fwd(nk_device* dev, const float* A, const float* B, float* C, int n, int m, int o);
@@ -165,12 +187,19 @@ int nk_mm_fwd(nk_device* dev, const float* A, const float* B, float* C, int n, i
 int nk_mm_bwd_left(nk_device* dev, float* dA, const float* G, const float* B, int n, int m, int o);
 /* MatrixMatrixMulBackwardRight::backward :95-105   dB(m,o) += A(n,m)^T.G(n,o) */
 int nk_mm_bwd_right(nk_device* dev, float* dB, const float* A, const float* G, int n, int m, int o);
+/* MatrixMatrixMulBackward::backward :121-126 (both operands differentiable: `self.left.backward(); self.right.backward()`)
+ * as one call = nk_sgemm_pair of the two products above; assign_x != 0: that gradient is freshly zeroed, written unread. */
+int nk_mm_bwd(nk_device* dev, float* dA, float* dB, const float* G, const float* A, const float* B, int n, int m, int o,
+              int assign_a, int assign_b);
 /* MatrixMatrixMulT::forward  node/matrix_matrix_mul_t/mod.rs:31-41  C(n,o) = A(n,m).B(o,m)^T */
 int nk_mm_t_fwd(nk_device* dev, const float* A, const float* B, float* C, int n, int m, int o);
 /* MatrixMatrixMulTBackwardLeft::backward  :63-73   dA(n,m) += G(n,o).B(o,m) */
 int nk_mm_t_bwd_left(nk_device* dev, float* dA, const float* G, const float* B, int n, int m, int o);
 /* MatrixMatrixMulTBackwardRight::backward :95-105  dB(o,m) += G(n,o)^T.A(n,m) */
 int nk_mm_t_bwd_right(nk_device* dev, float* dB, const float* G, const float* A, int n, int m, int o);
+/* MatrixMatrixMulTBackward::backward :121-126, both products as one call (see nk_mm_bwd) */
+int nk_mm_t_bwd(nk_device* dev, float* dA, float* dB, const float* G, const float* A, const float* B, int n, int m, int o,
+                int assign_a, int assign_b);
 
 /* `Linear::forward` neuronika-nn/src/lib.rs:425-447  Y(n,o) = X(n,m).W(o,m)^T + b(o): the MatrixMatrixMulT node
  * (matrix_matrix_mul_t/mod.rs:31-41) and the broadcast Addition node (addition/mod.rs:39-50) as ONE kernel - the

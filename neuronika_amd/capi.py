@@ -78,6 +78,15 @@ _SIGS = {
     "nk_sgemm_batched": [VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                          VP, C.c_int, C.c_longlong, C.c_longlong, VP, C.c_int, C.c_longlong, C.c_longlong,
                          C.c_float, VP, C.c_int, C.c_longlong, C.c_longlong, C.c_int, C.c_int],
+    "nk_sgemm_pair": [VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, VP, C.c_int, VP, C.c_int, C.c_float, VP, C.c_int,
+                      C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, VP, C.c_int, VP, C.c_int, C.c_float, VP, C.c_int],
+    "nk_sgemm_pair_batched": [VP, C.c_int, C.c_int,
+                              C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, VP, C.c_int, C.c_longlong, C.c_longlong, VP, C.c_int, C.c_longlong,
+                              C.c_longlong, C.c_float, VP, C.c_int, C.c_longlong, C.c_longlong,
+                              C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, VP, C.c_int, C.c_longlong, C.c_longlong, VP, C.c_int, C.c_longlong,
+                              C.c_longlong, C.c_float, VP, C.c_int, C.c_longlong, C.c_longlong],
+    "nk_mm_bwd": [VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int],
+    "nk_mm_t_bwd": [VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int],
     "nk_mm_fwd": [VP, VP, VP, VP, C.c_int, C.c_int, C.c_int],
     "nk_mm_bwd_left": [VP, VP, VP, VP, C.c_int, C.c_int, C.c_int],
     "nk_mm_bwd_right": [VP, VP, VP, VP, C.c_int, C.c_int, C.c_int],
@@ -190,7 +199,12 @@ _RESTYPES = {"nk_last_error": C.c_char_p, "nk_version": C.c_char_p, "nk_stream_c
 EXPORTED = tuple(_SIGS)
 
 for _name, _args in _SIGS.items():
-    _fn = getattr(lib, _name)  # AttributeError here = header/library mismatch: fail loudly
+    try:
+        _fn = getattr(lib, _name)  # AttributeError here = header/library mismatch: fail loudly ...
+    except AttributeError:
+        if not os.environ.get("NEURONIKA_HIP_LIB"):
+            raise
+        continue                   # ... except for an A/B variant library built from an OLDER revision (tools/build_rev_variant.sh)
     _fn.argtypes = _args
     _fn.restype = _RESTYPES.get(_name, C.c_int)
 
@@ -241,7 +255,7 @@ class Event:
             pass
 
 
-TUNE_GEMM_FORCE, TUNE_GEMM_KPAIR, TUNE_ATTENTION_OCC = 0, 1, 2   # include/neuronika_hip.h: nk_dev_tune knobs
+TUNE_GEMM_FORCE, TUNE_GEMM_KPAIR, TUNE_ATTENTION_OCC, TUNE_GEMM_PAIR = 0, 1, 2, 3   # include/neuronika_hip.h: nk_dev_tune knobs
 
 
 class Device:
@@ -257,7 +271,8 @@ class Device:
             self.h, self.idx, self._own = h, idx, True
         # The sweep scripts (benchmarks/ab_*.py, tools/sessions/*.sh) choose a schedule per process through environment
         # variables; it is THIS harness that reads them and calls nk_dev_tune - the library itself reads none.
-        for var, knob in (("NK_GEMM_FORCE", TUNE_GEMM_FORCE), ("NK_GEMM_KPAIR", TUNE_GEMM_KPAIR), ("NK_ATTN_OCC", TUNE_ATTENTION_OCC)):
+        for var, knob in (("NK_GEMM_FORCE", TUNE_GEMM_FORCE), ("NK_GEMM_KPAIR", TUNE_GEMM_KPAIR), ("NK_ATTN_OCC", TUNE_ATTENTION_OCC),
+                          ("NK_GEMM_PAIR", TUNE_GEMM_PAIR)):
             if os.environ.get(var):
                 self.tune(knob, os.environ[var])
 
@@ -278,6 +293,9 @@ class Device:
 
     def gemm_kpair(self, mode=None):
         self.tune(TUNE_GEMM_KPAIR, mode)
+
+    def gemm_pair(self, mode=None):
+        self.tune(TUNE_GEMM_PAIR, mode)
 
     def sync(self):
         check(lib.nk_device_sync(self.h))
@@ -357,8 +375,18 @@ class HipArray:
     def shape_c(self):
         return ints(self.shape)
 
+    def view_offset(self, first: int) -> "HipArray":
+        """Non-owning alias that starts `first` floats into this buffer (column blocks / row blocks of one allocation for the raw
+        entry points that take a pointer and a leading dimension); keeps `self` alive."""
+        v = HipArray.__new__(HipArray)
+        v.dev, v.shape, v.size, v._parent = self.dev, (self.size - first,), self.size - first, self
+        v.p = VP(self.p.value + 4 * int(first))
+        return v
+
     def __del__(self):
         try:
+            if getattr(self, "_parent", None) is not None:
+                return
             if self.p and self.dev.h:
                 lib.nk_free(self.dev.h, self.p)
         except Exception:
@@ -394,6 +422,30 @@ def mm_bwd_left(dev, dA, G, B):
 def mm_bwd_right(dev, dB, A, G):
     n, m = A.shape; o = G.shape[1]
     check(lib.nk_mm_bwd_right(dev.h, dB.p, A.p, G.p, n, m, o))
+
+
+def mm_bwd(dev, dA, dB, G, A, B, assign_a=False, assign_b=False):
+    """MatrixMatrixMulBackward::backward: both products, one launch when nk_sgemm_pair's rule says so"""
+    n, m = A.shape; o = B.shape[1]
+    check(lib.nk_mm_bwd(dev.h, dA.p, dB.p, G.p, A.p, B.p, n, m, o, int(assign_a), int(assign_b)))
+
+
+def mm_t_bwd(dev, dA, dB, G, A, B, assign_a=False, assign_b=False):
+    n, m = A.shape; o = B.shape[0]
+    check(lib.nk_mm_t_bwd(dev.h, dA.p, dB.p, G.p, A.p, B.p, n, m, o, int(assign_a), int(assign_b)))
+
+
+def sgemm_pair(dev, ta0, tb0, M0, N0, K0, A0, lda0, B0, ldb0, beta0, C0, ldc0, ta1, tb1, M1, N1, K1, A1, lda1, B1, ldb1, beta1, C1, ldc1):
+    check(lib.nk_sgemm_pair(dev.h, int(ta0), int(tb0), M0, N0, K0, A0.p, lda0, B0.p, ldb0, float(beta0), C0.p, ldc0,
+                            int(ta1), int(tb1), M1, N1, K1, A1.p, lda1, B1.p, ldb1, float(beta1), C1.p, ldc1))
+
+
+def sgemm_pair_batched(dev, batch_outer, batch_inner, p0, p1):
+    """p = (ta, tb, M, N, K, A, lda, sAo, sAi, B, ldb, sBo, sBi, beta, C, ldc, sCo, sCi)"""
+    def flat(q):
+        ta, tb, M, N, K, A, lda, sAo, sAi, B, ldb, sBo, sBi, beta, Cm, ldc, sCo, sCi = q
+        return [int(ta), int(tb), M, N, K, A.p, lda, sAo, sAi, B.p, ldb, sBo, sBi, float(beta), Cm.p, ldc, sCo, sCi]
+    check(lib.nk_sgemm_pair_batched(dev.h, batch_outer, batch_inner, *flat(p0), *flat(p1)))
 
 
 def mm_t_fwd(dev, A, B, out):

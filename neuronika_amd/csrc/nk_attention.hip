@@ -559,9 +559,9 @@ static int attention_bwd_impl(nk_device* dev, float* dQ, float* dK, float* dV, f
     // 128 x 32 tiles are single 16 KB runs for these products - was built and measured: kernel and products unchanged.)
     const int d = H * dh, SP = (S + 31) / 32 * 32;  // row stride of the scratch tensors (== S unless S is ragged)
     const long long so = (long long)S * d, sq = (long long)S * ld_qkv, po = (long long)H * SP * SP, pi = (long long)SP * SP;
-    rc = nk_sgemm_batched(dev, 1, 0, S, dh, S, 1.f, dS, SP, po, pi, Q, ld_qkv, sq, dh, assign_dk ? 0.f : 1.f, dK, ld_qkv, sq, dh, B, H);
-    if (rc) return rc;
-    return nk_sgemm_batched(dev, 1, 0, S, dh, S, 1.f, dropped, SP, po, pi, dO, d, so, dh, assign_dv ? 0.f : 1.f, dV, ld_qkv, sq, dh, B, H);
+    // (one launch for both when nk_sgemm_pair's rule says so: the two grids share their last wave of resident blocks)
+    return nk_sgemm_pair_batched(dev, B, H, 1, 0, S, dh, S, dS, SP, po, pi, Q, ld_qkv, sq, dh, assign_dk ? 0.f : 1.f, dK, ld_qkv, sq, dh,
+                                 1, 0, S, dh, S, dropped, SP, po, pi, dO, d, so, dh, assign_dv ? 0.f : 1.f, dV, ld_qkv, sq, dh);
 }
 int nk_attention_bwd(nk_device* dev, float* dQ, float* dK, float* dV, float* dS, float* dropped, const float* dO, const float* O,
                      const float* scores, const float* stats, const uint32_t* mask_bits, const float* Q, const float* K,

@@ -33,6 +33,7 @@ struct nk_device {
     int tune_gemm[6] = {0, 0, 0, 0, 0, 0};  // ti, tj, splits[, tiles per block[, tile-order group height[, look-ahead threshold]]]
     int tune_gemm_n = 0;                     // how many of them are set (< 3: the rules decide)
     int tune_kpair = -1;                     // k-pair blocks: -1 rule, 0 never, 1 lock-step groups, 2 skewed groups
+    int tune_pair = -1;                      // nk_sgemm_pair: -1 rule, 0 always two launches, 1 one launch whenever eligible
     int tune_attn_occ = 0;                   // attention forward: 2 = size the register budget for two blocks per CU
     // bench instrumentation (nk_profile_begin/end)
     bool prof_on = false;

@@ -8,6 +8,7 @@
 // per k-tile), XCD-aware tile order, split-K with a deterministic second pass when M*N alone
 // cannot fill the chip.
 #include "nk_mma.h"
+#include <utility>
 
 using namespace nkmma;
 
@@ -67,9 +68,9 @@ struct GemmArgs {
 // session l).  gemm_impl therefore takes the extended kernel where it is needed or faster (NT) and the plain one elsewhere.
 template <bool ALIGNED, int TI, int TJ, bool EPX>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[TI][TJ], int m0, int n0, int bo, int bi, int split,
-                                              int batch, int wr, int wc, int lane) {
+                                              int batch, int nbatch, int wr, int wc, int lane) {
     if (p.splits > 1) {
-        float* S = p.slabs + ((long long)split * gridDim.z + batch) * (long long)p.M * p.N;
+        float* S = p.slabs + ((long long)split * nbatch + batch) * (long long)p.M * p.N;
         const int M = p.M, N = p.N;
         acc_foreach<TI, TJ>(acc, wr, wc, lane, [&](int r, int c, float v) {
             const int row = m0 + r, col = n0 + c;
@@ -223,15 +224,20 @@ __device__ __forceinline__ void gemm_loop_lookahead2(TileLoader<AKC, 64 * TI>& l
 // launch gets from two resident blocks - without split-K's slabs and second pass.  The two groups share the block's
 // barriers (same trip count); with `kskew` group 1 issues the first half of a k-tile's MFMAs BEFORE its staging stores, so
 // that the two waves of a SIMD are not in their staging phase at the same time.
-template <bool TA, bool TB, bool ALIGNED, int TI, int TJ, int KG = 1, bool EPX = false>
-__global__ __launch_bounds__(NT * KG, (min_waves<TI, TJ, !TA && TB>())) void sgemm_kernel(GemmArgs p) {
+// floats of LDS one block of a given instantiation needs (both stages of every wave group)
+template <bool TA, bool TB, int TI, int TJ, int KG>
+constexpr int gemm_smem_floats() { return KG * 2 * (tile_floats<!TA, 64 * TI>() + tile_floats<TB, 64 * TJ>()); }
+
+// The whole block program of one GEMM launch, as a function of (block id, blocks of this problem, split, batch): sgemm_kernel
+// runs it on its own grid coordinates, sgemm_pair_kernel runs one of two problems per block.
+template <bool TA, bool TB, bool ALIGNED, int TI, int TJ, int KG, bool EPX>
+__device__ __forceinline__ void sgemm_body(const GemmArgs& p, float* smem_all, int bx, int nbx, int split, int batch, int nbatch) {
     constexpr int BM = 64 * TI, BN = 64 * TJ;
     constexpr bool AKC = !TA;  // A (M x K): k-contiguous unless stored transposed
     constexpr bool BKC = TB;   // B (K x N) stored as N x K when transposed -> k-contiguous
     constexpr int TA_FLOATS = tile_floats<AKC, BM>(), STAGE = TA_FLOATS + tile_floats<BKC, BN>();
     static_assert(KG == 1 || (ALIGNED && 2 * 2 * STAGE >= BM * BN), "k-pair: aligned problems; a group's images hold half a C tile");
     static_assert(KG * 2 * STAGE * sizeof(float) <= 160 * 1024, "the block's LDS images must fit the 160 KB of a gfx950 CU");
-    __shared__ __attribute__((aligned(16))) float smem_all[KG * 2 * STAGE];  // <= 73,728 B at 128x128 (k-pair: twice that)
 
     const int grp = KG == 2 ? (int)(threadIdx.x >> 8) : 0;  // NT == 256
     // (the mask is a no-op for the 256-thread blocks, but it tells the compiler the index has 8 bits - launch bounds do not: the
@@ -242,12 +248,11 @@ __global__ __launch_bounds__(NT * KG, (min_waves<TI, TJ, !TA && TB>())) void sge
     float* const smem = smem_all + grp * 2 * STAGE;
     const int wr = wid >> 1, wc = wid & 1;
     // this block's tiles: positions [seq, seq_end) of the tile sequence (each XCD gets a contiguous range of chunks)
-    int seq = xcd_chunk(blockIdx.x, gridDim.x) * p.chunk;
+    int seq = xcd_chunk(bx, nbx) * p.chunk;
     const int seq_end = min(p.tiles_m * p.tiles_n, seq + p.chunk);
     int tm, tn;
     tile_of_seq(seq, p.tiles_m, p.tiles_n, tm, tn, p.group_m);
     int m0 = tm * BM, n0 = tn * BN;
-    const int batch = blockIdx.z, split = blockIdx.y;
     const int bo = batch / p.batch_inner, bi = batch % p.batch_inner;
     const float* A = p.A + bo * p.sAo + bi * p.sAi;
     const float* B = p.B + bo * p.sBo + bi * p.sBi;
@@ -320,7 +325,7 @@ __global__ __launch_bounds__(NT * KG, (min_waves<TI, TJ, !TA && TB>())) void sge
             stage_store<AKC, BM>(nxt, ra, t);
             stage_store<BKC, BN>(nxt + TA_FLOATS, rb, t);
         }
-        gemm_epilogue<ALIGNED, TI, TJ, EPX>(p, acc, m0, n0, bo, bi, split, batch, wr, wc, lane);
+        gemm_epilogue<ALIGNED, TI, TJ, EPX>(p, acc, m0, n0, bo, bi, split, batch, nbatch, wr, wc, lane);
         if (!more) return;
         __syncthreads();  // the next tile's first k-tile is in LDS, everybody is done with the current buffer
         par ^= 1;
@@ -355,7 +360,7 @@ __global__ __launch_bounds__(NT * KG, (min_waves<TI, TJ, !TA && TB>())) void sge
                     const float4 v = slot[(j * 4 + q4) * 64];
                     acc[0][j][4 * q4] += v.x; acc[0][j][4 * q4 + 1] += v.y; acc[0][j][4 * q4 + 2] += v.z; acc[0][j][4 * q4 + 3] += v.w;
                 }
-            gemm_epilogue<ALIGNED, TI, TJ, EPX>(p, acc, m0, n0, bo, bi, split, batch, wr, wc, lane);
+            gemm_epilogue<ALIGNED, TI, TJ, EPX>(p, acc, m0, n0, bo, bi, split, batch, nbatch, wr, wc, lane);
             return;
         } else {
         static_assert(TI == 2, "k-pair: 128-row tiles swap halves");
@@ -379,11 +384,40 @@ __global__ __launch_bounds__(NT * KG, (min_waves<TI, TJ, !TA && TB>())) void sge
                 const float4 v = theirs_in[(j * 4 + q4) * 64];
                 keep[0][j][4 * q4] += v.x; keep[0][j][4 * q4 + 1] += v.y; keep[0][j][4 * q4 + 2] += v.z; keep[0][j][4 * q4 + 3] += v.w;
             }
-        gemm_epilogue<ALIGNED, 1, TJ, EPX>(p, keep, m0, n0, bo, bi, split, batch, wr * 2 + grp, wc, lane);
+        gemm_epilogue<ALIGNED, 1, TJ, EPX>(p, keep, m0, n0, bo, bi, split, batch, nbatch, wr * 2 + grp, wc, lane);
         return;
         }
     }
-    gemm_epilogue<ALIGNED, TI, TJ, EPX>(p, acc, m0, n0, bo, bi, split, batch, wr, wc, lane);
+    gemm_epilogue<ALIGNED, TI, TJ, EPX>(p, acc, m0, n0, bo, bi, split, batch, nbatch, wr, wc, lane);
+}
+
+template <bool TA, bool TB, bool ALIGNED, int TI, int TJ, int KG = 1, bool EPX = false>
+__global__ __launch_bounds__(NT * KG, (min_waves<TI, TJ, !TA && TB>())) void sgemm_kernel(GemmArgs p) {
+    __shared__ __attribute__((aligned(16))) float smem_all[gemm_smem_floats<TA, TB, TI, TJ, KG>()];  // <= 73,728 B at 128x128 (k-pair: twice that)
+    sgemm_body<TA, TB, ALIGNED, TI, TJ, KG, EPX>(p, smem_all, blockIdx.x, gridDim.x, blockIdx.y, blockIdx.z, gridDim.z);
+}
+
+// Two independent GEMMs in ONE launch: blocks [0, nblk0) run problem 0, the rest problem 1 (each with its own layout, same
+// tile shape).  For the two products of a MatMul node's backward pass (node/matrix_matrix_mul/mod.rs:63-105: dA += G.B^T and
+// dB += A^T.G read the same G) when neither fills the chip by itself: at 1024^3 / 2048^3 a launch is 256 blocks - one per CU,
+// a prologue, one wave of MFMAs and an epilogue with nothing else resident to hide them behind.  Two problems side by side
+// give every CU a second block (what a 4096^3 launch has) and pay the launch boundary, dispatch ramp and tail once; two large
+// grids (the dK / dV products of the attention backward) share their last, partly filled wave of resident blocks.
+// Aligned, unsplit, one tile per 256-thread block, plain epilogue (beta); every output is the SAME chain of fmas as in a
+// launch of its own without k-pair blocks - bit-identical.
+struct GemmPairArgs {
+    GemmArgs p0, p1;
+    int nblk0;
+};
+template <bool TA0, bool TB0, bool TA1, bool TB1, int TI, int TJ>
+__global__ __launch_bounds__(NT, (min_waves<TI, TJ, (!TA0 && TB0) || (!TA1 && TB1)>())) void sgemm_pair_kernel(GemmPairArgs pp) {
+    constexpr int F0 = gemm_smem_floats<TA0, TB0, TI, TJ, 1>(), F1 = gemm_smem_floats<TA1, TB1, TI, TJ, 1>();
+    __shared__ __attribute__((aligned(16))) float smem_all[F0 > F1 ? F0 : F1];
+    const int nblk0 = pp.nblk0;
+    if ((int)blockIdx.x < nblk0)
+        sgemm_body<TA0, TB0, true, TI, TJ, 1, false>(pp.p0, smem_all, blockIdx.x, nblk0, 0, blockIdx.z, gridDim.z);
+    else
+        sgemm_body<TA1, TB1, true, TI, TJ, 1, false>(pp.p1, smem_all, blockIdx.x - nblk0, gridDim.x - nblk0, 0, blockIdx.z, gridDim.z);
 }
 
 // Second pass of split-K: C = alpha * sum_s slab[s] + beta * C, fixed summation order.
@@ -470,15 +504,24 @@ static int launch(nk_device* dev, const GemmArgs& p, int nbatch, bool aligned, i
     return epx ? launch_epx<TA, TB, true>(dev, p, nbatch, aligned, ti, tj, kg) : launch_epx<TA, TB, false>(dev, p, nbatch, aligned, ti, tj, kg);
 }
 
-static int gemm_impl(nk_device* dev, int transA, int transB, int M, int N, int K, float alpha,
+// What gemm_impl decided for one problem: the kernel arguments and the instantiation (tile shape, k-pair, aligned loads).
+struct GemmPlan {
+    GemmArgs p;
+    int ti, tj, kg, nbatch;
+    bool aligned, empty;
+};
+
+static int gemm_plan(nk_device* dev, int transA, int transB, int M, int N, int K, float alpha,
                      const float* A, int lda, long long sAo, long long sAi, const float* B, int ldb,
                      long long sBo, long long sBi, float beta, float* C, int ldc, long long sCo,
-                     long long sCi, int batch_outer, int batch_inner, const float* bias = nullptr, int relu = 0,
-                     const float* mask = nullptr, long long ldm = 0) {
+                     long long sCi, int batch_outer, int batch_inner, const float* bias, int relu,
+                     const float* mask, long long ldm, GemmPlan* plan, bool allow_kpair = true) {
     NK_USE(dev);
     NK_CHECK(M >= 0 && N >= 0 && K >= 0 && batch_outer >= 0 && batch_inner >= 0, "negative GEMM extent");
     const int nbatch = batch_outer * batch_inner;
-    if (M == 0 || N == 0 || nbatch == 0) return NK_OK;
+    plan->empty = M == 0 || N == 0 || nbatch == 0;
+    plan->nbatch = nbatch;
+    if (plan->empty) return NK_OK;
     NK_CHECK(A && B && C, "null GEMM operand");
     NK_CHECK(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N,
              "leading dimension too small (lda=%d ldb=%d ldc=%d)", lda, ldb, ldc);
@@ -612,7 +655,7 @@ static int gemm_impl(nk_device* dev, int transA, int transB, int M, int N, int K
     // block, and a grid of at most ONE BLOCK PER CU - with more blocks than CUs two 256-thread blocks share a CU anyway.
     // (its two groups' LDS images, 131 - 147 KB, assume the 160 KB of a gfx950 CU: static_assert in sgemm_kernel.)
     // NK_TUNE_GEMM_KPAIR = 0 (never) / 1 (lock-step groups) / 2 (group 1 half a k-tile out of phase) overrides for sweeps.
-    const int kpair_tune = dev->tune_kpair;
+    const int kpair_tune = allow_kpair ? dev->tune_kpair : 0;
     int kg = 1;
     p.kskew = 1;
     {
@@ -624,13 +667,29 @@ static int gemm_impl(nk_device* dev, int transA, int transB, int M, int N, int K
         if (can && want) kg = 2;
         if (kpair_tune == 1) p.kskew = 0;
     }
+    plan->p = p; plan->ti = ti; plan->tj = tj; plan->kg = kg; plan->aligned = aligned;
+    return NK_OK;
+}
+
+static int gemm_impl(nk_device* dev, int transA, int transB, int M, int N, int K, float alpha,
+                     const float* A, int lda, long long sAo, long long sAi, const float* B, int ldb,
+                     long long sBo, long long sBi, float beta, float* C, int ldc, long long sCo,
+                     long long sCi, int batch_outer, int batch_inner, const float* bias = nullptr, int relu = 0,
+                     const float* mask = nullptr, long long ldm = 0) {
+    GemmPlan plan;
+    int rc = gemm_plan(dev, transA, transB, M, N, K, alpha, A, lda, sAo, sAi, B, ldb, sBo, sBi, beta, C, ldc, sCo, sCi, batch_outer,
+                       batch_inner, bias, relu, mask, ldm, &plan);
+    if (rc || plan.empty) return rc;
+    GemmArgs& p = plan.p;
+    const int nbatch = plan.nbatch, ti = plan.ti, tj = plan.tj, kg = plan.kg;
+    const bool aligned = plan.aligned;
     if (p.splits > 1) {
         void* ws = nullptr;
-        int rc = nk_workspace(dev, (size_t)p.splits * nbatch * M * N * sizeof(float), &ws);
+        rc = nk_workspace(dev, (size_t)p.splits * nbatch * M * N * sizeof(float), &ws);
         if (rc) return rc;
         p.slabs = (float*)ws;
     }
-    int rc = nk_prof_start(dev, NK_KERNEL_SGEMM, 2.0 * M * N * (double)K * nbatch);
+    rc = nk_prof_start(dev, NK_KERNEL_SGEMM, 2.0 * M * N * (double)K * nbatch);
     if (rc) return rc;
     if (!transA && !transB) rc = launch<false, false>(dev, p, nbatch, aligned, ti, tj, kg);
     else if (!transA && transB) rc = launch<false, true>(dev, p, nbatch, aligned, ti, tj, kg);
@@ -650,6 +709,111 @@ static int gemm_impl(nk_device* dev, int transA, int transB, int M, int N, int K
                            sCo, sCi, alpha, beta, bias, relu, mask, ldm);
         NK_LAUNCH_CHECK();
     }
+    return nk_prof_stop(dev);
+}
+
+// ---- two problems, one launch (sgemm_pair_kernel) -----------------------------------------------------------------------
+struct GemmProblem {
+    int transA, transB, M, N, K;
+    const float* A; int lda; long long sAo, sAi;
+    const float* B; int ldb; long long sBo, sBi;
+    float beta; float* C; int ldc; long long sCo, sCi;
+};
+
+template <bool TA0, bool TB0>
+static int launch_pair(nk_device* dev, const GemmPairArgs& pp, dim3 grid, int ti, int tj) {
+    if (ti == 2 && tj == 2) hipLaunchKernelGGL((sgemm_pair_kernel<TA0, TB0, true, false, 2, 2>), grid, dim3(NT), 0, dev->compute, pp);
+    else if (ti == 2 && tj == 1) hipLaunchKernelGGL((sgemm_pair_kernel<TA0, TB0, true, false, 2, 1>), grid, dim3(NT), 0, dev->compute, pp);
+    else hipLaunchKernelGGL((sgemm_pair_kernel<TA0, TB0, true, false, 1, 1>), grid, dim3(NT), 0, dev->compute, pp);
+    NK_LAUNCH_CHECK();
+    return NK_OK;
+}
+
+// C0 = op(A0).op(B0) + beta0*C0 and C1 = op(A1).op(B1) + beta1*C1, each over the same two-level batch.  One launch when the
+// pair is eligible (see sgemm_pair_kernel: aligned, unsplit, equal tile shapes, second product TN) and - by rule - when it
+// saves a wave of resident blocks: the two grids together fit the resident slots (two launches would each leave CUs without a
+// second block), or their two partly filled last waves fold into one.  Two ordinary launches otherwise.
+static int gemm_pair_impl(nk_device* dev, const GemmProblem& a, const GemmProblem& b, int batch_outer, int batch_inner) {
+    NK_USE(dev);
+    auto alone = [&](const GemmProblem& q) {
+        return gemm_impl(dev, q.transA, q.transB, q.M, q.N, q.K, 1.f, q.A, q.lda, q.sAo, q.sAi, q.B, q.ldb, q.sBo, q.sBi, q.beta, q.C, q.ldc,
+                         q.sCo, q.sCi, batch_outer, batch_inner);
+    };
+    auto two_launches = [&]() { const int rc = alone(a); return rc ? rc : alone(b); };
+    const int mode = dev->tune_pair;  // -1 rule, 0 never, 1 whenever eligible
+    if (mode == 0) return two_launches();
+    // the plans of 256-thread blocks (a k-pair block is a launch's way to a second wave per SIMD; the pair has the other problem)
+    GemmPlan q0, q1;
+    int rc = gemm_plan(dev, a.transA, a.transB, a.M, a.N, a.K, 1.f, a.A, a.lda, a.sAo, a.sAi, a.B, a.ldb, a.sBo, a.sBi, a.beta, a.C, a.ldc,
+                       a.sCo, a.sCi, batch_outer, batch_inner, nullptr, 0, nullptr, 0, &q0, false);
+    if (!rc)
+        rc = gemm_plan(dev, b.transA, b.transB, b.M, b.N, b.K, 1.f, b.A, b.lda, b.sAo, b.sAi, b.B, b.ldb, b.sBo, b.sBi, b.beta, b.C, b.ldc,
+                       b.sCo, b.sCi, batch_outer, batch_inner, nullptr, 0, nullptr, 0, &q1, false);
+    if (rc) return rc;
+    if (q0.empty || q1.empty) return two_launches();
+    const long long batch = (long long)batch_outer * batch_inner;
+    {   // One launch runs the problems concurrently: an output that overlaps the other problem's output or operands (x.mm(x):
+        // both gradients are one buffer) keeps the order of two launches.  An operand's footprint is `rows` runs of `width`
+        // floats, `ld` apart (heads that are column blocks of one matrix widen the run; samples stack rows); two footprints
+        // with the same `ld` are also disjoint when their column ranges are (dK and dV are column blocks of the packed
+        // projection gradient).
+        struct Foot { const float* p; long long rows, width, ld; bool ok; };
+        auto foot = [&](const float* p, long long rows, long long cols, long long ld, long long so, long long si) {
+            Foot f{p, rows, cols, ld, true};
+            if (batch_inner > 1) {
+                if (si < ld) f.width = cols + (batch_inner - 1) * si;
+                else if (si % ld == 0) f.rows = rows + (batch_inner - 1) * (si / ld);
+                else f.ok = false;
+            }
+            if (batch_outer > 1) {
+                if (so % ld == 0) f.rows += (batch_outer - 1) * (so / ld);
+                else f.ok = false;
+            }
+            if (f.width > ld) f.ok = false;
+            if (!f.ok) { f.rows = 1; f.ld = 0; f.width = (batch_outer - 1) * so + (batch_inner - 1) * si + (rows - 1) * ld + cols; }
+            return f;
+        };
+        auto opnd = [&](const GemmProblem& q, int which) {
+            if (which == 0) return foot(q.A, q.transA ? q.K : q.M, q.transA ? q.M : q.K, q.lda, q.sAo, q.sAi);
+            if (which == 1) return foot(q.B, q.transB ? q.N : q.K, q.transB ? q.K : q.N, q.ldb, q.sBo, q.sBi);
+            return foot(q.C, q.M, q.N, q.ldc, q.sCo, q.sCi);
+        };
+        auto hits = [](const Foot& x, const Foot& y) {
+            const uintptr_t x0 = (uintptr_t)x.p, x1 = (uintptr_t)(x.p + (x.rows - 1) * x.ld + x.width);
+            const uintptr_t y0 = (uintptr_t)y.p, y1 = (uintptr_t)(y.p + (y.rows - 1) * y.ld + y.width);
+            if (!(x0 < y1 && y0 < x1)) return false;  // the address ranges do not meet
+            if (x.ok && y.ok && x.ld == y.ld && x.ld > 0) {
+                const long long ld = x.ld, r = ((y.p - x.p) % ld + ld) % ld;  // y's first column relative to x's
+                if (r >= x.width && r + y.width <= ld) return false;          // disjoint column blocks of rows `ld` apart
+            }
+            return true;
+        };
+        bool clash = false;
+        for (int w = 0; w < 3; ++w) clash = clash || hits(opnd(a, 2), opnd(b, w)) || hits(opnd(b, 2), opnd(a, w));
+        if (clash) return two_launches();
+    }
+    const bool layouts = !(a.transA && a.transB) && b.transA && !b.transB;  // (NN | NT | TN) + TN
+    const bool tiles = q0.ti == q1.ti && q0.tj == q1.tj && (q0.ti == q0.tj || (q0.ti == 2 && q0.tj == 1));
+    const bool plain = q0.aligned && q1.aligned && q0.p.splits == 1 && q1.p.splits == 1 && q0.p.chunk == 1 && q1.p.chunk == 1;
+    if (!(layouts && tiles && plain)) return two_launches();
+    const long long nblk0 = (long long)q0.p.tiles_m * q0.p.tiles_n, nblk1 = (long long)q1.p.tiles_m * q1.p.tiles_n;
+    if (nblk0 + nblk1 > 0x7fffffffLL) return two_launches();
+    if (mode < 0) {
+        // resident 256-thread blocks per CU (min_waves): 2 at 128x128, 3 (2 with two padded images) at 128x64, 4 at 64x64
+        const int per_cu = q0.ti * q0.tj == 4 ? 2 : (q0.ti * q0.tj == 2 ? ((!a.transA && a.transB) ? 2 : 3) : 4);
+        const long long slots = (long long)dev->num_cus * per_cu, n0 = nblk0 * batch, n1 = nblk1 * batch;
+        const long long waves_two = (n0 + slots - 1) / slots + (n1 + slots - 1) / slots, waves_one = (n0 + n1 + slots - 1) / slots;
+        if (waves_one >= waves_two) return two_launches();  // 4096^3: 2 + 2 full waves either way, and two launches measure 0.5 % faster
+    }
+    GemmPairArgs pp;
+    pp.p0 = q0.p; pp.p1 = q1.p; pp.nblk0 = (int)nblk0;
+    rc = nk_prof_start(dev, NK_KERNEL_SGEMM, 2.0 * batch * ((double)a.M * a.N * a.K + (double)b.M * b.N * b.K));
+    if (rc) return rc;
+    const dim3 grid((unsigned)(nblk0 + nblk1), 1, (unsigned)batch);
+    if (a.transA) rc = launch_pair<true, false>(dev, pp, grid, q0.ti, q0.tj);
+    else if (a.transB) rc = launch_pair<false, true>(dev, pp, grid, q0.ti, q0.tj);
+    else rc = launch_pair<false, false>(dev, pp, grid, q0.ti, q0.tj);
+    if (rc) return rc;
     return nk_prof_stop(dev);
 }
 
@@ -677,6 +841,32 @@ int nk_mm_bwd_left(nk_device* dev, float* dA, const float* G, const float* B, in
 }
 int nk_mm_bwd_right(nk_device* dev, float* dB, const float* A, const float* G, int n, int m, int o) {
     return nk_sgemm(dev, 1, 0, m, o, n, 1.f, A, m, G, o, 1.f, dB, o);  // dB += A^T . G
+}
+int nk_sgemm_pair(nk_device* dev, int transA0, int transB0, int M0, int N0, int K0, const float* A0, int lda0, const float* B0, int ldb0,
+                  float beta0, float* C0, int ldc0, int transA1, int transB1, int M1, int N1, int K1, const float* A1, int lda1,
+                  const float* B1, int ldb1, float beta1, float* C1, int ldc1) {
+    const GemmProblem a{transA0, transB0, M0, N0, K0, A0, lda0, 0, 0, B0, ldb0, 0, 0, beta0, C0, ldc0, 0, 0};
+    const GemmProblem b{transA1, transB1, M1, N1, K1, A1, lda1, 0, 0, B1, ldb1, 0, 0, beta1, C1, ldc1, 0, 0};
+    return gemm_pair_impl(dev, a, b, 1, 1);
+}
+int nk_sgemm_pair_batched(nk_device* dev, int batch_outer, int batch_inner,
+                          int transA0, int transB0, int M0, int N0, int K0, const float* A0, int lda0, long long sA0o, long long sA0i,
+                          const float* B0, int ldb0, long long sB0o, long long sB0i, float beta0, float* C0, int ldc0, long long sC0o, long long sC0i,
+                          int transA1, int transB1, int M1, int N1, int K1, const float* A1, int lda1, long long sA1o, long long sA1i,
+                          const float* B1, int ldb1, long long sB1o, long long sB1i, float beta1, float* C1, int ldc1, long long sC1o, long long sC1i) {
+    const GemmProblem a{transA0, transB0, M0, N0, K0, A0, lda0, sA0o, sA0i, B0, ldb0, sB0o, sB0i, beta0, C0, ldc0, sC0o, sC0i};
+    const GemmProblem b{transA1, transB1, M1, N1, K1, A1, lda1, sA1o, sA1i, B1, ldb1, sB1o, sB1i, beta1, C1, ldc1, sC1o, sC1i};
+    return gemm_pair_impl(dev, a, b, batch_outer, batch_inner);
+}
+// MatrixMatrixMulBackward::backward (both operands differentiable): dA (+)= G . B^T and dB (+)= A^T . G
+int nk_mm_bwd(nk_device* dev, float* dA, float* dB, const float* G, const float* A, const float* B, int n, int m, int o, int assign_a,
+              int assign_b) {
+    return nk_sgemm_pair(dev, 0, 1, n, m, o, G, o, B, o, assign_a ? 0.f : 1.f, dA, m, 1, 0, m, o, n, A, m, G, o, assign_b ? 0.f : 1.f, dB, o);
+}
+// MatrixMatrixMulTBackward::backward: dA (+)= G . B and dB (+)= G^T . A, B is (o, m)
+int nk_mm_t_bwd(nk_device* dev, float* dA, float* dB, const float* G, const float* A, const float* B, int n, int m, int o, int assign_a,
+                int assign_b) {
+    return nk_sgemm_pair(dev, 0, 0, n, m, o, G, o, B, m, assign_a ? 0.f : 1.f, dA, m, 1, 0, o, m, n, G, o, A, m, assign_b ? 0.f : 1.f, dB, m);
 }
 int nk_mm_t_fwd(nk_device* dev, const float* A, const float* B, float* C, int n, int m, int o) {
     return nk_sgemm(dev, 0, 1, n, o, m, 1.f, A, m, B, m, 0.f, C, o);  // C = A . B^T, B is (o,m)

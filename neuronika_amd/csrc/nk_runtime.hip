@@ -166,6 +166,10 @@ int nk_dev_tune(nk_device* dev, int knob, const int* values, int n) {
             NK_CHECK(n <= 1 && (n == 0 || (values[0] >= -1 && values[0] <= 2)), "NK_TUNE_GEMM_KPAIR: -1, 0, 1 or 2");
             dev->tune_kpair = n ? values[0] : -1;
             return NK_OK;
+        case NK_TUNE_GEMM_PAIR:
+            NK_CHECK(n <= 1 && (n == 0 || (values[0] >= -1 && values[0] <= 1)), "NK_TUNE_GEMM_PAIR: -1, 0 or 1");
+            dev->tune_pair = n ? values[0] : -1;
+            return NK_OK;
         case NK_TUNE_ATTENTION_OCC:
             NK_CHECK(n <= 1 && (n == 0 || values[0] == 0 || values[0] == 2), "NK_TUNE_ATTENTION_OCC: 0 or 2");
             dev->tune_attn_occ = n ? values[0] : 0;

@@ -629,6 +629,114 @@ def test_C2_matmul_fwd_bwd_every_benchmark_size(dev, n):
         del got
 
 
+@pytest.mark.parametrize("node", ["mm", "mm_t"])
+@pytest.mark.parametrize("n,m,o", [(1024, 1024, 1024), (512, 1024, 256), (256, 256, 2048), (2048, 2048, 2048), (384, 640, 896),
+                                   (100, 70, 50), (64, 64, 64)])
+def test_mm_backward_as_one_call(dev, node, n, m, o):
+    """nk_mm_bwd / nk_mm_t_bwd (MatrixMatrixMulBackward::backward, matrix_matrix_mul/mod.rs:121-126 and the MatMulT twin: both
+    products of the node in one call, ONE launch of sgemm_pair_kernel when the pair is eligible) against the two single-product
+    entry points: every output must be the same fma chain as in a launch of its own without k-pair blocks, so the forced one
+    launch (mode 1) is BIT-identical to two launches under NK_TUNE_GEMM_KPAIR = 0; the rule (mode -1) equals either that or the
+    two launches under the k-pair rule; ragged shapes fall back to two launches; `+=` on a non-zero gradient and the assign
+    form; and the f64 oracle."""
+    c = capi()
+    a = rnd(1, (n, m))
+    b = rnd(2, (m, o) if node == "mm" else (o, m))
+    g = rnd(3, (n, o))
+    A, B, G = dev.array(a), dev.array(b), dev.array(g)
+    fn = c.mm_bwd if node == "mm" else c.mm_t_bwd
+    left = c.mm_bwd_left if node == "mm" else c.mm_t_bwd_left
+
+    def right(dB):
+        if node == "mm": c.mm_bwd_right(dev, dB, A, G)
+        else: c.mm_t_bwd_right(dev, dB, G, A)
+
+    def run(pair_mode, kpair, assign):
+        dev.gemm_pair(pair_mode); dev.gemm_kpair(kpair)
+        try:
+            dA, dB = dev.full(a.shape, 0.5), dev.full(b.shape, -0.25)
+            if pair_mode is False:       # the two single-product entry points (`+=` only)
+                left(dev, dA, G, B); right(dB)
+            else:
+                fn(dev, dA, dB, G, A, B, assign, assign)
+            return dA.numpy(), dB.numpy()
+        finally:
+            dev.gemm_pair(None); dev.gemm_kpair(None)
+
+    same = lambda x, y: all(np.array_equal(u, v) for u, v in zip(x, y))
+    for assign in (False, True):
+        two_rule, two_plain = run(0, None, assign), run(0, 0, assign)
+        assert same(run(1, None, assign), two_plain)
+        rule = run(-1, None, assign)
+        assert same(rule, two_rule) or same(rule, two_plain)
+    assert same(run(False, None, False), run(0, None, False))
+    a64, b64, g64 = a.astype(np.float64), b.astype(np.float64), g.astype(np.float64)
+    want_a = 0.5 + (g64 @ b64.T if node == "mm" else g64 @ b64)
+    want_b = -0.25 + (a64.T @ g64 if node == "mm" else g64.T @ a64)
+    got_a, got_b = run(-1, None, False)
+    assert np.abs(got_a - want_a).max() <= 1e-6 * o * np.abs(g).max() * np.abs(b).max() + 1e-6
+    assert np.abs(got_b - want_b).max() <= 1e-6 * n * np.abs(g).max() * np.abs(a).max() + 1e-6
+
+
+@pytest.mark.parametrize("packed", [False, True])
+def test_batched_pair_equals_two_batched_launches(dev, packed):
+    """nk_sgemm_pair_batched on the geometry of the attention backward's dK / dV products (TN + TN over (sample, head), heads as
+    column blocks): bit-identical to two nk_sgemm_batched launches, forced and by rule, also when the two outputs are column
+    blocks of ONE buffer (the packed projection gradient: their address ranges interleave, their elements do not)."""
+    c = capi()
+    Bn, H, S, dh = 2, 4, 256, 64
+    d = H * dh
+    ld = 3 * d if packed else d
+    ds, pd = rnd(1, (Bn * H, S, S), -1, 1), rnd(2, (Bn * H, S, S))
+    q, do = rnd(3, (Bn * S, ld), -1, 1), rnd(4, (Bn * S, d), -1, 1)
+    DS, PD, Q, DO = dev.array(ds), dev.array(pd), dev.array(q), dev.array(do)
+    so, sq, po, pi = S * d, S * ld, H * S * S, S * S
+    outs = []
+    for mode in (0, 1, -1):
+        dev.gemm_pair(mode)
+        try:
+            buf = dev.full((Bn * S, ld if packed else 2 * d), 0.25)   # packed: [ . | dK | dV ] column blocks; else two halves of the rows' columns
+            if packed:
+                dK, dV, ldo, sqo = buf.view_offset(d), buf.view_offset(2 * d), ld, sq
+            else:
+                dK, dV, ldo, sqo = buf.view_offset(0), buf.view_offset(d), 2 * d, S * 2 * d
+            c.sgemm_pair_batched(dev, Bn, H, (1, 0, S, dh, S, DS, S, po, pi, Q, ld, sq, dh, 1.0, dK, ldo, sqo, dh),
+                                 (1, 0, S, dh, S, PD, S, po, pi, DO, d, so, dh, 1.0, dV, ldo, sqo, dh))
+            outs.append(buf.numpy())
+        finally:
+            dev.gemm_pair(None)
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    got = outs[0].reshape(Bn, S, -1)
+    k0 = d if packed else 0
+    for bb in range(Bn):
+        for h in range(H):
+            wk = 0.25 + ds[bb * H + h].astype(np.float64).T @ q[bb * S:(bb + 1) * S, h * dh:(h + 1) * dh].astype(np.float64)
+            wv = 0.25 + pd[bb * H + h].astype(np.float64).T @ do[bb * S:(bb + 1) * S, h * dh:(h + 1) * dh].astype(np.float64)
+            close(got[bb, :, k0 + h * dh:k0 + (h + 1) * dh], wk, rtol=1e-5, atol=1e-6 * S)
+            close(got[bb, :, k0 + d + h * dh:k0 + d + (h + 1) * dh], wv, rtol=1e-5, atol=1e-6 * S)
+
+
+def test_mm_backward_one_call_keeps_order_on_aliased_gradients(dev):
+    """x.mm(x): both products accumulate into ONE gradient buffer.  Two launches on a stream are ordered; one launch would run
+    them concurrently - nk_sgemm_pair must notice the overlap and launch twice (forced mode 1 included)."""
+    c = capi()
+    n = 256
+    a, g = rnd(1, (n, n)), rnd(2, (n, n))
+    A, G = dev.array(a), dev.array(g)
+    outs = []
+    for mode in (0, 1, -1):
+        dev.gemm_pair(mode)
+        try:
+            D = dev.full((n, n), 0.125)
+            c.mm_bwd(dev, D, D, G, A, A)
+            outs.append(D.numpy())
+        finally:
+            dev.gemm_pair(None)
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    a64, g64 = a.astype(np.float64), g.astype(np.float64)
+    close(outs[0], 0.125 + g64 @ a64.T + a64.T @ g64, rtol=1e-5, atol=1e-6 * n)
+
+
 # ------------------------------------------------------------------------------ binaries
 BCAST = [((64, 96), (96,)), ((96,), (64, 96)), ((2, 2, 3), (1, 3)), ((1, 3), (2, 2, 3)), ((4, 8, 5, 6), (8, 1, 1)),
          ((7, 5), ()), ((33, 1), (1, 17)), ((2, 3, 1, 5, 2), (3, 4, 1, 2)), ((512, 1024), (512, 1024)), ((5, 7), (5, 7))]
