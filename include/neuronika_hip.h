@@ -161,17 +161,17 @@ int nk_sgemm_batched(nk_device* dev, int transA, int transB, int M, int N, int K
 
 /* Two independent products in ONE launch: C0 = op(A0).op(B0) + beta0*C0 and C1 = op(A1).op(B1) + beta1*C1 (alpha = 1).  When
  * neither product fills the chip by itself (1024^3: 256 blocks, one per CU) the two grids run side by side - every CU gets the
- * second resident block a large launch has, and launch boundary, dispatch ramp and tail are paid once; two large grids share
- * their last, partly filled wave of resident blocks.  Taken by rule for aligned, unsplit (NN | NT | TN) + TN pairs of equal
- * tile shape when it saves a wave of resident blocks; two ordinary launches otherwise (and whenever an output overlaps the other
- * product's output or operands).  Every output is the fma chain nk_sgemm gives it without k-pair blocks (NK_TUNE_GEMM_KPAIR = 0):
+ * second resident block a large launch has, and launch boundary, dispatch ramp and tail are paid once.  Taken by rule for
+ * aligned, unsplit (NN | NT | TN) + TN pairs of equal tile shape whose blocks together fit the chip's resident slots; two
+ * ordinary launches otherwise (and whenever an output overlaps the other product's output or operands).  Every output is the fma chain nk_sgemm gives it without k-pair blocks (NK_TUNE_GEMM_KPAIR = 0):
  * bit-identical to two calls under that setting. */
 int nk_sgemm_pair(nk_device* dev,
                   int transA0, int transB0, int M0, int N0, int K0, const float* A0, int lda0, const float* B0, int ldb0,
                   float beta0, float* C0, int ldc0,
                   int transA1, int transB1, int M1, int N1, int K1, const float* A1, int lda1, const float* B1, int ldb1,
                   float beta1, float* C1, int ldc1);
-/* ... over a two-level batch (nk_sgemm_batched's strides, per operand): the dK / dV products of the attention backward */
+/* ... over a two-level batch (nk_sgemm_batched's strides, per operand): the dK / dV products of the attention backward (one
+ * launch at small batch x heads; C5's 2 x 4096 blocks measure 0.5 - 1 % faster as two launches and stay two) */
 int nk_sgemm_pair_batched(nk_device* dev, int batch_outer, int batch_inner,
                           int transA0, int transB0, int M0, int N0, int K0, const float* A0, int lda0, long long sA0o, long long sA0i,
                           const float* B0, int ldb0, long long sB0o, long long sB0i, float beta0, float* C0, int ldc0,

@@ -594,7 +594,7 @@ impl HipVarDiff<Ix2> {
         let grad = Rc::new(Gradient::hip_zeros(var.data.borrow().dimension(), var.device()));
         let left = MatrixMatrixMulBackwardLeft::new(right_data, self.grad.clone(), grad.clone());
         let right = MatrixMatrixMulBackwardRight::new(left_data, rhs.grad.clone(), grad.clone());
-        let op: Rc<dyn Backward> = Rc::new(Pair(left, right));
+        let op: Rc<dyn Backward> = Rc::new(MatrixMatrixMulBackward::new(left, right));
         HipVarDiff::node(var, grad.clone(), (op, grad), self.history)
     }
 
@@ -606,7 +606,7 @@ impl HipVarDiff<Ix2> {
         let grad = Rc::new(Gradient::hip_zeros(var.data.borrow().dimension(), var.device()));
         let left = MatrixMatrixMulTBackwardLeft::new(right_data, self.grad.clone(), grad.clone());
         let right = MatrixMatrixMulTBackwardRight::new(left_data, rhs.grad.clone(), grad.clone());
-        let op: Rc<dyn Backward> = Rc::new(Pair(left, right));
+        let op: Rc<dyn Backward> = Rc::new(MatrixMatrixMulTBackward::new(left, right));
         HipVarDiff::node(var, grad.clone(), (op, grad), self.history)
     }
 

@@ -88,3 +88,36 @@ impl Backward for MatrixMatrixMulTBackwardRight {
         vec![grad_id(&self.right_gradient)]
     }
 }
+
+/// `MatrixMatrixMulTBackward` (`:107-126`): both halves as ONE call of `nk_mm_t_bwd` (see `MatrixMatrixMulBackward`).
+pub(crate) struct MatrixMatrixMulTBackward {
+    left: MatrixMatrixMulTBackwardLeft,
+    right: MatrixMatrixMulTBackwardRight,
+}
+
+impl MatrixMatrixMulTBackward {
+    pub(crate) fn new(left: MatrixMatrixMulTBackwardLeft, right: MatrixMatrixMulTBackwardRight) -> Self {
+        Self { left, right }
+    }
+}
+
+impl Backward for MatrixMatrixMulTBackward {
+    fn backward(&self) {
+        if Rc::ptr_eq(&self.left.left_gradient, &self.right.right_gradient) {
+            self.left.backward();
+            self.right.backward();
+            return;
+        }
+        let g = self.left.gradient.borrow();
+        let (a, b) = (self.right.left_data.borrow(), self.left.right_data.borrow());
+        let (mut da, mut db) = (self.left.left_gradient.borrow_mut(), self.right.right_gradient.borrow_mut());
+        let (n, m, o) = (a.dimension()[0] as i32, a.dimension()[1] as i32, b.dimension()[0] as i32);
+        ffi::check(unsafe {
+            ffi::nk_mm_t_bwd(g.device().as_raw(), da.as_mut_ptr(), db.as_mut_ptr(), g.as_ptr(), a.as_ptr(), b.as_ptr(), n, m, o, 0, 0)
+        });
+    }
+
+    fn targets(&self) -> Vec<usize> {
+        vec![grad_id(&self.left.left_gradient), grad_id(&self.right.right_gradient)]
+    }
+}

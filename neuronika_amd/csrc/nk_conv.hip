@@ -521,14 +521,12 @@ int conv_bwd_kernel(nk_device* dev, int nd, float* dw, const int* w_shape, const
     }
 #undef NK_LAUNCH_BWK
     NK_LAUNCH_CHECK();
-    hipLaunchKernelGGL(conv_dw_reduce_kernel, dim3((unsigned)((dw_elems + 63) / 64)), dim3(256), 0, dev->compute, dw,
-                       p.slabs, dw_elems, (int)splits, assign);
+    // dW (+)= sum over splits (fixed order) of the slabs; with the fused bias gradient db[co] (+)= the per-split sums' sum, by the
+    // blocks behind the dW ones in the same launch
+    hipLaunchKernelGGL(conv_dw_reduce_kernel, dim3((unsigned)((dw_elems + 63) / 64 + (fused_bias ? (g.Cout + 63) / 64 : 0))), dim3(256), 0,
+                       dev->compute, dw, p.slabs, dw_elems, (int)splits, assign, fused_bias ? db : nullptr, p.bias_slabs,
+                       (long long)g.Cout, assign_b);
     NK_LAUNCH_CHECK();
-    if (fused_bias) {  // db[co] (+)= sum over splits (fixed order) of the per-split sums
-        hipLaunchKernelGGL(conv_dw_reduce_kernel, dim3((unsigned)((g.Cout + 63) / 64)), dim3(256), 0, dev->compute, db, p.bias_slabs,
-                           (long long)g.Cout, (int)splits, assign_b);
-        NK_LAUNCH_CHECK();
-    }
     rc = nk_prof_stop(dev);
     if (rc) return rc;
     return fused_bias ? NK_OK : bias_by_reduction();

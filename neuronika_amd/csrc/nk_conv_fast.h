@@ -92,6 +92,19 @@ __global__ void conv_wq_tables_kernel(float* __restrict__ wq, const float* __res
             for (int i = 0; i < MAX_PHASES; ++i) phases[i] = tbl.ph[i];
         }
     }
+    // every block first works out the KK taps' positions once (KK threads, a loop over KK each) into LDS; its elements then look
+    // their tap up (each thread running the loop for its own element made this launch 10.7 us at C3 - 9 taps, 73,728 weights -
+    // against 4.8 for the forward's re-ordering of the same tensor)
+    constexpr int TAPS_IN_LDS = 512;
+    __shared__ int4 tp_s[TAPS_IN_LDS];
+    const bool in_lds = g.KK <= TAPS_IN_LDS;
+    if (in_lds) {
+        for (int tap = threadIdx.x; tap < g.KK; tap += blockDim.x) {
+            int kd[3];
+            tp_s[tap] = tap_position(g, tap, kd);
+        }
+        __syncthreads();
+    }
     const long long total = (long long)g.Cout * g.Cg * g.KK;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {  // i = source index ((grp*Mg + co)*Cg + ci)*KK + tap
@@ -101,7 +114,7 @@ __global__ void conv_wq_tables_kernel(float* __restrict__ wq, const float* __res
         const int co = (int)(rem % g.Mg);
         const int grp = (int)(rem / g.Mg);
         int kd[3];
-        const int4 tp = tap_position(g, tap, kd);
+        const int4 tp = in_lds ? tp_s[tap] : tap_position(g, tap, kd);
         const int chunk = co / BK, c32 = co - chunk * BK;
         wq[((long long)grp * g.Cg + ci) * ((long long)g.Mg * g.KK) + (long long)g.Mg * tp.x + (chunk * tp.y + tp.z) * BK + c32] = w[i];
     }

@@ -530,10 +530,18 @@ __global__ __launch_bounds__(NT, 2) void conv_bwd_kernel_kernel(BwdKArgs p) {
 // dW[i] += sum_s slabs[s][i].  64 elements x 4 split-lanes per block (lane j sums splits j, j+4, ... with two independent
 // accumulators), folded through LDS in a fixed order: `splits/4` loads deep instead of `splits` (the serial form took 28 us
 // for 30 MB at C3).  Deterministic.
-__global__ void conv_dw_reduce_kernel(float* __restrict__ dw, const float* __restrict__ slabs, long long n, int splits, int assign) {
+// `db` (optional): the bias gradient's per-split sums reduced by the blocks behind the dW ones, in the same launch
+__global__ void conv_dw_reduce_kernel(float* __restrict__ dw, const float* __restrict__ slabs, long long n, int splits, int assign,
+                                      float* __restrict__ db = nullptr, const float* __restrict__ bias_slabs = nullptr, long long nb = 0,
+                                      int assign_b = 0) {
     __shared__ float red[4][64];
     const int col = threadIdx.x & 63, lane = threadIdx.x >> 6;
-    const long long i = (long long)blockIdx.x * 64 + col;
+    long long blk = blockIdx.x;
+    const long long dw_blocks = (n + 63) / 64;
+    if (blk >= dw_blocks) {  // block-uniform: this block belongs to the bias gradient
+        blk -= dw_blocks; dw = db; slabs = bias_slabs; n = nb; assign = assign_b;
+    }
+    const long long i = blk * 64 + col;
     float s0 = 0.f, s1 = 0.f;
     if (i < n) {
         int k = lane;

@@ -80,8 +80,8 @@ def test_handwritten_modules_call_the_abi_consistently():
 
 # every §8(a) entry point of INTEGRATION.md section 3 and the HipVar / HipVarDiff method that must reach it
 REQUIRED = {
-    "mm": ["nk_mm_fwd", "nk_mm_bwd_left", "nk_mm_bwd_right"],
-    "mm_t": ["nk_mm_t_fwd", "nk_mm_t_bwd_left", "nk_mm_t_bwd_right"],
+    "mm": ["nk_mm_fwd", "nk_mm_bwd_left", "nk_mm_bwd_right", "nk_mm_bwd"],
+    "mm_t": ["nk_mm_t_fwd", "nk_mm_t_bwd_left", "nk_mm_t_bwd_right", "nk_mm_t_bwd"],
     "convolution": ["nk_conv_fwd", "nk_conv_bwd_input", "nk_conv_bwd_kernel"],
     "binary": ["nk_binary_fwd", "nk_binary_bwd_left", "nk_binary_bwd_right"],
     "sum": ["nk_sum_fwd", "nk_sum_bwd"], "mean": ["nk_mean_fwd", "nk_mean_bwd"],
