@@ -372,7 +372,8 @@ class _CapiSync:  # adapt capi.Device to the `sync()` interface of the tape's De
 
 
 def matmul_fwd_bwd(dist, dev, n, steps, warmup):
-    """C2 on device `dev` (capi.Device): C = A.B, dA += G.B^T, dB += A^T.G.  Returns (seconds for the K steps, max over
+    """C2 on device `dev` (capi.Device): C = A.B, then the node's backward dA += G.B^T, dB += A^T.G (one call: both products in
+    one launch where neither fills the chip, nk_sgemm_pair's rule - 1024 and 2048; two launches at 4096 and 8192).  Returns (seconds for the K steps, max over
     ranks, timed WITHOUT per-launch events; the GEMM launch statistics of a second pass of K steps with them)."""
     from neuronika_amd import capi as c
     mk = lambda s: dev.array(np.random.default_rng(s).random((n, n), dtype=np.float32))
@@ -380,7 +381,7 @@ def matmul_fwd_bwd(dist, dev, n, steps, warmup):
     Cm, dA, dB = dev.zeros((n, n)), dev.zeros((n, n)), dev.zeros((n, n))
 
     def step():
-        c.mm_fwd(dev, A, B, Cm); c.mm_bwd_left(dev, dA, G, B); c.mm_bwd_right(dev, dB, A, G)
+        c.mm_fwd(dev, A, B, Cm); c.mm_bwd(dev, dA, dB, G, A, B)   # MatrixMatrixMul::forward, MatrixMatrixMulBackward::backward
     sync = _CapiSync(dev)
     dt, _, _, _ = timed_steps(dist, sync, dev, step, steps, warmup, profile=False)
     settle = EXTRA_STATS["settle_steps"]
@@ -396,7 +397,7 @@ def matmul_record(dist, dev, n, steps, warmup):
     dt, gemm = matmul_fwd_bwd(dist, dev, n, steps, warmup)
     tf = 6.0 * n ** 3 * steps / dt / 1e12
     roof = roofline_mfma(gemm, "sgemm_kernel", "sgemm_kernel" if n == 4096 else None)
-    return {"workload": f"C2: mm fwd + bwd-left + bwd-right, N={n}, {steps} steps", "value": round(tf, 2), "unit": "TFLOP/s",
+    return {"workload": f"C2: mm fwd + bwd (left and right products), N={n}, {steps} steps", "value": round(tf, 2), "unit": "TFLOP/s",
             "tflops": round(tf, 2), "frac_of_mfma_peak": round(tf * 1e12 / MFMA_F32_PEAK, 4),
             "kernel_tflops": roof["achieved"], "kernel_frac": roof["frac"], "steps": steps,
             "ms_per_step": round(dt / steps * 1e3, 4), "roofline": roof}

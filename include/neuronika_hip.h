@@ -76,9 +76,11 @@ const char* nk_version(void);
  *   NK_TUNE_GEMM_KPAIR     values[0] = -1 rule / 0 never / 1 k-pair blocks, lock-step groups / 2 skewed groups
  *   NK_TUNE_ATTENTION_OCC  values[0] = 0 rule / 2: forward register budget sized for two blocks per CU
  *   NK_TUNE_GEMM_PAIR      values[0] = -1 rule / 0 nk_sgemm_pair always launches twice / 1 one launch whenever eligible
+ *   NK_TUNE_CONV_NARROW    values[0] = 0 the conv kernel gradient's uniform launch / 1..100 its mixed launch (the last, half-empty
+ *                          column tile through 64-wide blocks), a narrow block's k-tile priced at that percentage of a wide one's
  * For schedule sweeps (benchmarks/ab_*.py) and the tests that pit one schedule against another bit for bit; results never
  * depend on them beyond summation order (split-K). */
-enum { NK_TUNE_GEMM_FORCE = 0, NK_TUNE_GEMM_KPAIR = 1, NK_TUNE_ATTENTION_OCC = 2, NK_TUNE_GEMM_PAIR = 3 };
+enum { NK_TUNE_GEMM_FORCE = 0, NK_TUNE_GEMM_KPAIR = 1, NK_TUNE_ATTENTION_OCC = 2, NK_TUNE_GEMM_PAIR = 3, NK_TUNE_CONV_NARROW = 4 };
 int nk_dev_tune(nk_device* dev, int knob, const int* values, int n);
 
 /* ------------------------------------------------------------------ memory ------------- */

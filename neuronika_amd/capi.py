@@ -255,7 +255,7 @@ class Event:
             pass
 
 
-TUNE_GEMM_FORCE, TUNE_GEMM_KPAIR, TUNE_ATTENTION_OCC, TUNE_GEMM_PAIR = 0, 1, 2, 3   # include/neuronika_hip.h: nk_dev_tune knobs
+TUNE_GEMM_FORCE, TUNE_GEMM_KPAIR, TUNE_ATTENTION_OCC, TUNE_GEMM_PAIR, TUNE_CONV_NARROW = 0, 1, 2, 3, 4   # include/neuronika_hip.h: nk_dev_tune knobs
 
 
 class Device:
@@ -272,7 +272,7 @@ class Device:
         # The sweep scripts (benchmarks/ab_*.py, tools/sessions/*.sh) choose a schedule per process through environment
         # variables; it is THIS harness that reads them and calls nk_dev_tune - the library itself reads none.
         for var, knob in (("NK_GEMM_FORCE", TUNE_GEMM_FORCE), ("NK_GEMM_KPAIR", TUNE_GEMM_KPAIR), ("NK_ATTN_OCC", TUNE_ATTENTION_OCC),
-                          ("NK_GEMM_PAIR", TUNE_GEMM_PAIR)):
+                          ("NK_GEMM_PAIR", TUNE_GEMM_PAIR), ("NK_CONV_NARROW", TUNE_CONV_NARROW)):
             if os.environ.get(var):
                 self.tune(knob, os.environ[var])
 
@@ -296,6 +296,9 @@ class Device:
 
     def gemm_pair(self, mode=None):
         self.tune(TUNE_GEMM_PAIR, mode)
+
+    def conv_narrow(self, cost=None):
+        self.tune(TUNE_CONV_NARROW, cost)
 
     def sync(self):
         check(lib.nk_device_sync(self.h))

@@ -483,6 +483,35 @@ int conv_bwd_kernel(nk_device* dev, int nd, float* dw, const int* w_shape, const
     long long rts = (rtiles + splits - 1) / splits;
     splits = (rtiles + rts - 1) / rts;
     p.r_per_split = rts * BK;
+    // A column count that ends in half a tile (3 x 3 on 64 channels: 576 = 4.5 x 128): the mixed launch - 128-wide bodies for the
+    // whole tiles, the 64-wide body for the last one (no MFMA on padding columns), the narrow tile's reduction cut into fewer,
+    // longer ranges so that a narrow block takes as long as a wide one.  `narrow_cost` = time of a narrow block's k-tile in
+    // percent of a wide block's (nk_dev_tune NK_TUNE_CONV_NARROW; 0 = the uniform launch).
+    bool mixed = false;
+    {
+        const int narrow_cost = dev->tune_conv_narrow;
+        if (narrow_cost > 0 && quadr && g.stride[2] == 1 && ti == 2 && tj == 2 && Kc % 128 == 64 && p.tiles_n >= 2 && (g.L % 4 == 0) && al16(gy)) {
+            // s_w wide splits, s_n narrow ones: wide tiles * s_w + narrow tiles * s_n <= slots * waves, s_n = s_w * cost / 100
+            const long long nw = (long long)p.tiles_m * (p.tiles_n - 1) * groups, nn = (long long)p.tiles_m * groups;
+            long long sw = slots * waves * 100 / (nw * 100 + nn * narrow_cost);
+            if (sw > rtiles) sw = rtiles;
+            if (sw > 1024) sw = 1024;
+            long long sn = sw * narrow_cost / 100;
+            if (sw >= 2 && sn >= 1) {
+                long long rw = (rtiles + sw - 1) / sw;
+                sw = (rtiles + rw - 1) / rw;
+                long long rn = (rtiles + sn - 1) / sn;
+                sn = (rtiles + rn - 1) / rn;
+                if (sn < sw && groups == 1) {
+                    mixed = true;
+                    splits = sw; rts = rw;
+                    p.r_per_split = rw * BK;
+                    p.narrow_splits = (int)sn;
+                    p.r_per_split_narrow = rn * BK;
+                }
+            }
+        }
+    }
     const long long dw_elems = (long long)g.Cout * Kc;
     const bool fused_bias = db && quadr;
     const size_t slab_bytes = round256((size_t)splits * dw_elems * sizeof(float));
@@ -495,6 +524,10 @@ int conv_bwd_kernel(nk_device* dev, int nd, float* dw, const int* w_shape, const
     const bool vec_g = (g.L % 4 == 0) && al16(gy);
     rc = nk_prof_start(dev, NK_KERNEL_CONV, 2.0 * g.N * (double)g.Cout * g.L * g.Cg * g.KK);
     if (rc) return rc;
+    if (mixed) {
+        grid.x = (unsigned)(p.tiles_m * (p.tiles_n - 1) * splits + p.tiles_m * p.narrow_splits);
+        hipLaunchKernelGGL((conv_bwd_kernel_mixed_kernel<true, 2, true, 1>), grid, dim3(NT), 0, dev->compute, p);
+    } else
 #define NK_LAUNCH_BWK(VG, TI_, TJ_, Q) hipLaunchKernelGGL((conv_bwd_kernel_kernel<VG, TI_, TJ_, Q>), grid, dim3(NT), 0, dev->compute, p)
     if (quadr && g.stride[2] == 2) {
 #define NK_LAUNCH_BWK2(TI_, TJ_) hipLaunchKernelGGL((conv_bwd_kernel_kernel<true, TI_, TJ_, true, 2>), grid, dim3(NT), 0, dev->compute, p)
@@ -525,7 +558,7 @@ int conv_bwd_kernel(nk_device* dev, int nd, float* dw, const int* w_shape, const
     // blocks behind the dW ones in the same launch
     hipLaunchKernelGGL(conv_dw_reduce_kernel, dim3((unsigned)((dw_elems + 63) / 64 + (fused_bias ? (g.Cout + 63) / 64 : 0))), dim3(256), 0,
                        dev->compute, dw, p.slabs, dw_elems, (int)splits, assign, fused_bias ? db : nullptr, p.bias_slabs,
-                       (long long)g.Cout, assign_b);
+                       (long long)g.Cout, assign_b, mixed ? Kc : 0, Kc - 64, p.narrow_splits);
     NK_LAUNCH_CHECK();
     rc = nk_prof_stop(dev);
     if (rc) return rc;

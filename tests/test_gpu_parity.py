@@ -184,6 +184,45 @@ def test_conv_kernel_and_bias_gradient_in_one_pass(dev, xs, ws, s, d, g):
     np.testing.assert_allclose(DB2.numpy(), DB.numpy() - db0, rtol=1e-5, atol=1e-5 * np.abs(sum64).max() + 1e-6)
 
 
+@pytest.mark.parametrize("xs,ws,s,d", [
+    ((4, 64, 14, 14), (128, 64, 3, 3), (1, 1), (1, 1)),      # C3-shaped: 576 columns = 4.5 tiles
+    ((3, 64, 13, 18), (128, 64, 3, 3), (1, 1), (2, 1)),      # dilated rows, output rows of 16
+    ((2, 192, 9, 12), (256, 192, 1, 1), (1, 1), (1, 1)),     # 1 x 1: 192 columns = 1.5 tiles, two tile rows
+    ((16, 64, 30, 30), (128, 64, 3, 3), (1, 1), (1, 1)),     # reduction long enough for several k-tiles per split
+])
+@pytest.mark.parametrize("cost", [40, 70, 100])
+def test_conv_kernel_gradient_mixed_launch(dev, xs, ws, s, d, cost):
+    """The kernel gradient's mixed launch (conv_bwd_kernel_mixed_kernel: whole column tiles through 128-wide blocks, the last,
+    half-empty one through 64-wide blocks with its reduction cut into fewer ranges; NK_TUNE_CONV_NARROW prices a narrow block)
+    against the uniform launch and the oracle: dW and the fused bias gradient within the contraction policy, `+=` and first-write
+    forms, for several prices (each gives other split counts for the two tile shapes)."""
+    c = capi()
+    x, go = rnd(0, xs), rnd(2, O.conv_out_shape(xs, ws, s, d), -1, 1)
+    X, G = dev.array(x), dev.array(go)
+    dw0, db0 = rnd(4, ws), rnd(5, (ws[0], 1, 1))
+    dw32, dw64 = dw0.copy(), dw0.astype(np.float64)
+    O.convolution_backward_kernel(dw32, go, x, s, d, 1)
+    O.convolution_backward_kernel(dw64, go.astype(np.float64), x.astype(np.float64), s, d, 1)
+    outs = {}
+    for price in (0, cost):
+        dev.conv_narrow(price)
+        try:
+            DW, DB = dev.array(dw0), dev.array(db0)
+            c.conv_bwd_kernel_bias(dev, DW, DB, G, X, s, d, 1)
+            DW2, DB2 = dev.full(ws, 7.0), dev.full(db0.shape, 7.0)
+            c.conv_bwd_kernel_bias(dev, DW2, DB2, G, X, s, d, 1, assign=(True, True))
+            outs[price] = (DW.numpy(), DB.numpy(), DW2.numpy(), DB2.numpy())
+        finally:
+            dev.conv_narrow(None)
+    R = xs[0] * int(np.prod(go.shape[2:]))
+    for price, (dw, db, dw2, db2) in outs.items():
+        contraction_ok(dw, dw32, dw64, R, 1.0, 1.0)
+        np.testing.assert_allclose(dw2, dw64 - dw0, rtol=1e-4, atol=2e-6 * R)
+        np.testing.assert_allclose(db2.reshape(-1), go.astype(np.float64).sum(axis=(0, 2, 3)), rtol=1e-4, atol=1e-5 * R ** 0.5)
+        np.testing.assert_allclose(db - db0, db2, rtol=1e-4, atol=1e-5 * R ** 0.5)
+    np.testing.assert_allclose(outs[cost][0], outs[0][0], rtol=1e-4, atol=2e-6 * R)   # other split counts: other rounding, same sums
+
+
 CONV_PADDED = [
     # unpadded x shape, w shape, padding, stride, dilation, groups
     ((2, 64, 16, 16), (128, 64, 3, 3), (1, 1), (1, 1), (1, 1), 1),     # C3-shaped, fast kernel

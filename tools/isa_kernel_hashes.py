@@ -11,7 +11,7 @@ out = {}
 for m in re.finditer(r'^(_Z\w+): *;[^\n]*\n(.*?)^\t\.size\t\1', txt, re.S | re.M):
     name, body = m.group(1), m.group(2)
     ins = [l.strip() for l in body.split('\n') if l.startswith('\t') and not l.strip().startswith('.') and not l.strip().startswith(';')]
-    ins = [re.sub(r'\s*;.*$', '', l) for l in ins]
+    ins = [re.sub(r'\.LBB\d+_', '.LBB_', re.sub(r'\s*;.*$', '', l)) for l in ins]
     tail = txt[m.end():m.end() + 3000]
     def g(k):
         r = re.search(re.escape(name) + r'\.' + k + r', (\d+)', tail); return int(r.group(1)) if r else -1
