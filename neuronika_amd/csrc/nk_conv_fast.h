@@ -26,6 +26,13 @@ __global__ void conv_wp_kernel(float* __restrict__ wp, const float* __restrict__
         }
     }
     const long long total = (long long)g.Cout * g.Cg * g.KK;
+    if (total < 0x7fffffffLL) {  // 32-bit index arithmetic (a 64-bit division by a run-time value is a few hundred instructions)
+        for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)total; i += gridDim.x * blockDim.x) {
+            const unsigned rem = i / (unsigned)g.Cg, ci = i - rem * (unsigned)g.Cg, co = rem / (unsigned)g.KK, tap = rem - co * (unsigned)g.KK;
+            wp[i] = w[(co * (unsigned)g.Cg + ci) * (unsigned)g.KK + tap];
+        }
+        return;
+    }
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {
         const int ci = (int)(i % g.Cg);
@@ -76,36 +83,81 @@ __device__ __forceinline__ int4 tap_position(const ConvGeom& g, int tap, int* kd
     return make_int4(begin, cnt, rank, pid);
 }
 // One launch in front of the input-gradient pass: the first block writes the tap table - tapd[position in phase order] =
-// {d0, d1, d2, tap} with out = q - d (d = (k*dil - r)/stride >= 0) - and the phase table, every block re-lays its share of the weights, each thread working out its own
-// tap's position among the phases (a loop over the KK taps: nothing next to a global load).
+// {d0, d1, d2, tap} with out = q - d (d = (k*dil - r)/stride >= 0) - and the phase table, every block re-lays its share of the weights.
 __global__ void conv_wq_tables_kernel(float* __restrict__ wq, const float* __restrict__ w, int4* __restrict__ tapd,
                                       BwdInPhase* __restrict__ phases, BwdInPhaseTable tbl, ConvGeom g) {
+    // Every block first works out the KK taps' positions among the phases into LDS - (begin, count, rank, phase) per tap and the
+    // inverse, position in phase order -> tap - in two steps: each tap's phase (one decode per thread), then its rank among the
+    // taps of that phase (a loop over the KK phases in LDS: a few instructions per trip).  tap_position's loop of KK decodes per
+    // thread (3 divisions by run-time values each) was the whole launch: ~5 us per block, twice in block 0 - 10.7 - 13.5 us at C3
+    // for 9 taps and 73,728 weights against 4.8 for the forward's re-ordering of the same tensor.  A block then walks its share of
+    // the DESTINATION: consecutive threads write consecutive floats of wq and gather from w (295 KB at C3: L2 hits).
+    constexpr int TAPS_IN_LDS = 512;
+    __shared__ int4 tp_s[TAPS_IN_LDS];
+    __shared__ int tap_at[TAPS_IN_LDS];
+    __shared__ int pid_s[TAPS_IN_LDS];
+    const bool in_lds = g.KK <= TAPS_IN_LDS;
     if (blockIdx.x == 0) {
-        for (int tap = threadIdx.x; tap < g.KK; tap += blockDim.x) {
-            int kd[3];
-            const int4 tp = tap_position(g, tap, kd);
-            tapd[tp.x + tp.z] = make_int4((kd[0] - kd[0] % g.stride[0]) / g.stride[0], (kd[1] - kd[1] % g.stride[1]) / g.stride[1],
-                                          (kd[2] - kd[2] % g.stride[2]) / g.stride[2], tap);
+        if (!in_lds) {
+            for (int tap = threadIdx.x; tap < g.KK; tap += blockDim.x) {
+                int kd[3];
+                const int4 tp = tap_position(g, tap, kd);
+                tapd[tp.x + tp.z] = make_int4((kd[0] - kd[0] % g.stride[0]) / g.stride[0], (kd[1] - kd[1] % g.stride[1]) / g.stride[1],
+                                              (kd[2] - kd[2] % g.stride[2]) / g.stride[2], tap);
+            }
         }
         if (threadIdx.x == 0) {
 #pragma unroll
             for (int i = 0; i < MAX_PHASES; ++i) phases[i] = tbl.ph[i];
         }
     }
-    // every block first works out the KK taps' positions once (KK threads, a loop over KK each) into LDS; its elements then look
-    // their tap up (each thread running the loop for its own element made this launch 10.7 us at C3 - 9 taps, 73,728 weights -
-    // against 4.8 for the forward's re-ordering of the same tensor)
-    constexpr int TAPS_IN_LDS = 512;
-    __shared__ int4 tp_s[TAPS_IN_LDS];
-    const bool in_lds = g.KK <= TAPS_IN_LDS;
+    const long long total = (long long)g.Cout * g.Cg * g.KK;
     if (in_lds) {
         for (int tap = threadIdx.x; tap < g.KK; tap += blockDim.x) {
             int kd[3];
-            tp_s[tap] = tap_position(g, tap, kd);
+            pid_s[tap] = tap_phase(g, tap, kd);
         }
         __syncthreads();
+        for (int tap = threadIdx.x; tap < g.KK; tap += blockDim.x) {
+            const int pid = pid_s[tap];
+            int begin = 0, cnt = 0, rank = 0;
+            for (int t2 = 0; t2 < g.KK; ++t2) {
+                const int pid2 = pid_s[t2];
+                begin += pid2 < pid;
+                cnt += pid2 == pid;
+                rank += pid2 == pid && t2 < tap;
+            }
+            tp_s[tap] = make_int4(begin, cnt, rank, pid);
+            tap_at[begin + rank] = tap;
+            if (blockIdx.x == 0) {
+                int kd[3];
+                tap_phase(g, tap, kd);
+                tapd[begin + rank] = make_int4((kd[0] - kd[0] % g.stride[0]) / g.stride[0], (kd[1] - kd[1] % g.stride[1]) / g.stride[1],
+                                               (kd[2] - kd[2] % g.stride[2]) / g.stride[2], tap);
+            }
+        }
+        __syncthreads();
+        const int row = g.Mg * g.KK;  // one (group, input channel) row of wq
+        auto element = [&](long long i, int r, int ci, int grp) {
+            const int4 ph = tp_s[tap_at[r / g.Mg]];  // the phase region r lies in: positions [begin, begin + count)
+            const int rr = r - g.Mg * ph.x, c32 = rr % BK, t = rr / BK;
+            const int rank = t % ph.y, chunk = t / ph.y;
+            const int tap = tap_at[ph.x + rank];
+            wq[i] = w[(((long long)grp * g.Mg + chunk * BK + c32) * g.Cg + ci) * g.KK + tap];
+        };
+        if (total < 0x7fffffffLL) {  // 32-bit index arithmetic (a 64-bit division by a run-time value is a few hundred instructions)
+            for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)total; i += gridDim.x * blockDim.x) {
+                const unsigned gc = i / (unsigned)row, r = i - gc * (unsigned)row, grp = gc / (unsigned)g.Cg;
+                element(i, (int)r, (int)(gc - grp * (unsigned)g.Cg), (int)grp);
+            }
+            return;
+        }
+        for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+            const long long gc = i / row;
+            element(i, (int)(i % row), (int)(gc % g.Cg), (int)(gc / g.Cg));
+        }
+        return;
     }
-    const long long total = (long long)g.Cout * g.Cg * g.KK;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {  // i = source index ((grp*Mg + co)*Cg + ci)*KK + tap
         const int tap = (int)(i % g.KK);
@@ -114,7 +166,7 @@ __global__ void conv_wq_tables_kernel(float* __restrict__ wq, const float* __res
         const int co = (int)(rem % g.Mg);
         const int grp = (int)(rem / g.Mg);
         int kd[3];
-        const int4 tp = in_lds ? tp_s[tap] : tap_position(g, tap, kd);
+        const int4 tp = tap_position(g, tap, kd);
         const int chunk = co / BK, c32 = co - chunk * BK;
         wq[((long long)grp * g.Cg + ci) * ((long long)g.Mg * g.KK) + (long long)g.Mg * tp.x + (chunk * tp.y + tp.z) * BK + c32] = w[i];
     }
@@ -301,6 +353,22 @@ __global__ __launch_bounds__(NT, 2) void conv_fwd_fast_kernel(FastFwdArgs p) {
 // bit-identical to it), four loads in flight at a time - the one-load-per-trip loop ran at 1.4 TB/s (17.7 us for 25 MB at C3)
 __device__ __forceinline__ float tail_split_sum(const float* __restrict__ e, int splits, int stride) {
     float s = 0.f;
+    if (splits <= 8) {  // every load issued before the first add (C3: 6 splits in the forward pass, 12 in the input gradient)
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = e[(long long)min(k, splits - 1) * stride];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s = k < splits ? s + v[k] : s;
+        return s;
+    }
+    if (splits <= 16) {
+        float v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = e[(long long)min(k, splits - 1) * stride];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s = k < splits ? s + v[k] : s;
+        return s;
+    }
     int k = 0;
     for (; k + 4 <= splits; k += 4) {
         const float a = e[(long long)k * stride], b = e[(long long)(k + 1) * stride], c = e[(long long)(k + 2) * stride],
@@ -325,13 +393,16 @@ __global__ void conv_fwd_tail_reduce_kernel(FastFwdArgs p) {
     const int cols = g.N * rows_per_n * W4;  // row-padded column space of the fast kernel, < 2^31
     // blockIdx.y: a 1024-element slice of the tile (8 rows x 128 columns); consecutive threads = consecutive columns
     const int e = blockIdx.y * 1024 + threadIdx.x;
+    float sums[4];  // the slabs hold whole tiles: the four elements' sums are read unconditionally, all loads in flight together
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sums[i] = tail_split_sum(base + e + i * 256, p.tail_splits, BM * BN);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int ee = e + i * 256;
         const int r = ee / BN, c = ee - r * BN;
         const int co = tm * BM + r, cc = tn * BN + c;
         if (co >= g.Mg || cc >= cols) continue;
-        const float s = tail_split_sum(base + ee, p.tail_splits, BM * BN);
+        const float s = sums[i];
         const int rowid = cc / W4, cpos = cc - rowid * W4;
         if (cpos >= g.out[2]) continue;
         const int n = rowid / rows_per_n, l = (rowid - n * rows_per_n) * g.out[2] + cpos;
@@ -602,6 +673,9 @@ __global__ void conv_bwd_input_tail_reduce_kernel(FastBwdInArgs p) {
     const int cols = g.N * rows_per_n * W4;
     // blockIdx.y: a 1024-element slice of the tile (8 rows x 128 columns); consecutive threads = consecutive columns
     const int e = blockIdx.y * 1024 + threadIdx.x;
+    float sums[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sums[i] = tail_split_sum(base + e + i * 256, p.tail_splits, BM * BN);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int ee = e + i * 256;
@@ -610,7 +684,7 @@ __global__ void conv_bwd_input_tail_reduce_kernel(FastBwdInArgs p) {
         if (ci >= g.Cg || cc >= cols) continue;
         const int rowid = cc / W4, cpos = cc - rowid * W4;
         if (cpos >= ph.count[2]) continue;  // padding column of the row
-        const float s = tail_split_sum(base + ee, p.tail_splits, BM * BN);
+        const float s = sums[i];
         const int n = rowid / rows_per_n, ab = rowid - n * rows_per_n;
         const int i0 = ab / ph.count[1], i1 = ab - i0 * ph.count[1];
         float* d = p.dx + ((long long)n * g.Cin + ci) * g.uinplane +
