@@ -490,7 +490,7 @@ int conv_bwd_kernel(nk_device* dev, int nd, float* dw, const int* w_shape, const
     bool mixed = false;
     {
         const int narrow_cost = dev->tune_conv_narrow;
-        if (narrow_cost > 0 && quadr && g.stride[2] == 1 && ti == 2 && tj == 2 && Kc % 128 == 64 && p.tiles_n >= 2 && (g.L % 4 == 0) && al16(gy)) {
+        if (narrow_cost > 0 && quadr && g.stride[2] == 1 && ti == 2 && tj == 2 && Kc % 128 == 64 && p.tiles_n >= 2) {
             // s_w wide splits, s_n narrow ones: wide tiles * s_w + narrow tiles * s_n <= slots * waves, s_n = s_w * cost / 100
             const long long nw = (long long)p.tiles_m * (p.tiles_n - 1) * groups, nn = (long long)p.tiles_m * groups;
             long long sw = slots * waves * 100 / (nw * 100 + nn * narrow_cost);
