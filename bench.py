@@ -396,7 +396,8 @@ def matmul_record(dist, dev, n, steps, warmup):
     LAUNCH_EVENTS_EVERY-th step of it)."""
     dt, gemm = matmul_fwd_bwd(dist, dev, n, steps, warmup)
     tf = 6.0 * n ** 3 * steps / dt / 1e12
-    roof = roofline_mfma(gemm, "sgemm_kernel", "sgemm_kernel" if n == 4096 else None)
+    roof = roofline_mfma(gemm, "sgemm_kernel" if n >= 4096 else "sgemm_kernel (forward), sgemm_pair_kernel (both backward products, one launch)",
+                         "sgemm_kernel" if n == 4096 else None)
     return {"workload": f"C2: mm fwd + bwd (left and right products), N={n}, {steps} steps", "value": round(tf, 2), "unit": "TFLOP/s",
             "tflops": round(tf, 2), "frac_of_mfma_peak": round(tf * 1e12 / MFMA_F32_PEAK, 4),
             "kernel_tflops": roof["achieved"], "kernel_frac": roof["frac"], "steps": steps,
