@@ -150,8 +150,9 @@ __global__ void binary_bwd_same_kernel(float* __restrict__ d, const float* __res
             }
         }
         if (VEC) {
-            const float4 gv = *reinterpret_cast<const float4*>(g + i * 4);
-            float4 dv = assign ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<float4*>(d + i * 4);
+            // bit 1 of `assign`: `nt` loads of g and d (operands beyond the Infinity Cache, nk_common.h)
+            const float4 gv = nk_load_stream(reinterpret_cast<const float4*>(g + i * 4), assign & 2);
+            float4 dv = (assign & 1) ? make_float4(0.f, 0.f, 0.f, 0.f) : nk_load_stream(reinterpret_cast<const float4*>(d + i * 4), assign & 2);
             float4 ov = make_float4(0, 0, 0, 0), qv = make_float4(1, 1, 1, 1);
             if (MODE >= 2) ov = ld4(o, oo, b.os[b.nd - 1]);
             if (MODE == 4) qv = ld4(q, qo, b.qs[b.nd - 1]);
@@ -161,7 +162,7 @@ __global__ void binary_bwd_same_kernel(float* __restrict__ d, const float* __res
             dv.w += local_grad<MODE>(gv.w, ov.w, qv.w);
             nk_store_stream(reinterpret_cast<float4*>(d + i * 4), dv);
         } else {
-            d[i] = (assign ? 0.f : d[i]) + local_grad<MODE>(g[i], MODE >= 2 ? o[oo] : 0.f, MODE == 4 ? q[qo] : 1.f);
+            d[i] = ((assign & 1) ? 0.f : d[i]) + local_grad<MODE>(g[i], MODE >= 2 ? o[oo] : 0.f, MODE == 4 ? q[qo] : 1.f);
         }
     }
 }
@@ -377,8 +378,9 @@ int bwd_dispatch(nk_device* dev, float* d, const int* t_shape, int t_nd, const f
         const bool vec = (cshape[nd - 1] % 4 == 0) && al16(d) && al16(g) &&
                          (MODE < 2 || (os[nd - 1] <= 1 && al16(o))) && (MODE != 4 || (qs[nd - 1] <= 1 && al16(q)));
         const int grid = nk_stream_grid((size_t)(total / (vec ? 4 : 1)), 256);
-        if (vec) hipLaunchKernelGGL((binary_bwd_same_kernel<MODE, true>), dim3(grid), dim3(256), 0, dev->compute, d, g, o, q, b, total, assign);
-        else hipLaunchKernelGGL((binary_bwd_same_kernel<MODE, false>), dim3(grid), dim3(256), 0, dev->compute, d, g, o, q, b, total, assign);
+        const int amode = (assign ? 1 : 0) | (nk_streams_past_cache((size_t)total * (assign ? 8 : 12)) ? 2 : 0);
+        if (vec) hipLaunchKernelGGL((binary_bwd_same_kernel<MODE, true>), dim3(grid), dim3(256), 0, dev->compute, d, g, o, q, b, total, amode);
+        else hipLaunchKernelGGL((binary_bwd_same_kernel<MODE, false>), dim3(grid), dim3(256), 0, dev->compute, d, g, o, q, b, total, amode);
         NK_LAUNCH_CHECK();
         return NK_OK;
     }
@@ -485,30 +487,31 @@ __global__ void relu_bwd_kernel(float* __restrict__ dx, const float* __restrict_
     if (VEC) {
         const size_t n4 = n / 4;
         for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-            const float4 xv = reinterpret_cast<const float4*>(x)[i], gv = reinterpret_cast<const float4*>(g)[i];
-            float4 d = assign ? make_float4(0.f, 0.f, 0.f, 0.f) : reinterpret_cast<float4*>(dx)[i];
+            // bit 1 of `assign`: `nt` loads (operands beyond the Infinity Cache, nk_common.h)
+            const float4 xv = nk_load_stream(reinterpret_cast<const float4*>(x) + i, assign & 2), gv = nk_load_stream(reinterpret_cast<const float4*>(g) + i, assign & 2);
+            float4 d = (assign & 1) ? make_float4(0.f, 0.f, 0.f, 0.f) : nk_load_stream(reinterpret_cast<const float4*>(dx) + i, assign & 2);
             d.x += xv.x > 0.f ? gv.x : 0.f * gv.x; d.y += xv.y > 0.f ? gv.y : 0.f * gv.y;
             d.z += xv.z > 0.f ? gv.z : 0.f * gv.z; d.w += xv.w > 0.f ? gv.w : 0.f * gv.w;
             nk_store_stream(reinterpret_cast<float4*>(dx) + i, d);
         }
         if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
             const size_t i = n4 * 4 + threadIdx.x;
-            dx[i] = (assign ? 0.f : dx[i]) + (x[i] > 0.f ? g[i] : 0.f * g[i]);
+            dx[i] = ((assign & 1) ? 0.f : dx[i]) + (x[i] > 0.f ? g[i] : 0.f * g[i]);
         }
     } else {
         for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-            dx[i] = (assign ? 0.f : dx[i]) + (x[i] > 0.f ? g[i] : 0.f * g[i]);
+            dx[i] = ((assign & 1) ? 0.f : dx[i]) + (x[i] > 0.f ? g[i] : 0.f * g[i]);
     }
 }
 
 // g = ((y > 0) as f32) * g in place (one pointer for source and destination: no __restrict__ pair to alias)
 template <bool VEC>
-__global__ void relu_mask_inplace_kernel(float* g, const float* __restrict__ y, size_t n) {
+__global__ void relu_mask_inplace_kernel(float* g, const float* __restrict__ y, size_t n, bool nt = false) {
     if (VEC) {
         const size_t n4 = n / 4;
         for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-            const float4 yv = reinterpret_cast<const float4*>(y)[i];
-            float4 v = reinterpret_cast<float4*>(g)[i];
+            const float4 yv = nk_load_stream(reinterpret_cast<const float4*>(y) + i, nt);
+            float4 v = nk_load_stream(reinterpret_cast<const float4*>(g) + i, nt);
             v.x = yv.x > 0.f ? v.x : 0.f * v.x; v.y = yv.y > 0.f ? v.y : 0.f * v.y;
             v.z = yv.z > 0.f ? v.z : 0.f * v.z; v.w = yv.w > 0.f ? v.w : 0.f * v.w;
             reinterpret_cast<float4*>(g)[i] = v;
@@ -878,6 +881,7 @@ static int relu_bwd(nk_device* dev, float* dx, const float* g, const float* x, s
     if (n == 0) return NK_OK;
     NK_CHECK(dx && g && x, "null pointer in nk_relu_bwd");
     const bool vec = al16(x) && al16(g) && al16(dx);
+    assign = (assign ? 1 : 0) | (nk_streams_past_cache(n * (assign ? 12 : 16)) ? 2 : 0);
     if (vec) hipLaunchKernelGGL((relu_bwd_kernel<true>), dim3(nk_stream_grid(n / 4 + 1, 256)), dim3(256), 0, dev->compute, dx, g, x, n, assign);
     else hipLaunchKernelGGL((relu_bwd_kernel<false>), dim3(nk_stream_grid(n, 256)), dim3(256), 0, dev->compute, dx, g, x, n, assign);
     NK_LAUNCH_CHECK();
@@ -928,7 +932,8 @@ int nk_relu_mask_inplace(nk_device* dev, float* g, const float* y, size_t n) {
     if (n == 0) return NK_OK;
     NK_CHECK(g && y, "null pointer in nk_relu_mask_inplace");
     const bool vec = ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
-    if (vec) hipLaunchKernelGGL((relu_mask_inplace_kernel<true>), dim3(nk_stream_grid(n / 4 + 1, 256)), dim3(256), 0, dev->compute, g, y, n);
+    if (vec) hipLaunchKernelGGL((relu_mask_inplace_kernel<true>), dim3(nk_stream_grid(n / 4 + 1, 256)), dim3(256), 0, dev->compute, g, y, n,
+                                nk_streams_past_cache(n * 12));
     else hipLaunchKernelGGL((relu_mask_inplace_kernel<false>), dim3(nk_stream_grid(n, 256)), dim3(256), 0, dev->compute, g, y, n);
     NK_LAUNCH_CHECK();
     return NK_OK;

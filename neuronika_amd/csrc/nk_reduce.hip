@@ -56,11 +56,12 @@ __global__ void scalar_bwd_kernel(float* __restrict__ dx, const float* __restric
     const float g = gs[0];
     const size_t n4 = n / 4;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-        float4 d = assign ? make_float4(0.f, 0.f, 0.f, 0.f) : reinterpret_cast<float4*>(dx)[i];
+        // bit 1 of `assign`: `nt` loads (operands beyond the Infinity Cache, nk_common.h)
+        float4 d = (assign & 1) ? make_float4(0.f, 0.f, 0.f, 0.f) : nk_load_stream(reinterpret_cast<const float4*>(dx) + i, assign & 2);
         if (MODE == 0) { d.x += g; d.y += g; d.z += g; d.w += g; }
         if (MODE == 1) { const float v = g / den; d.x += v; d.y += v; d.z += v; d.w += v; }
         if (MODE >= 2) {
-            const float4 xv = reinterpret_cast<const float4*>(x)[i], tv = reinterpret_cast<const float4*>(t)[i];
+            const float4 xv = nk_load_stream(reinterpret_cast<const float4*>(x) + i, assign & 2), tv = nk_load_stream(reinterpret_cast<const float4*>(t) + i, assign & 2);
             if (MODE == 2) {
                 d.x += (2.f * (xv.x - tv.x)) * g / den; d.y += (2.f * (xv.y - tv.y)) * g / den;
                 d.z += (2.f * (xv.z - tv.z)) * g / den; d.w += (2.f * (xv.w - tv.w)) * g / den;
@@ -73,7 +74,7 @@ __global__ void scalar_bwd_kernel(float* __restrict__ dx, const float* __restric
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
         const size_t i = n4 * 4 + threadIdx.x;
-        const float d0 = assign ? 0.f : dx[i];
+        const float d0 = (assign & 1) ? 0.f : dx[i];
         if (MODE == 0) dx[i] = d0 + g;
         if (MODE == 1) dx[i] = d0 + g / den;
         if (MODE == 2) dx[i] = d0 + (2.f * (x[i] - t[i])) * g / den;
@@ -105,6 +106,7 @@ int scalar_bwd(nk_device* dev, float* dx, const float* g, const float* x, const 
     if (n == 0) return NK_OK;
     NK_CHECK(dx && g, "null pointer");
     NK_CHECK(al16(dx) && (MODE < 2 || (al16(x) && al16(t))), "gradient buffers must be 16-byte aligned");
+    assign = (assign ? 1 : 0) | ((MODE >= 2 && nk_streams_past_cache(n * (assign ? 12 : 16))) ? 2 : 0);
     hipLaunchKernelGGL((scalar_bwd_kernel<MODE>), dim3(nk_stream_grid(n / 4 + 1, 256)), dim3(256), 0, dev->compute, dx, g, x, t, n, den, assign);
     NK_LAUNCH_CHECK();
     return NK_OK;
