@@ -79,3 +79,58 @@ def test_sgemm_batched_random_strides(dev, seed):
     opb = np.swapaxes(b, 2, 3) if tb else b
     ref = opa.astype(np.float64) @ opb.astype(np.float64) + beta * c0.astype(np.float64)
     assert np.abs(Cd.numpy().astype(np.float64) - ref).max() <= 2e-6 * K + 3e-6
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_sgemm_pair_random_problem(dev, seed):
+    """nk_sgemm_pair on seeded pairs - the layouts of the MatMul / MatMulT backward ((NN | NT | TN) first, TN second) and layouts
+    the pair kernel does not take, tile-aligned and ragged extents, leading dimensions with padding, beta 0 / 1: whatever the
+    rule decides (one launch, or two), forced one launch and forced two launches give the SAME bits as two nk_sgemm calls
+    without k-pair blocks, the padding columns stay untouched, and the values match f64 NumPy."""
+    c = capi()
+    rng = np.random.default_rng(9000 + seed)
+    unit = int(rng.choice([64, 128, 128, 32, 1]))
+    dims = lambda: tuple(unit * int(rng.integers(1, 9)) if unit > 1 else int(rng.integers(1, 300)) for _ in range(3))
+    probs = []
+    for which in range(2):
+        M, N, K = dims()
+        if which == 1 or seed % 5 == 4:
+            ta, tb = (1, 0) if seed % 7 else (int(rng.integers(0, 2)), int(rng.integers(0, 2)))
+        else:
+            ta, tb = [(0, 0), (0, 1), (1, 0)][seed % 3]
+        pa, pb, pc = (int(rng.choice([0, 0, 4])) for _ in range(3))
+        ar, ac = (K, M) if ta else (M, K)
+        br, bc = (N, K) if tb else (K, N)
+        a = rng.random((ar, ac + pa), dtype=np.float32) * 2 - 1
+        b = rng.random((br, bc + pb), dtype=np.float32) * 2 - 1
+        cm = rng.random((M, N + pc), dtype=np.float32) * 2 - 1
+        probs.append((ta, tb, M, N, K, a, ac + pa, b, bc + pb, float(rng.choice([0.0, 1.0])), cm, N + pc, ac, bc))
+
+    def run(mode):
+        dev.gemm_pair(0 if mode == "singles" else mode); dev.gemm_kpair(0)
+        try:
+            bufs = [(dev.array(p[5]), dev.array(p[7]), dev.array(p[10])) for p in probs]
+            if mode == "singles":
+                for p, (A, B, Cd) in zip(probs, bufs):
+                    c.sgemm(dev, p[0], p[1], p[2], p[3], p[4], 1.0, A, p[6], B, p[8], p[9], Cd, p[11])
+            else:
+                (p0, (A0, B0, C0)), (p1, (A1, B1, C1)) = zip(probs, bufs)
+                c.sgemm_pair(dev, p0[0], p0[1], p0[2], p0[3], p0[4], A0, p0[6], B0, p0[8], p0[9], C0, p0[11],
+                             p1[0], p1[1], p1[2], p1[3], p1[4], A1, p1[6], B1, p1[8], p1[9], C1, p1[11])
+            return [b[2].numpy() for b in bufs]
+        finally:
+            dev.gemm_pair(None); dev.gemm_kpair(None)
+
+    ref = None
+    for mode in ("singles", 0, 1, -1):
+        got = run(mode)
+        if ref is None:
+            ref = got
+        for x, y in zip(got, ref):
+            assert np.array_equal(x, y), mode
+    for p, got in zip(probs, ref):
+        ta, tb, M, N, K, a, lda, b, ldb, beta, cm, ldc, ac, bc = p
+        opa, opb = (a[:, :ac].T if ta else a[:, :ac]).astype(np.float64), (b[:, :bc].T if tb else b[:, :bc]).astype(np.float64)
+        want = opa @ opb + beta * cm[:, :N].astype(np.float64)
+        assert np.abs(got[:, :N].astype(np.float64) - want).max() <= 2e-6 * K + 2e-6 * abs(beta) + 1e-6
+        assert np.array_equal(got[:, N:], cm[:, N:])
