@@ -17,6 +17,7 @@ dev = c.Device(0)
 SHAPES = [
     # name, x shape (padded), w shape, stride, dilation, groups
     ("C3 3x3 s1 64->128 @56", (128, 64, 58, 58), (128, 64, 3, 3), (1, 1), (1, 1), 1),
+    ("3x3 s1 64->64 @56", (128, 64, 58, 58), (64, 64, 3, 3), (1, 1), (1, 1), 1),
     ("3x3 s2 64->128 @56", (128, 64, 58, 58), (128, 64, 3, 3), (2, 2), (1, 1), 1),
     ("3x3 s2 128->256 @28", (128, 128, 30, 30), (256, 128, 3, 3), (2, 2), (1, 1), 1),
     ("1x1 s2 256->512 @28 (projection shortcut)", (128, 256, 28, 28), (512, 256, 1, 1), (2, 2), (1, 1), 1),

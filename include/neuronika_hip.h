@@ -77,7 +77,8 @@ const char* nk_version(void);
  *   NK_TUNE_ATTENTION_OCC  values[0] = 0 rule / 2: forward register budget sized for two blocks per CU
  *   NK_TUNE_GEMM_PAIR      values[0] = -1 rule / 0 nk_sgemm_pair always launches twice / 1 one launch whenever eligible
  *   NK_TUNE_CONV_NARROW    values[0] = 0 the conv kernel gradient's uniform launch / 1..100 its mixed launch (the last, half-empty
- *                          column tile through 64-wide blocks), a narrow block's k-tile priced at that percentage of a wide one's
+ *                          column tile through 64-wide blocks), a narrow block's k-tile priced at that percentage of a wide one's;
+ *                          n = 0: the measured rules (65 % with 128-row tiles, 80 % with 64-row tiles)
  * For schedule sweeps (benchmarks/ab_*.py) and the tests that pit one schedule against another bit for bit; results never
  * depend on them beyond summation order (split-K). */
 enum { NK_TUNE_GEMM_FORCE = 0, NK_TUNE_GEMM_KPAIR = 1, NK_TUNE_ATTENTION_OCC = 2, NK_TUNE_GEMM_PAIR = 3, NK_TUNE_CONV_NARROW = 4 };

@@ -16,9 +16,11 @@ struct nk_prof_rec {
     double flop;
 };
 
-// conv kernel gradient, mixed launch: a 64-wide block's k-tile priced at 65 % of a 128-wide one's (C3 sweep, same box: uniform
-// launch 528.1 us; prices 50 / 60 / 65 / 70 / 75 / 80 / 90 -> 547.1 / 501.9 / 495.9 / 503.3 / 509.2 / 511.5 / 521.3 us)
-constexpr int NK_CONV_NARROW_DEFAULT = 65;
+// conv kernel gradient, mixed launch: what a 64-wide block's k-tile costs in percent of a 128-wide one's - 65 with 128-row tiles
+// (C3 sweep, same box: uniform launch 528.1 us; prices 50 / 60 / 65 / 70 / 75 / 80 / 90 -> 547.1 / 501.9 / 495.9 / 503.3 / 509.2 /
+// 511.5 / 521.3 us), 80 with 64-row tiles (3 x 3, 64 -> 64 channels at 56 x 56: uniform 311.0 us; 70 / 75 / 80 / 85 / 90 -> 310.4 /
+// 301.9 / 299.9 / 301.2 / 303.5 us).  -1 in the device handle = these rules.
+constexpr int NK_CONV_NARROW_128 = 65, NK_CONV_NARROW_64 = 80;
 struct nk_device {
     int idx = 0;
     hipStream_t compute = nullptr;  // tape-ordered kernels
@@ -37,7 +39,7 @@ struct nk_device {
     int tune_gemm_n = 0;                     // how many of them are set (< 3: the rules decide)
     int tune_kpair = -1;                     // k-pair blocks: -1 rule, 0 never, 1 lock-step groups, 2 skewed groups
     int tune_pair = -1;                      // nk_sgemm_pair: -1 rule, 0 always two launches, 1 one launch whenever eligible
-    int tune_conv_narrow = NK_CONV_NARROW_DEFAULT;                // conv kernel gradient, mixed launch: cost of a 64-wide block's k-tile in % of a 128-wide one's; 0 = uniform launch
+    int tune_conv_narrow = -1;                // conv kernel gradient, mixed launch: -1 the rules above, 0 uniform launch, 1..100 the price in percent
     int tune_attn_occ = 0;                   // attention forward: 2 = size the register budget for two blocks per CU
     // bench instrumentation (nk_profile_begin/end)
     bool prof_on = false;

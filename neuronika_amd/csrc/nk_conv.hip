@@ -486,11 +486,11 @@ int conv_bwd_kernel(nk_device* dev, int nd, float* dw, const int* w_shape, const
     // A column count that ends in half a tile (3 x 3 on 64 channels: 576 = 4.5 x 128): the mixed launch - 128-wide bodies for the
     // whole tiles, the 64-wide body for the last one (no MFMA on padding columns), the narrow tile's reduction cut into fewer,
     // longer ranges so that a narrow block takes as long as a wide one.  `narrow_cost` = time of a narrow block's k-tile in
-    // percent of a wide block's (nk_dev_tune NK_TUNE_CONV_NARROW; 0 = the uniform launch).
+    // percent of a wide block's (the measured rules of nk_common.h; nk_dev_tune NK_TUNE_CONV_NARROW overrides, 0 = the uniform launch).
     bool mixed = false;
     {
-        const int narrow_cost = dev->tune_conv_narrow;
-        if (narrow_cost > 0 && quadr && g.stride[2] == 1 && ti == 2 && tj == 2 && Kc % 128 == 64 && p.tiles_n >= 2) {
+        const int narrow_cost = dev->tune_conv_narrow >= 0 ? dev->tune_conv_narrow : (ti == 2 ? NK_CONV_NARROW_128 : NK_CONV_NARROW_64);
+        if (narrow_cost > 0 && quadr && g.stride[2] == 1 && tj == 2 && Kc % 128 == 64 && p.tiles_n >= 2) {
             // s_w wide splits, s_n narrow ones: wide tiles * s_w + narrow tiles * s_n <= slots * waves, s_n = s_w * cost / 100
             const long long nw = (long long)p.tiles_m * (p.tiles_n - 1) * groups, nn = (long long)p.tiles_m * groups;
             long long sw = slots * waves * 100 / (nw * 100 + nn * narrow_cost);
@@ -526,7 +526,8 @@ int conv_bwd_kernel(nk_device* dev, int nd, float* dw, const int* w_shape, const
     if (rc) return rc;
     if (mixed) {
         grid.x = (unsigned)(p.tiles_m * (p.tiles_n - 1) * splits + p.tiles_m * p.narrow_splits);
-        hipLaunchKernelGGL((conv_bwd_kernel_mixed_kernel<true, 2, true, 1>), grid, dim3(NT), 0, dev->compute, p);
+        if (ti == 2) hipLaunchKernelGGL((conv_bwd_kernel_mixed_kernel<true, 2, true, 1>), grid, dim3(NT), 0, dev->compute, p);
+        else hipLaunchKernelGGL((conv_bwd_kernel_mixed_kernel<true, 1, true, 1>), grid, dim3(NT), 0, dev->compute, p);
     } else
 #define NK_LAUNCH_BWK(VG, TI_, TJ_, Q) hipLaunchKernelGGL((conv_bwd_kernel_kernel<VG, TI_, TJ_, Q>), grid, dim3(NT), 0, dev->compute, p)
     if (quadr && g.stride[2] == 2) {

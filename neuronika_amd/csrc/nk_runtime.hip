@@ -172,7 +172,7 @@ int nk_dev_tune(nk_device* dev, int knob, const int* values, int n) {
             return NK_OK;
         case NK_TUNE_CONV_NARROW:
             NK_CHECK(n <= 1 && (n == 0 || (values[0] >= 0 && values[0] <= 100)), "NK_TUNE_CONV_NARROW: 0 (off) or a cost in percent, 1..100");
-            dev->tune_conv_narrow = n ? values[0] : NK_CONV_NARROW_DEFAULT;
+            dev->tune_conv_narrow = n ? values[0] : -1;
             return NK_OK;
         case NK_TUNE_ATTENTION_OCC:
             NK_CHECK(n <= 1 && (n == 0 || values[0] == 0 || values[0] == 2), "NK_TUNE_ATTENTION_OCC: 0 or 2");

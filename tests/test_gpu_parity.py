@@ -190,7 +190,8 @@ def test_conv_kernel_and_bias_gradient_in_one_pass(dev, xs, ws, s, d, g):
     ((2, 192, 9, 12), (256, 192, 1, 1), (1, 1), (1, 1)),     # 1 x 1: 192 columns = 1.5 tiles, two tile rows
     ((16, 64, 30, 30), (128, 64, 3, 3), (1, 1), (1, 1)),     # reduction long enough for several k-tiles per split
     ((5, 64, 9, 9), (128, 64, 3, 3), (1, 1), (1, 1)),        # output rows of 7: row-padded quads (the last quad of a row re-reads one element)
-    ((3, 64, 12, 11), (192, 64, 3, 3), (2, 1), (1, 1)),      # strided rows, 192 output channels (a ragged second tile row)
+    ((3, 64, 12, 11), (192, 64, 3, 3), (2, 1), (1, 1)),      # strided rows, 192 output channels: 64-row tiles, three tile rows
+    ((4, 64, 14, 14), (64, 64, 3, 3), (1, 1), (1, 1)),       # 64 -> 64 channels (a ResNet stage-1 layer): 64-row tiles
 ])
 @pytest.mark.parametrize("cost", [40, 70, 100])
 def test_conv_kernel_gradient_mixed_launch(dev, xs, ws, s, d, cost):
