@@ -18,6 +18,7 @@ from benchmarks.microbench import timeit, rand  # noqa: E402
 
 dev = c.Device(0)
 sizes = [int(a) for a in sys.argv[1:]] or [1024, 2048, 4096]
+assert all(0 < n <= 16384 for n in sizes), "sizes are matrix extents (N of N^3), at most 16384"   # (a typo here once cost 14 GPU-minutes)
 for n in sizes:
     A, B, G = rand(dev, (n, n), 0, 0, 1), rand(dev, (n, n), 1, 0, 1), rand(dev, (n, n), 2, 0, 1)
     dA, dB = dev.zeros((n, n)), dev.zeros((n, n))
