@@ -42,6 +42,28 @@ def out_dx(): c.sgemm(dev, 0, 0, n, d, d, 1.0, G, d, Wo, d, 0.0, dCtx, d)       
 def out_dw(): c.sgemm(dev, 1, 0, d, d, n, 1.0, G, d, out, d, 0.0, dWo, d)                      # out-projection weight gradient
 
 
+def dkdv():          # the two batched TN products nk_attention_bwd runs internally
+    so, po, pi = S * d, H * S * S, S * S
+    c.sgemm_batched(dev, 1, 0, S, dh, S, 1.0, ds, S, po, pi, Q, d, so, dh, 0.0, dK, d, so, dh, B, H)
+    c.sgemm_batched(dev, 1, 0, S, dh, S, 1.0, pd, S, po, pi, G, d, so, dh, 0.0, dV, d, so, dh, B, H)
+
+
+if os.environ.get("C5_ORDER_SPLIT") == "1":
+    # with a library whose nk_attention_bwd leaves the dK / dV products to the caller (variant build, tools/sessions/r04_zz.sh): the
+    # out-projection's weight-gradient GEMM BETWEEN the attention backward kernel and its dK / dV products
+    rec = {}
+    seqs = (("A: attention kernel, dK / dV, out_dw, qkv_dx, qkv_dw (the tape's order)", [out_dx, attn_bwd, dkdv, out_dw, qkv_dx, qkv_dw]),
+            ("B: attention kernel, out_dw, dK / dV, qkv_dx, qkv_dw", [out_dx, attn_bwd, out_dw, dkdv, qkv_dx, qkv_dw]),
+            ("D: attention kernel, dK / dV, qkv_dx, out_dw, qkv_dw", [out_dx, attn_bwd, dkdv, qkv_dx, out_dw, qkv_dw]),
+            ("E: attention kernel, dK / dV, qkv_dx, qkv_dw, out_dw", [out_dx, attn_bwd, dkdv, qkv_dx, qkv_dw, out_dw]))
+    for name, seq in seqs:
+        timeit(dev, lambda: [f() for f in seq], 5)       # every order once before any is recorded
+    for rep in range(4):                                  # alternating: four passes over the four legal orders
+        for name, seq in seqs:
+            rec.setdefault(name, []).append(round(timeit(dev, lambda: [f() for f in seq], 20) * 1e3, 1))
+    print(json.dumps(rec))
+    sys.exit(0)
+
 orders = {
     "tape order: out_dx out_dw | attn_bwd | qkv_dx qkv_dw": [out_dx, out_dw, attn_bwd, qkv_dx, qkv_dw],
     "out_dw moved behind the attention backward": [out_dx, attn_bwd, out_dw, qkv_dx, qkv_dw],
