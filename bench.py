@@ -555,12 +555,16 @@ def run_mlp(a, dist):
     tgt = np.random.default_rng(200 + dist.rank).random((B, H), dtype=np.float32)
     lins = [t.nn.Linear(tdev, H, H, seed) for seed in (1, 3, 5)]      # identical weights on every rank
     X, T = t.from_ndarray(tdev, x), t.from_ndarray(tdev, tgt)
-    # Linear + ReLU as one node each (ReLU in the GEMM epilogues, forward and backward); NK_BENCH_UNFUSED_RELU=1: the
-    # node-by-node form `forward(x).relu()` (same values and gradients bit for bit, tests/test_gpu_tape.py)
-    if os.environ.get("NK_BENCH_UNFUSED_RELU") == "1":
+    # The model in the reference's own words (neuronika-nn/src/lib.rs:441-447 `Linear::forward`, vardiff.rs:282-288 `relu`):
+    # `forward(x).relu()` builds ONE Linear+ReLU node per hidden layer (graph-build peephole of the host mirror, ReLU in the
+    # GEMM epilogues forward and backward).  NK_BENCH_UNFUSED_RELU=1: the same words with the peephole off - the ReLU node
+    # over the Linear's output (same values and gradients bit for bit, tests/test_gpu_tape.py).
+    unfused = os.environ.get("NK_BENCH_UNFUSED_RELU") == "1"
+    was = t.nn.set_relu_peephole(not unfused)
+    try:
         out = lins[2].forward(lins[1].forward(lins[0].forward(X).relu()).relu())
-    else:
-        out = lins[2].forward(lins[1].forward_relu(lins[0].forward_relu(X)))
+    finally:
+        t.nn.set_relu_peephole(was)
     loss = out.mse(T, t.Reduction.Mean)
     params = []
     for lin in lins:

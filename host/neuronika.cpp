@@ -909,11 +909,15 @@ struct LinearBwd : Backward {
     void backward() const override {
         // Linear+ReLU: g must hold dL/dz = (y > 0) * dL/dy.  When every writer of g on this tape applied the mask while
         // storing (`premasked`, decided by VarDiff::run_backward), it already does; otherwise mask it in place now
+        // into a scratch copy (the traffic of an in-place pass): g itself keeps dL/dy, what `grad()` of this variable shows
+        // in the reference's graph - also for a root, whose gradient is the seed
+        Shared<HipArray> masked;
         if (y && !g->premasked()) {
-            HipArray& Gm = g->borrow();
-            check(nk_relu_mask_inplace(D(x), Gm.ptr(), y->ptr(), Gm.len()));
+            const HipArray& Gy = g->borrow();
+            masked = std::make_shared<HipArray>(x->device(), Gy.shape(), HipArray::Uninit{});
+            check(nk_relu_bwd_assign(D(x), masked->ptr(), Gy.ptr(), y->ptr(), Gy.len()));
         }
-        const HipArray& G = g->borrow();
+        const HipArray& G = masked ? *masked : g->borrow();
         nk_device* dev = D(x);
         const int n = x->shape()[0], m = x->shape()[1], o = w->shape()[0];
         // MatrixMatrixMulTBackward (left, right) and AdditionBackwardRight write three different buffers, so their
@@ -1450,14 +1454,6 @@ void VarDiff::backward(float seed, BackwardHook* hook) const {
 void VarDiff::backward_from(const Var& seed, BackwardHook* hook) const {
     if (var.history.len() != var.history.buffer_len()) panic("Perhaps you forgot to call .forward()?");
     if (seed.shape() != shape()) panic("backward_from: the seed must have the shape of the root");
-    if (grad->premask_source()) {
-        // a fused Linear+ReLU root masks its gradient buffer in place: give it a copy, not the caller's tensor
-        bool assign = false;
-        HipArray& own = grad->borrow_first_write(assign);
-        check(nk_copy(device()->raw(), own.ptr(), seed.data->ptr(), own.len()));
-        run_backward(hook);
-        return;
-    }
     // the root's backward nodes read the root gradient through `borrow()` when they run: let them see the seed's buffer
     const bool was_pending = grad->zero_pending();
     Shared<HipArray> own = grad->exchange_array(seed.data);
@@ -1527,7 +1523,16 @@ void VarDiff::with_grad() const {
 
 VarDiff VarDiff::sum() const { return unary_diff(Unary::Sum, 0, *this, {}); }
 VarDiff VarDiff::mean() const { return unary_diff(Unary::Mean, 0, *this, {}); }
-VarDiff VarDiff::relu() const { return unary_diff(Unary::Relu, 0, *this, shape()); }
+static thread_local bool g_relu_peephole = true;
+namespace nn {
+bool set_relu_peephole(bool on) { const bool was = g_relu_peephole; g_relu_peephole = on; return was; }
+VarDiff linear_relu_from_origin(const LinearOrigin& o);
+}  // namespace nn
+VarDiff VarDiff::relu() const {
+    // `lin.forward(x).relu()`: one Linear+ReLU node over the Linear's operands (see `linear_origin`)
+    if (linear_origin && g_relu_peephole) return nn::linear_relu_from_origin(*linear_origin);
+    return unary_diff(Unary::Relu, 0, *this, shape());
+}
 VarDiff VarDiff::neg() const { return pointwise_diff(NK_NEG, 0, *this); }
 VarDiff VarDiff::pow(int e) const { return pointwise_diff(NK_POW, e, *this); }
 VarDiff VarDiff::sqrt() const { return pointwise_diff(NK_SQRT, 0, *this); }
@@ -1852,7 +1857,19 @@ static VarDiff linear_node(const Linear& l, const Var& x, const Shared<Gradient>
     auto bw = std::make_shared<LinearBwd>();
     bw->x = x.data; bw->w = l.weight.var.data; bw->dx = dx; bw->dw = l.weight.grad; bw->db = l.bias.grad; bw->g = g;
     if (relu) bw->y = y;
-    return VarDiff::node(std::move(var), g, entry(bw, g), std::move(hb));
+    VarDiff out = VarDiff::node(std::move(var), g, entry(bw, g), std::move(hb));
+    if (!relu) {
+        auto origin = std::make_shared<LinearOrigin>();
+        origin->weight = l.weight; origin->bias = l.bias; origin->input = x; origin->input_grad = dx;
+        origin->differentiable_input = hx != nullptr;
+        if (hx) origin->input_history = *hx;
+        out.linear_origin = std::move(origin);
+    }
+    return out;
+}
+VarDiff linear_relu_from_origin(const LinearOrigin& o) {
+    const Linear l(o.weight, o.bias);
+    return linear_node(l, o.input, o.input_grad, o.differentiable_input ? &o.input_history : nullptr, true);
 }
 VarDiff Linear::forward(const Var& input) const {
     return fused ? linear_node(*this, input, nullptr, nullptr) : input.mm_t(weight) + bias;

@@ -350,6 +350,7 @@ class Var {
 // ---------------------------------------------------------------------------------------------
 // vardiff.rs — differentiable variable
 // ---------------------------------------------------------------------------------------------
+namespace nn { struct LinearOrigin; }
 class VarDiff {
     void run_backward(BackwardHook* hook) const;
 
@@ -357,6 +358,12 @@ class VarDiff {
     Var var;
     Shared<Gradient> grad;
     History<BackwardEntry> history;
+    // Set on the output of a fused `nn::Linear::forward`: how to build the same product again.  `relu()` on such a
+    // variable - the reference's spelling `lin.forward(x).relu()` (neuronika-nn/src/lib.rs:441-447, vardiff.rs:282-288) -
+    // answers the ONE Linear+ReLU node over the Linear's own operands instead of a ReLU node over this output (graph-build
+    // peephole, `nn::set_relu_peephole`).  The new node does not depend on this one: a dropped temporary never runs, a
+    // variable that is kept (other consumers) stays its own node with its own gradient.
+    Shared<const nn::LinearOrigin> linear_origin;
 
     static VarDiff leaf(Var var, Shared<Gradient> grad);                                        // vardiff.rs:48
     static VarDiff node(Var var, Shared<Gradient> grad, BackwardEntry op, History<BackwardEntry> h);  // :56
@@ -496,11 +503,24 @@ struct Linear {
     // `forward(input).relu()` as ONE node (ours; the reference composes the two): max(input.W^T + b, 0) from the GEMM
     // epilogue, the pre-activation never stored; in the backward pass the ReLU mask is applied by whichever GEMM produces
     // this node's output gradient (a following Linear's input-gradient GEMM), or in place when another kind of node does.
-    // Same values and gradients as the two nodes, bit for bit; the one observable difference: after `backward`, the
-    // OUTPUT's `grad()` holds the gradient of the pre-activation, (y > 0) * dL/dy.
+    // Same values and gradients as the two nodes, bit for bit; the one observable difference: in a pass where every writer
+    // of the OUTPUT's gradient applied the mask while storing (a following Linear), the output's `grad()` holds
+    // (y > 0) * dL/dy afterwards - the entries where y = 0 read 0.  (A root's gradient, and any gradient written by other
+    // kinds of nodes, keeps dL/dy: the mask then goes into a scratch copy.)
     VarDiff forward_relu(const Var& input) const;
     VarDiff forward_relu(const VarDiff& input) const;
 };
+// What `VarDiff::relu()` needs to rebuild a fused Linear as Linear+ReLU (see `VarDiff::linear_origin`)
+struct LinearOrigin {
+    VarDiff weight, bias;
+    Var input;
+    bool differentiable_input = false;       // the input was a VarDiff: its gradient and tape follow
+    Shared<Gradient> input_grad;
+    History<BackwardEntry> input_history;
+};
+// Graph-build peephole `forward(x).relu()` -> the Linear+ReLU node (on by default, per thread; off: the ReLU node over the
+// Linear's output, as the tests that pit the two graphs against each other bit for bit need it).  Returns the old setting.
+bool set_relu_peephole(bool on);
 
 // `LSTMCell` neuronika-nn/src/lib.rs:453-541.  Weights (4H,in)/(4H,H), biases (4H), U(-k,k), k = 1/sqrt(H).
 // `forward` keeps the reference's exact composition: state = (cell_state, hidden); gate chunks 0..3 get

@@ -240,6 +240,7 @@ PYBIND11_MODULE(_tape, m) {
     sd.def("linear_from_json", py::overload_cast<DevicePtr, const std::string&>(&serde::linear_from_json));
 
     py::module_ nn = m.def_submodule("nn");
+    nn.def("set_relu_peephole", &nn::set_relu_peephole, py::arg("on"));
     py::class_<nn::Linear>(nn, "Linear")
         .def(py::init<DevicePtr, int, int, uint64_t>(), py::arg("dev"), py::arg("in_features"), py::arg("out_features"), py::arg("seed") = 0)
         .def(py::init<VarDiff, VarDiff>())

@@ -21,10 +21,9 @@ def dev():
 
 
 def contraction_ok(gpu, cpu32, ref64, K, amax, bmax):
-    err_gpu = np.abs(gpu.astype(np.float64) - ref64).max() if gpu.size else 0.0
-    err_cpu = np.abs(cpu32.astype(np.float64) - ref64).max() if gpu.size else 0.0
-    bound = max(2 * err_cpu, 1e-6 * K * amax * bmax)
-    assert err_gpu <= bound, (err_gpu, err_cpu, bound)
+    """the one contraction policy of the suite: tests/tolerance.py"""
+    from tolerance import assert_contraction
+    assert_contraction("conv_fuzz", gpu, ref64, K, amax, bmax, cpu32=cpu32)
 
 
 CHANNELS = [1, 2, 3, 4, 8, 16, 20, 24, 32, 64]   # per group: <= 16 direct, 17..31 generic, multiples of 32 fast

@@ -1,6 +1,7 @@
 """Seeded random GEMM problems through nk_sgemm / nk_sgemm_batched: ragged and aligned shapes, leading dimensions larger
 than the rows, every layout, alpha / beta, two-level batch strides, and reduction lengths on both sides of the look-ahead
-threshold (48 k-tiles, even and odd counts) - against f64 NumPy with the contraction tolerance of test_gpu_parity."""
+threshold (48 k-tiles, even and odd counts) - against f64 NumPy under the suite's one contraction bound (tests/tolerance.py;
+err_cpu32 from OpenBLAS's f32 product of the same operands)."""
 import numpy as np
 import pytest
 
@@ -53,8 +54,9 @@ def test_sgemm_random_problem(dev, seed):
     c.sgemm(dev, ta, tb, M, N, K, alpha, A, ac + pa, B, bc + pb, beta, Cd, N + pc)
     got = Cd.numpy()
     ref = alpha * (opa @ opb) + beta * c_full[:, :N].astype(np.float64)
-    tol = 2e-6 * K * abs(alpha) + 2e-6 * abs(beta) + 1e-6
-    assert np.abs(got[:, :N].astype(np.float64) - ref).max() <= tol
+    from tolerance import assert_contraction
+    cpu32 = np.float32(alpha) * ((a.T if ta else a) @ (b.T if tb else b)) + np.float32(beta) * c_full[:, :N]
+    assert_contraction("sgemm_random_problem", got[:, :N], ref, K, cpu32=cpu32, scale=alpha, epilogue=True)
     assert np.array_equal(got[:, N:], c_full[:, N:])            # the padding columns of C are not touched
 
 
@@ -78,7 +80,8 @@ def test_sgemm_batched_random_strides(dev, seed):
     opa = np.swapaxes(a, 2, 3) if ta else a
     opb = np.swapaxes(b, 2, 3) if tb else b
     ref = opa.astype(np.float64) @ opb.astype(np.float64) + beta * c0.astype(np.float64)
-    assert np.abs(Cd.numpy().astype(np.float64) - ref).max() <= 2e-6 * K + 3e-6
+    from tolerance import assert_contraction
+    assert_contraction("sgemm_batched_random_strides", Cd.numpy(), ref, K, cpu32=opa @ opb + np.float32(beta) * c0, epilogue=True)
 
 
 @pytest.mark.parametrize("seed", range(40))
@@ -132,5 +135,7 @@ def test_sgemm_pair_random_problem(dev, seed):
         ta, tb, M, N, K, a, lda, b, ldb, beta, cm, ldc, ac, bc = p
         opa, opb = (a[:, :ac].T if ta else a[:, :ac]).astype(np.float64), (b[:, :bc].T if tb else b[:, :bc]).astype(np.float64)
         want = opa @ opb + beta * cm[:, :N].astype(np.float64)
-        assert np.abs(got[:, :N].astype(np.float64) - want).max() <= 2e-6 * K + 2e-6 * abs(beta) + 1e-6
+        from tolerance import assert_contraction
+        cpu32 = (a[:, :ac].T if ta else a[:, :ac]) @ (b[:, :bc].T if tb else b[:, :bc]) + np.float32(beta) * cm[:, :N]
+        assert_contraction("sgemm_pair_random_problem", got[:, :N], want, K, cpu32=cpu32, epilogue=True)
         assert np.array_equal(got[:, N:], cm[:, N:])

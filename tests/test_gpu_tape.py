@@ -106,7 +106,14 @@ def test_quickstart_mlp_C1(nk, tdev, golden):
     X, T = nk.from_ndarray(tdev, x), nk.from_ndarray(tdev, t)
     out = lins[2].forward(lins[1].forward(lins[0].forward(X).relu()).relu())
     loss = out.mse(T, nk.Reduction.Mean)
-    assert loss.history_len() == 6 and loss.forward_history_len() == 6   # [Linear,ReLU]x2, Linear, MSE
+    # the reference's spelling `forward(x).relu()` builds the Linear+ReLU node (graph-build peephole, VarDiff::linear_origin)
+    assert loss.history_len() == 4 and loss.forward_history_len() == 4   # [Linear+ReLU]x2, Linear, MSE
+    was = nk.nn.set_relu_peephole(False)
+    try:
+        by_node = lins[2].forward(lins[1].forward(lins[0].forward(X).relu()).relu()).mse(T, nk.Reduction.Mean)
+    finally:
+        nk.nn.set_relu_peephole(was)
+    assert was is True and by_node.history_len() == 6 and by_node.forward_history_len() == 6   # [Linear,ReLU]x2, Linear, MSE
     unfused = []
     for w, b in params:
         unfused.append(nk.nn.Linear(nk.from_ndarray(tdev, w).requires_grad(), nk.from_ndarray(tdev, b).requires_grad()))
@@ -463,7 +470,7 @@ def test_linear_fused_equals_two_nodes(nk, tdev):
         l1.fused = l2.fused = fused
         y = l2.forward(l1.forward(nk.from_ndarray(tdev, x)).relu())
         s = (y * y).sum(); s.forward(); s.backward(1.0)
-        assert y.history_len() == (3 if fused else 5)                 # backward nodes: 2 Linear + ReLU | 2x(mm_t, +) + ReLU
+        assert y.history_len() == (2 if fused else 5)                 # backward nodes: Linear+ReLU, Linear | 2x(mm_t, +) + ReLU
         res[fused] = [y.data()] + [p.grad() for p in (l1.weight, l1.bias, l2.weight, l2.bias)]
     for a, b in zip(res[True], res[False]):
         assert np.array_equal(a, b)
@@ -483,10 +490,19 @@ def test_linear_forward_relu_equals_the_two_nodes(nk, tdev):
     x, t = rnd(1, (96, 40), -1, 1), rnd(2, (96, 24), -1, 1)
     side = rnd(3, (96, 64), -1, 1)
 
+    def by_nodes(l, v):                                               # the ReLU node over the Linear's output: peephole off
+        was = nk.nn.set_relu_peephole(False)
+        try:
+            return l.forward(v).relu()
+        finally:
+            nk.nn.set_relu_peephole(was)
+
     def build(fused, case):
         l1, l2, l3 = nk.nn.Linear(tdev, 40, 64, 7), nk.nn.Linear(tdev, 64, 64, 9), nk.nn.Linear(tdev, 64, 24, 11)
         X = nk.from_ndarray(tdev, x).requires_grad()
-        act = (lambda l, v: l.forward_relu(v)) if fused else (lambda l, v: l.forward(v).relu())
+        # True: the explicit node; "spelling": the reference's words `forward(x).relu()` (the peephole builds the same node);
+        # False: node by node
+        act = {True: lambda l, v: l.forward_relu(v), "spelling": lambda l, v: l.forward(v).relu(), False: by_nodes}[fused]
         a1 = act(l1, X)
         if case == "chain":
             root = l3.forward(act(l2, a1)).mse(nk.from_ndarray(tdev, t), nk.Reduction.Mean)
@@ -508,7 +524,7 @@ def test_linear_forward_relu_equals_the_two_nodes(nk, tdev):
 
     for case in ("chain", "other_consumer", "diamond", "root"):
         res = {}
-        for fused in (True, False):
+        for fused in (True, "spelling", False):
             root, X, lins = build(fused, case)
             root.forward()
             if case == "root":
@@ -523,11 +539,34 @@ def test_linear_forward_relu_equals_the_two_nodes(nk, tdev):
                 root.backward(0.25)
                 used = lins if case != "other_consumer" else [lins[0]]
             res[fused] = [root.data()] + grads(X, used)
-        for i, (a, b) in enumerate(zip(res[True], res[False])):
-            assert np.array_equal(a, b), (case, i)
+        for i, (a, b, c) in enumerate(zip(res[True], res[False], res["spelling"])):
+            assert np.array_equal(a, b) and np.array_equal(c, b), (case, i)
     # (a) really runs without ReLU launches and without the pre-activation: 3 backward nodes, not 5
-    root, X, lins = build(True, "chain")
-    assert root.history_len() == 4                                     # 3 Linear(+ReLU) nodes + the loss
+    for how, nodes in ((True, 4), ("spelling", 4), (False, 6)):
+        root, X, lins = build(how, "chain")
+        assert root.history_len() == nodes, how                        # 3 Linear(+ReLU) nodes + the loss | + 2 ReLU nodes
+    # a root's gradient stays the seed (vardiff.rs:133) in every spelling: the fused node masks a scratch copy, not the buffer
+    for how in (True, "spelling", False):
+        root, X, lins = build(how, "root")
+        root.forward(); root.backward(0.5)
+        assert np.all(root.grad() == 0.5), how
+    # a Linear output that is KEPT stays its own node next to the Linear+ReLU node built from its operands: values and
+    # gradients of `z + z.relu()` equal the node-by-node graph's (two GEMM contributions summed instead of one: tolerance)
+    res = {}
+    for peephole in (True, False):
+        was = nk.nn.set_relu_peephole(peephole)
+        try:
+            l1 = nk.nn.Linear(tdev, 40, 64, 7)
+            X = nk.from_ndarray(tdev, x).requires_grad()
+            z = l1.forward(X)
+            root = (z * nk.from_ndarray(tdev, side) + z.relu()).sum()
+        finally:
+            nk.nn.set_relu_peephole(was)
+        root.forward(); root.backward(1.0)
+        res[peephole] = [root.data(), z.data(), X.grad(), l1.weight.grad(), l1.bias.grad()]
+    assert np.array_equal(res[True][1], res[False][1])
+    for a, b in zip(res[True], res[False]):
+        np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-5)
 
 
 @pytest.mark.parametrize("B,S,H,d,p", [(2, 128, 2, 128, 0.0), (3, 100, 4, 128, 0.2), (2, 64, 2, 256, 0.1)])
