@@ -94,6 +94,9 @@ def parse():
     ap.add_argument("--n", type=int, default=4096, help="matrix size (matmul)")
     ap.add_argument("--no-optimizer", action="store_true", help="time fwd+bwd+allreduce only (metric's literal definition)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dp-channels", type=int, default=16,
+                    help="N > 1: cap RCCL at this many channels (NCCL_MAX_NCHANNELS, unless the caller set it) and tell the GEMMs "
+                         "that many resident-block slots are busy while the exchange runs; 0: RCCL's own choice, GEMMs plan for an idle chip")
     return ap.parse_args()
 
 
@@ -586,6 +589,8 @@ def run_mlp(a, dist):
         if comm.size != world:
             raise SystemExit(f"[bench] RCCL communicator has {comm.size} ranks, expected {world}")
         sync = t.dp.GradientSync(comm, params)
+        if a.dp_channels > 0:
+            sync.set_busy_slots(int(os.environ.get("NCCL_MAX_NCHANNELS", a.dp_channels)))
         if single_rank_rccl:
             sync.set_force_exchange(True)
     elif replicas > 1:
@@ -666,6 +671,7 @@ def run_mlp(a, dist):
             "gemm_share_of_step": round(gemm[1] / ev_ms, 4) if ev_ms > 0 else None,
         }
         if sync is not None:
+            res["dp_channels"] = {"nccl_max_nchannels": os.environ.get("NCCL_MAX_NCHANNELS"), "gemm_busy_slots": sync.busy_slots()}
             res["per_rank_device_ms_per_step"] = [round(v, 4) for v in per_rank]
             res["per_rank_device_ms_min_max"] = [round(min(per_rank), 4), round(max(per_rank), 4)]
             # the same GEMM work per step with the exchange running beside it and without (sums of the HIP-event durations
@@ -852,6 +858,10 @@ def main():
         # a rank that hangs (rendezvous, ncclCommInitRank, a collective nobody else entered) dumps every thread's Python
         # stack on stderr and exits instead of waiting for the driver's kill with an empty tail
         faulthandler.dump_traceback_later(float(os.environ.get("NK_BENCH_TIMEOUT_S", "600")), exit=True)
+        if a.dp_channels > 0:
+            # RCCL's channel workgroups share the CUs with the backward GEMMs: a known, small number of them (the step's
+            # 201 MB of gradients need tens of GB/s, not the fabric's peak) that the GEMM launcher plans around
+            os.environ.setdefault("NCCL_MAX_NCHANNELS", str(a.dp_channels))
         if rank == 0 and "NCCL_DEBUG" not in os.environ:
             # what RCCL chose (channels, algorithm / protocol per size) goes into the record: rank 0 logs INIT + TUNING
             # to a file of its own, parsed after the run (read_rccl_log)

@@ -55,6 +55,34 @@ def main():
     for _ in range(2):
         base = gemms(8)                               # clock settle
     print(json.dumps({"background": "none", "gemm_us": base}), flush=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "defence":
+        # round 5: the same launches with the device handle told how many slots the generator holds
+        # (nk_device_set_busy_slots -> sgemm_tail_kernel: whole rounds of the free slots + the left-over tiles cut along K)
+        # against the plain launches, alternating under ONE background pass each; and what a wrong guess costs on an idle chip.
+        for channels in (8, 16, 32, 64):
+            dev.busy_slots(channels)
+            idle_told = gemms(4)
+            dev.busy_slots(0)
+            print(json.dumps({"background": "none, but told busy", "busy_slots": channels, "gemm_us": idle_told,
+                              "slowdown": {k: round(idle_told[k] / base[k], 4) for k in idle_told}}), flush=True)
+        for channels, gbps in ((8, 25.0), (16, 50.0), (32, 50.0), (64, 100.0)):
+            row = {"background": "hbm", "channels": channels, "asked_GBps": gbps}
+            for rep in range(2):
+                for busy in (0, channels):
+                    comm = c.Comm(dev, 1, 0, None, channels=channels, gbps=gbps)
+                    count = min(big.size, int(gbps * 1e9 * 0.045 / 4))
+                    comm.allreduce_sum_async(Raw(big.p.value, count))
+                    dev.busy_slots(busy)
+                    t = gemms(4)
+                    dev.busy_slots(0)
+                    comm.join(); dev.sync(); comm.close()
+                    key = f"{'defended' if busy else 'plain'}_run{rep}"
+                    row[key + "_us"] = t
+                    row[key + "_slowdown"] = {k: round(t[k] / base[k], 4) for k in t}
+            print(json.dumps(row), flush=True)
+        print(json.dumps({"background": "none (again)", "gemm_us": gemms(8)}), flush=True)
+        c.check(c.lib.nk_host_free(hp))
+        return
     for where, buf, points in (("hbm", big, ((16, 50.0), (16, 100.0), (16, 200.0), (32, 400.0), (64, 800.0))),
                                ("host-pinned", host, ((8, 10.0), (16, 25.0), (32, 50.0)))):
         for channels, gbps in points:

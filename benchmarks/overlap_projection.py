@@ -56,6 +56,24 @@ def main():
 
     base = run(None)
     print(json.dumps({"variant": "no exchange", "ms_per_step": round(base, 4)}), flush=True)
+    if len(sys.argv) > 2 and sys.argv[2] == "defence":
+        # round 5: the same step with the backward GEMMs told how many slots the exchange holds (GradientSync.set_busy_slots ->
+        # nk_device_set_busy_slots -> sgemm_tail_kernel) against the plain launches, same box, alternating
+        for gbps in (60.0, 120.0):
+            for k in (8, 16, 32):
+                comm = t.dp.Communicator.replicas(dev, ranks, int(k), float(gbps))
+                sync = t.dp.GradientSync(comm, params)
+                row = {"variant": "paced replica exchange", "channels": k, "algbw_GBps": gbps}
+                for rep in range(2):
+                    for busy in (0, k):
+                        sync.set_busy_slots(busy)
+                        row[f"ms_per_step_busy_slots_{'k' if busy else '0'}_run{rep}"] = round(run(sync), 4)
+                row["projected_efficiency_plain"] = round(base / min(row["ms_per_step_busy_slots_0_run0"], row["ms_per_step_busy_slots_0_run1"]), 4)
+                row["projected_efficiency_defended"] = round(base / min(row["ms_per_step_busy_slots_k_run0"], row["ms_per_step_busy_slots_k_run1"]), 4)
+                print(json.dumps(row), flush=True)
+                del sync, comm
+        print(json.dumps({"variant": "no exchange (again)", "ms_per_step": round(run(None), 4)}), flush=True)
+        return
     for gbps in (60.0, 120.0, 240.0):            # emulated algorithm bandwidth of the all-reduce (bytes of the buffer / time)
         for k in (8, 16, 32, 64, 128):
             comm = t.dp.Communicator.replicas(dev, ranks, int(k), float(gbps))

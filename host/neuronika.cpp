@@ -2350,6 +2350,7 @@ GradientSync::GradientSync(std::shared_ptr<Communicator> comm, const std::vector
     events_.push_back(ev);
 }
 GradientSync::~GradientSync() {
+    if (busy_told_) nk_device_set_busy_slots(comm_->device()->raw(), 0);
     for (nk_event* e : events_) nk_event_destroy(e);
 }
 bool GradientSync::wants_parts(const Gradient* g) const {
@@ -2400,6 +2401,10 @@ void GradientSync::grad_part_ready(const Gradient* g, size_t offset, size_t coun
     check(nk_allreduce_sum_async(comm_->raw(), a.ptr() + offset, count, ev));
     elems_ += count;
     ++issued_;
+    if (busy_slots_ > 0 && !busy_told_) {  // the exchange's workgroups share the chip with every launch from here to join()
+        check(nk_device_set_busy_slots(comm_->device()->raw(), busy_slots_));
+        busy_told_ = true;
+    }
 }
 void GradientSync::grad_ready(const Gradient* g) {
     auto it = params_.find(g);
@@ -2422,6 +2427,10 @@ void GradientSync::join() {
     last_large_ = nullptr;
     next_event_ = 0;
     for (auto& kv : parts_done_) kv.second = 0;
+    if (busy_told_) {
+        check(nk_device_set_busy_slots(comm_->device()->raw(), 0));
+        busy_told_ = false;
+    }
     if (active()) check(nk_comm_join(comm_->raw()));
 }
 

@@ -869,6 +869,13 @@ class GradientSync : public BackwardHook {
     // Default LastOnly; `set_parts` overrides (measurement aid).  The first pass of LastOnly splits nothing.
     enum class Parts { All, LastOnly, None };
     void set_parts(Parts p) { parts_ = p; }
+    // How many of the GPU's resident-block slots the exchange occupies while it runs: RCCL's channel workgroups (one slot
+    // each; cap them with NCCL_MAX_NCHANNELS and pass the same number).  From the first large gradient handed over until
+    // `join()` the device handle is told (nk_device_set_busy_slots), and the backward GEMMs issued in between plan their last
+    // round of tiles around the missing slots (sgemm_tail_kernel) instead of leaving a ragged one - 10 - 15 % per 4096^3 GEMM
+    // otherwise (profiles/r04_gemm_under_load.md, profiles/r05_gemm_under_load.md).  0 (default): the GEMMs assume an idle chip.
+    void set_busy_slots(int n) { busy_slots_ = n < 0 ? 0 : n; }
+    int busy_slots() const { return busy_slots_; }
 
    private:
     void flush_small();
@@ -884,6 +891,8 @@ class GradientSync : public BackwardHook {
     size_t small_elems_;
     size_t n_small_ = 0;
     bool force_ = false;
+    int busy_slots_ = 0;
+    bool busy_told_ = false;                      // the device handle currently carries busy_slots_
     Parts parts_ = Parts::LastOnly;
     const Gradient* last_large_ = nullptr;       // large gradient handed over last in the current pass
     const Gradient* split_next_ = nullptr;       // ... in the previous pass: the one LastOnly splits

@@ -398,6 +398,8 @@ PYBIND11_MODULE(_tape, m) {
         .def("join", &dp::GradientSync::join)
         .def("bytes_per_step", &dp::GradientSync::bytes_per_step)
         .def("set_force_exchange", &dp::GradientSync::set_force_exchange)
+        .def("set_busy_slots", &dp::GradientSync::set_busy_slots, py::arg("n"))
+        .def("busy_slots", &dp::GradientSync::busy_slots)
         .def("set_parts", [](dp::GradientSync& s, const std::string& mode) {
             if (mode == "all") s.set_parts(dp::GradientSync::Parts::All);
             else if (mode == "last") s.set_parts(dp::GradientSync::Parts::LastOnly);

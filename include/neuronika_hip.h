@@ -83,6 +83,14 @@ const char* nk_version(void);
  * depend on them beyond summation order (split-K). */
 enum { NK_TUNE_GEMM_FORCE = 0, NK_TUNE_GEMM_KPAIR = 1, NK_TUNE_ATTENTION_OCC = 2, NK_TUNE_GEMM_PAIR = 3, NK_TUNE_CONV_NARROW = 4 };
 int nk_dev_tune(nk_device* dev, int knob, const int* values, int n);
+/* Tell the device handle that `n` of the GPU's resident-block slots (two 128x128 GEMM blocks per CU) are held by work on another
+ * stream until further notice - the channel workgroups of an all-reduce in flight beside the backward pass
+ * (vardiff.rs:125-141 -> optimizer.rs:81-86 is where the exchange sits; dp::GradientSync sets it when it hands the first
+ * gradient over and clears it in join()).  GEMM launches whose tile count no longer divides the free slots then run whole
+ * rounds of one tile per block and cut the left-over tiles along K (sgemm_tail_kernel, nk_gemm.hip): deterministic, bits a
+ * function of (shape, n); every tile outside the left-over rectangle is the plain launch's.  n = 0 (the default): the chip is
+ * ours, plain launches.  0 <= n <= CUs. */
+int nk_device_set_busy_slots(nk_device* dev, int n);
 
 /* ------------------------------------------------------------------ memory ------------- */
 /* `CuArray::zeroed` cuda/cuarray.rs:35-42; outputs and gradients are allocated zeroed at

@@ -188,6 +188,7 @@ _SIGS = {
     "nk_comm_init_replicas": [VP, C.c_int, C.c_int, C.c_double, C.POINTER(VP)],
     "nk_comm_init_all": [C.c_int, C.POINTER(VP), C.POINTER(VP)],
     "nk_dev_tune": [VP, C.c_int, C.POINTER(C.c_int), C.c_int],
+    "nk_device_set_busy_slots": [VP, C.c_int],
     "nk_comm_destroy": [VP],
     "nk_allreduce_sum_async": [VP, VP, C.c_size_t, VP],
     "nk_allreduce_sum_group_async": [VP, C.POINTER(VP), C.POINTER(C.c_size_t), C.c_int, VP],
@@ -299,6 +300,10 @@ class Device:
 
     def conv_narrow(self, cost=None):
         self.tune(TUNE_CONV_NARROW, cost)
+
+    def busy_slots(self, n: int = 0):
+        """nk_device_set_busy_slots: `n` resident-block slots are held by work on another stream (an exchange in flight)."""
+        check(lib.nk_device_set_busy_slots(self.h, int(n)))
 
     def sync(self):
         check(lib.nk_device_sync(self.h))

@@ -33,6 +33,7 @@ struct nk_device {
     int graphs_alive = 0;           // nk_graph objects of this device: their kernels have workspace pointers baked in
     std::vector<void*> workspace_retired;  // outgrown workspaces kept while any graph may still replay into them
     int num_cus = 256;
+    int busy_slots = 0;             // resident-block slots held by work on another stream (nk_device_set_busy_slots)
     // development overrides, set through nk_dev_tune (schedule sweeps, schedule-against-schedule parity tests); the library
     // reads no environment variable
     int tune_gemm[6] = {0, 0, 0, 0, 0, 0};  // ti, tj, splits[, tiles per block[, tile-order group height[, look-ahead threshold]]]

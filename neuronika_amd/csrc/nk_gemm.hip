@@ -233,9 +233,11 @@ __global__ __launch_bounds__(NT * KG, (min_waves<TI, TJ, !TA && TB>())) void sge
     __shared__ __attribute__((aligned(16))) float smem_all[gemm_smem_floats<TA, TB, TI, TJ, KG>()];  // <= 73,728 B at 128x128 (k-pair: twice that)
 #define NK_GEMM_BX blockIdx.x
 #define NK_GEMM_NBX gridDim.x
+#define NK_GEMM_SPLIT blockIdx.y
 #include "nk_gemm_body.h"
 #undef NK_GEMM_BX
 #undef NK_GEMM_NBX
+#undef NK_GEMM_SPLIT
 }
 
 // one problem of sgemm_pair_kernel: the same block program for block `bx` of `nbx`
@@ -243,9 +245,22 @@ template <bool TA, bool TB, bool ALIGNED, int TI, int TJ, int KG, bool EPX>
 __device__ __forceinline__ void sgemm_body(const GemmArgs& p, float* smem_all, int bx, int nbx) {
 #define NK_GEMM_BX bx
 #define NK_GEMM_NBX nbx
+#define NK_GEMM_SPLIT blockIdx.y
 #include "nk_gemm_body.h"
 #undef NK_GEMM_BX
 #undef NK_GEMM_NBX
+#undef NK_GEMM_SPLIT
+}
+// ... and with the block's range of the reduction passed in (sgemm_tail_kernel)
+template <bool TA, bool TB, bool ALIGNED, int TI, int TJ, int KG, bool EPX>
+__device__ __forceinline__ void sgemm_body_split(const GemmArgs& p, float* smem_all, int bx, int nbx, int split_no) {
+#define NK_GEMM_BX bx
+#define NK_GEMM_NBX nbx
+#define NK_GEMM_SPLIT split_no
+#include "nk_gemm_body.h"
+#undef NK_GEMM_BX
+#undef NK_GEMM_NBX
+#undef NK_GEMM_SPLIT
 }
 
 // Two independent GEMMs in ONE launch: blocks [0, nblk0) run problem 0, the rest problem 1 (each with its own layout, same
@@ -269,6 +284,34 @@ __global__ __launch_bounds__(NT, (min_waves<TI, TJ, (!TA0 && TB0) || (!TA1 && TB
         sgemm_body<TA0, TB0, true, TI, TJ, 1, false>(pp.p0, smem_all, blockIdx.x, nblk0);
     else
         sgemm_body<TA1, TB1, true, TI, TJ, 1, false>(pp.p1, smem_all, blockIdx.x - nblk0, gridDim.x - nblk0);
+}
+
+// A grid that shares the chip (nk_device_set_busy_slots): the data-parallel exchange keeps `busy` of the GPU's resident-block
+// slots - RCCL's channel workgroups, one slot each - while the backward GEMMs run.  A 4096^3 launch is 1024 tiles = exactly
+// two rounds of the 512 slots of an idle chip; with 16 slots gone the tiles no longer divide, a CU that shares its registers
+// with a foreign workgroup runs one block at a time and picks up a whole tile (~0.4 ms) just before everybody else is done:
+// 10 - 15 % per GEMM with 8 - 64 foreign workgroups at ANY byte rate (profiles/r04_gemm_under_load.md).  The defence is
+// granularity where it matters: the grid runs as many WHOLE rounds of the free slots as fit (blocks [0, nfull), problem p0 over
+// the head of the tile sequence) and the tiles left over - the tail of the sequence, a rectangle of the last group of tile
+// rows: p1, the same product on sub-matrices - are cut along K into as many pieces as there are free slots (blocks
+// [nfull, ..), piece = (block - nfull) / ntail).  Pieces store into slabs; a second pass adds them in piece order and applies
+// the launch's epilogue (alpha, beta, bias, relu, mask) to that rectangle.  One launch, blocks dispatched in index order: the
+// pieces fill the chip as the last whole tiles drain.  Bits are a function of (shape, busy slots): deterministic, and equal to
+// a plain launch for every tile outside the rectangle.  Idle chip (busy = 0): never taken.
+struct GemmTailArgs {
+    GemmArgs p0, p1;
+    int nfull, ntail;
+};
+template <bool TA, bool TB, bool EPX>
+__global__ __launch_bounds__(NT, (min_waves<2, 2, !TA && TB>())) void sgemm_tail_kernel(GemmTailArgs pp) {
+    __shared__ __attribute__((aligned(16))) float smem_all[gemm_smem_floats<TA, TB, 2, 2, 1>()];
+    const int nfull = pp.nfull;
+    if ((int)blockIdx.x < nfull) {
+        sgemm_body_split<TA, TB, true, 2, 2, 1, EPX>(pp.p0, smem_all, blockIdx.x, nfull, 0);
+    } else {
+        const int r = (int)blockIdx.x - nfull, ntail = pp.ntail;
+        sgemm_body_split<TA, TB, true, 2, 2, 1, false>(pp.p1, smem_all, r % ntail, ntail, r / ntail);
+    }
 }
 
 // Second pass of split-K: C = alpha * sum_s slab[s] + beta * C, fixed summation order.
@@ -522,6 +565,65 @@ static int gemm_plan(nk_device* dev, int transA, int transB, int M, int N, int K
     return NK_OK;
 }
 
+// The shared-chip schedule (sgemm_tail_kernel): whole rounds of the free slots as one tile per block, the left-over tiles cut
+// along K.  `p`: the plan of an aligned, unsplit, unbatched 128x128-tile launch.  *taken = false: the grid divides (or the
+// tail cannot be cut usefully) - the caller launches as usual.
+template <bool TA, bool TB>
+static void launch_tail(nk_device* dev, const GemmTailArgs& pp, dim3 grid, bool epx) {
+    if (epx) hipLaunchKernelGGL((sgemm_tail_kernel<TA, TB, true>), grid, dim3(NT), 0, dev->compute, pp);
+    else hipLaunchKernelGGL((sgemm_tail_kernel<TA, TB, false>), grid, dim3(NT), 0, dev->compute, pp);
+}
+static int gemm_tail_launch(nk_device* dev, int transA, int transB, const GemmArgs& p, bool* taken) {
+    *taken = false;
+    const long long T = (long long)p.tiles_m * p.tiles_n;
+    const long long slots = 2LL * dev->num_cus - dev->busy_slots;  // 128x128 blocks: two per CU
+    if (slots < dev->num_cus || T <= slots || T % slots == 0) return NK_OK;
+    const int gsize = p.tiles_m % p.group_m == 0 ? p.group_m : p.tiles_m % p.group_m;  // tile rows of the last group
+    long long tail = T % slots;
+    tail = (tail + gsize - 1) / gsize * gsize;  // whole columns of that group: the tail of the tile sequence is a rectangle
+    if (tail > (long long)gsize * p.tiles_n || tail >= T) return NK_OK;
+    const int ktiles = p.K / BK;
+    long long pieces = slots / tail;
+    if (pieces < 2) return NK_OK;  // more than half a round is left over: the plain grid's last round is full enough
+    int kts = (int)((ktiles + pieces - 1) / pieces);
+    if (kts < 4) kts = 4;  // a piece must outlast its own prologue and slab store
+    const int s_eff = (ktiles + kts - 1) / kts;
+    if (s_eff < 2) return NK_OK;
+    const int cols = (int)(tail / gsize);
+    const int m_lo = (p.tiles_m - gsize) * 128, n_lo = (p.tiles_n - cols) * 128;
+    const int Ms = p.M - m_lo, Ns = p.N - n_lo;
+    void* ws = nullptr;
+    int rc = nk_workspace(dev, (size_t)s_eff * Ms * Ns * sizeof(float), &ws);
+    if (rc) return rc;
+    GemmTailArgs pp;
+    pp.p0 = p;
+    pp.p1 = p;
+    GemmArgs& q = pp.p1;
+    q.A = p.A + (transA ? (long long)m_lo : (long long)m_lo * p.lda);
+    q.B = p.B + (transB ? (long long)n_lo * p.ldb : (long long)n_lo);
+    q.C = p.C + (long long)m_lo * p.ldc + n_lo;
+    q.M = Ms; q.N = Ns;
+    q.tiles_m = gsize; q.tiles_n = cols;
+    q.splits = s_eff; q.k_per_split = kts * BK; q.slabs = (float*)ws;
+    q.bias = nullptr; q.relu = 0; q.mask = nullptr;
+    pp.nfull = (int)(T - tail);
+    pp.ntail = (int)tail;
+    rc = nk_prof_start(dev, NK_KERNEL_SGEMM, 2.0 * p.M * p.N * (double)p.K);
+    if (rc) return rc;
+    const dim3 grid((unsigned)(pp.nfull + tail * s_eff), 1, 1);
+    const bool epx = p.relu || p.mask != nullptr || (!transA && transB);
+    if (!transA && !transB) launch_tail<false, false>(dev, pp, grid, epx);
+    else if (!transA && transB) launch_tail<false, true>(dev, pp, grid, epx);
+    else launch_tail<true, false>(dev, pp, grid, epx);
+    NK_LAUNCH_CHECK();
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(nk_stream_grid((size_t)Ms * Ns, 256)), dim3(256), 0, dev->compute, q.slabs, q.C, Ms, Ns,
+                       p.ldc, s_eff, 1, 1, 0LL, 0LL, p.alpha, p.beta, p.bias ? p.bias + n_lo : nullptr, p.relu,
+                       p.mask ? p.mask + (long long)m_lo * p.ldm + n_lo : nullptr, p.ldm);
+    NK_LAUNCH_CHECK();
+    *taken = true;
+    return nk_prof_stop(dev);
+}
+
 static int gemm_impl(nk_device* dev, int transA, int transB, int M, int N, int K, float alpha,
                      const float* A, int lda, long long sAo, long long sAi, const float* B, int ldb,
                      long long sBo, long long sBi, float beta, float* C, int ldc, long long sCo,
@@ -534,6 +636,12 @@ static int gemm_impl(nk_device* dev, int transA, int transB, int M, int N, int K
     GemmArgs& p = plan.p;
     const int nbatch = plan.nbatch, ti = plan.ti, tj = plan.tj, kg = plan.kg;
     const bool aligned = plan.aligned;
+    if (dev->busy_slots > 0 && ti == 2 && tj == 2 && kg == 1 && aligned && p.splits == 1 && p.chunk == 1 && nbatch == 1 &&
+        !(transA && transB) && dev->tune_gemm_n < 3) {
+        bool taken = false;
+        rc = gemm_tail_launch(dev, transA, transB, p, &taken);
+        if (rc || taken) return rc;
+    }
     if (p.splits > 1) {
         void* ws = nullptr;
         rc = nk_workspace(dev, (size_t)p.splits * nbatch * M * N * sizeof(float), &ws);

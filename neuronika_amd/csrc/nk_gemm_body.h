@@ -4,8 +4,9 @@
 // into a function of (block id, blocks) cost NT 4096^3 1.2 % and all layouts 0.9 % at 2048^3, same box) - so the only thing
 // that differs between the two uses is where a block's position in the tile sequence comes from:
 //   NK_GEMM_BX / NK_GEMM_NBX   this block's index among the blocks of ITS problem / their number
+//   NK_GEMM_SPLIT              which range of the reduction it takes (blockIdx.y, except in sgemm_tail_kernel's second problem)
 // In scope: template parameters TA, TB, ALIGNED, TI, TJ, KG, EPX; `const GemmArgs& p`; `float* smem_all` (the block's LDS).
-// grid.y = split, grid.z = batch in both uses.  Not a stand-alone header.
+// grid.z = batch in every use.  Not a stand-alone header.
     constexpr int BM = 64 * TI, BN = 64 * TJ;
     constexpr bool AKC = !TA;  // A (M x K): k-contiguous unless stored transposed
     constexpr bool BKC = TB;   // B (K x N) stored as N x K when transposed -> k-contiguous
@@ -26,7 +27,7 @@
     int tm, tn;
     tile_of_seq(seq, p.tiles_m, p.tiles_n, tm, tn, p.group_m);
     int m0 = tm * BM, n0 = tn * BN;
-    const int batch = blockIdx.z, split = blockIdx.y;
+    const int batch = blockIdx.z, split = NK_GEMM_SPLIT;
     const int bo = batch / p.batch_inner, bi = batch % p.batch_inner;
     const float* A = p.A + bo * p.sAo + bi * p.sAi;
     const float* B = p.B + bo * p.sBo + bi * p.sBi;

@@ -154,6 +154,12 @@ int nk_device_destroy(nk_device* dev) {
     return NK_OK;
 }
 
+int nk_device_set_busy_slots(nk_device* dev, int n) {
+    NK_CHECK(dev != nullptr && n >= 0 && n <= dev->num_cus, "busy slots: 0 .. number of CUs");
+    dev->busy_slots = n;
+    return NK_OK;
+}
+
 int nk_dev_tune(nk_device* dev, int knob, const int* values, int n) {
     NK_CHECK(dev != nullptr && n >= 0 && (n == 0 || values != nullptr), "bad nk_dev_tune arguments");
     switch (knob) {

@@ -620,6 +620,119 @@ def test_sgemm_is_the_device_order_model_bit_for_bit(dev, ta, tb):
         dev.gemm_force(None); dev.gemm_kpair(None)
 
 
+def shared_chip_plan(M, N, K, busy, cus=256):
+    """The host-side plan of sgemm_tail_kernel (nk_gemm.hip: gemm_tail_launch), restated: None when the launch stays plain,
+    else (m_lo, n_lo, pieces, k-tiles per piece) of the rectangle that is cut along K."""
+    tm, tn, kt = M // 128, N // 128, K // 32
+    T, slots = tm * tn, 2 * cus - busy
+    if slots < cus or T <= slots or T % slots == 0:
+        return None
+    g = 8 if tm % 8 == 0 else tm % 8
+    tail = -(-(T % slots) // g) * g
+    if tail > g * tn or tail >= T or slots // tail < 2:
+        return None
+    kts = max(4, -(-kt // (slots // tail)))
+    pieces = -(-kt // kts)
+    if pieces < 2:
+        return None
+    return (tm - g) * 128, (tn - tail // g) * 128, pieces, kts
+
+
+@pytest.mark.parametrize("layout", ["NT", "NN", "TN"])
+@pytest.mark.parametrize("M,N,K,busy", [(3072, 3072, 512, 16), (2048, 4096, 1024, 8), (4096, 2048, 384, 32), (3072, 3200 - 128, 256, 100),
+                                        (2944, 3072, 640, 16)])
+def test_gemm_shared_chip_schedule(dev, layout, M, N, K, busy):
+    """nk_device_set_busy_slots(n): while an exchange holds n resident-block slots, a GEMM whose tiles no longer divide the free
+    slots runs whole rounds of one tile per block and cuts the LEFT-OVER tiles - a rectangle at the end of the tile sequence -
+    along K (sgemm_tail_kernel).  Checked, for the three layouts of a Linear layer's passes with their epilogues (NT: bias +
+    ReLU forward; NN: the masked input gradient, beta = 1; TN: the weight gradient, beta = 1):
+      * outside the rectangle the result is the plain launch's, bit for bit;
+      * inside it equals the same product of the sub-matrices under split-K with the plan's piece length (pieces added in
+        order, the launch's epilogue applied once) - bit for bit, through the forced split-K schedule of nk_sgemm;
+      * the whole result is inside the contraction bound against f64;
+      * run to run identical; busy = 0 afterwards gives the plain bits again."""
+    from tolerance import assert_contraction
+    c = capi()
+    ta, tb = {"NT": (0, 1), "NN": (0, 0), "TN": (1, 0)}[layout]
+    plan = shared_chip_plan(M, N, K, busy, dev.num_cus() if hasattr(dev, "num_cus") else 256)
+    assert plan is not None, "the case is meant to take the shared-chip schedule"
+    m_lo, n_lo, pieces, kts = plan
+    a = rnd(1, (K, M) if ta else (M, K), -1, 1)
+    b = rnd(2, (N, K) if tb else (K, N), -1, 1)
+    c0 = rnd(3, (M, N), -1, 1)
+    bias = rnd(4, (N,), -1, 1)
+    mask = rnd(5, (M, N), -1, 1)
+    A, B, Bi, Mk = dev.array(a), dev.array(b), dev.array(bias), dev.array(mask)
+
+    def run(Ad, Bd, Cd, biasd, maskd, m, n):
+        if layout == "NT":
+            c.linear_relu_fwd(dev, Ad, Bd, biasd, Cd)                         # C = max(A . B^T + bias, 0)
+        elif layout == "NN":
+            c.linear_bwd_input_relu(dev, Cd, Ad, Bd, maskd)                   # C += (A . B) where mask > 0
+        else:
+            c.sgemm(dev, 1, 0, m, n, K, 1.0, Ad, m, Bd, n, 1.0, Cd, n)       # C += A^T . B
+        return Cd.numpy()
+
+    plain = run(A, B, dev.array(c0), Bi, Mk, M, N)
+    try:
+        dev.busy_slots(busy)
+        shared = run(A, B, dev.array(c0), Bi, Mk, M, N)
+        again = run(A, B, dev.array(c0), Bi, Mk, M, N)
+    finally:
+        dev.busy_slots(0)
+    assert np.array_equal(shared, again)
+    assert np.array_equal(run(A, B, dev.array(c0), Bi, Mk, M, N), plain)
+    outside = np.ones((M, N), bool); outside[m_lo:, n_lo:] = False
+    assert np.array_equal(shared[outside], plain[outside])
+    assert not np.array_equal(shared[m_lo:, n_lo:], plain[m_lo:, n_lo:])      # the rectangle really is another chain order
+    # the rectangle as a problem of its own, split-K forced to the plan's pieces (kts k-tiles each)
+    opa, opb = (a.T if ta else a), (b.T if tb else b)
+    sa, sb = opa[m_lo:], opb[:, n_lo:]
+    sub_a = np.ascontiguousarray(sa.T if ta else sa)
+    sub_b = np.ascontiguousarray(sb.T if tb else sb)
+    assert -(-(K // 32) // pieces) == kts, "test case: the forced split must reproduce the plan's piece length"
+    try:
+        dev.gemm_force(f"2,2,{pieces}"); dev.gemm_kpair(0)
+        sub = run(dev.array(sub_a), dev.array(sub_b), dev.array(c0[m_lo:, n_lo:]), dev.array(bias[n_lo:]), dev.array(mask[m_lo:, n_lo:]),
+                  M - m_lo, N - n_lo)
+    finally:
+        dev.gemm_force(None); dev.gemm_kpair(None)
+    assert np.array_equal(shared[m_lo:, n_lo:], sub)
+    prod = opa.astype(np.float64) @ opb.astype(np.float64)
+    if layout == "NT":
+        want, cpu = np.maximum(prod + bias, 0), np.maximum(opa @ opb + bias, 0)
+    elif layout == "NN":
+        want, cpu = c0 + np.where(mask > 0, prod, 0), c0 + np.where(mask > 0, opa @ opb, 0).astype(np.float32)
+    else:
+        want, cpu = c0 + prod, c0 + opa @ opb
+    assert_contraction("gemm_shared_chip_schedule", shared, want, K, cpu32=cpu, epilogue=True)
+
+
+def test_gemm_shared_chip_schedule_leaves_other_launches_alone(dev):
+    """Grids that divide the free slots, fit into one round, are split / batched / ragged / 64-wide, or whose left-over is more
+    than half a round stay plain launches under nk_device_set_busy_slots: bit-identical results."""
+    c = capi()
+    try:
+        for (M, N, K, ta, tb, busy) in ((1024, 1024, 512, 0, 1, 16), (2048, 2048, 256, 0, 0, 16), (4096, 3968, 128, 0, 1, 16),
+                                        (1000, 3000, 300, 1, 0, 8), (3072, 3072, 256, 1, 1, 16), (4096, 4096, 64, 0, 1, 0),
+                                        (2816, 2816, 128, 0, 1, 200)):
+            a = rnd(1, (K, M) if ta else (M, K), -1, 1)
+            b = rnd(2, (N, K) if tb else (K, N), -1, 1)
+            A, B = dev.array(a), dev.array(b)
+            outs = []
+            for n in (0, busy):
+                dev.busy_slots(n)
+                Cd = dev.full((M, N), 0.5)
+                c.sgemm(dev, ta, tb, M, N, K, 1.0, A, a.shape[1], B, b.shape[1], 1.0, Cd, N)
+                outs.append(Cd.numpy())
+            if ta and tb or shared_chip_plan(M, N, K, busy) is None or M % 128 or N % 128 or K % 32:
+                assert np.array_equal(outs[0], outs[1]), (M, N, K, ta, tb, busy)
+    finally:
+        dev.busy_slots(0)
+    with pytest.raises(RuntimeError):
+        dev.busy_slots(-1)
+
+
 def test_sgemm_large_rowsum_identity(dev):
     """Size-independent check at the BASELINE size (4096^2): (A.B).1 == A.(B.1)."""
     c = capi()
