@@ -291,7 +291,7 @@ def cpu_baseline_mlp(hidden, rows):
                         f"fwd+bwd step of the same 3x Linear({hidden},{hidden}) MLP on all {rows} rows of the batch")
 
 
-def cpu_baseline_matmul(n):
+def cpu_baseline_matmul(n, min_s=6.0):
     from oracle import neuronika_oracle as O
     mk = lambda s: np.random.default_rng(s).random((n, n), dtype=np.float32)
     A, B, G = mk(0), mk(1), mk(2)
@@ -299,10 +299,10 @@ def cpu_baseline_matmul(n):
 
     def fn():
         O.mm_forward(A, B, Cm); O.mm_backward_left(dA, G, B); O.mm_backward_right(dB, G, A)
-    return cpu_baseline("TFLOP/s", 6.0 * n ** 3 / 1e12, fn, f"mm forward + both backward GEMMs at N={n}")
+    return cpu_baseline("TFLOP/s", 6.0 * n ** 3 / 1e12, fn, f"mm forward + both backward GEMMs at N={n}", min_s=min_s)
 
 
-def cpu_baseline_conv(batch=128):
+def cpu_baseline_conv(batch=128, min_s=5.0):
     """C3 on the host.  The reference's convolution is batch-parallel under rayon on every core
     (node/convolution/mod.rs:110-122), each task a single-threaded sgemm: modelled as a pool of worker PROCESSES
     (spawned, so none inherits this process's HIP state), one BLAS thread each, the batch split evenly.  The
@@ -325,7 +325,7 @@ def cpu_baseline_conv(batch=128):
             list(ex.map(_conv_chunk, [(i, per) for i in range(workers)]))
             reps += 1
             dt = time.perf_counter() - t0
-            if dt >= 5.0 or reps >= 16:
+            if dt >= min_s or reps >= 16:
                 break
     done = reps * per * workers
     main = {"value": round(done / dt, 3), "unit": "samples/s", "cores": workers, "kind": "port",
@@ -337,7 +337,7 @@ def cpu_baseline_conv(batch=128):
     return main
 
 
-def cpu_baseline_mha(b_sample, S, d, H, p):
+def cpu_baseline_mha(b_sample, S, d, H, p, min_s=5.0):
     from oracle import neuronika_oracle as O
     rng = np.random.default_rng(0)
     x = rng.random((b_sample * S, d), dtype=np.float32)
@@ -348,7 +348,7 @@ def cpu_baseline_mha(b_sample, S, d, H, p):
 
     def fn():
         O.mha_forward_backward(x, ws[0][0], ws[0][1], ws[1][0], ws[1][1], ws[2][0], ws[2][1], ws[3][0], ws[3][1], H, b_sample, p, noise, g)
-    return cpu_baseline("sequences/s", b_sample, fn, f"MHA fwd+bwd on {b_sample} of the 32 sequences (mask pre-drawn)", min_s=5.0,
+    return cpu_baseline("sequences/s", b_sample, fn, f"MHA fwd+bwd on {b_sample} of the 32 sequences (mask pre-drawn)", min_s=min_s,
                         scaled_from=f"{b_sample} of 32 sequences (per-sequence work is independent except the weight-gradient sums)")
 
 
@@ -433,6 +433,53 @@ def measure_conv(dist, tdev, cdev, steps, warmup):
             "step_tflops": round(3 * 2.0 * N * 128 * 56 * 56 * 64 * 9 * steps / dt / 1e12, 2),
             "roofline": roofline_mfma(conv_stats, "conv_fwd_fast / conv_bwd_input_fast / conv_bwd_kernel (implicit GEMM, f32 MFMA)", "conv"),
             "conv_share_of_step": round(conv_stats[1] / ev_ms, 4) if ev_ms > 0 else None}
+
+
+def measure_hbm_kernels(cdev):
+    """The HBM-bound kernels of the path on 256 MB tensors (beyond the 256 MB Infinity Cache: HBM rates), HIP events on the
+    compute stream: algorithmic bytes (4 B x elements read + written) / time, as a fraction of the 8.0 TB/s
+    peak and of what a plain device-to-device copy reaches in the same run (the achievable ceiling; the guide quotes 6.29)."""
+    from neuronika_amd import capi as c
+    rows, L = 64 * 1024, 1024                       # one eighth of the C5 score tensor per buffer
+    n = rows * L
+    rng = np.random.default_rng(0)
+    X = cdev.array(rng.random((rows, L), dtype=np.float32) * 8 - 4)
+    G = cdev.array(rng.random((rows, L), dtype=np.float32))
+    Y, D, NZ = cdev.zeros((rows, L)), cdev.zeros((rows, L)), cdev.zeros((rows, L))
+
+    def timeit(fn, settle_ms=25.0, min_ms=25.0):
+        e0, e1 = cdev.event(), cdev.event()
+        e0.record(); calls = 0
+        while True:
+            fn(); fn(); calls += 2
+            e1.record(); e1.sync()
+            if e0.elapsed_ms(e1) >= settle_ms:
+                break
+        iters = max(4, int(min_ms / max(e0.elapsed_ms(e1) / calls, 1e-3)) + 1)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record(); e1.sync()
+        return e0.elapsed_ms(e1) / iters
+
+    copy_ms = timeit(lambda: c.check(c.lib.nk_copy(cdev.h, Y.p, X.p, n)))
+    copy_rate = 8 * n / (copy_ms * 1e-3)
+    cases = [("softmax_fwd", lambda: c.softmax_fwd(cdev, X, Y, 1), 8 * n),
+             ("softmax_bwd", lambda: c.softmax_bwd(cdev, D, G, Y, 1), 16 * n),
+             ("dropout_fwd", lambda: c.dropout_fwd(cdev, X, Y, NZ, 0.1, True, 7, 0), 12 * n),
+             ("dropout_bwd", lambda: c.dropout_bwd(cdev, D, G, NZ, 0.1, True), 16 * n),
+             ("relu_bwd", lambda: c.relu_bwd(cdev, D, G, X), 16 * n),
+             ("sgd_multi (3 parameters)", lambda: c.sgd_step_multi(cdev, [X, Y, D], [G, G, G], None, lr=1e-12), 3 * 12 * n)]
+    out = {"workload": "HBM-bound kernels of the path on 64Ki x 1024 f32 tensors (256 MB each)",
+           "copy_GBps": round(copy_rate / 1e9, 1), "copy_frac_of_peak": round(copy_rate / HBM_PEAK, 4), "peak_GBps": HBM_PEAK / 1e9,
+           "guide_copy_ceiling_GBps": 6290.0, "kernels": {}}
+    for name, fn, nbytes in cases:
+        ms = timeit(fn)
+        rate = nbytes / (ms * 1e-3)
+        out["kernels"][name] = {"bound": "hbm", "algorithmic_bytes": nbytes, "ms": round(ms, 4), "achieved": round(rate / 1e9, 1), "unit": "GB/s",
+                                "frac": round(rate / HBM_PEAK, 4), "frac_of_copy_this_run": round(rate / copy_rate, 4),
+                                "frac_of_guide_copy_ceiling": round(rate / 6.29e12, 4)}
+    return out
 
 
 def measure_mha(dist, tdev, cdev, steps, warmup):
@@ -642,6 +689,13 @@ def run_mlp(a, dist):
             subs[f"matmul_{n}"] = matmul_record(dist, cdev, n, SUB_STEPS, SUB_WARMUP)
         subs["conv_c3"] = measure_conv(dist, tdev, cdev, SUB_STEPS, SUB_WARMUP)
         subs["mha_c5"] = measure_mha(dist, tdev, cdev, SUB_STEPS, SUB_WARMUP)
+        subs["hbm_kernels"] = measure_hbm_kernels(cdev)
+        if not a.no_cpu_baseline:
+            # the oracle on this host beside every configuration, bounded samples (a few seconds each; the stand-alone
+            # workloads `--workload matmul | conv | mha` time the longer ones of BASELINE.md section 4)
+            subs["matmul_4096"]["cpu_baseline"] = cpu_baseline_matmul(4096, min_s=2.0)
+            subs["conv_c3"]["cpu_baseline"] = cpu_baseline_conv(min_s=2.0)
+            subs["mha_c5"]["cpu_baseline"] = cpu_baseline_mha(1, 1024, 1024, 16, 0.1, min_s=1.5)
     elif os.environ.get("NK_BENCH_NO_SUBRECORDS") != "2":   # ("2": the C4 step alone - kernel traces of exactly this workload)
         subs["matmul_4096"] = matmul_record(dist, cdev, 4096, SUB_STEPS, SUB_WARMUP)
     res = None

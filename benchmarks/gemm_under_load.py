@@ -58,29 +58,54 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "defence":
         # round 5: the same launches with the device handle told how many slots the generator holds
         # (nk_device_set_busy_slots -> sgemm_tail_kernel: whole rounds of the free slots + the left-over tiles cut along K)
-        # against the plain launches, alternating under ONE background pass each; and what a wrong guess costs on an idle chip.
-        for channels in (8, 16, 32, 64):
-            dev.busy_slots(channels)
-            idle_told = gemms(4)
+        # against the plain launches - INTERLEAVED under one background pass (plain, told, plain, told ... per layout, three
+        # rounds, after ~12 ms of untimed GEMMs: the first measurement behind an idle gap reads high, r04's NT column) - and what
+        # a wrong guess costs on an idle chip.  Median of the three rounds, us per launch.
+        import statistics
+
+        def one(ta, tb, reps=3):
+            e0, e1 = dev.event(), dev.event()
+            e0.record()
+            for _ in range(reps):
+                c.sgemm(dev, ta, tb, n, n, n, 1.0, A, n, B, n, 0.0, Cm, n)
+            e1.record(); e1.sync()
+            return e0.elapsed_ms(e1) / reps * 1e3
+
+        def interleaved(busy):
+            for _ in range(12):
+                c.sgemm(dev, 0, 1, n, n, n, 1.0, A, n, B, n, 0.0, Cm, n)
+            got = {(name, b): [] for name, _, _ in layouts for b in (0, busy)}
+            for _ in range(3):
+                for name, ta, tb in layouts:
+                    for b in (0, busy):
+                        dev.busy_slots(b)
+                        got[(name, b)].append(one(ta, tb))
             dev.busy_slots(0)
-            print(json.dumps({"background": "none, but told busy", "busy_slots": channels, "gemm_us": idle_told,
-                              "slowdown": {k: round(idle_told[k] / base[k], 4) for k in idle_told}}), flush=True)
-        for channels, gbps in ((8, 25.0), (16, 50.0), (32, 50.0), (64, 100.0)):
-            row = {"background": "hbm", "channels": channels, "asked_GBps": gbps}
-            for rep in range(2):
-                for busy in (0, channels):
-                    comm = c.Comm(dev, 1, 0, None, channels=channels, gbps=gbps)
-                    count = min(big.size, int(gbps * 1e9 * 0.045 / 4))
-                    comm.allreduce_sum_async(Raw(big.p.value, count))
-                    dev.busy_slots(busy)
-                    t = gemms(4)
-                    dev.busy_slots(0)
-                    comm.join(); dev.sync(); comm.close()
-                    key = f"{'defended' if busy else 'plain'}_run{rep}"
-                    row[key + "_us"] = t
-                    row[key + "_slowdown"] = {k: round(t[k] / base[k], 4) for k in t}
+            return {f"{name}_{'told' if b else 'plain'}": round(statistics.median(v), 1) for (name, b), v in got.items() if b or True}
+
+        rate = 16.0                                   # GB/s each way: the loss does not follow the rate (r04); 1.9 GB lasts ~120 ms
+        for channels in (8, 16, 32, 64):
+            idle = interleaved(channels)
+            comm = c.Comm(dev, 1, 0, None, channels=channels, gbps=rate)
+            count = min(big.size, int(rate * 1e9 * 0.12 / 4))
+            bg0, bg1 = dev.event(), dev.event()
+            bg0.record(comm_stream=True)
+            comm.allreduce_sum_async(Raw(big.p.value, count))
+            bg1.record(comm_stream=True)
+            e_start, e_end = dev.event(), dev.event()
+            e_start.record()
+            loaded = interleaved(channels)
+            e_end.record(); e_end.sync()
+            gemm_window_ms = e_start.elapsed_ms(e_end)
+            comm.join(); dev.sync()
+            pass_ms = bg0.elapsed_ms(bg1)
+            comm.close()
+            row = {"channels": channels, "busy_slots_told": channels, "background_pass_ms": round(pass_ms, 1), "gemm_window_ms": round(gemm_window_ms, 1),
+                   "covered": pass_ms >= gemm_window_ms, "idle_chip_us": idle, "beside_generator_us": loaded}
+            row["loss_plain"] = {k: round(loaded[f"{k}_plain"] / idle[f"{k}_plain"] - 1, 4) for k, _, _ in layouts}
+            row["loss_told"] = {k: round(loaded[f"{k}_told"] / idle[f"{k}_plain"] - 1, 4) for k, _, _ in layouts}
+            row["idle_cost_of_telling"] = {k: round(idle[f"{k}_told"] / idle[f"{k}_plain"] - 1, 4) for k, _, _ in layouts}
             print(json.dumps(row), flush=True)
-        print(json.dumps({"background": "none (again)", "gemm_us": gemms(8)}), flush=True)
         c.check(c.lib.nk_host_free(hp))
         return
     for where, buf, points in (("hbm", big, ((16, 50.0), (16, 100.0), (16, 200.0), (32, 400.0), (64, 800.0))),

@@ -1985,6 +1985,13 @@ MultiheadAttention::MultiheadAttention(DevicePtr dev, int d_model_, int heads_, 
     : q(placeholder_linear(dev)), k(placeholder_linear(dev)), v(placeholder_linear(dev)), o(dev, d_model_, d_model_, seed + 6),
       d_model(d_model_), heads(heads_), drop(p) {
     if (d_model % heads != 0) panic("d_model must be divisible by heads");
+    if (d_model % 4 != 0) {
+        // the bias views of a packed allocation start d and 2d floats in: not 16-byte aligned unless d % 4 == 0, and kernels
+        // that take whole float4s (nk_fill with a value, the pointwise kernels) refuse such a buffer.  Three ordinary layers.
+        q = Linear(dev, d_model, d_model, seed); k = Linear(dev, d_model, d_model, seed + 2); v = Linear(dev, d_model, d_model, seed + 4);
+        packed_qkv = false;
+        return;
+    }
     wqkv_ = std::make_shared<HipArray>(dev, Shape{3 * d_model, d_model});
     bqkv_ = std::make_shared<HipArray>(dev, Shape{3 * d_model});
     gwqkv_ = std::make_shared<HipArray>(dev, Shape{3 * d_model, d_model}, HipArray::Uninit{});
@@ -2034,7 +2041,20 @@ VarDiff MultiheadAttention::forward(const VarDiff& x, int batch) const {
     const int rows = x.shape()[0], S = rows / batch, dh = d_model / heads;
     if (rows % batch != 0 || x.shape()[1] != d_model) panic("MultiheadAttention: bad input shape");
     const float scale = 1.f / std::sqrt((float)dh);
-    if (packed_qkv && wqkv_ && strided_heads && fused && fused_core && q.fused && k.fused && v.fused && Var::attention_core_supported(S, dh, drop.p))
+    // q / k / v are public members: the packed path is only valid while they still ARE the views of the packed storage
+    // (after `mha.q = Linear(...)` or a swap with deserialised layers the three-node path below runs on the new layers)
+    auto still_packed = [&]() {
+        const Linear* ls[3] = {&q, &k, &v};
+        const size_t dd = (size_t)d_model * d_model;
+        for (int i = 0; i < 3; ++i) {
+            if (ls[i]->weight.var.data->ptr() != wqkv_->ptr() + i * dd || ls[i]->bias.var.data->ptr() != bqkv_->ptr() + (size_t)i * d_model) return false;
+            if (ls[i]->weight.shape() != Shape{d_model, d_model} || ls[i]->bias.shape() != Shape{d_model}) return false;
+            if (!ls[i]->weight.grad->is_view_of(gwqkv_, i * dd) || !ls[i]->bias.grad->is_view_of(gbqkv_, (size_t)i * d_model)) return false;
+        }
+        return true;
+    };
+    if (packed_qkv && wqkv_ && strided_heads && fused && fused_core && q.fused && k.fused && v.fused && Var::attention_core_supported(S, dh, drop.p) &&
+        still_packed())
         return o.forward(qkv_attention_node(*this, wqkv_, bqkv_, gwqkv_, gbqkv_, x, batch, S, heads, dh, scale));
     if (strided_heads && dh % 4 == 0) {  // attention GEMMs address the heads inside the projection layout: no copies
         const VarDiff Qf = q.forward(x), Kf = k.forward(x), Vf = v.forward(x);
@@ -2243,6 +2263,9 @@ void SGD::step() {
         w.clear(); g.clear(); v.clear(); n.clear();
         for (size_t k = i; k < params_.size(); ++k) {
             if (done[k] || params_[k].device().get() != dev.get()) continue;
+            // a parameter registered twice is updated twice, one after the other (the reference iterates its list,
+            // optimizer.rs:81-86): the second registration waits for a later launch instead of racing in this one
+            if (std::find(w.begin(), w.end(), params_[k].var.data->ptr()) != w.end()) continue;
             done[k] = true;
             ++steps_[k];
             HipArray& gr = params_[k].grad->borrow();

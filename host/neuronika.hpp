@@ -178,6 +178,8 @@ class Gradient : public NoGrad {
     void zero();                           // `zero_grad` (vardiff.rs:100-102), lazily
     bool zero_pending() const { return pending_zero_; }
     Shared<HipArray> array() const { return array_; }
+    // true for a view gradient over `storage` starting `offset` elements in (packed parameters)
+    bool is_view_of(const Shared<HipArray>& storage, size_t offset) const { return storage_ && storage_.get() == storage.get() && offset_ == offset; }
     // Stand `external` in for this gradient's buffer (returns the previous one) without touching device memory: how
     // `VarDiff::backward_from` presents an upstream gradient tensor to the root's backward nodes (they read through
     // `borrow()` at run time).  The buffer counts as written.

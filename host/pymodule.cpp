@@ -319,10 +319,10 @@ PYBIND11_MODULE(_tape, m) {
     py::class_<nn::MultiheadAttention>(nn, "MultiheadAttention")
         .def(py::init<DevicePtr, int, int, double, uint64_t>(), py::arg("dev"), py::arg("d_model"), py::arg("heads"),
              py::arg("p") = 0.0, py::arg("seed") = 0)
-        .def_readonly("q", &nn::MultiheadAttention::q)
-        .def_readonly("k", &nn::MultiheadAttention::k)
-        .def_readonly("v", &nn::MultiheadAttention::v)
-        .def_readonly("o", &nn::MultiheadAttention::o)
+        .def_readwrite("q", &nn::MultiheadAttention::q)   // public, assignable members in the C++ mirror as well
+        .def_readwrite("k", &nn::MultiheadAttention::k)
+        .def_readwrite("v", &nn::MultiheadAttention::v)
+        .def_readwrite("o", &nn::MultiheadAttention::o)
         .def_readonly("drop", &nn::MultiheadAttention::drop)
         .def_readwrite("fused", &nn::MultiheadAttention::fused)
         .def_readwrite("strided_heads", &nn::MultiheadAttention::strided_heads)

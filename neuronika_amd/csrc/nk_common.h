@@ -44,6 +44,7 @@ struct nk_device {
     int tune_attn_occ = 0;                   // attention forward: 2 = size the register budget for two blocks per CU
     // bench instrumentation (nk_profile_begin/end)
     bool prof_on = false;
+    bool prof_window = false;           // between nk_profile_begin and the first nk_profile_end
     std::vector<nk_prof_rec> prof;      // records of the current window
     std::vector<nk_prof_rec> prof_free;  // recycled event pairs
 };

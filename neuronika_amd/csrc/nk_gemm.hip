@@ -628,10 +628,10 @@ static int gemm_impl(nk_device* dev, int transA, int transB, int M, int N, int K
                      const float* A, int lda, long long sAo, long long sAi, const float* B, int ldb,
                      long long sBo, long long sBi, float beta, float* C, int ldc, long long sCo,
                      long long sCi, int batch_outer, int batch_inner, const float* bias = nullptr, int relu = 0,
-                     const float* mask = nullptr, long long ldm = 0) {
+                     const float* mask = nullptr, long long ldm = 0, bool allow_kpair = true) {
     GemmPlan plan;
     int rc = gemm_plan(dev, transA, transB, M, N, K, alpha, A, lda, sAo, sAi, B, ldb, sBo, sBi, beta, C, ldc, sCo, sCi, batch_outer,
-                       batch_inner, bias, relu, mask, ldm, &plan);
+                       batch_inner, bias, relu, mask, ldm, &plan, allow_kpair);
     if (rc || plan.empty) return rc;
     GemmArgs& p = plan.p;
     const int nbatch = plan.nbatch, ti = plan.ti, tj = plan.tj, kg = plan.kg;
@@ -694,9 +694,12 @@ static int launch_pair(nk_device* dev, const GemmPairArgs& pp, dim3 grid, int ti
 // otherwise.
 static int gemm_pair_impl(nk_device* dev, const GemmProblem& a, const GemmProblem& b, int batch_outer, int batch_inner) {
     NK_USE(dev);
+    // (the plan of a launch of its own WITHOUT k-pair blocks, like the pair's: the bits of a MatMul node's gradients are a function
+    //  of the shapes alone - not of which of the two routes the fit-the-chip rule picks, nor of whether the node's other operand
+    //  is differentiable: the single-product entry points nk_mm_bwd_left / _right plan the same way)
     auto alone = [&](const GemmProblem& q) {
         return gemm_impl(dev, q.transA, q.transB, q.M, q.N, q.K, 1.f, q.A, q.lda, q.sAo, q.sAi, q.B, q.ldb, q.sBo, q.sBi, q.beta, q.C, q.ldc,
-                         q.sCo, q.sCi, batch_outer, batch_inner);
+                         q.sCo, q.sCi, batch_outer, batch_inner, nullptr, 0, nullptr, 0, false);
     };
     auto two_launches = [&]() { const int rc = alone(a); return rc ? rc : alone(b); };
     const int mode = dev->tune_pair;  // -1 rule, 0 never, 1 whenever eligible
@@ -796,11 +799,17 @@ int nk_sgemm_batched(nk_device* dev, int transA, int transB, int M, int N, int K
 int nk_mm_fwd(nk_device* dev, const float* A, const float* B, float* C, int n, int m, int o) {
     return nk_sgemm(dev, 0, 0, n, o, m, 1.f, A, m, B, o, 0.f, C, o);
 }
+// one product of a MatMul node's backward pass: the plan of nk_mm_bwd's products (no k-pair blocks), so that a gradient's bits do
+// not depend on whether the node's other operand is differentiable
+static int node_bwd_product(nk_device* dev, int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                            float* C, int ldc) {
+    return gemm_impl(dev, transA, transB, M, N, K, 1.f, A, lda, 0, 0, B, ldb, 0, 0, 1.f, C, ldc, 0, 0, 1, 1, nullptr, 0, nullptr, 0, false);
+}
 int nk_mm_bwd_left(nk_device* dev, float* dA, const float* G, const float* B, int n, int m, int o) {
-    return nk_sgemm(dev, 0, 1, n, m, o, 1.f, G, o, B, o, 1.f, dA, m);  // dA += G . B^T
+    return node_bwd_product(dev, 0, 1, n, m, o, G, o, B, o, dA, m);  // dA += G . B^T
 }
 int nk_mm_bwd_right(nk_device* dev, float* dB, const float* A, const float* G, int n, int m, int o) {
-    return nk_sgemm(dev, 1, 0, m, o, n, 1.f, A, m, G, o, 1.f, dB, o);  // dB += A^T . G
+    return node_bwd_product(dev, 1, 0, m, o, n, A, m, G, o, dB, o);  // dB += A^T . G
 }
 int nk_sgemm_pair(nk_device* dev, int transA0, int transB0, int M0, int N0, int K0, const float* A0, int lda0, const float* B0, int ldb0,
                   float beta0, float* C0, int ldc0, int transA1, int transB1, int M1, int N1, int K1, const float* A1, int lda1,
@@ -845,10 +854,10 @@ int nk_linear_bwd_input_relu(nk_device* dev, float* dX, const float* G, const fl
     return gemm_impl(dev, 0, 0, n, m, o, 1.f, G, o, 0, 0, W, m, 0, 0, assign ? 0.f : 1.f, dX, m, 0, 0, 1, 1, nullptr, 0, X, m);
 }
 int nk_mm_t_bwd_left(nk_device* dev, float* dA, const float* G, const float* B, int n, int m, int o) {
-    return nk_sgemm(dev, 0, 0, n, m, o, 1.f, G, o, B, m, 1.f, dA, m);  // dA += G . B
+    return node_bwd_product(dev, 0, 0, n, m, o, G, o, B, m, dA, m);  // dA += G . B
 }
 int nk_mm_t_bwd_right(nk_device* dev, float* dB, const float* G, const float* A, int n, int m, int o) {
-    return nk_sgemm(dev, 1, 0, o, m, n, 1.f, G, o, A, m, 1.f, dB, m);  // dB += G^T . A
+    return node_bwd_product(dev, 1, 0, o, m, n, G, o, A, m, dB, m);  // dB += G^T . A
 }
 
 }  // extern "C"

@@ -74,11 +74,14 @@ int nk_profile_begin(nk_device* dev) {
     for (auto& r : dev->prof) dev->prof_free.push_back(r);
     dev->prof.clear();
     dev->prof_on = true;
+    dev->prof_window = true;
     return NK_OK;
 }
 
 int nk_profile_pause(nk_device* dev, int paused) {
     NK_USE(dev);
+    // only inside a begin / end window: resuming outside one would switch event pairs on with nothing to drain them
+    NK_CHECK(dev->prof_window, "nk_profile_pause outside an nk_profile_begin / nk_profile_end window");
     dev->prof_on = paused == 0;   // the records collected so far stay: nk_profile_end reads them
     return NK_OK;
 }
@@ -87,6 +90,7 @@ int nk_profile_end(nk_device* dev, int kernel_class, int* launches, double* tota
     NK_USE(dev);
     NK_CHECK(launches && total_ms && total_flop, "null output");
     dev->prof_on = false;
+    dev->prof_window = false;
     NK_HIP(hipStreamSynchronize(dev->compute));
     int n = 0;
     double ms = 0.0, flop = 0.0;

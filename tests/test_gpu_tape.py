@@ -894,6 +894,48 @@ def test_heads_attention_node_without_gradients_keeps_nothing(nk, tdev):
                                                                         nk.from_ndarray(tdev, rnd(6, (64, 32), -1, 1)), 1, 64, 2, 16, 0.1, 0.0, st)
 
 
+def test_mha_packed_views_guards(nk, tdev):
+    """ADVICE r04: (a) d_model % 4 != 0 - the packed bias views would start 16-byte-unaligned, and `nn::init::constant` /
+    the pointwise kernels refuse such buffers: the module then holds three ordinary layers; (b) q / k / v are assignable
+    members - after `mha.q = Linear(...)` forward must run on the NEW layer (three-node path), not on the stale packed
+    storage; (c) a parameter registered twice with SGD is updated twice, one after the other."""
+    mha = nk.nn.MultiheadAttention(tdev, 6, 3, 0.0, 5)               # d_model = 6: not a multiple of 4
+    for lin in (mha.q, mha.k, mha.v):
+        nk.nn.init.constant(lin.bias, 0.25)                          # nk_fill with a value on every bias
+        assert np.all(lin.bias.data() == 0.25)
+    X = nk.from_ndarray(tdev, rnd(1, (2 * 5, 6), -1, 1)).requires_grad()
+    y = mha.forward(X, 2); s = (y * y).sum(); s.forward(); s.backward(1.0)
+    assert np.isfinite(X.grad()).all() and np.abs(mha.k.bias.grad()).sum() >= 0
+
+    d, H, B, S = 128, 2, 2, 64
+    x = rnd(2, (B * S, d), -1, 1)
+    ref = nk.nn.MultiheadAttention(tdev, d, H, 0.0, 7)
+    new_q = nk.nn.Linear(tdev, d, d, 99)
+    outs = []
+    for packed in (True, False):
+        mha = nk.nn.MultiheadAttention(tdev, d, H, 0.0, 7)
+        mha.packed_qkv = packed
+        mha.q = nk.nn.Linear(nk.from_ndarray(tdev, new_q.weight.data()).requires_grad(), nk.from_ndarray(tdev, new_q.bias.data()).requires_grad())
+        X = nk.from_ndarray(tdev, x).requires_grad()
+        y = mha.forward(X, B)
+        assert y.history_len() == 5                                  # q, k, v, core, out-projection: the packed node is not taken
+        s = (y * y).sum(); s.forward(); s.backward(1.0)
+        outs.append([y.data(), X.grad(), mha.q.weight.grad(), mha.k.weight.grad()])
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+    assert np.abs(outs[0][2]).sum() > 0                              # the gradient landed in the NEW layer
+    yref = ref.forward(nk.from_ndarray(tdev, x).requires_grad(), B); yref.forward()
+    assert not np.array_equal(yref.data(), outs[0][0])
+
+    w = nk.from_ndarray(tdev, np.ones((4, 4), np.float32)).requires_grad()
+    opt = nk.optim.SGD(0.5)
+    opt.register(w); opt.register(w)
+    (w * 1.0).sum().forward()
+    loss = (w * 2.0).sum(); loss.forward(); loss.backward(1.0)      # grad = 2
+    opt.step()
+    assert np.all(w.data() == 1.0 - 2 * 0.5 * 2.0)                  # two sequential updates
+
+
 def test_backward_from_equals_weighted_sum_scaffolding(nk, tdev):
     """`y.backward_from(G)` (the upstream gradient tensor stands in for the root gradient while the tape runs - no copy,
     no extra nodes) gives bit-identical leaf gradients to the scaffolding `(y * G).sum().backward(1.0)`; the seed is left
