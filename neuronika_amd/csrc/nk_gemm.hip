@@ -584,7 +584,10 @@ static int gemm_tail_launch(nk_device* dev, int transA, int transB, const GemmAr
     if (tail > (long long)gsize * p.tiles_n || tail >= T) return NK_OK;
     const int ktiles = p.K / BK;
     long long pieces = slots / tail;
-    if (pieces < 2) return NK_OK;  // more than half a round is left over: the plain grid's last round is full enough
+    // Fewer than four pieces per left-over tile (more than a quarter of a round left over: 64 busy slots at 4096^3) and the cut
+    // costs more than the ragged round it replaces: told 9.8 - 10.4 % against 7.0 - 12.2 % plain with 64 foreign workgroups,
+    // while 8 / 16 / 32 give 3.3 - 5.0 / 3.2 - 5.2 / 4.9 - 6.9 % against 7.1 - 13.5 % (profiles/r05_gemm_under_load.md)
+    if (pieces < 4) return NK_OK;
     int kts = (int)((ktiles + pieces - 1) / pieces);
     if (kts < 4) kts = 4;  // a piece must outlast its own prologue and slab store
     const int s_eff = (ktiles + kts - 1) / kts;

@@ -171,7 +171,6 @@ def test_C4_mlp_full_size(nk, spelling):
     for lin, (dw64, db64), (dw32, db32), gab in zip(lins, g64, g32, ab):
         # (i) the device's masks on every side: summation order alone.  L = K = 4096: one chain per output (unsplit 128x128 tiles)
         err_gpu, err_cpu = np.abs(lin.weight.grad() - dw64).max(), np.abs(dw32 - dw64).max()
-        record_margin(tag + ":dW against the unscaled 1e-6*K term (not asserted)", err_gpu, err_cpu, abs_term(n, gab, 1.0))
         assert_contraction(tag + ":dW (K = L = 4096)", lin.weight.grad(), dw64, n, gab, 1.0, cpu32=dw32, L=n)
         assert_contraction(tag + ":db", lin.bias.grad(), db64, n, gab, 1.0, cpu32=db32)
     # (ii) every evaluation with its OWN masks (the reference run by itself): the same bound plus the first-order effect of the

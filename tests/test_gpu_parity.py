@@ -629,7 +629,7 @@ def shared_chip_plan(M, N, K, busy, cus=256):
         return None
     g = 8 if tm % 8 == 0 else tm % 8
     tail = -(-(T % slots) // g) * g
-    if tail > g * tn or tail >= T or slots // tail < 2:
+    if tail > g * tn or tail >= T or slots // tail < 4:
         return None
     kts = max(4, -(-kt // (slots // tail)))
     pieces = -(-kt // kts)
@@ -639,8 +639,8 @@ def shared_chip_plan(M, N, K, busy, cus=256):
 
 
 @pytest.mark.parametrize("layout", ["NT", "NN", "TN"])
-@pytest.mark.parametrize("M,N,K,busy", [(4096, 4096, 256, 16), (2048, 4096, 1024, 8), (4096, 2048, 384, 32), (4096, 4096, 512, 100),
-                                        (3200, 5120, 256, 16)])   # tile counts the rules keep at 128x128: 1024, 512, 512, 1024, 1000 (25 tile rows: a last group of one)
+@pytest.mark.parametrize("M,N,K,busy", [(4096, 4096, 256, 16), (2048, 4096, 1024, 8), (4096, 2048, 384, 32), (4096, 4096, 512, 40),
+                                        (3200, 5120, 256, 16)])   # tile counts the rules keep at 128x128: 1024, 512, 512, 1024, 1000 (25 tile rows: a last group of one); >= 4 pieces possible
 def test_gemm_shared_chip_schedule(dev, layout, M, N, K, busy):
     """nk_device_set_busy_slots(n): while an exchange holds n resident-block slots, a GEMM whose tiles no longer divide the free
     slots runs whole rounds of one tile per block and cuts the LEFT-OVER tiles - a rectangle at the end of the tile sequence -
@@ -710,12 +710,12 @@ def test_gemm_shared_chip_schedule(dev, layout, M, N, K, busy):
 
 def test_gemm_shared_chip_schedule_leaves_other_launches_alone(dev):
     """Grids that divide the free slots, fit into one round, are split / batched / ragged / 64-wide, or whose left-over is more
-    than half a round stay plain launches under nk_device_set_busy_slots: bit-identical results."""
+    than a quarter of a round stay plain launches under nk_device_set_busy_slots: bit-identical results."""
     c = capi()
     try:
         for (M, N, K, ta, tb, busy) in ((1024, 1024, 512, 0, 1, 16), (2048, 2048, 256, 0, 0, 16), (4096, 3968, 128, 0, 1, 16),
                                         (1000, 3000, 300, 1, 0, 8), (3072, 3072, 256, 1, 1, 16), (4096, 4096, 64, 0, 1, 0),
-                                        (2816, 2816, 128, 0, 1, 200)):
+                                        (2816, 2816, 128, 0, 1, 200), (4096, 4096, 256, 0, 1, 64)):
             a = rnd(1, (K, M) if ta else (M, K), -1, 1)
             b = rnd(2, (N, K) if tb else (K, N), -1, 1)
             A, B = dev.array(a), dev.array(b)

@@ -44,5 +44,7 @@ def assert_contraction(label, got, ref64, K, amax=1.0, bmax=1.0, *, cpu32=None, 
     bound = max(CPU_FACTOR * err_cpu, a) + extra
     if label:
         record_margin(label, err_gpu, err_cpu, a + extra)
+        if chain_factor(L) > 1.0:   # for the record: the same error against the survey's UNSCALED absolute term (not asserted)
+            record_margin(label + " against the unscaled 1e-6*K term (not asserted)", err_gpu, err_cpu, abs_term(K, amax, bmax, None, scale) + extra)
     assert err_gpu <= bound, (label, err_gpu, err_cpu, a, extra)
     return err_gpu / bound if bound > 0 else 0.0

@@ -31,6 +31,27 @@ except Exception as e:
     print("    no record:", e)
 P
 done
+# How many RCCL channels, and does the shared-chip GEMM schedule pay?  At the largest N: channel caps 4 / 8 / 16 (the default run
+# above is 16 told), each with the backward GEMMs told that many busy slots and - same cap - planning for an idle chip.
+nmax=$ngpu; [ "$nmax" -gt 8 ] && nmax=8
+if [ "$nmax" -gt 1 ]; then
+  for ch in 4 8 16; do
+    for told in 1 0; do
+      tag="n${nmax}_ch${ch}_told${told}"
+      if [ "$told" = 1 ]; then flag="--dp-channels $ch"; env_ch=""; else flag="--dp-channels 0"; env_ch="NCCL_MAX_NCHANNELS=$ch"; fi
+      env $env_ch timeout -k 10 600 python bench.py --gpus $nmax --steps 50 --warmup 5 --no-cpu-baseline $flag \
+          > "$out/bench_$tag.json" 2> "$out/bench_$tag.err"
+      python - "$out/bench_$tag.json" "$tag" <<'P' | tee -a "$out/summary.txt"
+import json, sys
+try:
+    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    print("   ", sys.argv[2], d["ms_per_step"], "ms/step, exposed comm", d.get("exposed_comm_ms"), "ms, GEMM slowdown", (d.get("gemm_contention") or {}).get("slowdown"), d.get("dp_channels"))
+except Exception as e:
+    print("   ", sys.argv[2], "no record:", e)
+P
+    done
+  done
+fi
 python - "$out" <<'P' | tee -a "$out/summary.txt"
 import json, os, sys
 vals = {}
