@@ -1,0 +1,57 @@
+"""C3's forward (+ bias) and input gradient (padding folded in, assigning) with the Winograd F(2x2, 3x3) kernels and with the
+implicit-GEMM kernels (NK_TUNE_CONV_WINOGRAD 1 / 0), alternating on one box: us per call (HIP events), the direct algorithmic
+TFLOP/s each time represents, and the fraction of the f32 MFMA peak.  `python benchmarks/ab_winograd.py [N]`"""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np  # noqa: E402
+
+from neuronika_amd import capi as c  # noqa: E402
+
+PEAK = 157.3e12
+
+
+def main():
+    N = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+    dev = c.Device(0)
+    Cin, Cout, H = 64, 128, 56
+    rng = np.random.default_rng(0)
+    XP = dev.array(rng.random((N, Cin, H + 2, H + 2), dtype=np.float32))
+    W = dev.array((rng.random((Cout, Cin, 3, 3), dtype=np.float32) * 2 - 1) / 24)
+    B = dev.array(rng.random((Cout, 1, 1), dtype=np.float32))
+    G = dev.array(rng.random((N, Cout, H, H), dtype=np.float32))
+    Y, DX = dev.zeros((N, Cout, H, H)), dev.zeros((N, Cin, H, H))
+    flop = 2.0 * N * Cout * H * H * Cin * 9
+    calls = {"forward + bias": lambda: c.conv_fwd(dev, XP, W, Y, (1, 1), (1, 1), 1, bias=B),
+             "input gradient (pad folded, assign)": lambda: c.conv_bwd_input(dev, DX, G, W, (1, 1), (1, 1), 1, assign=True, padding=(1, 1))}
+
+    def time(fn, reps=20):
+        e0, e1 = dev.event(), dev.event()
+        for _ in range(3):
+            fn()
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record(); e1.sync()
+        return e0.elapsed_ms(e1) / reps * 1e3
+
+    for _ in range(30):                              # clocks
+        calls["forward + bias"]()
+    for rnd in range(3):
+        for name, fn in calls.items():
+            row = {"round": rnd, "pass": name, "N": N}
+            for mode, label in ((0, "implicit_gemm"), (1, "winograd")):
+                dev.conv_winograd(mode)
+                us = time(fn)
+                row[label + "_us"] = round(us, 1)
+                row[label + "_direct_tflops"] = round(flop / us / 1e6, 1)
+                row[label + "_frac_of_peak_on_direct_flops"] = round(flop / (us * 1e-6) / PEAK, 3)
+            dev.conv_winograd(None)
+            row["speedup"] = round(row["implicit_gemm_us"] / row["winograd_us"], 3)
+            print(json.dumps(row), flush=True)
+
+
+if __name__ == "__main__":
+    main()

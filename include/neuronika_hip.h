@@ -79,9 +79,12 @@ const char* nk_version(void);
  *   NK_TUNE_CONV_NARROW    values[0] = 0 the conv kernel gradient's uniform launch / 1..100 its mixed launch (the last, half-empty
  *                          column tile through 64-wide blocks), a narrow block's k-tile priced at that percentage of a wide one's;
  *                          n = 0: the measured rules (65 % with 128-row tiles, 80 % with 64-row tiles)
+ *   NK_TUNE_CONV_WINOGRAD  values[0] = -1 rule / 0 the 3x3 stride-1 forward and input gradient never take the Winograd F(2x2, 3x3)
+ *                          kernels (implicit GEMM as in rounds 1 - 4) / 1 whenever the shape allows (also below the block-count rule)
  * For schedule sweeps (benchmarks/ab_*.py) and the tests that pit one schedule against another bit for bit; results never
  * depend on them beyond summation order (split-K). */
-enum { NK_TUNE_GEMM_FORCE = 0, NK_TUNE_GEMM_KPAIR = 1, NK_TUNE_ATTENTION_OCC = 2, NK_TUNE_GEMM_PAIR = 3, NK_TUNE_CONV_NARROW = 4 };
+enum { NK_TUNE_GEMM_FORCE = 0, NK_TUNE_GEMM_KPAIR = 1, NK_TUNE_ATTENTION_OCC = 2, NK_TUNE_GEMM_PAIR = 3, NK_TUNE_CONV_NARROW = 4,
+       NK_TUNE_CONV_WINOGRAD = 5 };
 int nk_dev_tune(nk_device* dev, int knob, const int* values, int n);
 /* Tell the device handle that `n` of the GPU's resident-block slots (two 128x128 GEMM blocks per CU) are held by work on another
  * stream until further notice - the channel workgroups of an all-reduce in flight beside the backward pass

@@ -256,7 +256,7 @@ class Event:
             pass
 
 
-TUNE_GEMM_FORCE, TUNE_GEMM_KPAIR, TUNE_ATTENTION_OCC, TUNE_GEMM_PAIR, TUNE_CONV_NARROW = 0, 1, 2, 3, 4   # include/neuronika_hip.h: nk_dev_tune knobs
+TUNE_GEMM_FORCE, TUNE_GEMM_KPAIR, TUNE_ATTENTION_OCC, TUNE_GEMM_PAIR, TUNE_CONV_NARROW, TUNE_CONV_WINOGRAD = 0, 1, 2, 3, 4, 5   # include/neuronika_hip.h: nk_dev_tune knobs
 
 
 class Device:
@@ -273,7 +273,7 @@ class Device:
         # The sweep scripts (benchmarks/ab_*.py, tools/sessions/*.sh) choose a schedule per process through environment
         # variables; it is THIS harness that reads them and calls nk_dev_tune - the library itself reads none.
         for var, knob in (("NK_GEMM_FORCE", TUNE_GEMM_FORCE), ("NK_GEMM_KPAIR", TUNE_GEMM_KPAIR), ("NK_ATTN_OCC", TUNE_ATTENTION_OCC),
-                          ("NK_GEMM_PAIR", TUNE_GEMM_PAIR), ("NK_CONV_NARROW", TUNE_CONV_NARROW)):
+                          ("NK_GEMM_PAIR", TUNE_GEMM_PAIR), ("NK_CONV_NARROW", TUNE_CONV_NARROW), ("NK_CONV_WINOGRAD", TUNE_CONV_WINOGRAD)):
             if os.environ.get(var):
                 self.tune(knob, os.environ[var])
 
@@ -300,6 +300,9 @@ class Device:
 
     def conv_narrow(self, cost=None):
         self.tune(TUNE_CONV_NARROW, cost)
+
+    def conv_winograd(self, mode=None):
+        self.tune(TUNE_CONV_WINOGRAD, mode)
 
     def busy_slots(self, n: int = 0):
         """nk_device_set_busy_slots: `n` resident-block slots are held by work on another stream (an exchange in flight)."""

@@ -61,6 +61,14 @@ int make_geom(int nd, const int* x_shape, const int* w_shape, const int* stride,
 bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 size_t round256(size_t b) { return (b + 255) & ~size_t(255); }
 
+#include "nk_conv_winograd.h"
+
+// 3 x 3, stride 1, dilation 1, one group, two spatial dimensions: the shapes wino_launch may take
+bool wino_shape(const ConvGeom& g) {
+    return g.groups == 1 && g.in[0] == 1 && g.k[0] == 1 && g.k[1] == 3 && g.k[2] == 3 && g.stride[1] == 1 && g.stride[2] == 1 && g.dil[1] == 1 &&
+           g.dil[2] == 1;
+}
+
 int conv_fwd(nk_device* dev, int nd, const float* x, const int* x_shape, const float* w, const int* w_shape,
              const float* bias, float* y, const int* stride, const int* dilation, int groups) {
     NK_USE(dev);
@@ -92,6 +100,12 @@ int conv_fwd(nk_device* dev, int nd, const float* x, const int* x_shape, const f
 #undef NK_DF
         NK_LAUNCH_CHECK();
         return nk_prof_stop(dev);
+    }
+    if (wino_shape(g)) {  // Winograd F(2x2, 3x3) on the MFMA core (nk_conv_winograd.h)
+        bool taken = false;
+        rc = wino_launch(dev, false, x, w, y, bias, g.N, g.Cin, g.Cout, g.in[1], g.in[2], g.out[1], g.out[2], 0, 0, 1,
+                         2.0 * g.N * (double)g.Cout * g.L * g.Cg * g.KK, &taken);
+        if (rc || taken) return rc;
     }
     const int K = g.Cg * g.KK;
     const long long x_elems = (long long)g.N * g.Cin * g.inplane, y_elems = (long long)g.N * g.Cout * g.L;
@@ -253,6 +267,12 @@ int conv_bwd_input(nk_device* dev, int nd, float* dx, const int* x_shape, const 
 #undef NK_DI
         NK_LAUNCH_CHECK();
         return nk_prof_stop(dev);
+    }
+    if (wino_shape(g)) {  // the full correlation with the flipped kernel, the Pad node's padding folded in: patch origin 2 t - (2 - pad)
+        bool taken = false;
+        rc = wino_launch(dev, true, gy, w, dx, nullptr, g.N, g.Cout, g.Cin, g.out[1], g.out[2], g.uin[1], g.uin[2], 2 - g.pad[1], 2 - g.pad[2],
+                         assign, 2.0 * g.N * (double)g.Cout * g.L * g.Cg * g.KK, &taken);
+        if (rc || taken) return rc;
     }
     const int K = g.Mg * g.KK;
     {

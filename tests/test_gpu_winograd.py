@@ -1,0 +1,139 @@
+"""Winograd F(2x2, 3x3) forward and input gradient (nk_conv_winograd.h) against the direct implicit-GEMM kernels and the
+oracle: 3 x 3 / stride 1 / dilation 1 / one group, even output extents, channel counts in whole MFMA blocks.
+
+  * integer-valued data: the transforms are additions and halvings, every product and sum is exact in f32 - the Winograd
+    result must EQUAL the direct kernels' bit for bit (and the oracle's), forward, input gradient (`+=` and assign, with and
+    without the folded padding), bias;
+  * random data: both paths inside the suite's contraction bound (tests/tolerance.py, K = Cin * 9) against the f64 oracle,
+    margins recorded under winograd:*;
+  * tile counts that do not fill the last block, several chunks of reduction channels, several blocks of output channels,
+    image borders (the folded padding reads zeros outside the gradient);
+  * the rule (by block count) and the knob NK_TUNE_CONV_WINOGRAD = 0 / 1;
+  * run to run identical."""
+import numpy as np
+import pytest
+
+from oracle import neuronika_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def capi():
+    from neuronika_amd import capi as c
+    return c
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return capi().Device(0)
+
+
+def rnd(seed, shape, lo=0.0, hi=1.0):
+    a = np.random.default_rng(seed).random(shape, dtype=np.float32)
+    return np.asarray(a * np.float32(hi - lo) + np.float32(lo), dtype=np.float32)
+
+
+def ints(seed, shape, lo, hi):
+    return np.random.default_rng(seed).integers(lo, hi + 1, shape).astype(np.float32)
+
+
+# N, Cin, Cout, H, W of the (already padded) input; output (H - 2) x (W - 2)
+SHAPES = [
+    (2, 64, 128, 10, 10),      # 2 * 4 * 4 = 32 tiles: exactly one forward block, half an input-gradient block
+    (3, 64, 128, 8, 14),       # 3 * 3 * 6 = 54 tiles: a partly filled last block both ways
+    (1, 128, 128, 12, 12),     # forward: two chunks of 64 reduction channels; input gradient: 4 chunks, two channel blocks
+    (2, 64, 256, 6, 20),       # forward: two blocks of 128 output channels; input gradient: 8 chunks of 32
+    (5, 192, 128, 6, 6),       # 5 * 2 * 2 = 20 tiles; three forward chunks, three channel blocks of dX
+    (2, 64, 128, 58, 58),      # the C3 plane (28 x 28 tiles per image), two samples
+]
+
+
+def run_all(dev, x, w, b, go, dx0, pad, mode):
+    c = capi()
+    dev.conv_winograd(mode)
+    try:
+        N, Cin, H, W = x.shape
+        Cout = w.shape[0]
+        X, Wd, B, G = dev.array(x), dev.array(w), dev.array(b), dev.array(go)
+        Y, Yb = dev.full((N, Cout, H - 2, W - 2), 7.0), dev.full((N, Cout, H - 2, W - 2), 7.0)
+        c.conv_fwd(dev, X, Wd, Y, (1, 1), (1, 1), 1)
+        c.conv_fwd(dev, X, Wd, Yb, (1, 1), (1, 1), 1, bias=B)
+        DX, DXa = dev.array(dx0), dev.full(x.shape, np.nan)
+        c.conv_bwd_input(dev, DX, G, Wd, (1, 1), (1, 1), 1)
+        c.conv_bwd_input(dev, DXa, G, Wd, (1, 1), (1, 1), 1, assign=True)
+        up = (N, Cin, H - 2 * pad, W - 2 * pad)                     # gradient of the UNPADDED input of a zero Pad node
+        DXp = dev.array(dx0[:, :, pad:H - pad, pad:W - pad].copy())
+        DXpa = dev.full(up, np.nan)
+        c.conv_bwd_input(dev, DXp, G, Wd, (1, 1), (1, 1), 1, padding=(pad, pad))
+        c.conv_bwd_input(dev, DXpa, G, Wd, (1, 1), (1, 1), 1, assign=True, padding=(pad, pad))
+        return [a.numpy() for a in (Y, Yb, DX, DXa, DXp, DXpa)]
+    finally:
+        dev.conv_winograd(None)
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W", SHAPES)
+def test_winograd_equals_direct_exactly_on_integer_data(dev, N, Cin, Cout, H, W):
+    x, w = ints(1, (N, Cin, H, W), -3, 3), ints(2, (Cout, Cin, 3, 3), -2, 2)
+    b, go, dx0 = ints(3, (Cout, 1, 1), -4, 4), ints(4, (N, Cout, H - 2, W - 2), -3, 3), ints(5, (N, Cin, H, W), -5, 5)
+    wino = run_all(dev, x, w, b, go, dx0, 1, 1)
+    direct = run_all(dev, x, w, b, go, dx0, 1, 0)
+    again = run_all(dev, x, w, b, go, dx0, 1, 1)
+    for name, a, d, r in zip(("y", "y+bias", "dx+=", "dx=", "dx(pad)+=", "dx(pad)="), wino, direct, again):
+        assert np.array_equal(a, d), name
+        assert np.array_equal(a, r), name
+    y = np.zeros((N, Cout, H - 2, W - 2), np.float32); O.convolution_forward(x, w, y, (1, 1), (1, 1), 1)
+    assert np.array_equal(wino[0], y) and np.array_equal(wino[1], y + b)
+    dx = dx0.copy(); O.convolution_backward_input(dx, go, w, (1, 1), (1, 1), 1)
+    assert np.array_equal(wino[2], dx) and np.array_equal(wino[3], dx - dx0)
+    assert np.array_equal(wino[4], dx[:, :, 1:H - 1, 1:W - 1]) and np.array_equal(wino[5], (dx - dx0)[:, :, 1:H - 1, 1:W - 1])
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W", SHAPES[:5])
+@pytest.mark.parametrize("pad", [0, 1, 2])
+def test_winograd_random_inside_the_contraction_bound(dev, N, Cin, Cout, H, W, pad):
+    from tolerance import assert_contraction
+    if H - 2 * pad < 2 or W - 2 * pad < 2:
+        pytest.skip("nothing left of the unpadded input")
+    x, w = rnd(1, (N, Cin, H, W)), rnd(2, (Cout, Cin, 3, 3), -1, 1)
+    b, go, dx0 = rnd(3, (Cout, 1, 1), -1, 1), rnd(4, (N, Cout, H - 2, W - 2)), rnd(5, (N, Cin, H, W))
+    wino = run_all(dev, x, w, b, go, dx0, pad, 1)
+    direct = run_all(dev, x, w, b, go, dx0, pad, 0)
+    y64 = np.zeros((N, Cout, H - 2, W - 2)); O.convolution_forward(x.astype(np.float64), w.astype(np.float64), y64, (1, 1), (1, 1), 1)
+    y32 = np.zeros((N, Cout, H - 2, W - 2), np.float32); O.convolution_forward(x, w, y32, (1, 1), (1, 1), 1)
+    d64 = np.zeros(x.shape); O.convolution_backward_input(d64, go.astype(np.float64), w.astype(np.float64), (1, 1), (1, 1), 1)
+    d32 = np.zeros(x.shape, np.float32); O.convolution_backward_input(d32, go, w, (1, 1), (1, 1), 1)
+    inner = (slice(None), slice(None), slice(pad, H - pad), slice(pad, W - pad))
+    wants = [(y64, y32, Cin * 9), (y64 + b, y32 + b, Cin * 9), (dx0 + d64, dx0 + d32, Cout * 9), (d64, d32, Cout * 9),
+             (dx0[inner] + d64[inner], dx0[inner] + d32[inner], Cout * 9), (d64[inner], d32[inner], Cout * 9)]
+    for name, got_w, got_d, (ref, cpu, K) in zip(("y", "y+bias", "dx+=", "dx=", "dx(pad)+=", "dx(pad)="), wino, direct, wants):
+        assert_contraction("winograd:" + name, got_w, ref, K, 1.0, 1.0, cpu32=cpu, epilogue=True)
+        assert_contraction("direct (same cases):" + name, got_d, ref, K, 1.0, 1.0, cpu32=cpu, epilogue=True)
+
+
+def test_winograd_rule_and_knob(dev):
+    """By rule the path is taken from four rounds of blocks on (the C3 plane with 8 samples: 196 forward blocks - direct; with
+    48 samples: 1176 - Winograd); shapes it cannot take (odd output extent, stride 2, 5 x 5, groups, 48 channels) stay direct
+    under the forced knob.  Told apart by the bits on random data (the two orders of summation differ)."""
+    c = capi()
+
+    def fwd(x, w, s, g, mode):
+        dev.conv_winograd(mode)
+        try:
+            X, Wd = dev.array(x), dev.array(w)
+            oshape = O.conv_out_shape(x.shape, w.shape, s, (1, 1))
+            Y = dev.zeros(oshape)
+            c.conv_fwd(dev, X, Wd, Y, s, (1, 1), g)
+            return Y.numpy()
+        finally:
+            dev.conv_winograd(None)
+
+    w = rnd(2, (128, 64, 3, 3), -1, 1)
+    small, large = rnd(1, (8, 64, 58, 58)), rnd(1, (48, 64, 58, 58))
+    assert np.array_equal(fwd(small, w, (1, 1), 1, None), fwd(small, w, (1, 1), 1, 0))          # rule: direct
+    assert not np.array_equal(fwd(small, w, (1, 1), 1, 1), fwd(small, w, (1, 1), 1, 0))         # forced: Winograd
+    assert np.array_equal(fwd(large, w, (1, 1), 1, None), fwd(large, w, (1, 1), 1, 1))          # rule: Winograd
+    for x, wk, s, g in ((rnd(1, (2, 64, 9, 10)), w, (1, 1), 1), (rnd(1, (2, 64, 11, 11)), w, (2, 2), 1),
+                        (rnd(1, (2, 64, 12, 12)), rnd(2, (128, 64, 5, 5), -1, 1), (1, 1), 1),
+                        (rnd(1, (2, 128, 10, 10)), rnd(2, (128, 64, 3, 3), -1, 1), (1, 1), 2),
+                        (rnd(1, (2, 48, 10, 10)), rnd(2, (128, 48, 3, 3), -1, 1), (1, 1), 1)):
+        assert np.array_equal(fwd(x, wk, s, g, 1), fwd(x, wk, s, g, 0))
