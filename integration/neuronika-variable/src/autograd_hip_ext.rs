@@ -15,4 +15,17 @@ pub(crate) trait Backward {
     fn targets(&self) -> Vec<usize> {
         Vec::new()
     }
+
+    /// The subset of `targets` this node can write PRE-MASKED when the gradient belongs to a fused Linear+ReLU node (a
+    /// following Linear's input gradient: `nk_linear_bwd_input_relu` applies `(y > 0) *` in the GEMM epilogue).  Default: none.
+    fn premask_targets(&self) -> Vec<usize> {
+        Vec::new()
+    }
+
+    /// For the backward node of a fused Linear+ReLU (`hip::node::LinearBackward` with a mask): the identity of its OWN output
+    /// gradient and the state `HipVarDiff::backward` sets per pass - pre-masked iff every node that writes that gradient on
+    /// the tape can mask while storing.  Default: not such a node.
+    fn masked_gradient(&self) -> Option<(usize, std::rc::Rc<crate::hip::ReluMask>)> {
+        None
+    }
 }

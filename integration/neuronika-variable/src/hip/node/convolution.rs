@@ -128,3 +128,95 @@ where
         vec![grad_id(&self.kernel_gradient)]
     }
 }
+
+/// `nn::Conv{1,2,3}d::forward`'s convolution and bias addition as ONE node: `Convolution::forward` (`:296-355`) with the
+/// broadcast `Addition` of the `(Cout, 1, ..)` bias (`node/addition/mod.rs:31-50`) in the kernel's epilogue -
+/// `nk_conv_bias_fwd`.  Bit-identical to the two nodes (one f32 add per output on top of the same sums).
+pub(crate) struct ConvolutionBias<D, B>
+where
+    D: Dimension,
+    B: Dimension,
+{
+    input_data: Shared<HipArray<D>>,
+    kernel_data: Shared<HipArray<D>>,
+    bias_data: Shared<HipArray<B>>,
+    data: Shared<HipArray<D>>,
+    stride: Vec<i32>,
+    dilation: Vec<i32>,
+    groups: i32,
+}
+
+impl<D, B> ConvolutionBias<D, B>
+where
+    D: Dimension,
+    B: Dimension, {
+    #[allow(clippy::too_many_arguments)]
+    pub(crate) fn new(input_data: Shared<HipArray<D>>, kernel_data: Shared<HipArray<D>>, bias_data: Shared<HipArray<B>>, data: Shared<HipArray<D>>, stride: Vec<i32>, dilation: Vec<i32>, groups: i32) -> Self {
+        Self { input_data, kernel_data, bias_data, data, stride, dilation, groups }
+    }
+}
+
+impl<D, B> Forward for ConvolutionBias<D, B>
+where
+    D: Dimension,
+    B: Dimension,
+{
+    fn forward(&self) {
+        let (x, w, b) = (self.input_data.borrow(), self.kernel_data.borrow(), self.bias_data.borrow());
+        let mut y = self.data.borrow_mut();
+        let (xs, ws) = (x.shape_c(), w.shape_c());
+        ffi::check(unsafe {
+            ffi::nk_conv_bias_fwd(x.device().as_raw(), xs.len() as i32 - 2, x.as_ptr(), xs.as_ptr(), w.as_ptr(), ws.as_ptr(), b.as_ptr(), y.as_mut_ptr(),
+                                  self.stride.as_ptr(), self.dilation.as_ptr(), self.groups)
+        });
+    }
+}
+
+/// `ConvolutionBackwardKernel::backward` (`:451-510`) and the `AdditionBackwardRight` of the module's bias
+/// (`node/addition/mod.rs:113-135`: the un-broadcast sum of the output gradient over samples and positions) as ONE call:
+/// `nk_conv_bwd_kernel_bias` sums the bias gradient on the way through the kernel-gradient pass (same reduction, no second
+/// read of the 206 MB gradient at C3).
+pub(crate) struct ConvolutionBackwardKernelBias<D, B>
+where
+    D: Dimension,
+    B: Dimension,
+{
+    input_data: Shared<HipArray<D>>,
+    kernel_gradient: Rc<Gradient<HipArray<D>, D>>,
+    bias_gradient: Rc<Gradient<HipArray<B>, B>>,
+    gradient: Rc<Gradient<HipArray<D>, D>>,
+    stride: Vec<i32>,
+    dilation: Vec<i32>,
+    groups: i32,
+}
+
+impl<D, B> ConvolutionBackwardKernelBias<D, B>
+where
+    D: Dimension,
+    B: Dimension, {
+    #[allow(clippy::too_many_arguments)]
+    pub(crate) fn new(input_data: Shared<HipArray<D>>, kernel_gradient: Rc<Gradient<HipArray<D>, D>>, bias_gradient: Rc<Gradient<HipArray<B>, B>>, gradient: Rc<Gradient<HipArray<D>, D>>, stride: Vec<i32>, dilation: Vec<i32>, groups: i32) -> Self {
+        Self { input_data, kernel_gradient, bias_gradient, gradient, stride, dilation, groups }
+    }
+}
+
+impl<D, B> Backward for ConvolutionBackwardKernelBias<D, B>
+where
+    D: Dimension,
+    B: Dimension,
+{
+    fn backward(&self) {
+        let (g, x) = (self.gradient.borrow(), self.input_data.borrow());
+        let (mut dw, mut db) = (self.kernel_gradient.borrow_mut(), self.bias_gradient.borrow_mut());
+        let (ws, xs) = (dw.shape_c(), x.shape_c());
+        ffi::check(unsafe {
+            ffi::nk_conv_bwd_kernel_bias(g.device().as_raw(), xs.len() as i32 - 2, dw.as_mut_ptr(), db.as_mut_ptr(), ws.as_ptr(), g.as_ptr(), x.as_ptr(),
+                                         xs.as_ptr(), self.stride.as_ptr(), self.dilation.as_ptr(), self.groups, 0, 0)
+        });
+    }
+
+    /// The gradients this node accumulates into (`autograd.rs` extension: the last-writer rule of `backward_sync`).
+    fn targets(&self) -> Vec<usize> {
+        vec![grad_id(&self.kernel_gradient), grad_id(&self.bias_gradient)]
+    }
+}

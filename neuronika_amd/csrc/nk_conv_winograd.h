@@ -10,11 +10,11 @@
 // integer-valued data.  The 16 element-wise products, summed over input channels, are 16 small GEMMs
 //   M[xi] (Cm x P) = U[xi] (Cm x Ck) . V[xi] (Ck x P),   xi = 0..15,  P = N * (Hd/2) * (Wd/2) tiles,
 // which run on the MFMA core (v_mfma_f32_32x32x2_f32).  Everything stays on chip: a block transforms the patches of 32*PB
-// tiles into LDS (V, 128 KB), each wave holds the 16 accumulator tiles (xi) of its 32 output channels x 32 tiles in registers
-// (256 of the 512 a wave has at one wave per SIMD), takes its U fragments straight from L2 in MFMA operand order (the kernel
-// transform writes them that way), and applies the output transform to its own registers - V, M never touch HBM.
-//   forward        CB = 4 waves x 32 channels = 128 output channels, 32 tiles, all 64 input channels at once
-//   input gradient CB = 2 x 32 = 64 channels of dX, PB = 2 x 32 tiles, the gradient's channels in chunks of 32
+// tiles into LDS (V, two buffers of 64 KB), each wave holds the 16 accumulator tiles (xi) of its 32 output channels x 32 tiles
+// in registers (256 of the 512 a wave has at one wave per SIMD), takes its U fragments straight from L2 in MFMA operand order
+// (the kernel transform writes them that way), and applies the output transform to its own registers - V, M never touch HBM.
+//   forward        CB = 4 waves x 32 channels = 128 output channels, 32 tiles, the input channels in chunks of 32
+//   input gradient CB = 2 x 32 = 64 channels of dX, PB = 2 x 32 tiles, the gradient's channels in chunks of 16
 // One source for both: the "source" tensor is the input (forward) or the output gradient (backward), read at patch origin
 // (2 ty - offy, 2 tx - offx) with zeros outside [0, Hs) x [0, Ws); forward: off = 0 on the caller's padded input, backward:
 // off = 2 - pad (the Pad node's padding folded in, as in the direct input-gradient kernel).
@@ -74,29 +74,46 @@ __global__ void wino_weights_kernel(float* __restrict__ u, const float* __restri
         u[((((long long)(ch * 16 + xi) * CBT + cbt) * (KC / 8) + j) * 64 + lane) * 4 + tq] = uu[xi >> 2][xi & 3];
 }
 
+// One block per CU (128 KB of LDS, 512 registers per lane), PERSISTENT: block b walks the tile blocks b, b + gridDim.x, ... and, inside
+// each, the chunks of KC reduction channels.  The stream of (tile block, chunk) items is software-pipelined through two V buffers:
+// while the MFMAs of item i read V[i & 1], the same waves load and transform the patches of item i + 1 into V[(i + 1) & 1] - the loads
+// in the first quarter of the item's MFMA groups, the additions and LDS stores of one channel at a time further on, a few
+// instructions per group of four MFMAs - and prefetch their U fragments three xi ahead from L2.  One barrier per item.  Only the
+// first item's transform and each tile block's output transform run with the matrix pipe idle.
 template <int CB, int PB, int KC>
 __global__ __launch_bounds__(256, 1) void wino_kernel(WinoArgs a) {
-    constexpr int PT = 32 * PB;        // tiles per block
-    constexpr int KH = KC / 2;         // MFMA steps per chunk and xi (two reduction channels per step)
-    constexpr int NJ = KC / 8;         // float4 A fragments (groups of four steps) per chunk and xi
+    constexpr int PT = 32 * PB;        // tiles per tile block
+    constexpr int KH = KC / 2;         // MFMA steps per item and xi (two reduction channels per step)
+    constexpr int NJ = KC / 8;         // groups of four steps (one float4 of A per lane) per item and xi
     constexpr int CSTEP = 256 / PT;    // channels the block's threads cover per transform pass
-    constexpr int NQ = KC / CSTEP;     // transform passes per chunk
-    static_assert(CB * PB == 4 && KC % 8 == 0 && KC % CSTEP == 0, "four waves; whole float4 fragments");
-    static_assert(16 * KC * PT * sizeof(float) <= 160 * 1024, "V must fit the 160 KB of a gfx950 CU");
-    __shared__ __attribute__((aligned(16))) float V[16 * KC * PT];  // [xi][channel in chunk][tile]
+    constexpr int NQ = KC / CSTEP;     // channels per thread and item
+    constexpr int G = 16 * NJ;         // MFMA groups per item
+    constexpr int VBUF = 16 * KC * PT; // floats of one V buffer: [xi][channel in chunk][tile]
+    constexpr int LPG = 64 / (G / 4);  // patch loads per group while the loads are issued (groups 0 .. G/4 - 1)
+    constexpr int TG = G / 8;          // groups one channel's transform is spread over
+    constexpr int T0 = G / 4 + G / 8;  // first group of channel 0's transform (its loads left at least G/8 groups earlier)
+    constexpr int PPG = 8 / TG;        // transform parts (of 8 per channel: 4 column passes, 4 row passes + stores) per group
+    static_assert(CB * PB == 4 && NQ == 4 && KC % 8 == 0 && 16 % 4 == 0, "four waves, four channels per thread and item");
+    static_assert(T0 + NQ * TG <= G && LPG * (G / 4) == 16 * NQ && PPG * TG == 8, "the slices of the next item's transform fit the item's groups");
+    static_assert(2 * VBUF * sizeof(float) <= 160 * 1024, "two V buffers must fit the 160 KB of a gfx950 CU");
+    __shared__ __attribute__((aligned(16))) float V[2 * VBUF];
     const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
     const int cb = wid % CB, pb = wid / CB;
     const int c = lane & 31, h = lane >> 5;
     const int plane = a.Hs * a.Ws;  // (the host checks that the tensors have fewer than 2^31 elements)
+    const int per = a.TY * a.TX;
+    const int npb = (int)((a.P + PT - 1) / PT);
+    const int pl = t % PT, cl0 = t / PT;  // transform phase: this thread's tile of a tile block and its first channel
+    const int CBT = a.Cm / 32, cbg = blockIdx.y * CB + cb;
+    const long long ustep = (long long)CBT * NJ * 64;  // float4s from xi to xi + 1
+    const float4* const ubase = reinterpret_cast<const float4*>(a.u) + (long long)cbg * NJ * 64 + lane;  // + ch * 16 * ustep + xi * ustep + j * 64
 
-    // ---- transform phase geometry: this thread's patch (tile pl of the block) and its first channel.  Loads are branch-free:
-    // an element outside the source reads element 0 and is replaced by 0 afterwards.
-    const int pl = t % PT, cl0 = t / PT;
-    int poff[4][4];  // offset of patch element (i, j) from channel 0 of the patch's sample, -1 outside the source
-    {
-        const long long p = (long long)blockIdx.x * PT + pl;
-        const bool pvalid = p < a.P;
-        const int per = a.TY * a.TX;
+    // offset of patch element (i, j) of tile block `pbk` from channel 0 of the patch's sample, -1 outside the source (loads are
+    // branch-free: such an element reads element 0 and is replaced by 0)
+    int poff[16];
+    auto patch = [&](int pbk) {
+        const long long p = (long long)pbk * PT + pl;
+        const bool pvalid = pbk < npb && p < a.P;
         const int n = pvalid ? (int)(p / per) : 0, rem = pvalid ? (int)(p % per) : 0;
         const int ty = rem / a.TX, tx = rem % a.TX;
         const int r0 = 2 * ty - a.offy, c0 = 2 * tx - a.offx;
@@ -106,126 +123,156 @@ __global__ __launch_bounds__(256, 1) void wino_kernel(WinoArgs a) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const bool ok = pvalid && (unsigned)(r0 + i) < (unsigned)a.Hs && (unsigned)(c0 + j) < (unsigned)a.Ws;
-                poff[i][j] = ok ? sb + i * a.Ws + j : -1;
+                poff[4 * i + j] = ok ? sb + i * a.Ws + j : -1;
             }
+    };
+    // the pieces of one channel's transform (d: the 16 loaded values, tt: B^T d): column pass j, then row pass i + stores
+    auto col_pass = [&](const float (&d)[16], float (&tt)[16], int j) {
+        const float d0 = poff[j] >= 0 ? d[j] : 0.f, d1 = poff[4 + j] >= 0 ? d[4 + j] : 0.f;
+        const float d2 = poff[8 + j] >= 0 ? d[8 + j] : 0.f, d3 = poff[12 + j] >= 0 ? d[12 + j] : 0.f;
+        tt[j] = d0 - d2;
+        tt[4 + j] = d1 + d2;
+        tt[8 + j] = d2 - d1;
+        tt[12 + j] = d1 - d3;
+    };
+    auto row_pass = [&](const float (&tt)[16], float* vdst, int cl, int i) {
+        float* vp = vdst + ((4 * i) * KC + cl) * PT + pl;
+        vp[0 * KC * PT] = tt[4 * i] - tt[4 * i + 2];
+        vp[1 * KC * PT] = tt[4 * i + 1] + tt[4 * i + 2];
+        vp[2 * KC * PT] = tt[4 * i + 2] - tt[4 * i + 1];
+        vp[3 * KC * PT] = tt[4 * i + 1] - tt[4 * i + 3];
+    };
+
+    int pbk = blockIdx.x;
+    if (pbk >= npb) return;
+    // ---- prologue: item (pbk, chunk 0) into V[0], the matrix pipe idle
+    patch(pbk);
+    {
+        float d[NQ][16];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int coff = (cl0 + q * CSTEP) * plane;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) d[q][e] = a.src[poff[e] >= 0 ? poff[e] + coff : 0];
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            float tt[16];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) col_pass(d[q], tt, j);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) row_pass(tt, V, cl0 + q * CSTEP, i);
+        }
     }
+    // U fragments of xi = 0, 1, 2 of chunk 0: a ring of four, three xi ahead of the MFMAs
+    float4 af[4][NJ];
+#pragma unroll
+    for (int x = 0; x < 3; ++x)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) af[x][j] = ubase[x * ustep + j * 64];
+    __syncthreads();
 
-    nkmma::f32x16 acc[16];
+    int s = 0;
+    for (; pbk < npb; pbk += gridDim.x) {
+        nkmma::f32x16 acc[16];
 #pragma unroll
-    for (int xi = 0; xi < 16; ++xi)
+        for (int xi = 0; xi < 16; ++xi)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[xi][e] = 0.f;
-
-    const int CBT = a.Cm / 32, cbg = blockIdx.y * CB + cb;
-    const long long ustep = (long long)CBT * NJ * 64;  // float4s from xi to xi + 1
-    for (int ch = 0; ch < a.nchunk; ++ch) {
-        // ---- this chunk's first A fragments leave for L2 now (nothing in them depends on V): they land under the transform
-        const float4* up = reinterpret_cast<const float4*>(a.u) + (((long long)ch * 16 * CBT + cbg) * NJ) * 64 + lane;
-        float4 af[2][NJ];
+            for (int e = 0; e < 16; ++e) acc[xi][e] = 0.f;
+        for (int ch = 0; ch < a.nchunk; ++ch) {
+            // the item after this one: the next chunk, or chunk 0 of this block's next tile block (none: its loads read element 0
+            // and the values land in a V buffer nobody reads)
+            const bool last_ch = ch + 1 == a.nchunk;
+            const int nch = last_ch ? 0 : ch + 1;
+            if (last_ch) patch(pbk + gridDim.x);
+            const int ncoff = (nch * KC + cl0) * plane;
+            const float* const vcur = V + s * VBUF + (KH * h) * PT + 32 * pb + c;
+            float* const vnext = V + (s ^ 1) * VBUF;
+            const float4* const ucur = ubase + (long long)ch * 16 * ustep;
+            const float4* const unext = ubase + (long long)nch * 16 * ustep;
+            float d[NQ][16], tt[16];
+            float bf[2][4];
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) af[0][j] = up[j * 64];
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- data transform of NQ channels of the thread's patch: V = B^T d B into LDS, QB channels' loads in flight at a time
-        constexpr int QB = 4;
-        static_assert(NQ % QB == 0, "whole batches of channels");
+            for (int q4 = 0; q4 < 4; ++q4) bf[0][q4] = vcur[q4 * PT];
 #pragma unroll
-        for (int q0 = 0; q0 < NQ; q0 += QB) {
-            float d[QB][4][4];
+            for (int xi = 0; xi < 16; ++xi) {
+                // U fragments three xi ahead (past the item's end: the next item's first three)
 #pragma unroll
-            for (int qq = 0; qq < QB; ++qq) {
-                const int coff = (ch * KC + cl0 + (q0 + qq) * CSTEP) * plane;
+                for (int j = 0; j < NJ; ++j)
+                    af[(xi + 3) & 3][j] = xi + 3 < 16 ? ucur[(xi + 3) * ustep + j * 64] : unext[(xi + 3 - 16) * ustep + j * 64];
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int j = 0; j < NJ; ++j) {
+                    const int g = xi * NJ + j;  // group number inside the item: its B values are in bf[g & 1]
+                    if (g + 1 < G) {
+                        const int xn = (g + 1) / NJ, jn = (g + 1) % NJ;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) d[qq][i][j] = a.src[poff[i][j] >= 0 ? poff[i][j] + coff : 0];
+                        for (int q4 = 0; q4 < 4; ++q4) bf[(g + 1) & 1][q4] = vcur[(xn * KC + 4 * jn + q4) * PT];
+                    }
+                    // ---- this group's slice of the NEXT item's transform
+                    if (g < G / 4) {  // patch loads: LPG per group
+#pragma unroll
+                        for (int l = 0; l < LPG; ++l) {
+                            const int q = (g * LPG + l) / 16, e = (g * LPG + l) % 16;
+                            d[q][e] = a.src[poff[e] >= 0 ? poff[e] + ncoff + q * CSTEP * plane : 0];
+                        }
+                    }
+                    if (g >= T0 && g < T0 + NQ * TG) {  // channel q's transform, PPG of its 8 parts per group
+                        const int q = (g - T0) / TG, k0 = ((g - T0) % TG) * PPG;
+#pragma unroll
+                        for (int k = k0; k < k0 + PPG; ++k) {
+                            if (k < 4) col_pass(d[q], tt, k);
+                            else row_pass(tt, vnext, cl0 + q * CSTEP, k - 4);
+                        }
+                    }
+                    const float4 av = af[xi & 3][j];
+                    acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bf[g & 1][0], acc[xi], 0, 0, 0);
+                    acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bf[g & 1][1], acc[xi], 0, 0, 0);
+                    acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bf[g & 1][2], acc[xi], 0, 0, 0);
+                    acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bf[g & 1][3], acc[xi], 0, 0, 0);
+                    // the order inside the group: an MFMA, then a share of everything else the group carries (the wave would only
+                    // wait for the matrix pipe there: 64 cycles per MFMA) - four times
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // LDS reads (the next group's B values)
+                        __builtin_amdgcn_sched_group_barrier(0x020, 3, 0);  // global loads (patches, U fragments)
+                        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);  // VALU
+                        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // LDS stores
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
-            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();  // V[s] has been read by everybody, V[s ^ 1] is complete
+            s ^= 1;
+        }
+
+        // ---- output transform on the wave's own registers: lane (c, h) owns tile 32 pb + c and 16 channels (MFMA C layout)
+        const long long p = (long long)pbk * PT + 32 * pb + c;
+        if (p < a.P) {
+            const int n = (int)(p / per), rem = (int)(p % per), ty = rem / a.TX, tx = rem % a.TX;
+            const long long oplane = (long long)a.Hd * a.Wd;
+            float* const obase = a.dst + (long long)n * a.Cm * oplane + (long long)(2 * ty) * a.Wd + 2 * tx;
 #pragma unroll
-            for (int qq = 0; qq < QB; ++qq) {
-                const int cl = cl0 + (q0 + qq) * CSTEP;
-                float tt[4][4];
+            for (int e = 0; e < 16; ++e) {
+                const int co = 32 * cbg + (e & 3) + 8 * (e >> 2) + 4 * h;
+                float tm[2][4];  // A^T M
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float d0 = poff[0][j] >= 0 ? d[qq][0][j] : 0.f, d1 = poff[1][j] >= 0 ? d[qq][1][j] : 0.f;
-                    const float d2 = poff[2][j] >= 0 ? d[qq][2][j] : 0.f, d3 = poff[3][j] >= 0 ? d[qq][3][j] : 0.f;
-                    tt[0][j] = d0 - d2;
-                    tt[1][j] = d1 + d2;
-                    tt[2][j] = d2 - d1;
-                    tt[3][j] = d1 - d3;
+                    tm[0][j] = (acc[0 + j][e] + acc[4 + j][e]) + acc[8 + j][e];
+                    tm[1][j] = (acc[4 + j][e] - acc[8 + j][e]) - acc[12 + j][e];
                 }
+                const float bv = a.bias ? a.bias[co] : 0.f;
+                float* o = obase + (long long)co * oplane;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float* vp = V + ((4 * i) * KC + cl) * PT + pl;
-                    vp[0 * KC * PT] = tt[i][0] - tt[i][2];
-                    vp[1 * KC * PT] = tt[i][1] + tt[i][2];
-                    vp[2 * KC * PT] = tt[i][2] - tt[i][1];
-                    vp[3 * KC * PT] = tt[i][1] - tt[i][3];
+                for (int r = 0; r < 2; ++r) {
+                    float y0 = (tm[r][0] + tm[r][1]) + tm[r][2];
+                    float y1 = (tm[r][1] - tm[r][2]) - tm[r][3];
+                    if (a.bias) { y0 += bv; y1 += bv; }
+                    float2* q = reinterpret_cast<float2*>(o + r * a.Wd);
+                    if (!a.assign) { const float2 old = *q; y0 += old.x; y1 += old.y; }
+                    *q = make_float2(y0, y1);
                 }
             }
-        }
-        __syncthreads();
-        // ---- 16 products of (32 channels x KC) . (KC x 32 tiles).  A fragments come from L2 one xi ahead (NJ float4 per lane, a
-        // whole xi of MFMAs to land), B values from LDS one group of four steps ahead; sched_barriers pin that order - left to
-        // itself the scheduler sinks every load to its first use and waits there.
-        const float* vb0 = V + (KH * h) * PT + 32 * pb + c;
-        float bf[2][4];
-#pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) bf[0][q4] = vb0[q4 * PT];
-#pragma unroll
-        for (int xi = 0; xi < 16; ++xi) {
-            if (xi + 1 < 16) {
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) af[(xi + 1) & 1][j] = up[(xi + 1) * ustep + j * 64];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const int g = xi * NJ + j;  // group number: its B values are in bf[g & 1]
-                if (j + 1 < NJ) {
-#pragma unroll
-                    for (int q4 = 0; q4 < 4; ++q4) bf[(g + 1) & 1][q4] = vb0[(xi * KC + 4 * (j + 1) + q4) * PT];
-                } else if (xi + 1 < 16) {
-#pragma unroll
-                    for (int q4 = 0; q4 < 4; ++q4) bf[(g + 1) & 1][q4] = vb0[((xi + 1) * KC + q4) * PT];
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                const float4 av = af[xi & 1][j];
-                acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bf[g & 1][0], acc[xi], 0, 0, 0);
-                acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bf[g & 1][1], acc[xi], 0, 0, 0);
-                acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bf[g & 1][2], acc[xi], 0, 0, 0);
-                acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bf[g & 1][3], acc[xi], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        if (ch + 1 < a.nchunk) __syncthreads();  // everybody is done reading V before the next chunk overwrites it
-    }
-
-    // ---- output transform on the wave's own registers: lane (c, h) owns tile 32 pb + c and 16 channels (MFMA C layout)
-    const long long p = (long long)blockIdx.x * PT + 32 * pb + c;
-    if (p >= a.P) return;
-    const int per = a.TY * a.TX;
-    const int n = (int)(p / per), rem = (int)(p % per), ty = rem / a.TX, tx = rem % a.TX;
-    const long long oplane = (long long)a.Hd * a.Wd;
-    float* const obase = a.dst + (long long)n * a.Cm * oplane + (long long)(2 * ty) * a.Wd + 2 * tx;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const int co = 32 * cbg + (e & 3) + 8 * (e >> 2) + 4 * h;
-        float tm[2][4];  // A^T M
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            tm[0][j] = (acc[0 + j][e] + acc[4 + j][e]) + acc[8 + j][e];
-            tm[1][j] = (acc[4 + j][e] - acc[8 + j][e]) - acc[12 + j][e];
-        }
-        const float bv = a.bias ? a.bias[co] : 0.f;
-        float* o = obase + (long long)co * oplane;
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            float y0 = (tm[r][0] + tm[r][1]) + tm[r][2];
-            float y1 = (tm[r][1] - tm[r][2]) - tm[r][3];
-            if (a.bias) { y0 += bv; y1 += bv; }
-            float2* q = reinterpret_cast<float2*>(o + r * a.Wd);
-            if (!a.assign) { const float2 old = *q; y0 += old.x; y1 += old.y; }
-            *q = make_float2(y0, y1);
         }
     }
 }
@@ -238,7 +285,7 @@ int wino_launch(nk_device* dev, bool bwd, const float* src, const float* w, floa
     *taken = false;
     const int mode = dev->tune_conv_winograd;  // -1 rule, 0 never, 1 whenever the shape allows
     if (mode == 0) return NK_OK;
-    const int KC = bwd ? 32 : 64, CM = bwd ? 64 : 128, PT = bwd ? 64 : 32;
+    const int KC = bwd ? 16 : 32, CM = bwd ? 64 : 128, PT = bwd ? 64 : 32;
     if (Hd < 2 || Wd < 2 || Hd % 2 != 0 || Wd % 2 != 0 || Ck % KC != 0 || Cm % CM != 0) return NK_OK;
     if (!al16(dst) || !al16(src)) return NK_OK;
     const long long P = (long long)N * (Hd / 2) * (Wd / 2);
@@ -260,9 +307,12 @@ int wino_launch(nk_device* dev, bool bwd, const float* src, const float* w, floa
     a.Hs = Hs; a.Ws = Ws; a.Hd = Hd; a.Wd = Wd; a.offy = offy; a.offx = offx;
     a.TY = Hd / 2; a.TX = Wd / 2; a.P = P;
     a.nchunk = Ck / KC; a.assign = assign;
-    const dim3 grid((unsigned)((P + PT - 1) / PT), (unsigned)(Cm / CM));
-    if (bwd) hipLaunchKernelGGL((wino_kernel<2, 2, 32>), grid, dim3(256), 0, dev->compute, a);
-    else hipLaunchKernelGGL((wino_kernel<4, 1, 64>), grid, dim3(256), 0, dev->compute, a);
+    // persistent blocks, one per CU: block b walks the tile blocks b, b + grid.x, ...
+    const long long npb = (P + PT - 1) / PT;
+    const long long per_group = dev->num_cus / (Cm / CM) > 0 ? dev->num_cus / (Cm / CM) : 1;
+    const dim3 grid((unsigned)(npb < per_group ? npb : per_group), (unsigned)(Cm / CM));
+    if (bwd) hipLaunchKernelGGL((wino_kernel<2, 2, 16>), grid, dim3(256), 0, dev->compute, a);
+    else hipLaunchKernelGGL((wino_kernel<4, 1, 32>), grid, dim3(256), 0, dev->compute, a);
     NK_LAUNCH_CHECK();
     *taken = true;
     return nk_prof_stop(dev);
