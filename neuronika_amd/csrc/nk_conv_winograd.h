@@ -33,6 +33,7 @@ struct WinoArgs {
     long long P;        // N * TY * TX
     int nchunk;         // Ck / KC
     int assign;         // 1: dst = value, 0: dst += value
+    int src_bytes, u_bytes, dst_bytes;  // the buffer descriptors' extents (all below 2^31)
 };
 
 // U in MFMA A-operand order.  For chunk ch (KC reduction channels), xi, block of 32 output channels cbt: a wave's fragment is
@@ -74,205 +75,235 @@ __global__ void wino_weights_kernel(float* __restrict__ u, const float* __restri
         u[((((long long)(ch * 16 + xi) * CBT + cbt) * (KC / 8) + j) * 64 + lane) * 4 + tq] = uu[xi >> 2][xi & 3];
 }
 
+typedef unsigned wino_u2 __attribute__((ext_vector_type(2)));
+typedef unsigned wino_u4 __attribute__((ext_vector_type(4)));
+
 // One block per CU (128 KB of LDS, 512 registers per lane), PERSISTENT: block b walks the tile blocks b, b + gridDim.x, ... and, inside
 // each, the chunks of KC reduction channels.  The stream of (tile block, chunk) items is software-pipelined through two V buffers:
-// while the MFMAs of item i read V[i & 1], the same waves load and transform the patches of item i + 1 into V[(i + 1) & 1] - the loads
-// in the first quarter of the item's MFMA groups, the additions and LDS stores of one channel at a time further on, a few
-// instructions per group of four MFMAs - and prefetch their U fragments three xi ahead from L2.  One barrier per item.  Only the
-// first item's transform and each tile block's output transform run with the matrix pipe idle.
+// while the MFMAs of item i read V[i & 1], the same waves load and transform the patches of item i + 1 into V[(i + 1) & 1] and
+// prefetch their U fragments three xi ahead from L2.  One barrier per item.  Only the first item's transform and each tile
+// block's output transform run with the matrix pipe idle.
+//
+// Memory instructions carry no address arithmetic: everything goes through buffer descriptors (source, U, destination) with the
+// per-lane part of the address computed once per tile block (voffset), the per-item / per-channel part in a scalar register
+// (soffset) and the rest in the instruction's immediate.  A patch element outside the source (image border of the folded padding,
+// tile past the end) has voffset 0x80000000 - out of the descriptor's range, so the hardware returns 0 for it (and drops such a
+// store): no selects in the transform.  The host keeps this path to tensors below 2 GB.
+//
+// V layout: [xi][channel / 4][tile][channel % 4] - a thread of the transform owns one tile and FOUR consecutive channels (one
+// float4 per patch element, the additions of the four channels side by side), stores one ds_write_b128 per xi, and an MFMA group
+// (four k-steps of one xi) takes its four B values with one ds_read_b128.
 template <int CB, int PB, int KC>
 __global__ __launch_bounds__(256, 1) void wino_kernel(WinoArgs a) {
     constexpr int PT = 32 * PB;        // tiles per tile block
     constexpr int KH = KC / 2;         // MFMA steps per item and xi (two reduction channels per step)
-    constexpr int NJ = KC / 8;         // groups of four steps (one float4 of A per lane) per item and xi
-    constexpr int CSTEP = 256 / PT;    // channels the block's threads cover per transform pass
-    constexpr int NQ = KC / CSTEP;     // channels per thread and item
+    constexpr int NJ = KC / 8;         // groups of four steps (one float4 of A, one of B per lane) per item and xi
+    constexpr int KQ = KC / 4;         // channel quads per item
     constexpr int G = 16 * NJ;         // MFMA groups per item
-    constexpr int VBUF = 16 * KC * PT; // floats of one V buffer: [xi][channel in chunk][tile]
-    constexpr int LPG = 64 / (G / 4);  // patch loads per group while the loads are issued (groups 0 .. G/4 - 1)
-    constexpr int TG = G / 8;          // groups one channel's transform is spread over
-    constexpr int T0 = G / 4 + G / 8;  // first group of channel 0's transform (its loads left at least G/8 groups earlier)
-    constexpr int PPG = 8 / TG;        // transform parts (of 8 per channel: 4 column passes, 4 row passes + stores) per group
-    static_assert(CB * PB == 4 && NQ == 4 && KC % 8 == 0 && 16 % 4 == 0, "four waves, four channels per thread and item");
-    static_assert(T0 + NQ * TG <= G && LPG * (G / 4) == 16 * NQ && PPG * TG == 8, "the slices of the next item's transform fit the item's groups");
-    static_assert(2 * VBUF * sizeof(float) <= 160 * 1024, "two V buffers must fit the 160 KB of a gfx950 CU");
+    constexpr int VBUF = 16 * KC * PT; // floats of one V buffer
+    constexpr int LG = G / 4;          // groups that carry the next item's patch loads
+    constexpr int LPG = 64 / LG;       // ... loads per group
+    constexpr int TG = G / 16;         // groups per part of the next item's transform (8 parts: 4 column passes, 4 row passes + stores)
+    constexpr int T0 = G - 8 * TG - TG;  // first group of part 0
+    static_assert(CB * PB == 4 && KQ * PT == 256 && KC % 8 == 0, "four waves; one (tile, channel quad) per thread and item");
+    static_assert(LPG * LG == 64 && TG >= 1 && T0 >= LG, "the slices of the next item's transform fit the item's groups");
+    static_assert(2 * VBUF * sizeof(float) + 32 * CB * sizeof(float) <= 160 * 1024, "two V buffers must fit the 160 KB of a gfx950 CU");
     __shared__ __attribute__((aligned(16))) float V[2 * VBUF];
+    __shared__ float bias_s[32 * CB];
     const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
     const int cb = wid % CB, pb = wid / CB;
     const int c = lane & 31, h = lane >> 5;
-    const int plane = a.Hs * a.Ws;  // (the host checks that the tensors have fewer than 2^31 elements)
+    const int plane = a.Hs * a.Ws;
     const int per = a.TY * a.TX;
     const int npb = (int)((a.P + PT - 1) / PT);
-    const int pl = t % PT, cl0 = t / PT;  // transform phase: this thread's tile of a tile block and its first channel
+    const int pl = t % PT, kq0 = t / PT;  // transform phase: this thread's tile of a tile block and its channel quad
     const int CBT = a.Cm / 32, cbg = blockIdx.y * CB + cb;
-    const long long ustep = (long long)CBT * NJ * 64;  // float4s from xi to xi + 1
-    const float4* const ubase = reinterpret_cast<const float4*>(a.u) + (long long)cbg * NJ * 64 + lane;  // + ch * 16 * ustep + xi * ustep + j * 64
+    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc((void*)a.src, 0, a.src_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc((void*)a.u, 0, a.u_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc((void*)a.dst, 0, a.dst_bytes, 0x00020000);
+    const int ustep16 = CBT * NJ * 64 * 16;                 // bytes from xi to xi + 1
+    const unsigned uvoff = (unsigned)(cbg * NJ * 64 + lane) * 16u;
+    const int plane4 = plane * 4;
 
-    // offset of patch element (i, j) of tile block `pbk` from channel 0 of the patch's sample, -1 outside the source (loads are
-    // branch-free: such an element reads element 0 and is replaced by 0)
-    int poff[16];
+    if (t < 32 * CB) bias_s[t] = a.bias ? a.bias[32 * blockIdx.y * CB + t] : 0.f;
+
+    // byte offset of patch element (i, j) of tile block `pbk`, channel 4 kq0 of the chunk, from channel 0 of the patch's sample;
+    // 0x80000000 outside the source
+    unsigned poff[16];
     auto patch = [&](int pbk) {
-        const long long p = (long long)pbk * PT + pl;
-        const bool pvalid = pbk < npb && p < a.P;
-        const int n = pvalid ? (int)(p / per) : 0, rem = pvalid ? (int)(p % per) : 0;
-        const int ty = rem / a.TX, tx = rem % a.TX;
+        const unsigned p = (unsigned)pbk * PT + pl;  // (the host keeps P below 2^30)
+        const bool pvalid = pbk < npb && p < (unsigned)a.P;
+        const unsigned n = pvalid ? p / (unsigned)per : 0u, rem = pvalid ? p % (unsigned)per : 0u;
+        const int ty = (int)(rem / (unsigned)a.TX), tx = (int)(rem % (unsigned)a.TX);
         const int r0 = 2 * ty - a.offy, c0 = 2 * tx - a.offx;
-        const int sb = n * a.Ck * plane + r0 * a.Ws + c0;
+        const int sb = ((int)n * a.Ck + 4 * kq0) * plane + r0 * a.Ws + c0;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const bool ok = pvalid && (unsigned)(r0 + i) < (unsigned)a.Hs && (unsigned)(c0 + j) < (unsigned)a.Ws;
-                poff[4 * i + j] = ok ? sb + i * a.Ws + j : -1;
+                poff[4 * i + j] = ok ? (unsigned)(sb + i * a.Ws + j) * 4u : 0x80000000u;
             }
     };
-    // the pieces of one channel's transform (d: the 16 loaded values, tt: B^T d): column pass j, then row pass i + stores
-    auto col_pass = [&](const float (&d)[16], float (&tt)[16], int j) {
-        const float d0 = poff[j] >= 0 ? d[j] : 0.f, d1 = poff[4 + j] >= 0 ? d[4 + j] : 0.f;
-        const float d2 = poff[8 + j] >= 0 ? d[8 + j] : 0.f, d3 = poff[12 + j] >= 0 ? d[12 + j] : 0.f;
-        tt[j] = d0 - d2;
-        tt[4 + j] = d1 + d2;
-        tt[8 + j] = d2 - d1;
-        tt[12 + j] = d1 - d3;
+    // patch load number l of an item, in the order the column passes need them: l = 16 j + 4 i + q (column j, row i, channel q)
+    float4 d[16];
+    auto load = [&](int l, int ch) {
+        const int j = l / 16, i = (l / 4) % 4, q = l % 4;
+        const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srs, poff[4 * i + j], (ch * KC + q) * plane4, 0));
+        if (q == 0) d[4 * i + j].x = v;
+        else if (q == 1) d[4 * i + j].y = v;
+        else if (q == 2) d[4 * i + j].z = v;
+        else d[4 * i + j].w = v;
     };
-    auto row_pass = [&](const float (&tt)[16], float* vdst, int cl, int i) {
-        float* vp = vdst + ((4 * i) * KC + cl) * PT + pl;
-        vp[0 * KC * PT] = tt[4 * i] - tt[4 * i + 2];
-        vp[1 * KC * PT] = tt[4 * i + 1] + tt[4 * i + 2];
-        vp[2 * KC * PT] = tt[4 * i + 2] - tt[4 * i + 1];
-        vp[3 * KC * PT] = tt[4 * i + 1] - tt[4 * i + 3];
+    // the eight parts of an item's transform, in place on d (four channels side by side): column pass j = k (k < 4): B^T d;
+    // row pass i = k - 4 (k >= 4): (B^T d) B and the stores of xi = 4 i .. 4 i + 3
+    auto part = [&](int k, float* vdst) {
+        if (k < 4) {
+            const int j = k;
+            const float4 d0 = d[j], d1 = d[4 + j], d2 = d[8 + j], d3 = d[12 + j];
+            d[j] = d0 - d2;
+            d[4 + j] = d1 + d2;
+            d[8 + j] = d2 - d1;
+            d[12 + j] = d1 - d3;
+        } else {
+            const int i = k - 4;
+            const float4 t0 = d[4 * i], t1 = d[4 * i + 1], t2 = d[4 * i + 2], t3 = d[4 * i + 3];
+            float4* vp = reinterpret_cast<float4*>(vdst) + ((4 * i) * KQ + kq0) * PT + pl;
+            vp[0 * KQ * PT] = t0 - t2;
+            vp[1 * KQ * PT] = t1 + t2;
+            vp[2 * KQ * PT] = t2 - t1;
+            vp[3 * KQ * PT] = t1 - t3;
+        }
     };
 
     int pbk = blockIdx.x;
     if (pbk >= npb) return;
     // ---- prologue: item (pbk, chunk 0) into V[0], the matrix pipe idle
     patch(pbk);
-    {
-        float d[NQ][16];
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const int coff = (cl0 + q * CSTEP) * plane;
+    for (int l = 0; l < 64; ++l) load(l, 0);
 #pragma unroll
-            for (int e = 0; e < 16; ++e) d[q][e] = a.src[poff[e] >= 0 ? poff[e] + coff : 0];
-        }
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            float tt[16];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) col_pass(d[q], tt, j);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) row_pass(tt, V, cl0 + q * CSTEP, i);
-        }
-    }
+    for (int k = 0; k < 8; ++k) part(k, V);
     // U fragments of xi = 0, 1, 2 of chunk 0: a ring of four, three xi ahead of the MFMAs
     float4 af[4][NJ];
 #pragma unroll
     for (int x = 0; x < 3; ++x)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) af[x][j] = ubase[x * ustep + j * 64];
+        for (int j = 0; j < NJ; ++j)
+            af[x][j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(urs, uvoff + j * 1024, x * ustep16, 0));
     __syncthreads();
 
     int s = 0;
-    for (; pbk < npb; pbk += gridDim.x) {
-        nkmma::f32x16 acc[16];
+    nkmma::f32x16 acc[16];
+    // one item: the MFMAs of (tile block, chunk ch) on V[s], with the slices of the item after it (chunk nch; `first`: the accumulators
+    // start from zero - the first MFMA of each xi takes the constant)
+    auto item = [&](auto first, int ch, int nch) {
+        const float4* const vcur = reinterpret_cast<const float4*>(V + s * VBUF) + ((KH / 4) * h) * PT + 32 * pb + c;
+        float* const vnext = V + (s ^ 1) * VBUF;
+        float4 bf[2];
+        bf[0] = vcur[0];
 #pragma unroll
-        for (int xi = 0; xi < 16; ++xi)
+        for (int xi = 0; xi < 16; ++xi) {
+            // U fragments three xi ahead (past the item's end: the next item's first three)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[xi][e] = 0.f;
-        for (int ch = 0; ch < a.nchunk; ++ch) {
-            // the item after this one: the next chunk, or chunk 0 of this block's next tile block (none: its loads read element 0
-            // and the values land in a V buffer nobody reads)
-            const bool last_ch = ch + 1 == a.nchunk;
-            const int nch = last_ch ? 0 : ch + 1;
-            if (last_ch) patch(pbk + gridDim.x);
-            const int ncoff = (nch * KC + cl0) * plane;
-            const float* const vcur = V + s * VBUF + (KH * h) * PT + 32 * pb + c;
-            float* const vnext = V + (s ^ 1) * VBUF;
-            const float4* const ucur = ubase + (long long)ch * 16 * ustep;
-            const float4* const unext = ubase + (long long)nch * 16 * ustep;
-            float d[NQ][16], tt[16];
-            float bf[2][4];
+            for (int j = 0; j < NJ; ++j)
+                af[(xi + 3) & 3][j] = __builtin_bit_cast(
+                    float4, __builtin_amdgcn_raw_buffer_load_b128(urs, uvoff + j * 1024,
+                                                                  xi + 3 < 16 ? (ch * 16 + xi + 3) * ustep16 : (nch * 16 + xi + 3 - 16) * ustep16, 0));
 #pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) bf[0][q4] = vcur[q4 * PT];
+            for (int j = 0; j < NJ; ++j) {
+                const int g = xi * NJ + j;  // group number inside the item: its B values are in bf[g & 1]
+                if (g + 1 < G) bf[(g + 1) & 1] = vcur[(((g + 1) / NJ) * KQ + (g + 1) % NJ) * PT];
+                // ---- this group's slice of the NEXT item's transform
+                if (g < LG) {
 #pragma unroll
-            for (int xi = 0; xi < 16; ++xi) {
-                // U fragments three xi ahead (past the item's end: the next item's first three)
-#pragma unroll
-                for (int j = 0; j < NJ; ++j)
-                    af[(xi + 3) & 3][j] = xi + 3 < 16 ? ucur[(xi + 3) * ustep + j * 64] : unext[(xi + 3 - 16) * ustep + j * 64];
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    const int g = xi * NJ + j;  // group number inside the item: its B values are in bf[g & 1]
-                    if (g + 1 < G) {
-                        const int xn = (g + 1) / NJ, jn = (g + 1) % NJ;
-#pragma unroll
-                        for (int q4 = 0; q4 < 4; ++q4) bf[(g + 1) & 1][q4] = vcur[(xn * KC + 4 * jn + q4) * PT];
-                    }
-                    // ---- this group's slice of the NEXT item's transform
-                    if (g < G / 4) {  // patch loads: LPG per group
-#pragma unroll
-                        for (int l = 0; l < LPG; ++l) {
-                            const int q = (g * LPG + l) / 16, e = (g * LPG + l) % 16;
-                            d[q][e] = a.src[poff[e] >= 0 ? poff[e] + ncoff + q * CSTEP * plane : 0];
-                        }
-                    }
-                    if (g >= T0 && g < T0 + NQ * TG) {  // channel q's transform, PPG of its 8 parts per group
-                        const int q = (g - T0) / TG, k0 = ((g - T0) % TG) * PPG;
-#pragma unroll
-                        for (int k = k0; k < k0 + PPG; ++k) {
-                            if (k < 4) col_pass(d[q], tt, k);
-                            else row_pass(tt, vnext, cl0 + q * CSTEP, k - 4);
-                        }
-                    }
-                    const float4 av = af[xi & 3][j];
-                    acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bf[g & 1][0], acc[xi], 0, 0, 0);
-                    acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bf[g & 1][1], acc[xi], 0, 0, 0);
-                    acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bf[g & 1][2], acc[xi], 0, 0, 0);
-                    acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bf[g & 1][3], acc[xi], 0, 0, 0);
-                    // the order inside the group: an MFMA, then a share of everything else the group carries (the wave would only
-                    // wait for the matrix pipe there: 64 cycles per MFMA) - four times
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
-                        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // LDS reads (the next group's B values)
-                        __builtin_amdgcn_sched_group_barrier(0x020, 3, 0);  // global loads (patches, U fragments)
-                        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);  // VALU
-                        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // LDS stores
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
+                    for (int l = 0; l < LPG; ++l) load(g * LPG + l, nch);
                 }
+                if (g >= T0 && g < T0 + 8 * TG && (g - T0) % TG == 0) part((g - T0) / TG, vnext);
+                const float4 av = af[xi & 3][j];
+                const float4 bv = bf[g & 1];
+                if (decltype(first)::value && j == 0) {
+                    const nkmma::f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, zero, 0, 0, 0);
+                } else {
+                    acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[xi], 0, 0, 0);
+                }
+                acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[xi], 0, 0, 0);
+                acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[xi], 0, 0, 0);
+                acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[xi], 0, 0, 0);
+                // the order inside the group: an MFMA, then a share of everything else the group carries (the wave would only
+                // wait for the matrix pipe there: 64 cycles per MFMA) - four times
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // LDS read (the next group's B values)
+                    __builtin_amdgcn_sched_group_barrier(0x020, 3, 0);  // buffer loads (patches, U fragments)
+                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);  // VALU
+                    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // LDS stores
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __syncthreads();  // V[s] has been read by everybody, V[s ^ 1] is complete
-            s ^= 1;
+        }
+        __syncthreads();  // V[s] has been read by everybody, V[s ^ 1] is complete
+        s ^= 1;
+    };
+
+    for (; pbk < npb; pbk += gridDim.x) {
+        // the item after a tile block's last chunk is chunk 0 of this block's next tile block (none: every load is out of range
+        // and the values land in a V buffer nobody reads)
+        if (a.nchunk == 1) patch(pbk + gridDim.x);
+        item(std::true_type{}, 0, a.nchunk == 1 ? 0 : 1);
+        for (int ch = 1; ch < a.nchunk; ++ch) {
+            const bool last_ch = ch + 1 == a.nchunk;
+            if (last_ch) patch(pbk + gridDim.x);
+            item(std::false_type{}, ch, last_ch ? 0 : ch + 1);
         }
 
-        // ---- output transform on the wave's own registers: lane (c, h) owns tile 32 pb + c and 16 channels (MFMA C layout)
-        const long long p = (long long)pbk * PT + 32 * pb + c;
-        if (p < a.P) {
-            const int n = (int)(p / per), rem = (int)(p % per), ty = rem / a.TX, tx = rem % a.TX;
-            const long long oplane = (long long)a.Hd * a.Wd;
-            float* const obase = a.dst + (long long)n * a.Cm * oplane + (long long)(2 * ty) * a.Wd + 2 * tx;
+        // ---- output transform on the wave's own registers: lane (c, h) owns tile 32 pb + c and 16 channels (MFMA C layout):
+        // e = 4 Q + el is channel 32 cbg + 8 Q + 4 h + el.  No loads after the first store in the assigning form (loads and stores
+        // share one in-order counter: a load behind a store waits for every store before it).
+        const unsigned p = (unsigned)pbk * PT + 32 * pb + c;
+        const bool pvalid = p < (unsigned)a.P;
+        const unsigned un = pvalid ? p / (unsigned)per : 0u, urem = pvalid ? p % (unsigned)per : 0u;
+        const int n = (int)un, ty = (int)(urem / (unsigned)a.TX), tx = (int)(urem % (unsigned)a.TX);
+        const int oplane = a.Hd * a.Wd;
+        const unsigned ovoff = pvalid ? (unsigned)((n * a.Cm + 32 * cbg + 4 * h) * oplane + 2 * ty * a.Wd + 2 * tx) * 4u : 0x80000000u;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int co = 32 * cbg + (e & 3) + 8 * (e >> 2) + 4 * h;
+        for (int Q = 0; Q < 4; ++Q) {
+            float2 y[4][2];
+#pragma unroll
+            for (int el = 0; el < 4; ++el) {
+                const int e = 4 * Q + el;
                 float tm[2][4];  // A^T M
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     tm[0][j] = (acc[0 + j][e] + acc[4 + j][e]) + acc[8 + j][e];
                     tm[1][j] = (acc[4 + j][e] - acc[8 + j][e]) - acc[12 + j][e];
                 }
-                const float bv = a.bias ? a.bias[co] : 0.f;
-                float* o = obase + (long long)co * oplane;
+                const float bv = bias_s[32 * cb + 8 * Q + 4 * h + el];
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {
-                    float y0 = (tm[r][0] + tm[r][1]) + tm[r][2];
-                    float y1 = (tm[r][1] - tm[r][2]) - tm[r][3];
-                    if (a.bias) { y0 += bv; y1 += bv; }
-                    float2* q = reinterpret_cast<float2*>(o + r * a.Wd);
-                    if (!a.assign) { const float2 old = *q; y0 += old.x; y1 += old.y; }
-                    *q = make_float2(y0, y1);
+                    y[el][r].x = ((tm[r][0] + tm[r][1]) + tm[r][2]) + bv;
+                    y[el][r].y = ((tm[r][1] - tm[r][2]) - tm[r][3]) + bv;
                 }
             }
+            if (!a.assign) {
+                float2 old[4][2];
+#pragma unroll
+                for (int el = 0; el < 4; ++el)
+#pragma unroll
+                    for (int r = 0; r < 2; ++r)
+                        old[el][r] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(drs, ovoff, ((8 * Q + el) * oplane + r * a.Wd) * 4, 0));
+#pragma unroll
+                for (int el = 0; el < 4; ++el)
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) { y[el][r].x += old[el][r].x; y[el][r].y += old[el][r].y; }
+            }
+#pragma unroll
+            for (int el = 0; el < 4; ++el)
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(wino_u2, y[el][r]), drs, ovoff, ((8 * Q + el) * oplane + r * a.Wd) * 4, 0);
         }
     }
 }
@@ -290,7 +321,9 @@ int wino_launch(nk_device* dev, bool bwd, const float* src, const float* w, floa
     if (!al16(dst) || !al16(src)) return NK_OK;
     const long long P = (long long)N * (Hd / 2) * (Wd / 2);
     const long long blocks = (P + PT - 1) / PT * (Cm / CM);
-    if (blocks > 0x7fffffffLL || (long long)N * Ck * Hs * Ws >= 0x7fffffffLL || (long long)N * Cm * Hd * Wd >= 0x7fffffffLL) return NK_OK;
+    // buffer descriptors with 32-bit byte offsets, 0x80000000 as the out-of-range mark: every tensor below 2 GB
+    const long long src_bytes = (long long)N * Ck * Hs * Ws * 4, dst_bytes = (long long)N * Cm * Hd * Wd * 4, u_bytes = 16LL * Cm * Ck * 4;
+    if (P >= (1LL << 30) || src_bytes >= 0x7fffffffLL || dst_bytes >= 0x7fffffffLL || u_bytes >= 0x7fffffffLL) return NK_OK;
     // by rule: enough blocks for four rounds of the chip's CUs (one block per CU: 128 KB of LDS, 512 registers per lane)
     if (mode < 0 && blocks < 4LL * dev->num_cus) return NK_OK;
     void* ws = nullptr;
@@ -307,6 +340,7 @@ int wino_launch(nk_device* dev, bool bwd, const float* src, const float* w, floa
     a.Hs = Hs; a.Ws = Ws; a.Hd = Hd; a.Wd = Wd; a.offy = offy; a.offx = offx;
     a.TY = Hd / 2; a.TX = Wd / 2; a.P = P;
     a.nchunk = Ck / KC; a.assign = assign;
+    a.src_bytes = (int)src_bytes; a.u_bytes = (int)u_bytes; a.dst_bytes = (int)dst_bytes;
     // persistent blocks, one per CU: block b walks the tile blocks b, b + grid.x, ...
     const long long npb = (P + PT - 1) / PT;
     const long long per_group = dev->num_cus / (Cm / CM) > 0 ? dev->num_cus / (Cm / CM) : 1;
