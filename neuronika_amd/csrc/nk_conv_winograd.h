@@ -93,8 +93,8 @@ typedef unsigned wino_u4 __attribute__((ext_vector_type(4)));
 // V layout: [xi][channel / 4][tile][channel % 4] - a thread of the transform owns one tile and FOUR consecutive channels (one
 // float4 per patch element, the additions of the four channels side by side), stores one ds_write_b128 per xi, and an MFMA group
 // (four k-steps of one xi) takes its four B values with one ds_read_b128.
-template <int CB, int PB, int KC>
-__global__ __launch_bounds__(256, 1) void wino_kernel(WinoArgs a) {
+template <int CB, int PB, int KC, int UR>
+__global__ __launch_bounds__(64 * CB * PB, 1) void wino_kernel(WinoArgs a) {
     constexpr int PT = 32 * PB;        // tiles per tile block
     constexpr int KH = KC / 2;         // MFMA steps per item and xi (two reduction channels per step)
     constexpr int NJ = KC / 8;         // groups of four steps (one float4 of A, one of B per lane) per item and xi
@@ -105,7 +105,8 @@ __global__ __launch_bounds__(256, 1) void wino_kernel(WinoArgs a) {
     constexpr int LPG = 64 / LG;       // ... loads per group
     constexpr int TG = G / 16;         // groups per part of the next item's transform (8 parts: 4 column passes, 4 row passes + stores)
     constexpr int T0 = G - 8 * TG - TG;  // first group of part 0
-    static_assert(CB * PB == 4 && KQ * PT == 256 && KC % 8 == 0, "four waves; one (tile, channel quad) per thread and item");
+    static_assert((CB * PB == 4 || CB * PB == 2) && KQ * PT == 64 * CB * PB && KC % 8 == 0, "one (tile, channel quad) per thread and item");
+    static_assert(16 % UR == 0 && UR >= 2, "the ring of U fragments (UR - 1 xi ahead of the MFMAs) keeps its phase from item to item");
     static_assert(LPG * LG == 64 && TG >= 1 && T0 >= LG, "the slices of the next item's transform fit the item's groups");
     static_assert(2 * VBUF * sizeof(float) + 32 * CB * sizeof(float) <= 160 * 1024, "two V buffers must fit the 160 KB of a gfx950 CU");
     __shared__ __attribute__((aligned(16))) float V[2 * VBUF];
@@ -176,18 +177,24 @@ __global__ __launch_bounds__(256, 1) void wino_kernel(WinoArgs a) {
         }
     };
 
-    int pbk = blockIdx.x;
-    if (pbk >= npb) return;
+    // Blocks land on the eight XCDs round robin (block b on XCD b % 8), each XCD with its own L2: the tile blocks are dealt out in
+    // eight contiguous ranges, and inside a range the XCD's blocks walk side by side - neighbouring tile blocks share two of
+    // their four patch rows, the second reader finds them in its L2.
+    const int nx = gridDim.x % 8 == 0 ? 8 : 1, step = gridDim.x / nx;
+    const int range = (npb + nx - 1) / nx, lo = (int)(blockIdx.x % nx) * range, hi = lo + range < npb ? lo + range : npb;
+    int pbk = lo + (int)(blockIdx.x / nx);
+    if (pbk >= hi) return;
     // ---- prologue: item (pbk, chunk 0) into V[0], the matrix pipe idle
     patch(pbk);
 #pragma unroll
     for (int l = 0; l < 64; ++l) load(l, 0);
 #pragma unroll
     for (int k = 0; k < 8; ++k) part(k, V);
-    // U fragments of xi = 0, 1, 2 of chunk 0: a ring of four, three xi ahead of the MFMAs
-    float4 af[4][NJ];
+    // U fragments of the first UR - 1 xi of chunk 0: a ring of UR, UR - 1 xi ahead of the MFMAs (loads return in order: the wait
+    // for a fragment is also a wait for every patch load issued before it - the distance is the latency the patch loads may have)
+    float4 af[UR][NJ];
 #pragma unroll
-    for (int x = 0; x < 3; ++x)
+    for (int x = 0; x < UR - 1; ++x)
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
             af[x][j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(urs, uvoff + j * 1024, x * ustep16, 0));
@@ -204,12 +211,12 @@ __global__ __launch_bounds__(256, 1) void wino_kernel(WinoArgs a) {
         bf[0] = vcur[0];
 #pragma unroll
         for (int xi = 0; xi < 16; ++xi) {
-            // U fragments three xi ahead (past the item's end: the next item's first three)
+            // U fragments UR - 1 xi ahead (past the item's end: the next item's first ones)
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
-                af[(xi + 3) & 3][j] = __builtin_bit_cast(
-                    float4, __builtin_amdgcn_raw_buffer_load_b128(urs, uvoff + j * 1024,
-                                                                  xi + 3 < 16 ? (ch * 16 + xi + 3) * ustep16 : (nch * 16 + xi + 3 - 16) * ustep16, 0));
+                af[(xi + UR - 1) % UR][j] = __builtin_bit_cast(
+                    float4, __builtin_amdgcn_raw_buffer_load_b128(
+                                urs, uvoff + j * 1024, xi + UR - 1 < 16 ? (ch * 16 + xi + UR - 1) * ustep16 : (nch * 16 + xi + UR - 1 - 16) * ustep16, 0));
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 const int g = xi * NJ + j;  // group number inside the item: its B values are in bf[g & 1]
@@ -220,7 +227,7 @@ __global__ __launch_bounds__(256, 1) void wino_kernel(WinoArgs a) {
                     for (int l = 0; l < LPG; ++l) load(g * LPG + l, nch);
                 }
                 if (g >= T0 && g < T0 + 8 * TG && (g - T0) % TG == 0) part((g - T0) / TG, vnext);
-                const float4 av = af[xi & 3][j];
+                const float4 av = af[xi % UR][j];
                 const float4 bv = bf[g & 1];
                 if (decltype(first)::value && j == 0) {
                     const nkmma::f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -248,14 +255,15 @@ __global__ __launch_bounds__(256, 1) void wino_kernel(WinoArgs a) {
         s ^= 1;
     };
 
-    for (; pbk < npb; pbk += gridDim.x) {
+    for (; pbk < hi; pbk += step) {
         // the item after a tile block's last chunk is chunk 0 of this block's next tile block (none: every load is out of range
         // and the values land in a V buffer nobody reads)
-        if (a.nchunk == 1) patch(pbk + gridDim.x);
+        const int pnext = pbk + step < hi ? pbk + step : npb;
+        if (a.nchunk == 1) patch(pnext);
         item(std::true_type{}, 0, a.nchunk == 1 ? 0 : 1);
         for (int ch = 1; ch < a.nchunk; ++ch) {
             const bool last_ch = ch + 1 == a.nchunk;
-            if (last_ch) patch(pbk + gridDim.x);
+            if (last_ch) patch(pnext);
             item(std::false_type{}, ch, last_ch ? 0 : ch + 1);
         }
 
@@ -316,7 +324,7 @@ int wino_launch(nk_device* dev, bool bwd, const float* src, const float* w, floa
     *taken = false;
     const int mode = dev->tune_conv_winograd;  // -1 rule, 0 never, 1 whenever the shape allows
     if (mode == 0) return NK_OK;
-    const int KC = bwd ? 16 : 32, CM = bwd ? 64 : 128, PT = bwd ? 64 : 32;
+    const int KC = bwd ? 16 : 32, CM = bwd ? 64 : 128, PT = 32, NW = bwd ? 2 : 4;  // reduction chunk, channels / tiles / waves per block
     if (Hd < 2 || Wd < 2 || Hd % 2 != 0 || Wd % 2 != 0 || Ck % KC != 0 || Cm % CM != 0) return NK_OK;
     if (!al16(dst) || !al16(src)) return NK_OK;
     const long long P = (long long)N * (Hd / 2) * (Wd / 2);
@@ -343,10 +351,11 @@ int wino_launch(nk_device* dev, bool bwd, const float* src, const float* w, floa
     a.src_bytes = (int)src_bytes; a.u_bytes = (int)u_bytes; a.dst_bytes = (int)dst_bytes;
     // persistent blocks, one per CU: block b walks the tile blocks b, b + grid.x, ...
     const long long npb = (P + PT - 1) / PT;
-    const long long per_group = dev->num_cus / (Cm / CM) > 0 ? dev->num_cus / (Cm / CM) : 1;
+    const long long slots = (long long)dev->num_cus * (4 / NW);  // one wave per SIMD
+    const long long per_group = slots / (Cm / CM) > 0 ? slots / (Cm / CM) : 1;
     const dim3 grid((unsigned)(npb < per_group ? npb : per_group), (unsigned)(Cm / CM));
-    if (bwd) hipLaunchKernelGGL((wino_kernel<2, 2, 16>), grid, dim3(256), 0, dev->compute, a);
-    else hipLaunchKernelGGL((wino_kernel<4, 1, 32>), grid, dim3(256), 0, dev->compute, a);
+    if (bwd) hipLaunchKernelGGL((wino_kernel<2, 1, 16, 4>), grid, dim3(128), 0, dev->compute, a);
+    else hipLaunchKernelGGL((wino_kernel<4, 1, 32, 4>), grid, dim3(256), 0, dev->compute, a);
     NK_LAUNCH_CHECK();
     *taken = true;
     return nk_prof_stop(dev);
