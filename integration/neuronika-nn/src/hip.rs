@@ -31,18 +31,19 @@ fn uniform_parameter<D: Dimension + 'static>(dim: D, low: f32, high: f32, device
 /// Inputs a layer accepts: a device variable with or without gradient (`MatMatMulT<VarDiff<Ix2>>` bounds on
 /// `Linear::forward`, `neuronika-nn/src/lib.rs:441-447`).
 pub trait LinearInput {
-    fn linear(self, weight: HipVarDiff<Ix2>, bias: HipVarDiff<Ix1>) -> HipVarDiff<Ix2>;
+    /// `input.mm_t(weight) + bias` as ONE node on `nk_linear_fwd` (with `relu`: `.relu()` too, `nk_linear_relu_fwd`).
+    fn linear_layer(self, weight: HipVarDiff<Ix2>, bias: HipVarDiff<Ix1>, relu: bool) -> HipVarDiff<Ix2>;
 }
 
 impl LinearInput for HipVarDiff<Ix2> {
-    fn linear(self, weight: HipVarDiff<Ix2>, bias: HipVarDiff<Ix1>) -> HipVarDiff<Ix2> {
-        self.mm_t(weight) + bias
+    fn linear_layer(self, weight: HipVarDiff<Ix2>, bias: HipVarDiff<Ix1>, relu: bool) -> HipVarDiff<Ix2> {
+        self.linear(weight, bias, relu)
     }
 }
 
 impl LinearInput for HipVar<Ix2> {
-    fn linear(self, weight: HipVarDiff<Ix2>, bias: HipVarDiff<Ix1>) -> HipVarDiff<Ix2> {
-        self.mm_t_diff(weight) + bias
+    fn linear_layer(self, weight: HipVarDiff<Ix2>, bias: HipVarDiff<Ix1>, relu: bool) -> HipVarDiff<Ix2> {
+        self.linear_diff(weight, bias, relu)
     }
 }
 
@@ -62,9 +63,17 @@ impl Linear {
         }
     }
 
-    /// `input.mm_t(weight) + bias` (`:441-447`): an MFMA GEMM (`nk_mm_t_fwd`) and a broadcast addition (`nk_binary_fwd`).
+    /// `input.mm_t(weight) + bias` (`:441-447`) as ONE node: the MFMA GEMM with the bias in its epilogue (`nk_linear_fwd`);
+    /// backward one entry (`LinearBackward`: input, bias and weight gradient).  Bit-identical to the two reference nodes.
     pub fn forward<I: LinearInput>(&self, input: I) -> HipVarDiff<Ix2> {
-        input.linear(self.weight.clone(), self.bias.clone())
+        input.linear_layer(self.weight.clone(), self.bias.clone(), false)
+    }
+
+    /// `self.forward(input).relu()` (`vardiff.rs:282-288`) as ONE node (`nk_linear_relu_fwd`); the backward of a following
+    /// `Linear` writes this activation's gradient already masked (`nk_linear_bwd_input_relu`).  The explicit form of what the
+    /// C++ mirror of this repository also reaches by a graph-build peephole on `forward(x).relu()`; same bits either way.
+    pub fn forward_relu<I: LinearInput>(&self, input: I) -> HipVarDiff<Ix2> {
+        input.linear_layer(self.weight.clone(), self.bias.clone(), true)
     }
 }
 
@@ -126,11 +135,12 @@ macro_rules! conv_layer {
                 }
             }
 
-            /// pad -> convolution (`nk_conv_fwd`, implicit-GEMM on the MFMA core) -> + bias (broadcast over N and the
-            /// spatial axes).  The reference leaves the body as `todo!()` (`:712-717`).
+            /// pad -> convolution + bias as ONE node (`nk_conv_bias_fwd`: implicit GEMM or Winograd F(2x2, 3x3) on the MFMA core,
+            /// the bias in the epilogue; backward `nk_conv_bwd_input` and `nk_conv_bwd_kernel_bias`).  The reference leaves the
+            /// body as `todo!()` (`:712-717`).
             pub fn forward(&self, input: HipVarDiff<$dim>) -> HipVarDiff<$dim> {
                 let padded = input.pad(&$list(self.padding), self.padding_mode);
-                self.weight.clone().convolution(padded, &$list(self.stride), &$list(self.dilation), 1) + self.bias.clone()
+                self.weight.clone().convolution_bias(padded, self.bias.clone(), &$list(self.stride), &$list(self.dilation), 1)
             }
         }
 
@@ -164,7 +174,7 @@ macro_rules! conv_layer {
 
             pub fn forward(&self, input: HipVarDiff<$dim>) -> HipVarDiff<$dim> {
                 let padded = input.pad(&$list(self.padding), self.padding_mode);
-                self.weight.clone().convolution(padded, &$list(self.stride), &$list(self.dilation), self.groups) + self.bias.clone()
+                self.weight.clone().convolution_bias(padded, self.bias.clone(), &$list(self.stride), &$list(self.dilation), self.groups)
             }
         }
     };
@@ -184,12 +194,16 @@ conv_layer!(Conv3d, GroupedConv3d, Ix5, Ix4, (usize, usize, usize),
 
 /// Multi-head self-attention composed from reference operations (module named by `src/lib.rs:783-797`; SURVEY.md 8a note):
 /// `Q, K, V = x.mm_t(W) + b`; per (sample, head): `P = dropout(softmax(Q K^T / sqrt(dh)))`, `O = P V`; `out = O.mm_t(Wo) + bo`.
-/// Input rows are `(batch * seq, d_model)`.  The per-head chain is one node (`HipVarDiff::heads_attention`: the fused
-/// `nk_attention_fwd` / `nk_attention_bwd` kernels) reading the heads in place in the projection layout.
+/// Input rows are `(batch * seq, d_model)`.
+///
+/// The three input projections are PACKED: `qkv` is one `Linear(d_model, 3 * d_model)` whose weight rows are `[Wq; Wk; Wv]`
+/// (`q_weight()` / `k_weight()` / `v_weight()` name the row blocks for initialisation from separate matrices) - one GEMM with
+/// N = 3 d forward and one with K = 3 d for the input gradient instead of three each - and the per-head chain is one node
+/// reading queries, keys and values in place as the column blocks of that projection (`HipVarDiff::packed_heads_attention`:
+/// `nk_attention_qkv_fwd` / `nk_attention_qkv_bwd`).  Head sizes the fused core does not cover
+/// (`ffi::nk_attention_supported`: dh in {32, 64, 128}) are rejected at construction.
 pub struct MultiheadAttention {
-    pub q: Linear,
-    pub k: Linear,
-    pub v: Linear,
+    pub qkv: Linear,
     pub o: Linear,
     pub d_model: usize,
     pub heads: usize,
@@ -199,15 +213,23 @@ pub struct MultiheadAttention {
 impl MultiheadAttention {
     pub fn new(d_model: usize, heads: usize, p: f64, device: &Device) -> Self {
         assert!(heads > 0 && d_model % heads == 0, "d_model must be divisible by heads");
-        Self {
-            q: Linear::new(d_model, d_model, device),
-            k: Linear::new(d_model, d_model, device),
-            v: Linear::new(d_model, d_model, device),
-            o: Linear::new(d_model, d_model, device),
-            d_model,
-            heads,
-            dropout: Dropout::new(p),
-        }
+        assert!(matches!(d_model / heads, 32 | 64 | 128), "MultiheadAttention: head size must be 32, 64 or 128");
+        // each of the three row blocks is initialised as its own Linear(d_model, d_model): U(-k, k), k = 1 / sqrt(d_model) -
+        // the fan-in of the packed layer is d_model too, so one draw over (3 d, d) follows the same law
+        Self { qkv: Linear::new(d_model, 3 * d_model, device), o: Linear::new(d_model, d_model, device), d_model, heads, dropout: Dropout::new(p) }
+    }
+
+    /// Row range of the packed weight (and element range of the packed bias) holding the query / key / value projection.
+    pub fn q_rows(&self) -> std::ops::Range<usize> {
+        0..self.d_model
+    }
+
+    pub fn k_rows(&self) -> std::ops::Range<usize> {
+        self.d_model..2 * self.d_model
+    }
+
+    pub fn v_rows(&self) -> std::ops::Range<usize> {
+        2 * self.d_model..3 * self.d_model
     }
 
     /// `input`: `(batch * seq, d_model)`, rows of a sample contiguous.
@@ -216,8 +238,8 @@ impl MultiheadAttention {
         assert!(batch > 0 && rows % batch == 0, "MultiheadAttention: rows must be a multiple of batch");
         let (seq, dh) = (rows / batch, self.d_model / self.heads);
         let scale = 1. / (dh as f32).sqrt();
-        let (queries, keys, values) = (self.q.forward(input.clone()), self.k.forward(input.clone()), self.v.forward(input));
-        let context = queries.heads_attention(keys, values, batch, seq, self.heads, dh, scale, self.dropout.p, self.dropout.status.clone());
+        let packed = self.qkv.forward(input);
+        let context = packed.packed_heads_attention(batch, seq, self.heads, dh, scale, self.dropout.p, self.dropout.status.clone());
         self.o.forward(context)
     }
 }

@@ -8,7 +8,7 @@ use std::{
     rc::Rc,
 };
 
-use ndarray::{DimMax, Dimension, IntoDimension, Ix0, Ix2, Ix3, RemoveAxis};
+use ndarray::{DimMax, Dimension, IntoDimension, Ix0, Ix1, Ix2, Ix3, RemoveAxis};
 
 use super::{
     device::Device,
@@ -16,10 +16,11 @@ use super::{
     hiparray::HipArray,
     node::{
         AttentionState, BinaryOp, BinaryOperation, BinaryOperationBackwardLeft, BinaryOperationBackwardRight, Chunk, ChunkBackward,
-        Convolution, ConvolutionBackwardInput, ConvolutionBackwardKernel, Dropout, DropoutBackward, Heads, HeadsAttention,
-        HeadsAttentionBackward, LogSoftmax, LogSoftmaxBackward, MatrixMatrixMul, MatrixMatrixMulBackwardLeft,
+        Convolution, ConvolutionBackwardInput, ConvolutionBackwardKernel, ConvolutionBackwardKernelBias, ConvolutionBias, Dropout,
+        DropoutBackward, Heads, HeadsAttention, HeadsAttentionBackward, Linear, LinearBackward, LogSoftmax, LogSoftmaxBackward, MatrixMatrixMul, MatrixMatrixMulBackwardLeft,
         MatrixMatrixMulBackwardRight, MatrixMatrixMulT, MatrixMatrixMulTBackwardLeft, MatrixMatrixMulTBackwardRight, Mean, MeanBackward,
-        MultiConcatenate, MultiConcatenateBackward, Pad, PadBackward, PadMode, Pair, ReLU, ReLUBackward, Softmax, SoftmaxBackward,
+        MultiConcatenate, MultiConcatenateBackward, PackedHeadsAttention, PackedHeadsAttentionBackward, Pad, PadBackward, PadMode, Pair, ReLU,
+        ReLUBackward, ReluMask, Softmax, SoftmaxBackward,
         SquaredError, SquaredErrorBackward, Sum, SumBackward, Transpose, TransposeBackward,
     },
 };
@@ -118,7 +119,7 @@ where
     /// Promotes to a differentiable leaf (`Var::requires_grad`, `var.rs:138-148`).
     pub fn requires_grad(self) -> HipVarDiff<D> {
         let (dim, device) = (self.data.borrow().dimension(), self.device());
-        HipVarDiff { var: self, grad: Rc::new(Gradient::hip_zeros(dim, device)), history: History::default() }
+        HipVarDiff { var: self, grad: Rc::new(Gradient::hip_zeros(dim, device)), history: History::default(), relu_mask: None }
     }
 
     /// `Var::forward` (`var.rs:110-128`), verbatim logic: the ops are enqueued on the device's compute stream in
@@ -290,6 +291,32 @@ where
     }
 }
 
+impl<D> HipVar<D>
+where
+    D: 'static + Dimension + RemoveAxis,
+{
+    /// `convolution` followed by the broadcast `+ bias` of the `nn::Conv*` layers as ONE forward node (`nk_conv_bias_fwd`: the
+    /// bias in the epilogue that writes the output).  `bias` has the layer's shape `(out_channels, 1, ..)`.
+    pub fn convolution_bias<B>(mut self, input: HipVar<D>, bias: HipVar<B>, stride: &[usize], dilation: &[usize], groups: usize) -> HipVar<D>
+    where
+        B: 'static + Dimension,
+    {
+        self.history.merge(input.history);
+        self.history.merge(bias.history);
+        let shape: D = {
+            let (x, w) = (input.data.borrow(), self.data.borrow());
+            let (xs, ws): (Vec<usize>, Vec<usize>) = (x.dimension().slice().to_vec(), w.dimension().slice().to_vec());
+            check_conv_args(&xs, &ws, stride, dilation);
+            check_groups_args(&xs, &ws, groups);
+            conv_out_shape(&xs, &ws, stride, dilation)
+        };
+        let data = shared(shape, &self.device());
+        let to_i32 = |v: &[usize]| v.iter().map(|&s| s as i32).collect::<Vec<_>>();
+        let op = ConvolutionBias::new(input.data, self.data, bias.data, data.clone(), to_i32(stride), to_i32(dilation), groups as i32);
+        HipVar::node(data, Rc::new(op), self.history)
+    }
+}
+
 impl HipVar<Ix2> {
     /// `Var::mm` (`var.rs:1034-1061`).
     pub fn mm(mut self, rhs: HipVar<Ix2>) -> HipVar<Ix2> {
@@ -323,6 +350,36 @@ impl HipVar<Ix2> {
     }
 }
 
+impl HipVar<Ix2> {
+    /// `nn::Linear::forward` (`neuronika-nn/src/lib.rs:441-447`: `input.mm_t(weight) + bias`) as ONE forward node -
+    /// `nk_linear_fwd`, the bias in the GEMM epilogue - and, with `relu`, the `.relu()` that follows it in the reference's
+    /// words (`vardiff.rs:282-288`) in the same epilogue (`nk_linear_relu_fwd`).  Bit-identical to the separate nodes.
+    pub fn linear(mut self, weight: HipVar<Ix2>, bias: HipVar<Ix1>, relu: bool) -> HipVar<Ix2> {
+        self.history.merge(weight.history);
+        self.history.merge(bias.history);
+        let (n, o) = (self.data.borrow().dimension()[0], weight.data.borrow().dimension()[0]);
+        let data = shared(ndarray::Dim([n, o]), &self.device());
+        let op = Linear::new(self.data, weight.data, bias.data, data.clone(), relu);
+        HipVar::node(data, Rc::new(op), self.history)
+    }
+
+    /// The same layer over an input WITHOUT gradient (the first layer of C4: its input-gradient GEMM is never issued, as in
+    /// `Var::mm_t(VarDiff)`, `var.rs:1081-1094`).
+    pub fn linear_diff(self, weight: HipVarDiff<Ix2>, bias: HipVarDiff<Ix1>, relu: bool) -> HipVarDiff<Ix2> {
+        let (input_data, weight_data) = (self.data.clone(), weight.var.data.clone());
+        let mut history = weight.history;
+        history.merge(bias.history);
+        let var = self.linear(weight.var, bias.var, relu);
+        let grad = Rc::new(Gradient::hip_zeros(var.data.borrow().dimension(), var.device()));
+        let mask = if relu { Some(Rc::new(ReluMask::new(var.data.clone()))) } else { None };
+        let op: Rc<dyn Backward> = Rc::new(LinearBackward::new(input_data, weight_data, mask.clone(), None, None, weight.grad.clone(),
+                                                               bias.grad.clone(), grad.clone()));
+        let mut out = HipVarDiff::node(var, grad.clone(), (op, grad), history);
+        out.relu_mask = mask;
+        out
+    }
+}
+
 /// A differentiable variable with data and gradient in HBM (`VarDiff<D>`, `vardiff.rs:35-42`).
 pub struct HipVarDiff<D>
 where
@@ -331,11 +388,14 @@ where
     pub(crate) var: HipVar<D>,
     pub(crate) grad: Rc<Gradient<HipArray<D>, D>>,
     pub(crate) history: Bwd,
+    /// Set on the output of a fused Linear+ReLU node (`linear(.., relu = true)`): the mask record a following `linear` hands to
+    /// its backward node, so that the input gradient can be written pre-masked (`nk_linear_bwd_input_relu`).
+    pub(crate) relu_mask: Option<Rc<ReluMask>>,
 }
 
 impl<D: Dimension> Clone for HipVarDiff<D> {
     fn clone(&self) -> Self {
-        Self { var: self.var.clone(), grad: self.grad.clone(), history: self.history.clone() }
+        Self { var: self.var.clone(), grad: self.grad.clone(), history: self.history.clone(), relu_mask: self.relu_mask.clone() }
     }
 }
 
@@ -345,7 +405,7 @@ where
 {
     pub(crate) fn node(var: HipVar<D>, grad: Rc<Gradient<HipArray<D>, D>>, op: (Rc<dyn Backward>, Rc<dyn NoGrad>), mut history: Bwd) -> Self {
         history.insert(Rc::as_ptr(&op.0) as *const () as usize, op);
-        Self { var, grad, history }
+        Self { var, grad, history, relu_mask: None }
     }
 
     fn new_grad<E: Dimension>(&self, dim: E) -> Rc<Gradient<HipArray<E>, E>> {
@@ -366,7 +426,27 @@ where
         if buffer.is_empty() {
             *buffer = self.history.to_vec();
         }
+        Self::decide_premasking(&buffer);
         buffer.iter().rev().for_each(|(op, _)| op.backward());
+    }
+
+    /// Per pass, for every fused Linear+ReLU node on the tape: its output gradient may be stored PRE-MASKED (`(y > 0) *` applied
+    /// in the writer's GEMM epilogue, no ReLU-backward kernel) iff every node that accumulates into that gradient can mask
+    /// while storing (`Backward::premask_targets`); one plain writer (a second consumer of the activation) and the node masks
+    /// a scratch copy instead.  The rule `VarDiff::run_backward` applies in this repository's C++ tape (`host/neuronika.cpp`).
+    fn decide_premasking(buffer: &[(Rc<dyn Backward>, Rc<dyn NoGrad>)]) {
+        for (op, _) in buffer.iter() {
+            if let Some((id, mask)) = op.masked_gradient() {
+                let writers = buffer.iter().filter(|(w, _)| w.targets().contains(&id));
+                let mut all_mask = true;
+                let mut any = false;
+                for (w, _) in writers {
+                    any = true;
+                    all_mask &= w.premask_targets().contains(&id);
+                }
+                mask.premasked.set(any && all_mask);
+            }
+        }
     }
 
     /// The data-parallel form of `backward` (`vardiff.rs:125-141` with the exchange of `hip/dp.rs` inserted): seeds the root
@@ -382,6 +462,7 @@ where
         if buffer.is_empty() {
             *buffer = self.history.to_vec();
         }
+        Self::decide_premasking(&buffer);
         // execution order is the reverse of the tape: the LAST writer of a gradient is the entry with the smallest index
         let mut last_writer: std::collections::HashMap<usize, usize> = std::collections::HashMap::new();
         for (index, (op, _)) in buffer.iter().enumerate() {
@@ -585,6 +666,32 @@ where
     }
 }
 
+impl<D> HipVarDiff<D>
+where
+    D: 'static + Dimension + RemoveAxis,
+{
+    /// `convolution(..) + bias` of the `nn::Conv*` layers with kernel, input and bias differentiable: one forward node
+    /// (`HipVar::convolution_bias`), and as one tape entry `ConvolutionBackwardInput` + `ConvolutionBackwardKernelBias` (the bias
+    /// gradient summed on the way through the kernel-gradient pass - no second read of the output gradient).
+    pub fn convolution_bias<B>(mut self, input: HipVarDiff<D>, bias: HipVarDiff<B>, stride: &[usize], dilation: &[usize],
+                               groups: usize) -> HipVarDiff<D>
+    where
+        B: 'static + Dimension,
+    {
+        self.history.merge(input.history);
+        self.history.merge(bias.history);
+        let (input_data, kernel_data) = (input.var.data.clone(), self.var.data.clone());
+        let var = self.var.convolution_bias(input.var, bias.var, stride, dilation, groups);
+        let grad = Rc::new(Gradient::hip_zeros(var.data.borrow().dimension(), var.device()));
+        let to_i32 = |v: &[usize]| v.iter().map(|&s| s as i32).collect::<Vec<_>>();
+        let bwd_input = ConvolutionBackwardInput::new(kernel_data, input.grad.clone(), grad.clone(), to_i32(stride), to_i32(dilation), groups as i32);
+        let bwd_kernel = ConvolutionBackwardKernelBias::new(input_data, self.grad.clone(), bias.grad.clone(), grad.clone(), to_i32(stride),
+                                                            to_i32(dilation), groups as i32);
+        let node: Rc<dyn Backward> = Rc::new(Pair(bwd_input, bwd_kernel));
+        HipVarDiff::node(var, grad.clone(), (node, grad), self.history)
+    }
+}
+
 impl HipVarDiff<Ix2> {
     /// `mm` (`vardiff.rs:1073-1106`).
     pub fn mm(mut self, rhs: HipVarDiff<Ix2>) -> HipVarDiff<Ix2> {
@@ -607,6 +714,46 @@ impl HipVarDiff<Ix2> {
         let left = MatrixMatrixMulTBackwardLeft::new(right_data, self.grad.clone(), grad.clone());
         let right = MatrixMatrixMulTBackwardRight::new(left_data, rhs.grad.clone(), grad.clone());
         let op: Rc<dyn Backward> = Rc::new(MatrixMatrixMulTBackward::new(left, right));
+        HipVarDiff::node(var, grad.clone(), (op, grad), self.history)
+    }
+
+    /// `nn::Linear::forward` over a differentiable input: ONE forward node (`HipVar::linear`) and ONE backward entry
+    /// (`LinearBackward`: input gradient, bias gradient, weight gradient).  When `self` is itself the output of a
+    /// Linear+ReLU node, its mask record travels into the backward node: the input gradient is then written through
+    /// `nk_linear_bwd_input_relu` whenever the pass allows (`decide_premasking`) - the C4 graph runs without a single ReLU kernel.
+    pub fn linear(mut self, weight: HipVarDiff<Ix2>, bias: HipVarDiff<Ix1>, relu: bool) -> HipVarDiff<Ix2> {
+        self.history.merge(weight.history);
+        self.history.merge(bias.history);
+        let (input_data, weight_data) = (self.var.data.clone(), weight.var.data.clone());
+        let var = self.var.linear(weight.var, bias.var, relu);
+        let grad = Rc::new(Gradient::hip_zeros(var.data.borrow().dimension(), var.device()));
+        let mask = if relu { Some(Rc::new(ReluMask::new(var.data.clone()))) } else { None };
+        let op: Rc<dyn Backward> = Rc::new(LinearBackward::new(input_data, weight_data, mask.clone(), self.relu_mask.clone(),
+                                                               Some(self.grad.clone()), weight.grad.clone(), bias.grad.clone(), grad.clone()));
+        let mut out = HipVarDiff::node(var, grad.clone(), (op, grad), self.history);
+        out.relu_mask = mask;
+        out
+    }
+
+    /// `heads_attention` for PACKED projections: `self` is the `(batch*seq, 3*heads*dh)` output of one `Linear` over the
+    /// row-stacked weights `[Wq; Wk; Wv]`; queries, keys and values are read in place as its three column blocks
+    /// (`nk_attention_qkv_fwd` / `nk_attention_qkv_bwd`).  Output `(batch*seq, heads*dh)`.
+    #[allow(clippy::too_many_arguments)]
+    pub fn packed_heads_attention(self, batch: usize, seq: usize, heads: usize, dh: usize, scale: f32, p: f64,
+                                  status: Rc<Cell<bool>>) -> HipVarDiff<Ix2> {
+        let device = self.var.data.borrow().device().clone();
+        let geometry = Heads { batch: batch as i32, seq: seq as i32, heads: heads as i32, dh: dh as i32 };
+        let sp = (seq + 31) / 32 * 32;
+        let big = |last: usize| shared(ndarray::Dim([batch * heads, sp, last]), &device);
+        let state = Rc::new(AttentionState { scores: big(sp), stats: big(2), mask_bits: big(sp / 32), calls: Cell::new(0) });
+        let dim = ndarray::Dim([batch * seq, heads * dh]);
+        let data = shared(dim, &device);
+        let fwd = PackedHeadsAttention::new(geometry, self.var.data.clone(), state.clone(), data.clone(), scale, p, status.clone(), next_seed());
+        let var = HipVar::node(data.clone(), Rc::new(fwd), self.var.history);
+        let grad = Rc::new(Gradient::hip_zeros(dim, device));
+        let bwd = PackedHeadsAttentionBackward::new(geometry, self.var.data, data, state, big(sp), big(sp), self.grad, grad.clone(), scale, p,
+                                                    status);
+        let op: Rc<dyn Backward> = Rc::new(bwd);
         HipVarDiff::node(var, grad.clone(), (op, grad), self.history)
     }
 

@@ -6,10 +6,12 @@ mod ffi;
 mod hiparray;
 mod hipvar;
 mod node;
+mod optimizer;
 
 pub use {
     device::Device,
     dp::{Communicator, GradientSync, SyncEntry},
     hiparray::HipArray,
     hipvar::{manual_seed, HipVar, HipVarDiff, PaddingMode},
+    optimizer::SGD,
 };

@@ -135,3 +135,91 @@ impl Backward for HeadsAttentionBackward {
         vec![grad_id(&self.queries_gradient), grad_id(&self.keys_gradient), grad_id(&self.values_gradient)]
     }
 }
+
+/// The same node for `nn::MultiheadAttention`'s PACKED projections: queries, keys and values are the three column blocks of
+/// ONE `(batch*seq, 3*heads*dh)` matrix - the output of a single `Linear` over the row-stacked weights `[Wq; Wk; Wv]` (one
+/// GEMM with N = 3 d forward, one with K = 3 d for the input gradient, instead of three each): `nk_attention_qkv_fwd`.
+pub(crate) struct PackedHeadsAttention {
+    geometry: Heads,
+    packed: Shared<HipArray<Ix2>>,
+    state: Rc<AttentionState>,
+    data: Shared<HipArray<Ix2>>,
+    scale: f32,
+    p: f64,
+    status: Rc<Cell<bool>>,
+    seed: u64,
+}
+
+impl PackedHeadsAttention {
+    #[allow(clippy::too_many_arguments)]
+    pub(crate) fn new(geometry: Heads, packed: Shared<HipArray<Ix2>>, state: Rc<AttentionState>, data: Shared<HipArray<Ix2>>, scale: f32,
+                      p: f64, status: Rc<Cell<bool>>, seed: u64) -> Self {
+        if !(0. ..=1.).contains(&p) {
+            panic!("Wrong probability received: {}.", p);
+        }
+        Self { geometry, packed, state, data, scale, p, status, seed }
+    }
+}
+
+impl Forward for PackedHeadsAttention {
+    fn forward(&self) {
+        let qkv = self.packed.borrow();
+        let (mut scores, mut stats, mut bits) = (self.state.scores.borrow_mut(), self.state.stats.borrow_mut(), self.state.mask_bits.borrow_mut());
+        let mut out = self.data.borrow_mut();
+        let h = self.geometry;
+        let sp = ((h.seq as u64) + 31) / 32 * 32;
+        let elems = (h.batch as u64) * (h.heads as u64) * sp * sp;
+        let offset = self.state.calls.get() * ((elems + 7) / 8);
+        ffi::check(unsafe {
+            ffi::nk_attention_qkv_fwd(qkv.device().as_raw(), qkv.as_ptr(), scores.as_mut_ptr(), stats.as_mut_ptr(), bits.as_mut_ptr() as *mut u32,
+                                      out.as_mut_ptr(), h.batch, h.seq, h.heads, h.dh, self.scale, self.p, self.status.get() as i32, self.seed,
+                                      offset)
+        });
+        self.state.calls.set(self.state.calls.get() + 1);
+    }
+}
+
+/// Backward of the packed node: ONE call, `nk_attention_qkv_bwd`, accumulating into the three column blocks of the packed
+/// projection's gradient.
+pub(crate) struct PackedHeadsAttentionBackward {
+    geometry: Heads,
+    packed: Shared<HipArray<Ix2>>,
+    output: Shared<HipArray<Ix2>>,
+    state: Rc<AttentionState>,
+    d_scores: Shared<HipArray<Ix3>>, // scratch written here
+    dropped: Shared<HipArray<Ix3>>,  // scratch written here
+    packed_gradient: Rc<Gradient<HipArray<Ix2>, Ix2>>,
+    gradient: Rc<Gradient<HipArray<Ix2>, Ix2>>,
+    scale: f32,
+    p: f64,
+    status: Rc<Cell<bool>>,
+}
+
+impl PackedHeadsAttentionBackward {
+    #[allow(clippy::too_many_arguments)]
+    pub(crate) fn new(geometry: Heads, packed: Shared<HipArray<Ix2>>, output: Shared<HipArray<Ix2>>, state: Rc<AttentionState>,
+                      d_scores: Shared<HipArray<Ix3>>, dropped: Shared<HipArray<Ix3>>, packed_gradient: Rc<Gradient<HipArray<Ix2>, Ix2>>,
+                      gradient: Rc<Gradient<HipArray<Ix2>, Ix2>>, scale: f32, p: f64, status: Rc<Cell<bool>>) -> Self {
+        Self { geometry, packed, output, state, d_scores, dropped, packed_gradient, gradient, scale, p, status }
+    }
+}
+
+impl Backward for PackedHeadsAttentionBackward {
+    fn backward(&self) {
+        let g = self.gradient.borrow();
+        let (qkv, o) = (self.packed.borrow(), self.output.borrow());
+        let (scores, stats, bits) = (self.state.scores.borrow(), self.state.stats.borrow(), self.state.mask_bits.borrow());
+        let (mut ds, mut pd) = (self.d_scores.borrow_mut(), self.dropped.borrow_mut());
+        let h = self.geometry;
+        let mut dqkv = self.packed_gradient.borrow_mut();
+        ffi::check(unsafe {
+            ffi::nk_attention_qkv_bwd(g.device().as_raw(), dqkv.as_mut_ptr(), ds.as_mut_ptr(), pd.as_mut_ptr(), g.as_ptr(), o.as_ptr(),
+                                      scores.as_ptr(), stats.as_ptr(), bits.as_ptr() as *const u32, qkv.as_ptr(), h.batch, h.seq, h.heads, h.dh,
+                                      self.scale, self.p, self.status.get() as i32, 0)
+        });
+    }
+
+    fn targets(&self) -> Vec<usize> {
+        vec![grad_id(&self.packed_gradient)]
+    }
+}

@@ -8,6 +8,7 @@ mod attention;
 mod binary_op;
 mod convolution;
 mod layout;
+mod linear;
 mod matrix_matrix_mul;
 mod matrix_matrix_mul_t;
 mod optim;
@@ -18,6 +19,7 @@ pub(crate) use attention::*;
 pub(crate) use binary_op::*;
 pub(crate) use convolution::*;
 pub(crate) use layout::*;
+pub(crate) use linear::*;
 pub(crate) use matrix_matrix_mul::*;
 pub(crate) use matrix_matrix_mul_t::*;
 pub(crate) use optim::*;
@@ -46,6 +48,12 @@ impl<L: Backward, R: Backward> Backward for Pair<L, R> {
     fn targets(&self) -> Vec<usize> {
         let mut t = self.0.targets();
         t.extend(self.1.targets());
+        t
+    }
+
+    fn premask_targets(&self) -> Vec<usize> {
+        let mut t = self.0.premask_targets();
+        t.extend(self.1.premask_targets());
         t
     }
 }

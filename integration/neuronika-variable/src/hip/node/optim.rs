@@ -26,3 +26,23 @@ pub(crate) fn adam_step<D: Dimension>(w: &mut HipArray<D>, grad: &mut HipArray<D
                           lr, beta1, beta2, eps, step, l1, l2)
     });
 }
+
+/// `Optimizer::step` (`neuronika-optim/src/optimizer.rs:81-86`) for SGD over ALL registered parameters as ONE launch
+/// (`nk_sgd_step_multi`): the per-parameter updates are independent, element for element the arithmetic of `sgd_step`.
+/// `params`: (weights, gradient, velocity) raw buffers and element counts, collected by the optimizer from its
+/// `SGDParam`s (`sgd/mod.rs:186-236`); a parameter registered twice is updated once (the launch's updates run concurrently).
+#[allow(clippy::too_many_arguments)]
+pub(crate) fn sgd_step_multi(device: &crate::hip::device::Device, params: &[(*mut f32, *mut f32, *mut f32, usize)], lr: f32, momentum: f32,
+                             dampening: f32, nesterov: bool, l1: f32, l2: f32) {
+    let mut seen = std::collections::HashSet::new();
+    let unique: Vec<&(*mut f32, *mut f32, *mut f32, usize)> = params.iter().filter(|p| seen.insert(p.0 as usize)).collect();
+    let w: Vec<*mut f32> = unique.iter().map(|p| p.0).collect();
+    let g: Vec<*mut f32> = unique.iter().map(|p| p.1).collect();
+    let v: Vec<*mut f32> = unique.iter().map(|p| p.2).collect();
+    let n: Vec<usize> = unique.iter().map(|p| p.3).collect();
+    let velocity = if momentum != 0. { v.as_ptr() } else { std::ptr::null() };
+    ffi::check(unsafe {
+        ffi::nk_sgd_step_multi(device.as_raw(), w.len() as i32, w.as_ptr(), g.as_ptr(), velocity, n.as_ptr(), lr, momentum, dampening,
+                               nesterov as i32, l1, l2)
+    });
+}

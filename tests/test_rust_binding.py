@@ -90,6 +90,12 @@ REQUIRED = {
     "mse": ["nk_mse_fwd", "nk_mse_bwd"], "pad_with": ["nk_pad_const_fwd", "nk_pad_reflective_fwd", "nk_pad_replicative_fwd", "nk_pad_bwd"],
     "chunks": ["nk_chunk_fwd", "nk_chunk_bwd"], "cat": ["nk_concat_fwd_part", "nk_concat_bwd_part"],
     "t": ["nk_transpose_fwd", "nk_transpose_bwd"], "heads_attention": ["nk_attention_fwd", "nk_attention_bwd"],
+    # the fused entries the driver's numbers are measured on (VERDICT round 4, next #2b): what `neuronika_nn::hip`'s layers call
+    "linear": ["nk_linear_fwd", "nk_linear_relu_fwd", "nk_linear_bwd_input_relu", "nk_mm_t_bwd_left", "nk_mm_t_bwd_right", "nk_unbroadcast_add",
+               "nk_relu_bwd_assign"],
+    "linear_diff": ["nk_linear_fwd", "nk_linear_relu_fwd", "nk_mm_t_bwd_right", "nk_unbroadcast_add"],
+    "convolution_bias": ["nk_conv_bias_fwd", "nk_conv_bwd_input", "nk_conv_bwd_kernel_bias"],
+    "packed_heads_attention": ["nk_attention_qkv_fwd", "nk_attention_qkv_bwd"],
 }
 
 
@@ -116,7 +122,7 @@ def _rust_nodes():
         if not f.endswith(".rs") or f == "mod.rs":
             continue
         src = open(os.path.join(node_dir, f)).read()
-        for m in re.finditer(r"pub\(crate\) struct (\w+)", src):
+        for m in re.finditer(r"pub(?:\(crate\))? struct (\w+)", src):
             nodes.setdefault(m.group(1), [None, set()])
         for m in re.finditer(r"impl(?:<[^{]*?>)? (\w+)(?:<[^{]*?>)?\s*(?:where[^{]*)?\{\s*(?:///[^\n]*\n\s*)*(?:#\[[^\]]*\]\s*)*pub\(crate\) fn new\(", src):
             i, depth = m.end(), 1
@@ -367,12 +373,16 @@ def test_nn_layers_exist_and_call_variable_methods_that_exist():
     assert order, "Conv*::new argument order (neuronika-nn/src/lib.rs:671-679)"
     assert re.search(r"pub weight: HipVarDiff<Ix2>,\s*pub bias: HipVarDiff<Ix1>", src)             # Linear fields, :406-409
     methods = _pub_methods(os.path.join(HIP, "hipvar.rs"))
-    used = {"mm_t": 1, "mm_t_diff": 1, "pad": 2, "convolution": 4, "dropout": 2, "heads_attention": 9, "shape": 0, "parameter": 2}
+    # the layers are built from the FUSED variable methods: Linear = one node (nk_linear_fwd / nk_linear_relu_fwd), Conv* = one node with
+    # the bias (nk_conv_bias_fwd / nk_conv_bwd_kernel_bias), MultiheadAttention = packed projections + nk_attention_qkv_*
+    used = {"linear": 3, "linear_diff": 3, "pad": 2, "convolution_bias": 5, "dropout": 2, "packed_heads_attention": 7, "shape": 0, "parameter": 2}
+    for slow in ("mm_t", "mm_t_diff", "convolution", "heads_attention"):                       # ... and from nothing slower
+        assert not re.search(r"\.%s\(" % slow, src), slow
     for name, nargs in used.items():
         assert re.search(r"[.:]%s\(" % name, src), name
         assert name in methods and nargs in methods[name], (name, methods.get(name))
     # call sites pass that many arguments
-    for m in re.finditer(r"\.(mm_t|mm_t_diff|pad|convolution|dropout|heads_attention)\(", src):
+    for m in re.finditer(r"\.(linear|linear_diff|pad|convolution_bias|dropout|packed_heads_attention)\(", src):
         i, depth = m.end(), 1
         while depth:
             depth += {"(": 1, ")": -1}.get(src[i], 0)
@@ -407,3 +417,20 @@ def test_backward_sync_overlaps_the_exchange():
     assert "fn targets(&self) -> Vec<usize>" in ext and "Vec::new()" in ext       # defaulted: CPU nodes compile unchanged
     dp = _strip(open(os.path.join(HIP, "dp.rs")).read())
     assert "pub(crate) fn bucket_of(" in dp and "pub struct SyncEntry" in dp
+
+
+def test_optimizer_step_is_the_multi_tensor_launch():
+    """VERDICT round 4, next #2b: the Rust optimizer updates every registered parameter with ONE launch (`nk_sgd_step_multi`, what
+    the driver's C4 step is measured with), not one `nk_sgd_step` per parameter."""
+    opt = _strip(open(os.path.join(HIP, "optimizer.rs")).read())
+    step = opt[opt.index("pub fn step("):]
+    step = step[:step.index("\n    }") + 6]
+    assert "sgd_step_multi(" in step and "nk_sgd_step(" not in opt
+    node = _strip(open(os.path.join(HIP, "node", "optim.rs")).read())
+    body = node[node.index("fn sgd_step_multi"):]
+    assert "ffi::nk_sgd_step_multi(" in body
+    assert "seen.insert" in body                          # a parameter registered twice is updated once (ADVICE round 4)
+    mod = open(os.path.join(HIP, "mod.rs")).read()
+    assert "mod optimizer;" in mod and "optimizer::SGD" in mod
+    for name in ("register", "step", "zero_grad", "with_momentum"):      # neuronika-optim/src/optimizer.rs:60-94, sgd/mod.rs:62-110
+        assert re.search(r"pub fn %s[(<]" % name, opt), name
