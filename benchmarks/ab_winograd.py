@@ -39,6 +39,16 @@ def main():
 
     for _ in range(30):                              # clocks
         calls["forward + bias"]()
+    if len(sys.argv) > 2 and sys.argv[2] == "stagger":   # the staggered start: off, the rule, explicit units (shader clocks)
+        for rnd in range(2):
+            for name, fn in calls.items():
+                row = {"round": rnd, "pass": name, "N": N}
+                for st in (0, -1, 4000, 6000, 12000, 16000):
+                    dev.conv_winograd(1, st)
+                    row["stagger_%s_us" % ("rule" if st < 0 else st)] = round(time(fn), 1)
+                dev.conv_winograd(None)
+                print(json.dumps(row), flush=True)
+        return
     for rnd in range(3):
         for name, fn in calls.items():
             row = {"round": rnd, "pass": name, "N": N}

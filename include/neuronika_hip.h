@@ -80,7 +80,9 @@ const char* nk_version(void);
  *                          column tile through 64-wide blocks), a narrow block's k-tile priced at that percentage of a wide one's;
  *                          n = 0: the measured rules (65 % with 128-row tiles, 80 % with 64-row tiles)
  *   NK_TUNE_CONV_WINOGRAD  values[0] = -1 rule / 0 the 3x3 stride-1 forward and input gradient never take the Winograd F(2x2, 3x3)
- *                          kernels (implicit GEMM as in rounds 1 - 4) / 1 whenever the shape allows (also below the block-count rule)
+ *                          kernels (implicit GEMM as in rounds 1 - 4) / 1 whenever the shape allows (also below the block-count rule);
+ *                          values[1] (optional) = -1 rule / 0 no staggered start of its persistent blocks / > 0 the stagger unit in
+ *                          shader clocks (blocks one tile block short of the longest walk start 1 - 3 units late)
  * For schedule sweeps (benchmarks/ab_*.py) and the tests that pit one schedule against another bit for bit; results never
  * depend on them beyond summation order (split-K). */
 enum { NK_TUNE_GEMM_FORCE = 0, NK_TUNE_GEMM_KPAIR = 1, NK_TUNE_ATTENTION_OCC = 2, NK_TUNE_GEMM_PAIR = 3, NK_TUNE_CONV_NARROW = 4,

@@ -301,8 +301,8 @@ class Device:
     def conv_narrow(self, cost=None):
         self.tune(TUNE_CONV_NARROW, cost)
 
-    def conv_winograd(self, mode=None):
-        self.tune(TUNE_CONV_WINOGRAD, mode)
+    def conv_winograd(self, mode=None, stagger=None):
+        self.tune(TUNE_CONV_WINOGRAD, mode if stagger is None else [-1 if mode is None else mode, stagger])
 
     def busy_slots(self, n: int = 0):
         """nk_device_set_busy_slots: `n` resident-block slots are held by work on another stream (an exchange in flight)."""

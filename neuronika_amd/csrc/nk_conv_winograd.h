@@ -34,6 +34,7 @@ struct WinoArgs {
     int nchunk;         // Ck / KC
     int assign;         // 1: dst = value, 0: dst += value
     int src_bytes, u_bytes, dst_bytes;  // the buffer descriptors' extents (all below 2^31)
+    int stagger;        // unit of the staggered start in shader clocks (0: none)
 };
 
 // U in MFMA A-operand order.  For chunk ch (KC reduction channels), xi, block of 32 output channels cbt: a wave's fragment is
@@ -184,6 +185,17 @@ __global__ __launch_bounds__(64 * CB * PB, 1) void wino_kernel(WinoArgs a) {
     const int range = (npb + nx - 1) / nx, lo = (int)(blockIdx.x % nx) * range, hi = lo + range < npb ? lo + range : npb;
     int pbk = lo + (int)(blockIdx.x / nx);
     if (pbk >= hi) return;
+    // Blocks all take the same time per tile block, so the whole chip would reach its output phases together: bursts of stores
+    // (16 MB at C3) that the next tile block's first U waits sit behind (loads and stores complete in order).  The tile blocks do
+    // not divide evenly among the blocks; those with one tile block fewer than the longest walk start one, two or three units of
+    // `stagger` shader clocks late - nobody finishes later than the longest walk, and the output phases are spread out.
+    if (a.stagger > 0) {
+        const int lb = (int)(blockIdx.x / nx), mine = (hi - lo - lb + step - 1) / step, most = (hi - lo + step - 1) / step;
+        if (mine < most) {
+            const long long until = (long long)a.stagger * (1 + lb % 3), t0 = (long long)__builtin_readcyclecounter();
+            while ((long long)__builtin_readcyclecounter() - t0 < until) __builtin_amdgcn_s_sleep(64);
+        }
+    }
     // ---- prologue: item (pbk, chunk 0) into V[0], the matrix pipe idle
     patch(pbk);
 #pragma unroll
@@ -348,6 +360,9 @@ int wino_launch(nk_device* dev, bool bwd, const float* src, const float* w, floa
     a.Hs = Hs; a.Ws = Ws; a.Hd = Hd; a.Wd = Wd; a.offy = offy; a.offx = offx;
     a.TY = Hd / 2; a.TX = Wd / 2; a.P = P;
     a.nchunk = Ck / KC; a.assign = assign;
+    // measured at C3 (benchmarks/ab_winograd.py 128 stagger): forward 315 / 313 / 307 / 311 / 313 us at 0 / 4000 / 6000 / 12000 / 16000 clocks,
+    // input gradient 321 / 314 / 317 / 325 / 333 - a small offset is all it takes, larger ones only delay the late starters
+    a.stagger = dev->tune_conv_wino_stagger < 0 ? 5000 : dev->tune_conv_wino_stagger;
     a.src_bytes = (int)src_bytes; a.u_bytes = (int)u_bytes; a.dst_bytes = (int)dst_bytes;
     // persistent blocks, one per CU: block b walks the tile blocks b, b + grid.x, ...
     const long long npb = (P + PT - 1) / PT;
