@@ -88,6 +88,10 @@ const char* nk_version(void);
 enum { NK_TUNE_GEMM_FORCE = 0, NK_TUNE_GEMM_KPAIR = 1, NK_TUNE_ATTENTION_OCC = 2, NK_TUNE_GEMM_PAIR = 3, NK_TUNE_CONV_NARROW = 4,
        NK_TUNE_CONV_WINOGRAD = 5 };
 int nk_dev_tune(nk_device* dev, int knob, const int* values, int n);
+/* How many convolution launches on this handle took the Winograd F(2x2, 3x3) kernels so far (forward + input gradient; the rule
+ * of NK_TUNE_CONV_WINOGRAD decides per launch).  For harnesses that must say which algorithm produced a time: bench.py quotes the
+ * C3 roofline on the DIRECT algorithmic flops of node/convolution/mod.rs:85-123,146-189 and states beside it what was executed. */
+int nk_conv_winograd_launches(nk_device* dev, uint64_t* count);
 /* Tell the device handle that `n` of the GPU's resident-block slots (two 128x128 GEMM blocks per CU) are held by work on another
  * stream until further notice - the channel workgroups of an all-reduce in flight beside the backward pass
  * (vardiff.rs:125-141 -> optimizer.rs:81-86 is where the exchange sits; dp::GradientSync sets it when it hands the first

@@ -189,6 +189,7 @@ _SIGS = {
     "nk_comm_init_all": [C.c_int, C.POINTER(VP), C.POINTER(VP)],
     "nk_dev_tune": [VP, C.c_int, C.POINTER(C.c_int), C.c_int],
     "nk_device_set_busy_slots": [VP, C.c_int],
+    "nk_conv_winograd_launches": [VP, C.POINTER(C.c_uint64)],
     "nk_comm_destroy": [VP],
     "nk_allreduce_sum_async": [VP, VP, C.c_size_t, VP],
     "nk_allreduce_sum_group_async": [VP, C.POINTER(VP), C.POINTER(C.c_size_t), C.c_int, VP],
@@ -300,6 +301,12 @@ class Device:
 
     def conv_narrow(self, cost=None):
         self.tune(TUNE_CONV_NARROW, cost)
+
+    def conv_winograd_launches(self) -> int:
+        """nk_conv_winograd_launches: convolution launches on this handle that took the Winograd kernels so far."""
+        n = C.c_uint64(0)
+        check(lib.nk_conv_winograd_launches(self.h, C.byref(n)))
+        return int(n.value)
 
     def conv_winograd(self, mode=None, stagger=None):
         self.tune(TUNE_CONV_WINOGRAD, mode if stagger is None else [-1 if mode is None else mode, stagger])

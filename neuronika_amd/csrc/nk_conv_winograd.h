@@ -373,5 +373,6 @@ int wino_launch(nk_device* dev, bool bwd, const float* src, const float* w, floa
     else hipLaunchKernelGGL((wino_kernel<4, 1, 32, 4>), grid, dim3(256), 0, dev->compute, a);
     NK_LAUNCH_CHECK();
     *taken = true;
+    ++dev->wino_launches;
     return nk_prof_stop(dev);
 }

@@ -164,6 +164,12 @@ int nk_device_set_busy_slots(nk_device* dev, int n) {
     return NK_OK;
 }
 
+int nk_conv_winograd_launches(nk_device* dev, uint64_t* count) {
+    NK_CHECK(dev != nullptr && count != nullptr, "bad nk_conv_winograd_launches arguments");
+    *count = dev->wino_launches;
+    return NK_OK;
+}
+
 int nk_dev_tune(nk_device* dev, int knob, const int* values, int n) {
     NK_CHECK(dev != nullptr && n >= 0 && (n == 0 || values != nullptr), "bad nk_dev_tune arguments");
     switch (knob) {
