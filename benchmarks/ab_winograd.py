@@ -39,6 +39,26 @@ def main():
 
     for _ in range(30):                              # clocks
         calls["forward + bias"]()
+    if len(sys.argv) > 2 and sys.argv[2] == "shape":     # narrow (two-wave, 64-channel) against wide (four-wave, 128-channel) blocks
+        geoms = [("C3 forward 64 -> 128", 64, 128, True), ("128 -> 128 at 28 x 28, forward", 128, 128, True),
+                 ("128 -> 128 at 28 x 28, input gradient", 128, 128, False), ("256 -> 256 at 14 x 14, forward", 256, 256, True),
+                 ("256 -> 256 at 14 x 14, input gradient", 256, 256, False)]
+        for name, ci, co, fwd in geoms:
+            hh = 56 if ci == 64 else (28 if ci == 128 else 14)
+            xp = dev.array(rng.random((N, ci, hh + 2, hh + 2), dtype=np.float32))
+            ww = dev.array((rng.random((co, ci, 3, 3), dtype=np.float32) * 2 - 1) / 24)
+            gg = dev.array(rng.random((N, co, hh, hh), dtype=np.float32))
+            yy, dd = dev.zeros((N, co, hh, hh)), dev.zeros((N, ci, hh, hh))
+            fn = (lambda: c.conv_fwd(dev, xp, ww, yy, (1, 1), (1, 1), 1)) if fwd else \
+                 (lambda: c.conv_bwd_input(dev, dd, gg, ww, (1, 1), (1, 1), 1, assign=True, padding=(1, 1)))
+            row = {"case": name, "N": N}
+            for rnd in range(2):
+                for label, mode, shape in (("implicit_gemm", 0, None), ("narrow", 1, 0), ("wide", 1, 1)):
+                    dev.conv_winograd(mode, None, shape)
+                    row[label + "_us"] = round(time(fn), 1)
+            dev.conv_winograd(None)
+            print(json.dumps(row), flush=True)
+        return
     if len(sys.argv) > 2 and sys.argv[2] == "stagger":   # the staggered start: off, the rule, explicit units (shader clocks)
         for rnd in range(2):
             for name, fn in calls.items():

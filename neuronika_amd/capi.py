@@ -308,8 +308,13 @@ class Device:
         check(lib.nk_conv_winograd_launches(self.h, C.byref(n)))
         return int(n.value)
 
-    def conv_winograd(self, mode=None, stagger=None):
-        self.tune(TUNE_CONV_WINOGRAD, mode if stagger is None else [-1 if mode is None else mode, stagger])
+    def conv_winograd(self, mode=None, stagger=None, shape=None):
+        """NK_TUNE_CONV_WINOGRAD: mode -1 rule / 0 never / 1 whenever the shape allows; stagger unit in shader clocks (-1 rule);
+        block shape -1 rule / 0 narrow / 1 wide."""
+        if stagger is None and shape is None:
+            self.tune(TUNE_CONV_WINOGRAD, mode)
+        else:
+            self.tune(TUNE_CONV_WINOGRAD, [-1 if mode is None else mode, -1 if stagger is None else stagger, -1 if shape is None else shape])
 
     def busy_slots(self, n: int = 0):
         """nk_device_set_busy_slots: `n` resident-block slots are held by work on another stream (an exchange in flight)."""

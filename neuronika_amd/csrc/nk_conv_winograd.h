@@ -336,8 +336,18 @@ int wino_launch(nk_device* dev, bool bwd, const float* src, const float* w, floa
     *taken = false;
     const int mode = dev->tune_conv_winograd;  // -1 rule, 0 never, 1 whenever the shape allows
     if (mode == 0) return NK_OK;
-    const int KC = bwd ? 16 : 32, CM = bwd ? 64 : 128, PT = 32, NW = bwd ? 2 : 4;  // reduction chunk, channels / tiles / waves per block
-    if (Hd < 2 || Wd < 2 || Hd % 2 != 0 || Wd % 2 != 0 || Ck % KC != 0 || Cm % CM != 0) return NK_OK;
+    // Two block shapes, either pass: WIDE = four waves, 128 output channels, reduction chunks of 32 (one block per CU); NARROW = two
+    // waves, 64 output channels, chunks of 16 (two independent blocks per CU: a barrier joins two waves instead of four, the
+    // transform work per MFMA doubles).  Wide wherever the channel counts allow it - measured (benchmarks/ab_winograd.py 128 shape,
+    // profiles/r05_winograd_ab.txt): 309 / 313 us at C3's forward, 163 / 169 and 162 / 171 at 128 -> 128 channels on 28 x 28,
+    // 157 / 172 and 157 / 168 at 256 -> 256 on 14 x 14 (implicit GEMM: 494, 306, 327, 317, 323) - narrow for 64 output channels
+    // (C3's input gradient: 319 us against 507).
+    const bool wide_ok = Cm % 128 == 0 && Ck % 32 == 0, narrow_ok = Cm % 64 == 0 && Ck % 16 == 0;
+    const int shape = dev->tune_conv_wino_shape;  // -1 rule, 0 narrow, 1 wide
+    const bool wide = shape < 0 ? wide_ok : (shape == 1 ? wide_ok : !narrow_ok && wide_ok);
+    if (!wide && !narrow_ok) return NK_OK;
+    const int KC = wide ? 32 : 16, CM = wide ? 128 : 64, PT = 32, NW = wide ? 4 : 2;  // reduction chunk, channels / tiles / waves per block
+    if (Hd < 2 || Wd < 2 || Hd % 2 != 0 || Wd % 2 != 0) return NK_OK;
     if (!al16(dst) || !al16(src)) return NK_OK;
     const long long P = (long long)N * (Hd / 2) * (Wd / 2);
     const long long blocks = (P + PT - 1) / PT * (Cm / CM);
@@ -369,8 +379,8 @@ int wino_launch(nk_device* dev, bool bwd, const float* src, const float* w, floa
     const long long slots = (long long)dev->num_cus * (4 / NW);  // one wave per SIMD
     const long long per_group = slots / (Cm / CM) > 0 ? slots / (Cm / CM) : 1;
     const dim3 grid((unsigned)(npb < per_group ? npb : per_group), (unsigned)(Cm / CM));
-    if (bwd) hipLaunchKernelGGL((wino_kernel<2, 1, 16, 4>), grid, dim3(128), 0, dev->compute, a);
-    else hipLaunchKernelGGL((wino_kernel<4, 1, 32, 4>), grid, dim3(256), 0, dev->compute, a);
+    if (wide) hipLaunchKernelGGL((wino_kernel<4, 1, 32, 4>), grid, dim3(256), 0, dev->compute, a);
+    else hipLaunchKernelGGL((wino_kernel<2, 1, 16, 4>), grid, dim3(128), 0, dev->compute, a);
     NK_LAUNCH_CHECK();
     *taken = true;
     ++dev->wino_launches;

@@ -45,12 +45,16 @@ SHAPES = [
     (2, 64, 256, 6, 20),       # forward: two blocks of 128 output channels; input gradient: 8 chunks of 32
     (5, 192, 128, 6, 6),       # 5 * 2 * 2 = 20 tiles; three forward chunks, three channel blocks of dX
     (2, 64, 128, 58, 58),      # the C3 plane (28 x 28 tiles per image), two samples
+    (2, 64, 64, 10, 10),       # 64 output channels either way: the narrow blocks (two waves, chunks of 16) in both passes
+    (2, 48, 64, 8, 12),        # forward: three chunks of 16 (narrow only: 48 is no multiple of 32); input gradient: 48 channels - direct
+    (1, 32, 128, 12, 12),      # forward: ONE chunk of 32 (every item is a tile block's first and last); input gradient: 32 channels - direct
+    (2, 128, 128, 10, 10),     # both block shapes possible in both passes (the third knob value picks)
 ]
 
 
-def run_all(dev, x, w, b, go, dx0, pad, mode):
+def run_all(dev, x, w, b, go, dx0, pad, mode, shape=None):
     c = capi()
-    dev.conv_winograd(mode)
+    dev.conv_winograd(mode, None, shape)
     try:
         N, Cin, H, W = x.shape
         Cout = w.shape[0]
@@ -78,9 +82,11 @@ def test_winograd_equals_direct_exactly_on_integer_data(dev, N, Cin, Cout, H, W)
     wino = run_all(dev, x, w, b, go, dx0, 1, 1)
     direct = run_all(dev, x, w, b, go, dx0, 1, 0)
     again = run_all(dev, x, w, b, go, dx0, 1, 1)
-    for name, a, d, r in zip(("y", "y+bias", "dx+=", "dx=", "dx(pad)+=", "dx(pad)="), wino, direct, again):
+    narrow, wide = run_all(dev, x, w, b, go, dx0, 1, 1, 0), run_all(dev, x, w, b, go, dx0, 1, 1, 1)   # the two block shapes
+    for name, a, d, r, nr, wd in zip(("y", "y+bias", "dx+=", "dx=", "dx(pad)+=", "dx(pad)="), wino, direct, again, narrow, wide):
         assert np.array_equal(a, d), name
         assert np.array_equal(a, r), name
+        assert np.array_equal(a, nr) and np.array_equal(a, wd), name
     y = np.zeros((N, Cout, H - 2, W - 2), np.float32); O.convolution_forward(x, w, y, (1, 1), (1, 1), 1)
     assert np.array_equal(wino[0], y) and np.array_equal(wino[1], y + b)
     dx = dx0.copy(); O.convolution_backward_input(dx, go, w, (1, 1), (1, 1), 1)
@@ -88,7 +94,7 @@ def test_winograd_equals_direct_exactly_on_integer_data(dev, N, Cin, Cout, H, W)
     assert np.array_equal(wino[4], dx[:, :, 1:H - 1, 1:W - 1]) and np.array_equal(wino[5], (dx - dx0)[:, :, 1:H - 1, 1:W - 1])
 
 
-@pytest.mark.parametrize("N,Cin,Cout,H,W", SHAPES[:5])
+@pytest.mark.parametrize("N,Cin,Cout,H,W", SHAPES[:5] + SHAPES[6:])
 @pytest.mark.parametrize("pad", [0, 1, 2])
 def test_winograd_random_inside_the_contraction_bound(dev, N, Cin, Cout, H, W, pad):
     from tolerance import assert_contraction
@@ -112,7 +118,7 @@ def test_winograd_random_inside_the_contraction_bound(dev, N, Cin, Cout, H, W, p
 
 def test_winograd_rule_and_knob(dev):
     """By rule the path is taken from four rounds of blocks on (the C3 plane with 8 samples: 196 forward blocks - direct; with
-    48 samples: 1176 - Winograd); shapes it cannot take (odd output extent, stride 2, 5 x 5, groups, 48 channels) stay direct
+    48 samples: 1176 - Winograd); shapes it cannot take (odd output extent, stride 2, 5 x 5, groups, 40 channels) stay direct
     under the forced knob.  Told apart by the bits on random data (the two orders of summation differ)."""
     c = capi()
 
@@ -135,5 +141,5 @@ def test_winograd_rule_and_knob(dev):
     for x, wk, s, g in ((rnd(1, (2, 64, 9, 10)), w, (1, 1), 1), (rnd(1, (2, 64, 11, 11)), w, (2, 2), 1),
                         (rnd(1, (2, 64, 12, 12)), rnd(2, (128, 64, 5, 5), -1, 1), (1, 1), 1),
                         (rnd(1, (2, 128, 10, 10)), rnd(2, (128, 64, 3, 3), -1, 1), (1, 1), 2),
-                        (rnd(1, (2, 48, 10, 10)), rnd(2, (128, 48, 3, 3), -1, 1), (1, 1), 1)):
+                        (rnd(1, (2, 40, 10, 10)), rnd(2, (128, 40, 3, 3), -1, 1), (1, 1), 1)):
         assert np.array_equal(fwd(x, wk, s, g, 1), fwd(x, wk, s, g, 0))
