@@ -9,15 +9,16 @@
 // (Lavin & Gray 2016): the data and output transforms are additions, the kernel transform halves and quarters - exact on
 // integer-valued data.  The 16 element-wise products, summed over input channels, are 16 small GEMMs
 //   M[xi] (Cm x P) = U[xi] (Cm x Ck) . V[xi] (Ck x P),   xi = 0..15,  P = N * (Hd/2) * (Wd/2) tiles,
-// which run on the MFMA core (v_mfma_f32_32x32x2_f32).  Everything stays on chip: a block transforms the patches of 32*PB
-// tiles into LDS (V, two buffers of 64 KB), each wave holds the 16 accumulator tiles (xi) of its 32 output channels x 32 tiles
-// in registers (256 of the 512 a wave has at one wave per SIMD), takes its U fragments straight from L2 in MFMA operand order
-// (the kernel transform writes them that way), and applies the output transform to its own registers - V, M never touch HBM.
-//   forward        CB = 4 waves x 32 channels = 128 output channels, 32 tiles, the input channels in chunks of 32
-//   input gradient CB = 2 x 32 = 64 channels of dX, PB = 2 x 32 tiles, the gradient's channels in chunks of 16
-// One source for both: the "source" tensor is the input (forward) or the output gradient (backward), read at patch origin
-// (2 ty - offy, 2 tx - offx) with zeros outside [0, Hs) x [0, Ws); forward: off = 0 on the caller's padded input, backward:
-// off = 2 - pad (the Pad node's padding folded in, as in the direct input-gradient kernel).
+// which run on the MFMA core (v_mfma_f32_32x32x2_f32).  Everything stays on chip: a block transforms the patches of 32 tiles into LDS
+// (V, two images of 64 KB / 32 KB), each wave holds the 16 accumulator tiles (xi) of its 32 output channels x 32 tiles in registers
+// (256 of the 512 a wave has at one wave per SIMD), takes its U fragments straight from L2 in MFMA operand order (the kernel
+// transform writes them that way), and applies the output transform to its own registers - V, M never touch HBM.
+//   WIDE    four waves x 32 channels = 128 output channels, reduction channels in chunks of 32, one block per CU
+//   NARROW  two waves = 64 output channels, chunks of 16, two independent blocks per CU
+// either shape for either pass, by channel count (wino_launch).  One source for both passes: the "source" tensor is the input
+// (forward) or the output gradient (backward), read at patch origin (2 ty - offy, 2 tx - offx) with zeros outside [0, Hs) x [0, Ws);
+// forward: off = 0 on the caller's padded input, backward: off = 2 - pad (the Pad node's padding folded in, as in the direct
+// input-gradient kernel).  Design notes and measurements: DESIGN.md section 4.2.1, profiles/r05_winograd_ab.txt.
 // Summation order: per xi one fma chain over the reduction channels (two k per MFMA), then the fixed add trees of the output
 // transform: deterministic; NOT the direct kernels' order - equal to them to contraction tolerance, exact on integer data.
 #pragma once
