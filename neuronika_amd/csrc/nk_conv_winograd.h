@@ -36,6 +36,10 @@ struct WinoArgs {
     int assign;         // 1: dst = value, 0: dst += value
     int src_bytes, u_bytes, dst_bytes;  // the buffer descriptors' extents (all below 2^31)
     int stagger;        // unit of the staggered start in shader clocks (0: none)
+    // division of a tile index by TY * TX and of the remainder by TX without the 40-instruction software divide (two per tile block
+    // and thread in the patch offsets, two more in the output phase): Granlund - Montgomery multipliers, exact for every 32-bit dividend
+    unsigned per_m, tx_m;
+    int per_s1, per_s2, tx_s1, tx_s2;
 };
 
 // U in MFMA A-operand order.  For chunk ch (KC reduction channels), xi, block of 32 output channels cbt: a wave's fragment is
@@ -75,6 +79,19 @@ __global__ void wino_weights_kernel(float* __restrict__ u, const float* __restri
 #pragma unroll
     for (int xi = 0; xi < 16; ++xi)
         u[((((long long)(ch * 16 + xi) * CBT + cbt) * (KC / 8) + j) * 64 + lane) * 4 + tq] = uu[xi >> 2][xi & 3];
+}
+
+// q = n / d for the divisor behind (m, s1, s2) = wino_magic(d)
+__device__ __forceinline__ unsigned wino_div(unsigned n, unsigned m, int s1, int s2) {
+    const unsigned t = __umulhi(m, n);
+    return (t + ((n - t) >> s1)) >> s2;
+}
+inline void wino_magic(unsigned d, unsigned* m, int* s1, int* s2) {
+    int l = 0;
+    while ((1ull << l) < d) ++l;  // ceil(log2 d)
+    *m = (unsigned)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+    *s1 = l < 1 ? l : 1;
+    *s2 = l - 1 > 0 ? l - 1 : 0;
 }
 
 typedef unsigned wino_u2 __attribute__((ext_vector_type(2)));
@@ -136,8 +153,10 @@ __global__ __launch_bounds__(64 * CB * PB, 1) void wino_kernel(WinoArgs a) {
     auto patch = [&](int pbk) {
         const unsigned p = (unsigned)pbk * PT + pl;  // (the host keeps P below 2^30)
         const bool pvalid = pbk < npb && p < (unsigned)a.P;
-        const unsigned n = pvalid ? p / (unsigned)per : 0u, rem = pvalid ? p % (unsigned)per : 0u;
-        const int ty = (int)(rem / (unsigned)a.TX), tx = (int)(rem % (unsigned)a.TX);
+        const unsigned pv = pvalid ? p : 0u;
+        const unsigned n = wino_div(pv, a.per_m, a.per_s1, a.per_s2), rem = pv - n * (unsigned)per;
+        const unsigned uty = wino_div(rem, a.tx_m, a.tx_s1, a.tx_s2);
+        const int ty = (int)uty, tx = (int)(rem - uty * (unsigned)a.TX);
         const int r0 = 2 * ty - a.offy, c0 = 2 * tx - a.offx;
         const int sb = ((int)n * a.Ck + 4 * kq0) * plane + r0 * a.Ws + c0;
 #pragma unroll
@@ -285,8 +304,10 @@ __global__ __launch_bounds__(64 * CB * PB, 1) void wino_kernel(WinoArgs a) {
         // share one in-order counter: a load behind a store waits for every store before it).
         const unsigned p = (unsigned)pbk * PT + 32 * pb + c;
         const bool pvalid = p < (unsigned)a.P;
-        const unsigned un = pvalid ? p / (unsigned)per : 0u, urem = pvalid ? p % (unsigned)per : 0u;
-        const int n = (int)un, ty = (int)(urem / (unsigned)a.TX), tx = (int)(urem % (unsigned)a.TX);
+        const unsigned pv = pvalid ? p : 0u;
+        const unsigned un = wino_div(pv, a.per_m, a.per_s1, a.per_s2), urem = pv - un * (unsigned)per;
+        const unsigned uty = wino_div(urem, a.tx_m, a.tx_s1, a.tx_s2);
+        const int n = (int)un, ty = (int)uty, tx = (int)(urem - uty * (unsigned)a.TX);
         const int oplane = a.Hd * a.Wd;
         const unsigned ovoff = pvalid ? (unsigned)((n * a.Cm + 32 * cbg + 4 * h) * oplane + 2 * ty * a.Wd + 2 * tx) * 4u : 0x80000000u;
 #pragma unroll
@@ -374,6 +395,8 @@ int wino_launch(nk_device* dev, bool bwd, const float* src, const float* w, floa
     // measured at C3 (benchmarks/ab_winograd.py 128 stagger): forward 315 / 313 / 307 / 311 / 313 us at 0 / 4000 / 6000 / 12000 / 16000 clocks,
     // input gradient 321 / 314 / 317 / 325 / 333 - a small offset is all it takes, larger ones only delay the late starters
     a.stagger = dev->tune_conv_wino_stagger < 0 ? 5000 : dev->tune_conv_wino_stagger;
+    wino_magic((unsigned)(a.TY * a.TX), &a.per_m, &a.per_s1, &a.per_s2);
+    wino_magic((unsigned)a.TX, &a.tx_m, &a.tx_s1, &a.tx_s2);
     a.src_bytes = (int)src_bytes; a.u_bytes = (int)u_bytes; a.dst_bytes = (int)dst_bytes;
     // persistent blocks, one per CU: block b walks the tile blocks b, b + grid.x, ...
     const long long npb = (P + PT - 1) / PT;
