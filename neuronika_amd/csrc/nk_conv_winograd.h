@@ -301,7 +301,11 @@ __global__ __launch_bounds__(64 * CB * PB, 1) void wino_kernel(WinoArgs a) {
 
         // ---- output transform on the wave's own registers: lane (c, h) owns tile 32 pb + c and 16 channels (MFMA C layout):
         // e = 4 Q + el is channel 32 cbg + 8 Q + 4 h + el.  No loads after the first store in the assigning form (loads and stores
-        // share one in-order counter: a load behind a store waits for every store before it).
+        // share one in-order counter: a load behind a store waits for every store before it).  What is left of that in the ISA: the
+        // run-time `if (!a.assign)` makes the compiler wait for everything outstanding at each quarter's join (three drains of eight
+        // stores per tile block).  Both ways around it were built and are SLOWER, because they move the register allocation of a
+        // kernel that sits at its 512-register limit: `assign` as a template parameter (69 spilled registers instead of 54: forward
+        // 301 -> 341 us, input gradient 309 -> 314), two copies of the phase under one branch (108 spills: 343 / 329).
         const unsigned p = (unsigned)pbk * PT + 32 * pb + c;
         const bool pvalid = p < (unsigned)a.P;
         const unsigned pv = pvalid ? p : 0u;
