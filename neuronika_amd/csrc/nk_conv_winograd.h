@@ -407,7 +407,10 @@ int wino_launch(nk_device* dev, bool bwd, const float* src, const float* w, floa
     const long long slots = (long long)dev->num_cus * (4 / NW);  // one wave per SIMD
     const long long per_group = slots / (Cm / CM) > 0 ? slots / (Cm / CM) : 1;
     const dim3 grid((unsigned)(npb < per_group ? npb : per_group), (unsigned)(Cm / CM));
-    if (wide) hipLaunchKernelGGL((wino_kernel<4, 1, 32, 4>), grid, dim3(256), 0, dev->compute, a);
+    // U ring: 2 xi for the wide blocks (one xi = four MFMA groups ahead: 2 spilled registers and 283 us at C3's forward; a ring of 4
+    // - twelve groups ahead - costs 54 spills and 301 us), 4 xi for the narrow ones (one xi there is two groups: a ring of 2 gives 357 us
+    // against 309)
+    if (wide) hipLaunchKernelGGL((wino_kernel<4, 1, 32, 2>), grid, dim3(256), 0, dev->compute, a);
     else hipLaunchKernelGGL((wino_kernel<2, 1, 16, 4>), grid, dim3(128), 0, dev->compute, a);
     NK_LAUNCH_CHECK();
     *taken = true;
