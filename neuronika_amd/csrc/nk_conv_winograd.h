@@ -120,9 +120,9 @@ __global__ __launch_bounds__(64 * CB * PB, 1) void wino_kernel(WinoArgs a) {
     constexpr int KQ = KC / 4;         // channel quads per item
     constexpr int G = 16 * NJ;         // MFMA groups per item
     constexpr int VBUF = 16 * KC * PT; // floats of one V buffer
-    constexpr int LG = G / 4;          // groups that carry the next item's patch loads
+    constexpr int LG = G / 2;          // groups that carry the next item's patch loads (spread thin: 282 -> 267 / 309 -> 292 us at C3 against G / 4; G / 8: 295 / 341)
     constexpr int LPG = 64 / LG;       // ... loads per group
-    constexpr int TG = G / 16;         // groups per part of the next item's transform (8 parts: 4 column passes, 4 row passes + stores)
+    constexpr int TG = G / 32;         // groups per part of the next item's transform (8 parts: 4 column passes, 4 row passes + stores)
     constexpr int T0 = G - 8 * TG - TG;  // first group of part 0
     static_assert((CB * PB == 4 || CB * PB == 2) && KQ * PT == 64 * CB * PB && KC % 8 == 0, "one (tile, channel quad) per thread and item");
     static_assert(16 % UR == 0 && UR >= 2, "the ring of U fragments (UR - 1 xi ahead of the MFMAs) keeps its phase from item to item");
