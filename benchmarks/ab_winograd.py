@@ -39,6 +39,24 @@ def main():
 
     for _ in range(30):                              # clocks
         calls["forward + bias"]()
+    if len(sys.argv) > 2 and sys.argv[2] == "dw":        # the kernel gradient: implicit GEMM against Winograd F(3x3, 2x2), dW and db in one call
+        geoms = [("C3 64 -> 128 at 56 x 56", 64, 128, 56), ("64 -> 64 at 56 x 56", 64, 64, 56), ("128 -> 128 at 28 x 28", 128, 128, 28),
+                 ("256 -> 256 at 14 x 14", 256, 256, 14)]
+        for name, ci, co, hh in geoms:
+            xp = dev.array(rng.random((N, ci, hh + 2, hh + 2), dtype=np.float32))
+            gg = dev.array(rng.random((N, co, hh, hh), dtype=np.float32))
+            dww, dbb = dev.zeros((co, ci, 3, 3)), dev.zeros((co, 1, 1))
+            fn = lambda: c.conv_bwd_kernel_bias(dev, dww, dbb, gg, xp, (1, 1), (1, 1), 1, assign=(True, True))
+            row = {"case": name, "N": N}
+            for rnd in range(2):
+                for label, mode in (("implicit_gemm", 0), ("winograd", 1)):
+                    dev.conv_winograd(mode, None, None, mode)
+                    before = dev.conv_winograd_launches()
+                    row[label + "_us"] = round(time(fn), 1)
+                    row[label + "_winograd_launches"] = dev.conv_winograd_launches() - before
+            dev.conv_winograd(None)
+            print(json.dumps(row), flush=True)
+        return
     if len(sys.argv) > 2 and sys.argv[2] == "shape":     # narrow (two-wave, 64-channel) against wide (four-wave, 128-channel) blocks
         geoms = [("C3 forward 64 -> 128", 64, 128, True), ("128 -> 128 at 28 x 28, forward", 128, 128, True),
                  ("128 -> 128 at 28 x 28, input gradient", 128, 128, False), ("256 -> 256 at 14 x 14, forward", 256, 256, True),

@@ -84,7 +84,9 @@ const char* nk_version(void);
  *                          values[1] (optional) = -1 rule / 0 no staggered start of its persistent blocks / > 0 the stagger unit in
  *                          shader clocks (blocks one tile block short of the longest walk start 1 - 3 units late);
  *                          values[2] (optional) = -1 rule / 0 narrow blocks (two waves, 64 output channels, chunks of 16 reduction
- *                          channels) / 1 wide blocks (four waves, 128 channels, chunks of 32) where the channel counts allow both
+ *                          channels) / 1 wide blocks (four waves, 128 channels, chunks of 32) where the channel counts allow both;
+ *                          values[3] (optional) = -1 rule / 0 the kernel gradient never takes its Winograd F(3x3, 2x2) form / 1 whenever
+ *                          the shape allows (64 | both channel counts, even output extents)
  * For schedule sweeps (benchmarks/ab_*.py) and the tests that pit one schedule against another bit for bit; results never
  * depend on them beyond summation order (split-K). */
 enum { NK_TUNE_GEMM_FORCE = 0, NK_TUNE_GEMM_KPAIR = 1, NK_TUNE_ATTENTION_OCC = 2, NK_TUNE_GEMM_PAIR = 3, NK_TUNE_CONV_NARROW = 4,

@@ -308,13 +308,13 @@ class Device:
         check(lib.nk_conv_winograd_launches(self.h, C.byref(n)))
         return int(n.value)
 
-    def conv_winograd(self, mode=None, stagger=None, shape=None):
+    def conv_winograd(self, mode=None, stagger=None, shape=None, dw=None):
         """NK_TUNE_CONV_WINOGRAD: mode -1 rule / 0 never / 1 whenever the shape allows; stagger unit in shader clocks (-1 rule);
-        block shape -1 rule / 0 narrow / 1 wide."""
-        if stagger is None and shape is None:
+        block shape -1 rule / 0 narrow / 1 wide; kernel gradient (F(3x3, 2x2)) -1 rule / 0 never / 1 whenever the shape allows."""
+        if stagger is None and shape is None and dw is None:
             self.tune(TUNE_CONV_WINOGRAD, mode)
         else:
-            self.tune(TUNE_CONV_WINOGRAD, [-1 if mode is None else mode, -1 if stagger is None else stagger, -1 if shape is None else shape])
+            self.tune(TUNE_CONV_WINOGRAD, [-1 if v is None else v for v in (mode, stagger, shape, dw)])
 
     def busy_slots(self, n: int = 0):
         """nk_device_set_busy_slots: `n` resident-block slots are held by work on another stream (an exchange in flight)."""

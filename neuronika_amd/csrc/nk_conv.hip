@@ -62,6 +62,7 @@ bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 size_t round256(size_t b) { return (b + 255) & ~size_t(255); }
 
 #include "nk_conv_winograd.h"
+#include "nk_conv_winograd_dw.h"
 
 // 3 x 3, stride 1, dilation 1, one group, two spatial dimensions: the shapes wino_launch may take
 bool wino_shape(const ConvGeom& g) {
@@ -472,6 +473,12 @@ int conv_bwd_kernel(nk_device* dev, int nd, float* dw, const int* w_shape, const
         NK_LAUNCH_CHECK();
         rc = nk_prof_stop(dev);
         return rc ? rc : bias_by_reduction();
+    }
+    if (wino_shape(g)) {  // Winograd F(3x3, 2x2): the tiles as the reduction dimension (nk_conv_winograd_dw.h); dW and db in one call
+        bool taken = false;
+        rc = wino_dw_launch(dev, gy, x, dw, db, g.N, g.Cin, g.Cout, g.in[1], g.in[2], assign, assign_b,
+                            2.0 * g.N * (double)g.Cout * g.L * g.Cg * g.KK, &taken);
+        if (rc || taken) return rc;
     }
     BwdKArgs p{};
     p.g = g; p.gy = gy; p.x = x;

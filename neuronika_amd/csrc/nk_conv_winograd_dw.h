@@ -1,0 +1,285 @@
+// Winograd F(3x3, 2x2) for the KERNEL gradient of the 3x3 / stride 1 / dilation 1 / groups 1 convolution
+// (ConvolutionBackwardKernel::backward, node/convolution/mod.rs:191-228: dW[co][ci][ky][kx] = sum over samples and output
+// positions of dY[n][co][y][x] * X[n][ci][y + ky][x + kx]) - part of the convolution translation unit (included by nk_conv.hip
+// inside its anonymous namespace, after nk_conv_winograd.h).
+//
+// Per 2x2 tile of dY and the 4x4 patch of X under it the nine sums are a correlation with a 2x2 "kernel": 16 multiplies instead of 36,
+//   dW (3x3) += A^T [ (G dy G^T) . (B^T x B) ] A,   A^T = [1 1 1 0; 0 1 -1 0; 0 1 1 1],  G = [1 0; 1/2 1/2; 1/2 -1/2; 0 1],
+//                                                   B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 -1 0 1]
+// (the transposed form of the forward's F(2x2, 3x3): same points 0, 1, -1, inf; matrices checked against the direct sums in
+// tests/test_gpu_winograd.py).  Both transforms are linear, so the sum over the tiles is taken INSIDE:
+//   M[xi] (Co x Ci) = sum over tiles p of DY^[xi][co][p] * X^[xi][p][ci],   xi = 0..15,   dW[co][ci] = A^T M[.][co][ci] A,
+// 16 GEMMs with the tiles as the reduction dimension - 26.3 GFLOP at C3 instead of 59.2 - on v_mfma_f32_32x32x2_f32 (two tiles per
+// instruction).  Unlike the forward, BOTH operands are transformed on the fly and nothing is pre-transformed in HBM.
+//
+// Block = four waves = a 64 x 64 block of (co, ci) for all 16 xi: wave (wr, wc) holds the 16 accumulator tiles of 32 co x 32 ci in
+// registers (256 of its 512).  grid.y = the (co block, ci block) pairs, grid.x = slices of the tile sequence, one block per CU.
+// An ITEM is 8 tiles: every thread transforms the patch of one tile for TWO input channels and the dY tile for TWO output channels
+// (float2 = the channel pair) and stores the 16 + 16 xi values with ds_write_b64 into the LDS images
+//   X^ / DY^ : [xi][channel / 4][tile (8)][channel % 4] + 4 floats of padding per channel quad (36 floats: a wave's 32 lanes = 32
+//   channels read 32 distinct banks),
+// two images of each (2 x 72 KB of the 160 KB); the MFMA waves read one A and one B value per instruction (ds_read_b32).  Loads run
+// TWO items ahead of the MFMAs (registers), the transform one item ahead (LDS): an item is only 64 MFMAs per wave = 4096 clocks,
+// less than an HBM round trip under load.  One barrier per item.
+// Every slice block leaves its 16 x 64 x 64 sums (256 KB) in a workspace slab; a second kernel adds the slabs in slice order, applies
+// A^T . A and writes (or adds to) dW; the bias gradient (sum of dY per output channel) is summed on the way by the threads that load
+// dY and leaves through the same second kernel.  Deterministic: one fma chain per (xi, co, ci) and slice in tile order, slices in
+// order, fixed add trees - not the implicit-GEMM kernel's order; equal to it to contraction tolerance, exact on integer data.
+#pragma once
+
+struct WinoDwArgs {
+    const float* x;    // (N, Ci, Hs, Ws): the convolution's (padded) input
+    const float* gy;   // (N, Co, Hd, Wd), Hd = Hs - 2, Wd = Ws - 2
+    float* slabs;      // [slice][pair][xi 16][co 64][ci 64]
+    float* bslabs;     // [slice][Co] or null
+    int N, Ci, Co, Hs, Ws, Hd, Wd, TY, TX;
+    unsigned P;        // N * TY * TX tiles
+    int items;         // items of 8 tiles per slice (even)
+    int cib;           // ci blocks (Ci / 64): pair = cob * cib + cb
+    unsigned per_m, tx_m;
+    int per_s1, per_s2, tx_s1, tx_s2;
+    int x_bytes, gy_bytes;
+};
+
+constexpr int WDW_T = 8;                       // tiles per item
+constexpr int WDW_CQ = 36;                     // floats per (xi, channel quad): 8 tiles x 4 channels + 4 of padding
+constexpr int WDW_IMG = 16 * 16 * WDW_CQ;      // floats of one operand image: 16 xi x 16 channel quads (64 channels)
+
+__global__ __launch_bounds__(256, 1) void wino_dw_kernel(WinoDwArgs a) {
+    __shared__ __attribute__((aligned(16))) float XS[2 * WDW_IMG];
+    __shared__ __attribute__((aligned(16))) float YS[2 * WDW_IMG];
+    const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    const int wr = wid >> 1, wc = wid & 1;       // the wave's co block / ci block inside the 64 x 64 block
+    const int c = lane & 31, h = lane >> 5;
+    const int pair = blockIdx.y, cob = pair / a.cib, cb = pair % a.cib;
+    const int tl = t & 7, cp = t >> 3;           // transform phase: this thread's tile of an item and its channel pair (0..31)
+    const int plane = a.Hs * a.Ws, oplane = a.Hd * a.Wd;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.gy, 0, a.gy_bytes, 0x00020000);
+    const int ws4 = a.Ws * 4, wd4 = a.Wd * 4, plane4 = plane * 4, oplane4 = oplane * 4;
+
+    // loaded, not yet transformed operands of one item: two register sets (loads run two items ahead)
+    wino_u2 xr[2][2][4][2];  // [set][channel of the pair][patch row][columns 0-1 / 2-3]
+    wino_u2 yr[2][2][2];     // [set][channel of the pair][tile row]
+    float2 bsum = make_float2(0.f, 0.f);  // bias gradient of this thread's two output channels over its tiles
+
+    const unsigned tile0 = (unsigned)blockIdx.x * (unsigned)a.items * WDW_T;
+    auto load = [&](auto set, int item) {
+        constexpr int S = decltype(set)::value;
+        const unsigned p = tile0 + (unsigned)item * WDW_T + tl;
+        const bool valid = item < a.items && p < a.P;
+        const unsigned pv = valid ? p : 0u;
+        const unsigned n = wino_div(pv, a.per_m, a.per_s1, a.per_s2), rem = pv - n * (unsigned)(a.TY * a.TX);
+        const unsigned ty = wino_div(rem, a.tx_m, a.tx_s1, a.tx_s2), tx = rem - ty * (unsigned)a.TX;
+        const unsigned xo = valid ? (unsigned)(((int)n * a.Ci + 64 * cb + 2 * cp) * plane + 2 * (int)ty * a.Ws + 2 * (int)tx) * 4u : 0x80000000u;
+        const unsigned yo = valid ? (unsigned)(((int)n * a.Co + 64 * cob + 2 * cp) * oplane + 2 * (int)ty * a.Wd + 2 * (int)tx) * 4u : 0x80000000u;
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                xr[S][ch][i][0] = __builtin_amdgcn_raw_buffer_load_b64(xrs, xo, ch * plane4 + i * ws4, 0);
+                xr[S][ch][i][1] = __builtin_amdgcn_raw_buffer_load_b64(xrs, xo + 8, ch * plane4 + i * ws4, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 2; ++r) yr[S][ch][r] = __builtin_amdgcn_raw_buffer_load_b64(yrs, yo, ch * oplane4 + r * wd4, 0);
+        }
+    };
+    // transform of a loaded item into the images `xs`, `ys`: thread = (tile tl, channel pair cp); element (xi, channel quad cp / 2,
+    // tile, channels 2 (cp % 2), + 1) as one float2
+    auto transform = [&](auto set, float* xs, float* ys) {
+        constexpr int S = decltype(set)::value;
+        float2* const xw = reinterpret_cast<float2*>(xs + (cp >> 1) * WDW_CQ + tl * 4 + 2 * (cp & 1));
+        float2* const yw = reinterpret_cast<float2*>(ys + (cp >> 1) * WDW_CQ + tl * 4 + 2 * (cp & 1));
+        constexpr int XI = 16 * WDW_CQ / 2;  // float2 step from xi to xi + 1
+        float xv[2][16], yv[2][16];
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+            float d[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float2 lo = __builtin_bit_cast(float2, xr[S][ch][i][0]), hi = __builtin_bit_cast(float2, xr[S][ch][i][1]);
+                d[i][0] = lo.x; d[i][1] = lo.y; d[i][2] = hi.x; d[i][3] = hi.y;
+            }
+            float tt[4][4];  // B^T d
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                tt[0][j] = d[0][j] - d[2][j];
+                tt[1][j] = d[1][j] + d[2][j];
+                tt[2][j] = d[2][j] - d[1][j];
+                tt[3][j] = d[3][j] - d[1][j];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {  // (B^T d) B
+                xv[ch][4 * i + 0] = tt[i][0] - tt[i][2];
+                xv[ch][4 * i + 1] = tt[i][1] + tt[i][2];
+                xv[ch][4 * i + 2] = tt[i][2] - tt[i][1];
+                xv[ch][4 * i + 3] = tt[i][3] - tt[i][1];
+            }
+            const float2 r0 = __builtin_bit_cast(float2, yr[S][ch][0]), r1 = __builtin_bit_cast(float2, yr[S][ch][1]);
+            if (ch == 0) bsum.x += (r0.x + r0.y) + (r1.x + r1.y);
+            else bsum.y += (r0.x + r0.y) + (r1.x + r1.y);
+            float g[4][2];  // G dy
+            g[0][0] = r0.x; g[0][1] = r0.y;
+            g[1][0] = 0.5f * (r0.x + r1.x); g[1][1] = 0.5f * (r0.y + r1.y);
+            g[2][0] = 0.5f * (r0.x - r1.x); g[2][1] = 0.5f * (r0.y - r1.y);
+            g[3][0] = r1.x; g[3][1] = r1.y;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {  // (G dy) G^T
+                yv[ch][4 * i + 0] = g[i][0];
+                yv[ch][4 * i + 1] = 0.5f * (g[i][0] + g[i][1]);
+                yv[ch][4 * i + 2] = 0.5f * (g[i][0] - g[i][1]);
+                yv[ch][4 * i + 3] = g[i][1];
+            }
+        }
+#pragma unroll
+        for (int xi = 0; xi < 16; ++xi) {
+            xw[xi * XI] = make_float2(xv[0][xi], xv[1][xi]);
+            yw[xi * XI] = make_float2(yv[0][xi], yv[1][xi]);
+        }
+    };
+
+    nkmma::f32x16 acc[16];
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[xi][e] = 0.f;
+
+    // ---- prologue: item 0 transformed into image 0, item 1 loaded
+    load(std::integral_constant<int, 0>{}, 0);
+    load(std::integral_constant<int, 1>{}, 1);
+    transform(std::integral_constant<int, 0>{}, XS, YS);
+    __syncthreads();
+
+    // the MFMAs of item i on image `cur`, with: the loads of item i + 2 into register set `set` (item i's own, already transformed),
+    // the transform of item i + 1 (register set set ^ 1, loaded during item i - 1) into image cur ^ 1
+    auto item = [&](auto set, int i) {
+        constexpr int S = decltype(set)::value;
+        // lane (c, h): A = DY^[xi][co = 32 wr + c][tile 2 s + h], B = X^[xi][tile 2 s + h][ci = 32 wc + c], s = 0..3
+        const float* const ya = YS + S * WDW_IMG + ((32 * wr + c) >> 2) * WDW_CQ + (c & 3) + 4 * h;
+        const float* const xb = XS + S * WDW_IMG + ((32 * wc + c) >> 2) * WDW_CQ + (c & 3) + 4 * h;
+        load(set, i + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        float av[2][4], bv[2][4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) { av[0][s] = ya[8 * s]; bv[0][s] = xb[8 * s]; }
+#pragma unroll
+        for (int xi = 0; xi < 16; ++xi) {
+            if (xi + 1 < 16) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) { av[(xi + 1) & 1][s] = ya[(xi + 1) * 16 * WDW_CQ + 8 * s]; bv[(xi + 1) & 1][s] = xb[(xi + 1) * 16 * WDW_CQ + 8 * s]; }
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[xi & 1][s], bv[xi & 1][s], acc[xi], 0, 0, 0);
+        }
+        // the next item's transform: its loads are a whole item old
+        transform(std::integral_constant<int, S ^ 1>{}, XS + (S ^ 1) * WDW_IMG, YS + (S ^ 1) * WDW_IMG);
+        __syncthreads();
+    };
+    for (int i = 0; i < a.items; i += 2) {
+        item(std::integral_constant<int, 0>{}, i);
+        item(std::integral_constant<int, 1>{}, i + 1);
+    }
+
+    // ---- the block's sums to its slab: wave (wr, wc), lane (c, h), register e = row (co) 8 (e >> 2) + 4 h + (e & 3), column (ci) c
+    float* const slab = a.slabs + ((size_t)blockIdx.x * gridDim.y + pair) * (16 * 64 * 64);
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = 32 * wr + 8 * (e >> 2) + 4 * h + (e & 3), col = 32 * wc + c;
+            slab[(xi * 64 + row) * 64 + col] = acc[xi][e];
+        }
+    if (a.bslabs != nullptr && cb == 0) {  // every ci block of this co block saw the same dY: the first one reports
+        float2 b = bsum;
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) { b.x += __shfl_xor(b.x, o, 64); b.y += __shfl_xor(b.y, o, 64); }
+        if (tl == 0) {
+            float* const bs = a.bslabs + (size_t)blockIdx.x * a.Co + 64 * cob + 2 * cp;
+            bs[0] = b.x; bs[1] = b.y;
+        }
+    }
+}
+
+// slabs -> dW (Co, Ci, 3, 3): one block per output channel and 16 input channels, thread (xi, ci): the slabs added in slice order,
+// then A^T M A by the 16 threads of xi = 0.  Blocks beyond Co * Ci / 16 reduce the bias slabs (one thread per output channel).
+__global__ void wino_dw_reduce_kernel(float* __restrict__ dw, float* __restrict__ db, const float* __restrict__ slabs, const float* __restrict__ bslabs,
+                                      int Co, int Ci, int slices, int pairs, int cib, int assign, int assign_b) {
+    __shared__ float M[16][17];
+    const int nb = Co * (Ci / 16);
+    if ((int)blockIdx.x >= nb) {
+        const int co = ((int)blockIdx.x - nb) * 256 + threadIdx.x;
+        if (db == nullptr || co >= Co) return;
+        float s = 0.f;
+        for (int sl = 0; sl < slices; ++sl) s += bslabs[(size_t)sl * Co + co];
+        db[co] = assign_b ? s : db[co] + s;
+        return;
+    }
+    const int co = blockIdx.x / (Ci / 16), ci = (blockIdx.x % (Ci / 16)) * 16 + (threadIdx.x & 15), xi = threadIdx.x >> 4;
+    const int pair = (co / 64) * cib + ci / 64;
+    const float* p = slabs + (size_t)pair * (16 * 64 * 64) + ((size_t)xi * 64 + (co % 64)) * 64 + (ci % 64);
+    float s = 0.f;
+    for (int sl = 0; sl < slices; ++sl) s += p[(size_t)sl * pairs * (16 * 64 * 64)];
+    M[xi][threadIdx.x & 15] = s;
+    __syncthreads();
+    if (xi != 0) return;
+    const int l = threadIdx.x & 15;
+    float tm[3][4];  // A^T M
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        tm[0][j] = (M[0 + j][l] + M[4 + j][l]) + M[8 + j][l];
+        tm[1][j] = M[4 + j][l] - M[8 + j][l];
+        tm[2][j] = (M[4 + j][l] + M[8 + j][l]) + M[12 + j][l];
+    }
+    float* o = dw + ((size_t)co * Ci + ci) * 9;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float v0 = (tm[k][0] + tm[k][1]) + tm[k][2], v1 = tm[k][1] - tm[k][2], v2 = (tm[k][1] + tm[k][2]) + tm[k][3];
+        if (assign) { o[3 * k] = v0; o[3 * k + 1] = v1; o[3 * k + 2] = v2; }
+        else { o[3 * k] += v0; o[3 * k + 1] += v1; o[3 * k + 2] += v2; }
+    }
+}
+
+// Host side.  `taken` = false: not a case for this path (the caller goes on to the implicit-GEMM kernel).
+int wino_dw_launch(nk_device* dev, const float* gy, const float* x, float* dw, float* db, int N, int Ci, int Co, int Hs, int Ws, int assign,
+                   int assign_b, double flop, bool* taken) {
+    *taken = false;
+    const int mode = dev->tune_conv_wino_dw;  // -1 rule, 0 never, 1 whenever the shape allows
+    if (mode == 0 || dev->tune_conv_winograd == 0) return NK_OK;
+    const int Hd = Hs - 2, Wd = Ws - 2;
+    if (Hd < 2 || Wd < 2 || Hd % 2 != 0 || Wd % 2 != 0 || Ci % 64 != 0 || Co % 64 != 0) return NK_OK;
+    if (!al16(x) || !al16(gy)) return NK_OK;
+    const long long P = (long long)N * (Hd / 2) * (Wd / 2);
+    const long long x_bytes = (long long)N * Ci * Hs * Ws * 4, gy_bytes = (long long)N * Co * Hd * Wd * 4;
+    if (P >= (1LL << 30) || x_bytes >= 0x7fffffffLL || gy_bytes >= 0x7fffffffLL) return NK_OK;
+    const int pairs = (Co / 64) * (Ci / 64);
+    if (pairs > dev->num_cus) return NK_OK;
+    int slices = dev->num_cus / pairs;                          // one block per CU
+    const long long items_all = (P + WDW_T - 1) / WDW_T;
+    if (slices > items_all) slices = (int)items_all;
+    long long items = (items_all + slices - 1) / slices;
+    items += items & 1;                                         // the item loop is unrolled by two (register sets, LDS images)
+    // by rule: at least 16 items per slice (the slabs and the second kernel are a fixed cost: 256 KB per block)
+    if (mode < 0 && items < 16) return NK_OK;
+    const size_t slab_bytes = round256((size_t)slices * pairs * 16 * 64 * 64 * sizeof(float));
+    void* ws = nullptr;
+    int rc = nk_workspace(dev, slab_bytes + (db ? (size_t)slices * Co * sizeof(float) : 0), &ws);
+    if (rc) return rc;
+    rc = nk_prof_start(dev, NK_KERNEL_CONV, flop);
+    if (rc) return rc;
+    WinoDwArgs a{};
+    a.x = x; a.gy = gy; a.slabs = (float*)ws; a.bslabs = db ? (float*)((char*)ws + slab_bytes) : nullptr;
+    a.N = N; a.Ci = Ci; a.Co = Co; a.Hs = Hs; a.Ws = Ws; a.Hd = Hd; a.Wd = Wd; a.TY = Hd / 2; a.TX = Wd / 2;
+    a.P = (unsigned)P; a.items = (int)items; a.cib = Ci / 64;
+    wino_magic((unsigned)(a.TY * a.TX), &a.per_m, &a.per_s1, &a.per_s2);
+    wino_magic((unsigned)a.TX, &a.tx_m, &a.tx_s1, &a.tx_s2);
+    a.x_bytes = (int)x_bytes; a.gy_bytes = (int)gy_bytes;
+    hipLaunchKernelGGL(wino_dw_kernel, dim3((unsigned)slices, (unsigned)pairs), dim3(256), 0, dev->compute, a);
+    NK_LAUNCH_CHECK();
+    const int nb = Co * (Ci / 16) + (db ? (Co + 255) / 256 : 0);
+    hipLaunchKernelGGL(wino_dw_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, dev->compute, dw, db, (const float*)a.slabs, (const float*)a.bslabs, Co,
+                       Ci, slices, pairs, Ci / 64, assign, assign_b);
+    NK_LAUNCH_CHECK();
+    *taken = true;
+    ++dev->wino_launches;
+    return nk_prof_stop(dev);
+}

@@ -191,11 +191,13 @@ int nk_dev_tune(nk_device* dev, int knob, const int* values, int n) {
             dev->tune_conv_narrow = n ? values[0] : -1;
             return NK_OK;
         case NK_TUNE_CONV_WINOGRAD:
-            NK_CHECK(n <= 3 && (n == 0 || (values[0] >= -1 && values[0] <= 1)) && (n < 2 || values[1] >= -1) && (n < 3 || (values[2] >= -1 && values[2] <= 1)),
-                     "NK_TUNE_CONV_WINOGRAD: -1, 0 or 1[, stagger >= -1[, block shape -1, 0 or 1]]");
+            NK_CHECK(n <= 4 && (n == 0 || (values[0] >= -1 && values[0] <= 1)) && (n < 2 || values[1] >= -1) && (n < 3 || (values[2] >= -1 && values[2] <= 1)) &&
+                         (n < 4 || (values[3] >= -1 && values[3] <= 1)),
+                     "NK_TUNE_CONV_WINOGRAD: -1, 0 or 1[, stagger >= -1[, block shape -1, 0 or 1[, kernel gradient -1, 0 or 1]]]");
             dev->tune_conv_winograd = n ? values[0] : -1;
             dev->tune_conv_wino_stagger = n >= 2 ? values[1] : -1;
             dev->tune_conv_wino_shape = n >= 3 ? values[2] : -1;
+            dev->tune_conv_wino_dw = n >= 4 ? values[3] : -1;
             return NK_OK;
         case NK_TUNE_ATTENTION_OCC:
             NK_CHECK(n <= 1 && (n == 0 || values[0] == 0 || values[0] == 2), "NK_TUNE_ATTENTION_OCC: 0 or 2");

@@ -143,3 +143,72 @@ def test_winograd_rule_and_knob(dev):
                         (rnd(1, (2, 128, 10, 10)), rnd(2, (128, 64, 3, 3), -1, 1), (1, 1), 2),
                         (rnd(1, (2, 40, 10, 10)), rnd(2, (128, 40, 3, 3), -1, 1), (1, 1), 1)):
         assert np.array_equal(fwd(x, wk, s, g, 1), fwd(x, wk, s, g, 0))
+
+
+# ---- the kernel gradient, F(3x3, 2x2) (nk_conv_winograd_dw.h) -------------------------------------------------------------------------
+# N, Cin, Cout, H, W of the (already padded) input
+DW_SHAPES = [
+    (2, 64, 64, 10, 10),       # 32 tiles: 4 items, one (co, ci) block pair
+    (3, 64, 128, 8, 14),       # 54 tiles (a partly filled last item), two co blocks
+    (1, 128, 64, 12, 12),      # two ci blocks (the bias gradient is reported by the first only)
+    (2, 128, 128, 6, 20),      # four block pairs
+    (5, 64, 64, 6, 6),         # 20 tiles
+    (6, 64, 128, 58, 58),      # the C3 plane: 4704 tiles over 128 slices (ragged slices, an all-empty item at the end of each)
+]
+
+
+def run_dw(dev, x, go, dw0, db0, mode):
+    c = capi()
+    dev.conv_winograd(1 if mode else 0, None, None, mode)
+    try:
+        X, G = dev.array(x), dev.array(go)
+        DW, DWa, DWb, DB = dev.array(dw0), dev.full(dw0.shape, np.nan), dev.array(dw0), dev.array(db0)
+        DWc, DBc = dev.full(dw0.shape, np.nan), dev.full(db0.shape, np.nan)
+        c.conv_bwd_kernel(dev, DW, G, X, (1, 1), (1, 1), 1)
+        c.conv_bwd_kernel(dev, DWa, G, X, (1, 1), (1, 1), 1, assign=True)
+        c.conv_bwd_kernel_bias(dev, DWb, DB, G, X, (1, 1), (1, 1), 1)
+        c.conv_bwd_kernel_bias(dev, DWc, DBc, G, X, (1, 1), (1, 1), 1, assign=(True, True))
+        return [a.numpy() for a in (DW, DWa, DWb, DB, DWc, DBc)]
+    finally:
+        dev.conv_winograd(None)
+
+
+def test_kernel_gradient_transform_matrices():
+    """F(3x3, 2x2): A^T [(G g G^T) . (B^T d B)] A equals the nine direct sums for a 2x2 tile of dY on a 4x4 patch (the matrices of
+    nk_conv_winograd_dw.h, restated here)."""
+    AT = np.array([[1, 1, 1, 0], [0, 1, -1, 0], [0, 1, 1, 1]], float)
+    G = np.array([[1, 0], [.5, .5], [.5, -.5], [0, 1]], float)
+    BT = np.array([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, -1, 0, 1]], float)
+    rng = np.random.default_rng(0)
+    g, d = rng.integers(-4, 5, (2, 2)).astype(float), rng.integers(-4, 5, (4, 4)).astype(float)
+    want = np.array([[sum(g[a, b] * d[a + k, b + l] for a in range(2) for b in range(2)) for l in range(3)] for k in range(3)])
+    assert np.array_equal(AT @ ((G @ g @ G.T) * (BT @ d @ BT.T)) @ AT.T, want)
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W", DW_SHAPES)
+def test_winograd_kernel_gradient_equals_direct_exactly_on_integer_data(dev, N, Cin, Cout, H, W):
+    x, go = ints(1, (N, Cin, H, W), -3, 3), ints(4, (N, Cout, H - 2, W - 2), -2, 2)
+    dw0, db0 = ints(5, (Cout, Cin, 3, 3), -5, 5), ints(6, (Cout, 1, 1), -5, 5)
+    wino, direct, again = run_dw(dev, x, go, dw0, db0, 1), run_dw(dev, x, go, dw0, db0, 0), run_dw(dev, x, go, dw0, db0, 1)
+    for name, a, d, r in zip(("dw+=", "dw=", "dw+= (with db)", "db+=", "dw= (with db)", "db="), wino, direct, again):
+        assert np.array_equal(a, d), name
+        assert np.array_equal(a, r), name
+    dw = dw0.copy(); O.convolution_backward_kernel(dw, go, x, (1, 1), (1, 1), 1)
+    assert np.array_equal(wino[0], dw) and np.array_equal(wino[1], dw - dw0)
+    assert np.array_equal(wino[3], db0 + go.sum(axis=(0, 2, 3)).reshape(db0.shape))
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W", DW_SHAPES[:5])
+def test_winograd_kernel_gradient_random_inside_the_contraction_bound(dev, N, Cin, Cout, H, W):
+    from tolerance import assert_contraction
+    x, go = rnd(1, (N, Cin, H, W)), rnd(4, (N, Cout, H - 2, W - 2))
+    dw0, db0 = rnd(5, (Cout, Cin, 3, 3)), rnd(6, (Cout, 1, 1))
+    wino, direct = run_dw(dev, x, go, dw0, db0, 1), run_dw(dev, x, go, dw0, db0, 0)
+    d64 = np.zeros(dw0.shape); O.convolution_backward_kernel(d64, go.astype(np.float64), x.astype(np.float64), (1, 1), (1, 1), 1)
+    d32 = np.zeros(dw0.shape, np.float32); O.convolution_backward_kernel(d32, go, x, (1, 1), (1, 1), 1)
+    K = N * (H - 2) * (W - 2)
+    for name, w, d, ref, cpu in (("dw+=", wino[0], direct[0], dw0 + d64, dw0 + d32), ("dw=", wino[1], direct[1], d64, d32)):
+        assert_contraction("winograd:" + name, w, ref, K, 1.0, 1.0, cpu32=cpu)
+        assert_contraction("direct (same cases):" + name, d, ref, K, 1.0, 1.0, cpu32=cpu)
+    b64 = go.astype(np.float64).sum(axis=(0, 2, 3)).reshape(db0.shape)
+    np.testing.assert_allclose(wino[5], b64, rtol=1e-5, atol=1e-6 * K)
