@@ -56,7 +56,16 @@ __global__ __launch_bounds__(256, 1) void wino_dw_kernel(WinoDwArgs a) {
     const int plane = a.Hs * a.Ws, oplane = a.Hd * a.Wd;
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.gy, 0, a.gy_bytes, 0x00020000);
-    const int ws4 = a.Ws * 4, wd4 = a.Wd * 4, plane4 = plane * 4, oplane4 = oplane * 4;
+    // scalar offsets of the twelve loads of an item, made PROVABLY wave-uniform once (readfirstlane): left as expressions of the
+    // kernel arguments the compiler kept some of them in vector registers and wrapped those loads in waterfall loops
+    int xso[2][4], yso[2][2];
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xso[ch][i] = __builtin_amdgcn_readfirstlane((ch * plane + i * a.Ws) * 4);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) yso[ch][r] = __builtin_amdgcn_readfirstlane((ch * oplane + r * a.Wd) * 4);
+    }
 
     // loaded, not yet transformed operands of one item: two register sets (loads run two items ahead)
     wino_u2 xr[2][2][4][2];  // [set][channel of the pair][patch row][columns 0-1 / 2-3]
@@ -64,34 +73,40 @@ __global__ __launch_bounds__(256, 1) void wino_dw_kernel(WinoDwArgs a) {
     float2 bsum = make_float2(0.f, 0.f);  // bias gradient of this thread's two output channels over its tiles
 
     const unsigned tile0 = (unsigned)blockIdx.x * (unsigned)a.items * WDW_T;
-    auto load = [&](auto set, int item) {
-        constexpr int S = decltype(set)::value;
+    // the twelve loads of an item (8 patch rows of 16 bytes, 4 tile rows of 8), issued ONE AT A TIME between MFMA groups: as a burst
+    // at the top of the item the four waves' 48 instructions fill the address unit's queue and every wave waits for its turn with the
+    // matrix pipe idle - 1.1 us of a 3.1 us item
+    unsigned xo = 0x80000000u, yo = 0x80000000u;
+    auto address = [&](int item) {
         const unsigned p = tile0 + (unsigned)item * WDW_T + tl;
         const bool valid = item < a.items && p < a.P;
         const unsigned pv = valid ? p : 0u;
         const unsigned n = wino_div(pv, a.per_m, a.per_s1, a.per_s2), rem = pv - n * (unsigned)(a.TY * a.TX);
         const unsigned ty = wino_div(rem, a.tx_m, a.tx_s1, a.tx_s2), tx = rem - ty * (unsigned)a.TX;
-        const unsigned xo = valid ? (unsigned)(((int)n * a.Ci + 64 * cb + 2 * cp) * plane + 2 * (int)ty * a.Ws + 2 * (int)tx) * 4u : 0x80000000u;
-        const unsigned yo = valid ? (unsigned)(((int)n * a.Co + 64 * cob + 2 * cp) * oplane + 2 * (int)ty * a.Wd + 2 * (int)tx) * 4u : 0x80000000u;
-#pragma unroll
-        for (int ch = 0; ch < 2; ++ch) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                xr[S][ch][i][0] = __builtin_amdgcn_raw_buffer_load_b64(xrs, xo, ch * plane4 + i * ws4, 0);
-                xr[S][ch][i][1] = __builtin_amdgcn_raw_buffer_load_b64(xrs, xo + 8, ch * plane4 + i * ws4, 0);
-            }
-#pragma unroll
-            for (int r = 0; r < 2; ++r) yr[S][ch][r] = __builtin_amdgcn_raw_buffer_load_b64(yrs, yo, ch * oplane4 + r * wd4, 0);
+        xo = valid ? (unsigned)(((int)n * a.Ci + 64 * cb + 2 * cp) * plane + 2 * (int)ty * a.Ws + 2 * (int)tx) * 4u : 0x80000000u;
+        yo = valid ? (unsigned)(((int)n * a.Co + 64 * cob + 2 * cp) * oplane + 2 * (int)ty * a.Wd + 2 * (int)tx) * 4u : 0x80000000u;
+    };
+    auto load_one = [&](auto set, int k) {  // k = 0..11, compile-time at every call site
+        constexpr int S = decltype(set)::value;
+        if (k < 8) {
+            const int ch = k >> 2, i = k & 3;
+            xr[S][ch][i][0] = __builtin_amdgcn_raw_buffer_load_b64(xrs, xo, xso[ch][i], 0);
+            xr[S][ch][i][1] = __builtin_amdgcn_raw_buffer_load_b64(xrs, xo + 8, xso[ch][i], 0);
+        } else {
+            const int ch = (k - 8) >> 1, r = (k - 8) & 1;
+            yr[S][ch][r] = __builtin_amdgcn_raw_buffer_load_b64(yrs, yo, yso[ch][r], 0);
         }
     };
-    // transform of a loaded item into the images `xs`, `ys`: thread = (tile tl, channel pair cp); element (xi, channel quad cp / 2,
-    // tile, channels 2 (cp % 2), + 1) as one float2
-    auto transform = [&](auto set, float* xs, float* ys) {
+    auto load = [&](auto set, int item) {
+        address(item);
+#pragma unroll
+        for (int k = 0; k < 12; ++k) load_one(set, k);
+    };
+    // transform of a loaded item, in two steps: `compute` (registers only: the 16 + 16 xi values of the thread's tile and channel
+    // pair) and the stores, element (xi, channel quad cp / 2, tile, channels 2 (cp % 2), + 1) as one float2 each
+    float xv[2][16], yv[2][16];
+    auto compute = [&](auto set) {
         constexpr int S = decltype(set)::value;
-        float2* const xw = reinterpret_cast<float2*>(xs + (cp >> 1) * WDW_CQ + tl * 4 + 2 * (cp & 1));
-        float2* const yw = reinterpret_cast<float2*>(ys + (cp >> 1) * WDW_CQ + tl * 4 + 2 * (cp & 1));
-        constexpr int XI = 16 * WDW_CQ / 2;  // float2 step from xi to xi + 1
-        float xv[2][16], yv[2][16];
 #pragma unroll
         for (int ch = 0; ch < 2; ++ch) {
             float d[4][4];
@@ -116,8 +131,6 @@ __global__ __launch_bounds__(256, 1) void wino_dw_kernel(WinoDwArgs a) {
                 xv[ch][4 * i + 3] = tt[i][3] - tt[i][1];
             }
             const float2 r0 = __builtin_bit_cast(float2, yr[S][ch][0]), r1 = __builtin_bit_cast(float2, yr[S][ch][1]);
-            if (ch == 0) bsum.x += (r0.x + r0.y) + (r1.x + r1.y);
-            else bsum.y += (r0.x + r0.y) + (r1.x + r1.y);
             float g[4][2];  // G dy
             g[0][0] = r0.x; g[0][1] = r0.y;
             g[1][0] = 0.5f * (r0.x + r1.x); g[1][1] = 0.5f * (r0.y + r1.y);
@@ -131,11 +144,15 @@ __global__ __launch_bounds__(256, 1) void wino_dw_kernel(WinoDwArgs a) {
                 yv[ch][4 * i + 3] = g[i][1];
             }
         }
-#pragma unroll
-        for (int xi = 0; xi < 16; ++xi) {
-            xw[xi * XI] = make_float2(xv[0][xi], xv[1][xi]);
-            yw[xi * XI] = make_float2(yv[0][xi], yv[1][xi]);
-        }
+        // the bias gradient rides on the transform: element (1, 1) of G dy G^T is a quarter of the tile's sum (exact scaling)
+        bsum.x += yv[0][5];
+        bsum.y += yv[1][5];
+    };
+    constexpr int XI = 16 * WDW_CQ / 2;  // float2 step from xi to xi + 1
+    const int woff = (cp >> 1) * WDW_CQ + tl * 4 + 2 * (cp & 1);
+    auto store = [&](int xi, float* xs, float* ys) {
+        reinterpret_cast<float2*>(xs + woff)[xi * XI] = make_float2(xv[0][xi], xv[1][xi]);
+        reinterpret_cast<float2*>(ys + woff)[xi * XI] = make_float2(yv[0][xi], yv[1][xi]);
     };
 
     nkmma::f32x16 acc[16];
@@ -147,7 +164,9 @@ __global__ __launch_bounds__(256, 1) void wino_dw_kernel(WinoDwArgs a) {
     // ---- prologue: item 0 transformed into image 0, item 1 loaded
     load(std::integral_constant<int, 0>{}, 0);
     load(std::integral_constant<int, 1>{}, 1);
-    transform(std::integral_constant<int, 0>{}, XS, YS);
+    compute(std::integral_constant<int, 0>{});
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi) store(xi, XS, YS);
     __syncthreads();
 
     // the MFMAs of item i on image `cur`, with: the loads of item i + 2 into register set `set` (item i's own, already transformed),
@@ -157,22 +176,36 @@ __global__ __launch_bounds__(256, 1) void wino_dw_kernel(WinoDwArgs a) {
         // lane (c, h): A = DY^[xi][co = 32 wr + c][tile 2 s + h], B = X^[xi][tile 2 s + h][ci = 32 wc + c], s = 0..3
         const float* const ya = YS + S * WDW_IMG + ((32 * wr + c) >> 2) * WDW_CQ + (c & 3) + 4 * h;
         const float* const xb = XS + S * WDW_IMG + ((32 * wc + c) >> 2) * WDW_CQ + (c & 3) + 4 * h;
-        load(set, i + 2);
-        __builtin_amdgcn_sched_barrier(0);
+        float* const xn = XS + (S ^ 1) * WDW_IMG;
+        float* const yn = YS + (S ^ 1) * WDW_IMG;
+        address(i + 2);
         float av[2][4], bv[2][4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) { av[0][s] = ya[8 * s]; bv[0][s] = xb[8 * s]; }
+        // the next item's transform arithmetic FIRST (its loads are a whole item old): f32 VALU work cannot overlap the f32 MFMAs
+        // anyway, here it fills the wait for the item's first fragments after the barrier; the stores follow inside the MFMA groups
+        compute(std::integral_constant<int, S ^ 1>{});
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int xi = 0; xi < 16; ++xi) {
             if (xi + 1 < 16) {
 #pragma unroll
                 for (int s = 0; s < 4; ++s) { av[(xi + 1) & 1][s] = ya[(xi + 1) * 16 * WDW_CQ + 8 * s]; bv[(xi + 1) & 1][s] = xb[(xi + 1) * 16 * WDW_CQ + 8 * s]; }
             }
+            store(xi, xn, yn);
+            if (xi < 12) load_one(set, xi);  // item i + 2 into the register set item i was transformed out of
 #pragma unroll
             for (int s = 0; s < 4; ++s) acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[xi & 1][s], bv[xi & 1][s], acc[xi], 0, 0, 0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // LDS read (the next xi's fragments)
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // LDS write (the next item's images)
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // buffer load
+                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);  // VALU
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        // the next item's transform: its loads are a whole item old
-        transform(std::integral_constant<int, S ^ 1>{}, XS + (S ^ 1) * WDW_IMG, YS + (S ^ 1) * WDW_IMG);
         __syncthreads();
     };
     for (int i = 0; i < a.items; i += 2) {
@@ -195,40 +228,61 @@ __global__ __launch_bounds__(256, 1) void wino_dw_kernel(WinoDwArgs a) {
         for (int o = 1; o < 8; o <<= 1) { b.x += __shfl_xor(b.x, o, 64); b.y += __shfl_xor(b.y, o, 64); }
         if (tl == 0) {
             float* const bs = a.bslabs + (size_t)blockIdx.x * a.Co + 64 * cob + 2 * cp;
-            bs[0] = b.x; bs[1] = b.y;
+            bs[0] = 4.f * b.x; bs[1] = 4.f * b.y;
         }
     }
 }
 
-// slabs -> dW (Co, Ci, 3, 3): one block per output channel and 16 input channels, thread (xi, ci): the slabs added in slice order,
-// then A^T M A by the 16 threads of xi = 0.  Blocks beyond Co * Ci / 16 reduce the bias slabs (one thread per output channel).
-__global__ void wino_dw_reduce_kernel(float* __restrict__ dw, float* __restrict__ db, const float* __restrict__ slabs, const float* __restrict__ bslabs,
-                                      int Co, int Ci, int slices, int pairs, int cib, int assign, int assign_b) {
-    __shared__ float M[16][17];
-    const int nb = Co * (Ci / 16);
+// slabs -> dW (Co, Ci, 3, 3).  One block of 1024 threads per (output channel, block of 64 input channels): thread (quarter q of the
+// slices, xi, four input channels) adds its quarter's slabs in slice order (float4 loads, whole 256-byte rows per 16 lanes, eight in
+// flight), the quarters meet in LDS and 64 threads add them in order and apply A^T . A.  (First form: 256 threads = 16 xi x 16 input
+// channels, one chain over all slices per thread - 64-byte row pieces and one to eight loads in flight: 36 - 42 us for the 64 MB of
+// C3's slabs.)  Blocks beyond Co * Ci / 64 reduce the bias slabs (one thread per output channel).
+__global__ __launch_bounds__(1024) void wino_dw_reduce_kernel(float* __restrict__ dw, float* __restrict__ db, const float* __restrict__ slabs,
+                                                               const float* __restrict__ bslabs, int Co, int Ci, int slices, int pairs, int cib,
+                                                               int assign, int assign_b) {
+    __shared__ __attribute__((aligned(16))) float M[4][16][64];
+    const int nb = Co * (Ci / 64);
     if ((int)blockIdx.x >= nb) {
-        const int co = ((int)blockIdx.x - nb) * 256 + threadIdx.x;
+        const int co = ((int)blockIdx.x - nb) * 1024 + threadIdx.x;
         if (db == nullptr || co >= Co) return;
         float s = 0.f;
         for (int sl = 0; sl < slices; ++sl) s += bslabs[(size_t)sl * Co + co];
         db[co] = assign_b ? s : db[co] + s;
         return;
     }
-    const int co = blockIdx.x / (Ci / 16), ci = (blockIdx.x % (Ci / 16)) * 16 + (threadIdx.x & 15), xi = threadIdx.x >> 4;
-    const int pair = (co / 64) * cib + ci / 64;
-    const float* p = slabs + (size_t)pair * (16 * 64 * 64) + ((size_t)xi * 64 + (co % 64)) * 64 + (ci % 64);
-    float s = 0.f;
-    for (int sl = 0; sl < slices; ++sl) s += p[(size_t)sl * pairs * (16 * 64 * 64)];
-    M[xi][threadIdx.x & 15] = s;
+    const int co = blockIdx.x / (Ci / 64), cb = blockIdx.x % (Ci / 64);
+    const int q = threadIdx.x >> 8, xi = (threadIdx.x >> 4) & 15, c4 = threadIdx.x & 15;
+    const int pair = (co / 64) * cib + cb;
+    const size_t sstep = (size_t)pairs * (16 * 64 * 64);
+    const float* p = slabs + (size_t)pair * (16 * 64 * 64) + ((size_t)xi * 64 + (co % 64)) * 64 + 4 * c4;
+    const int per = (slices + 3) / 4, s0 = q * per, s1 = s0 + per < slices ? s0 + per : slices;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    int sl = s0;
+    for (; sl + 16 <= s1; sl += 16) {
+        float4 v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = *reinterpret_cast<const float4*>(p + (size_t)(sl + u) * sstep);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+    }
+    for (; sl < s1; ++sl) {
+        const float4 v = *reinterpret_cast<const float4*>(p + (size_t)sl * sstep);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    *reinterpret_cast<float4*>(&M[q][xi][4 * c4]) = s;
     __syncthreads();
-    if (xi != 0) return;
-    const int l = threadIdx.x & 15;
+    if (threadIdx.x >= 64) return;
+    const int l = threadIdx.x, ci = 64 * cb + l;
+    float m[16];
+#pragma unroll
+    for (int x = 0; x < 16; ++x) m[x] = ((M[0][x][l] + M[1][x][l]) + M[2][x][l]) + M[3][x][l];
     float tm[3][4];  // A^T M
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        tm[0][j] = (M[0 + j][l] + M[4 + j][l]) + M[8 + j][l];
-        tm[1][j] = M[4 + j][l] - M[8 + j][l];
-        tm[2][j] = (M[4 + j][l] + M[8 + j][l]) + M[12 + j][l];
+        tm[0][j] = (m[0 + j] + m[4 + j]) + m[8 + j];
+        tm[1][j] = m[4 + j] - m[8 + j];
+        tm[2][j] = (m[4 + j] + m[8 + j]) + m[12 + j];
     }
     float* o = dw + ((size_t)co * Ci + ci) * 9;
 #pragma unroll
@@ -275,8 +329,8 @@ int wino_dw_launch(nk_device* dev, const float* gy, const float* x, float* dw, f
     a.x_bytes = (int)x_bytes; a.gy_bytes = (int)gy_bytes;
     hipLaunchKernelGGL(wino_dw_kernel, dim3((unsigned)slices, (unsigned)pairs), dim3(256), 0, dev->compute, a);
     NK_LAUNCH_CHECK();
-    const int nb = Co * (Ci / 16) + (db ? (Co + 255) / 256 : 0);
-    hipLaunchKernelGGL(wino_dw_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, dev->compute, dw, db, (const float*)a.slabs, (const float*)a.bslabs, Co,
+    const int nb = Co * (Ci / 64) + (db ? (Co + 1023) / 1024 : 0);
+    hipLaunchKernelGGL(wino_dw_reduce_kernel, dim3((unsigned)nb), dim3(1024), 0, dev->compute, dw, db, (const float*)a.slabs, (const float*)a.bslabs, Co,
                        Ci, slices, pairs, Ci / 64, assign, assign_b);
     NK_LAUNCH_CHECK();
     *taken = true;
