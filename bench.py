@@ -428,11 +428,11 @@ def measure_conv(dist, tdev, cdev, steps, warmup):
 
     wino_before = cdev.conv_winograd_launches()
     dt, ev_ms, _, conv_stats = timed_steps(dist, tdev, cdev, step, steps, warmup)
-    wino = cdev.conv_winograd_launches() > wino_before
+    wino = cdev.conv_winograd_launches() - wino_before >= 3        # forward, input gradient and kernel gradient all took it
     direct = 2.0 * N * 128 * 56 * 56 * 64 * 9                       # one pass, node/convolution/mod.rs:85-123
-    executed = direct + 2 * direct * (16.0 / 36.0 if wino else 1.0)  # F(2x2, 3x3): 16 multiplies per 2x2 outputs and channel pair instead of 36
-    kernels = ("wino_kernel<4,1,32> (forward) / wino_kernel<2,1,16> (input gradient): Winograd F(2x2, 3x3) on f32 MFMA; conv_bwd_kernel "
-               "(kernel gradient): implicit GEMM, f32 MFMA") if wino else \
+    executed = 3 * direct * (16.0 / 36.0 if wino else 1.0)  # F(2x2, 3x3) / F(3x3, 2x2): 16 multiplies per 2x2 tile and channel pair instead of 36
+    kernels = ("wino_kernel<4,1,32> (forward) / wino_kernel<2,1,16> (input gradient): Winograd F(2x2, 3x3); wino_dw_kernel (kernel gradient): "
+               "Winograd F(3x3, 2x2) - all on f32 MFMA") if wino else \
         "conv_fwd_fast / conv_bwd_input_fast / conv_bwd_kernel (implicit GEMM, f32 MFMA)"
     roof = roofline_mfma(conv_stats, kernels, "conv")
     # `achieved` / `frac` are quoted on the DIRECT algorithmic flops of the three passes (what the reference's im2col GEMMs

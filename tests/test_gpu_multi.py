@@ -132,7 +132,10 @@ def test_bench_default_line_carries_every_baseline_config():
         rec = res[key]
         assert rec["unit"] == unit and rec["value"] > 0 and rec["ms_per_step"] > 0 and rec["steps"] == 20, key
         roof = rec["roofline"]
-        assert 0 < roof["frac"] < 1 and roof["launches"] > 0 and roof["avg_launch_ms"] > 0 and roof["achieved"] > 0, key
+        # (C3 with the Winograd kernels: `frac` is quoted on the DIRECT algorithmic flops - SURVEY.md 8d - and may exceed 1; the flops the
+        # launches execute are priced beside it and stay below the peak)
+        below_peak = roof["executed_frac"] if roof.get("winograd") else roof["frac"]
+        assert 0 < below_peak < 1 and roof["frac"] > 0 and roof["launches"] > 0 and roof["avg_launch_ms"] > 0 and roof["achieved"] > 0, key
     assert res["matmul_4096"]["roofline"]["launches"] == 3 * 20
     assert res["conv_c3"]["roofline"]["launches"] == 3 * 20           # one launch record per conv pass
     att = res["mha_c5"]["attention_core"]
