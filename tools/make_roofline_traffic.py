@@ -73,7 +73,7 @@ def main():
         # in its line whether `roofline.traffic` still belongs to them
         "_kernel_sources_sha16": kernel_sources_sha16(),
         "sgemm_kernel": family("gemm_once", lambda k: k.startswith(("sgemm_kernel", "sgemm_pair_kernel"))),
-        "conv": family("conv_step_once", lambda k: k.startswith(("conv_fwd_fast", "conv_bwd_input_fast", "conv_bwd_kernel_kernel", "conv_bwd_kernel_mixed_kernel"))),
+        "conv": family("conv_step_once", lambda k: k.startswith(("conv_fwd_fast", "conv_bwd_input_fast", "conv_bwd_kernel_kernel", "conv_bwd_kernel_mixed_kernel", "wino_kernel", "wino_dw_kernel"))),
         "mha_gemm": family("mha_step_once", lambda k: k.startswith(("sgemm_kernel", "sgemm_pair_kernel"))),
         "attention": family("mha_step_once", lambda k: k.startswith("attention_kernel")),
     }
