@@ -9,7 +9,11 @@ oracle: 3 x 3 / stride 1 / dilation 1 / one group, even output extents, channel 
   * tile counts that do not fill the last block, several chunks of reduction channels, several blocks of output channels,
     image borders (the folded padding reads zeros outside the gradient);
   * the rule (by block count) and the knob NK_TUNE_CONV_WINOGRAD = 0 / 1;
-  * run to run identical."""
+  * run to run identical.
+
+Second half of the file: the kernel gradient as F(3x3, 2x2) (nk_conv_winograd_dw.h) - its transform matrices against the nine direct
+sums, dW (+= and =) and db bit-equal to the implicit-GEMM pass and the oracle on integer data over slice counts that leave ragged and
+empty items, random data inside the contraction bound (K = N * Ho * Wo)."""
 import numpy as np
 import pytest
 
