@@ -1287,3 +1287,52 @@ def test_mha_strided_heads_equals_split_merge(nk, tdev):
     assert outs[0][-1] == outs[1][-1] - 4                      # 3 split + 1 merge nodes gone
     for a, b in zip(outs[0][:-1], outs[1][:-1]):
         assert np.array_equal(a, b)
+
+
+def test_conv2d_module_at_a_size_the_winograd_rule_takes(nk, tdev):
+    """nn::Conv2d (3 x 3, pad 1) through the tape at 48 x 64 x 56 x 56 -> 128 channels: by rule all three passes take the Winograd
+    kernels (nk_conv_bias_fwd, nk_conv_bwd_input_padded, nk_conv_bwd_kernel_bias - the launch counter says so); the same step with the
+    knob at 0 runs the implicit-GEMM kernels.  Both against f64 direct sums at sampled positions, and against each other inside the
+    contraction bound (the two orders of summation differ)."""
+    from neuronika_amd import capi
+    cdev = capi.Device(handle=tdev.raw())
+    N, Cin, Cout, H = 48, 64, 128, 56
+    x, gy = rnd(0, (N, Cin, H, H)), rnd(2, (N, Cout, H, H))
+    got = {}
+    for mode in (None, 0):
+        cdev.conv_winograd(mode)
+        try:
+            conv = nk.nn.Conv2d(tdev, Cin, Cout, [3, 3], [1, 1], nk.PaddingMode.zero(), [1, 1], [1, 1], 1)
+            X = nk.from_ndarray(tdev, x).requires_grad()
+            y = conv.forward(X)
+            before = cdev.conv_winograd_launches()
+            y.forward()
+            y.backward_from(nk.from_ndarray(tdev, gy))
+            took = cdev.conv_winograd_launches() - before
+            got[mode] = (y.data(), X.grad(), conv.weight.grad(), conv.bias.grad(), conv.weight.data(), conv.bias.data(), took)
+        finally:
+            cdev.conv_winograd(None)
+    assert got[None][6] == 3 and got[0][6] == 0                       # forward, input gradient, kernel gradient
+    w, b = got[None][4], got[None][5]
+    assert np.array_equal(w, got[0][4]) and np.array_equal(b, got[0][5])   # same seed, same parameters
+    xp = np.zeros((N, Cin, H + 2, H + 2), np.float64); xp[:, :, 1:-1, 1:-1] = x
+    w64, g64 = w.astype(np.float64), gy.astype(np.float64)
+    rng = np.random.default_rng(5)
+    for mode in (None, 0):
+        y, dx, dw, db = got[mode][:4]
+        for n, co, oh, ow in zip(rng.integers(0, N, 24), rng.integers(0, Cout, 24), rng.integers(0, H, 24), rng.integers(0, H, 24)):
+            ref = (xp[n, :, oh:oh + 3, ow:ow + 3] * w64[co]).sum() + float(b[co, 0, 0])
+            assert abs(y[n, co, oh, ow] - ref) <= 1e-6 * 576, (mode, n, co, oh, ow)
+        for n, ci, ih, iw in zip(rng.integers(0, N, 24), rng.integers(0, Cin, 24), rng.integers(0, H, 24), rng.integers(0, H, 24)):
+            ref = 0.0
+            for kh in range(3):
+                for kw in range(3):
+                    oh, ow = ih + 1 - kh, iw + 1 - kw
+                    if 0 <= oh < H and 0 <= ow < H:
+                        ref += (g64[n, :, oh, ow] * w64[:, ci, kh, kw]).sum()
+            assert abs(dx[n, ci, ih, iw] - ref) <= 1e-6 * 1152, (mode, n, ci, ih, iw)
+        for co, ci, kh, kw in zip(rng.integers(0, Cout, 8), rng.integers(0, Cin, 8), rng.integers(0, 3, 8), rng.integers(0, 3, 8)):
+            ref = (g64[:, co] * xp[:, ci, kh:kh + H, kw:kw + H]).sum()
+            assert abs(dw[co, ci, kh, kw] - ref) <= 2e-7 * N * H * H * 0.5, (mode, co, ci, kh, kw)
+        np.testing.assert_allclose(db.reshape(-1), g64.sum(axis=(0, 2, 3)), rtol=2e-6)
+    assert not np.array_equal(got[None][0], got[0][0])                # two algorithms, two orders of summation
