@@ -275,6 +275,22 @@ int nk_conv_bias_fwd(nk_device* dev, int nd, const float* x, const int* x_shape,
 int nk_conv_bwd_kernel_bias(nk_device* dev, int nd, float* dw, float* db, const int* w_shape, const float* g,
                             const float* x, const int* x_shape, const int* stride, const int* dilation, int groups,
                             int assign_dw, int assign_db);
+/* The `Conv2d` module (lib.rs:724-812: pad -> convolution -> + bias) with Zero padding FOLDED INTO the forward and the kernel-gradient
+ * pass: `x` / `x_shape` are the UNPADDED input, `padding[i]` the symmetric zero padding of spatial axis i; the padded copy (Pad::forward,
+ * pad/zero/mod.rs:5-31 - 110 MB and a 40 us kernel at C3) is never made.  Only the Winograd kernels read their operands through
+ * out-of-range-is-zero buffer loads, so only their geometries fold: 3 x 3, stride 1, dilation 1, one group, padding 0 or 1 per axis (not
+ * all zero), 64 | both channel counts, even output extents.  nk_conv_padding_folds answers, for a geometry and the rules in force on the
+ * handle, whether BOTH passes would run their Winograd kernels anyway (*folds = 1: build the module node without the Pad node and
+ * call the two `_padded` entries; 0: pad, then nk_conv_bias_fwd / nk_conv_bwd_kernel_bias).  The `_padded` entries themselves take every
+ * geometry the kernels can (whatever the block-count rules say) and return NK_ERR_UNSUPPORTED for the others.  Same values as the
+ * two-node form, bit for bit (zeros are read instead of stored).  bias / db may be NULL.  The input gradient's padded form is below. */
+int nk_conv_padding_folds(nk_device* dev, int nd, const int* x_shape, const int* padding, const int* w_shape, const int* stride,
+                          const int* dilation, int groups, int* folds);
+int nk_conv_bias_fwd_padded(nk_device* dev, int nd, const float* x, const int* x_shape, const int* padding, const float* w,
+                            const int* w_shape, const float* bias, float* y, const int* stride, const int* dilation, int groups);
+int nk_conv_bwd_kernel_bias_padded(nk_device* dev, int nd, float* dw, float* db, const int* w_shape, const float* g, const float* x,
+                                   const int* x_shape, const int* padding, const int* stride, const int* dilation, int groups,
+                                   int assign_dw, int assign_db);
 /* `Conv{1,2,3}d` module backward towards its input when the module's padding mode is Zero (lib.rs:630-916: pad ->
  * convolution): ConvolutionBackwardInput (convolution/mod.rs:146-189) followed by PadBackward (pad/mod.rs:131-181, the
  * centre block of the padded gradient is accumulated into dx) as ONE kernel.  x_shape is the UNPADDED input

@@ -106,6 +106,9 @@ _SIGS = {
     "nk_conv_bwd_input_padded_assign": [VP, C.c_int, VP, c_intp, c_intp, VP, VP, c_intp, c_intp, c_intp, C.c_int],
     "nk_conv_bwd_kernel": [VP, C.c_int, VP, c_intp, VP, VP, c_intp, c_intp, c_intp, C.c_int],
     "nk_conv_bwd_kernel_bias": [VP, C.c_int, VP, VP, c_intp, VP, VP, c_intp, c_intp, c_intp, C.c_int, C.c_int, C.c_int],
+    "nk_conv_padding_folds": [VP, C.c_int, c_intp, c_intp, c_intp, c_intp, c_intp, C.c_int, C.POINTER(C.c_int)],
+    "nk_conv_bias_fwd_padded": [VP, C.c_int, VP, c_intp, c_intp, VP, c_intp, VP, VP, c_intp, c_intp, C.c_int],
+    "nk_conv_bwd_kernel_bias_padded": [VP, C.c_int, VP, VP, c_intp, VP, VP, c_intp, c_intp, c_intp, c_intp, C.c_int, C.c_int, C.c_int],
     "nk_pad_const_fwd": [VP, C.c_int, VP, c_intp, VP, c_intp, C.c_float],
     "nk_pad_reflective_fwd": [VP, C.c_int, VP, c_intp, VP, c_intp],
     "nk_pad_replicative_fwd": [VP, C.c_int, VP, c_intp, VP, c_intp],
@@ -514,6 +517,28 @@ def conv_bwd_kernel_bias(dev, dw, db, g, x, stride, dilation, groups=1, assign=(
     nd = x.ndim - 2
     check(lib.nk_conv_bwd_kernel_bias(dev.h, nd, dw.p, db.p, dw.shape_c(), g.p, x.p, x.shape_c(), ints(stride), ints(dilation), groups,
                                       int(assign[0]), int(assign[1])))
+
+
+def conv_padding_folds(dev, x_shape, padding, w_shape, stride, dilation, groups=1) -> bool:
+    """nk_conv_padding_folds: would the Conv module's forward and kernel gradient both run with the Zero padding folded in?"""
+    nd = len(x_shape) - 2
+    out = C.c_int(0)
+    check(lib.nk_conv_padding_folds(dev.h, nd, ints(x_shape), ints(padding), ints(w_shape), ints(stride), ints(dilation), groups, C.byref(out)))
+    return bool(out.value)
+
+
+def conv_fwd_padded(dev, x, w, y, padding, stride, dilation, groups=1, bias=None):
+    """y = conv(zero_pad(x, padding), w) (+ bias): `x` is the UNPADDED input (nk_conv_bias_fwd_padded)."""
+    nd = x.ndim - 2
+    check(lib.nk_conv_bias_fwd_padded(dev.h, nd, x.p, x.shape_c(), ints(padding), w.p, w.shape_c(), bias.p if bias is not None else None, y.p,
+                                      ints(stride), ints(dilation), groups))
+
+
+def conv_bwd_kernel_padded(dev, dw, g, x, padding, stride, dilation, groups=1, db=None, assign=(False, False)):
+    """dw (+)= kernel gradient against zero_pad(x, padding), db (+)= bias gradient: `x` is the UNPADDED input."""
+    nd = x.ndim - 2
+    check(lib.nk_conv_bwd_kernel_bias_padded(dev.h, nd, dw.p, db.p if db is not None else None, dw.shape_c(), g.p, x.p, x.shape_c(), ints(padding),
+                                             ints(stride), ints(dilation), groups, int(assign[0]), int(assign[1])))
 
 
 def linear_fwd(dev, X, W, bias, Y):

@@ -593,9 +593,103 @@ int conv_bwd_kernel(nk_device* dev, int nd, float* dw, const int* w_shape, const
     return fused_bias ? NK_OK : bias_by_reduction();
 }
 
+// ---- the Conv module with its Zero padding folded into the forward and the kernel gradient (Winograd forms only) ----------------
+// geometry of pad -> convolution from the UNPADDED input shape; `fold` = the Winograd kernels can take it with the padding folded in
+// (3 x 3, stride 1, dilation 1, one group, two spatial dimensions, padding 0 or 1 per axis and not all zero)
+int fold_geom(int nd, const int* x_shape, const int* padding, const int* w_shape, const int* stride, const int* dilation, int groups, ConvGeom* g,
+              bool* fold) {
+    NK_CHECK(nd >= 1 && nd <= 3 && x_shape && padding && w_shape && stride && dilation, "bad arguments of a padded convolution entry");
+    int pshape[5] = {x_shape[0], x_shape[1], 1, 1, 1};
+    bool any = false, small = true;
+    for (int d = 0; d < nd; ++d) {
+        NK_CHECK(padding[d] >= 0, "negative padding on axis %d", d);
+        pshape[2 + d] = x_shape[2 + d] + 2 * padding[d];
+        any = any || padding[d] != 0;
+        small = small && padding[d] <= 1;
+    }
+    const int rc = make_geom(nd, pshape, w_shape, stride, dilation, groups, g);
+    if (rc) return rc;
+    *fold = nd == 2 && any && small && wino_shape(*g);
+    return NK_OK;
+}
+
+int conv_padding_folds(nk_device* dev, int nd, const int* x_shape, const int* padding, const int* w_shape, const int* stride, const int* dilation,
+                       int groups, int* folds) {
+    NK_USE(dev);
+    NK_CHECK(folds != nullptr, "null result pointer");
+    *folds = 0;
+    ConvGeom g;
+    bool fold = false;
+    int rc = fold_geom(nd, x_shape, padding, w_shape, stride, dilation, groups, &g, &fold);
+    if (rc || !fold) return rc;
+    bool fwd = false, dwk = false;  // by the rules in force on this handle: both kernels would be the Winograd ones anyway
+    rc = wino_launch(dev, false, nullptr, nullptr, nullptr, nullptr, g.N, g.Cin, g.Cout, x_shape[2], x_shape[3], g.out[1], g.out[2], padding[0],
+                     padding[1], 1, 0.0, &fwd, false, true);
+    if (rc) return rc;
+    rc = wino_dw_launch(dev, nullptr, nullptr, nullptr, nullptr, g.N, g.Cin, g.Cout, g.in[1], g.in[2], 1, 1, 0.0, &dwk, padding[0], padding[1], false,
+                        true);
+    if (rc) return rc;
+    *folds = fwd && dwk ? 1 : 0;
+    return NK_OK;
+}
+
+int conv_fwd_padded(nk_device* dev, int nd, const float* x, const int* x_shape, const int* padding, const float* w, const int* w_shape,
+                    const float* bias, float* y, const int* stride, const int* dilation, int groups) {
+    NK_USE(dev);
+    ConvGeom g;
+    bool fold = false;
+    int rc = fold_geom(nd, x_shape, padding, w_shape, stride, dilation, groups, &g, &fold);
+    if (rc) return rc;
+    NK_CHECK(x && w && y, "null pointer in nk_conv_bias_fwd_padded");
+    bool taken = false;
+    if (fold)
+        rc = wino_launch(dev, false, x, w, y, bias, g.N, g.Cin, g.Cout, x_shape[2], x_shape[3], g.out[1], g.out[2], padding[0], padding[1], 1,
+                         2.0 * g.N * (double)g.Cout * g.L * g.Cg * g.KK, &taken, true);
+    if (rc) return rc;
+    if (!taken) {
+        nk_set_error("nk_conv_bias_fwd_padded: this geometry has no kernel with the padding folded in (ask nk_conv_padding_folds; pad, then nk_conv_bias_fwd)");
+        return NK_ERR_UNSUPPORTED;
+    }
+    return NK_OK;
+}
+
+int conv_bwd_kernel_padded(nk_device* dev, int nd, float* dw, float* db, const int* w_shape, const float* gy, const float* x, const int* x_shape,
+                           const int* padding, const int* stride, const int* dilation, int groups, int assign, int assign_b) {
+    NK_USE(dev);
+    ConvGeom g;
+    bool fold = false;
+    int rc = fold_geom(nd, x_shape, padding, w_shape, stride, dilation, groups, &g, &fold);
+    if (rc) return rc;
+    NK_CHECK(dw && gy && x, "null pointer in nk_conv_bwd_kernel_bias_padded");
+    bool taken = false;
+    if (fold)
+        rc = wino_dw_launch(dev, gy, x, dw, db, g.N, g.Cin, g.Cout, g.in[1], g.in[2], assign, assign_b, 2.0 * g.N * (double)g.Cout * g.L * g.Cg * g.KK,
+                            &taken, padding[0], padding[1], true);
+    if (rc) return rc;
+    if (!taken) {
+        nk_set_error("nk_conv_bwd_kernel_bias_padded: this geometry has no kernel with the padding folded in (ask nk_conv_padding_folds)");
+        return NK_ERR_UNSUPPORTED;
+    }
+    return NK_OK;
+}
+
 }  // namespace
 
 extern "C" {
+
+int nk_conv_padding_folds(nk_device* dev, int nd, const int* x_shape, const int* padding, const int* w_shape, const int* stride,
+                          const int* dilation, int groups, int* folds) {
+    return conv_padding_folds(dev, nd, x_shape, padding, w_shape, stride, dilation, groups, folds);
+}
+int nk_conv_bias_fwd_padded(nk_device* dev, int nd, const float* x, const int* x_shape, const int* padding, const float* w, const int* w_shape,
+                            const float* bias, float* y, const int* stride, const int* dilation, int groups) {
+    return conv_fwd_padded(dev, nd, x, x_shape, padding, w, w_shape, bias, y, stride, dilation, groups);
+}
+int nk_conv_bwd_kernel_bias_padded(nk_device* dev, int nd, float* dw, float* db, const int* w_shape, const float* gy, const float* x,
+                                   const int* x_shape, const int* padding, const int* stride, const int* dilation, int groups, int assign_dw,
+                                   int assign_db) {
+    return conv_bwd_kernel_padded(dev, nd, dw, db, w_shape, gy, x, x_shape, padding, stride, dilation, groups, assign_dw ? 1 : 0, assign_db ? 1 : 0);
+}
 
 int nk_conv_fwd(nk_device* dev, int nd, const float* x, const int* x_shape, const float* w, const int* w_shape,
                 float* y, const int* stride, const int* dilation, int groups) {

@@ -357,10 +357,12 @@ __global__ __launch_bounds__(64 * CB * PB, 1) void wino_kernel(WinoArgs a) {
 // Host side.  `taken` = false: not a case for this path (the caller goes on to the implicit-GEMM kernels).
 //   fwd:  src = x (N, Ck = Cin, Hs, Ws),  dst = y (N, Cm = Cout, Hs - 2, Ws - 2), off = 0
 //   bwd:  src = gy (N, Ck = Cout, Hs, Ws), dst = dx (N, Cm = Cin, Hd, Wd), off = 2 - pad per axis, Hs = Hd + 2 pad - 2
+// `force`: whenever the shape allows, whatever the knob and the block-count rule say (the entry points with the module's padding
+// folded in have no other kernel to fall back on); `dry`: decide only.
 int wino_launch(nk_device* dev, bool bwd, const float* src, const float* w, float* dst, const float* bias, int N, int Ck, int Cm, int Hs,
-                int Ws, int Hd, int Wd, int offy, int offx, int assign, double flop, bool* taken) {
+                int Ws, int Hd, int Wd, int offy, int offx, int assign, double flop, bool* taken, bool force = false, bool dry = false) {
     *taken = false;
-    const int mode = dev->tune_conv_winograd;  // -1 rule, 0 never, 1 whenever the shape allows
+    const int mode = force ? 1 : dev->tune_conv_winograd;  // -1 rule, 0 never, 1 whenever the shape allows
     if (mode == 0) return NK_OK;
     // Two block shapes, either pass: WIDE = four waves, 128 output channels, reduction chunks of 32 (one block per CU); NARROW = two
     // waves, 64 output channels, chunks of 16 (two independent blocks per CU: a barrier joins two waves instead of four, the
@@ -382,6 +384,7 @@ int wino_launch(nk_device* dev, bool bwd, const float* src, const float* w, floa
     if (P >= (1LL << 30) || src_bytes >= 0x7fffffffLL || dst_bytes >= 0x7fffffffLL || u_bytes >= 0x7fffffffLL) return NK_OK;
     // by rule: enough blocks for four rounds of the chip's CUs (one block per CU: 128 KB of LDS, 512 registers per lane)
     if (mode < 0 && blocks < 4LL * dev->num_cus) return NK_OK;
+    if (dry) { *taken = true; return NK_OK; }
     void* ws = nullptr;
     int rc = nk_workspace(dev, (size_t)16 * Cm * Ck * sizeof(float), &ws);
     if (rc) return rc;

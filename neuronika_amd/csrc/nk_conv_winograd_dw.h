@@ -39,12 +39,16 @@ struct WinoDwArgs {
     unsigned per_m, tx_m;
     int per_s1, per_s2, tx_s1, tx_s2;
     int x_bytes, gy_bytes;
+    // FOLD instantiation (the Conv module's Zero padding folded in: `x` is the UNPADDED input of extents Hx x Wx, the patch of tile
+    // (ty, tx) starts at row 2 ty - pady, column 2 tx - padx, zeros outside; pady, padx in {0, 1}); Hs, Ws stay the padded extents
+    int Hx, Wx, pady, padx;
 };
 
 constexpr int WDW_T = 8;                       // tiles per item
 constexpr int WDW_CQ = 36;                     // floats per (xi, channel quad): 8 tiles x 4 channels + 4 of padding
 constexpr int WDW_IMG = 16 * 16 * WDW_CQ;      // floats of one operand image: 16 xi x 16 channel quads (64 channels)
 
+template <bool FOLD>
 __global__ __launch_bounds__(256, 1) void wino_dw_kernel(WinoDwArgs a) {
     __shared__ __attribute__((aligned(16))) float XS[2 * WDW_IMG];
     __shared__ __attribute__((aligned(16))) float YS[2 * WDW_IMG];
@@ -53,7 +57,7 @@ __global__ __launch_bounds__(256, 1) void wino_dw_kernel(WinoDwArgs a) {
     const int c = lane & 31, h = lane >> 5;
     const int pair = blockIdx.y, cob = pair / a.cib, cb = pair % a.cib;
     const int tl = t & 7, cp = t >> 3;           // transform phase: this thread's tile of an item and its channel pair (0..31)
-    const int plane = a.Hs * a.Ws, oplane = a.Hd * a.Wd;
+    const int plane = FOLD ? a.Hx * a.Wx : a.Hs * a.Ws, oplane = a.Hd * a.Wd;  // plane: of the tensor `x` points to
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.gy, 0, a.gy_bytes, 0x00020000);
     // scalar offsets of the twelve loads of an item, made PROVABLY wave-uniform once (readfirstlane): left as expressions of the
@@ -62,7 +66,7 @@ __global__ __launch_bounds__(256, 1) void wino_dw_kernel(WinoDwArgs a) {
 #pragma unroll
     for (int ch = 0; ch < 2; ++ch) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) xso[ch][i] = __builtin_amdgcn_readfirstlane((ch * plane + i * a.Ws) * 4);
+        for (int i = 0; i < 4; ++i) xso[ch][i] = __builtin_amdgcn_readfirstlane((ch * plane + (FOLD ? 0 : i * a.Ws)) * 4);
 #pragma unroll
         for (int r = 0; r < 2; ++r) yso[ch][r] = __builtin_amdgcn_readfirstlane((ch * oplane + r * a.Wd) * 4);
     }
@@ -71,34 +75,60 @@ __global__ __launch_bounds__(256, 1) void wino_dw_kernel(WinoDwArgs a) {
     wino_u2 xr[2][2][4][2];  // [set][channel of the pair][patch row][columns 0-1 / 2-3]
     wino_u2 yr[2][2][2];     // [set][channel of the pair][tile row]
     float2 bsum = make_float2(0.f, 0.f);  // bias gradient of this thread's two output channels over its tiles
+    bool fix_left[2] = {false, false}, fix_right[2] = {false, false};  // FOLD: border flags of the item in each register set
+    int fix_shift[2] = {-1, -1};                                        // ... and the patch row loaded from the tensor's first byte (-1: none)
 
     const unsigned tile0 = (unsigned)blockIdx.x * (unsigned)a.items * WDW_T;
     // the twelve loads of an item (8 patch rows of 16 bytes, 4 tile rows of 8), issued ONE AT A TIME between MFMA groups: as a burst
     // at the top of the item the four waves' 48 instructions fill the address unit's queue and every wave waits for its turn with the
     // matrix pipe idle - 1.1 us of a 3.1 us item
     unsigned xo = 0x80000000u, yo = 0x80000000u;
+    // FOLD: a byte offset per patch row (a row above / below the image is out of range as a whole: zeros), the left-most column of a
+    // tile in the first column of tiles and the right-most of one in the last lie outside the image (one select each per row); the
+    // single row in the whole tensor whose window would start 4 bytes BEFORE the tensor (sample 0, channel 0, image row 0, first tile)
+    // is loaded from its start and shifted
+    unsigned xrow[4] = {0x80000000u, 0x80000000u, 0x80000000u, 0x80000000u};
+    bool left = false, right = false;
+    int shifted = -1;
     auto address = [&](int item) {
         const unsigned p = tile0 + (unsigned)item * WDW_T + tl;
         const bool valid = item < a.items && p < a.P;
         const unsigned pv = valid ? p : 0u;
         const unsigned n = wino_div(pv, a.per_m, a.per_s1, a.per_s2), rem = pv - n * (unsigned)(a.TY * a.TX);
         const unsigned ty = wino_div(rem, a.tx_m, a.tx_s1, a.tx_s2), tx = rem - ty * (unsigned)a.TX;
-        xo = valid ? (unsigned)(((int)n * a.Ci + 64 * cb + 2 * cp) * plane + 2 * (int)ty * a.Ws + 2 * (int)tx) * 4u : 0x80000000u;
+        if constexpr (FOLD) {
+            const int r0 = 2 * (int)ty - a.pady, c0 = 2 * (int)tx - a.padx;
+            const int base = ((int)n * a.Ci + 64 * cb + 2 * cp) * plane + c0;
+            left = c0 < 0; right = c0 + 3 >= a.Wx;
+            shifted = -1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int off = base + (r0 + i) * a.Wx;  // elements; negative only for the one row described above
+                const bool rok = valid & ((unsigned)(r0 + i) < (unsigned)a.Hx);
+                if (rok & (off < 0)) shifted = i;          // (image row 0 of channel 0 of sample 0, first column of tiles: no other valid row)
+                xrow[i] = rok ? (unsigned)(off < 0 ? 0 : off) * 4u : 0x80000000u;
+            }
+        } else {
+            xo = valid ? (unsigned)(((int)n * a.Ci + 64 * cb + 2 * cp) * plane + 2 * (int)ty * a.Ws + 2 * (int)tx) * 4u : 0x80000000u;
+        }
         yo = valid ? (unsigned)(((int)n * a.Co + 64 * cob + 2 * cp) * oplane + 2 * (int)ty * a.Wd + 2 * (int)tx) * 4u : 0x80000000u;
     };
     auto load_one = [&](auto set, int k) {  // k = 0..11, compile-time at every call site
         constexpr int S = decltype(set)::value;
         if (k < 8) {
             const int ch = k >> 2, i = k & 3;
-            xr[S][ch][i][0] = __builtin_amdgcn_raw_buffer_load_b64(xrs, xo, xso[ch][i], 0);
-            xr[S][ch][i][1] = __builtin_amdgcn_raw_buffer_load_b64(xrs, xo + 8, xso[ch][i], 0);
+            const unsigned vo = FOLD ? xrow[i] : xo;
+            xr[S][ch][i][0] = __builtin_amdgcn_raw_buffer_load_b64(xrs, vo, xso[ch][i], 0);
+            xr[S][ch][i][1] = __builtin_amdgcn_raw_buffer_load_b64(xrs, vo + 8, xso[ch][i], 0);
         } else {
             const int ch = (k - 8) >> 1, r = (k - 8) & 1;
             yr[S][ch][r] = __builtin_amdgcn_raw_buffer_load_b64(yrs, yo, yso[ch][r], 0);
         }
     };
     auto load = [&](auto set, int item) {
+        constexpr int S_ = decltype(set)::value;
         address(item);
+        fix_left[S_] = left; fix_right[S_] = right; fix_shift[S_] = shifted;
 #pragma unroll
         for (int k = 0; k < 12; ++k) load_one(set, k);
     };
@@ -114,6 +144,14 @@ __global__ __launch_bounds__(256, 1) void wino_dw_kernel(WinoDwArgs a) {
             for (int i = 0; i < 4; ++i) {
                 const float2 lo = __builtin_bit_cast(float2, xr[S][ch][i][0]), hi = __builtin_bit_cast(float2, xr[S][ch][i][1]);
                 d[i][0] = lo.x; d[i][1] = lo.y; d[i][2] = hi.x; d[i][3] = hi.y;
+                if constexpr (FOLD) {
+                    if (i < 2 && __any(fix_shift[S] == i)) {  // (one wave of one block of the launch; image row 0 is patch row 0 or 1)
+                        const bool sh = fix_shift[S] == i;
+                        d[i][3] = sh ? d[i][2] : d[i][3]; d[i][2] = sh ? d[i][1] : d[i][2]; d[i][1] = sh ? d[i][0] : d[i][1];
+                    }
+                    d[i][0] = fix_left[S] ? 0.f : d[i][0];
+                    d[i][3] = fix_right[S] ? 0.f : d[i][3];
+                }
             }
             float tt[4][4];  // B^T d
 #pragma unroll
@@ -179,6 +217,7 @@ __global__ __launch_bounds__(256, 1) void wino_dw_kernel(WinoDwArgs a) {
         float* const xn = XS + (S ^ 1) * WDW_IMG;
         float* const yn = YS + (S ^ 1) * WDW_IMG;
         address(i + 2);
+        fix_left[S] = left; fix_right[S] = right; fix_shift[S] = shifted;
         float av[2][4], bv[2][4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) { av[0][s] = ya[8 * s]; bv[0][s] = xb[8 * s]; }
@@ -296,16 +335,22 @@ __global__ __launch_bounds__(1024) void wino_dw_reduce_kernel(float* __restrict_
 }
 
 // Host side.  `taken` = false: not a case for this path (the caller goes on to the implicit-GEMM kernel).
+// (Hs, Ws): extents of the convolution's (padded) input.  pady / padx > 0: `x` is the UNPADDED input (Hs - 2 pady) x (Ws - 2 padx) and
+// the Zero padding is folded in (the FOLD instantiation; 0 or 1 per axis).  `force` / `dry`: as wino_launch.
 int wino_dw_launch(nk_device* dev, const float* gy, const float* x, float* dw, float* db, int N, int Ci, int Co, int Hs, int Ws, int assign,
-                   int assign_b, double flop, bool* taken) {
+                   int assign_b, double flop, bool* taken, int pady = 0, int padx = 0, bool force = false, bool dry = false) {
     *taken = false;
-    const int mode = dev->tune_conv_wino_dw;  // -1 rule, 0 never, 1 whenever the shape allows
-    if (mode == 0 || dev->tune_conv_winograd == 0) return NK_OK;
+    const int mode = force ? 1 : dev->tune_conv_wino_dw;  // -1 rule, 0 never, 1 whenever the shape allows
+    if (mode == 0 || (!force && dev->tune_conv_winograd == 0)) return NK_OK;
+    if (pady < 0 || pady > 1 || padx < 0 || padx > 1) return NK_OK;
+    const bool fold = pady + padx > 0;
+    const int Hx = Hs - 2 * pady, Wx = Ws - 2 * padx;
+    if (Hx < 1 || Wx < 1) return NK_OK;
     const int Hd = Hs - 2, Wd = Ws - 2;
     if (Hd < 2 || Wd < 2 || Hd % 2 != 0 || Wd % 2 != 0 || Ci % 64 != 0 || Co % 64 != 0) return NK_OK;
     if (!al16(x) || !al16(gy)) return NK_OK;
     const long long P = (long long)N * (Hd / 2) * (Wd / 2);
-    const long long x_bytes = (long long)N * Ci * Hs * Ws * 4, gy_bytes = (long long)N * Co * Hd * Wd * 4;
+    const long long x_bytes = (long long)N * Ci * Hx * Wx * 4, gy_bytes = (long long)N * Co * Hd * Wd * 4;
     if (P >= (1LL << 30) || x_bytes >= 0x7fffffffLL || gy_bytes >= 0x7fffffffLL) return NK_OK;
     const int pairs = (Co / 64) * (Ci / 64);
     if (pairs > dev->num_cus) return NK_OK;
@@ -316,6 +361,7 @@ int wino_dw_launch(nk_device* dev, const float* gy, const float* x, float* dw, f
     items += items & 1;                                         // the item loop is unrolled by two (register sets, LDS images)
     // by rule: at least 16 items per slice (the slabs and the second kernel are a fixed cost: 256 KB per block)
     if (mode < 0 && items < 16) return NK_OK;
+    if (dry) { *taken = true; return NK_OK; }
     const size_t slab_bytes = round256((size_t)slices * pairs * 16 * 64 * 64 * sizeof(float));
     void* ws = nullptr;
     int rc = nk_workspace(dev, slab_bytes + (db ? (size_t)slices * Co * sizeof(float) : 0), &ws);
@@ -329,7 +375,9 @@ int wino_dw_launch(nk_device* dev, const float* gy, const float* x, float* dw, f
     wino_magic((unsigned)(a.TY * a.TX), &a.per_m, &a.per_s1, &a.per_s2);
     wino_magic((unsigned)a.TX, &a.tx_m, &a.tx_s1, &a.tx_s2);
     a.x_bytes = (int)x_bytes; a.gy_bytes = (int)gy_bytes;
-    hipLaunchKernelGGL(wino_dw_kernel, dim3((unsigned)slices, (unsigned)pairs), dim3(256), 0, dev->compute, a);
+    a.Hx = Hx; a.Wx = Wx; a.pady = pady; a.padx = padx;
+    if (fold) hipLaunchKernelGGL(wino_dw_kernel<true>, dim3((unsigned)slices, (unsigned)pairs), dim3(256), 0, dev->compute, a);
+    else hipLaunchKernelGGL(wino_dw_kernel<false>, dim3((unsigned)slices, (unsigned)pairs), dim3(256), 0, dev->compute, a);
     NK_LAUNCH_CHECK();
     const int nb = Co * (Ci / 64) + (db ? (Co + 1023) / 1024 : 0);
     hipLaunchKernelGGL(wino_dw_reduce_kernel, dim3((unsigned)nb), dim3(1024), 0, dev->compute, dw, db, (const float*)a.slabs, (const float*)a.bslabs, Co,

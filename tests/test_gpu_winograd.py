@@ -216,3 +216,81 @@ def test_winograd_kernel_gradient_random_inside_the_contraction_bound(dev, N, Ci
         assert_contraction("direct (same cases):" + name, d, ref, K, 1.0, 1.0, cpu32=cpu)
     b64 = go.astype(np.float64).sum(axis=(0, 2, 3)).reshape(db0.shape)
     np.testing.assert_allclose(wino[5], b64, rtol=1e-5, atol=1e-6 * K)
+
+
+# ---- the Conv module's Zero padding folded into the forward and the kernel gradient ---------------------------------------------------
+# N, Cin, Cout, H, W of the UNPADDED input, padding per axis
+FOLD_SHAPES = [
+    (2, 64, 64, 8, 8, (1, 1)),        # every tile touches a border or a corner; the first tile of sample 0 / channel 0 is the shifted load
+    (3, 64, 128, 6, 12, (1, 1)),      # two co blocks (forward: the wide blocks), 54 tiles
+    (1, 128, 64, 10, 10, (1, 1)),     # two ci blocks
+    (2, 64, 64, 2, 2, (1, 1)),        # ONE tile per sample: left and right, top and bottom border at once
+    (2, 64, 128, 8, 10, (1, 0)),      # rows only (output 8 x 8)
+    (2, 64, 64, 10, 8, (0, 1)),       # columns only
+    (4, 64, 128, 56, 56, (1, 1)),     # the C3 plane
+]
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W,pad", FOLD_SHAPES)
+def test_folded_padding_equals_the_padded_copy_bit_for_bit(dev, N, Cin, Cout, H, W, pad):
+    """nk_conv_bias_fwd_padded / nk_conv_bwd_kernel_bias_padded on the UNPADDED input against nk_conv_bias_fwd /
+    nk_conv_bwd_kernel_bias on the zero-padded copy (both through the Winograd kernels): the same arithmetic on zeros that are read
+    instead of stored - equal bit for bit on RANDOM data, `+=` and `=`, with and without the bias terms."""
+    c = capi()
+    x, w, b = rnd(1, (N, Cin, H, W), -1, 1), rnd(2, (Cout, Cin, 3, 3), -1, 1), rnd(3, (Cout, 1, 1), -1, 1)
+    Ho, Wo = H + 2 * pad[0] - 2, W + 2 * pad[1] - 2
+    go, dw0, db0 = rnd(4, (N, Cout, Ho, Wo), -1, 1), rnd(5, (Cout, Cin, 3, 3)), rnd(6, (Cout, 1, 1))
+    xp = np.zeros((N, Cin, H + 2 * pad[0], W + 2 * pad[1]), np.float32)
+    xp[:, :, pad[0]:pad[0] + H, pad[1]:pad[1] + W] = x
+    dev.conv_winograd(1, None, None, 1)
+    try:
+        X, XP, Wd, B, G = dev.array(x), dev.array(xp), dev.array(w), dev.array(b), dev.array(go)
+        got, want = [], []
+        for bias in (None, B):
+            Y1, Y2 = dev.full((N, Cout, Ho, Wo), np.nan), dev.full((N, Cout, Ho, Wo), np.nan)
+            c.conv_fwd_padded(dev, X, Wd, Y1, pad, (1, 1), (1, 1), 1, bias=bias)
+            c.conv_fwd(dev, XP, Wd, Y2, (1, 1), (1, 1), 1, bias=bias)
+            got.append(Y1.numpy()); want.append(Y2.numpy())
+        for assign in (False, True):
+            D1, D2 = dev.array(dw0), dev.array(dw0)
+            E1, E2 = dev.array(db0), dev.array(db0)
+            c.conv_bwd_kernel_padded(dev, D1, G, X, pad, (1, 1), (1, 1), 1, db=E1, assign=(assign, assign))
+            c.conv_bwd_kernel_bias(dev, D2, E2, G, XP, (1, 1), (1, 1), 1, assign=(assign, assign))
+            got += [D1.numpy(), E1.numpy()]; want += [D2.numpy(), E2.numpy()]
+        D3 = dev.array(dw0)
+        c.conv_bwd_kernel_padded(dev, D3, G, X, pad, (1, 1), (1, 1), 1)     # no bias gradient
+        got.append(D3.numpy()); want.append(want[2])
+    finally:
+        dev.conv_winograd(None)
+    for i, (a, r) in enumerate(zip(got, want)):
+        assert np.array_equal(a, r), i
+    y = np.zeros((N, Cout, Ho, Wo), np.float32); O.convolution_forward(xp, w, y, (1, 1), (1, 1), 1)
+    np.testing.assert_allclose(got[0], y, rtol=0, atol=1e-6 * Cin * 9 * 2)
+
+
+def test_padding_folds_query_and_refusals(dev):
+    """nk_conv_padding_folds follows the rules in force (block counts, the knob); the `_padded` entries refuse what the kernels cannot
+    take (stride 2, 5 x 5, groups, padding 2, 40 channels, no padding at all) with NK_ERR_UNSUPPORTED instead of computing something else."""
+    c = capi()
+    big, small = (48, 64, 56, 56), (2, 64, 8, 8)
+    assert c.conv_padding_folds(dev, big, (1, 1), (128, 64, 3, 3), (1, 1), (1, 1))
+    assert not c.conv_padding_folds(dev, small, (1, 1), (128, 64, 3, 3), (1, 1), (1, 1))          # below the block-count rules
+    dev.conv_winograd(1, None, None, 1)
+    try:
+        assert c.conv_padding_folds(dev, small, (1, 1), (128, 64, 3, 3), (1, 1), (1, 1))
+    finally:
+        dev.conv_winograd(None)
+    dev.conv_winograd(0)
+    try:
+        assert not c.conv_padding_folds(dev, big, (1, 1), (128, 64, 3, 3), (1, 1), (1, 1))
+    finally:
+        dev.conv_winograd(None)
+    for xs, pad, ws, st, g in ((small, (1, 1), (128, 64, 3, 3), (2, 2), 1), (small, (2, 2), (128, 64, 5, 5), (1, 1), 1),
+                               ((2, 128, 8, 8), (1, 1), (128, 64, 3, 3), (1, 1), 2), (small, (2, 2), (128, 64, 3, 3), (1, 1), 1),
+                               ((2, 40, 8, 8), (1, 1), (128, 40, 3, 3), (1, 1), 1), (small, (0, 0), (128, 64, 3, 3), (1, 1), 1)):
+        assert not c.conv_padding_folds(dev, xs, pad, ws, st, (1, 1), g)
+        X, Wd = dev.zeros(xs), dev.zeros(ws)
+        oshape = O.conv_out_shape(tuple(xs[:2]) + tuple(xs[2 + i] + 2 * pad[i] for i in range(2)), ws, st, (1, 1))
+        Y = dev.zeros(oshape)
+        with pytest.raises(c.NeuronikaHipError):
+            c.conv_fwd_padded(dev, X, Wd, Y, pad, st, (1, 1), g)
