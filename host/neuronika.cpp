@@ -410,10 +410,14 @@ struct MatMulBwd : Backward {
 struct ConvFwd : Forward {  // node/convolution/mod.rs:296-355 (+ the module's broadcast bias Addition when b is set)
     Shared<HipArray> x, w, b, y;
     std::vector<int> stride, dilation;
+    std::vector<int> fold;  // module node with its Zero padding folded in: x is the UNPADDED input (nk_conv_bias_fwd_padded)
     int groups;
     void forward() const override {
         const int nd = (int)x->shape().size() - 2;
-        if (b)
+        if (!fold.empty())
+            check(nk_conv_bias_fwd_padded(D(x), nd, x->ptr(), x->shape().data(), fold.data(), w->ptr(), w->shape().data(), b ? b->ptr() : nullptr,
+                                          y->ptr(), stride.data(), dilation.data(), groups));
+        else if (b)
             check(nk_conv_bias_fwd(D(x), nd, x->ptr(), x->shape().data(), w->ptr(), w->shape().data(), b->ptr(), y->ptr(),
                                    stride.data(), dilation.data(), groups));
         else
@@ -426,6 +430,7 @@ struct ConvBwd : Backward {  // ConvolutionBackward{Input,Kernel}  :357-510
     Shared<Gradient> dx, dw, db, g;  // dx may be null (input is a non-differentiable Var); db only for the fused module node
     std::vector<int> stride, dilation;
     std::vector<int> padding;  // fused module node with Zero padding: x is the padded input, dx the UNPADDED input's gradient
+    bool x_unpadded = false;   // ... and with the padding folded into forward and kernel gradient too: x is the UNPADDED input
     int groups;
     void backward() const override {
         const HipArray& G = g->borrow();
@@ -441,7 +446,13 @@ struct ConvBwd : Backward {  // ConvolutionBackward{Input,Kernel}  :357-510
                 check((assign ? nk_conv_bwd_input_assign : nk_conv_bwd_input)(D(x), nd, d.ptr(), x->shape().data(), G.ptr(), w->ptr(),
                                                                               w->shape().data(), stride.data(), dilation.data(), groups));
         }
-        if (dw && db) {  // kernel and bias gradient of the fused module node in one pass over G
+        if (dw && x_unpadded) {  // the Pad node folded into the kernel-gradient pass (db optional)
+            bool assign_b = false;
+            HipArray& d = dw->borrow_first_write(assign);
+            HipArray* b = db ? &db->borrow_first_write(assign_b) : nullptr;
+            check(nk_conv_bwd_kernel_bias_padded(D(x), nd, d.ptr(), b ? b->ptr() : nullptr, w->shape().data(), G.ptr(), x->ptr(), x->shape().data(),
+                                                 padding.data(), stride.data(), dilation.data(), groups, assign ? 1 : 0, assign_b ? 1 : 0));
+        } else if (dw && db) {  // kernel and bias gradient of the fused module node in one pass over G
             bool assign_b = false;
             HipArray& d = dw->borrow_first_write(assign);
             HipArray& b = db->borrow_first_write(assign_b);
@@ -1657,6 +1668,44 @@ static VarDiff conv_diff(const VarDiff& kernel, const Var& input, const Shared<G
     bw->stride = stride; bw->dilation = dilation; bw->groups = groups;
     return VarDiff::node(std::move(out), g, entry(bw, g), std::move(h));
 }
+// The Conv module node WITHOUT its Pad node: forward and kernel gradient read the unpadded input through the library's folded
+// entry points (nk_conv_bias_fwd_padded, nk_conv_bwd_kernel_bias_padded), the input gradient through nk_conv_bwd_input_padded as
+// before.  Only built after nk_conv_padding_folds said yes for this geometry (ConvNd::forward).
+static VarDiff conv_folded(const VarDiff& kernel, const Var& input, const Shared<Gradient>& dx, const History<BackwardEntry>* hx,
+                           const std::vector<int>& padding, const std::vector<int>& stride, const std::vector<int>& dilation, int groups,
+                           const VarDiff& bias) {
+    Shape padded = input.shape();
+    for (size_t i = 0; i < padding.size(); ++i) padded[2 + i] += 2 * padding[i];
+    const Shape out = conv_out_shape(padded, kernel.shape(), stride, dilation, groups);
+    Shape want{out[1]};
+    want.insert(want.end(), out.size() - 2, 1);
+    if (bias.shape() != want) panic("conv bias must have shape (out_channels, 1, ...)");
+    History<ForwardEntry> fh = kernel.var.history;
+    fh.merge(input.history);
+    fh.merge(bias.var.history);
+    auto fw = std::make_shared<ConvFwd>();
+    fw->x = input.data; fw->w = kernel.var.data; fw->b = bias.var.data; fw->y = zeros_like(kernel.var.data, out);
+    fw->stride = stride; fw->dilation = dilation; fw->groups = groups; fw->fold = padding;
+    auto y = fw->y;
+    Var outv = Var::node(y, fw, std::move(fh));
+    History<BackwardEntry> h = kernel.history;
+    if (hx) h.merge(*hx);
+    h.merge(bias.history);
+    auto g = std::make_shared<Gradient>(outv.device(), outv.shape());
+    auto bw = std::make_shared<ConvBwd>();
+    bw->x = input.data; bw->w = kernel.var.data; bw->dx = dx; bw->dw = kernel.grad; bw->db = bias.grad; bw->g = g;
+    bw->padding = padding; bw->x_unpadded = true;
+    bw->stride = stride; bw->dilation = dilation; bw->groups = groups;
+    return VarDiff::node(std::move(outv), g, entry(bw, g), std::move(h));
+}
+static bool padding_folds(const Var& input, const VarDiff& weight, const std::vector<int>& padding, const std::vector<int>& stride,
+                          const std::vector<int>& dilation, int groups) {
+    int folds = 0;
+    const int nd = (int)input.shape().size() - 2;
+    check(nk_conv_padding_folds(input.device()->raw(), nd, input.shape().data(), padding.data(), weight.shape().data(), stride.data(),
+                                dilation.data(), groups, &folds));
+    return folds != 0;
+}
 VarDiff VarDiff::convolution(const Var& input, const std::vector<int>& stride, const std::vector<int>& dilation, int groups) const {
     return conv_diff(*this, input, nullptr, nullptr, stride, dilation, groups);
 }
@@ -1950,6 +1999,9 @@ ConvNd::ConvNd(int nd, DevicePtr dev, int in_channels, int out_channels, std::ve
         panic("Conv" + std::to_string(nd) + "d: kernel/padding/stride/dilation need " + std::to_string(nd) + " entries");
 }
 VarDiff ConvNd::forward(const Var& input) const {
+    const bool zero_pad = padding_mode.kind == PaddingMode::Zero || (padding_mode.kind == PaddingMode::Constant && padding_mode.value == 0.f);
+    if (fused && fold_padding && zero_pad && padding_folds(input, weight, padding, stride, dilation, groups))
+        return conv_folded(weight, input, nullptr, nullptr, padding, stride, dilation, groups, bias);
     const Var padded = input.pad(padding, padding_mode);
     if (!fused) return weight.convolution(padded, stride, dilation, groups) + bias;
     return conv_diff(weight, padded, nullptr, nullptr, stride, dilation, groups, &bias);
@@ -1959,7 +2011,10 @@ VarDiff ConvNd::forward(const VarDiff& input) const {
     for (int p : padding) any_pad = any_pad || p != 0;
     if (fused && any_pad && (padding_mode.kind == PaddingMode::Zero || (padding_mode.kind == PaddingMode::Constant && padding_mode.value == 0.f))) {
         // pad -> convolution -> + bias with the Pad node's backward folded into the convolution's: the padded copy is a
-        // forward-only node, the convolution's input gradient lands in input.grad directly (no padded gradient buffer)
+        // forward-only node, the convolution's input gradient lands in input.grad directly (no padded gradient buffer) - or, where
+        // the library's kernels read the unpadded input, no Pad node at all
+        if (fold_padding && padding_folds(input.var, weight, padding, stride, dilation, groups))
+            return conv_folded(weight, input.var, input.grad, &input.history, padding, stride, dilation, groups, bias);
         const Var padded = input.var.pad(padding, padding_mode);
         return conv_diff(weight, padded, input.grad, &input.history, stride, dilation, groups, &bias, &padding);
     }

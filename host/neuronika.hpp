@@ -552,6 +552,10 @@ struct ConvNd {
     PaddingMode padding_mode;
     int groups = 1;
     bool fused = true;  // bias added in the convolution epilogue (one node); false: convolution node + Addition node
+    // Zero padding folded into the forward and the kernel gradient where the library's kernels can read the unpadded input
+    // (nk_conv_padding_folds: the Winograd geometries at sizes the rules give to those kernels): no Pad node, no padded copy
+    // (C3: 110 MB and a 40 us kernel per step less); false: the padded copy as a forward-only node (what rounds 2 - 4 built)
+    bool fold_padding = true;
     ConvNd(int nd, DevicePtr dev, int in_channels, int out_channels, std::vector<int> kernel, std::vector<int> padding,
            PaddingMode mode, std::vector<int> stride, std::vector<int> dilation, int groups, uint64_t seed);
     VarDiff forward(const Var& input) const;

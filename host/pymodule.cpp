@@ -282,6 +282,7 @@ PYBIND11_MODULE(_tape, m) {
         .def_readonly("weight", &nn::ConvNd::weight)
         .def_readonly("bias", &nn::ConvNd::bias)
         .def_readwrite("fused", &nn::ConvNd::fused)
+        .def_readwrite("fold_padding", &nn::ConvNd::fold_padding)
         .def_readonly("groups", &nn::ConvNd::groups)
         .def_readonly("padding", &nn::ConvNd::padding).def_readonly("stride", &nn::ConvNd::stride).def_readonly("dilation", &nn::ConvNd::dilation)
         .def("forward", py::overload_cast<const Var&>(&nn::ConvNd::forward, py::const_))

@@ -1313,6 +1313,14 @@ def test_conv2d_module_at_a_size_the_winograd_rule_takes(nk, tdev):
         finally:
             cdev.conv_winograd(None)
     assert got[None][6] == 3 and got[0][6] == 0                       # forward, input gradient, kernel gradient
+    # the same module with the padded copy as a node of its own (fold_padding = false): the folded node computes the same bits
+    conv = nk.nn.Conv2d(tdev, Cin, Cout, [3, 3], [1, 1], nk.PaddingMode.zero(), [1, 1], [1, 1], 1)
+    conv.fold_padding = False
+    X = nk.from_ndarray(tdev, x).requires_grad()
+    y = conv.forward(X)
+    y.forward(); y.backward_from(nk.from_ndarray(tdev, gy))
+    for a, r in zip((y.data(), X.grad(), conv.weight.grad(), conv.bias.grad()), got[None][:4]):
+        assert np.array_equal(a, r)
     w, b = got[None][4], got[None][5]
     assert np.array_equal(w, got[0][4]) and np.array_equal(b, got[0][5])   # same seed, same parameters
     xp = np.zeros((N, Cin, H + 2, H + 2), np.float64); xp[:, :, 1:-1, 1:-1] = x
