@@ -442,7 +442,7 @@ def measure_conv(dist, tdev, cdev, steps, warmup):
     roof["executed_mfma_flop_per_launch"] = executed / 3
     roof["executed_frac"] = round(roof["frac"] * executed / (3 * direct), 4)
     roof["winograd"] = bool(wino)
-    return {"workload": "C3: pad(1) -> conv 3x3 s1 d1 g1, x 128x64x56x56 -> 128 ch, +bias, fwd+bwd-input+bwd-kernel",
+    return {"workload": "C3: nn::Conv2d = pad(1) -> conv 3x3 s1 d1 g1 -> + bias, x 128x64x56x56 -> 128 ch, fwd+bwd-input+bwd-kernel (Zero padding folded into the kernels)",
             "value": round(N * steps * dist.world / dt, 2), "unit": "samples/s", "steps": steps,
             "ms_per_step": round(dt / steps * 1e3, 4),
             "step_tflops": round(3 * 2.0 * N * 128 * 56 * 56 * 64 * 9 * steps / dt / 1e12, 2),

@@ -139,6 +139,13 @@ macro_rules! conv_layer {
             /// the bias in the epilogue; backward `nk_conv_bwd_input` and `nk_conv_bwd_kernel_bias`).  The reference leaves the
             /// body as `todo!()` (`:712-717`).
             pub fn forward(&self, input: HipVarDiff<$dim>) -> HipVarDiff<$dim> {
+                // Zero padding the library's kernels can read through (the Winograd geometries): no Pad node, no padded copy
+                if matches!(self.padding_mode, PaddingMode::Zero)
+                    && self.weight.padding_folds(&input, &$list(self.padding), &$list(self.stride), &$list(self.dilation), 1)
+                {
+                    return self.weight.clone().convolution_bias_padded(input, self.bias.clone(), &$list(self.padding), &$list(self.stride),
+                                                                       &$list(self.dilation), 1);
+                }
                 let padded = input.pad(&$list(self.padding), self.padding_mode);
                 self.weight.clone().convolution_bias(padded, self.bias.clone(), &$list(self.stride), &$list(self.dilation), 1)
             }

@@ -16,7 +16,8 @@ use super::{
     hiparray::HipArray,
     node::{
         AttentionState, BinaryOp, BinaryOperation, BinaryOperationBackwardLeft, BinaryOperationBackwardRight, Chunk, ChunkBackward,
-        Convolution, ConvolutionBackwardInput, ConvolutionBackwardKernel, ConvolutionBackwardKernelBias, ConvolutionBias, Dropout,
+        Convolution, ConvolutionBackwardInput, ConvolutionBackwardKernel, ConvolutionBackwardKernelBias, ConvolutionBackwardPadded, ConvolutionBias,
+        ConvolutionBiasPadded, Dropout,
         DropoutBackward, Heads, HeadsAttention, HeadsAttentionBackward, Linear, LinearBackward, LogSoftmax, LogSoftmaxBackward, MatrixMatrixMul, MatrixMatrixMulBackwardLeft,
         MatrixMatrixMulBackwardRight, MatrixMatrixMulT, MatrixMatrixMulTBackwardLeft, MatrixMatrixMulTBackwardRight, Mean, MeanBackward,
         MultiConcatenate, MultiConcatenateBackward, PackedHeadsAttention, PackedHeadsAttentionBackward, Pad, PadBackward, PadMode, Pair, ReLU,
@@ -689,6 +690,61 @@ where
                                                             to_i32(dilation), groups as i32);
         let node: Rc<dyn Backward> = Rc::new(Pair(bwd_input, bwd_kernel));
         HipVarDiff::node(var, grad.clone(), (node, grad), self.history)
+    }
+}
+
+impl<D> HipVarDiff<D>
+where
+    D: 'static + Dimension + RemoveAxis,
+{
+    /// Does the library run this module geometry with the Zero padding folded in (`nk_conv_padding_folds`: 3 x 3, stride 1, one group,
+    /// padding 0 / 1, 64 | channel counts, even output extents, and sizes the rules give to the Winograd kernels)?  `self` is the KERNEL.
+    pub fn padding_folds(&self, input: &HipVarDiff<D>, padding: &[usize], stride: &[usize], dilation: &[usize], groups: usize) -> bool {
+        let to_i32 = |v: &[usize]| v.iter().map(|&s| s as i32).collect::<Vec<_>>();
+        let (xs, ws) = (input.var.data.borrow().shape_c(), self.var.data.borrow().shape_c());
+        let mut folds = 0i32;
+        super::ffi::check(unsafe {
+            super::ffi::nk_conv_padding_folds(self.var.device().as_raw(), xs.len() as i32 - 2, xs.as_ptr(), to_i32(padding).as_ptr(), ws.as_ptr(),
+                                              to_i32(stride).as_ptr(), to_i32(dilation).as_ptr(), groups as i32, &mut folds)
+        });
+        folds != 0
+    }
+
+    /// `pad(padding, Zero) -> convolution -> + bias` of the `nn::Conv*` layers as ONE node pair WITHOUT the Pad node: `input` is the
+    /// unpadded variable, forward on `nk_conv_bias_fwd_padded`, backward `nk_conv_bwd_input_padded` + `nk_conv_bwd_kernel_bias_padded`.
+    /// Call only after `padding_folds` said yes (the entry points refuse other geometries).
+    pub fn convolution_bias_padded<B>(mut self, input: HipVarDiff<D>, bias: HipVarDiff<B>, padding: &[usize], stride: &[usize],
+                                      dilation: &[usize], groups: usize) -> HipVarDiff<D>
+    where
+        B: 'static + Dimension,
+    {
+        self.history.merge(input.history);
+        self.history.merge(bias.history);
+        let mut fwd_history = self.var.history;
+        fwd_history.merge(input.var.history);
+        fwd_history.merge(bias.var.history);
+        let to_i32 = |v: &[usize]| v.iter().map(|&s| s as i32).collect::<Vec<_>>();
+        let device = self.var.data.borrow().device().clone();
+        let shape: D = {
+            let (x, w) = (input.var.data.borrow(), self.var.data.borrow());
+            let mut xs: Vec<usize> = x.dimension().slice().to_vec();
+            for (i, p) in padding.iter().enumerate() {
+                xs[2 + i] += 2 * p;
+            }
+            let ws: Vec<usize> = w.dimension().slice().to_vec();
+            check_conv_args(&xs, &ws, stride, dilation);
+            check_groups_args(&xs, &ws, groups);
+            conv_out_shape(&xs, &ws, stride, dilation)
+        };
+        let data = shared(shape.clone(), &device);
+        let fwd = ConvolutionBiasPadded::new(input.var.data.clone(), self.var.data.clone(), bias.var.data.clone(), data.clone(), to_i32(padding),
+                                             to_i32(stride), to_i32(dilation), groups as i32);
+        let var = HipVar::node(data, Rc::new(fwd), fwd_history);
+        let grad = Rc::new(Gradient::hip_zeros(shape, device));
+        let bwd = ConvolutionBackwardPadded::new(input.var.data, self.var.data, input.grad, self.grad, bias.grad, grad.clone(), to_i32(padding),
+                                                 to_i32(stride), to_i32(dilation), groups as i32);
+        let op: Rc<dyn Backward> = Rc::new(bwd);
+        HipVarDiff::node(var, grad.clone(), (op, grad), self.history)
     }
 }
 

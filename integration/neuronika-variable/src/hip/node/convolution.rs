@@ -220,3 +220,105 @@ where
         vec![grad_id(&self.kernel_gradient), grad_id(&self.bias_gradient)]
     }
 }
+
+/// The `Conv2d` module with its ZERO padding folded in (`nn::Conv*::forward` = pad -> convolution -> + bias, `neuronika-nn/src/lib.rs:
+/// 724-812`): `input_data` is the UNPADDED input, no `Pad` node and no padded copy exist (`Pad::forward`, `node/pad/zero/mod.rs:5-31`:
+/// 110 MB and a 40 us kernel per step at C3) - `nk_conv_bias_fwd_padded`.  Built by `HipVarDiff::convolution_bias_padded` only after
+/// `nk_conv_padding_folds` said that the Winograd kernels take this geometry (they read out-of-range elements as zeros).
+pub(crate) struct ConvolutionBiasPadded<D, B>
+where
+    D: Dimension,
+    B: Dimension,
+{
+    input_data: Shared<HipArray<D>>,
+    kernel_data: Shared<HipArray<D>>,
+    bias_data: Shared<HipArray<B>>,
+    data: Shared<HipArray<D>>,
+    padding: Vec<i32>,
+    stride: Vec<i32>,
+    dilation: Vec<i32>,
+    groups: i32,
+}
+
+impl<D, B> ConvolutionBiasPadded<D, B>
+where
+    D: Dimension,
+    B: Dimension, {
+    #[allow(clippy::too_many_arguments)]
+    pub(crate) fn new(input_data: Shared<HipArray<D>>, kernel_data: Shared<HipArray<D>>, bias_data: Shared<HipArray<B>>, data: Shared<HipArray<D>>, padding: Vec<i32>, stride: Vec<i32>, dilation: Vec<i32>, groups: i32) -> Self {
+        Self { input_data, kernel_data, bias_data, data, padding, stride, dilation, groups }
+    }
+}
+
+impl<D, B> Forward for ConvolutionBiasPadded<D, B>
+where
+    D: Dimension,
+    B: Dimension,
+{
+    fn forward(&self) {
+        let (x, w, b) = (self.input_data.borrow(), self.kernel_data.borrow(), self.bias_data.borrow());
+        let mut y = self.data.borrow_mut();
+        let (xs, ws) = (x.shape_c(), w.shape_c());
+        ffi::check(unsafe {
+            ffi::nk_conv_bias_fwd_padded(x.device().as_raw(), xs.len() as i32 - 2, x.as_ptr(), xs.as_ptr(), self.padding.as_ptr(), w.as_ptr(), ws.as_ptr(),
+                                         b.as_ptr(), y.as_mut_ptr(), self.stride.as_ptr(), self.dilation.as_ptr(), self.groups)
+        });
+    }
+}
+
+/// Its backward entry: `ConvolutionBackwardInput` + `PadBackward` as one kernel (`nk_conv_bwd_input_padded`: the gradient lands in the
+/// UNPADDED input's buffer), then kernel and bias gradient against the unpadded input (`nk_conv_bwd_kernel_bias_padded`).
+pub(crate) struct ConvolutionBackwardPadded<D, B>
+where
+    D: Dimension,
+    B: Dimension,
+{
+    input_data: Shared<HipArray<D>>,
+    kernel_data: Shared<HipArray<D>>,
+    input_gradient: Rc<Gradient<HipArray<D>, D>>,
+    kernel_gradient: Rc<Gradient<HipArray<D>, D>>,
+    bias_gradient: Rc<Gradient<HipArray<B>, B>>,
+    gradient: Rc<Gradient<HipArray<D>, D>>,
+    padding: Vec<i32>,
+    stride: Vec<i32>,
+    dilation: Vec<i32>,
+    groups: i32,
+}
+
+impl<D, B> ConvolutionBackwardPadded<D, B>
+where
+    D: Dimension,
+    B: Dimension, {
+    #[allow(clippy::too_many_arguments)]
+    pub(crate) fn new(input_data: Shared<HipArray<D>>, kernel_data: Shared<HipArray<D>>, input_gradient: Rc<Gradient<HipArray<D>, D>>, kernel_gradient: Rc<Gradient<HipArray<D>, D>>, bias_gradient: Rc<Gradient<HipArray<B>, B>>, gradient: Rc<Gradient<HipArray<D>, D>>, padding: Vec<i32>, stride: Vec<i32>, dilation: Vec<i32>, groups: i32) -> Self {
+        Self { input_data, kernel_data, input_gradient, kernel_gradient, bias_gradient, gradient, padding, stride, dilation, groups }
+    }
+}
+
+impl<D, B> Backward for ConvolutionBackwardPadded<D, B>
+where
+    D: Dimension,
+    B: Dimension,
+{
+    fn backward(&self) {
+        let (g, x, w) = (self.gradient.borrow(), self.input_data.borrow(), self.kernel_data.borrow());
+        let (xs, ws) = (x.shape_c(), w.shape_c());
+        let dev = g.device().as_raw();
+        {
+            let mut dx = self.input_gradient.borrow_mut();
+            ffi::check(unsafe {
+                ffi::nk_conv_bwd_input_padded(dev, xs.len() as i32 - 2, dx.as_mut_ptr(), xs.as_ptr(), self.padding.as_ptr(), g.as_ptr(), w.as_ptr(),
+                                              ws.as_ptr(), self.stride.as_ptr(), self.dilation.as_ptr(), self.groups)
+            });
+        }
+        let (mut dw, mut db) = (self.kernel_gradient.borrow_mut(), self.bias_gradient.borrow_mut());
+        ffi::check(unsafe {
+            ffi::nk_conv_bwd_kernel_bias_padded(dev, xs.len() as i32 - 2, dw.as_mut_ptr(), db.as_mut_ptr(), ws.as_ptr(), g.as_ptr(), x.as_ptr(),
+                                                xs.as_ptr(), self.padding.as_ptr(), self.stride.as_ptr(), self.dilation.as_ptr(), self.groups, 0, 0)
+        });
+    }
+
+    fn targets(&self) -> Vec<usize> {
+        vec![grad_id(&self.input_gradient), grad_id(&self.kernel_gradient), grad_id(&self.bias_gradient)]
+    }
+}

@@ -95,6 +95,7 @@ REQUIRED = {
                "nk_relu_bwd_assign"],
     "linear_diff": ["nk_linear_fwd", "nk_linear_relu_fwd", "nk_mm_t_bwd_right", "nk_unbroadcast_add"],
     "convolution_bias": ["nk_conv_bias_fwd", "nk_conv_bwd_input", "nk_conv_bwd_kernel_bias"],
+    "convolution_bias_padded": ["nk_conv_bias_fwd_padded", "nk_conv_bwd_input_padded", "nk_conv_bwd_kernel_bias_padded"],
     "packed_heads_attention": ["nk_attention_qkv_fwd", "nk_attention_qkv_bwd"],
 }
 
@@ -375,14 +376,15 @@ def test_nn_layers_exist_and_call_variable_methods_that_exist():
     methods = _pub_methods(os.path.join(HIP, "hipvar.rs"))
     # the layers are built from the FUSED variable methods: Linear = one node (nk_linear_fwd / nk_linear_relu_fwd), Conv* = one node with
     # the bias (nk_conv_bias_fwd / nk_conv_bwd_kernel_bias), MultiheadAttention = packed projections + nk_attention_qkv_*
-    used = {"linear": 3, "linear_diff": 3, "pad": 2, "convolution_bias": 5, "dropout": 2, "packed_heads_attention": 7, "shape": 0, "parameter": 2}
+    used = {"linear": 3, "linear_diff": 3, "pad": 2, "convolution_bias": 5, "convolution_bias_padded": 6, "padding_folds": 5, "dropout": 2,
+            "packed_heads_attention": 7, "shape": 0, "parameter": 2}
     for slow in ("mm_t", "mm_t_diff", "convolution", "heads_attention"):                       # ... and from nothing slower
         assert not re.search(r"\.%s\(" % slow, src), slow
     for name, nargs in used.items():
         assert re.search(r"[.:]%s\(" % name, src), name
         assert name in methods and nargs in methods[name], (name, methods.get(name))
     # call sites pass that many arguments
-    for m in re.finditer(r"\.(linear|linear_diff|pad|convolution_bias|dropout|packed_heads_attention)\(", src):
+    for m in re.finditer(r"\.(linear|linear_diff|pad|convolution_bias|convolution_bias_padded|padding_folds|dropout|packed_heads_attention)\(", src):
         i, depth = m.end(), 1
         while depth:
             depth += {"(": 1, ")": -1}.get(src[i], 0)
