@@ -382,8 +382,11 @@ int wino_launch(nk_device* dev, bool bwd, const float* src, const float* w, floa
     // buffer descriptors with 32-bit byte offsets, 0x80000000 as the out-of-range mark: every tensor below 2 GB
     const long long src_bytes = (long long)N * Ck * Hs * Ws * 4, dst_bytes = (long long)N * Cm * Hd * Wd * 4, u_bytes = 16LL * Cm * Ck * 4;
     if (P >= (1LL << 30) || src_bytes >= 0x7fffffffLL || dst_bytes >= 0x7fffffffLL || u_bytes >= 0x7fffffffLL) return NK_OK;
-    // by rule: enough blocks for four rounds of the chip's CUs (one block per CU: 128 KB of LDS, 512 registers per lane)
-    if (mode < 0 && blocks < 4LL * dev->num_cus) return NK_OK;
+    // by rule: from an eighth of the CUs' worth of wide blocks, one CU's worth of narrow ones.  Measured at C3's geometry with small
+    // batches (benchmarks/ab_winograd.py N; profiles/r05_winograd_ab.txt section 7): forward (wide) 49 / 52 / 84 / 161 us -> 27 / 29 / 46 /
+    // 82 at N = 4 / 8 / 16 / 32 (98 blocks at N = 4), input gradient (narrow) 42 / 63 / 91 / 146 -> 43 / 44 / 53 / 95 (196 blocks at N = 4: a
+    // draw).  (The first rule, four rounds of the CUs, dated from the first version of the kernels.)
+    if (mode < 0 && blocks < (wide ? dev->num_cus / 8 : dev->num_cus)) return NK_OK;
     if (dry) { *taken = true; return NK_OK; }
     void* ws = nullptr;
     int rc = nk_workspace(dev, (size_t)16 * Cm * Ck * sizeof(float), &ws);

@@ -121,8 +121,8 @@ def test_winograd_random_inside_the_contraction_bound(dev, N, Cin, Cout, H, W, p
 
 
 def test_winograd_rule_and_knob(dev):
-    """By rule the path is taken from four rounds of blocks on (the C3 plane with 8 samples: 196 forward blocks - direct; with
-    48 samples: 1176 - Winograd); shapes it cannot take (odd output extent, stride 2, 5 x 5, groups, 40 channels) stay direct
+    """By rule the path is taken from an eighth of the CUs' worth of wide blocks on (an 18 x 18 plane, one sample: 2 forward blocks -
+    direct; the C3 plane with 8 samples: 196 - Winograd); shapes it cannot take (odd output extent, stride 2, 5 x 5, groups, 40 channels) stay direct
     under the forced knob.  Told apart by the bits on random data (the two orders of summation differ)."""
     c = capi()
 
@@ -138,7 +138,7 @@ def test_winograd_rule_and_knob(dev):
             dev.conv_winograd(None)
 
     w = rnd(2, (128, 64, 3, 3), -1, 1)
-    small, large = rnd(1, (8, 64, 58, 58)), rnd(1, (48, 64, 58, 58))
+    small, large = rnd(1, (1, 64, 18, 18)), rnd(1, (8, 64, 58, 58))
     assert np.array_equal(fwd(small, w, (1, 1), 1, None), fwd(small, w, (1, 1), 1, 0))          # rule: direct
     assert not np.array_equal(fwd(small, w, (1, 1), 1, 1), fwd(small, w, (1, 1), 1, 0))         # forced: Winograd
     assert np.array_equal(fwd(large, w, (1, 1), 1, None), fwd(large, w, (1, 1), 1, 1))          # rule: Winograd
