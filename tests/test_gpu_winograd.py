@@ -294,3 +294,32 @@ def test_padding_folds_query_and_refusals(dev):
         Y = dev.zeros(oshape)
         with pytest.raises(c.NeuronikaHipError):
             c.conv_fwd_padded(dev, X, Wd, Y, pad, st, (1, 1), g)
+
+
+def test_winograd_non_finite_input_stays_inside_the_tiles_that_see_it(dev):
+    """Non-finite inputs: the transforms add and subtract patch elements, so a +inf in the input reaches the outputs
+    as +-inf or - where two infinite terms meet in an add tree - as NaN, where the direct kernels give +-inf.  Pinned here: the SET of
+    non-finite outputs is a superset of the direct form's and stays inside the 2 x 2 tiles whose 4 x 4 patch contains the element (in
+    this case it is the same 3 x 3 window), every other output is untouched, and NK_TUNE_CONV_WINOGRAD = 0 restores the direct values."""
+    c = capi()
+    N, Cin, Cout, H = 2, 64, 128, 12
+    x, w = rnd(1, (N, Cin, H, H), -1, 1), rnd(2, (Cout, Cin, 3, 3), -1, 1)
+    x[1, 5, 6, 7] = np.inf                                   # padded-input coordinates (the caller's tensor)
+    out = {}
+    for mode in (1, 0):
+        dev.conv_winograd(mode)
+        try:
+            X, Wd, Y = dev.array(x), dev.array(w), dev.zeros((N, Cout, H - 2, H - 2))
+            c.conv_fwd(dev, X, Wd, Y, (1, 1), (1, 1), 1)
+            out[mode] = Y.numpy()
+        finally:
+            dev.conv_winograd(None)
+    direct_bad = ~np.isfinite(out[0])
+    want_direct = np.zeros_like(direct_bad); want_direct[1, :, 4:7, 5:8] = True       # outputs whose 3 x 3 window covers (6, 7)
+    assert np.array_equal(direct_bad, want_direct)
+    wino_bad = ~np.isfinite(out[1])
+    tiles = np.zeros_like(wino_bad); tiles[1, :, 4:8, 4:8] = True                     # tiles (2, 2), (2, 3), (3, 2), (3, 3): patches rows / cols 4..9
+    assert np.all(wino_bad[direct_bad]) and not np.any(wino_bad & ~tiles)             # a superset of the direct pattern, confined to those tiles
+    print("non-finite outputs per channel: direct", int(direct_bad[1, 0].sum()), "winograd", int(wino_bad[1, 0].sum()), "of the tiles' 16")
+    np.testing.assert_allclose(out[1][~tiles], out[0][~tiles], rtol=0, atol=1e-6 * Cin * 9 * 2)
+    assert np.all(np.isfinite(out[1][0]))                               # the other sample is untouched
