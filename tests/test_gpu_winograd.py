@@ -323,3 +323,54 @@ def test_winograd_non_finite_input_stays_inside_the_tiles_that_see_it(dev):
     print("non-finite outputs per channel: direct", int(direct_bad[1, 0].sum()), "winograd", int(wino_bad[1, 0].sum()), "of the tiles' 16")
     np.testing.assert_allclose(out[1][~tiles], out[0][~tiles], rtol=0, atol=1e-6 * Cin * 9 * 2)
     assert np.all(np.isfinite(out[1][0]))                               # the other sample is untouched
+
+
+def _fuzz_geometries(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    while len(out) < n:
+        N = int(rng.integers(1, 6))
+        Cin, Cout = int(rng.choice([64, 128, 192])), int(rng.choice([64, 128, 192, 256]))
+        Ho, Wo = 2 * int(rng.integers(1, 13)), 2 * int(rng.integers(1, 13))
+        pad = (int(rng.integers(0, 2)), int(rng.integers(0, 2)))
+        if Ho + 2 - 2 * pad[0] < 1 or Wo + 2 - 2 * pad[1] < 1:
+            continue
+        out.append((N, Cin, Cout, Ho, Wo, pad))
+    return out
+
+
+@pytest.mark.parametrize("N,Cin,Cout,Ho,Wo,pad", _fuzz_geometries(36, 20260925))
+def test_winograd_fuzz_all_three_passes_equal_the_direct_kernels_on_integer_data(dev, N, Cin, Cout, Ho, Wo, pad):
+    """Seeded random geometries (1 - 5 samples, 64 - 256 channels, even output extents 2 - 24, zero padding 0 / 1 per axis): forward + bias,
+    input gradient with the padding folded, kernel gradient + bias gradient - the Winograd kernels (forced, whatever the size) against the
+    implicit-GEMM / direct kernels on integer-valued data, bit for bit; with padding also the folded entry points against the padded copy."""
+    c = capi()
+    H, W = Ho + 2 - 2 * pad[0], Wo + 2 - 2 * pad[1]                    # unpadded input
+    x, w, b = ints(1, (N, Cin, H, W), -3, 3), ints(2, (Cout, Cin, 3, 3), -2, 2), ints(3, (Cout, 1, 1), -4, 4)
+    go = ints(4, (N, Cout, Ho, Wo), -2, 2)
+    xp = np.zeros((N, Cin, H + 2 * pad[0], W + 2 * pad[1]), np.float32)
+    xp[:, :, pad[0]:pad[0] + H, pad[1]:pad[1] + W] = x
+    res = {}
+    for mode in (1, 0):
+        dev.conv_winograd(mode, None, None, mode)
+        try:
+            XP, Wd, B, G = dev.array(xp), dev.array(w), dev.array(b), dev.array(go)
+            Y, DX = dev.full((N, Cout, Ho, Wo), np.nan), dev.full((N, Cin, H, W), np.nan)
+            DW, DB = dev.full(w.shape, np.nan), dev.full(b.shape, np.nan)
+            c.conv_fwd(dev, XP, Wd, Y, (1, 1), (1, 1), 1, bias=B)
+            c.conv_bwd_input(dev, DX, G, Wd, (1, 1), (1, 1), 1, assign=True, padding=pad)
+            c.conv_bwd_kernel_bias(dev, DW, DB, G, XP, (1, 1), (1, 1), 1, assign=(True, True))
+            res[mode] = [a.numpy() for a in (Y, DX, DW, DB)]
+            if mode == 1 and pad != (0, 0):
+                X = dev.array(x)
+                Y2, DW2, DB2 = dev.full((N, Cout, Ho, Wo), np.nan), dev.full(w.shape, np.nan), dev.full(b.shape, np.nan)
+                c.conv_fwd_padded(dev, X, Wd, Y2, pad, (1, 1), (1, 1), 1, bias=B)
+                c.conv_bwd_kernel_padded(dev, DW2, G, X, pad, (1, 1), (1, 1), 1, db=DB2, assign=(True, True))
+                res["fold"] = [a.numpy() for a in (Y2, DW2, DB2)]
+        finally:
+            dev.conv_winograd(None)
+    for name, a, d in zip(("y", "dx", "dw", "db"), res[1], res[0]):
+        assert np.array_equal(a, d), name
+    if "fold" in res:
+        for name, a, d in zip(("y", "dw", "db"), res["fold"], (res[0][0], res[0][2], res[0][3])):
+            assert np.array_equal(a, d), "folded " + name
