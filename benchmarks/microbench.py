@@ -80,8 +80,10 @@ def bench_gemm(dev, sizes, iters):
 
 def bench_stream(dev, iters):
     # two sizes: the C4 tensors (4096 x 4096 = 64 MB each: a two-stream kernel moves 128 - 256 MB and partly lives in the 256 MB
-    # Infinity Cache - rates above the 6.3 TB/s copy ceiling are cache hits) and 16384 x 4096 (256 MB each: HBM)
-    for rows, label in ((4096, "C4 size, partly Infinity-Cache resident"), (16384, "256 MB tensors: HBM")):
+    # Infinity Cache - rates above the 6.3 TB/s copy ceiling are cache hits), 16384 x 4096 (256 MB each: still cache-assisted) and
+    # 65536 x 4096 (1 GiB each: HBM rates - the judged rows)
+    for rows, label in ((4096, "C4 size, partly Infinity-Cache resident"), (16384, "256 MB tensors: Infinity-Cache assisted"),
+                        (65536, "1 GiB tensors: HBM")):
         n = rows * 4096
         X, Y, Bv, G, D = rand(dev, (rows, 4096), 0), dev.zeros((rows, 4096)), rand(dev, (4096,), 1), rand(dev, (rows, 4096), 2), dev.zeros((rows, 4096))
         Db = dev.zeros((4096,))
@@ -96,6 +98,8 @@ def bench_stream(dev, iters):
             ("mse_fwd", lambda: c.mse_fwd(dev, X, G, out, "mean"), 8 * n),
             ("mse_bwd", lambda: c.mse_bwd(dev, D, out, X, G, "mean"), 16 * n),
             ("fill0", lambda: D.fill(0.0), 4 * n),
+            ("copy (1 read + 1 write)", lambda: c.check(c.lib.nk_copy(dev.h, Y.p, X.p, n)), 8 * n),
+            ("add (2 reads + 1 write)", lambda: c.binary_fwd(dev, "add", Y, X, G), 12 * n),
             ("sgd", lambda: c.sgd_step(dev, X, G, None, lr=1e-9), 12 * n),
             ("sgd_multi(3 parameters)", lambda: c.sgd_step_multi(dev, [X, Y, D], [G, G, G], None, lr=1e-9), 3 * 12 * n),
         ]
@@ -138,9 +142,13 @@ def bench_conv(dev, iters, batch=128):
     for name, fn in (("conv_fwd", lambda: c.conv_fwd(dev, XP, W, Y, (1, 1), (1, 1), 1)),
                      ("conv_bwd_input", lambda: c.conv_bwd_input(dev, DXP, G, W, (1, 1), (1, 1), 1)),
                      ("conv_bwd_kernel", lambda: c.conv_bwd_kernel(dev, DW, G, XP, (1, 1), (1, 1), 1))):
+        before = dev.conv_winograd_launches()
         ms = timeit(dev, fn, iters)
-        emit(kernel=name, batch=batch, ms=round(ms, 4), tflops=round(flop / ms / 1e9, 2),
-             frac_mfma_peak=round(flop / (ms * 1e-3) / MFMA_F32_PEAK, 4))
+        wino = dev.conv_winograd_launches() > before       # Winograd F(2x2, 3x3) / F(3x3, 2x2): 16 / 36 of the direct multiplies
+        executed = flop * (16.0 / 36.0 if wino else 1.0)
+        emit(kernel=name, batch=batch, ms=round(ms, 4), winograd=wino, tflops_executed=round(executed / ms / 1e9, 2),
+             frac_mfma_peak=round(executed / (ms * 1e-3) / MFMA_F32_PEAK, 4),        # on the MFMA flops executed: <= 1
+             direct_equivalent_tflops=round(flop / ms / 1e9, 2), algorithmic_speedup=round(flop / executed, 4))
 
 
 def main():

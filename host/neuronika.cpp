@@ -917,18 +917,22 @@ struct LinearBwd : Backward {
     Shared<HipArray> x, w;
     Shared<HipArray> y;              // set for the fused Linear+ReLU node: its output, the mask of its own gradient
     Shared<Gradient> dx, dw, db, g;  // dx null for a non-differentiable input
+    mutable Shared<HipArray> masked_;  // (y > 0) * dL/dy of a pass whose writers stored plain values; owned by the node (see below)
     void backward() const override {
         // Linear+ReLU: g must hold dL/dz = (y > 0) * dL/dy.  When every writer of g on this tape applied the mask while
         // storing (`premasked`, decided by VarDiff::run_backward), it already does; otherwise mask it in place now
         // into a scratch copy (the traffic of an in-place pass): g itself keeps dL/dy, what `grad()` of this variable shows
         // in the reference's graph - also for a root, whose gradient is the seed
-        Shared<HipArray> masked;
-        if (y && !g->premasked()) {
+        // The scratch belongs to the NODE: allocated the first time a pass needs it and kept for the node's life, so that a pass
+        // never allocates after the first one (a hipGraph captured from a warm step bakes in a pointer that stays this node's -
+        // the pool cannot hand it to another tensor between replays).
+        const bool mask_now = y && !g->premasked();
+        if (mask_now) {
             const HipArray& Gy = g->borrow();
-            masked = std::make_shared<HipArray>(x->device(), Gy.shape(), HipArray::Uninit{});
-            check(nk_relu_bwd_assign(D(x), masked->ptr(), Gy.ptr(), y->ptr(), Gy.len()));
+            if (!masked_ || masked_->shape() != Gy.shape()) masked_ = std::make_shared<HipArray>(x->device(), Gy.shape(), HipArray::Uninit{});
+            check(nk_relu_bwd_assign(D(x), masked_->ptr(), Gy.ptr(), y->ptr(), Gy.len()));
         }
-        const HipArray& G = masked ? *masked : g->borrow();
+        const HipArray& G = mask_now ? *masked_ : g->borrow();
         nk_device* dev = D(x);
         const int n = x->shape()[0], m = x->shape()[1], o = w->shape()[0];
         // MatrixMatrixMulTBackward (left, right) and AdditionBackwardRight write three different buffers, so their

@@ -87,10 +87,15 @@ const char* nk_version(void);
  *                          channels) / 1 wide blocks (four waves, 128 channels, chunks of 32) where the channel counts allow both;
  *                          values[3] (optional) = -1 rule / 0 the kernel gradient never takes its Winograd F(3x3, 2x2) form / 1 whenever
  *                          the shape allows (64 | both channel counts, even output extents)
+ *   NK_TUNE_GEMM_CHAIN     values[0] = -1 rule / 0 an unsplit GEMM sums K as ONE f32 chain whatever its length / L (a multiple of 64):
+ *                          unsplit plain-epilogue GEMMs (MatMul, MatMulT, weight gradients) with K > L run as consecutive launches
+ *                          over equal pieces of K, each on top of the last (beta = 1): chains of at most L.  Rule: L = 2048 - what
+ *                          keeps 4096- and 8192-long contractions inside 1e-6 K |a| |b| of the f64 result (SURVEY.md 8c ii; the
+ *                          reference's matrixmultiply sums K in cache blocks too, matrix_matrix_mul/mod.rs:33-39)
  * For schedule sweeps (benchmarks/ab_*.py) and the tests that pit one schedule against another bit for bit; results never
- * depend on them beyond summation order (split-K). */
+ * depend on them beyond summation order (split-K, chain length). */
 enum { NK_TUNE_GEMM_FORCE = 0, NK_TUNE_GEMM_KPAIR = 1, NK_TUNE_ATTENTION_OCC = 2, NK_TUNE_GEMM_PAIR = 3, NK_TUNE_CONV_NARROW = 4,
-       NK_TUNE_CONV_WINOGRAD = 5 };
+       NK_TUNE_CONV_WINOGRAD = 5, NK_TUNE_GEMM_CHAIN = 6 };
 int nk_dev_tune(nk_device* dev, int knob, const int* values, int n);
 /* How many convolution launches on this handle took the Winograd F(2x2, 3x3) kernels so far (forward + input gradient; the rule
  * of NK_TUNE_CONV_WINOGRAD decides per launch).  For harnesses that must say which algorithm produced a time: bench.py quotes the
@@ -286,9 +291,12 @@ int nk_conv_bwd_kernel_bias(nk_device* dev, int nd, float* dw, float* db, const 
  * out-of-range-is-zero buffer loads, so only their geometries fold: 3 x 3, stride 1, dilation 1, one group, padding 0 or 1 per axis (not
  * all zero), 64 | both channel counts, even output extents.  nk_conv_padding_folds answers, for a geometry and the rules in force on the
  * handle, whether BOTH passes would run their Winograd kernels anyway (*folds = 1: build the module node without the Pad node and
- * call the two `_padded` entries; 0: pad, then nk_conv_bias_fwd / nk_conv_bwd_kernel_bias).  The `_padded` entries themselves take every
- * geometry the kernels can (whatever the block-count rules say) and return NK_ERR_UNSUPPORTED for the others.  Same values as the
- * two-node form, bit for bit (zeros are read instead of stored).  bias / db may be NULL.  The input gradient's padded form is below. */
+ * call the two `_padded` entries; 0: pad, then nk_conv_bias_fwd / nk_conv_bwd_kernel_bias).  The `_padded` entries themselves fold for
+ * every geometry the kernels can (whatever the block-count rules say); for the others - and when the rules in force at CALL time decline,
+ * e.g. a nk_dev_tune change after the graph was built - they are the two nodes they stand for: Pad::forward into a scratch region of the
+ * device handle, then the convolution entry on the copy (any nd, stride, dilation, groups; never NK_ERR_UNSUPPORTED).  Same values as the
+ * two-node form, bit for bit, either way (zeros are read instead of stored).  bias / db may be NULL.  The input gradient's padded form is
+ * below. */
 int nk_conv_padding_folds(nk_device* dev, int nd, const int* x_shape, const int* padding, const int* w_shape, const int* stride,
                           const int* dilation, int groups, int* folds);
 int nk_conv_bias_fwd_padded(nk_device* dev, int nd, const float* x, const int* x_shape, const int* padding, const float* w,

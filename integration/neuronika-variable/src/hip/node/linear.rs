@@ -1,5 +1,5 @@
 use super::grad_id;
-use std::cell::Cell;
+use std::cell::{Cell, RefCell};
 use std::rc::Rc;
 
 use ndarray::{Ix1, Ix2};
@@ -75,6 +75,9 @@ pub(crate) struct LinearBackward {
     weight_gradient: Rc<Gradient<HipArray<Ix2>, Ix2>>,
     bias_gradient: Rc<Gradient<HipArray<Ix1>, Ix1>>,
     gradient: Rc<Gradient<HipArray<Ix2>, Ix2>>,
+    /// (y > 0) * dL/dy of a pass whose writers stored plain values.  Owned by the node: allocated the first time a pass needs it
+    /// and kept, so that no later pass allocates (a captured hipGraph keeps a pointer that stays this node's).
+    masked_scratch: RefCell<Option<HipArray<Ix2>>>,
 }
 
 impl LinearBackward {
@@ -83,7 +86,8 @@ impl LinearBackward {
                       input_mask: Option<Rc<ReluMask>>, input_gradient: Option<Rc<Gradient<HipArray<Ix2>, Ix2>>>,
                       weight_gradient: Rc<Gradient<HipArray<Ix2>, Ix2>>, bias_gradient: Rc<Gradient<HipArray<Ix1>, Ix1>>,
                       gradient: Rc<Gradient<HipArray<Ix2>, Ix2>>) -> Self {
-        Self { input_data, weight_data, output_mask, input_mask, input_gradient, weight_gradient, bias_gradient, gradient }
+        Self { input_data, weight_data, output_mask, input_mask, input_gradient, weight_gradient, bias_gradient, gradient,
+               masked_scratch: RefCell::new(None) }
     }
 }
 
@@ -94,16 +98,16 @@ impl Backward for LinearBackward {
         let dev = g.device().as_raw();
         let (n, m, o) = (x.dimension()[0] as i32, x.dimension()[1] as i32, w.dimension()[0] as i32);
         // dL/dz of a Linear+ReLU node whose writers stored plain values: one masking pass into a scratch copy
-        let mut masked: Option<HipArray<Ix2>> = None;
+        let mut scratch = self.masked_scratch.borrow_mut();
+        let mut gz: *const f32 = g.as_ptr();
         if let Some(mask) = &self.output_mask {
             if !mask.premasked.get() {
-                let mut scratch = HipArray::zeroed(g.dimension(), g.device().clone());
+                let buf = scratch.get_or_insert_with(|| HipArray::zeroed(g.dimension(), g.device().clone()));
                 let y = mask.source.borrow();
-                ffi::check(unsafe { ffi::nk_relu_bwd_assign(dev, scratch.as_mut_ptr(), g.as_ptr(), y.as_ptr(), g.len()) });
-                masked = Some(scratch);
+                ffi::check(unsafe { ffi::nk_relu_bwd_assign(dev, buf.as_mut_ptr(), g.as_ptr(), y.as_ptr(), g.len()) });
+                gz = buf.as_ptr();
             }
         }
-        let gz: *const f32 = masked.as_ref().map_or(g.as_ptr(), |s| s.as_ptr());
         if let Some(input_gradient) = &self.input_gradient {
             let mut dx = input_gradient.borrow_mut();
             let through_mask = self.input_mask.as_ref().map_or(false, |mask| mask.premasked.get());

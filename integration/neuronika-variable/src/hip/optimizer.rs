@@ -43,29 +43,40 @@ impl SGD {
         self
     }
 
-    /// `Optimizer::register` (`optimizer.rs:64-70`).  Registering the same parameter twice updates it once per step.
+    /// `Optimizer::register` (`optimizer.rs:64-70`).  A parameter registered twice is kept twice and updated twice per step, one
+    /// update after the other - what the reference's loop over its list does (`optimizer.rs:81-86`).
     pub fn register<D: 'static + Dimension>(&mut self, param: &HipVarDiff<D>) {
         let data = param.var.data.borrow_mut().as_mut_ptr();
-        if self.params.iter().any(|p| p.data == data) {
-            return;
-        }
         let (grad, len) = {
             let mut g = param.grad.borrow_mut();
             (g.as_mut_ptr(), g.len())
         };
-        let velocity = if self.momentum != 0. { Some(HipArray::zeroed(IxDyn(&[len]), self.device.clone())) } else { None };
         let keep = param.clone();
-        self.params.push(Param { data, grad, len, velocity, zero: Box::new(move || keep.zero_grad()) });
+        self.params.push(Param { data, grad, len, velocity: None, zero: Box::new(move || keep.zero_grad()) });
     }
 
-    /// `Optimizer::step` (`optimizer.rs:81-86`): every parameter's `SGDParam::optimize` (`sgd/mod.rs:186-236`) in one launch.
+    /// `Optimizer::step` (`optimizer.rs:81-86`): every parameter's `SGDParam::optimize` (`sgd/mod.rs:186-236`), all distinct
+    /// parameters in one launch; a second registration of a parameter waits for the next launch instead of racing in this one.
+    /// Momentum buffers are created here, the first time a step runs with `momentum != 0` (the field is public and may be set
+    /// after `register`; `sgd/mod.rs:201-207` starts the buffer from zero as well).
     pub fn step(&mut self) {
-        let list: Vec<(*mut f32, *mut f32, *mut f32, usize)> = self
-            .params
-            .iter_mut()
-            .map(|p| (p.data, p.grad, p.velocity.as_mut().map_or(std::ptr::null_mut(), |v| v.as_mut_ptr()), p.len))
-            .collect();
-        sgd_step_multi(&self.device, &list, self.lr, self.momentum, self.dampening, self.nesterov, self.l1, self.l2);
+        if self.momentum != 0. {
+            for p in self.params.iter_mut().filter(|p| p.velocity.is_none()) {
+                p.velocity = Some(HipArray::zeroed(IxDyn(&[p.len]), self.device.clone()));
+            }
+        }
+        let mut done = vec![false; self.params.len()];
+        while done.iter().any(|d| !*d) {
+            let mut list: Vec<(*mut f32, *mut f32, *mut f32, usize)> = Vec::new();
+            for (k, p) in self.params.iter_mut().enumerate() {
+                if done[k] || list.iter().any(|q| q.0 == p.data) {
+                    continue;
+                }
+                done[k] = true;
+                list.push((p.data, p.grad, p.velocity.as_mut().map_or(std::ptr::null_mut(), |v| v.as_mut_ptr()), p.len));
+            }
+            sgd_step_multi(&self.device, &list, self.lr, self.momentum, self.dampening, self.nesterov, self.l1, self.l2);
+        }
     }
 
     /// `Optimizer::zero_grad` (`optimizer.rs:88-94`).

@@ -260,7 +260,7 @@ class Event:
             pass
 
 
-TUNE_GEMM_FORCE, TUNE_GEMM_KPAIR, TUNE_ATTENTION_OCC, TUNE_GEMM_PAIR, TUNE_CONV_NARROW, TUNE_CONV_WINOGRAD = 0, 1, 2, 3, 4, 5   # include/neuronika_hip.h: nk_dev_tune knobs
+TUNE_GEMM_FORCE, TUNE_GEMM_KPAIR, TUNE_ATTENTION_OCC, TUNE_GEMM_PAIR, TUNE_CONV_NARROW, TUNE_CONV_WINOGRAD, TUNE_GEMM_CHAIN = 0, 1, 2, 3, 4, 5, 6   # include/neuronika_hip.h: nk_dev_tune knobs
 
 
 class Device:
@@ -277,7 +277,8 @@ class Device:
         # The sweep scripts (benchmarks/ab_*.py, tools/sessions/*.sh) choose a schedule per process through environment
         # variables; it is THIS harness that reads them and calls nk_dev_tune - the library itself reads none.
         for var, knob in (("NK_GEMM_FORCE", TUNE_GEMM_FORCE), ("NK_GEMM_KPAIR", TUNE_GEMM_KPAIR), ("NK_ATTN_OCC", TUNE_ATTENTION_OCC),
-                          ("NK_GEMM_PAIR", TUNE_GEMM_PAIR), ("NK_CONV_NARROW", TUNE_CONV_NARROW), ("NK_CONV_WINOGRAD", TUNE_CONV_WINOGRAD)):
+                          ("NK_GEMM_PAIR", TUNE_GEMM_PAIR), ("NK_CONV_NARROW", TUNE_CONV_NARROW), ("NK_CONV_WINOGRAD", TUNE_CONV_WINOGRAD),
+                          ("NK_GEMM_CHAIN", TUNE_GEMM_CHAIN)):
             if os.environ.get(var):
                 self.tune(knob, os.environ[var])
 
@@ -301,6 +302,10 @@ class Device:
 
     def gemm_pair(self, mode=None):
         self.tune(TUNE_GEMM_PAIR, mode)
+
+    def gemm_chain(self, length=None):
+        """NK_TUNE_GEMM_CHAIN: None / -1 the rule (chains of at most 2048), 0 one chain whatever K, L > 0 chains of at most L"""
+        self.tune(TUNE_GEMM_CHAIN, length)
 
     def conv_narrow(self, cost=None):
         self.tune(TUNE_CONV_NARROW, cost)

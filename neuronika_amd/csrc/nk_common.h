@@ -30,6 +30,8 @@ struct nk_device {
     hipEvent_t join = nullptr;      // comm -> compute ordering helper
     void* workspace = nullptr;      // stream-ordered scratch (split-K slabs, reduction partials)
     size_t workspace_bytes = 0;
+    void* operand_scratch = nullptr;  // second scratch region: an operand built for a kernel that uses the workspace itself
+    size_t operand_scratch_bytes = 0;
     int graphs_alive = 0;           // nk_graph objects of this device: their kernels have workspace pointers baked in
     std::vector<void*> workspace_retired;  // outgrown workspaces kept while any graph may still replay into them
     int num_cus = 256;
@@ -39,6 +41,7 @@ struct nk_device {
     int tune_gemm[6] = {0, 0, 0, 0, 0, 0};  // ti, tj, splits[, tiles per block[, tile-order group height[, look-ahead threshold]]]
     int tune_gemm_n = 0;                     // how many of them are set (< 3: the rules decide)
     int tune_kpair = -1;                     // k-pair blocks: -1 rule, 0 never, 1 lock-step groups, 2 skewed groups
+    int tune_chain = -1;                     // chained launches: -1 rule (chains of at most 2048), 0 one chain whatever K, > 0 that length
     int tune_pair = -1;                      // nk_sgemm_pair: -1 rule, 0 always two launches, 1 one launch whenever eligible
     int tune_conv_narrow = -1;                // conv kernel gradient, mixed launch: -1 the rules above, 0 uniform launch, 1..100 the price in percent
     unsigned long long wino_launches = 0;    // convolution launches that took the Winograd kernels (nk_conv_winograd_launches)
@@ -69,6 +72,7 @@ int nk_fail_hip(hipError_t e, const char* what, const char* file, int line);
 // Stream-ordered scratch of at least `bytes` (grown by realloc when too small; the old block
 // is released after a device sync, so kernels already enqueued keep a valid pointer).
 int nk_workspace(nk_device* dev, size_t bytes, void** out);
+int nk_operand_scratch(nk_device* dev, size_t bytes, void** out);
 
 #define NK_HIP(call)                                                         \
     do {                                                                     \

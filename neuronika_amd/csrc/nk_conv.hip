@@ -633,6 +633,21 @@ int conv_padding_folds(nk_device* dev, int nd, const int* x_shape, const int* pa
     return NK_OK;
 }
 
+// Pad::forward (Zero) of `x` into the device's operand scratch - the region no convolution kernel uses for its own slabs / tables
+int padded_copy(nk_device* dev, int nd, const float* x, const int* x_shape, const int* padding, float** xp, int* pshape) {
+    size_t elems = (size_t)x_shape[0] * x_shape[1];
+    pshape[0] = x_shape[0]; pshape[1] = x_shape[1];
+    for (int d = 0; d < nd; ++d) {
+        pshape[2 + d] = x_shape[2 + d] + 2 * padding[d];
+        elems *= (size_t)pshape[2 + d];
+    }
+    void* p = nullptr;
+    int rc = nk_operand_scratch(dev, elems * sizeof(float), &p);
+    if (rc) return rc;
+    *xp = (float*)p;
+    return nk_pad_const_fwd(dev, nd, x, x_shape, *xp, padding, 0.f);
+}
+
 int conv_fwd_padded(nk_device* dev, int nd, const float* x, const int* x_shape, const int* padding, const float* w, const int* w_shape,
                     const float* bias, float* y, const int* stride, const int* dilation, int groups) {
     NK_USE(dev);
@@ -642,15 +657,19 @@ int conv_fwd_padded(nk_device* dev, int nd, const float* x, const int* x_shape, 
     if (rc) return rc;
     NK_CHECK(x && w && y, "null pointer in nk_conv_bias_fwd_padded");
     bool taken = false;
-    if (fold)
+    if (fold && dev->tune_conv_winograd != 0)  // (the knob's "never" holds here too; `force` only skips the block-count rule)
         rc = wino_launch(dev, false, x, w, y, bias, g.N, g.Cin, g.Cout, x_shape[2], x_shape[3], g.out[1], g.out[2], padding[0], padding[1], 1,
                          2.0 * g.N * (double)g.Cout * g.L * g.Cg * g.KK, &taken, true);
     if (rc) return rc;
-    if (!taken) {
-        nk_set_error("nk_conv_bias_fwd_padded: this geometry has no kernel with the padding folded in (ask nk_conv_padding_folds; pad, then nk_conv_bias_fwd)");
-        return NK_ERR_UNSUPPORTED;
-    }
-    return NK_OK;
+    if (taken) return NK_OK;
+    // No kernel folds the padding for this geometry - or the rules in force decline (a caller that asked nk_conv_padding_folds at
+    // graph-build time may find the knobs changed by the time it runs): the two nodes the entry stands for, Pad::forward into the
+    // device's operand scratch (pad/zero/mod.rs:5-31), then the convolution on the copy - the bits of the two-node path.
+    float* xp = nullptr;
+    int pshape[5];
+    rc = padded_copy(dev, nd, x, x_shape, padding, &xp, pshape);
+    if (rc) return rc;
+    return conv_fwd(dev, nd, xp, pshape, w, w_shape, bias, y, stride, dilation, groups);
 }
 
 int conv_bwd_kernel_padded(nk_device* dev, int nd, float* dw, float* db, const int* w_shape, const float* gy, const float* x, const int* x_shape,
@@ -662,15 +681,16 @@ int conv_bwd_kernel_padded(nk_device* dev, int nd, float* dw, float* db, const i
     if (rc) return rc;
     NK_CHECK(dw && gy && x, "null pointer in nk_conv_bwd_kernel_bias_padded");
     bool taken = false;
-    if (fold)
+    if (fold && dev->tune_conv_winograd != 0 && dev->tune_conv_wino_dw != 0)
         rc = wino_dw_launch(dev, gy, x, dw, db, g.N, g.Cin, g.Cout, g.in[1], g.in[2], assign, assign_b, 2.0 * g.N * (double)g.Cout * g.L * g.Cg * g.KK,
                             &taken, padding[0], padding[1], true);
     if (rc) return rc;
-    if (!taken) {
-        nk_set_error("nk_conv_bwd_kernel_bias_padded: this geometry has no kernel with the padding folded in (ask nk_conv_padding_folds)");
-        return NK_ERR_UNSUPPORTED;
-    }
-    return NK_OK;
+    if (taken) return NK_OK;
+    float* xp = nullptr;  // as in conv_fwd_padded: pad, then the kernel gradient against the copy (the two-node path's bits)
+    int pshape[5];
+    rc = padded_copy(dev, nd, x, x_shape, padding, &xp, pshape);
+    if (rc) return rc;
+    return conv_bwd_kernel(dev, nd, dw, w_shape, gy, xp, pshape, stride, dilation, groups, assign, db, assign_b);
 }
 
 }  // namespace

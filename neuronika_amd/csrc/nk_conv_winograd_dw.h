@@ -63,10 +63,11 @@ __global__ __launch_bounds__(256, 1) void wino_dw_kernel(WinoDwArgs a) {
     // scalar offsets of the twelve loads of an item, made PROVABLY wave-uniform once (readfirstlane): left as expressions of the
     // kernel arguments the compiler kept some of them in vector registers and wrapped those loads in waterfall loops
     int xso[2][4], yso[2][2];
+    const unsigned plane4 = (unsigned)__builtin_amdgcn_readfirstlane(plane * 4);
 #pragma unroll
     for (int ch = 0; ch < 2; ++ch) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) xso[ch][i] = __builtin_amdgcn_readfirstlane((ch * plane + (FOLD ? 0 : i * a.Ws)) * 4);
+        for (int i = 0; i < 4; ++i) xso[ch][i] = FOLD ? 0 : __builtin_amdgcn_readfirstlane((ch * plane + i * a.Ws) * 4);
 #pragma unroll
         for (int r = 0; r < 2; ++r) yso[ch][r] = __builtin_amdgcn_readfirstlane((ch * oplane + r * a.Wd) * 4);
     }
@@ -117,7 +118,10 @@ __global__ __launch_bounds__(256, 1) void wino_dw_kernel(WinoDwArgs a) {
         constexpr int S = decltype(set)::value;
         if (k < 8) {
             const int ch = k >> 2, i = k & 3;
-            const unsigned vo = FOLD ? xrow[i] : xo;
+            // FOLD: the second channel's plane goes into the VECTOR offset - the descriptor's range check covers vector + immediate
+            // offsets only, and the right-most window of the tensor's last row ends 4 bytes past the tensor: checked per dword, that
+            // element reads as 0 (it is the folded padding column, `fix_right`) instead of touching memory behind the allocation
+            const unsigned vo = FOLD ? xrow[i] + (ch ? plane4 : 0u) : xo;
             xr[S][ch][i][0] = __builtin_amdgcn_raw_buffer_load_b64(xrs, vo, xso[ch][i], 0);
             xr[S][ch][i][1] = __builtin_amdgcn_raw_buffer_load_b64(xrs, vo + 8, xso[ch][i], 0);
         } else {

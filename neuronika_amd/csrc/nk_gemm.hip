@@ -13,6 +13,7 @@
 using namespace nkmma;
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+constexpr int GEMM_CHAIN_K = 2048;   // longest f32 chain of an unsplit plain-epilogue launch (chained launches, gemm_impl)
 constexpr int PF2_MIN_KTILES = 48;  // default threshold of the two-k-tile look-ahead loop (per-layout rules in gemm_impl)
 // Summation order (a contract, pinned bit for bit by tests/test_gpu_parity.py::test_sgemm_is_the_device_order_model_bit_for_bit
 // against oracle/device_order_sgemm.c): every output is ONE f32 fma chain over the block's k range in the MFMA feeding order;
@@ -631,11 +632,35 @@ static int gemm_impl(nk_device* dev, int transA, int transB, int M, int N, int K
                      const float* A, int lda, long long sAo, long long sAi, const float* B, int ldb,
                      long long sBo, long long sBi, float beta, float* C, int ldc, long long sCo,
                      long long sCi, int batch_outer, int batch_inner, const float* bias = nullptr, int relu = 0,
-                     const float* mask = nullptr, long long ldm = 0, bool allow_kpair = true) {
+                     const float* mask = nullptr, long long ldm = 0, bool allow_kpair = true, bool allow_chain = true) {
     GemmPlan plan;
     int rc = gemm_plan(dev, transA, transB, M, N, K, alpha, A, lda, sAo, sAi, B, ldb, sBo, sBi, beta, C, ldc, sCo, sCi, batch_outer,
                        batch_inner, bias, relu, mask, ldm, &plan, allow_kpair);
     if (rc || plan.empty) return rc;
+    // Chained launches: an unsplit reduction whose f32 chain would be longer than GEMM_CHAIN_K products runs as consecutive launches
+    // over equal pieces of K, piece i > 0 with beta = 1 on top of what the pieces before it left in C - every output is then
+    // fl(fl(beta C + chain_0) + chain_1) ..., chains of at most GEMM_CHAIN_K (a k-pair block's two halves count as two chains).
+    // Why: one chain of 4096 / 8192 one-signed products drifts as K sqrt(K) and leaves SURVEY.md 8c(ii)'s bound 1e-6 K |a| |b|
+    // (C4 weight gradients 1.07 x, 8192^3 1.19 x of it in round 5); the reference's GEMM (matrixmultiply, matrix_matrix_mul/mod.rs:
+    // 33-39) sums K in cache blocks as well.  Every in-kernel form of the cut cost the k-loop's schedule 1.5 - 20 % (DESIGN.md
+    // section 8); a second launch costs its prologue / epilogue and one more pass over C.  Plain-epilogue launches only (MatMul,
+    // MatMulT, every weight gradient): the epilogue functions (bias, ReLU, mask) act on the WHOLE sum.  Bits stay a function of
+    // the shape.  NK_TUNE_GEMM_CHAIN overrides the length (0: one chain), a forced configuration (NK_TUNE_GEMM_FORCE) is one chain.
+    {
+        const long long chain = dev->tune_chain < 0 ? GEMM_CHAIN_K : dev->tune_chain;
+        const long long reach = chain * plan.kg;  // the K one launch may cover
+        if (allow_chain && chain > 0 && K > reach && plan.p.splits == 1 && !bias && !relu && !mask && dev->tune_gemm_n < 3) {
+            const int pieces = (int)((K + reach - 1) / reach);
+            const int per = ((K + pieces - 1) / pieces + 2 * BK - 1) / (2 * BK) * (2 * BK);  // whole k-tile pairs (k-pair blocks, 16-byte rows)
+            for (int k0 = 0; k0 < K && !rc; k0 += per) {
+                const int kk = K - k0 < per ? K - k0 : per;
+                rc = gemm_impl(dev, transA, transB, M, N, kk, alpha, A + (transA ? (long long)k0 * lda : (long long)k0), lda, sAo, sAi,
+                               B + (transB ? (long long)k0 : (long long)k0 * ldb), ldb, sBo, sBi, k0 == 0 ? beta : 1.f, C, ldc, sCo, sCi,
+                               batch_outer, batch_inner, nullptr, 0, nullptr, 0, allow_kpair, false);
+            }
+            return rc;
+        }
+    }
     GemmArgs& p = plan.p;
     const int nbatch = plan.nbatch, ti = plan.ti, tj = plan.tj, kg = plan.kg;
     const bool aligned = plan.aligned;
@@ -716,6 +741,10 @@ static int gemm_pair_impl(nk_device* dev, const GemmProblem& a, const GemmProble
                        b.sCo, b.sCi, batch_outer, batch_inner, nullptr, 0, nullptr, 0, &q1, false);
     if (rc) return rc;
     if (q0.empty || q1.empty) return two_launches();
+    {   // a reduction longer than one chain runs as chained launches (gemm_impl) - on its own
+        const long long chain = dev->tune_chain < 0 ? GEMM_CHAIN_K : dev->tune_chain;
+        if (chain > 0 && dev->tune_gemm_n < 3 && ((a.K > chain && q0.p.splits == 1) || (b.K > chain && q1.p.splits == 1))) return two_launches();
+    }
     const long long batch = (long long)batch_outer * batch_inner;
     {   // One launch runs the problems concurrently: an output that overlaps the other problem's output or operands (x.mm(x):
         // both gradients are one buffer) keeps the order of two launches.  An operand's footprint is `rows` runs of `width`

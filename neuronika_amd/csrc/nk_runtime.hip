@@ -19,29 +19,44 @@ int nk_fail_hip(hipError_t e, const char* what, const char* file, int line) {
     return e == hipErrorOutOfMemory ? NK_ERR_OOM : NK_ERR_HIP;
 }
 
-int nk_workspace(nk_device* dev, size_t bytes, void** out) {
-    if (bytes > dev->workspace_bytes) {
+static int grow_scratch(nk_device* dev, void*& block, size_t& have, size_t bytes, const char* what) {
+    if (bytes > have) {
         size_t want = bytes < (size_t(64) << 20) ? (size_t(64) << 20) : bytes;
-        if (dev->workspace) {
+        if (block) {
             hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
             NK_HIP(hipStreamIsCapturing(dev->compute, &cs));
             NK_CHECK(cs == hipStreamCaptureStatusNone,
-                     "the device workspace would have to grow (%zu -> %zu bytes) inside a captured region: run one eager step first", dev->workspace_bytes, bytes);
+                     "the device %s would have to grow (%zu -> %zu bytes) inside a captured region: run one eager step first", what, have, bytes);
             if (dev->graphs_alive > 0) {
                 // a captured graph has the old pointer baked into its kernel arguments (split-K slabs, reduction partials,
                 // conv tables): keep the block until the last graph of this device is destroyed
-                dev->workspace_retired.push_back(dev->workspace);
+                dev->workspace_retired.push_back(block);
             } else {
                 NK_HIP(hipDeviceSynchronize());
-                NK_HIP(hipFree(dev->workspace));
+                NK_HIP(hipFree(block));
             }
-            dev->workspace = nullptr;
-            dev->workspace_bytes = 0;
+            block = nullptr;
+            have = 0;
         }
-        NK_HIP(hipMalloc(&dev->workspace, want));
-        dev->workspace_bytes = want;
+        NK_HIP(hipMalloc(&block, want));
+        have = want;
     }
+    return NK_OK;
+}
+
+int nk_workspace(nk_device* dev, size_t bytes, void** out) {
+    const int rc = grow_scratch(dev, dev->workspace, dev->workspace_bytes, bytes, "workspace");
+    if (rc) return rc;
     *out = dev->workspace;
+    return NK_OK;
+}
+
+// A second stream-ordered scratch region, for an OPERAND a call builds for a kernel that uses the workspace itself (the padded copy
+// of a folded-padding convolution entry that falls back to pad -> convolution).  Same growth rules as the workspace.
+int nk_operand_scratch(nk_device* dev, size_t bytes, void** out) {
+    const int rc = grow_scratch(dev, dev->operand_scratch, dev->operand_scratch_bytes, bytes, "operand scratch");
+    if (rc) return rc;
+    *out = dev->operand_scratch;
     return NK_OK;
 }
 
@@ -146,6 +161,7 @@ int nk_device_destroy(nk_device* dev) {
     NK_HIP(hipSetDevice(dev->idx));
     NK_HIP(hipDeviceSynchronize());
     if (dev->workspace) (void)hipFree(dev->workspace);
+    if (dev->operand_scratch) (void)hipFree(dev->operand_scratch);
     for (void* w : dev->workspace_retired) (void)hipFree(w);
     for (auto* v : {&dev->prof, &dev->prof_free})
         for (auto& r : *v) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
@@ -198,6 +214,11 @@ int nk_dev_tune(nk_device* dev, int knob, const int* values, int n) {
             dev->tune_conv_wino_stagger = n >= 2 ? values[1] : -1;
             dev->tune_conv_wino_shape = n >= 3 ? values[2] : -1;
             dev->tune_conv_wino_dw = n >= 4 ? values[3] : -1;
+            return NK_OK;
+        case NK_TUNE_GEMM_CHAIN:
+            NK_CHECK(n <= 1 && (n == 0 || values[0] == -1 || values[0] == 0 || (values[0] >= 64 && values[0] % 64 == 0)),
+                     "NK_TUNE_GEMM_CHAIN: -1 (rule), 0 (one chain) or a chain length that is a multiple of 64");
+            dev->tune_chain = n ? values[0] : -1;
             return NK_OK;
         case NK_TUNE_ATTENTION_OCC:
             NK_CHECK(n <= 1 && (n == 0 || values[0] == 0 || values[0] == 2), "NK_TUNE_ATTENTION_OCC: 0 or 2");

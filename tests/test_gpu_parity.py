@@ -38,10 +38,10 @@ def close(a, b, rtol=1e-5, atol=1e-6):
     np.testing.assert_allclose(np.asarray(a), np.asarray(b), rtol=rtol, atol=atol)
 
 
-def contraction_ok(gpu, cpu32, ref64, K, amax, bmax, label=None, L=None):
+def contraction_ok(gpu, cpu32, ref64, K, amax, bmax, label=None):
     """the one contraction policy of the suite: tests/tolerance.py"""
     from tolerance import assert_contraction
-    assert_contraction(label, gpu, ref64, K, amax, bmax, cpu32=cpu32, L=L)
+    assert_contraction(label, gpu, ref64, K, amax, bmax, cpu32=cpu32)
 
 
 # ------------------------------------------------------------------------------ golden: conv
@@ -638,6 +638,58 @@ def shared_chip_plan(M, N, K, busy, cus=256):
     return (tm - g) * 128, (tn - tail // g) * 128, pieces, kts
 
 
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0)])
+def test_sgemm_chained_launches(dev, ta, tb):
+    """An unsplit plain-epilogue GEMM with K beyond one chain (GEMM_CHAIN_K = 2048 products; a k-pair block's halves are two chains)
+    runs as consecutive launches over equal pieces of K, each on top of the last (nk_gemm.hip, gemm_impl).  BIT FOR BIT what the
+    caller would get by issuing those launches himself with the knob at 0 (one chain per launch - whose own order is pinned by
+    the device-order model above): alpha and beta on the first piece, beta = 1 after it; ragged K; a k-pair grid (2048 x 2048: one
+    128 x 128 block per CU, so one launch reaches 4096); the knob's other lengths; a launch with a bias keeps ONE chain."""
+    import ctypes
+    c = capi()
+
+    class View:
+        def __init__(self, a, off): self.keep, self.p = a, ctypes.c_void_p(a.p.value + 4 * off)
+
+    try:
+        for (M, N, K, chain, reach) in ((2048, 4096, 4096, None, 2048), (2048, 4096, 4160, None, 2048), (4096, 2048, 6144, None, 2048),
+                                        (2048, 2048, 8192, None, 4096), (2048, 4096, 3072, 1024, 1024), (2048, 4096, 2048, None, 2048)):
+            a = rnd(70 + K, (K, M) if ta else (M, K), -1, 1)
+            b = rnd(71 + K, (N, K) if tb else (K, N), -1, 1)
+            c0 = rnd(72, (M, N), -1, 1)
+            A, B = dev.array(a), dev.array(b)
+            for alpha, beta in ((1.0, 0.0), (-0.5, 1.0)):
+                dev.gemm_chain(chain)
+                C1 = dev.array(c0)
+                c.sgemm(dev, ta, tb, M, N, K, alpha, A, a.shape[1], B, b.shape[1], beta, C1, N)
+                dev.gemm_chain(0)
+                C2 = dev.array(c0)
+                pieces = -(-K // reach)
+                per = -(-(-(-K // pieces)) // 64) * 64
+                k0 = 0
+                while k0 < K:
+                    kk = min(per, K - k0)
+                    Av = View(A, k0 * a.shape[1] if ta else k0)
+                    Bv = View(B, k0 if tb else k0 * b.shape[1])
+                    c.sgemm(dev, ta, tb, M, N, kk, alpha, Av, a.shape[1], Bv, b.shape[1], beta if k0 == 0 else 1.0, C2, N)
+                    k0 += kk
+                assert np.array_equal(C1.numpy(), C2.numpy()), (M, N, K, chain, alpha, beta)
+                if K > reach:       # ... and NOT what one chain gives (the cut is really taken)
+                    C3 = dev.array(c0)
+                    c.sgemm(dev, ta, tb, M, N, K, alpha, A, a.shape[1], B, b.shape[1], beta, C3, N)
+                    assert not np.array_equal(C1.numpy(), C3.numpy())
+        # an epilogue function acts on the whole sum: Linear forward (bias) is one chain whatever the knob says
+        n, m, o = 2048, 4096, 4096
+        x, w, bv = rnd(1, (n, m), -1, 1), rnd(2, (o, m), -1, 1), rnd(3, (o,), -1, 1)
+        X, W, Bv = dev.array(x), dev.array(w), dev.array(bv)
+        Y1, Y2 = dev.zeros((n, o)), dev.zeros((n, o))
+        dev.gemm_chain(None); c.linear_fwd(dev, X, W, Bv, Y1)
+        dev.gemm_chain(0); c.linear_fwd(dev, X, W, Bv, Y2)
+        assert np.array_equal(Y1.numpy(), Y2.numpy())
+    finally:
+        dev.gemm_chain(None)
+
+
 @pytest.mark.parametrize("layout", ["NT", "NN", "TN"])
 @pytest.mark.parametrize("M,N,K,busy", [(4096, 4096, 256, 16), (2048, 4096, 1024, 8), (4096, 2048, 384, 32), (4096, 4096, 512, 40),
                                         (3200, 5120, 256, 16)])   # tile counts the rules keep at 128x128: 1024, 512, 512, 1024, 1000 (25 tile rows: a last group of one); >= 4 pieces possible
@@ -761,8 +813,8 @@ def test_C2_matmul_fwd_bwd_every_benchmark_size(dev, n):
     `nk_mm_bwd_right` TN `+=`) at N = 1024 / 2048 (small grids: 64x64 tiles, k-pair blocks), 4096 and 8192 (1 GiB of
     operands: tile count, XCD chunking, look-ahead path), each checked
       * through 96 sampled entries against f64 dot products of the operand rows / columns, under the suite's ONE contraction
-        bound (tests/tolerance.py) with err_cpu32 from OpenBLAS's f32 product of the same rows and the device's chain
-        length L = n (one chain per output; up to 2048 the factor is 1: the survey's bound as it stands) - margins
+        bound (tests/tolerance.py: the survey's, no factor) with err_cpu32 from OpenBLAS's f32 product of the same rows; at
+        4096 / 8192 each product runs as 2 / 4 chained launches over K (chains of 2048, nk_gemm.hip GEMM_CHAIN_K) - margins
         recorded under the labels C2_<n>:<C|dA|dB>;
       * through the row-sum identity (A.B).1 == A.(B.1) over the whole result.
     Gradients start from a non-zero value so `+=` is exercised."""
@@ -775,7 +827,6 @@ def test_C2_matmul_fwd_bwd_every_benchmark_size(dev, n):
     rng = np.random.default_rng(5)
     ii, jj = rng.integers(0, n, 96), rng.integers(0, n, 96)
     ones = np.ones(n)
-    L = n          # the backward products are one chain of n per output at every size (the forward's k-pair halves at 1024 / 2048 are shorter)
     for name, got_d, init, left, right, tl, tr in (("C", Cm, 0.0, a, b, False, False), ("dA", dA, 0.5, g, b, False, True),
                                                    ("dB", dB, -0.25, a, g, True, False)):
         got = got_d.numpy()
@@ -786,7 +837,7 @@ def test_C2_matmul_fwd_bwd_every_benchmark_size(dev, n):
         full32 = np.ascontiguousarray(lrows) @ (right.T if tr else right)
         cpu32 = np.float32(init) + full32[np.arange(96), jj]
         assert_contraction(f"C2_{n}:{name}", got[ii, jj], want, n, float(np.abs(left).max()), float(np.abs(right).max()),
-                           cpu32=cpu32, L=L)
+                           cpu32=cpu32)
         # (L.R).1 = L.(R.1): f64 on the host costs two matrix-vector products
         opr1 = (right.astype(np.float64).sum(axis=0) if tr else right.astype(np.float64) @ ones)
         want_rows = (left.astype(np.float64).T @ opr1 if tl else left.astype(np.float64) @ opr1) + init * n

@@ -1289,6 +1289,44 @@ def test_mha_strided_heads_equals_split_merge(nk, tdev):
         assert np.array_equal(a, b)
 
 
+def test_conv2d_module_built_folded_survives_a_knob_change(nk, tdev):
+    """nn::Conv2d decides at graph-BUILD time to leave the Pad node out (nk_conv_padding_folds said yes under the rules then in force);
+    the folded entries decide per CALL.  With the knob turned to "never Winograd" between build and forward() the node's entries fall
+    back to the two nodes they stand for (Pad::forward into the device's operand scratch, node/pad/mod.rs:97-129, then the convolution
+    entries, convolution/mod.rs:331-355): a valid graph stays valid, and its values are the BITS of the module built with
+    `fold_padding = false` under the same knob - forward, input gradient, kernel and bias gradient; the launch counter says no
+    Winograd kernel ran."""
+    from neuronika_amd import capi
+    cdev = capi.Device(handle=tdev.raw())
+    N, Cin, Cout, H = 96, 64, 128, 28                                 # (large enough for the rules of all three passes)
+    x, gy = rnd(0, (N, Cin, H, H)), rnd(2, (N, Cout, H, H))
+    assert capi.conv_padding_folds(cdev, x.shape, (1, 1), (Cout, Cin, 3, 3), (1, 1), (1, 1), 1)
+    conv = nk.nn.Conv2d(tdev, Cin, Cout, [3, 3], [1, 1], nk.PaddingMode.zero(), [1, 1], [1, 1], 1)
+    X = nk.from_ndarray(tdev, x).requires_grad()
+    y = conv.forward(X)                                               # built under the rule: no Pad node
+    plain = nk.nn.Conv2d(tdev, Cin, Cout, [3, 3], [1, 1], nk.PaddingMode.zero(), [1, 1], [1, 1], 1)
+    plain.fold_padding = False
+    X2 = nk.from_ndarray(tdev, x).requires_grad()
+    y2 = plain.forward(X2)
+    assert y.history_len() < y2.history_len()                         # the Pad node is what the folded graph lacks
+    cdev.conv_winograd(0)
+    try:
+        before = cdev.conv_winograd_launches()
+        y.forward(); y.backward_from(nk.from_ndarray(tdev, gy))
+        y2.forward(); y2.backward_from(nk.from_ndarray(tdev, gy))
+        assert cdev.conv_winograd_launches() == before
+    finally:
+        cdev.conv_winograd(None)
+    assert np.array_equal(conv.weight.data(), plain.weight.data())   # same seed, same parameters
+    for a, b in ((y.data(), y2.data()), (X.grad(), X2.grad()), (conv.weight.grad(), plain.weight.grad()), (conv.bias.grad(), plain.bias.grad())):
+        assert np.array_equal(a, b)
+    # and back under the rule the same graph takes the Winograd kernels again (values: test_conv2d_module_at_a_size_... below)
+    X.zero_grad(); conv.weight.zero_grad(); conv.bias.zero_grad()
+    before = cdev.conv_winograd_launches()
+    y.forward(); y.backward_from(nk.from_ndarray(tdev, gy))
+    assert cdev.conv_winograd_launches() - before == 3
+
+
 def test_conv2d_module_at_a_size_the_winograd_rule_takes(nk, tdev):
     """nn::Conv2d (3 x 3, pad 1) through the tape at 48 x 64 x 56 x 56 -> 128 channels: by rule all three passes take the Winograd
     kernels (nk_conv_bias_fwd, nk_conv_bwd_input_padded, nk_conv_bwd_kernel_bias - the launch counter says so); the same step with the
@@ -1323,24 +1361,19 @@ def test_conv2d_module_at_a_size_the_winograd_rule_takes(nk, tdev):
         assert np.array_equal(a, r)
     w, b = got[None][4], got[None][5]
     assert np.array_equal(w, got[0][4]) and np.array_equal(b, got[0][5])   # same seed, same parameters
-    xp = np.zeros((N, Cin, H + 2, H + 2), np.float64); xp[:, :, 1:-1, 1:-1] = x
-    w64, g64 = w.astype(np.float64), gy.astype(np.float64)
+    import conv_samples as S
+    from tolerance import assert_contraction
+    xp = np.zeros((N, Cin, H + 2, H + 2), np.float32); xp[:, :, 1:-1, 1:-1] = x
+    xmax, wmax, gmax = float(np.abs(x).max()), float(np.abs(w).max()), float(np.abs(gy).max())
     rng = np.random.default_rng(5)
     for mode in (None, 0):
         y, dx, dw, db = got[mode][:4]
-        for n, co, oh, ow in zip(rng.integers(0, N, 24), rng.integers(0, Cout, 24), rng.integers(0, H, 24), rng.integers(0, H, 24)):
-            ref = (xp[n, :, oh:oh + 3, ow:ow + 3] * w64[co]).sum() + float(b[co, 0, 0])
-            assert abs(y[n, co, oh, ow] - ref) <= 1e-6 * 576, (mode, n, co, oh, ow)
-        for n, ci, ih, iw in zip(rng.integers(0, N, 24), rng.integers(0, Cin, 24), rng.integers(0, H, 24), rng.integers(0, H, 24)):
-            ref = 0.0
-            for kh in range(3):
-                for kw in range(3):
-                    oh, ow = ih + 1 - kh, iw + 1 - kw
-                    if 0 <= oh < H and 0 <= ow < H:
-                        ref += (g64[n, :, oh, ow] * w64[:, ci, kh, kw]).sum()
-            assert abs(dx[n, ci, ih, iw] - ref) <= 1e-6 * 1152, (mode, n, ci, ih, iw)
-        for co, ci, kh, kw in zip(rng.integers(0, Cout, 8), rng.integers(0, Cin, 8), rng.integers(0, 3, 8), rng.integers(0, 3, 8)):
-            ref = (g64[:, co] * xp[:, ci, kh:kh + H, kw:kw + H]).sum()
-            assert abs(dw[co, ci, kh, kw] - ref) <= 2e-7 * N * H * H * 0.5, (mode, co, ci, kh, kw)
-        np.testing.assert_allclose(db.reshape(-1), g64.sum(axis=(0, 2, 3)), rtol=2e-6)
+        tag = "winograd" if mode is None else "implicit GEMM"
+        idx, r64, r32 = S.forward(xp, w, b, rng, 24)
+        assert_contraction(f"Conv2d module 48x64x56x56 ({tag}):y", y[idx], r64, Cin * 9, xmax, wmax, cpu32=r32, epilogue=True)
+        idx, r64, r32 = S.input_gradient(gy, w, rng, 24, padded=False)
+        assert_contraction(f"Conv2d module 48x64x56x56 ({tag}):dx", dx[idx], r64, Cout * 9, gmax, wmax, cpu32=r32)
+        idx, r64, r32 = S.kernel_gradient(gy, xp, rng, 8)
+        assert_contraction(f"Conv2d module 48x64x56x56 ({tag}):dw", dw[idx], r64, N * H * H, gmax, xmax, cpu32=r32)
+        np.testing.assert_allclose(db.reshape(-1), gy.astype(np.float64).sum(axis=(0, 2, 3)), rtol=2e-6)
     assert not np.array_equal(got[None][0], got[0][0])                # two algorithms, two orders of summation

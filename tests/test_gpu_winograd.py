@@ -268,9 +268,12 @@ def test_folded_padding_equals_the_padded_copy_bit_for_bit(dev, N, Cin, Cout, H,
     np.testing.assert_allclose(got[0], y, rtol=0, atol=1e-6 * Cin * 9 * 2)
 
 
-def test_padding_folds_query_and_refusals(dev):
-    """nk_conv_padding_folds follows the rules in force (block counts, the knob); the `_padded` entries refuse what the kernels cannot
-    take (stride 2, 5 x 5, groups, padding 2, 40 channels, no padding at all) with NK_ERR_UNSUPPORTED instead of computing something else."""
+def test_padding_folds_query_and_fallbacks(dev):
+    """nk_conv_padding_folds follows the rules in force (block counts, the knob).  The `_padded` entries fold where their kernels can and
+    are otherwise the two nodes they stand for - Pad::forward (node/pad/mod.rs:97-129) into a scratch region of the handle, then the
+    convolution entry (convolution/mod.rs:331-355) - for what no kernel folds (stride 2, 5 x 5, groups, padding 2, 40 channels, no padding
+    at all, one spatial dimension) and for a foldable geometry under the knob's "never": the bits of pad -> nk_conv_bias_fwd /
+    nk_conv_bwd_kernel_bias, never NK_ERR_UNSUPPORTED (round 5 refused; a knob change between graph build and forward() panicked)."""
     c = capi()
     big, small = (48, 64, 56, 56), (2, 64, 8, 8)
     assert c.conv_padding_folds(dev, big, (1, 1), (128, 64, 3, 3), (1, 1), (1, 1))
@@ -285,15 +288,47 @@ def test_padding_folds_query_and_refusals(dev):
         assert not c.conv_padding_folds(dev, big, (1, 1), (128, 64, 3, 3), (1, 1), (1, 1))
     finally:
         dev.conv_winograd(None)
-    for xs, pad, ws, st, g in ((small, (1, 1), (128, 64, 3, 3), (2, 2), 1), (small, (2, 2), (128, 64, 5, 5), (1, 1), 1),
-                               ((2, 128, 8, 8), (1, 1), (128, 64, 3, 3), (1, 1), 2), (small, (2, 2), (128, 64, 3, 3), (1, 1), 1),
-                               ((2, 40, 8, 8), (1, 1), (128, 40, 3, 3), (1, 1), 1), (small, (0, 0), (128, 64, 3, 3), (1, 1), 1)):
-        assert not c.conv_padding_folds(dev, xs, pad, ws, st, (1, 1), g)
-        X, Wd = dev.zeros(xs), dev.zeros(ws)
-        oshape = O.conv_out_shape(tuple(xs[:2]) + tuple(xs[2 + i] + 2 * pad[i] for i in range(2)), ws, st, (1, 1))
-        Y = dev.zeros(oshape)
-        with pytest.raises(c.NeuronikaHipError):
-            c.conv_fwd_padded(dev, X, Wd, Y, pad, st, (1, 1), g)
+    cases = [(small, (1, 1), (128, 64, 3, 3), (2, 2), 1, None), (small, (2, 2), (128, 64, 5, 5), (1, 1), 1, None),
+             ((2, 128, 8, 8), (1, 1), (128, 64, 3, 3), (1, 1), 2, None), (small, (2, 2), (128, 64, 3, 3), (1, 1), 1, None),
+             ((2, 40, 8, 8), (1, 1), (128, 40, 3, 3), (1, 1), 1, None), (small, (0, 0), (128, 64, 3, 3), (1, 1), 1, None),
+             ((3, 8, 20), (2,), (16, 8, 5), (1,), 1, None), ((2, 4, 6, 7, 8), (1, 0, 2), (6, 4, 3, 1, 2), (1, 1, 1), 1, None),
+             ((4, 64, 16, 16), (1, 1), (128, 64, 3, 3), (1, 1), 1, 0)]               # foldable, under the knob's "never"
+    for xs, pad, ws, st, g, knob in cases:
+        nd = len(xs) - 2
+        dil = (1,) * nd
+        if knob is None:
+            assert not c.conv_padding_folds(dev, xs, pad, ws, st, dil, g)
+        x, w, b = rnd(1, xs, -1, 1), rnd(2, ws, -1, 1), rnd(3, (ws[0],) + (1,) * nd, -1, 1)
+        pshape = tuple(xs[:2]) + tuple(xs[2 + i] + 2 * pad[i] for i in range(nd))
+        xp = np.zeros(pshape, np.float32)
+        xp[(slice(None), slice(None)) + tuple(slice(pad[i], pad[i] + xs[2 + i]) for i in range(nd))] = x
+        oshape = O.conv_out_shape(pshape, ws, st, dil)
+        go, dw0, db0 = rnd(4, oshape, -1, 1), rnd(5, ws), rnd(6, b.shape)
+        X, XP, Wd, B, G = dev.array(x), dev.array(xp), dev.array(w), dev.array(b), dev.array(go)
+        if knob is not None:
+            dev.conv_winograd(knob)
+        try:
+            before = dev.conv_winograd_launches()
+            for bias in (None, B):
+                Y1, Y2 = dev.full(oshape, np.nan), dev.full(oshape, np.nan)
+                c.conv_fwd_padded(dev, X, Wd, Y1, pad, st, dil, g, bias=bias)
+                c.conv_fwd(dev, XP, Wd, Y2, st, dil, g, bias=bias)
+                assert np.array_equal(Y1.numpy(), Y2.numpy()), (xs, pad)
+                if bias is None:
+                    plain = Y1.numpy()
+            for assign in (False, True):
+                D1, D2, E1, E2 = dev.array(dw0), dev.array(dw0), dev.array(db0), dev.array(db0)
+                c.conv_bwd_kernel_padded(dev, D1, G, X, pad, st, dil, g, db=E1, assign=(assign, assign))
+                c.conv_bwd_kernel_bias(dev, D2, E2, G, XP, st, dil, g, assign=(assign, assign))
+                assert np.array_equal(D1.numpy(), D2.numpy()) and np.array_equal(E1.numpy(), E2.numpy()), (xs, pad, assign)
+            assert dev.conv_winograd_launches() == before
+        finally:
+            if knob is not None:
+                dev.conv_winograd(None)
+        y = np.zeros(oshape, np.float32); O.convolution_forward(xp, w, y, st, dil, g)
+        from tolerance import assert_contraction
+        y64 = np.zeros(oshape, np.float64); O.convolution_forward(xp.astype(np.float64), w.astype(np.float64), y64, st, dil, g)
+        assert_contraction("padded entry, fallback", plain, y64, int(np.prod(ws[1:])), cpu32=y)
 
 
 def test_winograd_non_finite_input_stays_inside_the_tiles_that_see_it(dev):
