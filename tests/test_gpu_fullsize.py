@@ -26,7 +26,7 @@ def test_C3_conv_full_size(dev):
     padded-copy entries beside them: sampled outputs / input gradients / kernel gradients against f64 direct sums through
     `assert_contraction` with the operands' own maxima (max|w| = 1/24), margins recorded as `C3_full_size:*`;
     (2) exact linearity: conv(x, 2w) == 2 conv(x, w) bit for bit (power-of-two scaling commutes with every rounding);
-    (3) folded == padded copy bit for bit at the full size."""
+    (3) folded == padded copy bit for bit at the full size (forward, kernel and bias gradient; the input gradients tile differently)."""
     from neuronika_amd import capi as c
     import conv_samples as S
     from tolerance import assert_contraction
@@ -100,7 +100,10 @@ def test_C3_conv_full_size(dev):
     DX = dev.zeros(x.shape)
     c.pad_bwd(dev, DX, DXP, (1, 1))
     assert np.array_equal(DX.numpy(), dxp[:, :, 1:-1, 1:-1])
-    assert np.array_equal(dxf, dxp[:, :, 1:-1, 1:-1])                 # (3)
+    # (the input gradient of the padded copy walks 29 x 29 tiles whose origins lie one element off the folded form's 28 x 28: the same
+    #  products, other add trees - equal to twice the bound each side has just been held to, not bit for bit)
+    from tolerance import abs_term
+    assert np.abs(dxf - dxp[:, :, 1:-1, 1:-1]).max() <= 2 * abs_term(KI, gmax, wmax)
     assert np.array_equal(dwf, dw)                                    # (3)
 
     # bias gradient summed on the way by the kernel-gradient pass (`nk_conv_bwd_kernel_bias`): same dW bits, db by its own bound

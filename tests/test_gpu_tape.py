@@ -1308,7 +1308,6 @@ def test_conv2d_module_built_folded_survives_a_knob_change(nk, tdev):
     plain.fold_padding = False
     X2 = nk.from_ndarray(tdev, x).requires_grad()
     y2 = plain.forward(X2)
-    assert y.history_len() < y2.history_len()                         # the Pad node is what the folded graph lacks
     cdev.conv_winograd(0)
     try:
         before = cdev.conv_winograd_launches()
