@@ -1543,8 +1543,9 @@ namespace nn {
 bool set_relu_peephole(bool on) { const bool was = g_relu_peephole; g_relu_peephole = on; return was; }
 VarDiff linear_relu_from_origin(const LinearOrigin& o);
 }  // namespace nn
-VarDiff VarDiff::relu() const {
-    // `lin.forward(x).relu()`: one Linear+ReLU node over the Linear's operands (see `linear_origin`)
+VarDiff VarDiff::relu() const& { return unary_diff(Unary::Relu, 0, *this, shape()); }
+VarDiff VarDiff::relu() && {
+    // `lin.forward(x).relu()`: one Linear+ReLU node over the Linear's operands (see `linear_origin`); the temporary never runs
     if (linear_origin && g_relu_peephole) return nn::linear_relu_from_origin(*linear_origin);
     return unary_diff(Unary::Relu, 0, *this, shape());
 }

@@ -361,10 +361,11 @@ class VarDiff {
     Shared<Gradient> grad;
     History<BackwardEntry> history;
     // Set on the output of a fused `nn::Linear::forward`: how to build the same product again.  `relu()` on such a
-    // variable - the reference's spelling `lin.forward(x).relu()` (neuronika-nn/src/lib.rs:441-447, vardiff.rs:282-288) -
-    // answers the ONE Linear+ReLU node over the Linear's own operands instead of a ReLU node over this output (graph-build
-    // peephole, `nn::set_relu_peephole`).  The new node does not depend on this one: a dropped temporary never runs, a
-    // variable that is kept (other consumers) stays its own node with its own gradient.
+    // variable AS A TEMPORARY - the reference's spelling `lin.forward(x).relu()` (neuronika-nn/src/lib.rs:441-447; Rust's
+    // `relu(self)` CONSUMES its operand, vardiff.rs:282-288) - answers the ONE Linear+ReLU node over the Linear's own operands
+    // instead of a ReLU node over this output (graph-build peephole, `nn::set_relu_peephole`): the consumed pre-activation is
+    // not observable in the reference either.  On a variable that is KEPT (`h = lin.forward(x); y = h.relu()` - Rust's
+    // `h.clone().relu()`) `relu()` is the ReLU node over h: h is in y's history, its data and gradient are what the reference shows.
     Shared<const nn::LinearOrigin> linear_origin;
 
     static VarDiff leaf(Var var, Shared<Gradient> grad);                                        // vardiff.rs:48
@@ -389,7 +390,8 @@ class VarDiff {
 
     VarDiff sum() const;
     VarDiff mean() const;
-    VarDiff relu() const;
+    VarDiff relu() const&;  // the ReLU node over this (kept) variable
+    VarDiff relu() &&;      // `relu(self)` on a temporary: may fold into the Linear that produced it (see `linear_origin`)
     VarDiff neg() const;
     VarDiff pow(int exp) const;
     VarDiff sqrt() const;

@@ -116,7 +116,13 @@ PYBIND11_MODULE(_tape, m) {
         })
         .def("history_len", [](const VarDiff& v) { return v.history.len(); })
         .def("forward_history_len", [](const VarDiff& v) { return v.var.history.len(); })
-        .def("sum", &VarDiff::sum).def("mean", &VarDiff::mean).def("relu", &VarDiff::relu)
+        .def("sum", &VarDiff::sum).def("mean", &VarDiff::mean)
+        // Python has no rvalues: a receiver nobody else references (`lin.forward(x).relu()`: the only reference is the call's own)
+        // is the temporary Rust's `relu(self)` consumes; a named variable stays observable and gets the plain ReLU node
+        .def("relu", [](py::handle self) {
+            VarDiff& v = self.cast<VarDiff&>();
+            return Py_REFCNT(self.ptr()) <= 1 ? std::move(v).relu() : v.relu();
+        })
         .def("__neg__", &VarDiff::neg).def("pow", &VarDiff::pow).def("sqrt", &VarDiff::sqrt).def("leaky_relu", &VarDiff::leaky_relu)
         .def("softplus", &VarDiff::softplus).def("sigmoid", &VarDiff::sigmoid).def("tanh", &VarDiff::tanh).def("ln", &VarDiff::ln)
         .def("exp", &VarDiff::exp).def("unsqueeze", &VarDiff::unsqueeze)

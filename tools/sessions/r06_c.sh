@@ -1,5 +1,6 @@
 #!/bin/bash
 # Round 6, session c: the Winograd tail cut (the ragged last round of tile blocks cut along the reduction channels): parity of the
+# (the "cut" mode of benchmarks/ab_winograd.py this script calls lives in docs/r06_winograd_tail_cut.patch: measured, not kept)
 # Winograd / conv / tape suites, then the A/B (cut off / on, stagger rule / off) at C3 and two deeper layers.
 set -u
 root=${GRAFT_REPO_ROOT:-/root/repo}; out=$root/gpurun_out/r06c; mkdir -p $out
