@@ -52,16 +52,32 @@ P
     done
   done
 fi
+# The curve in the driver's SCALE_rNN.json shape (one object, one entry per N): absolute samples/s, ms per step, weak-scaling efficiency
+# against the N = 1 run of this same session, the ranks RCCL really ran with, the stand-alone all-reduce (algorithm and bus bandwidth:
+# busbw = algbw * 2 (p - 1) / p) and the exposed communication per step.
 python - "$out" <<'P' | tee -a "$out/summary.txt"
 import json, os, sys
-vals = {}
+runs = {}
 for n in (1, 2, 4, 8):
     try:
-        vals[n] = json.loads(open(os.path.join(sys.argv[1], f"bench_n{n}.json")).read().strip().splitlines()[-1])["value"]
+        runs[n] = json.loads(open(os.path.join(sys.argv[1], f"bench_n{n}.json")).read().strip().splitlines()[-1])
     except Exception:
         pass
-if 1 in vals:
-    for n, v in sorted(vals.items()):
-        print(f"weak-scaling efficiency at {n}: {v / (n * vals[1]):.3f}")
+scale = {"metric": None, "unit": None, "scaling": "weak", "measured_on": "tools/first_multi_gpu.sh", "runs": []}
+for n, d in sorted(runs.items()):
+    ar = d.get("allreduce_alone") or {}
+    alg = ar.get("algbw_GBps")
+    row = {"n_gpus": d.get("n_gpus", n), "value": d.get("value"), "ms_per_step": d.get("ms_per_step"), "steps": d.get("steps"),
+           "efficiency_vs_n1": round(d["value"] / (n * runs[1]["value"]), 4) if 1 in runs and d.get("value") else None,
+           "rccl_ranks": (d.get("rccl") or {}).get("ranks", d.get("rccl_ranks", n if n > 1 else None)),
+           "exposed_comm_ms": d.get("exposed_comm_ms"), "allreduce_alone_ms": ar.get("ms"), "allreduce_algbw_GBps": alg,
+           "allreduce_busbw_GBps": round(alg * 2 * (n - 1) / n, 1) if alg and n > 1 else None,
+           "dp_channels": d.get("dp_channels"), "gemm_slowdown_under_exchange": (d.get("gemm_contention") or {}).get("slowdown")}
+    scale["metric"], scale["unit"] = d.get("metric"), d.get("unit")
+    scale["runs"].append(row)
+    if row["efficiency_vs_n1"] is not None:
+        print(f"weak-scaling efficiency at {n}: {row['efficiency_vs_n1']:.3f}  ({d['value']} {d.get('unit')}, busbw {row['allreduce_busbw_GBps']} GB/s)")
+json.dump(scale, open(os.path.join(sys.argv[1], "SCALE_first_multi_gpu.json"), "w"), indent=1)
+print("wrote", os.path.join(sys.argv[1], "SCALE_first_multi_gpu.json"))
 P
 tar czf "$out.tgz" -C "$(dirname "$out")" "$(basename "$out")" && echo "wrote $out.tgz"
