@@ -84,6 +84,32 @@ int main(int argc, char** argv) {
     hipMalloc(&D, n * 4); hipMalloc(&G, n * 4); hipMalloc(&X, n * 4); hipMalloc(&O, n * 4);
     hipMemset(D, 0, n * 4); hipMemset(G, 0, n * 4); hipMemset(X, 0x3f, n * 4); hipMemset(O, 0, n * 4);
     hipEventCreate(&e0); hipEventCreate(&e1);
+    if (argc > 2) {  // second sweep: the span walk over grids, loads in flight and stream counts (what session d's first table pointed at)
+        run<3, 4, true, true, true>("relu_bwd span U4 b256", 512, 256);
+        run<3, 4, true, true, true>("relu_bwd span U4 b256", 1024, 256);
+        run<3, 4, true, true, true>("relu_bwd span U4 b256", 2048, 256);
+        run<3, 4, true, true, true>("relu_bwd span U4 b256", 4096, 256);
+        run<3, 4, true, true, true>("relu_bwd span U4 b256", 8192, 256);
+        run<3, 2, true, true, true>("relu_bwd span U2 b256", 2048, 256);
+        run<3, 2, true, true, true>("relu_bwd span U2 b256", 4096, 256);
+        run<3, 8, true, true, true>("relu_bwd span U8 b256", 1024, 256);
+        run<3, 8, true, true, true>("relu_bwd span U8 b256", 2048, 256);
+        run<3, 4, true, true, true>("relu_bwd span U4 b512", 1024, 512);
+        run<3, 4, true, true, true>("relu_bwd span U4 b512", 2048, 512);
+        run<3, 2, true, true, true>("relu_bwd span U2 b512", 2048, 512);
+        run<3, 4, true, false, true>("relu_bwd span U4 b256 plain loads", 2048, 256);
+        run<3, 4, true, true, false>("relu_bwd span U4 b256 plain stores", 2048, 256);
+        run<3, 4, true, false, false>("relu_bwd span U4 b256 plain both", 2048, 256);
+        run<4, 4, true, true, true>("relu_bwd out of place span U4 b256", 2048, 256);
+        run<1, 4, true, true, true>("copy span U4 b256", 2048, 256);
+        run<1, 8, true, true, true>("copy span U8 b256", 2048, 256);
+        run<1, 4, true, true, true>("copy span U4 b256", 1024, 256);
+        run<1, 4, true, false, true>("copy span U4 b256 plain loads", 2048, 256);
+        run<2, 4, true, true, true>("add span U4 b256", 2048, 256);
+        run<2, 4, true, true, true>("add span U4 b256", 1024, 256);
+        run<2, 8, true, true, true>("add span U8 b256", 2048, 256);
+        return 0;
+    }
     // (a) stream count, the library's form: grid stride, 8192 blocks of 256, one float4 per lane and trip, nt loads + nt stores
     run<1, 1, false, true, true>("copy", 8192, 256);
     run<2, 1, false, true, true>("add", 8192, 256);

