@@ -260,8 +260,9 @@ int nk_relu_mask_inplace(nk_device* dev, float* g, const float* y, size_t n);
  * ConvolutionBackwardInput        :427-449 (-> :146-189, 256-274)               dx += ...
  * ConvolutionBackwardKernel       :488-510 (-> :191-226, 276-294)               dw += ...
  * Algorithms, chosen inside each call by geometry and size (rules in csrc/nk_conv.hip, overridable through nk_dev_tune): Winograd
- * F(2x2, 3x3) (forward, input gradient) and F(3x3, 2x2) (kernel gradient) on the f32 MFMA core for 3 x 3 / stride 1 / dilation 1 / one
- * group with 64 | channel counts and even output extents; implicit GEMM on the same core for channel counts that are multiples of 32 and
+ * F(2x2, 3x3) (forward, input gradient: any output extents from 2 x 2 on, odd ones through instantiations with masked border tiles) and
+ * F(3x3, 2x2) (kernel gradient: even output extents) on the f32 MFMA core for 3 x 3 / stride 1 / dilation 1 / one group with 64 | channel
+ * counts; implicit GEMM on the same core for channel counts that are multiples of 32 and
  * a generic form for the rest; direct kernels for <= 16 channels per group.  Every form sums in a fixed order (run-to-run identical);
  * the forms differ from each other in that order only (equal on integer-valued data, to contraction tolerance otherwise). */
 int nk_conv_fwd(nk_device* dev, int nd, const float* x, const int* x_shape, const float* w,

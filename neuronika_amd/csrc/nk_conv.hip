@@ -125,10 +125,15 @@ int conv_fwd(nk_device* dev, int nd, const float* x, const int* x_shape, const f
         int nblocks = tiles;
         size_t slab_bytes = 0;
         fp.full_blocks = tiles;
-        const int tail = tiles % slots;
-        if (groups == 1 && tiles > slots && tail > 0 && tail * 2 <= slots && nkt >= 4) {
+        // ... and a grid that cannot even fill half the resident slots (late layers: 3x3 512 -> 512 at 7x7 is 224 tiles with a
+        // 144-k-tile reduction each - 0.50 of peak in round 5 with half the chip idle) is split along k as a whole, as the input
+        // gradient below has done since round 3: every tile is a "tail" tile
+        const int tail = tiles > slots ? tiles % slots : (tiles * 2 <= slots ? tiles : 0);
+        if (groups == 1 && tail > 0 && tail * 2 <= slots && nkt >= 4) {
             int S = slots / tail;
             if (S > nkt / 2) S = nkt / 2;
+            if (tiles <= slots && S > nkt / 8) S = nkt / 8;  // whole-grid split: keep >= 8 k-tiles per block
+            if (S < 1) S = 1;
             const int kts = (nkt + S - 1) / S;
             S = (nkt + kts - 1) / kts;
             if (S >= 2) {

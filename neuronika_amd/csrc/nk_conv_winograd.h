@@ -112,7 +112,12 @@ typedef unsigned wino_u4 __attribute__((ext_vector_type(4)));
 // V layout: [xi][channel / 4][tile][channel % 4] - a thread of the transform owns one tile and FOUR consecutive channels (one
 // float4 per patch element, the additions of the four channels side by side), stores one ds_write_b128 per xi, and an MFMA group
 // (four k-steps of one xi) takes its four B values with one ds_read_b128.
-template <int CB, int PB, int KC, int UR>
+// ODD (round 6): output extents that are not both even (7 x 7, 13 x 13 planes).  TY / TX = ceil(extent / 2); a border tile's second row /
+// column does not exist: its row stores go to the out-of-range offset (dropped), its row pair is stored as ONE float instead of a
+// float2 (two store instructions per row pair, each lane served by exactly one of them through the same out-of-range trick), and a
+// float2 may start on any 4-byte boundary (rows of odd length).  The source side needs nothing: patch elements beyond the source are
+// out of range already.  A separate instantiation - the even kernels' output phase, and with it their register allocation, is untouched.
+template <int CB, int PB, int KC, int UR, bool ODD = false>
 __global__ __launch_bounds__(64 * CB * PB, 1) void wino_kernel(WinoArgs a) {
     constexpr int PT = 32 * PB;        // tiles per tile block
     constexpr int KH = KC / 2;         // MFMA steps per item and xi (two reduction channels per step)
@@ -314,6 +319,19 @@ __global__ __launch_bounds__(64 * CB * PB, 1) void wino_kernel(WinoArgs a) {
         const int n = (int)un, ty = (int)uty, tx = (int)(urem - uty * (unsigned)a.TX);
         const int oplane = a.Hd * a.Wd;
         const unsigned ovoff = pvalid ? (unsigned)((n * a.Cm + 32 * cbg + 4 * h) * oplane + 2 * ty * a.Wd + 2 * tx) * 4u : 0x80000000u;
+        // ODD: per row r the offset of its float2 store (lanes whose tile has both columns) and of its float store (lanes whose tile has
+        // only the first); a row that does not exist has neither
+        unsigned ov2[2], ov1[2];
+        if constexpr (ODD) {
+            const bool two_cols = 2 * tx + 1 < a.Wd;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const bool row_ok = pvalid && 2 * ty + r < a.Hd;
+                const unsigned o = ovoff + (unsigned)(r * a.Wd) * 4u;
+                ov2[r] = row_ok && two_cols ? o : 0x80000000u;
+                ov1[r] = row_ok && !two_cols ? o : 0x80000000u;
+            }
+        }
 #pragma unroll
         for (int Q = 0; Q < 4; ++Q) {
             float2 y[4][2];
@@ -338,8 +356,13 @@ __global__ __launch_bounds__(64 * CB * PB, 1) void wino_kernel(WinoArgs a) {
 #pragma unroll
                 for (int el = 0; el < 4; ++el)
 #pragma unroll
-                    for (int r = 0; r < 2; ++r)
-                        old[el][r] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(drs, ovoff, ((8 * Q + el) * oplane + r * a.Wd) * 4, 0));
+                    for (int r = 0; r < 2; ++r) {
+                        if constexpr (ODD)  // (the second element of a one-column tile is read - the next row's first, or 0 past the end - and not stored)
+                            old[el][r] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(drs, ov2[r] < ov1[r] ? ov2[r] : ov1[r],  // the one in range, if any
+                                                                                                        (8 * Q + el) * oplane * 4, 0));
+                        else
+                            old[el][r] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(drs, ovoff, ((8 * Q + el) * oplane + r * a.Wd) * 4, 0));
+                    }
 #pragma unroll
                 for (int el = 0; el < 4; ++el)
 #pragma unroll
@@ -348,8 +371,14 @@ __global__ __launch_bounds__(64 * CB * PB, 1) void wino_kernel(WinoArgs a) {
 #pragma unroll
             for (int el = 0; el < 4; ++el)
 #pragma unroll
-                for (int r = 0; r < 2; ++r)
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(wino_u2, y[el][r]), drs, ovoff, ((8 * Q + el) * oplane + r * a.Wd) * 4, 0);
+                for (int r = 0; r < 2; ++r) {
+                    if constexpr (ODD) {
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(wino_u2, y[el][r]), drs, ov2[r], (8 * Q + el) * oplane * 4, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y[el][r].x), drs, ov1[r], (8 * Q + el) * oplane * 4, 0);
+                    } else {
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(wino_u2, y[el][r]), drs, ovoff, ((8 * Q + el) * oplane + r * a.Wd) * 4, 0);
+                    }
+                }
         }
     }
 }
@@ -375,9 +404,11 @@ int wino_launch(nk_device* dev, bool bwd, const float* src, const float* w, floa
     const bool wide = shape < 0 ? wide_ok : (shape == 1 ? wide_ok : !narrow_ok && wide_ok);
     if (!wide && !narrow_ok) return NK_OK;
     const int KC = wide ? 32 : 16, CM = wide ? 128 : 64, PT = 32, NW = wide ? 4 : 2;  // reduction chunk, channels / tiles / waves per block
-    if (Hd < 2 || Wd < 2 || Hd % 2 != 0 || Wd % 2 != 0) return NK_OK;
+    if (Hd < 2 || Wd < 2) return NK_OK;
+    const bool odd = Hd % 2 != 0 || Wd % 2 != 0;  // a border tile row / column is half empty: the ODD instantiation
     if (!al16(dst) || !al16(src)) return NK_OK;
-    const long long P = (long long)N * (Hd / 2) * (Wd / 2);
+    const int TYc = (Hd + 1) / 2, TXc = (Wd + 1) / 2;
+    const long long P = (long long)N * TYc * TXc;
     const long long blocks = (P + PT - 1) / PT * (Cm / CM);
     // buffer descriptors with 32-bit byte offsets, 0x80000000 as the out-of-range mark: every tensor below 2 GB
     const long long src_bytes = (long long)N * Ck * Hs * Ws * 4, dst_bytes = (long long)N * Cm * Hd * Wd * 4, u_bytes = 16LL * Cm * Ck * 4;
@@ -400,7 +431,7 @@ int wino_launch(nk_device* dev, bool bwd, const float* src, const float* w, floa
     a.src = src; a.u = (const float*)ws; a.dst = dst; a.bias = bias;
     a.N = N; a.Ck = Ck; a.Cm = Cm;
     a.Hs = Hs; a.Ws = Ws; a.Hd = Hd; a.Wd = Wd; a.offy = offy; a.offx = offx;
-    a.TY = Hd / 2; a.TX = Wd / 2; a.P = P;
+    a.TY = TYc; a.TX = TXc; a.P = P;
     a.nchunk = Ck / KC; a.assign = assign;
     // measured at C3 (benchmarks/ab_winograd.py 128 stagger): forward 315 / 313 / 307 / 311 / 313 us at 0 / 4000 / 6000 / 12000 / 16000 clocks,
     // input gradient 321 / 314 / 317 / 325 / 333 - a small offset is all it takes, larger ones only delay the late starters
@@ -416,7 +447,9 @@ int wino_launch(nk_device* dev, bool bwd, const float* src, const float* w, floa
     // U ring: 2 xi for the wide blocks (one xi = four MFMA groups ahead: 2 spilled registers and 283 us at C3's forward; a ring of 4
     // - twelve groups ahead - costs 54 spills and 301 us), 4 xi for the narrow ones (one xi there is two groups: a ring of 2 gives 357 us
     // against 309)
-    if (wide) hipLaunchKernelGGL((wino_kernel<4, 1, 32, 2>), grid, dim3(256), 0, dev->compute, a);
+    if (wide && odd) hipLaunchKernelGGL((wino_kernel<4, 1, 32, 2, true>), grid, dim3(256), 0, dev->compute, a);
+    else if (wide) hipLaunchKernelGGL((wino_kernel<4, 1, 32, 2>), grid, dim3(256), 0, dev->compute, a);
+    else if (odd) hipLaunchKernelGGL((wino_kernel<2, 1, 16, 4, true>), grid, dim3(128), 0, dev->compute, a);
     else hipLaunchKernelGGL((wino_kernel<2, 1, 16, 4>), grid, dim3(128), 0, dev->compute, a);
     NK_LAUNCH_CHECK();
     *taken = true;

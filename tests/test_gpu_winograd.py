@@ -53,6 +53,13 @@ SHAPES = [
     (2, 48, 64, 8, 12),        # forward: three chunks of 16 (narrow only: 48 is no multiple of 32); input gradient: 48 channels - direct
     (1, 32, 128, 12, 12),      # forward: ONE chunk of 32 (every item is a tile block's first and last); input gradient: 32 channels - direct
     (2, 128, 128, 10, 10),     # both block shapes possible in both passes (the third knob value picks)
+    # round 6, the ODD instantiations: output extents that are not both even (border tiles with one row / one column)
+    (2, 64, 128, 9, 9),        # 7 x 7 outputs (4 x 4 tiles per image, the last row and column half empty); dX of the 9 x 9 / 7 x 7 input alike
+    (3, 64, 64, 9, 15),        # 7 x 13: narrow blocks both ways
+    (1, 128, 128, 11, 8),      # 9 x 6: only the rows are odd
+    (2, 64, 128, 8, 13),       # 6 x 11: only the columns are odd
+    (4, 128, 256, 15, 15),     # 13 x 13, several tile blocks, two blocks of output channels
+    (130, 64, 64, 5, 5),       # 3 x 3 outputs: 4 tiles per image, three of them border tiles
 ]
 
 
@@ -98,7 +105,7 @@ def test_winograd_equals_direct_exactly_on_integer_data(dev, N, Cin, Cout, H, W)
     assert np.array_equal(wino[4], dx[:, :, 1:H - 1, 1:W - 1]) and np.array_equal(wino[5], (dx - dx0)[:, :, 1:H - 1, 1:W - 1])
 
 
-@pytest.mark.parametrize("N,Cin,Cout,H,W", SHAPES[:5] + SHAPES[6:])
+@pytest.mark.parametrize("N,Cin,Cout,H,W", SHAPES[:5] + SHAPES[6:15])
 @pytest.mark.parametrize("pad", [0, 1, 2])
 def test_winograd_random_inside_the_contraction_bound(dev, N, Cin, Cout, H, W, pad):
     from tolerance import assert_contraction
@@ -122,8 +129,8 @@ def test_winograd_random_inside_the_contraction_bound(dev, N, Cin, Cout, H, W, p
 
 def test_winograd_rule_and_knob(dev):
     """By rule the path is taken from an eighth of the CUs' worth of wide blocks on (an 18 x 18 plane, one sample: 2 forward blocks -
-    direct; the C3 plane with 8 samples: 196 - Winograd); shapes it cannot take (odd output extent, stride 2, 5 x 5, groups, 40 channels) stay direct
-    under the forced knob.  Told apart by the bits on random data (the two orders of summation differ)."""
+    direct; the C3 plane with 8 samples: 196 - Winograd); shapes it cannot take (stride 2, 5 x 5, groups, 40 channels) stay direct
+    under the forced knob, an odd output extent (7 x 8) is taken since round 6.  Told apart by the bits on random data (the two orders of summation differ)."""
     c = capi()
 
     def fwd(x, w, s, g, mode):
@@ -142,7 +149,9 @@ def test_winograd_rule_and_knob(dev):
     assert np.array_equal(fwd(small, w, (1, 1), 1, None), fwd(small, w, (1, 1), 1, 0))          # rule: direct
     assert not np.array_equal(fwd(small, w, (1, 1), 1, 1), fwd(small, w, (1, 1), 1, 0))         # forced: Winograd
     assert np.array_equal(fwd(large, w, (1, 1), 1, None), fwd(large, w, (1, 1), 1, 1))          # rule: Winograd
-    for x, wk, s, g in ((rnd(1, (2, 64, 9, 10)), w, (1, 1), 1), (rnd(1, (2, 64, 11, 11)), w, (2, 2), 1),
+    odd = rnd(1, (2, 64, 9, 10))
+    assert not np.array_equal(fwd(odd, w, (1, 1), 1, 1), fwd(odd, w, (1, 1), 1, 0))
+    for x, wk, s, g in ((rnd(1, (2, 64, 11, 11)), w, (2, 2), 1),
                         (rnd(1, (2, 64, 12, 12)), rnd(2, (128, 64, 5, 5), -1, 1), (1, 1), 1),
                         (rnd(1, (2, 128, 10, 10)), rnd(2, (128, 64, 3, 3), -1, 1), (1, 1), 2),
                         (rnd(1, (2, 40, 10, 10)), rnd(2, (128, 40, 3, 3), -1, 1), (1, 1), 1)):
@@ -360,13 +369,15 @@ def test_winograd_non_finite_input_stays_inside_the_tiles_that_see_it(dev):
     assert np.all(np.isfinite(out[1][0]))                               # the other sample is untouched
 
 
-def _fuzz_geometries(n, seed):
+def _fuzz_geometries(n, seed, any_extent=False):
     rng = np.random.default_rng(seed)
     out = []
     while len(out) < n:
         N = int(rng.integers(1, 6))
         Cin, Cout = int(rng.choice([64, 128, 192])), int(rng.choice([64, 128, 192, 256]))
         Ho, Wo = 2 * int(rng.integers(1, 13)), 2 * int(rng.integers(1, 13))
+        if any_extent:      # round 6: odd extents too (the ODD instantiations of the forward / input-gradient kernel; 1 is below its minimum)
+            Ho, Wo = int(rng.integers(1, 26)), int(rng.integers(1, 26))
         pad = (int(rng.integers(0, 2)), int(rng.integers(0, 2)))
         if Ho + 2 - 2 * pad[0] < 1 or Wo + 2 - 2 * pad[1] < 1:
             continue
@@ -374,10 +385,11 @@ def _fuzz_geometries(n, seed):
     return out
 
 
-@pytest.mark.parametrize("N,Cin,Cout,Ho,Wo,pad", _fuzz_geometries(36, 20260925))
+@pytest.mark.parametrize("N,Cin,Cout,Ho,Wo,pad", _fuzz_geometries(36, 20260925) + _fuzz_geometries(40, 20260930, any_extent=True))
 def test_winograd_fuzz_all_three_passes_equal_the_direct_kernels_on_integer_data(dev, N, Cin, Cout, Ho, Wo, pad):
-    """Seeded random geometries (1 - 5 samples, 64 - 256 channels, even output extents 2 - 24, zero padding 0 / 1 per axis): forward + bias,
-    input gradient with the padding folded, kernel gradient + bias gradient - the Winograd kernels (forced, whatever the size) against the
+    """Seeded random geometries (1 - 5 samples, 64 - 256 channels, even output extents 2 - 24 and - the second set - any extent 1 - 25,
+    zero padding 0 / 1 per axis): forward + bias, input gradient with the padding folded, kernel gradient + bias gradient - the Winograd
+    kernels (forced, whatever the size; the kernel gradient has no odd-extent form and runs the implicit GEMM there) against the
     implicit-GEMM / direct kernels on integer-valued data, bit for bit; with padding also the folded entry points against the padded copy."""
     c = capi()
     H, W = Ho + 2 - 2 * pad[0], Wo + 2 - 2 * pad[1]                    # unpadded input
