@@ -86,7 +86,7 @@ const char* nk_version(void);
  *                          values[2] (optional) = -1 rule / 0 narrow blocks (two waves, 64 output channels, chunks of 16 reduction
  *                          channels) / 1 wide blocks (four waves, 128 channels, chunks of 32) where the channel counts allow both;
  *                          values[3] (optional) = -1 rule / 0 the kernel gradient never takes its Winograd F(3x3, 2x2) form / 1 whenever
- *                          the shape allows (64 | both channel counts, even output extents)
+ *                          the shape allows (64 | both channel counts)
  *   NK_TUNE_GEMM_CHAIN     values[0] = -1 rule / 0 an unsplit GEMM sums K as ONE f32 chain whatever its length / L (a multiple of 64):
  *                          unsplit plain-epilogue GEMMs (MatMul, MatMulT, weight gradients) with K > L run as consecutive launches
  *                          over equal pieces of K, each on top of the last (beta = 1): chains of at most L.  Rule: L = 2048 - what
@@ -260,9 +260,8 @@ int nk_relu_mask_inplace(nk_device* dev, float* g, const float* y, size_t n);
  * ConvolutionBackwardInput        :427-449 (-> :146-189, 256-274)               dx += ...
  * ConvolutionBackwardKernel       :488-510 (-> :191-226, 276-294)               dw += ...
  * Algorithms, chosen inside each call by geometry and size (rules in csrc/nk_conv.hip, overridable through nk_dev_tune): Winograd
- * F(2x2, 3x3) (forward, input gradient: any output extents from 2 x 2 on, odd ones through instantiations with masked border tiles) and
- * F(3x3, 2x2) (kernel gradient: even output extents) on the f32 MFMA core for 3 x 3 / stride 1 / dilation 1 / one group with 64 | channel
- * counts; implicit GEMM on the same core for channel counts that are multiples of 32 and
+ * F(2x2, 3x3) (forward, input gradient) and F(3x3, 2x2) (kernel gradient) on the f32 MFMA core for 3 x 3 / stride 1 / dilation 1 / one
+ * group with 64 | channel counts and any output extents from 2 x 2 on (odd ones through instantiations with masked border tiles); implicit GEMM on the same core for channel counts that are multiples of 32 and
  * a generic form for the rest; direct kernels for <= 16 channels per group.  Every form sums in a fixed order (run-to-run identical);
  * the forms differ from each other in that order only (equal on integer-valued data, to contraction tolerance otherwise). */
 int nk_conv_fwd(nk_device* dev, int nd, const float* x, const int* x_shape, const float* w,
@@ -290,7 +289,7 @@ int nk_conv_bwd_kernel_bias(nk_device* dev, int nd, float* dw, float* db, const 
  * pass: `x` / `x_shape` are the UNPADDED input, `padding[i]` the symmetric zero padding of spatial axis i; the padded copy (Pad::forward,
  * pad/zero/mod.rs:5-31 - 110 MB and a 40 us kernel at C3) is never made.  Only the Winograd kernels read their operands through
  * out-of-range-is-zero buffer loads, so only their geometries fold: 3 x 3, stride 1, dilation 1, one group, padding 0 or 1 per axis (not
- * all zero), 64 | both channel counts, even output extents.  nk_conv_padding_folds answers, for a geometry and the rules in force on the
+ * all zero), 64 | both channel counts.  nk_conv_padding_folds answers, for a geometry and the rules in force on the
  * handle, whether BOTH passes would run their Winograd kernels anyway (*folds = 1: build the module node without the Pad node and
  * call the two `_padded` entries; 0: pad, then nk_conv_bias_fwd / nk_conv_bwd_kernel_bias).  The `_padded` entries themselves fold for
  * every geometry the kernels can (whatever the block-count rules say); for the others - and when the rules in force at CALL time decline,

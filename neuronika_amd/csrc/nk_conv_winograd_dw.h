@@ -48,7 +48,13 @@ constexpr int WDW_T = 8;                       // tiles per item
 constexpr int WDW_CQ = 36;                     // floats per (xi, channel quad): 8 tiles x 4 channels + 4 of padding
 constexpr int WDW_IMG = 16 * 16 * WDW_CQ;      // floats of one operand image: 16 xi x 16 channel quads (64 channels)
 
-template <bool FOLD>
+// ODD (round 6): output extents that are not both even; TY / TX = ceil(extent / 2).  A border tile's second dY row / column does not
+// exist and must contribute nothing: the row is loaded from the out-of-range offset (zeros), the column is zeroed with one select per
+// row - and with it the patch elements only that row / column would have met (patch row 3, patch column 3; with folded padding of 1
+// also patch column 2 lies beyond the image there): they belong to the next row / channel or lie past the tensor, and a non-finite
+// value among them must not reach a tile that does not see it.  Loads may start on any 4-byte boundary (rows of odd length).  Separate
+// instantiations: the even kernels are untouched.
+template <bool FOLD, bool ODD = false>
 __global__ __launch_bounds__(256, 1) void wino_dw_kernel(WinoDwArgs a) {
     __shared__ __attribute__((aligned(16))) float XS[2 * WDW_IMG];
     __shared__ __attribute__((aligned(16))) float YS[2 * WDW_IMG];
@@ -76,6 +82,8 @@ __global__ __launch_bounds__(256, 1) void wino_dw_kernel(WinoDwArgs a) {
     wino_u2 xr[2][2][4][2];  // [set][channel of the pair][patch row][columns 0-1 / 2-3]
     wino_u2 yr[2][2][2];     // [set][channel of the pair][tile row]
     float2 bsum = make_float2(0.f, 0.f);  // bias gradient of this thread's two output channels over its tiles
+    bool fix_col[2] = {false, false};   // ODD: the tile of the item in each register set has one dY column (the last column of tiles)
+    bool fix_x2[2] = {false, false};    // ODD + FOLD: ... and its patch column 2 lies beyond the image as well (padx = 1)
     bool fix_left[2] = {false, false}, fix_right[2] = {false, false};  // FOLD: border flags of the item in each register set
     int fix_shift[2] = {-1, -1};                                        // ... and the patch row loaded from the tensor's first byte (-1: none)
 
@@ -84,6 +92,8 @@ __global__ __launch_bounds__(256, 1) void wino_dw_kernel(WinoDwArgs a) {
     // at the top of the item the four waves' 48 instructions fill the address unit's queue and every wave waits for its turn with the
     // matrix pipe idle - 1.1 us of a 3.1 us item
     unsigned xo = 0x80000000u, yo = 0x80000000u;
+    unsigned yo1 = 0x80000000u, xo3 = 0x80000000u;  // ODD: dY row 1 and (unfolded) patch row 3 - out of range when the tile has one row
+    bool one_col = false, x2_out = false;
     // FOLD: a byte offset per patch row (a row above / below the image is out of range as a whole: zeros), the left-most column of a
     // tile in the first column of tiles and the right-most of one in the last lie outside the image (one select each per row); the
     // single row in the whole tensor whose window would start 4 bytes BEFORE the tensor (sample 0, channel 0, image row 0, first tile)
@@ -113,6 +123,13 @@ __global__ __launch_bounds__(256, 1) void wino_dw_kernel(WinoDwArgs a) {
             xo = valid ? (unsigned)(((int)n * a.Ci + 64 * cb + 2 * cp) * plane + 2 * (int)ty * a.Ws + 2 * (int)tx) * 4u : 0x80000000u;
         }
         yo = valid ? (unsigned)(((int)n * a.Co + 64 * cob + 2 * cp) * oplane + 2 * (int)ty * a.Wd + 2 * (int)tx) * 4u : 0x80000000u;
+        if constexpr (ODD) {
+            const bool two_rows = 2 * (int)ty + 1 < a.Hd;
+            yo1 = two_rows ? yo : 0x80000000u;
+            if constexpr (!FOLD) xo3 = two_rows ? xo : 0x80000000u;   // (FOLD: that row lies below the image, out of range already)
+            one_col = valid && 2 * (int)tx + 1 >= a.Wd;
+            if constexpr (FOLD) x2_out = valid && 2 * (int)tx - a.padx + 2 >= a.Wx;
+        }
     };
     auto load_one = [&](auto set, int k) {  // k = 0..11, compile-time at every call site
         constexpr int S = decltype(set)::value;
@@ -121,18 +138,19 @@ __global__ __launch_bounds__(256, 1) void wino_dw_kernel(WinoDwArgs a) {
             // FOLD: the second channel's plane goes into the VECTOR offset - the descriptor's range check covers vector + immediate
             // offsets only, and the right-most window of the tensor's last row ends 4 bytes past the tensor: checked per dword, that
             // element reads as 0 (it is the folded padding column, `fix_right`) instead of touching memory behind the allocation
-            const unsigned vo = FOLD ? xrow[i] + (ch ? plane4 : 0u) : xo;
+            const unsigned vo = FOLD ? xrow[i] + (ch ? plane4 : 0u) : (ODD && i == 3 ? xo3 : xo);
             xr[S][ch][i][0] = __builtin_amdgcn_raw_buffer_load_b64(xrs, vo, xso[ch][i], 0);
             xr[S][ch][i][1] = __builtin_amdgcn_raw_buffer_load_b64(xrs, vo + 8, xso[ch][i], 0);
         } else {
             const int ch = (k - 8) >> 1, r = (k - 8) & 1;
-            yr[S][ch][r] = __builtin_amdgcn_raw_buffer_load_b64(yrs, yo, yso[ch][r], 0);
+            yr[S][ch][r] = __builtin_amdgcn_raw_buffer_load_b64(yrs, ODD && r == 1 ? yo1 : yo, yso[ch][r], 0);
         }
     };
     auto load = [&](auto set, int item) {
         constexpr int S_ = decltype(set)::value;
         address(item);
         fix_left[S_] = left; fix_right[S_] = right; fix_shift[S_] = shifted;
+        fix_col[S_] = one_col; fix_x2[S_] = x2_out;
 #pragma unroll
         for (int k = 0; k < 12; ++k) load_one(set, k);
     };
@@ -155,6 +173,9 @@ __global__ __launch_bounds__(256, 1) void wino_dw_kernel(WinoDwArgs a) {
                     }
                     d[i][0] = fix_left[S] ? 0.f : d[i][0];
                     d[i][3] = fix_right[S] ? 0.f : d[i][3];
+                    if constexpr (ODD) d[i][2] = fix_x2[S] ? 0.f : d[i][2];
+                } else if constexpr (ODD) {
+                    d[i][3] = fix_col[S] ? 0.f : d[i][3];
                 }
             }
             float tt[4][4];  // B^T d
@@ -172,7 +193,8 @@ __global__ __launch_bounds__(256, 1) void wino_dw_kernel(WinoDwArgs a) {
                 xv[ch][4 * i + 2] = tt[i][2] - tt[i][1];
                 xv[ch][4 * i + 3] = tt[i][3] - tt[i][1];
             }
-            const float2 r0 = __builtin_bit_cast(float2, yr[S][ch][0]), r1 = __builtin_bit_cast(float2, yr[S][ch][1]);
+            float2 r0 = __builtin_bit_cast(float2, yr[S][ch][0]), r1 = __builtin_bit_cast(float2, yr[S][ch][1]);
+            if constexpr (ODD) { r0.y = fix_col[S] ? 0.f : r0.y; r1.y = fix_col[S] ? 0.f : r1.y; }
             float g[4][2];  // G dy
             g[0][0] = r0.x; g[0][1] = r0.y;
             g[1][0] = 0.5f * (r0.x + r1.x); g[1][1] = 0.5f * (r0.y + r1.y);
@@ -222,6 +244,7 @@ __global__ __launch_bounds__(256, 1) void wino_dw_kernel(WinoDwArgs a) {
         float* const yn = YS + (S ^ 1) * WDW_IMG;
         address(i + 2);
         fix_left[S] = left; fix_right[S] = right; fix_shift[S] = shifted;
+        fix_col[S] = one_col; fix_x2[S] = x2_out;
         float av[2][4], bv[2][4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) { av[0][s] = ya[8 * s]; bv[0][s] = xb[8 * s]; }
@@ -351,9 +374,10 @@ int wino_dw_launch(nk_device* dev, const float* gy, const float* x, float* dw, f
     const int Hx = Hs - 2 * pady, Wx = Ws - 2 * padx;
     if (Hx < 1 || Wx < 1) return NK_OK;
     const int Hd = Hs - 2, Wd = Ws - 2;
-    if (Hd < 2 || Wd < 2 || Hd % 2 != 0 || Wd % 2 != 0 || Ci % 64 != 0 || Co % 64 != 0) return NK_OK;
+    if (Hd < 2 || Wd < 2 || Ci % 64 != 0 || Co % 64 != 0) return NK_OK;
+    const bool odd = Hd % 2 != 0 || Wd % 2 != 0;  // border tiles with one row / one column: the ODD instantiations
     if (!al16(x) || !al16(gy)) return NK_OK;
-    const long long P = (long long)N * (Hd / 2) * (Wd / 2);
+    const long long P = (long long)N * ((Hd + 1) / 2) * ((Wd + 1) / 2);
     const long long x_bytes = (long long)N * Ci * Hx * Wx * 4, gy_bytes = (long long)N * Co * Hd * Wd * 4;
     if (P >= (1LL << 30) || x_bytes >= 0x7fffffffLL || gy_bytes >= 0x7fffffffLL) return NK_OK;
     const int pairs = (Co / 64) * (Ci / 64);
@@ -374,14 +398,17 @@ int wino_dw_launch(nk_device* dev, const float* gy, const float* x, float* dw, f
     if (rc) return rc;
     WinoDwArgs a{};
     a.x = x; a.gy = gy; a.slabs = (float*)ws; a.bslabs = db ? (float*)((char*)ws + slab_bytes) : nullptr;
-    a.N = N; a.Ci = Ci; a.Co = Co; a.Hs = Hs; a.Ws = Ws; a.Hd = Hd; a.Wd = Wd; a.TY = Hd / 2; a.TX = Wd / 2;
+    a.N = N; a.Ci = Ci; a.Co = Co; a.Hs = Hs; a.Ws = Ws; a.Hd = Hd; a.Wd = Wd; a.TY = (Hd + 1) / 2; a.TX = (Wd + 1) / 2;
     a.P = (unsigned)P; a.items = (int)items; a.cib = Ci / 64;
     wino_magic((unsigned)(a.TY * a.TX), &a.per_m, &a.per_s1, &a.per_s2);
     wino_magic((unsigned)a.TX, &a.tx_m, &a.tx_s1, &a.tx_s2);
     a.x_bytes = (int)x_bytes; a.gy_bytes = (int)gy_bytes;
     a.Hx = Hx; a.Wx = Wx; a.pady = pady; a.padx = padx;
-    if (fold) hipLaunchKernelGGL(wino_dw_kernel<true>, dim3((unsigned)slices, (unsigned)pairs), dim3(256), 0, dev->compute, a);
-    else hipLaunchKernelGGL(wino_dw_kernel<false>, dim3((unsigned)slices, (unsigned)pairs), dim3(256), 0, dev->compute, a);
+    const dim3 grid((unsigned)slices, (unsigned)pairs);
+    if (fold && odd) hipLaunchKernelGGL((wino_dw_kernel<true, true>), grid, dim3(256), 0, dev->compute, a);
+    else if (fold) hipLaunchKernelGGL((wino_dw_kernel<true>), grid, dim3(256), 0, dev->compute, a);
+    else if (odd) hipLaunchKernelGGL((wino_dw_kernel<false, true>), grid, dim3(256), 0, dev->compute, a);
+    else hipLaunchKernelGGL((wino_dw_kernel<false>), grid, dim3(256), 0, dev->compute, a);
     NK_LAUNCH_CHECK();
     const int nb = Co * (Ci / 64) + (db ? (Co + 1023) / 1024 : 0);
     hipLaunchKernelGGL(wino_dw_reduce_kernel, dim3((unsigned)nb), dim3(1024), 0, dev->compute, dw, db, (const float*)a.slabs, (const float*)a.bslabs, Co,

@@ -167,6 +167,13 @@ DW_SHAPES = [
     (2, 128, 128, 6, 20),      # four block pairs
     (5, 64, 64, 6, 6),         # 20 tiles
     (6, 64, 128, 58, 58),      # the C3 plane: 4704 tiles over 128 slices (ragged slices, an all-empty item at the end of each)
+    # round 6, the ODD instantiations: border tiles with one dY row / column
+    (2, 64, 64, 9, 9),         # 7 x 7 outputs
+    (3, 64, 128, 9, 15),       # 7 x 13
+    (1, 128, 64, 11, 8),       # 9 x 6: only the rows are odd
+    (2, 64, 128, 8, 13),       # 6 x 11: only the columns are odd
+    (5, 128, 128, 15, 15),     # 13 x 13
+    (40, 64, 64, 5, 5),        # 3 x 3 outputs: 4 tiles per image, three of them border tiles
 ]
 
 
@@ -237,6 +244,13 @@ FOLD_SHAPES = [
     (2, 64, 128, 8, 10, (1, 0)),      # rows only (output 8 x 8)
     (2, 64, 64, 10, 8, (0, 1)),       # columns only
     (4, 64, 128, 56, 56, (1, 1)),     # the C3 plane
+    # round 6: odd output extents (ODD + FOLD: with padding 1 the last tile's patch columns 2 AND 3 / rows 2 and 3 lie beyond the image)
+    (2, 64, 64, 7, 7, (1, 1)),
+    (3, 64, 128, 7, 13, (1, 1)),
+    (2, 64, 128, 7, 10, (1, 0)),      # output 7 x 8
+    (2, 64, 64, 9, 7, (0, 1)),        # output 7 x 7
+    (4, 128, 128, 13, 13, (1, 1)),
+    (6, 64, 64, 3, 3, (1, 1)),        # 3 x 3 outputs
 ]
 
 
@@ -389,7 +403,7 @@ def _fuzz_geometries(n, seed, any_extent=False):
 def test_winograd_fuzz_all_three_passes_equal_the_direct_kernels_on_integer_data(dev, N, Cin, Cout, Ho, Wo, pad):
     """Seeded random geometries (1 - 5 samples, 64 - 256 channels, even output extents 2 - 24 and - the second set - any extent 1 - 25,
     zero padding 0 / 1 per axis): forward + bias, input gradient with the padding folded, kernel gradient + bias gradient - the Winograd
-    kernels (forced, whatever the size; the kernel gradient has no odd-extent form and runs the implicit GEMM there) against the
+    kernels (forced, whatever the size) against the
     implicit-GEMM / direct kernels on integer-valued data, bit for bit; with padding also the folded entry points against the padded copy."""
     c = capi()
     H, W = Ho + 2 - 2 * pad[0], Wo + 2 - 2 * pad[1]                    # unpadded input
