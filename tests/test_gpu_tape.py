@@ -1328,6 +1328,57 @@ def test_conv2d_module_built_folded_survives_a_knob_change(nk, tdev):
     assert cdev.conv_winograd_launches() - before == 3
 
 
+def test_conv2d_module_at_an_odd_extent_and_on_a_plain_input(nk, tdev):
+    """(i) nn::Conv2d (3 x 3, pad 1) on 13 x 13 planes: since round 6 the Winograd kernels take odd output extents, so the rule folds the
+    module's Zero padding here as well (no Pad node; three Winograd launches per step) - values equal to the module built with
+    `fold_padding = false` bit for bit, and on integer-valued data to the oracle exactly.
+    (ii) The same layer on a NON-differentiable input (`Var`: the data of a network's first layer): the reference builds no
+    backward-input node for it (var.rs:1296-1371), and neither does the mirror - the step launches TWO convolution passes (forward,
+    kernel gradient), not three; for a 7 x 7 / stride-2 stem that is the 3.8 ms direct input-gradient kernel that never runs."""
+    from neuronika_amd import capi
+    cdev = capi.Device(handle=tdev.raw())
+    N, Cin, Cout, H = 352, 64, 128, 13                                # (enough tiles for the rules of all three passes)
+    rng = np.random.default_rng(0)
+    x = rng.integers(-3, 4, (N, Cin, H, H)).astype(np.float32)
+    gy = rng.integers(-2, 3, (N, Cout, H, H)).astype(np.float32)
+    assert capi.conv_padding_folds(cdev, x.shape, (1, 1), (Cout, Cin, 3, 3), (1, 1), (1, 1), 1)
+    outs = []
+    for fold in (True, False):
+        conv = nk.nn.Conv2d(tdev, Cin, Cout, [3, 3], [1, 1], nk.PaddingMode.zero(), [1, 1], [1, 1], 1)
+        conv.fold_padding = fold
+        w = np.round(conv.weight.data() * 48).astype(np.float32)     # integer-valued parameters: every partial sum is exact in f32
+        conv.weight.set_data(w); conv.bias.set_data(np.round(conv.bias.data() * 48).astype(np.float32))
+        X = nk.from_ndarray(tdev, x).requires_grad()
+        y = conv.forward(X)
+        before = cdev.conv_winograd_launches()
+        y.forward(); y.backward_from(nk.from_ndarray(tdev, gy))
+        assert cdev.conv_winograd_launches() - before == 3
+        outs.append([y.data(), X.grad(), conv.weight.grad(), conv.bias.grad(), conv.weight.data(), conv.bias.data()])
+    for a, b in zip(outs[0], outs[1]):
+        assert np.array_equal(a, b)
+    w, b = outs[0][4], outs[0][5]
+    xp = np.zeros((N, Cin, H + 2, H + 2), np.float32); xp[:, :, 1:-1, 1:-1] = x
+    yr = np.zeros((N, Cout, H, H), np.float32); O.convolution_forward(xp, w, yr, (1, 1), (1, 1), 1)
+    assert np.array_equal(outs[0][0], yr + b)
+    dxp = np.zeros_like(xp); O.convolution_backward_input(dxp, gy, w, (1, 1), (1, 1), 1)
+    assert np.array_equal(outs[0][1], dxp[:, :, 1:-1, 1:-1])
+    dw = np.zeros_like(w); O.convolution_backward_kernel(dw, gy, xp, (1, 1), (1, 1), 1)
+    assert np.array_equal(outs[0][2], dw)
+    # (ii)
+    stem = nk.nn.Conv2d(tdev, 3, 64, [7, 7], [3, 3], nk.PaddingMode.zero(), [2, 2], [1, 1], 1)
+    xs = rnd(1, (4, 3, 64, 64))
+    for differentiable, passes in ((False, 2), (True, 3)):
+        Xs = nk.from_ndarray(tdev, xs)
+        if differentiable:
+            Xs = Xs.requires_grad()
+        ys = stem.forward(Xs)
+        cdev.profile_begin()
+        ys.forward(); ys.backward_from(nk.from_ndarray(tdev, rnd(2, (4, 64, 32, 32))))
+        launches, _, _ = cdev.profile_end(capi.KERNEL_CONV)
+        assert launches == passes, (differentiable, launches)
+        stem.weight.zero_grad(); stem.bias.zero_grad()
+
+
 def test_conv2d_module_at_a_size_the_winograd_rule_takes(nk, tdev):
     """nn::Conv2d (3 x 3, pad 1) through the tape at 48 x 64 x 56 x 56 -> 128 channels: by rule all three passes take the Winograd
     kernels (nk_conv_bias_fwd, nk_conv_bwd_input_padded, nk_conv_bwd_kernel_bias - the launch counter says so); the same step with the
