@@ -92,10 +92,14 @@ const char* nk_version(void);
  *                          over equal pieces of K, each on top of the last (beta = 1): chains of at most L.  Rule: L = 2048 - what
  *                          keeps 4096- and 8192-long contractions inside 1e-6 K |a| |b| of the f64 result (SURVEY.md 8c ii; the
  *                          reference's matrixmultiply sums K in cache blocks too, matrix_matrix_mul/mod.rs:33-39)
+ *   NK_TUNE_CONV_S2DX      values[0] = -1 rule / 0 the 3x3 stride-2 input gradient never takes its fused-phase kernel (the four stride
+ *                          phases of a tile in one block walk; per-phase implicit GEMMs as in rounds 1 - 5) / 1 whenever the shape
+ *                          allows (one group, even input extents, padding 0 or 1 alike on both axes, 64 | input channels, 16 | output
+ *                          channels) / 2, 3: the same with narrow (two waves, 64 channels) / wide (four waves, 128 channels) blocks forced
  * For schedule sweeps (benchmarks/ab_*.py) and the tests that pit one schedule against another bit for bit; results never
- * depend on them beyond summation order (split-K, chain length). */
+ * depend on them beyond summation order (split-K, chain length, algorithm). */
 enum { NK_TUNE_GEMM_FORCE = 0, NK_TUNE_GEMM_KPAIR = 1, NK_TUNE_ATTENTION_OCC = 2, NK_TUNE_GEMM_PAIR = 3, NK_TUNE_CONV_NARROW = 4,
-       NK_TUNE_CONV_WINOGRAD = 5, NK_TUNE_GEMM_CHAIN = 6 };
+       NK_TUNE_CONV_WINOGRAD = 5, NK_TUNE_GEMM_CHAIN = 6, NK_TUNE_CONV_S2DX = 7 };
 int nk_dev_tune(nk_device* dev, int knob, const int* values, int n);
 /* How many convolution launches on this handle took the Winograd F(2x2, 3x3) kernels so far (forward + input gradient; the rule
  * of NK_TUNE_CONV_WINOGRAD decides per launch).  For harnesses that must say which algorithm produced a time: bench.py quotes the

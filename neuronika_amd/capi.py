@@ -260,7 +260,7 @@ class Event:
             pass
 
 
-TUNE_GEMM_FORCE, TUNE_GEMM_KPAIR, TUNE_ATTENTION_OCC, TUNE_GEMM_PAIR, TUNE_CONV_NARROW, TUNE_CONV_WINOGRAD, TUNE_GEMM_CHAIN = 0, 1, 2, 3, 4, 5, 6   # include/neuronika_hip.h: nk_dev_tune knobs
+TUNE_GEMM_FORCE, TUNE_GEMM_KPAIR, TUNE_ATTENTION_OCC, TUNE_GEMM_PAIR, TUNE_CONV_NARROW, TUNE_CONV_WINOGRAD, TUNE_GEMM_CHAIN, TUNE_CONV_S2DX = 0, 1, 2, 3, 4, 5, 6, 7   # include/neuronika_hip.h: nk_dev_tune knobs
 
 
 class Device:
@@ -278,7 +278,7 @@ class Device:
         # variables; it is THIS harness that reads them and calls nk_dev_tune - the library itself reads none.
         for var, knob in (("NK_GEMM_FORCE", TUNE_GEMM_FORCE), ("NK_GEMM_KPAIR", TUNE_GEMM_KPAIR), ("NK_ATTN_OCC", TUNE_ATTENTION_OCC),
                           ("NK_GEMM_PAIR", TUNE_GEMM_PAIR), ("NK_CONV_NARROW", TUNE_CONV_NARROW), ("NK_CONV_WINOGRAD", TUNE_CONV_WINOGRAD),
-                          ("NK_GEMM_CHAIN", TUNE_GEMM_CHAIN)):
+                          ("NK_GEMM_CHAIN", TUNE_GEMM_CHAIN), ("NK_CONV_S2DX", TUNE_CONV_S2DX)):
             if os.environ.get(var):
                 self.tune(knob, os.environ[var])
 
@@ -306,6 +306,11 @@ class Device:
     def gemm_chain(self, length=None):
         """NK_TUNE_GEMM_CHAIN: None / -1 the rule (chains of at most 2048), 0 one chain whatever K, L > 0 chains of at most L"""
         self.tune(TUNE_GEMM_CHAIN, length)
+
+    def conv_s2dx(self, mode=None):
+        """NK_TUNE_CONV_S2DX: None / -1 rule, 0 the 3x3 stride-2 input gradient never takes the fused-phase kernel, 1 whenever the shape allows,
+        2 / 3 the same with narrow / wide blocks forced"""
+        self.tune(TUNE_CONV_S2DX, mode)
 
     def conv_narrow(self, cost=None):
         self.tune(TUNE_CONV_NARROW, cost)

@@ -45,6 +45,7 @@ struct nk_device {
     int tune_pair = -1;                      // nk_sgemm_pair: -1 rule, 0 always two launches, 1 one launch whenever eligible
     int tune_conv_narrow = -1;                // conv kernel gradient, mixed launch: -1 the rules above, 0 uniform launch, 1..100 the price in percent
     unsigned long long wino_launches = 0;    // convolution launches that took the Winograd kernels (nk_conv_winograd_launches)
+    int tune_conv_s2dx = -1;                 // 3x3 stride-2 input gradient, the fused-phase kernel: -1 rule, 0 never, 1 whenever the shape allows
     int tune_conv_wino_dw = -1;              // Winograd kernel gradient: -1 rule, 0 never, 1 whenever the shape allows
     int tune_conv_wino_shape = -1;           // Winograd block shape: -1 rule, 0 narrow (two waves, 64 channels), 1 wide (four waves, 128 channels)
     int tune_conv_wino_stagger = -1;         // staggered start of the Winograd blocks: -1 rule (a quarter of a tile block's MFMA time), 0 off, > 0 shader clocks

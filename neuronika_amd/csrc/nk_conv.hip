@@ -63,6 +63,7 @@ size_t round256(size_t b) { return (b + 255) & ~size_t(255); }
 
 #include "nk_conv_winograd.h"
 #include "nk_conv_winograd_dw.h"
+#include "nk_conv_s2dx.h"
 
 // 3 x 3, stride 1, dilation 1, one group, two spatial dimensions: the shapes wino_launch may take
 bool wino_shape(const ConvGeom& g) {
@@ -278,6 +279,13 @@ int conv_bwd_input(nk_device* dev, int nd, float* dx, const int* x_shape, const 
         bool taken = false;
         rc = wino_launch(dev, true, gy, w, dx, nullptr, g.N, g.Cout, g.Cin, g.out[1], g.out[2], g.uin[1], g.uin[2], 2 - g.pad[1], 2 - g.pad[2],
                          assign, 2.0 * g.N * (double)g.Cout * g.L * g.Cg * g.KK, &taken);
+        if (rc || taken) return rc;
+    }
+    if (g.groups == 1 && g.in[0] == 1 && g.k[0] == 1 && g.k[1] == 3 && g.k[2] == 3 && g.stride[1] == 2 && g.stride[2] == 2 && g.dil[1] == 1 &&
+        g.dil[2] == 1 && g.pad[0] == 0 && g.pad[1] == g.pad[2]) {  // the four stride phases of a tile in one block walk (nk_conv_s2dx.h)
+        bool taken = false;
+        rc = s2dx_launch(dev, gy, w, dx, g.N, g.Cout, g.Cin, g.out[1], g.out[2], g.uin[1], g.uin[2], g.pad[1], assign,
+                         2.0 * g.N * (double)g.Cout * g.L * g.Cg * g.KK, &taken);
         if (rc || taken) return rc;
     }
     const int K = g.Mg * g.KK;

@@ -215,6 +215,10 @@ int nk_dev_tune(nk_device* dev, int knob, const int* values, int n) {
             dev->tune_conv_wino_shape = n >= 3 ? values[2] : -1;
             dev->tune_conv_wino_dw = n >= 4 ? values[3] : -1;
             return NK_OK;
+        case NK_TUNE_CONV_S2DX:
+            NK_CHECK(n <= 1 && (n == 0 || (values[0] >= -1 && values[0] <= 3)), "NK_TUNE_CONV_S2DX: -1, 0, 1, 2 (narrow blocks) or 3 (wide blocks)");
+            dev->tune_conv_s2dx = n ? values[0] : -1;
+            return NK_OK;
         case NK_TUNE_GEMM_CHAIN:
             NK_CHECK(n <= 1 && (n == 0 || values[0] == -1 || values[0] == 0 || (values[0] >= 64 && values[0] % 64 == 0)),
                      "NK_TUNE_GEMM_CHAIN: -1 (rule), 0 (one chain) or a chain length that is a multiple of 64");

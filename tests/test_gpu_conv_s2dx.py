@@ -1,0 +1,121 @@
+"""The fused-phase input gradient of the 3 x 3 / stride-2 convolution (csrc/nk_conv_s2dx.h: the four stride phases of a tile in one block
+walk) against the per-phase implicit-GEMM kernels it replaces by rule (NK_TUNE_CONV_S2DX = 0) and the oracle
+(`convolution_backward_input`, node/convolution/mod.rs:146-189, 256-274): bit for bit on integer-valued data (every partial sum exact
+in f32), inside the suite's contraction bound on random data; `+=` and first-write forms; the module's Zero padding folded in (1) and the
+gradient of an already padded input (0); both block shapes; the geometries the kernel does not take stay with the per-phase kernels."""
+import numpy as np
+import pytest
+
+from oracle import neuronika_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def capi():
+    from neuronika_amd import capi as c
+    return c
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return capi().Device(0)
+
+
+def ints(seed, shape, lo, hi):
+    return np.random.default_rng(seed).integers(lo, hi + 1, shape).astype(np.float32)
+
+
+def rnd(seed, shape, lo=0.0, hi=1.0):
+    a = np.random.default_rng(seed).random(shape, dtype=np.float32)
+    return np.asarray(a * np.float32(hi - lo) + np.float32(lo), dtype=np.float32)
+
+
+# N, Cin, Cout, H, W of the UNPADDED input (even), padding (both axes)
+SHAPES = [
+    (2, 64, 128, 8, 8, 1),        # narrow blocks (64 input channels), one block of super-pixels per sample and a half
+    (3, 64, 64, 6, 10, 1),        # 45 super-pixels: a partly filled last block
+    (2, 128, 256, 8, 8, 1),       # wide blocks (128 input channels), chunks of 32 reduction channels
+    (1, 256, 128, 12, 4, 1),      # two wide channel blocks
+    (2, 192, 48, 6, 6, 1),        # 192 = 3 x 64: narrow only; 48 reduction channels = three chunks of 16
+    (2, 64, 128, 10, 10, 0),      # the gradient of an already padded input: neighbours (a - 1, b - 1) .. (a, b); output 4 x 4
+    (3, 128, 64, 8, 12, 0),
+    (5, 64, 64, 2, 2, 1),         # one super-pixel per sample: every neighbour but one out of range
+    (4, 64, 128, 56, 56, 1),      # the layer of the shape table (3 x 3 s2 64 -> 128 at 56 x 56), four samples
+]
+
+
+def run(dev, go, w, dx0, xs, pad, mode):
+    c = capi()
+    dev.conv_s2dx(mode)
+    try:
+        G, Wd = dev.array(go), dev.array(w)
+        DX, DXa = dev.array(dx0), dev.full(xs, np.nan)
+        padding = (pad, pad) if pad else None
+        c.conv_bwd_input(dev, DX, G, Wd, (2, 2), (1, 1), 1, padding=padding)
+        c.conv_bwd_input(dev, DXa, G, Wd, (2, 2), (1, 1), 1, assign=True, padding=padding)
+        return DX.numpy(), DXa.numpy()
+    finally:
+        dev.conv_s2dx(None)
+
+
+def oracle_dx(go, w, xs, pad, dtype):
+    N, Cin, H, W = xs
+    dxp = np.zeros((N, Cin, H + 2 * pad, W + 2 * pad), dtype)
+    O.convolution_backward_input(dxp, go.astype(dtype), w.astype(dtype), (2, 2), (1, 1), 1)
+    return dxp[:, :, pad:pad + H, pad:pad + W]
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W,pad", SHAPES)
+def test_s2dx_equals_the_per_phase_kernels_exactly_on_integer_data(dev, N, Cin, Cout, H, W, pad):
+    xs = (N, Cin, H, W)
+    Ho, Wo = (H + 2 * pad - 3) // 2 + 1, (W + 2 * pad - 3) // 2 + 1
+    go, w, dx0 = ints(1, (N, Cout, Ho, Wo), -3, 3), ints(2, (Cout, Cin, 3, 3), -2, 2), ints(3, xs, -5, 5)
+    fused, phases, again = run(dev, go, w, dx0, xs, pad, 1), run(dev, go, w, dx0, xs, pad, 0), run(dev, go, w, dx0, xs, pad, 1)
+    want = oracle_dx(go, w, xs, pad, np.float32)
+    for a, b, r in zip(fused, phases, again):
+        assert np.array_equal(a, b) and np.array_equal(a, r)
+    assert np.array_equal(fused[0], dx0 + want) and np.array_equal(fused[1], want)
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W,pad", SHAPES[:8])
+def test_s2dx_random_inside_the_contraction_bound(dev, N, Cin, Cout, H, W, pad):
+    from tolerance import assert_contraction
+    xs = (N, Cin, H, W)
+    Ho, Wo = (H + 2 * pad - 3) // 2 + 1, (W + 2 * pad - 3) // 2 + 1
+    go, w, dx0 = rnd(1, (N, Cout, Ho, Wo)), rnd(2, (Cout, Cin, 3, 3), -1, 1), rnd(3, xs)
+    fused, phases = run(dev, go, w, dx0, xs, pad, 1), run(dev, go, w, dx0, xs, pad, 0)
+    d64, d32 = oracle_dx(go, w, xs, pad, np.float64), oracle_dx(go, w, xs, pad, np.float32)
+    K = Cout * 4                                            # the longest phase: four taps
+    for name, got in (("fused +=", fused[0] - dx0), ("fused =", fused[1]), ("per phase =", phases[1])):
+        assert_contraction("s2dx:" + name, got, d64, K, 1.0, 1.0, cpu32=d32, epilogue=True)
+    assert not np.array_equal(fused[1], phases[1]) or Cout <= 16      # two orders of summation
+
+
+def test_s2dx_rule_and_what_it_leaves_alone(dev):
+    """By rule from one block per CU on; odd extents, other kernels / strides, groups, dilation, 40 channels and mixed padding stay with the
+    per-phase (or direct) kernels even under the forced knob: the same bits as with the knob at 0."""
+    c = capi()
+
+    def dx_of(xs, ws, stride, pad, groups, dil, mode, seed=1):
+        N, Cin = xs[0], xs[1]
+        padded = tuple(xs[2 + i] + 2 * pad[i] for i in range(2))
+        oshape = O.conv_out_shape((N, Cin) + padded, ws, stride, dil)
+        go, w = rnd(seed, oshape), rnd(seed + 1, ws, -1, 1)
+        dev.conv_s2dx(mode)
+        try:
+            D = dev.full(xs, np.nan)
+            c.conv_bwd_input(dev, D, dev.array(go), dev.array(w), stride, dil, groups, assign=True, padding=pad if any(pad) else None)
+            return D.numpy()
+        finally:
+            dev.conv_s2dx(None)
+
+    small, large = (2, 64, 8, 8), (64, 64, 56, 56)
+    ws = (128, 64, 3, 3)
+    assert np.array_equal(dx_of(small, ws, (2, 2), (1, 1), 1, (1, 1), None), dx_of(small, ws, (2, 2), (1, 1), 1, (1, 1), 0))      # rule: per phase
+    assert not np.array_equal(dx_of(small, ws, (2, 2), (1, 1), 1, (1, 1), 1), dx_of(small, ws, (2, 2), (1, 1), 1, (1, 1), 0))     # forced: fused
+    assert np.array_equal(dx_of(large, ws, (2, 2), (1, 1), 1, (1, 1), None), dx_of(large, ws, (2, 2), (1, 1), 1, (1, 1), 1))      # rule: fused
+    for xs, wk, st, pad, g, dil in (((2, 64, 7, 8), ws, (2, 2), (1, 1), 1, (1, 1)), ((2, 64, 8, 8), (128, 64, 5, 5), (2, 2), (2, 2), 1, (1, 1)),
+                                    ((2, 64, 8, 8), ws, (2, 1), (1, 1), 1, (1, 1)), ((2, 128, 8, 8), ws, (2, 2), (1, 1), 2, (1, 1)),
+                                    ((2, 64, 10, 10), ws, (2, 2), (2, 2), 1, (2, 2)), ((2, 40, 8, 8), (128, 40, 3, 3), (2, 2), (1, 1), 1, (1, 1)),
+                                    ((2, 64, 8, 8), ws, (2, 2), (1, 0), 1, (1, 1))):
+        assert np.array_equal(dx_of(xs, wk, st, pad, g, dil, 1), dx_of(xs, wk, st, pad, g, dil, 0)), (xs, wk, st, pad, g, dil)
