@@ -57,6 +57,17 @@ def main():
             dev.conv_winograd(None)
             print(json.dumps(row), flush=True)
         return
+    if len(sys.argv) > 2 and sys.argv[2] == "dwfold":    # round 6: the kernel gradient with the module's padding FOLDED in (what the C3 step launches)
+        for name, ci, co, hh in (("C3 64 -> 128 at 56 x 56", 64, 128, 56), ("128 -> 128 at 28 x 28", 128, 128, 28), ("256 -> 256 at 14 x 14", 256, 256, 14)):
+            xx = dev.array(rng.random((N, ci, hh, hh), dtype=np.float32))
+            gg = dev.array(rng.random((N, co, hh, hh), dtype=np.float32))
+            dww, dbb = dev.zeros((co, ci, 3, 3)), dev.zeros((co, 1, 1))
+            fn = lambda: c.conv_bwd_kernel_padded(dev, dww, gg, xx, (1, 1), (1, 1), (1, 1), 1, db=dbb, assign=(True, True))
+            row = {"case": name, "N": N, "folded_us": []}
+            for rnd in range(3):
+                row["folded_us"].append(round(time(fn), 1))
+            print(json.dumps(row), flush=True)
+        return
     if len(sys.argv) > 2 and sys.argv[2] == "shape":     # narrow (two-wave, 64-channel) against wide (four-wave, 128-channel) blocks
         geoms = [("C3 forward 64 -> 128", 64, 128, True), ("128 -> 128 at 28 x 28, forward", 128, 128, True),
                  ("128 -> 128 at 28 x 28, input gradient", 128, 128, False), ("256 -> 256 at 14 x 14, forward", 256, 256, True),

@@ -47,6 +47,13 @@ elif what in ("attn_fwd", "attn_fwd_nodrop", "attn_bwd"):
         f = lambda: c.attention_bwd(dev, dQ, dK, dV, dS, Pd, G, out, scores, stats, bits, Q, Kk, V, B, S, H, dh, 0.125, p, True, (True, True, True))
     else:
         f = fwd
+elif what == "conv_s2_bwd_input":   # round 6: the fused-phase input gradient of the 3x3 stride-2 layer 64 -> 128 at 56 x 56 (nk_conv_s2dx.h)
+    batch = 128
+    k = 1.0 / np.sqrt(576.0)
+    W = rand(dev, (128, 64, 3, 3), 1, -k, k)
+    G = rand(dev, (batch, 128, 28, 28), 2, 0, 1)
+    DX = dev.zeros((batch, 64, 56, 56))
+    f = lambda: c.conv_bwd_input(dev, DX, G, W, (2, 2), (1, 1), 1, assign=True, padding=(1, 1))
 else:
     batch = 128
     x = rand(dev, (batch, 64, 56, 56), 0, 0, 1)

@@ -156,54 +156,108 @@ __global__ __launch_bounds__(256, 1) void wino_dw_kernel(WinoDwArgs a) {
     };
     // transform of a loaded item, in two steps: `compute` (registers only: the 16 + 16 xi values of the thread's tile and channel
     // pair) and the stores, element (xi, channel quad cp / 2, tile, channels 2 (cp % 2), + 1) as one float2 each
-    // (round 6: the arithmetic runs on COLUMN PAIRS - a loaded b64 is two adjacent columns of one channel in a register pair, and the
+    // (round 6, unfolded instantiations: the arithmetic runs on COLUMN PAIRS - a loaded b64 is two adjacent columns of one channel in a register pair, and the
     //  pairs' adds, subtractions and halvings are v_pk_add_f32 / v_pk_fma_f32 / v_pk_mul_f32 with op_sel / neg modifiers: 28 packed
     //  instructions per channel where the element-wise form issued 56; f32 VALU work cannot overlap the f32 MFMAs, every one counts)
     typedef float v2f __attribute__((ext_vector_type(2)));
     float xv[2][16], yv[2][16];
     auto compute = [&](auto set) {
         constexpr int S = decltype(set)::value;
+        if constexpr (!FOLD) {
 #pragma unroll
-        for (int ch = 0; ch < 2; ++ch) {
-            v2f dl[4], dh[4];  // patch row i: columns 0-1, columns 2-3
+            for (int ch = 0; ch < 2; ++ch) {
+                v2f dl[4], dh[4];  // patch row i: columns 0-1, columns 2-3
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                dl[i] = __builtin_bit_cast(v2f, xr[S][ch][i][0]);
-                dh[i] = __builtin_bit_cast(v2f, xr[S][ch][i][1]);
-                if constexpr (FOLD) {
-                    if (i < 2 && __any(fix_shift[S] == i)) {  // (one wave of one block of the launch; image row 0 is patch row 0 or 1)
-                        const bool sh = fix_shift[S] == i;
-                        dh[i].y = sh ? dh[i].x : dh[i].y; dh[i].x = sh ? dl[i].y : dh[i].x; dl[i].y = sh ? dl[i].x : dl[i].y;
+                for (int i = 0; i < 4; ++i) {
+                    dl[i] = __builtin_bit_cast(v2f, xr[S][ch][i][0]);
+                    dh[i] = __builtin_bit_cast(v2f, xr[S][ch][i][1]);
+                    if constexpr (FOLD) {
+                        if (i < 2 && __any(fix_shift[S] == i)) {  // (one wave of one block of the launch; image row 0 is patch row 0 or 1)
+                            const bool sh = fix_shift[S] == i;
+                            dh[i].y = sh ? dh[i].x : dh[i].y; dh[i].x = sh ? dl[i].y : dh[i].x; dl[i].y = sh ? dl[i].x : dl[i].y;
+                        }
+                        dl[i].x = fix_left[S] ? 0.f : dl[i].x;
+                        dh[i].y = fix_right[S] ? 0.f : dh[i].y;
+                        if constexpr (ODD) dh[i].x = fix_x2[S] ? 0.f : dh[i].x;
+                    } else if constexpr (ODD) {
+                        dh[i].y = fix_col[S] ? 0.f : dh[i].y;
                     }
-                    dl[i].x = fix_left[S] ? 0.f : dl[i].x;
-                    dh[i].y = fix_right[S] ? 0.f : dh[i].y;
-                    if constexpr (ODD) dh[i].x = fix_x2[S] ? 0.f : dh[i].x;
-                } else if constexpr (ODD) {
-                    dh[i].y = fix_col[S] ? 0.f : dh[i].y;
+                }
+                // B^T d, both column pairs of a row at once
+                const v2f tl[4] = {dl[0] - dl[2], dl[1] + dl[2], dl[2] - dl[1], dl[3] - dl[1]};
+                const v2f th[4] = {dh[0] - dh[2], dh[1] + dh[2], dh[2] - dh[1], dh[3] - dh[1]};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {  // (B^T d) B: (t0 - t2, t1 + t2) and (t2 - t1, t3 - t1)
+                    const v2f t22 = __builtin_shufflevector(th[i], th[i], 0, 0), t11 = __builtin_shufflevector(tl[i], tl[i], 1, 1);
+                    const v2f o01 = tl[i] + t22 * (v2f){-1.f, 1.f};  // (an exact product: the same bits as the subtraction / addition)
+                    const v2f o23 = th[i] - t11;
+                    xv[ch][4 * i + 0] = o01.x; xv[ch][4 * i + 1] = o01.y;
+                    xv[ch][4 * i + 2] = o23.x; xv[ch][4 * i + 3] = o23.y;
+                }
+                v2f r0 = __builtin_bit_cast(v2f, yr[S][ch][0]), r1 = __builtin_bit_cast(v2f, yr[S][ch][1]);
+                if constexpr (ODD) { r0.y = fix_col[S] ? 0.f : r0.y; r1.y = fix_col[S] ? 0.f : r1.y; }
+                const v2f g[4] = {r0, 0.5f * (r0 + r1), 0.5f * (r0 - r1), r1};  // G dy, both columns of a row at once
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {  // (G dy) G^T: g.x, (g.x + g.y) / 2, (g.x - g.y) / 2, g.y
+                    const v2f gx = __builtin_shufflevector(g[i], g[i], 0, 0), gy_ = __builtin_shufflevector(g[i], g[i], 1, 1);
+                    const v2f mid = 0.5f * (gx + gy_ * (v2f){1.f, -1.f});
+                    yv[ch][4 * i + 0] = g[i].x;
+                    yv[ch][4 * i + 1] = mid.x;
+                    yv[ch][4 * i + 2] = mid.y;
+                    yv[ch][4 * i + 3] = g[i].y;
                 }
             }
-            // B^T d, both column pairs of a row at once
-            const v2f tl[4] = {dl[0] - dl[2], dl[1] + dl[2], dl[2] - dl[1], dl[3] - dl[1]};
-            const v2f th[4] = {dh[0] - dh[2], dh[1] + dh[2], dh[2] - dh[1], dh[3] - dh[1]};
+        } else {
+            // (the FOLD instantiations keep the element-wise form: with their border fix-ups on single elements of the pairs the packed
+            //  form measured 6 % SLOWER - C3 303 -> 323 us, same box, alternating - while the unfolded kernels gain 4 - 7 %)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {  // (B^T d) B: (t0 - t2, t1 + t2) and (t2 - t1, t3 - t1)
-                const v2f t22 = __builtin_shufflevector(th[i], th[i], 0, 0), t11 = __builtin_shufflevector(tl[i], tl[i], 1, 1);
-                const v2f o01 = tl[i] + t22 * (v2f){-1.f, 1.f};  // (an exact product: the same bits as the subtraction / addition)
-                const v2f o23 = th[i] - t11;
-                xv[ch][4 * i + 0] = o01.x; xv[ch][4 * i + 1] = o01.y;
-                xv[ch][4 * i + 2] = o23.x; xv[ch][4 * i + 3] = o23.y;
-            }
-            v2f r0 = __builtin_bit_cast(v2f, yr[S][ch][0]), r1 = __builtin_bit_cast(v2f, yr[S][ch][1]);
-            if constexpr (ODD) { r0.y = fix_col[S] ? 0.f : r0.y; r1.y = fix_col[S] ? 0.f : r1.y; }
-            const v2f g[4] = {r0, 0.5f * (r0 + r1), 0.5f * (r0 - r1), r1};  // G dy, both columns of a row at once
+            for (int ch = 0; ch < 2; ++ch) {
+                float d[4][4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {  // (G dy) G^T: g.x, (g.x + g.y) / 2, (g.x - g.y) / 2, g.y
-                const v2f gx = __builtin_shufflevector(g[i], g[i], 0, 0), gy_ = __builtin_shufflevector(g[i], g[i], 1, 1);
-                const v2f mid = 0.5f * (gx + gy_ * (v2f){1.f, -1.f});
-                yv[ch][4 * i + 0] = g[i].x;
-                yv[ch][4 * i + 1] = mid.x;
-                yv[ch][4 * i + 2] = mid.y;
-                yv[ch][4 * i + 3] = g[i].y;
+                for (int i = 0; i < 4; ++i) {
+                    const float2 lo = __builtin_bit_cast(float2, xr[S][ch][i][0]), hi = __builtin_bit_cast(float2, xr[S][ch][i][1]);
+                    d[i][0] = lo.x; d[i][1] = lo.y; d[i][2] = hi.x; d[i][3] = hi.y;
+                    if constexpr (FOLD) {
+                        if (i < 2 && __any(fix_shift[S] == i)) {  // (one wave of one block of the launch; image row 0 is patch row 0 or 1)
+                            const bool sh = fix_shift[S] == i;
+                            d[i][3] = sh ? d[i][2] : d[i][3]; d[i][2] = sh ? d[i][1] : d[i][2]; d[i][1] = sh ? d[i][0] : d[i][1];
+                        }
+                        d[i][0] = fix_left[S] ? 0.f : d[i][0];
+                        d[i][3] = fix_right[S] ? 0.f : d[i][3];
+                        if constexpr (ODD) d[i][2] = fix_x2[S] ? 0.f : d[i][2];
+                    } else if constexpr (ODD) {
+                        d[i][3] = fix_col[S] ? 0.f : d[i][3];
+                    }
+                }
+                float tt[4][4];  // B^T d
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    tt[0][j] = d[0][j] - d[2][j];
+                    tt[1][j] = d[1][j] + d[2][j];
+                    tt[2][j] = d[2][j] - d[1][j];
+                    tt[3][j] = d[3][j] - d[1][j];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {  // (B^T d) B
+                    xv[ch][4 * i + 0] = tt[i][0] - tt[i][2];
+                    xv[ch][4 * i + 1] = tt[i][1] + tt[i][2];
+                    xv[ch][4 * i + 2] = tt[i][2] - tt[i][1];
+                    xv[ch][4 * i + 3] = tt[i][3] - tt[i][1];
+                }
+                float2 r0 = __builtin_bit_cast(float2, yr[S][ch][0]), r1 = __builtin_bit_cast(float2, yr[S][ch][1]);
+                if constexpr (ODD) { r0.y = fix_col[S] ? 0.f : r0.y; r1.y = fix_col[S] ? 0.f : r1.y; }
+                float g[4][2];  // G dy
+                g[0][0] = r0.x; g[0][1] = r0.y;
+                g[1][0] = 0.5f * (r0.x + r1.x); g[1][1] = 0.5f * (r0.y + r1.y);
+                g[2][0] = 0.5f * (r0.x - r1.x); g[2][1] = 0.5f * (r0.y - r1.y);
+                g[3][0] = r1.x; g[3][1] = r1.y;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {  // (G dy) G^T
+                    yv[ch][4 * i + 0] = g[i][0];
+                    yv[ch][4 * i + 1] = 0.5f * (g[i][0] + g[i][1]);
+                    yv[ch][4 * i + 2] = 0.5f * (g[i][0] - g[i][1]);
+                    yv[ch][4 * i + 3] = g[i][1];
+                }
             }
         }
         // the bias gradient rides on the transform: element (1, 1) of G dy G^T is a quarter of the tile's sum (exact scaling)
