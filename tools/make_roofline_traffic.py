@@ -63,8 +63,9 @@ def main():
 
     traffic = {
         "_note": "HBM/fabric bytes per launch from rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in KB, separate runs; FETCH doubled "
-                 "per MI355X_MICROARCH.md's gfx950 wide-read correction), launch-weighted means. sgemm_kernel: 4096^3, the NT / NN / TN "
-                 "launches of benchmarks/gemm_once.py; conv: the three passes of the C3 module step (benchmarks/conv_step_once.py); "
+                 "per MI355X_MICROARCH.md's gfx950 wide-read correction), launch-weighted means. sgemm_kernel: the NT / NN / TN launches of "
+                 "benchmarks/gemm_once.py - 4096^3 products, since round 6 each as two chained launches over K (4096 x 4096 x 2048 per "
+                 "launch: algorithmic 134 - 201 MB); conv: the three passes of the C3 module step (benchmarks/conv_step_once.py); "
                  "mha_gemm: every sgemm_kernel launch of one C5 step (benchmarks/mha_step_once.py), attention: the forward and backward "
                  "launches of the fused attention core in the same step. Regenerate after a GEMM / conv "
                  "change: bash tools/traffic_pmc.sh DIR && python tools/make_roofline_traffic.py DIR",
