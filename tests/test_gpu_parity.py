@@ -690,6 +690,42 @@ def test_sgemm_chained_launches(dev, ta, tb):
         dev.gemm_chain(None)
 
 
+def test_sgemm_chained_launches_batched_and_copy_kernel(dev):
+    """(i) The chain over K carries the two-level batch strides through its pieces: a batched unsplit GEMM with K = 4096 equals, bit for
+    bit, the two batched calls over the halves of K issued by hand with the knob at 0 (beta = 1 on the second) - and not the one-chain
+    launch.  (ii) `nk_copy` from 1 Mi floats on is a span-walk kernel (nk_common.h) instead of the runtime's blit: exact copies at sizes
+    around the threshold, ragged lengths and misaligned pointers (those fall back to the blit)."""
+    import ctypes
+    c = capi()
+    bo, bi, M, N, K = 2, 2, 1024, 2048, 4096                       # 4 x 128 tiles = 512 blocks: unsplit, K beyond one chain
+    a, b = rnd(1, (bo * bi, M, K), -1, 1), rnd(2, (bo * bi, K, N), -1, 1)
+    A, B, Cb = dev.array(a), dev.array(b), dev.full((bo * bi, M, N), np.nan)
+
+    class View:
+        def __init__(self, arr, off): self.keep, self.p = arr, ctypes.c_void_p(arr.p.value + 4 * off)
+
+    def batched(Av, Bv, Cm, k, beta):
+        c.sgemm_batched(dev, 0, 0, M, N, k, 1.0, Av, K, bi * M * K, M * K, Bv, N, bi * K * N, K * N, beta, Cm, N, bi * M * N, M * N, bo, bi)
+    batched(A, B, Cb, K, 0.0)
+    dev.gemm_chain(0)
+    try:
+        C1, C2 = dev.full((bo * bi, M, N), np.nan), dev.full((bo * bi, M, N), np.nan)
+        batched(A, B, C1, K, 0.0)                                   # one chain of 4096
+        batched(A, B, C2, K // 2, 0.0)                              # the pieces by hand
+        batched(View(A, K // 2), View(B, (K // 2) * N), C2, K // 2, 1.0)
+    finally:
+        dev.gemm_chain(None)
+    assert np.array_equal(Cb.numpy(), C2.numpy()) and not np.array_equal(Cb.numpy(), C1.numpy())
+    for n, off_d, off_s in (((1 << 20), 0, 0), ((1 << 20) + 4, 0, 0), ((1 << 20) - 4, 0, 0), (5 * (1 << 20) + 8, 4, 8), ((1 << 21) + 3, 0, 0),
+                            ((1 << 21), 1, 0), ((1 << 21), 0, 3), (3 << 20, 4, 4)):
+        src = rnd(n, (n + 16,), -1, 1)
+        S, D = dev.array(src), dev.full((n + 16,), 7.0)
+        c.check(c.lib.nk_copy(dev.h, ctypes.c_void_p(D.p.value + 4 * off_d), ctypes.c_void_p(S.p.value + 4 * off_s), n))
+        got = D.numpy()
+        assert np.array_equal(got[off_d:off_d + n], src[off_s:off_s + n]), (n, off_d, off_s)
+        assert np.all(got[:off_d] == 7.0) and np.all(got[off_d + n:] == 7.0), (n, off_d, off_s)
+
+
 @pytest.mark.parametrize("layout", ["NT", "NN", "TN"])
 @pytest.mark.parametrize("M,N,K,busy", [(4096, 4096, 256, 16), (2048, 4096, 1024, 8), (4096, 2048, 384, 32), (4096, 4096, 512, 40),
                                         (3200, 5120, 256, 16)])   # tile counts the rules keep at 128x128: 1024, 512, 512, 1024, 1000 (25 tile rows: a last group of one); >= 4 pieces possible
