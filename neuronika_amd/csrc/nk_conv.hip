@@ -263,6 +263,12 @@ int conv_bwd_input(nk_device* dev, int nd, float* dx, const int* x_shape, const 
         }
         const int pt = g.uinplane >= 512 ? 4 : 1;
         const dim3 dgrid((unsigned)(g.N * g.Cin), (unsigned)((g.uinplane + 256 * pt - 1) / (256 * pt)));
+        if (!unit && g.dil[0] == 1 && g.dil[1] == 1 && g.dil[2] == 1) {  // a lane walks its own residue class of taps: no division per tap
+            if (pt == 4) hipLaunchKernelGGL((conv_direct_bwd_input_strided_kernel<4>), dgrid, dim3(256), 0, dev->compute, dx, gy, w, g);
+            else hipLaunchKernelGGL((conv_direct_bwd_input_strided_kernel<1>), dgrid, dim3(256), 0, dev->compute, dx, gy, w, g);
+            NK_LAUNCH_CHECK();
+            return nk_prof_stop(dev);
+        }
 #define NK_DI(U, PT_, A, B) hipLaunchKernelGGL((conv_direct_bwd_input_kernel<U, PT_, A, B>), dgrid, dim3(256), 0, dev->compute, dx, gy, w, g)
         if (g.k[1] == 3 && g.k[2] == 3) {
             if (unit) { if (pt == 4) NK_DI(true, 4, 3, 3); else NK_DI(true, 1, 3, 3); }

@@ -167,6 +167,74 @@ __global__ __launch_bounds__(256) void conv_direct_bwd_input_kernel(float* __res
     }
 }
 
+// Strided backward-input (some stride > 1, every dilation 1) WITHOUT a division per tap (round 6): of the taps of an axis only those
+// with k = (p + pad) mod stride reach position p, so a lane walks its OWN residue class - k = r, r + s, r + 2 s, ... against output
+// coordinates o0, o0 - 1, o0 - 2, ... - where the general kernel above tests every tap with `%` and `/` (two integer divisions of
+// ~ 20 instructions each per tap and position) and masks three of four at stride 2.  The residue differs from lane to lane, so the
+// weight is a per-lane load (the whole kernel tensor is a few KB: L1 hits) instead of a scalar broadcast.  Same (m, k0, k1, k2)
+// accumulation order per element as the general kernel - the skipped taps contributed exact zeros: bit-identical results.
+// The 7 x 7 / stride-2 stem (3 -> 64 channels at 224 x 224, N = 128): 3.8 ms -> see profiles/r06_conv_shapes.jsonl.
+template <int PT>
+__global__ __launch_bounds__(256) void conv_direct_bwd_input_strided_kernel(float* __restrict__ dx, const float* __restrict__ gy,
+                                                                            const float* __restrict__ w, ConvGeom g) {
+    const int nc = blockIdx.x, cabs = nc % g.Cin, n = nc / g.Cin, grp = cabs / g.Cg, ci = cabs - grp * g.Cg;
+    const int p0 = blockIdx.y * (256 * PT) + threadIdx.x;
+    int r[PT][3], o0[PT][3];  // per position and axis: the residue class (first tap) and the output coordinate that tap meets
+    float acc[PT];
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+        int pos = p0 + 256 * i;
+        pos = pos < g.uinplane ? pos : 0;
+        int pc[3];
+        pc[2] = pos % g.uin[2] + g.pad[2]; pos /= g.uin[2];
+        pc[1] = pos % g.uin[1] + g.pad[1];
+        pc[0] = pos / g.uin[1] + g.pad[0];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            r[i][d] = pc[d] % g.stride[d];
+            o0[i][d] = (pc[d] - r[i][d]) / g.stride[d];
+        }
+        acc[i] = 0.f;
+    }
+    const int J0 = (g.k[0] + g.stride[0] - 1) / g.stride[0], J1 = (g.k[1] + g.stride[1] - 1) / g.stride[1],
+              J2 = (g.k[2] + g.stride[2] - 1) / g.stride[2];  // taps per residue class and axis, at most
+    const float* gs = gy + ((long long)n * g.Cout + (long long)grp * g.Mg) * g.L;
+    for (int m = 0; m < g.Mg; ++m) {
+        const float* gc = gs + (long long)m * g.L;
+        const float* wc = w + ((long long)(grp * g.Mg + m) * g.Cg + ci) * g.KK;
+        for (int j0 = 0; j0 < J0; ++j0)
+            for (int j1 = 0; j1 < J1; ++j1) {
+                int rbase[PT], wbase[PT];  // gradient row offset and weight row offset, or -1
+#pragma unroll
+                for (int i = 0; i < PT; ++i) {
+                    const int k0 = r[i][0] + j0 * g.stride[0], k1 = r[i][1] + j1 * g.stride[1];
+                    const int a = o0[i][0] - j0, b = o0[i][1] - j1;
+                    const bool ok = k0 < g.k[0] && k1 < g.k[1] && a >= 0 && a < g.out[0] && b >= 0 && b < g.out[1];
+                    rbase[i] = ok ? (a * g.out[1] + b) * g.out[2] : -1;
+                    wbase[i] = (k0 * g.k[1] + k1) * g.k[2];
+                }
+                for (int j2 = 0; j2 < J2; ++j2) {
+#pragma unroll
+                    for (int i = 0; i < PT; ++i) {  // branch-free: clamped (always valid) addresses, the product masked
+                        const int k2 = r[i][2] + j2 * g.stride[2], c = o0[i][2] - j2;
+                        const bool ok = rbase[i] >= 0 && k2 < g.k[2] && c >= 0 && c < g.out[2];
+                        const float gv = gc[ok ? rbase[i] + c : 0];
+                        const float wv = wc[ok ? wbase[i] + k2 : 0];
+                        acc[i] = fmaf(ok ? wv : 0.f, ok ? gv : 0.f, acc[i]);  // (a tap that does not reach the position adds an exact 0, whatever its weight)
+                    }
+                }
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+        const int pos = p0 + 256 * i;
+        if (pos < g.uinplane) {
+            const long long o = (long long)nc * g.uinplane + pos;
+            dx[o] = g.assign ? acc[i] : dx[o] + acc[i];
+        }
+    }
+}
+
 // Row-blocked backward-input, same idea (unit stride on every axis, unit dilation on the innermost one, k[0] == 1,
 // uin[2] % 4 == 0, 16-byte aligned dx): four adjacent input positions share one 4 + TK2 - 1 element segment of each
 // gradient row; positions outside the gradient read a clamped address and are masked.  Same (m, k1, k2) accumulation

@@ -119,3 +119,32 @@ def test_s2dx_rule_and_what_it_leaves_alone(dev):
                                     ((2, 64, 10, 10), ws, (2, 2), (2, 2), 1, (2, 2)), ((2, 40, 8, 8), (128, 40, 3, 3), (2, 2), (1, 1), 1, (1, 1)),
                                     ((2, 64, 8, 8), ws, (2, 2), (1, 0), 1, (1, 1))):
         assert np.array_equal(dx_of(xs, wk, st, pad, g, dil, 1), dx_of(xs, wk, st, pad, g, dil, 0)), (xs, wk, st, pad, g, dil)
+
+
+@pytest.mark.parametrize("xs,ws,stride,pad,groups", [((2, 3, 20, 20), (8, 3, 7, 7), (2, 2), (3, 3), 1),     # the stem's geometry in small
+                                                     ((3, 4, 9, 11), (6, 2, 3, 3), (2, 3), (1, 0), 2),       # groups, unequal strides
+                                                     ((2, 2, 5, 6, 7), (4, 2, 2, 3, 1), (2, 1, 3), (0, 1, 0), 1),   # three dimensions
+                                                     ((2, 8, 33), (16, 8, 5), (4,), (2,), 1),               # one dimension, stride 4
+                                                     ((1, 3, 224, 224), (64, 3, 7, 7), (2, 2), (3, 3), 1)])  # the stem itself, one sample
+def test_strided_direct_input_gradient_walks_residue_classes(dev, xs, ws, stride, pad, groups):
+    """The direct (<= 16 channels per group) input gradient of a STRIDED convolution: a lane walks its own residue class of taps
+    (`conv_direct_bwd_input_strided_kernel`, round 6: no division per tap - the 7 x 7 / stride-2 stem 3.8 ms -> see the shape table) -
+    against the oracle on integer-valued data, exactly, `+=` and first write, with the module's padding folded and without."""
+    c = capi()
+    nd = len(xs) - 2
+    dil = (1,) * nd
+    padded = tuple(xs[:2]) + tuple(xs[2 + i] + 2 * pad[i] for i in range(nd))
+    oshape = O.conv_out_shape(padded, ws, stride, dil)
+    go, w, dx0 = ints(1, oshape, -3, 3), ints(2, ws, -2, 2), ints(3, xs, -5, 5)
+    want_p = np.zeros(padded, np.float32)
+    O.convolution_backward_input(want_p, go, w, stride, dil, groups)
+    inner = (slice(None), slice(None)) + tuple(slice(pad[i], pad[i] + xs[2 + i]) for i in range(nd))
+    G, Wd = dev.array(go), dev.array(w)
+    D, Da = dev.array(dx0), dev.full(xs, np.nan)
+    padding = pad if any(pad) else None
+    c.conv_bwd_input(dev, D, G, Wd, stride, dil, groups, padding=padding)
+    c.conv_bwd_input(dev, Da, G, Wd, stride, dil, groups, assign=True, padding=padding)
+    assert np.array_equal(Da.numpy(), want_p[inner]) and np.array_equal(D.numpy(), dx0 + want_p[inner])
+    DP = dev.full(padded, np.nan)                                   # the gradient of the padded input itself
+    c.conv_bwd_input(dev, DP, G, Wd, stride, dil, groups, assign=True)
+    assert np.array_equal(DP.numpy(), want_p)
