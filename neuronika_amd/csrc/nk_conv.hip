@@ -255,7 +255,11 @@ int conv_bwd_input(nk_device* dev, int nd, float* dx, const int* x_shape, const 
                              ((g.k[1] == 3 && g.k[2] == 3) || (g.k[1] == 5 && g.k[2] == 5) || (g.k[1] == 1 && g.k[2] == 3));
         if (rows_ok) {
             const dim3 rgrid((unsigned)(g.N * g.Cin), (unsigned)((g.uin[1] * (g.uin[2] / 4) + 255) / 256));
-            if (g.k[1] == 3) hipLaunchKernelGGL((conv_direct_bwd_input_rows_kernel<3, 3>), rgrid, dim3(256), 0, dev->compute, dx, gy, w, g);
+            const bool buf = (long long)g.N * g.Cout * g.L * 4 < 0x7fffffffLL;  // 32-bit byte offsets through a buffer descriptor
+            if (g.k[1] == 3 && buf) hipLaunchKernelGGL((conv_direct_bwd_input_rows_kernel<3, 3, true>), rgrid, dim3(256), 0, dev->compute, dx, gy, w, g);
+            else if (g.k[1] == 5 && buf) hipLaunchKernelGGL((conv_direct_bwd_input_rows_kernel<5, 5, true>), rgrid, dim3(256), 0, dev->compute, dx, gy, w, g);
+            else if (buf) hipLaunchKernelGGL((conv_direct_bwd_input_rows_kernel<1, 3, true>), rgrid, dim3(256), 0, dev->compute, dx, gy, w, g);
+            else if (g.k[1] == 3) hipLaunchKernelGGL((conv_direct_bwd_input_rows_kernel<3, 3>), rgrid, dim3(256), 0, dev->compute, dx, gy, w, g);
             else if (g.k[1] == 5) hipLaunchKernelGGL((conv_direct_bwd_input_rows_kernel<5, 5>), rgrid, dim3(256), 0, dev->compute, dx, gy, w, g);
             else hipLaunchKernelGGL((conv_direct_bwd_input_rows_kernel<1, 3>), rgrid, dim3(256), 0, dev->compute, dx, gy, w, g);
             NK_LAUNCH_CHECK();

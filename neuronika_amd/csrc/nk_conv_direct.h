@@ -239,7 +239,10 @@ __global__ __launch_bounds__(256) void conv_direct_bwd_input_strided_kernel(floa
 // uin[2] % 4 == 0, 16-byte aligned dx): four adjacent input positions share one 4 + TK2 - 1 element segment of each
 // gradient row; positions outside the gradient read a clamped address and are masked.  Same (m, k1, k2) accumulation
 // order per element as the one-position kernel.
-template <int TK1, int TK2>
+// BUF (round 6, tensors below 2 GB): the segment comes in as 8-byte buffer loads (merged to 16 + 8 / 16 + 16 bytes, any 4-byte boundary) from
+// gr + c0 instead of 4 + TK2 - 1 masked scalar loads - the depthwise / grouped input gradients are bound by the rate at which a CU issues
+// loads, not by HBM; an address before / past the tensor reads 0 through the descriptor, elements of a neighbouring row are masked as before.
+template <int TK1, int TK2, bool BUF = false>
 __global__ __launch_bounds__(256) void conv_direct_bwd_input_rows_kernel(float* __restrict__ dx, const float* __restrict__ gy,
                                                                          const float* __restrict__ w, ConvGeom g) {
     const int nc = blockIdx.x, cabs = nc % g.Cin, n = nc / g.Cin, grp = cabs / g.Cg, ci = cabs - grp * g.Cg;
@@ -249,6 +252,8 @@ __global__ __launch_bounds__(256) void conv_direct_bwd_input_rows_kernel(float* 
     const int a = q / qpr, b = (q - a * qpr) * 4;
     const int pa = a + g.pad[1], c0 = b + g.pad[2] - (TK2 - 1);  // gradient column of segment element 0
     const float* gs = gy + ((long long)n * g.Cout + (long long)grp * g.Mg) * g.L;
+    const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc((void*)gy, 0, BUF ? (int)((long long)g.N * g.Cout * g.L * 4) : 0, 0x00020000);
+    const long long gs_off = ((long long)n * g.Cout + (long long)grp * g.Mg) * g.L;
     float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
     for (int m = 0; m < g.Mg; ++m) {
         const float* gc = gs + (long long)m * g.L;
@@ -259,12 +264,34 @@ __global__ __launch_bounds__(256) void conv_direct_bwd_input_rows_kernel(float* 
             const bool rowok = ra >= 0 && ra < g.out[1];
             const float* gr = gc + (rowok ? ra : 0) * g.out[2];
             float seg[4 + TK2 - 1];
+            // element offset of segment element 0 in gy; negative only in the tensor's very first row (n = 0, first channel, row 0) for the
+            // first quad of a row: a byte offset that wrapped below zero does not wrap back inside a multi-dword load, so the ONE wave of
+            // the launch that holds such a lane takes the scalar loads for that row (wave-uniform branch)
+            const int eoff = (int)(gs_off + (long long)m * g.L) + ra * g.out[2] + c0;
+            if (BUF && !__any(rowok && eoff < 0)) {
+                static_assert(!BUF || TK2 == 3 || TK2 == 5, "segments of 6 or 8 floats");
+                const unsigned vo = rowok ? (unsigned)eoff * 4u : 0x80000000u;  // (a row that does not exist: out of range, zeros)
+                float raw[8];
 #pragma unroll
-            for (int j = 0; j < 4 + TK2 - 1; ++j) {
-                const int col = c0 + j;
-                const bool ok = rowok && col >= 0 && col < g.out[2];
-                const float v = gr[ok ? col : 0];
-                seg[j] = ok ? v : 0.f;
+                for (int k = 0; k < (4 + TK2 - 1 + 1) / 2; ++k) {  // (the compiler merges neighbours into 16-byte loads; any 4-byte boundary)
+                    const auto v = __builtin_amdgcn_raw_buffer_load_b64(grs, vo + 8u * k, 0, 0);
+                    static_assert(sizeof(v) == 8, "two dwords");
+                    const float2 f = __builtin_bit_cast(float2, v);
+                    raw[2 * k] = f.x; raw[2 * k + 1] = f.y;
+                }
+#pragma unroll
+                for (int j = 0; j < 4 + TK2 - 1; ++j) {
+                    const int col = c0 + j;
+                    seg[j] = rowok && col >= 0 && col < g.out[2] ? raw[j] : 0.f;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4 + TK2 - 1; ++j) {
+                    const int col = c0 + j;
+                    const bool ok = rowok && col >= 0 && col < g.out[2];
+                    const float v = gr[ok ? col : 0];
+                    seg[j] = ok ? v : 0.f;
+                }
             }
 #pragma unroll
             for (int k2 = 0; k2 < TK2; ++k2) {
