@@ -1379,6 +1379,42 @@ def test_conv2d_module_at_an_odd_extent_and_on_a_plain_input(nk, tdev):
         stem.weight.zero_grad(); stem.bias.zero_grad()
 
 
+def test_conv2d_module_stride_2_takes_the_fused_phase_input_gradient(nk, tdev):
+    """nn::Conv2d (3 x 3, stride 2, pad 1) 64 -> 128 on 56 x 56 planes through the tape - a CNN's down-sampling layer: the input gradient
+    lands in the caller's unpadded tensor through `nk_conv_bwd_input_padded`, which by rule is the fused-phase kernel (csrc/nk_conv_s2dx.h);
+    forward, input, kernel and bias gradients against the oracle on integer-valued data, exactly; the knob at 0 gives the same bits."""
+    from neuronika_amd import capi
+    cdev = capi.Device(handle=tdev.raw())
+    N, Cin, Cout, H = 16, 64, 128, 56
+    rng = np.random.default_rng(0)
+    x = rng.integers(-3, 4, (N, Cin, H, H)).astype(np.float32)
+    gy = rng.integers(-2, 3, (N, Cout, H // 2, H // 2)).astype(np.float32)
+    outs = []
+    for mode in (None, 0):
+        cdev.conv_s2dx(mode)
+        try:
+            conv = nk.nn.Conv2d(tdev, Cin, Cout, [3, 3], [1, 1], nk.PaddingMode.zero(), [2, 2], [1, 1], 1)
+            conv.weight.set_data(np.round(conv.weight.data() * 48).astype(np.float32))
+            conv.bias.set_data(np.round(conv.bias.data() * 48).astype(np.float32))
+            X = nk.from_ndarray(tdev, x).requires_grad()
+            y = conv.forward(X)
+            y.forward(); y.backward_from(nk.from_ndarray(tdev, gy))
+            outs.append([y.data(), X.grad(), conv.weight.grad(), conv.bias.grad(), conv.weight.data(), conv.bias.data()])
+        finally:
+            cdev.conv_s2dx(None)
+    for a, b in zip(outs[0], outs[1]):
+        assert np.array_equal(a, b)
+    w, b = outs[0][4], outs[0][5]
+    xp = np.zeros((N, Cin, H + 2, H + 2), np.float32); xp[:, :, 1:-1, 1:-1] = x
+    yr = np.zeros((N, Cout, H // 2, H // 2), np.float32); O.convolution_forward(xp, w, yr, (2, 2), (1, 1), 1)
+    assert np.array_equal(outs[0][0], yr + b)
+    dxp = np.zeros_like(xp); O.convolution_backward_input(dxp, gy, w, (2, 2), (1, 1), 1)
+    assert np.array_equal(outs[0][1], dxp[:, :, 1:-1, 1:-1])
+    dw = np.zeros_like(w); O.convolution_backward_kernel(dw, gy, xp, (2, 2), (1, 1), 1)
+    assert np.array_equal(outs[0][2], dw)
+    assert np.array_equal(outs[0][3].reshape(-1), gy.sum(axis=(0, 2, 3)))
+
+
 def test_conv2d_module_at_a_size_the_winograd_rule_takes(nk, tdev):
     """nn::Conv2d (3 x 3, pad 1) through the tape at 48 x 64 x 56 x 56 -> 128 channels: by rule all three passes take the Winograd
     kernels (nk_conv_bias_fwd, nk_conv_bwd_input_padded, nk_conv_bwd_kernel_bias - the launch counter says so); the same step with the
