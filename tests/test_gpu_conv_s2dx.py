@@ -91,6 +91,32 @@ def test_s2dx_random_inside_the_contraction_bound(dev, N, Cin, Cout, H, W, pad):
     assert not np.array_equal(fused[1], phases[1]) or Cout <= 16      # two orders of summation
 
 
+def _fuzz(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        out.append((int(rng.integers(1, 7)), int(rng.choice([64, 128, 192, 256])), int(rng.choice([16, 32, 48, 64, 96, 128])),
+                    2 * int(rng.integers(1, 13)), 2 * int(rng.integers(1, 13)), int(rng.integers(0, 2))))
+    return out
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W,pad", _fuzz(32, 20260930))
+def test_s2dx_fuzz_equals_the_per_phase_kernels_on_integer_data(dev, N, Cin, Cout, H, W, pad):
+    """Seeded random geometries (1 - 6 samples, 64 - 256 input channels, 16 - 128 output channels, even extents 2 - 24, padding 0 / 1): the
+    fused-phase kernel (forced, whatever the size; narrow or wide blocks by the channel counts) against the per-phase kernels and the
+    oracle on integer-valued data, bit for bit, `+=` and first write."""
+    if H + 2 * pad < 3 or W + 2 * pad < 3:
+        pytest.skip("no output position")
+    xs = (N, Cin, H, W)
+    Ho, Wo = (H + 2 * pad - 3) // 2 + 1, (W + 2 * pad - 3) // 2 + 1
+    go, w, dx0 = ints(1, (N, Cout, Ho, Wo), -3, 3), ints(2, (Cout, Cin, 3, 3), -2, 2), ints(3, xs, -5, 5)
+    fused, phases = run(dev, go, w, dx0, xs, pad, 1), run(dev, go, w, dx0, xs, pad, 0)
+    want = oracle_dx(go, w, xs, pad, np.float32)
+    for a, b in zip(fused, phases):
+        assert np.array_equal(a, b)
+    assert np.array_equal(fused[0], dx0 + want) and np.array_equal(fused[1], want)
+
+
 def test_s2dx_rule_and_what_it_leaves_alone(dev):
     """By rule from one block per CU on; odd extents, other kernels / strides, groups, dilation, 40 channels and mixed padding stay with the
     per-phase (or direct) kernels even under the forced knob: the same bits as with the knob at 0."""
