@@ -25,6 +25,6 @@ if os.path.exists(summary):
     md = os.path.join(prof, f"{tag}_pmc_stalls.md")
     if os.path.exists(md):  # replace the table, keep the prose
         text = open(md).read()
-        text = re.sub(r"\| kernel \| us under PMC .*?\n(\|.*\n)+", table, text, count=1, flags=re.S)
+        text = re.sub(r"\| kernel \| us under PMC [^\n]*\n(\|[^\n]*\n)+", table, text, count=1)
         open(md, "w").write(text)
 print("installed", tag, "from", out)
