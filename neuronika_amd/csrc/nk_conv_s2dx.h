@@ -18,7 +18,7 @@
 // (a reorder kernel writes them that way per launch), B = the tap's neighbour plane, C = the tap's phase.  The output is the 2 x 2 block
 // of each super-pixel: float2 stores of whole row pairs, adjacent lanes adjacent super-pixels - every line written once, whole.
 //   WIDE    four waves x 32 channels = 128 output channels, chunks of 32;  NARROW  two waves = 64 output channels, chunks of 16
-// Several blocks per CU (64 accumulator registers, 8 - 16 KB of LDS each): the hardware interleaves them, the loop needs no hand
+// Several blocks per CU (64 accumulator registers, 16 - 32 KB of LDS each): the hardware interleaves them, the loop needs no hand
 // pipelining beyond the register-staged loads of the next chunk.  Out-of-range neighbours (a + 1 = Ho at the bottom / right border for
 // p = 1, a - 1 = -1 at the top / left for p = 0) and tiles past the end have buffer offset 0x80000000: the hardware returns 0.
 // Summation order: per (phase, channel, pixel) one fma chain over (reduction channel chunk, tap in ky-major order, channel) -
