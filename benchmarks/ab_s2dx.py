@@ -36,7 +36,11 @@ def main():
         DX = dev.zeros((N, ci, h, h))
         fn = lambda: c.conv_bwd_input(dev, DX, G, W, (2, 2), (1, 1), 1, assign=True, padding=(1, 1))
         flop = 2.0 * N * co * ho * ho * ci * 9
-        row = {"shape": name, "N": N, "gflop": round(flop / 1e9, 2)}
+        if len(sys.argv) > 2 and sys.argv[2] == "fwd":      # the forward twin (csrc/nk_conv_s2fwd.h) on the padded copy, as the module's Pad node leaves it
+            XP = dev.array(rng.random((N, ci, h + 2, h + 2), dtype=np.float32))
+            Y = dev.zeros((N, co, ho, ho))
+            fn = lambda: c.conv_fwd(dev, XP, W, Y, (2, 2), (1, 1), 1)
+        row = {"shape": name, "N": N, "gflop": round(flop / 1e9, 2), "pass": "forward" if len(sys.argv) > 2 and sys.argv[2] == "fwd" else "input gradient"}
         for rnd in range(3):
             for label, mode in (("per_phase", 0), ("rule", None), ("narrow", 2), ("wide", 3)):
                 dev.conv_s2dx(mode)

@@ -93,7 +93,8 @@ const char* nk_version(void);
  *                          keeps 4096- and 8192-long contractions inside 1e-6 K |a| |b| of the f64 result (SURVEY.md 8c ii; the
  *                          reference's matrixmultiply sums K in cache blocks too, matrix_matrix_mul/mod.rs:33-39)
  *   NK_TUNE_CONV_S2DX      values[0] = -1 rule / 0 the 3x3 stride-2 input gradient never takes its fused-phase kernel (the four stride
- *                          phases of a tile in one block walk; per-phase implicit GEMMs as in rounds 1 - 5) / 1 whenever the shape
+ *                          phases of a tile in one block walk; per-phase implicit GEMMs as in rounds 1 - 5) and the 3x3 stride-2 forward
+ *                          never its tap-plane kernel (by rule only with 128 | output channels and eight or more blocks per CU) / 1 whenever the shape
  *                          allows (one group, even input extents, padding 0 or 1 alike on both axes, 64 | input channels, 16 | output
  *                          channels) / 2, 3: the same with narrow (two waves, 64 channels) / wide (four waves, 128 channels) blocks forced
  * For schedule sweeps (benchmarks/ab_*.py) and the tests that pit one schedule against another bit for bit; results never

@@ -64,6 +64,7 @@ size_t round256(size_t b) { return (b + 255) & ~size_t(255); }
 #include "nk_conv_winograd.h"
 #include "nk_conv_winograd_dw.h"
 #include "nk_conv_s2dx.h"
+#include "nk_conv_s2fwd.h"
 
 // 3 x 3, stride 1, dilation 1, one group, two spatial dimensions: the shapes wino_launch may take
 bool wino_shape(const ConvGeom& g) {
@@ -107,6 +108,13 @@ int conv_fwd(nk_device* dev, int nd, const float* x, const int* x_shape, const f
         bool taken = false;
         rc = wino_launch(dev, false, x, w, y, bias, g.N, g.Cin, g.Cout, g.in[1], g.in[2], g.out[1], g.out[2], 0, 0, 1,
                          2.0 * g.N * (double)g.Cout * g.L * g.Cg * g.KK, &taken);
+        if (rc || taken) return rc;
+    }
+    if (g.groups == 1 && g.in[0] == 1 && g.k[0] == 1 && g.k[1] == 3 && g.k[2] == 3 && g.stride[1] == 2 && g.stride[2] == 2 && g.dil[1] == 1 &&
+        g.dil[2] == 1) {  // nine tap products on staged tap planes (nk_conv_s2fwd.h)
+        bool taken = false;
+        rc = s2f_launch(dev, x, w, bias, y, g.N, g.Cin, g.Cout, g.in[1], g.in[2], g.out[1], g.out[2], 0,
+                        2.0 * g.N * (double)g.Cout * g.L * g.Cg * g.KK, &taken);
         if (rc || taken) return rc;
     }
     const int K = g.Cg * g.KK;
@@ -685,6 +693,12 @@ int conv_fwd_padded(nk_device* dev, int nd, const float* x, const int* x_shape, 
                          2.0 * g.N * (double)g.Cout * g.L * g.Cg * g.KK, &taken, true);
     if (rc) return rc;
     if (taken) return NK_OK;
+    if (nd == 2 && groups == 1 && w_shape[2] == 3 && w_shape[3] == 3 && stride[0] == 2 && stride[1] == 2 && dilation[0] == 1 && dilation[1] == 1 &&
+        padding[0] == 1 && padding[1] == 1) {  // the stride-2 forward reads through out-of-range-is-zero buffer loads too (nk_conv_s2fwd.h)
+        rc = s2f_launch(dev, x, w, bias, y, g.N, g.Cin, g.Cout, x_shape[2], x_shape[3], g.out[1], g.out[2], 1,
+                        2.0 * g.N * (double)g.Cout * g.L * g.Cg * g.KK, &taken);
+        if (rc || taken) return rc;
+    }
     // No kernel folds the padding for this geometry - or the rules in force decline (a caller that asked nk_conv_padding_folds at
     // graph-build time may find the knobs changed by the time it runs): the two nodes the entry stands for, Pad::forward into the
     // device's operand scratch (pad/zero/mod.rs:5-31), then the convolution on the copy - the bits of the two-node path.

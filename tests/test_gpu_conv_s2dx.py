@@ -174,3 +174,63 @@ def test_strided_direct_input_gradient_walks_residue_classes(dev, xs, ws, stride
     DP = dev.full(padded, np.nan)                                   # the gradient of the padded input itself
     c.conv_bwd_input(dev, DP, G, Wd, stride, dil, groups, assign=True)
     assert np.array_equal(DP.numpy(), want_p)
+
+
+# N, Cin, Cout, H, W of the UNPADDED input, padding (both axes)
+FWD_SHAPES = [
+    (2, 64, 128, 8, 8, 1),        # wide-capable (128 output channels) but few blocks: narrow by rule under the forced knob
+    (3, 64, 64, 7, 10, 1),        # odd input extent: 4 x 5 outputs, a partly filled block
+    (2, 128, 256, 9, 9, 0),       # no padding: 4 x 4 outputs
+    (1, 32, 128, 12, 6, 1),       # one chunk of 32 (wide) / two of 16 (narrow)
+    (2, 48, 64, 6, 6, 1),         # 48 input channels: narrow only (three chunks of 16)
+    (5, 64, 64, 2, 2, 1),         # one output position per sample
+    (4, 64, 128, 56, 56, 1),      # the layer of the shape table, four samples
+]
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W,pad", FWD_SHAPES)
+def test_s2_forward_tap_planes_equal_the_implicit_gemm_exactly_on_integer_data(dev, N, Cin, Cout, H, W, pad):
+    """The stride-2 3 x 3 forward as nine tap products on staged tap planes (csrc/nk_conv_s2fwd.h) against the implicit-GEMM kernel
+    (NK_TUNE_CONV_S2DX = 0) and the oracle on integer-valued data, bit for bit, with and without the fused bias, on the padded copy
+    (`nk_conv_fwd` / `nk_conv_bias_fwd`) and - padding 1 - with the padding folded (`nk_conv_bias_fwd_padded`); both block shapes."""
+    c = capi()
+    x, w, b = ints(1, (N, Cin, H, W), -3, 3), ints(2, (Cout, Cin, 3, 3), -2, 2), ints(3, (Cout, 1, 1), -4, 4)
+    xp = np.zeros((N, Cin, H + 2 * pad, W + 2 * pad), np.float32)
+    xp[:, :, pad:pad + H, pad:pad + W] = x
+    oshape = O.conv_out_shape(xp.shape, w.shape, (2, 2), (1, 1))
+    want = np.zeros(oshape, np.float32); O.convolution_forward(xp, w, want, (2, 2), (1, 1), 1)
+    outs = {}
+    for mode in (1, 0, 2, 3):
+        dev.conv_s2dx(mode)
+        try:
+            XP, X, Wd, B = dev.array(xp), dev.array(x), dev.array(w), dev.array(b)
+            Y, Yb, Yf = dev.full(oshape, np.nan), dev.full(oshape, np.nan), dev.full(oshape, np.nan)
+            c.conv_fwd(dev, XP, Wd, Y, (2, 2), (1, 1), 1)
+            c.conv_fwd(dev, XP, Wd, Yb, (2, 2), (1, 1), 1, bias=B)
+            c.conv_fwd_padded(dev, X, Wd, Yf, (pad, pad), (2, 2), (1, 1), 1, bias=B)
+            outs[mode] = [Y.numpy(), Yb.numpy(), Yf.numpy()]
+        finally:
+            dev.conv_s2dx(None)
+    for mode in (1, 0, 2, 3):
+        assert np.array_equal(outs[mode][0], want) and np.array_equal(outs[mode][1], want + b) and np.array_equal(outs[mode][2], want + b), mode
+
+
+def test_s2_forward_random_inside_the_contraction_bound(dev):
+    from tolerance import assert_contraction
+    c = capi()
+    N, Cin, Cout, H = 3, 128, 128, 20
+    x, w = rnd(1, (N, Cin, H, H)), rnd(2, (Cout, Cin, 3, 3), -1, 1)
+    oshape = O.conv_out_shape(x.shape, w.shape, (2, 2), (1, 1))
+    y64 = np.zeros(oshape); O.convolution_forward(x.astype(np.float64), w.astype(np.float64), y64, (2, 2), (1, 1), 1)
+    y32 = np.zeros(oshape, np.float32); O.convolution_forward(x, w, y32, (2, 2), (1, 1), 1)
+    got = {}
+    for mode in (1, 0):
+        dev.conv_s2dx(mode)
+        try:
+            Y = dev.full(oshape, np.nan)
+            c.conv_fwd(dev, dev.array(x), dev.array(w), Y, (2, 2), (1, 1), 1)
+            got[mode] = Y.numpy()
+        finally:
+            dev.conv_s2dx(None)
+        assert_contraction("s2 forward (%s)" % ("tap planes" if mode else "implicit GEMM"), got[mode], y64, Cin * 9, 1.0, 1.0, cpu32=y32)
+    assert not np.array_equal(got[1], got[0])                        # two orders of summation
